@@ -1,0 +1,159 @@
+"""Deterministic inputs for the golden cases (shared by ``make_golden.py``, which runs
+the reference on them, and by the tests, which run the oracle / the HIP path on them).
+All randomness is ``np.random.RandomState`` (legacy generator: stream frozen across
+NumPy versions), so inputs regenerate identically on the GPU box."""
+import os
+from collections import OrderedDict
+
+import numpy as np
+
+from oracle import models_ref as M
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def sample_index(n):
+    """16 fixed positions in a flattened array of n elements."""
+    return (np.arange(16, dtype=np.int64) * 7919 + 13) % n
+
+
+def load(name):
+    with np.load(os.path.join(HERE, name + '.npz')) as z:
+        return {k: z[k] for k in z.files}
+
+
+# ----------------------------------------------------------------------- block cases
+def _lin(out, prefix, n_in, n_out, wn):
+    out[prefix + '.weight'] = (n_out, n_in)
+    out[prefix + '.bias'] = (n_out,)
+    if wn:
+        out[prefix + '.g'] = (n_out,)
+
+
+def _fill(shapes, seed, scale=None):
+    rs = np.random.RandomState(seed)
+    out = OrderedDict()
+    fan = 1
+    for k, shp in shapes.items():
+        if k.endswith('.g'):
+            a = rs.uniform(0.5, 1.5, shp)
+        elif k.endswith('W_mu') or k.endswith('bias_mu'):
+            a = rs.uniform(-0.3, 0.3, shp)
+        else:
+            if k.endswith('.weight'):
+                fan = shp[1]
+            a = rs.uniform(-1, 1, shp) * (scale or 1.0) / np.sqrt(fan)
+        out[k] = a.astype(np.float32)
+    return out
+
+
+def block_inputs(tag):
+    seed = sum(ord(ch) * (i + 1) for i, ch in enumerate(tag))
+    rs = np.random.RandomState(seed)
+    f = lambda *s: rs.standard_normal(s).astype(np.float32)
+    n = 7
+    sh = OrderedDict()
+    if tag == 'G1':
+        _lin(sh, '', 13, 5, True)
+        sh = OrderedDict((k[1:], v) for k, v in sh.items())
+        return dict(params=_fill(sh, seed), x=f(n, 13), dy=f(n, 5))
+    if tag.startswith('G2'):
+        wn = tag in ('G2b', 'G2c')
+        _lin(sh, 'model.linear1', 13, 11, wn)
+        _lin(sh, 'model.linear2', 11, 6, wn)
+        return dict(params=_fill(sh, seed), xa=f(n, 9), xb=f(n, 4), dy=f(n, 6))
+    if tag.startswith('G3'):
+        wn = tag == 'G3b'
+        _lin(sh, 'nnet.model.linear1', 13, 11, wn)
+        _lin(sh, 'encoder_mu.linear_mu', 11, 5, wn)
+        _lin(sh, 'encoder_lv.linear_lv', 11, 5, wn)
+        return dict(params=_fill(sh, seed), xa=f(n, 9), xb=f(n, 4), eps=f(n, 5), s=f(n, 5),
+                    mu_p=f(n, 5), lv_p=(0.5 * f(n, 5)))
+    if tag.startswith('G4'):
+        wn = tag == 'G4b'
+        _lin(sh, 'nnet.model.linear1', 5, 11, wn)
+        _lin(sh, 'encoder_mu.linear_mu', 11, 17, wn)
+        _lin(sh, 'encoder_sg.linear_sg', 11, 17, wn)
+        return dict(params=_fill(sh, seed, 2.0), z=f(n, 5), x=f(n, 17), eps=f(n, 17), mu_p=f(n, 17),
+                    sd_p=np.abs(f(n, 17)) + 0.2)
+    if tag.startswith('G5'):
+        sh['W_mu'] = (5, 5)
+        sh['bias_mu'] = (5,)
+        _lin(sh, 'encoder_lv.linear_lv', 5, 5, False)
+        return dict(params=_fill(sh, seed), z=f(n, 5))
+    if tag in ('G6a', 'G6b'):
+        rdim = 3 if tag == 'G6a' else 1
+        _lin(sh, 'decoder_p.linear_p', 10, rdim, False)
+        ncls = 3 if tag == 'G6a' else 2
+        prior = np.full((n, ncls), 1.0 / ncls, np.float32)
+        return dict(params=_fill(sh, seed, 3.0), za=f(n, 5), zb=f(n, 5),
+                    y=rs.randint(0, ncls, (n, 1)).astype(np.int64), prior=prior)
+    if tag == 'G6c':
+        _lin(sh, 'nnet.model.linear1', 5, 7, False)
+        _lin(sh, 'decoder_p.linear_p', 7, 2, False)
+        # huge logits so that softmax saturates and the 1e-10 clamp is active
+        return dict(params=_fill(sh, seed, 60.0), za=3 * f(n, 5), y=rs.randint(0, 2, (n, 1)).astype(np.int64),
+                    prior=np.tile(np.array([[0.3, 0.7]], np.float32), (n, 1)))
+    if tag == 'G7':
+        return dict(x1=f(6, 5), x2=0.5 * f(9, 5) + 0.3, rnd_a=f(5, 500),
+                    rnd_b=rs.uniform(0, 1, 500).astype(np.float32))
+    if tag == 'G8':
+        return dict(y=np.array([[0], [3], [1], [1], [2]], np.int64))
+    if tag == 'G9':
+        return dict(kl=np.array([0.1, 1.999, 2.0, 2.001, 7.5, -1.0], np.float32),
+                    anneal_args=[(0, 1, 0), (1, 1, 0), (5, 100, 0), (5, 100, 5), (6, 100, 5), (2000, 1000, 0)])
+    raise KeyError(tag)
+
+
+# ----------------------------------------------------------------------- model cases
+def tiny_spec(kind, **over):
+    kw = dict(kind=kind, dim_x=13, dim_y=2, dim_z1=5, dim_z3=4, h_en_z1=[7], h_de_z1=[6], h_en_z3=[6],
+              h_de_x=[8], h_clf=[], L=2, learning_rate=5e-3)
+    kw.update(over)
+    return M.ModelSpec(**kw)
+
+
+def _flags(pattern):
+    """pattern: string of 'a' (labeled single) 'b' (unlabeled single) 'c' (labeled pair) 'd' (unlabeled pair)"""
+    has_y = np.array([ch in 'ac' for ch in pattern], np.int64)
+    has_x2 = np.array([ch in 'cd' for ch in pattern], np.int64)
+    return has_y, has_x2
+
+
+MODEL_CASES = OrderedDict([
+    # name: (spec factory, rows, group pattern or None, n_steps, full-output?)
+    ('tiny_drvae', (lambda: tiny_spec('drvae'), 'acbdaabcdbacab', 3, True)),
+    ('tiny_drvae_nolp', (lambda: tiny_spec('drvae', dim_y=3, h_clf=[3], L=3), 'abdbadabbdaa', 2, True)),
+    ('tiny_drvae_wn', (lambda: tiny_spec('drvae', weight_norm=True), 'cadbcabdbca', 2, True)),
+    ('tiny_drvae_only_up', (lambda: tiny_spec('drvae', L=1), 'ddddd', 2, True)),
+    ('tiny_pvae', (lambda: tiny_spec('pvae'), 'bdbbdddbdb', 3, True)),
+    ('tiny_vfae', (lambda: tiny_spec('vfae', dim_y=3), 'abbabaabbb', 3, True)),
+    ('tiny_vfae_sup', (lambda: tiny_spec('vfae', semi_supervised=False, add_noise_var=0.), 'aababaaa', 2, True)),
+    ('cfg1_pvae', (lambda: M.ModelSpec(kind='pvae', L=1), 150, 3, False)),
+    ('cfg2_drvae', (lambda: M.ModelSpec(kind='drvae', L=2), 150, 3, False)),
+    ('cfg4_vfae', (lambda: M.ModelSpec(kind='vfae', L=2, add_noise_var=0.), 150, 3, False)),
+])
+
+
+def model_case(name):
+    mk, rows, steps, full = MODEL_CASES[name]
+    spec = mk()
+    seed = sum(ord(ch) * (i + 1) for i, ch in enumerate(name))
+    if isinstance(rows, str):
+        batch = M.make_batch(spec, len(rows), seed=seed)
+        has_y, has_x2 = _flags(rows)
+        if spec.kind == 'pvae':
+            has_y[:] = 0
+        if spec.kind == 'vfae':
+            has_x2[:] = 0
+        # rebuild x2 for the overridden pairing (zero-imputed singletons)
+        rs = np.random.RandomState(seed + 1)
+        x2 = (batch['x1'] + 0.1 * rs.standard_normal(batch['x1'].shape)).astype(np.float32)
+        batch['x2'] = x2 * has_x2[:, None].astype(np.float32)
+        batch['has_y'], batch['has_x2'] = has_y, has_x2
+        n = len(rows)
+    else:
+        n = rows
+        batch = M.make_batch(spec, n, seed=1234)
+    noises = [M.make_noise(spec, n, seed=seed + 100 + i) for i in range(steps)]
+    return dict(name=name, spec=spec, batch=batch, noises=noises, param_seed=123, full=full)

@@ -1,0 +1,344 @@
+#!/usr/bin/env python3
+"""Generate ``tests/golden/*.npz`` by running the REFERENCE (rampasek/DrVAE, mounted
+read-only at /root/reference) on CPU in the build container.
+
+Run:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+The reference cannot travel to the GPU box, so its outputs are committed as small
+array fixtures (this script is the provenance).  Shims, all
+non-invasive (nothing under /root/reference is modified or copied):
+  1. ``sys.modules['h5py']`` stub -- utils.py:8 imports h5py (absent here);
+  2. ``blocks.one_hot`` replaced by a pure equivalent -- the original relies on
+     ``y.data.unsqueeze_(1)`` reshaping ``y`` in place (blocks.py:83-84), which torch>=0.4
+     no longer does, so 1-D labels crash in ``scatter_`` (blocks.py:89);
+  3. ``model.add_noise`` set explicitly (only ``fit`` creates it, DrVAE.py:769);
+     ``PVAE.prior_y = None`` (PVAE.py:77 reads an attribute PVAE never defines).
+Noise: ``torch.Tensor.normal_`` / ``uniform_`` are patched during the reference run to
+pop pre-generated arrays (``oracle.models_ref.make_noise``) in the reference's own draw
+order; every pop asserts the requested shape, which pins that draw order.
+"""
+import contextlib
+import io
+import os
+import sys
+import types
+import warnings
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True
+
+from oracle import models_ref as M            # noqa: E402  (spec / params / noise / batch helpers)
+from tests.golden import cases as C           # noqa: E402
+
+warnings.filterwarnings('ignore')
+sys.modules['h5py'] = types.ModuleType('h5py')
+sys.path.insert(0, '/root/reference/src')
+import blocks as rblk                          # noqa: E402
+import layers as rlyr                          # noqa: E402
+import DrVAE as rDrVAE                         # noqa: E402
+import PVAE as rPVAE                           # noqa: E402
+import VFAE as rVFAE                           # noqa: E402
+
+
+def _one_hot(y, max_dim):
+    if y is None or len(y) == 0:
+        return None
+    idx = y.data.reshape(-1, 1).long()
+    out = torch.zeros(idx.size(0), max_dim)
+    out.scatter_(1, idx, 1)
+    return out
+
+
+rblk.one_hot = _one_hot
+rPVAE.PVAE.prior_y = None
+
+
+# ------------------------------------------------------------------ noise replaying
+class Replay:
+    """Patch Tensor.normal_ (and uniform_) to pop from queues of numpy arrays."""
+
+    def __init__(self, normals, uniforms=()):
+        self.normals, self.uniforms = list(normals), list(uniforms)
+
+    def __enter__(self):
+        self._n, self._u = torch.Tensor.normal_, torch.Tensor.uniform_
+        me = self
+
+        def normal_(t, *a, **k):
+            arr = me.normals.pop(0)
+            assert tuple(t.shape) == tuple(arr.shape), ('normal_ draw order', tuple(t.shape), arr.shape)
+            return t.copy_(torch.from_numpy(np.ascontiguousarray(arr)))
+
+        def uniform_(t, *a, **k):
+            arr = me.uniforms.pop(0)
+            assert tuple(t.shape) == tuple(arr.shape), ('uniform_ draw order', tuple(t.shape), arr.shape)
+            return t.copy_(torch.from_numpy(np.ascontiguousarray(arr)))
+
+        torch.Tensor.normal_ = normal_
+        if self.uniforms:
+            torch.Tensor.uniform_ = uniform_
+        return self
+
+    def __exit__(self, *exc):
+        torch.Tensor.normal_, torch.Tensor.uniform_ = self._n, self._u
+        if exc[0] is None:
+            assert not self.normals and not self.uniforms, 'unconsumed noise: draw order mismatch'
+
+
+def noise_queue(spec, batch, noise, training):
+    """The reference's draw order, from the row-addressed container."""
+    hy, hx = batch['has_y'].astype(bool), batch['has_x2'].astype(bool)
+    if spec.kind == 'drvae':
+        groups = [(hy & ~hx, False, True), (~hy & ~hx, False, False), (hy & hx, True, True), (~hy & hx, True, False)]
+    elif spec.kind == 'pvae':
+        groups = [(~hx, False, False), (hx, True, False)]
+    elif spec.semi_supervised:
+        groups = [(hy, False, True), (~hy, False, False)]
+    else:
+        groups = [(hy, False, True)]
+    q = []
+    for mask, pair, labeled in groups:
+        idx = np.nonzero(mask)[0]
+        if len(idx) == 0:
+            continue
+        if training and spec.add_noise_var > 0:
+            q.append(noise['nx1'][idx])
+            if pair:
+                q.append(noise['nx2'][idx])
+        for l in range(spec.L):
+            q.append(noise['ez1'][l][idx])
+            if spec.kind != 'vfae':
+                if pair:
+                    q.append(noise['ez2'][l][idx])
+                q.append(noise['ez2F'][l][idx])
+            if spec.kind != 'pvae':
+                for j in range(1 if labeled else spec.dim_y):
+                    q.append(noise['ez3'][l][j][idx])
+    return q
+
+
+# ------------------------------------------------------------------ reference models
+def build_reference_model(spec, params):
+    common = dict(dim_x=spec.dim_x, dim_s=1, dim_y=spec.dim_y, dim_h_en_z1=list(spec.h_en_z1),
+                  dim_h_de_x=list(spec.h_de_x), dim_z1=spec.dim_z1, type_rec='diag_gaussian',
+                  nonlinearity=spec.nonlin, learning_rate=spec.learning_rate, L=spec.L,
+                  weight_decay=spec.weight_decay, add_noise_var=spec.add_noise_var, use_MMD=False,
+                  use_s=False, random_seed=123)
+    pert = dict(kl_qz2pz2_rate=spec.kl_qz2pz2_rate, pertloss_rate=spec.pertloss_rate,
+                anneal_perturb_rate_itermax=spec.anneal_perturb_rate_itermax,
+                anneal_perturb_rate_offset=spec.anneal_perturb_rate_offset)
+    ycfg = dict(dim_h_de_z1=list(spec.h_de_z1), dim_h_clf=list(spec.h_clf), yloss_rate=spec.yloss_rate)
+    if spec.kind == 'drvae':
+        cls, kw = rDrVAE.DrVAE, dict(common, dim_h_en_z3=list(spec.h_en_z3), dim_z3=spec.dim_z3,
+                                     clf_z1z2=spec.clf_z1z2, **pert, **ycfg)
+    elif spec.kind == 'pvae':
+        cls, kw = rPVAE.PVAE, dict(common, **pert)
+    else:
+        cls, kw = rVFAE.VFAE, dict(common, dim_h_en_z2=list(spec.h_en_z3), dim_z2=spec.dim_z3,
+                                   semi_supervised=spec.semi_supervised, **ycfg)
+    orig = cls._build_blocks
+
+    def build_with_wn(self):        # self.wn is hard-coded False in __init__ (DrVAE.py:79)
+        self.wn = spec.weight_norm
+        orig(self)
+
+    cls._build_blocks = build_with_wn
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            model = cls(**kw)
+    finally:
+        cls._build_blocks = orig
+    sd = model.state_dict()
+    assert list(sd.keys()) == list(params.keys()), (list(sd.keys()), list(params.keys()))
+    model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in params.items()})
+    model.add_noise = spec.add_noise_var > 0
+    return model
+
+
+def reference_kwargs(spec, batch):
+    t = lambda k: torch.from_numpy(batch[k].copy())
+    if spec.kind == 'drvae':
+        return dict(x1=t('x1'), x2=t('x2'), s=t('s'), y=t('y'), has_x2=t('has_x2'), has_y=t('has_y'))
+    if spec.kind == 'pvae':
+        return dict(x1=t('x1'), x2=t('x2'), s=t('s'), has_x2=t('has_x2'))
+    return dict(x1=t('x1'), s=t('s'), y=t('y'), has_y=t('has_y'))
+
+
+def run_model_case(case):
+    spec, batch, noises = case['spec'], case['batch'], case['noises']
+    params = M.init_params(spec, case['param_seed'], as_numpy=True)
+    model = build_reference_model(spec, params)
+    out = {}
+    # eval-mode loss (no input noise, still samples eps; quirk 8)
+    with Replay(noise_queue(spec, batch, noises[0], False)):
+        ev = model.run_on_batch(train_mode=False, **reference_kwargs(spec, batch))
+    for k, v in ev.items():
+        out['eval/' + k] = np.float32(float(v))
+    # train steps
+    for step, noise in enumerate(noises):
+        with Replay(noise_queue(spec, batch, noise, True)):
+            losses = model.run_on_batch(train_mode=True, **reference_kwargs(spec, batch))
+        for k, v in losses.items():
+            out['step%d/%s' % (step, k)] = np.float32(float(v))
+        if step == 0:
+            for k, prm in model.named_parameters():
+                g = prm.grad.detach().numpy()
+                if case['full']:
+                    out['grad/' + k] = g.copy()
+                else:
+                    out['gradnorm/' + k] = np.float32(np.sqrt((g.astype(np.float64) ** 2).sum()))
+                    out['gradsample/' + k] = g.reshape(-1)[C.sample_index(g.size)].copy()
+        if step in (0, len(noises) - 1):
+            for k, v in model.state_dict().items():
+                a = v.numpy()
+                if case['full']:
+                    out['param%d/%s' % (step, k)] = a.copy()
+                else:
+                    out['paramsum%d/%s' % (step, k)] = np.float64(a.astype(np.float64).sum())
+                    out['paramsample%d/%s' % (step, k)] = a.reshape(-1)[C.sample_index(a.size)].copy()
+    assert model.finished_training_iters == len(noises)
+    return out
+
+
+# ------------------------------------------------------------------ reference blocks
+def load_sd(module, params):
+    sd = module.state_dict()
+    assert list(sd.keys()) == list(params.keys()), (list(sd.keys()), list(params.keys()))
+    module.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in params.items()})
+
+
+def run_block_cases():
+    out = {}
+    T = lambda a: torch.from_numpy(np.asarray(a).copy())
+
+    def put(prefix, **kw):
+        for k, v in kw.items():
+            out['%s/%s' % (prefix, k)] = v.detach().numpy().copy() if torch.is_tensor(v) else np.asarray(v)
+
+    # G1 WeightNormLinear fwd + grads
+    c = C.block_inputs('G1')
+    m = rlyr.WeightNormLinear(13, 5)
+    load_sd(m, c['params'])
+    x = T(c['x']).requires_grad_(True)
+    y = m(x)
+    (y * T(c['dy'])).sum().backward()
+    put('G1', y=y, dx=x.grad, dW=m.weight.grad, dg=m.g.grad, db=m.bias.grad)
+
+    # G2 MLP: two concatenated inputs, wn on/off, elu & softplus, two hidden layers
+    for tag, wn, nl in (('G2a', False, 'elu'), ('G2b', True, 'softplus'), ('G2c', True, 'elu')):
+        c = C.block_inputs(tag)
+        m = rblk.MLP([9, 4], [11, 6], nonlin=nl, weight_norm=wn)
+        load_sd(m, c['params'])
+        xs = [T(c['xa']).requires_grad_(True), T(c['xb']).requires_grad_(True)]
+        y = m(xs)
+        (y * T(c['dy'])).sum().backward()
+        put(tag, y=y, dxa=xs[0].grad, dxb=xs[1].grad,
+            **{'d_' + k: v.grad for k, v in m.named_parameters()})
+
+    # G3 DiagGaussianModule + logvar mixin
+    for tag, wn in (('G3a', False), ('G3b', True)):
+        c = C.block_inputs(tag)
+        m = rblk.DiagGaussianModule([9, 4], [11], 5, nonlin='elu', weight_norm=wn, prior_mu=0.3, prior_sg=1.7)
+        load_sd(m, c['params'])
+        mu, lv = m([T(c['xa']), T(c['xb'])])
+        with Replay([c['eps']]):
+            z = m.sample(mu, lv)
+        assert isinstance(z, tuple) and len(z) == 1
+        mu_p, lv_p = T(c['mu_p']), T(c['lv_p'])
+        put(tag, mu=mu, lv=lv, z=z[0], kl=m.kldivergence_perx(mu, lv, mu_p, lv_p),
+            kl_prior=m.kldivergence_from_prior_perx(mu, lv), logp=m.logp_perx(T(c['s']), mu, lv),
+            logp_prior=m.logp_prior_perx(T(c['s'])), kl_sum=m.kldivergence(mu, lv, mu_p, lv_p),
+            logp_sum=m.logp(T(c['s']), mu, lv))
+    # fixed_variance + constrain_means variant (regression head of DrVAE.py:167-168)
+    c = C.block_inputs('G3c')
+    m = rblk.DiagGaussianModule([9, 4], [11], 5, nonlin='elu', fixed_variance=0.05 ** 2, constrain_means=True)
+    load_sd(m, c['params'])
+    mu, lv = m([T(c['xa']), T(c['xb'])])
+    put('G3c', mu=mu, lv=lv)
+
+    # G4 DiagGaussianSigmaModule + sigma mixin
+    for tag, wn in (('G4a', False), ('G4b', True)):
+        c = C.block_inputs(tag)
+        m = rblk.DiagGaussianSigmaModule([5], [11], 17, nonlin='elu', weight_norm=wn)
+        load_sd(m, c['params'])
+        mu, sd = m([T(c['z'])])
+        with Replay([c['eps']]):
+            smp = m.sample(mu, sd)
+        put(tag, mu=mu, std=sd, sample=smp[0], logp=m.logp_perx(T(c['x']), mu, sd),
+            kl=m.kldivergence_perx(mu, sd, T(c['mu_p']), T(c['sd_p'])),
+            kl_prior=m.kldivergence_from_prior_perx(mu, sd), logp_prior=m.logp_prior_perx(T(c['x'])))
+
+    # G5 DiagGaussianModuleLinear
+    for tag, bias_only in (('G5a', False), ('G5b', True)):
+        c = C.block_inputs(tag)
+        m = rblk.DiagGaussianModuleLinear([5], [], 5, bias_only=bias_only)
+        load_sd(m, c['params'])
+        mu, lv = m([T(c['z'])])
+        put(tag, mu=mu, lv=lv)
+
+    # G6 CategoricalDecoder
+    for tag, rdim in (('G6a', 3), ('G6b', 1)):
+        c = C.block_inputs(tag)
+        m = rblk.CategoricalDecoder([5, 5], [], rdim, nonlin='elu')
+        load_sd(m, c['params'])
+        res = m([T(c['za']), T(c['zb'])])
+        assert isinstance(res, list) and len(res) == 1
+        ps = res[0]
+        prior = T(c['prior'])
+        put(tag, ps=ps, logp=m.logp_perx(T(c['y']), ps), kl=m.kldivergence_perx(ps, prior),
+            entropy=m.entropy(ps), best=m.most_probable(ps), logp_sum=m.logp(T(c['y']), ps))
+    c = C.block_inputs('G6c')   # with a hidden layer + extreme logits (clamp active)
+    m = rblk.CategoricalDecoder([5], [7], 2, nonlin='elu')
+    load_sd(m, c['params'])
+    ps = m([T(c['za'])])[0]
+    put('G6c', ps=ps, logp=m.logp_perx(T(c['y']), ps), kl=m.kldivergence_perx(ps, T(c['prior'])))
+
+    # G7 MMD kernels
+    c = C.block_inputs('G7')
+    x1, x2 = T(c['x1']), T(c['x2'])
+    with Replay([c['rnd_a']], [c['rnd_b']]):
+        put('G7', rbf_fourier=rblk.mmd_objective(x1, x2, 'rbf_fourier'))
+    put('G7', identity=rblk.mmd_objective(x1, x2, 'identity'), poly=rblk.mmd_objective(x1, x2, 'poly'))
+    try:
+        rblk.mmd_objective(x1, x2, 'rbf')
+        out['G7/rbf_raises'] = np.int64(0)
+    except Exception:
+        out['G7/rbf_raises'] = np.int64(1)
+
+    # G8 one_hot (2-D labels: the un-shimmed reference function works for these)
+    c = C.block_inputs('G8')
+    import importlib
+    fresh = importlib.reload(importlib.import_module('blocks'))
+    put('G8', onehot=fresh.one_hot(T(c['y']), 4))
+    rblk.one_hot = _one_hot
+    fresh.one_hot = _one_hot
+
+    # G9 free bits + anneal coefficient (DGMMixin.py:68-89)
+    c = C.block_inputs('G9')
+    model = build_reference_model(C.tiny_spec('pvae'), M.init_params(C.tiny_spec('pvae'), 1, as_numpy=True))
+    put('G9', fb=model._use_free_bits(T(c['kl'])),
+        anneal=np.array([model._compute_anneal_coef(i, iter_max=mx, iter_offset=off)
+                         for (i, mx, off) in c['anneal_args']], np.float64))
+    return out
+
+
+def main():
+    os.makedirs(HERE, exist_ok=True)
+    blocks = run_block_cases()
+    np.savez_compressed(os.path.join(HERE, 'blocks.npz'), **blocks)
+    print('blocks.npz', len(blocks), 'arrays')
+    for name in C.MODEL_CASES:
+        case = C.model_case(name)
+        out = run_model_case(case)
+        np.savez_compressed(os.path.join(HERE, 'model_%s.npz' % name), **out)
+        print('model_%s.npz' % name, len(out), 'arrays;',
+              {k: float(v) for k, v in out.items() if k.startswith('step0/')})
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,186 @@
+"""Pin the CPU oracle (``oracle/``) against the golden vectors that
+``tests/golden/make_golden.py`` produced by running the reference itself."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import blocks_ref as B
+from oracle import models_ref as M
+from tests.golden import cases as C
+
+RTOL, ATOL = 2e-6, 2e-6      # same ATen kernels on both sides; only summation grouping differs
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a).copy())
+
+
+def P(params, grad=False):
+    return {k: T(v).requires_grad_(grad) for k, v in params.items()}
+
+
+def close(a, b, rtol=RTOL, atol=ATOL):
+    a = a.detach().numpy() if torch.is_tensor(a) else np.asarray(a)
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol)
+
+
+@pytest.fixture(scope='module')
+def G():
+    return C.load('blocks')
+
+
+def test_weightnorm_linear(G):
+    c = C.block_inputs('G1')
+    p = P(c['params'], True)
+    x = T(c['x']).requires_grad_(True)
+    y = B.weightnorm_linear(x, p['weight'], p['g'], p['bias'])
+    (y * T(c['dy'])).sum().backward()
+    close(y, G['G1/y'])
+    close(x.grad, G['G1/dx'])
+    close(p['weight'].grad, G['G1/dW'])
+    close(p['g'].grad, G['G1/dg'])
+    close(p['bias'].grad, G['G1/db'])
+
+
+@pytest.mark.parametrize('tag,nl', [('G2a', 'elu'), ('G2b', 'softplus'), ('G2c', 'elu')])
+def test_mlp(G, tag, nl):
+    c = C.block_inputs(tag)
+    p = P(c['params'], True)
+    xa, xb = T(c['xa']).requires_grad_(True), T(c['xb']).requires_grad_(True)
+    y = B.mlp([xa, xb], {'m.' + k: v for k, v in p.items()}, 'm', 2, nl)
+    (y * T(c['dy'])).sum().backward()
+    close(y, G[tag + '/y'])
+    close(xa.grad, G[tag + '/dxa'])
+    close(xb.grad, G[tag + '/dxb'])
+    for k, v in p.items():
+        close(v.grad, G['%s/d_%s' % (tag, k)])
+
+
+def _pref(params, prefix):
+    return {prefix + '.' + k: v for k, v in P(params).items()}
+
+
+@pytest.mark.parametrize('tag', ['G3a', 'G3b'])
+def test_diag_gaussian_logvar(G, tag):
+    c = C.block_inputs(tag)
+    p = _pref(c['params'], 'm')
+    mu, lv = B.diag_gaussian([T(c['xa']), T(c['xb'])], p, 'm', 1, 'elu')
+    close(mu, G[tag + '/mu'])
+    close(lv, G[tag + '/lv'])
+    close(B.sample_logvar(mu, lv, T(c['eps'])), G[tag + '/z'])
+    close(B.kl_logvar_rows(mu, lv, T(c['mu_p']), T(c['lv_p'])), G[tag + '/kl'])
+    close(B.kl_logvar_prior_rows(mu, lv, 0.3, 1.7), G[tag + '/kl_prior'])
+    close(B.logp_logvar_rows(T(c['s']), mu, lv), G[tag + '/logp'])
+    close(B.logp_logvar_prior_rows(T(c['s']), 0.3, 1.7), G[tag + '/logp_prior'])
+    close(B.kl_logvar_rows(mu, lv, T(c['mu_p']), T(c['lv_p'])).sum(), G[tag + '/kl_sum'], 1e-5)
+    close(B.logp_logvar_rows(T(c['s']), mu, lv).sum(), G[tag + '/logp_sum'], 1e-5)
+
+
+def test_diag_gaussian_fixed_variance(G):
+    c = C.block_inputs('G3c')
+    p = _pref(c['params'], 'm')
+    mu, lv = B.diag_gaussian([T(c['xa']), T(c['xb'])], p, 'm', 1, 'elu', constrain_means=True,
+                             fixed_variance=0.05 ** 2)
+    close(mu, G['G3c/mu'])
+    close(lv, G['G3c/lv'])
+
+
+@pytest.mark.parametrize('tag', ['G4a', 'G4b'])
+def test_diag_gaussian_sigma(G, tag):
+    c = C.block_inputs(tag)
+    p = _pref(c['params'], 'm')
+    mu, sd = B.diag_gaussian_sigma([T(c['z'])], p, 'm', 1, 'elu')
+    close(mu, G[tag + '/mu'])
+    close(sd, G[tag + '/std'])
+    close(B.sample_sigma(mu, sd, T(c['eps'])), G[tag + '/sample'])
+    close(B.logp_sigma_rows(T(c['x']), mu, sd), G[tag + '/logp'], 1e-5)
+    close(B.kl_sigma_rows(mu, sd, T(c['mu_p']), T(c['sd_p'])), G[tag + '/kl'], 1e-5)
+    one = torch.ones(1)
+    close(B.kl_sigma_rows(mu, sd, (0 * one).expand_as(mu), one.expand_as(sd)), G[tag + '/kl_prior'], 1e-5)
+    close(B.logp_sigma_rows(T(c['x']), (0 * one).expand_as(mu), one.expand_as(mu)), G[tag + '/logp_prior'])
+
+
+@pytest.mark.parametrize('tag,bias_only', [('G5a', False), ('G5b', True)])
+def test_diag_gaussian_linear(G, tag, bias_only):
+    c = C.block_inputs(tag)
+    mu, lv = B.diag_gaussian_linear([T(c['z'])], _pref(c['params'], 'm'), 'm', bias_only)
+    close(mu, G[tag + '/mu'])
+    close(lv, G[tag + '/lv'])
+
+
+@pytest.mark.parametrize('tag,rdim', [('G6a', 3), ('G6b', 1)])
+def test_categorical(G, tag, rdim):
+    c = C.block_inputs(tag)
+    ps = B.categorical([T(c['za']), T(c['zb'])], _pref(c['params'], 'm'), 'm', 0, 'elu', rdim)
+    close(ps, G[tag + '/ps'])
+    close(B.categorical_logp_rows(T(c['y']), ps), G[tag + '/logp'])
+    close(B.categorical_kl_elem(ps, T(c['prior'])), G[tag + '/kl'])
+    close(B.categorical_entropy(ps), G[tag + '/entropy'])
+    assert (B.categorical_most_probable(ps).numpy() == G[tag + '/best']).all()
+    close(B.categorical_logp_rows(T(c['y']), ps).sum(), G[tag + '/logp_sum'])
+
+
+def test_categorical_clamped(G):
+    c = C.block_inputs('G6c')
+    ps = B.categorical([T(c['za'])], _pref(c['params'], 'm'), 'm', 1, 'elu', 2)
+    assert float(ps.min()) == pytest.approx(1e-10, rel=1e-3)      # the clamp is active in this case
+    close(ps, G['G6c/ps'])
+    close(B.categorical_logp_rows(T(c['y']), ps), G['G6c/logp'])
+    close(B.categorical_kl_elem(ps, T(c['prior'])), G['G6c/kl'])
+
+
+def test_mmd(G):
+    c = C.block_inputs('G7')
+    x1, x2 = T(c['x1']), T(c['x2'])
+    close(B.mmd_objective(x1, x2, 'rbf_fourier', rnd_a=T(c['rnd_a']), rnd_b=T(c['rnd_b'])), G['G7/rbf_fourier'])
+    close(B.mmd_objective(x1, x2, 'identity'), G['G7/identity'])
+    close(B.mmd_objective(x1, x2, 'poly'), G['G7/poly'])
+    assert int(G['G7/rbf_raises']) == 1       # pinned: the reference's 'rbf' kernel raises on torch>=0.4
+    with pytest.raises(NotImplementedError):
+        B.mmd_objective(x1, x2, 'rbf')
+
+
+def test_one_hot_free_bits_anneal(G):
+    close(B.one_hot(T(C.block_inputs('G8')['y']), 4), G['G8/onehot'])
+    assert B.one_hot(None, 4) is None and B.one_hot(torch.zeros(0), 4) is None
+    c = C.block_inputs('G9')
+    close(B.free_bits(T(c['kl'])), G['G9/fb'])
+    got = [B.anneal_coef(i, mx, off) for (i, mx, off) in c['anneal_args']]
+    np.testing.assert_allclose(got, G['G9/anneal'], rtol=0, atol=0)
+
+
+@pytest.mark.parametrize('name', list(C.MODEL_CASES))
+def test_model_train_steps(name):
+    case, gold = C.model_case(name), C.load('model_' + name)
+    spec = case['spec']
+    tr = M.RefTrainer(spec, M.init_params(spec, case['param_seed']))
+    ev, _ = tr.loss(case['batch'], case['noises'][0], training=False)
+    for k, v in ev.items():
+        close(v, gold['eval/' + k], 1e-5, 1e-6)
+    nsteps = len(case['noises'])
+    for step, noise in enumerate(case['noises']):
+        losses, rows = tr.step(case['batch'], noise)
+        for k, v in losses.items():
+            close(v, gold['step%d/%s' % (step, k)], 1e-5, 1e-6)
+        # per-row accumulators are consistent with the batch sums
+        n = case['batch']['x1'].shape[0]
+        n_tot = int(case['batch']['has_y'].sum()) if (spec.kind == 'vfae' and not spec.semi_supervised) else n
+        close(rows['RECL'].sum() / n_tot, float(losses['RECL']), 1e-5, 1e-6)
+        close(rows['KLD'].sum() / n_tot, float(losses['KLD']), 1e-5, 1e-6)
+        if step == 0:
+            for k, prm in tr.params.items():
+                g = prm.grad.numpy()
+                if case['full']:
+                    close(g, gold['grad/' + k], 2e-4, 2e-6)
+                else:
+                    close(np.sqrt((g.astype(np.float64) ** 2).sum()), gold['gradnorm/' + k], 1e-4, 1e-7)
+                    close(g.reshape(-1)[C.sample_index(g.size)], gold['gradsample/' + k], 2e-3, 2e-6)
+        if step in (0, nsteps - 1):
+            for k, prm in tr.params.items():
+                a = prm.detach().numpy()
+                if case['full']:
+                    close(a, gold['param%d/%s' % (step, k)], 1e-4, 2e-5)
+                else:
+                    close(a.astype(np.float64).sum(), gold['paramsum%d/%s' % (step, k)], 1e-4, 2e-3)
+                    close(a.reshape(-1)[C.sample_index(a.size)], gold['paramsample%d/%s' % (step, k)], 1e-4, 2e-5)
+    assert tr.iters == nsteps
