@@ -1,0 +1,92 @@
+"""ctypes binding of libdrvae_hip.so (the C-ABI declared in include/drvae_hip.h).
+
+There is NO fallback: if the shared object is missing or a symbol is absent, importing
+code gets a loud RuntimeError -- the product path never silently computes elsewhere.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libdrvae_hip.so')
+
+# enums of include/drvae_hip.h
+ACT = {'identity': 0, 'elu': 1, 'softplus': 2, 'sigmoid': 3, 'tanh': 4, 'relu': 5, 'leaky_relu': 6, 'selu': 7,
+       'softsign': 8, 'cos': 9}
+GAUSS_LOGVAR, GAUSS_SIGMA = 0, 1
+EPI_PLAIN, EPI_FWD, EPI_BWD = 0, 1, 2
+
+_f, _i32, _i64, _u64, _p = C.c_float, C.c_int32, C.c_int64, C.c_uint64, C.c_void_p
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [('M', _i32), ('N', _i32), ('K', _i32), ('a_kcontig', _i32), ('b_kcontig', _i32),
+                ('A', _p), ('lda', _i64), ('A2', _p), ('lda2', _i64), ('K1', _i32), ('a_kscale', _p),
+                ('B', _p), ('ldb', _i64), ('C', _p), ('ldc', _i64), ('alpha', _f), ('beta', _f),
+                ('epilogue', _i32), ('scale', _p), ('bias', _p), ('split', _i32), ('act0', _i32), ('act1', _i32),
+                ('shift0', _f), ('shift1', _f), ('resid', _p), ('ldr', _i64), ('resid_cols', _i32),
+                ('yref', _p), ('ldy', _i64), ('a_colsum', _p), ('colsum_beta', _f)]
+
+
+# name -> argtypes (restype is int unless noted); mirrors include/drvae_hip.h one to one
+SIGNATURES = {
+    'dv_abi_version': [],
+    'dv_error_string': [_i32],
+    'dv_gemm': [C.POINTER(GemmDesc), _p],
+    'dv_gemm_force_tiling': [_i32],
+    'dv_colsum': [_p, _i64, _i32, _i32, _p, _f, _p],
+    'dv_act_bwd': [_p, _i64, _p, _i64, _i32, _i32, _i32, _i32, _i32, _f, _f, _p],
+    'dv_wn_scale': [_p, _i64, _p, _i32, _i32, _p, _p, _p],
+    'dv_wn_bwd': [_p, _i64, _p, _i64, _p, _p, _i32, _i32, _p, _i64, _p, _f, _p],
+    'dv_reparam_fwd': [_p, _p, _i64, _p, _i32, _i32, _i32, _p, _i64, _i32, _p, _i64, _p, _i64, _p, _i64, _p],
+    'dv_reparam_bwd': [_p, _i64, _p, _i64, _p, _i64, _p, _i32, _i32, _i32, _i32, _p, _p, _i64, _f, _p],
+    'dv_kl_rows_fwd': [_p, _p, _i64, _p, _p, _p, _i64, _p, _f, _f, _i32, _i32, _i32, _i32, _i32, _f, _p, _p, _p],
+    'dv_kl_rows_bwd': [_p, _p, _i32, _f, _p, _p, _i64, _p, _p, _p, _i64, _p, _f, _f, _i32, _i32, _i32, _i32,
+                       _p, _p, _i64, _p, _p, _i64, _f, _p],
+    'dv_gauss_nll_rows_fwd': [_p, _i64, _p, _p, _p, _i64, _i32, _i32, _i32, _p, _p],
+    'dv_gauss_nll_rows_bwd': [_p, _p, _i64, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _f, _p, _p, _i64, _p, _i64,
+                              _f, _p],
+    'dv_softmax_clamp_fwd': [_p, _i64, _i32, _i32, _i32, _p, _i64, _p],
+    'dv_softmax_clamp_bwd': [_p, _i64, _p, _i64, _i32, _i32, _i32, _p, _i64, _f, _p],
+    'dv_cat_terms_fwd': [_p, _i64, _i32, _i32, _p, _p, _i64, _p, _p, _i64, _p, _p, _p],
+    'dv_cat_terms_bwd': [_p, _i64, _i32, _i32, _p, _p, _i64, _p, _p, _i64, _p, _p, _i64, _f, _p],
+    'dv_ymarg_fwd': [_p, _i64, _p, _p, _p, _f, _i32, _i32, _p, _p, _p],
+    'dv_ymarg_bwd': [_p, _i64, _p, _p, _p, _f, _p, _p, _i32, _i32, _p, _p, _i64, _p],
+    'dv_rows_gather': [_p, _i64, _p, _i32, _i32, _p, _i64, _f, _p, _i32, _p, _i64, _p],
+    'dv_rows_segment_sum': [_p, _i64, _p, _p, _p, _i32, _i32, _p, _p, _i64, _f, _p],
+    'dv_weighted_sum': [_p, _p, _p, _i32, _f, _p, _f, _p],
+    'dv_axpby': [_p, _f, _p, _f, _i64, _p],
+    'dv_adam_l2': [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _f, _p, _p],
+    'dv_counter_add': [_p, _i32, _i64, _p],
+    'dv_fill_normal': [_p, _i64, _u64, _p, _p],
+}
+
+_lib = None
+
+
+def load():
+    """Return the loaded library (cached).  Raises RuntimeError when it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            'drvae_amd: %s is missing -- build it with `python -m drvae_amd.build` (hipcc, gfx950). '
+            'There is no CPU/PyTorch fallback for the hot path.' % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise RuntimeError('drvae_amd: symbol %s missing from %s (stale build?)' % (name, LIB_PATH)) from e
+        fn.argtypes = argtypes
+        fn.restype = C.c_char_p if name == 'dv_error_string' else C.c_int
+    if lib.dv_abi_version() != 1:
+        raise RuntimeError('drvae_amd: ABI version mismatch in %s' % LIB_PATH)
+    _lib = lib
+    return lib
+
+
+def check(code, what):
+    if code != 0:
+        msg = load().dv_error_string(code)
+        raise RuntimeError('drvae_amd: %s failed: %s (%d)' % (what, msg.decode() if msg else '?', code))

@@ -1,0 +1,404 @@
+"""Drop-in for the reference's ``blocks`` module (``import blocks as blk``,
+src/DrVAE.py:21, src/PVAE.py:21, src/VFAE.py:21).
+
+Same public names, constructor signatures, ``forward(list_of_tensors)`` convention,
+return types (tuples / 1-tuples / 1-element lists) and ``state_dict`` keys as
+src/blocks.py, so the reference's model classes consume these blocks unchanged when
+this module is installed as ``sys.modules['blocks']``.  All
+arithmetic -- Linear(+WeightNorm)+activation GEMMs, reparameterisation, diagonal-
+Gaussian KL, Gaussian log-likelihood over genes, the categorical head -- runs in the
+hand-written HIP kernels behind ``drvae_amd.ops``; tensors must live on the GPU.
+"""
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import layers as lyr
+from . import ops
+from ._lib import GAUSS_LOGVAR, GAUSS_SIGMA
+
+# name -> module, as src/blocks.py:21-24 (the modules are parameter-free; MLP fuses the
+# activation into the producing GEMM's epilogue instead of calling them)
+nonlinearities = {'tanh': nn.Tanh(), 'sigmoid': nn.Sigmoid(), 'softmax': nn.Softmax(dim=-1),
+                  'softplus': nn.Softplus(), 'softsign': nn.Softsign(), 'relu': nn.ReLU(),
+                  'leaky_relu': nn.LeakyReLU(0.1), 'elu': nn.ELU(), 'selu': nn.SELU()}
+
+
+def _fusable(module):
+    """name of the fused-epilogue activation equivalent to an activation module, or None"""
+    if isinstance(module, nn.ELU):
+        return 'elu' if module.alpha == 1.0 else None
+    if isinstance(module, nn.Softplus):
+        return 'softplus' if (module.beta in (1, 1.0) and module.threshold in (20, 20.0)) else None
+    if isinstance(module, nn.LeakyReLU):
+        return 'leaky_relu' if abs(module.negative_slope - 0.1) < 1e-12 else None
+    for cls, name in ((nn.Sigmoid, 'sigmoid'), (nn.Tanh, 'tanh'), (nn.ReLU, 'relu'), (nn.SELU, 'selu'),
+                      (nn.Softsign, 'softsign')):
+        if isinstance(module, cls):
+            return name
+    return None
+
+
+def _apply_linear(layer, inputs, act='identity', shift=0.0):
+    g = getattr(layer, 'g', None)
+    if isinstance(layer, lyr.WeightNormLinear) and layer._pending_data_init:
+        layer._data_init(torch.cat(list(inputs), 1))
+    return ops.linear_act(inputs, layer.weight, layer.bias, g, act, shift)
+
+
+def _run_sequential(seq, inputs, shift=0.0):
+    """Evaluate an nn.Sequential of [Dropout|BatchNorm|Linear|activation] modules, fusing each
+    Linear with the activation module that follows it into one GEMM launch."""
+    mods = list(seq.children())
+    x, i, shifted = list(inputs), 0, (shift == 0.0)
+    while i < len(mods):
+        m = mods[i]
+        if isinstance(m, nn.Linear):
+            act = _fusable(mods[i + 1]) if i + 1 < len(mods) else None
+            last = (i + (2 if act else 1)) >= len(mods)
+            x = [_apply_linear(m, x, act or 'identity', shift if last else 0.0)]
+            shifted = shifted or last
+            i += 2 if act else 1
+        else:
+            t = x[0] if len(x) == 1 else torch.cat(x, 1)
+            x = [m(t)]
+            i += 1
+    out = x[0] if len(x) == 1 else torch.cat(x, 1)
+    return out if shifted else out + shift
+
+
+# ------------------------------------------------------------------------ MMD kernels
+def rbf(x1, x2, gamma=1.):
+    """src/blocks.py:29-32.  The reference implementation raises on torch >= 0.4
+    (``squeeze_(2)`` of a 2-D tensor); the intended Gram matrix is returned here."""
+    d2 = ((x1[None, :, :] - x2[:, None, :]) ** 2).sum(2)
+    return torch.exp(-d2 * gamma).t()
+
+
+def poly(x1, x2, degree=2, gamma=1., bias=1.):
+    """src/blocks.py:34-35 (the x1 x2^T product runs on the MFMA GEMM)."""
+    gram = ops.linear_act([x1], x2.contiguous(), None)
+    return torch.pow(gamma * gram + bias, degree)
+
+
+def identity(x1, x2):
+    """src/blocks.py:37-38."""
+    return ((x1.mean(0) - x2.mean(0)) ** 2).sum()
+
+
+def mmd_fourier(x1, x2, bandwidth=2., dim_r=500):
+    """Random-Fourier-feature MMD (src/blocks.py:40-55): draws W~N(0,1) (Z,dim_r) then
+    b~U(0,1) (dim_r), in that order, from the framework generator like the reference."""
+    z = x1.size(1)
+    rnd_a = torch.empty(z, dim_r, device=x1.device).normal_()
+    rnd_b = torch.empty(dim_r, device=x1.device).uniform_()
+    w_t = (math.sqrt(2. / bandwidth) * rnd_a / math.sqrt(z)).t().contiguous()     # (dim_r, Z) Linear layout
+    rb = 2 * math.pi * rnd_b
+    c = math.sqrt(2. / dim_r)
+    rf0 = c * torch.cos(ops.linear_act([x1], w_t, rb))
+    rf1 = c * torch.cos(ops.linear_act([x2], w_t, rb))
+    return ((rf0.mean(0) - rf1.mean(0)) ** 2).sum()
+
+
+kernels = {'rbf': rbf, 'poly': poly, 'identity': identity, 'rbf_fourier': mmd_fourier}
+
+
+def mmd_objective(x1, x2, kernel='rbf', bandwidths=1. / (2 * (np.array([1., 2., 5., 8., 10]) ** 2))):
+    """MMD score between two row sets (src/blocks.py:59-76)."""
+    fn = kernels[kernel]
+    if kernel == 'identity':
+        return torch.sqrt(fn(x1, x2))
+    if kernel == 'rbf_fourier':
+        return torch.sqrt(fn(x1, x2, bandwidth=2.))
+    k11 = k12 = k22 = 0
+    nb = len(bandwidths)
+    for bw in bandwidths:
+        k11 = k11 + fn(x1, x1, gamma=math.sqrt(x1.size(1)) * bw) / nb
+        k22 = k22 + fn(x2, x2, gamma=math.sqrt(x2.size(1)) * bw) / nb
+        k12 = k12 + fn(x1, x2, gamma=math.sqrt(x1.size(1)) * bw) / nb
+    return torch.sqrt(k11.mean() - 2 * k12.mean() + k22.mean())
+
+
+def one_hot(y, max_dim):
+    """(n,) or (n,1) integer labels -> (n,max_dim) float one-hot; None for None/empty
+    (src/blocks.py:78-92; pure: does not reshape its argument in place)."""
+    if y is None or len(y) == 0:
+        return None
+    idx = y.detach().reshape(-1, 1).long()
+    out = torch.zeros(idx.size(0), max_dim, device=idx.device)
+    out.scatter_(1, idx, 1.0)
+    return out
+
+
+# -------------------------------------------------------------------------------- MLP
+class MLP(nn.Module):
+    """Deterministic MLP over the concatenation of its inputs, returning the last hidden
+    layer (src/blocks.py:95-164).  Sub-modules of ``self.model`` are named ``bn_input``,
+    ``dropout{i}``, ``linear{i}``, ``activ{i}``, ``bn{i}`` exactly as in the reference."""
+
+    def __init__(self, input_dims, hidden_dims, nonlin='softplus', weight_norm=False, batch_norm=False,
+                 dropout_rate=0., input_dropout_rates=None):
+        super().__init__()
+        self.input_dims, self.hidden_dims, self.nonlin = input_dims, hidden_dims, nonlin
+        self.weight_norm, self.batch_norm, self.dropout_rate = weight_norm, batch_norm, dropout_rate
+        if input_dropout_rates is None:
+            input_dropout_rates = [max(0., dropout_rate - 0.3)] * len(input_dims)
+        if len(input_dropout_rates) != len(input_dims):
+            raise ValueError('MLP: input_dropout_rates is not the same length as input_dims %s %s'
+                             % (input_dropout_rates, input_dims))
+        self.input_dropout_rates = input_dropout_rates
+        # kept for state/API parity; the reference computes input dropout and then discards
+        # it (src/blocks.py:159-161), so it is never applied
+        self.input_dropouts = nn.ModuleList([nn.Dropout(p=r) for r in input_dropout_rates])
+        make = lyr.WeightNormLinear if weight_norm else nn.Linear
+        mods = OrderedDict()
+        width = int(np.asarray(input_dims).sum())
+        if batch_norm:
+            mods['bn_input'] = nn.BatchNorm1d(width, affine=True)
+        for i, h in enumerate(hidden_dims, start=1):
+            if i > 1 and dropout_rate > 0.:
+                mods['dropout%d' % i] = nn.Dropout(p=dropout_rate)
+            mods['linear%d' % i] = make(width, h)
+            mods['activ%d' % i] = nonlinearities[nonlin]
+            if batch_norm:
+                mods['bn%d' % i] = nn.BatchNorm1d(h, affine=True)
+            width = h
+        self.model = nn.Sequential(mods)
+
+    def forward(self, inputs):
+        assert len(inputs) == len(self.input_dims)
+        return _run_sequential(self.model, inputs)
+
+    def features(self, inputs):
+        """like forward, but an empty trunk hands the un-concatenated inputs to the next
+        Linear (which reads both sources directly) instead of materialising torch.cat"""
+        assert len(inputs) == len(self.input_dims)
+        if len(self.model) == 0:
+            return list(inputs)
+        return [_run_sequential(self.model, inputs)]
+
+
+# ----------------------------------------------------------------------------- mixins
+def _noise_like(t):
+    return torch.empty_like(t, memory_format=torch.contiguous_format).normal_()
+
+
+class GaussianLogVarMixin:
+    """Diagonal Gaussian parametrised by (mu, log sigma^2): src/blocks.py:166-202."""
+
+    def sample(self, mu, logvar):
+        return (ops.reparam(mu, logvar, _noise_like(mu), GAUSS_LOGVAR),)
+
+    def kldivergence_perx(self, mu_q, logvar_q, mu_p, logvar_p):
+        return ops.kl_rows(mu_q, logvar_q, mu_p, logvar_p, GAUSS_LOGVAR)
+
+    def kldivergence(self, mu_q, logvar_q, mu_p, logvar_p):
+        return self.kldivergence_perx(mu_q, logvar_q, mu_p, logvar_p).sum()
+
+    def kldivergence_from_prior_perx(self, mu, logvar):
+        return ops.kl_rows_prior(mu, logvar, float(self.prior_mu), float(self.prior_lv), GAUSS_LOGVAR)
+
+    def kldivergence_from_prior(self, mu, logvar):
+        return self.kldivergence_from_prior_perx(mu, logvar).sum()
+
+    def logp_perx(self, sample, mu, logvar):
+        return ops.nll_rows(sample, mu, logvar, GAUSS_LOGVAR)
+
+    def logp(self, sample, mu, logvar):
+        return self.logp_perx(sample, mu, logvar).sum()
+
+    def logp_prior_perx(self, sample):
+        mu = torch.full_like(sample, float(self.prior_mu))
+        lv = torch.full_like(sample, float(self.prior_lv))
+        return ops.nll_rows(sample, mu, lv, GAUSS_LOGVAR)
+
+    def logp_prior(self, sample):
+        return self.logp_prior_perx(sample).sum()
+
+
+class GaussianSigmaMixin:
+    """Diagonal Gaussian parametrised by (mu, sigma): src/blocks.py:204-240."""
+
+    def sample(self, mu, std):
+        return (ops.reparam(mu, std, _noise_like(mu), GAUSS_SIGMA),)
+
+    def kldivergence_perx(self, mu_q, std_q, mu_p, std_p):
+        return ops.kl_rows(mu_q, std_q, mu_p, std_p, GAUSS_SIGMA)
+
+    def kldivergence(self, mu_q, std_q, mu_p, std_p):
+        return self.kldivergence_perx(mu_q, std_q, mu_p, std_p).sum()
+
+    def kldivergence_from_prior_perx(self, mu, std):
+        return ops.kl_rows_prior(mu, std, float(self.prior_mu), float(self.prior_sg), GAUSS_SIGMA)
+
+    def kldivergence_from_prior(self, mu, std):
+        return self.kldivergence_from_prior_perx(mu, std).sum()
+
+    def logp_perx(self, sample, mu, std):
+        return ops.nll_rows(sample, mu, std, GAUSS_SIGMA)
+
+    def logp(self, sample, mu, std):
+        return self.logp_perx(sample, mu, std).sum()
+
+    def logp_prior_perx(self, sample):
+        mu = torch.full_like(sample, float(self.prior_mu))
+        sd = torch.full_like(sample, float(self.prior_sg))
+        return ops.nll_rows(sample, mu, sd, GAUSS_SIGMA)
+
+    def logp_prior(self, sample):
+        return self.logp_prior_perx(sample).sum()
+
+
+def _head(suffix, make, n_in, n_out, dropout_rate, activation=None):
+    mods = OrderedDict()
+    if dropout_rate > 0.:
+        mods['dropout_' + suffix] = nn.Dropout(p=dropout_rate)
+    mods['linear_' + suffix] = make(n_in, n_out)
+    if activation is not None:
+        mods['activ_' + suffix] = nonlinearities[activation]
+    return nn.Sequential(mods)
+
+
+def _trunk_width(input_dims, hidden_dims):
+    return hidden_dims[-1] if len(hidden_dims) > 0 else int(np.asarray(input_dims).sum())
+
+
+# ---------------------------------------------------------------------------- modules
+class DiagGaussianModule(GaussianLogVarMixin, nn.Module):
+    """inputs -> (mu, logvar): MLP trunk ``nnet`` + heads ``encoder_mu.linear_mu`` and
+    ``encoder_lv.linear_lv``; ``logvar = lv(h) - 2`` (src/blocks.py:243-301)."""
+
+    def __init__(self, input_dims, hidden_dims, output_dim, nonlin='softplus', weight_norm=False, batch_norm=False,
+                 dropout_rate=0., input_dropout_rates=None, prior_mu=0., prior_sg=1., constrain_means=False,
+                 fixed_variance=None):
+        super().__init__()
+        self.nnet = MLP(input_dims=input_dims, hidden_dims=hidden_dims, nonlin=nonlin, weight_norm=weight_norm,
+                        batch_norm=batch_norm, dropout_rate=dropout_rate, input_dropout_rates=input_dropout_rates)
+        self.output_dim, self.constrain_means = output_dim, constrain_means
+        self.fixed_variance = None if fixed_variance is None else (torch.zeros(1) + fixed_variance).log()
+        make = lyr.WeightNormLinear if weight_norm else nn.Linear
+        width = _trunk_width(input_dims, hidden_dims)
+        self.encoder_mu = _head('mu', make, width, output_dim, dropout_rate,
+                                'sigmoid' if constrain_means else None)
+        self.encoder_lv = _head('lv', make, width, output_dim, dropout_rate)
+        # plain tensors, not buffers -- as in the reference (src/blocks.py:288-289)
+        self.prior_mu = torch.zeros(1) + prior_mu
+        self.prior_lv = (torch.zeros(1) + prior_sg ** 2).log()
+
+    def forward(self, inputs):
+        h = self.nnet.features(inputs)
+        mu = _run_sequential(self.encoder_mu, h)
+        if self.fixed_variance is not None:
+            logvar = self.fixed_variance.to(mu.device).expand_as(mu)
+        else:
+            logvar = _run_sequential(self.encoder_lv, h, shift=-2.0)
+        return mu, logvar
+
+
+class DiagGaussianModuleLinear(GaussianLogVarMixin, nn.Module):
+    """The perturbation function p(z2|z1): ``mu = x + x W_mu^T + b`` (or ``x + b`` when
+    ``bias_only``), ``logvar = Linear(x) - 2`` (src/blocks.py:304-361)."""
+
+    def __init__(self, input_dims, hidden_dims, latent_dim, nonlin='softplus', weight_norm=False, batch_norm=False,
+                 dropout_rate=0., input_dropout_rates=None, prior_mu=0., prior_sg=1., constrain_means=False,
+                 bias_only=False):
+        super().__init__()
+        self.input_dims, self.hidden_dims, self.nonlin = input_dims, hidden_dims, nonlin
+        self.weight_norm, self.batch_norm, self.dropout_rate = weight_norm, batch_norm, dropout_rate
+        self.input_dropout_rates = input_dropout_rates
+        self.constrain_means, self.bias_only = constrain_means, bias_only
+        assert len(input_dims) == 1 and input_dims[0] == latent_dim     # must not change dimensionality
+        if constrain_means:
+            raise NameError("name 'modules_mu' is not defined")         # reference behaviour, src/blocks.py:335
+        self.W_mu = nn.Parameter(torch.empty(latent_dim, latent_dim).uniform_(-0.0001, 0.0001))
+        self.bias_mu = nn.Parameter(torch.empty(latent_dim).uniform_(-0.0001, 0.0001))
+        # the logvar head is a plain Linear whatever weight_norm says (src/blocks.py:332)
+        self.encoder_lv = _head('lv', nn.Linear, latent_dim, latent_dim, dropout_rate)
+        self.prior_mu = torch.zeros(1) + prior_mu
+        self.prior_lv = (torch.zeros(1) + prior_sg ** 2).log()
+
+    def forward(self, inputs):
+        assert len(inputs) == len(self.input_dims)
+        x = inputs[0] if len(inputs) == 1 else torch.cat(inputs, 1)
+        if self.bias_only:
+            mu = x + self.bias_mu.expand_as(x)
+        else:
+            mu = x + ops.linear_act([x], self.W_mu, self.bias_mu)
+        logvar = _run_sequential(self.encoder_lv, [x], shift=-2.0)
+        return mu, logvar
+
+
+class DiagGaussianSigmaModule(GaussianSigmaMixin, nn.Module):
+    """inputs -> (mu, std) with ``std = softplus(sg(h)) + 1e-3`` -- the data decoder
+    p(x|z) (src/blocks.py:364-416)."""
+
+    def __init__(self, input_dims, hidden_dims, latent_dim, nonlin='softplus', weight_norm=False, batch_norm=False,
+                 dropout_rate=0., input_dropout_rates=None, prior_mu=0., prior_sg=1., constrain_means=False):
+        super().__init__()
+        self.nnet = MLP(input_dims=input_dims, hidden_dims=hidden_dims, nonlin=nonlin, weight_norm=weight_norm,
+                        batch_norm=batch_norm, dropout_rate=dropout_rate, input_dropout_rates=input_dropout_rates)
+        self.latent_dim, self.constrain_means = latent_dim, constrain_means
+        make = lyr.WeightNormLinear if weight_norm else nn.Linear
+        width = _trunk_width(input_dims, hidden_dims)
+        self.encoder_mu = _head('mu', make, width, latent_dim, dropout_rate,
+                                'sigmoid' if constrain_means else None)
+        self.encoder_sg = _head('sg', make, width, latent_dim, dropout_rate, 'softplus')
+        self.prior_mu = torch.zeros(1) + prior_mu
+        self.prior_sg = torch.zeros(1) + prior_sg
+
+    def forward(self, inputs):
+        h = self.nnet.features(inputs)
+        mu = _run_sequential(self.encoder_mu, h)
+        std = _run_sequential(self.encoder_sg, h, shift=1e-3)
+        return mu, std
+
+
+class CategoricalDecoder(nn.Module):
+    """inputs -> [clamped class probabilities] (a 1-element list), plus the categorical
+    log-likelihood / KL / entropy helpers (src/blocks.py:419-486)."""
+
+    def __init__(self, input_dims, hidden_dims, reconstruction_dim, nonlin='softplus', weight_norm=False,
+                 batch_norm=False, dropout_rate=0., input_dropout_rates=None):
+        super().__init__()
+        self.nnet = MLP(input_dims=input_dims, hidden_dims=hidden_dims, nonlin=nonlin, weight_norm=weight_norm,
+                        batch_norm=batch_norm, dropout_rate=dropout_rate, input_dropout_rates=input_dropout_rates)
+        self.reconstruction_dim = reconstruction_dim
+        make = lyr.WeightNormLinear if weight_norm else nn.Linear
+        width = _trunk_width(input_dims, hidden_dims)
+        mods = OrderedDict()
+        if dropout_rate > 0.:
+            mods['dropout_p'] = nn.Dropout(p=dropout_rate)
+        mods['linear_p'] = make(width, reconstruction_dim)
+        mods['activ_p'] = nn.Softmax(dim=-1) if reconstruction_dim > 1 else nn.Sigmoid()
+        self.decoder_p = nn.Sequential(mods)
+
+    def forward(self, inputs):
+        h = self.nnet.features(inputs)
+        if hasattr(self.decoder_p, 'dropout_p'):
+            h = [self.decoder_p.dropout_p(h[0] if len(h) == 1 else torch.cat(h, 1))]
+        logits = _apply_linear(self.decoder_p.linear_p, h)
+        return [ops.softmax_clamp(logits, sigmoid1=(self.reconstruction_dim == 1))]
+
+    def sample(self, ps):
+        return torch.multinomial(ps, 1)
+
+    def logp_perx(self, x, ps):
+        return ops.cat_logp_rows(ps, x)
+
+    def logp(self, x, ps):
+        return torch.sum(self.logp_perx(x, ps))
+
+    def entropy(self, ps):
+        return ops.cat_entropy_rows(ps).sum()
+
+    def kldivergence_perx(self, ps, prior):
+        return ops.cat_kl_elem(ps, prior)
+
+    def kldivergence(self, ps, prior):
+        return self.kldivergence_perx(ps, prior).sum()
+
+    def most_probable(self, ps):
+        return ops.cat_most_probable(ps)

@@ -1,0 +1,79 @@
+// Shared device helpers for the Dr.VAE ELBO hot path kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/drvae_hip.h"
+
+#define DV_WAVE 64
+
+// Launch-check used by every C-ABI entry point: never throws, never syncs.
+#define DV_RETURN_LAUNCH()                                   \
+    do {                                                     \
+        hipError_t e__ = hipGetLastError();                  \
+        return e__ == hipSuccess ? DV_OK : DV_ERR_LAUNCH;    \
+    } while (0)
+
+#define DV_REQUIRE(cond)              \
+    do {                              \
+        if (!(cond)) return DV_ERR_ARG; \
+    } while (0)
+
+// ---------------------------------------------------------------- activations
+// Forward value and derivative-from-OUTPUT (so backward never needs the pre-activation):
+//   elu(a=1):  y = x>0 ? x : expm1(x)         dy/dx = y>0 ? 1 : y+1
+//   softplus:  y = x>20 ? x : log1p(exp(x))   dy/dx = 1-exp(-y)        (torch beta=1, threshold=20)
+//   sigmoid:   dy/dx = y(1-y);  tanh: 1-y^2;  relu: y>0;  leaky(0.1): y>0?1:0.1
+//   selu:      y = l*(x>0?x:a*expm1(x))       dy/dx = y>0 ? l : y+l*a
+//   softsign:  y = x/(1+|x|)                  dy/dx = (1-|y|)^2
+// (reference table: src/blocks.py:21-24)
+__device__ __forceinline__ float dv_act(int act, float x) {
+    switch (act) {
+        case DV_ACT_ELU: return x > 0.f ? x : expm1f(x);
+        case DV_ACT_SOFTPLUS: return x > 20.f ? x : log1pf(expf(x));
+        case DV_ACT_SIGMOID: return 1.f / (1.f + expf(-x));
+        case DV_ACT_TANH: return tanhf(x);
+        case DV_ACT_RELU: return x > 0.f ? x : 0.f;
+        case DV_ACT_LEAKY_RELU: return x > 0.f ? x : 0.1f * x;
+        case DV_ACT_SELU: {
+            const float l = 1.0507009873554804934193349852946f, a = 1.6732632423543772848170429916717f;
+            return l * (x > 0.f ? x : a * expm1f(x));
+        }
+        case DV_ACT_SOFTSIGN: return x / (1.f + fabsf(x));
+        case DV_ACT_COS: return cosf(x);
+        default: return x;
+    }
+}
+
+__device__ __forceinline__ float dv_dact_from_y(int act, float y) {
+    switch (act) {
+        case DV_ACT_ELU: return y > 0.f ? 1.f : y + 1.f;
+        case DV_ACT_SOFTPLUS: return 1.f - expf(-y);
+        case DV_ACT_SIGMOID: return y * (1.f - y);
+        case DV_ACT_TANH: return 1.f - y * y;
+        case DV_ACT_RELU: return y > 0.f ? 1.f : 0.f;
+        case DV_ACT_LEAKY_RELU: return y > 0.f ? 1.f : 0.1f;
+        case DV_ACT_SELU: {
+            const float l = 1.0507009873554804934193349852946f, a = 1.6732632423543772848170429916717f;
+            return y > 0.f ? l : y + l * a;
+        }
+        case DV_ACT_SOFTSIGN: {
+            float t = 1.f - fabsf(y);
+            return t * t;
+        }
+        default: return 1.f;
+    }
+}
+
+// ---------------------------------------------------------------- wave reductions
+__device__ __forceinline__ float dv_wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;   // valid in lane 0
+}
+
+__device__ __forceinline__ float dv_wave_sum_all(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;   // valid in every lane
+}

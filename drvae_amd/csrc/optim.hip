@@ -1,0 +1,169 @@
+// Fused Adam (coupled L2) over a flat fp32 arena, device-side step/RNG counters and the
+// on-device N(0,1) generator (Philox4x32-10 + Box-Muller) of the Dr.VAE train step.
+// All HBM-streaming: 16-B per lane, grid-stride, 7 words of traffic per parameter.
+#include "dv_common.h"
+
+namespace {
+
+struct AdamC {
+    float lr_over_bc1, inv_unused, bc2_sqrt, eps, wd, one_minus_b1, b2, one_minus_b2, gscale;
+};
+
+// bias corrections from the device-side step counter, in double like torch's python floats
+__device__ __forceinline__ void adam_consts(float lr, float b1, float b2, const int32_t* step_dev, float* step_size,
+                                            float* bc2_sqrt) {
+    const double t = (double)step_dev[0];
+    const double bc1 = 1.0 - pow((double)b1, t);
+    const double bc2 = 1.0 - pow((double)b2, t);
+    *step_size = (float)((double)lr / bc1);
+    *bc2_sqrt = (float)sqrt(bc2);
+}
+
+__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, float step_size, float bc2_sqrt,
+                                         float eps, float wd, float w1, float b2, float w2, float gscale) {
+    // torch/optim/adam.py::_single_tensor_adam (2.x): grad += wd*p; m.lerp_(g, 1-b1);
+    // v = v*b2 + (1-b2)*g*g; denom = sqrt(v)/sqrt(bc2) + eps; p += -(lr/bc1) * (m/denom)
+    g *= gscale;
+    if (wd != 0.f) g = g + wd * p;
+    m = m + w1 * (g - m);
+    v = v * b2 + (w2 * g) * g;
+    const float denom = sqrtf(v) / bc2_sqrt + eps;
+    p = p + (-step_size) * (m / denom);
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, int64_t n, float lr,
+                                                   float b1, float b2, float eps, float wd, float gscale,
+                                                   const int32_t* __restrict__ step_dev, int vec4) {
+    __shared__ float sc[2];
+    if (threadIdx.x == 0) adam_consts(lr, b1, b2, step_dev, &sc[0], &sc[1]);
+    __syncthreads();
+    const float step_size = sc[0], bc2_sqrt = sc[1];
+    // (float)(1 - beta) computed in double first, as python does before the op sees it
+    const float w1 = (float)(1.0 - (double)b1), w2 = (float)(1.0 - (double)b2);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t t0 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (vec4) {
+        const int64_t n4 = n >> 2;
+        float4* p4 = reinterpret_cast<float4*>(p);
+        const float4* g4 = reinterpret_cast<const float4*>(g);
+        float4* m4 = reinterpret_cast<float4*>(m);
+        float4* v4 = reinterpret_cast<float4*>(v);
+        for (int64_t i = t0; i < n4; i += stride) {
+            float4 pp = p4[i], gg = g4[i], mm = m4[i], vv = v4[i];
+            adam_one(pp.x, gg.x, mm.x, vv.x, step_size, bc2_sqrt, eps, wd, w1, b2, w2, gscale);
+            adam_one(pp.y, gg.y, mm.y, vv.y, step_size, bc2_sqrt, eps, wd, w1, b2, w2, gscale);
+            adam_one(pp.z, gg.z, mm.z, vv.z, step_size, bc2_sqrt, eps, wd, w1, b2, w2, gscale);
+            adam_one(pp.w, gg.w, mm.w, vv.w, step_size, bc2_sqrt, eps, wd, w1, b2, w2, gscale);
+            p4[i] = pp;
+            m4[i] = mm;
+            v4[i] = vv;
+        }
+        for (int64_t i = (n4 << 2) + t0; i < n; i += stride)
+            adam_one(p[i], g[i], m[i], v[i], step_size, bc2_sqrt, eps, wd, w1, b2, w2, gscale);
+    } else {
+        for (int64_t i = t0; i < n; i += stride)
+            adam_one(p[i], g[i], m[i], v[i], step_size, bc2_sqrt, eps, wd, w1, b2, w2, gscale);
+    }
+}
+
+__global__ void counter_add_kernel(int32_t* c, int n_words, int64_t inc) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (n_words == 1) {
+        c[0] = (int32_t)(c[0] + inc);
+    } else {
+        uint64_t v = ((uint64_t)(uint32_t)c[1] << 32) | (uint32_t)c[0];
+        v += (uint64_t)inc;
+        c[0] = (int32_t)(uint32_t)v;
+        c[1] = (int32_t)(uint32_t)(v >> 32);
+    }
+}
+
+// ------------------------------------------------------------------ Philox4x32-10
+__device__ __forceinline__ void philox_round(uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3, uint32_t k0,
+                                             uint32_t k1) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+    c0 = n0;
+    c1 = n1;
+    c2 = n2;
+    c3 = n3;
+}
+
+__device__ __forceinline__ float u01(uint32_t x) { return ((float)x + 0.5f) * 2.3283064365386963e-10f; }
+
+__global__ __launch_bounds__(256) void fill_normal_kernel(float* __restrict__ out, int64_t n, uint64_t seed,
+                                                          const int32_t* __restrict__ ctr_dev) {
+    uint64_t base = 0;
+    if (ctr_dev) base = ((uint64_t)(uint32_t)ctr_dev[1] << 32) | (uint32_t)ctr_dev[0];
+    const int64_t n4 = (n + 3) >> 2;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint64_t ctr = base + (uint64_t)i;
+        uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = 0u, c3 = 0u;
+        uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            philox_round(c0, c1, c2, c3, k0, k1);
+            k0 += 0x9E3779B9u;
+            k1 += 0xBB67AE85u;
+        }
+        const float r0 = sqrtf(-2.f * logf(u01(c0))), r1 = sqrtf(-2.f * logf(u01(c2)));
+        float s0, co0, s1, co1;
+        sincosf(6.283185307179586f * u01(c1), &s0, &co0);
+        sincosf(6.283185307179586f * u01(c3), &s1, &co1);
+        const float z[4] = {r0 * co0, r0 * s0, r1 * co1, r1 * s1};
+        const int64_t o = i << 2;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (o + e < n) out[o + e] = z[e];
+    }
+}
+
+}  // namespace
+
+#define ST(s) static_cast<hipStream_t>(s)
+
+extern "C" int dv_abi_version(void) { return DV_ABI_VERSION; }
+
+extern "C" const char* dv_error_string(int code) {
+    switch (code) {
+        case DV_OK: return "ok";
+        case DV_ERR_ARG: return "invalid argument";
+        case DV_ERR_LAUNCH: return "kernel launch failed";
+        case DV_ERR_UNSUPPORTED: return "unsupported configuration";
+        default: return "unknown error";
+    }
+}
+
+extern "C" int dv_adam_l2(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                          float beta2, float eps, float weight_decay, float gscale, const int32_t* step_dev,
+                          dv_stream_t stream) {
+    DV_REQUIRE(n >= 0);
+    if (n == 0) return DV_OK;
+    DV_REQUIRE(p && g && m && v && step_dev);
+    auto al = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    const int vec4 = al(p) && al(g) && al(m) && al(v);
+    int64_t blocks = ((vec4 ? (n >> 2) : n) + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, ST(stream), p, g, m, v, n, lr, beta1,
+                       beta2, eps, weight_decay, gscale, step_dev, vec4);
+    DV_RETURN_LAUNCH();
+}
+
+extern "C" int dv_counter_add(int32_t* counter_lo_hi, int32_t n_words, int64_t inc, dv_stream_t stream) {
+    DV_REQUIRE(counter_lo_hi && (n_words == 1 || n_words == 2));
+    hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(64), 0, ST(stream), counter_lo_hi, n_words, inc);
+    DV_RETURN_LAUNCH();
+}
+
+extern "C" int dv_fill_normal(float* out, int64_t n, uint64_t seed, const int32_t* ctr_dev, dv_stream_t stream) {
+    DV_REQUIRE(n >= 0);
+    if (n == 0) return DV_OK;
+    DV_REQUIRE(out);
+    int64_t blocks = (((n + 3) >> 2) + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(fill_normal_kernel, dim3((unsigned)blocks), dim3(256), 0, ST(stream), out, n, seed, ctr_dev);
+    DV_RETURN_LAUNCH();
+}

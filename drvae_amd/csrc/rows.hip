@@ -1,0 +1,725 @@
+// Row-wise kernels of the Dr.VAE ELBO hot path (gfx950): reparameterisation, diagonal-
+// Gaussian KL with free bits, Gaussian log-likelihood over genes, the categorical head,
+// the y-marginalisation, row gathers / segment sums, WeightNorm scale + backward.
+// All are HBM/L2-bound streaming kernels: coalesced row reads (16-B per lane where the
+// layout allows), one 64-lane wavefront per row for the reductions (__shfl), no atomics
+// (results are bitwise reproducible).
+#include "dv_common.h"
+
+namespace {
+
+constexpr float kLog2Pi = 1.8378770664093453f;   // float(np.log(2*np.pi)), src/blocks.py:196,234
+
+inline int grid_for(int64_t work, int per_block, int cap = 4096) {
+    int64_t b = (work + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    if (b > cap) b = cap;
+    return (int)b;
+}
+
+// ------------------------------------------------------------------ colsum / act_bwd
+// 64 columns x 4 row-lanes per block; rows strided by 4*gridDim.y
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, int64_t ldx, int M, int N,
+                                                     float* __restrict__ out, float beta) {
+    __shared__ float part[4][64];
+    const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + c;
+    float s = 0.f;
+    if (col < N)
+        for (int m = rl; m < M; m += 4) s += X[(int64_t)m * ldx + col];
+    part[rl][c] = s;
+    __syncthreads();
+    if (rl == 0 && col < N) {
+        s = part[0][c] + part[1][c] + part[2][c] + part[3][c];
+        out[col] = (beta != 0.f ? beta * out[col] : 0.f) + s;
+    }
+}
+
+__global__ void act_bwd_kernel(float* __restrict__ dY, int64_t ldd, const float* __restrict__ Y, int64_t ldy, int M,
+                               int N, int split, int act0, int act1, float shift0, float shift1) {
+    const int64_t total = (int64_t)M * N;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int m = (int)(e / N), n = (int)(e % N);
+        const bool first = n < split;
+        const float y = Y[(int64_t)m * ldy + n] - (first ? shift0 : shift1);
+        dY[(int64_t)m * ldd + n] *= dv_dact_from_y(first ? act0 : act1, y);
+    }
+}
+
+// --------------------------------------------------------------------- WeightNorm
+__global__ __launch_bounds__(256) void wn_scale_kernel(const float* __restrict__ W, int64_t ldw,
+                                                       const float* __restrict__ g, int N, int K,
+                                                       float* __restrict__ scale, float* __restrict__ norm) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= N) return;
+    const float* w = W + (int64_t)row * ldw;
+    float s = 0.f;
+    for (int k = lane; k < K; k += 64) s += w[k] * w[k];
+    s = dv_wave_sum_all(s);
+    if (lane == 0) {
+        const float nrm = sqrtf(s);
+        if (norm) norm[row] = nrm;
+        scale[row] = g[row] / nrm;
+    }
+}
+
+__global__ __launch_bounds__(256) void wn_bwd_kernel(const float* __restrict__ dWraw, int64_t ldr,
+                                                     const float* __restrict__ W, int64_t ldw,
+                                                     const float* __restrict__ g, const float* __restrict__ norm,
+                                                     int N, int K, float* __restrict__ dW, int64_t ldd,
+                                                     float* __restrict__ dg, float beta) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= N) return;
+    const float* w = W + (int64_t)row * ldw;
+    const float* r = dWraw + (int64_t)row * ldr;
+    float dot = 0.f;
+    for (int k = lane; k < K; k += 64) dot += w[k] * r[k];
+    dot = dv_wave_sum_all(dot);
+    const float nrm = norm[row], gg = g[row];
+    const float sc = gg / nrm, cw = dot * gg / (nrm * nrm * nrm);
+    float* o = dW + (int64_t)row * ldd;
+    for (int k = lane; k < K; k += 64) {
+        const float v = sc * r[k] - cw * w[k];
+        o[k] = (beta != 0.f ? beta * o[k] : 0.f) + v;
+    }
+    if (lane == 0) dg[row] = (beta != 0.f ? beta * dg[row] : 0.f) + dot / nrm;
+}
+
+// ---------------------------------------------------------------------- reparam
+__global__ void reparam_fwd_kernel(const float* __restrict__ mu, const float* __restrict__ sd, int64_t ldq,
+                                   const int32_t* __restrict__ src_idx, int n, int reps, int Z,
+                                   const float* __restrict__ eps, int64_t lde, int mode, float* __restrict__ out,
+                                   int64_t ldo, const float* __restrict__ sub, int64_t lds,
+                                   float* __restrict__ out2, int64_t ldo2) {
+    const int64_t total = (int64_t)n * reps * Z;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int r = (int)(e / Z), d = (int)(e % Z);
+        const int j = r % n;
+        const int64_t qi = src_idx ? src_idx[j] : j;
+        const float s = sd[qi * ldq + d];
+        const float std_ = mode == DV_GAUSS_LOGVAR ? expf(0.5f * s) : s;
+        const float z = eps[(int64_t)r * lde + d] * std_ + mu[qi * ldq + d];
+        out[(int64_t)r * ldo + d] = z;
+        if (out2) out2[(int64_t)r * ldo2 + d] = z - sub[(int64_t)r * lds + d];
+    }
+}
+
+__global__ void reparam_bwd_kernel(const float* __restrict__ dz, int64_t ldz, const float* __restrict__ eps,
+                                   int64_t lde, const float* __restrict__ sd, int64_t ldq,
+                                   const int32_t* __restrict__ src_idx, int n, int reps, int Z, int mode,
+                                   float* __restrict__ dmu, float* __restrict__ dsd, int64_t lddq, float beta) {
+    const int64_t total = (int64_t)n * Z;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int j = (int)(e / Z), d = (int)(e % Z);
+        const int64_t qi = src_idx ? src_idx[j] : j;
+        float a = 0.f, b = 0.f;
+        for (int l = 0; l < reps; ++l) {
+            const int64_t r = (int64_t)l * n + j;
+            const float g = dz[r * ldz + d];
+            a += g;
+            b += g * eps[r * lde + d];
+        }
+        if (mode == DV_GAUSS_LOGVAR) b *= 0.5f * expf(0.5f * sd[qi * ldq + d]);
+        float* pm = dmu + qi * lddq + d;
+        float* ps = dsd + qi * lddq + d;
+        *pm = (beta != 0.f ? beta * *pm : 0.f) + a;
+        *ps = (beta != 0.f ? beta * *ps : 0.f) + b;
+    }
+}
+
+// ---------------------------------------------------------------------- KL rows
+struct KlArgs {
+    const float *mu_q, *sd_q;
+    int64_t ldq;
+    const int32_t* qidx;
+    const float *mu_p, *sd_p;
+    int64_t ldp;
+    const int32_t* pidx;
+    float prior_mu, prior_sd;
+    int n, reps, Z, mode;
+};
+
+__device__ __forceinline__ float kl_term(int mode, float mq, float sq, float mp, float sp) {
+    const float dm = mq - mp;
+    if (mode == DV_GAUSS_LOGVAR) return 1.f - sp + sq - (dm * dm + expf(sq)) / expf(sp);
+    const float vq = sq * sq, vp = sp * sp;
+    return 1.f - logf(vp) + logf(vq) - (dm * dm + vq) / vp;
+}
+
+__global__ __launch_bounds__(256) void kl_rows_fwd_kernel(KlArgs a, int free_bits, float kl_min,
+                                                          float* __restrict__ raw_out, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int rows = a.n * a.reps;
+    for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += gridDim.x * 4) {
+        const int j = r % a.n;
+        const int64_t qi = a.qidx ? a.qidx[j] : j;
+        const int64_t pi = a.pidx ? a.pidx[r] : r;
+        float s = 0.f;
+        for (int d = lane; d < a.Z; d += 64) {
+            const float mq = a.mu_q[qi * a.ldq + d], sq = a.sd_q[qi * a.ldq + d];
+            const float mp = a.mu_p ? a.mu_p[pi * a.ldp + d] : a.prior_mu;
+            const float sp = a.mu_p ? a.sd_p[pi * a.ldp + d] : a.prior_sd;
+            s += kl_term(a.mode, mq, sq, mp, sp);
+        }
+        s = dv_wave_sum_all(s);
+        if (lane == 0) {
+            const float raw = -0.5f * s;
+            if (raw_out) raw_out[r] = raw;
+            out[r] = free_bits ? fmaxf(raw, kl_min) : raw;
+        }
+    }
+}
+
+__global__ void kl_rows_bwd_kernel(KlArgs a, const float* __restrict__ coef, const float* __restrict__ raw,
+                                   int free_bits, float kl_min, float* __restrict__ dq_mu,
+                                   float* __restrict__ dq_sd, int64_t lddq, float* __restrict__ dp_mu,
+                                   float* __restrict__ dp_sd, int64_t lddp, float beta) {
+    const int64_t total = (int64_t)a.n * a.reps * a.Z;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int r = (int)(e / a.Z), d = (int)(e % a.Z);
+        const int j = r % a.n;
+        const int64_t qi = a.qidx ? a.qidx[j] : j;
+        const int64_t pi = a.pidx ? a.pidx[r] : r;
+        float c = coef[r];
+        if (free_bits) {   // d max(raw, kl_min)/d raw: 1 above, 0 below, 1/2 on a tie (torch.max)
+            const float rv = raw[r];
+            c *= rv > kl_min ? 1.f : (rv == kl_min ? 0.5f : 0.f);
+        }
+        const float mq = a.mu_q[qi * a.ldq + d], sq = a.sd_q[qi * a.ldq + d];
+        const float mp = a.mu_p ? a.mu_p[pi * a.ldp + d] : a.prior_mu;
+        const float sp = a.mu_p ? a.sd_p[pi * a.ldp + d] : a.prior_sd;
+        const float dm = mq - mp;
+        float gmq, gsq, gmp, gsp;
+        if (a.mode == DV_GAUSS_LOGVAR) {
+            const float ivp = expf(-sp), vq = expf(sq);
+            gmq = dm * ivp;
+            gsq = -0.5f * (1.f - vq * ivp);
+            gmp = -gmq;
+            gsp = -0.5f * (-1.f + (dm * dm + vq) * ivp);
+        } else {
+            const float vp = sp * sp;
+            gmq = dm / vp;
+            gsq = -1.f / sq + sq / vp;
+            gmp = -gmq;
+            gsp = 1.f / sp - (dm * dm + sq * sq) / (vp * sp);
+        }
+        const int64_t oq = (int64_t)r * lddq + d;
+        dq_mu[oq] = (beta != 0.f ? beta * dq_mu[oq] : 0.f) + c * gmq;
+        dq_sd[oq] = (beta != 0.f ? beta * dq_sd[oq] : 0.f) + c * gsq;
+        if (dp_mu) {
+            const int64_t op = (int64_t)r * lddp + d;
+            dp_mu[op] = (beta != 0.f ? beta * dp_mu[op] : 0.f) + c * gmp;
+            dp_sd[op] = (beta != 0.f ? beta * dp_sd[op] : 0.f) + c * gsp;
+        }
+    }
+}
+
+// -------------------------------------------------------- Gaussian NLL over genes
+__device__ __forceinline__ float nll_term(int mode, float x, float m, float s) {
+    const float d = x - m;
+    if (mode == DV_GAUSS_SIGMA) {
+        const float v = s * s;
+        return kLog2Pi + logf(v) + d * d / v;
+    }
+    return kLog2Pi + s + d * d / expf(s);
+}
+
+template <bool VEC4>
+__global__ __launch_bounds__(256) void nll_rows_fwd_kernel(const float* __restrict__ x, int64_t ldx,
+                                                           const int32_t* __restrict__ xidx,
+                                                           const float* __restrict__ mu,
+                                                           const float* __restrict__ sd, int64_t ldp, int M, int X,
+                                                           int mode, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < M; r += gridDim.x * 4) {
+        const float* xr = x + (int64_t)(xidx ? xidx[r] : r) * ldx;
+        const float* mr = mu + (int64_t)r * ldp;
+        const float* sr = sd + (int64_t)r * ldp;
+        float s = 0.f;
+        if (VEC4) {
+            const int X4 = X >> 2;
+            for (int c = lane; c < X4; c += 64) {
+                const float4 xv = reinterpret_cast<const float4*>(xr)[c];
+                const float4 mv = reinterpret_cast<const float4*>(mr)[c];
+                const float4 sv = reinterpret_cast<const float4*>(sr)[c];
+                s += nll_term(mode, xv.x, mv.x, sv.x) + nll_term(mode, xv.y, mv.y, sv.y) +
+                     nll_term(mode, xv.z, mv.z, sv.z) + nll_term(mode, xv.w, mv.w, sv.w);
+            }
+            for (int g = (X4 << 2) + lane; g < X; g += 64) s += nll_term(mode, xr[g], mr[g], sr[g]);
+        } else {
+            for (int g = lane; g < X; g += 64) s += nll_term(mode, xr[g], mr[g], sr[g]);
+        }
+        s = dv_wave_sum_all(s);
+        if (lane == 0) out[r] = -0.5f * s;
+    }
+}
+
+__global__ void nll_rows_bwd_kernel(const float* __restrict__ coef, const float* __restrict__ x, int64_t ldx,
+                                    const int32_t* __restrict__ xidx, const float* __restrict__ mu,
+                                    const float* __restrict__ sd, int64_t ldp, int M, int X, int mode, int sd_act,
+                                    float sd_shift, float* __restrict__ dmu, float* __restrict__ dsd, int64_t ldd,
+                                    float* __restrict__ dx, int64_t lddx, float beta) {
+    const int64_t total = (int64_t)M * X;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int r = (int)(e / X), g = (int)(e % X);
+        const float c = coef[r];
+        const float xv = x[(int64_t)(xidx ? xidx[r] : r) * ldx + g];
+        const float m = mu[(int64_t)r * ldp + g], s = sd[(int64_t)r * ldp + g];
+        const float d = xv - m;
+        float gm, gs;
+        if (mode == DV_GAUSS_SIGMA) {
+            const float v = s * s;
+            gm = d / v;
+            gs = -1.f / s + d * d / (v * s);
+        } else {
+            const float iv = expf(-s);
+            gm = d * iv;
+            gs = -0.5f * (1.f - d * d * iv);
+        }
+        if (sd_act != DV_ACT_IDENTITY) gs *= dv_dact_from_y(sd_act, s - sd_shift);
+        const int64_t o = (int64_t)r * ldd + g;
+        dmu[o] = (beta != 0.f ? beta * dmu[o] : 0.f) + c * gm;
+        dsd[o] = (beta != 0.f ? beta * dsd[o] : 0.f) + c * gs;
+        if (dx) {
+            const int64_t ox = (int64_t)r * lddx + g;
+            dx[ox] = (beta != 0.f ? beta * dx[ox] : 0.f) - c * gm;
+        }
+    }
+}
+
+// ------------------------------------------------------------------- categorical
+constexpr float kPMin = 1e-10f;
+constexpr float kPMax = 1.f - 1e-10f;   // == 1.0f in fp32, as in the reference's fp32 clamp
+
+__global__ void softmax_clamp_fwd_kernel(const float* __restrict__ logits, int64_t ldl, int M, int Y, int sigmoid1,
+                                         float* __restrict__ probs, int64_t ldp) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= M) return;
+    const float* a = logits + (int64_t)r * ldl;
+    float* p = probs + (int64_t)r * ldp;
+    if (sigmoid1) {
+        const float s = 1.f / (1.f + expf(-a[0]));
+        p[0] = fminf(fmaxf(1.f - s, kPMin), kPMax);
+        p[1] = fminf(fmaxf(s, kPMin), kPMax);
+        return;
+    }
+    float mx = a[0];
+    for (int j = 1; j < Y; ++j) mx = fmaxf(mx, a[j]);
+    float den = 0.f;
+    for (int j = 0; j < Y; ++j) den += expf(a[j] - mx);
+    for (int j = 0; j < Y; ++j) p[j] = fminf(fmaxf(expf(a[j] - mx) / den, kPMin), kPMax);
+}
+
+__global__ void softmax_clamp_bwd_kernel(const float* __restrict__ dprobs, int64_t lddp,
+                                         const float* __restrict__ probs, int64_t ldp, int M, int Y, int sigmoid1,
+                                         float* __restrict__ dlogits, int64_t ldl, float beta) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= M) return;
+    const float* g = dprobs + (int64_t)r * lddp;
+    const float* p = probs + (int64_t)r * ldp;
+    float* o = dlogits + (int64_t)r * ldl;
+    // clamp passes the gradient only where the unclamped value lies inside [1e-10, 1]
+    if (sigmoid1) {
+        const float s = p[1], g1 = p[1] > kPMin ? g[1] : 0.f, g0 = p[0] > kPMin ? g[0] : 0.f;
+        const float v = (g1 - g0) * s * (1.f - s);
+        o[0] = (beta != 0.f ? beta * o[0] : 0.f) + v;
+        return;
+    }
+    float dot = 0.f;
+    for (int j = 0; j < Y; ++j) dot += (p[j] > kPMin ? g[j] : 0.f) * p[j];
+    for (int j = 0; j < Y; ++j) {
+        const float v = p[j] * ((p[j] > kPMin ? g[j] : 0.f) - dot);
+        o[j] = (beta != 0.f ? beta * o[j] : 0.f) + v;
+    }
+}
+
+__global__ void cat_terms_fwd_kernel(const float* __restrict__ probs, int64_t ldp, int M, int Y,
+                                     const int32_t* __restrict__ labels, const float* __restrict__ prior,
+                                     int64_t ldpr, float* __restrict__ logp, float* __restrict__ kl, int64_t ldk,
+                                     float* __restrict__ ent, int32_t* __restrict__ best) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= M) return;
+    const float* p = probs + (int64_t)r * ldp;
+    if (logp) logp[r] = logf(p[labels[r]]);
+    float e = 0.f, bv = p[0];
+    int bi = 0;
+    for (int j = 0; j < Y; ++j) {
+        const float lp = logf(p[j]);
+        if (kl) kl[(int64_t)r * ldk + j] = -p[j] * (logf(prior[(int64_t)r * ldpr + j]) - lp);
+        e += p[j] * lp;
+        if (p[j] > bv) {
+            bv = p[j];
+            bi = j;
+        }
+    }
+    if (ent) ent[r] = -e;
+    if (best) best[r] = bi;
+}
+
+__global__ void cat_terms_bwd_kernel(const float* __restrict__ probs, int64_t ldp, int M, int Y,
+                                     const int32_t* __restrict__ labels, const float* __restrict__ prior,
+                                     int64_t ldpr, const float* __restrict__ c_logp, const float* __restrict__ g_kl,
+                                     int64_t ldg, const float* __restrict__ c_ent, float* __restrict__ dprobs,
+                                     int64_t lddp, float beta) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= M) return;
+    const float* p = probs + (int64_t)r * ldp;
+    for (int j = 0; j < Y; ++j) {
+        const float lp = logf(p[j]);
+        float v = 0.f;
+        if (c_logp && labels[r] == j) v += c_logp[r] / p[j];
+        if (g_kl) v += g_kl[(int64_t)r * ldg + j] * (lp - logf(prior[(int64_t)r * ldpr + j]) + 1.f);
+        if (c_ent) v -= c_ent[r] * (lp + 1.f);
+        float* o = dprobs + (int64_t)r * lddp + j;
+        *o = (beta != 0.f ? beta * *o : 0.f) + v;
+    }
+}
+
+// ------------------------------------------------------------- y-marginalisation
+__global__ void ymarg_fwd_kernel(const float* __restrict__ qy, int64_t ldq, const int32_t* __restrict__ label,
+                                 const int32_t* __restrict__ fp_ptr, const float* __restrict__ klfp,
+                                 float log_prior, int R, int Y, float* __restrict__ yl, float* __restrict__ kld) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const float* q = qy + (int64_t)r * ldq;
+    const int f0 = fp_ptr[r], nf = fp_ptr[r + 1] - f0;
+    if (nf == 1) {
+        yl[r] = logf(q[label[r]]);
+        kld[r] = klfp[f0];
+    } else {
+        float a = 0.f, b = 0.f;
+        for (int j = 0; j < Y; ++j) {
+            a += q[j] * klfp[f0 + j];
+            b += -q[j] * (log_prior - logf(q[j]));
+        }
+        yl[r] = 0.f;
+        kld[r] = a + b;
+    }
+}
+
+__global__ void ymarg_bwd_kernel(const float* __restrict__ qy, int64_t ldq, const int32_t* __restrict__ label,
+                                 const int32_t* __restrict__ fp_ptr, const float* __restrict__ klfp,
+                                 float log_prior, const float* __restrict__ c_kld, const float* __restrict__ c_yl,
+                                 int R, int Y, float* __restrict__ cfp, float* __restrict__ dqy, int64_t lddq) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const float* q = qy + (int64_t)r * ldq;
+    float* dq = dqy + (int64_t)r * lddq;
+    const int f0 = fp_ptr[r], nf = fp_ptr[r + 1] - f0;
+    const float ck = c_kld[r];
+    if (nf == 1) {
+        const int lab = label[r];
+        for (int j = 0; j < Y; ++j) dq[j] = (j == lab) ? c_yl[r] / q[j] : 0.f;
+        cfp[f0] = ck;
+    } else {
+        for (int j = 0; j < Y; ++j) {
+            cfp[f0 + j] = ck * q[j];
+            dq[j] = ck * (klfp[f0 + j] + logf(q[j]) - log_prior + 1.f);
+        }
+    }
+}
+
+// ---------------------------------------------------------------- row movement
+__global__ void rows_gather_kernel(const float* __restrict__ src, int64_t lds, const int32_t* __restrict__ idx,
+                                   int n, int W, const float* __restrict__ noise, int64_t ldn, float sigma,
+                                   const int32_t* __restrict__ onehot_cls, int Y, float* __restrict__ out,
+                                   int64_t ldo) {
+    const int WT = W + (onehot_cls ? Y : 0);
+    const int64_t total = (int64_t)n * WT;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int r = (int)(e / WT), d = (int)(e % WT);
+        float v;
+        if (d < W) {
+            v = src[(int64_t)(idx ? idx[r] : r) * lds + d];
+            if (noise) v += sigma * noise[(int64_t)r * ldn + d];
+        } else {
+            v = (d - W) == onehot_cls[r] ? 1.f : 0.f;
+        }
+        out[(int64_t)r * ldo + d] = v;
+    }
+}
+
+__global__ void rows_segment_sum_kernel(const float* __restrict__ src, int64_t lds,
+                                        const int32_t* __restrict__ seg_ptr, const int32_t* __restrict__ seg_rows,
+                                        const float* __restrict__ w, int n, int W,
+                                        const int32_t* __restrict__ dst_idx, float* __restrict__ dst, int64_t ldd,
+                                        float beta) {
+    const int64_t total = (int64_t)n * W;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int i = (int)(e / W), d = (int)(e % W);
+        float s = 0.f;
+        if (seg_ptr) {
+            for (int t = seg_ptr[i]; t < seg_ptr[i + 1]; ++t)
+                s += (w ? w[t] : 1.f) * src[(int64_t)(seg_rows ? seg_rows[t] : t) * lds + d];
+        } else {
+            s = (w ? w[i] : 1.f) * src[(int64_t)(seg_rows ? seg_rows[i] : i) * lds + d];
+        }
+        float* o = dst + (int64_t)(dst_idx ? dst_idx[i] : i) * ldd + d;
+        *o = (beta != 0.f ? beta * *o : 0.f) + s;
+    }
+}
+
+__global__ __launch_bounds__(256) void weighted_sum_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           const int32_t* __restrict__ idx, int n, float scale,
+                                                           float* __restrict__ out, float beta) {
+    __shared__ float part[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += (w ? w[i] : 1.f) * x[idx ? idx[i] : i];
+    s = dv_wave_sum_all(s);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        s = (part[0] + part[1]) + (part[2] + part[3]);
+        out[0] = (beta != 0.f ? beta * out[0] : 0.f) + scale * s;
+    }
+}
+
+__global__ void axpby_kernel(const float* __restrict__ x, float a, float* __restrict__ y, float b, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        y[i] = a * x[i] + (b != 0.f ? b * y[i] : 0.f);
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+#define ST(s) static_cast<hipStream_t>(s)
+
+extern "C" int dv_colsum(const float* X, int64_t ldx, int32_t M, int32_t N, float* out, float beta,
+                         dv_stream_t stream) {
+    DV_REQUIRE(M >= 0 && N >= 0);
+    if (N == 0) return DV_OK;
+    DV_REQUIRE(X && out);
+    hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64), dim3(256), 0, ST(stream), X, ldx, M, N, out, beta);
+    DV_RETURN_LAUNCH();
+}
+
+extern "C" int dv_act_bwd(float* dY, int64_t ldd, const float* Y, int64_t ldy, int32_t M, int32_t N, int32_t split,
+                          int32_t act0, int32_t act1, float shift0, float shift1, dv_stream_t stream) {
+    DV_REQUIRE(M >= 0 && N >= 0);
+    if (M == 0 || N == 0) return DV_OK;
+    DV_REQUIRE(dY && Y);
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for((int64_t)M * N, 256)), dim3(256), 0, ST(stream), dY, ldd, Y,
+                       ldy, M, N, split, act0, act1, shift0, shift1);
+    DV_RETURN_LAUNCH();
+}
+
+extern "C" int dv_wn_scale(const float* W, int64_t ldw, const float* g, int32_t N, int32_t K, float* scale,
+                           float* norm, dv_stream_t stream) {
+    DV_REQUIRE(N >= 0 && K >= 0);
+    if (N == 0) return DV_OK;
+    DV_REQUIRE(W && g && scale);
+    hipLaunchKernelGGL(wn_scale_kernel, dim3((N + 3) / 4), dim3(256), 0, ST(stream), W, ldw, g, N, K, scale, norm);
+    DV_RETURN_LAUNCH();
+}
+
+extern "C" int dv_wn_bwd(const float* dWraw, int64_t ldr, const float* W, int64_t ldw, const float* g,
+                         const float* norm, int32_t N, int32_t K, float* dW, int64_t ldd, float* dg, float beta,
+                         dv_stream_t stream) {
+    DV_REQUIRE(N >= 0 && K >= 0);
+    if (N == 0) return DV_OK;
+    DV_REQUIRE(dWraw && W && g && norm && dW && dg);
+    hipLaunchKernelGGL(wn_bwd_kernel, dim3((N + 3) / 4), dim3(256), 0, ST(stream), dWraw, ldr, W, ldw, g, norm, N,
+                       K, dW, ldd, dg, beta);
+    DV_RETURN_LAUNCH();
+}
+
+extern "C" int dv_reparam_fwd(const float* mu, const float* sd, int64_t ldq, const int32_t* src_idx, int32_t n,
+                              int32_t reps, int32_t Z, const float* eps, int64_t lde, int32_t mode, float* out,
+                              int64_t ldo, const float* sub, int64_t lds, float* out2, int64_t ldo2,
+                              dv_stream_t stream) {
+    DV_REQUIRE(n >= 0 && reps >= 0 && Z >= 0);
+    if (n == 0 || reps == 0 || Z == 0) return DV_OK;
+    DV_REQUIRE(mu && sd && eps && out);
+    DV_REQUIRE(out2 == nullptr || sub != nullptr);
+    hipLaunchKernelGGL(reparam_fwd_kernel, dim3(grid_for((int64_t)n * reps * Z, 256)), dim3(256), 0, ST(stream), mu,
+                       sd, ldq, src_idx, n, reps, Z, eps, lde, mode, out, ldo, sub, lds, out2, ldo2);
+    DV_RETURN_LAUNCH();
+}
+
+extern "C" int dv_reparam_bwd(const float* dz, int64_t ldz, const float* eps, int64_t lde, const float* sd,
+                              int64_t ldq, const int32_t* src_idx, int32_t n, int32_t reps, int32_t Z, int32_t mode,
+                              float* dmu, float* dsd, int64_t lddq, float beta, dv_stream_t stream) {
+    DV_REQUIRE(n >= 0 && reps >= 0 && Z >= 0);
+    if (n == 0 || Z == 0) return DV_OK;
+    DV_REQUIRE(dz && eps && sd && dmu && dsd);
+    hipLaunchKernelGGL(reparam_bwd_kernel, dim3(grid_for((int64_t)n * Z, 256)), dim3(256), 0, ST(stream), dz, ldz,
+                       eps, lde, sd, ldq, src_idx, n, reps, Z, mode, dmu, dsd, lddq, beta);
+    DV_RETURN_LAUNCH();
+}
+
+extern "C" int dv_kl_rows_fwd(const float* mu_q, const float* sd_q, int64_t ldq, const int32_t* qidx,
+                              const float* mu_p, const float* sd_p, int64_t ldp, const int32_t* pidx,
+                              float prior_mu, float prior_sd, int32_t n, int32_t reps, int32_t Z, int32_t mode,
+                              int32_t free_bits, float kl_min, float* raw_out, float* out, dv_stream_t stream) {
+    DV_REQUIRE(n >= 0 && reps >= 0 && Z >= 0);
+    if (n == 0 || reps == 0) return DV_OK;
+    DV_REQUIRE(mu_q && sd_q && out);
+    DV_REQUIRE((mu_p == nullptr) == (sd_p == nullptr));
+    KlArgs a{mu_q, sd_q, ldq, qidx, mu_p, sd_p, ldp, pidx, prior_mu, prior_sd, n, reps, Z, mode};
+    hipLaunchKernelGGL(kl_rows_fwd_kernel, dim3(grid_for((int64_t)n * reps, 4)), dim3(256), 0, ST(stream), a,
+                       free_bits, kl_min, raw_out, out);
+    DV_RETURN_LAUNCH();
+}
+
+extern "C" int dv_kl_rows_bwd(const float* coef, const float* raw, int32_t free_bits, float kl_min,
+                              const float* mu_q, const float* sd_q, int64_t ldq, const int32_t* qidx,
+                              const float* mu_p, const float* sd_p, int64_t ldp, const int32_t* pidx,
+                              float prior_mu, float prior_sd, int32_t n, int32_t reps, int32_t Z, int32_t mode,
+                              float* dq_mu, float* dq_sd, int64_t lddq, float* dp_mu, float* dp_sd, int64_t lddp,
+                              float beta, dv_stream_t stream) {
+    DV_REQUIRE(n >= 0 && reps >= 0 && Z >= 0);
+    if (n == 0 || reps == 0 || Z == 0) return DV_OK;
+    DV_REQUIRE(coef && mu_q && sd_q && dq_mu && dq_sd);
+    DV_REQUIRE(!free_bits || raw != nullptr);
+    DV_REQUIRE((mu_p == nullptr) == (sd_p == nullptr));
+    DV_REQUIRE((dp_mu == nullptr) == (dp_sd == nullptr));
+    DV_REQUIRE(dp_mu == nullptr || mu_p != nullptr);
+    KlArgs a{mu_q, sd_q, ldq, qidx, mu_p, sd_p, ldp, pidx, prior_mu, prior_sd, n, reps, Z, mode};
+    hipLaunchKernelGGL(kl_rows_bwd_kernel, dim3(grid_for((int64_t)n * reps * Z, 256)), dim3(256), 0, ST(stream), a,
+                       coef, raw, free_bits, kl_min, dq_mu, dq_sd, lddq, dp_mu, dp_sd, lddp, beta);
+    DV_RETURN_LAUNCH();
+}
+
+extern "C" int dv_gauss_nll_rows_fwd(const float* x, int64_t ldx, const int32_t* xidx, const float* mu,
+                                     const float* sd, int64_t ldp, int32_t M, int32_t X, int32_t mode, float* out,
+                                     dv_stream_t stream) {
+    DV_REQUIRE(M >= 0 && X >= 0);
+    if (M == 0) return DV_OK;
+    DV_REQUIRE(x && mu && sd && out);
+    const bool v4 = aligned16(x) && aligned16(mu) && aligned16(sd) && (ldx % 4 == 0) && (ldp % 4 == 0);
+    const dim3 grid(grid_for(M, 4, 8192)), block(256);
+    if (v4)
+        hipLaunchKernelGGL(nll_rows_fwd_kernel<true>, grid, block, 0, ST(stream), x, ldx, xidx, mu, sd, ldp, M, X,
+                           mode, out);
+    else
+        hipLaunchKernelGGL(nll_rows_fwd_kernel<false>, grid, block, 0, ST(stream), x, ldx, xidx, mu, sd, ldp, M, X,
+                           mode, out);
+    DV_RETURN_LAUNCH();
+}
+
+extern "C" int dv_gauss_nll_rows_bwd(const float* coef, const float* x, int64_t ldx, const int32_t* xidx,
+                                     const float* mu, const float* sd, int64_t ldp, int32_t M, int32_t X,
+                                     int32_t mode, int32_t sd_act, float sd_shift, float* dmu, float* dsd,
+                                     int64_t ldd, float* dx, int64_t lddx, float beta, dv_stream_t stream) {
+    DV_REQUIRE(M >= 0 && X >= 0);
+    if (M == 0 || X == 0) return DV_OK;
+    DV_REQUIRE(coef && x && mu && sd && dmu && dsd);
+    hipLaunchKernelGGL(nll_rows_bwd_kernel, dim3(grid_for((int64_t)M * X, 256, 8192)), dim3(256), 0, ST(stream),
+                       coef, x, ldx, xidx, mu, sd, ldp, M, X, mode, sd_act, sd_shift, dmu, dsd, ldd, dx, lddx, beta);
+    DV_RETURN_LAUNCH();
+}
+
+extern "C" int dv_softmax_clamp_fwd(const float* logits, int64_t ldl, int32_t M, int32_t Y, int32_t sigmoid1,
+                                    float* probs, int64_t ldp, dv_stream_t stream) {
+    DV_REQUIRE(M >= 0 && Y >= 1);
+    if (M == 0) return DV_OK;
+    DV_REQUIRE(logits && probs);
+    DV_REQUIRE(!sigmoid1 || Y == 2);
+    hipLaunchKernelGGL(softmax_clamp_fwd_kernel, dim3((M + 255) / 256), dim3(256), 0, ST(stream), logits, ldl, M, Y,
+                       sigmoid1, probs, ldp);
+    DV_RETURN_LAUNCH();
+}
+
+extern "C" int dv_softmax_clamp_bwd(const float* dprobs, int64_t lddp, const float* probs, int64_t ldp, int32_t M,
+                                    int32_t Y, int32_t sigmoid1, float* dlogits, int64_t ldl, float beta,
+                                    dv_stream_t stream) {
+    DV_REQUIRE(M >= 0 && Y >= 1);
+    if (M == 0) return DV_OK;
+    DV_REQUIRE(dprobs && probs && dlogits);
+    DV_REQUIRE(!sigmoid1 || Y == 2);
+    hipLaunchKernelGGL(softmax_clamp_bwd_kernel, dim3((M + 255) / 256), dim3(256), 0, ST(stream), dprobs, lddp,
+                       probs, ldp, M, Y, sigmoid1, dlogits, ldl, beta);
+    DV_RETURN_LAUNCH();
+}
+
+extern "C" int dv_cat_terms_fwd(const float* probs, int64_t ldp, int32_t M, int32_t Y, const int32_t* labels,
+                                const float* prior, int64_t ldpr, float* logp, float* kl, int64_t ldk, float* ent,
+                                int32_t* best, dv_stream_t stream) {
+    DV_REQUIRE(M >= 0 && Y >= 1);
+    if (M == 0) return DV_OK;
+    DV_REQUIRE(probs);
+    DV_REQUIRE(logp == nullptr || labels != nullptr);
+    DV_REQUIRE(kl == nullptr || prior != nullptr);
+    hipLaunchKernelGGL(cat_terms_fwd_kernel, dim3((M + 255) / 256), dim3(256), 0, ST(stream), probs, ldp, M, Y,
+                       labels, prior, ldpr, logp, kl, ldk, ent, best);
+    DV_RETURN_LAUNCH();
+}
+
+extern "C" int dv_cat_terms_bwd(const float* probs, int64_t ldp, int32_t M, int32_t Y, const int32_t* labels,
+                                const float* prior, int64_t ldpr, const float* c_logp, const float* g_kl,
+                                int64_t ldg, const float* c_ent, float* dprobs, int64_t lddp, float beta,
+                                dv_stream_t stream) {
+    DV_REQUIRE(M >= 0 && Y >= 1);
+    if (M == 0) return DV_OK;
+    DV_REQUIRE(probs && dprobs);
+    DV_REQUIRE(c_logp == nullptr || labels != nullptr);
+    DV_REQUIRE(g_kl == nullptr || prior != nullptr);
+    hipLaunchKernelGGL(cat_terms_bwd_kernel, dim3((M + 255) / 256), dim3(256), 0, ST(stream), probs, ldp, M, Y,
+                       labels, prior, ldpr, c_logp, g_kl, ldg, c_ent, dprobs, lddp, beta);
+    DV_RETURN_LAUNCH();
+}
+
+extern "C" int dv_ymarg_fwd(const float* qy, int64_t ldq, const int32_t* label, const int32_t* fp_ptr,
+                            const float* klfp, float log_prior, int32_t R, int32_t Y, float* yl, float* kld,
+                            dv_stream_t stream) {
+    DV_REQUIRE(R >= 0 && Y >= 1);
+    if (R == 0) return DV_OK;
+    DV_REQUIRE(qy && label && fp_ptr && klfp && yl && kld);
+    hipLaunchKernelGGL(ymarg_fwd_kernel, dim3((R + 255) / 256), dim3(256), 0, ST(stream), qy, ldq, label, fp_ptr,
+                       klfp, log_prior, R, Y, yl, kld);
+    DV_RETURN_LAUNCH();
+}
+
+extern "C" int dv_ymarg_bwd(const float* qy, int64_t ldq, const int32_t* label, const int32_t* fp_ptr,
+                            const float* klfp, float log_prior, const float* c_kld, const float* c_yl, int32_t R,
+                            int32_t Y, float* cfp, float* dqy, int64_t lddq, dv_stream_t stream) {
+    DV_REQUIRE(R >= 0 && Y >= 1);
+    if (R == 0) return DV_OK;
+    DV_REQUIRE(qy && label && fp_ptr && klfp && c_kld && c_yl && cfp && dqy);
+    hipLaunchKernelGGL(ymarg_bwd_kernel, dim3((R + 255) / 256), dim3(256), 0, ST(stream), qy, ldq, label, fp_ptr,
+                       klfp, log_prior, c_kld, c_yl, R, Y, cfp, dqy, lddq);
+    DV_RETURN_LAUNCH();
+}
+
+extern "C" int dv_rows_gather(const float* src, int64_t lds, const int32_t* idx, int32_t n, int32_t W,
+                              const float* noise, int64_t ldn, float sigma, const int32_t* onehot_cls, int32_t Y,
+                              float* out, int64_t ldo, dv_stream_t stream) {
+    DV_REQUIRE(n >= 0 && W >= 0 && Y >= 0);
+    if (n == 0) return DV_OK;
+    DV_REQUIRE(out && (src || W == 0));
+    const int64_t total = (int64_t)n * (W + (onehot_cls ? Y : 0));
+    if (total == 0) return DV_OK;
+    hipLaunchKernelGGL(rows_gather_kernel, dim3(grid_for(total, 256)), dim3(256), 0, ST(stream), src, lds, idx, n,
+                       W, noise, ldn, sigma, onehot_cls, Y, out, ldo);
+    DV_RETURN_LAUNCH();
+}
+
+extern "C" int dv_rows_segment_sum(const float* src, int64_t lds, const int32_t* seg_ptr, const int32_t* seg_rows,
+                                   const float* w, int32_t n, int32_t W, const int32_t* dst_idx, float* dst,
+                                   int64_t ldd, float beta, dv_stream_t stream) {
+    DV_REQUIRE(n >= 0 && W >= 0);
+    if (n == 0 || W == 0) return DV_OK;
+    DV_REQUIRE(src && dst);
+    hipLaunchKernelGGL(rows_segment_sum_kernel, dim3(grid_for((int64_t)n * W, 256)), dim3(256), 0, ST(stream), src,
+                       lds, seg_ptr, seg_rows, w, n, W, dst_idx, dst, ldd, beta);
+    DV_RETURN_LAUNCH();
+}
+
+extern "C" int dv_weighted_sum(const float* x, const float* w, const int32_t* idx, int32_t n, float scale,
+                               float* out, float beta, dv_stream_t stream) {
+    DV_REQUIRE(n >= 0 && out);
+    DV_REQUIRE(n == 0 || x);
+    hipLaunchKernelGGL(weighted_sum_kernel, dim3(1), dim3(256), 0, ST(stream), x, w, idx, n, scale, out, beta);
+    DV_RETURN_LAUNCH();
+}
+
+extern "C" int dv_axpby(const float* x, float a, float* y, float b, int64_t n, dv_stream_t stream) {
+    DV_REQUIRE(n >= 0);
+    if (n == 0) return DV_OK;
+    DV_REQUIRE(x && y);
+    hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ST(stream), x, a, y, b, n);
+    DV_RETURN_LAUNCH();
+}

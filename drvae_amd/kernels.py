@@ -1,0 +1,280 @@
+"""Tensor-level launchers for the C-ABI kernels (device fp32 tensors in, enqueue on the
+current HIP stream, nothing returned that needs a sync).
+
+Every function writes into caller-provided output tensors (``out=``-style), so the
+callers own all memory and the sequence is hipGraph-capturable.  2-D tensors may be
+row-strided views (``stride(1) == 1``); the row stride is passed as the leading
+dimension.  There is no CPU path here: tensors must live on the GPU.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import ACT, EPI_BWD, EPI_FWD, EPI_PLAIN, GAUSS_LOGVAR, GAUSS_SIGMA, GemmDesc  # noqa: F401
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _f32(t, name='tensor'):
+    if t is None:
+        return None
+    if not (t.is_cuda and t.dtype == torch.float32):
+        raise RuntimeError('drvae_amd kernels need CUDA/HIP float32 tensors (%s is %s on %s); there is no CPU '
+                           'fallback' % (name, t.dtype, t.device))
+    if t.dim() >= 1 and t.numel() > 0 and t.stride(-1) != 1 and t.size(-1) != 1:
+        raise RuntimeError('%s must have unit inner stride' % name)
+    return t.data_ptr()
+
+
+def _i32(t, name='index'):
+    if t is None:
+        return None
+    if not (t.is_cuda and t.dtype == torch.int32 and t.is_contiguous()):
+        raise RuntimeError('%s must be a contiguous CUDA int32 tensor' % name)
+    return t.data_ptr()
+
+
+def _ld(t):
+    if t is None:
+        return 0
+    if t.dim() == 1:
+        return t.numel()
+    return t.stride(0) if t.size(0) > 1 else max(t.stride(0), t.size(1))
+
+
+def _act(a):
+    return ACT[a] if isinstance(a, str) else int(a)
+
+
+# ------------------------------------------------------------------------------ GEMM
+def gemm(Cm, A, B, a_kc, b_kc, *, A2=None, a_kscale=None, alpha=1.0, beta=0.0, epi=EPI_PLAIN, scale=None,
+         bias=None, split=None, act0=0, act1=0, shift0=0.0, shift1=0.0, resid=None, resid_cols=0, yref=None,
+         a_colsum=None, colsum_beta=0.0):
+    """C[M,N] = epilogue(alpha * Aop @ Bop) + beta*C, see ``dv_gemm`` in include/drvae_hip.h."""
+    M, N = Cm.shape
+    if a_kc:
+        K = A.shape[1] + (A2.shape[1] if A2 is not None else 0)
+        assert A.shape[0] == M
+    else:
+        K = A.shape[0]
+        assert A.shape[1] == M and A2 is None
+    if b_kc:
+        assert tuple(B.shape) == (N, K), (tuple(B.shape), N, K)
+    else:
+        assert tuple(B.shape) == (K, N), (tuple(B.shape), K, N)
+    d = GemmDesc()
+    d.M, d.N, d.K, d.a_kcontig, d.b_kcontig = M, N, K, int(bool(a_kc)), int(bool(b_kc))
+    d.A, d.lda = _f32(A, 'A'), _ld(A)
+    d.A2, d.lda2, d.K1 = _f32(A2, 'A2'), _ld(A2), (A.shape[1] if A2 is not None else K)
+    d.a_kscale = _f32(a_kscale, 'a_kscale')
+    d.B, d.ldb = _f32(B, 'B'), _ld(B)
+    d.C, d.ldc = _f32(Cm, 'C'), _ld(Cm)
+    d.alpha, d.beta, d.epilogue = alpha, beta, epi
+    d.scale, d.bias = _f32(scale, 'scale'), _f32(bias, 'bias')
+    d.split = N if split is None else split
+    d.act0, d.act1, d.shift0, d.shift1 = _act(act0), _act(act1), shift0, shift1
+    d.resid, d.ldr, d.resid_cols = _f32(resid, 'resid'), _ld(resid), resid_cols
+    d.yref, d.ldy = _f32(yref, 'yref'), _ld(yref)
+    d.a_colsum, d.colsum_beta = _f32(a_colsum, 'a_colsum'), colsum_beta
+    _lib.check(_lib.load().dv_gemm(C.byref(d), _stream()), 'dv_gemm')
+
+
+def linear_fwd(out, x, W, bias=None, *, x2=None, scale=None, split=None, act0=0, act1=0, shift0=0.0, shift1=0.0,
+               resid=None, resid_cols=0):
+    """out = act([x|x2] W^T * scale + bias) + shift (+ resid) -- one Linear (or two heads) forward."""
+    gemm(out, x, W, True, True, A2=x2, epi=EPI_FWD, scale=scale, bias=bias, split=split, act0=act0, act1=act1,
+         shift0=shift0, shift1=shift1, resid=resid, resid_cols=resid_cols)
+
+
+def linear_bwd_data(dx, dpre, W, *, kscale=None, alpha=1.0, beta=0.0, yref=None, act=0, shift=0.0):
+    """dx = beta*dx + alpha*((dpre*kscale) W) * act'(yref)   (W may be a column slice view)."""
+    if yref is None:
+        gemm(dx, dpre, W, True, False, a_kscale=kscale, alpha=alpha, beta=beta)
+    else:
+        gemm(dx, dpre, W, True, False, a_kscale=kscale, alpha=alpha, beta=beta, epi=EPI_BWD, yref=yref, act0=act,
+             act1=act, shift0=shift, shift1=shift)
+
+
+def linear_bwd_weight(dW, dpre, x, *, beta=0.0, dbias=None):
+    """dW = beta*dW + dpre^T x ;  dbias = beta*dbias + colsum(dpre) fused in the same launch."""
+    gemm(dW, dpre, x, False, False, beta=beta, a_colsum=dbias, colsum_beta=beta)
+
+
+def colsum(out, X, beta=0.0):
+    M, N = X.shape
+    _lib.check(_lib.load().dv_colsum(_f32(X), _ld(X), M, N, _f32(out), beta, _stream()), 'dv_colsum')
+
+
+def act_bwd_(dY, Y, *, split=None, act0=0, act1=0, shift0=0.0, shift1=0.0):
+    M, N = Y.shape
+    _lib.check(_lib.load().dv_act_bwd(_f32(dY), _ld(dY), _f32(Y), _ld(Y), M, N, N if split is None else split,
+                                      _act(act0), _act(act1), shift0, shift1, _stream()), 'dv_act_bwd')
+
+
+def wn_scale(scale, norm, W, g):
+    N, K = W.shape
+    _lib.check(_lib.load().dv_wn_scale(_f32(W), _ld(W), _f32(g), N, K, _f32(scale), _f32(norm), _stream()),
+               'dv_wn_scale')
+
+
+def wn_bwd(dW, dg, dWraw, W, g, norm, beta=0.0):
+    N, K = W.shape
+    _lib.check(_lib.load().dv_wn_bwd(_f32(dWraw), _ld(dWraw), _f32(W), _ld(W), _f32(g), _f32(norm), N, K, _f32(dW),
+                                     _ld(dW), _f32(dg), beta, _stream()), 'dv_wn_bwd')
+
+
+# --------------------------------------------------------------------------- reparam
+def reparam_fwd(out, mu, sd, eps, *, mode=GAUSS_LOGVAR, src_idx=None, reps=1, sub=None, out2=None):
+    """out[l*n+j] = mu[q] + eps[l*n+j]*std(sd[q]), q = src_idx[j] or j; out2 = out - sub."""
+    R, Z = out.shape
+    n = R // reps
+    assert n * reps == R and eps.shape[0] == R
+    _lib.check(_lib.load().dv_reparam_fwd(_f32(mu), _f32(sd), _ld(mu), _i32(src_idx), n, reps, Z, _f32(eps),
+                                          _ld(eps), mode, _f32(out), _ld(out), _f32(sub), _ld(sub), _f32(out2),
+                                          _ld(out2), _stream()), 'dv_reparam_fwd')
+    assert _ld(mu) == _ld(sd)
+
+
+def reparam_bwd(dmu, dsd, dz, eps, sd, *, mode=GAUSS_LOGVAR, src_idx=None, reps=1, beta=0.0):
+    R, Z = dz.shape
+    n = R // reps
+    assert _ld(dmu) == _ld(dsd)
+    _lib.check(_lib.load().dv_reparam_bwd(_f32(dz), _ld(dz), _f32(eps), _ld(eps), _f32(sd), _ld(sd), _i32(src_idx),
+                                          n, reps, Z, mode, _f32(dmu), _f32(dsd), _ld(dmu), beta, _stream()),
+               'dv_reparam_bwd')
+
+
+# --------------------------------------------------------------------------- KL rows
+def kl_rows_fwd(out, raw, mu_q, sd_q, mu_p=None, sd_p=None, *, prior=(0.0, 0.0), mode=GAUSS_LOGVAR, qidx=None,
+                pidx=None, reps=1, free_bits=False, kl_min=0.0):
+    R = out.numel()
+    n = R // reps
+    Z = mu_q.shape[1]
+    assert _ld(mu_q) == _ld(sd_q) and (mu_p is None or _ld(mu_p) == _ld(sd_p))
+    _lib.check(_lib.load().dv_kl_rows_fwd(_f32(mu_q), _f32(sd_q), _ld(mu_q), _i32(qidx), _f32(mu_p), _f32(sd_p),
+                                          _ld(mu_p), _i32(pidx), prior[0], prior[1], n, reps, Z, mode,
+                                          int(free_bits), kl_min, _f32(raw), _f32(out), _stream()),
+               'dv_kl_rows_fwd')
+
+
+def kl_rows_bwd(dq_mu, dq_sd, dp_mu, dp_sd, coef, raw, mu_q, sd_q, mu_p=None, sd_p=None, *, prior=(0.0, 0.0),
+                mode=GAUSS_LOGVAR, qidx=None, pidx=None, reps=1, free_bits=False, kl_min=0.0, beta=0.0):
+    R = coef.numel()
+    n = R // reps
+    Z = mu_q.shape[1]
+    assert _ld(dq_mu) == _ld(dq_sd) and (dp_mu is None or _ld(dp_mu) == _ld(dp_sd))
+    _lib.check(_lib.load().dv_kl_rows_bwd(_f32(coef), _f32(raw), int(free_bits), kl_min, _f32(mu_q), _f32(sd_q),
+                                          _ld(mu_q), _i32(qidx), _f32(mu_p), _f32(sd_p), _ld(mu_p), _i32(pidx),
+                                          prior[0], prior[1], n, reps, Z, mode, _f32(dq_mu), _f32(dq_sd),
+                                          _ld(dq_mu), _f32(dp_mu), _f32(dp_sd), _ld(dp_mu), beta, _stream()),
+               'dv_kl_rows_bwd')
+
+
+# ------------------------------------------------------------------------- NLL rows
+def nll_rows_fwd(out, x, mu, sd, *, mode=GAUSS_SIGMA, xidx=None):
+    M, X = mu.shape
+    assert _ld(mu) == _ld(sd)
+    _lib.check(_lib.load().dv_gauss_nll_rows_fwd(_f32(x), _ld(x), _i32(xidx), _f32(mu), _f32(sd), _ld(mu), M, X,
+                                                 mode, _f32(out), _stream()), 'dv_gauss_nll_rows_fwd')
+
+
+def nll_rows_bwd(dmu, dsd, coef, x, mu, sd, *, mode=GAUSS_SIGMA, xidx=None, sd_act=0, sd_shift=0.0, dx=None,
+                 beta=0.0):
+    M, X = mu.shape
+    assert _ld(mu) == _ld(sd) and _ld(dmu) == _ld(dsd)
+    _lib.check(_lib.load().dv_gauss_nll_rows_bwd(_f32(coef), _f32(x), _ld(x), _i32(xidx), _f32(mu), _f32(sd),
+                                                 _ld(mu), M, X, mode, _act(sd_act), sd_shift, _f32(dmu), _f32(dsd),
+                                                 _ld(dmu), _f32(dx), _ld(dx), beta, _stream()),
+               'dv_gauss_nll_rows_bwd')
+
+
+# ----------------------------------------------------------------------- categorical
+def softmax_clamp_fwd(probs, logits, sigmoid1=False):
+    M, Y = probs.shape
+    _lib.check(_lib.load().dv_softmax_clamp_fwd(_f32(logits), _ld(logits), M, Y, int(sigmoid1), _f32(probs),
+                                                _ld(probs), _stream()), 'dv_softmax_clamp_fwd')
+
+
+def softmax_clamp_bwd(dlogits, dprobs, probs, sigmoid1=False, beta=0.0):
+    M, Y = probs.shape
+    _lib.check(_lib.load().dv_softmax_clamp_bwd(_f32(dprobs), _ld(dprobs), _f32(probs), _ld(probs), M, Y,
+                                                int(sigmoid1), _f32(dlogits), _ld(dlogits), beta, _stream()),
+               'dv_softmax_clamp_bwd')
+
+
+def cat_terms_fwd(probs, *, labels=None, prior=None, logp=None, kl=None, ent=None, best=None):
+    M, Y = probs.shape
+    _lib.check(_lib.load().dv_cat_terms_fwd(_f32(probs), _ld(probs), M, Y, _i32(labels), _f32(prior), _ld(prior),
+                                            _f32(logp), _f32(kl), _ld(kl), _f32(ent), _i32(best), _stream()),
+               'dv_cat_terms_fwd')
+
+
+def cat_terms_bwd(dprobs, probs, *, labels=None, prior=None, c_logp=None, g_kl=None, c_ent=None, beta=0.0):
+    M, Y = probs.shape
+    _lib.check(_lib.load().dv_cat_terms_bwd(_f32(probs), _ld(probs), M, Y, _i32(labels), _f32(prior), _ld(prior),
+                                            _f32(c_logp), _f32(g_kl), _ld(g_kl), _f32(c_ent), _f32(dprobs),
+                                            _ld(dprobs), beta, _stream()), 'dv_cat_terms_bwd')
+
+
+def ymarg_fwd(yl, kld, qy, label, fp_ptr, klfp, log_prior):
+    R, Y = qy.shape
+    _lib.check(_lib.load().dv_ymarg_fwd(_f32(qy), _ld(qy), _i32(label), _i32(fp_ptr), _f32(klfp), log_prior, R, Y,
+                                        _f32(yl), _f32(kld), _stream()), 'dv_ymarg_fwd')
+
+
+def ymarg_bwd(cfp, dqy, qy, label, fp_ptr, klfp, log_prior, c_kld, c_yl):
+    R, Y = qy.shape
+    _lib.check(_lib.load().dv_ymarg_bwd(_f32(qy), _ld(qy), _i32(label), _i32(fp_ptr), _f32(klfp), log_prior,
+                                        _f32(c_kld), _f32(c_yl), R, Y, _f32(cfp), _f32(dqy), _ld(dqy), _stream()),
+               'dv_ymarg_bwd')
+
+
+# ---------------------------------------------------------------------- row movement
+def rows_gather(out, src, idx=None, *, noise=None, sigma=0.0, onehot_cls=None, n_classes=0, width=None):
+    n = out.shape[0]
+    W = (src.shape[1] if src is not None else 0) if width is None else width
+    _lib.check(_lib.load().dv_rows_gather(_f32(src), _ld(src), _i32(idx), n, W, _f32(noise), _ld(noise), sigma,
+                                          _i32(onehot_cls), n_classes, _f32(out), _ld(out), _stream()),
+               'dv_rows_gather')
+
+
+def rows_segment_sum(dst, src, *, seg_ptr=None, seg_rows=None, w=None, n=None, dst_idx=None, beta=0.0, width=None):
+    if n is None:
+        n = seg_ptr.numel() - 1 if seg_ptr is not None else (seg_rows.numel() if seg_rows is not None else
+                                                              src.shape[0])
+    W = dst.shape[1] if width is None else width
+    _lib.check(_lib.load().dv_rows_segment_sum(_f32(src), _ld(src), _i32(seg_ptr), _i32(seg_rows), _f32(w), n, W,
+                                               _i32(dst_idx), _f32(dst), _ld(dst), beta, _stream()),
+               'dv_rows_segment_sum')
+
+
+def weighted_sum(out, x, w=None, idx=None, scale=1.0, beta=0.0, n=None):
+    if n is None:
+        n = idx.numel() if idx is not None else x.numel()
+    _lib.check(_lib.load().dv_weighted_sum(_f32(x), _f32(w), _i32(idx), n, scale, _f32(out), beta, _stream()),
+               'dv_weighted_sum')
+
+
+def axpby(y, x, a=1.0, b=0.0):
+    assert x.is_contiguous() and y.is_contiguous() and x.numel() == y.numel()
+    _lib.check(_lib.load().dv_axpby(_f32(x), a, _f32(y), b, x.numel(), _stream()), 'dv_axpby')
+
+
+# ------------------------------------------------------------------------- optimiser
+def adam_l2(p, g, m, v, step_dev, *, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, gscale=1.0):
+    assert p.is_contiguous() and g.is_contiguous() and m.is_contiguous() and v.is_contiguous()
+    _lib.check(_lib.load().dv_adam_l2(_f32(p), _f32(g), _f32(m), _f32(v), p.numel(), lr, beta1, beta2, eps,
+                                      weight_decay, gscale, _i32(step_dev), _stream()), 'dv_adam_l2')
+
+
+def counter_add(counter, inc=1):
+    _lib.check(_lib.load().dv_counter_add(_i32(counter), counter.numel(), inc, _stream()), 'dv_counter_add')
+
+
+def fill_normal(out, seed, ctr_dev=None):
+    assert out.is_contiguous()
+    _lib.check(_lib.load().dv_fill_normal(_f32(out), out.numel(), seed, _i32(ctr_dev), _stream()),
+               'dv_fill_normal')

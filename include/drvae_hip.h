@@ -1,0 +1,244 @@
+/* drvae_hip.h -- C-ABI of libdrvae_hip.so: the Dr.VAE ELBO training hot path as
+ * hand-written HIP kernels for gfx950 (MI355X / CDNA4).
+ *
+ * The reference (rampasek/DrVAE, pure Python on PyTorch CPU ATen, no native layer,
+ * no FFI) reaches this arithmetic only through `import blocks as blk` /
+ * `import layers as lyr` (src/DrVAE.py:21, src/blocks.py:12).  The Python modules
+ * `drvae_amd.blocks` / `drvae_amd.layers` mirror that interface and call the entry
+ * points below through ctypes (INTEGRATION.md shows the stub).  Each entry point
+ * cites the reference expression it replaces.
+ *
+ * Conventions
+ *  - plain C: raw DEVICE pointers, int sizes, leading dimensions in ELEMENTS,
+ *    `dv_stream_t` = hipStream_t passed as void*.  No torch types.
+ *  - all matrices fp32 row-major with unit inner stride; index arrays int32.
+ *  - every call only ENQUEUES work on `stream`: no allocation, no host sync, no
+ *    hidden state -> re-entrant and hipGraph-capturable (SURVEY.md 8(b) threading).
+ *  - returns DV_OK (0) or a negative DV_ERR_* code; never throws, never aborts.
+ *  - `beta` arguments: out = beta*out + result (beta == 0 never reads out).
+ */
+#ifndef DRVAE_HIP_H
+#define DRVAE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* dv_stream_t;
+
+#define DV_ABI_VERSION 1
+
+enum { DV_OK = 0, DV_ERR_ARG = -1, DV_ERR_LAUNCH = -2, DV_ERR_UNSUPPORTED = -3 };
+
+/* activation ids -- the `nonlinearities` table of src/blocks.py:21-24 (+ cos for the
+ * random-Fourier MMD features of src/blocks.py:53-54; forward only) */
+enum {
+    DV_ACT_IDENTITY = 0, DV_ACT_ELU = 1, DV_ACT_SOFTPLUS = 2, DV_ACT_SIGMOID = 3, DV_ACT_TANH = 4,
+    DV_ACT_RELU = 5, DV_ACT_LEAKY_RELU = 6, DV_ACT_SELU = 7, DV_ACT_SOFTSIGN = 8, DV_ACT_COS = 9
+};
+
+/* Gaussian parametrisation: GaussianLogVarMixin (src/blocks.py:166-202) or
+ * GaussianSigmaMixin (src/blocks.py:204-240) */
+enum { DV_GAUSS_LOGVAR = 0, DV_GAUSS_SIGMA = 1 };
+
+enum { DV_EPI_PLAIN = 0, DV_EPI_FWD = 1, DV_EPI_BWD = 2 };
+
+int dv_abi_version(void);
+const char* dv_error_string(int code);
+
+/* ------------------------------------------------------------------ GEMM family
+ * C[M,N] = epilogue( alpha * sum_k Aop[m,k] * Bop[k,n] ) + beta*C      (fp32 MFMA,
+ * v_mfma_f32_32x32x2_f32: bit-for-bit an fp32 fma chain -- no reduced precision).
+ *   a_kcontig: Aop[m,k] = A[m*lda + k]   else A[k*lda + m]
+ *   b_kcontig: Bop[k,n] = B[n*ldb + k]   else B[k*ldb + n]
+ * which covers the three products of a Linear layer y = x W^T (+b):
+ *   forward      y  = x  W^T      a_kcontig=1 b_kcontig=1   F.linear, src/layers.py:38,
+ *                                                            nn.Linear in src/blocks.py:144,278-279,396-397,446
+ *   backward dx  dx = dy W        a_kcontig=1 b_kcontig=0   (autograd AddmmBackward in the reference)
+ *   backward dW  dW = dy^T x      a_kcontig=0 b_kcontig=0
+ * A2/K1: optional second A source for k >= K1 -- `torch.cat(inputs, 1)` of
+ *   src/blocks.py:161 without materialising the concat (a_kcontig only).
+ * a_kscale: optional per-k multiplier on Aop (WeightNorm backward: dy * g/||W||).
+ *
+ * epilogue DV_EPI_FWD (per element, col = n):
+ *   v = scale[n]*v (WeightNorm g/||W||, src/layers.py:39-40) + bias[n];
+ *   v = act(v) + shift, with (act0,shift0) for n < split and (act1,shift1) otherwise
+ *       -- dual heads sharing one GEMM: `logvar = lv(h) - 2.` (src/blocks.py:296,360),
+ *          `std = softplus(sg(h)) + 1e-3` (src/blocks.py:401,415);
+ *   v += resid[m*ldr+n] for n < resid_cols  -- `mu = x + F.linear(x,W_mu) + b` (src/blocks.py:357).
+ * epilogue DV_EPI_BWD: v *= act'(yref[m*ldy+n] - shift) with the same (split, act, shift)
+ *   selection: the activation backward of the layer BELOW fused into the dx GEMM.
+ */
+typedef struct dv_gemm_desc {
+    int32_t M, N, K;
+    int32_t a_kcontig, b_kcontig;
+    const float* A;
+    int64_t lda;
+    const float* A2;
+    int64_t lda2;
+    int32_t K1;
+    const float* a_kscale;
+    const float* B;
+    int64_t ldb;
+    float* C;
+    int64_t ldc;
+    float alpha, beta;
+    int32_t epilogue;
+    const float* scale;
+    const float* bias;
+    int32_t split;
+    int32_t act0, act1;
+    float shift0, shift1;
+    const float* resid;
+    int64_t ldr;
+    int32_t resid_cols;
+    const float* yref;
+    int64_t ldy;
+    /* optional fused bias gradient (a_kcontig == 0 only, i.e. the dW product where
+     * Aop[m,k] = dy[k, m]):  a_colsum[m] = colsum_beta*a_colsum[m] + sum_k Aop[m,k]
+     * -- `db = dy.sum(0)` computed from the dy tiles the dW GEMM stages anyway. */
+    float* a_colsum;
+    float colsum_beta;
+} dv_gemm_desc;
+
+int dv_gemm(const dv_gemm_desc* desc, dv_stream_t stream);
+/* test/tuning hook: 0 = heuristic tiling, 1 = 64x64, 2 = 32x32 K-split, 3 = 128x128 */
+int dv_gemm_force_tiling(int tiling);
+
+/* out[n] = beta*out[n] + sum_m X[m*ldx+n]            (bias gradient) */
+int dv_colsum(const float* X, int64_t ldx, int32_t M, int32_t N, float* out, float beta, dv_stream_t stream);
+
+/* dY[m,n] *= act'(Y[m,n]-shift), (act,shift) chosen by n<split as in DV_EPI_FWD */
+int dv_act_bwd(float* dY, int64_t ldd, const float* Y, int64_t ldy, int32_t M, int32_t N, int32_t split,
+               int32_t act0, int32_t act1, float shift0, float shift1, dv_stream_t stream);
+
+/* WeightNorm (src/layers.py:39): norm[n] = ||W[n,:]||_2, scale[n] = g[n]/norm[n] */
+int dv_wn_scale(const float* W, int64_t ldw, const float* g, int32_t N, int32_t K, float* scale, float* norm,
+                dv_stream_t stream);
+/* WeightNorm backward from dWraw = dpre^T x (dpre NOT yet multiplied by scale):
+ *   dot = <W[n,:], dWraw[n,:]>;  dg[n] = beta*dg[n] + dot/norm[n]
+ *   dW[n,k] = beta*dW[n,k] + scale[n]*dWraw[n,k] - dot*g[n]/norm[n]^3 * W[n,k] */
+int dv_wn_bwd(const float* dWraw, int64_t ldr, const float* W, int64_t ldw, const float* g, const float* norm,
+              int32_t N, int32_t K, float* dW, int64_t ldd, float* dg, float beta, dv_stream_t stream);
+
+/* ------------------------------------------------------- reparameterisation (K3)
+ * out row r = l*n + j (l < reps, j < n) samples from q row qi = src_idx ? src_idx[j] : j:
+ *   out[r,d] = mu[qi,d] + eps[r,d] * (mode==LOGVAR ? exp(0.5*sd[qi,d]) : sd[qi,d])
+ * (src/blocks.py:170-174, 208-211; eps is explicit so parity tests can inject it).
+ * Optional out2[r,d] = out[r,d] - sub[r,d]   (`z2Fz1_sample - z1_sample`, src/DrVAE.py:495).
+ * backward: dmu[qi] = beta*dmu[qi] + sum_l dz[l*n+j]; dsd likewise with the chain factor. */
+int dv_reparam_fwd(const float* mu, const float* sd, int64_t ldq, const int32_t* src_idx, int32_t n, int32_t reps,
+                   int32_t Z, const float* eps, int64_t lde, int32_t mode, float* out, int64_t ldo,
+                   const float* sub, int64_t lds, float* out2, int64_t ldo2, dv_stream_t stream);
+int dv_reparam_bwd(const float* dz, int64_t ldz, const float* eps, int64_t lde, const float* sd, int64_t ldq,
+                   const int32_t* src_idx, int32_t n, int32_t reps, int32_t Z, int32_t mode, float* dmu, float* dsd,
+                   int64_t lddq, float beta, dv_stream_t stream);
+
+/* ------------------------------------------------ diagonal-Gaussian KL per row (K4)
+ * row r = l*n + j: q row = qidx ? qidx[j] : j ; p row = pidx ? pidx[r] : r, or the
+ * scalar prior (prior_mu, prior_sd) when mu_p == NULL (prior_sd is a log-variance in
+ * LOGVAR mode, a std in SIGMA mode).
+ *   LOGVAR: raw = -1/2 sum_d [1 - lv_p + lv_q - ((mu_q-mu_p)^2 + e^lv_q)/e^lv_p]   src/blocks.py:180-182
+ *   SIGMA : same with log(std^2), std^2                                              src/blocks.py:217-220
+ *   out = free_bits ? max(raw, kl_min) : raw      (per-ROW free bits, src/DGMMixin.py:68-75)
+ * backward: coef[r] = dLoss/d out[r]; gradients are written ROW-ALIGNED (row r of
+ * dq_* / dp_*); callers reduce duplicates with dv_rows_segment_sum. */
+int dv_kl_rows_fwd(const float* mu_q, const float* sd_q, int64_t ldq, const int32_t* qidx, const float* mu_p,
+                   const float* sd_p, int64_t ldp, const int32_t* pidx, float prior_mu, float prior_sd, int32_t n,
+                   int32_t reps, int32_t Z, int32_t mode, int32_t free_bits, float kl_min, float* raw_out,
+                   float* out, dv_stream_t stream);
+int dv_kl_rows_bwd(const float* coef, const float* raw, int32_t free_bits, float kl_min, const float* mu_q,
+                   const float* sd_q, int64_t ldq, const int32_t* qidx, const float* mu_p, const float* sd_p,
+                   int64_t ldp, const int32_t* pidx, float prior_mu, float prior_sd, int32_t n, int32_t reps,
+                   int32_t Z, int32_t mode, float* dq_mu, float* dq_sd, int64_t lddq, float* dp_mu, float* dp_sd,
+                   int64_t lddp, float beta, dv_stream_t stream);
+
+/* ------------------------------------- Gaussian log-likelihood over genes per row (K5)
+ * out[r] = -1/2 sum_g [log 2pi + log var + (x-mu)^2/var], x row = xidx ? xidx[r] : r
+ *   SIGMA : var = sd^2  (src/blocks.py:233-234, the reconstruction term of src/DrVAE.py:442,452,460)
+ *   LOGVAR: var = e^sd  (src/blocks.py:195-196)
+ * backward: coef[r] = dLoss/d out[r]; writes d/dmu and d/d(sd) -- the latter chained
+ * through sd = sd_act(pre) + sd_shift when sd_act != IDENTITY, i.e. directly the
+ * gradient w.r.t. the head's pre-activation (src/blocks.py:415).  dx optional. */
+int dv_gauss_nll_rows_fwd(const float* x, int64_t ldx, const int32_t* xidx, const float* mu, const float* sd,
+                          int64_t ldp, int32_t M, int32_t X, int32_t mode, float* out, dv_stream_t stream);
+int dv_gauss_nll_rows_bwd(const float* coef, const float* x, int64_t ldx, const int32_t* xidx, const float* mu,
+                          const float* sd, int64_t ldp, int32_t M, int32_t X, int32_t mode, int32_t sd_act,
+                          float sd_shift, float* dmu, float* dsd, int64_t ldd, float* dx, int64_t lddx, float beta,
+                          dv_stream_t stream);
+
+/* --------------------------------------------------------- categorical head (K6/K7)
+ * probs = clamp(softmax(logits), 1e-10, 1-1e-10)   (src/blocks.py:446-463); with
+ * sigmoid1 != 0 logits is (M,1) and probs = clamp(cat(1-s, s)) (src/blocks.py:448-451,461-462). */
+int dv_softmax_clamp_fwd(const float* logits, int64_t ldl, int32_t M, int32_t Y, int32_t sigmoid1, float* probs,
+                         int64_t ldp, dv_stream_t stream);
+int dv_softmax_clamp_bwd(const float* dprobs, int64_t lddp, const float* probs, int64_t ldp, int32_t M, int32_t Y,
+                         int32_t sigmoid1, float* dlogits, int64_t ldl, float beta, dv_stream_t stream);
+/* per-row terms of a categorical q (any may be NULL):
+ *   logp[r]   = log probs[r, labels[r]]                               src/blocks.py:473-474
+ *   kl[r,j]   = -p (log prior[r,j] - log p)   (elementwise)           src/blocks.py:479-480
+ *   ent[r]    = -sum_j p log p                                        src/blocks.py:476-477
+ *   best[r]   = argmax_j p                                            src/blocks.py:485-486 */
+int dv_cat_terms_fwd(const float* probs, int64_t ldp, int32_t M, int32_t Y, const int32_t* labels,
+                     const float* prior, int64_t ldpr, float* logp, float* kl, int64_t ldk, float* ent,
+                     int32_t* best, dv_stream_t stream);
+/* dprobs[r,j] = beta*dprobs + c_logp[r]*[j==label]/p + g_kl[r,j]*(log p - log prior + 1) - c_ent[r]*(log p + 1) */
+int dv_cat_terms_bwd(const float* probs, int64_t ldp, int32_t M, int32_t Y, const int32_t* labels,
+                     const float* prior, int64_t ldpr, const float* c_logp, const float* g_kl, int64_t ldg,
+                     const float* c_ent, float* dprobs, int64_t lddp, float beta, dv_stream_t stream);
+
+/* y-marginalisation of src/DrVAE.py:503-534 / src/VFAE.py:331-390 over the stacked
+ * "fprop" rows.  For every (l, i) classifier row r (R rows):
+ *   labeled   (fp_ptr[r+1]-fp_ptr[r] == 1): yl[r] = log qy[r, label[r]]; kld[r] = klfp[fp row]
+ *   unlabeled (== Y fp rows, class j at fp_ptr[r]+j): yl[r] = 0;
+ *       kld[r] = sum_j qy[r,j]*klfp[fp_ptr[r]+j] + sum_j qy[r,j](log qy[r,j] - log prior_j)
+ * backward: c_kld[r], c_yl[r] are dLoss/d kld[r], d yl[r]; writes cfp[fp row] = dLoss/d klfp
+ * and dqy (R,Y). */
+int dv_ymarg_fwd(const float* qy, int64_t ldq, const int32_t* label, const int32_t* fp_ptr, const float* klfp,
+                 float log_prior, int32_t R, int32_t Y, float* yl, float* kld, dv_stream_t stream);
+int dv_ymarg_bwd(const float* qy, int64_t ldq, const int32_t* label, const int32_t* fp_ptr, const float* klfp,
+                 float log_prior, const float* c_kld, const float* c_yl, int32_t R, int32_t Y, float* cfp,
+                 float* dqy, int64_t lddq, dv_stream_t stream);
+
+/* ------------------------------------------------------------- row movement
+ * out[r,:W] = src[idx?idx[r]:r, :W] (+ sigma*noise[r,:W])  -- the group gathers of
+ *   src/DrVAE.py:585-608 and the training-noise augmentation of src/DrVAE.py:404-407
+ *   (N(0,1)*add_noise_var) in one pass.
+ * onehot_cls != NULL additionally writes out[r, W + c] = (c == onehot_cls[r]) for c < Y:
+ *   `torch.cat([z, one_hot(y)], 1)` of src/blocks.py:161 + src/blocks.py:78-92. */
+int dv_rows_gather(const float* src, int64_t lds, const int32_t* idx, int32_t n, int32_t W, const float* noise,
+                   int64_t ldn, float sigma, const int32_t* onehot_cls, int32_t Y, float* out, int64_t ldo,
+                   dv_stream_t stream);
+/* dst[di,:W] = beta*dst[di,:W] + sum_{t in [seg_ptr[i],seg_ptr[i+1])} w[t]*src[seg_rows[t],:W],
+ * di = dst_idx?dst_idx[i]:i; seg_ptr==NULL: segment i is the single row (seg_rows?seg_rows[i]:i).
+ * Deterministic (no atomics): the transpose of every gather above. */
+int dv_rows_segment_sum(const float* src, int64_t lds, const int32_t* seg_ptr, const int32_t* seg_rows,
+                        const float* w, int32_t n, int32_t W, const int32_t* dst_idx, float* dst, int64_t ldd,
+                        float beta, dv_stream_t stream);
+/* out[0] = beta*out[0] + scale * sum_i w[i]*x[idx?idx[i]:i]   (loss scalars; one workgroup) */
+int dv_weighted_sum(const float* x, const float* w, const int32_t* idx, int32_t n, float scale, float* out,
+                    float beta, dv_stream_t stream);
+/* y[i] = a*x[i] + b*y[i] over n contiguous floats */
+int dv_axpby(const float* x, float a, float* y, float b, int64_t n, dv_stream_t stream);
+
+/* ------------------------------------------------------------------ optimiser (K11)
+ * torch.optim.Adam as configured by src/DGMMixin.py:36 (coupled L2: g += wd*p), in the
+ * arithmetic order of torch 2.x `_single_tensor_adam`, on a flat fp32 arena.
+ * step_dev[0] (int32, device) is the 1-based step used for the bias corrections; it is
+ * read, not modified (bump it with dv_counter_add so graph replays advance). gscale
+ * multiplies g first (1/world_size style scaling; 1.0 for summed gradients). */
+int dv_adam_l2(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+               float eps, float weight_decay, float gscale, const int32_t* step_dev, dv_stream_t stream);
+int dv_counter_add(int32_t* counter_lo_hi, int32_t n_words, int64_t inc, dv_stream_t stream);
+
+/* out[i] ~ N(0,1), Philox4x32-10 keyed by `seed`, counter = ctr_dev[0..1] (uint64 as two
+ * int32 words, device) + i/4, Box-Muller on the four outputs.  (the `normal_()` draws of
+ * src/blocks.py:172,210 and src/DrVAE.py:405,415 moved on device). */
+int dv_fill_normal(float* out, int64_t n, uint64_t seed, const int32_t* ctr_dev, dv_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DRVAE_HIP_H */

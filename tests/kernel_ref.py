@@ -1,0 +1,427 @@
+"""Plain-PyTorch fp32 reference of every launcher in ``drvae_amd.kernels`` (same names,
+same signatures, writes into the same output tensors; works on CPU or GPU tensors).
+
+Two uses, both test-only:
+  * ``-m gpu`` tests run each HIP kernel next to its reference here;
+  * CPU tests install these as a stand-in for ``drvae_amd.kernels`` (see
+    ``install``) to check the host-side orchestration (autograd wrappers, the fused
+    step engine's hand-written backward, data-parallel sharding) against the oracle
+    without a GPU.  The product never imports this module.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from drvae_amd._lib import ACT, EPI_BWD, EPI_FWD, EPI_PLAIN, GAUSS_LOGVAR, GAUSS_SIGMA  # noqa: F401
+
+LOG_2PI = 1.8378770664093453
+_ACT_NAME = {v: k for k, v in ACT.items()}
+
+
+def _name(a):
+    return a if isinstance(a, str) else _ACT_NAME[int(a)]
+
+
+def act_fwd(a, x):
+    a = _name(a)
+    if a == 'identity':
+        return x
+    if a == 'elu':
+        return F.elu(x)
+    if a == 'softplus':
+        return F.softplus(x)
+    if a == 'sigmoid':
+        return torch.sigmoid(x)
+    if a == 'tanh':
+        return torch.tanh(x)
+    if a == 'relu':
+        return torch.relu(x)
+    if a == 'leaky_relu':
+        return F.leaky_relu(x, 0.1)
+    if a == 'selu':
+        return F.selu(x)
+    if a == 'softsign':
+        return F.softsign(x)
+    if a == 'cos':
+        return torch.cos(x)
+    raise KeyError(a)
+
+
+def dact_from_y(a, y):
+    a = _name(a)
+    one = torch.ones_like(y)
+    if a == 'identity':
+        return one
+    if a == 'elu':
+        return torch.where(y > 0, one, y + 1)
+    if a == 'softplus':
+        return 1 - torch.exp(-y)
+    if a == 'sigmoid':
+        return y * (1 - y)
+    if a == 'tanh':
+        return 1 - y * y
+    if a == 'relu':
+        return (y > 0).float()
+    if a == 'leaky_relu':
+        return torch.where(y > 0, one, 0.1 * one)
+    if a == 'selu':
+        l_, a_ = 1.0507009873554804934193349852946, 1.6732632423543772848170429916717
+        return torch.where(y > 0, l_ * one, y + l_ * a_)
+    if a == 'softsign':
+        return (1 - y.abs()) ** 2
+    raise KeyError(a)
+
+
+def _acc(out, val, beta):
+    if beta != 0.0:
+        out.copy_(beta * out + val)
+    else:
+        out.copy_(val)
+
+
+def _seg(N, split, a0, a1, v0, v1, dev):
+    """per-column selection helper for the dual-head epilogues"""
+    first = (torch.arange(N, device=dev) < split)
+    return first
+
+
+def gemm(Cm, A, B, a_kc, b_kc, *, A2=None, a_kscale=None, alpha=1.0, beta=0.0, epi=EPI_PLAIN, scale=None,
+         bias=None, split=None, act0=0, act1=0, shift0=0.0, shift1=0.0, resid=None, resid_cols=0, yref=None,
+         a_colsum=None, colsum_beta=0.0):
+    M, N = Cm.shape
+    Aop = (torch.cat([A, A2], 1) if A2 is not None else A) if a_kc else A.t()
+    if a_kscale is not None:
+        Aop = Aop * a_kscale[None, :]
+    Bop = B.t() if b_kc else B
+    v = alpha * (Aop @ Bop)
+    split = N if split is None else split
+    first = _seg(N, split, act0, act1, shift0, shift1, Cm.device)[None, :]
+    if epi == EPI_FWD:
+        if scale is not None:
+            v = v * scale[None, :]
+        if bias is not None:
+            v = v + bias[None, :]
+        v = torch.where(first, act_fwd(act0, v) + shift0, act_fwd(act1, v) + shift1)
+        if resid is not None and resid_cols > 0:
+            v = torch.cat([v[:, :resid_cols] + resid[:, :resid_cols], v[:, resid_cols:]], 1)
+    elif epi == EPI_BWD:
+        d = torch.where(first, dact_from_y(act0, yref - shift0), dact_from_y(act1, yref - shift1))
+        v = v * d
+    _acc(Cm, v, beta)
+    if a_colsum is not None:
+        _acc(a_colsum, Aop.sum(1), colsum_beta)
+
+
+def linear_fwd(out, x, W, bias=None, *, x2=None, scale=None, split=None, act0=0, act1=0, shift0=0.0, shift1=0.0,
+               resid=None, resid_cols=0):
+    gemm(out, x, W, True, True, A2=x2, epi=EPI_FWD, scale=scale, bias=bias, split=split, act0=act0, act1=act1,
+         shift0=shift0, shift1=shift1, resid=resid, resid_cols=resid_cols)
+
+
+def linear_bwd_data(dx, dpre, W, *, kscale=None, alpha=1.0, beta=0.0, yref=None, act=0, shift=0.0):
+    if yref is None:
+        gemm(dx, dpre, W, True, False, a_kscale=kscale, alpha=alpha, beta=beta)
+    else:
+        gemm(dx, dpre, W, True, False, a_kscale=kscale, alpha=alpha, beta=beta, epi=EPI_BWD, yref=yref, act0=act,
+             act1=act, shift0=shift, shift1=shift)
+
+
+def linear_bwd_weight(dW, dpre, x, *, beta=0.0, dbias=None):
+    gemm(dW, dpre, x, False, False, beta=beta, a_colsum=dbias, colsum_beta=beta)
+
+
+def colsum(out, X, beta=0.0):
+    _acc(out, X.sum(0), beta)
+
+
+def act_bwd_(dY, Y, *, split=None, act0=0, act1=0, shift0=0.0, shift1=0.0):
+    N = Y.shape[1]
+    first = _seg(N, N if split is None else split, 0, 0, 0, 0, Y.device)[None, :]
+    dY.mul_(torch.where(first, dact_from_y(act0, Y - shift0), dact_from_y(act1, Y - shift1)))
+
+
+def wn_scale(scale, norm, W, g):
+    nrm = torch.norm(W, 2, 1)
+    if norm is not None:
+        norm.copy_(nrm)
+    scale.copy_(g / nrm)
+
+
+def wn_bwd(dW, dg, dWraw, W, g, norm, beta=0.0):
+    dot = (W * dWraw).sum(1)
+    _acc(dW, (g / norm)[:, None] * dWraw - (dot * g / norm ** 3)[:, None] * W, beta)
+    _acc(dg, dot / norm, beta)
+
+
+def _std(sd, mode):
+    return torch.exp(0.5 * sd) if mode == GAUSS_LOGVAR else sd
+
+
+def _qrows(n, reps, idx, dev):
+    j = torch.arange(n * reps, device=dev) % n
+    return idx.long()[j] if idx is not None else j
+
+
+def reparam_fwd(out, mu, sd, eps, *, mode=GAUSS_LOGVAR, src_idx=None, reps=1, sub=None, out2=None):
+    R = out.shape[0]
+    q = _qrows(R // reps, reps, src_idx, out.device)
+    z = mu[q] + eps * _std(sd[q], mode)
+    out.copy_(z)
+    if out2 is not None:
+        out2.copy_(z - sub)
+
+
+def reparam_bwd(dmu, dsd, dz, eps, sd, *, mode=GAUSS_LOGVAR, src_idx=None, reps=1, beta=0.0):
+    R, Z = dz.shape
+    n = R // reps
+    a = dz.reshape(reps, n, Z).sum(0)
+    b = (dz * eps).reshape(reps, n, Z).sum(0)
+    q = src_idx.long() if src_idx is not None else torch.arange(n, device=dz.device)
+    if mode == GAUSS_LOGVAR:
+        b = b * 0.5 * torch.exp(0.5 * sd[q])
+    if beta != 0.0:
+        dmu[q] = beta * dmu[q] + a
+        dsd[q] = beta * dsd[q] + b
+    else:
+        dmu[q] = a
+        dsd[q] = b
+
+
+def _kl_operands(mu_q, sd_q, mu_p, sd_p, prior, qidx, pidx, R, reps):
+    q = _qrows(R // reps, reps, qidx, mu_q.device)
+    mq, sq = mu_q[q], sd_q[q]
+    if mu_p is None:
+        mp, sp = torch.full_like(mq, prior[0]), torch.full_like(sq, prior[1])
+    else:
+        p = pidx.long() if pidx is not None else torch.arange(R, device=mu_q.device)
+        mp, sp = mu_p[p], sd_p[p]
+    return mq, sq, mp, sp
+
+
+def kl_rows_fwd(out, raw, mu_q, sd_q, mu_p=None, sd_p=None, *, prior=(0.0, 0.0), mode=GAUSS_LOGVAR, qidx=None,
+                pidx=None, reps=1, free_bits=False, kl_min=0.0):
+    R = out.numel()
+    mq, sq, mp, sp = _kl_operands(mu_q, sd_q, mu_p, sd_p, prior, qidx, pidx, R, reps)
+    if mode == GAUSS_LOGVAR:
+        t = 1 - sp + sq - ((mq - mp) ** 2 + sq.exp()) / sp.exp()
+    else:
+        t = 1 - torch.log(sp ** 2) + torch.log(sq ** 2) - ((mq - mp) ** 2 + sq ** 2) / sp ** 2
+    r = -0.5 * t.sum(1)
+    if raw is not None:
+        raw.copy_(r)
+    out.copy_(torch.clamp(r, min=kl_min) if free_bits else r)
+
+
+def kl_rows_bwd(dq_mu, dq_sd, dp_mu, dp_sd, coef, raw, mu_q, sd_q, mu_p=None, sd_p=None, *, prior=(0.0, 0.0),
+                mode=GAUSS_LOGVAR, qidx=None, pidx=None, reps=1, free_bits=False, kl_min=0.0, beta=0.0):
+    R = coef.numel()
+    mq, sq, mp, sp = _kl_operands(mu_q, sd_q, mu_p, sd_p, prior, qidx, pidx, R, reps)
+    c = coef.clone()
+    if free_bits:
+        c = c * torch.where(raw > kl_min, torch.ones_like(raw),
+                            torch.where(raw == kl_min, 0.5 * torch.ones_like(raw), torch.zeros_like(raw)))
+    c = c[:, None]
+    dm = mq - mp
+    if mode == GAUSS_LOGVAR:
+        ivp, vq = torch.exp(-sp), torch.exp(sq)
+        gmq, gsq = dm * ivp, -0.5 * (1 - vq * ivp)
+        gsp = -0.5 * (-1 + (dm * dm + vq) * ivp)
+    else:
+        vp = sp * sp
+        gmq, gsq = dm / vp, -1 / sq + sq / vp
+        gsp = 1 / sp - (dm * dm + sq * sq) / (vp * sp)
+    _acc(dq_mu, c * gmq, beta)
+    _acc(dq_sd, c * gsq, beta)
+    if dp_mu is not None:
+        _acc(dp_mu, -c * gmq, beta)
+        _acc(dp_sd, c * gsp, beta)
+
+
+def nll_rows_fwd(out, x, mu, sd, *, mode=GAUSS_SIGMA, xidx=None):
+    xr = x[xidx.long()] if xidx is not None else x
+    if mode == GAUSS_SIGMA:
+        t = LOG_2PI + torch.log(sd ** 2) + (xr - mu) ** 2 / sd ** 2
+    else:
+        t = LOG_2PI + sd + (xr - mu) ** 2 / sd.exp()
+    out.copy_(-0.5 * t.sum(1))
+
+
+def nll_rows_bwd(dmu, dsd, coef, x, mu, sd, *, mode=GAUSS_SIGMA, xidx=None, sd_act=0, sd_shift=0.0, dx=None,
+                 beta=0.0):
+    xr = x[xidx.long()] if xidx is not None else x
+    d = xr - mu
+    c = coef[:, None]
+    if mode == GAUSS_SIGMA:
+        gm, gs = d / sd ** 2, -1 / sd + d * d / sd ** 3
+    else:
+        gm, gs = d * torch.exp(-sd), -0.5 * (1 - d * d * torch.exp(-sd))
+    if _name(sd_act) != 'identity':
+        gs = gs * dact_from_y(sd_act, sd - sd_shift)
+    _acc(dmu, c * gm, beta)
+    _acc(dsd, c * gs, beta)
+    if dx is not None:
+        _acc(dx, -c * gm, beta)
+
+
+P_MIN = 1e-10
+
+
+def softmax_clamp_fwd(probs, logits, sigmoid1=False):
+    if sigmoid1:
+        s = torch.sigmoid(logits[:, :1])
+        p = torch.cat([1 - s, s], 1)
+    else:
+        p = torch.softmax(logits, -1)
+    probs.copy_(torch.clamp(p, min=P_MIN, max=1. - 1e-10))
+
+
+def softmax_clamp_bwd(dlogits, dprobs, probs, sigmoid1=False, beta=0.0):
+    g = torch.where(probs > P_MIN, dprobs, torch.zeros_like(dprobs))
+    if sigmoid1:
+        s = probs[:, 1:2]
+        _acc(dlogits, (g[:, 1:2] - g[:, 0:1]) * s * (1 - s), beta)
+    else:
+        dot = (g * probs).sum(1, keepdim=True)
+        _acc(dlogits, probs * (g - dot), beta)
+
+
+def cat_terms_fwd(probs, *, labels=None, prior=None, logp=None, kl=None, ent=None, best=None):
+    lp = probs.log()
+    if logp is not None:
+        logp.copy_(lp.gather(1, labels.long()[:, None])[:, 0])
+    if kl is not None:
+        kl.copy_(-probs * (prior.log() - lp))
+    if ent is not None:
+        ent.copy_(-(probs * lp).sum(1))
+    if best is not None:
+        best.copy_(torch.max(probs, 1)[1].to(best.dtype))
+
+
+def cat_terms_bwd(dprobs, probs, *, labels=None, prior=None, c_logp=None, g_kl=None, c_ent=None, beta=0.0):
+    lp = probs.log()
+    v = torch.zeros_like(probs)
+    if c_logp is not None:
+        oh = F.one_hot(labels.long(), probs.shape[1]).to(probs.dtype)
+        v = v + oh * (c_logp[:, None] / probs)
+    if g_kl is not None:
+        v = v + g_kl * (lp - prior.log() + 1)
+    if c_ent is not None:
+        v = v - c_ent[:, None] * (lp + 1)
+    _acc(dprobs, v, beta)
+
+
+def ymarg_fwd(yl, kld, qy, label, fp_ptr, klfp, log_prior):
+    R, Y = qy.shape
+    f0 = fp_ptr[:-1].long()
+    nf = (fp_ptr[1:] - fp_ptr[:-1]).long()
+    lab = nf == 1
+    j = torch.arange(Y, device=qy.device)[None, :]
+    fidx = torch.where(lab[:, None], f0[:, None].expand(R, Y), f0[:, None] + j).clamp(max=max(klfp.numel() - 1, 0))
+    kf = klfp[fidx]
+    lq = qy.log()
+    yl.copy_(torch.where(lab, lq.gather(1, label.long()[:, None])[:, 0], torch.zeros_like(yl)))
+    marg = (qy * kf).sum(1) + (-qy * (log_prior - lq)).sum(1)
+    kld.copy_(torch.where(lab, kf[:, 0], marg))
+
+
+def ymarg_bwd(cfp, dqy, qy, label, fp_ptr, klfp, log_prior, c_kld, c_yl):
+    R, Y = qy.shape
+    f0 = fp_ptr[:-1].long()
+    nf = (fp_ptr[1:] - fp_ptr[:-1]).long()
+    for r in range(R):       # small R in tests; clarity over speed
+        if int(nf[r]) == 1:
+            dqy[r].zero_()
+            dqy[r, int(label[r])] = c_yl[r] / qy[r, int(label[r])]
+            cfp[int(f0[r])] = c_kld[r]
+        else:
+            sl = slice(int(f0[r]), int(f0[r]) + Y)
+            cfp[sl] = c_kld[r] * qy[r]
+            dqy[r] = c_kld[r] * (klfp[sl] + qy[r].log() - log_prior + 1)
+
+
+def rows_gather(out, src, idx=None, *, noise=None, sigma=0.0, onehot_cls=None, n_classes=0, width=None):
+    n = out.shape[0]
+    W = (src.shape[1] if src is not None else 0) if width is None else width
+    if W > 0:
+        v = src[idx.long()][:, :W] if idx is not None else src[:n, :W]
+        if noise is not None:
+            v = v + sigma * noise[:n, :W]
+        out[:, :W] = v
+    if onehot_cls is not None:
+        out[:, W:W + n_classes] = F.one_hot(onehot_cls.long(), n_classes).to(out.dtype)
+
+
+def rows_segment_sum(dst, src, *, seg_ptr=None, seg_rows=None, w=None, n=None, dst_idx=None, beta=0.0, width=None):
+    if n is None:
+        n = seg_ptr.numel() - 1 if seg_ptr is not None else (seg_rows.numel() if seg_rows is not None else
+                                                              src.shape[0])
+    W = dst.shape[1] if width is None else width
+    for i in range(n):
+        if seg_ptr is not None:
+            ts = range(int(seg_ptr[i]), int(seg_ptr[i + 1]))
+        else:
+            ts = [i]
+        s = torch.zeros(W, device=dst.device)
+        for t in ts:
+            row = int(seg_rows[t]) if seg_rows is not None else t
+            s = s + (float(w[t]) if w is not None else 1.0) * src[row, :W]
+        di = int(dst_idx[i]) if dst_idx is not None else i
+        dst[di, :W] = (beta * dst[di, :W] if beta != 0.0 else 0) + s
+
+
+def weighted_sum(out, x, w=None, idx=None, scale=1.0, beta=0.0, n=None):
+    if n is None:
+        n = idx.numel() if idx is not None else x.numel()
+    xv = x.reshape(-1)[idx.long()[:n]] if idx is not None else x.reshape(-1)[:n]
+    s = (xv * w.reshape(-1)[:n]).sum() if w is not None else xv.sum()
+    out.reshape(-1)[0] = (beta * out.reshape(-1)[0] if beta != 0.0 else 0) + scale * s
+
+
+def axpby(y, x, a=1.0, b=0.0):
+    y.copy_(a * x + (b * y if b != 0.0 else 0))
+
+
+def adam_l2(p, g, m, v, step_dev, *, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, gscale=1.0):
+    t = int(step_dev.reshape(-1)[0])
+    gg = g * gscale
+    if weight_decay != 0.0:
+        gg = gg + weight_decay * p
+    m.lerp_(gg, 1 - beta1)
+    v.mul_(beta2).addcmul_(gg, gg, value=1 - beta2)
+    bc1, bc2 = 1 - beta1 ** t, 1 - beta2 ** t
+    denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
+    p.addcdiv_(m, denom, value=-(lr / bc1))
+
+
+def counter_add(counter, inc=1):
+    if counter.numel() == 1:
+        counter += inc
+    else:
+        v = (int(counter[1]) & 0xffffffff) << 32 | (int(counter[0]) & 0xffffffff)
+        v = (v + inc) & 0xffffffffffffffff
+        lo, hi = v & 0xffffffff, v >> 32
+        counter[0] = lo - (1 << 32) if lo >= (1 << 31) else lo
+        counter[1] = hi - (1 << 32) if hi >= (1 << 31) else hi
+
+
+def fill_normal(out, seed, ctr_dev=None):
+    """Stand-in only (NOT bit-compatible with the device Philox stream)."""
+    g = torch.Generator(device='cpu')
+    base = 0 if ctr_dev is None else (int(ctr_dev[1]) << 32 | (int(ctr_dev[0]) & 0xffffffff))
+    g.manual_seed((seed * 1000003 + base) % (1 << 62))
+    out.copy_(torch.randn(out.shape, generator=g).to(out.device))
+
+
+FUNCTIONS = ['gemm', 'linear_fwd', 'linear_bwd_data', 'linear_bwd_weight', 'colsum', 'act_bwd_', 'wn_scale', 'wn_bwd',
+             'reparam_fwd', 'reparam_bwd', 'kl_rows_fwd', 'kl_rows_bwd', 'nll_rows_fwd', 'nll_rows_bwd',
+             'softmax_clamp_fwd', 'softmax_clamp_bwd', 'cat_terms_fwd', 'cat_terms_bwd', 'ymarg_fwd', 'ymarg_bwd',
+             'rows_gather', 'rows_segment_sum', 'weighted_sum', 'axpby', 'adam_l2', 'counter_add', 'fill_normal']
+
+
+def install(monkeypatch):
+    """Replace the HIP launchers by these references for one CPU test (pytest monkeypatch)."""
+    import drvae_amd.kernels as K
+    me = globals()
+    for name in FUNCTIONS:
+        monkeypatch.setattr(K, name, me[name])

@@ -1,0 +1,81 @@
+"""CPU checks of the drop-in boundary: the C-ABI library builds for gfx950, loads, and
+exports every symbol include/drvae_hip.h declares with the declared arity (no compute
+calls -- there is no GPU here)."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_decls():
+    src = open(os.path.join(ROOT, 'include', 'drvae_hip.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    out = {}
+    for m in re.finditer(r'(?:int|const char\*)\s+(dv_\w+)\s*\(([^)]*)\)\s*;', src):
+        args = m.group(2).strip()
+        out[m.group(1)] = 0 if args in ('', 'void') else len(args.split(','))
+    return out
+
+
+@pytest.fixture(scope='module')
+def lib():
+    from drvae_amd import build, _lib
+    build.build(verbose=False)
+    return _lib.load()
+
+
+def test_header_declares_the_whole_abi():
+    decls = _header_decls()
+    assert len(decls) >= 27
+    from drvae_amd import _lib
+    assert set(decls) == set(_lib.SIGNATURES), set(decls) ^ set(_lib.SIGNATURES)
+    for name, n in decls.items():
+        assert len(_lib.SIGNATURES[name]) == n, (name, n, len(_lib.SIGNATURES[name]))
+
+
+def test_library_exports_every_symbol(lib):
+    for name in _header_decls():
+        assert hasattr(lib, name), name
+    assert lib.dv_abi_version() == 1
+    assert lib.dv_error_string(0) == b'ok'
+    assert lib.dv_error_string(-1) == b'invalid argument'
+
+
+def test_gemm_desc_layout_matches_header():
+    """ctypes struct field order/names == the C struct in the header."""
+    from drvae_amd._lib import GemmDesc
+    src = open(os.path.join(ROOT, 'include', 'drvae_hip.h')).read()
+    body = re.search(r'typedef struct dv_gemm_desc \{(.*?)\} dv_gemm_desc;', src, flags=re.S).group(1)
+    body = re.sub(r'/\*.*?\*/', '', body, flags=re.S)
+    names = []
+    for stmt in body.split(';'):
+        stmt = stmt.strip()
+        if not stmt:
+            continue
+        for part in stmt.split(','):
+            names.append(re.sub(r'.*[\s\*]', '', part.strip()))
+    assert names == [f[0] for f in GemmDesc._fields_]
+
+
+def test_argument_validation_without_gpu(lib):
+    """Entry points reject bad arguments before touching the device (error code, no abort)."""
+    assert lib.dv_gemm(None, None) == -1
+    assert lib.dv_counter_add(None, 3, 1, None) == -1
+    assert lib.dv_softmax_clamp_fwd(None, 0, 5, 0, 0, None, 0, None) == -1   # Y < 1
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from drvae_amd import _lib
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(_lib, 'LIB_PATH', str(tmp_path / 'nope.so'))
+    with pytest.raises(RuntimeError, match='no CPU/PyTorch fallback'):
+        _lib.load()
+
+
+def test_kernels_refuse_cpu_tensors():
+    import torch
+    import drvae_amd.kernels as K
+    with pytest.raises(RuntimeError, match='no CPU'):
+        K.colsum(torch.zeros(3), torch.zeros(2, 3))

@@ -1,0 +1,237 @@
+"""-m gpu: the drop-in ``drvae_amd.blocks`` / ``drvae_amd.layers`` modules (HIP kernels via
+autograd wrappers) against the golden vectors produced by the reference's own blocks,
+and against the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from tests.golden import cases as C
+
+pytestmark = pytest.mark.gpu
+
+RT, AT = 1e-4, 2e-5       # BASELINE.json: 1e-4 relative fp32 tolerance
+
+
+@pytest.fixture(scope='module')
+def G():
+    return C.load('blocks')
+
+
+@pytest.fixture(scope='module')
+def mods(dev):
+    import drvae_amd.blocks as blk
+    import drvae_amd.layers as lyr
+    return blk, lyr
+
+
+def T(a, dev):
+    return torch.from_numpy(np.asarray(a).copy()).to(dev)
+
+
+def close(a, b, rtol=RT, atol=AT):
+    a = a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol)
+
+
+def load_sd(module, params, dev):
+    module.to(dev)
+    sd = module.state_dict()
+    assert list(sd.keys()) == list(params.keys()), (list(sd.keys()), list(params.keys()))
+    module.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in params.items()})
+    return module
+
+
+class Replay:
+    """same noise-injection mechanism as tests/golden/make_golden.py"""
+
+    def __init__(self, normals, uniforms=()):
+        self.normals, self.uniforms = list(normals), list(uniforms)
+
+    def __enter__(self):
+        self._n, self._u = torch.Tensor.normal_, torch.Tensor.uniform_
+        me = self
+
+        def normal_(t, *a, **k):
+            return t.copy_(torch.from_numpy(np.ascontiguousarray(me.normals.pop(0))))
+
+        def uniform_(t, *a, **k):
+            return t.copy_(torch.from_numpy(np.ascontiguousarray(me.uniforms.pop(0))))
+
+        torch.Tensor.normal_ = normal_
+        if self.uniforms:
+            torch.Tensor.uniform_ = uniform_
+        return self
+
+    def __exit__(self, *exc):
+        torch.Tensor.normal_, torch.Tensor.uniform_ = self._n, self._u
+
+
+def test_weightnorm_linear(G, mods, dev):
+    blk, lyr = mods
+    c = C.block_inputs('G1')
+    m = load_sd(lyr.WeightNormLinear(13, 5), c['params'], dev)
+    x = T(c['x'], dev).requires_grad_(True)
+    y = m(x)
+    (y * T(c['dy'], dev)).sum().backward()
+    close(y, G['G1/y'])
+    close(x.grad, G['G1/dx'])
+    close(m.weight.grad, G['G1/dW'])
+    close(m.g.grad, G['G1/dg'])
+    close(m.bias.grad, G['G1/db'])
+
+
+@pytest.mark.parametrize('tag,wn,nl', [('G2a', False, 'elu'), ('G2b', True, 'softplus'), ('G2c', True, 'elu')])
+def test_mlp(G, mods, dev, tag, wn, nl):
+    blk, _ = mods
+    c = C.block_inputs(tag)
+    m = load_sd(blk.MLP([9, 4], [11, 6], nonlin=nl, weight_norm=wn), c['params'], dev)
+    xs = [T(c['xa'], dev).requires_grad_(True), T(c['xb'], dev).requires_grad_(True)]
+    y = m(xs)
+    (y * T(c['dy'], dev)).sum().backward()
+    close(y, G[tag + '/y'])
+    close(xs[0].grad, G[tag + '/dxa'])
+    close(xs[1].grad, G[tag + '/dxb'])
+    for k, v in m.named_parameters():
+        close(v.grad, G['%s/d_%s' % (tag, k)])
+    with pytest.raises(AssertionError):
+        m([xs[0]])                                       # input-list length check, src/blocks.py:158
+    with pytest.raises(ValueError):
+        blk.MLP([9, 4], [3], input_dropout_rates=[0.1])  # src/blocks.py:128-130
+
+
+@pytest.mark.parametrize('tag,wn', [('G3a', False), ('G3b', True)])
+def test_diag_gaussian_module(G, mods, dev, tag, wn):
+    blk, _ = mods
+    c = C.block_inputs(tag)
+    m = load_sd(blk.DiagGaussianModule([9, 4], [11], 5, nonlin='elu', weight_norm=wn, prior_mu=0.3, prior_sg=1.7),
+                c['params'], dev)
+    out = m([T(c['xa'], dev), T(c['xb'], dev)])
+    assert isinstance(out, tuple) and len(out) == 2
+    mu, lv = out
+    close(mu, G[tag + '/mu'])
+    close(lv, G[tag + '/lv'])
+    with Replay([c['eps']]):
+        z = m.sample(mu, lv)
+    assert isinstance(z, tuple) and len(z) == 1
+    close(z[0], G[tag + '/z'])
+    mu_p, lv_p, s = T(c['mu_p'], dev), T(c['lv_p'], dev), T(c['s'], dev)
+    close(m.kldivergence_perx(mu, lv, mu_p, lv_p), G[tag + '/kl'])
+    close(m.kldivergence_from_prior_perx(mu, lv), G[tag + '/kl_prior'])
+    close(m.logp_perx(s, mu, lv), G[tag + '/logp'])
+    close(m.logp_prior_perx(s), G[tag + '/logp_prior'])
+    close(m.kldivergence(mu, lv, mu_p, lv_p), G[tag + '/kl_sum'])
+    close(m.logp(s, mu, lv), G[tag + '/logp_sum'])
+    assert 'prior_mu' not in m.state_dict() and not isinstance(m.prior_mu, torch.nn.Parameter)
+
+
+def test_diag_gaussian_fixed_variance(G, mods, dev):
+    blk, _ = mods
+    c = C.block_inputs('G3c')
+    m = load_sd(blk.DiagGaussianModule([9, 4], [11], 5, nonlin='elu', fixed_variance=0.05 ** 2,
+                                       constrain_means=True), c['params'], dev)
+    mu, lv = m([T(c['xa'], dev), T(c['xb'], dev)])
+    close(mu, G['G3c/mu'])
+    close(lv, G['G3c/lv'])
+
+
+@pytest.mark.parametrize('tag,wn', [('G4a', False), ('G4b', True)])
+def test_diag_gaussian_sigma_module(G, mods, dev, tag, wn):
+    blk, _ = mods
+    c = C.block_inputs(tag)
+    m = load_sd(blk.DiagGaussianSigmaModule([5], [11], 17, nonlin='elu', weight_norm=wn), c['params'], dev)
+    mu, sd = m([T(c['z'], dev)])
+    close(mu, G[tag + '/mu'])
+    close(sd, G[tag + '/std'])
+    with Replay([c['eps']]):
+        smp = m.sample(mu, sd)
+    close(smp[0], G[tag + '/sample'])
+    x = T(c['x'], dev)
+    close(m.logp_perx(x, mu, sd), G[tag + '/logp'])
+    close(m.kldivergence_perx(mu, sd, T(c['mu_p'], dev), T(c['sd_p'], dev)), G[tag + '/kl'])
+    close(m.kldivergence_from_prior_perx(mu, sd), G[tag + '/kl_prior'])
+    close(m.logp_prior_perx(x), G[tag + '/logp_prior'])
+
+
+@pytest.mark.parametrize('tag,bias_only', [('G5a', False), ('G5b', True)])
+def test_diag_gaussian_module_linear(G, mods, dev, tag, bias_only):
+    blk, _ = mods
+    c = C.block_inputs(tag)
+    m = load_sd(blk.DiagGaussianModuleLinear([5], [], 5, bias_only=bias_only), c['params'], dev)
+    mu, lv = m([T(c['z'], dev)])
+    close(mu, G[tag + '/mu'])
+    close(lv, G[tag + '/lv'])
+    with pytest.raises(AssertionError):
+        blk.DiagGaussianModuleLinear([5], [], 6)         # src/blocks.py:324
+    assert tuple(m.W_mu.shape) == (5, 5)
+
+
+@pytest.mark.parametrize('tag,rdim', [('G6a', 3), ('G6b', 1)])
+def test_categorical_decoder(G, mods, dev, tag, rdim):
+    blk, _ = mods
+    c = C.block_inputs(tag)
+    m = load_sd(blk.CategoricalDecoder([5, 5], [], rdim, nonlin='elu'), c['params'], dev)
+    res = m([T(c['za'], dev), T(c['zb'], dev)])
+    assert isinstance(res, list) and len(res) == 1
+    ps = res[0]
+    close(ps, G[tag + '/ps'])
+    y, prior = T(c['y'], dev), T(c['prior'], dev)
+    close(m.logp_perx(y, ps), G[tag + '/logp'])
+    close(m.kldivergence_perx(ps, prior), G[tag + '/kl'])
+    close(m.entropy(ps), G[tag + '/entropy'])
+    assert (m.most_probable(ps).cpu().numpy() == G[tag + '/best']).all()
+    close(m.logp(y, ps), G[tag + '/logp_sum'])
+    assert m.sample(ps).shape == (ps.shape[0], 1)
+
+
+def test_categorical_decoder_clamped(G, mods, dev):
+    blk, _ = mods
+    c = C.block_inputs('G6c')
+    m = load_sd(blk.CategoricalDecoder([5], [7], 2, nonlin='elu'), c['params'], dev)
+    ps = m([T(c['za'], dev)])[0]
+    close(ps, G['G6c/ps'], rtol=2e-4, atol=1e-12)
+    close(m.logp_perx(T(c['y'], dev), ps), G['G6c/logp'], rtol=2e-4)
+    close(m.kldivergence_perx(ps, T(c['prior'], dev)), G['G6c/kl'], rtol=2e-4, atol=1e-8)
+
+
+def test_mmd_and_one_hot(G, mods, dev):
+    blk, _ = mods
+    c = C.block_inputs('G7')
+    x1, x2 = T(c['x1'], dev), T(c['x2'], dev)
+    with Replay([c['rnd_a']], [c['rnd_b']]):
+        close(blk.mmd_objective(x1, x2, 'rbf_fourier'), G['G7/rbf_fourier'])
+    close(blk.mmd_objective(x1, x2, 'identity'), G['G7/identity'])
+    close(blk.mmd_objective(x1, x2, 'poly'), G['G7/poly'])
+    close(blk.one_hot(T(C.block_inputs('G8')['y'], dev), 4), G['G8/onehot'])
+    assert blk.one_hot(None, 4) is None
+    assert set(blk.kernels) == {'rbf', 'poly', 'identity', 'rbf_fourier'}
+    assert set(blk.nonlinearities) == {'tanh', 'sigmoid', 'softmax', 'softplus', 'softsign', 'relu',
+                                       'leaky_relu', 'elu', 'selu'}
+
+
+def test_gradients_through_block_chain_vs_oracle(mods, dev):
+    """encoder -> sample -> decoder -> logp + KL, gradients w.r.t. every parameter vs the CPU oracle."""
+    from oracle import blocks_ref as B
+    blk, _ = mods
+    torch.manual_seed(0)
+    enc = blk.DiagGaussianModule([13], [11], 5, nonlin='elu', weight_norm=True).to(dev)
+    dec = blk.DiagGaussianSigmaModule([5], [9], 13, nonlin='elu').to(dev)
+    x = torch.randn(21, 13)
+    eps = torch.randn(21, 5)
+    xd = x.to(dev)
+    mu, lv = enc([xd])
+    with Replay([eps.numpy()]):
+        z = enc.sample(mu, lv)[0]
+    loss = -dec.logp(xd, *dec([z])) + enc.kldivergence_from_prior(mu, lv)
+    loss.backward()
+    p = {'e.' + k: v.detach().cpu().clone().requires_grad_(True) for k, v in enc.state_dict().items()}
+    p.update({'d.' + k: v.detach().cpu().clone().requires_grad_(True) for k, v in dec.state_dict().items()})
+    rmu, rlv = B.diag_gaussian([x], p, 'e', 1, 'elu')
+    rz = B.sample_logvar(rmu, rlv, eps)
+    rloss = -B.logp_sigma_rows(x, *B.diag_gaussian_sigma([rz], p, 'd', 1, 'elu')).sum() \
+        + B.kl_logvar_prior_rows(rmu, rlv).sum()
+    rloss.backward()
+    close(loss, rloss.detach().numpy(), rtol=1e-4)
+    for k, v in enc.named_parameters():
+        close(v.grad, p['e.' + k].grad.numpy(), rtol=2e-3, atol=2e-4)
+    for k, v in dec.named_parameters():
+        close(v.grad, p['d.' + k].grad.numpy(), rtol=2e-3, atol=2e-4)

@@ -1,0 +1,402 @@
+"""-m gpu: every HIP kernel (through the C-ABI) against its plain-PyTorch fp32 reference."""
+import numpy as np
+import pytest
+import torch
+
+from tests import kernel_ref as R
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def K(dev):
+    import drvae_amd.kernels as K
+    from drvae_amd import _lib
+    _lib.load()
+    return K
+
+
+def rnd(dev, *shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, generator=g) * scale).to(dev)
+
+
+def strided(dev, rows, cols, pad, seed=0):
+    """(rows, cols) view into a wider buffer: exercises leading dimensions != cols"""
+    buf = rnd(dev, rows, cols + pad, seed=seed)
+    return buf[:, :cols]
+
+
+def close(a, b, rtol=2e-5, atol=2e-5):
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().cpu().numpy(), rtol=rtol, atol=atol)
+
+
+def gemm_tol(K_):
+    # fp32 fma chain in a different summation order than the reference: ~sqrt(K)*eps relative to |a||b|
+    return dict(rtol=2e-4, atol=2e-5 * max(1.0, K_ ** 0.5))
+
+
+SHAPES = [(7, 5, 13), (64, 64, 32), (65, 33, 31), (225, 800, 978), (150, 200, 102), (300, 2, 200), (1, 1, 1),
+          (130, 257, 100), (600, 100, 6)]
+
+
+@pytest.mark.parametrize('tiling', [0, 1, 2, 3])
+@pytest.mark.parametrize('M,N,Kd', SHAPES)
+def test_gemm_forward_epilogue(K, dev, tiling, M, N, Kd):
+    from drvae_amd import _lib
+    _lib.load().dv_gemm_force_tiling(tiling)
+    try:
+        x, W, b = rnd(dev, M, Kd, seed=1), rnd(dev, N, Kd, seed=2, scale=Kd ** -0.5), rnd(dev, N, seed=3)
+        sc = rnd(dev, N, seed=4).abs() + 0.5
+        for kw in (dict(), dict(bias=b, act0='elu', act1='elu'),
+                   dict(bias=b, scale=sc, split=N // 2, act0='identity', act1='softplus', shift1=1e-3),
+                   dict(bias=b, split=N // 2, act0='identity', act1='identity', shift1=-2.0)):
+            out, ref = torch.full((M, N), 7.0, device=dev), torch.zeros(M, N, device=dev)
+            K.linear_fwd(out, x, W, **kw)
+            R.linear_fwd(ref, x, W, **kw)
+            close(out, ref, **gemm_tol(Kd))
+    finally:
+        _lib.load().dv_gemm_force_tiling(0)
+
+
+@pytest.mark.parametrize('tiling', [0, 1, 2, 3])
+@pytest.mark.parametrize('M,N,Kd', SHAPES)
+def test_gemm_backward_products(K, dev, tiling, M, N, Kd):
+    from drvae_amd import _lib
+    _lib.load().dv_gemm_force_tiling(tiling)
+    try:
+        x, W = rnd(dev, M, Kd, seed=1), rnd(dev, N, Kd, seed=2, scale=Kd ** -0.5)
+        dpre, yprev = rnd(dev, M, N, seed=5), rnd(dev, M, Kd, seed=6)
+        ks = rnd(dev, N, seed=7).abs() + 0.5
+        # dx = (dpre*ks) W * elu'(yprev), accumulate on top of existing values
+        dx, ref = rnd(dev, M, Kd, seed=8), None
+        ref = dx.clone()
+        K.linear_bwd_data(dx, dpre, W, kscale=ks, alpha=-0.5, beta=1.0, yref=yprev, act='elu')
+        R.linear_bwd_data(ref, dpre, W, kscale=ks, alpha=-0.5, beta=1.0, yref=yprev, act='elu')
+        close(dx, ref, **gemm_tol(N))
+        dx2, ref2 = torch.empty(M, Kd, device=dev), torch.empty(M, Kd, device=dev)
+        K.linear_bwd_data(dx2, dpre, W)
+        R.linear_bwd_data(ref2, dpre, W)
+        close(dx2, ref2, **gemm_tol(N))
+        # dW = dpre^T x (+ fused bias gradient)
+        dW, db = rnd(dev, N, Kd, seed=9), rnd(dev, N, seed=10)
+        rW, rb = dW.clone(), db.clone()
+        K.linear_bwd_weight(dW, dpre, x, beta=1.0, dbias=db)
+        R.linear_bwd_weight(rW, dpre, x, beta=1.0, dbias=rb)
+        close(dW, rW, **gemm_tol(M))
+        close(db, rb, **gemm_tol(M))
+        dW0, db0 = torch.empty(N, Kd, device=dev), torch.empty(N, device=dev)
+        rW0, rb0 = torch.empty(N, Kd, device=dev), torch.empty(N, device=dev)
+        K.linear_bwd_weight(dW0, dpre, x, dbias=db0)
+        R.linear_bwd_weight(rW0, dpre, x, dbias=rb0)
+        close(dW0, rW0, **gemm_tol(M))
+        close(db0, rb0, **gemm_tol(M))
+    finally:
+        _lib.load().dv_gemm_force_tiling(0)
+
+
+def test_gemm_mfma_layout_asymmetric(K, dev):
+    """A = I with an asymmetric B: catches a transposed C/D register map (guide section 3)."""
+    n = 96
+    eye = torch.eye(n, device=dev)
+    Bm = (torch.arange(n * n, device=dev, dtype=torch.float32).reshape(n, n) % 251) * 0.01
+    out = torch.empty(n, n, device=dev)
+    K.gemm(out, eye, Bm, True, False)
+    close(out, Bm, rtol=0, atol=0)
+    K.gemm(out, eye, Bm, True, True)
+    close(out, Bm.t(), rtol=0, atol=0)
+    K.gemm(out, Bm, eye, False, False)
+    close(out, Bm.t(), rtol=0, atol=0)
+
+
+def test_gemm_split_sources_residual_strided(K, dev):
+    M, K1, K2, N = 37, 10, 6, 20          # K1 % 4 != 0 -> scalar load path for the concat
+    for K1_ in (K1, 12):
+        x1, x2 = strided(dev, M, K1_, 3, seed=1), strided(dev, M, K2, 1, seed=2)
+        W, b = rnd(dev, N, K1_ + K2, seed=3), rnd(dev, N, seed=4)
+        res = strided(dev, M, N // 2, 5, seed=5)
+        buf = torch.zeros(M, N + 4, device=dev)
+        out, ref = buf[:, :N], torch.zeros(M, N, device=dev)
+        kw = dict(x2=x2, split=N // 2, act0='identity', act1='identity', shift1=-2.0, resid=res, resid_cols=N // 2)
+        K.linear_fwd(out, x1, W, b, **kw)
+        R.linear_fwd(ref, x1, W, b, **kw)
+        close(out, ref, rtol=1e-4, atol=1e-5)
+        assert float(buf[:, N:].abs().max()) == 0.0          # padding columns untouched
+        # column-sliced W views in the backward products
+        dpre = rnd(dev, M, N, seed=6)
+        dx2, rx2 = torch.empty(M, K2, device=dev), torch.empty(M, K2, device=dev)
+        K.linear_bwd_data(dx2, dpre, W[:, K1_:])
+        R.linear_bwd_data(rx2, dpre, W[:, K1_:])
+        close(dx2, rx2, rtol=1e-4, atol=1e-5)
+        dW = torch.zeros(N, K1_ + K2, device=dev)
+        rW = torch.zeros(N, K1_ + K2, device=dev)
+        K.linear_bwd_weight(dW[:, K1_:], dpre, x2)
+        R.linear_bwd_weight(rW[:, K1_:], dpre, x2)
+        close(dW, rW, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize('act', ['elu', 'softplus', 'sigmoid', 'tanh', 'relu', 'leaky_relu', 'selu', 'softsign'])
+def test_activations(K, dev, act):
+    M, N, Kd = 33, 47, 8
+    x, W, b = rnd(dev, M, Kd, seed=1, scale=3.0), rnd(dev, N, Kd, seed=2), rnd(dev, N, seed=3)
+    y, ry = torch.empty(M, N, device=dev), torch.empty(M, N, device=dev)
+    K.linear_fwd(y, x, W, b, act0=act, act1=act)
+    R.linear_fwd(ry, x, W, b, act0=act, act1=act)
+    close(y, ry, rtol=1e-5, atol=1e-5)
+    # derivative from the output agrees with autograd through the torch activation
+    pre = (x @ W.t() + b).requires_grad_(True)
+    R.act_fwd(act, pre).backward(torch.ones_like(pre))
+    dY = torch.ones(M, N, device=dev)
+    K.act_bwd_(dY, y, act0=act, act1=act)
+    close(dY, pre.grad, rtol=2e-4, atol=2e-5)
+
+
+def test_colsum_wn(K, dev):
+    X = strided(dev, 301, 77, 3, seed=1)
+    out, ref = rnd(dev, 77, seed=2), None
+    ref = out.clone()
+    K.colsum(out, X, beta=1.0)
+    R.colsum(ref, X, beta=1.0)
+    close(out, ref, rtol=1e-5, atol=1e-4)
+    N, Kd = 45, 978
+    W, g = rnd(dev, N, Kd, seed=3, scale=0.05), rnd(dev, N, seed=4).abs() + 0.5
+    sc, nm, rsc, rnm = (torch.empty(N, device=dev) for _ in range(4))
+    K.wn_scale(sc, nm, W, g)
+    R.wn_scale(rsc, rnm, W, g)
+    close(sc, rsc, rtol=1e-5)
+    close(nm, rnm, rtol=1e-5)
+    dWraw = rnd(dev, N, Kd, seed=5)
+    dW, dg = rnd(dev, N, Kd, seed=6), rnd(dev, N, seed=7)
+    rW, rg = dW.clone(), dg.clone()
+    K.wn_bwd(dW, dg, dWraw, W, g, nm, beta=1.0)
+    R.wn_bwd(rW, rg, dWraw, W, g, rnm, beta=1.0)
+    close(dW, rW, rtol=1e-4, atol=1e-4)
+    close(dg, rg, rtol=1e-4, atol=1e-4)
+    # against autograd of the closed form (src/layers.py:38-40)
+    Wt, gt = W.clone().requires_grad_(True), g.clone().requires_grad_(True)
+    x, dy = rnd(dev, 9, Kd, seed=8), rnd(dev, 9, N, seed=9)
+    y = (gt / torch.norm(Wt, 2, 1)) * (x @ Wt.t())
+    (y * dy).sum().backward()
+    dW2, dg2 = torch.empty(N, Kd, device=dev), torch.empty(N, device=dev)
+    K.wn_bwd(dW2, dg2, dy.t() @ x, W, g, nm)
+    close(dW2, Wt.grad, rtol=2e-4, atol=2e-5)
+    close(dg2, gt.grad, rtol=2e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize('mode', [0, 1])
+def test_reparam(K, dev, mode):
+    n, reps, Z, nq = 11, 3, 100, 17
+    Q = rnd(dev, nq, 2 * Z, seed=1, scale=0.5)
+    if mode == 1:
+        Q[:, Z:] = Q[:, Z:].abs() + 0.1
+    mu, sd = Q[:, :Z], Q[:, Z:]
+    idx = torch.randperm(nq)[:n].to(torch.int32).to(dev)
+    eps, sub = rnd(dev, n * reps, Z, seed=2), rnd(dev, n * reps, Z, seed=3)
+    for src in (idx, None):
+        muv, sdv = (mu, sd) if src is not None else (mu[:n], sd[:n])
+        out, out2 = torch.empty(n * reps, Z, device=dev), torch.empty(n * reps, Z, device=dev)
+        ro, ro2 = torch.empty_like(out), torch.empty_like(out2)
+        K.reparam_fwd(out, muv, sdv, eps, mode=mode, src_idx=src, reps=reps, sub=sub, out2=out2)
+        R.reparam_fwd(ro, muv, sdv, eps, mode=mode, src_idx=src, reps=reps, sub=sub, out2=ro2)
+        close(out, ro, rtol=1e-6, atol=1e-6)
+        close(out2, ro2, rtol=1e-6, atol=1e-6)
+        dz = rnd(dev, n * reps, Z, seed=4)
+        dQ = rnd(dev, nq, 2 * Z, seed=5)
+        rQ = dQ.clone()
+        K.reparam_bwd(dQ[:, :Z], dQ[:, Z:], dz, eps, sdv, mode=mode, src_idx=src, reps=reps, beta=1.0)
+        R.reparam_bwd(rQ[:, :Z], rQ[:, Z:], dz, eps, sdv, mode=mode, src_idx=src, reps=reps, beta=1.0)
+        close(dQ, rQ, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize('mode', [0, 1])
+@pytest.mark.parametrize('with_p', [True, False])
+def test_kl_rows(K, dev, mode, with_p):
+    n, reps, Z, nq = 9, 2, 100, 12
+    Rr = n * reps
+    Q, P = rnd(dev, nq, 2 * Z, seed=1, scale=0.7), rnd(dev, Rr + 3, 2 * Z, seed=2, scale=0.7)
+    if mode == 1:
+        Q[:, Z:] = Q[:, Z:].abs() + 0.2
+        P[:, Z:] = P[:, Z:].abs() + 0.2
+    mq, sq, mp, sp = Q[:, :Z], Q[:, Z:], P[:, :Z], P[:, Z:]
+    qidx = torch.randperm(nq)[:n].to(torch.int32).to(dev)
+    pidx = torch.randperm(Rr + 3)[:Rr].to(torch.int32).to(dev)
+    kw = dict(mode=mode, qidx=qidx, reps=reps, free_bits=True, kl_min=float(Z) * 0.3,
+              prior=(0.1, 0.2 if mode == 0 else 1.3))
+    pk = dict(mu_p=mp, sd_p=sp, pidx=pidx) if with_p else {}
+    out, raw, ro, rr = (torch.empty(Rr, device=dev) for _ in range(4))
+    K.kl_rows_fwd(out, raw, mq, sq, **pk, **kw)
+    R.kl_rows_fwd(ro, rr, mq, sq, **pk, **kw)
+    close(raw, rr, rtol=2e-5, atol=1e-4)
+    close(out, ro, rtol=2e-5, atol=1e-4)
+    coef = rnd(dev, Rr, seed=3)
+    dq, dp = rnd(dev, Rr, 2 * Z, seed=4), rnd(dev, Rr, 2 * Z, seed=5)
+    rq, rp = dq.clone(), dp.clone()
+    dpa = (dp[:, :Z], dp[:, Z:]) if with_p else (None, None)
+    rpa = (rp[:, :Z], rp[:, Z:]) if with_p else (None, None)
+    K.kl_rows_bwd(dq[:, :Z], dq[:, Z:], dpa[0], dpa[1], coef, raw, mq, sq, **pk, beta=1.0, **kw)
+    R.kl_rows_bwd(rq[:, :Z], rq[:, Z:], rpa[0], rpa[1], coef, rr, mq, sq, **pk, beta=1.0, **kw)
+    close(dq, rq, rtol=2e-5, atol=2e-5)
+    close(dp, rp, rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize('mode', [0, 1])
+@pytest.mark.parametrize('X,pad', [(978, 0), (978, 2), (980, 0), (13, 0), (20000, 0)])
+def test_nll_rows(K, dev, mode, X, pad):
+    M, nx = 23, 9
+    x = strided(dev, nx, X, pad, seed=1)
+    P = rnd(dev, M, 2 * (X + pad), seed=2)
+    mu, sd = P[:, :X], P[:, X + pad:2 * X + pad]
+    if mode == 1:
+        sd.copy_(torch.nn.functional.softplus(sd) + 1e-3)
+    xidx = torch.randint(0, nx, (M,)).to(torch.int32).to(dev)
+    out, ro = torch.empty(M, device=dev), torch.empty(M, device=dev)
+    K.nll_rows_fwd(out, x, mu, sd, mode=mode, xidx=xidx)
+    R.nll_rows_fwd(ro, x, mu, sd, mode=mode, xidx=xidx)
+    close(out, ro, rtol=2e-5, atol=1e-3)
+    coef = rnd(dev, M, seed=3)
+    D, RD = rnd(dev, M, 2 * X, seed=4), None
+    RD = D.clone()
+    dx, rdx = torch.zeros(M, X, device=dev), torch.zeros(M, X, device=dev)
+    kw = dict(mode=mode, xidx=xidx, beta=1.0)
+    if mode == 1:
+        kw.update(sd_act='softplus', sd_shift=1e-3)
+    K.nll_rows_bwd(D[:, :X], D[:, X:], coef, x, mu, sd, dx=dx, **kw)
+    R.nll_rows_bwd(RD[:, :X], RD[:, X:], coef, x, mu, sd, dx=rdx, **kw)
+    close(D, RD, rtol=2e-4, atol=2e-4)
+    close(dx, rdx, rtol=2e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize('Y,sig', [(2, False), (3, False), (7, False), (2, True)])
+def test_categorical(K, dev, Y, sig):
+    M = 301
+    logits = rnd(dev, M, 1 if sig else Y, seed=1, scale=4.0)
+    logits[0] = 60.0 if sig else torch.tensor([60.0] + [-60.0] * (Y - 1), device=dev)   # clamp active
+    p, rp = torch.empty(M, Y, device=dev), torch.empty(M, Y, device=dev)
+    K.softmax_clamp_fwd(p, logits, sig)
+    R.softmax_clamp_fwd(rp, logits, sig)
+    close(p, rp, rtol=1e-5, atol=1e-12)
+    assert float(p.min()) >= 1e-10 * 0.999
+    g = rnd(dev, M, Y, seed=2)
+    dl, rdl = rnd(dev, M, logits.shape[1], seed=3), None
+    rdl = dl.clone()
+    K.softmax_clamp_bwd(dl, g, p, sig, beta=1.0)
+    R.softmax_clamp_bwd(rdl, g, rp, sig, beta=1.0)
+    close(dl, rdl, rtol=1e-4, atol=1e-6)
+    labels = torch.randint(0, Y, (M,)).to(torch.int32).to(dev)
+    prior = torch.softmax(rnd(dev, M, Y, seed=4), -1)
+    logp, kl, ent = torch.empty(M, device=dev), torch.empty(M, Y, device=dev), torch.empty(M, device=dev)
+    best = torch.empty(M, dtype=torch.int32, device=dev)
+    rlogp, rkl, rent, rbest = torch.empty_like(logp), torch.empty_like(kl), torch.empty_like(ent), best.clone()
+    K.cat_terms_fwd(p, labels=labels, prior=prior, logp=logp, kl=kl, ent=ent, best=best)
+    R.cat_terms_fwd(rp, labels=labels, prior=prior, logp=rlogp, kl=rkl, ent=rent, best=rbest)
+    close(logp, rlogp, rtol=1e-5, atol=1e-5)
+    close(kl, rkl, rtol=1e-5, atol=1e-6)
+    close(ent, rent, rtol=1e-5, atol=1e-6)
+    assert bool((best == rbest).all())
+    c1, gk, c2 = rnd(dev, M, seed=5), rnd(dev, M, Y, seed=6), rnd(dev, M, seed=7)
+    dpb, rdp = rnd(dev, M, Y, seed=8), None
+    rdp = dpb.clone()
+    K.cat_terms_bwd(dpb, p, labels=labels, prior=prior, c_logp=c1, g_kl=gk, c_ent=c2, beta=1.0)
+    R.cat_terms_bwd(rdp, rp, labels=labels, prior=prior, c_logp=c1, g_kl=gk, c_ent=c2, beta=1.0)
+    close(dpb, rdp, rtol=1e-4, atol=1e-4)
+
+
+def test_ymarg(K, dev):
+    Rr, Y = 40, 3
+    lab = torch.rand(Rr) < 0.5
+    nf = torch.where(lab, torch.ones(Rr, dtype=torch.int64), torch.full((Rr,), Y))
+    fp_ptr = torch.cat([torch.zeros(1, dtype=torch.int64), nf.cumsum(0)]).to(torch.int32).to(dev)
+    F_ = int(fp_ptr[-1])
+    qy = torch.softmax(rnd(dev, Rr, Y, seed=1), -1)
+    label = torch.randint(0, Y, (Rr,)).to(torch.int32).to(dev)
+    klfp = rnd(dev, F_, seed=2).abs() + 2
+    lp = float(np.log(1.0 / Y))
+    yl, kld, ryl, rkld = (torch.empty(Rr, device=dev) for _ in range(4))
+    K.ymarg_fwd(yl, kld, qy, label, fp_ptr, klfp, lp)
+    R.ymarg_fwd(ryl, rkld, qy, label, fp_ptr, klfp, lp)
+    close(yl, ryl, rtol=1e-5, atol=1e-6)
+    close(kld, rkld, rtol=1e-5, atol=1e-5)
+    ck, cy = rnd(dev, Rr, seed=3), rnd(dev, Rr, seed=4)
+    cfp, dqy = torch.empty(F_, device=dev), torch.empty(Rr, Y, device=dev)
+    rcfp, rdqy = torch.empty(F_, device=dev), torch.empty(Rr, Y, device=dev)
+    K.ymarg_bwd(cfp, dqy, qy, label, fp_ptr, klfp, lp, ck, cy)
+    R.ymarg_bwd(rcfp, rdqy, qy, label, fp_ptr, klfp, lp, ck, cy)
+    close(cfp, rcfp, rtol=1e-5, atol=1e-6)
+    close(dqy, rdqy, rtol=1e-5, atol=1e-5)
+
+
+def test_row_movement(K, dev):
+    n, W, Y, ns = 19, 13, 3, 30
+    src, noise = strided(dev, ns, W, 2, seed=1), rnd(dev, n, W, seed=2)
+    idx = torch.randint(0, ns, (n,)).to(torch.int32).to(dev)
+    cls = torch.randint(0, Y, (n,)).to(torch.int32).to(dev)
+    out, ro = torch.zeros(n, W + Y + 1, device=dev), torch.zeros(n, W + Y + 1, device=dev)
+    K.rows_gather(out, src, idx, noise=noise, sigma=0.01, onehot_cls=cls, n_classes=Y)
+    R.rows_gather(ro, src, idx, noise=noise, sigma=0.01, onehot_cls=cls, n_classes=Y)
+    close(out, ro, rtol=0, atol=1e-6)
+    out2, ro2 = torch.zeros(n, W, device=dev), torch.zeros(n, W, device=dev)
+    K.rows_gather(out2, src[:n])
+    R.rows_gather(ro2, src[:n])
+    close(out2, ro2, rtol=0, atol=0)
+    # segment sum with CSR, weights and destination indices
+    sizes = torch.randint(0, 4, (7,))
+    ptr = torch.cat([torch.zeros(1, dtype=torch.int64), sizes.cumsum(0)]).to(torch.int32).to(dev)
+    T = int(ptr[-1])
+    rows = torch.randint(0, ns, (T,)).to(torch.int32).to(dev)
+    w = rnd(dev, T, seed=3)
+    didx = torch.randperm(11)[:7].to(torch.int32).to(dev)
+    dst, rdst = rnd(dev, 11, W, seed=4), None
+    rdst = dst.clone()
+    K.rows_segment_sum(dst, src, seg_ptr=ptr, seg_rows=rows, w=w, dst_idx=didx, beta=1.0)
+    R.rows_segment_sum(rdst, src, seg_ptr=ptr, seg_rows=rows, w=w, dst_idx=didx, beta=1.0)
+    close(dst, rdst, rtol=1e-5, atol=1e-5)
+    dst2, rdst2 = rnd(dev, 11, W, seed=5), None
+    rdst2 = dst2.clone()
+    K.rows_segment_sum(dst2, src, seg_rows=rows[:5] if T >= 5 else None, dst_idx=didx[:5], n=5, beta=1.0)
+    R.rows_segment_sum(rdst2, src, seg_rows=rows[:5] if T >= 5 else None, dst_idx=didx[:5], n=5, beta=1.0)
+    close(dst2, rdst2, rtol=1e-5, atol=1e-5)
+    x, wv = rnd(dev, 1000, seed=6), rnd(dev, 1000, seed=7)
+    o, r_ = torch.ones(1, device=dev), torch.ones(1)
+    K.weighted_sum(o, x, wv, scale=0.5, beta=1.0)
+    close(o, (1 + 0.5 * (x * wv).sum()).reshape(1), rtol=1e-4, atol=1e-4)
+    y, ry = rnd(dev, 1000, seed=8), None
+    ry = y.clone()
+    K.axpby(y, x, a=-2.0, b=0.5)
+    close(y, -2 * x + 0.5 * ry, rtol=1e-6, atol=1e-6)
+
+
+def test_adam_matches_torch_optim(K, dev):
+    n = 100003
+    p0, g = rnd(dev, n, seed=1), rnd(dev, n, seed=2)
+    p = p0.clone()
+    m, v = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    step = torch.zeros(1, dtype=torch.int32, device=dev)
+    ref = p0.clone().cpu().requires_grad_(True)
+    opt = torch.optim.Adam([ref], lr=5e-4, weight_decay=0.05)
+    for it in range(3):
+        gi = g * (it + 1)
+        K.counter_add(step, 1)
+        K.adam_l2(p, gi, m, v, step, lr=5e-4, weight_decay=0.05)
+        ref.grad = gi.cpu().clone()
+        opt.step()
+    assert int(step.item()) == 3
+    close(p, ref.detach(), rtol=1e-6, atol=1e-7)
+
+
+def test_fill_normal_statistics_and_counter(K, dev):
+    n = 1 << 20
+    a, b = torch.empty(n, device=dev), torch.empty(n, device=dev)
+    ctr = torch.zeros(2, dtype=torch.int32, device=dev)
+    K.fill_normal(a, 1234, ctr)
+    K.fill_normal(b, 1234, ctr)
+    close(a, b, rtol=0, atol=0)                       # same (seed, counter) -> same stream
+    K.counter_add(ctr, n // 4)
+    K.fill_normal(b, 1234, ctr)
+    assert float((a - b).abs().max()) > 0             # advanced counter -> fresh stream
+    assert abs(float(a.mean())) < 5e-3 and abs(float(a.std()) - 1) < 5e-3
+    assert abs(float((a ** 3).mean())) < 2e-2 and abs(float((a ** 4).mean()) - 3) < 5e-2
+    assert bool(torch.isfinite(a).all())
+    c2 = torch.tensor([-1, 0], dtype=torch.int32, device=dev)     # 0x00000000ffffffff + 1 carries
+    K.counter_add(c2, 1)
+    assert c2.tolist() == [0, 1]
