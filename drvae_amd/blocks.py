@@ -52,7 +52,7 @@ def _apply_linear(layer, inputs, act='identity', shift=0.0):
 def _run_sequential(seq, inputs, shift=0.0):
     """Evaluate an nn.Sequential of [Dropout|BatchNorm|Linear|activation] modules, fusing each
     Linear with the activation module that follows it into one GEMM launch."""
-    mods = list(seq.children())
+    mods = list(seq._modules.values())      # not children(): it de-duplicates the shared activation module
     x, i, shifted = list(inputs), 0, (shift == 0.0)
     while i < len(mods):
         m = mods[i]

@@ -1,0 +1,629 @@
+"""Fused ELBO train step for DrVAE / PVAE / VFAE: hand-written forward AND backward
+as one static sequence of HIP kernel launches over pre-allocated buffers (no autograd,
+no allocation, no host sync) -> capturable in a hipGraph and replayed per step.
+
+Restructuring relative to the reference (arithmetic identical):
+  * the 4 data groups (ls/us/lp/up, src/DrVAE.py:585-608), the L Monte-Carlo samples
+    (src/DrVAE.py:421) and the per-class passes for unlabeled rows (src/DrVAE.py:520-524)
+    are stacked into the GEMM M dimension: every Linear layer runs ONCE per step;
+  * group membership becomes row-index lists; the loss is linear in per-row terms with
+    coefficients known before the forward pass (1/(L N), beta_pert ..., src/DrVAE.py:611-624),
+    so the backward starts directly from per-row coefficients;
+  * both heads of a block are one GEMM with a split epilogue; bias gradients ride on the
+    dW GEMM; every scatter-add is a deterministic segment sum (no atomics).
+
+Row layout (B rows, Np pairs, L samples):
+  XIN  [B + Np]            noisy x1 rows, then noisy x2 rows of the pairs    (src/DrVAE.py:404-418)
+  Q    [B + Np, 2 Z1]      (mu | logvar) of q(z1|x1) and q(z2|x2)            (shared encoder, src/DrVAE.py:418)
+  ZDEC [L B + 2 L Np, Z1]  z1 samples | z2 samples (from qz1: src/DrVAE.py:427) | z2Fz1 samples of pairs
+  fprop rows               per (l, row): 1 row if labeled else Y rows        (src/DrVAE.py:503-526)
+"""
+import math
+from collections import OrderedDict
+from dataclasses import dataclass, field
+from typing import List
+
+import numpy as np
+import torch
+
+from . import kernels as K
+from ._lib import GAUSS_LOGVAR, GAUSS_SIGMA
+from .arena import N_LOSS, ParamArena
+
+LOSS_IDX = {'RECL': 0, 'KLD': 1, 'PERT': 2, 'YL': 3, 'MMD': 4, 'ELBO': 5, 'CMPL': 6}
+
+
+@dataclass
+class StepConfig:
+    """Shapes and hyper-parameters that reach the loss (ctor args of src/DrVAE.py:45-69,
+    src/PVAE.py:46-62, src/VFAE.py:42-61 plus the attributes hard-coded in their __init__)."""
+    kind: str = 'drvae'
+    dim_x: int = 978
+    dim_y: int = 2
+    dim_z1: int = 100
+    dim_z3: int = 100
+    h_en_z1: List[int] = field(default_factory=lambda: [800])
+    h_de_z1: List[int] = field(default_factory=lambda: [200])
+    h_en_z3: List[int] = field(default_factory=lambda: [200])
+    h_de_x: List[int] = field(default_factory=lambda: [600])
+    h_clf: List[int] = field(default_factory=list)
+    nonlin: str = 'elu'
+    weight_norm: bool = False
+    L: int = 2
+    learning_rate: float = 5e-4
+    weight_decay: float = 0.05
+    add_noise_var: float = 0.01
+    yloss_rate: float = 1.0
+    kl_qz2pz2_rate: float = 1.0
+    pertloss_rate: float = 0.05
+    anneal_perturb_rate_itermax: int = 1
+    anneal_perturb_rate_offset: int = 0
+    clf_z1z2: bool = True
+    semi_supervised: bool = True
+    kl_min: float = 2.0
+    optim_alg: str = 'adam'
+
+    @property
+    def top_name(self):
+        return 'encoder_z2' if self.kind == 'vfae' else 'encoder_z3'
+
+    @property
+    def has_pert(self):
+        return self.kind in ('drvae', 'pvae')
+
+    @property
+    def has_y(self):
+        return self.kind in ('drvae', 'vfae')
+
+
+def anneal_coef(iter_num, iter_max=1000, iter_offset=0):
+    """src/DGMMixin.py:77-89."""
+    if iter_num - iter_offset > 0:
+        return min(1., 0.01 + (iter_num - iter_offset) / (1. * iter_max))
+    return 0.01
+
+
+def param_shapes(cfg):
+    """state_dict name -> shape in the reference's construction order (src/DrVAE.py:112-183,
+    src/PVAE.py:106-153, src/VFAE.py:103-165)."""
+    out = OrderedDict()
+
+    def lin(prefix, n_in, n_out):
+        out[prefix + '.weight'] = (n_out, n_in)
+        out[prefix + '.bias'] = (n_out,)
+        if cfg.weight_norm:
+            out[prefix + '.g'] = (n_out,)
+
+    def trunk(prefix, n_in, hidden):
+        for i, h in enumerate(hidden, start=1):
+            lin('%s.model.linear%d' % (prefix, i), n_in, h)
+            n_in = h
+        return n_in
+
+    def gauss(prefix, n_in, hidden, n_out, second='lv'):
+        n = trunk(prefix + '.nnet', n_in, hidden)
+        lin(prefix + '.encoder_mu.linear_mu', n, n_out)
+        lin('%s.encoder_%s.linear_%s' % (prefix, second, second), n, n_out)
+
+    X, Y, Z1, Z3 = cfg.dim_x, cfg.dim_y, cfg.dim_z1, cfg.dim_z3
+    gauss('encoder_z1', X, cfg.h_en_z1, Z1)
+    if cfg.has_pert:
+        out['decoder_z2Fz1.W_mu'] = (Z1, Z1)
+        out['decoder_z2Fz1.bias_mu'] = (Z1,)
+        out['decoder_z2Fz1.encoder_lv.linear_lv.weight'] = (Z1, Z1)
+        out['decoder_z2Fz1.encoder_lv.linear_lv.bias'] = (Z1,)
+    if cfg.has_y:
+        n_in = 2 * Z1 if (cfg.kind == 'drvae' and cfg.clf_z1z2) else Z1
+        n = trunk('encoder_y.nnet', n_in, cfg.h_clf)
+        lin('encoder_y.decoder_p.linear_p', n, Y)
+        gauss(cfg.top_name, Z1 + Y, cfg.h_en_z3, Z3)
+        gauss('decoder_z1', Z3 + Y, cfg.h_de_z1, Z1)
+    gauss('decoder_x', Z1, cfg.h_de_x, X, second='sg')
+    return out
+
+
+def _pad4(n):
+    return (n + 3) // 4 * 4
+
+
+class _Lin:
+    """One Linear layer (or two fused heads) bound to arena views."""
+
+    def __init__(self, arena, wname, bname, gname=None, second=None, act='identity', act1=None, shift0=0.0,
+                 shift1=0.0):
+        if second is None:
+            self.W, self.dW = arena.p(wname), arena.g(wname)
+            self.b, self.db = arena.p(bname), arena.g(bname)
+            self.g = arena.p(gname) if gname else None
+            self.dg = arena.g(gname) if gname else None
+            self.split = self.W.shape[0]
+        else:
+            w2, b2, g2 = second
+            self.W, self.dW = arena.fused(arena.param, wname, w2), arena.fused(arena.grad, wname, w2)
+            self.b, self.db = arena.fused(arena.param, bname, b2), arena.fused(arena.grad, bname, b2)
+            self.g = arena.fused(arena.param, gname, g2) if gname and g2 else None
+            self.dg = arena.fused(arena.grad, gname, g2) if gname and g2 else None
+            self.split = arena.shapes[wname][0]
+        self.N, self.Kin = self.W.shape
+        self.act0, self.act1 = act, (act if act1 is None else act1)
+        self.shift0, self.shift1 = shift0, shift1
+        dev = self.W.device
+        if self.g is not None:
+            self.scale = torch.empty(self.N, device=dev)
+            self.norm = torch.empty(self.N, device=dev)
+            self.raw = torch.empty(self.N, self.Kin, device=dev)
+        else:
+            self.scale = self.norm = self.raw = None
+
+
+class _Chain:
+    """trunk layers + final layer of one block evaluated on M stacked rows, with buffers."""
+
+    def __init__(self, layers, M, device, resid_cols=0):
+        self.layers, self.M, self.resid_cols = layers, M, resid_cols
+        self.out = [torch.zeros(M, _pad4(l.N), device=device)[:, :l.N] for l in layers]
+        # gradient w.r.t. the pre-activation of every layer but the last (the caller owns that one)
+        self.dpre = [torch.zeros(M, _pad4(l.N), device=device)[:, :l.N] for l in layers[:-1]]
+
+    def forward(self, inputs, resid=None):
+        x = list(inputs)
+        for li, l in enumerate(self.layers):
+            if l.g is not None:
+                K.wn_scale(l.scale, l.norm, l.W, l.g)
+            last = li == len(self.layers) - 1
+            K.linear_fwd(self.out[li], x[0], l.W, l.b, x2=x[1] if len(x) > 1 else None, scale=l.scale, split=l.split,
+                         act0=l.act0, act1=l.act1, shift0=l.shift0, shift1=l.shift1,
+                         resid=resid if last else None, resid_cols=self.resid_cols if (last and resid is not None) else 0)
+            x = [self.out[li]]
+        return self.out[-1]
+
+    def backward(self, dpre_last, inputs, dinputs=None):
+        """dpre_last: gradient w.r.t. the last layer's pre-activation.  ``dinputs``: per input
+        source a list of (dst, alpha, beta) destinations for its gradient (or None to skip)."""
+        dpre = dpre_last
+        for li in range(len(self.layers) - 1, -1, -1):
+            l = self.layers[li]
+            srcs = list(inputs) if li == 0 else [self.out[li - 1]]
+            dW = l.raw if l.g is not None else l.dW
+            c0 = 0
+            for si, s in enumerate(srcs):
+                w = s.shape[1]
+                K.linear_bwd_weight(dW[:, c0:c0 + w], dpre, s, dbias=l.db if si == 0 else None)
+                c0 += w
+            if l.g is not None:
+                K.wn_bwd(l.dW, l.dg, l.raw, l.W, l.g, l.norm)
+            if li > 0:
+                prev = self.layers[li - 1]
+                K.linear_bwd_data(self.dpre[li - 1], dpre, l.W, kscale=l.scale, yref=self.out[li - 1], act=prev.act0,
+                                  shift=prev.shift0)
+                dpre = self.dpre[li - 1]
+            elif dinputs is not None:
+                c0 = 0
+                for si, s in enumerate(srcs):
+                    w = s.shape[1]
+                    for (dst, alpha, beta) in (dinputs[si] or []):
+                        K.linear_bwd_data(dst, dpre, l.W[:, c0:c0 + w], kscale=l.scale, alpha=alpha, beta=beta)
+                    c0 += w
+
+
+class FusedStep:
+    """Owns the arena views, the per-batch plan (index lists + buffers) and the launch
+    sequence.  Typical use::
+
+        eng = FusedStep(cfg, arena)
+        eng.set_batch(x1, x2, y, has_x2, has_y)      # device tensors + host flags
+        eng.set_noise(noise) | eng.draw_noise()
+        eng.forward(); eng.backward(); eng.optimizer_step()
+    """
+
+    def __init__(self, cfg, arena, seed=12345):
+        self.cfg, self.arena = cfg, arena
+        self.dev = arena.device
+        self.iters = 0                      # finished_training_iters (src/DGMMixin.py:124)
+        self.plan = None
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=self.dev)       # Adam step (device side)
+        self.rng_ctr = torch.zeros(2, dtype=torch.int32, device=self.dev)        # Philox counter (device side)
+        self.seed = seed
+        self.training = True
+        self._build_layers()
+
+    # ------------------------------------------------------------------ layer table
+    def _gauss(self, prefix, n_hidden, second, act_second='identity', shift_second=0.0):
+        cfg, a = self.cfg, self.arena
+        wn = cfg.weight_norm
+        layers = []
+        for i in range(1, n_hidden + 1):
+            p = '%s.nnet.model.linear%d' % (prefix, i)
+            layers.append(_Lin(a, p + '.weight', p + '.bias', p + '.g' if wn else None, act=cfg.nonlin))
+        m = prefix + '.encoder_mu.linear_mu'
+        s = '%s.encoder_%s.linear_%s' % (prefix, second, second)
+        layers.append(_Lin(a, m + '.weight', m + '.bias', m + '.g' if wn else None,
+                           second=(s + '.weight', s + '.bias', s + '.g' if wn else None),
+                           act='identity', act1=act_second, shift1=shift_second))
+        return layers
+
+    def _build_layers(self):
+        cfg, a = self.cfg, self.arena
+        wn = cfg.weight_norm
+        self.L_enc = self._gauss('encoder_z1', len(cfg.h_en_z1), 'lv', shift_second=-2.0)
+        self.L_decx = self._gauss('decoder_x', len(cfg.h_de_x), 'sg', 'softplus', 1e-3)
+        if cfg.has_pert:
+            p = 'decoder_z2Fz1.'
+            self.L_z2F = [_Lin(a, p + 'W_mu', p + 'bias_mu', None,
+                               second=(p + 'encoder_lv.linear_lv.weight', p + 'encoder_lv.linear_lv.bias', None),
+                               act='identity', shift1=-2.0)]
+        if cfg.has_y:
+            layers = []
+            for i in range(1, len(cfg.h_clf) + 1):
+                q = 'encoder_y.nnet.model.linear%d' % i
+                layers.append(_Lin(a, q + '.weight', q + '.bias', q + '.g' if wn else None, act=cfg.nonlin))
+            q = 'encoder_y.decoder_p.linear_p'
+            layers.append(_Lin(a, q + '.weight', q + '.bias', q + '.g' if wn else None))
+            self.L_clf = layers
+            self.L_top = self._gauss(cfg.top_name, len(cfg.h_en_z3), 'lv', shift_second=-2.0)
+            self.L_dz1 = self._gauss('decoder_z1', len(cfg.h_de_z1), 'lv', shift_second=-2.0)
+
+    # ------------------------------------------------------------------------- plan
+    def set_batch(self, x1, x2, y, has_x2, has_y, counts=None):
+        """x1,x2: (B,X) device fp32; y: (B,) or (B,1) ints (host or device); has_*: host bool/int
+        arrays.  ``counts`` = (N_total, N_pairs, N_labeled) GLOBAL normalisers under data
+        parallelism; default: this batch's own counts (src/DrVAE.py:611-616)."""
+        cfg = self.cfg
+        has_x2 = np.asarray(has_x2.cpu() if torch.is_tensor(has_x2) else has_x2).astype(bool).reshape(-1)
+        has_y = np.asarray(has_y.cpu() if torch.is_tensor(has_y) else has_y).astype(bool).reshape(-1)
+        yv = np.asarray(y.cpu() if torch.is_tensor(y) else y).astype(np.int64).reshape(-1) if y is not None \
+            else np.zeros(len(has_y), np.int64)
+        if not cfg.has_pert:
+            has_x2 = np.zeros_like(has_x2)
+        if not cfg.has_y:
+            has_y = np.zeros_like(has_y)
+        rows = np.arange(len(has_y))
+        if cfg.kind == 'vfae' and not cfg.semi_supervised:
+            rows = rows[has_y]               # supervised-only model ignores unlabeled rows (src/VFAE.py:445-450)
+        key = (len(rows), has_x2[rows].tobytes(), has_y[rows].tobytes(), yv[rows].tobytes(), counts)
+        if self.plan is None or self.plan.key != key:
+            self.plan = _Plan(self, rows, has_x2[rows], has_y[rows], yv[rows], counts, key)
+        p = self.plan
+        sel = torch.as_tensor(rows, device=self.dev) if len(rows) != len(has_y) else None
+        p.x1 = x1.index_select(0, sel).contiguous() if sel is not None else x1
+        p.x2 = (x2.index_select(0, sel).contiguous() if sel is not None else x2) if x2 is not None else None
+        return p
+
+    # ------------------------------------------------------------------------ noise
+    def set_noise(self, noise):
+        """Inject explicit N(0,1) draws addressed by global row (``oracle.models_ref.make_noise``
+        layout: nx1/nx2 (B,X); ez1/ez2/ez2F (L,B,Z1); ez3 (L,Y,B,Z3))."""
+        p, cfg = self.plan, self.cfg
+        t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32)
+        rows, L = p.rows, cfg.L
+        p.EX[:p.B].copy_(t(np.asarray(noise['nx1'])[rows]))
+        if p.Np:
+            pr = rows[p.pair_host]
+            p.EX[p.B:].copy_(t(np.asarray(noise['nx2'])[pr]))
+            p.E2.copy_(t(np.asarray(noise['ez2'])[:, pr].reshape(L * p.Np, -1)))
+        p.E1.copy_(t(np.asarray(noise['ez1'])[:, rows].reshape(L * p.B, -1)))
+        if cfg.has_pert:
+            p.E2F.copy_(t(np.asarray(noise['ez2F'])[:, rows].reshape(L * p.B, -1)))
+        if cfg.has_y and p.Mf:
+            ez3 = np.asarray(noise['ez3'])
+            p.E3.copy_(t(ez3[p.fp_l_host, p.fp_slot_host, rows[p.fp_i_host]]))
+
+    def draw_noise(self):
+        """Fresh on-device N(0,1) for every draw of the step (Philox, one launch)."""
+        K.fill_normal(self.plan.noise, self.seed, self.rng_ctr)
+        K.counter_add(self.rng_ctr, (self.plan.noise.numel() + 3) // 4)
+
+    # ---------------------------------------------------------------------- forward
+    def beta_pert(self):
+        cfg = self.cfg
+        if cfg.anneal_perturb_rate_itermax > 0:
+            return anneal_coef(self.iters, cfg.anneal_perturb_rate_itermax, cfg.anneal_perturb_rate_offset)
+        return 1.
+
+    def forward(self):
+        cfg, p = self.cfg, self.plan
+        p.set_beta(self.beta_pert())
+        B, Np, L, Z1 = p.B, p.Np, cfg.L, cfg.dim_z1
+        sigma = cfg.add_noise_var if (self.training and cfg.add_noise_var > 0) else 0.0
+        # ---- inputs (+ training noise N(0,1)*add_noise_var, src/DrVAE.py:404-407,414-417)
+        K.rows_gather(p.XIN[:B], p.x1, None, noise=p.EX[:B] if sigma else None, sigma=sigma)
+        if Np:
+            K.rows_gather(p.XIN[B:], p.x2, p.pair_idx, noise=p.EX[B:] if sigma else None, sigma=sigma)
+        # ---- q(z1|x1), q(z2|x2): one pass of the shared encoder
+        Q = p.c_enc.forward([p.XIN])
+        Qmu, Qlv = Q[:, :Z1], Q[:, Z1:]
+        # ---- samples (reparameterisation, src/blocks.py:170-174)
+        Z1blk = p.ZDEC[:L * B]
+        K.reparam_fwd(Z1blk, Qmu, Qlv, p.E1, reps=L)
+        if Np:
+            K.reparam_fwd(p.ZDEC[p.o2:p.o3], Qmu, Qlv, p.E2, src_idx=p.pair_idx, reps=L)   # from qz1! (quirk 1)
+        if cfg.has_pert:
+            P2 = p.c_z2F.forward([Z1blk], resid=Z1blk)
+            K.reparam_fwd(p.Z2F, P2[:, :Z1], P2[:, Z1:], p.E2F, sub=Z1blk, out2=p.D)
+            if Np:
+                K.rows_gather(p.ZDEC[p.o3:], p.Z2F, p.pidx)
+                K.kl_rows_fwd(p.KLZ2, p.KLZ2raw, Qmu, Qlv, P2[:, :Z1], P2[:, Z1:], qidx=p.qz2_idx, pidx=p.pidx,
+                              reps=L, free_bits=True, kl_min=cfg.kl_min)
+        if cfg.kind == 'pvae':
+            K.kl_rows_fwd(p.KLP, p.KLPraw, Qmu, Qlv, prior=(0.0, 0.0), free_bits=True, kl_min=cfg.kl_min)
+        # ---- p(x|z): decoder over all stacked samples, then the NLL over genes
+        X = cfg.dim_x
+        PX = p.c_decx.forward([p.ZDEC])
+        K.nll_rows_fwd(p.NLL, p.XIN, PX[:, :X], PX[:, X:], mode=GAUSS_SIGMA, xidx=p.tgt)
+        # ---- q(y|.), fprop over (labeled: true class | unlabeled: every class)
+        if cfg.has_y:
+            if cfg.kind == 'drvae':
+                clf_in = [Z1blk, p.D] if cfg.clf_z1z2 else [p.Z2F]
+            else:
+                clf_in = [Z1blk]
+            logits = p.c_clf.forward(clf_in)
+            K.softmax_clamp_fwd(p.QY, logits)
+            if p.Mf:
+                Z3, Y = cfg.dim_z3, cfg.dim_y
+                K.rows_gather(p.FPIN, Z1blk, p.fp_src, onehot_cls=p.fp_cls, n_classes=Y)
+                Q3 = p.c_top.forward([p.FPIN])
+                K.reparam_fwd(p.Z3IN[:, :Z3], Q3[:, :Z3], Q3[:, Z3:], p.E3)
+                K.kl_rows_fwd(p.KL3, p.KL3raw, Q3[:, :Z3], Q3[:, Z3:], prior=(0.0, 0.0), free_bits=True,
+                              kl_min=cfg.kl_min)
+                PZ1 = p.c_dz1.forward([p.Z3IN])
+                K.kl_rows_fwd(p.KL1, p.KL1raw, Qmu, Qlv, PZ1[:, :Z1], PZ1[:, Z1:], qidx=p.fp_q, free_bits=True,
+                              kl_min=cfg.kl_min)
+                K.axpby(p.KLFP, p.KL3, 1.0, 0.0)
+                K.axpby(p.KLFP, p.KL1, 1.0, 1.0)
+            K.ymarg_fwd(p.YLrow, p.KLDrow, p.QY, p.label_r, p.fp_ptr, p.KLFP, math.log(1.0 / cfg.dim_y))
+        self._loss_scalars()
+
+    def _loss_scalars(self):
+        """RECL, KLD, PERT, YL, ELBO, CMPL (src/DrVAE.py:611-624) as device scalars."""
+        cfg, p = self.cfg, self.plan
+        loss = self.arena.loss
+        L = cfg.L
+        loss.zero_()
+        K.weighted_sum(loss[0:1], p.NLL[:p.o3], scale=1.0 / (L * p.n_tot))
+        if cfg.has_pert and p.Np:
+            K.weighted_sum(loss[2:3], p.NLL[p.o3:], scale=1.0 / (L * max(1., p.n_pairs)))
+            K.weighted_sum(loss[1:2], p.KLZ2, scale=p.beta * cfg.kl_qz2pz2_rate / (L * p.n_tot))
+        if cfg.kind == 'pvae':
+            K.weighted_sum(loss[1:2], p.KLP, scale=1.0 / p.n_tot, beta=1.0)
+        if cfg.has_y:
+            K.weighted_sum(loss[1:2], p.KLDrow, scale=1.0 / (L * p.n_tot), beta=1.0)
+            K.weighted_sum(loss[3:4], p.YLrow, scale=1.0 / (L * max(1., p.n_lab)))
+        K.weighted_sum(loss[5:6], loss[0:3], w=p.w_elbo)
+        K.weighted_sum(loss[6:7], loss, w=p.w_cmpl, n=N_LOSS)
+
+    # --------------------------------------------------------------------- backward
+    def backward(self):
+        cfg, p = self.cfg, self.plan
+        B, Np, L, Z1, X = p.B, p.Np, cfg.L, cfg.dim_z1, cfg.dim_x
+        Q = p.c_enc.out[-1]
+        Qmu, Qlv = Q[:, :Z1], Q[:, Z1:]
+        DQ = p.DQ
+        Z1blk, DZ1 = p.ZDEC[:L * B], p.DZDEC[:L * B]
+        # ---- reconstruction terms: d/d(mu, pre-softplus) straight from the per-row coefficients
+        PX = p.c_decx.out[-1]
+        K.nll_rows_bwd(p.DPX[:, :X], p.DPX[:, X:], p.c_nll, p.XIN, PX[:, :X], PX[:, X:], mode=GAUSS_SIGMA,
+                       xidx=p.tgt, sd_act='softplus', sd_shift=1e-3)
+        p.c_decx.backward(p.DPX, [p.ZDEC], [[(p.DZDEC, 1.0, 0.0)]])
+        if cfg.has_y:
+            Y = cfg.dim_y
+            K.ymarg_bwd(p.CFP, p.DQY, p.QY, p.label_r, p.fp_ptr, p.KLFP, math.log(1.0 / Y), p.c_kld, p.c_yl)
+            if p.Mf:
+                Z3 = cfg.dim_z3
+                PZ1, Q3 = p.c_dz1.out[-1], p.c_top.out[-1]
+                # KL(q(z1|x) || p(z1|z3,y)): gradient to p (decoder_z1 heads) and, row-aligned, to q
+                K.kl_rows_bwd(p.DQFP[:, :Z1], p.DQFP[:, Z1:], p.DPZ1[:, :Z1], p.DPZ1[:, Z1:], p.CFP, p.KL1raw,
+                              Qmu, Qlv, PZ1[:, :Z1], PZ1[:, Z1:], qidx=p.fp_q, free_bits=True, kl_min=cfg.kl_min)
+                p.c_dz1.backward(p.DPZ1, [p.Z3IN], [[(p.DZ3IN, 1.0, 0.0)]])
+                # KL(q(z3|z1,y) || N(0,I)) + the sample path
+                K.kl_rows_bwd(p.DQ3[:, :Z3], p.DQ3[:, Z3:], None, None, p.CFP, p.KL3raw, Q3[:, :Z3], Q3[:, Z3:],
+                              prior=(0.0, 0.0), free_bits=True, kl_min=cfg.kl_min)
+                K.reparam_bwd(p.DQ3[:, :Z3], p.DQ3[:, Z3:], p.DZ3IN[:, :Z3], p.E3, Q3[:, Z3:], beta=1.0)
+                p.c_top.backward(p.DQ3, [p.FPIN], [[(p.DFPIN, 1.0, 0.0)]])
+                # z1 feeds one (labeled) or Y (unlabeled) fprop rows
+                K.rows_segment_sum(DZ1, p.DFPIN, seg_ptr=p.fp_ptr, beta=1.0, width=Z1)
+            # classifier
+            K.softmax_clamp_bwd(p.DLOG, p.DQY, p.QY)
+            if cfg.kind == 'drvae' and cfg.clf_z1z2:
+                p.c_clf.backward(p.DLOG, [Z1blk, p.D],
+                                 [[(DZ1, 1.0, 1.0)], [(p.DZ2F, 1.0, 0.0), (DZ1, -1.0, 1.0)]])
+            elif cfg.kind == 'drvae':
+                p.c_clf.backward(p.DLOG, [p.Z2F], [[(p.DZ2F, 1.0, 0.0)]])
+            else:
+                p.c_clf.backward(p.DLOG, [Z1blk], [[(DZ1, 1.0, 1.0)]])
+        elif cfg.has_pert:
+            p.DZ2F.zero_()
+        if cfg.has_pert:
+            P2 = p.c_z2F.out[-1]
+            if Np:
+                # z2Fz1 samples of the pairs were decoded (PERT term): scatter their gradient back
+                K.rows_segment_sum(p.DZ2F, p.DZDEC[p.o3:], dst_idx=p.pidx, beta=1.0, n=L * Np)
+            K.reparam_bwd(p.DP2[:, :Z1], p.DP2[:, Z1:], p.DZ2F, p.E2F, P2[:, Z1:])
+            if Np:
+                # KL(q(z2|x2) || p(z2|z1)) with free bits, src/DrVAE.py:466,482-487
+                K.kl_rows_bwd(p.TQ[:, :Z1], p.TQ[:, Z1:], p.TP[:, :Z1], p.TP[:, Z1:], p.c_klz2, p.KLZ2raw, Qmu, Qlv,
+                              P2[:, :Z1], P2[:, Z1:], qidx=p.qz2_idx, pidx=p.pidx, reps=L, free_bits=True,
+                              kl_min=cfg.kl_min)
+                K.rows_segment_sum(p.DP2, p.TP, dst_idx=p.pidx, beta=1.0, n=L * Np)
+                K.rows_segment_sum(DQ[B:], p.TQ, seg_ptr=p.z2_ptr, seg_rows=p.z2_rows)
+            # perturbation function: mu = z1 + z1 W^T + b (residual), logvar head
+            p.c_z2F.backward(p.DP2, [Z1blk], [[(DZ1, 1.0, 1.0)]])
+            K.rows_segment_sum(DZ1, p.DP2, beta=1.0, width=Z1, n=L * B)
+        # ---- back through the samples into q(z1|x1)
+        K.reparam_bwd(DQ[:B, :Z1], DQ[:B, Z1:], DZ1, p.E1, Qlv, reps=L)
+        if Np:
+            K.reparam_bwd(DQ[:, :Z1], DQ[:, Z1:], p.DZDEC[p.o2:p.o3], p.E2, Qlv, src_idx=p.pair_idx, reps=L,
+                          beta=1.0)
+        if cfg.has_y and p.Mf:
+            K.rows_segment_sum(DQ, p.DQFP, seg_ptr=p.q_ptr, seg_rows=p.q_rows, beta=1.0)
+        if cfg.kind == 'pvae':
+            K.kl_rows_bwd(DQ[:, :Z1], DQ[:, Z1:], None, None, p.c_klp, p.KLPraw, Qmu, Qlv, prior=(0.0, 0.0),
+                          free_bits=True, kl_min=cfg.kl_min, beta=1.0)
+        p.c_enc.backward(DQ, [p.XIN], None)
+
+    # -------------------------------------------------------------------- optimiser
+    def optimizer_step(self, gscale=1.0):
+        """torch.optim.Adam with coupled L2 on EVERY parameter (src/DGMMixin.py:36)."""
+        cfg, a = self.cfg, self.arena
+        K.counter_add(self.step_dev, 1)
+        K.adam_l2(a.param, a.grad[:a.n_params], a.exp_avg, a.exp_avg_sq, self.step_dev, lr=cfg.learning_rate,
+                  weight_decay=cfg.weight_decay, gscale=gscale)
+
+    def train_step(self, noise=None, allreduce=None):
+        """forward + backward (+ gradient all-reduce) + Adam + iteration count: the body of
+        ``run_on_batch(train_mode=True)`` (src/DGMMixin.py:91-126)."""
+        self.training = True
+        if noise is not None:
+            self.set_noise(noise)
+        else:
+            self.draw_noise()
+        self.forward()
+        self.backward()
+        if allreduce is not None:
+            allreduce(self.arena.grad)
+        self.optimizer_step()
+        self.iters += 1
+
+    def losses(self):
+        """OrderedDict of python floats (one device->host copy; the only sync of a step)."""
+        v = self.arena.loss.detach().cpu().tolist()
+        keys = ['RECL', 'KLD', 'PERT', 'YL', 'MMD', 'ELBO', 'CMPL']
+        if self.cfg.kind == 'pvae':
+            keys.remove('YL')
+        if self.cfg.kind == 'vfae':
+            keys.remove('PERT')
+        return OrderedDict((k, v[LOSS_IDX[k]]) for k in keys)
+
+
+class _Plan:
+    """Index lists, coefficient vectors and buffers for one batch structure."""
+
+    def __init__(self, eng, rows, has_x2, has_y, yv, counts, key):
+        cfg, dev = eng.cfg, eng.dev
+        self.key, self.rows = key, rows
+        L, Y, X, Z1, Z3 = cfg.L, cfg.dim_y, cfg.dim_x, cfg.dim_z1, cfg.dim_z3
+        B = self.B = len(rows)
+        self.pair_host = np.nonzero(has_x2)[0]
+        Np = self.Np = len(self.pair_host)
+        n_lab = int(has_y.sum())
+        if counts is None:
+            counts = (B, Np, n_lab)
+        self.n_tot, self.n_pairs, self.n_lab = [float(c) for c in counts]
+        i32 = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.int32, device=dev)
+        zf = lambda *s: torch.zeros(*s, device=dev)
+
+        def mat(rws, cols):      # row stride padded to 16 B so that rows allow vector access
+            return torch.zeros(rws, _pad4(cols), device=dev)[:, :cols]
+
+        self.pair_idx = i32(self.pair_host)
+        Me = B + Np
+        self.o2, self.o3 = L * B, L * B + L * Np            # ZDEC block offsets (z2 | z2Fz1-of-pairs)
+        Md = L * B + 2 * L * Np
+        tgt = np.concatenate([np.tile(np.arange(B), L), np.tile(B + np.arange(Np), L), np.tile(B + np.arange(Np), L)])
+        self.tgt = i32(tgt)
+        self.pidx = i32((np.arange(L)[:, None] * B + self.pair_host[None, :]).reshape(-1))
+        self.qz2_idx = i32(B + np.arange(Np))
+        self.z2_ptr = i32(np.arange(Np + 1) * L)
+        self.z2_rows = i32((np.arange(L)[None, :] * Np + np.arange(Np)[:, None]).reshape(-1))
+        # ---- noise arena: one flat buffer, one Philox launch per step
+        sizes = [Me * X, L * B * Z1, L * Np * Z1, L * B * Z1 if cfg.has_pert else 0]
+        # fprop rows
+        self.Mf = 0
+        if cfg.has_y:
+            nf_row = np.where(has_y, 1, Y)                   # fprop rows per data row (per sample l)
+            fp_ptr = np.concatenate([[0], np.cumsum(np.tile(nf_row, L))])
+            self.Mf = int(fp_ptr[-1])
+            fl, fi, fslot, fcls = [], [], [], []
+            for l in range(L):
+                for i in range(B):
+                    if has_y[i]:
+                        fl.append(l); fi.append(i); fslot.append(0); fcls.append(int(yv[i]))
+                    else:
+                        for j in range(Y):
+                            fl.append(l); fi.append(i); fslot.append(j); fcls.append(j)
+            self.fp_l_host, self.fp_i_host = np.asarray(fl, np.int64), np.asarray(fi, np.int64)
+            self.fp_slot_host = np.asarray(fslot, np.int64)
+            self.fp_ptr = i32(fp_ptr)
+            self.fp_src = i32(self.fp_l_host * B + self.fp_i_host)
+            self.fp_cls = i32(np.asarray(fcls, np.int64))
+            self.fp_q = i32(self.fp_i_host)
+            order = np.argsort(self.fp_i_host, kind='stable')
+            self.q_rows = i32(order)
+            self.q_ptr = i32(np.concatenate([[0], np.cumsum(np.bincount(self.fp_i_host, minlength=B))]))
+            self.label_r = i32(np.tile(np.where(has_y, yv, 0), L))
+            sizes.append(self.Mf * Z3)
+        self.noise = zf(int(sum(sizes)))
+        views, o = [], 0
+        for s in sizes:
+            views.append(self.noise[o:o + s])
+            o += s
+        self.EX = views[0].view(Me, X)
+        self.E1 = views[1].view(L * B, Z1)
+        self.E2 = views[2].view(L * Np, Z1)
+        self.E2F = views[3].view(L * B, Z1) if cfg.has_pert else None
+        self.E3 = views[4].view(self.Mf, Z3) if cfg.has_y else None
+        # ---- activations / gradients
+        self.XIN = mat(Me, X)
+        self.ZDEC, self.DZDEC = mat(Md, Z1), mat(Md, Z1)
+        self.c_enc = _Chain(eng.L_enc, Me, dev)
+        self.c_decx = _Chain(eng.L_decx, Md, dev)
+        self.DQ = zf(Me, 2 * Z1)
+        self.DPX = mat(Md, 2 * X)
+        self.NLL = zf(Md)
+        if cfg.has_pert:
+            self.c_z2F = _Chain(eng.L_z2F, L * B, dev, resid_cols=Z1)
+            self.Z2F, self.D, self.DZ2F = mat(L * B, Z1), mat(L * B, Z1), mat(L * B, Z1)
+            self.DP2 = zf(L * B, 2 * Z1)
+            self.KLZ2, self.KLZ2raw = zf(L * Np), zf(L * Np)
+            self.TQ, self.TP = zf(L * Np, 2 * Z1), zf(L * Np, 2 * Z1)
+        if cfg.kind == 'pvae':
+            self.KLP, self.KLPraw = zf(Me), zf(Me)
+        if cfg.has_y:
+            R, Mf = L * B, self.Mf
+            self.c_clf = _Chain(eng.L_clf, R, dev)
+            self.QY, self.DQY, self.DLOG = zf(R, Y), zf(R, Y), zf(R, Y)
+            self.YLrow, self.KLDrow = zf(R), zf(R)
+            self.c_top = _Chain(eng.L_top, Mf, dev)
+            self.c_dz1 = _Chain(eng.L_dz1, Mf, dev)
+            self.FPIN, self.DFPIN = mat(Mf, Z1 + Y), mat(Mf, Z1 + Y)
+            self.Z3IN, self.DZ3IN = mat(Mf, Z3 + Y), mat(Mf, Z3 + Y)
+            self.DQ3, self.DPZ1, self.DQFP = zf(Mf, 2 * Z3), zf(Mf, 2 * Z1), zf(Mf, 2 * Z1)
+            self.KL3, self.KL3raw, self.KL1, self.KL1raw = zf(Mf), zf(Mf), zf(Mf), zf(Mf)
+            self.KLFP, self.CFP = zf(max(Mf, 1)), zf(max(Mf, 1))
+            if Mf:   # the one-hot class columns of the decoder_z1 input never change for this batch
+                oh = torch.zeros(Mf, Y, device=dev)
+                oh[torch.arange(Mf, device=dev), self.fp_cls.long()] = 1.0
+                self.Z3IN[:, Z3:] = oh
+        # ---- per-row loss coefficients dCMPL/d(row term) (src/DrVAE.py:611-624)
+        self.beta = None
+        self.c_nll = zf(Md)
+        self.c_nll[:self.o3] = -1.0 / (L * self.n_tot)
+        if cfg.has_y:
+            self.c_kld = torch.full((L * B,), 1.0 / (L * self.n_tot), device=dev)
+            self.c_yl = torch.full((L * B,), -cfg.yloss_rate / (L * max(1., self.n_lab)), device=dev)
+        if cfg.kind == 'pvae':
+            self.c_klp = torch.full((Me,), 1.0 / self.n_tot, device=dev)
+        if cfg.has_pert:
+            self.c_klz2 = zf(L * Np)
+        self.w_elbo = zf(3)
+        self.w_cmpl = zf(N_LOSS)
+        self._cfg = cfg
+        self.x1 = self.x2 = None
+
+    def set_beta(self, beta):
+        """(re)write the coefficients that depend on the perturbation annealing coefficient
+        (0.01 on the very first iteration, 1.0 afterwards with the driver settings)."""
+        if self.beta == beta:
+            return
+        cfg, L = self._cfg, self._cfg.L
+        self.beta = beta
+        if cfg.has_pert:
+            self.c_nll[self.o3:] = -beta * cfg.pertloss_rate / (L * max(1., self.n_pairs))
+            self.c_klz2.fill_(beta * cfg.kl_qz2pz2_rate / (L * self.n_tot))
+            self.w_elbo.copy_(torch.tensor([1.0, -1.0, beta * cfg.pertloss_rate]))
+        else:
+            self.w_elbo.copy_(torch.tensor([1.0, -1.0, 0.0]))
+        w = [0.0] * N_LOSS
+        w[LOSS_IDX['ELBO']] = -1.0
+        if cfg.has_y:
+            w[LOSS_IDX['YL']] = -cfg.yloss_rate
+        self.w_cmpl.copy_(torch.tensor(w))
