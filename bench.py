@@ -1,0 +1,238 @@
+#!/usr/bin/env python3
+"""Benchmark of the Dr.VAE ELBO train step on MI355X (contract: see the task brief).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg1|cfg4|wide]
+
+One "step" = one full train step (Philox noise + stacked forward + hand-written backward
++ gradient all-reduce + fused Adam) over one synthetic minibatch per GPU, inputs resident
+in HBM.  Prints ONE JSON line on rank 0 with the whole-job samples/s (rows x L), the
+roofline of the dominant kernel (the fp32 MFMA GEMM family, timed with HIP events on its
+launch stream) and a bounded CPU baseline (the oracle on this box's host cores).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (kind, rows/GPU, L, overrides, description)
+    'cfg2': ('drvae', 150, 2, {}, 'DrVAE bortezomib shape: 978 genes, z1=z3=100, enc-z1 800, dec-x 600, '
+                                  'enc-z3/dec-z1 200, batch 150/GPU, L=2'),
+    'cfg1': ('pvae', 150, 1, {}, 'PVAE: 978 genes, z1=100, enc 800, dec 600, batch 150/GPU, L=1'),
+    'cfg4': ('vfae', 150, 2, {'add_noise_var': 0.0}, 'VFAE/SSVAE: 978 genes, z1=z2=100, enc 800, dec 600, '
+                                                       'batch 150/GPU, L=2'),
+    'wide': ('drvae', 1024, 4, {'dim_x': 20000, 'dim_z1': 200, 'dim_z3': 200, 'h_en_z1': [2048],
+                                'h_de_x': [2048]},
+             'DrVAE wide synthetic: 20000 genes, z1=z3=200, enc 2048, dec 2048 (assumed), batch 1024/GPU, L=4'),
+}
+FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak (dense, exact fp32)
+
+
+def build(workload, device, rank, world, seed=123):
+    from drvae_amd import engine as E
+    from drvae_amd import synth
+    from drvae_amd.arena import ParamArena
+    kind, rows, L, over, desc = WORKLOADS[workload]
+    cfg = E.StepConfig(kind=kind, L=L, **over)
+    shapes = E.param_shapes(cfg)
+    arena = ParamArena(shapes, device)
+    rs = np.random.RandomState(seed)                 # random-init weights of that architecture
+    fan = 1
+    for k, shp in shapes.items():
+        if k.endswith('W_mu') or k.endswith('bias_mu'):
+            a = rs.uniform(-1e-4, 1e-4, shp)
+        else:
+            if k.endswith('.weight'):
+                fan = shp[1]
+            a = rs.uniform(-1, 1, shp) / np.sqrt(fan)
+        arena.p(k).copy_(torch.as_tensor(a, dtype=torch.float32))
+    eng = E.FusedStep(cfg, arena, seed=1000 + rank)
+    batch = synth.make_batch(kind, rows, cfg.dim_x, cfg.dim_y, seed=1234, row0=rank * rows)
+    hx, hy = batch['has_x2'].astype(bool), batch['has_y'].astype(bool)
+    # weak scaling: every rank has the same group mix, so the global counts are world * local
+    counts = (world * rows, world * int(hx.sum()), world * int(hy.sum()))
+    t = lambda k: torch.from_numpy(batch[k]).to(device)
+    eng.set_batch(t('x1'), t('x2'), batch['y'], hx, hy, counts=counts)
+    return cfg, eng, arena, batch, desc
+
+
+def cpu_baseline(workload, budget_s=12.0, threads=4):
+    """The CPU oracle (restatement of the reference's PyTorch-CPU train step, pinned to the
+    reference's own outputs by tests/golden) timed on this box's host cores."""
+    from oracle import models_ref as M
+    kind, rows, L, over, _ = WORKLOADS[workload]
+    spec = M.ModelSpec(kind=kind, L=L, **over)
+    torch.set_num_threads(threads)                   # the reference's own setting, src/run_drvae.py:40
+    tr = M.RefTrainer(spec, M.init_params(spec, 123))
+    batch = M.make_batch(spec, rows, seed=1234)
+    noises = [M.make_noise(spec, rows, seed=s) for s in range(2)]
+    tr.step(batch, noises[0])
+    tr.step(batch, noises[1])                        # skip iteration 0 (beta_pert differs) + warm caches
+    n, t0 = 0, time.perf_counter()
+    while True:
+        tr.step(batch, noises[n % 2])
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= budget_s or n >= 200:
+            break
+    return {'value': round(rows * L * n / dt, 1), 'unit': 'samples/s', 'cores': threads, 'kind': 'port',
+            'ms_per_step': round(1e3 * dt / n, 2),
+            'sample': '%d full train steps of the same workload (%s rows x L=%d) with torch.set_num_threads(%d), '
+                      '%.1f s of CPU work; host has %d logical cores' % (n, rows, L, threads, dt, os.cpu_count())}
+
+
+def gemm_roofline(eng, cfg, rows, frac_pair, frac_lab, repeats=20):
+    """Roofline of the dominant kernel family: the fp32-MFMA GEMM (all tilings/layouts; 32
+    launches per cfg-2 step).  Every GEMM launch of one train step is re-issued `repeats`
+    times back to back from a small hipGraph and timed with HIP events recorded on the
+    launch stream (so host launch latency is not in the bracket); the per-launch times are
+    summed over the step.  achieved = algorithmic GEMM FLOPs per step (SURVEY.md 8(d) model)
+    / that sum -- equivalently avg FLOPs per launch / avg launch duration."""
+    import drvae_amd.kernels as K
+    from drvae_amd import synth
+    calls = []
+    real = K.gemm
+
+    def rec(Cm, A, B, a_kc, b_kc, **kw):
+        calls.append((Cm, A, B, a_kc, b_kc, kw))
+        real(Cm, A, B, a_kc, b_kc, **kw)
+
+    K.gemm = rec
+    try:
+        eng.training = True
+        eng.draw_noise()
+        eng.forward()
+        eng.backward()
+        torch.cuda.synchronize()
+    finally:
+        K.gemm = real
+    per_call = []
+    for (Cm, A, B, a_kc, b_kc, kw) in calls:
+        kw = dict(kw)
+        keep = Cm.clone() if kw.get('beta', 0.0) != 0.0 else None
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(repeats):
+                real(Cm, A, B, a_kc, b_kc, **kw)
+        best = 1e30
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            g.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1) * 1e-3 / repeats)
+        if keep is not None:
+            Cm.copy_(keep)
+        M_, N_ = Cm.shape
+        K_ = (A.shape[1] + (kw['A2'].shape[1] if kw.get('A2') is not None else 0)) if a_kc else A.shape[0]
+        per_call.append((best, 2.0 * M_ * N_ * K_, (M_, N_, K_, int(bool(a_kc)), int(bool(b_kc)))))
+    t_step = sum(t for t, _, _ in per_call)
+    executed = sum(f for _, f, _ in per_call)
+    algorithmic = synth.gemm_flops_per_step(cfg, rows, frac_pair, frac_lab)
+    achieved = algorithmic / t_step / 1e12
+    top = sorted(per_call, key=lambda r: -r[0])[:3]
+    return {'bound': 'mfma', 'achieved': round(achieved, 3), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+            'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': None,
+            'kernel': 'gemm_kernel<...> (fp32 v_mfma_f32_32x32x2_f32; all tilings/layouts)',
+            'launches_per_step': len(per_call), 'avg_launch_us': round(1e6 * t_step / len(per_call), 2),
+            'gemm_us_per_step': round(1e6 * t_step, 1),
+            'algorithmic_gflop_per_step': round(algorithmic / 1e9, 3),
+            'executed_gflop_per_step': round(executed / 1e9, 3),
+            'top_launches': [{'MNK_akc_bkc': list(sh), 'us': round(1e6 * t, 2), 'tflops': round(f / t / 1e12, 2)}
+                             for t, f, sh in top]}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--workload', default='cfg2', choices=list(WORKLOADS))
+    ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    args = ap.parse_args()
+
+    from drvae_amd import _lib, dist as D
+    _lib.load()                                       # fail loudly if the HIP library is missing
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU (no CPU fallback for the hot path)')
+    rank, world, local = D.init_from_env()
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('launch with torch.distributed.run --nproc-per-node %d' % args.gpus)
+    torch.cuda.set_device(local)
+    device = torch.device('cuda', local)
+    import torch.distributed as dist
+
+    cfg, eng, arena, batch, desc = build(args.workload, device, rank, world)
+    kind, rows, L = WORKLOADS[args.workload][:3]
+    D.broadcast_params(arena)
+    allreduce = D.allreduce_sum if world > 1 else None
+
+    # iteration 0 runs eagerly (beta_pert = 0.01 only there), then the steady-state step is captured
+    eng.train_step(allreduce=allreduce)
+    use_graph = not args.no_graph
+    if use_graph:
+        eng.capture(split_for_allreduce=world > 1)
+        step = lambda: eng.replay(allreduce)
+    else:
+        step = lambda: eng.train_step(allreduce=allreduce)
+    for _ in range(max(args.warmup - 1, 0)):
+        step()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    losses = eng.losses()
+    ok = all(np.isfinite(v) for v in losses.values())
+
+    out = {
+        'metric': 'DrVAE ELBO training samples/sec (batch x L)', 'value': round(world * rows * L * args.steps / dt, 1),
+        'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': round(1e3 * dt / args.steps, 4), 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': '%s: %s' % (args.workload, desc), 'global_batch': world * rows, 'L': L,
+                   'parallelism': 'dp%d' % world, 'launch': 'hipGraph replay' if use_graph else 'eager',
+                   'params': int(sum(int(np.prod(s)) for s in arena.shapes.values()))},
+        'losses_last_step': {k: round(v, 4) for k, v in losses.items()}, 'finite': ok,
+    }
+    if rank == 0:
+        hx, hy = batch['has_x2'].astype(bool), batch['has_y'].astype(bool)
+        if not args.no_roofline:
+            out['roofline'] = gemm_roofline(eng, cfg, rows, float(hx.mean()), float(hy.mean()),
+                                            repeats=20 if args.workload != 'wide' else 3)
+        if not args.no_cpu_baseline and args.workload != 'wide':
+            out['cpu_baseline'] = cpu_baseline(args.workload)
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    return 0 if ok else 1
+
+
+if __name__ == '__main__':
+    sys.exit(main())

@@ -1,0 +1,122 @@
+"""Train-step mixin shared by the three models -- counterpart of the hot-path part of
+reference ``src/DGMMixin.py`` (``_create_optimizer``, ``_use_free_bits``,
+``_compute_anneal_coef``, ``run_on_batch``, ``save_to_file``/``load_params_from_file``).
+
+Differences by design: the optimizer is not a ``torch.optim`` object but the fused Adam
+kernel over the flat parameter arena, and ``run_on_batch(train_mode=True)`` is the fused
+forward+backward+Adam launch sequence of ``drvae_amd.engine`` (optionally replayed from a
+hipGraph) instead of autograd.  Out of scope here:
+``fit``, early stopping, the sklearn/scipy evaluation metrics.
+"""
+from collections import OrderedDict
+
+import torch
+
+from . import engine as E
+from .arena import ParamArena
+
+
+class DeepGenerativeModelMixin:
+    def w2log(self, *args):
+        """print, and append to logs/<log_txt> when set (src/DGMMixin.py:20-29)."""
+        if getattr(self, 'verbose_log', False):
+            print(*args)
+        if getattr(self, 'log_txt', None) is not None:
+            import os
+            os.makedirs('logs', exist_ok=True)
+            with open(os.path.join('logs', self.log_txt), 'a') as f:
+                f.write(' '.join(str(e) for e in args) + '\n')
+
+    # ----------------------------------------------------------------- optimiser
+    def _create_optimizer(self):
+        """Adam with coupled L2 ``weight_decay`` on every parameter (src/DGMMixin.py:31-40),
+        as one fused kernel over the arena.  Adamax is not implemented."""
+        if self.optim_alg != 'adam':
+            raise ValueError('Selected unknown optimizer: ' + str(self.optim_alg))
+        self.optimizer = None          # kept for attribute parity; the state lives in the arena
+        self._engine = None
+
+    def _step_config(self):
+        raise NotImplementedError
+
+    def engine(self):
+        """Build (once) the parameter arena + fused step engine on the model's device."""
+        if self._engine is None:
+            dev = next(self.parameters()).device
+            cfg = self._step_config()
+            shapes = OrderedDict((k, tuple(v.shape)) for k, v in self.named_parameters())
+            want = E.param_shapes(cfg)
+            if list(shapes.items()) != list(want.items()):
+                raise RuntimeError('model parameters do not match the fused-step layout: %s'
+                                   % (set(shapes.items()) ^ set(want.items())))
+            self._arena = ParamArena(shapes, dev).adopt(self)
+            self._engine = E.FusedStep(cfg, self._arena, seed=self.random_seed)
+        return self._engine
+
+    # --------------------------------------------------------------- small helpers
+    def _use_free_bits(self, KL_perx, override_default_kl_min=None):
+        """max(KL_row, kl_min) on the per-row KL (src/DGMMixin.py:68-75)."""
+        kl_min = self.kl_min if override_default_kl_min is None else override_default_kl_min
+        return torch.clamp(KL_perx, min=float(kl_min))
+
+    def _compute_anneal_coef(self, iter_num, iter_max=1000, iter_offset=0, func_type='linear'):
+        if func_type != 'linear':
+            raise ValueError('Unknown annealing function: ' + func_type)
+        return E.anneal_coef(iter_num, iter_max, iter_offset)
+
+    # -------------------------------------------------------------------- the step
+    def _batch_to_engine(self, x1, x2=None, s=None, y=None, has_x2=None, has_y=None):
+        eng = self.engine()
+        n = x1.shape[0]
+        dev = eng.dev
+        x1 = x1.to(dev, torch.float32).contiguous()
+        x2 = x2.to(dev, torch.float32).contiguous() if x2 is not None else None
+        zeros = torch.zeros(n, dtype=torch.int64)
+        eng.set_batch(x1, x2, y, has_x2 if has_x2 is not None else zeros, has_y if has_y is not None else zeros,
+                      counts=getattr(self, '_global_counts', None))
+        return eng
+
+    def _loss_tensors(self, eng):
+        loss = eng.arena.loss
+        keys = list(E.LOSS_IDX)
+        if eng.cfg.kind == 'pvae':
+            keys.remove('YL')
+        if eng.cfg.kind == 'vfae':
+            keys.remove('PERT')
+        return OrderedDict((k, loss[E.LOSS_IDX[k]]) for k in keys)
+
+    def loss_function(self, noise=None, **kwargs):
+        """The 7 loss scalars (RECL, KLD, PERT, YL, MMD, ELBO, CMPL) of src/DrVAE.py:545-626 as
+        0-d device tensors (views: valid until the next call).  Forward only."""
+        eng = self._batch_to_engine(**kwargs)
+        eng.training = self.training
+        eng.add_noise = bool(getattr(self, 'add_noise', False))
+        eng.iters = self.finished_training_iters
+        if noise is not None:
+            eng.set_noise(noise)
+        else:
+            eng.draw_noise()
+        eng.forward()
+        return self._loss_tensors(eng)
+
+    def run_on_batch(self, train_mode=False, noise=None, **kwargs):
+        """Train / evaluate on one minibatch (src/DGMMixin.py:91-126).  ``noise`` optionally
+        injects the N(0,1) draws (parity tests); by default they come from on-device Philox."""
+        if not train_mode:
+            self.eval()
+            return self.loss_function(noise=noise, **kwargs)
+        self.train()
+        eng = self._batch_to_engine(**kwargs)
+        eng.add_noise = bool(getattr(self, 'add_noise', False))
+        eng.iters = self.finished_training_iters
+        eng.train_step(noise, allreduce=getattr(self, '_allreduce', None))
+        self.finished_training_iters = eng.iters
+        return self._loss_tensors(eng)
+
+    # ---------------------------------------------------------------- checkpoints
+    def save_to_file(self, filename):
+        """``torch.save(state_dict)`` with the reference's key names (src/DGMMixin.py:192-197)."""
+        torch.save(OrderedDict((k, v.detach().cpu().clone()) for k, v in self.state_dict().items()), filename)
+
+    def load_params_from_file(self, filename):
+        self.load_state_dict(torch.load(filename, map_location='cpu'))

@@ -313,10 +313,12 @@ class DiagGaussianModuleLinear(GaussianLogVarMixin, nn.Module):
         assert len(input_dims) == 1 and input_dims[0] == latent_dim     # must not change dimensionality
         if constrain_means:
             raise NameError("name 'modules_mu' is not defined")         # reference behaviour, src/blocks.py:335
+        # the logvar head is a plain Linear whatever weight_norm says (src/blocks.py:332); it is
+        # created first so that the parameter-init RNG stream matches the reference's
+        head_lv = _head('lv', nn.Linear, latent_dim, latent_dim, dropout_rate)
         self.W_mu = nn.Parameter(torch.empty(latent_dim, latent_dim).uniform_(-0.0001, 0.0001))
         self.bias_mu = nn.Parameter(torch.empty(latent_dim).uniform_(-0.0001, 0.0001))
-        # the logvar head is a plain Linear whatever weight_norm says (src/blocks.py:332)
-        self.encoder_lv = _head('lv', nn.Linear, latent_dim, latent_dim, dropout_rate)
+        self.encoder_lv = head_lv
         self.prior_mu = torch.zeros(1) + prior_mu
         self.prior_lv = (torch.zeros(1) + prior_sg ** 2).log()
 

@@ -1,0 +1,67 @@
+"""Data parallelism for the train step: one process per GPU, the minibatch rows sharded
+across ranks, parameters + Adam state replicated, ONE exchange per step -- a sum
+all-reduce (RCCL over xGMI; ``torch.distributed`` backend "nccl" is RCCL on ROCm) of the
+flat gradient arena, whose tail also carries the loss scalars.  The reference has no
+distributed code; semantics are defined in SURVEY.md 8(e): every rank normalises its
+row sums by the GLOBAL counts (N_total, N_pairs, N_labeled) so that summed shard
+gradients equal the gradient of the concatenated batch, and all ranks then apply the
+identical fused Adam update."""
+import os
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun).  Returns
+    (rank, world_size, local_rank); a no-op (0, 1, 0) for single-process runs."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world <= 1:
+        return 0, 1, 0
+    rank, local = int(os.environ['RANK']), int(os.environ.get('LOCAL_RANK', '0'))
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    if backend is None:
+        backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+    if backend == 'nccl':
+        torch.cuda.set_device(local)
+    if not dist.is_initialized():
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def allreduce_sum(flat):
+    """In-place sum over ranks of a flat fp32 tensor (the gradient arena)."""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    return flat
+
+
+def global_counts(has_x2, has_y, kind='drvae', semi_supervised=True):
+    """(N_total, N_pairs, N_labeled) over all ranks (tiny host-side all-reduce; the flags
+    come from the host data pipeline)."""
+    hx = np.asarray(has_x2).astype(bool).reshape(-1)
+    hy = np.asarray(has_y).astype(bool).reshape(-1)
+    n_tot = int(hy.sum()) if (kind == 'vfae' and not semi_supervised) else len(hy)
+    c = torch.tensor([n_tot, int(hx.sum()) if kind != 'vfae' else 0, int(hy.sum()) if kind != 'pvae' else 0],
+                     dtype=torch.float64)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        if dist.get_backend() == 'nccl':
+            c = c.cuda()
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        c = c.cpu()
+    return tuple(int(v) for v in c.tolist())
+
+
+def shard_rows(n_rows, rank, world):
+    """contiguous row range [lo, hi) of this rank (SURVEY.md 8(e) partitioning)."""
+    per = n_rows // world
+    assert per * world == n_rows, 'global batch must divide evenly over ranks'
+    return rank * per, (rank + 1) * per
+
+
+def broadcast_params(arena):
+    """make every rank start from rank 0's parameters"""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.broadcast(arena.param, src=0)

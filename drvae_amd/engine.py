@@ -225,6 +225,7 @@ class FusedStep:
         self.rng_ctr = torch.zeros(2, dtype=torch.int32, device=self.dev)        # Philox counter (device side)
         self.seed = seed
         self.training = True
+        self.add_noise = True               # `fit(add_noise=...)` flag of the reference (src/DrVAE.py:769)
         self._build_layers()
 
     # ------------------------------------------------------------------ layer table
@@ -324,7 +325,7 @@ class FusedStep:
         cfg, p = self.cfg, self.plan
         p.set_beta(self.beta_pert())
         B, Np, L, Z1 = p.B, p.Np, cfg.L, cfg.dim_z1
-        sigma = cfg.add_noise_var if (self.training and cfg.add_noise_var > 0) else 0.0
+        sigma = cfg.add_noise_var if (self.training and self.add_noise and cfg.add_noise_var > 0) else 0.0
         # ---- inputs (+ training noise N(0,1)*add_noise_var, src/DrVAE.py:404-407,414-417)
         K.rows_gather(p.XIN[:B], p.x1, None, noise=p.EX[:B] if sigma else None, sigma=sigma)
         if Np:
@@ -382,7 +383,7 @@ class FusedStep:
         K.weighted_sum(loss[0:1], p.NLL[:p.o3], scale=1.0 / (L * p.n_tot))
         if cfg.has_pert and p.Np:
             K.weighted_sum(loss[2:3], p.NLL[p.o3:], scale=1.0 / (L * max(1., p.n_pairs)))
-            K.weighted_sum(loss[1:2], p.KLZ2, scale=p.beta * cfg.kl_qz2pz2_rate / (L * p.n_tot))
+            K.weighted_sum(loss[1:2], p.KLZ2, w=p.c_klz2)     # beta_pert*rate/(L N) lives on the device
         if cfg.kind == 'pvae':
             K.weighted_sum(loss[1:2], p.KLP, scale=1.0 / p.n_tot, beta=1.0)
         if cfg.has_y:
@@ -481,6 +482,60 @@ class FusedStep:
         if allreduce is not None:
             allreduce(self.arena.grad)
         self.optimizer_step()
+        self.iters += 1
+
+    # ------------------------------------------------------------------- hipGraph
+    def _launch_sequence(self, allreduce=None):
+        self.draw_noise()
+        self.forward()
+        self.backward()
+        if allreduce is not None:
+            allreduce(self.arena.grad)
+        self.optimizer_step()
+
+    def capture(self, split_for_allreduce=False):
+        """Capture the train step (Philox noise + forward + backward + Adam: ~100 launches)
+        into hipGraph(s) for the current batch structure.  With ``split_for_allreduce`` the
+        step is captured as two graphs so that an (uncaptured) RCCL all-reduce of the
+        gradient arena can run between backward and Adam."""
+        assert self.plan is not None, 'set_batch first'
+        self.training = True
+        self.plan.set_beta(self.beta_pert())
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):         # warm-up on a side stream (loads code objects)
+            self.draw_noise()
+            self.forward()
+            self.backward()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self._graphs = []
+        if split_for_allreduce:
+            g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g1):
+                self.draw_noise()
+                self.forward()
+                self.backward()
+            with torch.cuda.graph(g2):
+                self.optimizer_step()
+            self._graphs = [g1, g2]
+        else:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._launch_sequence()
+            self._graphs = [g]
+        self._graph_key = self.plan.key
+        return self
+
+    def replay(self, allreduce=None):
+        """One captured train step.  New data is fed by copying into plan.x1 / plan.x2 in place."""
+        assert self._graph_key == self.plan.key, 'batch structure changed: capture again'
+        self.plan.set_beta(self.beta_pert())      # 0.01 on iteration 0, 1.0 afterwards (device-side coefficients)
+        self._graphs[0].replay()
+        if len(self._graphs) == 2:
+            if allreduce is not None:
+                allreduce(self.arena.grad)
+            self._graphs[1].replay()
         self.iters += 1
 
     def losses(self):

@@ -1,0 +1,136 @@
+"""-m gpu: the model classes (drop-in counterparts of the reference's DrVAE / PVAE / VFAE)
+through their reference-style API -- ctor kwargs, state_dict, run_on_batch, forward --
+against the golden vectors, plus hipGraph replay == eager launches."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import models_ref as M
+from tests.golden import cases as C
+
+pytestmark = pytest.mark.gpu
+
+
+def build_model(spec, dev):
+    from drvae_amd.DrVAE import DrVAE
+    from drvae_amd.PVAE import PVAE
+    from drvae_amd.VFAE import VFAE
+    common = dict(dim_x=spec.dim_x, dim_s=1, dim_y=spec.dim_y, dim_h_en_z1=list(spec.h_en_z1),
+                  dim_h_de_x=list(spec.h_de_x), dim_z1=spec.dim_z1, type_rec='diag_gaussian',
+                  nonlinearity=spec.nonlin, learning_rate=spec.learning_rate, L=spec.L,
+                  weight_decay=spec.weight_decay, add_noise_var=spec.add_noise_var, use_MMD=False, random_seed=123,
+                  weight_norm=spec.weight_norm, device=dev)
+    pert = dict(kl_qz2pz2_rate=spec.kl_qz2pz2_rate, pertloss_rate=spec.pertloss_rate,
+                anneal_perturb_rate_itermax=spec.anneal_perturb_rate_itermax,
+                anneal_perturb_rate_offset=spec.anneal_perturb_rate_offset)
+    ycfg = dict(dim_h_de_z1=list(spec.h_de_z1), dim_h_clf=list(spec.h_clf), yloss_rate=spec.yloss_rate)
+    if spec.kind == 'drvae':
+        return DrVAE(dim_h_en_z3=list(spec.h_en_z3), dim_z3=spec.dim_z3, clf_z1z2=spec.clf_z1z2, **common, **pert,
+                     **ycfg)
+    if spec.kind == 'pvae':
+        return PVAE(**common, **pert)
+    return VFAE(dim_h_en_z2=list(spec.h_en_z3), dim_z2=spec.dim_z3, semi_supervised=spec.semi_supervised, **common,
+                **ycfg)
+
+
+def kwargs_for(spec, batch, dev):
+    t = lambda k: torch.from_numpy(batch[k].copy()).to(dev)
+    if spec.kind == 'drvae':
+        return dict(x1=t('x1'), x2=t('x2'), s=t('s'), y=t('y'), has_x2=t('has_x2'), has_y=t('has_y'))
+    if spec.kind == 'pvae':
+        return dict(x1=t('x1'), x2=t('x2'), s=t('s'), has_x2=t('has_x2'))
+    return dict(x1=t('x1'), s=t('s'), y=t('y'), has_y=t('has_y'))
+
+
+@pytest.mark.parametrize('name', ['tiny_drvae', 'tiny_drvae_nolp', 'tiny_drvae_wn', 'tiny_pvae', 'tiny_vfae',
+                                  'tiny_vfae_sup', 'cfg2_drvae'])
+def test_run_on_batch_matches_reference(name, dev):
+    case, gold = C.model_case(name), C.load('model_' + name)
+    spec = case['spec']
+    model = build_model(spec, dev)
+    params = M.init_params(spec, case['param_seed'], as_numpy=True)
+    assert list(model.state_dict().keys()) == list(params.keys())          # reference state_dict names/order
+    model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in params.items()})
+    model.add_noise = spec.add_noise_var > 0
+    kw = kwargs_for(spec, case['batch'], dev)
+    ev = model.run_on_batch(train_mode=False, noise=case['noises'][0], **kw)
+    for k, v in ev.items():
+        np.testing.assert_allclose(float(v), gold['eval/' + k], rtol=1e-4, atol=1e-5)
+    for step, noise in enumerate(case['noises']):
+        losses = model.run_on_batch(train_mode=True, noise=noise, **kw)
+        assert list(losses.keys()) == [k[len('step0/'):] for k in gold if k.startswith('step0/')]
+        for k, v in losses.items():
+            np.testing.assert_allclose(float(v), gold['step%d/%s' % (step, k)], rtol=1e-4, atol=1e-5)
+    assert model.finished_training_iters == len(case['noises'])
+    # the nn.Parameters alias the arena: state_dict reflects the fused Adam updates
+    last = len(case['noises']) - 1
+    for k, v in model.state_dict().items():
+        a = v.cpu().numpy()
+        if case['full']:
+            np.testing.assert_allclose(a, gold['param%d/%s' % (last, k)], rtol=2e-4, atol=5e-5)
+        else:
+            np.testing.assert_allclose(a.reshape(-1)[C.sample_index(a.size)], gold['paramsample%d/%s' % (last, k)],
+                                       rtol=2e-4, atol=5e-5)
+
+
+def test_inference_forward_uses_means(dev):
+    """forward(): posterior means only, no sampling (src/DrVAE.py:253-311) vs the oracle blocks."""
+    from oracle import blocks_ref as B
+    spec = C.tiny_spec('drvae')
+    model = build_model(spec, dev)
+    params = M.init_params(spec, 3, as_numpy=True)
+    model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in params.items()})
+    x1 = torch.from_numpy(M.make_batch(spec, 9, seed=2)['x1'])
+    res = model.forward(x1=x1.to(dev))
+    p = {k: torch.from_numpy(v) for k, v in params.items()}
+    mu1, _ = B.diag_gaussian([x1], p, 'encoder_z1', 1, 'elu')
+    mu2, _ = B.diag_gaussian_linear([mu1], p, 'decoder_z2Fz1')
+    qy = B.categorical([mu1, mu2 - mu1], p, 'encoder_y', 0, 'elu', 2)
+    px1 = B.diag_gaussian_sigma([mu1], p, 'decoder_x', 1, 'elu')
+    px2 = B.diag_gaussian_sigma([mu2], p, 'decoder_x', 1, 'elu')
+    c = lambda a, b: np.testing.assert_allclose(a.cpu().numpy(), b.numpy(), rtol=1e-4, atol=1e-5)
+    c(res['z1'], mu1); c(res['z2'], mu2); c(res['proba'], qy); c(res['x1_rec'], px1[0]); c(res['px1'][1], px1[1])
+    c(res['x2_pert'], px2[0])
+    assert (res['pred'].cpu().numpy() == qy.argmax(1).numpy()).all()
+    pred, proba = model.predict(x1=x1)
+    assert pred.shape == (9,) and proba.shape == (9, 2)
+    assert not model.training
+
+
+def test_graph_replay_equals_eager(dev):
+    from tests.test_engine_cpu import make_engine, set_batch
+    spec = M.ModelSpec(kind='drvae', L=2)
+    params = M.init_params(spec, 3, as_numpy=True)
+    batch = M.make_batch(spec, 150, seed=5)
+    eager, a0 = make_engine(spec, params, dev)
+    graph, a1 = make_engine(spec, params, dev)
+    for e in (eager, graph):
+        set_batch(e, batch, dev)
+        e.train_step()                       # iteration 0 (beta_pert = 0.01) always eager
+    eager.draw_noise()                       # capture() spends one Philox draw on its warm-up
+    graph.capture()
+    for _ in range(4):
+        eager.train_step()
+        graph.replay()
+    torch.cuda.synchronize()
+    assert graph.iters == eager.iters == 5
+    assert torch.equal(a0.param, a1.param)
+    assert eager.losses() == graph.losses()
+
+
+def test_checkpoint_roundtrip_and_errors(dev, tmp_path):
+    spec = C.tiny_spec('vfae', dim_y=3)
+    m1, m2 = build_model(spec, dev), build_model(spec, dev)
+    with torch.no_grad():
+        for p in m1.parameters():
+            p.add_(0.01)
+    f = str(tmp_path / 'ckpt.pth')
+    m1.save_to_file(f)
+    m2.load_params_from_file(f)
+    for (k, a), (_, b) in zip(m1.state_dict().items(), m2.state_dict().items()):
+        assert torch.equal(a, b), k
+    from drvae_amd.DrVAE import DrVAE
+    with pytest.raises(ValueError):
+        DrVAE(dim_x=5, dim_s=1, dim_y=2, type_rec='binary', device=dev)       # src/DrVAE.py:124-131
+    with pytest.raises(ValueError):
+        DrVAE(dim_x=5, dim_s=1, dim_y=2, type_rec='diag_gaussian', optim_alg='sgd', device=dev)
