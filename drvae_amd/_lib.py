@@ -24,7 +24,7 @@ class GemmDesc(C.Structure):
                 ('B', _p), ('ldb', _i64), ('C', _p), ('ldc', _i64), ('alpha', _f), ('beta', _f),
                 ('epilogue', _i32), ('scale', _p), ('bias', _p), ('split', _i32), ('act0', _i32), ('act1', _i32),
                 ('shift0', _f), ('shift1', _f), ('resid', _p), ('ldr', _i64), ('resid_cols', _i32),
-                ('yref', _p), ('ldy', _i64), ('a_colsum', _p), ('colsum_beta', _f)]
+                ('yref', _p), ('ldy', _i64), ('a_colsum', _p), ('colsum_beta', _f), ('flags', _i32)]
 
 
 # name -> argtypes (restype is int unless noted); mirrors include/drvae_hip.h one to one
@@ -33,6 +33,7 @@ SIGNATURES = {
     'dv_error_string': [_i32],
     'dv_gemm': [C.POINTER(GemmDesc), _p],
     'dv_gemm_force_tiling': [_i32],
+    'dv_gemm_set_option': [_i32, _i32],
     'dv_colsum': [_p, _i64, _i32, _i32, _p, _f, _p],
     'dv_act_bwd': [_p, _i64, _p, _i64, _i32, _i32, _i32, _i32, _i32, _f, _f, _p],
     'dv_wn_scale': [_p, _i64, _p, _i32, _i32, _p, _p, _p],

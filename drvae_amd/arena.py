@@ -62,7 +62,8 @@ class ParamArena:
                     numel *= s
                 off += numel
         self.n_params = (off + 3) // 4 * 4
-        z = lambda n: torch.zeros(n, dtype=torch.float32, device=self.device)
+        PAD = 16    # tail slack: GEMM edge tiles may over-read a row end by up to 3 floats (dv_gemm_desc.flags)
+        z = lambda n: torch.zeros(n + PAD, dtype=torch.float32, device=self.device)[:n]
         self.param = z(self.n_params)
         self.grad = z(self.n_params + N_LOSS)              # [gradients | loss scalars]
         self.exp_avg = z(self.n_params)

@@ -27,48 +27,125 @@ namespace {
 
 struct LoadCfg {
     int vecA, vecB;   // widest aligned vector width (4, 2 or 1 floats) per operand
+    int map;          // workgroup -> tile mapping: 0 linear, 1 XCD chunk-major (default)
+    int dbg;          // tuning only: bit0 skip in-loop global loads, bit1 skip MFMAs, bit2 skip in-loop LDS stores
+    unsigned long long* stamps;   // tuning only: per-phase s_memtime sums of block 0 / wave 0
 };
 
-__device__ __forceinline__ float4 ld_chunk(const float* p, int valid, int vec) {
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (valid >= 4) {
-        if (vec == 4) {
-            v = *reinterpret_cast<const float4*>(p);
-        } else if (vec == 2) {
-            float2 a = *reinterpret_cast<const float2*>(p);
-            float2 b = *reinterpret_cast<const float2*>(p + 2);
-            v = make_float4(a.x, a.y, b.x, b.y);
+// XCD-aware workgroup -> tile map.  Observed dispatch: blocks b and b+8 share an XCD and its
+// 4 MiB L2 (placement is a speed matter only).  XCD x = b&7 owns cnt_x = nwg/8 (+1) blocks;
+// give it a CONTIGUOUS range of the tile list ordered chunk-major along the longer tile
+// dimension, i.e. a compact column (or row) band of the output: its A/B panels then stay in
+// that XCD's L2 instead of every XCD streaming every panel from the Infinity Cache.
+__device__ __forceinline__ void tile_of_block(int bid, int nwg, int tiles_m, int tiles_n, int map, int& tm,
+                                              int& tn) {
+    int t = bid;
+    if (map == 1 && nwg >= 16) {
+        const int x = bid & 7, j = bid >> 3, base = nwg >> 3, rem = nwg & 7;
+        t = x * base + (x < rem ? x : rem) + j;
+        if (tiles_n >= tiles_m) {
+            const int cw = (tiles_n + 7) >> 3, per = cw * tiles_m, c = t / per, r = t - c * per;
+            const int w = (tiles_n - c * cw) < cw ? (tiles_n - c * cw) : cw;
+            tm = r / w;
+            tn = c * cw + r % w;
         } else {
-            v = make_float4(p[0], p[1], p[2], p[3]);
+            const int ch = (tiles_m + 7) >> 3, per = ch * tiles_n, c = t / per, r = t - c * per;
+            const int h = (tiles_m - c * ch) < ch ? (tiles_m - c * ch) : ch;
+            tn = r / h;
+            tm = c * ch + r % h;
         }
-    } else if (valid > 0) {
-        v.x = p[0];
-        if (valid > 1) v.y = p[1];
-        if (valid > 2) v.z = p[2];
+        return;
     }
-    return v;
+    tm = t / tiles_n;
+    tn = t % tiles_n;
 }
 
-__device__ __forceinline__ int clamp04(int v) { return v < 0 ? 0 : (v > 4 ? 4 : v); }
-
-// epilogue + store of one element
-__device__ __forceinline__ void epi_store(const dv_gemm_desc& g, int row, int col, float v) {
-    if (row >= g.M || col >= g.N) return;
-    v *= g.alpha;
+// Epilogue of one 16-register accumulator column (fixed `col`, 16 rows `row0 + rmap(r)`).
+// Everything that depends only on the column (scale, bias, activation id, shift) is fetched
+// ONCE; the optional per-element operands (residual / yref / old C) are loaded as one batch
+// before any store, so no load ever waits behind a store's vmcnt.
+template <int NR, typename RowOf>
+__device__ __forceinline__ void epi_store_col(const dv_gemm_desc& g, const float (&acc)[NR], int col, RowOf row_of) {
+    const bool cok = col < g.N;
+    const int cc = cok ? col : g.N - 1;
+    const bool first = col < g.split;
+    const int act = first ? g.act0 : g.act1;
+    const float shift = first ? g.shift0 : g.shift1;
+    float sc = 1.f, bi = 0.f;
     if (g.epilogue == DV_EPI_FWD) {
-        if (g.scale) v *= g.scale[col];
-        if (g.bias) v += g.bias[col];
-        const bool first = col < g.split;
-        v = dv_act(first ? g.act0 : g.act1, v) + (first ? g.shift0 : g.shift1);
-        if (g.resid && col < g.resid_cols) v += g.resid[(int64_t)row * g.ldr + col];
-    } else if (g.epilogue == DV_EPI_BWD) {
-        const bool first = col < g.split;
-        const float y = g.yref[(int64_t)row * g.ldy + col] - (first ? g.shift0 : g.shift1);
-        v *= dv_dact_from_y(first ? g.act0 : g.act1, y);
+        if (g.scale) sc = g.scale[cc];
+        if (g.bias) bi = g.bias[cc];
     }
-    float* c = g.C + (int64_t)row * g.ldc + col;
-    if (g.beta != 0.f) v += g.beta * (*c);
-    *c = v;
+    float ex[NR], old[NR];
+    const float* exsrc = nullptr;
+    int64_t exld = 0;
+    if (g.epilogue == DV_EPI_FWD && g.resid) {
+        exsrc = g.resid;
+        exld = g.ldr;
+    } else if (g.epilogue == DV_EPI_BWD) {
+        exsrc = g.yref;
+        exld = g.ldy;
+    }
+    const bool use_ex = exsrc != nullptr;
+    const bool use_old = g.beta != 0.f;
+    const int exc = (g.epilogue == DV_EPI_FWD && use_ex) ? (col < g.resid_cols ? col : 0) : cc;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int row = row_of(r), rc = row < g.M ? row : g.M - 1;
+        ex[r] = use_ex ? exsrc[(int64_t)rc * exld + exc] : 0.f;
+        old[r] = use_old ? g.C[(int64_t)rc * g.ldc + cc] : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int row = row_of(r);
+        float v = acc[r] * g.alpha;
+        if (g.epilogue == DV_EPI_FWD) {
+            v = dv_act(act, v * sc + bi) + shift;
+            if (use_ex && col < g.resid_cols) v += ex[r];
+        } else if (g.epilogue == DV_EPI_BWD) {
+            v *= dv_dact_from_y(act, ex[r] - shift);
+        }
+        if (use_old) v += g.beta * old[r];
+        if (cok && row < g.M) g.C[(int64_t)row * g.ldc + col] = v;
+    }
+}
+
+// One staged operand.  Element (line, pos) lives at base[line*ld + pos]:
+//   k-contiguous operand  : line = output row (m or n), pos = k
+//   row-contiguous operand: line = k,                   pos = output row
+// A staging chunk is 4 consecutive `pos` values of one line.
+struct Operand {
+    const float* base;
+    int64_t ld;
+    int n_line, n_pos;   // extents along line / pos
+};
+
+// Fast path: the whole chunk is in bounds -> ONE unconditional (vector) load, no branches, so
+// all of a thread's staging loads are in flight together (a per-load `if` makes hipcc wait
+// vmcnt(0) after each one: dependent L2 round trips).
+__device__ __forceinline__ float4 ld_fast(const Operand& o, int line, int pos, int vec) {
+    const float* p = o.base + (int64_t)line * o.ld + pos;
+    if (vec == 4) return *reinterpret_cast<const float4*>(p);
+    if (vec == 2) {
+        const float2 a = *reinterpret_cast<const float2*>(p), b = *reinterpret_cast<const float2*>(p + 2);
+        return make_float4(a.x, a.y, b.x, b.y);
+    }
+    return make_float4(p[0], p[1], p[2], p[3]);
+}
+
+// Edge path: indices clamped into the matrix, out-of-range elements selected to zero --
+// still branch-free (4 scalar loads + v_cndmask).
+__device__ __forceinline__ float4 ld_edge(const Operand& o, int line, int pos) {
+    const bool lok = line < o.n_line;
+    const float* row = o.base + (int64_t)(lok ? line : o.n_line - 1) * o.ld;
+    float e[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int q = pos + j;
+        const float v = row[q < o.n_pos ? q : o.n_pos - 1];
+        e[j] = (lok && q < o.n_pos) ? v : 0.f;
+    }
+    return make_float4(e[0], e[1], e[2], e[3]);
 }
 
 template <int BM, int BN, int BK, int WM, int WN, int KS, bool AKC, bool BKC>
@@ -79,22 +156,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(const dv_gemm_desc g, const L
     constexpr int LDB_S = (BKC ? BK : BN) + 4;
     constexpr int A_ELEMS = (AKC ? BM : BK) * LDA_S;
     constexpr int B_ELEMS = (BKC ? BN : BK) * LDB_S;
+    constexpr int STAGE = A_ELEMS + B_ELEMS;
     constexpr int RED_ELEMS = (KS > 1) ? KS * 32 * 33 : 0;
-    constexpr int SMEM = (A_ELEMS + B_ELEMS) > RED_ELEMS ? (A_ELEMS + B_ELEMS) : RED_ELEMS;
+    constexpr int SMEM = 2 * STAGE > RED_ELEMS ? 2 * STAGE : RED_ELEMS;   // double-buffered tiles
     static_assert(WM * WN * KS == 4, "4 waves");
     static_assert(KS == 1 || (BM == 32 && BN == 32), "K-split tiling is 32x32");
     __shared__ __attribute__((aligned(16))) float smem[SMEM];
-    float* sA = smem;
-    float* sB = smem + A_ELEMS;
 
-    // ---- workgroup -> tile, XCD-aware: blocks b and b+8 share an XCD (and its L2), so give
-    // each XCD a contiguous run of tiles (neighbouring tiles share an A row-panel).
-    const int tiles_n = (g.N + BN - 1) / BN;
-    const int nwg = gridDim.x;
-    int bid = blockIdx.x;
-    if ((nwg & 7) == 0) bid = (bid & 7) * (nwg >> 3) + (bid >> 3);
-    const int m0 = (bid / tiles_n) * BM;
-    const int n0 = (bid % tiles_n) * BN;
+    const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
+    int tm, tn;
+    tile_of_block(blockIdx.x, gridDim.x, tiles_m, tiles_n, lc.map, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
@@ -111,74 +183,74 @@ __global__ __launch_bounds__(256) void gemm_kernel(const dv_gemm_desc g, const L
     static_assert(A_NP >= 1 && B_NP >= 1, "tile too small for 256 threads");
     const int a_c = tid % A_CPL, a_l = tid / A_CPL;
     const int b_c = tid % B_CPL, b_l = tid / B_CPL;
-    float4 ra[A_NP], rb[B_NP];
     // fused bias gradient: the first column-tile of every row-panel sums its A tiles over k
     const bool do_colsum = !AKC && g.a_colsum != nullptr && n0 == 0;
     float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
 
-    auto load_a = [&](int k0) {
+    const Operand oa{g.A, g.lda, AKC ? g.M : g.K, AKC ? g.K : g.M};
+    const Operand ob{g.B, g.ldb, BKC ? g.N : g.K, BKC ? g.K : g.N};
+    // workgroup-uniform: may this tile use the unconditional vector loads?  k-contiguous
+    // operands only need a full K tile (rows past the edge are clamped: their products are
+    // never stored); row-contiguous operands also need the row range interior.
+    const bool a_plain = g.A2 == nullptr;
+    const bool a_int = AKC ? true : (m0 + BM <= g.M);
+    const bool b_int = BKC ? true : (n0 + BN <= g.N);
+    // edge tiles of row-contiguous operands may still use the aligned vector loads when the
+    // caller vouches that a row end can be over-read (flags); chunks entirely past the edge are
+    // redirected to chunk 0 of the line (their values only feed outputs that are never stored)
+    const bool wg_fast = a_plain && (a_int || (g.flags & 1)) && (b_int || (g.flags & 2)) && g.a_kscale == nullptr;
+
+    // generic (edge / two-source / k-scaled) staging loads: clamped indices + selects, branch-free per element
+    auto gen_load = [&](int k0, float4 (&ra)[A_NP], float4 (&rb)[B_NP]) {
 #pragma unroll
         for (int p = 0; p < A_NP; ++p) {
-            const int line = a_l + p * A_LPP;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (AKC) {   // line = m, chunk along k
-                const int m = m0 + line, k = k0 + a_c * 4;
-                if (m < g.M && k < g.K) {
-                    if (lc.vecA > 1) {
-                        if (g.A2 && k >= g.K1)
-                            v = ld_chunk(g.A2 + (int64_t)m * g.lda2 + (k - g.K1), clamp04(g.K - k), lc.vecA);
-                        else
-                            v = ld_chunk(g.A + (int64_t)m * g.lda + k, clamp04((g.A2 ? g.K1 : g.K) - k), lc.vecA);
-                    } else {
-                        float e[4];
+            const int l = a_l + p * A_LPP;
+            const int line = AKC ? (m0 + l) : (k0 + l);
+            const int pos = AKC ? (k0 + a_c * 4) : (m0 + a_c * 4);
+            float4 v;
+            if (a_plain) {
+                v = ld_edge(oa, line, pos);
+            } else {   // two concatenated sources (AKC only): per-element source select
+                const bool lok = line < g.M;
+                const int64_t r = lok ? line : g.M - 1;
+                float e[4];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const int kk = k + j;
-                            e[j] = kk >= g.K ? 0.f
-                                   : (g.A2 && kk >= g.K1) ? g.A2[(int64_t)m * g.lda2 + (kk - g.K1)]
-                                                          : g.A[(int64_t)m * g.lda + kk];
-                        }
-                        v = make_float4(e[0], e[1], e[2], e[3]);
-                    }
-                    if (g.a_kscale) {
-                        v.x *= g.a_kscale[k];
-                        if (k + 1 < g.K) v.y *= g.a_kscale[k + 1];
-                        if (k + 2 < g.K) v.z *= g.a_kscale[k + 2];
-                        if (k + 3 < g.K) v.w *= g.a_kscale[k + 3];
-                    }
+                for (int j = 0; j < 4; ++j) {
+                    const int q = pos + j, qc = q < g.K ? q : g.K - 1;
+                    const float* src = qc >= g.K1 ? g.A2 + r * g.lda2 + (qc - g.K1) : g.A + r * g.lda + qc;
+                    const float x = *src;
+                    e[j] = (lok && q < g.K) ? x : 0.f;
                 }
-            } else {     // line = k, chunk along m
-                const int k = k0 + line, m = m0 + a_c * 4;
-                if (k < g.K && m < g.M) v = ld_chunk(g.A + (int64_t)k * g.lda + m, clamp04(g.M - m), lc.vecA);
-                if (do_colsum) {
-                    csum.x += v.x;
-                    csum.y += v.y;
-                    csum.z += v.z;
-                    csum.w += v.w;
-                }
+                v = make_float4(e[0], e[1], e[2], e[3]);
+            }
+            if (AKC && g.a_kscale) {   // uniform
+                const int kq = g.K - 1;
+                v.x *= g.a_kscale[pos < kq ? pos : kq];
+                v.y *= g.a_kscale[pos + 1 < kq ? pos + 1 : kq];
+                v.z *= g.a_kscale[pos + 2 < kq ? pos + 2 : kq];
+                v.w *= g.a_kscale[pos + 3 < kq ? pos + 3 : kq];
             }
             ra[p] = v;
         }
-    };
-    auto load_b = [&](int k0) {
 #pragma unroll
         for (int p = 0; p < B_NP; ++p) {
-            const int line = b_l + p * B_LPP;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (BKC) {   // line = n, chunk along k
-                const int n = n0 + line, k = k0 + b_c * 4;
-                if (n < g.N && k < g.K) v = ld_chunk(g.B + (int64_t)n * g.ldb + k, clamp04(g.K - k), lc.vecB);
-            } else {     // line = k, chunk along n
-                const int k = k0 + line, n = n0 + b_c * 4;
-                if (k < g.K && n < g.N) v = ld_chunk(g.B + (int64_t)k * g.ldb + n, clamp04(g.N - n), lc.vecB);
-            }
-            rb[p] = v;
+            const int l = b_l + p * B_LPP;
+            rb[p] = ld_edge(ob, BKC ? (n0 + l) : (k0 + l), BKC ? (k0 + b_c * 4) : (n0 + b_c * 4));
         }
     };
-    auto store_ab = [&]() {
+    auto stage_store = [&](float* buf, const float4 (&ra)[A_NP], const float4 (&rb)[B_NP]) {
+        float* sA = buf;
+        float* sB = buf + A_ELEMS;
 #pragma unroll
-        for (int p = 0; p < A_NP; ++p)
+        for (int p = 0; p < A_NP; ++p) {
             *reinterpret_cast<float4*>(&sA[(a_l + p * A_LPP) * LDA_S + a_c * 4]) = ra[p];
+            if (do_colsum) {
+                csum.x += ra[p].x;
+                csum.y += ra[p].y;
+                csum.z += ra[p].z;
+                csum.w += ra[p].w;
+            }
+        }
 #pragma unroll
         for (int p = 0; p < B_NP; ++p)
             *reinterpret_cast<float4*>(&sB[(b_l + p * B_LPP) * LDB_S + b_c * 4]) = rb[p];
@@ -192,53 +264,136 @@ __global__ __launch_bounds__(256) void gemm_kernel(const dv_gemm_desc g, const L
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nkt = (g.K + BK - 1) / BK;
     const int kb = ks_id * KW + lh * KH;   // this lane's first k inside the tile
-    load_a(0);
-    load_b(0);
-    store_ab();
-    __syncthreads();
-    for (int kt = 0; kt < nkt; ++kt) {
-        if (kt + 1 < nkt) {   // global loads of the next tile fly under this tile's MFMAs
-            load_a((kt + 1) * BK);
-            load_b((kt + 1) * BK);
+    auto compute = [&](const float* sA) {
+        const float* sB = sA + A_ELEMS;
+        // all fragment reads of the tile are issued up front (in-order LDS returns: the first
+        // MFMA only waits for the first read, the rest land under the MFMA chain)
+        float fa[TM][KH], fb[TN][KH];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int row = wm * TM * 32 + i * 32 + li;
+#pragma unroll
+            for (int s = 0; s < KH; s += 4) {
+                if (AKC) {
+                    const float4 v = *reinterpret_cast<const float4*>(&sA[row * LDA_S + kb + s]);
+                    fa[i][s] = v.x;
+                    fa[i][s + 1] = v.y;
+                    fa[i][s + 2] = v.z;
+                    fa[i][s + 3] = v.w;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) fa[i][s + e] = sA[(kb + s + e) * LDA_S + row];
+                }
+            }
         }
 #pragma unroll
-        for (int s = 0; s < KH; s += 4) {
-            float4 fa[TM], fb[TN];
+        for (int j = 0; j < TN; ++j) {
+            const int col = wn * TN * 32 + j * 32 + li;
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int row = wm * TM * 32 + i * 32 + li;
-                if (AKC) {
-                    fa[i] = *reinterpret_cast<const float4*>(&sA[row * LDA_S + kb + s]);
-                } else {
-                    fa[i] = make_float4(sA[(kb + s) * LDA_S + row], sA[(kb + s + 1) * LDA_S + row],
-                                        sA[(kb + s + 2) * LDA_S + row], sA[(kb + s + 3) * LDA_S + row]);
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int col = wn * TN * 32 + j * 32 + li;
+            for (int s = 0; s < KH; s += 4) {
                 if (BKC) {
-                    fb[j] = *reinterpret_cast<const float4*>(&sB[col * LDB_S + kb + s]);
+                    const float4 v = *reinterpret_cast<const float4*>(&sB[col * LDB_S + kb + s]);
+                    fb[j][s] = v.x;
+                    fb[j][s + 1] = v.y;
+                    fb[j][s + 2] = v.z;
+                    fb[j][s + 3] = v.w;
                 } else {
-                    fb[j] = make_float4(sB[(kb + s) * LDB_S + col], sB[(kb + s + 1) * LDB_S + col],
-                                        sB[(kb + s + 2) * LDB_S + col], sB[(kb + s + 3) * LDB_S + col]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) fb[j][s + e] = sB[(kb + s + e) * LDB_S + col];
                 }
             }
+        }
+#pragma unroll
+        for (int s = 0; s < KH; ++s)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
-                }
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s], fb[j][s], acc[i][j], 0, 0, 0);
+    };
+
+    const int nkt = (g.K + BK - 1) / BK, nfull = g.K / BK;
+    float* const buf0 = smem;
+    float* const buf1 = smem + STAGE;
+    if (wg_fast && nfull >= 1) {
+        // ---- interior workgroups: per-thread staging pointers advanced by one K tile per step,
+        // unconditional vector loads, TWO register sets (two tiles in flight: each load has two
+        // MFMA phases to land), LDS double buffer (one barrier per K tile).
+        const float* pa[A_NP];
+        const float* pb[B_NP];
+#pragma unroll
+        for (int p = 0; p < A_NP; ++p) {
+            const int l = a_l + p * A_LPP;
+            int line = AKC ? (m0 + l) : l;
+            if (AKC) line = line < g.M ? line : g.M - 1;
+            pa[p] = g.A + (int64_t)line * g.lda + (AKC ? a_c * 4 : (m0 + a_c * 4 < g.M ? m0 + a_c * 4 : 0));
         }
+#pragma unroll
+        for (int p = 0; p < B_NP; ++p) {
+            const int l = b_l + p * B_LPP;
+            int line = BKC ? (n0 + l) : l;
+            if (BKC) line = line < g.N ? line : g.N - 1;
+            pb[p] = g.B + (int64_t)line * g.ldb + (BKC ? b_c * 4 : (n0 + b_c * 4 < g.N ? n0 + b_c * 4 : 0));
+        }
+        const int64_t step_a = AKC ? (int64_t)BK : (int64_t)BK * g.lda;
+        const int64_t step_b = BKC ? (int64_t)BK : (int64_t)BK * g.ldb;
+        const int va = lc.vecA, vb = lc.vecB;
+        auto ldv = [](const float* p, int vec) -> float4 {
+            if (vec == 4) return *reinterpret_cast<const float4*>(p);
+            if (vec == 2) {
+                const float2 a = *reinterpret_cast<const float2*>(p), b = *reinterpret_cast<const float2*>(p + 2);
+                return make_float4(a.x, a.y, b.x, b.y);
+            }
+            return make_float4(p[0], p[1], p[2], p[3]);
+        };
+        auto fetch = [&](int t, float4 (&ra)[A_NP], float4 (&rb)[B_NP]) {
+            if (t < nfull) {
+#pragma unroll
+                for (int p = 0; p < A_NP; ++p) {
+                    ra[p] = ldv(pa[p], va);
+                    pa[p] += step_a;
+                }
+#pragma unroll
+                for (int p = 0; p < B_NP; ++p) {
+                    rb[p] = ldv(pb[p], vb);
+                    pb[p] += step_b;
+                }
+            } else {
+                gen_load(t * BK, ra, rb);   // the partial K tail tile
+            }
+        };
+        float4 a0[A_NP], b0[B_NP], a1[A_NP], b1[B_NP];
+        fetch(0, a0, b0);
+        if (nkt > 1) fetch(1, a1, b1);
+        stage_store(buf0, a0, b0);
+        if (nkt > 2) fetch(2, a0, b0);
         __syncthreads();
-        if (kt + 1 < nkt) {
-            store_ab();
+        for (int kt = 0; kt < nkt; kt += 2) {
+            compute(buf0);
+            if (kt + 1 < nkt) {
+                stage_store(buf1, a1, b1);
+                if (kt + 3 < nkt) fetch(kt + 3, a1, b1);
+            }
+            __syncthreads();
+            if (kt + 1 >= nkt) break;
+            compute(buf1);
+            if (kt + 2 < nkt) {
+                stage_store(buf0, a0, b0);
+                if (kt + 4 < nkt) fetch(kt + 4, a0, b0);
+            }
+            __syncthreads();
+        }
+    } else {
+        // ---- edge tiles / concatenated sources / k-scaled operand: simple loop, generic loads
+        float4 ra[A_NP], rb[B_NP];
+        gen_load(0, ra, rb);
+        stage_store(buf0, ra, rb);
+        __syncthreads();
+        for (int kt = 0; kt < nkt; ++kt) {
+            if (kt + 1 < nkt) gen_load((kt + 1) * BK, ra, rb);
+            compute((kt & 1) ? buf1 : buf0);
+            if (kt + 1 < nkt) stage_store((kt & 1) ? buf0 : buf1, ra, rb);
             __syncthreads();
         }
     }
@@ -260,13 +415,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(const dv_gemm_desc g, const L
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
+            for (int j = 0; j < TN; ++j) {
+                float a16[16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    const int col = n0 + wn * TN * 32 + j * 32 + li;
-                    epi_store(g, row, col, acc[i][j][r]);
-                }
+                for (int r = 0; r < 16; ++r) a16[r] = acc[i][j][r];
+                const int rbase = m0 + wm * TM * 32 + i * 32 + 4 * lh;
+                epi_store_col<16>(g, a16, n0 + wn * TN * 32 + j * 32 + li,
+                                  [rbase](int r) { return rbase + (r & 3) + 8 * (r >> 2); });
+            }
     } else {
         // the 4 waves hold partial sums over disjoint k: reduce through LDS (tiles are dead now)
         float* red = smem;
@@ -276,14 +432,18 @@ __global__ __launch_bounds__(256) void gemm_kernel(const dv_gemm_desc g, const L
             red[(ks_id * 32 + row) * 33 + li] = acc[0][0][r];
         }
         __syncthreads();
-        const int row = tid >> 3, c4 = (tid & 7) * 4;
+        // thread -> (4 consecutive rows, one column): column-wise like the register epilogue
+        const int col = tid & 31, r4 = (tid >> 5) * 4;
+        float a4[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             float v = 0.f;
 #pragma unroll
-            for (int w = 0; w < KS; ++w) v += red[(w * 32 + row) * 33 + c4 + e];
-            epi_store(g, m0 + row, n0 + c4 + e, v);
+            for (int w = 0; w < KS; ++w) v += red[(w * 32 + r4 + e) * 33 + col];
+            a4[e] = v;
         }
+        const int rbase = m0 + r4;
+        epi_store_col<4>(g, a4, n0 + col, [rbase](int r) { return rbase + r; });
     }
 }
 
@@ -312,6 +472,19 @@ int launch_cfg(const dv_gemm_desc& g, const LoadCfg& lc, hipStream_t st) {
 }  // namespace
 
 static int g_force_tiling = 0;   // 0 = heuristic; 1 = T64, 2 = T32K, 3 = T128 (tests / tuning)
+static int g_opt[8] = {1, 0, 0, 0, 0, 0, 0, 0};   // [0] = tile map (0 linear, 1 XCD chunk-major)
+static unsigned long long* g_stamps = nullptr;
+
+extern "C" int dv_gemm_debug_stamps(unsigned long long* dev_buf) {   // tuning hook, not part of the ABI
+    g_stamps = dev_buf;
+    return DV_OK;
+}
+
+extern "C" int dv_gemm_set_option(int key, int value) {
+    if (key < 0 || key >= 8) return DV_ERR_ARG;
+    g_opt[key] = value;
+    return DV_OK;
+}
 
 extern "C" int dv_gemm_force_tiling(int t) {
     g_force_tiling = t;
@@ -321,7 +494,7 @@ extern "C" int dv_gemm_force_tiling(int t) {
 extern "C" int dv_gemm(const dv_gemm_desc* d, dv_stream_t stream) {
     DV_REQUIRE(d != nullptr);
     const dv_gemm_desc& g = *d;
-    DV_REQUIRE(g.M >= 0 && g.N >= 0 && g.K >= 0);
+    DV_REQUIRE(g.M >= 0 && g.N >= 0 && g.K >= 1);
     if (g.M == 0 || g.N == 0) return DV_OK;
     DV_REQUIRE(g.A && g.B && g.C);
     DV_REQUIRE(g.epilogue == DV_EPI_PLAIN || g.epilogue == DV_EPI_FWD || g.epilogue == DV_EPI_BWD);
@@ -337,12 +510,21 @@ extern "C" int dv_gemm(const dv_gemm_desc* d, dv_stream_t stream) {
         if (g.K1 & 3) lc.vecA = 1;   // a 4-chunk could straddle the two sources
     }
     lc.vecB = vec_width(g.B, g.ldb);
+    lc.map = g_opt[0];
+    lc.dbg = g_opt[1];
+    lc.stamps = g_stamps;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int64_t t64 = (int64_t)((g.M + 63) / 64) * ((g.N + 63) / 64);
     const int64_t t128 = (int64_t)((g.M + 127) / 128) * ((g.N + 127) / 128);
     int tiling = g_force_tiling;
-    if (tiling == 0) tiling = (t128 >= 512) ? 3 : (t64 >= 192 ? 1 : 2);
+    // measured on MI355X (tools/gemm_bench.py): below ~4 workgroups per CU the 32x32 K-split
+    // tiling wins (more resident workgroups hide the per-K-tile latency chain); the larger
+    // tiles only pay once their grids alone fill the chip several times over
+    if (tiling == 0) tiling = (t128 >= 1024) ? 3 : (t64 >= 1024 ? 1 : 2);
     if (tiling == 3) return launch_cfg<128, 128, 32, 2, 2, 1>(g, lc, st);
+    if (tiling == 4) return launch_cfg<64, 64, 64, 2, 2, 1>(g, lc, st);
+    if (tiling == 5) return launch_cfg<128, 64, 32, 2, 2, 1>(g, lc, st);
+    if (tiling == 6) return launch_cfg<64, 128, 32, 2, 2, 1>(g, lc, st);
     if (tiling == 1) return launch_cfg<64, 64, 32, 2, 2, 1>(g, lc, st);
     return launch_cfg<32, 32, 64, 1, 1, 4>(g, lc, st);
 }

@@ -173,7 +173,8 @@ class _Chain:
             last = li == len(self.layers) - 1
             K.linear_fwd(self.out[li], x[0], l.W, l.b, x2=x[1] if len(x) > 1 else None, scale=l.scale, split=l.split,
                          act0=l.act0, act1=l.act1, shift0=l.shift0, shift1=l.shift1,
-                         resid=resid if last else None, resid_cols=self.resid_cols if (last and resid is not None) else 0)
+                         resid=resid if last else None, resid_cols=self.resid_cols if (last and resid is not None) else 0,
+                         overread=True)
             x = [self.out[li]]
         return self.out[-1]
 
@@ -188,21 +189,22 @@ class _Chain:
             c0 = 0
             for si, s in enumerate(srcs):
                 w = s.shape[1]
-                K.linear_bwd_weight(dW[:, c0:c0 + w], dpre, s, dbias=l.db if si == 0 else None)
+                K.linear_bwd_weight(dW[:, c0:c0 + w], dpre, s, dbias=l.db if si == 0 else None, overread=True)
                 c0 += w
             if l.g is not None:
                 K.wn_bwd(l.dW, l.dg, l.raw, l.W, l.g, l.norm)
             if li > 0:
                 prev = self.layers[li - 1]
                 K.linear_bwd_data(self.dpre[li - 1], dpre, l.W, kscale=l.scale, yref=self.out[li - 1], act=prev.act0,
-                                  shift=prev.shift0)
+                                  shift=prev.shift0, overread=True)
                 dpre = self.dpre[li - 1]
             elif dinputs is not None:
                 c0 = 0
                 for si, s in enumerate(srcs):
                     w = s.shape[1]
                     for (dst, alpha, beta) in (dinputs[si] or []):
-                        K.linear_bwd_data(dst, dpre, l.W[:, c0:c0 + w], kscale=l.scale, alpha=alpha, beta=beta)
+                        K.linear_bwd_data(dst, dpre, l.W[:, c0:c0 + w], kscale=l.scale, alpha=alpha, beta=beta,
+                                          overread=True)
                     c0 += w
 
 

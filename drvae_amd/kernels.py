@@ -52,8 +52,9 @@ def _act(a):
 # ------------------------------------------------------------------------------ GEMM
 def gemm(Cm, A, B, a_kc, b_kc, *, A2=None, a_kscale=None, alpha=1.0, beta=0.0, epi=EPI_PLAIN, scale=None,
          bias=None, split=None, act0=0, act1=0, shift0=0.0, shift1=0.0, resid=None, resid_cols=0, yref=None,
-         a_colsum=None, colsum_beta=0.0):
-    """C[M,N] = epilogue(alpha * Aop @ Bop) + beta*C, see ``dv_gemm`` in include/drvae_hip.h."""
+         a_colsum=None, colsum_beta=0.0, overread=False):
+    """C[M,N] = epilogue(alpha * Aop @ Bop) + beta*C, see ``dv_gemm`` in include/drvae_hip.h.
+    ``overread``: rows of A and B may be over-read by up to 3 floats (padded / arena buffers)."""
     M, N = Cm.shape
     if a_kc:
         K = A.shape[1] + (A2.shape[1] if A2 is not None else 0)
@@ -79,28 +80,29 @@ def gemm(Cm, A, B, a_kc, b_kc, *, A2=None, a_kscale=None, alpha=1.0, beta=0.0, e
     d.resid, d.ldr, d.resid_cols = _f32(resid, 'resid'), _ld(resid), resid_cols
     d.yref, d.ldy = _f32(yref, 'yref'), _ld(yref)
     d.a_colsum, d.colsum_beta = _f32(a_colsum, 'a_colsum'), colsum_beta
+    d.flags = 3 if overread else 0
     _lib.check(_lib.load().dv_gemm(C.byref(d), _stream()), 'dv_gemm')
 
 
 def linear_fwd(out, x, W, bias=None, *, x2=None, scale=None, split=None, act0=0, act1=0, shift0=0.0, shift1=0.0,
-               resid=None, resid_cols=0):
+               resid=None, resid_cols=0, overread=False):
     """out = act([x|x2] W^T * scale + bias) + shift (+ resid) -- one Linear (or two heads) forward."""
     gemm(out, x, W, True, True, A2=x2, epi=EPI_FWD, scale=scale, bias=bias, split=split, act0=act0, act1=act1,
-         shift0=shift0, shift1=shift1, resid=resid, resid_cols=resid_cols)
+         shift0=shift0, shift1=shift1, resid=resid, resid_cols=resid_cols, overread=overread)
 
 
-def linear_bwd_data(dx, dpre, W, *, kscale=None, alpha=1.0, beta=0.0, yref=None, act=0, shift=0.0):
+def linear_bwd_data(dx, dpre, W, *, kscale=None, alpha=1.0, beta=0.0, yref=None, act=0, shift=0.0, overread=False):
     """dx = beta*dx + alpha*((dpre*kscale) W) * act'(yref)   (W may be a column slice view)."""
     if yref is None:
-        gemm(dx, dpre, W, True, False, a_kscale=kscale, alpha=alpha, beta=beta)
+        gemm(dx, dpre, W, True, False, a_kscale=kscale, alpha=alpha, beta=beta, overread=overread)
     else:
         gemm(dx, dpre, W, True, False, a_kscale=kscale, alpha=alpha, beta=beta, epi=EPI_BWD, yref=yref, act0=act,
-             act1=act, shift0=shift, shift1=shift)
+             act1=act, shift0=shift, shift1=shift, overread=overread)
 
 
-def linear_bwd_weight(dW, dpre, x, *, beta=0.0, dbias=None):
+def linear_bwd_weight(dW, dpre, x, *, beta=0.0, dbias=None, overread=False):
     """dW = beta*dW + dpre^T x ;  dbias = beta*dbias + colsum(dpre) fused in the same launch."""
-    gemm(dW, dpre, x, False, False, beta=beta, a_colsum=dbias, colsum_beta=beta)
+    gemm(dW, dpre, x, False, False, beta=beta, a_colsum=dbias, colsum_beta=beta, overread=overread)
 
 
 def colsum(out, X, beta=0.0):

@@ -101,11 +101,18 @@ typedef struct dv_gemm_desc {
      * -- `db = dy.sum(0)` computed from the dy tiles the dW GEMM stages anyway. */
     float* a_colsum;
     float colsum_beta;
+    /* bit0 / bit1: reading up to 3 floats past the END OF ANY ROW of A / B stays inside the
+     * caller's allocation (rows padded to 4 floats, or followed by more of the same buffer).
+     * Lets edge tiles of row-contiguous operands use aligned 16-B loads (the over-read values
+     * only feed output elements that are never stored).  0 = never over-read (default). */
+    int32_t flags;
 } dv_gemm_desc;
 
 int dv_gemm(const dv_gemm_desc* desc, dv_stream_t stream);
 /* test/tuning hook: 0 = heuristic tiling, 1 = 64x64, 2 = 32x32 K-split, 3 = 128x128 */
 int dv_gemm_force_tiling(int tiling);
+/* test/tuning hook: key 0 = workgroup->tile map (0 linear, 1 XCD chunk-major [default]) */
+int dv_gemm_set_option(int key, int value);
 
 /* out[n] = beta*out[n] + sum_m X[m*ldx+n]            (bias gradient) */
 int dv_colsum(const float* X, int64_t ldx, int32_t M, int32_t N, float* out, float beta, dv_stream_t stream);
