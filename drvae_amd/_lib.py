@@ -27,6 +27,10 @@ class GemmDesc(C.Structure):
                 ('yref', _p), ('ldy', _i64), ('a_colsum', _p), ('colsum_beta', _f), ('flags', _i32)]
 
 
+class LossTerm(C.Structure):
+    _fields_ = [('x', _p), ('w', _p), ('n', _i32), ('scale', _f), ('out', _i32)]
+
+
 # name -> argtypes (restype is int unless noted); mirrors include/drvae_hip.h one to one
 SIGNATURES = {
     'dv_abi_version': [],
@@ -55,6 +59,7 @@ SIGNATURES = {
     'dv_rows_gather': [_p, _i64, _p, _i32, _i32, _p, _i64, _f, _p, _i32, _p, _i64, _p],
     'dv_rows_segment_sum': [_p, _i64, _p, _p, _p, _i32, _i32, _p, _p, _i64, _f, _p],
     'dv_weighted_sum': [_p, _p, _p, _i32, _f, _p, _f, _p],
+    'dv_loss_assemble': [C.POINTER(LossTerm), _i32, _p, _p, _p, _p],
     'dv_axpby': [_p, _f, _p, _f, _i64, _p],
     'dv_adam_l2': [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _f, _p, _p],
     'dv_counter_add': [_p, _i32, _i64, _p],

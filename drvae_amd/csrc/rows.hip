@@ -476,6 +476,39 @@ __global__ __launch_bounds__(256) void weighted_sum_kernel(const float* __restri
     }
 }
 
+struct LossTerms {
+    dv_loss_term t[DV_MAX_LOSS_TERMS];
+    int n;
+};
+
+// all loss scalars of a step in ONE single-workgroup launch: loss[out] += scale * sum_i w[i]*x[i]
+// per term, then ELBO = <w_elbo, loss[0:3]>, CMPL = <w_cmpl, loss[0:8]>  (src/DrVAE.py:611-624)
+__global__ __launch_bounds__(256) void loss_assemble_kernel(LossTerms lt, const float* __restrict__ w_elbo,
+                                                            const float* __restrict__ w_cmpl,
+                                                            float* __restrict__ loss) {
+    __shared__ float part[4];
+    __shared__ float acc[8];
+    if (threadIdx.x < 8) acc[threadIdx.x] = 0.f;
+    __syncthreads();
+    for (int k = 0; k < lt.n; ++k) {
+        const dv_loss_term t = lt.t[k];
+        float s = 0.f;
+        for (int i = threadIdx.x; i < t.n; i += 256) s += (t.w ? t.w[i] : 1.f) * t.x[i];
+        s = dv_wave_sum_all(s);
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) acc[t.out] += t.scale * ((part[0] + part[1]) + (part[2] + part[3]));
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        acc[5] = w_elbo[0] * acc[0] + w_elbo[1] * acc[1] + w_elbo[2] * acc[2];
+        float c = 0.f;
+        for (int i = 0; i < 8; ++i) c += w_cmpl[i] * acc[i];
+        acc[6] = c;
+        for (int i = 0; i < 8; ++i) loss[i] = acc[i];
+    }
+}
+
 __global__ void axpby_kernel(const float* __restrict__ x, float a, float* __restrict__ y, float b, int64_t n) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         y[i] = a * x[i] + (b != 0.f ? b * y[i] : 0.f);
@@ -713,6 +746,20 @@ extern "C" int dv_weighted_sum(const float* x, const float* w, const int32_t* id
     DV_REQUIRE(n >= 0 && out);
     DV_REQUIRE(n == 0 || x);
     hipLaunchKernelGGL(weighted_sum_kernel, dim3(1), dim3(256), 0, ST(stream), x, w, idx, n, scale, out, beta);
+    DV_RETURN_LAUNCH();
+}
+
+extern "C" int dv_loss_assemble(const dv_loss_term* terms, int32_t n_terms, const float* w_elbo,
+                                const float* w_cmpl, float* loss, dv_stream_t stream) {
+    DV_REQUIRE(n_terms >= 0 && n_terms <= DV_MAX_LOSS_TERMS && (terms || n_terms == 0));
+    DV_REQUIRE(w_elbo && w_cmpl && loss);
+    LossTerms lt;
+    lt.n = n_terms;
+    for (int i = 0; i < n_terms; ++i) {
+        DV_REQUIRE(terms[i].out >= 0 && terms[i].out < 5 && terms[i].n >= 0 && (terms[i].x || terms[i].n == 0));
+        lt.t[i] = terms[i];
+    }
+    hipLaunchKernelGGL(loss_assemble_kernel, dim3(1), dim3(256), 0, ST(stream), lt, w_elbo, w_cmpl, loss);
     DV_RETURN_LAUNCH();
 }
 

@@ -208,6 +208,31 @@ class _Chain:
                     c0 += w
 
 
+class _Branch:
+    """Fork/join of an independent launch chain onto a side HIP stream.  Inside a hipGraph
+    capture the side stream joins the capture, so the chain becomes a parallel branch of the
+    graph; on CPU tensors (unit tests with stand-in launchers) it degrades to inline execution."""
+
+    def __init__(self, device, enabled=True):
+        self.on = enabled and torch.device(device).type == 'cuda'
+        self.side = torch.cuda.Stream(device=device) if self.on else None
+
+    def __enter__(self):
+        if self.on:
+            self.side.wait_stream(torch.cuda.current_stream())
+            self._ctx = torch.cuda.stream(self.side)
+            self._ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            self._ctx.__exit__(*exc)
+
+    def join(self):
+        if self.on:
+            torch.cuda.current_stream().wait_stream(self.side)
+
+
 class FusedStep:
     """Owns the arena views, the per-batch plan (index lists + buffers) and the launch
     sequence.  Typical use::
@@ -218,7 +243,7 @@ class FusedStep:
         eng.forward(); eng.backward(); eng.optimizer_step()
     """
 
-    def __init__(self, cfg, arena, seed=12345):
+    def __init__(self, cfg, arena, seed=12345, concurrent=True):
         self.cfg, self.arena = cfg, arena
         self.dev = arena.device
         self.iters = 0                      # finished_training_iters (src/DGMMixin.py:124)
@@ -228,6 +253,7 @@ class FusedStep:
         self.seed = seed
         self.training = True
         self.add_noise = True               # `fit(add_noise=...)` flag of the reference (src/DrVAE.py:769)
+        self.branch = _Branch(self.dev, enabled=concurrent)   # classifier/fprop chain || decoder chain
         self._build_layers()
 
     # ------------------------------------------------------------------ layer table
@@ -343,56 +369,59 @@ class FusedStep:
         if cfg.has_pert:
             P2 = p.c_z2F.forward([Z1blk], resid=Z1blk)
             K.reparam_fwd(p.Z2F, P2[:, :Z1], P2[:, Z1:], p.E2F, sub=Z1blk, out2=p.D)
-            if Np:
-                K.rows_gather(p.ZDEC[p.o3:], p.Z2F, p.pidx)
+        # ---- two independent chains from here: the classifier / fprop chain (many small launches)
+        # runs on a side stream next to the decoder chain (the big GEMMs)
+        with self.branch:
+            if cfg.kind == 'pvae':
+                K.kl_rows_fwd(p.KLP, p.KLPraw, Qmu, Qlv, prior=(0.0, 0.0), free_bits=True, kl_min=cfg.kl_min)
+            if cfg.has_pert and Np:
+                P2 = p.c_z2F.out[-1]
                 K.kl_rows_fwd(p.KLZ2, p.KLZ2raw, Qmu, Qlv, P2[:, :Z1], P2[:, Z1:], qidx=p.qz2_idx, pidx=p.pidx,
                               reps=L, free_bits=True, kl_min=cfg.kl_min)
-        if cfg.kind == 'pvae':
-            K.kl_rows_fwd(p.KLP, p.KLPraw, Qmu, Qlv, prior=(0.0, 0.0), free_bits=True, kl_min=cfg.kl_min)
+            # ---- q(y|.), fprop over (labeled: true class | unlabeled: every class)
+            if cfg.has_y:
+                if cfg.kind == 'drvae':
+                    clf_in = [Z1blk, p.D] if cfg.clf_z1z2 else [p.Z2F]
+                else:
+                    clf_in = [Z1blk]
+                logits = p.c_clf.forward(clf_in)
+                K.softmax_clamp_fwd(p.QY, logits)
+                if p.Mf:
+                    Z3, Y = cfg.dim_z3, cfg.dim_y
+                    K.rows_gather(p.FPIN, Z1blk, p.fp_src, onehot_cls=p.fp_cls, n_classes=Y)
+                    Q3 = p.c_top.forward([p.FPIN])
+                    K.reparam_fwd(p.Z3IN[:, :Z3], Q3[:, :Z3], Q3[:, Z3:], p.E3)
+                    K.kl_rows_fwd(p.KL3, p.KL3raw, Q3[:, :Z3], Q3[:, Z3:], prior=(0.0, 0.0), free_bits=True,
+                                  kl_min=cfg.kl_min)
+                    PZ1 = p.c_dz1.forward([p.Z3IN])
+                    K.kl_rows_fwd(p.KL1, p.KL1raw, Qmu, Qlv, PZ1[:, :Z1], PZ1[:, Z1:], qidx=p.fp_q, free_bits=True,
+                                  kl_min=cfg.kl_min)
+                    K.axpby(p.KLFP, p.KL3, 1.0, 0.0)
+                    K.axpby(p.KLFP, p.KL1, 1.0, 1.0)
+                K.ymarg_fwd(p.YLrow, p.KLDrow, p.QY, p.label_r, p.fp_ptr, p.KLFP, math.log(1.0 / cfg.dim_y))
         # ---- p(x|z): decoder over all stacked samples, then the NLL over genes
+        if cfg.has_pert and Np:
+            K.rows_gather(p.ZDEC[p.o3:], p.Z2F, p.pidx)
         X = cfg.dim_x
         PX = p.c_decx.forward([p.ZDEC])
         K.nll_rows_fwd(p.NLL, p.XIN, PX[:, :X], PX[:, X:], mode=GAUSS_SIGMA, xidx=p.tgt)
-        # ---- q(y|.), fprop over (labeled: true class | unlabeled: every class)
-        if cfg.has_y:
-            if cfg.kind == 'drvae':
-                clf_in = [Z1blk, p.D] if cfg.clf_z1z2 else [p.Z2F]
-            else:
-                clf_in = [Z1blk]
-            logits = p.c_clf.forward(clf_in)
-            K.softmax_clamp_fwd(p.QY, logits)
-            if p.Mf:
-                Z3, Y = cfg.dim_z3, cfg.dim_y
-                K.rows_gather(p.FPIN, Z1blk, p.fp_src, onehot_cls=p.fp_cls, n_classes=Y)
-                Q3 = p.c_top.forward([p.FPIN])
-                K.reparam_fwd(p.Z3IN[:, :Z3], Q3[:, :Z3], Q3[:, Z3:], p.E3)
-                K.kl_rows_fwd(p.KL3, p.KL3raw, Q3[:, :Z3], Q3[:, Z3:], prior=(0.0, 0.0), free_bits=True,
-                              kl_min=cfg.kl_min)
-                PZ1 = p.c_dz1.forward([p.Z3IN])
-                K.kl_rows_fwd(p.KL1, p.KL1raw, Qmu, Qlv, PZ1[:, :Z1], PZ1[:, Z1:], qidx=p.fp_q, free_bits=True,
-                              kl_min=cfg.kl_min)
-                K.axpby(p.KLFP, p.KL3, 1.0, 0.0)
-                K.axpby(p.KLFP, p.KL1, 1.0, 1.0)
-            K.ymarg_fwd(p.YLrow, p.KLDrow, p.QY, p.label_r, p.fp_ptr, p.KLFP, math.log(1.0 / cfg.dim_y))
+        self.branch.join()
         self._loss_scalars()
 
     def _loss_scalars(self):
         """RECL, KLD, PERT, YL, ELBO, CMPL (src/DrVAE.py:611-624) as device scalars."""
         cfg, p = self.cfg, self.plan
-        loss = self.arena.loss
         L = cfg.L
-        loss.zero_()
-        K.weighted_sum(loss[0:1], p.NLL[:p.o3], scale=1.0 / (L * p.n_tot))
+        terms = [(p.NLL[:p.o3], None, 1.0 / (L * p.n_tot), 0)]
         if cfg.has_pert and p.Np:
-            K.weighted_sum(loss[2:3], p.NLL[p.o3:], scale=1.0 / (L * max(1., p.n_pairs)))
-            K.weighted_sum(loss[1:2], p.KLZ2, w=p.c_klz2)     # beta_pert*rate/(L N) lives on the device
+            terms.append((p.NLL[p.o3:], None, 1.0 / (L * max(1., p.n_pairs)), 2))
+            terms.append((p.KLZ2, p.c_klz2, 1.0, 1))           # beta_pert*rate/(L N) lives on the device
         if cfg.kind == 'pvae':
-            K.weighted_sum(loss[1:2], p.KLP, scale=1.0 / p.n_tot, beta=1.0)
+            terms.append((p.KLP, None, 1.0 / p.n_tot, 1))
         if cfg.has_y:
-            K.weighted_sum(loss[1:2], p.KLDrow, scale=1.0 / (L * p.n_tot), beta=1.0)
-            K.weighted_sum(loss[3:4], p.YLrow, scale=1.0 / (L * max(1., p.n_lab)))
-        K.weighted_sum(loss[5:6], loss[0:3], w=p.w_elbo)
-        K.weighted_sum(loss[6:7], loss, w=p.w_cmpl, n=N_LOSS)
+            terms.append((p.KLDrow, None, 1.0 / (L * p.n_tot), 1))
+            terms.append((p.YLrow, None, 1.0 / (L * max(1., p.n_lab)), 3))
+        K.loss_assemble(self.arena.loss, terms, p.w_elbo, p.w_cmpl)
 
     # --------------------------------------------------------------------- backward
     def backward(self):
@@ -402,38 +431,48 @@ class FusedStep:
         Qmu, Qlv = Q[:, :Z1], Q[:, Z1:]
         DQ = p.DQ
         Z1blk, DZ1 = p.ZDEC[:L * B], p.DZDEC[:L * B]
-        # ---- reconstruction terms: d/d(mu, pre-softplus) straight from the per-row coefficients
+        # ---- side chain: y-marginalisation, fprop, classifier -> DZ1B (its share of d/dz1), DZ2F
+        with self.branch:
+            if cfg.has_y:
+                Y = cfg.dim_y
+                K.ymarg_bwd(p.CFP, p.DQY, p.QY, p.label_r, p.fp_ptr, p.KLFP, math.log(1.0 / Y), p.c_kld, p.c_yl)
+                if p.Mf:
+                    Z3 = cfg.dim_z3
+                    PZ1, Q3 = p.c_dz1.out[-1], p.c_top.out[-1]
+                    # KL(q(z1|x) || p(z1|z3,y)): gradient to p (decoder_z1 heads) and, row-aligned, to q
+                    K.kl_rows_bwd(p.DQFP[:, :Z1], p.DQFP[:, Z1:], p.DPZ1[:, :Z1], p.DPZ1[:, Z1:], p.CFP, p.KL1raw,
+                                  Qmu, Qlv, PZ1[:, :Z1], PZ1[:, Z1:], qidx=p.fp_q, free_bits=True,
+                                  kl_min=cfg.kl_min)
+                    p.c_dz1.backward(p.DPZ1, [p.Z3IN], [[(p.DZ3IN, 1.0, 0.0)]])
+                    # KL(q(z3|z1,y) || N(0,I)) + the sample path
+                    K.kl_rows_bwd(p.DQ3[:, :Z3], p.DQ3[:, Z3:], None, None, p.CFP, p.KL3raw, Q3[:, :Z3], Q3[:, Z3:],
+                                  prior=(0.0, 0.0), free_bits=True, kl_min=cfg.kl_min)
+                    K.reparam_bwd(p.DQ3[:, :Z3], p.DQ3[:, Z3:], p.DZ3IN[:, :Z3], p.E3, Q3[:, Z3:], beta=1.0)
+                    p.c_top.backward(p.DQ3, [p.FPIN], [[(p.DFPIN, 1.0, 0.0)]])
+                    # z1 feeds one (labeled) or Y (unlabeled) fprop rows
+                    K.rows_segment_sum(p.DZ1B, p.DFPIN, seg_ptr=p.fp_ptr, beta=0.0, width=Z1)
+                # classifier
+                K.softmax_clamp_bwd(p.DLOG, p.DQY, p.QY)
+                b1 = 1.0 if p.Mf else 0.0
+                if cfg.kind == 'drvae' and cfg.clf_z1z2:
+                    p.c_clf.backward(p.DLOG, [Z1blk, p.D],
+                                     [[(p.DZ1B, 1.0, b1)], [(p.DZ2F, 1.0, 0.0), (p.DZ1B, -1.0, 1.0)]])
+                elif cfg.kind == 'drvae':
+                    p.c_clf.backward(p.DLOG, [p.Z2F], [[(p.DZ2F, 1.0, 0.0)]])
+                    if not p.Mf:
+                        p.DZ1B.zero_()
+                else:
+                    p.c_clf.backward(p.DLOG, [Z1blk], [[(p.DZ1B, 1.0, b1)]])
+        # ---- main chain: reconstruction terms, d/d(mu, pre-softplus) straight from the per-row
+        # coefficients, then back through the decoder (the three big GEMMs)
         PX = p.c_decx.out[-1]
         K.nll_rows_bwd(p.DPX[:, :X], p.DPX[:, X:], p.c_nll, p.XIN, PX[:, :X], PX[:, X:], mode=GAUSS_SIGMA,
                        xidx=p.tgt, sd_act='softplus', sd_shift=1e-3)
         p.c_decx.backward(p.DPX, [p.ZDEC], [[(p.DZDEC, 1.0, 0.0)]])
+        self.branch.join()
         if cfg.has_y:
-            Y = cfg.dim_y
-            K.ymarg_bwd(p.CFP, p.DQY, p.QY, p.label_r, p.fp_ptr, p.KLFP, math.log(1.0 / Y), p.c_kld, p.c_yl)
-            if p.Mf:
-                Z3 = cfg.dim_z3
-                PZ1, Q3 = p.c_dz1.out[-1], p.c_top.out[-1]
-                # KL(q(z1|x) || p(z1|z3,y)): gradient to p (decoder_z1 heads) and, row-aligned, to q
-                K.kl_rows_bwd(p.DQFP[:, :Z1], p.DQFP[:, Z1:], p.DPZ1[:, :Z1], p.DPZ1[:, Z1:], p.CFP, p.KL1raw,
-                              Qmu, Qlv, PZ1[:, :Z1], PZ1[:, Z1:], qidx=p.fp_q, free_bits=True, kl_min=cfg.kl_min)
-                p.c_dz1.backward(p.DPZ1, [p.Z3IN], [[(p.DZ3IN, 1.0, 0.0)]])
-                # KL(q(z3|z1,y) || N(0,I)) + the sample path
-                K.kl_rows_bwd(p.DQ3[:, :Z3], p.DQ3[:, Z3:], None, None, p.CFP, p.KL3raw, Q3[:, :Z3], Q3[:, Z3:],
-                              prior=(0.0, 0.0), free_bits=True, kl_min=cfg.kl_min)
-                K.reparam_bwd(p.DQ3[:, :Z3], p.DQ3[:, Z3:], p.DZ3IN[:, :Z3], p.E3, Q3[:, Z3:], beta=1.0)
-                p.c_top.backward(p.DQ3, [p.FPIN], [[(p.DFPIN, 1.0, 0.0)]])
-                # z1 feeds one (labeled) or Y (unlabeled) fprop rows
-                K.rows_segment_sum(DZ1, p.DFPIN, seg_ptr=p.fp_ptr, beta=1.0, width=Z1)
-            # classifier
-            K.softmax_clamp_bwd(p.DLOG, p.DQY, p.QY)
-            if cfg.kind == 'drvae' and cfg.clf_z1z2:
-                p.c_clf.backward(p.DLOG, [Z1blk, p.D],
-                                 [[(DZ1, 1.0, 1.0)], [(p.DZ2F, 1.0, 0.0), (DZ1, -1.0, 1.0)]])
-            elif cfg.kind == 'drvae':
-                p.c_clf.backward(p.DLOG, [p.Z2F], [[(p.DZ2F, 1.0, 0.0)]])
-            else:
-                p.c_clf.backward(p.DLOG, [Z1blk], [[(DZ1, 1.0, 1.0)]])
-        elif cfg.has_pert:
+            K.rows_segment_sum(DZ1, p.DZ1B, beta=1.0, width=Z1, n=L * B)
+        if cfg.has_pert and not cfg.has_y:
             p.DZ2F.zero_()
         if cfg.has_pert:
             P2 = p.c_z2F.out[-1]
@@ -638,6 +677,7 @@ class _Plan:
             R, Mf = L * B, self.Mf
             self.c_clf = _Chain(eng.L_clf, R, dev)
             self.QY, self.DQY, self.DLOG = zf(R, Y), zf(R, Y), zf(R, Y)
+            self.DZ1B = mat(R, Z1)
             self.YLrow, self.KLDrow = zf(R), zf(R)
             self.c_top = _Chain(eng.L_top, Mf, dev)
             self.c_dz1 = _Chain(eng.L_dz1, Mf, dev)

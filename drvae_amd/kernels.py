@@ -260,6 +260,15 @@ def weighted_sum(out, x, w=None, idx=None, scale=1.0, beta=0.0, n=None):
                'dv_weighted_sum')
 
 
+def loss_assemble(loss, terms, w_elbo, w_cmpl):
+    """terms: list of (x, w_or_None, scale, out_index); see ``dv_loss_assemble``."""
+    arr = (_lib.LossTerm * max(len(terms), 1))()
+    for i, (x, w, scale, out) in enumerate(terms):
+        arr[i].x, arr[i].w, arr[i].n, arr[i].scale, arr[i].out = _f32(x), _f32(w), x.numel(), scale, out
+    _lib.check(_lib.load().dv_loss_assemble(arr, len(terms), _f32(w_elbo), _f32(w_cmpl), _f32(loss), _stream()),
+               'dv_loss_assemble')
+
+
 def axpby(y, x, a=1.0, b=0.0):
     assert x.is_contiguous() and y.is_contiguous() and x.numel() == y.numel()
     _lib.check(_lib.load().dv_axpby(_f32(x), a, _f32(y), b, x.numel(), _stream()), 'dv_axpby')

@@ -227,6 +227,20 @@ int dv_rows_segment_sum(const float* src, int64_t lds, const int32_t* seg_ptr, c
 /* out[0] = beta*out[0] + scale * sum_i w[i]*x[idx?idx[i]:i]   (loss scalars; one workgroup) */
 int dv_weighted_sum(const float* x, const float* w, const int32_t* idx, int32_t n, float scale, float* out,
                     float beta, dv_stream_t stream);
+/* All loss scalars of one step in a single launch (src/DrVAE.py:611-624):
+ *   loss[0..4] = 0; for each term: loss[out] += scale * sum_i w[i]*x[i]   (w == NULL: plain sum)
+ *   loss[5] (ELBO) = <w_elbo[0..2], loss[0..2]>;  loss[6] (CMPL) = <w_cmpl[0..7], loss[0..7]>
+ * `terms` is a HOST array (copied into the kernel arguments); x/w are device pointers. */
+#define DV_MAX_LOSS_TERMS 8
+typedef struct dv_loss_term {
+    const float* x;
+    const float* w;
+    int32_t n;
+    float scale;
+    int32_t out; /* 0 RECL, 1 KLD, 2 PERT, 3 YL, 4 MMD */
+} dv_loss_term;
+int dv_loss_assemble(const dv_loss_term* terms, int32_t n_terms, const float* w_elbo, const float* w_cmpl,
+                     float* loss, dv_stream_t stream);
 /* y[i] = a*x[i] + b*y[i] over n contiguous floats */
 int dv_axpby(const float* x, float a, float* y, float b, int64_t n, dv_stream_t stream);
 

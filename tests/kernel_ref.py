@@ -378,6 +378,16 @@ def weighted_sum(out, x, w=None, idx=None, scale=1.0, beta=0.0, n=None):
     out.reshape(-1)[0] = (beta * out.reshape(-1)[0] if beta != 0.0 else 0) + scale * s
 
 
+def loss_assemble(loss, terms, w_elbo, w_cmpl):
+    acc = torch.zeros(8, device=loss.device)
+    for (x, w, scale, out) in terms:
+        v = x.reshape(-1)
+        acc[out] = acc[out] + scale * ((v * w.reshape(-1)).sum() if w is not None else v.sum())
+    acc[5] = (w_elbo[:3] * acc[:3]).sum()
+    acc[6] = (w_cmpl[:8] * acc[:8]).sum()
+    loss[:8] = acc
+
+
 def axpby(y, x, a=1.0, b=0.0):
     y.copy_(a * x + (b * y if b != 0.0 else 0))
 
@@ -416,7 +426,7 @@ def fill_normal(out, seed, ctr_dev=None):
 FUNCTIONS = ['gemm', 'linear_fwd', 'linear_bwd_data', 'linear_bwd_weight', 'colsum', 'act_bwd_', 'wn_scale', 'wn_bwd',
              'reparam_fwd', 'reparam_bwd', 'kl_rows_fwd', 'kl_rows_bwd', 'nll_rows_fwd', 'nll_rows_bwd',
              'softmax_clamp_fwd', 'softmax_clamp_bwd', 'cat_terms_fwd', 'cat_terms_bwd', 'ymarg_fwd', 'ymarg_bwd',
-             'rows_gather', 'rows_segment_sum', 'weighted_sum', 'axpby', 'adam_l2', 'counter_add', 'fill_normal']
+             'rows_gather', 'rows_segment_sum', 'weighted_sum', 'loss_assemble', 'axpby', 'adam_l2', 'counter_add', 'fill_normal']
 
 
 def install(monkeypatch):

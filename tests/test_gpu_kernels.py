@@ -400,3 +400,16 @@ def test_fill_normal_statistics_and_counter(K, dev):
     c2 = torch.tensor([-1, 0], dtype=torch.int32, device=dev)     # 0x00000000ffffffff + 1 carries
     K.counter_add(c2, 1)
     assert c2.tolist() == [0, 1]
+
+
+def test_loss_assemble(K, dev):
+    xs = [rnd(dev, n, seed=i) for i, n in enumerate((596, 148, 300, 300, 7))]
+    w1 = rnd(dev, 148, seed=9)
+    terms = [(xs[0][:448], None, 0.25, 0), (xs[0][448:], None, 0.5, 2), (xs[1], w1, 1.0, 1), (xs[2], None, 0.1, 1),
+             (xs[3], None, -0.3, 3), (xs[4], None, 2.0, 1)]
+    w_elbo = torch.tensor([1.0, -1.0, 0.05], device=dev)
+    w_cmpl = torch.tensor([0, 0, 0, -1.0, 0, -1.0, 0, 0], device=dev)
+    loss, ref = torch.full((8,), 9.0, device=dev), torch.zeros(8, device=dev)
+    K.loss_assemble(loss, terms, w_elbo, w_cmpl)
+    R.loss_assemble(ref, terms, w_elbo, w_cmpl)
+    close(loss, ref, rtol=1e-5, atol=1e-4)
