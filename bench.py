@@ -54,7 +54,7 @@ def build(workload, device, rank, world, seed=123):
                 fan = shp[1]
             a = rs.uniform(-1, 1, shp) / np.sqrt(fan)
         arena.p(k).copy_(torch.as_tensor(a, dtype=torch.float32))
-    eng = E.FusedStep(cfg, arena, seed=1000 + rank)
+    eng = E.FusedStep(cfg, arena, seed=1000 + rank, concurrent=os.environ.get('DRVAE_CONCURRENT', '1') != '0')
     batch = synth.make_batch(kind, rows, cfg.dim_x, cfg.dim_y, seed=1234, row0=rank * rows)
     hx, hy = batch['has_x2'].astype(bool), batch['has_y'].astype(bool)
     # weak scaling: every rank has the same group mix, so the global counts are world * local

@@ -377,6 +377,137 @@ __global__ void cat_terms_bwd_kernel(const float* __restrict__ probs, int64_t ld
     }
 }
 
+// ------------------------------------------------- small-N linear head (the classifier)
+// q(y|.) = clamp(softmax([a1|a2] W^T + b)) with N = dim_y <= 8 outputs: an MFMA tile would be
+// >90 % padding, so one wavefront per row does the N dot products, the softmax and the clamp.
+constexpr int kMaxSmallN = 8;
+
+__global__ __launch_bounds__(256) void smalln_fwd_kernel(const float* __restrict__ a1, int64_t lda1, int K1,
+                                                         const float* __restrict__ a2, int64_t lda2, int K2,
+                                                         const float* __restrict__ W, int64_t ldw,
+                                                         const float* __restrict__ bias, int M, int N,
+                                                         float* __restrict__ logits, int64_t ldl,
+                                                         float* __restrict__ probs, int64_t ldp) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= M) return;
+    float acc[kMaxSmallN];
+#pragma unroll
+    for (int j = 0; j < kMaxSmallN; ++j) acc[j] = 0.f;
+    for (int k = lane; k < K1 + K2; k += 64) {
+        const float x = k < K1 ? a1[(int64_t)r * lda1 + k] : a2[(int64_t)r * lda2 + (k - K1)];
+#pragma unroll
+        for (int j = 0; j < kMaxSmallN; ++j)
+            if (j < N) acc[j] += x * W[(int64_t)j * ldw + k];
+    }
+#pragma unroll
+    for (int j = 0; j < kMaxSmallN; ++j) acc[j] = dv_wave_sum_all(acc[j]);
+    if (lane == 0) {
+        float mx = -3.4e38f;
+        for (int j = 0; j < N; ++j) {
+            acc[j] += bias ? bias[j] : 0.f;
+            if (logits) logits[(int64_t)r * ldl + j] = acc[j];
+            mx = fmaxf(mx, acc[j]);
+        }
+        if (probs) {
+            float den = 0.f;
+            for (int j = 0; j < N; ++j) den += expf(acc[j] - mx);
+            for (int j = 0; j < N; ++j)
+                probs[(int64_t)r * ldp + j] = fminf(fmaxf(expf(acc[j] - mx) / den, kPMin), kPMax);
+        }
+    }
+}
+
+// d logits of row r from (d probs, probs) through clamp + softmax, see softmax_clamp_bwd_kernel
+__device__ __forceinline__ void smalln_dlogits(const float* g, const float* p, int N, float* dl) {
+    float dot = 0.f;
+    for (int j = 0; j < N; ++j) dot += (p[j] > kPMin ? g[j] : 0.f) * p[j];
+    for (int j = 0; j < N; ++j) dl[j] = p[j] * ((p[j] > kPMin ? g[j] : 0.f) - dot);
+}
+
+struct SmallNDst {
+    float* dst[3];
+    int64_t ld[3];
+    int col0[3], ncol[3];     // columns [col0, col0+ncol) of W feed this destination
+    int col1[3];              // optional second column block (alpha2 != 0): `[z1, z2F - z1]` inputs
+    float alpha[3], alpha2[3], beta[3];
+    int n;
+};
+
+// dst_t[r, c] = beta*dst_t[r, c] + sum_j dlogit[r,j] * (alpha*W[j, col0_t + c] + alpha2*W[j, col1_t + c])
+__global__ void smalln_bwd_data_kernel(const float* __restrict__ dprobs, int64_t lddp,
+                                       const float* __restrict__ probs, int64_t ldp, int from_probs,
+                                       const float* __restrict__ W, int64_t ldw, int M, int N, SmallNDst d) {
+    int total_cols = 0;
+    for (int t = 0; t < d.n; ++t) total_cols += d.ncol[t];
+    const int64_t total = (int64_t)M * total_cols;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int r = (int)(e / total_cols);
+        int c = (int)(e % total_cols), t = 0;
+        while (c >= d.ncol[t]) {
+            c -= d.ncol[t];
+            ++t;
+        }
+        float dl[kMaxSmallN];
+        if (from_probs) {
+            smalln_dlogits(dprobs + (int64_t)r * lddp, probs + (int64_t)r * ldp, N, dl);
+        } else {
+            for (int j = 0; j < N; ++j) dl[j] = dprobs[(int64_t)r * lddp + j];
+        }
+        float s = 0.f, s2 = 0.f;
+        for (int j = 0; j < N; ++j) s += dl[j] * W[(int64_t)j * ldw + d.col0[t] + c];
+        if (d.alpha2[t] != 0.f)
+            for (int j = 0; j < N; ++j) s2 += dl[j] * W[(int64_t)j * ldw + d.col1[t] + c];
+        float* o = d.dst[t] + (int64_t)r * d.ld[t] + c;
+        *o = (d.beta[t] != 0.f ? d.beta[t] * *o : 0.f) + d.alpha[t] * s + d.alpha2[t] * s2;
+    }
+}
+
+// dW[j, k] = beta*dW + sum_r dlogit[r,j] * [a1|a2][r,k];  db[j] = beta*db + sum_r dlogit[r,j]
+// block = 64 columns x 16 row-groups (1024 threads, LDS reduce over the row-groups in a fixed
+// order: deterministic); rows are walked 4 at a time so that 12 loads are in flight per thread
+constexpr int kSnRG = 16;
+__global__ __launch_bounds__(1024) void smalln_bwd_weight_kernel(const float* __restrict__ dprobs, int64_t lddp,
+                                                                 const float* __restrict__ probs, int64_t ldp,
+                                                                 int from_probs, const float* __restrict__ a1,
+                                                                 int64_t lda1, int K1, const float* __restrict__ a2,
+                                                                 int64_t lda2, int K2, int M, int N,
+                                                                 float* __restrict__ dW, int64_t ldd,
+                                                                 float* __restrict__ db, float beta) {
+    __shared__ float part[kSnRG][kMaxSmallN][64];
+    const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int k = blockIdx.x * 64 + c, KT = K1 + K2;   // k == KT is the bias column
+    float acc[kMaxSmallN];
+#pragma unroll
+    for (int j = 0; j < kMaxSmallN; ++j) acc[j] = 0.f;
+    if (k <= KT) {
+#pragma unroll 4
+        for (int r = rg; r < M; r += kSnRG) {
+            float dl[kMaxSmallN];
+            if (from_probs) {
+                smalln_dlogits(dprobs + (int64_t)r * lddp, probs + (int64_t)r * ldp, N, dl);
+            } else {
+                for (int j = 0; j < N; ++j) dl[j] = dprobs[(int64_t)r * lddp + j];
+            }
+            const float x = k == KT ? 1.f : (k < K1 ? a1[(int64_t)r * lda1 + k] : a2[(int64_t)r * lda2 + (k - K1)]);
+#pragma unroll
+            for (int j = 0; j < kMaxSmallN; ++j)
+                if (j < N) acc[j] += dl[j] * x;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < kMaxSmallN; ++j) part[rg][j][c] = acc[j];
+    __syncthreads();
+    if (rg == 0 && k <= KT) {
+        for (int j = 0; j < N; ++j) {
+            float v = 0.f;
+            for (int g = 0; g < kSnRG; ++g) v += part[g][j][c];
+            float* o = k == KT ? (db ? db + j : nullptr) : dW + (int64_t)j * ldd + k;
+            if (o) *o = (beta != 0.f ? beta * *o : 0.f) + v;
+        }
+    }
+}
+
 // ------------------------------------------------------------- y-marginalisation
 __global__ void ymarg_fwd_kernel(const float* __restrict__ qy, int64_t ldq, const int32_t* __restrict__ label,
                                  const int32_t* __restrict__ fp_ptr, const float* __restrict__ klfp,
@@ -692,6 +823,57 @@ extern "C" int dv_cat_terms_bwd(const float* probs, int64_t ldp, int32_t M, int3
     DV_REQUIRE(g_kl == nullptr || prior != nullptr);
     hipLaunchKernelGGL(cat_terms_bwd_kernel, dim3((M + 255) / 256), dim3(256), 0, ST(stream), probs, ldp, M, Y,
                        labels, prior, ldpr, c_logp, g_kl, ldg, c_ent, dprobs, lddp, beta);
+    DV_RETURN_LAUNCH();
+}
+
+extern "C" int dv_smalln_linear_fwd(const float* a1, int64_t lda1, int32_t K1, const float* a2, int64_t lda2,
+                                    int32_t K2, const float* W, int64_t ldw, const float* bias, int32_t M, int32_t N,
+                                    float* logits, int64_t ldl, float* probs, int64_t ldp, dv_stream_t stream) {
+    DV_REQUIRE(M >= 0 && N >= 1 && N <= kMaxSmallN && K1 >= 0 && K2 >= 0);
+    if (M == 0) return DV_OK;
+    DV_REQUIRE(a1 && W && (a2 || K2 == 0) && (logits || probs));
+    hipLaunchKernelGGL(smalln_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, ST(stream), a1, lda1, K1, a2, lda2, K2, W,
+                       ldw, bias, M, N, logits, ldl, probs, ldp);
+    DV_RETURN_LAUNCH();
+}
+
+extern "C" int dv_smalln_linear_bwd_data(const float* dprobs, int64_t lddp, const float* probs, int64_t ldp,
+                                         const float* W, int64_t ldw, int32_t M, int32_t N, int32_t n_dst,
+                                         float* const* dst, const int64_t* ld, const int32_t* col0,
+                                         const int32_t* ncol, const float* alpha, const float* beta,
+                                         const int32_t* col1, const float* alpha2, dv_stream_t stream) {
+    DV_REQUIRE(M >= 0 && N >= 1 && N <= kMaxSmallN && n_dst >= 1 && n_dst <= 3);
+    if (M == 0) return DV_OK;
+    DV_REQUIRE(dprobs && W && dst && ld && col0 && ncol && alpha && beta);
+    SmallNDst d;
+    d.n = n_dst;
+    int cols = 0;
+    for (int t = 0; t < n_dst; ++t) {
+        DV_REQUIRE(dst[t] != nullptr && ncol[t] >= 0);
+        d.dst[t] = dst[t];
+        d.ld[t] = ld[t];
+        d.col0[t] = col0[t];
+        d.ncol[t] = ncol[t];
+        d.alpha[t] = alpha[t];
+        d.beta[t] = beta[t];
+        d.col1[t] = col1 ? col1[t] : 0;
+        d.alpha2[t] = alpha2 ? alpha2[t] : 0.f;
+        cols += ncol[t];
+    }
+    if (cols == 0) return DV_OK;
+    hipLaunchKernelGGL(smalln_bwd_data_kernel, dim3(grid_for((int64_t)M * cols, 256)), dim3(256), 0, ST(stream),
+                       dprobs, lddp, probs, ldp, probs != nullptr, W, ldw, M, N, d);
+    DV_RETURN_LAUNCH();
+}
+
+extern "C" int dv_smalln_linear_bwd_weight(const float* dprobs, int64_t lddp, const float* probs, int64_t ldp,
+                                           const float* a1, int64_t lda1, int32_t K1, const float* a2,
+                                           int64_t lda2, int32_t K2, int32_t M, int32_t N, float* dW, int64_t ldd,
+                                           float* db, float beta, dv_stream_t stream) {
+    DV_REQUIRE(M >= 0 && N >= 1 && N <= kMaxSmallN && K1 >= 0 && K2 >= 0);
+    DV_REQUIRE(dprobs && a1 && dW && (a2 || K2 == 0));
+    hipLaunchKernelGGL(smalln_bwd_weight_kernel, dim3((K1 + K2 + 1 + 63) / 64), dim3(1024), 0, ST(stream), dprobs,
+                       lddp, probs, ldp, probs != nullptr, a1, lda1, K1, a2, lda2, K2, M, N, dW, ldd, db, beta);
     DV_RETURN_LAUNCH();
 }
 

@@ -19,6 +19,7 @@ Row layout (B rows, Np pairs, L samples):
   fprop rows               per (l, row): 1 row if labeled else Y rows        (src/DrVAE.py:503-526)
 """
 import math
+import os
 from collections import OrderedDict
 from dataclasses import dataclass, field
 from typing import List
@@ -289,6 +290,8 @@ class FusedStep:
             q = 'encoder_y.decoder_p.linear_p'
             layers.append(_Lin(a, q + '.weight', q + '.bias', q + '.g' if wn else None))
             self.L_clf = layers
+            # single Linear with <= 8 classes: dedicated wave-per-row kernels instead of MFMA tiles
+            self.clf_small = (not cfg.h_clf) and cfg.dim_y <= 8 and not wn and os.environ.get('DRVAE_CLF_SMALL', '1') != '0'
             self.L_top = self._gauss(cfg.top_name, len(cfg.h_en_z3), 'lv', shift_second=-2.0)
             self.L_dz1 = self._gauss('decoder_z1', len(cfg.h_de_z1), 'lv', shift_second=-2.0)
 
@@ -384,8 +387,11 @@ class FusedStep:
                     clf_in = [Z1blk, p.D] if cfg.clf_z1z2 else [p.Z2F]
                 else:
                     clf_in = [Z1blk]
-                logits = p.c_clf.forward(clf_in)
-                K.softmax_clamp_fwd(p.QY, logits)
+                if self.clf_small:
+                    lc = self.L_clf[0]
+                    K.smalln_fwd(p.QY, None, clf_in[0], lc.W, lc.b, clf_in[1] if len(clf_in) > 1 else None)
+                else:
+                    K.softmax_clamp_fwd(p.QY, p.c_clf.forward(clf_in))
                 if p.Mf:
                     Z3, Y = cfg.dim_z3, cfg.dim_y
                     K.rows_gather(p.FPIN, Z1blk, p.fp_src, onehot_cls=p.fp_cls, n_classes=Y)
@@ -452,17 +458,32 @@ class FusedStep:
                     # z1 feeds one (labeled) or Y (unlabeled) fprop rows
                     K.rows_segment_sum(p.DZ1B, p.DFPIN, seg_ptr=p.fp_ptr, beta=0.0, width=Z1)
                 # classifier
-                K.softmax_clamp_bwd(p.DLOG, p.DQY, p.QY)
                 b1 = 1.0 if p.Mf else 0.0
-                if cfg.kind == 'drvae' and cfg.clf_z1z2:
-                    p.c_clf.backward(p.DLOG, [Z1blk, p.D],
-                                     [[(p.DZ1B, 1.0, b1)], [(p.DZ2F, 1.0, 0.0), (p.DZ1B, -1.0, 1.0)]])
-                elif cfg.kind == 'drvae':
-                    p.c_clf.backward(p.DLOG, [p.Z2F], [[(p.DZ2F, 1.0, 0.0)]])
-                    if not p.Mf:
-                        p.DZ1B.zero_()
+                two = cfg.kind == 'drvae' and cfg.clf_z1z2
+                if self.clf_small:
+                    lc = self.L_clf[0]
+                    if two:      # input [z1, z2F - z1]: d/dz1 gets W1 - W2, d/dz2F gets W2
+                        K.smalln_bwd_data([(p.DZ1B, 0, 1.0, b1, Z1, -1.0), (p.DZ2F, Z1, 1.0, 0.0)], p.DQY, p.QY, lc.W)
+                        K.smalln_bwd_weight(lc.dW, lc.db, p.DQY, p.QY, Z1blk, p.D)
+                    elif cfg.kind == 'drvae':
+                        K.smalln_bwd_data([(p.DZ2F, 0, 1.0, 0.0)], p.DQY, p.QY, lc.W)
+                        K.smalln_bwd_weight(lc.dW, lc.db, p.DQY, p.QY, p.Z2F)
+                        if not p.Mf:
+                            p.DZ1B.zero_()
+                    else:
+                        K.smalln_bwd_data([(p.DZ1B, 0, 1.0, b1)], p.DQY, p.QY, lc.W)
+                        K.smalln_bwd_weight(lc.dW, lc.db, p.DQY, p.QY, Z1blk)
                 else:
-                    p.c_clf.backward(p.DLOG, [Z1blk], [[(p.DZ1B, 1.0, b1)]])
+                    K.softmax_clamp_bwd(p.DLOG, p.DQY, p.QY)
+                    if two:
+                        p.c_clf.backward(p.DLOG, [Z1blk, p.D],
+                                         [[(p.DZ1B, 1.0, b1)], [(p.DZ2F, 1.0, 0.0), (p.DZ1B, -1.0, 1.0)]])
+                    elif cfg.kind == 'drvae':
+                        p.c_clf.backward(p.DLOG, [p.Z2F], [[(p.DZ2F, 1.0, 0.0)]])
+                        if not p.Mf:
+                            p.DZ1B.zero_()
+                    else:
+                        p.c_clf.backward(p.DLOG, [Z1blk], [[(p.DZ1B, 1.0, b1)]])
         # ---- main chain: reconstruction terms, d/d(mu, pre-softplus) straight from the per-row
         # coefficients, then back through the decoder (the three big GEMMs)
         PX = p.c_decx.out[-1]

@@ -221,6 +221,42 @@ def cat_terms_bwd(dprobs, probs, *, labels=None, prior=None, c_logp=None, g_kl=N
                                             _ld(dprobs), beta, _stream()), 'dv_cat_terms_bwd')
 
 
+def smalln_fwd(probs, logits, a1, W, bias=None, a2=None):
+    """probs = clamp(softmax([a1|a2] W^T + b)) for N <= 8 outputs (either output may be None)."""
+    M = a1.shape[0]
+    N = W.shape[0]
+    K1, K2 = a1.shape[1], (a2.shape[1] if a2 is not None else 0)
+    _lib.check(_lib.load().dv_smalln_linear_fwd(_f32(a1), _ld(a1), K1, _f32(a2), _ld(a2), K2, _f32(W), _ld(W),
+                                                _f32(bias), M, N, _f32(logits), _ld(logits), _f32(probs),
+                                                _ld(probs), _stream()), 'dv_smalln_linear_fwd')
+
+
+def smalln_bwd_data(dsts, dprobs, probs, W):
+    """dsts: list of (dst, col0, alpha, beta[, col1, alpha2]);
+    dst = beta*dst + dlogit @ (alpha*W[:, col0:col0+w] + alpha2*W[:, col1:col1+w]), w = dst.shape[1]."""
+    M, N = dprobs.shape
+    n = len(dsts)
+    P = (C.c_void_p * n)(*[_f32(d[0]) for d in dsts])
+    LD = (C.c_int64 * n)(*[_ld(d[0]) for d in dsts])
+    C0 = (C.c_int32 * n)(*[d[1] for d in dsts])
+    NC = (C.c_int32 * n)(*[d[0].shape[1] for d in dsts])
+    AL = (C.c_float * n)(*[d[2] for d in dsts])
+    BE = (C.c_float * n)(*[d[3] for d in dsts])
+    C1 = (C.c_int32 * n)(*[(d[4] if len(d) > 4 else 0) for d in dsts])
+    A2 = (C.c_float * n)(*[(d[5] if len(d) > 5 else 0.0) for d in dsts])
+    _lib.check(_lib.load().dv_smalln_linear_bwd_data(_f32(dprobs), _ld(dprobs), _f32(probs), _ld(probs), _f32(W),
+                                                     _ld(W), M, N, n, P, LD, C0, NC, AL, BE, C1, A2, _stream()),
+               'dv_smalln_linear_bwd_data')
+
+
+def smalln_bwd_weight(dW, db, dprobs, probs, a1, a2=None, beta=0.0):
+    M, N = dprobs.shape
+    K1, K2 = a1.shape[1], (a2.shape[1] if a2 is not None else 0)
+    _lib.check(_lib.load().dv_smalln_linear_bwd_weight(_f32(dprobs), _ld(dprobs), _f32(probs), _ld(probs), _f32(a1),
+                                                       _ld(a1), K1, _f32(a2), _ld(a2), K2, M, N, _f32(dW), _ld(dW),
+                                                       _f32(db), beta, _stream()), 'dv_smalln_linear_bwd_weight')
+
+
 def ymarg_fwd(yl, kld, qy, label, fp_ptr, klfp, log_prior):
     R, Y = qy.shape
     _lib.check(_lib.load().dv_ymarg_fwd(_f32(qy), _ld(qy), _i32(label), _i32(fp_ptr), _f32(klfp), log_prior, R, Y,

@@ -196,6 +196,28 @@ int dv_cat_terms_bwd(const float* probs, int64_t ldp, int32_t M, int32_t Y, cons
                      const float* prior, int64_t ldpr, const float* c_logp, const float* g_kl, int64_t ldg,
                      const float* c_ent, float* dprobs, int64_t lddp, float beta, dv_stream_t stream);
 
+/* Small-N linear head, N <= 8 outputs -- the classifier q(y|z1,z2) when `dim_h_clf=[]`
+ * (src/DrVAE.py:165, src/blocks.py:446): logits = [a1|a2] W^T + b, probs = clamp(softmax).
+ * One wavefront per row instead of a >90 %-padded MFMA tile.  Either output may be NULL.
+ * Backward takes d(probs) (+ probs: chained through clamp+softmax) or, with probs == NULL,
+ * d(logits) directly:
+ *   bwd_data  : dst_t[r,c] = beta_t*dst_t[r,c] + sum_j dlogit[r,j] (alpha_t W[j,col0_t+c] + alpha2_t W[j,col1_t+c])
+ *               for up to 3 destinations; col1/alpha2 may be NULL (the `[z1, z2F - z1]` input of
+ *               src/DrVAE.py:495 sends W1 - W2 to z1 and W2 to z2F)
+ *   bwd_weight: dW[j,k] = beta*dW + sum_r dlogit[r,j] [a1|a2][r,k];  db[j] likewise (db may be NULL)
+ * The pointer/size arrays of bwd_data are HOST arrays. */
+int dv_smalln_linear_fwd(const float* a1, int64_t lda1, int32_t K1, const float* a2, int64_t lda2, int32_t K2,
+                         const float* W, int64_t ldw, const float* bias, int32_t M, int32_t N, float* logits,
+                         int64_t ldl, float* probs, int64_t ldp, dv_stream_t stream);
+int dv_smalln_linear_bwd_data(const float* dprobs, int64_t lddp, const float* probs, int64_t ldp, const float* W,
+                              int64_t ldw, int32_t M, int32_t N, int32_t n_dst, float* const* dst,
+                              const int64_t* ld, const int32_t* col0, const int32_t* ncol, const float* alpha,
+                              const float* beta, const int32_t* col1, const float* alpha2, dv_stream_t stream);
+int dv_smalln_linear_bwd_weight(const float* dprobs, int64_t lddp, const float* probs, int64_t ldp,
+                                const float* a1, int64_t lda1, int32_t K1, const float* a2, int64_t lda2,
+                                int32_t K2, int32_t M, int32_t N, float* dW, int64_t ldd, float* db, float beta,
+                                dv_stream_t stream);
+
 /* y-marginalisation of src/DrVAE.py:503-534 / src/VFAE.py:331-390 over the stacked
  * "fprop" rows.  For every (l, i) classifier row r (R rows):
  *   labeled   (fp_ptr[r+1]-fp_ptr[r] == 1): yl[r] = log qy[r, label[r]]; kld[r] = klfp[fp row]

@@ -311,6 +311,41 @@ def cat_terms_bwd(dprobs, probs, *, labels=None, prior=None, c_logp=None, g_kl=N
     _acc(dprobs, v, beta)
 
 
+def _dlogits(dprobs, probs):
+    if probs is None:
+        return dprobs
+    g = torch.where(probs > P_MIN, dprobs, torch.zeros_like(dprobs))
+    return probs * (g - (g * probs).sum(1, keepdim=True))
+
+
+def smalln_fwd(probs, logits, a1, W, bias=None, a2=None):
+    x = torch.cat([a1, a2], 1) if a2 is not None else a1
+    z = x @ W.t() + (bias if bias is not None else 0)
+    if logits is not None:
+        logits.copy_(z)
+    if probs is not None:
+        probs.copy_(torch.clamp(torch.softmax(z, -1), min=P_MIN, max=1. - 1e-10))
+
+
+def smalln_bwd_data(dsts, dprobs, probs, W):
+    dl = _dlogits(dprobs, probs)
+    for d in dsts:
+        dst, col0, alpha, beta = d[:4]
+        w = dst.shape[1]
+        v = alpha * (dl @ W[:, col0:col0 + w])
+        if len(d) > 5 and d[5] != 0.0:
+            v = v + d[5] * (dl @ W[:, d[4]:d[4] + w])
+        _acc(dst, v, beta)
+
+
+def smalln_bwd_weight(dW, db, dprobs, probs, a1, a2=None, beta=0.0):
+    dl = _dlogits(dprobs, probs)
+    x = torch.cat([a1, a2], 1) if a2 is not None else a1
+    _acc(dW, dl.t() @ x, beta)
+    if db is not None:
+        _acc(db, dl.sum(0), beta)
+
+
 def ymarg_fwd(yl, kld, qy, label, fp_ptr, klfp, log_prior):
     R, Y = qy.shape
     f0 = fp_ptr[:-1].long()
@@ -425,7 +460,8 @@ def fill_normal(out, seed, ctr_dev=None):
 
 FUNCTIONS = ['gemm', 'linear_fwd', 'linear_bwd_data', 'linear_bwd_weight', 'colsum', 'act_bwd_', 'wn_scale', 'wn_bwd',
              'reparam_fwd', 'reparam_bwd', 'kl_rows_fwd', 'kl_rows_bwd', 'nll_rows_fwd', 'nll_rows_bwd',
-             'softmax_clamp_fwd', 'softmax_clamp_bwd', 'cat_terms_fwd', 'cat_terms_bwd', 'ymarg_fwd', 'ymarg_bwd',
+             'softmax_clamp_fwd', 'softmax_clamp_bwd', 'cat_terms_fwd', 'cat_terms_bwd', 'smalln_fwd', 'smalln_bwd_data',
+             'smalln_bwd_weight', 'ymarg_fwd', 'ymarg_bwd',
              'rows_gather', 'rows_segment_sum', 'weighted_sum', 'loss_assemble', 'axpby', 'adam_l2', 'counter_add', 'fill_normal']
 
 

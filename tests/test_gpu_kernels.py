@@ -413,3 +413,35 @@ def test_loss_assemble(K, dev):
     K.loss_assemble(loss, terms, w_elbo, w_cmpl)
     R.loss_assemble(ref, terms, w_elbo, w_cmpl)
     close(loss, ref, rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize('Y,two', [(2, True), (3, False), (8, True), (1, False)])
+def test_smalln_linear_head(K, dev, Y, two):
+    M, K1, K2 = 301, 100, 100 if two else 0
+    a1 = strided(dev, M, K1, 4, seed=1)
+    a2 = strided(dev, M, K2, 0, seed=2) if two else None
+    W, b = rnd(dev, Y, K1 + K2, seed=3, scale=0.3), rnd(dev, Y, seed=4)
+    p, lg, rp, rlg = (torch.empty(M, Y, device=dev) for _ in range(4))
+    K.smalln_fwd(p, lg, a1, W, b, a2)
+    R.smalln_fwd(rp, rlg, a1, W, b, a2)
+    close(lg, rlg, rtol=1e-4, atol=1e-4)
+    close(p, rp, rtol=1e-4, atol=1e-6)
+    g = rnd(dev, M, Y, seed=5)
+    for probs in (p, None):
+        d1, d2 = rnd(dev, M, K1, seed=6), rnd(dev, M, max(K2, 1), seed=7)
+        r1, r2 = d1.clone(), d2.clone()
+        dsts = [(d1, 0, 1.0, 1.0, K1, -1.0)] if two else [(d1, 0, 0.5, 0.0)]
+        rds = [(r1, 0, 1.0, 1.0, K1, -1.0)] if two else [(r1, 0, 0.5, 0.0)]
+        if two:
+            dsts.append((d2, K1, 1.0, 0.0))
+            rds.append((r2, K1, 1.0, 0.0))
+        K.smalln_bwd_data(dsts, g, probs, W)
+        R.smalln_bwd_data(rds, g, rp if probs is not None else None, W)
+        close(d1, r1, rtol=1e-4, atol=1e-5)
+        close(d2, r2, rtol=1e-4, atol=1e-5)
+        dW, db = rnd(dev, Y, K1 + K2, seed=8), rnd(dev, Y, seed=9)
+        rW, rb = dW.clone(), db.clone()
+        K.smalln_bwd_weight(dW, db, g, probs, a1, a2, beta=1.0)
+        R.smalln_bwd_weight(rW, rb, g, rp if probs is not None else None, a1, a2, beta=1.0)
+        close(dW, rW, rtol=1e-4, atol=1e-4)
+        close(db, rb, rtol=1e-4, atol=1e-4)

@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Per-launch timing of one train step WITHOUT a profiler: every launcher call of a step is
+recorded as a closure, then each is re-issued 10x from its own hipGraph and timed with HIP
+events (so dispatch gaps of graph replay are included, host launch latency is not).  Also
+times the main-stream chain, the side-stream chain and the whole step as single-stream graphs."""
+import os, sys, collections
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+import drvae_amd.kernels as K
+from tests.kernel_ref import FUNCTIONS
+
+def timed_graph(fns, reps=1):
+    g = torch.cuda.CUDAGraph()
+    for f in fns: f()
+    torch.cuda.synchronize()
+    with torch.cuda.graph(g):
+        for _ in range(reps):
+            for f in fns: f()
+    best = 1e9
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); g.replay(); e1.record(); torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) * 1e3 / reps)
+    return best
+
+def main():
+    wl = sys.argv[1] if len(sys.argv) > 1 else 'cfg2'
+    dev = torch.device('cuda:0')
+    cfg, eng, arena, batch, desc = bench.build(wl, dev, 0, 1)
+    eng.train_step()
+    rec = []
+    main_stream = torch.cuda.current_stream().cuda_stream
+    real = {n: getattr(K, n) for n in FUNCTIONS}
+    def mk(name):
+        def f(*a, **kw):
+            side = torch.cuda.current_stream().cuda_stream != main_stream
+            rec.append((name, side, (lambda: real[name](*a, **kw))))
+            return real[name](*a, **kw)
+        return f
+    for n in FUNCTIONS: setattr(K, n, mk(n))
+    eng.draw_noise(); eng.forward(); eng.backward(); eng.optimizer_step()
+    torch.cuda.synchronize()
+    for n in FUNCTIONS: setattr(K, n, real[n])
+    keep = arena.param.clone(), arena.exp_avg.clone(), arena.exp_avg_sq.clone()
+    per = []
+    for i, (name, side, fn) in enumerate(rec):
+        per.append(timed_graph([fn], reps=10))
+    tot = sum(per)
+    print('launches: %d (main %d, side %d); sum of per-launch times %.1f us' % (len(rec), sum(not s for _, s, _ in rec), sum(s for _, s, _ in rec), tot))
+    agg = collections.OrderedDict()
+    for (name, side, _), t in zip(rec, per):
+        k = (name, 'side' if side else 'main')
+        a = agg.setdefault(k, [0, 0.0]); a[0] += 1; a[1] += t
+    for (name, where), (n, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        print('  %-18s %-5s x%-3d %8.1f us  (%.1f each)' % (name, where, n, t, t / n))
+    print('single-stream graph, main-stream launches only : %.1f us' % timed_graph([f for _, s, f in rec if not s]))
+    print('single-stream graph, side-stream launches only : %.1f us' % timed_graph([f for _, s, f in rec if s]))
+    print('single-stream graph, all launches in order     : %.1f us' % timed_graph([f for _, _, f in rec]))
+    print('\nsequence:')
+    for (name, side, _), t in zip(rec, per):
+        print('  %s %-18s %7.1f' % ('S' if side else 'M', name, t))
+
+if __name__ == '__main__':
+    main()
