@@ -34,6 +34,9 @@ WORKLOADS = {
              'DrVAE wide synthetic: 20000 genes, z1=z3=200, enc 2048, dec 2048 (assumed), batch 1024/GPU, L=4'),
 }
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak (dense, exact fp32)
+# HBM-side bytes per GEMM launch from the PMC passes (FETCH_SIZE x2 gfx950 wide-load correction +
+# WRITE_SIZE; rocprofv3 cannot run inside this process): profiles/r01_cfg2_pmc_summary.txt
+PMC_TRAFFIC_BYTES_PER_GEMM_LAUNCH = {'cfg2': 7.01e6}
 
 
 def build(workload, device, rank, world, seed=123):
@@ -89,7 +92,7 @@ def cpu_baseline(workload, budget_s=12.0, threads=4):
                       '%.1f s of CPU work; host has %d logical cores' % (n, rows, L, threads, dt, os.cpu_count())}
 
 
-def gemm_roofline(eng, cfg, rows, frac_pair, frac_lab, repeats=20):
+def gemm_roofline(eng, cfg, rows, frac_pair, frac_lab, repeats=20, traffic=None):
     """Roofline of the dominant kernel family: the fp32-MFMA GEMM (all tilings/layouts; 32
     launches per cfg-2 step).  Every GEMM launch of one train step is re-issued `repeats`
     times back to back from a small hipGraph and timed with HIP events recorded on the
@@ -141,7 +144,9 @@ def gemm_roofline(eng, cfg, rows, frac_pair, frac_lab, repeats=20):
     achieved = algorithmic / t_step / 1e12
     top = sorted(per_call, key=lambda r: -r[0])[:3]
     return {'bound': 'mfma', 'achieved': round(achieved, 3), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-            'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': None,
+            'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': traffic,
+            'traffic_source': 'profiles/r01_cfg2_pmc_summary.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)'
+            if traffic else None,
             'kernel': 'gemm_kernel<...> (fp32 v_mfma_f32_32x32x2_f32; all tilings/layouts)',
             'launches_per_step': len(per_call), 'avg_launch_us': round(1e6 * t_step / len(per_call), 2),
             'gemm_us_per_step': round(1e6 * t_step, 1),
@@ -222,7 +227,8 @@ def main():
         hx, hy = batch['has_x2'].astype(bool), batch['has_y'].astype(bool)
         if not args.no_roofline:
             out['roofline'] = gemm_roofline(eng, cfg, rows, float(hx.mean()), float(hy.mean()),
-                                            repeats=20 if args.workload != 'wide' else 3)
+                                            repeats=20 if args.workload != 'wide' else 3,
+                                            traffic=PMC_TRAFFIC_BYTES_PER_GEMM_LAUNCH.get(args.workload))
         if not args.no_cpu_baseline and args.workload != 'wide':
             out['cpu_baseline'] = cpu_baseline(args.workload)
     if world > 1:

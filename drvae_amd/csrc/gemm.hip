@@ -522,9 +522,7 @@ extern "C" int dv_gemm(const dv_gemm_desc* d, dv_stream_t stream) {
     // tiles only pay once their grids alone fill the chip several times over
     if (tiling == 0) tiling = (t128 >= 1024) ? 3 : (t64 >= 1024 ? 1 : 2);
     if (tiling == 3) return launch_cfg<128, 128, 32, 2, 2, 1>(g, lc, st);
-    if (tiling == 4) return launch_cfg<64, 64, 64, 2, 2, 1>(g, lc, st);
-    if (tiling == 5) return launch_cfg<128, 64, 32, 2, 2, 1>(g, lc, st);
-    if (tiling == 6) return launch_cfg<64, 128, 32, 2, 2, 1>(g, lc, st);
+    if (tiling == 4) return launch_cfg<32, 32, 128, 1, 1, 4>(g, lc, st);
     if (tiling == 1) return launch_cfg<64, 64, 32, 2, 2, 1>(g, lc, st);
     return launch_cfg<32, 32, 64, 1, 1, 4>(g, lc, st);
 }
