@@ -42,11 +42,17 @@ SIGNATURES = {
     'dv_act_bwd': [_p, _i64, _p, _i64, _i32, _i32, _i32, _i32, _i32, _f, _f, _p],
     'dv_wn_scale': [_p, _i64, _p, _i32, _i32, _p, _p, _p],
     'dv_wn_bwd': [_p, _i64, _p, _i64, _p, _p, _i32, _i32, _p, _i64, _p, _f, _p],
-    'dv_reparam_fwd': [_p, _p, _i64, _p, _i32, _i32, _i32, _p, _i64, _i32, _p, _i64, _p, _i64, _p, _i64, _p],
+    'dv_reparam_fwd': [_p, _p, _i64, _p, _i32, _i32, _i32, _p, _i64, _i32, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p,
+                       _p],
+    'dv_reparam_bwd_seg': [_p, _i64, _p, _i64, _p, _i64, _p, _p, _i32, _i32, _i32, _p, _i64, _p, _p, _p, _p, _i64, _f,
+                           _p],
+    'dv_z2f_post_bwd': [_p, _i64, _p, _i64, _p, _p, _i64, _p, _i64, _p, _i64, _p, _p, _f, _p, _i64, _p, _i64, _p, _i64,
+                        _p, _i64, _i32, _i32, _i32, _i32, _p],
     'dv_reparam_bwd': [_p, _i64, _p, _i64, _p, _i64, _p, _i32, _i32, _i32, _i32, _p, _p, _i64, _f, _p],
-    'dv_kl_rows_fwd': [_p, _p, _i64, _p, _p, _p, _i64, _p, _f, _f, _i32, _i32, _i32, _i32, _i32, _f, _p, _p, _p],
+    'dv_kl_rows_fwd': [_p, _p, _i64, _p, _p, _p, _i64, _p, _f, _f, _i32, _i32, _i32, _i32, _i32, _f, _p, _p, _p, _p,
+                       _i64, _p, _i64, _p],
     'dv_kl_rows_bwd': [_p, _p, _i32, _f, _p, _p, _i64, _p, _p, _p, _i64, _p, _f, _f, _i32, _i32, _i32, _i32,
-                       _p, _p, _i64, _p, _p, _i64, _f, _p],
+                       _p, _p, _i64, _p, _p, _i64, _f, _p, _i64, _p, _i64, _p],
     'dv_gauss_nll_rows_fwd': [_p, _i64, _p, _p, _p, _i64, _i32, _i32, _i32, _p, _p],
     'dv_gauss_nll_rows_bwd': [_p, _p, _i64, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _f, _p, _p, _i64, _p, _i64,
                               _f, _p],

@@ -92,7 +92,8 @@ __global__ void reparam_fwd_kernel(const float* __restrict__ mu, const float* __
                                    const int32_t* __restrict__ src_idx, int n, int reps, int Z,
                                    const float* __restrict__ eps, int64_t lde, int mode, float* __restrict__ out,
                                    int64_t ldo, const float* __restrict__ sub, int64_t lds,
-                                   float* __restrict__ out2, int64_t ldo2) {
+                                   float* __restrict__ out2, int64_t ldo2, float* __restrict__ out3, int64_t ldo3,
+                                   const int32_t* __restrict__ out3_idx) {
     const int64_t total = (int64_t)n * reps * Z;
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         const int r = (int)(e / Z), d = (int)(e % Z);
@@ -103,6 +104,10 @@ __global__ void reparam_fwd_kernel(const float* __restrict__ mu, const float* __
         const float z = eps[(int64_t)r * lde + d] * std_ + mu[qi * ldq + d];
         out[(int64_t)r * ldo + d] = z;
         if (out2) out2[(int64_t)r * ldo2 + d] = z - sub[(int64_t)r * lds + d];
+        if (out3) {
+            const int t = out3_idx[r];
+            if (t >= 0) out3[(int64_t)t * ldo3 + d] = z;
+        }
     }
 }
 
@@ -129,6 +134,100 @@ __global__ void reparam_bwd_kernel(const float* __restrict__ dz, int64_t ldz, co
     }
 }
 
+// CSR form: q row i collects the samples listed in seg_rows[seg_ptr[i]..seg_ptr[i+1]) (any number of
+// draws per row, e.g. L z1-samples + L z2-samples of a paired row) plus, optionally, row-aligned
+// (dmu | dsd) contributions listed in a second CSR (the KL(q(z1|x)||p(z1|z3,y)) gradients of its
+// fprop rows).  One launch replaces reparam_bwd x2 + a segment sum; deterministic.
+__global__ void reparam_bwd_seg_kernel(const float* __restrict__ dz, int64_t ldz, const float* __restrict__ eps,
+                                       int64_t lde, const float* __restrict__ sd, int64_t ldq,
+                                       const int32_t* __restrict__ seg_ptr, const int32_t* __restrict__ seg_rows,
+                                       int nq, int Z, int mode, const float* __restrict__ extra, int64_t ldx,
+                                       const int32_t* __restrict__ ex_ptr, const int32_t* __restrict__ ex_rows,
+                                       float* __restrict__ dmu, float* __restrict__ dsd, int64_t lddq, float beta) {
+    const int64_t total = (int64_t)nq * Z;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int i = (int)(e / Z), d = (int)(e % Z);
+        float a = 0.f, b = 0.f;
+        for (int t = seg_ptr[i]; t < seg_ptr[i + 1]; ++t) {
+            const int64_t r = seg_rows[t];
+            const float g = dz[r * ldz + d];
+            a += g;
+            b += g * eps[r * lde + d];
+        }
+        if (mode == DV_GAUSS_LOGVAR) b *= 0.5f * expf(0.5f * sd[(int64_t)i * ldq + d]);
+        if (extra) {
+            for (int t = ex_ptr[i]; t < ex_ptr[i + 1]; ++t) {
+                const int64_t r = ex_rows[t];
+                a += extra[r * ldx + d];
+                b += extra[r * ldx + Z + d];
+            }
+        }
+        float* pm = dmu + (int64_t)i * lddq + d;
+        float* ps = dsd + (int64_t)i * lddq + d;
+        *pm = (beta != 0.f ? beta * *pm : 0.f) + a;
+        *ps = (beta != 0.f ? beta * *ps : 0.f) + b;
+    }
+}
+
+// Backward of everything that hangs on the z2Fz1 samples (src/DrVAE.py:431-433,459-487) in one
+// pass over (row i, dim d), looping the L samples:
+//   dz2F = DZ2F[(l,i)] (+ gradient of the decoded copy for pairs)
+//   DP2[(l,i)] = (dmu2 | dlv2) of p(z2|z1): reparam backward (+ KL(q(z2|x2)||p(z2|z1)) wrt p for pairs)
+//   DZ1[(l,i)] += dmu2 (residual path mu2 = z1 + ...) (+ DZ1B[(l,i)], the side chain's share)
+//   DQ2[jp]    = sum_l KL gradient wrt q(z2|x2)           (pairs only)
+struct Z2FArgs {
+    const float* dz2f; int64_t ld_dz2f;       // (L*B, Z)
+    const float* dzdec_pert; int64_t ld_pert;  // (L*Np, Z) gradient of the decoded z2Fz1 copies, or NULL
+    const int32_t* pair_slot;                  // (B) jp or -1
+    const float* eps; int64_t lde;             // (L*B, Z)
+    const float* p2; int64_t ldp2;             // (L*B, 2Z)  mu2 | lv2
+    const float* q2; int64_t ldq2;             // (Np, 2Z)   mu | lv of q(z2|x2)
+    const float* coef; const float* raw; float kl_min;   // (L*Np) KL coefficients / raw KL (free bits)
+    const float* dz1b; int64_t ld_dz1b;        // (L*B, Z) or NULL
+    float* dp2; int64_t ld_dp2;                // (L*B, 2Z) out
+    float* dz1; int64_t ld_dz1;                // (L*B, Z) in/out (+=)
+    float* dq2; int64_t ld_dq2;                // (Np, 2Z) out, or NULL
+    int L, B, Np, Z;
+};
+
+__global__ void z2f_post_bwd_kernel(Z2FArgs a) {
+    const int64_t total = (int64_t)a.B * a.Z;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int i = (int)(e / a.Z), d = (int)(e % a.Z);
+        const int jp = a.pair_slot ? a.pair_slot[i] : -1;
+        float mq = 0.f, lq = 0.f, gq_mu = 0.f, gq_lv = 0.f;
+        if (jp >= 0) {
+            mq = a.q2[(int64_t)jp * a.ldq2 + d];
+            lq = a.q2[(int64_t)jp * a.ldq2 + a.Z + d];
+        }
+        for (int l = 0; l < a.L; ++l) {
+            const int64_t r = (int64_t)l * a.B + i;
+            const float mp = a.p2[r * a.ldp2 + d], lp = a.p2[r * a.ldp2 + a.Z + d];
+            float g = a.dz2f[r * a.ld_dz2f + d];
+            if (jp >= 0 && a.dzdec_pert) g += a.dzdec_pert[((int64_t)l * a.Np + jp) * a.ld_pert + d];
+            float dmu = g, dlv = g * a.eps[r * a.lde + d] * 0.5f * expf(0.5f * lp);
+            if (jp >= 0) {
+                const int64_t kr = (int64_t)l * a.Np + jp;
+                const float rv = a.raw[kr];
+                const float c = a.coef[kr] * (rv > a.kl_min ? 1.f : (rv == a.kl_min ? 0.5f : 0.f));
+                const float dm = mq - mp, ivp = expf(-lp), vq = expf(lq);
+                gq_mu += c * dm * ivp;
+                gq_lv += c * (-0.5f * (1.f - vq * ivp));
+                dmu += -c * dm * ivp;
+                dlv += c * (-0.5f * (-1.f + (dm * dm + vq) * ivp));
+            }
+            a.dp2[r * a.ld_dp2 + d] = dmu;
+            a.dp2[r * a.ld_dp2 + a.Z + d] = dlv;
+            float* z1 = a.dz1 + r * a.ld_dz1 + d;
+            *z1 += dmu + (a.dz1b ? a.dz1b[r * a.ld_dz1b + d] : 0.f);
+        }
+        if (jp >= 0 && a.dq2) {
+            a.dq2[(int64_t)jp * a.ld_dq2 + d] = gq_mu;
+            a.dq2[(int64_t)jp * a.ld_dq2 + a.Z + d] = gq_lv;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------- KL rows
 struct KlArgs {
     const float *mu_q, *sd_q;
@@ -149,7 +248,10 @@ __device__ __forceinline__ float kl_term(int mode, float mq, float sq, float mp,
 }
 
 __global__ __launch_bounds__(256) void kl_rows_fwd_kernel(KlArgs a, int free_bits, float kl_min,
-                                                          float* __restrict__ raw_out, float* __restrict__ out) {
+                                                          float* __restrict__ raw_out, float* __restrict__ out,
+                                                          const float* __restrict__ add,
+                                                          const float* __restrict__ eps, int64_t lde,
+                                                          float* __restrict__ zout, int64_t ldz) {
     const int lane = threadIdx.x & 63;
     const int rows = a.n * a.reps;
     for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += gridDim.x * 4) {
@@ -162,12 +264,15 @@ __global__ __launch_bounds__(256) void kl_rows_fwd_kernel(KlArgs a, int free_bit
             const float mp = a.mu_p ? a.mu_p[pi * a.ldp + d] : a.prior_mu;
             const float sp = a.mu_p ? a.sd_p[pi * a.ldp + d] : a.prior_sd;
             s += kl_term(a.mode, mq, sq, mp, sp);
+            if (zout)   // fused reparameterised sample of q (same row pass)
+                zout[(int64_t)r * ldz + d] =
+                    mq + eps[(int64_t)r * lde + d] * (a.mode == DV_GAUSS_LOGVAR ? expf(0.5f * sq) : sq);
         }
         s = dv_wave_sum_all(s);
         if (lane == 0) {
             const float raw = -0.5f * s;
             if (raw_out) raw_out[r] = raw;
-            out[r] = free_bits ? fmaxf(raw, kl_min) : raw;
+            out[r] = (free_bits ? fmaxf(raw, kl_min) : raw) + (add ? add[r] : 0.f);
         }
     }
 }
@@ -175,7 +280,9 @@ __global__ __launch_bounds__(256) void kl_rows_fwd_kernel(KlArgs a, int free_bit
 __global__ void kl_rows_bwd_kernel(KlArgs a, const float* __restrict__ coef, const float* __restrict__ raw,
                                    int free_bits, float kl_min, float* __restrict__ dq_mu,
                                    float* __restrict__ dq_sd, int64_t lddq, float* __restrict__ dp_mu,
-                                   float* __restrict__ dp_sd, int64_t lddp, float beta) {
+                                   float* __restrict__ dp_sd, int64_t lddp, float beta,
+                                   const float* __restrict__ dz, int64_t ldz, const float* __restrict__ eps,
+                                   int64_t lde) {
     const int64_t total = (int64_t)a.n * a.reps * a.Z;
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         const int r = (int)(e / a.Z), d = (int)(e % a.Z);
@@ -205,9 +312,15 @@ __global__ void kl_rows_bwd_kernel(KlArgs a, const float* __restrict__ coef, con
             gmp = -gmq;
             gsp = 1.f / sp - (dm * dm + sq * sq) / (vp * sp);
         }
+        float tq_mu = c * gmq, tq_sd = c * gsq;
+        if (dz) {   // the sample drawn from q in the forward pass: z = mu + eps*std
+            const float g = dz[(int64_t)r * ldz + d];
+            tq_mu += g;
+            tq_sd += g * eps[(int64_t)r * lde + d] * (a.mode == DV_GAUSS_LOGVAR ? 0.5f * expf(0.5f * sq) : 1.f);
+        }
         const int64_t oq = (int64_t)r * lddq + d;
-        dq_mu[oq] = (beta != 0.f ? beta * dq_mu[oq] : 0.f) + c * gmq;
-        dq_sd[oq] = (beta != 0.f ? beta * dq_sd[oq] : 0.f) + c * gsq;
+        dq_mu[oq] = (beta != 0.f ? beta * dq_mu[oq] : 0.f) + tq_mu;
+        dq_sd[oq] = (beta != 0.f ? beta * dq_sd[oq] : 0.f) + tq_sd;
         if (dp_mu) {
             const int64_t op = (int64_t)r * lddp + d;
             dp_mu[op] = (beta != 0.f ? beta * dp_mu[op] : 0.f) + c * gmp;
@@ -692,14 +805,16 @@ extern "C" int dv_wn_bwd(const float* dWraw, int64_t ldr, const float* W, int64_
 
 extern "C" int dv_reparam_fwd(const float* mu, const float* sd, int64_t ldq, const int32_t* src_idx, int32_t n,
                               int32_t reps, int32_t Z, const float* eps, int64_t lde, int32_t mode, float* out,
-                              int64_t ldo, const float* sub, int64_t lds, float* out2, int64_t ldo2,
-                              dv_stream_t stream) {
+                              int64_t ldo, const float* sub, int64_t lds, float* out2, int64_t ldo2, float* out3,
+                              int64_t ldo3, const int32_t* out3_idx, dv_stream_t stream) {
     DV_REQUIRE(n >= 0 && reps >= 0 && Z >= 0);
     if (n == 0 || reps == 0 || Z == 0) return DV_OK;
     DV_REQUIRE(mu && sd && eps && out);
     DV_REQUIRE(out2 == nullptr || sub != nullptr);
+    DV_REQUIRE(out3 == nullptr || out3_idx != nullptr);
     hipLaunchKernelGGL(reparam_fwd_kernel, dim3(grid_for((int64_t)n * reps * Z, 256)), dim3(256), 0, ST(stream), mu,
-                       sd, ldq, src_idx, n, reps, Z, eps, lde, mode, out, ldo, sub, lds, out2, ldo2);
+                       sd, ldq, src_idx, n, reps, Z, eps, lde, mode, out, ldo, sub, lds, out2, ldo2, out3, ldo3,
+                       out3_idx);
     DV_RETURN_LAUNCH();
 }
 
@@ -714,17 +829,50 @@ extern "C" int dv_reparam_bwd(const float* dz, int64_t ldz, const float* eps, in
     DV_RETURN_LAUNCH();
 }
 
+extern "C" int dv_reparam_bwd_seg(const float* dz, int64_t ldz, const float* eps, int64_t lde, const float* sd,
+                                  int64_t ldq, const int32_t* seg_ptr, const int32_t* seg_rows, int32_t nq,
+                                  int32_t Z, int32_t mode, const float* extra, int64_t ldx, const int32_t* ex_ptr,
+                                  const int32_t* ex_rows, float* dmu, float* dsd, int64_t lddq, float beta,
+                                  dv_stream_t stream) {
+    DV_REQUIRE(nq >= 0 && Z >= 0);
+    if (nq == 0 || Z == 0) return DV_OK;
+    DV_REQUIRE(dz && eps && sd && seg_ptr && seg_rows && dmu && dsd);
+    DV_REQUIRE(extra == nullptr || (ex_ptr && ex_rows));
+    hipLaunchKernelGGL(reparam_bwd_seg_kernel, dim3(grid_for((int64_t)nq * Z, 256)), dim3(256), 0, ST(stream), dz,
+                       ldz, eps, lde, sd, ldq, seg_ptr, seg_rows, nq, Z, mode, extra, ldx, ex_ptr, ex_rows, dmu, dsd,
+                       lddq, beta);
+    DV_RETURN_LAUNCH();
+}
+
+extern "C" int dv_z2f_post_bwd(const float* dz2f, int64_t ld_dz2f, const float* dzdec_pert, int64_t ld_pert,
+                               const int32_t* pair_slot, const float* eps, int64_t lde, const float* p2, int64_t ldp2,
+                               const float* q2, int64_t ldq2, const float* coef, const float* raw, float kl_min,
+                               const float* dz1b, int64_t ld_dz1b, float* dp2, int64_t ld_dp2, float* dz1,
+                               int64_t ld_dz1, float* dq2, int64_t ld_dq2, int32_t L, int32_t B, int32_t Np, int32_t Z,
+                               dv_stream_t stream) {
+    DV_REQUIRE(L >= 0 && B >= 0 && Np >= 0 && Z >= 0);
+    if (L == 0 || B == 0 || Z == 0) return DV_OK;
+    DV_REQUIRE(dz2f && eps && p2 && dp2 && dz1);
+    DV_REQUIRE(Np == 0 || (pair_slot && q2 && coef && raw));
+    Z2FArgs a{dz2f, ld_dz2f, dzdec_pert, ld_pert, Np ? pair_slot : nullptr, eps, lde, p2, ldp2, q2, ldq2, coef, raw,
+              kl_min, dz1b, ld_dz1b, dp2, ld_dp2, dz1, ld_dz1, dq2, ld_dq2, L, B, Np, Z};
+    hipLaunchKernelGGL(z2f_post_bwd_kernel, dim3(grid_for((int64_t)B * Z, 256)), dim3(256), 0, ST(stream), a);
+    DV_RETURN_LAUNCH();
+}
+
 extern "C" int dv_kl_rows_fwd(const float* mu_q, const float* sd_q, int64_t ldq, const int32_t* qidx,
                               const float* mu_p, const float* sd_p, int64_t ldp, const int32_t* pidx,
                               float prior_mu, float prior_sd, int32_t n, int32_t reps, int32_t Z, int32_t mode,
-                              int32_t free_bits, float kl_min, float* raw_out, float* out, dv_stream_t stream) {
+                              int32_t free_bits, float kl_min, float* raw_out, float* out, const float* add,
+                              const float* eps, int64_t lde, float* zout, int64_t ldz, dv_stream_t stream) {
     DV_REQUIRE(n >= 0 && reps >= 0 && Z >= 0);
     if (n == 0 || reps == 0) return DV_OK;
     DV_REQUIRE(mu_q && sd_q && out);
     DV_REQUIRE((mu_p == nullptr) == (sd_p == nullptr));
+    DV_REQUIRE(zout == nullptr || eps != nullptr);
     KlArgs a{mu_q, sd_q, ldq, qidx, mu_p, sd_p, ldp, pidx, prior_mu, prior_sd, n, reps, Z, mode};
     hipLaunchKernelGGL(kl_rows_fwd_kernel, dim3(grid_for((int64_t)n * reps, 4)), dim3(256), 0, ST(stream), a,
-                       free_bits, kl_min, raw_out, out);
+                       free_bits, kl_min, raw_out, out, add, eps, lde, zout, ldz);
     DV_RETURN_LAUNCH();
 }
 
@@ -733,7 +881,8 @@ extern "C" int dv_kl_rows_bwd(const float* coef, const float* raw, int32_t free_
                               const float* mu_p, const float* sd_p, int64_t ldp, const int32_t* pidx,
                               float prior_mu, float prior_sd, int32_t n, int32_t reps, int32_t Z, int32_t mode,
                               float* dq_mu, float* dq_sd, int64_t lddq, float* dp_mu, float* dp_sd, int64_t lddp,
-                              float beta, dv_stream_t stream) {
+                              float beta, const float* dz, int64_t ldz, const float* eps, int64_t lde,
+                              dv_stream_t stream) {
     DV_REQUIRE(n >= 0 && reps >= 0 && Z >= 0);
     if (n == 0 || reps == 0 || Z == 0) return DV_OK;
     DV_REQUIRE(coef && mu_q && sd_q && dq_mu && dq_sd);
@@ -741,9 +890,10 @@ extern "C" int dv_kl_rows_bwd(const float* coef, const float* raw, int32_t free_
     DV_REQUIRE((mu_p == nullptr) == (sd_p == nullptr));
     DV_REQUIRE((dp_mu == nullptr) == (dp_sd == nullptr));
     DV_REQUIRE(dp_mu == nullptr || mu_p != nullptr);
+    DV_REQUIRE(dz == nullptr || eps != nullptr);
     KlArgs a{mu_q, sd_q, ldq, qidx, mu_p, sd_p, ldp, pidx, prior_mu, prior_sd, n, reps, Z, mode};
     hipLaunchKernelGGL(kl_rows_bwd_kernel, dim3(grid_for((int64_t)n * reps * Z, 256)), dim3(256), 0, ST(stream), a,
-                       coef, raw, free_bits, kl_min, dq_mu, dq_sd, lddq, dp_mu, dp_sd, lddp, beta);
+                       coef, raw, free_bits, kl_min, dq_mu, dq_sd, lddq, dp_mu, dp_sd, lddp, beta, dz, ldz, eps, lde);
     DV_RETURN_LAUNCH();
 }
 

@@ -317,8 +317,9 @@ class FusedStep:
             self.plan = _Plan(self, rows, has_x2[rows], has_y[rows], yv[rows], counts, key)
         p = self.plan
         sel = torch.as_tensor(rows, device=self.dev) if len(rows) != len(has_y) else None
-        p.x1 = x1.index_select(0, sel).contiguous() if sel is not None else x1
-        p.x2 = (x2.index_select(0, sel).contiguous() if sel is not None else x2) if x2 is not None else None
+        p.XSRC[:p.B].copy_(x1.index_select(0, sel) if sel is not None else x1)
+        if x2 is not None and cfg.has_pert:
+            p.XSRC[p.B:].copy_(x2.index_select(0, sel) if sel is not None else x2)
         return p
 
     # ------------------------------------------------------------------------ noise
@@ -357,21 +358,20 @@ class FusedStep:
         p.set_beta(self.beta_pert())
         B, Np, L, Z1 = p.B, p.Np, cfg.L, cfg.dim_z1
         sigma = cfg.add_noise_var if (self.training and self.add_noise and cfg.add_noise_var > 0) else 0.0
-        # ---- inputs (+ training noise N(0,1)*add_noise_var, src/DrVAE.py:404-407,414-417)
-        K.rows_gather(p.XIN[:B], p.x1, None, noise=p.EX[:B] if sigma else None, sigma=sigma)
-        if Np:
-            K.rows_gather(p.XIN[B:], p.x2, p.pair_idx, noise=p.EX[B:] if sigma else None, sigma=sigma)
+        # ---- inputs (+ training noise N(0,1)*add_noise_var, src/DrVAE.py:404-407,414-417): one gather
+        K.rows_gather(p.XIN, p.XSRC, p.xin_idx, noise=p.EX if sigma else None, sigma=sigma)
         # ---- q(z1|x1), q(z2|x2): one pass of the shared encoder
         Q = p.c_enc.forward([p.XIN])
         Qmu, Qlv = Q[:, :Z1], Q[:, Z1:]
-        # ---- samples (reparameterisation, src/blocks.py:170-174)
+        # ---- samples (src/blocks.py:170-174): z1 for every row and z2 for the pairs -- drawn from
+        # q(z1|x1), not q(z2|x2) (quirk 1, src/DrVAE.py:427) -- in one launch
         Z1blk = p.ZDEC[:L * B]
-        K.reparam_fwd(Z1blk, Qmu, Qlv, p.E1, reps=L)
-        if Np:
-            K.reparam_fwd(p.ZDEC[p.o2:p.o3], Qmu, Qlv, p.E2, src_idx=p.pair_idx, reps=L)   # from qz1! (quirk 1)
+        K.reparam_fwd(p.ZDEC[:p.o3], Qmu, Qlv, p.E12, src_idx=p.z_src_idx)
         if cfg.has_pert:
             P2 = p.c_z2F.forward([Z1blk], resid=Z1blk)
-            K.reparam_fwd(p.Z2F, P2[:, :Z1], P2[:, Z1:], p.E2F, sub=Z1blk, out2=p.D)
+            # z2Fz1 sample, the classifier input z2Fz1 - z1, and the decoder's copy for the pairs
+            K.reparam_fwd(p.Z2F, P2[:, :Z1], P2[:, Z1:], p.E2F, sub=Z1blk, out2=p.D,
+                          out3=p.ZDEC if Np else None, out3_idx=p.pert_out_idx if Np else None)
         # ---- two independent chains from here: the classifier / fprop chain (many small launches)
         # runs on a side stream next to the decoder chain (the big GEMMs)
         with self.branch:
@@ -396,18 +396,15 @@ class FusedStep:
                     Z3, Y = cfg.dim_z3, cfg.dim_y
                     K.rows_gather(p.FPIN, Z1blk, p.fp_src, onehot_cls=p.fp_cls, n_classes=Y)
                     Q3 = p.c_top.forward([p.FPIN])
-                    K.reparam_fwd(p.Z3IN[:, :Z3], Q3[:, :Z3], Q3[:, Z3:], p.E3)
+                    # KL(q(z3|z1,y)||N(0,I)) with free bits + the z3 sample, one row pass
                     K.kl_rows_fwd(p.KL3, p.KL3raw, Q3[:, :Z3], Q3[:, Z3:], prior=(0.0, 0.0), free_bits=True,
-                                  kl_min=cfg.kl_min)
+                                  kl_min=cfg.kl_min, eps=p.E3, zout=p.Z3IN[:, :Z3])
                     PZ1 = p.c_dz1.forward([p.Z3IN])
-                    K.kl_rows_fwd(p.KL1, p.KL1raw, Qmu, Qlv, PZ1[:, :Z1], PZ1[:, Z1:], qidx=p.fp_q, free_bits=True,
-                                  kl_min=cfg.kl_min)
-                    K.axpby(p.KLFP, p.KL3, 1.0, 0.0)
-                    K.axpby(p.KLFP, p.KL1, 1.0, 1.0)
+                    # KLFP = max(KL(q(z1|x)||p(z1|z3,y)), kl_min) + the z3 term   (src/DrVAE.py:347,358)
+                    K.kl_rows_fwd(p.KLFP, p.KL1raw, Qmu, Qlv, PZ1[:, :Z1], PZ1[:, Z1:], qidx=p.fp_q, free_bits=True,
+                                  kl_min=cfg.kl_min, add=p.KL3)
                 K.ymarg_fwd(p.YLrow, p.KLDrow, p.QY, p.label_r, p.fp_ptr, p.KLFP, math.log(1.0 / cfg.dim_y))
         # ---- p(x|z): decoder over all stacked samples, then the NLL over genes
-        if cfg.has_pert and Np:
-            K.rows_gather(p.ZDEC[p.o3:], p.Z2F, p.pidx)
         X = cfg.dim_x
         PX = p.c_decx.forward([p.ZDEC])
         K.nll_rows_fwd(p.NLL, p.XIN, PX[:, :X], PX[:, X:], mode=GAUSS_SIGMA, xidx=p.tgt)
@@ -452,8 +449,7 @@ class FusedStep:
                     p.c_dz1.backward(p.DPZ1, [p.Z3IN], [[(p.DZ3IN, 1.0, 0.0)]])
                     # KL(q(z3|z1,y) || N(0,I)) + the sample path
                     K.kl_rows_bwd(p.DQ3[:, :Z3], p.DQ3[:, Z3:], None, None, p.CFP, p.KL3raw, Q3[:, :Z3], Q3[:, Z3:],
-                                  prior=(0.0, 0.0), free_bits=True, kl_min=cfg.kl_min)
-                    K.reparam_bwd(p.DQ3[:, :Z3], p.DQ3[:, Z3:], p.DZ3IN[:, :Z3], p.E3, Q3[:, Z3:], beta=1.0)
+                                  prior=(0.0, 0.0), free_bits=True, kl_min=cfg.kl_min, dz=p.DZ3IN[:, :Z3], eps=p.E3)
                     p.c_top.backward(p.DQ3, [p.FPIN], [[(p.DFPIN, 1.0, 0.0)]])
                     # z1 feeds one (labeled) or Y (unlabeled) fprop rows
                     K.rows_segment_sum(p.DZ1B, p.DFPIN, seg_ptr=p.fp_ptr, beta=0.0, width=Z1)
@@ -491,33 +487,26 @@ class FusedStep:
                        xidx=p.tgt, sd_act='softplus', sd_shift=1e-3)
         p.c_decx.backward(p.DPX, [p.ZDEC], [[(p.DZDEC, 1.0, 0.0)]])
         self.branch.join()
-        if cfg.has_y:
-            K.rows_segment_sum(DZ1, p.DZ1B, beta=1.0, width=Z1, n=L * B)
-        if cfg.has_pert and not cfg.has_y:
-            p.DZ2F.zero_()
         if cfg.has_pert:
+            if not cfg.has_y:
+                p.DZ2F.zero_()
             P2 = p.c_z2F.out[-1]
-            if Np:
-                # z2Fz1 samples of the pairs were decoded (PERT term): scatter their gradient back
-                K.rows_segment_sum(p.DZ2F, p.DZDEC[p.o3:], dst_idx=p.pidx, beta=1.0, n=L * Np)
-            K.reparam_bwd(p.DP2[:, :Z1], p.DP2[:, Z1:], p.DZ2F, p.E2F, P2[:, Z1:])
-            if Np:
-                # KL(q(z2|x2) || p(z2|z1)) with free bits, src/DrVAE.py:466,482-487
-                K.kl_rows_bwd(p.TQ[:, :Z1], p.TQ[:, Z1:], p.TP[:, :Z1], p.TP[:, Z1:], p.c_klz2, p.KLZ2raw, Qmu, Qlv,
-                              P2[:, :Z1], P2[:, Z1:], qidx=p.qz2_idx, pidx=p.pidx, reps=L, free_bits=True,
-                              kl_min=cfg.kl_min)
-                K.rows_segment_sum(p.DP2, p.TP, dst_idx=p.pidx, beta=1.0, n=L * Np)
-                K.rows_segment_sum(DQ[B:], p.TQ, seg_ptr=p.z2_ptr, seg_rows=p.z2_rows)
-            # perturbation function: mu = z1 + z1 W^T + b (residual), logvar head
+            # everything that hangs on the z2Fz1 samples, one launch: scatter-back of the decoded
+            # copies, reparam backward, KL(q(z2|x2)||p(z2|z1)) with free bits (src/DrVAE.py:466,482-487)
+            # wrt both arguments, the residual path, and the side chain's share of d/dz1
+            K.z2f_post_bwd(p.DP2, DZ1, DQ[B:] if Np else None, p.DZ2F, p.DZDEC[p.o3:] if Np else None, p.pair_slot,
+                           p.E2F, P2, Q[B:] if Np else None, p.c_klz2, p.KLZ2raw, cfg.kl_min,
+                           p.DZ1B if cfg.has_y else None, L, B, Np)
+            # perturbation function: mu = z1 + z1 W^T + b, logvar head
             p.c_z2F.backward(p.DP2, [Z1blk], [[(DZ1, 1.0, 1.0)]])
-            K.rows_segment_sum(DZ1, p.DP2, beta=1.0, width=Z1, n=L * B)
-        # ---- back through the samples into q(z1|x1)
-        K.reparam_bwd(DQ[:B, :Z1], DQ[:B, Z1:], DZ1, p.E1, Qlv, reps=L)
-        if Np:
-            K.reparam_bwd(DQ[:, :Z1], DQ[:, Z1:], p.DZDEC[p.o2:p.o3], p.E2, Qlv, src_idx=p.pair_idx, reps=L,
-                          beta=1.0)
-        if cfg.has_y and p.Mf:
-            K.rows_segment_sum(DQ, p.DQFP, seg_ptr=p.q_ptr, seg_rows=p.q_rows, beta=1.0)
+        elif cfg.has_y:
+            K.rows_segment_sum(DZ1, p.DZ1B, beta=1.0, width=Z1, n=L * B)
+        # ---- back through the samples into q(z1|x1): L z1-samples (+ L z2-samples for pairs) per row,
+        # plus the row-aligned KL(q(z1|x)||p(z1|z3,y)) gradients of the row's fprop rows
+        fp = cfg.has_y and p.Mf
+        K.reparam_bwd_seg(DQ[:B, :Z1], DQ[:B, Z1:], p.DZDEC, p.E12, Qlv, p.zseg_ptr, p.zseg_rows,
+                          extra=p.DQFP if fp else None, ex_ptr=p.q_ptr if fp else None,
+                          ex_rows=p.q_rows if fp else None)
         if cfg.kind == 'pvae':
             K.kl_rows_bwd(DQ[:, :Z1], DQ[:, Z1:], None, None, p.c_klp, p.KLPraw, Qmu, Qlv, prior=(0.0, 0.0),
                           free_bits=True, kl_min=cfg.kl_min, beta=1.0)
@@ -639,6 +628,22 @@ class _Plan:
         self.tgt = i32(tgt)
         self.pidx = i32((np.arange(L)[:, None] * B + self.pair_host[None, :]).reshape(-1))
         self.qz2_idx = i32(B + np.arange(Np))
+        # stacked input source [x1 ; x2] and the row list that builds XIN in one gather
+        self.XSRC = torch.zeros(2 * B, X, device=dev)
+        self.xin_idx = i32(np.concatenate([np.arange(B), B + self.pair_host]))
+        # q row of every sample row of ZDEC[:o3] (z1 samples, then z2 samples drawn from q(z1|x1) of the pairs)
+        self.z_src_idx = i32(np.concatenate([np.tile(np.arange(B), L), np.tile(self.pair_host, L)]))
+        slot = np.full(B, -1, np.int64)
+        slot[self.pair_host] = np.arange(Np)
+        self.pair_slot = i32(slot)
+        # ZDEC row that receives the z2Fz1 sample of (l, i) (pairs only)
+        self.pert_out_idx = i32(np.where(slot[None, :] >= 0, (L * B + L * Np) + np.arange(L)[:, None] * Np + slot[None, :],
+                                         -1).reshape(-1))
+        # CSR: q row i -> its sample rows in ZDEC[:o3]
+        zrows = [[l * B + i for l in range(L)] + ([L * B + l * Np + slot[i] for l in range(L)] if slot[i] >= 0 else [])
+                 for i in range(B)]
+        self.zseg_ptr = i32(np.concatenate([[0], np.cumsum([len(r) for r in zrows])]))
+        self.zseg_rows = i32(np.concatenate(zrows) if B else np.zeros(0))
         self.z2_ptr = i32(np.arange(Np + 1) * L)
         self.z2_rows = i32((np.arange(L)[None, :] * Np + np.arange(Np)[:, None]).reshape(-1))
         # ---- noise arena: one flat buffer, one Philox launch per step
@@ -676,6 +681,7 @@ class _Plan:
         self.EX = views[0].view(Me, X)
         self.E1 = views[1].view(L * B, Z1)
         self.E2 = views[2].view(L * Np, Z1)
+        self.E12 = self.noise[sizes[0]:sizes[0] + sizes[1] + sizes[2]].view(L * B + L * Np, Z1)
         self.E2F = views[3].view(L * B, Z1) if cfg.has_pert else None
         self.E3 = views[4].view(self.Mf, Z3) if cfg.has_y else None
         # ---- activations / gradients

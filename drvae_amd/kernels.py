@@ -129,15 +129,18 @@ def wn_bwd(dW, dg, dWraw, W, g, norm, beta=0.0):
 
 
 # --------------------------------------------------------------------------- reparam
-def reparam_fwd(out, mu, sd, eps, *, mode=GAUSS_LOGVAR, src_idx=None, reps=1, sub=None, out2=None):
-    """out[l*n+j] = mu[q] + eps[l*n+j]*std(sd[q]), q = src_idx[j] or j; out2 = out - sub."""
+def reparam_fwd(out, mu, sd, eps, *, mode=GAUSS_LOGVAR, src_idx=None, reps=1, sub=None, out2=None, out3=None,
+                out3_idx=None):
+    """out[l*n+j] = mu[q] + eps[l*n+j]*std(sd[q]), q = src_idx[j] or j; out2 = out - sub;
+    out3[out3_idx[r]] = out[r] where out3_idx[r] >= 0."""
     R, Z = out.shape
     n = R // reps
     assert n * reps == R and eps.shape[0] == R
+    assert _ld(mu) == _ld(sd)
     _lib.check(_lib.load().dv_reparam_fwd(_f32(mu), _f32(sd), _ld(mu), _i32(src_idx), n, reps, Z, _f32(eps),
                                           _ld(eps), mode, _f32(out), _ld(out), _f32(sub), _ld(sub), _f32(out2),
-                                          _ld(out2), _stream()), 'dv_reparam_fwd')
-    assert _ld(mu) == _ld(sd)
+                                          _ld(out2), _f32(out3), _ld(out3), _i32(out3_idx), _stream()),
+               'dv_reparam_fwd')
 
 
 def reparam_bwd(dmu, dsd, dz, eps, sd, *, mode=GAUSS_LOGVAR, src_idx=None, reps=1, beta=0.0):
@@ -149,21 +152,43 @@ def reparam_bwd(dmu, dsd, dz, eps, sd, *, mode=GAUSS_LOGVAR, src_idx=None, reps=
                'dv_reparam_bwd')
 
 
+def reparam_bwd_seg(dmu, dsd, dz, eps, sd, seg_ptr, seg_rows, *, mode=GAUSS_LOGVAR, extra=None, ex_ptr=None,
+                    ex_rows=None, beta=0.0):
+    """CSR backward of the reparameterisation (+ row-aligned extra (dmu|dsd) rows), see dv_reparam_bwd_seg."""
+    nq, Z = seg_ptr.numel() - 1, dz.shape[1]
+    assert _ld(dmu) == _ld(dsd)
+    _lib.check(_lib.load().dv_reparam_bwd_seg(_f32(dz), _ld(dz), _f32(eps), _ld(eps), _f32(sd), _ld(sd),
+                                              _i32(seg_ptr), _i32(seg_rows), nq, Z, mode, _f32(extra), _ld(extra),
+                                              _i32(ex_ptr), _i32(ex_rows), _f32(dmu), _f32(dsd), _ld(dmu), beta,
+                                              _stream()), 'dv_reparam_bwd_seg')
+
+
+def z2f_post_bwd(dp2, dz1, dq2, dz2f, dzdec_pert, pair_slot, eps, p2, q2, coef, raw, kl_min, dz1b, L, B, Np):
+    """fused backward of the z2Fz1 sample / KL(q(z2|x2)||p(z2|z1)) / residual block, see dv_z2f_post_bwd."""
+    Z = dz2f.shape[1]
+    _lib.check(_lib.load().dv_z2f_post_bwd(_f32(dz2f), _ld(dz2f), _f32(dzdec_pert), _ld(dzdec_pert),
+                                           _i32(pair_slot), _f32(eps), _ld(eps), _f32(p2), _ld(p2), _f32(q2),
+                                           _ld(q2), _f32(coef), _f32(raw), kl_min, _f32(dz1b), _ld(dz1b),
+                                           _f32(dp2), _ld(dp2), _f32(dz1), _ld(dz1), _f32(dq2), _ld(dq2), L, B, Np, Z,
+                                           _stream()), 'dv_z2f_post_bwd')
+
+
 # --------------------------------------------------------------------------- KL rows
 def kl_rows_fwd(out, raw, mu_q, sd_q, mu_p=None, sd_p=None, *, prior=(0.0, 0.0), mode=GAUSS_LOGVAR, qidx=None,
-                pidx=None, reps=1, free_bits=False, kl_min=0.0):
+                pidx=None, reps=1, free_bits=False, kl_min=0.0, add=None, eps=None, zout=None):
     R = out.numel()
     n = R // reps
     Z = mu_q.shape[1]
     assert _ld(mu_q) == _ld(sd_q) and (mu_p is None or _ld(mu_p) == _ld(sd_p))
     _lib.check(_lib.load().dv_kl_rows_fwd(_f32(mu_q), _f32(sd_q), _ld(mu_q), _i32(qidx), _f32(mu_p), _f32(sd_p),
                                           _ld(mu_p), _i32(pidx), prior[0], prior[1], n, reps, Z, mode,
-                                          int(free_bits), kl_min, _f32(raw), _f32(out), _stream()),
-               'dv_kl_rows_fwd')
+                                          int(free_bits), kl_min, _f32(raw), _f32(out), _f32(add), _f32(eps),
+                                          _ld(eps), _f32(zout), _ld(zout), _stream()), 'dv_kl_rows_fwd')
 
 
 def kl_rows_bwd(dq_mu, dq_sd, dp_mu, dp_sd, coef, raw, mu_q, sd_q, mu_p=None, sd_p=None, *, prior=(0.0, 0.0),
-                mode=GAUSS_LOGVAR, qidx=None, pidx=None, reps=1, free_bits=False, kl_min=0.0, beta=0.0):
+                mode=GAUSS_LOGVAR, qidx=None, pidx=None, reps=1, free_bits=False, kl_min=0.0, beta=0.0, dz=None,
+                eps=None):
     R = coef.numel()
     n = R // reps
     Z = mu_q.shape[1]
@@ -171,8 +196,8 @@ def kl_rows_bwd(dq_mu, dq_sd, dp_mu, dp_sd, coef, raw, mu_q, sd_q, mu_p=None, sd
     _lib.check(_lib.load().dv_kl_rows_bwd(_f32(coef), _f32(raw), int(free_bits), kl_min, _f32(mu_q), _f32(sd_q),
                                           _ld(mu_q), _i32(qidx), _f32(mu_p), _f32(sd_p), _ld(mu_p), _i32(pidx),
                                           prior[0], prior[1], n, reps, Z, mode, _f32(dq_mu), _f32(dq_sd),
-                                          _ld(dq_mu), _f32(dp_mu), _f32(dp_sd), _ld(dp_mu), beta, _stream()),
-               'dv_kl_rows_bwd')
+                                          _ld(dq_mu), _f32(dp_mu), _f32(dp_sd), _ld(dp_mu), beta, _f32(dz), _ld(dz),
+                                          _f32(eps), _ld(eps), _stream()), 'dv_kl_rows_bwd')
 
 
 # ------------------------------------------------------------------------- NLL rows

@@ -135,13 +135,34 @@ int dv_wn_bwd(const float* dWraw, int64_t ldr, const float* W, int64_t ldw, cons
  *   out[r,d] = mu[qi,d] + eps[r,d] * (mode==LOGVAR ? exp(0.5*sd[qi,d]) : sd[qi,d])
  * (src/blocks.py:170-174, 208-211; eps is explicit so parity tests can inject it).
  * Optional out2[r,d] = out[r,d] - sub[r,d]   (`z2Fz1_sample - z1_sample`, src/DrVAE.py:495).
+ * Optional out3[out3_idx[r], d] = out[r,d] for out3_idx[r] >= 0 (a second, scattered copy:
+ * the z2Fz1 samples of paired rows also feed the decoder, src/DrVAE.py:455-459).
  * backward: dmu[qi] = beta*dmu[qi] + sum_l dz[l*n+j]; dsd likewise with the chain factor. */
 int dv_reparam_fwd(const float* mu, const float* sd, int64_t ldq, const int32_t* src_idx, int32_t n, int32_t reps,
                    int32_t Z, const float* eps, int64_t lde, int32_t mode, float* out, int64_t ldo,
-                   const float* sub, int64_t lds, float* out2, int64_t ldo2, dv_stream_t stream);
+                   const float* sub, int64_t lds, float* out2, int64_t ldo2, float* out3, int64_t ldo3,
+                   const int32_t* out3_idx, dv_stream_t stream);
 int dv_reparam_bwd(const float* dz, int64_t ldz, const float* eps, int64_t lde, const float* sd, int64_t ldq,
                    const int32_t* src_idx, int32_t n, int32_t reps, int32_t Z, int32_t mode, float* dmu, float* dsd,
                    int64_t lddq, float beta, dv_stream_t stream);
+/* CSR form of the backward: q row i (nq rows) sums the sample rows seg_rows[seg_ptr[i]..seg_ptr[i+1])
+ * of dz/eps (any number of draws per q row), and optionally the row-aligned (dmu|dsd) contributions
+ * `extra[ex_rows[t], :2Z]`, t in [ex_ptr[i], ex_ptr[i+1]).  dmu/dsd[i] = beta*old + sums. */
+int dv_reparam_bwd_seg(const float* dz, int64_t ldz, const float* eps, int64_t lde, const float* sd, int64_t ldq,
+                       const int32_t* seg_ptr, const int32_t* seg_rows, int32_t nq, int32_t Z, int32_t mode,
+                       const float* extra, int64_t ldx, const int32_t* ex_ptr, const int32_t* ex_rows, float* dmu,
+                       float* dsd, int64_t lddq, float beta, dv_stream_t stream);
+/* Backward of everything hanging on the z2Fz1 samples (src/DrVAE.py:431-433, 459-487) in one pass
+ * over (row i < B, dim d < Z), looping the L samples r = l*B + i; jp = pair_slot[i] (-1: singleton):
+ *   g       = dz2f[r] + (jp >= 0 ? dzdec_pert[l*Np + jp] : 0)
+ *   dp2[r]  = (g | g*eps*0.5*exp(0.5*lv2)) + [jp >= 0] d KL(q2[jp] || p2[r]) / d p2 * coef[l*Np+jp]*mask
+ *   dz1[r] += dp2[r].mu (residual mu2 = z1 + ..., src/blocks.py:357) + (dz1b ? dz1b[r] : 0)
+ *   dq2[jp] = sum_l d KL / d q2 * coef*mask                      (mask = free-bits gate on raw)      */
+int dv_z2f_post_bwd(const float* dz2f, int64_t ld_dz2f, const float* dzdec_pert, int64_t ld_pert,
+                    const int32_t* pair_slot, const float* eps, int64_t lde, const float* p2, int64_t ldp2,
+                    const float* q2, int64_t ldq2, const float* coef, const float* raw, float kl_min,
+                    const float* dz1b, int64_t ld_dz1b, float* dp2, int64_t ld_dp2, float* dz1, int64_t ld_dz1,
+                    float* dq2, int64_t ld_dq2, int32_t L, int32_t B, int32_t Np, int32_t Z, dv_stream_t stream);
 
 /* ------------------------------------------------ diagonal-Gaussian KL per row (K4)
  * row r = l*n + j: q row = qidx ? qidx[j] : j ; p row = pidx ? pidx[r] : r, or the
@@ -150,17 +171,22 @@ int dv_reparam_bwd(const float* dz, int64_t ldz, const float* eps, int64_t lde, 
  *   LOGVAR: raw = -1/2 sum_d [1 - lv_p + lv_q - ((mu_q-mu_p)^2 + e^lv_q)/e^lv_p]   src/blocks.py:180-182
  *   SIGMA : same with log(std^2), std^2                                              src/blocks.py:217-220
  *   out = free_bits ? max(raw, kl_min) : raw      (per-ROW free bits, src/DGMMixin.py:68-75)
+ *   out[r] += add[r] (optional);  zout[r,d] = mu_q + eps[r,d]*std_q (optional): the reparameterised
+ *   sample of q drawn in the same row pass (q(z3|z1,y): src/DrVAE.py:341-347).
  * backward: coef[r] = dLoss/d out[r]; gradients are written ROW-ALIGNED (row r of
- * dq_* / dp_*); callers reduce duplicates with dv_rows_segment_sum. */
+ * dq_* / dp_*); callers reduce duplicates with dv_rows_segment_sum.  With dz != NULL the
+ * backward of that fused sample (dq_mu += dz, dq_sd += dz*eps*dstd/dsd) rides along. */
 int dv_kl_rows_fwd(const float* mu_q, const float* sd_q, int64_t ldq, const int32_t* qidx, const float* mu_p,
                    const float* sd_p, int64_t ldp, const int32_t* pidx, float prior_mu, float prior_sd, int32_t n,
                    int32_t reps, int32_t Z, int32_t mode, int32_t free_bits, float kl_min, float* raw_out,
-                   float* out, dv_stream_t stream);
+                   float* out, const float* add, const float* eps, int64_t lde, float* zout, int64_t ldz,
+                   dv_stream_t stream);
 int dv_kl_rows_bwd(const float* coef, const float* raw, int32_t free_bits, float kl_min, const float* mu_q,
                    const float* sd_q, int64_t ldq, const int32_t* qidx, const float* mu_p, const float* sd_p,
                    int64_t ldp, const int32_t* pidx, float prior_mu, float prior_sd, int32_t n, int32_t reps,
                    int32_t Z, int32_t mode, float* dq_mu, float* dq_sd, int64_t lddq, float* dp_mu, float* dp_sd,
-                   int64_t lddp, float beta, dv_stream_t stream);
+                   int64_t lddp, float beta, const float* dz, int64_t ldz, const float* eps, int64_t lde,
+                   dv_stream_t stream);
 
 /* ------------------------------------- Gaussian log-likelihood over genes per row (K5)
  * out[r] = -1/2 sum_g [log 2pi + log var + (x-mu)^2/var], x row = xidx ? xidx[r] : r

@@ -163,13 +163,17 @@ def _qrows(n, reps, idx, dev):
     return idx.long()[j] if idx is not None else j
 
 
-def reparam_fwd(out, mu, sd, eps, *, mode=GAUSS_LOGVAR, src_idx=None, reps=1, sub=None, out2=None):
+def reparam_fwd(out, mu, sd, eps, *, mode=GAUSS_LOGVAR, src_idx=None, reps=1, sub=None, out2=None, out3=None,
+                out3_idx=None):
     R = out.shape[0]
     q = _qrows(R // reps, reps, src_idx, out.device)
     z = mu[q] + eps * _std(sd[q], mode)
     out.copy_(z)
     if out2 is not None:
         out2.copy_(z - sub)
+    if out3 is not None:
+        sel = out3_idx.long() >= 0
+        out3[out3_idx.long()[sel]] = z[sel]
 
 
 def reparam_bwd(dmu, dsd, dz, eps, sd, *, mode=GAUSS_LOGVAR, src_idx=None, reps=1, beta=0.0):
@@ -188,6 +192,55 @@ def reparam_bwd(dmu, dsd, dz, eps, sd, *, mode=GAUSS_LOGVAR, src_idx=None, reps=
         dsd[q] = b
 
 
+def reparam_bwd_seg(dmu, dsd, dz, eps, sd, seg_ptr, seg_rows, *, mode=GAUSS_LOGVAR, extra=None, ex_ptr=None,
+                    ex_rows=None, beta=0.0):
+    nq, Z = seg_ptr.numel() - 1, dz.shape[1]
+    for i in range(nq):
+        rows = seg_rows[int(seg_ptr[i]):int(seg_ptr[i + 1])].long()
+        a = dz[rows].sum(0)
+        b = (dz[rows] * eps[rows]).sum(0)
+        if mode == GAUSS_LOGVAR:
+            b = b * 0.5 * torch.exp(0.5 * sd[i])
+        if extra is not None:
+            er = ex_rows[int(ex_ptr[i]):int(ex_ptr[i + 1])].long()
+            a = a + extra[er][:, :Z].sum(0)
+            b = b + extra[er][:, Z:2 * Z].sum(0)
+        dmu[i] = (beta * dmu[i] if beta != 0.0 else 0) + a
+        dsd[i] = (beta * dsd[i] if beta != 0.0 else 0) + b
+
+
+def z2f_post_bwd(dp2, dz1, dq2, dz2f, dzdec_pert, pair_slot, eps, p2, q2, coef, raw, kl_min, dz1b, L, B, Np):
+    Z = dz2f.shape[1]
+    dev = dz2f.device
+    slot = pair_slot.long() if (pair_slot is not None and Np) else torch.full((B,), -1, dtype=torch.long, device=dev)
+    is_pair = slot >= 0
+    if Np and dq2 is not None:
+        dq2.zero_()
+    for l in range(L):
+        rs = slice(l * B, (l + 1) * B)
+        mp, lp = p2[rs, :Z], p2[rs, Z:2 * Z]
+        g = dz2f[rs].clone()
+        if Np and dzdec_pert is not None:
+            g[is_pair] = g[is_pair] + dzdec_pert[l * Np + slot[is_pair]]
+        dmu = g.clone()
+        dlv = g * eps[rs] * 0.5 * torch.exp(0.5 * lp)
+        if Np:
+            kr = l * Np + slot[is_pair]
+            rv = raw[kr]
+            c = (coef[kr] * torch.where(rv > kl_min, torch.ones_like(rv),
+                                        torch.where(rv == kl_min, 0.5 * torch.ones_like(rv), torch.zeros_like(rv))))[:, None]
+            mq, lq = q2[slot[is_pair], :Z], q2[slot[is_pair], Z:2 * Z]
+            dm, ivp, vq = mq - mp[is_pair], torch.exp(-lp[is_pair]), torch.exp(lq)
+            if dq2 is not None:
+                dq2[slot[is_pair], :Z] += c * dm * ivp
+                dq2[slot[is_pair], Z:2 * Z] += c * (-0.5 * (1 - vq * ivp))
+            dmu[is_pair] = dmu[is_pair] - c * dm * ivp
+            dlv[is_pair] = dlv[is_pair] + c * (-0.5 * (-1 + (dm * dm + vq) * ivp))
+        dp2[rs, :Z] = dmu
+        dp2[rs, Z:2 * Z] = dlv
+        dz1[rs] = dz1[rs] + dmu + (dz1b[rs] if dz1b is not None else 0)
+
+
 def _kl_operands(mu_q, sd_q, mu_p, sd_p, prior, qidx, pidx, R, reps):
     q = _qrows(R // reps, reps, qidx, mu_q.device)
     mq, sq = mu_q[q], sd_q[q]
@@ -200,9 +253,11 @@ def _kl_operands(mu_q, sd_q, mu_p, sd_p, prior, qidx, pidx, R, reps):
 
 
 def kl_rows_fwd(out, raw, mu_q, sd_q, mu_p=None, sd_p=None, *, prior=(0.0, 0.0), mode=GAUSS_LOGVAR, qidx=None,
-                pidx=None, reps=1, free_bits=False, kl_min=0.0):
+                pidx=None, reps=1, free_bits=False, kl_min=0.0, add=None, eps=None, zout=None):
     R = out.numel()
     mq, sq, mp, sp = _kl_operands(mu_q, sd_q, mu_p, sd_p, prior, qidx, pidx, R, reps)
+    if zout is not None:
+        zout.copy_(mq + eps * _std(sq, mode))
     if mode == GAUSS_LOGVAR:
         t = 1 - sp + sq - ((mq - mp) ** 2 + sq.exp()) / sp.exp()
     else:
@@ -210,11 +265,13 @@ def kl_rows_fwd(out, raw, mu_q, sd_q, mu_p=None, sd_p=None, *, prior=(0.0, 0.0),
     r = -0.5 * t.sum(1)
     if raw is not None:
         raw.copy_(r)
-    out.copy_(torch.clamp(r, min=kl_min) if free_bits else r)
+    v = torch.clamp(r, min=kl_min) if free_bits else r
+    out.copy_(v + add if add is not None else v)
 
 
 def kl_rows_bwd(dq_mu, dq_sd, dp_mu, dp_sd, coef, raw, mu_q, sd_q, mu_p=None, sd_p=None, *, prior=(0.0, 0.0),
-                mode=GAUSS_LOGVAR, qidx=None, pidx=None, reps=1, free_bits=False, kl_min=0.0, beta=0.0):
+                mode=GAUSS_LOGVAR, qidx=None, pidx=None, reps=1, free_bits=False, kl_min=0.0, beta=0.0, dz=None,
+                eps=None):
     R = coef.numel()
     mq, sq, mp, sp = _kl_operands(mu_q, sd_q, mu_p, sd_p, prior, qidx, pidx, R, reps)
     c = coef.clone()
@@ -231,8 +288,12 @@ def kl_rows_bwd(dq_mu, dq_sd, dp_mu, dp_sd, coef, raw, mu_q, sd_q, mu_p=None, sd
         vp = sp * sp
         gmq, gsq = dm / vp, -1 / sq + sq / vp
         gsp = 1 / sp - (dm * dm + sq * sq) / (vp * sp)
-    _acc(dq_mu, c * gmq, beta)
-    _acc(dq_sd, c * gsq, beta)
+    tq_mu, tq_sd = c * gmq, c * gsq
+    if dz is not None:
+        tq_mu = tq_mu + dz
+        tq_sd = tq_sd + dz * eps * (0.5 * torch.exp(0.5 * sq) if mode == GAUSS_LOGVAR else 1.0)
+    _acc(dq_mu, tq_mu, beta)
+    _acc(dq_sd, tq_sd, beta)
     if dp_mu is not None:
         _acc(dp_mu, -c * gmq, beta)
         _acc(dp_sd, c * gsp, beta)
@@ -459,7 +520,7 @@ def fill_normal(out, seed, ctr_dev=None):
 
 
 FUNCTIONS = ['gemm', 'linear_fwd', 'linear_bwd_data', 'linear_bwd_weight', 'colsum', 'act_bwd_', 'wn_scale', 'wn_bwd',
-             'reparam_fwd', 'reparam_bwd', 'kl_rows_fwd', 'kl_rows_bwd', 'nll_rows_fwd', 'nll_rows_bwd',
+             'reparam_fwd', 'reparam_bwd', 'reparam_bwd_seg', 'z2f_post_bwd', 'kl_rows_fwd', 'kl_rows_bwd', 'nll_rows_fwd', 'nll_rows_bwd',
              'softmax_clamp_fwd', 'softmax_clamp_bwd', 'cat_terms_fwd', 'cat_terms_bwd', 'smalln_fwd', 'smalln_bwd_data',
              'smalln_bwd_weight', 'ymarg_fwd', 'ymarg_bwd',
              'rows_gather', 'rows_segment_sum', 'weighted_sum', 'loss_assemble', 'axpby', 'adam_l2', 'counter_add', 'fill_normal']

@@ -445,3 +445,82 @@ def test_smalln_linear_head(K, dev, Y, two):
         R.smalln_bwd_weight(rW, rb, g, rp if probs is not None else None, a1, a2, beta=1.0)
         close(dW, rW, rtol=1e-4, atol=1e-4)
         close(db, rb, rtol=1e-4, atol=1e-4)
+
+
+def test_fused_extensions_reparam_kl(K, dev):
+    n, Z = 37, 100
+    Q = rnd(dev, n, 2 * Z, seed=1, scale=0.5)
+    mu, lv = Q[:, :Z], Q[:, Z:]
+    eps = rnd(dev, n, Z, seed=2)
+    # reparam with a scattered second copy
+    idx3 = torch.full((n,), -1, dtype=torch.int32)
+    idx3[::3] = torch.randperm(20)[:len(idx3[::3])].to(torch.int32)
+    idx3 = idx3.to(dev)
+    out, o3 = torch.empty(n, Z, device=dev), torch.zeros(20, Z + 4, device=dev)
+    ro, r3 = torch.empty(n, Z, device=dev), torch.zeros(20, Z + 4, device=dev)
+    K.reparam_fwd(out, mu, lv, eps, out3=o3[:, :Z], out3_idx=idx3)
+    R.reparam_fwd(ro, mu, lv, eps, out3=r3[:, :Z], out3_idx=idx3)
+    close(out, ro, rtol=1e-6, atol=1e-6)
+    close(o3, r3, rtol=1e-6, atol=1e-6)
+    # KL vs prior with free bits, fused sample and additive term
+    add = rnd(dev, n, seed=3)
+    kl, raw, z = torch.empty(n, device=dev), torch.empty(n, device=dev), torch.zeros(n, Z + 2, device=dev)
+    rkl, rraw, rz = torch.empty(n, device=dev), torch.empty(n, device=dev), torch.zeros(n, Z + 2, device=dev)
+    kw = dict(prior=(0.0, 0.0), free_bits=True, kl_min=30.0, add=add, eps=eps)
+    K.kl_rows_fwd(kl, raw, mu, lv, zout=z[:, :Z], **kw)
+    R.kl_rows_fwd(rkl, rraw, mu, lv, zout=rz[:, :Z], **kw)
+    close(kl, rkl, rtol=2e-5, atol=1e-4)
+    close(z, rz, rtol=1e-6, atol=1e-6)
+    # backward with the fused sample term
+    coef, dz = rnd(dev, n, seed=4), rnd(dev, n, Z, seed=5)
+    dq, rq = torch.empty(n, 2 * Z, device=dev), torch.empty(n, 2 * Z, device=dev)
+    kwb = dict(prior=(0.0, 0.0), free_bits=True, kl_min=30.0, dz=dz, eps=eps)
+    K.kl_rows_bwd(dq[:, :Z], dq[:, Z:], None, None, coef, raw, mu, lv, **kwb)
+    R.kl_rows_bwd(rq[:, :Z], rq[:, Z:], None, None, coef, rraw, mu, lv, **kwb)
+    close(dq, rq, rtol=2e-5, atol=2e-5)
+
+
+def _csr(sizes, total, dev, seed):
+    g = torch.Generator().manual_seed(seed)
+    ptr = torch.cat([torch.zeros(1, dtype=torch.int64), torch.tensor(sizes).cumsum(0)])
+    rows = torch.randint(0, total, (int(ptr[-1]),), generator=g)
+    return ptr.to(torch.int32).to(dev), rows.to(torch.int32).to(dev)
+
+
+def test_reparam_bwd_seg(K, dev):
+    nq, Z, R_, F_ = 23, 100, 90, 40
+    sd = rnd(dev, nq + 5, 2 * Z, seed=1, scale=0.5)[:, Z:]
+    dz, eps, extra = rnd(dev, R_, Z, seed=2), rnd(dev, R_, Z, seed=3), rnd(dev, F_, 2 * Z, seed=4)
+    sp, sr = _csr([int(v) for v in torch.randint(1, 5, (nq,), generator=torch.Generator().manual_seed(5))], R_, dev, 6)
+    ep, er = _csr([int(v) for v in torch.randint(0, 3, (nq,), generator=torch.Generator().manual_seed(7))], F_, dev, 8)
+    for ex in (True, False):
+        dq, rq = rnd(dev, nq, 2 * Z, seed=9), None
+        rq = dq.clone()
+        kw = dict(extra=extra, ex_ptr=ep, ex_rows=er) if ex else {}
+        K.reparam_bwd_seg(dq[:, :Z], dq[:, Z:], dz, eps, sd, sp, sr, beta=1.0, **kw)
+        R.reparam_bwd_seg(rq[:, :Z], rq[:, Z:], dz, eps, sd, sp, sr, beta=1.0, **kw)
+        close(dq, rq, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize('with_pairs,with_b', [(True, True), (True, False), (False, True)])
+def test_z2f_post_bwd(K, dev, with_pairs, with_b):
+    L, B, Z = 2, 19, 100
+    pairs = torch.arange(B)[torch.arange(B) % 3 == 1] if with_pairs else torch.zeros(0, dtype=torch.int64)
+    Np = len(pairs)
+    slot = torch.full((B,), -1, dtype=torch.int32)
+    slot[pairs] = torch.arange(Np, dtype=torch.int32)
+    slot = slot.to(dev)
+    dz2f, eps = rnd(dev, L * B, Z, seed=1), rnd(dev, L * B, Z, seed=2)
+    p2, q2 = rnd(dev, L * B, 2 * Z, seed=3, scale=0.5), rnd(dev, max(Np, 1), 2 * Z, seed=4, scale=0.5)
+    pert = rnd(dev, max(L * Np, 1), Z, seed=5)
+    coef, raw = rnd(dev, max(L * Np, 1), seed=6), rnd(dev, max(L * Np, 1), seed=7).abs() * 40
+    dz1b = rnd(dev, L * B, Z, seed=8) if with_b else None
+    outs = []
+    for F_ in (K, R):
+        dp2, dz1, dq2 = torch.zeros(L * B, 2 * Z, device=dev), rnd(dev, L * B, Z, seed=9), torch.zeros(max(Np, 1), 2 * Z,
+                                                                                                 device=dev)
+        F_.z2f_post_bwd(dp2, dz1, dq2[:Np] if Np else None, dz2f, pert[:L * Np] if Np else None, slot, eps, p2,
+                        q2[:Np] if Np else None, coef, raw, 30.0, dz1b, L, B, Np)
+        outs.append((dp2, dz1, dq2))
+    for a, b in zip(*outs):
+        close(a, b, rtol=2e-5, atol=2e-5)
