@@ -577,9 +577,9 @@ __global__ void smalln_bwd_data_kernel(const float* __restrict__ dprobs, int64_t
 }
 
 // dW[j, k] = beta*dW + sum_r dlogit[r,j] * [a1|a2][r,k];  db[j] = beta*db + sum_r dlogit[r,j]
-// block = 64 columns x 16 row-groups (1024 threads, LDS reduce over the row-groups in a fixed
-// order: deterministic); rows are walked 4 at a time so that 12 loads are in flight per thread
-constexpr int kSnRG = 16;
+// block = 16 columns x 64 row-groups (1024 threads): every thread walks only M/64 rows, so the
+// chain of dependent global loads is short; fixed-order LDS tree over the row-groups (deterministic)
+constexpr int kSnCols = 16, kSnRG = 64;
 __global__ __launch_bounds__(1024) void smalln_bwd_weight_kernel(const float* __restrict__ dprobs, int64_t lddp,
                                                                  const float* __restrict__ probs, int64_t ldp,
                                                                  int from_probs, const float* __restrict__ a1,
@@ -587,14 +587,13 @@ __global__ __launch_bounds__(1024) void smalln_bwd_weight_kernel(const float* __
                                                                  int64_t lda2, int K2, int M, int N,
                                                                  float* __restrict__ dW, int64_t ldd,
                                                                  float* __restrict__ db, float beta) {
-    __shared__ float part[kSnRG][kMaxSmallN][64];
-    const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
-    const int k = blockIdx.x * 64 + c, KT = K1 + K2;   // k == KT is the bias column
+    __shared__ float part[kSnRG][kMaxSmallN][kSnCols];
+    const int c = threadIdx.x % kSnCols, rg = threadIdx.x / kSnCols;
+    const int k = blockIdx.x * kSnCols + c, KT = K1 + K2;   // k == KT is the bias column
     float acc[kMaxSmallN];
 #pragma unroll
     for (int j = 0; j < kMaxSmallN; ++j) acc[j] = 0.f;
     if (k <= KT) {
-#pragma unroll 4
         for (int r = rg; r < M; r += kSnRG) {
             float dl[kMaxSmallN];
             if (from_probs) {
@@ -611,12 +610,15 @@ __global__ __launch_bounds__(1024) void smalln_bwd_weight_kernel(const float* __
 #pragma unroll
     for (int j = 0; j < kMaxSmallN; ++j) part[rg][j][c] = acc[j];
     __syncthreads();
+    for (int h = kSnRG / 2; h >= 1; h >>= 1) {
+        if (rg < h)
+            for (int j = 0; j < N; ++j) part[rg][j][c] += part[rg + h][j][c];
+        __syncthreads();
+    }
     if (rg == 0 && k <= KT) {
         for (int j = 0; j < N; ++j) {
-            float v = 0.f;
-            for (int g = 0; g < kSnRG; ++g) v += part[g][j][c];
             float* o = k == KT ? (db ? db + j : nullptr) : dW + (int64_t)j * ldd + k;
-            if (o) *o = (beta != 0.f ? beta * *o : 0.f) + v;
+            if (o) *o = (beta != 0.f ? beta * *o : 0.f) + part[0][j][c];
         }
     }
 }
@@ -1022,7 +1024,8 @@ extern "C" int dv_smalln_linear_bwd_weight(const float* dprobs, int64_t lddp, co
                                            float* db, float beta, dv_stream_t stream) {
     DV_REQUIRE(M >= 0 && N >= 1 && N <= kMaxSmallN && K1 >= 0 && K2 >= 0);
     DV_REQUIRE(dprobs && a1 && dW && (a2 || K2 == 0));
-    hipLaunchKernelGGL(smalln_bwd_weight_kernel, dim3((K1 + K2 + 1 + 63) / 64), dim3(1024), 0, ST(stream), dprobs,
+    hipLaunchKernelGGL(smalln_bwd_weight_kernel, dim3((K1 + K2 + 1 + kSnCols - 1) / kSnCols), dim3(1024), 0,
+                       ST(stream), dprobs,
                        lddp, probs, ldp, probs != nullptr, a1, lda1, K1, a2, lda2, K2, M, N, dW, ldd, db, beta);
     DV_RETURN_LAUNCH();
 }

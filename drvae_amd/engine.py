@@ -179,21 +179,31 @@ class _Chain:
             x = [self.out[li]]
         return self.out[-1]
 
-    def backward(self, dpre_last, inputs, dinputs=None):
+    def backward(self, dpre_last, inputs, dinputs=None, wbranch=None):
         """dpre_last: gradient w.r.t. the last layer's pre-activation.  ``dinputs``: per input
-        source a list of (dst, alpha, beta) destinations for its gradient (or None to skip)."""
+        source a list of (dst, alpha, beta) destinations for its gradient (or None to skip).
+        ``wbranch``: optional side stream for the weight-gradient GEMMs (they are leaves: only
+        Adam reads them), so that they overlap the dx chain."""
         dpre = dpre_last
         for li in range(len(self.layers) - 1, -1, -1):
             l = self.layers[li]
             srcs = list(inputs) if li == 0 else [self.out[li - 1]]
-            dW = l.raw if l.g is not None else l.dW
-            c0 = 0
-            for si, s in enumerate(srcs):
-                w = s.shape[1]
-                K.linear_bwd_weight(dW[:, c0:c0 + w], dpre, s, dbias=l.db if si == 0 else None, overread=True)
-                c0 += w
-            if l.g is not None:
-                K.wn_bwd(l.dW, l.dg, l.raw, l.W, l.g, l.norm)
+
+            def wgrad(l=l, srcs=srcs, dpre=dpre):
+                dW = l.raw if l.g is not None else l.dW
+                c0 = 0
+                for si, s in enumerate(srcs):
+                    w = s.shape[1]
+                    K.linear_bwd_weight(dW[:, c0:c0 + w], dpre, s, dbias=l.db if si == 0 else None, overread=True)
+                    c0 += w
+                if l.g is not None:
+                    K.wn_bwd(l.dW, l.dg, l.raw, l.W, l.g, l.norm)
+
+            if wbranch is not None:
+                with wbranch:
+                    wgrad()
+            else:
+                wgrad()
             if li > 0:
                 prev = self.layers[li - 1]
                 K.linear_bwd_data(self.dpre[li - 1], dpre, l.W, kscale=l.scale, yref=self.out[li - 1], act=prev.act0,
@@ -207,6 +217,8 @@ class _Chain:
                         K.linear_bwd_data(dst, dpre, l.W[:, c0:c0 + w], kscale=l.scale, alpha=alpha, beta=beta,
                                           overread=True)
                     c0 += w
+        if wbranch is not None:
+            wbranch.join()
 
 
 class _Branch:
@@ -255,6 +267,7 @@ class FusedStep:
         self.training = True
         self.add_noise = True               # `fit(add_noise=...)` flag of the reference (src/DrVAE.py:769)
         self.branch = _Branch(self.dev, enabled=concurrent)   # classifier/fprop chain || decoder chain
+        self.wbranch = _Branch(self.dev, enabled=concurrent and os.environ.get('DRVAE_WBRANCH', '0') == '1')   # measured slower on MI355X (third graph branch): off
         self._build_layers()
 
     # ------------------------------------------------------------------ layer table
@@ -485,7 +498,7 @@ class FusedStep:
         PX = p.c_decx.out[-1]
         K.nll_rows_bwd(p.DPX[:, :X], p.DPX[:, X:], p.c_nll, p.XIN, PX[:, :X], PX[:, X:], mode=GAUSS_SIGMA,
                        xidx=p.tgt, sd_act='softplus', sd_shift=1e-3)
-        p.c_decx.backward(p.DPX, [p.ZDEC], [[(p.DZDEC, 1.0, 0.0)]])
+        p.c_decx.backward(p.DPX, [p.ZDEC], [[(p.DZDEC, 1.0, 0.0)]], wbranch=self.wbranch if self.wbranch.on else None)
         self.branch.join()
         if cfg.has_pert:
             if not cfg.has_y:
