@@ -113,6 +113,37 @@ class DeepGenerativeModelMixin:
         self.finished_training_iters = eng.iters
         return self._loss_tensors(eng)
 
+    # ---------------------------------------------------------------- evaluation
+    @torch.no_grad()
+    def eval_x_reconstruction(self, x, x_rec, x_rec_logvar=None):
+        """RMSE, variance-weighted R^2, mean per-row Pearson r and mean log-likelihood of a
+        reconstruction (src/DGMMixin.py:128-156).  The O(rows x genes) reductions run in two HIP
+        kernels; the final combination of the (rows x 6) / (3 x genes) partials is done in float64
+        on the host, like the reference's numpy/scipy/sklearn code.  ``x_rec_logvar`` is what the
+        reference passes as third argument of ``decoder_x.logp_perx``: the decoder's std."""
+        from . import kernels as K
+        dev = next(self.parameters()).device
+        x = x.to(dev, torch.float32).contiguous()
+        x_rec = x_rec.to(dev, torch.float32).contiguous()
+        M, X = x.shape
+        rows = torch.empty(M, 6, device=dev)
+        cols = torch.empty(3, X, dtype=torch.float64, device=dev)
+        K.recon_row_stats(rows, x, x_rec)
+        K.col_moments(cols, x, x_rec)
+        r, c = rows.double().cpu().numpy(), cols.cpu().numpy()
+        import numpy as np
+        out = dict()
+        out['rmse'] = float(np.sqrt(r[:, 0].sum() / (M * X)))
+        ss_tot = c[1] - c[0] ** 2 / M
+        out['r2'] = float(1.0 - c[2].sum() / ss_tot.sum())
+        with np.errstate(divide='ignore', invalid='ignore'):
+            out['pearr'] = float((r[:, 5] / np.sqrt(r[:, 3] * r[:, 4])).mean())
+        if x_rec_logvar is not None:
+            out['ll'] = float(self.decoder_x.logp_perx(x, x_rec, x_rec_logvar.to(dev, torch.float32)).mean())
+        else:
+            out['ll'] = float('nan')
+        return out
+
     # ---------------------------------------------------------------- checkpoints
     def save_to_file(self, filename):
         """``torch.save(state_dict)`` with the reference's key names (src/DGMMixin.py:192-197)."""

@@ -722,6 +722,70 @@ __global__ __launch_bounds__(256) void weighted_sum_kernel(const float* __restri
     }
 }
 
+// ------------------------------------------------ reconstruction metrics (evaluation, N1)
+// per row i: [ sum (x-r)^2, mean x, mean r, sum (x-mx)^2, sum (r-mr)^2, sum (x-mx)(r-mr) ]
+// two passes over the (cache-hot) row so that the centred sums do not cancel in fp32; the
+// per-row Pearson r and the RMSE of src/DGMMixin.py:128-156 follow from these six numbers.
+__global__ __launch_bounds__(256) void recon_row_stats_kernel(const float* __restrict__ x, int64_t ldx,
+                                                              const float* __restrict__ r, int64_t ldr, int M, int X,
+                                                              float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < M; i += gridDim.x * 4) {
+        const float* xr = x + (int64_t)i * ldx;
+        const float* rr = r + (int64_t)i * ldr;
+        float sx = 0.f, sr = 0.f, sse = 0.f;
+        for (int g = lane; g < X; g += 64) {
+            const float a = xr[g], b = rr[g];
+            sx += a;
+            sr += b;
+            sse += (a - b) * (a - b);
+        }
+        sx = dv_wave_sum_all(sx);
+        sr = dv_wave_sum_all(sr);
+        sse = dv_wave_sum_all(sse);
+        const float mx = sx / X, mr = sr / X;
+        float cxx = 0.f, crr = 0.f, cxr = 0.f;
+        for (int g = lane; g < X; g += 64) {
+            const float a = xr[g] - mx, b = rr[g] - mr;
+            cxx += a * a;
+            crr += b * b;
+            cxr += a * b;
+        }
+        cxx = dv_wave_sum_all(cxx);
+        crr = dv_wave_sum_all(crr);
+        cxr = dv_wave_sum_all(cxr);
+        if (lane == 0) {
+            float* o = out + (int64_t)i * 6;
+            o[0] = sse; o[1] = mx; o[2] = mr; o[3] = cxx; o[4] = crr; o[5] = cxr;
+        }
+    }
+}
+
+// per column g: sum_i x[i,g] and sum_i x[i,g]^2 (double accumulation) and sum_i (x-r)^2:
+// the ingredients of the variance-weighted R^2 (sklearn r2_score, src/DGMMixin.py:137)
+__global__ __launch_bounds__(256) void col_moments_kernel(const float* __restrict__ x, int64_t ldx,
+                                                          const float* __restrict__ r, int64_t ldr, int M, int X,
+                                                          double* __restrict__ out) {
+    __shared__ double part[4][3][64];
+    const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int g = blockIdx.x * 64 + c;
+    double s1 = 0., s2 = 0., se = 0.;
+    if (g < X)
+        for (int i = rg; i < M; i += 4) {
+            const double a = x[(int64_t)i * ldx + g], b = r[(int64_t)i * ldr + g];
+            s1 += a;
+            s2 += a * a;
+            se += (a - b) * (a - b);
+        }
+    part[rg][0][c] = s1;
+    part[rg][1][c] = s2;
+    part[rg][2][c] = se;
+    __syncthreads();
+    if (rg == 0 && g < X)
+        for (int k = 0; k < 3; ++k)
+            out[(int64_t)k * X + g] = (part[0][k][c] + part[1][k][c]) + (part[2][k][c] + part[3][k][c]);
+}
+
 struct LossTerms {
     dv_loss_term t[DV_MAX_LOSS_TERMS];
     int n;
@@ -1081,6 +1145,24 @@ extern "C" int dv_weighted_sum(const float* x, const float* w, const int32_t* id
     DV_REQUIRE(n >= 0 && out);
     DV_REQUIRE(n == 0 || x);
     hipLaunchKernelGGL(weighted_sum_kernel, dim3(1), dim3(256), 0, ST(stream), x, w, idx, n, scale, out, beta);
+    DV_RETURN_LAUNCH();
+}
+
+extern "C" int dv_recon_row_stats(const float* x, int64_t ldx, const float* r, int64_t ldr, int32_t M, int32_t X,
+                                  float* out, dv_stream_t stream) {
+    DV_REQUIRE(M >= 0 && X >= 1);
+    if (M == 0) return DV_OK;
+    DV_REQUIRE(x && r && out);
+    hipLaunchKernelGGL(recon_row_stats_kernel, dim3(grid_for(M, 4, 8192)), dim3(256), 0, ST(stream), x, ldx, r, ldr,
+                       M, X, out);
+    DV_RETURN_LAUNCH();
+}
+
+extern "C" int dv_col_moments(const float* x, int64_t ldx, const float* r, int64_t ldr, int32_t M, int32_t X,
+                              double* out, dv_stream_t stream) {
+    DV_REQUIRE(M >= 0 && X >= 1);
+    DV_REQUIRE(x && r && out);
+    hipLaunchKernelGGL(col_moments_kernel, dim3((X + 63) / 64), dim3(256), 0, ST(stream), x, ldx, r, ldr, M, X, out);
     DV_RETURN_LAUNCH();
 }
 

@@ -321,6 +321,22 @@ def weighted_sum(out, x, w=None, idx=None, scale=1.0, beta=0.0, n=None):
                'dv_weighted_sum')
 
 
+def recon_row_stats(out, x, r):
+    """out (M,6): per-row {SSE, mean x, mean r, centred sums xx, rr, xr} (evaluation metrics)."""
+    M, X = x.shape
+    assert out.is_contiguous() and tuple(out.shape) == (M, 6)
+    _lib.check(_lib.load().dv_recon_row_stats(_f32(x), _ld(x), _f32(r), _ld(r), M, X, _f32(out), _stream()),
+               'dv_recon_row_stats')
+
+
+def col_moments(out, x, r):
+    """out (3,X) float64: per-column sum x, sum x^2, sum (x-r)^2."""
+    M, X = x.shape
+    assert out.dtype == torch.float64 and out.is_cuda and out.is_contiguous() and tuple(out.shape) == (3, X)
+    _lib.check(_lib.load().dv_col_moments(_f32(x), _ld(x), _f32(r), _ld(r), M, X, out.data_ptr(), _stream()),
+               'dv_col_moments')
+
+
 def loss_assemble(loss, terms, w_elbo, w_cmpl):
     """terms: list of (x, w_or_None, scale, out_index); see ``dv_loss_assemble``."""
     arr = (_lib.LossTerm * max(len(terms), 1))()

@@ -275,6 +275,16 @@ int dv_rows_segment_sum(const float* src, int64_t lds, const int32_t* seg_ptr, c
 /* out[0] = beta*out[0] + scale * sum_i w[i]*x[idx?idx[i]:i]   (loss scalars; one workgroup) */
 int dv_weighted_sum(const float* x, const float* w, const int32_t* idx, int32_t n, float scale, float* out,
                     float beta, dv_stream_t stream);
+/* Reconstruction metrics of `eval_x_reconstruction` (src/DGMMixin.py:128-156), the O(M*X) part:
+ *   dv_recon_row_stats: out[i, 0..5] = { sum_g (x-r)^2, mean_g x, mean_g r, sum (x-mx)^2, sum (r-mr)^2,
+ *                                        sum (x-mx)(r-mr) }   -> RMSE and the per-row Pearson r
+ *   dv_col_moments   : out[0,g] = sum_i x, out[1,g] = sum_i x^2, out[2,g] = sum_i (x-r)^2  (fp64)
+ *                      -> variance-weighted R^2 (sklearn r2_score(multioutput='variance_weighted')) */
+int dv_recon_row_stats(const float* x, int64_t ldx, const float* r, int64_t ldr, int32_t M, int32_t X, float* out,
+                       dv_stream_t stream);
+int dv_col_moments(const float* x, int64_t ldx, const float* r, int64_t ldr, int32_t M, int32_t X, double* out,
+                   dv_stream_t stream);
+
 /* All loss scalars of one step in a single launch (src/DrVAE.py:611-624):
  *   loss[0..4] = 0; for each term: loss[out] += scale * sum_i w[i]*x[i]   (w == NULL: plain sum)
  *   loss[5] (ELBO) = <w_elbo[0..2], loss[0..2]>;  loss[6] (CMPL) = <w_cmpl[0..7], loss[0..7]>

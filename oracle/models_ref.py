@@ -322,6 +322,21 @@ def loss_function(spec, p, batch, noise, iters=0, training=True, counts=None):
     return out, acc.rows
 
 
+# ----------------------------------------------------------------------- evaluation
+def eval_x_reconstruction(x, x_rec, x_rec_std=None):
+    """DGMMixin.py:128-156: RMSE, variance-weighted R^2 (sklearn), mean per-row Pearson r (scipy),
+    mean Gaussian log-likelihood (decoder_x.logp_perx = the sigma form, blocks.py:233-234)."""
+    import scipy.stats
+    import sklearn.metrics
+    x_np, r_np = _t(x).numpy().astype(float), _t(x_rec).numpy().astype(float)
+    out = {'rmse': float(np.sqrt(((x_np - r_np) ** 2).mean())),
+           'r2': float(sklearn.metrics.r2_score(x_np, r_np, multioutput='variance_weighted')),
+           'pearr': float(np.mean([scipy.stats.pearsonr(x_np[i], r_np[i])[0] for i in range(x_np.shape[0])]))}
+    out['ll'] = float(B.logp_sigma_rows(_t(x), _t(x_rec), _t(x_rec_std)).mean()) if x_rec_std is not None \
+        else float('nan')
+    return out
+
+
 # ----------------------------------------------------------------------- train step
 class RefTrainer:
     """``run_on_batch(train_mode=True)`` of DGMMixin.py:91-126 with the optimizer of

@@ -102,6 +102,11 @@ def block_inputs(tag):
     if tag == 'G9':
         return dict(kl=np.array([0.1, 1.999, 2.0, 2.001, 7.5, -1.0], np.float32),
                     anneal_args=[(0, 1, 0), (1, 1, 0), (5, 100, 0), (5, 100, 5), (6, 100, 5), (2000, 1000, 0)])
+    if tag in ('G10a', 'G10b'):   # reconstruction metrics: (rows, genes) = (40, 13) and (150, 978)
+        m, x = (40, 13) if tag == 'G10a' else (150, 978)
+        xx = (f(m, x) * 1.3 + 0.4).astype(np.float32)
+        return dict(x=xx, x_rec=(0.8 * xx + 0.5 * f(m, x)).astype(np.float32),
+                    std=(np.abs(f(m, x)) * 0.3 + 0.2).astype(np.float32))
     raise KeyError(tag)
 
 

@@ -324,6 +324,14 @@ def run_block_cases():
     put('G9', fb=model._use_free_bits(T(c['kl'])),
         anneal=np.array([model._compute_anneal_coef(i, iter_max=mx, iter_offset=off)
                          for (i, mx, off) in c['anneal_args']], np.float64))
+    # G10 eval_x_reconstruction (DGMMixin.py:128-156); the `ll` branch of the reference crashes on
+    # torch>=0.4 (`.numpy()[0]` of a 0-d array, DGMMixin.py:153), so ll is pinned through logp_perx
+    for tag in ('G10a', 'G10b'):
+        c = C.block_inputs(tag)
+        res = model.eval_x_reconstruction(T(c['x']), T(c['x_rec']))
+        out[tag + '/rmse'], out[tag + '/r2'], out[tag + '/pearr'] = (np.float64(res[k]) for k in ('rmse', 'r2', 'pearr'))
+        dec = rblk.DiagGaussianSigmaModule([5], [7], c['x'].shape[1], nonlin='elu')
+        out[tag + '/ll'] = np.float64(float(dec.logp_perx(T(c['x']), T(c['x_rec']), T(c['std'])).mean()))
     return out
 
 

@@ -474,6 +474,17 @@ def weighted_sum(out, x, w=None, idx=None, scale=1.0, beta=0.0, n=None):
     out.reshape(-1)[0] = (beta * out.reshape(-1)[0] if beta != 0.0 else 0) + scale * s
 
 
+def recon_row_stats(out, x, r):
+    mx, mr = x.mean(1, keepdim=True), r.mean(1, keepdim=True)
+    out.copy_(torch.stack([((x - r) ** 2).sum(1), mx[:, 0], mr[:, 0], ((x - mx) ** 2).sum(1), ((r - mr) ** 2).sum(1),
+                           ((x - mx) * (r - mr)).sum(1)], 1))
+
+
+def col_moments(out, x, r):
+    xd, rd = x.double(), r.double()
+    out.copy_(torch.stack([xd.sum(0), (xd * xd).sum(0), ((xd - rd) ** 2).sum(0)], 0))
+
+
 def loss_assemble(loss, terms, w_elbo, w_cmpl):
     acc = torch.zeros(8, device=loss.device)
     for (x, w, scale, out) in terms:
@@ -523,7 +534,7 @@ FUNCTIONS = ['gemm', 'linear_fwd', 'linear_bwd_data', 'linear_bwd_weight', 'cols
              'reparam_fwd', 'reparam_bwd', 'reparam_bwd_seg', 'z2f_post_bwd', 'kl_rows_fwd', 'kl_rows_bwd', 'nll_rows_fwd', 'nll_rows_bwd',
              'softmax_clamp_fwd', 'softmax_clamp_bwd', 'cat_terms_fwd', 'cat_terms_bwd', 'smalln_fwd', 'smalln_bwd_data',
              'smalln_bwd_weight', 'ymarg_fwd', 'ymarg_bwd',
-             'rows_gather', 'rows_segment_sum', 'weighted_sum', 'loss_assemble', 'axpby', 'adam_l2', 'counter_add', 'fill_normal']
+             'rows_gather', 'rows_segment_sum', 'weighted_sum', 'recon_row_stats', 'col_moments', 'loss_assemble', 'axpby', 'adam_l2', 'counter_add', 'fill_normal']
 
 
 def install(monkeypatch):

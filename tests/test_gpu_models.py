@@ -134,3 +134,26 @@ def test_checkpoint_roundtrip_and_errors(dev, tmp_path):
         DrVAE(dim_x=5, dim_s=1, dim_y=2, type_rec='binary', device=dev)       # src/DrVAE.py:124-131
     with pytest.raises(ValueError):
         DrVAE(dim_x=5, dim_s=1, dim_y=2, type_rec='diag_gaussian', optim_alg='sgd', device=dev)
+
+
+@pytest.mark.parametrize('tag', ['G10a', 'G10b'])
+def test_eval_x_reconstruction_matches_reference(tag, dev):
+    """N1: RMSE / variance-weighted R^2 / mean per-row Pearson / mean logL (src/DGMMixin.py:128-156)."""
+    gold = C.load('blocks')
+    c = C.block_inputs(tag)
+    spec = C.tiny_spec('pvae', dim_x=c['x'].shape[1])
+    model = build_model(spec, dev)
+    t = lambda a: torch.from_numpy(a.copy())
+    got = model.eval_x_reconstruction(t(c['x']), t(c['x_rec']), t(c['std']))
+    for k in ('rmse', 'r2', 'pearr', 'll'):
+        np.testing.assert_allclose(got[k], float(gold['%s/%s' % (tag, k)]), rtol=1e-5)
+    assert np.isnan(model.eval_x_reconstruction(t(c['x']), t(c['x_rec']))['ll'])
+    from tests import kernel_ref as R
+    import drvae_amd.kernels as K
+    x, r = t(c['x']).to(dev), t(c['x_rec']).to(dev)
+    rows, rr = torch.empty(x.shape[0], 6, device=dev), torch.empty(x.shape[0], 6, device=dev)
+    cols, rc = (torch.empty(3, x.shape[1], dtype=torch.float64, device=dev) for _ in range(2))
+    K.recon_row_stats(rows, x, r); R.recon_row_stats(rr, x, r)
+    K.col_moments(cols, x, r); R.col_moments(rc, x, r)
+    np.testing.assert_allclose(rows.cpu().numpy(), rr.cpu().numpy(), rtol=2e-5, atol=1e-4)
+    np.testing.assert_allclose(cols.cpu().numpy(), rc.cpu().numpy(), rtol=1e-12, atol=1e-9)

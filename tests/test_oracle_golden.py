@@ -184,3 +184,12 @@ def test_model_train_steps(name):
                     close(a.astype(np.float64).sum(), gold['paramsum%d/%s' % (step, k)], 1e-4, 2e-3)
                     close(a.reshape(-1)[C.sample_index(a.size)], gold['paramsample%d/%s' % (step, k)], 1e-4, 2e-5)
     assert tr.iters == nsteps
+
+
+@pytest.mark.parametrize('tag', ['G10a', 'G10b'])
+def test_eval_x_reconstruction_metrics(G, tag):
+    c = C.block_inputs(tag)
+    got = M.eval_x_reconstruction(c['x'], c['x_rec'], c['std'])
+    for k in ('rmse', 'r2', 'pearr'):
+        np.testing.assert_allclose(got[k], float(G['%s/%s' % (tag, k)]), rtol=1e-9)
+    np.testing.assert_allclose(got['ll'], float(G[tag + '/ll']), rtol=1e-6)
