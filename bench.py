@@ -102,13 +102,23 @@ def gemm_roofline(eng, cfg, rows, frac_pair, frac_lab, repeats=20, traffic=None)
     import drvae_amd.kernels as K
     from drvae_amd import synth
     calls = []
-    real = K.gemm
+    real_gemm, real_pair = K.gemm, K.linear_bwd_pair
 
-    def rec(Cm, A, B, a_kc, b_kc, **kw):
-        calls.append((Cm, A, B, a_kc, b_kc, kw))
-        real(Cm, A, B, a_kc, b_kc, **kw)
+    def rec_gemm(Cm, A, B, a_kc, b_kc, **kw):
+        M_, N_ = Cm.shape
+        K_ = (A.shape[1] + (kw['A2'].shape[1] if kw.get('A2') is not None else 0)) if a_kc else A.shape[0]
+        calls.append((lambda: real_gemm(Cm, A, B, a_kc, b_kc, **kw), [Cm] if kw.get('beta', 0.0) != 0.0 else [],
+                      2.0 * M_ * N_ * K_, ('gemm', M_, N_, K_, int(bool(a_kc)), int(bool(b_kc)))))
+        real_gemm(Cm, A, B, a_kc, b_kc, **kw)
 
-    K.gemm = rec
+    def rec_pair(dW, dbias, dx, dpre, x, W, **kw):      # dW = dpre^T x and dx = dpre W share one launch
+        Mb, Nw = dpre.shape
+        calls.append((lambda: real_pair(dW, dbias, dx, dpre, x, W, **kw), [dx] if kw.get('beta_x', 0.0) != 0.0 else [],
+                      2.0 * Mb * Nw * x.shape[1] + 2.0 * Mb * Nw * dx.shape[1],
+                      ('pair dW+dX', Mb, Nw, x.shape[1], dx.shape[1])))
+        real_pair(dW, dbias, dx, dpre, x, W, **kw)
+
+    K.gemm, K.linear_bwd_pair = rec_gemm, rec_pair
     try:
         eng.training = True
         eng.draw_noise()
@@ -116,15 +126,14 @@ def gemm_roofline(eng, cfg, rows, frac_pair, frac_lab, repeats=20, traffic=None)
         eng.backward()
         torch.cuda.synchronize()
     finally:
-        K.gemm = real
+        K.gemm, K.linear_bwd_pair = real_gemm, real_pair
     per_call = []
-    for (Cm, A, B, a_kc, b_kc, kw) in calls:
-        kw = dict(kw)
-        keep = Cm.clone() if kw.get('beta', 0.0) != 0.0 else None
+    for (fn, accum, flops, shape) in calls:
+        keep = [t.clone() for t in accum]
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             for _ in range(repeats):
-                real(Cm, A, B, a_kc, b_kc, **kw)
+                fn()
         best = 1e30
         for _ in range(3):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -133,11 +142,9 @@ def gemm_roofline(eng, cfg, rows, frac_pair, frac_lab, repeats=20, traffic=None)
             e1.record()
             torch.cuda.synchronize()
             best = min(best, e0.elapsed_time(e1) * 1e-3 / repeats)
-        if keep is not None:
-            Cm.copy_(keep)
-        M_, N_ = Cm.shape
-        K_ = (A.shape[1] + (kw['A2'].shape[1] if kw.get('A2') is not None else 0)) if a_kc else A.shape[0]
-        per_call.append((best, 2.0 * M_ * N_ * K_, (M_, N_, K_, int(bool(a_kc)), int(bool(b_kc)))))
+        for t, k in zip(accum, keep):
+            t.copy_(k)
+        per_call.append((best, flops, shape))
     t_step = sum(t for t, _, _ in per_call)
     executed = sum(f for _, f, _ in per_call)
     algorithmic = synth.gemm_flops_per_step(cfg, rows, frac_pair, frac_lab)
@@ -147,12 +154,12 @@ def gemm_roofline(eng, cfg, rows, frac_pair, frac_lab, repeats=20, traffic=None)
             'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': traffic,
             'traffic_source': 'profiles/r01_cfg2_pmc_summary.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)'
             if traffic else None,
-            'kernel': 'gemm_kernel<...> (fp32 v_mfma_f32_32x32x2_f32; all tilings/layouts)',
+            'kernel': 'gemm_kernel / gemm_pair_kernel<...> (fp32 v_mfma_f32_32x32x2_f32; all tilings/layouts)',
             'launches_per_step': len(per_call), 'avg_launch_us': round(1e6 * t_step / len(per_call), 2),
             'gemm_us_per_step': round(1e6 * t_step, 1),
             'algorithmic_gflop_per_step': round(algorithmic / 1e9, 3),
             'executed_gflop_per_step': round(executed / 1e9, 3),
-            'top_launches': [{'MNK_akc_bkc': list(sh), 'us': round(1e6 * t, 2), 'tflops': round(f / t / 1e12, 2)}
+            'top_launches': [{'shape': list(sh), 'us': round(1e6 * t, 2), 'tflops': round(f / t / 1e12, 2)}
                              for t, f, sh in top]}
 
 

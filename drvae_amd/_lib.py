@@ -36,6 +36,7 @@ SIGNATURES = {
     'dv_abi_version': [],
     'dv_error_string': [_i32],
     'dv_gemm': [C.POINTER(GemmDesc), _p],
+    'dv_gemm_pair': [C.POINTER(GemmDesc), C.POINTER(GemmDesc), _p],
     'dv_gemm_force_tiling': [_i32],
     'dv_gemm_set_option': [_i32, _i32],
     'dv_colsum': [_p, _i64, _i32, _i32, _p, _f, _p],

@@ -148,8 +148,16 @@ __device__ __forceinline__ float4 ld_edge(const Operand& o, int line, int pos) {
     return make_float4(e[0], e[1], e[2], e[3]);
 }
 
+template <int BM, int BN, int BK, int KS, bool AKC, bool BKC>
+constexpr int gemm_smem_floats() {
+    constexpr int stage = (AKC ? BM : BK) * ((AKC ? BK : BM) + 4) + (BKC ? BN : BK) * ((BKC ? BK : BN) + 4);
+    constexpr int red = (KS > 1) ? KS * 32 * 33 : 0;
+    return 2 * stage > red ? 2 * stage : red;
+}
+
+// One workgroup's share of one product: `bid` of `nwg` workgroups.
 template <int BM, int BN, int BK, int WM, int WN, int KS, bool AKC, bool BKC>
-__global__ __launch_bounds__(256) void gemm_kernel(const dv_gemm_desc g, const LoadCfg lc) {
+__device__ __forceinline__ void gemm_body(const dv_gemm_desc& g, const LoadCfg& lc, float* smem, int bid, int nwg) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int KW = BK / KS, KH = KW / 2;
     constexpr int LDA_S = (AKC ? BK : BM) + 4;
@@ -158,14 +166,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(const dv_gemm_desc g, const L
     constexpr int B_ELEMS = (BKC ? BN : BK) * LDB_S;
     constexpr int STAGE = A_ELEMS + B_ELEMS;
     constexpr int RED_ELEMS = (KS > 1) ? KS * 32 * 33 : 0;
-    constexpr int SMEM = 2 * STAGE > RED_ELEMS ? 2 * STAGE : RED_ELEMS;   // double-buffered tiles
+    static_assert(2 * STAGE <= gemm_smem_floats<BM, BN, BK, KS, AKC, BKC>() && RED_ELEMS <= gemm_smem_floats<BM, BN, BK, KS, AKC, BKC>(), "smem");
     static_assert(WM * WN * KS == 4, "4 waves");
     static_assert(KS == 1 || (BM == 32 && BN == 32), "K-split tiling is 32x32");
-    __shared__ __attribute__((aligned(16))) float smem[SMEM];
 
     const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
     int tm, tn;
-    tile_of_block(blockIdx.x, gridDim.x, tiles_m, tiles_n, lc.map, tm, tn);
+    tile_of_block(bid, nwg, tiles_m, tiles_n, lc.map, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -447,6 +454,26 @@ __global__ __launch_bounds__(256) void gemm_kernel(const dv_gemm_desc g, const L
     }
 }
 
+template <int BM, int BN, int BK, int WM, int WN, int KS, bool AKC, bool BKC>
+__global__ __launch_bounds__(256) void gemm_kernel(const dv_gemm_desc g, const LoadCfg lc) {
+    __shared__ __attribute__((aligned(16))) float smem[gemm_smem_floats<BM, BN, BK, KS, AKC, BKC>()];
+    gemm_body<BM, BN, BK, WM, WN, KS, AKC, BKC>(g, lc, smem, blockIdx.x, gridDim.x);
+}
+
+// Two independent products in ONE launch (workgroups [0,tiles1) run the first, the rest the
+// second): the weight-gradient dW = dy^T x and the data-gradient dx = dy W of a layer both only
+// need dy, so they share a launch slot instead of paying the per-launch latency chain twice.
+template <int BM, int BN, int BK, int WM, int WN, int KS, bool A1, bool B1, bool A2, bool B2>
+__global__ __launch_bounds__(256) void gemm_pair_kernel(const dv_gemm_desc g1, const LoadCfg lc1, const dv_gemm_desc g2,
+                                                        const LoadCfg lc2, int tiles1) {
+    constexpr int S1 = gemm_smem_floats<BM, BN, BK, KS, A1, B1>(), S2 = gemm_smem_floats<BM, BN, BK, KS, A2, B2>();
+    __shared__ __attribute__((aligned(16))) float smem[S1 > S2 ? S1 : S2];
+    if ((int)blockIdx.x < tiles1)
+        gemm_body<BM, BN, BK, WM, WN, KS, A1, B1>(g1, lc1, smem, blockIdx.x, tiles1);
+    else
+        gemm_body<BM, BN, BK, WM, WN, KS, A2, B2>(g2, lc2, smem, blockIdx.x - tiles1, gridDim.x - tiles1);
+}
+
 inline int vec_width(const void* p, int64_t ld) {
     const uintptr_t a = reinterpret_cast<uintptr_t>(p);
     if ((a & 15) == 0 && (ld & 3) == 0) return 4;
@@ -491,18 +518,21 @@ extern "C" int dv_gemm_force_tiling(int t) {
     return DV_OK;
 }
 
-extern "C" int dv_gemm(const dv_gemm_desc* d, dv_stream_t stream) {
+static int gemm_prepare(const dv_gemm_desc* d, LoadCfg& lc, int& tiling) {
     DV_REQUIRE(d != nullptr);
     const dv_gemm_desc& g = *d;
     DV_REQUIRE(g.M >= 0 && g.N >= 0 && g.K >= 1);
-    if (g.M == 0 || g.N == 0) return DV_OK;
+    if (g.M == 0 || g.N == 0) {
+        tiling = -1;
+        return DV_OK;
+    }
     DV_REQUIRE(g.A && g.B && g.C);
     DV_REQUIRE(g.epilogue == DV_EPI_PLAIN || g.epilogue == DV_EPI_FWD || g.epilogue == DV_EPI_BWD);
     DV_REQUIRE(g.epilogue != DV_EPI_BWD || g.yref != nullptr);
     DV_REQUIRE(g.A2 == nullptr || (g.a_kcontig && g.K1 >= 0 && g.K1 <= g.K));
     DV_REQUIRE(g.a_kscale == nullptr || g.a_kcontig);
     DV_REQUIRE(g.a_colsum == nullptr || !g.a_kcontig);
-    LoadCfg lc;
+    DV_REQUIRE(!( !g.a_kcontig && g.b_kcontig));
     lc.vecA = vec_width(g.A, g.lda);
     if (g.A2) {
         const int v2 = vec_width(g.A2, g.lda2);
@@ -513,16 +543,50 @@ extern "C" int dv_gemm(const dv_gemm_desc* d, dv_stream_t stream) {
     lc.map = g_opt[0];
     lc.dbg = g_opt[1];
     lc.stamps = g_stamps;
-    hipStream_t st = static_cast<hipStream_t>(stream);
     const int64_t t64 = (int64_t)((g.M + 63) / 64) * ((g.N + 63) / 64);
     const int64_t t128 = (int64_t)((g.M + 127) / 128) * ((g.N + 127) / 128);
-    int tiling = g_force_tiling;
+    tiling = g_force_tiling;
     // measured on MI355X (tools/gemm_bench.py): below ~4 workgroups per CU the 32x32 K-split
     // tiling wins (more resident workgroups hide the per-K-tile latency chain); the larger
     // tiles only pay once their grids alone fill the chip several times over
     if (tiling == 0) tiling = (t128 >= 1024) ? 3 : (t64 >= 1024 ? 1 : 2);
+    return DV_OK;
+}
+
+static int gemm_launch(const dv_gemm_desc& g, const LoadCfg& lc, int tiling, hipStream_t st) {
+    if (tiling < 0) return DV_OK;
     if (tiling == 3) return launch_cfg<128, 128, 32, 2, 2, 1>(g, lc, st);
     if (tiling == 4) return launch_cfg<32, 32, 128, 1, 1, 4>(g, lc, st);
     if (tiling == 1) return launch_cfg<64, 64, 32, 2, 2, 1>(g, lc, st);
     return launch_cfg<32, 32, 64, 1, 1, 4>(g, lc, st);
+}
+
+extern "C" int dv_gemm(const dv_gemm_desc* d, dv_stream_t stream) {
+    LoadCfg lc;
+    int tiling = 0;
+    const int rc = gemm_prepare(d, lc, tiling);
+    if (rc != DV_OK) return rc;
+    return gemm_launch(*d, lc, tiling, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int dv_gemm_pair(const dv_gemm_desc* d1, const dv_gemm_desc* d2, dv_stream_t stream) {
+    LoadCfg lc1, lc2;
+    int t1 = 0, t2 = 0;
+    int rc = gemm_prepare(d1, lc1, t1);
+    if (rc != DV_OK) return rc;
+    rc = gemm_prepare(d2, lc2, t2);
+    if (rc != DV_OK) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // fused form: both products on the 32x32 K-split tiling, (dy^T x) + (dy W) layouts
+    const bool fuse = t1 == 2 && t2 == 2 && !d1->a_kcontig && !d1->b_kcontig && d2->a_kcontig && !d2->b_kcontig &&
+                      g_opt[2] == 0;
+    if (!fuse) {
+        rc = gemm_launch(*d1, lc1, t1, st);
+        if (rc != DV_OK) return rc;
+        return gemm_launch(*d2, lc2, t2, st);
+    }
+    const int tiles1 = ((d1->M + 31) / 32) * ((d1->N + 31) / 32), tiles2 = ((d2->M + 31) / 32) * ((d2->N + 31) / 32);
+    hipLaunchKernelGGL((gemm_pair_kernel<32, 32, 64, 1, 1, 4, false, false, true, false>), dim3(tiles1 + tiles2),
+                       dim3(256), 0, st, *d1, lc1, *d2, lc2, tiles1);
+    DV_RETURN_LAUNCH();
 }

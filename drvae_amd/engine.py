@@ -199,6 +199,20 @@ class _Chain:
                 if l.g is not None:
                     K.wn_bwd(l.dW, l.dg, l.raw, l.W, l.g, l.norm)
 
+            # the layer's weight- and data-gradient both only need dpre: one paired launch when the
+            # layer has a single input source, no WeightNorm and a single data-gradient destination
+            single_dst = li > 0 or (dinputs is not None and len(srcs) == 1 and dinputs[0] is not None
+                                    and len(dinputs[0]) == 1)
+            if wbranch is None and l.g is None and len(srcs) == 1 and single_dst:
+                if li > 0:
+                    prev = self.layers[li - 1]
+                    K.linear_bwd_pair(l.dW, l.db, self.dpre[li - 1], dpre, srcs[0], l.W, yref=self.out[li - 1],
+                                      act=prev.act0, shift=prev.shift0, overread=True)
+                    dpre = self.dpre[li - 1]
+                else:
+                    dst, alpha, beta = dinputs[0][0]
+                    K.linear_bwd_pair(l.dW, l.db, dst, dpre, srcs[0], l.W, alpha=alpha, beta_x=beta, overread=True)
+                continue
             if wbranch is not None:
                 with wbranch:
                     wgrad()

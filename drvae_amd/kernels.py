@@ -50,11 +50,9 @@ def _act(a):
 
 
 # ------------------------------------------------------------------------------ GEMM
-def gemm(Cm, A, B, a_kc, b_kc, *, A2=None, a_kscale=None, alpha=1.0, beta=0.0, epi=EPI_PLAIN, scale=None,
-         bias=None, split=None, act0=0, act1=0, shift0=0.0, shift1=0.0, resid=None, resid_cols=0, yref=None,
-         a_colsum=None, colsum_beta=0.0, overread=False):
-    """C[M,N] = epilogue(alpha * Aop @ Bop) + beta*C, see ``dv_gemm`` in include/drvae_hip.h.
-    ``overread``: rows of A and B may be over-read by up to 3 floats (padded / arena buffers)."""
+def _gemm_desc(Cm, A, B, a_kc, b_kc, *, A2=None, a_kscale=None, alpha=1.0, beta=0.0, epi=EPI_PLAIN, scale=None,
+               bias=None, split=None, act0=0, act1=0, shift0=0.0, shift1=0.0, resid=None, resid_cols=0, yref=None,
+               a_colsum=None, colsum_beta=0.0, overread=False):
     M, N = Cm.shape
     if a_kc:
         K = A.shape[1] + (A2.shape[1] if A2 is not None else 0)
@@ -81,7 +79,27 @@ def gemm(Cm, A, B, a_kc, b_kc, *, A2=None, a_kscale=None, alpha=1.0, beta=0.0, e
     d.yref, d.ldy = _f32(yref, 'yref'), _ld(yref)
     d.a_colsum, d.colsum_beta = _f32(a_colsum, 'a_colsum'), colsum_beta
     d.flags = 3 if overread else 0
+    return d
+
+
+def gemm(Cm, A, B, a_kc, b_kc, **kw):
+    """C[M,N] = epilogue(alpha * Aop @ Bop) + beta*C, see ``dv_gemm`` in include/drvae_hip.h.
+    ``overread``: rows of A and B may be over-read by up to 3 floats (padded / arena buffers)."""
+    d = _gemm_desc(Cm, A, B, a_kc, b_kc, **kw)
     _lib.check(_lib.load().dv_gemm(C.byref(d), _stream()), 'dv_gemm')
+
+
+def linear_bwd_pair(dW, dbias, dx, dpre, x, W, *, kscale=None, alpha=1.0, beta_x=0.0, yref=None, act=0, shift=0.0,
+                    overread=False):
+    """dW = dpre^T x (+ dbias) and dx = beta_x*dx + alpha*(dpre W) * act'(yref) in ONE launch when both fit
+    the fused form of ``dv_gemm_pair`` (otherwise two launches)."""
+    d1 = _gemm_desc(dW, dpre, x, False, False, a_colsum=dbias, overread=overread)
+    if yref is None:
+        d2 = _gemm_desc(dx, dpre, W, True, False, a_kscale=kscale, alpha=alpha, beta=beta_x, overread=overread)
+    else:
+        d2 = _gemm_desc(dx, dpre, W, True, False, a_kscale=kscale, alpha=alpha, beta=beta_x, epi=EPI_BWD, yref=yref,
+                        act0=act, act1=act, shift0=shift, shift1=shift, overread=overread)
+    _lib.check(_lib.load().dv_gemm_pair(C.byref(d1), C.byref(d2), _stream()), 'dv_gemm_pair')
 
 
 def linear_fwd(out, x, W, bias=None, *, x2=None, scale=None, split=None, act0=0, act1=0, shift0=0.0, shift1=0.0,

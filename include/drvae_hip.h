@@ -109,9 +109,14 @@ typedef struct dv_gemm_desc {
 } dv_gemm_desc;
 
 int dv_gemm(const dv_gemm_desc* desc, dv_stream_t stream);
+/* Two independent products in one launch when both take the 32x32 K-split tiling with the
+ * (dy^T x) and (dy W) layouts -- the weight- and data-gradient of one Linear layer, which both
+ * only need dy; otherwise exactly dv_gemm(d1) followed by dv_gemm(d2). */
+int dv_gemm_pair(const dv_gemm_desc* d1, const dv_gemm_desc* d2, dv_stream_t stream);
 /* test/tuning hook: 0 = heuristic tiling, 1 = 64x64, 2 = 32x32 K-split, 3 = 128x128 */
 int dv_gemm_force_tiling(int tiling);
-/* test/tuning hook: key 0 = workgroup->tile map (0 linear, 1 XCD chunk-major [default]) */
+/* test/tuning hook: key 0 = workgroup->tile map (0 linear, 1 XCD chunk-major [default]);
+ * key 2 = 1 disables the fused form of dv_gemm_pair */
 int dv_gemm_set_option(int key, int value);
 
 /* out[n] = beta*out[n] + sum_m X[m*ldx+n]            (bias gradient) */

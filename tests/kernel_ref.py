@@ -131,6 +131,12 @@ def linear_bwd_weight(dW, dpre, x, *, beta=0.0, dbias=None, overread=False):
     gemm(dW, dpre, x, False, False, beta=beta, a_colsum=dbias, colsum_beta=beta)
 
 
+def linear_bwd_pair(dW, dbias, dx, dpre, x, W, *, kscale=None, alpha=1.0, beta_x=0.0, yref=None, act=0, shift=0.0,
+                    overread=False):
+    linear_bwd_weight(dW, dpre, x, dbias=dbias)
+    linear_bwd_data(dx, dpre, W, kscale=kscale, alpha=alpha, beta=beta_x, yref=yref, act=act, shift=shift)
+
+
 def colsum(out, X, beta=0.0):
     _acc(out, X.sum(0), beta)
 
@@ -530,7 +536,7 @@ def fill_normal(out, seed, ctr_dev=None):
     out.copy_(torch.randn(out.shape, generator=g).to(out.device))
 
 
-FUNCTIONS = ['gemm', 'linear_fwd', 'linear_bwd_data', 'linear_bwd_weight', 'colsum', 'act_bwd_', 'wn_scale', 'wn_bwd',
+FUNCTIONS = ['gemm', 'linear_fwd', 'linear_bwd_data', 'linear_bwd_weight', 'linear_bwd_pair', 'colsum', 'act_bwd_', 'wn_scale', 'wn_bwd',
              'reparam_fwd', 'reparam_bwd', 'reparam_bwd_seg', 'z2f_post_bwd', 'kl_rows_fwd', 'kl_rows_bwd', 'nll_rows_fwd', 'nll_rows_bwd',
              'softmax_clamp_fwd', 'softmax_clamp_bwd', 'cat_terms_fwd', 'cat_terms_bwd', 'smalln_fwd', 'smalln_bwd_data',
              'smalln_bwd_weight', 'ymarg_fwd', 'ymarg_bwd',

@@ -524,3 +524,18 @@ def test_z2f_post_bwd(K, dev, with_pairs, with_b):
         outs.append((dp2, dz1, dq2))
     for a, b in zip(*outs):
         close(a, b, rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize('M,N,Kd', [(450, 200, 102), (596, 1956, 600), (37, 9, 5), (5000, 300, 64)])
+def test_gemm_pair_matches_two_launches(K, dev, M, N, Kd):
+    """dW = dpre^T x and dx = (dpre W)*act'(yref) as one paired launch == the two single launches."""
+    x, W = strided(dev, M, Kd, 2, seed=1), rnd(dev, N, Kd, seed=2, scale=Kd ** -0.5)
+    dpre, yref = rnd(dev, M, N, seed=3), rnd(dev, M, Kd, seed=4)
+    for beta_x in (0.0, 1.0):
+        dW, db, dx = torch.empty(N, Kd, device=dev), torch.empty(N, device=dev), rnd(dev, M, Kd, seed=5)
+        rW, rb, rx = torch.empty(N, Kd, device=dev), torch.empty(N, device=dev), dx.clone()
+        K.linear_bwd_pair(dW, db, dx, dpre, x, W, alpha=0.5, beta_x=beta_x, yref=yref, act='elu', overread=True)
+        R.linear_bwd_pair(rW, rb, rx, dpre, x, W, alpha=0.5, beta_x=beta_x, yref=yref, act='elu')
+        close(dW, rW, **gemm_tol(M))
+        close(db, rb, **gemm_tol(M))
+        close(dx, rx, **gemm_tol(N))
