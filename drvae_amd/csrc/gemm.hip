@@ -151,7 +151,7 @@ __device__ __forceinline__ float4 ld_edge(const Operand& o, int line, int pos) {
 template <int BM, int BN, int BK, int KS, bool AKC, bool BKC>
 constexpr int gemm_smem_floats() {
     constexpr int stage = (AKC ? BM : BK) * ((AKC ? BK : BM) + 4) + (BKC ? BN : BK) * ((BKC ? BK : BN) + 4);
-    constexpr int red = (KS > 1) ? KS * 32 * 33 : 0;
+    constexpr int red = (KS > 1) ? KS * BM * (BN + 1) : 0;
     return 2 * stage > red ? 2 * stage : red;
 }
 
@@ -165,10 +165,10 @@ __device__ __forceinline__ void gemm_body(const dv_gemm_desc& g, const LoadCfg& 
     constexpr int A_ELEMS = (AKC ? BM : BK) * LDA_S;
     constexpr int B_ELEMS = (BKC ? BN : BK) * LDB_S;
     constexpr int STAGE = A_ELEMS + B_ELEMS;
-    constexpr int RED_ELEMS = (KS > 1) ? KS * 32 * 33 : 0;
+    constexpr int RED_ELEMS = (KS > 1) ? KS * BM * (BN + 1) : 0;
+    constexpr int NT = 64 * WM * WN * KS;   // threads per workgroup
     static_assert(2 * STAGE <= gemm_smem_floats<BM, BN, BK, KS, AKC, BKC>() && RED_ELEMS <= gemm_smem_floats<BM, BN, BK, KS, AKC, BKC>(), "smem");
-    static_assert(WM * WN * KS == 4, "4 waves");
-    static_assert(KS == 1 || (BM == 32 && BN == 32), "K-split tiling is 32x32");
+    static_assert(NT == 256 || NT == 512, "4 or 8 waves");
 
     const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
     int tm, tn;
@@ -182,12 +182,12 @@ __device__ __forceinline__ void gemm_body(const dv_gemm_desc& g, const LoadCfg& 
 
     // ---- staging geometry: a chunk = 4 consecutive floats along the contiguous global index
     constexpr int A_CPL = (AKC ? BK : BM) / 4;      // chunks per staged line
-    constexpr int A_LPP = 256 / A_CPL;              // lines per pass
+    constexpr int A_LPP = NT / A_CPL;               // lines per pass
     constexpr int A_NP = (AKC ? BM : BK) / A_LPP;   // passes
     constexpr int B_CPL = (BKC ? BK : BN) / 4;
-    constexpr int B_LPP = 256 / B_CPL;
+    constexpr int B_LPP = NT / B_CPL;
     constexpr int B_NP = (BKC ? BN : BK) / B_LPP;
-    static_assert(A_NP >= 1 && B_NP >= 1, "tile too small for 256 threads");
+    static_assert(A_NP >= 1 && B_NP >= 1, "tile too small for the workgroup");
     const int a_c = tid % A_CPL, a_l = tid / A_CPL;
     const int b_c = tid % B_CPL, b_l = tid / B_CPL;
     // fused bias gradient: the first column-tile of every row-panel sums its A tiles over k
@@ -431,31 +431,37 @@ __device__ __forceinline__ void gemm_body(const dv_gemm_desc& g, const LoadCfg& 
                                   [rbase](int r) { return rbase + (r & 3) + 8 * (r >> 2); });
             }
     } else {
-        // the 4 waves hold partial sums over disjoint k: reduce through LDS (tiles are dead now)
+        // the KS wave groups hold partial sums over disjoint k: reduce through LDS (tiles are dead now)
         float* red = smem;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-            red[(ks_id * 32 + row) * 33 + li] = acc[0][0][r];
-        }
-        __syncthreads();
-        // thread -> (4 consecutive rows, one column): column-wise like the register epilogue
-        const int col = tid & 31, r4 = (tid >> 5) * 4;
-        float a4[4];
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    const int col = wn * TN * 32 + j * 32 + li;
+                    red[(ks_id * BM + row) * (BN + 1) + col] = acc[i][j][r];
+                }
+        __syncthreads();
+        // thread -> (RPT consecutive rows, one column): column-wise like the register epilogue
+        constexpr int RPT = BM / (NT / BN);
+        const int col = tid % BN, r0 = (tid / BN) * RPT;
+        float a4[RPT];
+#pragma unroll
+        for (int e = 0; e < RPT; ++e) {
             float v = 0.f;
 #pragma unroll
-            for (int w = 0; w < KS; ++w) v += red[(w * 32 + r4 + e) * 33 + col];
+            for (int w = 0; w < KS; ++w) v += red[(w * BM + r0 + e) * (BN + 1) + col];
             a4[e] = v;
         }
-        const int rbase = m0 + r4;
-        epi_store_col<4>(g, a4, n0 + col, [rbase](int r) { return rbase + r; });
+        const int rbase = m0 + r0;
+        epi_store_col<RPT>(g, a4, n0 + col, [rbase](int r) { return rbase + r; });
     }
 }
 
 template <int BM, int BN, int BK, int WM, int WN, int KS, bool AKC, bool BKC>
-__global__ __launch_bounds__(256) void gemm_kernel(const dv_gemm_desc g, const LoadCfg lc) {
+__global__ __launch_bounds__(64 * WM * WN * KS) void gemm_kernel(const dv_gemm_desc g, const LoadCfg lc) {
     __shared__ __attribute__((aligned(16))) float smem[gemm_smem_floats<BM, BN, BK, KS, AKC, BKC>()];
     gemm_body<BM, BN, BK, WM, WN, KS, AKC, BKC>(g, lc, smem, blockIdx.x, gridDim.x);
 }
@@ -484,7 +490,7 @@ inline int vec_width(const void* p, int64_t ld) {
 template <int BM, int BN, int BK, int WM, int WN, int KS>
 int launch_cfg(const dv_gemm_desc& g, const LoadCfg& lc, hipStream_t st) {
     const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
-    dim3 grid(tiles), block(256);
+    dim3 grid(tiles), block(64 * WM * WN * KS);
     if (g.a_kcontig && g.b_kcontig)
         hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, WM, WN, KS, true, true>), grid, block, 0, st, g, lc);
     else if (g.a_kcontig && !g.b_kcontig)
@@ -549,7 +555,8 @@ static int gemm_prepare(const dv_gemm_desc* d, LoadCfg& lc, int& tiling) {
     // measured on MI355X (tools/gemm_bench.py): below ~4 workgroups per CU the 32x32 K-split
     // tiling wins (more resident workgroups hide the per-K-tile latency chain); the larger
     // tiles only pay once their grids alone fill the chip several times over
-    if (tiling == 0) tiling = (t128 >= 1024) ? 3 : (t64 >= 1024 ? 1 : 2);
+    const int64_t t64_min = g_opt[3] > 0 ? g_opt[3] : 1024;
+    if (tiling == 0) tiling = (t128 >= 1024) ? 3 : (t64 >= t64_min ? 1 : 2);
     return DV_OK;
 }
 
@@ -557,6 +564,7 @@ static int gemm_launch(const dv_gemm_desc& g, const LoadCfg& lc, int tiling, hip
     if (tiling < 0) return DV_OK;
     if (tiling == 3) return launch_cfg<128, 128, 32, 2, 2, 1>(g, lc, st);
     if (tiling == 4) return launch_cfg<32, 32, 128, 1, 1, 4>(g, lc, st);
+    if (tiling == 5) return launch_cfg<64, 64, 64, 2, 2, 2>(g, lc, st);   // 8 waves: 2 per SIMD
     if (tiling == 1) return launch_cfg<64, 64, 32, 2, 2, 1>(g, lc, st);
     return launch_cfg<32, 32, 64, 1, 1, 4>(g, lc, st);
 }
@@ -578,14 +586,17 @@ extern "C" int dv_gemm_pair(const dv_gemm_desc* d1, const dv_gemm_desc* d2, dv_s
     if (rc != DV_OK) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
     // fused form: both products on the 32x32 K-split tiling, (dy^T x) + (dy W) layouts
+    const int tiles1 = ((d1->M + 31) / 32) * ((d1->N + 31) / 32), tiles2 = ((d2->M + 31) / 32) * ((d2->N + 31) / 32);
+    // pairing pays for the latency-bound small products; a product that already fills the chip
+    // several times over (>= 4 workgroups per CU) gains nothing from a partner (measured: the
+    // decoder-heads pair ran 66 us paired vs 29 + 29 us alone)
     const bool fuse = t1 == 2 && t2 == 2 && !d1->a_kcontig && !d1->b_kcontig && d2->a_kcontig && !d2->b_kcontig &&
-                      g_opt[2] == 0;
+                      g_opt[2] == 0 && tiles1 < 1024 && tiles2 < 1024;
     if (!fuse) {
         rc = gemm_launch(*d1, lc1, t1, st);
         if (rc != DV_OK) return rc;
         return gemm_launch(*d2, lc2, t2, st);
     }
-    const int tiles1 = ((d1->M + 31) / 32) * ((d1->N + 31) / 32), tiles2 = ((d2->M + 31) / 32) * ((d2->N + 31) / 32);
     hipLaunchKernelGGL((gemm_pair_kernel<32, 32, 64, 1, 1, 4, false, false, true, false>), dim3(tiles1 + tiles2),
                        dim3(256), 0, st, *d1, lc1, *d2, lc2, tiles1);
     DV_RETURN_LAUNCH();
