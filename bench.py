@@ -238,7 +238,7 @@ def main():
             out['roofline'] = gemm_roofline(eng, cfg, rows, float(hx.mean()), float(hy.mean()),
                                             repeats=20 if args.workload != 'wide' else 3,
                                             traffic=PMC_TRAFFIC_BYTES_PER_GEMM_LAUNCH.get(args.workload))
-        if not args.no_cpu_baseline and args.workload != 'wide':
+        if not args.no_cpu_baseline and args.workload != 'wide' and world == 1:   # rank 0 at N=1 only
             out['cpu_baseline'] = cpu_baseline(args.workload)
     if world > 1:
         dist.barrier()

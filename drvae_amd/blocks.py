@@ -22,9 +22,11 @@ from ._lib import GAUSS_LOGVAR, GAUSS_SIGMA
 
 # name -> module, as src/blocks.py:21-24 (the modules are parameter-free; MLP fuses the
 # activation into the producing GEMM's epilogue instead of calling them)
-nonlinearities = {'tanh': nn.Tanh(), 'sigmoid': nn.Sigmoid(), 'softmax': nn.Softmax(dim=-1),
-                  'softplus': nn.Softplus(), 'softsign': nn.Softsign(), 'relu': nn.ReLU(),
-                  'leaky_relu': nn.LeakyReLU(0.1), 'elu': nn.ELU(), 'selu': nn.SELU()}
+nonlinearities = {}
+for _name, _factory in (('tanh', nn.Tanh), ('sigmoid', nn.Sigmoid), ('softmax', lambda: nn.Softmax(dim=-1)),
+                        ('softplus', nn.Softplus), ('softsign', nn.Softsign), ('relu', nn.ReLU),
+                        ('leaky_relu', lambda: nn.LeakyReLU(0.1)), ('elu', nn.ELU), ('selu', nn.SELU)):
+    nonlinearities[_name] = _factory()
 
 
 def _fusable(module):
@@ -186,70 +188,59 @@ def _noise_like(t):
     return torch.empty_like(t, memory_format=torch.contiguous_format).normal_()
 
 
-class GaussianLogVarMixin:
+class _DiagGaussianOps:
+    """Shared implementation of the two Gaussian mixins of src/blocks.py:166-240.  The second
+    distribution parameter is a log-variance (``_MODE = GAUSS_LOGVAR``, prior attribute ``prior_lv``) or
+    a standard deviation (``GAUSS_SIGMA``, ``prior_sg``); every method is one HIP launch
+    (plus one for its backward)."""
+    _MODE = None
+    _PRIOR2 = None
+
+    def _prior(self):
+        return float(self.prior_mu), float(getattr(self, self._PRIOR2))
+
+    def sample(self, mu, second):
+        """reparameterised draw; a 1-tuple, because callers concatenate tuples (src/DrVAE.py:350)"""
+        return (ops.reparam(mu, second, _noise_like(mu), self._MODE),)
+
+    def kldivergence_perx(self, mu_q, second_q, mu_p, second_p):
+        """KL(q || p) per row"""
+        return ops.kl_rows(mu_q, second_q, mu_p, second_p, self._MODE)
+
+    def kldivergence(self, mu_q, second_q, mu_p, second_p):
+        return self.kldivergence_perx(mu_q, second_q, mu_p, second_p).sum()
+
+    def kldivergence_from_prior_perx(self, mu, second):
+        """KL(q || scalar prior) per row"""
+        pm, p2 = self._prior()
+        return ops.kl_rows_prior(mu, second, pm, p2, self._MODE)
+
+    def kldivergence_from_prior(self, mu, second):
+        return self.kldivergence_from_prior_perx(mu, second).sum()
+
+    def logp_perx(self, sample, mu, second):
+        """Gaussian log-density of ``sample`` summed over features, per row"""
+        return ops.nll_rows(sample, mu, second, self._MODE)
+
+    def logp(self, sample, mu, second):
+        return self.logp_perx(sample, mu, second).sum()
+
+    def logp_prior_perx(self, sample):
+        pm, p2 = self._prior()
+        return ops.nll_rows(sample, torch.full_like(sample, pm), torch.full_like(sample, p2), self._MODE)
+
+    def logp_prior(self, sample):
+        return self.logp_prior_perx(sample).sum()
+
+
+class GaussianLogVarMixin(_DiagGaussianOps):
     """Diagonal Gaussian parametrised by (mu, log sigma^2): src/blocks.py:166-202."""
-
-    def sample(self, mu, logvar):
-        return (ops.reparam(mu, logvar, _noise_like(mu), GAUSS_LOGVAR),)
-
-    def kldivergence_perx(self, mu_q, logvar_q, mu_p, logvar_p):
-        return ops.kl_rows(mu_q, logvar_q, mu_p, logvar_p, GAUSS_LOGVAR)
-
-    def kldivergence(self, mu_q, logvar_q, mu_p, logvar_p):
-        return self.kldivergence_perx(mu_q, logvar_q, mu_p, logvar_p).sum()
-
-    def kldivergence_from_prior_perx(self, mu, logvar):
-        return ops.kl_rows_prior(mu, logvar, float(self.prior_mu), float(self.prior_lv), GAUSS_LOGVAR)
-
-    def kldivergence_from_prior(self, mu, logvar):
-        return self.kldivergence_from_prior_perx(mu, logvar).sum()
-
-    def logp_perx(self, sample, mu, logvar):
-        return ops.nll_rows(sample, mu, logvar, GAUSS_LOGVAR)
-
-    def logp(self, sample, mu, logvar):
-        return self.logp_perx(sample, mu, logvar).sum()
-
-    def logp_prior_perx(self, sample):
-        mu = torch.full_like(sample, float(self.prior_mu))
-        lv = torch.full_like(sample, float(self.prior_lv))
-        return ops.nll_rows(sample, mu, lv, GAUSS_LOGVAR)
-
-    def logp_prior(self, sample):
-        return self.logp_prior_perx(sample).sum()
+    _MODE, _PRIOR2 = GAUSS_LOGVAR, 'prior_lv'
 
 
-class GaussianSigmaMixin:
+class GaussianSigmaMixin(_DiagGaussianOps):
     """Diagonal Gaussian parametrised by (mu, sigma): src/blocks.py:204-240."""
-
-    def sample(self, mu, std):
-        return (ops.reparam(mu, std, _noise_like(mu), GAUSS_SIGMA),)
-
-    def kldivergence_perx(self, mu_q, std_q, mu_p, std_p):
-        return ops.kl_rows(mu_q, std_q, mu_p, std_p, GAUSS_SIGMA)
-
-    def kldivergence(self, mu_q, std_q, mu_p, std_p):
-        return self.kldivergence_perx(mu_q, std_q, mu_p, std_p).sum()
-
-    def kldivergence_from_prior_perx(self, mu, std):
-        return ops.kl_rows_prior(mu, std, float(self.prior_mu), float(self.prior_sg), GAUSS_SIGMA)
-
-    def kldivergence_from_prior(self, mu, std):
-        return self.kldivergence_from_prior_perx(mu, std).sum()
-
-    def logp_perx(self, sample, mu, std):
-        return ops.nll_rows(sample, mu, std, GAUSS_SIGMA)
-
-    def logp(self, sample, mu, std):
-        return self.logp_perx(sample, mu, std).sum()
-
-    def logp_prior_perx(self, sample):
-        mu = torch.full_like(sample, float(self.prior_mu))
-        sd = torch.full_like(sample, float(self.prior_sg))
-        return ops.nll_rows(sample, mu, sd, GAUSS_SIGMA)
-
-    def logp_prior(self, sample):
-        return self.logp_prior_perx(sample).sum()
+    _MODE, _PRIOR2 = GAUSS_SIGMA, 'prior_sg'
 
 
 def _head(suffix, make, n_in, n_out, dropout_rate, activation=None):
