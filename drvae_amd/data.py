@@ -1,0 +1,163 @@
+"""Input pipeline next to the hot path: the reference's dataset
+containers and sampler weights (src/DrVAE.py:880-963, src/VFAE.py:658-721,
+src/utils.py:292-327, src/run_drvae.py:150-166), plus a DEVICE-RESIDENT batcher that
+feeds the fused step without host round trips.
+
+Difference by design: the reference draws every batch with ``WeightedRandomSampler`` +
+``DataLoader(drop_last)``, so the number of rows per data group (labeled/unlabeled x
+singleton/pair) fluctuates from batch to batch.  ``DeviceBatcher`` keeps the same per-row
+sampling weights but STRATIFIES each batch: a fixed number of rows per group (the expected
+composition under the weights), drawn on the GPU, in a fixed group order.  Every batch then
+has the same structure, so one step plan and one captured hipGraph serve the whole epoch and
+only data (rows, labels) move -- device to device.
+"""
+import numpy as np
+import torch
+
+from . import kernels as K
+
+
+class DrVAEDataset(torch.utils.data.Dataset):
+    """``(x1, x2, s, y, has_x2, has_y)`` rows (src/DrVAE.py:880-905)."""
+
+    FIELDS = ('x1', 'x2', 's', 'y', 'has_x2', 'has_y')
+
+    def __init__(self, x1, x2, s, y, has_x2, has_y):
+        n = x1.size(0)
+        assert x2.size(0) == n and x1.size(1) == x2.size(1)
+        assert y.size(0) == n and s.size(0) == n and has_x2.size(0) == n and has_y.size(0) == n
+        self.x1, self.x2, self.s, self.y, self.has_x2, self.has_y = x1, x2, s, y, has_x2, has_y
+
+    def __getitem__(self, index):
+        return tuple(getattr(self, f)[index] for f in self.FIELDS)
+
+    def __len__(self):
+        return self.x1.size(0)
+
+    def to(self, device):
+        """HBM-resident copy (x1/x2 as contiguous fp32: the gather kernels read them in place)."""
+        return DrVAEDataset(self.x1.to(device, torch.float32).contiguous(),
+                            self.x2.to(device, torch.float32).contiguous(), self.s.to(device), self.y.to(device),
+                            self.has_x2.to(device), self.has_y.to(device))
+
+
+class VFAEDataset(torch.utils.data.Dataset):
+    """``(x1, s, y, has_y)`` rows (src/VFAE.py:658-680)."""
+
+    def __init__(self, x1, s, y, has_y):
+        n = x1.size(0)
+        assert y.size(0) == n and s.size(0) == n and has_y.size(0) == n
+        self.x1, self.s, self.y, self.has_y = x1, s, y, has_y
+
+    def __getitem__(self, index):
+        return self.x1[index], self.s[index], self.y[index], self.has_y[index]
+
+    def __len__(self):
+        return self.x1.size(0)
+
+
+def wrap_in_DrVAEDataset(sing, pair, y_key='y', concat='both', downlabel_to=None, remove_unlabeled=False):
+    """Dict(s) of numpy arrays -> (DrVAEDataset, merged dict)  (src/DrVAE.py:908-963):
+    'both' stacks singletons on top of pairs with zero-imputed x2, 'pair_only' / 'sing_only'
+    keep one side; ``downlabel_to`` keeps the labels of that many random cell lines (``cid``) and
+    marks the rest unlabeled (-66); ``remove_unlabeled`` drops rows without a label."""
+    if concat == 'both':
+        d = {k: np.concatenate((sing[k], pair[k])) for k in set(sing) & set(pair)}
+        d['x2'] = np.concatenate((np.zeros(sing['x1'].shape), pair['x2']))
+        d['has_x2'] = np.concatenate((np.zeros(len(sing['x1'])), np.ones(len(pair['x2']))))
+    elif concat == 'pair_only':
+        d = pair
+        d['has_x2'] = np.ones(len(pair['x2']))
+    elif concat == 'sing_only':
+        d = sing
+        d['x2'] = np.zeros(sing['x1'].shape)
+        d['has_x2'] = np.zeros(len(sing['x1']))
+    else:
+        raise ValueError('Invalid parameter for dataset concatenation type')
+    if downlabel_to is not None:
+        cids = np.unique(d['cid'][d['has_y']])
+        np.random.shuffle(cids)
+        keep = set(cids[:downlabel_to].tolist())
+        drop = np.array([c not in keep for c in d['cid']])
+        d['has_y'][drop] = 0
+        d['y'][drop] = -66
+        d['ycont'][drop] = -66
+    if remove_unlabeled:
+        sel = d['has_y'] != 0
+        for k in list(d):
+            d[k] = d[k][sel]
+    ds = DrVAEDataset(x1=torch.from_numpy(d['x1']).float(), x2=torch.from_numpy(d['x2']).float(),
+                      s=torch.from_numpy(d['s'].astype(np.int32)), y=torch.from_numpy(d[y_key]),
+                      has_x2=torch.from_numpy(d['has_x2'].astype(np.int32)),
+                      has_y=torch.from_numpy(d['has_y'].astype(np.int32)))
+    return ds, d
+
+
+def compute_balanced_weights(labels, unlabeled_data_ratio=None, unlabeled_token=None):
+    """Per-sample weights that make every class equally likely in a minibatch
+    (src/utils.py:292-327); with ``unlabeled_data_ratio`` the unlabeled token gets that share."""
+    if unlabeled_data_ratio is not None:
+        assert unlabeled_token is not None and 0. < unlabeled_data_ratio < 1.
+    labels = np.asarray(labels)
+    classes, inverse, counts = np.unique(labels, return_inverse=True, return_counts=True)
+    w = 1. / counts
+    if unlabeled_data_ratio is not None:
+        w[classes != unlabeled_token] *= (1. - unlabeled_data_ratio) / (len(classes) - 1)
+        w[classes == unlabeled_token] *= unlabeled_data_ratio
+    return torch.from_numpy(w[inverse]).double()
+
+
+_GROUPS = ((1, 0), (0, 0), (1, 1), (0, 1))      # (has_y, has_x2) in the reference's order ls, us, lp, up
+
+
+class DeviceBatcher:
+    """Stratified, weighted, with-replacement minibatches drawn ON the device and written
+    straight into the fused step's input buffers (see the module docstring)."""
+
+    def __init__(self, dataset, weights, batch_size, group_counts=None, seed=0):
+        self.ds, self.batch_size = dataset, batch_size
+        dev = dataset.x1.device
+        w = torch.as_tensor(weights, dtype=torch.float64).to(dev)
+        hy, hx = dataset.has_y.reshape(-1).bool(), dataset.has_x2.reshape(-1).bool()
+        self.members, self.gweights, mass = [], [], []
+        for (gy, gx) in _GROUPS:
+            idx = torch.nonzero((hy == bool(gy)) & (hx == bool(gx))).reshape(-1)
+            self.members.append(idx)
+            self.gweights.append(w[idx].float())
+            mass.append(float(w[idx].sum()))
+        if group_counts is None:          # expected composition of a batch, largest-remainder rounding
+            share = np.asarray(mass) / max(sum(mass), 1e-300) * batch_size
+            cnt = np.floor(share).astype(int)
+            for j in np.argsort(-(share - cnt))[:batch_size - cnt.sum()]:
+                cnt[j] += 1
+            group_counts = cnt.tolist()
+        assert sum(group_counts) == batch_size and all(c == 0 or len(m) > 0 for c, m in zip(group_counts, self.members))
+        self.group_counts = list(group_counts)
+        self.has_y = np.concatenate([np.full(c, gy) for c, (gy, gx) in zip(group_counts, _GROUPS)]).astype(np.int64)
+        self.has_x2 = np.concatenate([np.full(c, gx) for c, (gy, gx) in zip(group_counts, _GROUPS)]).astype(np.int64)
+        self.gen = torch.Generator(device=dev)
+        self.gen.manual_seed(seed)
+        self._idx32 = torch.zeros(batch_size, dtype=torch.int32, device=dev)
+
+    def bind(self, engine, counts=None):
+        """build / select the step plan for this batcher's fixed batch structure"""
+        self.engine = engine
+        engine.set_structure(self.has_x2, self.has_y, counts)
+        return engine.plan
+
+    def next_indices(self):
+        parts = [m[torch.multinomial(w, c, replacement=True, generator=self.gen)]
+                 for m, w, c in zip(self.members, self.gweights, self.group_counts) if c > 0]
+        return torch.cat(parts)
+
+    def feed(self, idx=None):
+        """draw the next batch and write it into the bound engine's buffers (device to device)"""
+        p = self.engine.plan
+        idx = self.next_indices() if idx is None else idx
+        self._idx32.copy_(idx)
+        K.rows_gather(p.XSRC[:p.B], self.ds.x1, self._idx32)
+        if self.engine.cfg.has_pert:
+            K.rows_gather(p.XSRC[p.B:], self.ds.x2, self._idx32)
+        if self.engine.cfg.has_y:
+            p.set_labels_device(self.ds.y.reshape(-1)[idx])
+        return idx

@@ -275,6 +275,7 @@ class FusedStep:
         self.dev = arena.device
         self.iters = 0                      # finished_training_iters (src/DGMMixin.py:124)
         self.plan = None
+        self._plans = {}                    # plans by batch structure (a handful of signatures in practice)
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=self.dev)       # Adam step (device side)
         self.rng_ctr = torch.zeros(2, dtype=torch.int32, device=self.dev)        # Philox counter (device side)
         self.seed = seed
@@ -323,15 +324,12 @@ class FusedStep:
             self.L_dz1 = self._gauss('decoder_z1', len(cfg.h_de_z1), 'lv', shift_second=-2.0)
 
     # ------------------------------------------------------------------------- plan
-    def set_batch(self, x1, x2, y, has_x2, has_y, counts=None):
-        """x1,x2: (B,X) device fp32; y: (B,) or (B,1) ints (host or device); has_*: host bool/int
-        arrays.  ``counts`` = (N_total, N_pairs, N_labeled) GLOBAL normalisers under data
-        parallelism (SURVEY.md 8(e)); default: this batch's own counts (src/DrVAE.py:611-616)."""
+    def set_structure(self, has_x2, has_y, counts=None):
+        """Select (or build) the plan for a batch STRUCTURE: which rows are pairs / labeled.
+        Returns (plan, rows) where ``rows`` are the participating row positions."""
         cfg = self.cfg
         has_x2 = np.asarray(has_x2.cpu() if torch.is_tensor(has_x2) else has_x2).astype(bool).reshape(-1)
         has_y = np.asarray(has_y.cpu() if torch.is_tensor(has_y) else has_y).astype(bool).reshape(-1)
-        yv = np.asarray(y.cpu() if torch.is_tensor(y) else y).astype(np.int64).reshape(-1) if y is not None \
-            else np.zeros(len(has_y), np.int64)
         if not cfg.has_pert:
             has_x2 = np.zeros_like(has_x2)
         if not cfg.has_y:
@@ -339,14 +337,30 @@ class FusedStep:
         rows = np.arange(len(has_y))
         if cfg.kind == 'vfae' and not cfg.semi_supervised:
             rows = rows[has_y]               # supervised-only model ignores unlabeled rows (src/VFAE.py:445-450)
-        key = (len(rows), has_x2[rows].tobytes(), has_y[rows].tobytes(), yv[rows].tobytes(), counts)
+        # the plan (index lists, buffers, captured graph) depends on the group STRUCTURE only; the
+        # class labels of the labeled rows are data and are refreshed in place
+        key = (len(rows), has_x2[rows].tobytes(), has_y[rows].tobytes(), counts)
         if self.plan is None or self.plan.key != key:
-            self.plan = _Plan(self, rows, has_x2[rows], has_y[rows], yv[rows], counts, key)
-        p = self.plan
-        sel = torch.as_tensor(rows, device=self.dev) if len(rows) != len(has_y) else None
+            self.plan = self._plans.get(key)
+            if self.plan is None:
+                self.plan = self._plans[key] = _Plan(self, rows, has_x2[rows], has_y[rows], counts, key)
+        return self.plan, rows
+
+    def set_batch(self, x1, x2, y, has_x2, has_y, counts=None):
+        """x1,x2: (B,X) device fp32; y: (B,) or (B,1) ints (host or device); has_*: host bool/int
+        arrays.  ``counts`` = (N_total, N_pairs, N_labeled) GLOBAL normalisers under data
+        parallelism (SURVEY.md 8(e)); default: this batch's own counts (src/DrVAE.py:611-616)."""
+        cfg = self.cfg
+        p, rows = self.set_structure(has_x2, has_y, counts)
+        n_in = len(np.asarray(has_y.cpu() if torch.is_tensor(has_y) else has_y).reshape(-1))
+        sel = torch.as_tensor(rows, device=self.dev) if len(rows) != n_in else None
         p.XSRC[:p.B].copy_(x1.index_select(0, sel) if sel is not None else x1)
         if x2 is not None and cfg.has_pert:
             p.XSRC[p.B:].copy_(x2.index_select(0, sel) if sel is not None else x2)
+        if cfg.has_y:
+            yv = np.asarray(y.cpu() if torch.is_tensor(y) else y).astype(np.int64).reshape(-1) if y is not None \
+                else np.zeros(n_in, np.int64)
+            p.set_labels_host(yv[rows])
         return p
 
     # ------------------------------------------------------------------------ noise
@@ -630,7 +644,7 @@ class FusedStep:
 class _Plan:
     """Index lists, coefficient vectors and buffers for one batch structure."""
 
-    def __init__(self, eng, rows, has_x2, has_y, yv, counts, key):
+    def __init__(self, eng, rows, has_x2, has_y, counts, key):
         cfg, dev = eng.cfg, eng.dev
         self.key, self.rows = key, rows
         L, Y, X, Z1, Z3 = cfg.L, cfg.dim_y, cfg.dim_x, cfg.dim_z1, cfg.dim_z3
@@ -685,7 +699,7 @@ class _Plan:
             for l in range(L):
                 for i in range(B):
                     if has_y[i]:
-                        fl.append(l); fi.append(i); fslot.append(0); fcls.append(int(yv[i]))
+                        fl.append(l); fi.append(i); fslot.append(0); fcls.append(0)
                     else:
                         for j in range(Y):
                             fl.append(l); fi.append(i); fslot.append(j); fcls.append(j)
@@ -698,7 +712,13 @@ class _Plan:
             order = np.argsort(self.fp_i_host, kind='stable')
             self.q_rows = i32(order)
             self.q_ptr = i32(np.concatenate([[0], np.cumsum(np.bincount(self.fp_i_host, minlength=B))]))
-            self.label_r = i32(np.tile(np.where(has_y, yv, 0), L))
+            self.label_r = i32(np.zeros(L * B, np.int64))
+            self._has_y_host = has_y.copy()
+            self._fp_lab_host = has_y[self.fp_i_host]
+            self.has_y_dev = torch.as_tensor(has_y, device=dev)
+            self.fp_i_dev = torch.as_tensor(self.fp_i_host, device=dev)
+            self.fp_lab_dev = torch.as_tensor(self._fp_lab_host, device=dev)
+            self.fp_slot_dev = i32(self.fp_slot_host)
             sizes.append(self.Mf * Z3)
         self.noise = zf(int(sum(sizes)))
         views, o = [], 0
@@ -740,10 +760,6 @@ class _Plan:
             self.DQ3, self.DPZ1, self.DQFP = zf(Mf, 2 * Z3), zf(Mf, 2 * Z1), zf(Mf, 2 * Z1)
             self.KL3, self.KL3raw, self.KL1, self.KL1raw = zf(Mf), zf(Mf), zf(Mf), zf(Mf)
             self.KLFP, self.CFP = zf(max(Mf, 1)), zf(max(Mf, 1))
-            if Mf:   # the one-hot class columns of the decoder_z1 input never change for this batch
-                oh = torch.zeros(Mf, Y, device=dev)
-                oh[torch.arange(Mf, device=dev), self.fp_cls.long()] = 1.0
-                self.Z3IN[:, Z3:] = oh
         # ---- per-row loss coefficients dCMPL/d(row term) (src/DrVAE.py:611-624)
         self.beta = None
         self.c_nll = zf(Md)
@@ -759,6 +775,32 @@ class _Plan:
         self.w_cmpl = zf(N_LOSS)
         self._cfg = cfg
         self.x1 = self.x2 = None
+
+    def set_labels_host(self, yv):
+        """class labels of this batch's rows (host ints; only the labeled rows' entries matter)"""
+        cfg = self._cfg
+        yv = np.asarray(yv).astype(np.int64).reshape(-1)
+        lab = np.where(self._has_y_host, yv, 0)
+        self.label_r.copy_(torch.as_tensor(np.tile(lab, cfg.L), dtype=torch.int32))
+        if self.Mf:
+            cls = np.where(self._fp_lab_host, yv[self.fp_i_host], self.fp_slot_host)
+            self.fp_cls.copy_(torch.as_tensor(cls, dtype=torch.int32))
+        self._refresh_onehot()
+
+    def set_labels_device(self, y_dev):
+        """same from a device tensor of B labels (device-resident input pipeline: no host sync)"""
+        cfg = self._cfg
+        y32 = y_dev.reshape(-1).to(torch.int32)
+        self.label_r.copy_(torch.where(self.has_y_dev, y32, torch.zeros_like(y32)).repeat(cfg.L))
+        if self.Mf:
+            self.fp_cls.copy_(torch.where(self.fp_lab_dev, y32[self.fp_i_dev], self.fp_slot_dev))
+        self._refresh_onehot()
+
+    def _refresh_onehot(self):
+        # one-hot class columns of the decoder_z1 input [z3 | onehot(y)] (src/DrVAE.py:355)
+        if self._cfg.has_y and self.Mf:
+            Z3, Y = self._cfg.dim_z3, self._cfg.dim_y
+            K.rows_gather(self.Z3IN[:, Z3:], None, None, onehot_cls=self.fp_cls, n_classes=Y, width=0)
 
     def set_beta(self, beta):
         """(re)write the coefficients that depend on the perturbation annealing coefficient

@@ -107,6 +107,15 @@ def block_inputs(tag):
         xx = (f(m, x) * 1.3 + 0.4).astype(np.float32)
         return dict(x=xx, x_rec=(0.8 * xx + 0.5 * f(m, x)).astype(np.float32),
                     std=(np.abs(f(m, x)) * 0.3 + 0.2).astype(np.float32))
+    if tag == 'G11':   # dataset wrapping / sampler weights
+        def side(n, paired, off):
+            d = {'x1': f(n, 6), 's': np.zeros(n), 'y': rs.randint(0, 2, n), 'ycont': rs.rand(n),
+                 'has_y': (rs.rand(n) < 0.6).astype(np.int64), 'cid': off + np.arange(n) % 5}
+            if paired:
+                d['x2'] = f(n, 6)
+            return d
+        return dict(sing=side(9, False, 0), pair=side(6, True, 3),
+                    labels=np.array([3, 3, 7, 7, 7, 7, 1, -1, -1, -1, 3, 1]), ratio=0.25, token=-1)
     raise KeyError(tag)
 
 

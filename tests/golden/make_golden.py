@@ -332,6 +332,20 @@ def run_block_cases():
         out[tag + '/rmse'], out[tag + '/r2'], out[tag + '/pearr'] = (np.float64(res[k]) for k in ('rmse', 'r2', 'pearr'))
         dec = rblk.DiagGaussianSigmaModule([5], [7], c['x'].shape[1], nonlin='elu')
         out[tag + '/ll'] = np.float64(float(dec.logp_perx(T(c['x']), T(c['x_rec']), T(c['std'])).mean()))
+    # G11 dataset wrapping + balanced sampler weights (DrVAE.py:908-963, utils.py:292-327)
+    import copy
+    import utils as rutl
+    c = C.block_inputs('G11')
+    out['G11/w_plain'] = rutl.compute_balanced_weights(c['labels']).numpy()
+    out['G11/w_ratio'] = rutl.compute_balanced_weights(c['labels'], unlabeled_data_ratio=c['ratio'],
+                                                       unlabeled_token=c['token']).numpy()
+    for mode in ('both', 'pair_only', 'sing_only'):
+        for rm in (False, True):
+            ds, dd = rDrVAE.wrap_in_DrVAEDataset(copy.deepcopy(c['sing']), copy.deepcopy(c['pair']), concat=mode,
+                                                 remove_unlabeled=rm)
+            tag = 'G11/%s_%d' % (mode, int(rm))
+            for fld in ('x1', 'x2', 's', 'y', 'has_x2', 'has_y'):
+                out['%s/%s' % (tag, fld)] = getattr(ds, fld).numpy().copy()
     return out
 
 

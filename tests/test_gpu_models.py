@@ -157,3 +157,38 @@ def test_eval_x_reconstruction_matches_reference(tag, dev):
     K.col_moments(cols, x, r); R.col_moments(rc, x, r)
     np.testing.assert_allclose(rows.cpu().numpy(), rr.cpu().numpy(), rtol=2e-5, atol=1e-4)
     np.testing.assert_allclose(cols.cpu().numpy(), rc.cpu().numpy(), rtol=1e-12, atol=1e-9)
+
+
+def test_device_batcher_feeds_one_captured_graph(dev):
+    """N2: a device-resident dataset, stratified on-device batches, ONE plan + ONE hipGraph for all
+    batches (only rows/labels change, device to device) == eager steps fed the same rows via set_batch."""
+    from drvae_amd import data as D
+    from tests.test_engine_cpu import make_engine
+    spec = M.ModelSpec(kind='drvae', L=2)
+    params = M.init_params(spec, 3, as_numpy=True)
+    big = M.make_batch(spec, 1200, seed=9)
+    t = lambda k: torch.from_numpy(big[k].copy())
+    ds = D.DrVAEDataset(t('x1'), t('x2'), t('s'), t('y'), t('has_x2'), t('has_y')).to(dev)
+    w = D.compute_balanced_weights(np.arange(1200) % 7)
+    bat = D.DeviceBatcher(ds, w, 150, seed=5)
+    fed, a1 = make_engine(spec, params, dev)
+    eager, a0 = make_engine(spec, params, dev)
+    plan = bat.bind(fed)
+    idxs = [bat.next_indices() for _ in range(5)]
+    # iteration 0 eager on both (beta_pert = 0.01), then capture once and replay with fresh data
+    bat.feed(idxs[0])
+    fed.train_step()
+    fed.capture()
+    for i in idxs[1:]:
+        bat.feed(i)
+        fed.replay()
+    assert fed.plan is plan and len(fed._plans) == 1
+    for k, i in enumerate(idxs):
+        ic = i.cpu()
+        eager.set_batch(ds.x1[i], ds.x2[i], ds.y[i].cpu(), bat.has_x2, bat.has_y)
+        if k == 1:
+            eager.draw_noise()               # capture() spends one Philox draw on its warm-up
+        eager.train_step()
+    torch.cuda.synchronize()
+    assert torch.equal(a0.param, a1.param)
+    assert eager.losses() == fed.losses()
