@@ -280,6 +280,7 @@ class FusedStep:
         self.rng_ctr = torch.zeros(2, dtype=torch.int32, device=self.dev)        # Philox counter (device side)
         self.seed = seed
         self.training = True
+        self.fuse_bwd = False               # set by train_step/capture: forward is followed by backward
         self.add_noise = True               # `fit(add_noise=...)` flag of the reference (src/DrVAE.py:769)
         self.branch = _Branch(self.dev, enabled=concurrent)   # classifier/fprop chain || decoder chain
         self.wbranch = _Branch(self.dev, enabled=concurrent and os.environ.get('DRVAE_WBRANCH', '0') == '1')   # measured slower on MI355X (third graph branch): off
@@ -448,8 +449,14 @@ class FusedStep:
         # ---- p(x|z): decoder over all stacked samples, then the NLL over genes
         X = cfg.dim_x
         PX = p.c_decx.forward([p.ZDEC])
-        K.nll_rows_fwd(p.NLL, p.XIN, PX[:, :X], PX[:, X:], mode=GAUSS_SIGMA, xidx=p.tgt)
+        if self.fuse_bwd:      # train step: d/d(mu, pre-softplus) emitted in the same row pass
+            K.nll_rows_fwdbwd(p.NLL, p.DPX[:, :X], p.DPX[:, X:], p.c_nll, p.XIN, PX[:, :X], PX[:, X:], mode=GAUSS_SIGMA,
+                              xidx=p.tgt, sd_act='softplus', sd_shift=1e-3)
+        else:
+            K.nll_rows_fwd(p.NLL, p.XIN, PX[:, :X], PX[:, X:], mode=GAUSS_SIGMA, xidx=p.tgt)
         self.branch.join()
+        if self.fuse_bwd:
+            return             # the loss scalars are assembled on the side chain of backward()
         self._loss_scalars()
 
     def _loss_scalars(self):
@@ -477,6 +484,8 @@ class FusedStep:
         Z1blk, DZ1 = p.ZDEC[:L * B], p.DZDEC[:L * B]
         # ---- side chain: y-marginalisation, fprop, classifier -> DZ1B (its share of d/dz1), DZ2F
         with self.branch:
+            if self.fuse_bwd:
+                self._loss_scalars()         # leaf work, off the critical path
             if cfg.has_y:
                 Y = cfg.dim_y
                 K.ymarg_bwd(p.CFP, p.DQY, p.QY, p.label_r, p.fp_ptr, p.KLFP, math.log(1.0 / Y), p.c_kld, p.c_yl)
@@ -524,8 +533,9 @@ class FusedStep:
         # ---- main chain: reconstruction terms, d/d(mu, pre-softplus) straight from the per-row
         # coefficients, then back through the decoder (the three big GEMMs)
         PX = p.c_decx.out[-1]
-        K.nll_rows_bwd(p.DPX[:, :X], p.DPX[:, X:], p.c_nll, p.XIN, PX[:, :X], PX[:, X:], mode=GAUSS_SIGMA,
-                       xidx=p.tgt, sd_act='softplus', sd_shift=1e-3)
+        if not self.fuse_bwd:
+            K.nll_rows_bwd(p.DPX[:, :X], p.DPX[:, X:], p.c_nll, p.XIN, PX[:, :X], PX[:, X:], mode=GAUSS_SIGMA,
+                           xidx=p.tgt, sd_act='softplus', sd_shift=1e-3)
         p.c_decx.backward(p.DPX, [p.ZDEC], [[(p.DZDEC, 1.0, 0.0)]], wbranch=self.wbranch if self.wbranch.on else None)
         self.branch.join()
         if cfg.has_pert:
@@ -569,8 +579,12 @@ class FusedStep:
             self.set_noise(noise)
         else:
             self.draw_noise()
-        self.forward()
-        self.backward()
+        self.fuse_bwd = True
+        try:
+            self.forward()
+            self.backward()
+        finally:
+            self.fuse_bwd = False
         if allreduce is not None:
             allreduce(self.arena.grad)
         self.optimizer_step()
@@ -579,8 +593,12 @@ class FusedStep:
     # ------------------------------------------------------------------- hipGraph
     def _launch_sequence(self, allreduce=None):
         self.draw_noise()
-        self.forward()
-        self.backward()
+        self.fuse_bwd = True
+        try:
+            self.forward()
+            self.backward()
+        finally:
+            self.fuse_bwd = False
         if allreduce is not None:
             allreduce(self.arena.grad)
         self.optimizer_step()
@@ -606,8 +624,12 @@ class FusedStep:
             g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             with torch.cuda.graph(g1):
                 self.draw_noise()
-                self.forward()
-                self.backward()
+                self.fuse_bwd = True
+                try:
+                    self.forward()
+                    self.backward()
+                finally:
+                    self.fuse_bwd = False
             with torch.cuda.graph(g2):
                 self.optimizer_step()
             self._graphs = [g1, g2]

@@ -207,6 +207,12 @@ int dv_gauss_nll_rows_bwd(const float* coef, const float* x, int64_t ldx, const 
                           float sd_shift, float* dmu, float* dsd, int64_t ldd, float* dx, int64_t lddx, float beta,
                           dv_stream_t stream);
 
+/* forward + backward in one row pass (the loss is linear in the row terms with coefficients
+ * known up front): out[r] as _fwd, dmu/dsd[r,:] = coef[r] * d out[r]/d(mu, pre-activation of sd). */
+int dv_gauss_nll_rows_fwdbwd(const float* coef, const float* x, int64_t ldx, const int32_t* xidx, const float* mu,
+                             const float* sd, int64_t ldp, int32_t M, int32_t X, int32_t mode, int32_t sd_act,
+                             float sd_shift, float* out, float* dmu, float* dsd, int64_t ldd, dv_stream_t stream);
+
 /* --------------------------------------------------------- categorical head (K6/K7)
  * probs = clamp(softmax(logits), 1e-10, 1-1e-10)   (src/blocks.py:446-463); with
  * sigmoid1 != 0 logits is (M,1) and probs = clamp(cat(1-s, s)) (src/blocks.py:448-451,461-462). */

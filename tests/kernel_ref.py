@@ -331,6 +331,11 @@ def nll_rows_bwd(dmu, dsd, coef, x, mu, sd, *, mode=GAUSS_SIGMA, xidx=None, sd_a
         _acc(dx, -c * gm, beta)
 
 
+def nll_rows_fwdbwd(out, dmu, dsd, coef, x, mu, sd, *, mode=GAUSS_SIGMA, xidx=None, sd_act=0, sd_shift=0.0):
+    nll_rows_fwd(out, x, mu, sd, mode=mode, xidx=xidx)
+    nll_rows_bwd(dmu, dsd, coef, x, mu, sd, mode=mode, xidx=xidx, sd_act=sd_act, sd_shift=sd_shift)
+
+
 P_MIN = 1e-10
 
 
@@ -537,7 +542,7 @@ def fill_normal(out, seed, ctr_dev=None):
 
 
 FUNCTIONS = ['gemm', 'linear_fwd', 'linear_bwd_data', 'linear_bwd_weight', 'linear_bwd_pair', 'colsum', 'act_bwd_', 'wn_scale', 'wn_bwd',
-             'reparam_fwd', 'reparam_bwd', 'reparam_bwd_seg', 'z2f_post_bwd', 'kl_rows_fwd', 'kl_rows_bwd', 'nll_rows_fwd', 'nll_rows_bwd',
+             'reparam_fwd', 'reparam_bwd', 'reparam_bwd_seg', 'z2f_post_bwd', 'kl_rows_fwd', 'kl_rows_bwd', 'nll_rows_fwd', 'nll_rows_bwd', 'nll_rows_fwdbwd',
              'softmax_clamp_fwd', 'softmax_clamp_bwd', 'cat_terms_fwd', 'cat_terms_bwd', 'smalln_fwd', 'smalln_bwd_data',
              'smalln_bwd_weight', 'ymarg_fwd', 'ymarg_bwd',
              'rows_gather', 'rows_segment_sum', 'weighted_sum', 'recon_row_stats', 'col_moments', 'loss_assemble', 'axpby', 'adam_l2', 'counter_add', 'fill_normal']

@@ -265,6 +265,15 @@ def test_nll_rows(K, dev, mode, X, pad):
     R.nll_rows_bwd(RD[:, :X], RD[:, X:], coef, x, mu, sd, dx=rdx, **kw)
     close(D, RD, rtol=2e-4, atol=2e-4)
     close(dx, rdx, rtol=2e-4, atol=2e-4)
+    # the one-pass forward+backward agrees with the two separate launches (odd X / odd offsets
+    # take the scalar path, even ones the float2 path)
+    kw.pop('beta')
+    o2 = torch.empty(M, device=dev)
+    D2, RD2 = torch.full((M, 2 * X), 7.0, device=dev), torch.empty(M, 2 * X, device=dev)
+    K.nll_rows_fwdbwd(o2, D2[:, :X], D2[:, X:], coef, x, mu, sd, **kw)
+    R.nll_rows_bwd(RD2[:, :X], RD2[:, X:], coef, x, mu, sd, **kw)
+    close(o2, ro, rtol=2e-5, atol=1e-3)
+    close(D2, RD2, rtol=2e-4, atol=2e-4)
 
 
 @pytest.mark.parametrize('Y,sig', [(2, False), (3, False), (7, False), (2, True)])
