@@ -5,8 +5,8 @@ reference ``src/DGMMixin.py`` (``_create_optimizer``, ``_use_free_bits``,
 Differences by design: the optimizer is not a ``torch.optim`` object but the fused Adam
 kernel over the flat parameter arena, and ``run_on_batch(train_mode=True)`` is the fused
 forward+backward+Adam launch sequence of ``drvae_amd.engine`` (optionally replayed from a
-hipGraph) instead of autograd.  Out of scope here:
-``fit``, early stopping, the sklearn/scipy evaluation metrics.
+hipGraph) instead of autograd.  ``fit``, early stopping and the prediction metrics live in
+``drvae_amd/fit.py`` / ``drvae_amd/metrics.py``.
 """
 from collections import OrderedDict
 

@@ -28,3 +28,7 @@ class DrVAE(ELBOModel):
     def loss_function(self, x1, x2, s, y, has_x2, has_y, noise=None):
         self._warn_empty_groups(has_x2, has_y)
         return super().loss_function(noise=noise, x1=x1, x2=x2, s=s, y=y, has_x2=has_x2, has_y=has_y)
+
+    def evaluate_performance(self, x1, x2, s, y, has_x2, has_y, return_full_data=False):
+        """(perf dict, summary string) of src/DrVAE.py:640-741"""
+        return self._evaluate(x1, x2, s, y, has_x2, has_y, return_full_data)

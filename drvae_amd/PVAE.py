@@ -23,3 +23,7 @@ class PVAE(ELBOModel):
     def loss_function(self, x1, x2, s, has_x2, noise=None):
         self._warn_empty_groups(has_x2, has_x2 * 0)
         return super().loss_function(noise=noise, x1=x1, x2=x2, s=s, has_x2=has_x2)
+
+    def evaluate_performance(self, x1, x2, s, has_x2, return_full_data=False):
+        """(perf dict, summary string) of src/PVAE.py:479-552"""
+        return self._evaluate(x1, x2, s, None, has_x2, None, return_full_data)

@@ -5,6 +5,7 @@ from ._model_base import ELBOModel
 class VFAE(ELBOModel):
     """p(x,z1,z2,y) = p(z2)p(y)p(z1|z2,y)p(x|z1); q(z1|x) q(y|z1) q(z2|z1,y)  (arXiv:1511.00830)."""
     kind = 'vfae'
+    fit_patience = 40       # src/VFAE.py:536
 
     def __init__(self, dim_x, dim_s, dim_y, dim_h_en_z1=(50, 50), dim_h_de_z1=(50, 50), dim_h_en_z2=(50, 50),
                  dim_h_de_x=(50, 50), dim_h_clf=(50, 50), dim_z1=50, dim_z2=50, type_rec='binary',
@@ -22,3 +23,7 @@ class VFAE(ELBOModel):
     def loss_function(self, x1, s, y, has_y, noise=None):
         self._warn_empty_groups(has_y * 0, has_y)
         return super().loss_function(noise=noise, x1=x1, s=s, y=y, has_y=has_y)
+
+    def evaluate_performance(self, x1, s, y, has_y, return_full_data=False):
+        """(perf dict, summary string) of src/VFAE.py:472-521"""
+        return self._evaluate(x1, None, s, y, None, has_y, return_full_data)

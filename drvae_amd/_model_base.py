@@ -12,9 +12,10 @@ import torch.nn as nn
 from . import blocks as blk
 from . import engine as E
 from .DGMMixin import DeepGenerativeModelMixin
+from .fit import FitMixin
 
 
-class ELBOModel(DeepGenerativeModelMixin, nn.Module):
+class ELBOModel(FitMixin, DeepGenerativeModelMixin, nn.Module):
     kind = None             # 'drvae' | 'pvae' | 'vfae'
 
     def _init_common(self, args):

@@ -118,7 +118,8 @@ class DeviceBatcher:
         self.ds, self.batch_size = dataset, batch_size
         dev = dataset.x1.device
         w = torch.as_tensor(weights, dtype=torch.float64).to(dev)
-        hy, hx = dataset.has_y.reshape(-1).bool(), dataset.has_x2.reshape(-1).bool()
+        hy = dataset.has_y.reshape(-1).bool()
+        hx = dataset.has_x2.reshape(-1).bool() if hasattr(dataset, 'has_x2') else torch.zeros_like(hy)
         self.members, self.gweights, mass = [], [], []
         for (gy, gx) in _GROUPS:
             idx = torch.nonzero((hy == bool(gy)) & (hx == bool(gx))).reshape(-1)
@@ -138,6 +139,15 @@ class DeviceBatcher:
         self.gen = torch.Generator(device=dev)
         self.gen.manual_seed(seed)
         self._idx32 = torch.zeros(batch_size, dtype=torch.int32, device=dev)
+
+    @property
+    def dataset(self):
+        return self.ds
+
+    def __len__(self):
+        """batches per epoch: what the reference's DataLoader yields with a len(dataset)-draw
+        weighted sampler and drop_last (src/run_drvae.py:150-162)"""
+        return max(1, len(self.ds) // self.batch_size)
 
     def bind(self, engine, counts=None):
         """build / select the step plan for this batcher's fixed batch structure"""

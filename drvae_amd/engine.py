@@ -276,6 +276,7 @@ class FusedStep:
         self.iters = 0                      # finished_training_iters (src/DGMMixin.py:124)
         self.plan = None
         self._plans = {}                    # plans by batch structure (a handful of signatures in practice)
+        self.max_plans = 8
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=self.dev)       # Adam step (device side)
         self.rng_ctr = torch.zeros(2, dtype=torch.int32, device=self.dev)        # Philox counter (device side)
         self.seed = seed
@@ -345,6 +346,13 @@ class FusedStep:
             self.plan = self._plans.get(key)
             if self.plan is None:
                 self.plan = self._plans[key] = _Plan(self, rows, has_x2[rows], has_y[rows], counts, key)
+                # randomly composed minibatches (plain DataLoader) rarely repeat a structure: keep the
+                # cache bounded, never dropping the plan a captured graph points into
+                for old in list(self._plans):
+                    if len(self._plans) <= self.max_plans:
+                        break
+                    if old != key and old != getattr(self, '_graph_key', None):
+                        del self._plans[old]
         return self.plan, rows
 
     def set_batch(self, x1, x2, y, has_x2, has_y, counts=None):

@@ -1,0 +1,290 @@
+"""The ``fit`` protocol of the three models: epoch loop, whole-set evaluation,
+rolling-mean early stopping and the snapshot policy of the reference
+(src/DrVAE.py:743-877, src/PVAE.py:554-672, src/VFAE.py:523-656), on top of the fused step.
+
+Two ways to feed the epoch loop:
+  * a ``drvae_amd.data.DeviceBatcher`` -- the dataset lives in HBM, batches are drawn on the
+    device, and every step is ONE hipGraph replay (no host<->device traffic, one host sync
+    per epoch for the logged train loss);
+  * any iterable of batch tuples (e.g. the reference's ``torch.utils.data.DataLoader``):
+    compatibility path, one ``run_on_batch`` per tuple.
+"""
+import time
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import metrics as MET
+
+
+class EarlyStopping:
+    """The patience / rolling-mean / snapshot controller spelled out inline in the reference's
+    ``fit`` (src/DrVAE.py:755-766, 829-868).  One ``update`` per epoch."""
+
+    def __init__(self, epochs, early_stop, patience=50, patience_increase=15, improvement_threshold=0.999,
+                 memory_length=3, save_model_after=0):
+        self.epochs, self.early_stop = epochs, early_stop
+        self.patience, self.patience_increase = patience, patience_increase
+        self.improvement_threshold = improvement_threshold
+        self.memory_length, self.save_model_after = memory_length, save_model_after
+        self.best = -np.inf
+        self.rolling = np.array([], dtype=float)
+        self.since_improvement = 0
+        self.snapshotted = False
+
+    def update(self, epoch, valid_obj):
+        """-> dict(snapshot, stop, patience_hit, continuing, rolling_mean, best_before)"""
+        self.since_improvement += 1
+        self.rolling = np.append(self.rolling, valid_obj)[-self.memory_length:]
+        out = dict(best_before=self.best, rolling=self.rolling.copy(), snapshot=False, stop=False,
+                   patience_hit=False, continuing=False)
+        score = out['rolling_mean'] = self.rolling.mean()
+        if score * self.improvement_threshold > self.best:      # False for nan: no improvement
+            self.patience = max(self.patience, epoch + self.patience_increase)
+            self.best = score
+            self.since_improvement = 0
+        if (self.early_stop and self.since_improvement == self.save_model_after) or \
+                (self.patience <= epoch and not self.snapshotted):
+            self.snapshotted = out['snapshot'] = True
+        if self.patience <= epoch:
+            out['patience_hit'] = True
+            if self.early_stop:
+                if not self.snapshotted:
+                    self.snapshotted = out['snapshot'] = True
+                out['stop'] = True
+            else:                                               # keep training to the last epoch
+                out['continuing'] = True
+                self.patience = self.epochs + 1
+                self.snapshotted = False
+        out['best'] = self.best
+        return out
+
+    def on_interrupt(self):
+        """KeyboardInterrupt: snapshot unless one was already taken (src/DrVAE.py:869-874)"""
+        take = not self.snapshotted
+        self.snapshotted = True
+        return take
+
+
+_REC = 'RMSE: {:.3f} R2: {:.3f} Pearson: {:.3f}'
+_NAN4 = ('rmse', 'r2', 'pearr', 'll')
+
+
+class FitMixin:
+    """evaluate_performance / fit for ``ELBOModel`` (``self.kind`` selects the model's variant)."""
+    fit_patience = 50         # src/DrVAE.py:756, src/PVAE.py:567 (VFAE: 40, src/VFAE.py:536)
+
+    # ------------------------------------------------------------------ metrics
+    def eval_y_prediction(self, pred, proba, ylab):
+        if getattr(self, 'type_y', 'discrete') != 'discrete':
+            raise NotImplementedError("type_y='cont'")
+        return MET.eval_y_prediction(pred, proba, ylab, self.dim_y)
+
+    def _np(self, t):
+        return t.detach().cpu().numpy()
+
+    @torch.no_grad()
+    def _evaluate(self, x1, x2, s, y, has_x2, has_y, return_full_data=False):
+        """one pass of losses + means-only inference + metrics over a row set
+        (src/DrVAE.py:640-741, src/PVAE.py:479-552, src/VFAE.py:472-521)"""
+        kind = self.kind
+        dev = next(self.parameters()).device
+        dv = lambda t: None if t is None else t.to(dev)
+        x1, x2, y, has_x2, has_y = dv(x1), dv(x2), dv(y), dv(has_x2), dv(has_y)
+        perf = OrderedDict()
+        kw = dict(x1=x1, s=s)
+        if kind != 'vfae':
+            kw.update(x2=x2, has_x2=has_x2)
+        if kind != 'pvae':
+            kw.update(y=y, has_y=has_y)
+        try:
+            losses = self.run_on_batch(train_mode=False, **kw)
+            perf['losses'] = OrderedDict((k, v.clone()) for k, v in losses.items())
+        except Exception as e:          # the reference evaluates on regardless (src/DrVAE.py:648-654)
+            if kind == 'pvae':
+                raise
+            print('Warning, computation of losses failed in evaluation!')
+            print(e)
+            perf['losses'] = None
+        res = self.forward(x1, s)
+        parts = []
+        if kind != 'pvae':
+            yidx = torch.nonzero(has_y.reshape(-1)).reshape(-1)
+            ylab = y.reshape(-1)[yidx]
+            for k, v in self.eval_y_prediction(res['pred'][yidx], res['proba'][yidx], ylab).items():
+                perf['y_' + k] = v
+            parts.append('Y: Accuracy: {:.3f}% AUROC: {:.3f} AUPR: {:.3f}'.format(
+                perf['y_acc'] * 100., perf['y_auroc'], perf['y_aupr']))
+        for k, v in self.eval_x_reconstruction(x1, *res['px1']).items():
+            perf['x1_' + k] = v
+        parts.append('X1: ' + _REC.format(perf['x1_rmse'], perf['x1_r2'], perf['x1_pearr']))
+        x2idx = None
+        if kind != 'vfae':
+            x2idx = torch.nonzero(has_x2.reshape(-1)).reshape(-1)
+            if len(x2idx) > 0:
+                x2p = x2[x2idx]
+                rp = self.eval_x_reconstruction(x2p, res['px2'][0][x2idx], res['px2'][1][x2idx])
+                for k, v in rp.items():
+                    perf['x2_' + k] = v
+                parts.append('X2: ' + _REC.format(perf['x2_rmse'], perf['x2_r2'], perf['x2_pearr']))
+            else:
+                for k in _NAN4:
+                    perf['x2_' + k] = np.nan
+                parts.append('X2: no x2 data')
+        if return_full_data:
+            perf['z1'] = self._np(res['z1'])
+            if kind != 'vfae':
+                perf['z2'] = self._np(res['z2'])
+                perf['x2_pert'] = self._np(res['x2_pert'])
+            if kind != 'pvae':
+                perf['pred'] = self._np(res['pred'])
+                perf['proba'] = self._np(res['proba'])
+            if kind != 'vfae':
+                self._evaluate_identity_pert(perf, res, x1, x2, s, x2idx, yidx if kind == 'drvae' else None,
+                                             ylab if kind == 'drvae' else None)
+        perf['model_class'] = self.__class__.__name__
+        return perf, '\t '.join(parts)
+
+    def _evaluate_identity_pert(self, perf, res, x1, x2, s, x2idx, yidx, ylab):
+        """the extra report with the perturbation function set to the identity
+        (src/DrVAE.py:696-738, src/PVAE.py:514-549)"""
+        res2 = self.forward_w_pert_identity(x1, x2, s)
+        if yidx is not None:
+            for k, v in self.eval_y_prediction(res2['pred'][yidx], res2['proba'][yidx], ylab).items():
+                perf['y_wI_' + k] = v
+        if len(x2idx) > 0:
+            x2p = x2[x2idx]
+            for tag, key in (('x2_wI_', 'px2'), ('x2_rec_', 'px2_rec')):
+                rp = self.eval_x_reconstruction(x2p, res2[key][0][x2idx], res2[key][1][x2idx])
+                for k, v in rp.items():
+                    perf[tag + k] = v
+            q1, q2 = res2['z1'][x2idx].double(), res2['z2'][x2idx].double()
+            pz = res['z2'][x2idx].double()
+            perf['qz1mu_qz2mu_rmse'] = float(torch.sqrt(((q1 - q2) ** 2).mean()))
+            perf['pz2Fz1mu_qz2mu_rmse'] = float(torch.sqrt(((pz - q2) ** 2).mean()))
+            qz1 = [t[x2idx].contiguous() for t in res2['qz1']]
+            qz2 = [t[x2idx].contiguous() for t in res2['qz2']]
+            pz2 = [t[x2idx].contiguous() for t in res['pz2']]
+            perf['KL_qz2_qz1'] = float(self.encoder_z1.kldivergence_perx(*(qz2 + qz1)).mean())
+            perf['KL_qz2_pz2Fz1'] = float(self.encoder_z1.kldivergence_perx(*(qz2 + pz2)).mean())
+        else:
+            for tag in ('x2_wI_', 'x2_rec_'):
+                for k in _NAN4:
+                    perf[tag + k] = np.nan
+            for k in ('qz1mu_qz2mu_rmse', 'pz2Fz1mu_qz2mu_rmse', 'KL_qz2_qz1', 'KL_qz2_pz2Fz1'):
+                perf[k] = np.nan
+
+    def evaluate_performance_on_dataset(self, ds, return_full_data=False):
+        g = lambda k: getattr(ds, k, None)
+        return self._evaluate(g('x1'), g('x2'), g('s'), g('y'), g('has_x2'), g('has_y'), return_full_data)
+
+    # ------------------------------------------------------------- the objective
+    def _valid_objective(self, perf):
+        """what early stopping maximises (src/DrVAE.py:822-825, src/PVAE.py:617, src/VFAE.py:600-603)"""
+        if self.kind == 'pvae':
+            return perf['x1_pearr'] + perf['x2_pearr']
+        v = perf['y_auroc'] + perf['y_aupr'] + perf['x1_pearr']
+        return v + perf['x2_pearr'] if self.kind == 'drvae' else v
+
+    def _batch_kwargs(self, batch):
+        if self.kind == 'vfae':
+            x1, s, y, has_y = batch
+            return dict(x1=x1, s=s, y=y, has_y=has_y)
+        x1, x2, s, y, has_x2, has_y = batch
+        if self.kind == 'pvae':
+            return dict(x1=x1, x2=x2, s=s, has_x2=has_x2)
+        return dict(x1=x1, x2=x2, s=s, y=y, has_x2=has_x2, has_y=has_y)
+
+    def _train_objective(self, loss):
+        v = loss['RECL']
+        return v + self.yloss_rate * loss['YL'] if 'YL' in loss else v
+
+    def _log_losses(self, epoch, seen, n_data, frac, loss):
+        keys = [k for k in ('CMPL', 'ELBO', 'RECL', 'PERT', 'YL') if k in loss]
+        txt = '\t'.join('{}: {:.3f}'.format(k, float(loss[k])) for k in keys)
+        self.w2log('training epoch: {} [{}/{} ({:.0f}%)]\t{}'.format(epoch, seen, n_data, 100. * frac, txt))
+
+    # --------------------------------------------------------------- epoch loops
+    def _epoch_device(self, batcher, epoch, verbose):
+        """one epoch of hipGraph replays fed by the device batcher; returns the mean train objective"""
+        eng = self.engine()
+        eng.add_noise = bool(self.add_noise)
+        eng.iters = self.finished_training_iters
+        batcher.bind(eng, counts=getattr(self, '_global_counts', None))
+        if getattr(eng, '_graph_key', None) != eng.plan.key or getattr(eng, '_graph_noise', None) != eng.add_noise:
+            batcher.feed()
+            eng.capture(split_for_allreduce=getattr(self, '_allreduce', None) is not None)
+            eng._graph_noise = eng.add_noise
+        n_b = len(batcher)
+        every = max(10, n_b / 10)
+        total = torch.zeros((), device=eng.dev)
+        for b in range(n_b):
+            batcher.feed()
+            eng.replay(allreduce=getattr(self, '_allreduce', None))
+            loss = self._loss_tensors(eng)
+            total += self._train_objective(loss)
+            if verbose and b % every == 0:
+                self._log_losses(epoch, b * batcher.batch_size, len(batcher.dataset), b / n_b, loss)
+        self.finished_training_iters = eng.iters
+        return float(total) / n_b
+
+    def _epoch_loader(self, loader, epoch, verbose):
+        n_b = len(loader)
+        every = max(10, n_b / 10)
+        total = None
+        for b, batch in enumerate(loader):
+            loss = self.run_on_batch(train_mode=True, **self._batch_kwargs(batch))
+            v = self._train_objective(loss)
+            total = v.clone() if total is None else total + v
+            if verbose and b % every == 0:
+                self._log_losses(epoch, b * len(batch[0]), len(loader.dataset), b / n_b, loss)
+        return float(total) / n_b
+
+    def fit(self, train_loader, valid_loader, add_noise=False, verbose=False, early_stop=False,
+            model_filename='best_model.pth'):
+        """Train for ``self.epochs`` epochs with the reference's validation / early-stopping /
+        snapshot protocol (signature and log lines of src/DrVAE.py:743)."""
+        from .data import DeviceBatcher
+        np.set_printoptions(precision=4)
+        ctl = EarlyStopping(self.epochs, early_stop, patience=self.fit_patience)
+        self.w2log('Starting training at: {}'.format(time.strftime('%c')))
+        epoch = 0
+        try:
+            self.add_noise = add_noise
+            for epoch in range(1, self.epochs + 1):
+                t = time.time()
+                if isinstance(train_loader, DeviceBatcher):
+                    train_loss = self._epoch_device(train_loader, epoch, verbose)
+                else:
+                    train_loss = self._epoch_loader(train_loader, epoch, verbose)
+                train_perf, train_str = self.evaluate_performance_on_dataset(train_loader.dataset)
+                self.w2log('====> Epoch: {}\tIter: {}'.format(epoch, self.finished_training_iters))
+                self.w2log('Train: sec/epoch: {:.2f}\tAvg train loss: {:9.4f}\t{}'.format(time.time() - t, train_loss,
+                                                                                     train_str))
+                t = time.time()
+                valid_perf, perf_str = self.evaluate_performance_on_dataset(valid_loader.dataset)
+                valid_loss = self._valid_objective(valid_perf)
+                self.w2log('Valid: sec/epoch: {:.2f}\tValid set loss: {:9.4f}\t{}'.format(time.time() - t, valid_loss,
+                                                                                      perf_str))
+                d = ctl.update(epoch, valid_loss)
+                self.w2log('Valid rolling mem: {}\tmean: {:.4f}\tbest: {:.4f}'.format(d['rolling'], d['rolling_mean'],
+                                                                                    d['best_before']))
+                if d['snapshot']:
+                    self.save_to_file(model_filename)
+                    self.w2log('* Snapshotting at epoch {}'.format(epoch))
+                if d['patience_hit']:
+                    self.w2log('Early stopping at: {} with train: {:.4f} valid: {:.4f} evaluate_valid_obj: {:.4f} '
+                               'best_valid_obj: {:.4f}'.format(epoch, train_loss, valid_loss, d['rolling_mean'],
+                                                               d['best']))
+                    if d['stop']:
+                        break
+                    self.w2log('Continuing')
+        except KeyboardInterrupt:
+            self.w2log('KeyboardInterrupt')
+            if ctl.on_interrupt():
+                self.save_to_file(model_filename)
+                self.w2log('* Snapshotting at epoch {}'.format(epoch))
+        self.w2log('Finished training at: {}'.format(time.strftime('%c')))
+        self._fit_controller = ctl
+        return

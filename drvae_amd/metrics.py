@@ -1,0 +1,71 @@
+"""Prediction metrics of ``eval_y_prediction`` (src/DGMMixin.py:158-190) computed where the
+scores live (device tensors, float64): accuracy, ROC-AUC and average precision, binary and
+macro-averaged.  The reference moves everything to numpy and calls scikit-learn; here the
+sort/scan runs on the device and only the final scalars cross to the host.  Ties in the
+scores are handled like scikit-learn does (one threshold per distinct score)."""
+import math
+
+import torch
+
+
+def _groups_desc(score, positive):
+    """distinct score values in DEscending order -> (cumulative positives, cumulative count)
+    at the end of every tie group."""
+    s, order = torch.sort(score.double(), descending=True)
+    pos = positive[order].double()
+    last = torch.ones_like(s, dtype=torch.bool)
+    last[:-1] = s[1:] != s[:-1]
+    ctp = torch.cumsum(pos, 0)[last]
+    cnt = torch.arange(1, s.numel() + 1, device=s.device, dtype=torch.float64)[last]
+    return ctp, cnt
+
+
+def roc_auc(y_true, score):
+    """area under the ROC curve (trapezoids over the distinct thresholds); nan when only one
+    class is present (scikit-learn raises there and the reference turns that into nan,
+    src/DGMMixin.py:168-171)."""
+    positive = y_true.reshape(-1) > 0
+    n = positive.numel()
+    n_pos = int(positive.sum())
+    if n == 0 or n_pos == 0 or n_pos == n:
+        return float('nan')
+    ctp, cnt = _groups_desc(score.reshape(-1), positive)
+    cfp = cnt - ctp
+    z = torch.zeros(1, dtype=torch.float64, device=ctp.device)
+    tp, fp = torch.cat([z, ctp]), torch.cat([z, cfp])
+    area = ((fp[1:] - fp[:-1]) * (tp[1:] + tp[:-1])).sum() * 0.5
+    return float(area / (n_pos * (n - n_pos)))
+
+
+def average_precision(y_true, score):
+    """sum_k (R_k - R_{k-1}) P_k over the distinct thresholds (sklearn.metrics.average_precision_score)."""
+    positive = y_true.reshape(-1) > 0
+    n_pos = int(positive.sum())
+    if positive.numel() == 0 or n_pos == 0:
+        return 0.0
+    ctp, cnt = _groups_desc(score.reshape(-1), positive)
+    prev = torch.cat([torch.zeros(1, dtype=torch.float64, device=ctp.device), ctp[:-1]])
+    return float((((ctp - prev) / n_pos) * (ctp / cnt)).sum())
+
+
+def macro(metric, labels, proba):
+    """unweighted mean of the one-vs-rest metric over the classes (``average='macro'`` on the one-hot
+    labels: what src/DGMMixin.py:173-180 intends; that branch cannot run in the reference, see
+    tests/golden/make_golden.py)."""
+    vals = [metric(labels.reshape(-1) == j, proba[:, j]) for j in range(proba.shape[1])]
+    return float('nan') if any(math.isnan(v) for v in vals) else sum(vals) / len(vals)
+
+
+def eval_y_prediction(pred, proba, ylab, dim_y):
+    """dict(acc, auroc, aupr) for a discrete target (src/DGMMixin.py:163-180)."""
+    ylab = ylab.reshape(-1)
+    out = dict()
+    out['acc'] = float((pred.reshape(-1).int() == ylab.int()).float().sum() / max(ylab.numel(), 1)) \
+        if ylab.numel() else float('nan')
+    if dim_y == 2:
+        out['auroc'] = roc_auc(ylab, proba[:, 1])
+        out['aupr'] = average_precision(ylab, proba[:, 1])
+    else:
+        out['auroc'] = macro(roc_auc, ylab, proba)
+        out['aupr'] = macro(average_precision, ylab, proba)
+    return out

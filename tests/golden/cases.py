@@ -119,6 +119,51 @@ def block_inputs(tag):
     raise KeyError(tag)
 
 
+# ----------------------------------------------------------------------- fit policy / y metrics
+def fit_policy_cases():
+    """scripted per-epoch validation objectives for the early-stopping / snapshot policy of ``fit``"""
+    rs = np.random.RandomState(77)
+    up = 1.0 + 0.01 * np.arange(200)
+    plateau = np.concatenate([np.linspace(0.5, 1.5, 12), 1.5 - 0.002 * np.arange(188)])
+    noisy = 1.0 + 0.3 * np.sin(np.arange(200) / 7.0) + 0.1 * rs.standard_normal(200) + 0.004 * np.arange(200)
+    late = np.concatenate([np.full(45, 1.0), 1.0 + 0.05 * np.arange(30), np.full(125, 2.0)])
+    withnan = plateau.copy()
+    withnan[[3, 20, 21]] = np.nan
+    negative = -2.0 + 0.01 * np.arange(200)     # threshold test multiplies by 0.999: sign matters
+    out = OrderedDict()
+    for kind in ('drvae', 'pvae', 'vfae'):
+        for nm, objs in (('up', up), ('plateau', plateau), ('noisy', noisy), ('late', late)):
+            for es in (True, False):
+                out['%s_%s_%s' % (kind, nm, 'es' if es else 'noes')] = dict(
+                    kind=kind, epochs=120, objs=objs, early_stop=es, n_batches=3)
+    out['drvae_nan_es'] = dict(kind='drvae', epochs=120, objs=withnan, early_stop=True, n_batches=2)
+    out['drvae_neg_es'] = dict(kind='drvae', epochs=150, objs=negative, early_stop=True, n_batches=1)
+    out['vfae_short_es'] = dict(kind='vfae', epochs=10, objs=plateau, early_stop=True, n_batches=2)
+    out['pvae_short_noes'] = dict(kind='pvae', epochs=10, objs=plateau, early_stop=False, n_batches=2)
+    out['drvae_interrupt'] = dict(kind='drvae', epochs=30, objs=up, early_stop=True, n_batches=4, interrupt_at=50)
+    out['drvae_interrupt_first'] = dict(kind='drvae', epochs=30, objs=plateau, early_stop=False, n_batches=4,
+                                        interrupt_at=3)
+    return out
+
+
+def y_metric_cases():
+    rs = np.random.RandomState(4242)
+    out = OrderedDict()
+    n = 57
+    y = rs.randint(0, 2, n).astype(np.int64)
+    p1 = np.clip(0.5 + 0.25 * (2 * y - 1) * rs.rand(n) + 0.2 * rs.standard_normal(n), 0.01, 0.99).astype(np.float32)
+    out['Y2'] = dict(ylab=y, proba=np.stack([1 - p1, p1], 1), pred=(p1 > 0.5).astype(np.int64))
+    pt = np.round(p1 * 8) / 8                      # heavy ties in the scores
+    out['Y2ties'] = dict(ylab=y, proba=np.stack([1 - pt, pt], 1).astype(np.float32), pred=(pt > 0.5).astype(np.int64))
+    y3 = rs.randint(0, 3, n).astype(np.int64)
+    lg = rs.standard_normal((n, 3)) + 1.5 * np.eye(3)[y3]
+    p3 = (np.exp(lg) / np.exp(lg).sum(1, keepdims=True)).astype(np.float32)
+    out['Y3'] = dict(ylab=y3, proba=p3, pred=p3.argmax(1).astype(np.int64))
+    out['Y2oneclass'] = dict(ylab=np.ones(9, np.int64), proba=out['Y2']['proba'][:9].copy(),
+                             pred=out['Y2']['pred'][:9].copy())
+    return out
+
+
 # ----------------------------------------------------------------------- model cases
 def tiny_spec(kind, **over):
     kw = dict(kind=kind, dim_x=13, dim_y=2, dim_z1=5, dim_z3=4, h_en_z1=[7], h_de_z1=[6], h_en_z3=[6],
