@@ -172,6 +172,11 @@ def main():
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--feed', default='resident', choices=['resident', 'batcher', 'epoch'],
+                    help='resident: one batch parked in HBM (default); batcher: a fresh stratified minibatch drawn on '
+                         'the device from an HBM-resident dataset before every step (host-driven gathers); epoch: the '
+                         "same, but the captured step gathers its batch itself from the epoch's index table")
+    ap.add_argument('--dataset-rows', type=int, default=16384)
     args = ap.parse_args()
 
     from drvae_amd import _lib, dist as D
@@ -196,9 +201,29 @@ def main():
     # iteration 0 runs eagerly (beta_pert = 0.01 only there), then the steady-state step is captured
     eng.train_step(allreduce=allreduce)
     use_graph = not args.no_graph
+    bat = None
+    if args.feed != 'resident':
+        from drvae_amd import data as DD, synth
+        big = synth.make_batch(kind, args.dataset_rows, cfg.dim_x, cfg.dim_y, seed=77 + rank)
+        tt = lambda k: torch.from_numpy(big[k]).to(device)
+        ds = DD.DrVAEDataset(tt('x1'), tt('x2'), torch.zeros(args.dataset_rows, dtype=torch.int64, device=device),
+                             tt('y'), tt('has_x2'), tt('has_y'))
+        hx, hy = batch['has_x2'].astype(bool), batch['has_y'].astype(bool)
+        gc = [int(((hy == bool(gy)) & (hx == bool(gx))).sum()) for (gy, gx) in DD._GROUPS]
+        bat = DD.DeviceBatcher(ds, torch.ones(args.dataset_rows), rows, group_counts=gc, seed=5 + rank)
+        bat.bind(eng, counts=(world * rows, world * int(hx.sum()), world * int(hy.sum())))
+        if args.feed == 'epoch':
+            bat.begin_epoch(n_batches=args.steps + args.warmup + 8)
+        else:
+            bat.feed()
     if use_graph:
         eng.capture(split_for_allreduce=world > 1)
-        step = lambda: eng.replay(allreduce)
+        if args.feed == 'batcher':
+            def step():
+                bat.feed()
+                eng.replay(allreduce)
+        else:
+            step = lambda: eng.replay(allreduce)
     else:
         step = lambda: eng.train_step(allreduce=allreduce)
     for _ in range(max(args.warmup - 1, 0)):
@@ -228,7 +253,7 @@ def main():
         'ms_per_step': round(1e3 * dt / args.steps, 4), 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': '%s: %s' % (args.workload, desc), 'global_batch': world * rows, 'L': L,
-                   'parallelism': 'dp%d' % world, 'launch': 'hipGraph replay' if use_graph else 'eager',
+                   'parallelism': 'dp%d' % world, 'launch': 'hipGraph replay' if use_graph else 'eager', 'feed': args.feed,
                    'params': int(sum(int(np.prod(s)) for s in arena.shapes.values()))},
         'losses_last_step': {k: round(v, 4) for k, v in losses.items()}, 'finite': ok,
     }

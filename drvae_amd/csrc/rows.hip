@@ -751,11 +751,64 @@ __global__ void rows_gather_kernel(const float* __restrict__ src, int64_t lds, c
         float v;
         if (d < W) {
             v = src[(int64_t)(idx ? idx[r] : r) * lds + d];
-            if (noise) v += sigma * noise[(int64_t)r * ldn + d];
+            if (noise) v = fmaf(sigma, noise[(int64_t)r * ldn + d], v);
         } else {
             v = (d - W) == onehot_cls[r] ? 1.f : 0.f;
         }
         out[(int64_t)r * ldo + d] = v;
+    }
+}
+
+// Graph-resident input feed: batch `b = ctr - base` of an epoch's index table is gathered from
+// the HBM-resident dataset straight into the step's input rows ([x1 rows ; x2 rows of the pairs],
+// + training noise), and the label-dependent index buffers of the step are refreshed, in ONE
+// launch whose arguments never change -- so the whole epoch is replays of one captured graph.
+__global__ __launch_bounds__(256) void batch_feed_kernel(
+    const float* __restrict__ x1, int64_t ld1, const float* __restrict__ x2, int64_t ld2,
+    const int32_t* __restrict__ y, const int32_t* __restrict__ table, int n_batches,
+    const int32_t* __restrict__ ctr, const int32_t* __restrict__ base, int B, const int32_t* __restrict__ pair_rows,
+    int Np, int X, const float* __restrict__ noise, int64_t ldn, float sigma, float* __restrict__ xin, int64_t ldo,
+    const int32_t* __restrict__ has_y, int L, int32_t* __restrict__ label_r, const int32_t* __restrict__ fp_i,
+    const int32_t* __restrict__ fp_lab, const int32_t* __restrict__ fp_slot, int Mf, int32_t* __restrict__ fp_cls,
+    float* __restrict__ onehot, int64_t ldh, int Y, int row_blocks, int vec4) {
+    int b = ctr[0] - base[0];
+    b = b < 0 ? 0 : (b >= n_batches ? n_batches - 1 : b);
+    const int32_t* tb = table + (int64_t)b * B;
+    if ((int)blockIdx.x < row_blocks) {
+        const int lane = threadIdx.x & 63;
+        const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+        if (r >= B + Np) return;
+        const float* src = r < B ? x1 + (int64_t)tb[r] * ld1 : x2 + (int64_t)tb[pair_rows[r - B]] * ld2;
+        const float* nz = noise ? noise + (int64_t)r * ldn : nullptr;
+        float* dst = xin + (int64_t)r * ldo;
+        if (vec4) {
+            for (int q = lane; q < (X >> 2); q += 64) {
+                float4 v = reinterpret_cast<const float4*>(src)[q];
+                if (nz) {
+                    const float4 e = reinterpret_cast<const float4*>(nz)[q];
+                    v.x = fmaf(sigma, e.x, v.x);
+                    v.y = fmaf(sigma, e.y, v.y);
+                    v.z = fmaf(sigma, e.z, v.z);
+                    v.w = fmaf(sigma, e.w, v.w);
+                }
+                reinterpret_cast<float4*>(dst)[q] = v;
+            }
+            for (int g = (X & ~3) + lane; g < X; g += 64) dst[g] = nz ? fmaf(sigma, nz[g], src[g]) : src[g];
+        } else {
+            for (int g = lane; g < X; g += 64) dst[g] = nz ? fmaf(sigma, nz[g], src[g]) : src[g];
+        }
+        return;
+    }
+    const int t = ((int)blockIdx.x - row_blocks) * 256 + threadIdx.x;
+    if (label_r && t < L * B) {
+        const int i = t % B;
+        label_r[t] = has_y[i] ? y[tb[i]] : 0;
+    }
+    if (fp_cls && t < Mf) {
+        const int cls = fp_lab[t] ? y[tb[fp_i[t]]] : fp_slot[t];
+        fp_cls[t] = cls;
+        if (onehot)
+            for (int c = 0; c < Y; ++c) onehot[(int64_t)t * ldh + c] = c == cls ? 1.f : 0.f;
     }
 }
 
@@ -1217,6 +1270,29 @@ extern "C" int dv_rows_gather(const float* src, int64_t lds, const int32_t* idx,
     if (total == 0) return DV_OK;
     hipLaunchKernelGGL(rows_gather_kernel, dim3(grid_for(total, 256)), dim3(256), 0, ST(stream), src, lds, idx, n,
                        W, noise, ldn, sigma, onehot_cls, Y, out, ldo);
+    DV_RETURN_LAUNCH();
+}
+
+extern "C" int dv_batch_feed(const float* x1, int64_t ld1, const float* x2, int64_t ld2, const int32_t* y,
+                             const int32_t* table, int32_t n_batches, const int32_t* ctr, const int32_t* base,
+                             int32_t B, const int32_t* pair_rows, int32_t Np, int32_t X, const float* noise,
+                             int64_t ldn, float sigma, float* xin, int64_t ldo, const int32_t* has_y, int32_t L,
+                             int32_t* label_r, const int32_t* fp_i, const int32_t* fp_lab, const int32_t* fp_slot,
+                             int32_t Mf, int32_t* fp_cls, float* onehot, int64_t ldh, int32_t Y,
+                             dv_stream_t stream) {
+    DV_REQUIRE(B >= 0 && Np >= 0 && X >= 0 && n_batches >= 1 && L >= 1 && Mf >= 0 && Y >= 0);
+    if (B == 0) return DV_OK;
+    DV_REQUIRE(x1 && table && ctr && base && xin && (Np == 0 || (x2 && pair_rows)));
+    DV_REQUIRE(!label_r || (y && has_y));
+    DV_REQUIRE(!fp_cls || Mf == 0 || (y && fp_i && fp_lab && fp_slot));
+    const int row_blocks = (B + Np + 3) / 4;
+    const int nlab = (label_r ? L * B : 0) > (fp_cls ? Mf : 0) ? (label_r ? L * B : 0) : (fp_cls ? Mf : 0);
+    const int lab_blocks = (nlab + 255) / 256;
+    const bool v4 = aligned16(x1) && (Np == 0 || aligned16(x2)) && aligned16(xin) && (!noise || aligned16(noise)) &&
+                    ld1 % 4 == 0 && (Np == 0 || ld2 % 4 == 0) && ldo % 4 == 0 && (!noise || ldn % 4 == 0);
+    hipLaunchKernelGGL(batch_feed_kernel, dim3(row_blocks + lab_blocks), dim3(256), 0, ST(stream), x1, ld1, x2, ld2, y,
+                       table, n_batches, ctr, base, B, pair_rows, Np, X, noise, ldn, sigma, xin, ldo, has_y, L,
+                       label_r, fp_i, fp_lab, fp_slot, Mf, fp_cls, onehot, ldh, Y, row_blocks, v4 ? 1 : 0);
     DV_RETURN_LAUNCH();
 }
 

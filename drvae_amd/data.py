@@ -11,6 +11,8 @@ composition under the weights), drawn on the GPU, in a fixed group order.  Every
 has the same structure, so one step plan and one captured hipGraph serve the whole epoch and
 only data (rows, labels) move -- device to device.
 """
+import types
+
 import numpy as np
 import torch
 
@@ -154,6 +156,28 @@ class DeviceBatcher:
         self.engine = engine
         engine.set_structure(self.has_x2, self.has_y, counts)
         return engine.plan
+
+    def begin_epoch(self, n_batches=None):
+        """Draw the index table of a whole epoch on the device (one multinomial per group) and
+        install it as the bound plan's graph-resident feed: from here on every captured train step
+        gathers its own minibatch (``dv_batch_feed``), i.e. an epoch is ``len(self)`` graph replays
+        with no other host work.  Returns the table (n_batches, batch_size) int32."""
+        eng, p = self.engine, self.engine.plan
+        n_b = len(self) if n_batches is None else n_batches
+        fd = p.feed
+        if fd is None or fd.owner is not self or fd.n_batches != n_b:
+            dev = self.ds.x1.device
+            fd = types.SimpleNamespace(owner=self, n_batches=n_b, x1=self.ds.x1,
+                                       x2=getattr(self.ds, 'x2', None) if eng.cfg.has_pert else None,
+                                       y32=self.ds.y.reshape(-1).to(torch.int32).contiguous(),
+                                       table=torch.zeros(n_b, self.batch_size, dtype=torch.int32, device=dev),
+                                       base=torch.zeros(1, dtype=torch.int32, device=dev))
+            p.feed = fd
+        parts = [m[torch.multinomial(w, c * n_b, replacement=True, generator=self.gen)].reshape(n_b, c)
+                 for m, w, c in zip(self.members, self.gweights, self.group_counts) if c > 0]
+        fd.table.copy_(torch.cat(parts, 1))
+        fd.base.copy_(eng.step_dev)         # device to device: batch index = optimiser step - base
+        return fd.table
 
     def next_indices(self):
         parts = [m[torch.multinomial(w, c, replacement=True, generator=self.gen)]

@@ -409,7 +409,19 @@ class FusedStep:
         B, Np, L, Z1 = p.B, p.Np, cfg.L, cfg.dim_z1
         sigma = cfg.add_noise_var if (self.training and self.add_noise and cfg.add_noise_var > 0) else 0.0
         # ---- inputs (+ training noise N(0,1)*add_noise_var, src/DrVAE.py:404-407,414-417): one gather
-        K.rows_gather(p.XIN, p.XSRC, p.xin_idx, noise=p.EX if sigma else None, sigma=sigma)
+        fd = p.feed if (self.fuse_bwd and self.training) else None
+        if fd is not None:
+            # batch (optimiser step - epoch base) of the epoch's index table, straight from the
+            # HBM-resident dataset; also refreshes the label-dependent index buffers
+            lab = cfg.has_y
+            K.batch_feed(p.XIN, fd.x1, fd.x2, fd.y32, fd.table, fd.n_batches, self.step_dev, fd.base,
+                         pair_rows=p.pair_idx if Np else None, noise=p.EX if sigma else None, sigma=sigma,
+                         has_y=p.has_y_i32 if lab else None, L=L, label_r=p.label_r if lab else None,
+                         fp_i=p.fp_q if lab else None, fp_lab=p.fp_lab_i32 if lab else None,
+                         fp_slot=p.fp_slot_dev if lab else None, fp_cls=p.fp_cls if (lab and p.Mf) else None,
+                         onehot=p.Z3IN[:, cfg.dim_z3:] if (lab and p.Mf) else None, n_classes=cfg.dim_y)
+        else:
+            K.rows_gather(p.XIN, p.XSRC, p.xin_idx, noise=p.EX if sigma else None, sigma=sigma)
         # ---- q(z1|x1), q(z2|x2): one pass of the shared encoder
         Q = p.c_enc.forward([p.XIN])
         Qmu, Qlv = Q[:, :Z1], Q[:, Z1:]
@@ -647,11 +659,13 @@ class FusedStep:
                 self._launch_sequence()
             self._graphs = [g]
         self._graph_key = self.plan.key
+        self._graph_feed = self.plan.feed
         return self
 
     def replay(self, allreduce=None):
         """One captured train step.  New data is fed by copying into plan.x1 / plan.x2 in place."""
         assert self._graph_key == self.plan.key, 'batch structure changed: capture again'
+        assert self._graph_feed is self.plan.feed, 'input feed changed: capture again'
         self.plan.set_beta(self.beta_pert())      # 0.01 on iteration 0, 1.0 afterwards (device-side coefficients)
         self._graphs[0].replay()
         if len(self._graphs) == 2:
@@ -749,6 +763,7 @@ class _Plan:
             self.fp_i_dev = torch.as_tensor(self.fp_i_host, device=dev)
             self.fp_lab_dev = torch.as_tensor(self._fp_lab_host, device=dev)
             self.fp_slot_dev = i32(self.fp_slot_host)
+            self.has_y_i32, self.fp_lab_i32 = i32(has_y), i32(self._fp_lab_host)
             sizes.append(self.Mf * Z3)
         self.noise = zf(int(sum(sizes)))
         views, o = [], 0
@@ -805,6 +820,7 @@ class _Plan:
         self.w_cmpl = zf(N_LOSS)
         self._cfg = cfg
         self.x1 = self.x2 = None
+        self.feed = None        # graph-resident input feed (drvae_amd.data.DeviceBatcher.begin_epoch)
 
     def set_labels_host(self, yv):
         """class labels of this batch's rows (host ints; only the labeled rows' entries matter)"""

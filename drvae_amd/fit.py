@@ -212,15 +212,15 @@ class FitMixin:
         eng.add_noise = bool(self.add_noise)
         eng.iters = self.finished_training_iters
         batcher.bind(eng, counts=getattr(self, '_global_counts', None))
-        if getattr(eng, '_graph_key', None) != eng.plan.key or getattr(eng, '_graph_noise', None) != eng.add_noise:
-            batcher.feed()
+        batcher.begin_epoch()               # this epoch's index table; the graph gathers batch b itself
+        if getattr(eng, '_graph_key', None) != eng.plan.key or getattr(eng, '_graph_noise', None) != eng.add_noise \
+                or getattr(eng, '_graph_feed', None) is not eng.plan.feed:
             eng.capture(split_for_allreduce=getattr(self, '_allreduce', None) is not None)
             eng._graph_noise = eng.add_noise
         n_b = len(batcher)
         every = max(10, n_b / 10)
         total = torch.zeros((), device=eng.dev)
         for b in range(n_b):
-            batcher.feed()
             eng.replay(allreduce=getattr(self, '_allreduce', None))
             loss = self._loss_tensors(eng)
             total += self._train_objective(loss)

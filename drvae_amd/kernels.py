@@ -332,6 +332,21 @@ def rows_gather(out, src, idx=None, *, noise=None, sigma=0.0, onehot_cls=None, n
                'dv_rows_gather')
 
 
+def batch_feed(xin, x1, x2, y32, table, n_batches, ctr, base, *, pair_rows=None, noise=None, sigma=0.0, has_y=None,
+               L=1, label_r=None, fp_i=None, fp_lab=None, fp_slot=None, fp_cls=None, onehot=None, n_classes=0):
+    """graph-resident minibatch feed: see dv_batch_feed in include/drvae_hip.h"""
+    B = table.shape[1]
+    Np = pair_rows.numel() if pair_rows is not None else 0
+    assert xin.shape[0] == B + Np and table.shape[0] == n_batches and table.is_contiguous()
+    Mf = fp_cls.numel() if fp_cls is not None else 0
+    _lib.check(_lib.load().dv_batch_feed(_f32(x1), _ld(x1), _f32(x2) if Np else None, _ld(x2) if Np else 0, _i32(y32),
+                                         _i32(table), n_batches, _i32(ctr), _i32(base), B, _i32(pair_rows), Np,
+                                         xin.shape[1], _f32(noise), _ld(noise), sigma, _f32(xin), _ld(xin),
+                                         _i32(has_y), L, _i32(label_r), _i32(fp_i), _i32(fp_lab), _i32(fp_slot), Mf,
+                                         _i32(fp_cls), _f32(onehot), _ld(onehot), n_classes, _stream()),
+               'dv_batch_feed')
+
+
 def rows_segment_sum(dst, src, *, seg_ptr=None, seg_rows=None, w=None, n=None, dst_idx=None, beta=0.0, width=None):
     if n is None:
         n = seg_ptr.numel() - 1 if seg_ptr is not None else (seg_rows.numel() if seg_rows is not None else

@@ -277,6 +277,22 @@ int dv_ymarg_bwd(const float* qy, int64_t ldq, const int32_t* label, const int32
 int dv_rows_gather(const float* src, int64_t lds, const int32_t* idx, int32_t n, int32_t W, const float* noise,
                    int64_t ldn, float sigma, const int32_t* onehot_cls, int32_t Y, float* out, int64_t ldo,
                    dv_stream_t stream);
+/* Graph-resident minibatch feed (input pipeline of src/run_drvae.py:150-166 + the group gathers of
+ * src/DrVAE.py:585-608, kept on the device).  `table` holds the dataset row of every slot of every
+ * batch of an epoch (n_batches x B, drawn by the weighted sampler on the device); batch
+ * b = clamp(ctr[0] - base[0], 0, n_batches-1) is written into the step's buffers:
+ *   xin[r]     = x1[table[b,r]]                (r <  B)      } + sigma*noise[r]
+ *   xin[B + j] = x2[table[b,pair_rows[j]]]     (j <  Np)     }
+ *   label_r[l*B+i] = has_y[i] ? y[table[b,i]] : 0
+ *   fp_cls[m]  = fp_lab[m] ? y[table[b,fp_i[m]]] : fp_slot[m];  onehot[m,c] = (c == fp_cls[m])
+ * ctr/base are DEVICE scalars (ctr = the optimiser's step counter), so the launch arguments are
+ * constant and the launch can live inside the captured train-step graph. */
+int dv_batch_feed(const float* x1, int64_t ld1, const float* x2, int64_t ld2, const int32_t* y, const int32_t* table,
+                  int32_t n_batches, const int32_t* ctr, const int32_t* base, int32_t B, const int32_t* pair_rows,
+                  int32_t Np, int32_t X, const float* noise, int64_t ldn, float sigma, float* xin, int64_t ldo,
+                  const int32_t* has_y, int32_t L, int32_t* label_r, const int32_t* fp_i, const int32_t* fp_lab,
+                  const int32_t* fp_slot, int32_t Mf, int32_t* fp_cls, float* onehot, int64_t ldh, int32_t Y,
+                  dv_stream_t stream);
 /* dst[di,:W] = beta*dst[di,:W] + sum_{t in [seg_ptr[i],seg_ptr[i+1])} w[t]*src[seg_rows[t],:W],
  * di = dst_idx?dst_idx[i]:i; seg_ptr==NULL: segment i is the single row (seg_rows?seg_rows[i]:i).
  * Deterministic (no atomics): the transpose of every gather above. */

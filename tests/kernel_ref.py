@@ -459,6 +459,25 @@ def rows_gather(out, src, idx=None, *, noise=None, sigma=0.0, onehot_cls=None, n
         out[:, W:W + n_classes] = F.one_hot(onehot_cls.long(), n_classes).to(out.dtype)
 
 
+def batch_feed(xin, x1, x2, y32, table, n_batches, ctr, base, *, pair_rows=None, noise=None, sigma=0.0, has_y=None,
+               L=1, label_r=None, fp_i=None, fp_lab=None, fp_slot=None, fp_cls=None, onehot=None, n_classes=0):
+    b = min(max(int(ctr[0]) - int(base[0]), 0), n_batches - 1)
+    tb = table[b].long()
+    B = tb.numel()
+    xin[:B] = x1[tb]
+    if pair_rows is not None and pair_rows.numel():
+        xin[B:] = x2[tb[pair_rows.long()]]
+    if noise is not None:
+        xin += sigma * noise
+    if label_r is not None:
+        label_r.copy_(torch.where(has_y.bool(), y32[tb], torch.zeros_like(y32[tb])).repeat(L))
+    if fp_cls is not None and fp_cls.numel():
+        cls = torch.where(fp_lab.bool(), y32[tb[fp_i.long()]], fp_slot)
+        fp_cls.copy_(cls)
+        if onehot is not None:
+            onehot.copy_(torch.nn.functional.one_hot(cls.long(), n_classes).to(onehot.dtype))
+
+
 def rows_segment_sum(dst, src, *, seg_ptr=None, seg_rows=None, w=None, n=None, dst_idx=None, beta=0.0, width=None):
     if n is None:
         n = seg_ptr.numel() - 1 if seg_ptr is not None else (seg_rows.numel() if seg_rows is not None else
@@ -541,7 +560,7 @@ def fill_normal(out, seed, ctr_dev=None):
     out.copy_(torch.randn(out.shape, generator=g).to(out.device))
 
 
-FUNCTIONS = ['gemm', 'linear_fwd', 'linear_bwd_data', 'linear_bwd_weight', 'linear_bwd_pair', 'colsum', 'act_bwd_', 'wn_scale', 'wn_bwd',
+FUNCTIONS = ['batch_feed', 'gemm', 'linear_fwd', 'linear_bwd_data', 'linear_bwd_weight', 'linear_bwd_pair', 'colsum', 'act_bwd_', 'wn_scale', 'wn_bwd',
              'reparam_fwd', 'reparam_bwd', 'reparam_bwd_seg', 'z2f_post_bwd', 'kl_rows_fwd', 'kl_rows_bwd', 'nll_rows_fwd', 'nll_rows_bwd', 'nll_rows_fwdbwd',
              'softmax_clamp_fwd', 'softmax_clamp_bwd', 'cat_terms_fwd', 'cat_terms_bwd', 'smalln_fwd', 'smalln_bwd_data',
              'smalln_bwd_weight', 'ymarg_fwd', 'ymarg_bwd',

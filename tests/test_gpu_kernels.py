@@ -548,3 +548,39 @@ def test_gemm_pair_matches_two_launches(K, dev, M, N, Kd):
         close(dW, rW, **gemm_tol(M))
         close(db, rb, **gemm_tol(M))
         close(dx, rx, **gemm_tol(N))
+
+
+@pytest.mark.parametrize('X,pad,Np,Mf', [(978, 2, 37, 0), (13, 0, 0, 40), (980, 0, 5, 333)])
+def test_batch_feed(K, dev, X, pad, Np, Mf):
+    N, B, L, Y, nb = 211, 50, 2, 3, 4
+    x1, x2 = strided(dev, N, X, pad, seed=1), strided(dev, N, X, pad, seed=2)
+    y32 = torch.randint(0, Y, (N,), dtype=torch.int32).to(dev)
+    table = torch.randint(0, N, (nb, B), dtype=torch.int32).to(dev)
+    pair_rows = torch.randperm(B)[:Np].sort().values.to(torch.int32).to(dev) if Np else None
+    noise = rnd(dev, B + Np, X, seed=3)
+    has_y = (torch.arange(B) % 3 != 0).to(torch.int32).to(dev)
+    fp_i = torch.randint(0, B, (Mf,), dtype=torch.int32).to(dev)
+    fp_lab = has_y[fp_i.long()].contiguous()
+    fp_slot = torch.randint(0, Y, (Mf,), dtype=torch.int32).to(dev)
+    for step, base in ((7, 5), (3, 3), (9, 2), (1, 4)):      # batch 2, 0, clamped to 3, clamped to 0
+        ctr = torch.tensor([step], dtype=torch.int32, device=dev)
+        bs = torch.tensor([base], dtype=torch.int32, device=dev)
+        outs = []
+        for mod in (K, R):
+            xin = strided(dev, B + Np, X, 4 - X % 4 if X % 4 else 0, seed=9).clone()
+            label_r = torch.full((L * B,), -1, dtype=torch.int32, device=dev)
+            fp_cls = torch.full((Mf,), -1, dtype=torch.int32, device=dev)
+            onehot = torch.full((Mf, Y + 1), 7.0, device=dev)[:, :Y]
+            mod.batch_feed(xin, x1, x2, y32, table, nb, ctr, bs, pair_rows=pair_rows, noise=noise, sigma=0.01,
+                           has_y=has_y, L=L, label_r=label_r, fp_i=fp_i if Mf else None,
+                           fp_lab=fp_lab if Mf else None, fp_slot=fp_slot if Mf else None,
+                           fp_cls=fp_cls if Mf else None, onehot=onehot if Mf else None, n_classes=Y)
+            outs.append((xin, label_r, fp_cls, onehot))
+        close(outs[0][0], outs[1][0], rtol=1e-6, atol=1e-6)
+        for a, b in zip(outs[0][1:], outs[1][1:]):
+            assert torch.equal(a, b)
+    # no noise / no labels (PVAE-style call)
+    xin, rin = torch.empty(B + Np, X, device=dev), torch.empty(B + Np, X, device=dev)
+    K.batch_feed(xin, x1, x2, None, table, nb, ctr, bs, pair_rows=pair_rows)
+    R.batch_feed(rin, x1, x2, None, table, nb, ctr, bs, pair_rows=pair_rows)
+    assert torch.equal(xin, rin)

@@ -192,3 +192,41 @@ def test_device_batcher_feeds_one_captured_graph(dev):
     torch.cuda.synchronize()
     assert torch.equal(a0.param, a1.param)
     assert eager.losses() == fed.losses()
+
+
+@pytest.mark.parametrize('kind', ['drvae', 'pvae', 'vfae'])
+def test_graph_resident_epoch_feed(kind, dev):
+    """N2/N3: the epoch's index table lives on the device and the captured step gathers batch
+    (optimiser step - epoch base) itself: an epoch is n graph replays with no other host work, and
+    equals eager steps fed the same rows from the host."""
+    from drvae_amd import data as D
+    from tests.test_engine_cpu import make_engine
+    spec = M.ModelSpec(kind=kind, L=2)
+    params = M.init_params(spec, 3, as_numpy=True)
+    big = M.make_batch(spec, 900, seed=9)
+    t = lambda k: torch.from_numpy(big[k].copy())
+    ds = D.DrVAEDataset(t('x1'), t('x2'), t('s'), t('y'), t('has_x2'), t('has_y')).to(dev)
+    w = D.compute_balanced_weights(np.arange(900) % 7)
+    bat = D.DeviceBatcher(ds, w, 150, seed=5)
+    fed, a1 = make_engine(spec, params, dev)
+    eager, a0 = make_engine(spec, params, dev)
+    bat.bind(fed)
+    tables = []
+    for epoch in range(2):
+        tables.append(bat.begin_epoch(n_batches=3).clone())
+        if epoch == 0:
+            fed.capture()
+        for _ in range(3):
+            fed.replay()
+    assert len(fed._plans) == 1 and fed.iters == 6
+    assert not torch.equal(tables[0], tables[1])
+    eager.set_structure(bat.has_x2, bat.has_y)
+    eager.draw_noise()                       # capture() spends one Philox draw on its warm-up
+    for tab in tables:
+        for b in range(3):
+            i = tab[b].long()
+            eager.set_batch(ds.x1[i], ds.x2[i], ds.y[i].cpu(), bat.has_x2, bat.has_y)
+            eager.train_step()
+    torch.cuda.synchronize()
+    assert torch.equal(a0.param, a1.param)
+    assert eager.losses() == fed.losses()
