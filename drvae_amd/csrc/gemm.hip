@@ -25,8 +25,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
+// what staging chunks past the end of K read (see the K tail of the fast path)
+__device__ __attribute__((aligned(16))) const float dv_zero_chunk[4] = {0.f, 0.f, 0.f, 0.f};
+
 struct LoadCfg {
     int vecA, vecB;   // widest aligned vector width (4, 2 or 1 floats) per operand
+    int vecA_t, vecB_t;   // same for the ragged last K tile of a k-contiguous operand: also divides K
     int map;          // workgroup -> tile mapping: 0 linear, 1 XCD chunk-major (default)
     int dbg;          // tuning only: bit0 skip in-loop global loads, bit1 skip MFMAs, bit2 skip in-loop LDS stores
     unsigned long long* stamps;   // tuning only: per-phase s_memtime sums of block 0 / wave 0
@@ -354,6 +358,18 @@ __device__ __forceinline__ void gemm_body(const dv_gemm_desc& g, const LoadCfg& 
             }
             return make_float4(p[0], p[1], p[2], p[3]);
         };
+        // chunk of a k-contiguous operand in the K tail: `left` = K - (k of the chunk's first element)
+        auto ldv_tail = [](const float* p, int vec, int left) -> float4 {
+            const float* z = dv_zero_chunk;
+            if (vec == 4) return *reinterpret_cast<const float4*>(left >= 4 ? p : z);
+            if (vec == 2) {
+                const float2 a = *reinterpret_cast<const float2*>(left >= 2 ? p : z);
+                const float2 b = *reinterpret_cast<const float2*>(left >= 4 ? p + 2 : z);
+                return make_float4(a.x, a.y, b.x, b.y);
+            }
+            return make_float4(*(left >= 1 ? p : z), *(left >= 2 ? p + 1 : z), *(left >= 3 ? p + 2 : z),
+                               *(left >= 4 ? p + 3 : z));
+        };
         auto fetch = [&](int t, float4 (&ra)[A_NP], float4 (&rb)[B_NP]) {
             if (t < nfull) {
 #pragma unroll
@@ -367,7 +383,26 @@ __device__ __forceinline__ void gemm_body(const dv_gemm_desc& g, const LoadCfg& 
                     pb[p] += step_b;
                 }
             } else {
-                gen_load(t * BK, ra, rb);   // the partial K tail tile
+                // the partial K tail tile: same loads, but every sub-load (of the widest width that divides
+                // K, so that none straddles it) past K reads a block of zeros instead -- no branches, and
+                // nothing here waits on the loads
+                const int kt0 = nfull * BK;
+#pragma unroll
+                for (int p = 0; p < A_NP; ++p) {
+                    if (AKC) {
+                        ra[p] = ldv_tail(pa[p], lc.vecA_t, g.K - (kt0 + a_c * 4));
+                    } else {
+                        ra[p] = ldv((kt0 + a_l + p * A_LPP < g.K) ? pa[p] : dv_zero_chunk, va);
+                    }
+                }
+#pragma unroll
+                for (int p = 0; p < B_NP; ++p) {
+                    if (BKC) {
+                        rb[p] = ldv_tail(pb[p], lc.vecB_t, g.K - (kt0 + b_c * 4));
+                    } else {
+                        rb[p] = ldv((kt0 + b_l + p * B_LPP < g.K) ? pb[p] : dv_zero_chunk, vb);
+                    }
+                }
             }
         };
         float4 a0[A_NP], b0[B_NP], a1[A_NP], b1[B_NP];
@@ -546,6 +581,10 @@ static int gemm_prepare(const dv_gemm_desc* d, LoadCfg& lc, int& tiling) {
         if (g.K1 & 3) lc.vecA = 1;   // a 4-chunk could straddle the two sources
     }
     lc.vecB = vec_width(g.B, g.ldb);
+    lc.vecA_t = lc.vecA;
+    lc.vecB_t = lc.vecB;
+    while (g.K % lc.vecA_t) lc.vecA_t >>= 1;
+    while (g.K % lc.vecB_t) lc.vecB_t >>= 1;
     lc.map = g_opt[0];
     lc.dbg = g_opt[1];
     lc.stamps = g_stamps;
