@@ -80,6 +80,8 @@ SIGNATURES = {
     'dv_loss_assemble': [C.POINTER(LossTerm), _i32, _p, _p, _p, _p],
     'dv_axpby': [_p, _f, _p, _f, _i64, _p],
     'dv_adam_l2': [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _f, _p, _p],
+    'dv_flag_publish': [_p, _p, _i32, _p],
+    'dv_flag_wait': [_p, _p, _i32, _p, _i32, _p],
     'dv_counter_add': [_p, _i32, _i64, _p],
     'dv_fill_normal': [_p, _i64, _u64, _p, _p],
 }
@@ -92,11 +94,12 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get('DRVAE_HIP_LIB', LIB_PATH)      # tuning builds (tools/gemm_lab.sh)
+    if not os.path.exists(path):
         raise RuntimeError(
             'drvae_amd: %s is missing -- build it with `python -m drvae_amd.build` (hipcc, gfx950). '
             'There is no CPU/PyTorch fallback for the hot path.' % LIB_PATH)
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     for name, argtypes in SIGNATURES.items():
         try:
             fn = getattr(lib, name)

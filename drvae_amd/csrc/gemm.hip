@@ -23,6 +23,16 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// tuning builds only (tools/gemm_lab.sh): knock out one phase of the fast-path K loop to see what
+// bounds it. 1: no global loads in the loop, 2: VALU fma instead of the MFMAs, 4: no LDS stores in
+// the loop, 8: no barriers in the loop.  Results are wrong for any value but 0.
+#ifndef DV_DBG
+#define DV_DBG 0
+#endif
+#ifndef DV_LOOP
+#define DV_LOOP 0
+#endif
+
 namespace {
 
 // what staging chunks past the end of K read (see the K tail of the fast path)
@@ -276,11 +286,10 @@ __device__ __forceinline__ void gemm_body(const dv_gemm_desc& g, const LoadCfg& 
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int kb = ks_id * KW + lh * KH;   // this lane's first k inside the tile
-    auto compute = [&](const float* sA) {
+    // all fragment reads of a tile are issued up front (in-order LDS returns: the first MFMA only
+    // waits for the first read, the rest land under the MFMA chain)
+    auto read_frags = [&](const float* sA, float (&fa)[TM][KH], float (&fb)[TN][KH]) {
         const float* sB = sA + A_ELEMS;
-        // all fragment reads of the tile are issued up front (in-order LDS returns: the first
-        // MFMA only waits for the first read, the rest land under the MFMA chain)
-        float fa[TM][KH], fb[TN][KH];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int row = wm * TM * 32 + i * 32 + li;
@@ -315,13 +324,24 @@ __device__ __forceinline__ void gemm_body(const dv_gemm_desc& g, const LoadCfg& 
                 }
             }
         }
+    };
+    auto mma = [&](const float (&fa)[TM][KH], const float (&fb)[TN][KH]) {
 #pragma unroll
         for (int s = 0; s < KH; ++s)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s], fb[j][s], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; ++j) {
+                    if (DV_DBG & 2)
+                        acc[i][j][s & 15] += fa[i][s] * fb[j][s];
+                    else
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s], fb[j][s], acc[i][j], 0, 0, 0);
+                }
+    };
+    auto compute = [&](const float* sA) {
+        float fa[TM][KH], fb[TN][KH];
+        read_frags(sA, fa, fb);
+        mma(fa, fb);
     };
 
     const int nkt = (g.K + BK - 1) / BK, nfull = g.K / BK;
@@ -405,6 +425,74 @@ __device__ __forceinline__ void gemm_body(const dv_gemm_desc& g, const LoadCfg& 
                 }
             }
         };
+#if DV_LOOP == 1
+        // one staging set; the next tile's LDS stores and the global loads of the one after are
+        // issued BEFORE the MFMA chain of the current tile, so they complete in its shadow
+        float4 sa[A_NP], sb[B_NP];
+        fetch(0, sa, sb);
+        stage_store(buf0, sa, sb);
+        if (nkt > 1) fetch(1, sa, sb);
+        __syncthreads();
+        for (int kt = 0; kt < nkt; kt += 2) {
+            {
+                float fa[TM][KH], fb[TN][KH];
+                read_frags(buf0, fa, fb);
+                if (kt + 1 < nkt) {
+                    stage_store(buf1, sa, sb);
+                    if (kt + 2 < nkt) fetch(kt + 2, sa, sb);
+                }
+                mma(fa, fb);
+            }
+            __syncthreads();
+            if (kt + 1 >= nkt) break;
+            {
+                float fa[TM][KH], fb[TN][KH];
+                read_frags(buf1, fa, fb);
+                if (kt + 2 < nkt) {
+                    stage_store(buf0, sa, sb);
+                    if (kt + 3 < nkt) fetch(kt + 3, sa, sb);
+                }
+                mma(fa, fb);
+            }
+            __syncthreads();
+        }
+#elif DV_LOOP == 2
+        // fragment registers double-buffered as well: at the top of iteration kt the fragments of
+        // tile kt are already in registers, tile kt+1 is complete in LDS and tile kt+2 is in flight
+        // from global memory.  The iteration issues the fragment reads of tile kt+1, the LDS stores
+        // of tile kt+2 and the global loads of tile kt+3, and only then runs the MFMA chain of tile
+        // kt: every memory operation of the loop completes in the shadow of matrix-core work.
+        float4 sa[A_NP], sb[B_NP];
+        float f0a[TM][KH], f0b[TN][KH], f1a[TM][KH], f1b[TN][KH];
+        {
+            float4 ta[A_NP], tb[B_NP];
+            fetch(0, sa, sb);
+            if (nkt > 1) fetch(1, ta, tb);
+            stage_store(buf0, sa, sb);
+            if (nkt > 1) stage_store(buf1, ta, tb);
+            if (nkt > 2) fetch(2, sa, sb);
+        }
+        __syncthreads();
+        read_frags(buf0, f0a, f0b);
+        __syncthreads();
+        for (int kt = 0; kt < nkt; kt += 2) {
+            if (kt + 1 < nkt) read_frags(buf1, f1a, f1b);
+            if (kt + 2 < nkt) {
+                stage_store(buf0, sa, sb);
+                if (kt + 3 < nkt) fetch(kt + 3, sa, sb);
+            }
+            mma(f0a, f0b);
+            __syncthreads();
+            if (kt + 1 >= nkt) break;
+            if (kt + 2 < nkt) read_frags(buf0, f0a, f0b);
+            if (kt + 3 < nkt) {
+                stage_store(buf1, sa, sb);
+                if (kt + 4 < nkt) fetch(kt + 4, sa, sb);
+            }
+            mma(f1a, f1b);
+            __syncthreads();
+        }
+#else
         float4 a0[A_NP], b0[B_NP], a1[A_NP], b1[B_NP];
         fetch(0, a0, b0);
         if (nkt > 1) fetch(1, a1, b1);
@@ -414,18 +502,19 @@ __device__ __forceinline__ void gemm_body(const dv_gemm_desc& g, const LoadCfg& 
         for (int kt = 0; kt < nkt; kt += 2) {
             compute(buf0);
             if (kt + 1 < nkt) {
-                stage_store(buf1, a1, b1);
-                if (kt + 3 < nkt) fetch(kt + 3, a1, b1);
+                if (!(DV_DBG & 4)) stage_store(buf1, a1, b1);
+                if (kt + 3 < nkt && !(DV_DBG & 1)) fetch(kt + 3, a1, b1);
             }
-            __syncthreads();
+            if (!(DV_DBG & 8)) __syncthreads();
             if (kt + 1 >= nkt) break;
             compute(buf1);
             if (kt + 2 < nkt) {
-                stage_store(buf0, a0, b0);
-                if (kt + 4 < nkt) fetch(kt + 4, a0, b0);
+                if (!(DV_DBG & 4)) stage_store(buf0, a0, b0);
+                if (kt + 4 < nkt && !(DV_DBG & 1)) fetch(kt + 4, a0, b0);
             }
-            __syncthreads();
+            if (!(DV_DBG & 8)) __syncthreads();
         }
+#endif
     } else {
         // ---- edge tiles / concatenated sources / k-scaled operand: simple loop, generic loads
         float4 ra[A_NP], rb[B_NP];

@@ -152,6 +152,40 @@ extern "C" int dv_adam_l2(float* p, const float* g, float* m, float* v, int64_t 
     DV_RETURN_LAUNCH();
 }
 
+// Device-side ordering between two concurrently running launch chains (two root branches of one
+// hipGraph): the producer chain publishes flag = ctr + add after the kernel whose results are
+// needed, the consumer chain parks a one-thread kernel on the flag.  Data visibility is provided by
+// the ordinary kernel boundaries on either side; only the flag itself is accessed atomically.
+__global__ void flag_publish_kernel(int32_t* flag, const int32_t* ctr, int add) {
+    if (threadIdx.x == 0) __hip_atomic_store(flag, ctr[0] + add, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ void flag_wait_kernel(int32_t* flag, const int32_t* ctr, int add, int32_t* err, int max_spins) {
+    if (threadIdx.x != 0) return;
+    const int want = ctr[0] + add;
+    int n = 0;
+    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - want < 0) {
+        __builtin_amdgcn_s_sleep(4);
+        if (++n > max_spins) {       // never hang the device: report and let the chain run on
+            atomicExch(err, 1);
+            break;
+        }
+    }
+}
+
+extern "C" int dv_flag_publish(int32_t* flag, const int32_t* ctr, int32_t add, dv_stream_t stream) {
+    DV_REQUIRE(flag && ctr);
+    hipLaunchKernelGGL(flag_publish_kernel, dim3(1), dim3(64), 0, ST(stream), flag, ctr, add);
+    DV_RETURN_LAUNCH();
+}
+
+extern "C" int dv_flag_wait(int32_t* flag, const int32_t* ctr, int32_t add, int32_t* err, int32_t max_spins,
+                            dv_stream_t stream) {
+    DV_REQUIRE(flag && ctr && err && max_spins > 0);
+    hipLaunchKernelGGL(flag_wait_kernel, dim3(1), dim3(64), 0, ST(stream), flag, ctr, add, err, max_spins);
+    DV_RETURN_LAUNCH();
+}
+
 extern "C" int dv_counter_add(int32_t* counter_lo_hi, int32_t n_words, int64_t inc, dv_stream_t stream) {
     DV_REQUIRE(counter_lo_hi && (n_words == 1 || n_words == 2));
     hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(64), 0, ST(stream), counter_lo_hi, n_words, inc);

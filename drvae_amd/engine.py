@@ -242,11 +242,29 @@ class _Branch:
 
     def __init__(self, device, enabled=True):
         self.on = enabled and torch.device(device).type == 'cuda'
-        self.side = torch.cuda.Stream(device=device) if self.on else None
+        # high priority: its own hardware queue (never the one of the launching stream), and its small
+        # kernels are dispatched ahead of the bulk GEMM workgroups of the main chain
+        self.side = torch.cuda.Stream(device=device, priority=-1) if self.on else None
+
+    def fork(self):
+        """mark the point of the current stream the side chain depends on; the chain itself may be
+        recorded later (``with branch:``).  Measured on MI355X (tools/graph_fork_probe.py): the hipGraph
+        executor runs a fork/join ~30 us faster when the MAIN continuation is recorded before the side
+        chain, so callers fork, record the main work, and only then the side chain."""
+        if self.on:
+            self.side.wait_stream(torch.cuda.current_stream())
+            self._forked = True
+
+    def wait_main(self):
+        """extra edge main -> side at the current point of the main stream"""
+        if self.on:
+            self.side.wait_stream(torch.cuda.current_stream())
 
     def __enter__(self):
         if self.on:
-            self.side.wait_stream(torch.cuda.current_stream())
+            if not getattr(self, '_forked', False):
+                self.side.wait_stream(torch.cuda.current_stream())
+            self._forked = False
             self._ctx = torch.cuda.stream(self.side)
             self._ctx.__enter__()
         return self
@@ -282,6 +300,17 @@ class FusedStep:
         self.seed = seed
         self.training = True
         self.fuse_bwd = False               # set by train_step/capture: forward is followed by backward
+        # train-step scheduling of the classifier/fprop side chain: 1 = graph fork/join per pass,
+        # 3 = one graph fork/join per step, 4 = the side chain is a ROOT branch of the graph and is
+        # ordered against the main chain by device flags (dv_flag_publish / dv_flag_wait)
+        self.sched = int(os.environ.get('DRVAE_SCHED', '5'))
+        #   5 = two single-stream graphs (main chain / side chain) launched on two streams per step
+        #       and ordered ONLY by the device flags: no graph edges, no events
+        self._rec = 'both'
+        self._side_graph = None
+        self.side_ctr = torch.zeros(1, dtype=torch.int32, device=self.dev)   # the side chain's own step count
+        self.flags = torch.zeros(3, dtype=torch.int32, device=self.dev)
+        self.sync_err = torch.zeros(1, dtype=torch.int32, device=self.dev)
         self.add_noise = True               # `fit(add_noise=...)` flag of the reference (src/DrVAE.py:769)
         self.branch = _Branch(self.dev, enabled=concurrent)   # classifier/fprop chain || decoder chain
         self.wbranch = _Branch(self.dev, enabled=concurrent and os.environ.get('DRVAE_WBRANCH', '0') == '1')   # measured slower on MI355X (third graph branch): off
@@ -408,52 +437,49 @@ class FusedStep:
         p.set_beta(self.beta_pert())
         B, Np, L, Z1 = p.B, p.Np, cfg.L, cfg.dim_z1
         sigma = cfg.add_noise_var if (self.training and self.add_noise and cfg.add_noise_var > 0) else 0.0
-        # ---- inputs (+ training noise N(0,1)*add_noise_var, src/DrVAE.py:404-407,414-417): one gather
-        fd = p.feed if (self.fuse_bwd and self.training) else None
-        if fd is not None:
-            # batch (optimiser step - epoch base) of the epoch's index table, straight from the
-            # HBM-resident dataset; also refreshes the label-dependent index buffers
-            lab = cfg.has_y
-            K.batch_feed(p.XIN, fd.x1, fd.x2, fd.y32, fd.table, fd.n_batches, self.step_dev, fd.base,
-                         pair_rows=p.pair_idx if Np else None, noise=p.EX if sigma else None, sigma=sigma,
-                         has_y=p.has_y_i32 if lab else None, L=L, label_r=p.label_r if lab else None,
-                         fp_i=p.fp_q if lab else None, fp_lab=p.fp_lab_i32 if lab else None,
-                         fp_slot=p.fp_slot_dev if lab else None, fp_cls=p.fp_cls if (lab and p.Mf) else None,
-                         onehot=p.Z3IN[:, cfg.dim_z3:] if (lab and p.Mf) else None, n_classes=cfg.dim_y)
-        else:
-            K.rows_gather(p.XIN, p.XSRC, p.xin_idx, noise=p.EX if sigma else None, sigma=sigma)
-        # ---- q(z1|x1), q(z2|x2): one pass of the shared encoder
-        Q = p.c_enc.forward([p.XIN])
-        Qmu, Qlv = Q[:, :Z1], Q[:, Z1:]
-        # ---- samples (src/blocks.py:170-174): z1 for every row and z2 for the pairs -- drawn from
-        # q(z1|x1), not q(z2|x2) (quirk 1, src/DrVAE.py:427) -- in one launch
+        rec = self._rec
         Z1blk = p.ZDEC[:L * B]
-        K.reparam_fwd(p.ZDEC[:p.o3], Qmu, Qlv, p.E12, src_idx=p.z_src_idx)
-        if cfg.has_pert:
-            P2 = p.c_z2F.forward([Z1blk], resid=Z1blk)
-            # z2Fz1 sample, the classifier input z2Fz1 - z1, and the decoder's copy for the pairs
-            K.reparam_fwd(p.Z2F, P2[:, :Z1], P2[:, Z1:], p.E2F, sub=Z1blk, out2=p.D,
-                          out3=p.ZDEC if Np else None, out3_idx=p.pert_out_idx if Np else None)
+        if rec == 'side':           # side-chain graph: the main graph launches these; only the views are needed
+            Q = p.c_enc.out[-1]
+            Qmu, Qlv = Q[:, :Z1], Q[:, Z1:]
+        else:
+            # ---- inputs (+ training noise N(0,1)*add_noise_var, src/DrVAE.py:404-407,414-417): one gather
+            fd = p.feed if (self.fuse_bwd and self.training) else None
+            if fd is not None:
+                # batch (optimiser step - epoch base) of the epoch's index table, straight from the
+                # HBM-resident dataset; also refreshes the label-dependent index buffers
+                lab = cfg.has_y
+                K.batch_feed(p.XIN, fd.x1, fd.x2, fd.y32, fd.table, fd.n_batches, self.step_dev, fd.base,
+                             pair_rows=p.pair_idx if Np else None, noise=p.EX if sigma else None, sigma=sigma,
+                             has_y=p.has_y_i32 if lab else None, L=L, label_r=p.label_r if lab else None,
+                             fp_i=p.fp_q if lab else None, fp_lab=p.fp_lab_i32 if lab else None,
+                             fp_slot=p.fp_slot_dev if lab else None, fp_cls=p.fp_cls if (lab and p.Mf) else None,
+                             onehot=p.Z3IN[:, cfg.dim_z3:] if (lab and p.Mf) else None, n_classes=cfg.dim_y)
+            else:
+                K.rows_gather(p.XIN, p.XSRC, p.xin_idx, noise=p.EX if sigma else None, sigma=sigma)
+            # ---- q(z1|x1), q(z2|x2): one pass of the shared encoder
+            Q = p.c_enc.forward([p.XIN])
+            Qmu, Qlv = Q[:, :Z1], Q[:, Z1:]
+            # ---- samples (src/blocks.py:170-174): z1 for every row and z2 for the pairs -- drawn from
+            # q(z1|x1), not q(z2|x2) (quirk 1, src/DrVAE.py:427) -- in one launch
+            Z1blk = p.ZDEC[:L * B]
+            K.reparam_fwd(p.ZDEC[:p.o3], Qmu, Qlv, p.E12, src_idx=p.z_src_idx)
+            if rec == 'main' and cfg.has_pert:
+                K.flag_publish(self.flags[0:1], self.step_dev)       # lets the side chain's fprop start early
+            if cfg.has_pert:
+                P2 = p.c_z2F.forward([Z1blk], resid=Z1blk)
+                # z2Fz1 sample, the classifier input z2Fz1 - z1, and the decoder's copy for the pairs
+                K.reparam_fwd(p.Z2F, P2[:, :Z1], P2[:, Z1:], p.E2F, sub=Z1blk, out2=p.D,
+                              out3=p.ZDEC if Np else None, out3_idx=p.pert_out_idx if Np else None)
         # ---- two independent chains from here: the classifier / fprop chain (many small launches)
         # runs on a side stream next to the decoder chain (the big GEMMs)
-        with self.branch:
+        def side_forward(mid=None):
+            """fprop first: it only needs the z1 samples, so (dual-graph schedule) it can start before
+            the perturbation function has run; ``mid`` then waits for the z2Fz1 samples"""
             if cfg.kind == 'pvae':
                 K.kl_rows_fwd(p.KLP, p.KLPraw, Qmu, Qlv, prior=(0.0, 0.0), free_bits=True, kl_min=cfg.kl_min)
-            if cfg.has_pert and Np:
-                P2 = p.c_z2F.out[-1]
-                K.kl_rows_fwd(p.KLZ2, p.KLZ2raw, Qmu, Qlv, P2[:, :Z1], P2[:, Z1:], qidx=p.qz2_idx, pidx=p.pidx,
-                              reps=L, free_bits=True, kl_min=cfg.kl_min)
-            # ---- q(y|.), fprop over (labeled: true class | unlabeled: every class)
+            # ---- fprop over (labeled: true class | unlabeled: every class)
             if cfg.has_y:
-                if cfg.kind == 'drvae':
-                    clf_in = [Z1blk, p.D] if cfg.clf_z1z2 else [p.Z2F]
-                else:
-                    clf_in = [Z1blk]
-                if self.clf_small:
-                    lc = self.L_clf[0]
-                    K.smalln_fwd(p.QY, None, clf_in[0], lc.W, lc.b, clf_in[1] if len(clf_in) > 1 else None)
-                else:
-                    K.softmax_clamp_fwd(p.QY, p.c_clf.forward(clf_in))
                 if p.Mf:
                     Z3, Y = cfg.dim_z3, cfg.dim_y
                     K.rows_gather(p.FPIN, Z1blk, p.fp_src, onehot_cls=p.fp_cls, n_classes=Y)
@@ -465,7 +491,37 @@ class FusedStep:
                     # KLFP = max(KL(q(z1|x)||p(z1|z3,y)), kl_min) + the z3 term   (src/DrVAE.py:347,358)
                     K.kl_rows_fwd(p.KLFP, p.KL1raw, Qmu, Qlv, PZ1[:, :Z1], PZ1[:, Z1:], qidx=p.fp_q, free_bits=True,
                                   kl_min=cfg.kl_min, add=p.KL3)
+            if mid is not None:
+                mid()
+            if cfg.has_pert and Np:
+                P2 = p.c_z2F.out[-1]
+                K.kl_rows_fwd(p.KLZ2, p.KLZ2raw, Qmu, Qlv, P2[:, :Z1], P2[:, Z1:], qidx=p.qz2_idx, pidx=p.pidx,
+                              reps=L, free_bits=True, kl_min=cfg.kl_min)
+            # ---- q(y|.)
+            if cfg.has_y:
+                if cfg.kind == 'drvae':
+                    clf_in = [Z1blk, p.D] if cfg.clf_z1z2 else [p.Z2F]
+                else:
+                    clf_in = [Z1blk]
+                if self.clf_small:
+                    lc = self.L_clf[0]
+                    K.smalln_fwd(p.QY, None, clf_in[0], lc.W, lc.b, clf_in[1] if len(clf_in) > 1 else None)
+                else:
+                    K.softmax_clamp_fwd(p.QY, p.c_clf.forward(clf_in))
                 K.ymarg_fwd(p.YLrow, p.KLDrow, p.QY, p.label_r, p.fp_ptr, p.KLFP, math.log(1.0 / cfg.dim_y))
+        mode = self._mode()
+        if mode == 5:
+            two = cfg.has_pert                      # flag 0: z1 samples final; flag 2: z2Fz1 samples final
+            if rec == 'side':
+                K.flag_wait(self.flags[0:1], self.side_ctr, self.sync_err)
+                if not os.environ.get('DRVAE_SIDE_DUMMY'):
+                    side_forward((lambda: K.flag_wait(self.flags[2:3], self.side_ctr, self.sync_err)) if two else None)
+                return
+            K.flag_publish(self.flags[2:3] if two else self.flags[0:1], self.step_dev)
+        elif mode == 4:
+            K.flag_publish(self.flags[0:1], self.step_dev)
+        else:
+            self.branch.fork()
         # ---- p(x|z): decoder over all stacked samples, then the NLL over genes
         X = cfg.dim_x
         PX = p.c_decx.forward([p.ZDEC])
@@ -474,6 +530,19 @@ class FusedStep:
                               xidx=p.tgt, sd_act='softplus', sd_shift=1e-3)
         else:
             K.nll_rows_fwd(p.NLL, p.XIN, PX[:, :X], PX[:, X:], mode=GAUSS_SIGMA, xidx=p.tgt)
+        if mode == 5:
+            return             # main-chain graph: the side chain lives in its own graph on the side stream
+        if mode == 4:
+            self.branch._forked = True                  # forked at the start of the step: no new graph edge
+        with self.branch:
+            if mode == 4:
+                K.flag_wait(self.flags[0:1], self.step_dev, self.sync_err)
+            if os.environ.get('DRVAE_SIDE_DUMMY'):      # tuning probe: one spinning kernel instead of the chain
+                torch.cuda._sleep(int(os.environ['DRVAE_SIDE_DUMMY']))
+            else:
+                side_forward()
+        if mode >= 2:
+            return             # train step, single fork/join: the side chain runs on into its backward
         self.branch.join()
         if self.fuse_bwd:
             return             # the loss scalars are assembled on the side chain of backward()
@@ -503,8 +572,10 @@ class FusedStep:
         DQ = p.DQ
         Z1blk, DZ1 = p.ZDEC[:L * B], p.DZDEC[:L * B]
         # ---- side chain: y-marginalisation, fprop, classifier -> DZ1B (its share of d/dz1), DZ2F
-        with self.branch:
-            if self.fuse_bwd:
+        mode = self._mode()
+
+        def side_backward():
+            if self.fuse_bwd and mode < 2:
                 self._loss_scalars()         # leaf work, off the critical path
             if cfg.has_y:
                 Y = cfg.dim_y
@@ -556,8 +627,35 @@ class FusedStep:
         if not self.fuse_bwd:
             K.nll_rows_bwd(p.DPX[:, :X], p.DPX[:, X:], p.c_nll, p.XIN, PX[:, :X], PX[:, X:], mode=GAUSS_SIGMA,
                            xidx=p.tgt, sd_act='softplus', sd_shift=1e-3)
+        if mode == 5 and self._rec == 'side':
+            if not os.environ.get('DRVAE_SIDE_DUMMY'):
+                side_backward()
+            K.flag_publish(self.flags[1:2], self.side_ctr)       # DZ1B / DZ2F / side gradients are final
+            K.counter_add(self.side_ctr, 1)
+            return
+        if mode < 2:
+            self.branch.fork()
+        elif mode == 5:
+            pass
+        else:
+            if mode == 2:
+                self.branch.wait_main()      # the loss scalars need the main chain's NLL rows
+            self.branch._forked = True       # the side chain simply continues: no new dependency
         p.c_decx.backward(p.DPX, [p.ZDEC], [[(p.DZDEC, 1.0, 0.0)]], wbranch=self.wbranch if self.wbranch.on else None)
-        self.branch.join()
+        if mode != 5:
+            with self.branch:
+                if not os.environ.get('DRVAE_SIDE_DUMMY'):
+                    side_backward()
+                if mode == 2:
+                    self._loss_scalars()
+                if mode == 4:
+                    K.flag_publish(self.flags[1:2], self.step_dev)   # DZ1B / DZ2F / side gradients are final
+        if mode >= 4:
+            K.flag_wait(self.flags[1:2], self.step_dev, self.sync_err)
+        else:
+            self.branch.join()
+        if mode >= 3:
+            self._loss_scalars()
         if cfg.has_pert:
             if not cfg.has_y:
                 p.DZ2F.zero_()
@@ -583,11 +681,30 @@ class FusedStep:
                           free_bits=True, kl_min=cfg.kl_min, beta=1.0)
         p.c_enc.backward(DQ, [p.XIN], None)
 
+    def _mode(self):
+        if not self.fuse_bwd:
+            return 0
+        if self._rec != 'both':
+            return 5
+        if self.sched == 5:
+            return 3                 # eager steps of the dual-graph schedule use plain stream edges
+        return self.sched if (self.sched != 4 or self.branch.on) else 1
+
+    def _step_begin(self):
+        if self._mode() == 4:
+            self.branch.fork()       # side chain = second root of the step (eager: waits for the previous step)
+
+    def _step_end(self):
+        if self.fuse_bwd and self.sched == 4 and self.branch.on:
+            self.branch.join()       # streams rejoin (required to end a capture); off the critical path
+
     # -------------------------------------------------------------------- optimiser
     def optimizer_step(self, gscale=1.0):
         """torch.optim.Adam with coupled L2 on EVERY parameter (src/DGMMixin.py:36)."""
         cfg, a = self.cfg, self.arena
         K.counter_add(self.step_dev, 1)
+        if self._rec == 'both' and self.sched == 5:
+            K.counter_add(self.side_ctr, 1)      # eager step: the side chain's counter follows
         K.adam_l2(a.param, a.grad[:a.n_params], a.exp_avg, a.exp_avg_sq, self.step_dev, lr=cfg.learning_rate,
                   weight_decay=cfg.weight_decay, gscale=gscale)
 
@@ -601,27 +718,31 @@ class FusedStep:
             self.draw_noise()
         self.fuse_bwd = True
         try:
+            self._step_begin()
             self.forward()
             self.backward()
+            if allreduce is not None:
+                allreduce(self.arena.grad)
+            self.optimizer_step()
+            self._step_end()
         finally:
             self.fuse_bwd = False
-        if allreduce is not None:
-            allreduce(self.arena.grad)
-        self.optimizer_step()
         self.iters += 1
 
     # ------------------------------------------------------------------- hipGraph
     def _launch_sequence(self, allreduce=None):
-        self.draw_noise()
         self.fuse_bwd = True
         try:
+            self._step_begin()
+            self.draw_noise()
             self.forward()
             self.backward()
+            if allreduce is not None:
+                allreduce(self.arena.grad)
+            self.optimizer_step()
+            self._step_end()        # after Adam: the rejoin edge stays off the critical path
         finally:
             self.fuse_bwd = False
-        if allreduce is not None:
-            allreduce(self.arena.grad)
-        self.optimizer_step()
 
     def capture(self, split_for_allreduce=False):
         """Capture the train step (Philox noise + forward + backward + Adam: ~100 launches)
@@ -640,14 +761,64 @@ class FusedStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self._graphs = []
+        self._side_graph = None
+        dual = self.sched == 5 and self.branch.on and self.cfg.has_y and self._flags_usable()
+        if dual:
+            self._rec = 'main'
+        try:
+            self._capture_main(split_for_allreduce)
+            if dual:
+                self._rec = 'side'
+                self.side_ctr.copy_(self.step_dev)
+                self.branch.side.wait_stream(torch.cuda.current_stream())
+                gs = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gs, stream=self.branch.side):
+                    self.fuse_bwd = True
+                    try:
+                        self.forward()
+                        self.backward()
+                    finally:
+                        self.fuse_bwd = False
+                self._side_graph = gs
+        finally:
+            self._rec = 'both'
+        self._graph_key = self.plan.key
+        self._graph_feed = self.plan.feed
+        return self
+
+    def _flags_usable(self):
+        """Device-flag ordering needs the two streams on DIFFERENT hardware queues (a parked wait kernel
+        blocks everything behind it in its queue).  Probe it once: park a short wait on the launching
+        stream, publish from the side stream; a timeout means the queues coincide -> use graph edges."""
+        if getattr(self, '_flags_ok', None) is None:
+            probe = torch.zeros(3, dtype=torch.int32, device=self.dev)      # flag, counter, error
+            torch.cuda.synchronize()
+            K.flag_wait(probe[0:1], probe[1:2], probe[2:3], add=1, max_spins=20000)
+            with torch.cuda.stream(self.branch.side):
+                K.flag_publish(probe[0:1], probe[1:2], 1)
+            torch.cuda.synchronize()
+            self._flags_ok = int(probe[2]) == 0
+            if not self._flags_ok:
+                import warnings
+                warnings.warn('drvae_amd: main and side stream share a hardware queue; falling back to graph edges')
+        return self._flags_ok
+
+    def check_sync(self):
+        """raise if a device-side wait of the dual-graph schedule ever timed out (results would be stale)"""
+        if int(self.sync_err) != 0:
+            raise RuntimeError('drvae_amd: a device-side chain wait timed out (main / side stream ordering)')
+
+    def _capture_main(self, split_for_allreduce):
         if split_for_allreduce:
             g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             with torch.cuda.graph(g1):
-                self.draw_noise()
                 self.fuse_bwd = True
                 try:
+                    self._step_begin()
+                    self.draw_noise()
                     self.forward()
                     self.backward()
+                    self._step_end()
                 finally:
                     self.fuse_bwd = False
             with torch.cuda.graph(g2):
@@ -658,15 +829,15 @@ class FusedStep:
             with torch.cuda.graph(g):
                 self._launch_sequence()
             self._graphs = [g]
-        self._graph_key = self.plan.key
-        self._graph_feed = self.plan.feed
-        return self
 
     def replay(self, allreduce=None):
         """One captured train step.  New data is fed by copying into plan.x1 / plan.x2 in place."""
         assert self._graph_key == self.plan.key, 'batch structure changed: capture again'
         assert self._graph_feed is self.plan.feed, 'input feed changed: capture again'
         self.plan.set_beta(self.beta_pert())      # 0.01 on iteration 0, 1.0 afterwards (device-side coefficients)
+        if self._side_graph is not None:         # first: its wait kernel is parked before the main chain publishes
+            with torch.cuda.stream(self.branch.side):
+                self._side_graph.replay()
         self._graphs[0].replay()
         if len(self._graphs) == 2:
             if allreduce is not None:
@@ -677,6 +848,8 @@ class FusedStep:
     def losses(self):
         """OrderedDict of python floats (one device->host copy; the only sync of a step)."""
         v = self.arena.loss.detach().cpu().tolist()
+        if self._side_graph is not None:
+            self.check_sync()
         keys = ['RECL', 'KLD', 'PERT', 'YL', 'MMD', 'ELBO', 'CMPL']
         if self.cfg.kind == 'pvae':
             keys.remove('YL')

@@ -227,7 +227,9 @@ class FitMixin:
             if verbose and b % every == 0:
                 self._log_losses(epoch, b * batcher.batch_size, len(batcher.dataset), b / n_b, loss)
         self.finished_training_iters = eng.iters
-        return float(total) / n_b
+        mean = float(total) / n_b          # the epoch's one host sync
+        eng.check_sync()
+        return mean
 
     def _epoch_loader(self, loader, epoch, verbose):
         n_b = len(loader)

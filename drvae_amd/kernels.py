@@ -401,6 +401,14 @@ def adam_l2(p, g, m, v, step_dev, *, lr, beta1=0.9, beta2=0.999, eps=1e-8, weigh
                                       weight_decay, gscale, _i32(step_dev), _stream()), 'dv_adam_l2')
 
 
+def flag_publish(flag, ctr, add=1):
+    _lib.check(_lib.load().dv_flag_publish(_i32(flag), _i32(ctr), add, _stream()), 'dv_flag_publish')
+
+
+def flag_wait(flag, ctr, err, add=1, max_spins=400000):
+    _lib.check(_lib.load().dv_flag_wait(_i32(flag), _i32(ctr), add, _i32(err), max_spins, _stream()), 'dv_flag_wait')
+
+
 def counter_add(counter, inc=1):
     _lib.check(_lib.load().dv_counter_add(_i32(counter), counter.numel(), inc, _stream()), 'dv_counter_add')
 

@@ -339,6 +339,15 @@ int dv_adam_l2(float* p, const float* g, float* m, float* v, int64_t n, float lr
                float eps, float weight_decay, float gscale, const int32_t* step_dev, dv_stream_t stream);
 int dv_counter_add(int32_t* counter_lo_hi, int32_t n_words, int64_t inc, dv_stream_t stream);
 
+/* Device-side fork/join between two launch chains that run concurrently (two root branches of one
+ * hipGraph; no reference counterpart -- replaces graph edges, which cost ~27 us per fork+join on the
+ * ROCm executor): dv_flag_publish stores flag[0] = ctr[0] + add (release) after the kernels before it
+ * in its stream; dv_flag_wait parks ONE thread until flag[0] >= ctr[0] + add (acquire), so the kernels
+ * after it in ITS stream see the producer's results.  It never hangs: after max_spins polls (~0.1 us
+ * each) it sets err[0] = 1 and returns. */
+int dv_flag_publish(int32_t* flag, const int32_t* ctr, int32_t add, dv_stream_t stream);
+int dv_flag_wait(int32_t* flag, const int32_t* ctr, int32_t add, int32_t* err, int32_t max_spins, dv_stream_t stream);
+
 /* out[i] ~ N(0,1), Philox4x32-10 keyed by `seed`, counter = ctr_dev[0..1] (uint64 as two
  * int32 words, device) + i/4, Box-Muller on the four outputs.  (the `normal_()` draws of
  * src/blocks.py:172,210 and src/DrVAE.py:405,415 moved on device). */

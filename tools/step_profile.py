@@ -40,7 +40,7 @@ def main():
             return real[name](*a, **kw)
         return f
     for n in LEAF: setattr(K, n, mk(n))
-    eng.draw_noise(); eng.forward(); eng.backward(); eng.optimizer_step()
+    eng._launch_sequence()
     torch.cuda.synchronize()
     for n in LEAF: setattr(K, n, real[n])
     keep = arena.param.clone(), arena.exp_avg.clone(), arena.exp_avg_sq.clone()
