@@ -194,6 +194,8 @@ def main():
     import torch.distributed as dist
 
     cfg, eng, arena, batch, desc = build(args.workload, device, rank, world)
+    part = eng.partition()          # side chain on reserved CUs (dual-graph schedule); no-op otherwise
+    part.__enter__()
     kind, rows, L = WORKLOADS[args.workload][:3]
     D.broadcast_params(arena)
     allreduce = D.allreduce_sum if world > 1 else None
@@ -245,6 +247,8 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     losses = eng.losses()
+    part.__exit__(None, None, None)
+    waits = eng.sync_err.cpu().tolist() if hasattr(eng, 'sync_err') else None
     ok = all(np.isfinite(v) for v in losses.values())
 
     out = {
@@ -256,6 +260,7 @@ def main():
                    'parallelism': 'dp%d' % world, 'launch': 'hipGraph replay' if use_graph else 'eager', 'feed': args.feed,
                    'params': int(sum(int(np.prod(s)) for s in arena.shapes.values()))},
         'losses_last_step': {k: round(v, 4) for k, v in losses.items()}, 'finite': ok,
+        'chain_wait_ticks': waits,
     }
     if rank == 0:
         hx, hy = batch['has_x2'].astype(bool), batch['has_y'].astype(bool)

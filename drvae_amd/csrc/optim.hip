@@ -163,6 +163,7 @@ __global__ void flag_publish_kernel(int32_t* flag, const int32_t* ctr, int add) 
 __global__ void flag_wait_kernel(int32_t* flag, const int32_t* ctr, int add, int32_t* err, int max_spins) {
     if (threadIdx.x != 0) return;
     const int want = ctr[0] + add;
+    const long long t0 = wall_clock64();
     int n = 0;
     while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - want < 0) {
         __builtin_amdgcn_s_sleep(4);
@@ -171,6 +172,7 @@ __global__ void flag_wait_kernel(int32_t* flag, const int32_t* ctr, int add, int
             break;
         }
     }
+    err[1] += (int32_t)(wall_clock64() - t0);   // time parked, in constant-clock ticks (tuning statistic)
 }
 
 extern "C" int dv_flag_publish(int32_t* flag, const int32_t* ctr, int32_t add, dv_stream_t stream) {

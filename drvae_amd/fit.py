@@ -209,6 +209,10 @@ class FitMixin:
     def _epoch_device(self, batcher, epoch, verbose):
         """one epoch of hipGraph replays fed by the device batcher; returns the mean train objective"""
         eng = self.engine()
+        with eng.partition():
+            return self._epoch_device_body(eng, batcher, epoch, verbose)
+
+    def _epoch_device_body(self, eng, batcher, epoch, verbose):
         eng.add_noise = bool(self.add_noise)
         eng.iters = self.finished_training_iters
         batcher.bind(eng, counts=getattr(self, '_global_counts', None))

@@ -344,7 +344,7 @@ int dv_counter_add(int32_t* counter_lo_hi, int32_t n_words, int64_t inc, dv_stre
  * ROCm executor): dv_flag_publish stores flag[0] = ctr[0] + add (release) after the kernels before it
  * in its stream; dv_flag_wait parks ONE thread until flag[0] >= ctr[0] + add (acquire), so the kernels
  * after it in ITS stream see the producer's results.  It never hangs: after max_spins polls (~0.1 us
- * each) it sets err[0] = 1 and returns. */
+ * each) it sets err[0] = 1 and returns.  err[1] accumulates the time spent parked (wall_clock64 ticks). */
 int dv_flag_publish(int32_t* flag, const int32_t* ctr, int32_t add, dv_stream_t stream);
 int dv_flag_wait(int32_t* flag, const int32_t* ctr, int32_t add, int32_t* err, int32_t max_spins, dv_stream_t stream);
 
