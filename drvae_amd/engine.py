@@ -246,6 +246,15 @@ def _masked_stream(bits, device):
         rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), len(bits), arr)
     if rc != 0:
         raise RuntimeError('hipExtStreamCreateWithCUMask failed: %d' % rc)
+    import atexit
+
+    def _destroy(handle=st.value):       # before the HIP runtime tears down (profilers crash otherwise)
+        try:
+            torch.cuda.synchronize()
+            hip.hipStreamDestroy(ctypes.c_void_p(handle))
+        except Exception:
+            pass
+    atexit.register(_destroy)
     return torch.cuda.ExternalStream(st.value, device=device)
 
 
@@ -256,9 +265,7 @@ class _Branch:
 
     def __init__(self, device, enabled=True):
         self.on = enabled and torch.device(device).type == 'cuda'
-        # high priority: its own hardware queue (never the one of the launching stream), and its small
-        # kernels are dispatched ahead of the bulk GEMM workgroups of the main chain
-        self.side = torch.cuda.Stream(device=device, priority=-1) if self.on else None
+        self.side = torch.cuda.Stream(device=device) if self.on else None
 
     def fork(self):
         """mark the point of the current stream the side chain depends on; the chain itself may be
@@ -322,11 +329,14 @@ class FusedStep:
         #       and ordered ONLY by the device flags: no graph edges, no events
         self._rec = 'both'
         self._side_graph = None
+        self._flag_side = None
         self.side_ctr = torch.zeros(1, dtype=torch.int32, device=self.dev)   # the side chain's own step count
         self.flags = torch.zeros(3, dtype=torch.int32, device=self.dev)
         self.sync_err = torch.zeros(6, dtype=torch.int32, device=self.dev)   # (error, ticks parked) x 3 wait sites
         self.add_noise = True               # `fit(add_noise=...)` flag of the reference (src/DrVAE.py:769)
-        self.branch = _Branch(self.dev, enabled=concurrent)   # classifier/fprop chain || decoder chain
+        # classifier/fprop chain || decoder chain.  PVAE's side chain is one tiny KL kernel: a second stream
+        # costs it far more than it hides (measured 0.19 ms single-stream vs 0.9 ms forked), so it runs serial
+        self.branch = _Branch(self.dev, enabled=concurrent and cfg.has_y)
         self.wbranch = _Branch(self.dev, enabled=concurrent and os.environ.get('DRVAE_WBRANCH', '0') == '1')   # measured slower on MI355X (third graph branch): off
         self._build_layers()
 
@@ -784,9 +794,9 @@ class FusedStep:
             if dual:
                 self._rec = 'side'
                 self.side_ctr.copy_(self.step_dev)
-                self.branch.side.wait_stream(torch.cuda.current_stream())
+                self.flag_side.wait_stream(torch.cuda.current_stream())
                 gs = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gs, stream=self.branch.side):
+                with torch.cuda.graph(gs, stream=self.flag_side):
                     self.fuse_bwd = True
                     try:
                         self.forward()
@@ -812,7 +822,10 @@ class FusedStep:
         chain waits ~32 us per step at the join.  No-op when disabled (DRVAE_SIDE_CUS=0) or off-GPU."""
         import contextlib
         n_side = int(os.environ.get('DRVAE_SIDE_CUS', '64'))
-        if not (self.branch.on and n_side > 0 and self.sched == 5 and self.cfg.has_y):
+        # only for latency-bound steps: once the decoder products alone fill the chip many times over
+        # (wide configuration) the main chain needs every CU (measured: 52 ms -> 66 ms/step when masked)
+        small = self.plan is not None and self.plan.DPX.shape[0] * self.plan.DPX.shape[1] <= (4 << 20)
+        if not (self.branch.on and n_side > 0 and self.sched == 5 and self.cfg.has_y and small):
             return contextlib.nullcontext()
         if getattr(self, '_part', None) is None:
             n_cu = torch.cuda.get_device_properties(self.dev).multi_processor_count
@@ -831,7 +844,7 @@ class FusedStep:
                 warnings.warn('drvae_amd: CU partition unavailable (%s)' % e)
                 self._part = False
             if self._part:
-                self.branch.side = self._part[1]
+                self._flag_side = self._part[1]
                 self._flags_ok = None                # re-probe on the streams actually used
         if not self._part:
             return contextlib.nullcontext()
@@ -844,24 +857,45 @@ class FusedStep:
             with torch.cuda.stream(main):
                 yield self
             outer.wait_stream(main)
-            outer.wait_stream(self.branch.side)
+            outer.wait_stream(self.flag_side)
         return ctx()
 
+    @property
+    def flag_side(self):
+        """the stream the side-chain graph of the dual-graph schedule is launched on: CU-masked inside
+        ``partition()``, otherwise a plain stream that ``_flags_usable`` has verified to sit on a
+        different hardware queue than the launching stream."""
+        if self._flag_side is None:
+            self._flag_side = torch.cuda.Stream(device=self.dev)
+        return self._flag_side
+
+    def _probe(self, side):
+        """park a short wait on the launching stream, publish from ``side``: a timeout means the two
+        streams share a hardware queue (a parked wait kernel blocks everything behind it in its queue)"""
+        probe = torch.zeros(4, dtype=torch.int32, device=self.dev)      # flag, counter, error, ticks
+        torch.cuda.synchronize()
+        K.flag_wait(probe[0:1], probe[1:2], probe[2:4], add=1, max_spins=20000)
+        with torch.cuda.stream(side):
+            K.flag_publish(probe[0:1], probe[1:2], 1)
+        torch.cuda.synchronize()
+        return int(probe[2]) == 0
+
     def _flags_usable(self):
-        """Device-flag ordering needs the two streams on DIFFERENT hardware queues (a parked wait kernel
-        blocks everything behind it in its queue).  Probe it once: park a short wait on the launching
-        stream, publish from the side stream; a timeout means the queues coincide -> use graph edges."""
+        """Device-flag ordering needs the two streams on DIFFERENT hardware queues.  HIP multiplexes its
+        streams onto a few queues, so probe candidates until one qualifies (the CU-masked stream of
+        ``partition()`` has a queue of its own); otherwise fall back to graph edges.  (High-priority
+        streams are avoided on purpose: with one in the process, captured fork/joins ran 2.4x slower.)"""
         if getattr(self, '_flags_ok', None) is None:
-            probe = torch.zeros(4, dtype=torch.int32, device=self.dev)      # flag, counter, error, ticks
-            torch.cuda.synchronize()
-            K.flag_wait(probe[0:1], probe[1:2], probe[2:4], add=1, max_spins=20000)
-            with torch.cuda.stream(self.branch.side):
-                K.flag_publish(probe[0:1], probe[1:2], 1)
-            torch.cuda.synchronize()
-            self._flags_ok = int(probe[2]) == 0
-            if not self._flags_ok:
+            ok = self._probe(self.flag_side)
+            tries = 0
+            while not ok and not getattr(self, '_part', None) and tries < 8:
+                self._flag_side = torch.cuda.Stream(device=self.dev)
+                ok = self._probe(self._flag_side)
+                tries += 1
+            self._flags_ok = ok
+            if not ok:
                 import warnings
-                warnings.warn('drvae_amd: main and side stream share a hardware queue; falling back to graph edges')
+                warnings.warn('drvae_amd: no side stream on a hardware queue of its own; using graph edges')
         return self._flags_ok
 
     def check_sync(self):
@@ -897,7 +931,7 @@ class FusedStep:
         assert self._graph_feed is self.plan.feed, 'input feed changed: capture again'
         self.plan.set_beta(self.beta_pert())      # 0.01 on iteration 0, 1.0 afterwards (device-side coefficients)
         if self._side_graph is not None:         # first: its wait kernel is parked before the main chain publishes
-            with torch.cuda.stream(self.branch.side):
+            with torch.cuda.stream(self.flag_side):
                 self._side_graph.replay()
         self._graphs[0].replay()
         if len(self._graphs) == 2:

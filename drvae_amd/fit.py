@@ -209,13 +209,13 @@ class FitMixin:
     def _epoch_device(self, batcher, epoch, verbose):
         """one epoch of hipGraph replays fed by the device batcher; returns the mean train objective"""
         eng = self.engine()
+        batcher.bind(eng, counts=getattr(self, '_global_counts', None))
         with eng.partition():
             return self._epoch_device_body(eng, batcher, epoch, verbose)
 
     def _epoch_device_body(self, eng, batcher, epoch, verbose):
         eng.add_noise = bool(self.add_noise)
         eng.iters = self.finished_training_iters
-        batcher.bind(eng, counts=getattr(self, '_global_counts', None))
         batcher.begin_epoch()               # this epoch's index table; the graph gathers batch b itself
         if getattr(eng, '_graph_key', None) != eng.plan.key or getattr(eng, '_graph_noise', None) != eng.add_noise \
                 or getattr(eng, '_graph_feed', None) is not eng.plan.feed:

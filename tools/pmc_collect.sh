@@ -2,6 +2,9 @@
 # PMC passes over the cfg-2 bench (separate passes, counters only: no trace domains), per
 # MI355X_MICROARCH.md "rocprofv3 PMC slots".  Output: gpurun_out/pmc_r1/<pass>/...csv
 export TMPDIR=/tmp
+# counter collection serializes kernel dispatches: use the single-graph schedule (same kernels; a parked
+# device-side wait of the dual-graph schedule could only time out there)
+export DRVAE_SCHED=3 DRVAE_SIDE_CUS=0
 CMD="python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline"
 mkdir -p gpurun_out/pmc_r1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_r1/fetch -o p -- $CMD > gpurun_out/pmc_r1/fetch.log 2>&1

@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Per-kernel, per-step summary of the rocprofv3 --pmc passes written by tools/pmc_collect.sh."""
+import csv
+import gzip
+import sys
+from collections import defaultdict
+
+root = sys.argv[1] if len(sys.argv) > 1 else 'gpurun_out/pmc_r1'
+
+
+def load(sub):
+    acc = defaultdict(lambda: defaultdict(float))
+    calls = defaultdict(int)
+    steps = 0
+    with gzip.open('%s/%s/p_counter_collection.csv.gz' % (root, sub), 'rt') as fh:
+        seen = set()
+        for row in csv.DictReader(fh):
+            k = row['Kernel_Name'].replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0]
+            acc[k][row['Counter_Name']] += float(row['Counter_Value'])
+            key = (row['Dispatch_Id'])
+            if key not in seen:
+                seen.add(key)
+                calls[k] += 1
+                steps += 'fill_normal' in k
+    return acc, calls, max(steps, 1)
+
+
+fetch, calls, steps = load('fetch')
+write, _, s2 = load('write')
+sq, _, s3 = load('sq')
+tcc, _, s4 = load('tcc')
+print('# rocprofv3 --pmc passes (separate runs: FETCH_SIZE | WRITE_SIZE | 8 SQ counters | TCC_HIT/MISS) over')
+print('#   python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline     (tools/pmc_collect.sh;')
+print('#   single-graph schedule: counter collection serializes dispatches).  Per-STEP averages over %d steps.' % steps)
+print('# FETCH_SIZE/WRITE_SIZE in KB as reported; gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE counts')
+print('# 1/2 of the bytes of wide (16 B/lane) coalesced reads.')
+print('%-46s %6s %10s %10s %6s %8s %8s %8s %12s' % ('kernel', 'calls', 'FETCH_KB', 'WRITE_KB', 'L2hit', 'waitAny', 'waitInst',
+                                                   'active', 'mfmaBusyCyc'))
+tot_f = tot_w = gf = gw = gc = 0
+for k in sorted(fetch, key=lambda k: -fetch[k]['FETCH_SIZE']):
+    f, w = fetch[k]['FETCH_SIZE'] / steps, write[k]['WRITE_SIZE'] / s2
+    h, m = tcc[k]['TCC_HIT_sum'], tcc[k]['TCC_MISS_sum']
+    wc = max(sq[k]['SQ_WAVE_CYCLES'], 1)
+    print('%-46s %6.1f %10.0f %10.0f %6.2f %8.2f %8.2f %8.2f %12.0f' % (
+        k[:46], calls[k] / steps, f, w, h / max(h + m, 1), sq[k]['SQ_WAIT_ANY'] / wc, sq[k]['SQ_WAIT_INST_ANY'] / wc,
+        sq[k]['SQ_ACTIVE_INST_ANY'] / wc, sq[k]['SQ_VALU_MFMA_BUSY_CYCLES'] / s3))
+    tot_f += f
+    tot_w += w
+    if 'gemm' in k:
+        gf += f
+        gw += w
+        gc += calls[k] / steps
+print('# TOTAL per step: FETCH %.1f MB (reported; <= %.1f MB after the x2 wide-load correction), WRITE %.1f MB; '
+      'algorithmic ~94 MB (SURVEY 8(d))' % (tot_f / 1e3, 2 * tot_f / 1e3, tot_w / 1e3))
+print('# GEMM family per step: %.0f launches, FETCH %.1f MB reported -> %.1f MB corrected, WRITE %.1f MB => %.2f MB '
+      'HBM-side traffic per launch' % (gc, gf / 1e3, 2 * gf / 1e3, gw / 1e3, (2 * gf + gw) / 1e3 / max(gc, 1)))
+lds = sum(v.get('SQ_LDS_BANK_CONFLICT', 0) for v in sq.values())
+print('# SQ_LDS_BANK_CONFLICT summed over all kernels: %.0f' % lds)
