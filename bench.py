@@ -36,7 +36,7 @@ WORKLOADS = {
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak (dense, exact fp32)
 # HBM-side bytes per GEMM launch from the PMC passes (FETCH_SIZE x2 gfx950 wide-load correction +
 # WRITE_SIZE; rocprofv3 cannot run inside this process): profiles/r01_cfg2_pmc_summary.txt
-PMC_TRAFFIC_BYTES_PER_GEMM_LAUNCH = {'cfg2': 7.01e6}
+PMC_TRAFFIC_BYTES_PER_GEMM_LAUNCH = {'cfg2': 9.50e6}
 
 
 def build(workload, device, rank, world, seed=123):
