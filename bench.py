@@ -189,6 +189,7 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit('launch with torch.distributed.run --nproc-per-node %d' % args.gpus)
+    local = local % torch.cuda.device_count()        # (one-GPU functional tests of the multi-rank path)
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
     import torch.distributed as dist
@@ -219,7 +220,10 @@ def main():
         else:
             bat.feed()
     if use_graph:
-        eng.capture(split_for_allreduce=world > 1)
+        overlap = world > 1 and os.environ.get('DRVAE_DP_OVERLAP', '1') != '0'
+        eng.capture(split_for_allreduce=('overlap' if overlap else world > 1))
+        if overlap and len(eng._graphs) == 3:
+            allreduce = D.OverlappedAllReduce()      # decoder block travels while the encoder backward runs
         if args.feed == 'batcher':
             def step():
                 bat.feed()

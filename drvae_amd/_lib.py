@@ -94,6 +94,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch first: it brings its own HIP runtime, and this library must bind to THAT copy (loaded the
+    # other way round the process ends up with two runtimes and every launch fails)
+    import torch  # noqa: F401
     path = os.environ.get('DRVAE_HIP_LIB', LIB_PATH)      # tuning builds (tools/gemm_lab.sh)
     if not os.path.exists(path):
         raise RuntimeError(

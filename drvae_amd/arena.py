@@ -3,8 +3,8 @@ device buffer, with sibling buffers for gradients and the Adam moments.
 
 Why: (1) the optimiser is a single fused kernel over the arena (HBM-bound, 7 words per
 parameter) instead of ~30 tiny per-tensor updates; (2) the data-parallel gradient
-exchange is a single RCCL all-reduce of ``grad`` (+ the loss scalars parked at its
-tail); (3) the two heads of every Gaussian block are laid out back to back so that one
+exchange is an RCCL all-reduce of ``xchg`` = [loss scalars | gradients] (in two pieces when
+overlapped with backward); (3) the two heads of every Gaussian block are laid out back to back so that one
 GEMM with a split epilogue evaluates both.  Names, shapes and (out,in)
 row-major layout of the reference ``state_dict`` are preserved: the nn.Parameters
 simply alias the arena.
@@ -13,7 +13,7 @@ from collections import OrderedDict
 
 import torch
 
-N_LOSS = 8   # RECL KLD PERT YL MMD ELBO CMPL + 1 spare, parked behind the gradients
+N_LOSS = 8   # RECL KLD PERT YL MMD ELBO CMPL + 1 spare, parked in FRONT of the gradients
 
 _HEAD_PAIRS = (('encoder_mu.linear_mu', 'encoder_lv.linear_lv'),
                ('encoder_mu.linear_mu', 'encoder_sg.linear_sg'))
@@ -65,10 +65,21 @@ class ParamArena:
         PAD = 16    # tail slack: GEMM edge tiles may over-read a row end by up to 3 floats (dv_gemm_desc.flags)
         z = lambda n: torch.zeros(n + PAD, dtype=torch.float32, device=self.device)[:n]
         self.param = z(self.n_params)
-        self.grad = z(self.n_params + N_LOSS)              # [gradients | loss scalars]
+        # one exchange buffer [loss scalars | gradients]; the decoder_x block (the largest, and the first
+        # whose gradients are final in the backward pass) is the tail, so the data-parallel exchange can
+        # send it early: ``xchg[late_end:]`` while the rest of backward runs, ``xchg[:late_end]`` after
+        self.xchg = z(N_LOSS + self.n_params)
+        self.loss = self.xchg[:N_LOSS]
+        self.grad = self.xchg[N_LOSS:]
         self.exp_avg = z(self.n_params)
         self.exp_avg_sq = z(self.n_params)
-        self.loss = self.grad[self.n_params:]
+        early = [o for n, o in self.offsets.items() if n.startswith('decoder_x.')]
+        names = list(self.offsets)
+        first = min(early) if early else self.n_params
+        # valid only when decoder_x really is the tail of the arena
+        tail_ok = early and all(o >= first for n, o in self.offsets.items() if n.startswith('decoder_x.')) and \
+            all(o < first for n, o in self.offsets.items() if not n.startswith('decoder_x.'))
+        self.late_end = N_LOSS + (first if tail_ok else self.n_params)
 
     def numel(self, name):
         n = 1

@@ -330,6 +330,7 @@ class FusedStep:
         self._rec = 'both'
         self._side_graph = None
         self._flag_side = None
+        self._after_decoder_bwd = None
         self.side_ctr = torch.zeros(1, dtype=torch.int32, device=self.dev)   # the side chain's own step count
         self.flags = torch.zeros(3, dtype=torch.int32, device=self.dev)
         self.sync_err = torch.zeros(6, dtype=torch.int32, device=self.dev)   # (error, ticks parked) x 3 wait sites
@@ -666,6 +667,8 @@ class FusedStep:
                 self.branch.wait_main()      # the loss scalars need the main chain's NLL rows
             self.branch._forked = True       # the side chain simply continues: no new dependency
         p.c_decx.backward(p.DPX, [p.ZDEC], [[(p.DZDEC, 1.0, 0.0)]], wbranch=self.wbranch if self.wbranch.on else None)
+        if self._after_decoder_bwd is not None:
+            self._after_decoder_bwd()        # decoder_x gradients are final: graph split point of the overlapped exchange
         if mode != 5:
             with self.branch:
                 if not os.environ.get('DRVAE_SIDE_DUMMY'):
@@ -746,7 +749,7 @@ class FusedStep:
             self.forward()
             self.backward()
             if allreduce is not None:
-                allreduce(self.arena.grad)
+                allreduce(self.arena.xchg)
             self.optimizer_step()
             self._step_end()
         finally:
@@ -762,7 +765,7 @@ class FusedStep:
             self.forward()
             self.backward()
             if allreduce is not None:
-                allreduce(self.arena.grad)
+                allreduce(self.arena.xchg)
             self.optimizer_step()
             self._step_end()        # after Adam: the rejoin edge stays off the critical path
         finally:
@@ -904,7 +907,35 @@ class FusedStep:
             raise RuntimeError('drvae_amd: a device-side chain wait timed out (main / side stream ordering)')
 
     def _capture_main(self, split_for_allreduce):
-        if split_for_allreduce:
+        if split_for_allreduce == 'overlap' and self.arena.late_end < self.arena.xchg.numel():
+            # three graphs: [noise .. decoder backward] | [rest of backward] | [Adam]; the exchange of the
+            # decoder block is launched between the first two and travels while the second runs
+            ga, gb, gc = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            cap = torch.cuda.Stream(device=self.dev)
+            cap.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(cap):
+                def split():
+                    ga.capture_end()
+                    gb.capture_begin()
+                self._after_decoder_bwd = split
+                self.fuse_bwd = True
+                try:
+                    ga.capture_begin()
+                    self._step_begin()
+                    self.draw_noise()
+                    self.forward()
+                    self.backward()
+                    self._step_end()
+                    gb.capture_end()
+                finally:
+                    self.fuse_bwd = False
+                    self._after_decoder_bwd = None
+                gc.capture_begin()
+                self.optimizer_step()
+                gc.capture_end()
+            torch.cuda.current_stream().wait_stream(cap)
+            self._graphs = [ga, gb, gc]
+        elif split_for_allreduce:
             g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             with torch.cuda.graph(g1):
                 self.fuse_bwd = True
@@ -934,9 +965,17 @@ class FusedStep:
             with torch.cuda.stream(self.flag_side):
                 self._side_graph.replay()
         self._graphs[0].replay()
-        if len(self._graphs) == 2:
+        if len(self._graphs) == 3:               # overlapped exchange: ``allreduce`` has start()/finish()
+            a = self.arena
+            w_early = allreduce.start(a.xchg[a.late_end:])
+            self._graphs[1].replay()
+            w_late = allreduce.start(a.xchg[:a.late_end])
+            allreduce.finish(w_early)
+            allreduce.finish(w_late)
+            self._graphs[2].replay()
+        elif len(self._graphs) == 2:
             if allreduce is not None:
-                allreduce(self.arena.grad)
+                allreduce(self.arena.xchg)
             self._graphs[1].replay()
         self.iters += 1
 

@@ -40,7 +40,7 @@ def _run_steps(spec, params, batch, noises, counts, allreduce, lo=None, hi=None)
     for noise in noises:
         eng.train_step(noise, allreduce=allreduce)
         out.append(arena.loss.clone().numpy())
-    return np.stack(out), arena.param.clone().numpy(), arena.grad[:arena.n_params].clone().numpy()
+    return np.stack(out), arena.param.clone().numpy(), arena.grad.clone().numpy()
 
 
 def _worker(rank, world, port, kind, q):

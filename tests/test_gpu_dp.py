@@ -1,0 +1,76 @@
+"""-m gpu: the multi-rank train step on real kernels.  Two ranks share the one GPU of the test box and
+exchange through gloo (RCCL refuses two ranks on one device), which exercises everything but the
+transport: global-count normalisation, the graph split around the exchange, the two-piece overlapped
+all-reduce (decoder block early, the rest + loss scalars late) and replica consistency."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, q):
+    try:
+        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                          LOCAL_RANK='0')
+        import torch.distributed as dist
+        from drvae_amd import dist as D
+        from oracle import models_ref as M
+        from tests.test_engine_cpu import make_engine, set_batch
+        D.init_from_env(backend='gloo')
+        dev = torch.device('cuda', 0)
+        torch.cuda.set_device(0)
+        spec = M.ModelSpec(kind='drvae', L=2)
+        params = M.init_params(spec, 3, as_numpy=True)
+        full = M.make_batch(spec, 96, seed=5)
+        lo, hi = D.shard_rows(96, rank, world)
+        batch = {k: v[lo:hi] for k, v in full.items()}
+        counts = D.global_counts(batch['has_x2'], batch['has_y'])
+        assert counts[0] == 96
+        res = {}
+        for mode in ('overlap', 'split', 'eager'):
+            eng, arena = make_engine(spec, params, dev)
+            eng.seed = 77 + rank
+            set_batch(eng, batch, dev, counts=counts)
+            eng.train_step(allreduce=D.allreduce_sum)
+            if mode == 'eager':
+                eng.draw_noise()                      # capture() spends one Philox draw on its warm-up
+                for _ in range(3):
+                    eng.train_step(allreduce=D.allreduce_sum)
+            else:
+                eng.capture(split_for_allreduce=mode if mode == 'overlap' else True)
+                assert len(eng._graphs) == (3 if mode == 'overlap' else 2)
+                ar = D.OverlappedAllReduce() if mode == 'overlap' else D.allreduce_sum
+                for _ in range(3):
+                    eng.replay(ar)
+            torch.cuda.synchronize()
+            eng.check_sync()
+            res[mode] = (arena.param.clone().cpu(), arena.loss.clone().cpu())
+        same = all(torch.equal(res['eager'][i], res[m][i]) for m in ('overlap', 'split') for i in (0, 1))
+        # replicas agree: compare rank 0's parameters with this rank's
+        ref = res['overlap'][0].clone().to(dev)
+        dist.broadcast(ref, src=0)
+        replicas = torch.equal(ref.cpu(), res['overlap'][0])
+        q.put((rank, bool(same), bool(replicas), bool(torch.isfinite(res['overlap'][1]).all())))
+        dist.destroy_process_group()
+    except Exception as e:       # surface the failure instead of a hung join
+        import traceback
+        q.put((rank, 'error', traceback.format_exc(), str(e)))
+
+
+def test_two_rank_overlapped_exchange_matches_eager(dev):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29700 + os.getpid() % 200
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for o in out:
+        assert o[1] != 'error', o[2]
+        assert o[1] and o[2] and o[3], o
