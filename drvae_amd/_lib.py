@@ -24,7 +24,8 @@ class GemmDesc(C.Structure):
                 ('B', _p), ('ldb', _i64), ('C', _p), ('ldc', _i64), ('alpha', _f), ('beta', _f),
                 ('epilogue', _i32), ('scale', _p), ('bias', _p), ('split', _i32), ('act0', _i32), ('act1', _i32),
                 ('shift0', _f), ('shift1', _f), ('resid', _p), ('ldr', _i64), ('resid_cols', _i32),
-                ('yref', _p), ('ldy', _i64), ('a_colsum', _p), ('colsum_beta', _f), ('flags', _i32)]
+                ('yref', _p), ('ldy', _i64), ('a_colsum', _p), ('colsum_beta', _f), ('flags', _i32),
+                ('pub_flag', _p), ('pub_ctr', _p), ('pub_add', _i32)]
 
 
 class LossTerm(C.Structure):
@@ -78,6 +79,7 @@ SIGNATURES = {
     'dv_recon_row_stats': [_p, _i64, _p, _i64, _i32, _i32, _p, _p],
     'dv_col_moments': [_p, _i64, _p, _i64, _i32, _i32, _p, _p],
     'dv_loss_assemble': [C.POINTER(LossTerm), _i32, _p, _p, _p, _p],
+    'dv_loss_assemble_after': [_p, _p, _i32, _p, _i32, C.POINTER(LossTerm), _i32, _p, _p, _p, _p],
     'dv_axpby': [_p, _f, _p, _f, _i64, _p],
     'dv_adam_l2': [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _f, _p, _p],
     'dv_flag_publish': [_p, _p, _i32, _p],

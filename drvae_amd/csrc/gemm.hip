@@ -584,9 +584,17 @@ __device__ __forceinline__ void gemm_body(const dv_gemm_desc& g, const LoadCfg& 
     }
 }
 
+// this launch started => everything before it in its stream is complete: a free place to tell another
+// launch chain so (see dv_flag_publish)
+__device__ __forceinline__ void publish_on_entry(const dv_gemm_desc& g) {
+    if (g.pub_flag != nullptr && blockIdx.x == 0 && threadIdx.x == 0)
+        __hip_atomic_store(g.pub_flag, g.pub_ctr[0] + g.pub_add, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 template <int BM, int BN, int BK, int WM, int WN, int KS, bool AKC, bool BKC>
 __global__ __launch_bounds__(64 * WM * WN * KS) void gemm_kernel(const dv_gemm_desc g, const LoadCfg lc) {
     __shared__ __attribute__((aligned(16))) float smem[gemm_smem_floats<BM, BN, BK, KS, AKC, BKC>()];
+    publish_on_entry(g);
     gemm_body<BM, BN, BK, WM, WN, KS, AKC, BKC>(g, lc, smem, blockIdx.x, gridDim.x);
 }
 
@@ -598,6 +606,7 @@ __global__ __launch_bounds__(256) void gemm_pair_kernel(const dv_gemm_desc g1, c
                                                         const LoadCfg lc2, int tiles1) {
     constexpr int S1 = gemm_smem_floats<BM, BN, BK, KS, A1, B1>(), S2 = gemm_smem_floats<BM, BN, BK, KS, A2, B2>();
     __shared__ __attribute__((aligned(16))) float smem[S1 > S2 ? S1 : S2];
+    publish_on_entry(g1);
     if ((int)blockIdx.x < tiles1)
         gemm_body<BM, BN, BK, WM, WN, KS, A1, B1>(g1, lc1, smem, blockIdx.x, tiles1);
     else
@@ -663,6 +672,7 @@ static int gemm_prepare(const dv_gemm_desc* d, LoadCfg& lc, int& tiling) {
     DV_REQUIRE(g.a_kscale == nullptr || g.a_kcontig);
     DV_REQUIRE(g.a_colsum == nullptr || !g.a_kcontig);
     DV_REQUIRE(!( !g.a_kcontig && g.b_kcontig));
+    DV_REQUIRE(g.pub_flag == nullptr || g.pub_ctr != nullptr);
     lc.vecA = vec_width(g.A, g.lda);
     if (g.A2) {
         const int v2 = vec_width(g.A2, g.lda2);

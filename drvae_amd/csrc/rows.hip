@@ -920,9 +920,27 @@ struct LossTerms {
 // per term, then ELBO = <w_elbo, loss[0:3]>, CMPL = <w_cmpl, loss[0:8]>  (src/DrVAE.py:611-624)
 __global__ __launch_bounds__(256) void loss_assemble_kernel(LossTerms lt, const float* __restrict__ w_elbo,
                                                             const float* __restrict__ w_cmpl,
-                                                            float* __restrict__ loss) {
+                                                            float* __restrict__ loss, int32_t* flag,
+                                                            const int32_t* ctr, int add, int32_t* err, int max_spins) {
     __shared__ float part[4];
     __shared__ float acc[8];
+    if (flag != nullptr) {      // park until the other launch chain has published its results
+        if (threadIdx.x == 0) {
+            const int want = ctr[0] + add;
+            const long long t0 = wall_clock64();
+            int n = 0;
+            while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - want < 0) {
+                __builtin_amdgcn_s_sleep(4);
+                if (++n > max_spins) {
+                    atomicExch(err, 1);
+                    break;
+                }
+            }
+            err[1] += (int32_t)(wall_clock64() - t0);
+        }
+        __syncthreads();
+        (void)__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);   // every wave acquires
+    }
     if (threadIdx.x < 8) acc[threadIdx.x] = 0.f;
     __syncthreads();
     for (int k = 0; k < lt.n; ++k) {
@@ -1343,7 +1361,24 @@ extern "C" int dv_loss_assemble(const dv_loss_term* terms, int32_t n_terms, cons
         DV_REQUIRE(terms[i].out >= 0 && terms[i].out < 5 && terms[i].n >= 0 && (terms[i].x || terms[i].n == 0));
         lt.t[i] = terms[i];
     }
-    hipLaunchKernelGGL(loss_assemble_kernel, dim3(1), dim3(256), 0, ST(stream), lt, w_elbo, w_cmpl, loss);
+    hipLaunchKernelGGL(loss_assemble_kernel, dim3(1), dim3(256), 0, ST(stream), lt, w_elbo, w_cmpl, loss,
+                       (int32_t*)nullptr, (const int32_t*)nullptr, 0, (int32_t*)nullptr, 0);
+    DV_RETURN_LAUNCH();
+}
+
+extern "C" int dv_loss_assemble_after(int32_t* flag, const int32_t* ctr, int32_t add, int32_t* err, int32_t max_spins,
+                                      const dv_loss_term* terms, int32_t n_terms, const float* w_elbo,
+                                      const float* w_cmpl, float* loss, dv_stream_t stream) {
+    DV_REQUIRE(n_terms >= 0 && n_terms <= DV_MAX_LOSS_TERMS && (terms || n_terms == 0));
+    DV_REQUIRE(w_elbo && w_cmpl && loss && flag && ctr && err && max_spins > 0);
+    LossTerms lt;
+    lt.n = n_terms;
+    for (int i = 0; i < n_terms; ++i) {
+        DV_REQUIRE(terms[i].out >= 0 && terms[i].out <= 4 && terms[i].n >= 0 && (terms[i].x || terms[i].n == 0));
+        lt.t[i] = terms[i];
+    }
+    hipLaunchKernelGGL(loss_assemble_kernel, dim3(1), dim3(256), 0, ST(stream), lt, w_elbo, w_cmpl, loss, flag, ctr,
+                       add, err, max_spins);
     DV_RETURN_LAUNCH();
 }
 

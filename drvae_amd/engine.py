@@ -166,7 +166,8 @@ class _Chain:
         # gradient w.r.t. the pre-activation of every layer but the last (the caller owns that one)
         self.dpre = [torch.zeros(M, _pad4(l.N), device=device)[:, :l.N] for l in layers[:-1]]
 
-    def forward(self, inputs, resid=None):
+    def forward(self, inputs, resid=None, publish=None):
+        """``publish`` = (flag, counter, add): the FIRST launch of the chain publishes on entry"""
         x = list(inputs)
         for li, l in enumerate(self.layers):
             if l.g is not None:
@@ -175,7 +176,7 @@ class _Chain:
             K.linear_fwd(self.out[li], x[0], l.W, l.b, x2=x[1] if len(x) > 1 else None, scale=l.scale, split=l.split,
                          act0=l.act0, act1=l.act1, shift0=l.shift0, shift1=l.shift1,
                          resid=resid if last else None, resid_cols=self.resid_cols if (last and resid is not None) else 0,
-                         overread=True)
+                         overread=True, publish=publish if (li == 0 and l.g is None) else None)
             x = [self.out[li]]
         return self.out[-1]
 
@@ -489,10 +490,11 @@ class FusedStep:
             # q(z1|x1), not q(z2|x2) (quirk 1, src/DrVAE.py:427) -- in one launch
             Z1blk = p.ZDEC[:L * B]
             K.reparam_fwd(p.ZDEC[:p.o3], Qmu, Qlv, p.E12, src_idx=p.z_src_idx)
-            if rec == 'main' and cfg.has_pert:
-                K.flag_publish(self.flags[0:1], self.step_dev)       # lets the side chain's fprop start early
             if cfg.has_pert:
-                P2 = p.c_z2F.forward([Z1blk], resid=Z1blk)
+                # (dual-graph schedule) entry of this launch = the z1 samples are final: lets the side
+                # chain's fprop start before the perturbation function has run
+                P2 = p.c_z2F.forward([Z1blk], resid=Z1blk,
+                                     publish=(self.flags[0:1], self.step_dev, 1) if rec == 'main' else None)
                 # z2Fz1 sample, the classifier input z2Fz1 - z1, and the decoder's copy for the pairs
                 K.reparam_fwd(p.Z2F, P2[:, :Z1], P2[:, Z1:], p.E2F, sub=Z1blk, out2=p.D,
                               out3=p.ZDEC if Np else None, out3_idx=p.pert_out_idx if Np else None)
@@ -542,14 +544,19 @@ class FusedStep:
                 if not os.environ.get('DRVAE_SIDE_DUMMY'):
                     side_forward((lambda: K.flag_wait(self.flags[2:3], self.side_ctr, self.sync_err[4:6])) if two else None)
                 return
-            K.flag_publish(self.flags[2:3] if two else self.flags[0:1], self.step_dev)
+            pub = (self.flags[2:3] if two else self.flags[0:1], self.step_dev, 1)
+            if self.L_decx[0].g is not None:             # WeightNorm: the chain's first launch is not the GEMM
+                K.flag_publish(pub[0], pub[1], 1)
+                pub = None
         elif mode == 4:
             K.flag_publish(self.flags[0:1], self.step_dev)
         else:
             self.branch.fork()
+        if mode != 5:
+            pub = None
         # ---- p(x|z): decoder over all stacked samples, then the NLL over genes
         X = cfg.dim_x
-        PX = p.c_decx.forward([p.ZDEC])
+        PX = p.c_decx.forward([p.ZDEC], publish=pub if mode == 5 else None)
         if self.fuse_bwd:      # train step: d/d(mu, pre-softplus) emitted in the same row pass
             K.nll_rows_fwdbwd(p.NLL, p.DPX[:, :X], p.DPX[:, X:], p.c_nll, p.XIN, PX[:, :X], PX[:, X:], mode=GAUSS_SIGMA,
                               xidx=p.tgt, sd_act='softplus', sd_shift=1e-3)
@@ -573,7 +580,7 @@ class FusedStep:
             return             # the loss scalars are assembled on the side chain of backward()
         self._loss_scalars()
 
-    def _loss_scalars(self):
+    def _loss_scalars(self, after=None):
         """RECL, KLD, PERT, YL, ELBO, CMPL (src/DrVAE.py:611-624) as device scalars."""
         cfg, p = self.cfg, self.plan
         L = cfg.L
@@ -586,7 +593,7 @@ class FusedStep:
         if cfg.has_y:
             terms.append((p.KLDrow, None, 1.0 / (L * p.n_tot), 1))
             terms.append((p.YLrow, None, 1.0 / (L * max(1., p.n_lab)), 3))
-        K.loss_assemble(self.arena.loss, terms, p.w_elbo, p.w_cmpl)
+        K.loss_assemble(self.arena.loss, terms, p.w_elbo, p.w_cmpl, after=after)
 
     # --------------------------------------------------------------------- backward
     def backward(self):
@@ -677,11 +684,13 @@ class FusedStep:
                     self._loss_scalars()
                 if mode == 4:
                     K.flag_publish(self.flags[1:2], self.step_dev)   # DZ1B / DZ2F / side gradients are final
-        if mode >= 4:
+        if mode == 4:
             K.flag_wait(self.flags[1:2], self.step_dev, self.sync_err[0:2])
-        else:
+        elif mode < 4:
             self.branch.join()
-        if mode >= 3:
+        if mode == 5:      # the launch that assembles the loss scalars also parks on the side chain's flag
+            self._loss_scalars(after=(self.flags[1:2], self.step_dev, self.sync_err[0:2], 1, 400000))
+        elif mode >= 3:
             self._loss_scalars()
         if cfg.has_pert:
             if not cfg.has_y:

@@ -52,7 +52,7 @@ def _act(a):
 # ------------------------------------------------------------------------------ GEMM
 def _gemm_desc(Cm, A, B, a_kc, b_kc, *, A2=None, a_kscale=None, alpha=1.0, beta=0.0, epi=EPI_PLAIN, scale=None,
                bias=None, split=None, act0=0, act1=0, shift0=0.0, shift1=0.0, resid=None, resid_cols=0, yref=None,
-               a_colsum=None, colsum_beta=0.0, overread=False):
+               a_colsum=None, colsum_beta=0.0, overread=False, publish=None):
     M, N = Cm.shape
     if a_kc:
         K = A.shape[1] + (A2.shape[1] if A2 is not None else 0)
@@ -79,6 +79,8 @@ def _gemm_desc(Cm, A, B, a_kc, b_kc, *, A2=None, a_kscale=None, alpha=1.0, beta=
     d.yref, d.ldy = _f32(yref, 'yref'), _ld(yref)
     d.a_colsum, d.colsum_beta = _f32(a_colsum, 'a_colsum'), colsum_beta
     d.flags = 3 if overread else 0
+    if publish is not None:                 # (flag, counter, add): publish on kernel entry, see dv_flag_publish
+        d.pub_flag, d.pub_ctr, d.pub_add = _i32(publish[0]), _i32(publish[1]), publish[2]
     return d
 
 
@@ -103,10 +105,10 @@ def linear_bwd_pair(dW, dbias, dx, dpre, x, W, *, kscale=None, alpha=1.0, beta_x
 
 
 def linear_fwd(out, x, W, bias=None, *, x2=None, scale=None, split=None, act0=0, act1=0, shift0=0.0, shift1=0.0,
-               resid=None, resid_cols=0, overread=False):
+               resid=None, resid_cols=0, overread=False, publish=None):
     """out = act([x|x2] W^T * scale + bias) + shift (+ resid) -- one Linear (or two heads) forward."""
     gemm(out, x, W, True, True, A2=x2, epi=EPI_FWD, scale=scale, bias=bias, split=split, act0=act0, act1=act1,
-         shift0=shift0, shift1=shift1, resid=resid, resid_cols=resid_cols, overread=overread)
+         shift0=shift0, shift1=shift1, resid=resid, resid_cols=resid_cols, overread=overread, publish=publish)
 
 
 def linear_bwd_data(dx, dpre, W, *, kscale=None, alpha=1.0, beta=0.0, yref=None, act=0, shift=0.0, overread=False):
@@ -380,13 +382,20 @@ def col_moments(out, x, r):
                'dv_col_moments')
 
 
-def loss_assemble(loss, terms, w_elbo, w_cmpl):
-    """terms: list of (x, w_or_None, scale, out_index); see ``dv_loss_assemble``."""
+def loss_assemble(loss, terms, w_elbo, w_cmpl, after=None):
+    """terms: list of (x, w_or_None, scale, out_index); see ``dv_loss_assemble``.  ``after`` =
+    (flag, counter, err, add, max_spins): park like ``flag_wait`` inside the same launch first."""
     arr = (_lib.LossTerm * max(len(terms), 1))()
     for i, (x, w, scale, out) in enumerate(terms):
         arr[i].x, arr[i].w, arr[i].n, arr[i].scale, arr[i].out = _f32(x), _f32(w), x.numel(), scale, out
-    _lib.check(_lib.load().dv_loss_assemble(arr, len(terms), _f32(w_elbo), _f32(w_cmpl), _f32(loss), _stream()),
-               'dv_loss_assemble')
+    if after is None:
+        _lib.check(_lib.load().dv_loss_assemble(arr, len(terms), _f32(w_elbo), _f32(w_cmpl), _f32(loss), _stream()),
+                   'dv_loss_assemble')
+    else:
+        flag, ctr, err, add, spins = after
+        _lib.check(_lib.load().dv_loss_assemble_after(_i32(flag), _i32(ctr), add, _i32(err), spins, arr, len(terms),
+                                                      _f32(w_elbo), _f32(w_cmpl), _f32(loss), _stream()),
+                   'dv_loss_assemble_after')
 
 
 def axpby(y, x, a=1.0, b=0.0):

@@ -106,6 +106,11 @@ typedef struct dv_gemm_desc {
      * Lets edge tiles of row-contiguous operands use aligned 16-B loads (the over-read values
      * only feed output elements that are never stored).  0 = never over-read (default). */
     int32_t flags;
+    /* optional: on kernel ENTRY (i.e. once everything before this launch in its stream is complete)
+     * publish pub_flag[0] = pub_ctr[0] + pub_add like dv_flag_publish -- saves the separate launch. */
+    int32_t* pub_flag;
+    const int32_t* pub_ctr;
+    int32_t pub_add;
 } dv_gemm_desc;
 
 int dv_gemm(const dv_gemm_desc* desc, dv_stream_t stream);
@@ -326,6 +331,11 @@ typedef struct dv_loss_term {
 } dv_loss_term;
 int dv_loss_assemble(const dv_loss_term* terms, int32_t n_terms, const float* w_elbo, const float* w_cmpl,
                      float* loss, dv_stream_t stream);
+/* same, but first parks like dv_flag_wait(flag, ctr, add, err, max_spins) inside the launch (the terms
+ * of another chain are read only after the wait; saves the separate wait launch) */
+int dv_loss_assemble_after(int32_t* flag, const int32_t* ctr, int32_t add, int32_t* err, int32_t max_spins,
+                           const dv_loss_term* terms, int32_t n_terms, const float* w_elbo, const float* w_cmpl,
+                           float* loss, dv_stream_t stream);
 /* y[i] = a*x[i] + b*y[i] over n contiguous floats */
 int dv_axpby(const float* x, float a, float* y, float b, int64_t n, dv_stream_t stream);
 

@@ -88,7 +88,9 @@ def _seg(N, split, a0, a1, v0, v1, dev):
 
 def gemm(Cm, A, B, a_kc, b_kc, *, A2=None, a_kscale=None, alpha=1.0, beta=0.0, epi=EPI_PLAIN, scale=None,
          bias=None, split=None, act0=0, act1=0, shift0=0.0, shift1=0.0, resid=None, resid_cols=0, yref=None,
-         a_colsum=None, colsum_beta=0.0, overread=False):
+         a_colsum=None, colsum_beta=0.0, overread=False, publish=None):
+    if publish is not None:
+        flag_publish(publish[0], publish[1], publish[2])
     M, N = Cm.shape
     Aop = (torch.cat([A, A2], 1) if A2 is not None else A) if a_kc else A.t()
     if a_kscale is not None:
@@ -114,9 +116,9 @@ def gemm(Cm, A, B, a_kc, b_kc, *, A2=None, a_kscale=None, alpha=1.0, beta=0.0, e
 
 
 def linear_fwd(out, x, W, bias=None, *, x2=None, scale=None, split=None, act0=0, act1=0, shift0=0.0, shift1=0.0,
-               resid=None, resid_cols=0, overread=False):
+               resid=None, resid_cols=0, overread=False, publish=None):
     gemm(out, x, W, True, True, A2=x2, epi=EPI_FWD, scale=scale, bias=bias, split=split, act0=act0, act1=act1,
-         shift0=shift0, shift1=shift1, resid=resid, resid_cols=resid_cols)
+         shift0=shift0, shift1=shift1, resid=resid, resid_cols=resid_cols, publish=publish)
 
 
 def linear_bwd_data(dx, dpre, W, *, kscale=None, alpha=1.0, beta=0.0, yref=None, act=0, shift=0.0, overread=False):
@@ -515,7 +517,9 @@ def col_moments(out, x, r):
     out.copy_(torch.stack([xd.sum(0), (xd * xd).sum(0), ((xd - rd) ** 2).sum(0)], 0))
 
 
-def loss_assemble(loss, terms, w_elbo, w_cmpl):
+def loss_assemble(loss, terms, w_elbo, w_cmpl, after=None):
+    if after is not None:
+        flag_wait(after[0], after[1], after[2], after[3], after[4])
     acc = torch.zeros(8, device=loss.device)
     for (x, w, scale, out) in terms:
         v = x.reshape(-1)
