@@ -592,7 +592,7 @@ __device__ __forceinline__ void publish_on_entry(const dv_gemm_desc& g) {
 }
 
 template <int BM, int BN, int BK, int WM, int WN, int KS, bool AKC, bool BKC>
-__global__ __launch_bounds__(64 * WM * WN * KS) void gemm_kernel(const dv_gemm_desc g, const LoadCfg lc) {
+__global__ __launch_bounds__(64 * WM * WN * KS, (BM >= 128 || BK >= 128) ? 2 : (WM * WN * KS == 8 ? 2 : 4)) void gemm_kernel(const dv_gemm_desc g, const LoadCfg lc) {
     __shared__ __attribute__((aligned(16))) float smem[gemm_smem_floats<BM, BN, BK, KS, AKC, BKC>()];
     publish_on_entry(g);
     gemm_body<BM, BN, BK, WM, WN, KS, AKC, BKC>(g, lc, smem, blockIdx.x, gridDim.x);
@@ -602,7 +602,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void gemm_kernel(const dv_gemm_d
 // second): the weight-gradient dW = dy^T x and the data-gradient dx = dy W of a layer both only
 // need dy, so they share a launch slot instead of paying the per-launch latency chain twice.
 template <int BM, int BN, int BK, int WM, int WN, int KS, bool A1, bool B1, bool A2, bool B2>
-__global__ __launch_bounds__(256) void gemm_pair_kernel(const dv_gemm_desc g1, const LoadCfg lc1, const dv_gemm_desc g2,
+__global__ __launch_bounds__(256, 4) void gemm_pair_kernel(const dv_gemm_desc g1, const LoadCfg lc1, const dv_gemm_desc g2,
                                                         const LoadCfg lc2, int tiles1) {
     constexpr int S1 = gemm_smem_floats<BM, BN, BK, KS, A1, B1>(), S2 = gemm_smem_floats<BM, BN, BK, KS, A2, B2>();
     __shared__ __attribute__((aligned(16))) float smem[S1 > S2 ? S1 : S2];
