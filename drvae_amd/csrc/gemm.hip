@@ -32,6 +32,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef DV_LOOP
 #define DV_LOOP 0
 #endif
+#ifndef DV_STAGGER
+#define DV_STAGGER 0
+#endif
 
 namespace {
 
@@ -595,6 +598,14 @@ template <int BM, int BN, int BK, int WM, int WN, int KS, bool AKC, bool BKC>
 __global__ __launch_bounds__(64 * WM * WN * KS, (BM >= 128 || BK >= 128) ? 2 : (WM * WN * KS == 8 ? 2 : 4)) void gemm_kernel(const dv_gemm_desc g, const LoadCfg lc) {
     __shared__ __attribute__((aligned(16))) float smem[gemm_smem_floats<BM, BN, BK, KS, AKC, BKC>()];
     publish_on_entry(g);
+#if DV_STAGGER
+    {   // tuning: de-phase the workgroups that share a CU (dispatch is round-robin over the CUs)
+        const int ph = (blockIdx.x / DV_STAGGER) & 3;
+        if (ph == 1) __builtin_amdgcn_s_sleep(6);
+        if (ph == 2) __builtin_amdgcn_s_sleep(12);
+        if (ph == 3) __builtin_amdgcn_s_sleep(18);
+    }
+#endif
     gemm_body<BM, BN, BK, WM, WN, KS, AKC, BKC>(g, lc, smem, blockIdx.x, gridDim.x);
 }
 
@@ -703,6 +714,8 @@ static int gemm_launch(const dv_gemm_desc& g, const LoadCfg& lc, int tiling, hip
     if (tiling == 3) return launch_cfg<128, 128, 32, 2, 2, 1>(g, lc, st);
     if (tiling == 4) return launch_cfg<32, 32, 128, 1, 1, 4>(g, lc, st);
     if (tiling == 5) return launch_cfg<64, 64, 64, 2, 2, 2>(g, lc, st);   // 8 waves: 2 per SIMD
+    if (tiling == 6) return launch_cfg<64, 32, 64, 2, 1, 2>(g, lc, st);   // 2 row blocks x 2-way K split
+    if (tiling == 7) return launch_cfg<32, 64, 64, 1, 2, 2>(g, lc, st);   // 2 column blocks x 2-way K split
     if (tiling == 1) return launch_cfg<64, 64, 32, 2, 2, 1>(g, lc, st);
     return launch_cfg<32, 32, 64, 1, 1, 4>(g, lc, st);
 }

@@ -457,8 +457,55 @@ def run_fit_cases():
     return out
 
 
+# ------------------------------------------------------------------ inference (N1)
+INFER_CASES = ('tiny_drvae', 'tiny_drvae_nolp', 'tiny_drvae_wn', 'tiny_pvae', 'tiny_vfae', 'cfg2_drvae', 'cfg4_vfae')
+
+
+def _flat(res):
+    out = {}
+    for k, v in res.items():
+        if isinstance(v, (tuple, list)):
+            for i, t in enumerate(v):
+                out['%s.%d' % (k, i)] = t.detach().numpy().copy()
+        else:
+            out[k] = v.detach().numpy().copy()
+    return out
+
+
+def run_inference_cases():
+    """the reference's means-only inference passes: ``forward`` (DrVAE.py:253-311, PVAE.py:203-246,
+    VFAE.py:178-215) and ``forward_w_pert_identity`` (DrVAE.py:185-251, PVAE.py:155-201)"""
+    out = {}
+    for name in INFER_CASES:
+        case = C.model_case(name)
+        spec = case['spec']
+        model = build_reference_model(spec, M.init_params(spec, case['param_seed'], as_numpy=True))
+        model.eval()
+        b = case['batch']
+        x1, x2 = torch.from_numpy(b['x1'].copy()), torch.from_numpy(b['x2'].copy())
+        s = torch.from_numpy(b['s'].copy())
+        with torch.no_grad():
+            res = _flat(model.forward(x1, s))
+            res2 = _flat(model.forward_w_pert_identity(x1, x2, s)) if spec.kind != 'vfae' else {}
+        full = case['full']
+        for tag, r in (('fwd', res), ('ident', res2)):
+            for k, v in r.items():
+                if full or v.ndim == 1 or v.shape[1] <= 4:
+                    out['%s/%s/%s' % (name, tag, k)] = v
+                else:            # BASELINE sizes: checksums + a fixed sample of entries
+                    out['%s/%s/%s@sum' % (name, tag, k)] = np.float64(v.astype(np.float64).sum())
+                    out['%s/%s/%s@abs' % (name, tag, k)] = np.float64(np.abs(v.astype(np.float64)).sum())
+                    out['%s/%s/%s@smp' % (name, tag, k)] = v.reshape(-1)[C.sample_index(v.size)]
+    return out
+
+
 def main():
     os.makedirs(HERE, exist_ok=True)
+    inf = run_inference_cases()
+    np.savez_compressed(os.path.join(HERE, 'inference.npz'), **inf)
+    print('inference.npz', len(inf), 'arrays')
+    if '--inference-only' in sys.argv:
+        return
     fit = run_fit_cases()
     np.savez_compressed(os.path.join(HERE, 'fit.npz'), **fit)
     print('fit.npz', len(fit), 'arrays')
