@@ -181,6 +181,8 @@ def main():
 
     from drvae_amd import _lib, dist as D
     _lib.load()                                       # fail loudly if the HIP library is missing
+    if os.environ.get('DRVAE_GEMM_MAP'):              # tuning: workgroup->tile map (0 linear, 1 XCD chunk-major)
+        _lib.load().dv_gemm_set_option(0, int(os.environ['DRVAE_GEMM_MAP']))
     if os.environ.get('DRVAE_T64_MIN'):               # tuning: 64x64-tile threshold of the GEMM heuristic
         _lib.load().dv_gemm_set_option(3, int(os.environ['DRVAE_T64_MIN']))
     if not torch.cuda.is_available():
