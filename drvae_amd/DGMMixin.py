@@ -30,8 +30,8 @@ class DeepGenerativeModelMixin:
     # ----------------------------------------------------------------- optimiser
     def _create_optimizer(self):
         """Adam with coupled L2 ``weight_decay`` on every parameter (src/DGMMixin.py:31-40),
-        as one fused kernel over the arena.  Adamax is not implemented."""
-        if self.optim_alg != 'adam':
+        or Adamax (src/DGMMixin.py:37-38), as one fused kernel over the arena."""
+        if self.optim_alg not in ('adam', 'adamax'):
             raise ValueError('Selected unknown optimizer: ' + str(self.optim_alg))
         self.optimizer = None          # kept for attribute parity; the state lives in the arena
         self._engine = None

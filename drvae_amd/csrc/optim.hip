@@ -126,6 +126,30 @@ __global__ __launch_bounds__(256) void fill_normal_kernel(float* __restrict__ ou
 
 extern "C" int dv_abi_version(void) { return DV_ABI_VERSION; }
 
+// torch.optim.Adamax (2.x `_single_tensor_adamax`), the other branch of src/DGMMixin.py:37-38:
+// grad += wd*p; m.lerp_(g, 1-b1); u = max(u*b2, |g|+eps); p += -(lr/(1-b1^t)) * (m/u)
+__global__ __launch_bounds__(256) void adamax_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                     float* __restrict__ m, float* __restrict__ u, int64_t n, float lr,
+                                                     float b1, float b2, float eps, float wd, float gscale,
+                                                     const int32_t* __restrict__ step_dev) {
+    __shared__ float sc[2];
+    if (threadIdx.x == 0) adam_consts(lr, b1, b2, step_dev, &sc[0], &sc[1]);
+    __syncthreads();
+    const float clr = sc[0];
+    const float w1 = (float)(1.0 - (double)b1);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += stride) {
+        float gg = g[i] * gscale;
+        const float pp = p[i];
+        if (wd != 0.f) gg = gg + wd * pp;
+        const float mm = m[i] + w1 * (gg - m[i]);
+        const float uu = fmaxf(u[i] * b2, fabsf(gg) + eps);
+        m[i] = mm;
+        u[i] = uu;
+        p[i] = pp + (-clr) * (mm / uu);
+    }
+}
+
 extern "C" const char* dv_error_string(int code) {
     switch (code) {
         case DV_OK: return "ok";
@@ -149,6 +173,19 @@ extern "C" int dv_adam_l2(float* p, const float* g, float* m, float* v, int64_t 
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, ST(stream), p, g, m, v, n, lr, beta1,
                        beta2, eps, weight_decay, gscale, step_dev, vec4);
+    DV_RETURN_LAUNCH();
+}
+
+extern "C" int dv_adamax_l2(float* p, const float* g, float* m, float* u, int64_t n, float lr, float beta1,
+                            float beta2, float eps, float weight_decay, float gscale, const int32_t* step_dev,
+                            dv_stream_t stream) {
+    DV_REQUIRE(n >= 0);
+    if (n == 0) return DV_OK;
+    DV_REQUIRE(p && g && m && u && step_dev);
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(adamax_kernel, dim3((unsigned)blocks), dim3(256), 0, ST(stream), p, g, m, u, n, lr, beta1, beta2,
+                       eps, weight_decay, gscale, step_dev);
     DV_RETURN_LAUNCH();
 }
 

@@ -741,8 +741,9 @@ class FusedStep:
         K.counter_add(self.step_dev, 1)
         if self._rec == 'both' and self.sched == 5:
             K.counter_add(self.side_ctr, 1)      # eager step: the side chain's counter follows
-        K.adam_l2(a.param, a.grad[:a.n_params], a.exp_avg, a.exp_avg_sq, self.step_dev, lr=cfg.learning_rate,
-                  weight_decay=cfg.weight_decay, gscale=gscale)
+        step = K.adamax_l2 if cfg.optim_alg == 'adamax' else K.adam_l2    # exp_avg_sq doubles as Adamax's exp_inf
+        step(a.param, a.grad[:a.n_params], a.exp_avg, a.exp_avg_sq, self.step_dev, lr=cfg.learning_rate,
+             weight_decay=cfg.weight_decay, gscale=gscale)
 
     def train_step(self, noise=None, allreduce=None):
         """forward + backward (+ gradient all-reduce) + Adam + iteration count: the body of

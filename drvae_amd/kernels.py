@@ -410,6 +410,12 @@ def adam_l2(p, g, m, v, step_dev, *, lr, beta1=0.9, beta2=0.999, eps=1e-8, weigh
                                       weight_decay, gscale, _i32(step_dev), _stream()), 'dv_adam_l2')
 
 
+def adamax_l2(p, g, m, u, step_dev, *, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, gscale=1.0):
+    assert p.is_contiguous() and g.is_contiguous() and m.is_contiguous() and u.is_contiguous()
+    _lib.check(_lib.load().dv_adamax_l2(_f32(p), _f32(g), _f32(m), _f32(u), p.numel(), lr, beta1, beta2, eps,
+                                        weight_decay, gscale, _i32(step_dev), _stream()), 'dv_adamax_l2')
+
+
 def flag_publish(flag, ctr, add=1):
     _lib.check(_lib.load().dv_flag_publish(_i32(flag), _i32(ctr), add, _stream()), 'dv_flag_publish')
 

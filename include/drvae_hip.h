@@ -347,6 +347,10 @@ int dv_axpby(const float* x, float a, float* y, float b, int64_t n, dv_stream_t 
  * multiplies g first (1/world_size style scaling; 1.0 for summed gradients). */
 int dv_adam_l2(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                float eps, float weight_decay, float gscale, const int32_t* step_dev, dv_stream_t stream);
+/* torch.optim.Adamax with coupled L2 (the `optim_alg='adamax'` branch of src/DGMMixin.py:37-38):
+ * u is the exponentially weighted infinity norm; same conventions as dv_adam_l2. */
+int dv_adamax_l2(float* p, const float* g, float* m, float* u, int64_t n, float lr, float beta1, float beta2,
+                 float eps, float weight_decay, float gscale, const int32_t* step_dev, dv_stream_t stream);
 int dv_counter_add(int32_t* counter_lo_hi, int32_t n_words, int64_t inc, dv_stream_t stream);
 
 /* Device-side fork/join between two launch chains that run concurrently (two root branches of one

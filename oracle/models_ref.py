@@ -52,6 +52,7 @@ class ModelSpec:
     clf_z1z2: bool = True
     semi_supervised: bool = True        # VFAE only (VFAE.py:54)
     kl_min: float = 2.0                 # DrVAE.py:90
+    optim_alg: str = 'adam'             # 'adam' | 'adamax' (DGMMixin.py:35-38)
     top_name: str = ''                  # filled in __post_init__
 
     def __post_init__(self):
@@ -346,8 +347,8 @@ class RefTrainer:
         self.spec = spec
         self.params = params
         self.iters = 0
-        self.opt = torch.optim.Adam(list(params.values()), lr=spec.learning_rate,
-                                    weight_decay=spec.weight_decay)
+        opt = {'adam': torch.optim.Adam, 'adamax': torch.optim.Adamax}[spec.optim_alg]
+        self.opt = opt(list(params.values()), lr=spec.learning_rate, weight_decay=spec.weight_decay)
 
     def loss(self, batch, noise, training=True, counts=None):
         return loss_function(self.spec, self.params, batch, noise, self.iters, training, counts)

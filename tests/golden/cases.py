@@ -185,6 +185,7 @@ MODEL_CASES = OrderedDict([
     ('tiny_drvae_nolp', (lambda: tiny_spec('drvae', dim_y=3, h_clf=[3], L=3), 'abdbadabbdaa', 2, True)),
     ('tiny_drvae_wn', (lambda: tiny_spec('drvae', weight_norm=True), 'cadbcabdbca', 2, True)),
     ('tiny_drvae_only_up', (lambda: tiny_spec('drvae', L=1), 'ddddd', 2, True)),
+    ('tiny_drvae_adamax', (lambda: tiny_spec('drvae', optim_alg='adamax'), 'acbdaabcdbacab', 3, True)),
     ('tiny_pvae', (lambda: tiny_spec('pvae'), 'bdbbdddbdb', 3, True)),
     ('tiny_vfae', (lambda: tiny_spec('vfae', dim_y=3), 'abbabaabbb', 3, True)),
     ('tiny_vfae_sup', (lambda: tiny_spec('vfae', semi_supervised=False, add_noise_var=0.), 'aababaaa', 2, True)),

@@ -128,7 +128,7 @@ def build_reference_model(spec, params):
                   dim_h_de_x=list(spec.h_de_x), dim_z1=spec.dim_z1, type_rec='diag_gaussian',
                   nonlinearity=spec.nonlin, learning_rate=spec.learning_rate, L=spec.L,
                   weight_decay=spec.weight_decay, add_noise_var=spec.add_noise_var, use_MMD=False,
-                  use_s=False, random_seed=123)
+                  use_s=False, random_seed=123, optim_alg=spec.optim_alg)
     pert = dict(kl_qz2pz2_rate=spec.kl_qz2pz2_rate, pertloss_rate=spec.pertloss_rate,
                 anneal_perturb_rate_itermax=spec.anneal_perturb_rate_itermax,
                 anneal_perturb_rate_offset=spec.anneal_perturb_rate_offset)

@@ -545,6 +545,16 @@ def adam_l2(p, g, m, v, step_dev, *, lr, beta1=0.9, beta2=0.999, eps=1e-8, weigh
     p.addcdiv_(m, denom, value=-(lr / bc1))
 
 
+def adamax_l2(p, g, m, u, step_dev, *, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, gscale=1.0):
+    t = int(step_dev.reshape(-1)[0])
+    gg = g * gscale
+    if weight_decay != 0.0:
+        gg = gg + weight_decay * p
+    m.lerp_(gg, 1 - beta1)
+    torch.maximum(u.mul_(beta2), gg.abs().add_(eps), out=u)
+    p.addcdiv_(m, u, value=-(lr / (1 - beta1 ** t)))
+
+
 def flag_publish(flag, ctr, add=1):
     flag[0] = int(ctr[0]) + add
 
@@ -573,7 +583,7 @@ def fill_normal(out, seed, ctr_dev=None):
     out.copy_(torch.randn(out.shape, generator=g).to(out.device))
 
 
-FUNCTIONS = ['batch_feed', 'flag_publish', 'flag_wait', 'gemm', 'linear_fwd', 'linear_bwd_data', 'linear_bwd_weight', 'linear_bwd_pair', 'colsum', 'act_bwd_', 'wn_scale', 'wn_bwd',
+FUNCTIONS = ['adamax_l2', 'batch_feed', 'flag_publish', 'flag_wait', 'gemm', 'linear_fwd', 'linear_bwd_data', 'linear_bwd_weight', 'linear_bwd_pair', 'colsum', 'act_bwd_', 'wn_scale', 'wn_bwd',
              'reparam_fwd', 'reparam_bwd', 'reparam_bwd_seg', 'z2f_post_bwd', 'kl_rows_fwd', 'kl_rows_bwd', 'nll_rows_fwd', 'nll_rows_bwd', 'nll_rows_fwdbwd',
              'softmax_clamp_fwd', 'softmax_clamp_bwd', 'cat_terms_fwd', 'cat_terms_bwd', 'smalln_fwd', 'smalln_bwd_data',
              'smalln_bwd_weight', 'ymarg_fwd', 'ymarg_bwd',

@@ -393,6 +393,24 @@ def test_adam_matches_torch_optim(K, dev):
     close(p, ref.detach(), rtol=1e-6, atol=1e-7)
 
 
+def test_adamax_matches_torch_optim(K, dev):
+    n = 100003
+    p0, g = rnd(dev, n, seed=1), rnd(dev, n, seed=2)
+    p = p0.clone()
+    m, u = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    step = torch.zeros(1, dtype=torch.int32, device=dev)
+    ref = p0.clone().cpu().requires_grad_(True)
+    opt = torch.optim.Adamax([ref], lr=5e-4, weight_decay=0.05)
+    for it in range(3):
+        gi = g * (0.5 ** it)                          # shrinking gradients: the running max matters
+        K.counter_add(step, 1)
+        K.adamax_l2(p, gi, m, u, step, lr=5e-4, weight_decay=0.05)
+        ref.grad = gi.cpu().clone()
+        opt.step()
+    close(p, ref.detach(), rtol=1e-6, atol=1e-7)
+    close(u, opt.state[ref]['exp_inf'], rtol=1e-6, atol=1e-9)
+
+
 def test_fill_normal_statistics_and_counter(K, dev):
     n = 1 << 20
     a, b = torch.empty(n, device=dev), torch.empty(n, device=dev)

@@ -19,7 +19,7 @@ def build_model(spec, dev):
                   dim_h_de_x=list(spec.h_de_x), dim_z1=spec.dim_z1, type_rec='diag_gaussian',
                   nonlinearity=spec.nonlin, learning_rate=spec.learning_rate, L=spec.L,
                   weight_decay=spec.weight_decay, add_noise_var=spec.add_noise_var, use_MMD=False, random_seed=123,
-                  weight_norm=spec.weight_norm, device=dev)
+                  weight_norm=spec.weight_norm, optim_alg=spec.optim_alg, device=dev)
     pert = dict(kl_qz2pz2_rate=spec.kl_qz2pz2_rate, pertloss_rate=spec.pertloss_rate,
                 anneal_perturb_rate_itermax=spec.anneal_perturb_rate_itermax,
                 anneal_perturb_rate_offset=spec.anneal_perturb_rate_offset)
@@ -42,7 +42,7 @@ def kwargs_for(spec, batch, dev):
     return dict(x1=t('x1'), s=t('s'), y=t('y'), has_y=t('has_y'))
 
 
-@pytest.mark.parametrize('name', ['tiny_drvae', 'tiny_drvae_nolp', 'tiny_drvae_wn', 'tiny_pvae', 'tiny_vfae',
+@pytest.mark.parametrize('name', ['tiny_drvae', 'tiny_drvae_nolp', 'tiny_drvae_wn', 'tiny_drvae_adamax', 'tiny_pvae', 'tiny_vfae',
                                   'tiny_vfae_sup', 'cfg2_drvae'])
 def test_run_on_batch_matches_reference(name, dev):
     case, gold = C.model_case(name), C.load('model_' + name)
