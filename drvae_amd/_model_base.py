@@ -55,12 +55,13 @@ class ELBOModel(FitMixin, DeepGenerativeModelMixin, nn.Module):
             bad.append('use_s=True (crashes in the reference too: torch.cat([z, s_raw]), src/DrVAE.py:438)')
         if getattr(self, 'type_y', 'discrete') != 'discrete':
             bad.append("type_y='cont'")
-        if getattr(self, 'clf_1sig', False):
-            bad.append('clf_1sig=True')
+        if getattr(self, 'clf_1sig', False) and self.dim_y != 2:
+            raise ValueError('Invalid combination of clf_1sig and dim_y')      # src/DrVAE.py:161
         if self.dropout_rate > 0 or getattr(self, 'input_x_dropout', 0.) > 0:
             bad.append('dropout')
-        if getattr(self, 'prior_y', 'uniform') not in ('uniform', None):
-            bad.append('non-uniform prior_y')
+        pr = getattr(self, 'prior_y', 'uniform')
+        if pr is not None and not isinstance(pr, str):       # a class prior given as data (src/DrVAE.py:83-85)
+            assert isinstance(pr, np.ndarray) and len(pr) == self.dim_y
         if getattr(self, 'use_c', False) or getattr(self, 'use_m', False):
             bad.append('use_c/use_m')
         if bad:
@@ -81,7 +82,8 @@ class ELBOModel(FitMixin, DeepGenerativeModelMixin, nn.Module):
             self.decoder_z2Fz1 = blk.DiagGaussianModuleLinear([Z1], [], Z1, bias_only=False, **pri, **hp)
         if self.kind in ('drvae', 'vfae'):
             clf_in = [Z1, Z1] if (self.kind == 'drvae' and self.clf_z1z2) else [Z1]
-            self.encoder_y = blk.CategoricalDecoder(clf_in, self.dim_h_clf, self.dim_y, **hp)
+            self.encoder_y = blk.CategoricalDecoder(clf_in, self.dim_h_clf, 1 if getattr(self, 'clf_1sig', False) else self.dim_y,
+                                                    **hp)
             top_h = self.dim_h_en_z3 if self.kind == 'drvae' else self.dim_h_en_z2
             top_z = self.dim_z3 if self.kind == 'drvae' else self.dim_z2
             top = blk.DiagGaussianModule([Z1, self.dim_y], top_h, top_z, **pri, **hp)
@@ -103,7 +105,9 @@ class ELBOModel(FitMixin, DeepGenerativeModelMixin, nn.Module):
             anneal_perturb_rate_itermax=getattr(self, 'anneal_perturb_rate_itermax', 0),
             anneal_perturb_rate_offset=getattr(self, 'anneal_perturb_rate_offset', 0),
             clf_z1z2=getattr(self, 'clf_z1z2', True), semi_supervised=getattr(self, 'semi_supervised', True),
-            kl_min=self.kl_min, optim_alg=self.optim_alg)
+            kl_min=self.kl_min, optim_alg=self.optim_alg, clf_1sig=bool(getattr(self, 'clf_1sig', False)),
+            prior_y=None if (getattr(self, 'prior_y', None) is None or isinstance(getattr(self, 'prior_y', None), str))
+            else tuple(float(v) for v in self.prior_y))
 
     # ---------------------------------------------------------------- inference
     @torch.no_grad()

@@ -698,7 +698,8 @@ __global__ __launch_bounds__(1024) void smalln_bwd_weight_kernel(const float* __
 // ------------------------------------------------------------- y-marginalisation
 __global__ void ymarg_fwd_kernel(const float* __restrict__ qy, int64_t ldq, const int32_t* __restrict__ label,
                                  const int32_t* __restrict__ fp_ptr, const float* __restrict__ klfp,
-                                 float log_prior, int R, int Y, float* __restrict__ yl, float* __restrict__ kld) {
+                                 float log_prior, const float* __restrict__ log_prior_v, int R, int Y,
+                                 float* __restrict__ yl, float* __restrict__ kld) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= R) return;
     const float* q = qy + (int64_t)r * ldq;
@@ -710,7 +711,7 @@ __global__ void ymarg_fwd_kernel(const float* __restrict__ qy, int64_t ldq, cons
         float a = 0.f, b = 0.f;
         for (int j = 0; j < Y; ++j) {
             a += q[j] * klfp[f0 + j];
-            b += -q[j] * (log_prior - logf(q[j]));
+            b += -q[j] * ((log_prior_v ? log_prior_v[j] : log_prior) - logf(q[j]));
         }
         yl[r] = 0.f;
         kld[r] = a + b;
@@ -719,8 +720,9 @@ __global__ void ymarg_fwd_kernel(const float* __restrict__ qy, int64_t ldq, cons
 
 __global__ void ymarg_bwd_kernel(const float* __restrict__ qy, int64_t ldq, const int32_t* __restrict__ label,
                                  const int32_t* __restrict__ fp_ptr, const float* __restrict__ klfp,
-                                 float log_prior, const float* __restrict__ c_kld, const float* __restrict__ c_yl,
-                                 int R, int Y, float* __restrict__ cfp, float* __restrict__ dqy, int64_t lddq) {
+                                 float log_prior, const float* __restrict__ log_prior_v,
+                                 const float* __restrict__ c_kld, const float* __restrict__ c_yl, int R, int Y,
+                                 float* __restrict__ cfp, float* __restrict__ dqy, int64_t lddq) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= R) return;
     const float* q = qy + (int64_t)r * ldq;
@@ -734,7 +736,7 @@ __global__ void ymarg_bwd_kernel(const float* __restrict__ qy, int64_t ldq, cons
     } else {
         for (int j = 0; j < Y; ++j) {
             cfp[f0 + j] = ck * q[j];
-            dq[j] = ck * (klfp[f0 + j] + logf(q[j]) - log_prior + 1.f);
+            dq[j] = ck * (klfp[f0 + j] + logf(q[j]) - (log_prior_v ? log_prior_v[j] : log_prior) + 1.f);
         }
     }
 }
@@ -1257,24 +1259,25 @@ extern "C" int dv_smalln_linear_bwd_weight(const float* dprobs, int64_t lddp, co
 }
 
 extern "C" int dv_ymarg_fwd(const float* qy, int64_t ldq, const int32_t* label, const int32_t* fp_ptr,
-                            const float* klfp, float log_prior, int32_t R, int32_t Y, float* yl, float* kld,
-                            dv_stream_t stream) {
+                            const float* klfp, float log_prior, const float* log_prior_v, int32_t R, int32_t Y,
+                            float* yl, float* kld, dv_stream_t stream) {
     DV_REQUIRE(R >= 0 && Y >= 1);
     if (R == 0) return DV_OK;
     DV_REQUIRE(qy && label && fp_ptr && klfp && yl && kld);
     hipLaunchKernelGGL(ymarg_fwd_kernel, dim3((R + 255) / 256), dim3(256), 0, ST(stream), qy, ldq, label, fp_ptr,
-                       klfp, log_prior, R, Y, yl, kld);
+                       klfp, log_prior, log_prior_v, R, Y, yl, kld);
     DV_RETURN_LAUNCH();
 }
 
 extern "C" int dv_ymarg_bwd(const float* qy, int64_t ldq, const int32_t* label, const int32_t* fp_ptr,
-                            const float* klfp, float log_prior, const float* c_kld, const float* c_yl, int32_t R,
-                            int32_t Y, float* cfp, float* dqy, int64_t lddq, dv_stream_t stream) {
+                            const float* klfp, float log_prior, const float* log_prior_v, const float* c_kld,
+                            const float* c_yl, int32_t R, int32_t Y, float* cfp, float* dqy, int64_t lddq,
+                            dv_stream_t stream) {
     DV_REQUIRE(R >= 0 && Y >= 1);
     if (R == 0) return DV_OK;
     DV_REQUIRE(qy && label && fp_ptr && klfp && c_kld && c_yl && cfp && dqy);
     hipLaunchKernelGGL(ymarg_bwd_kernel, dim3((R + 255) / 256), dim3(256), 0, ST(stream), qy, ldq, label, fp_ptr,
-                       klfp, log_prior, c_kld, c_yl, R, Y, cfp, dqy, lddq);
+                       klfp, log_prior, log_prior_v, c_kld, c_yl, R, Y, cfp, dqy, lddq);
     DV_RETURN_LAUNCH();
 }
 

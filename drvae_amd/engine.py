@@ -22,7 +22,7 @@ import math
 import os
 from collections import OrderedDict
 from dataclasses import dataclass, field
-from typing import List
+from typing import List, Optional, Tuple
 
 import numpy as np
 import torch
@@ -63,6 +63,8 @@ class StepConfig:
     semi_supervised: bool = True
     kl_min: float = 2.0
     optim_alg: str = 'adam'
+    prior_y: Optional[Tuple[float, ...]] = None    # None = 'uniform' (src/DrVAE.py:386-389)
+    clf_1sig: bool = False                          # two classes from one sigmoid output (src/DrVAE.py:160-163)
 
     @property
     def top_name(self):
@@ -116,7 +118,7 @@ def param_shapes(cfg):
     if cfg.has_y:
         n_in = 2 * Z1 if (cfg.kind == 'drvae' and cfg.clf_z1z2) else Z1
         n = trunk('encoder_y.nnet', n_in, cfg.h_clf)
-        lin('encoder_y.decoder_p.linear_p', n, Y)
+        lin('encoder_y.decoder_p.linear_p', n, 1 if cfg.clf_1sig else Y)
         gauss(cfg.top_name, Z1 + Y, cfg.h_en_z3, Z3)
         gauss('decoder_z1', Z3 + Y, cfg.h_de_z1, Z1)
     gauss('decoder_x', Z1, cfg.h_de_x, X, second='sg')
@@ -376,7 +378,8 @@ class FusedStep:
             layers.append(_Lin(a, q + '.weight', q + '.bias', q + '.g' if wn else None))
             self.L_clf = layers
             # single Linear with <= 8 classes: dedicated wave-per-row kernels instead of MFMA tiles
-            self.clf_small = (not cfg.h_clf) and cfg.dim_y <= 8 and not wn and os.environ.get('DRVAE_CLF_SMALL', '1') != '0'
+            self.clf_small = (not cfg.h_clf) and cfg.dim_y <= 8 and not wn and not cfg.clf_1sig and \
+                os.environ.get('DRVAE_CLF_SMALL', '1') != '0'
             self.L_top = self._gauss(cfg.top_name, len(cfg.h_en_z3), 'lv', shift_second=-2.0)
             self.L_dz1 = self._gauss('decoder_z1', len(cfg.h_de_z1), 'lv', shift_second=-2.0)
 
@@ -534,8 +537,8 @@ class FusedStep:
                     lc = self.L_clf[0]
                     K.smalln_fwd(p.QY, None, clf_in[0], lc.W, lc.b, clf_in[1] if len(clf_in) > 1 else None)
                 else:
-                    K.softmax_clamp_fwd(p.QY, p.c_clf.forward(clf_in))
-                K.ymarg_fwd(p.YLrow, p.KLDrow, p.QY, p.label_r, p.fp_ptr, p.KLFP, math.log(1.0 / cfg.dim_y))
+                    K.softmax_clamp_fwd(p.QY, p.c_clf.forward(clf_in), sigmoid1=cfg.clf_1sig)
+                K.ymarg_fwd(p.YLrow, p.KLDrow, p.QY, p.label_r, p.fp_ptr, p.KLFP, p.log_prior)
         mode = self._mode()
         if mode == 5:
             two = cfg.has_pert                      # flag 0: z1 samples final; flag 2: z2Fz1 samples final
@@ -611,7 +614,7 @@ class FusedStep:
                 self._loss_scalars()         # leaf work, off the critical path
             if cfg.has_y:
                 Y = cfg.dim_y
-                K.ymarg_bwd(p.CFP, p.DQY, p.QY, p.label_r, p.fp_ptr, p.KLFP, math.log(1.0 / Y), p.c_kld, p.c_yl)
+                K.ymarg_bwd(p.CFP, p.DQY, p.QY, p.label_r, p.fp_ptr, p.KLFP, p.log_prior, p.c_kld, p.c_yl)
                 if p.Mf:
                     Z3 = cfg.dim_z3
                     PZ1, Q3 = p.c_dz1.out[-1], p.c_top.out[-1]
@@ -643,7 +646,7 @@ class FusedStep:
                         K.smalln_bwd_data([(p.DZ1B, 0, 1.0, b1)], p.DQY, p.QY, lc.W)
                         K.smalln_bwd_weight(lc.dW, lc.db, p.DQY, p.QY, Z1blk)
                 else:
-                    K.softmax_clamp_bwd(p.DLOG, p.DQY, p.QY)
+                    K.softmax_clamp_bwd(p.DLOG, p.DQY, p.QY, sigmoid1=cfg.clf_1sig)
                     if two:
                         p.c_clf.backward(p.DLOG, [Z1blk, p.D],
                                          [[(p.DZ1B, 1.0, b1)], [(p.DZ2F, 1.0, 0.0), (p.DZ1B, -1.0, 1.0)]])
@@ -1112,7 +1115,10 @@ class _Plan:
         if cfg.has_y:
             R, Mf = L * B, self.Mf
             self.c_clf = _Chain(eng.L_clf, R, dev)
-            self.QY, self.DQY, self.DLOG = zf(R, Y), zf(R, Y), zf(R, Y)
+            self.QY, self.DQY, self.DLOG = zf(R, Y), zf(R, Y), zf(R, 1 if cfg.clf_1sig else Y)
+            # log p(y): the uniform prior as a scalar, a class prior given as data as a device vector
+            self.log_prior = math.log(1.0 / Y) if cfg.prior_y is None else \
+                torch.log(torch.tensor(cfg.prior_y, dtype=torch.float64)).float().to(dev)
             self.DZ1B = mat(R, Z1)
             self.YLrow, self.KLDrow = zf(R), zf(R)
             self.c_top = _Chain(eng.L_top, Mf, dev)

@@ -313,19 +313,22 @@ def smalln_bwd_weight(dW, db, dprobs, probs, a1, a2=None, beta=0.0):
 
 
 def ymarg_fwd(yl, kld, qy, label, fp_ptr, klfp, log_prior):
+    """``log_prior``: python float (uniform prior) or a device vector of Y log-probabilities"""
     R, Y = qy.shape
-    _lib.check(_lib.load().dv_ymarg_fwd(_f32(qy), _ld(qy), _i32(label), _i32(fp_ptr), _f32(klfp), log_prior, R, Y,
-                                        _f32(yl), _f32(kld), _stream()), 'dv_ymarg_fwd')
+    vec = log_prior if torch.is_tensor(log_prior) else None
+    _lib.check(_lib.load().dv_ymarg_fwd(_f32(qy), _ld(qy), _i32(label), _i32(fp_ptr), _f32(klfp),
+                                        0.0 if vec is not None else log_prior, _f32(vec), R, Y, _f32(yl), _f32(kld),
+                                        _stream()), 'dv_ymarg_fwd')
 
 
 def ymarg_bwd(cfp, dqy, qy, label, fp_ptr, klfp, log_prior, c_kld, c_yl):
     R, Y = qy.shape
-    _lib.check(_lib.load().dv_ymarg_bwd(_f32(qy), _ld(qy), _i32(label), _i32(fp_ptr), _f32(klfp), log_prior,
-                                        _f32(c_kld), _f32(c_yl), R, Y, _f32(cfp), _f32(dqy), _ld(dqy), _stream()),
-               'dv_ymarg_bwd')
+    vec = log_prior if torch.is_tensor(log_prior) else None
+    _lib.check(_lib.load().dv_ymarg_bwd(_f32(qy), _ld(qy), _i32(label), _i32(fp_ptr), _f32(klfp),
+                                        0.0 if vec is not None else log_prior, _f32(vec), _f32(c_kld), _f32(c_yl), R, Y,
+                                        _f32(cfp), _f32(dqy), _ld(dqy), _stream()), 'dv_ymarg_bwd')
 
 
-# ---------------------------------------------------------------------- row movement
 def rows_gather(out, src, idx=None, *, noise=None, sigma=0.0, onehot_cls=None, n_classes=0, width=None):
     n = out.shape[0]
     W = (src.shape[1] if src is not None else 0) if width is None else width

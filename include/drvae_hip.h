@@ -265,13 +265,16 @@ int dv_smalln_linear_bwd_weight(const float* dprobs, int64_t lddp, const float* 
  *   labeled   (fp_ptr[r+1]-fp_ptr[r] == 1): yl[r] = log qy[r, label[r]]; kld[r] = klfp[fp row]
  *   unlabeled (== Y fp rows, class j at fp_ptr[r]+j): yl[r] = 0;
  *       kld[r] = sum_j qy[r,j]*klfp[fp_ptr[r]+j] + sum_j qy[r,j](log qy[r,j] - log prior_j)
+ * log prior_j = log_prior_v[j] when log_prior_v != NULL (a class prior given as data, `prior_y` of
+ * src/DrVAE.py:83-85,389), else the scalar log_prior ('uniform').
  * backward: c_kld[r], c_yl[r] are dLoss/d kld[r], d yl[r]; writes cfp[fp row] = dLoss/d klfp
  * and dqy (R,Y). */
 int dv_ymarg_fwd(const float* qy, int64_t ldq, const int32_t* label, const int32_t* fp_ptr, const float* klfp,
-                 float log_prior, int32_t R, int32_t Y, float* yl, float* kld, dv_stream_t stream);
+                 float log_prior, const float* log_prior_v, int32_t R, int32_t Y, float* yl, float* kld,
+                 dv_stream_t stream);
 int dv_ymarg_bwd(const float* qy, int64_t ldq, const int32_t* label, const int32_t* fp_ptr, const float* klfp,
-                 float log_prior, const float* c_kld, const float* c_yl, int32_t R, int32_t Y, float* cfp,
-                 float* dqy, int64_t lddq, dv_stream_t stream);
+                 float log_prior, const float* log_prior_v, const float* c_kld, const float* c_yl, int32_t R,
+                 int32_t Y, float* cfp, float* dqy, int64_t lddq, dv_stream_t stream);
 
 /* ------------------------------------------------------------- row movement
  * out[r,:W] = src[idx?idx[r]:r, :W] (+ sigma*noise[r,:W])  -- the group gathers of

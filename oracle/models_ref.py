@@ -53,6 +53,8 @@ class ModelSpec:
     semi_supervised: bool = True        # VFAE only (VFAE.py:54)
     kl_min: float = 2.0                 # DrVAE.py:90
     optim_alg: str = 'adam'             # 'adam' | 'adamax' (DGMMixin.py:35-38)
+    prior_y: Optional[List[float]] = None   # None = 'uniform'; else class prior of length dim_y (DrVAE.py:83-85)
+    clf_1sig: bool = False              # 2 classes from ONE sigmoid output (DrVAE.py:160-163)
     top_name: str = ''                  # filled in __post_init__
 
     def __post_init__(self):
@@ -91,7 +93,7 @@ def param_shapes(spec):
     if spec.kind in ('drvae', 'vfae'):
         n_clf_in = 2 * Z1 if (spec.kind == 'drvae' and spec.clf_z1z2) else Z1
         n = mlp('encoder_y.nnet', n_clf_in, spec.h_clf)
-        lin('encoder_y.decoder_p.linear_p', n, Y)
+        lin('encoder_y.decoder_p.linear_p', n, 1 if spec.clf_1sig else Y)
         gauss(spec.top_name, Z1 + Y, spec.h_en_z3, Z3)
         gauss('decoder_z1', Z3 + Y, spec.h_de_z1, Z1)
     gauss('decoder_x', Z1, spec.h_de_x, X, second='sg')
@@ -254,7 +256,7 @@ def _group_losses(spec, p, acc, idx, x1, x2, y, noise, iters, training):
             clf_in = [z1, z2F - z1] if spec.clf_z1z2 else [z2F]           # DrVAE.py:495-498
         else:
             clf_in = [z1]                                                  # VFAE.py:325
-        qy = B.categorical(clf_in, p, 'encoder_y', nhc, spec.nonlin, spec.dim_y)
+        qy = B.categorical(clf_in, p, 'encoder_y', nhc, spec.nonlin, 1 if spec.clf_1sig else spec.dim_y)
         if labeled:
             acc.add('YL', idx, B.categorical_logp_rows(y, qy), 1. / Lf)   # DrVAE.py:506
             kld = _fprop(spec, p, z1, qz1, y1hot, nz('ez3', l, 0))
@@ -263,7 +265,10 @@ def _group_losses(spec, p, acc, idx, x1, x2, y, noise, iters, training):
             for j in range(spec.dim_y):                                    # DrVAE.py:520-524
                 yj = B.one_hot(torch.full((n,), j), spec.dim_y)
                 kld = kld + qy[:, j] * _fprop(spec, p, z1, qz1, yj, nz('ez3', l, j))
-            prior = torch.full((n, spec.dim_y), 1. / spec.dim_y)          # 'uniform', DrVAE.py:388-389
+            if spec.prior_y is None:
+                prior = torch.full((n, spec.dim_y), 1. / spec.dim_y)      # 'uniform', DrVAE.py:388-389
+            else:                                                          # np.ones((N,Y)) * prior_y, DrVAE.py:389
+                prior = torch.from_numpy(np.ones((n, spec.dim_y)) * np.asarray(spec.prior_y)).float()
             kld = kld + B.categorical_kl_elem(qy, prior).sum(1)           # DrVAE.py:526
         acc.add('KLD', idx, kld, 1. / Lf)                                  # DrVAE.py:534
 

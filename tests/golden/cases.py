@@ -186,6 +186,9 @@ MODEL_CASES = OrderedDict([
     ('tiny_drvae_wn', (lambda: tiny_spec('drvae', weight_norm=True), 'cadbcabdbca', 2, True)),
     ('tiny_drvae_only_up', (lambda: tiny_spec('drvae', L=1), 'ddddd', 2, True)),
     ('tiny_drvae_adamax', (lambda: tiny_spec('drvae', optim_alg='adamax'), 'acbdaabcdbacab', 3, True)),
+    ('tiny_drvae_prior', (lambda: tiny_spec('drvae', dim_y=3, prior_y=[0.2, 0.5, 0.3]), 'abdbcdabbdac', 2, True)),
+    ('tiny_drvae_1sig', (lambda: tiny_spec('drvae', clf_1sig=True, h_clf=[3]), 'cadbcabdbca', 2, True)),
+    ('tiny_vfae_prior_1sig', (lambda: tiny_spec('vfae', clf_1sig=True, prior_y=[0.7, 0.3]), 'abbabaabbb', 2, True)),
     ('tiny_pvae', (lambda: tiny_spec('pvae'), 'bdbbdddbdb', 3, True)),
     ('tiny_vfae', (lambda: tiny_spec('vfae', dim_y=3), 'abbabaabbb', 3, True)),
     ('tiny_vfae_sup', (lambda: tiny_spec('vfae', semi_supervised=False, add_noise_var=0.), 'aababaaa', 2, True)),

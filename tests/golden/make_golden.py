@@ -132,7 +132,9 @@ def build_reference_model(spec, params):
     pert = dict(kl_qz2pz2_rate=spec.kl_qz2pz2_rate, pertloss_rate=spec.pertloss_rate,
                 anneal_perturb_rate_itermax=spec.anneal_perturb_rate_itermax,
                 anneal_perturb_rate_offset=spec.anneal_perturb_rate_offset)
-    ycfg = dict(dim_h_de_z1=list(spec.h_de_z1), dim_h_clf=list(spec.h_clf), yloss_rate=spec.yloss_rate)
+    ycfg = dict(dim_h_de_z1=list(spec.h_de_z1), dim_h_clf=list(spec.h_clf), yloss_rate=spec.yloss_rate,
+                clf_1sig=spec.clf_1sig,
+                prior_y='uniform' if spec.prior_y is None else np.asarray(spec.prior_y, np.float64))
     if spec.kind == 'drvae':
         cls, kw = rDrVAE.DrVAE, dict(common, dim_h_en_z3=list(spec.h_en_z3), dim_z3=spec.dim_z3,
                                      clf_z1z2=spec.clf_z1z2, **pert, **ycfg)
