@@ -401,8 +401,12 @@ __global__ __launch_bounds__(256) void nll_rows_fwdbwd_kernel(const float* __res
                                                               int mode, int sd_act, float sd_shift,
                                                               float* __restrict__ out, float* __restrict__ dmu,
                                                               float* __restrict__ dsd, int64_t ldd) {
-    const int lane = threadIdx.x & 63;
-    for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < M; r += gridDim.x * 4) {
+    // one WORKGROUP per row, its four waves splitting the genes: a few hundred rows of ~1000 genes is
+    // too little for wave-per-row to fill the chip (596 waves = 149 workgroups), and each wave's
+    // dependent load->store chain is then 4x shorter
+    __shared__ float part[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int r = blockIdx.x; r < M; r += gridDim.x) {
         const float* xr = x + (int64_t)(xidx ? xidx[r] : r) * ldx;
         const float* mr = mu + (int64_t)r * ldp;
         const float* sr = sd + (int64_t)r * ldp;
@@ -412,7 +416,7 @@ __global__ __launch_bounds__(256) void nll_rows_fwdbwd_kernel(const float* __res
         float acc = 0.f;
         if (VEC2) {
             const int X2 = X >> 1;
-            for (int q = lane; q < X2; q += 64) {
+            for (int q = threadIdx.x; q < X2; q += 256) {
                 const float2 xv = reinterpret_cast<const float2*>(xr)[q];
                 const float2 mv = reinterpret_cast<const float2*>(mr)[q];
                 const float2 sv = reinterpret_cast<const float2*>(sr)[q];
@@ -422,14 +426,14 @@ __global__ __launch_bounds__(256) void nll_rows_fwdbwd_kernel(const float* __res
                 reinterpret_cast<float2*>(gmr)[q] = gm;
                 reinterpret_cast<float2*>(gsr)[q] = gs;
             }
-            if ((X & 1) && lane == 0) {
+            if ((X & 1) && threadIdx.x == 0) {
                 float gm, gs;
                 nll_fb_elem(mode, sd_act, sd_shift, c, xr[X - 1], mr[X - 1], sr[X - 1], acc, gm, gs);
                 gmr[X - 1] = gm;
                 gsr[X - 1] = gs;
             }
         } else {
-            for (int g = lane; g < X; g += 64) {
+            for (int g = threadIdx.x; g < X; g += 256) {
                 float gm, gs;
                 nll_fb_elem(mode, sd_act, sd_shift, c, xr[g], mr[g], sr[g], acc, gm, gs);
                 gmr[g] = gm;
@@ -437,7 +441,10 @@ __global__ __launch_bounds__(256) void nll_rows_fwdbwd_kernel(const float* __res
             }
         }
         acc = dv_wave_sum_all(acc);
-        if (lane == 0) out[r] = -0.5f * acc;
+        if (lane == 0) part[wave] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) out[r] = -0.5f * ((part[0] + part[1]) + (part[2] + part[3]));
+        __syncthreads();
     }
 }
 
@@ -1134,7 +1141,7 @@ extern "C" int dv_gauss_nll_rows_fwdbwd(const float* coef, const float* x, int64
     DV_REQUIRE(coef && x && mu && sd && out && dmu && dsd);
     auto a8 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7) == 0; };
     const bool v2 = a8(x) && a8(mu) && a8(sd) && a8(dmu) && a8(dsd) && (ldx % 2 == 0) && (ldp % 2 == 0) && (ldd % 2 == 0);
-    const dim3 grid(grid_for(M, 4, 8192)), block(256);
+    const dim3 grid(M < 16384 ? M : 16384), block(256);
     if (v2)
         hipLaunchKernelGGL(nll_rows_fwdbwd_kernel<true>, grid, block, 0, ST(stream), coef, x, ldx, xidx, mu, sd, ldp, M,
                            X, mode, sd_act, sd_shift, out, dmu, dsd, ldd);

@@ -827,54 +827,110 @@ class FusedStep:
         return self
 
     # ------------------------------------------------------------ CU partition
-    def partition(self):
+    def _partition_applicable(self):
+        # only for latency-bound steps: once the decoder products alone fill the chip many times over
+        # (wide configuration) the main chain needs every CU (measured: 52 ms -> 66 ms/step when masked)
+        small = self.plan is not None and self.plan.DPX.shape[0] * self.plan.DPX.shape[1] <= (4 << 20)
+        return bool(self.branch.on and self.sched == 5 and self.cfg.has_y and small and
+                    int(os.environ.get('DRVAE_SIDE_CUS', '64')) > 0)
+
+    def _part_streams(self, n_side):
+        """(main, side) CU-masked streams reserving ``n_side`` CUs for the side chain (cached)"""
+        cache = self.__dict__.setdefault('_parts', {})
+        if n_side not in cache:
+            n_cu = torch.cuda.get_device_properties(self.dev).multi_processor_count
+            words = (n_cu + 31) // 32
+            side_bits, all_bits = [0] * words, [0] * words
+            for i in range(n_cu):
+                all_bits[i // 32] |= 1 << (i % 32)
+                if i < min(n_side, n_cu - 1):
+                    side_bits[i // 32] |= 1 << (i % 32)
+            main_bits = [a & ~b for a, b in zip(all_bits, side_bits)]
+            try:
+                pair = (_masked_stream(main_bits, self.dev), _masked_stream(side_bits, self.dev))
+                with torch.cuda.stream(pair[0]):
+                    if not self._probe(pair[1]):         # must sit on different hardware queues
+                        pair = None
+            except (OSError, RuntimeError, AttributeError) as e:      # runtime without CU masking: plain streams
+                import warnings
+                warnings.warn('drvae_amd: CU partition unavailable (%s)' % e)
+                pair = None
+            cache[n_side] = pair
+        return cache[n_side]
+
+    def partition(self, n_side=None):
         """Context manager: run the train step with the GPU's compute units split between the two
-        launch chains -- the side chain (many small launches) on ``side_cus`` reserved CUs, the main
+        launch chains -- the side chain (many small launches) on ``n_side`` reserved CUs, the main
         chain (the big GEMMs) on the rest -- via CU-masked HIP streams.  Inside the context the
         masked main stream is the current stream, so everything the caller enqueues (batch feed,
         loss accumulation, replays) is ordered with the step; on exit the outer stream waits for it.
         Measured on MI355X (cfg 2): 64 reserved CUs take the step from 0.264 to 0.240 ms; without the
         reservation the side chain's small kernels queue behind the GEMM workgroups and the main
-        chain waits ~32 us per step at the join.  No-op when disabled (DRVAE_SIDE_CUS=0) or off-GPU."""
+        chain waits ~32 us per step at the join.  ``tune_partition()`` picks the split by timing.
+        No-op when not applicable, disabled (DRVAE_SIDE_CUS=0) or off-GPU."""
         import contextlib
-        n_side = int(os.environ.get('DRVAE_SIDE_CUS', '64'))
-        # only for latency-bound steps: once the decoder products alone fill the chip many times over
-        # (wide configuration) the main chain needs every CU (measured: 52 ms -> 66 ms/step when masked)
-        small = self.plan is not None and self.plan.DPX.shape[0] * self.plan.DPX.shape[1] <= (4 << 20)
-        if not (self.branch.on and n_side > 0 and self.sched == 5 and self.cfg.has_y and small):
+        if not self._partition_applicable():
             return contextlib.nullcontext()
-        if getattr(self, '_part', None) is None:
-            n_cu = torch.cuda.get_device_properties(self.dev).multi_processor_count
-            words = (n_cu + 31) // 32
-            side_bits = [0] * words
-            for i in range(min(n_side, n_cu - 1)):
-                side_bits[i // 32] |= 1 << (i % 32)
-            all_bits = [0] * words
-            for i in range(n_cu):
-                all_bits[i // 32] |= 1 << (i % 32)
-            main_bits = [a & ~b for a, b in zip(all_bits, side_bits)]
-            try:
-                self._part = (_masked_stream(main_bits, self.dev), _masked_stream(side_bits, self.dev))
-            except (OSError, RuntimeError, AttributeError) as e:      # runtime without CU masking: plain streams
-                import warnings
-                warnings.warn('drvae_amd: CU partition unavailable (%s)' % e)
-                self._part = False
-            if self._part:
-                self._flag_side = self._part[1]
-                self._flags_ok = None                # re-probe on the streams actually used
-        if not self._part:
+        if n_side is None:
+            n_side = getattr(self, '_side_cus', None) or int(os.environ.get('DRVAE_SIDE_CUS', '64'))
+        pair = self._part_streams(n_side)
+        if pair is None:
             return contextlib.nullcontext()
-        main = self._part[0]
+        main, side = pair
 
         @contextlib.contextmanager
         def ctx():
             outer = torch.cuda.current_stream()
+            prev = self._flag_side
             main.wait_stream(outer)
-            with torch.cuda.stream(main):
-                yield self
-            outer.wait_stream(main)
-            outer.wait_stream(self.flag_side)
+            side.wait_stream(outer)
+            self._flag_side = side
+            try:
+                with torch.cuda.stream(main):
+                    yield self
+            finally:
+                outer.wait_stream(main)
+                outer.wait_stream(side)
+                self._flag_side = prev
         return ctx()
+
+    def tune_partition(self, candidates=(48, 64, 72, 80, 96), steps=24):
+        """Pick the CU split of ``partition()`` by timing replays of the captured step (the best split
+        depends on how the two chains balance, i.e. on the model and on the individual GPU).  Runs on a
+        scratch copy of the training state: parameters, Adam moments and all device counters are restored
+        afterwards.  Returns the chosen number of reserved CUs (None when partitioning does not apply)."""
+        if not (self._partition_applicable() and self._side_graph is not None and len(self._graphs) == 1) or \
+                'DRVAE_SIDE_CUS' in os.environ:       # (multi-rank: split graphs need the exchange; keep the default)
+            return None
+        a = self.arena
+        keep = [t.clone() for t in (a.param, a.exp_avg, a.exp_avg_sq, self.step_dev, self.side_ctr, self.rng_ctr,
+                                    self.flags)]
+        iters = self.iters
+        best = (None, float('inf'))
+        for n in candidates:
+            if self._part_streams(n) is None:
+                continue
+            with self.partition(n):
+                for _ in range(4):
+                    self.replay()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(steps):
+                    self.replay()
+                e1.record()
+                e1.synchronize()
+                t = e0.elapsed_time(e1)
+            if t < best[1]:
+                best = (n, t)
+        torch.cuda.synchronize()
+        for dst, src in zip((a.param, a.exp_avg, a.exp_avg_sq, self.step_dev, self.side_ctr, self.rng_ctr,
+                             self.flags), keep):
+            dst.copy_(src)
+        self.iters = iters
+        self.plan.set_beta(self.beta_pert())
+        torch.cuda.synchronize()
+        self._side_cus = best[0]
+        return best[0]
 
     @property
     def flag_side(self):

@@ -210,10 +210,6 @@ class FitMixin:
         """one epoch of hipGraph replays fed by the device batcher; returns the mean train objective"""
         eng = self.engine()
         batcher.bind(eng, counts=getattr(self, '_global_counts', None))
-        with eng.partition():
-            return self._epoch_device_body(eng, batcher, epoch, verbose)
-
-    def _epoch_device_body(self, eng, batcher, epoch, verbose):
         eng.add_noise = bool(self.add_noise)
         eng.iters = self.finished_training_iters
         batcher.begin_epoch()               # this epoch's index table; the graph gathers batch b itself
@@ -221,6 +217,13 @@ class FitMixin:
                 or getattr(eng, '_graph_feed', None) is not eng.plan.feed:
             eng.capture(split_for_allreduce=getattr(self, '_allreduce', None) is not None)
             eng._graph_noise = eng.add_noise
+            if getattr(self, '_allreduce', None) is None:
+                eng.tune_partition()        # CU split of the two launch chains, by timing (state restored)
+            batcher.begin_epoch()           # (the tuning replays advanced the step counter: re-base the table)
+        with eng.partition():
+            return self._epoch_device_body(eng, batcher, epoch, verbose)
+
+    def _epoch_device_body(self, eng, batcher, epoch, verbose):
         n_b = len(batcher)
         every = max(10, n_b / 10)
         total = torch.zeros((), device=eng.dev)
