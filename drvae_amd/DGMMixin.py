@@ -49,7 +49,7 @@ class DeepGenerativeModelMixin:
             if list(shapes.items()) != list(want.items()):
                 raise RuntimeError('model parameters do not match the fused-step layout: %s'
                                    % (set(shapes.items()) ^ set(want.items())))
-            self._arena = ParamArena(shapes, dev).adopt(self)
+            self._arena = ParamArena(shapes, dev, frozen=E.frozen_params(cfg)).adopt(self)
             self._engine = E.FusedStep(cfg, self._arena, seed=self.random_seed)
         return self._engine
 

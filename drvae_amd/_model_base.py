@@ -53,8 +53,14 @@ class ELBOModel(FitMixin, DeepGenerativeModelMixin, nn.Module):
         bad = []
         if getattr(self, 'use_s', False):
             bad.append('use_s=True (crashes in the reference too: torch.cat([z, s_raw]), src/DrVAE.py:438)')
-        if getattr(self, 'type_y', 'discrete') != 'discrete':
-            bad.append("type_y='cont'")
+        if getattr(self, 'type_y', 'discrete') not in ('discrete', 'cont'):
+            raise ValueError('Invalid type_y')
+        if getattr(self, 'type_y', 'discrete') == 'cont' and self.kind == 'vfae':
+            # the reference's own semi-supervised regression branch crashes (src/VFAE.py:386 passes the
+            # 1-tuple returned by sample() on to torch.cat): nothing to be identical to
+            bad.append("VFAE with type_y='cont'")
+        if getattr(self, 'type_y', 'discrete') == 'cont' and not isinstance(getattr(self, 'prior_y', 'uniform'), str):
+            bad.append("type_y='cont' with a data prior")
         if getattr(self, 'clf_1sig', False) and self.dim_y != 2:
             raise ValueError('Invalid combination of clf_1sig and dim_y')      # src/DrVAE.py:161
         if self.dropout_rate > 0 or getattr(self, 'input_x_dropout', 0.) > 0:
@@ -82,8 +88,12 @@ class ELBOModel(FitMixin, DeepGenerativeModelMixin, nn.Module):
             self.decoder_z2Fz1 = blk.DiagGaussianModuleLinear([Z1], [], Z1, bias_only=False, **pri, **hp)
         if self.kind in ('drvae', 'vfae'):
             clf_in = [Z1, Z1] if (self.kind == 'drvae' and self.clf_z1z2) else [Z1]
-            self.encoder_y = blk.CategoricalDecoder(clf_in, self.dim_h_clf, 1 if getattr(self, 'clf_1sig', False) else self.dim_y,
-                                                    **hp)
+            if getattr(self, 'type_y', 'discrete') == 'cont':      # regression head (src/DrVAE.py:166-169)
+                self.encoder_y = blk.DiagGaussianModule(clf_in, self.dim_h_clf, self.dim_y, fixed_variance=0.05 ** 2,
+                                                        constrain_means=True, **hp)
+            else:
+                self.encoder_y = blk.CategoricalDecoder(clf_in, self.dim_h_clf,
+                                                        1 if getattr(self, 'clf_1sig', False) else self.dim_y, **hp)
             top_h = self.dim_h_en_z3 if self.kind == 'drvae' else self.dim_h_en_z2
             top_z = self.dim_z3 if self.kind == 'drvae' else self.dim_z2
             top = blk.DiagGaussianModule([Z1, self.dim_y], top_h, top_z, **pri, **hp)
@@ -106,6 +116,7 @@ class ELBOModel(FitMixin, DeepGenerativeModelMixin, nn.Module):
             anneal_perturb_rate_offset=getattr(self, 'anneal_perturb_rate_offset', 0),
             clf_z1z2=getattr(self, 'clf_z1z2', True), semi_supervised=getattr(self, 'semi_supervised', True),
             kl_min=self.kl_min, optim_alg=self.optim_alg, clf_1sig=bool(getattr(self, 'clf_1sig', False)),
+            type_y=getattr(self, 'type_y', 'discrete'),
             prior_y=None if (getattr(self, 'prior_y', None) is None or isinstance(getattr(self, 'prior_y', None), str))
             else tuple(float(v) for v in self.prior_y))
 
@@ -129,7 +140,7 @@ class ELBOModel(FitMixin, DeepGenerativeModelMixin, nn.Module):
             else:
                 clf_in = [z1]
             qy = self.encoder_y(clf_in)
-            res.update(pred=self.encoder_y.most_probable(*qy), proba=qy[0])
+            res.update(**self._pred_proba(qy))
         px1 = self.decoder_x([z1])
         res.update(px1=px1, x1_rec=px1[0])
         if self.kind in ('drvae', 'pvae'):
@@ -151,12 +162,18 @@ class ELBOModel(FitMixin, DeepGenerativeModelMixin, nn.Module):
         res = OrderedDict(z1=z1, qz1=qz1)
         if self.kind == 'drvae':
             qy = self.encoder_y([z1, z1 - z1] if self.clf_z1z2 else [z1])
-            res.update(pred=self.encoder_y.most_probable(*qy), proba=qy[0])
+            res.update(**self._pred_proba(qy))
         px2 = self.decoder_x([z1])
         qz2 = self.encoder_z1([x2])
         px2_rec = self.decoder_x([qz2[0]])
         res.update(px2=px2, x2_pert=px2[0], z2=qz2[0], qz2=qz2, px2_rec=px2_rec, x2_rec=px2_rec[0])
         return res
+
+    def _pred_proba(self, qy):
+        """(pred, proba) of src/DrVAE.py:212-220: class + probabilities, or mean + log-variance"""
+        if getattr(self, 'type_y', 'discrete') == 'cont':
+            return dict(pred=qy[0], proba=qy[1])
+        return dict(pred=self.encoder_y.most_probable(*qy), proba=qy[0])
 
     def predict(self, **kwargs):
         res = self.forward(**kwargs)

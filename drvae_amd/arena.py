@@ -19,9 +19,10 @@ _HEAD_PAIRS = (('encoder_mu.linear_mu', 'encoder_lv.linear_lv'),
                ('encoder_mu.linear_mu', 'encoder_sg.linear_sg'))
 
 
-def _fusion_groups(names):
-    """order parameter names so that fused-head partners are adjacent: returns list of groups"""
-    names = list(names)
+def _fusion_groups(names, frozen=()):
+    """order parameter names so that fused-head partners are adjacent: returns list of groups
+    (``frozen`` names are never fused: they live behind the optimised range)"""
+    names = [n for n in names if n not in frozen]
     used, groups = set(), []
     for n in names:
         if n in used:
@@ -47,13 +48,17 @@ def _fusion_groups(names):
 
 
 class ParamArena:
-    def __init__(self, named_shapes, device):
-        """named_shapes: OrderedDict name -> shape (reference state_dict names)."""
+    def __init__(self, named_shapes, device, frozen=()):
+        """named_shapes: OrderedDict name -> shape (reference state_dict names).  ``frozen``: parameters
+        that never receive a gradient; torch's optimisers skip such parameters altogether (no weight
+        decay), so they are parked behind the range the fused optimiser kernel sweeps (``n_live``)."""
         self.device = torch.device(device)
         self.shapes = OrderedDict((k, tuple(v)) for k, v in named_shapes.items())
         self.offsets = {}
         off = 0
-        for grp in _fusion_groups(self.shapes):
+        for grp in _fusion_groups(self.shapes, frozen) + [[n] for n in self.shapes if n in frozen]:
+            if grp[0] in frozen and not hasattr(self, 'n_live'):
+                self.n_live = (off + 3) // 4 * 4
             off = (off + 3) // 4 * 4                       # 16-B aligned group start
             for n in grp:
                 self.offsets[n] = off
@@ -62,6 +67,8 @@ class ParamArena:
                     numel *= s
                 off += numel
         self.n_params = (off + 3) // 4 * 4
+        if not hasattr(self, 'n_live'):
+            self.n_live = self.n_params
         PAD = 16    # tail slack: GEMM edge tiles may over-read a row end by up to 3 floats (dv_gemm_desc.flags)
         z = lambda n: torch.zeros(n + PAD, dtype=torch.float32, device=self.device)[:n]
         self.param = z(self.n_params)
@@ -78,7 +85,7 @@ class ParamArena:
         first = min(early) if early else self.n_params
         # valid only when decoder_x really is the tail of the arena
         tail_ok = early and all(o >= first for n, o in self.offsets.items() if n.startswith('decoder_x.')) and \
-            all(o < first for n, o in self.offsets.items() if not n.startswith('decoder_x.'))
+            all(o < first for n, o in self.offsets.items() if not n.startswith('decoder_x.') and n not in frozen)
         self.late_end = N_LOSS + (first if tail_ok else self.n_params)
 
     def numel(self, name):

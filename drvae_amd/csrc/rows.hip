@@ -748,6 +748,61 @@ __global__ void ymarg_bwd_kernel(const float* __restrict__ qy, int64_t ldq, cons
     }
 }
 
+// ------------------------------------------------ regression head (type_y = 'cont')
+// q(y|.) = N(mu, var) with mu = sigmoid(.) and a FIXED variance (src/DrVAE.py:167-169).  Per classifier
+// row r = (l, i):  labeled -> yl[r] = log N(y_i; mu, var), the fprop input takes the true y;
+// unlabeled -> y is sampled (SGVB, src/DrVAE.py:527-529): yv = mu + sd*eps, yl[r] = 0.
+// The y columns of the two fprop inputs [z1 | y] and [z3 | y] are written here.
+__global__ void ycont_fwd_kernel(const float* __restrict__ mu, int64_t ldm, const float* __restrict__ ylab,
+                                 const int32_t* __restrict__ has_y, const float* __restrict__ eps, int64_t lde,
+                                 float logvar, int R, int B, int Y, float* __restrict__ yl,
+                                 float* __restrict__ fpin_y, int64_t ld1, float* __restrict__ z3in_y, int64_t ld2) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const int i = r % B;
+    const bool lab = has_y[i] != 0;
+    const float sd = expf(0.5f * logvar), iv = expf(-logvar);
+    float acc = 0.f;
+    for (int d = 0; d < Y; ++d) {
+        const float m = mu[(int64_t)r * ldm + d];
+        float yv;
+        if (lab) {
+            yv = ylab[(int64_t)i * Y + d];
+            const float df = yv - m;
+            acc += kLog2Pi + logvar + df * df * iv;
+        } else {
+            yv = m + sd * eps[(int64_t)r * lde + d];
+        }
+        fpin_y[(int64_t)r * ld1 + d] = yv;
+        z3in_y[(int64_t)r * ld2 + d] = yv;
+    }
+    yl[r] = lab ? -0.5f * acc : 0.f;
+}
+
+// dlogit[r,d] = dmu * mu(1-mu):  labeled dmu = c_yl[r]*(y-mu)/var;  unlabeled dmu = d/d(y columns of
+// the two fprop inputs) (the sample is mu + const*eps).  cfp[r] = c_kld[r] (one fprop row per row).
+__global__ void ycont_bwd_kernel(const float* __restrict__ mu, int64_t ldm, const float* __restrict__ ylab,
+                                 const int32_t* __restrict__ has_y, float logvar, const float* __restrict__ c_yl,
+                                 const float* __restrict__ c_kld, const float* __restrict__ dfpin_y, int64_t ld1,
+                                 const float* __restrict__ dz3in_y, int64_t ld2, int R, int B, int Y,
+                                 float* __restrict__ dlogit, int64_t ldd, float* __restrict__ cfp, int write_cfp) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const int i = r % B;
+    const bool lab = has_y[i] != 0;
+    const float iv = expf(-logvar);
+    if (write_cfp) {
+        cfp[r] = c_kld[r];
+        return;
+    }
+    for (int d = 0; d < Y; ++d) {
+        const float m = mu[(int64_t)r * ldm + d];
+        const float dmu = lab ? c_yl[r] * (ylab[(int64_t)i * Y + d] - m) * iv
+                              : dfpin_y[(int64_t)r * ld1 + d] + dz3in_y[(int64_t)r * ld2 + d];
+        dlogit[(int64_t)r * ldd + d] = dmu * m * (1.f - m);
+    }
+}
+
 // ---------------------------------------------------------------- row movement
 __global__ void rows_gather_kernel(const float* __restrict__ src, int64_t lds, const int32_t* __restrict__ idx,
                                    int n, int W, const float* __restrict__ noise, int64_t ldn, float sigma,
@@ -1285,6 +1340,29 @@ extern "C" int dv_ymarg_bwd(const float* qy, int64_t ldq, const int32_t* label, 
     DV_REQUIRE(qy && label && fp_ptr && klfp && c_kld && c_yl && cfp && dqy);
     hipLaunchKernelGGL(ymarg_bwd_kernel, dim3((R + 255) / 256), dim3(256), 0, ST(stream), qy, ldq, label, fp_ptr,
                        klfp, log_prior, log_prior_v, c_kld, c_yl, R, Y, cfp, dqy, lddq);
+    DV_RETURN_LAUNCH();
+}
+
+extern "C" int dv_ycont_fwd(const float* mu, int64_t ldm, const float* ylab, const int32_t* has_y, const float* eps,
+                            int64_t lde, float logvar, int32_t R, int32_t B, int32_t Y, float* yl, float* fpin_y,
+                            int64_t ld1, float* z3in_y, int64_t ld2, dv_stream_t stream) {
+    DV_REQUIRE(R >= 0 && B >= 1 && Y >= 1);
+    if (R == 0) return DV_OK;
+    DV_REQUIRE(mu && ylab && has_y && eps && yl && fpin_y && z3in_y);
+    hipLaunchKernelGGL(ycont_fwd_kernel, dim3((R + 255) / 256), dim3(256), 0, ST(stream), mu, ldm, ylab, has_y, eps, lde,
+                       logvar, R, B, Y, yl, fpin_y, ld1, z3in_y, ld2);
+    DV_RETURN_LAUNCH();
+}
+
+extern "C" int dv_ycont_bwd(const float* mu, int64_t ldm, const float* ylab, const int32_t* has_y, float logvar,
+                            const float* c_yl, const float* c_kld, const float* dfpin_y, int64_t ld1,
+                            const float* dz3in_y, int64_t ld2, int32_t R, int32_t B, int32_t Y, float* dlogit,
+                            int64_t ldd, float* cfp, dv_stream_t stream) {
+    DV_REQUIRE(R >= 0 && B >= 1 && Y >= 1);
+    if (R == 0) return DV_OK;
+    DV_REQUIRE(has_y && ((cfp && c_kld) || (mu && ylab && c_yl && dfpin_y && dz3in_y && dlogit)));
+    hipLaunchKernelGGL(ycont_bwd_kernel, dim3((R + 255) / 256), dim3(256), 0, ST(stream), mu, ldm, ylab, has_y, logvar,
+                       c_yl, c_kld, dfpin_y, ld1, dz3in_y, ld2, R, B, Y, dlogit, ldd, cfp, dlogit == nullptr ? 1 : 0);
     DV_RETURN_LAUNCH();
 }
 

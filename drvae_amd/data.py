@@ -192,6 +192,8 @@ class DeviceBatcher:
         K.rows_gather(p.XSRC[:p.B], self.ds.x1, self._idx32)
         if self.engine.cfg.has_pert:
             K.rows_gather(p.XSRC[p.B:], self.ds.x2, self._idx32)
-        if self.engine.cfg.has_y:
+        if self.engine.cfg.has_y and self.engine.cfg.cont:
+            p.ylab.copy_(self.ds.y.reshape(len(self.ds), -1)[idx].float())
+        elif self.engine.cfg.has_y:
             p.set_labels_device(self.ds.y.reshape(-1)[idx])
         return idx

@@ -65,6 +65,11 @@ class StepConfig:
     optim_alg: str = 'adam'
     prior_y: Optional[Tuple[float, ...]] = None    # None = 'uniform' (src/DrVAE.py:386-389)
     clf_1sig: bool = False                          # two classes from one sigmoid output (src/DrVAE.py:160-163)
+    type_y: str = 'discrete'                        # 'cont': regression head N(sigmoid(.), 0.05^2) (src/DrVAE.py:167-169)
+
+    @property
+    def cont(self):
+        return self.type_y == 'cont'
 
     @property
     def top_name(self):
@@ -117,12 +122,28 @@ def param_shapes(cfg):
         out['decoder_z2Fz1.encoder_lv.linear_lv.bias'] = (Z1,)
     if cfg.has_y:
         n_in = 2 * Z1 if (cfg.kind == 'drvae' and cfg.clf_z1z2) else Z1
-        n = trunk('encoder_y.nnet', n_in, cfg.h_clf)
-        lin('encoder_y.decoder_p.linear_p', n, 1 if cfg.clf_1sig else Y)
+        if cfg.cont:
+            gauss('encoder_y', n_in, cfg.h_clf, Y)
+        else:
+            n = trunk('encoder_y.nnet', n_in, cfg.h_clf)
+            lin('encoder_y.decoder_p.linear_p', n, 1 if cfg.clf_1sig else Y)
         gauss(cfg.top_name, Z1 + Y, cfg.h_en_z3, Z3)
         gauss('decoder_z1', Z3 + Y, cfg.h_de_z1, Z1)
     gauss('decoder_x', Z1, cfg.h_de_x, X, second='sg')
     return out
+
+
+Y_LOGVAR_CONT = math.log(0.05 ** 2)      # fixed variance of the regression head (src/DrVAE.py:168)
+
+
+def frozen_params(cfg):
+    """parameters that exist in the state_dict but never receive a gradient (torch's Adam then skips
+    them entirely -- no weight decay either): the log-variance head of the fixed-variance regression
+    classifier (src/blocks.py:297-298)"""
+    if cfg.has_y and cfg.cont:
+        q = 'encoder_y.encoder_lv.linear_lv'
+        return tuple([q + '.weight', q + '.bias'] + ([q + '.g'] if cfg.weight_norm else []))
+    return ()
 
 
 def _pad4(n):
@@ -374,11 +395,12 @@ class FusedStep:
             for i in range(1, len(cfg.h_clf) + 1):
                 q = 'encoder_y.nnet.model.linear%d' % i
                 layers.append(_Lin(a, q + '.weight', q + '.bias', q + '.g' if wn else None, act=cfg.nonlin))
-            q = 'encoder_y.decoder_p.linear_p'
-            layers.append(_Lin(a, q + '.weight', q + '.bias', q + '.g' if wn else None))
+            q = 'encoder_y.encoder_mu.linear_mu' if cfg.cont else 'encoder_y.decoder_p.linear_p'
+            layers.append(_Lin(a, q + '.weight', q + '.bias', q + '.g' if wn else None,
+                               act='sigmoid' if cfg.cont else 'identity'))
             self.L_clf = layers
             # single Linear with <= 8 classes: dedicated wave-per-row kernels instead of MFMA tiles
-            self.clf_small = (not cfg.h_clf) and cfg.dim_y <= 8 and not wn and not cfg.clf_1sig and \
+            self.clf_small = (not cfg.h_clf) and cfg.dim_y <= 8 and not wn and not cfg.clf_1sig and not cfg.cont and \
                 os.environ.get('DRVAE_CLF_SMALL', '1') != '0'
             self.L_top = self._gauss(cfg.top_name, len(cfg.h_en_z3), 'lv', shift_second=-2.0)
             self.L_dz1 = self._gauss('decoder_z1', len(cfg.h_de_z1), 'lv', shift_second=-2.0)
@@ -424,7 +446,11 @@ class FusedStep:
         p.XSRC[:p.B].copy_(x1.index_select(0, sel) if sel is not None else x1)
         if x2 is not None and cfg.has_pert:
             p.XSRC[p.B:].copy_(x2.index_select(0, sel) if sel is not None else x2)
-        if cfg.has_y:
+        if cfg.has_y and cfg.cont:
+            yv = np.asarray(y.cpu() if torch.is_tensor(y) else y).astype(np.float32).reshape(n_in, -1) \
+                if y is not None else np.zeros((n_in, cfg.dim_y), np.float32)
+            p.ylab.copy_(torch.from_numpy(np.ascontiguousarray(yv[rows])))
+        elif cfg.has_y:
             yv = np.asarray(y.cpu() if torch.is_tensor(y) else y).astype(np.int64).reshape(-1) if y is not None \
                 else np.zeros(n_in, np.int64)
             p.set_labels_host(yv[rows])
@@ -448,6 +474,8 @@ class FusedStep:
         if cfg.has_y and p.Mf:
             ez3 = np.asarray(noise['ez3'])
             p.E3.copy_(t(ez3[p.fp_l_host, p.fp_slot_host, rows[p.fp_i_host]]))
+        if cfg.has_y and cfg.cont:
+            p.EY.copy_(t(np.asarray(noise['ey'])[:, rows].reshape(L * p.B, -1)))
 
     def draw_noise(self):
         """Fresh on-device N(0,1) for every draw of the step (Philox, one launch)."""
@@ -508,6 +536,30 @@ class FusedStep:
             the perturbation function has run; ``mid`` then waits for the z2Fz1 samples"""
             if cfg.kind == 'pvae':
                 K.kl_rows_fwd(p.KLP, p.KLPraw, Qmu, Qlv, prior=(0.0, 0.0), free_bits=True, kl_min=cfg.kl_min)
+            if cfg.has_y and cfg.cont:
+                # regression head (src/DrVAE.py:159-169,503-530): q(y|.) first -- the fprop of an unlabeled
+                # row conditions on a SAMPLE of it -- then one fprop row per classifier row
+                if mid is not None:
+                    mid()
+                if cfg.has_pert and Np:
+                    P2 = p.c_z2F.out[-1]
+                    K.kl_rows_fwd(p.KLZ2, p.KLZ2raw, Qmu, Qlv, P2[:, :Z1], P2[:, Z1:], qidx=p.qz2_idx, pidx=p.pidx,
+                                  reps=L, free_bits=True, kl_min=cfg.kl_min)
+                Z3, Y = cfg.dim_z3, cfg.dim_y
+                if cfg.kind == 'drvae':
+                    clf_in = [Z1blk, p.D] if cfg.clf_z1z2 else [p.Z2F]
+                else:
+                    clf_in = [Z1blk]
+                QYm = p.c_clf.forward(clf_in)                         # sigmoid-constrained means
+                K.rows_gather(p.FPIN[:, :Z1], Z1blk, p.fp_src)
+                K.ycont_fwd(p.YLrow, p.FPIN[:, Z1:], p.Z3IN[:, Z3:], QYm, p.ylab, p.has_y_i32, p.EY, Y_LOGVAR_CONT, B)
+                Q3 = p.c_top.forward([p.FPIN])
+                K.kl_rows_fwd(p.KL3, p.KL3raw, Q3[:, :Z3], Q3[:, Z3:], prior=(0.0, 0.0), free_bits=True,
+                              kl_min=cfg.kl_min, eps=p.E3, zout=p.Z3IN[:, :Z3])
+                PZ1 = p.c_dz1.forward([p.Z3IN])
+                K.kl_rows_fwd(p.KLDrow, p.KL1raw, Qmu, Qlv, PZ1[:, :Z1], PZ1[:, Z1:], qidx=p.fp_q, free_bits=True,
+                              kl_min=cfg.kl_min, add=p.KL3)
+                return
             # ---- fprop over (labeled: true class | unlabeled: every class)
             if cfg.has_y:
                 if p.Mf:
@@ -612,7 +664,28 @@ class FusedStep:
         def side_backward():
             if self.fuse_bwd and mode < 2:
                 self._loss_scalars()         # leaf work, off the critical path
-            if cfg.has_y:
+            if cfg.has_y and cfg.cont:
+                Y, Z3 = cfg.dim_y, cfg.dim_z3
+                PZ1, Q3, QYm = p.c_dz1.out[-1], p.c_top.out[-1], p.c_clf.out[-1]
+                K.ycont_bwd(None, p.CFP, QYm, p.ylab, p.has_y_i32, Y_LOGVAR_CONT, p.c_yl, p.c_kld, p.DFPIN[:, Z1:],
+                            p.DZ3IN[:, Z3:], B)                    # cfp[r] = c_kld[r]: one fprop row per row
+                K.kl_rows_bwd(p.DQFP[:, :Z1], p.DQFP[:, Z1:], p.DPZ1[:, :Z1], p.DPZ1[:, Z1:], p.CFP, p.KL1raw,
+                              Qmu, Qlv, PZ1[:, :Z1], PZ1[:, Z1:], qidx=p.fp_q, free_bits=True, kl_min=cfg.kl_min)
+                p.c_dz1.backward(p.DPZ1, [p.Z3IN], [[(p.DZ3IN, 1.0, 0.0)]])
+                K.kl_rows_bwd(p.DQ3[:, :Z3], p.DQ3[:, Z3:], None, None, p.CFP, p.KL3raw, Q3[:, :Z3], Q3[:, Z3:],
+                              prior=(0.0, 0.0), free_bits=True, kl_min=cfg.kl_min, dz=p.DZ3IN[:, :Z3], eps=p.E3)
+                p.c_top.backward(p.DQ3, [p.FPIN], [[(p.DFPIN, 1.0, 0.0)]])
+                K.rows_segment_sum(p.DZ1B, p.DFPIN, seg_ptr=p.fp_ptr, beta=0.0, width=Z1)
+                # the y columns of both fprop inputs carry d/d(y sample); labeled rows: the log-likelihood
+                K.ycont_bwd(p.DLOG, None, QYm, p.ylab, p.has_y_i32, Y_LOGVAR_CONT, p.c_yl, p.c_kld, p.DFPIN[:, Z1:],
+                            p.DZ3IN[:, Z3:], B)
+                if cfg.kind == 'drvae' and cfg.clf_z1z2:
+                    p.c_clf.backward(p.DLOG, [Z1blk, p.D], [[(p.DZ1B, 1.0, 1.0)], [(p.DZ2F, 1.0, 0.0), (p.DZ1B, -1.0, 1.0)]])
+                elif cfg.kind == 'drvae':
+                    p.c_clf.backward(p.DLOG, [p.Z2F], [[(p.DZ2F, 1.0, 0.0)]])
+                else:
+                    p.c_clf.backward(p.DLOG, [Z1blk], [[(p.DZ1B, 1.0, 1.0)]])
+            elif cfg.has_y:
                 Y = cfg.dim_y
                 K.ymarg_bwd(p.CFP, p.DQY, p.QY, p.label_r, p.fp_ptr, p.KLFP, p.log_prior, p.c_kld, p.c_yl)
                 if p.Mf:
@@ -745,7 +818,8 @@ class FusedStep:
         if self._rec == 'both' and self.sched == 5:
             K.counter_add(self.side_ctr, 1)      # eager step: the side chain's counter follows
         step = K.adamax_l2 if cfg.optim_alg == 'adamax' else K.adam_l2    # exp_avg_sq doubles as Adamax's exp_inf
-        step(a.param, a.grad[:a.n_params], a.exp_avg, a.exp_avg_sq, self.step_dev, lr=cfg.learning_rate,
+        n = a.n_live                      # parameters without gradients sit behind it (untouched, like torch)
+        step(a.param[:n], a.grad[:n], a.exp_avg[:n], a.exp_avg_sq[:n], self.step_dev, lr=cfg.learning_rate,
              weight_decay=cfg.weight_decay, gscale=gscale)
 
     def train_step(self, noise=None, allreduce=None):
@@ -1112,13 +1186,15 @@ class _Plan:
         # fprop rows
         self.Mf = 0
         if cfg.has_y:
-            nf_row = np.where(has_y, 1, Y)                   # fprop rows per data row (per sample l)
+            # fprop rows per data row (per sample l): true class | every class; the regression head always
+            # conditions on ONE y (the target, or a sample of q(y|.))
+            nf_row = np.ones(B, np.int64) if cfg.cont else np.where(has_y, 1, Y)
             fp_ptr = np.concatenate([[0], np.cumsum(np.tile(nf_row, L))])
             self.Mf = int(fp_ptr[-1])
             fl, fi, fslot, fcls = [], [], [], []
             for l in range(L):
                 for i in range(B):
-                    if has_y[i]:
+                    if has_y[i] or cfg.cont:
                         fl.append(l); fi.append(i); fslot.append(0); fcls.append(0)
                     else:
                         for j in range(Y):
@@ -1141,6 +1217,8 @@ class _Plan:
             self.fp_slot_dev = i32(self.fp_slot_host)
             self.has_y_i32, self.fp_lab_i32 = i32(has_y), i32(self._fp_lab_host)
             sizes.append(self.Mf * Z3)
+            if cfg.cont:
+                sizes.append(L * B * Y)                      # eps of the y samples (unlabeled rows use them)
         self.noise = zf(int(sum(sizes)))
         views, o = [], 0
         for s in sizes:
@@ -1152,6 +1230,7 @@ class _Plan:
         self.E12 = self.noise[sizes[0]:sizes[0] + sizes[1] + sizes[2]].view(L * B + L * Np, Z1)
         self.E2F = views[3].view(L * B, Z1) if cfg.has_pert else None
         self.E3 = views[4].view(self.Mf, Z3) if cfg.has_y else None
+        self.EY = views[5].view(L * B, Y) if (cfg.has_y and cfg.cont) else None
         # ---- activations / gradients
         self.XIN = mat(Me, X)
         self.ZDEC, self.DZDEC = mat(Md, Z1), mat(Md, Z1)
@@ -1172,6 +1251,7 @@ class _Plan:
             R, Mf = L * B, self.Mf
             self.c_clf = _Chain(eng.L_clf, R, dev)
             self.QY, self.DQY, self.DLOG = zf(R, Y), zf(R, Y), zf(R, 1 if cfg.clf_1sig else Y)
+            self.ylab = zf(B, Y)                            # regression targets (type_y='cont')
             # log p(y): the uniform prior as a scalar, a class prior given as data as a device vector
             self.log_prior = math.log(1.0 / Y) if cfg.prior_y is None else \
                 torch.log(torch.tensor(cfg.prior_y, dtype=torch.float64)).float().to(dev)

@@ -78,7 +78,7 @@ class FitMixin:
     # ------------------------------------------------------------------ metrics
     def eval_y_prediction(self, pred, proba, ylab):
         if getattr(self, 'type_y', 'discrete') != 'discrete':
-            raise NotImplementedError("type_y='cont'")
+            return MET.eval_y_regression(pred, ylab)
         return MET.eval_y_prediction(pred, proba, ylab, self.dim_y)
 
     def _np(self, t):
@@ -111,11 +111,16 @@ class FitMixin:
         parts = []
         if kind != 'pvae':
             yidx = torch.nonzero(has_y.reshape(-1)).reshape(-1)
-            ylab = y.reshape(-1)[yidx]
+            cont = getattr(self, 'type_y', 'discrete') != 'discrete'
+            ylab = y.reshape(y.shape[0], -1)[yidx] if cont else y.reshape(-1)[yidx]
             for k, v in self.eval_y_prediction(res['pred'][yidx], res['proba'][yidx], ylab).items():
                 perf['y_' + k] = v
-            parts.append('Y: Accuracy: {:.3f}% AUROC: {:.3f} AUPR: {:.3f}'.format(
-                perf['y_acc'] * 100., perf['y_auroc'], perf['y_aupr']))
+            if cont:
+                parts.append('Y: RMSE: {:.3f} R2: {:.3f} Pearson: {:.3f}'.format(perf['y_rmse'], perf['y_r2'],
+                                                                                 perf['y_pearr']))
+            else:
+                parts.append('Y: Accuracy: {:.3f}% AUROC: {:.3f} AUPR: {:.3f}'.format(
+                    perf['y_acc'] * 100., perf['y_auroc'], perf['y_aupr']))
         for k, v in self.eval_x_reconstruction(x1, *res['px1']).items():
             perf['x1_' + k] = v
         parts.append('X1: ' + _REC.format(perf['x1_rmse'], perf['x1_r2'], perf['x1_pearr']))
@@ -184,7 +189,10 @@ class FitMixin:
         """what early stopping maximises (src/DrVAE.py:822-825, src/PVAE.py:617, src/VFAE.py:600-603)"""
         if self.kind == 'pvae':
             return perf['x1_pearr'] + perf['x2_pearr']
-        v = perf['y_auroc'] + perf['y_aupr'] + perf['x1_pearr']
+        if getattr(self, 'type_y', 'discrete') != 'discrete':         # src/DrVAE.py:824-825
+            v = perf['y_r2'] + perf['y_pearr'] + perf['x1_pearr']
+        else:
+            v = perf['y_auroc'] + perf['y_aupr'] + perf['x1_pearr']
         return v + perf['x2_pearr'] if self.kind == 'drvae' else v
 
     def _batch_kwargs(self, batch):
@@ -212,14 +220,19 @@ class FitMixin:
         batcher.bind(eng, counts=getattr(self, '_global_counts', None))
         eng.add_noise = bool(self.add_noise)
         eng.iters = self.finished_training_iters
-        batcher.begin_epoch()               # this epoch's index table; the graph gathers batch b itself
+        resident_feed = not eng.cfg.cont    # (regression targets are fed per step: the feed kernel moves int labels)
+        if resident_feed:
+            batcher.begin_epoch()           # this epoch's index table; the graph gathers batch b itself
+        else:
+            batcher.feed()
         if getattr(eng, '_graph_key', None) != eng.plan.key or getattr(eng, '_graph_noise', None) != eng.add_noise \
                 or getattr(eng, '_graph_feed', None) is not eng.plan.feed:
             eng.capture(split_for_allreduce=getattr(self, '_allreduce', None) is not None)
             eng._graph_noise = eng.add_noise
             if getattr(self, '_allreduce', None) is None:
                 eng.tune_partition()        # CU split of the two launch chains, by timing (state restored)
-            batcher.begin_epoch()           # (the tuning replays advanced the step counter: re-base the table)
+            if resident_feed:
+                batcher.begin_epoch()       # (the tuning replays advanced the step counter: re-base the table)
         with eng.partition():
             return self._epoch_device_body(eng, batcher, epoch, verbose)
 
@@ -228,6 +241,8 @@ class FitMixin:
         every = max(10, n_b / 10)
         total = torch.zeros((), device=eng.dev)
         for b in range(n_b):
+            if eng.plan.feed is None:
+                batcher.feed()
             eng.replay(allreduce=getattr(self, '_allreduce', None))
             loss = self._loss_tensors(eng)
             total += self._train_objective(loss)

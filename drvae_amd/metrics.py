@@ -56,6 +56,20 @@ def macro(metric, labels, proba):
     return float('nan') if any(math.isnan(v) for v in vals) else sum(vals) / len(vals)
 
 
+def eval_y_regression(pred, ylab):
+    """dict(rmse, r2, pearr) for a continuous target (src/DGMMixin.py:181-188: numpy / sklearn r2_score /
+    scipy pearsonr on the flattened vectors), in float64 where the tensors live"""
+    y = ylab.reshape(-1).double()
+    p = pred.reshape(-1).double()
+    out = dict(rmse=float(torch.sqrt(((y - p) ** 2).mean())))
+    ss_tot = ((y - y.mean()) ** 2).sum()
+    out['r2'] = float(1.0 - ((y - p) ** 2).sum() / ss_tot) if float(ss_tot) > 0 else float('nan')
+    yc, pc = y - y.mean(), p - p.mean()
+    den = torch.sqrt((yc ** 2).sum() * (pc ** 2).sum())
+    out['pearr'] = float((yc * pc).sum() / den) if float(den) > 0 else float('nan')
+    return out
+
+
 def eval_y_prediction(pred, proba, ylab, dim_y):
     """dict(acc, auroc, aupr) for a discrete target (src/DGMMixin.py:163-180)."""
     ylab = ylab.reshape(-1)

@@ -276,6 +276,21 @@ int dv_ymarg_bwd(const float* qy, int64_t ldq, const int32_t* label, const int32
                  float log_prior, const float* log_prior_v, const float* c_kld, const float* c_yl, int32_t R,
                  int32_t Y, float* cfp, float* dqy, int64_t lddq, dv_stream_t stream);
 
+/* Regression head (`type_y='cont'`, src/DrVAE.py:159-169,503-530): q(y|.) = N(sigmoid(.), fixed var).
+ * Per classifier row r=(l,i), i = r % B:
+ *   labeled   (has_y[i]): yl[r] = log N(ylab[i,:]; mu[r,:], var);  yv = ylab[i,:]
+ *   unlabeled            : yl[r] = 0;                               yv = mu + sd*eps[r,:]   (SGVB sample)
+ * yv is written into the y columns of both fprop inputs (fpin_y, z3in_y point at column Z of [z | y]).
+ * backward: dlogit = dmu * mu(1-mu) with dmu = c_yl*(y-mu)/var (labeled) or the sum of the gradients of
+ * the two y columns (unlabeled); called with dlogit == NULL it only writes cfp[r] = c_kld[r]. */
+int dv_ycont_fwd(const float* mu, int64_t ldm, const float* ylab, const int32_t* has_y, const float* eps, int64_t lde,
+                 float logvar, int32_t R, int32_t B, int32_t Y, float* yl, float* fpin_y, int64_t ld1,
+                 float* z3in_y, int64_t ld2, dv_stream_t stream);
+int dv_ycont_bwd(const float* mu, int64_t ldm, const float* ylab, const int32_t* has_y, float logvar,
+                 const float* c_yl, const float* c_kld, const float* dfpin_y, int64_t ld1, const float* dz3in_y,
+                 int64_t ld2, int32_t R, int32_t B, int32_t Y, float* dlogit, int64_t ldd, float* cfp,
+                 dv_stream_t stream);
+
 /* ------------------------------------------------------------- row movement
  * out[r,:W] = src[idx?idx[r]:r, :W] (+ sigma*noise[r,:W])  -- the group gathers of
  *   src/DrVAE.py:585-608 and the training-noise augmentation of src/DrVAE.py:404-407

@@ -55,6 +55,7 @@ class ModelSpec:
     optim_alg: str = 'adam'             # 'adam' | 'adamax' (DGMMixin.py:35-38)
     prior_y: Optional[List[float]] = None   # None = 'uniform'; else class prior of length dim_y (DrVAE.py:83-85)
     clf_1sig: bool = False              # 2 classes from ONE sigmoid output (DrVAE.py:160-163)
+    type_y: str = 'discrete'            # 'discrete' | 'cont' (regression head, DrVAE.py:159-169)
     top_name: str = ''                  # filled in __post_init__
 
     def __post_init__(self):
@@ -92,8 +93,11 @@ def param_shapes(spec):
         out['decoder_z2Fz1.encoder_lv.linear_lv.bias'] = (Z1,)
     if spec.kind in ('drvae', 'vfae'):
         n_clf_in = 2 * Z1 if (spec.kind == 'drvae' and spec.clf_z1z2) else Z1
-        n = mlp('encoder_y.nnet', n_clf_in, spec.h_clf)
-        lin('encoder_y.decoder_p.linear_p', n, 1 if spec.clf_1sig else Y)
+        if spec.type_y == 'cont':        # DiagGaussianModule(fixed_variance=0.05**2, constrain_means=True), DrVAE.py:167-169
+            gauss('encoder_y', n_clf_in, spec.h_clf, Y)
+        else:
+            n = mlp('encoder_y.nnet', n_clf_in, spec.h_clf)
+            lin('encoder_y.decoder_p.linear_p', n, 1 if spec.clf_1sig else Y)
         gauss(spec.top_name, Z1 + Y, spec.h_en_z3, Z3)
         gauss('decoder_z1', Z3 + Y, spec.h_de_z1, Z1)
     gauss('decoder_x', Z1, spec.h_de_x, X, second='sg')
@@ -135,6 +139,7 @@ def make_noise(spec, n_rows, seed=7):
         'nx1': f(n_rows, spec.dim_x), 'nx2': f(n_rows, spec.dim_x),
         'ez1': f(L, n_rows, spec.dim_z1), 'ez2': f(L, n_rows, spec.dim_z1),
         'ez2F': f(L, n_rows, spec.dim_z1), 'ez3': f(L, Y, n_rows, spec.dim_z3),
+        'ey': f(L, n_rows, Y),          # regression head only: the y sample of unlabeled rows (DrVAE.py:528-529)
     }
 
 
@@ -222,8 +227,9 @@ def _group_losses(spec, p, acc, idx, x1, x2, y, noise, iters, training):
         if training and spec.add_noise_var > 0.:      # DrVAE.py:414-417
             x2 = x2 + nz('nx2') * spec.add_noise_var
         qz2 = B.diag_gaussian([x2], p, 'encoder_z1', nh1, spec.nonlin)   # same encoder, DrVAE.py:418
+    cont = spec.type_y == 'cont'
     if has_y and labeled:
-        y1hot = B.one_hot(y, spec.dim_y)
+        y1hot = y.float().reshape(n, -1) if cont else B.one_hot(y, spec.dim_y)      # DrVAE.py:511-515
 
     for l in range(L):
         z1 = B.sample_logvar(qz1[0], qz1[1], nz('ez1', l))
@@ -256,6 +262,17 @@ def _group_losses(spec, p, acc, idx, x1, x2, y, noise, iters, training):
             clf_in = [z1, z2F - z1] if spec.clf_z1z2 else [z2F]           # DrVAE.py:495-498
         else:
             clf_in = [z1]                                                  # VFAE.py:325
+        if cont:
+            qy = B.diag_gaussian(clf_in, p, 'encoder_y', nhc, spec.nonlin, constrain_means=True,
+                                 fixed_variance=0.05 ** 2)
+            if labeled:
+                acc.add('YL', idx, B.logp_logvar_rows(y1hot, *qy), 1. / Lf)          # DrVAE.py:506
+                kld = _fprop(spec, p, z1, qz1, y1hot, nz('ez3', l, 0))
+            else:       # SGVB: sample y (DrVAE.py:527-530); the log-prior term only exists for a data prior
+                ys = B.sample_logvar(qy[0], qy[1], nz('ey', l))
+                kld = _fprop(spec, p, z1, qz1, ys, nz('ez3', l, 0))
+            acc.add('KLD', idx, kld, 1. / Lf)
+            continue
         qy = B.categorical(clf_in, p, 'encoder_y', nhc, spec.nonlin, 1 if spec.clf_1sig else spec.dim_y)
         if labeled:
             acc.add('YL', idx, B.categorical_logp_rows(y, qy), 1. / Lf)   # DrVAE.py:506

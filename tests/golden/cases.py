@@ -159,6 +159,9 @@ def y_metric_cases():
     lg = rs.standard_normal((n, 3)) + 1.5 * np.eye(3)[y3]
     p3 = (np.exp(lg) / np.exp(lg).sum(1, keepdims=True)).astype(np.float32)
     out['Y3'] = dict(ylab=y3, proba=p3, pred=p3.argmax(1).astype(np.int64))
+    yc = rs.rand(n).astype(np.float32)
+    out['Ycont'] = dict(ylab=yc, pred=(0.6 * yc + 0.2 + 0.15 * rs.standard_normal(n)).astype(np.float32)[:, None],
+                        proba=np.full((n, 1), np.log(0.05 ** 2), np.float32), cont=True)
     out['Y2oneclass'] = dict(ylab=np.ones(9, np.int64), proba=out['Y2']['proba'][:9].copy(),
                              pred=out['Y2']['pred'][:9].copy())
     return out
@@ -189,6 +192,7 @@ MODEL_CASES = OrderedDict([
     ('tiny_drvae_prior', (lambda: tiny_spec('drvae', dim_y=3, prior_y=[0.2, 0.5, 0.3]), 'abdbcdabbdac', 2, True)),
     ('tiny_drvae_1sig', (lambda: tiny_spec('drvae', clf_1sig=True, h_clf=[3]), 'cadbcabdbca', 2, True)),
     ('tiny_vfae_prior_1sig', (lambda: tiny_spec('vfae', clf_1sig=True, prior_y=[0.7, 0.3]), 'abbabaabbb', 2, True)),
+    ('tiny_drvae_cont', (lambda: tiny_spec('drvae', type_y='cont', dim_y=1), 'acbdaabcdbacab', 3, True)),
     ('tiny_pvae', (lambda: tiny_spec('pvae'), 'bdbbdddbdb', 3, True)),
     ('tiny_vfae', (lambda: tiny_spec('vfae', dim_y=3), 'abbabaabbb', 3, True)),
     ('tiny_vfae_sup', (lambda: tiny_spec('vfae', semi_supervised=False, add_noise_var=0.), 'aababaaa', 2, True)),
@@ -218,5 +222,7 @@ def model_case(name):
     else:
         n = rows
         batch = M.make_batch(spec, n, seed=1234)
+    if spec.type_y == 'cont':          # regression targets in (0,1) (the head's means are sigmoid-constrained)
+        batch['y'] = np.random.RandomState(seed + 2).rand(n, spec.dim_y).astype(np.float32)
     noises = [M.make_noise(spec, n, seed=seed + 100 + i) for i in range(steps)]
     return dict(name=name, spec=spec, batch=batch, noises=noises, param_seed=123, full=full)

@@ -117,8 +117,13 @@ def noise_queue(spec, batch, noise, training):
                     q.append(noise['ez2'][l][idx])
                 q.append(noise['ez2F'][l][idx])
             if spec.kind != 'pvae':
-                for j in range(1 if labeled else spec.dim_y):
-                    q.append(noise['ez3'][l][j][idx])
+                if spec.type_y == 'cont':
+                    if not labeled:
+                        q.append(noise['ey'][l][idx])
+                    q.append(noise['ez3'][l][0][idx])
+                else:
+                    for j in range(1 if labeled else spec.dim_y):
+                        q.append(noise['ez3'][l][j][idx])
     return q
 
 
@@ -133,7 +138,7 @@ def build_reference_model(spec, params):
                 anneal_perturb_rate_itermax=spec.anneal_perturb_rate_itermax,
                 anneal_perturb_rate_offset=spec.anneal_perturb_rate_offset)
     ycfg = dict(dim_h_de_z1=list(spec.h_de_z1), dim_h_clf=list(spec.h_clf), yloss_rate=spec.yloss_rate,
-                clf_1sig=spec.clf_1sig,
+                clf_1sig=spec.clf_1sig, type_y=spec.type_y,
                 prior_y='uniform' if spec.prior_y is None else np.asarray(spec.prior_y, np.float64))
     if spec.kind == 'drvae':
         cls, kw = rDrVAE.DrVAE, dict(common, dim_h_en_z3=list(spec.h_en_z3), dim_z3=spec.dim_z3,
@@ -189,7 +194,8 @@ def run_model_case(case):
             out['step%d/%s' % (step, k)] = np.float32(float(v))
         if step == 0:
             for k, prm in model.named_parameters():
-                g = prm.grad.detach().numpy()
+                # (a parameter the loss never touches has grad None: torch's Adam skips it entirely)
+                g = prm.grad.detach().numpy() if prm.grad is not None else np.zeros(tuple(prm.shape), np.float32)
                 if case['full']:
                     out['grad/' + k] = g.copy()
                 else:
@@ -435,9 +441,14 @@ def run_fit_cases():
         out[name + '/avg_train_loss'] = np.array(avg_train)
     # y-prediction metrics (DGMMixin.py:158-190): accuracy / AUROC / average precision, binary and macro
     for tag, c in C.y_metric_cases().items():
-        spec = C.tiny_spec('drvae', dim_y=c['proba'].shape[1])
+        spec = C.tiny_spec('drvae', dim_y=c['proba'].shape[1], type_y='cont' if c.get('cont') else 'discrete')
         model = build_reference_model(spec, M.init_params(spec, 1, as_numpy=True))
         args = (torch.from_numpy(c['pred']), torch.from_numpy(c['proba']), torch.from_numpy(c['ylab']))
+        if c.get('cont'):                   # regression metrics (DGMMixin.py:181-188)
+            res = model.eval_y_prediction(*args)
+            for k in ('rmse', 'r2', 'pearr'):
+                out['%s/%s' % (tag, k)] = np.float64(float(res[k]))
+            continue
         if c['proba'].shape[1] > 2:
             # the macro branch of the reference cannot run: DGMMixin.py:175-180 uses `blk`, which that
             # module never imports (AUROC: swallowed by its bare except -> nan; AUPR: NameError).  Pinned
@@ -460,7 +471,8 @@ def run_fit_cases():
 
 
 # ------------------------------------------------------------------ inference (N1)
-INFER_CASES = ('tiny_drvae', 'tiny_drvae_nolp', 'tiny_drvae_wn', 'tiny_pvae', 'tiny_vfae', 'cfg2_drvae', 'cfg4_vfae')
+INFER_CASES = ('tiny_drvae', 'tiny_drvae_nolp', 'tiny_drvae_wn', 'tiny_drvae_cont', 'tiny_drvae_1sig', 'tiny_pvae',
+               'tiny_vfae', 'cfg2_drvae', 'cfg4_vfae')
 
 
 def _flat(res):

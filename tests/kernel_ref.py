@@ -449,6 +449,28 @@ def ymarg_bwd(cfp, dqy, qy, label, fp_ptr, klfp, log_prior, c_kld, c_yl):
             dqy[r] = c_kld[r] * (klfp[sl] + qy[r].log() - log_prior + 1)
 
 
+def ycont_fwd(yl, fpin_y, z3in_y, mu, ylab, has_y, eps, logvar, B):
+    R, Y = mu.shape
+    i = torch.arange(R, device=mu.device) % B
+    lab = has_y[i].bool()
+    yv = torch.where(lab[:, None], ylab[i], mu + math.exp(0.5 * logvar) * eps[:, :Y])
+    ll = -0.5 * (LOG_2PI + logvar + (ylab[i] - mu) ** 2 / math.exp(logvar)).sum(1)
+    yl.copy_(torch.where(lab, ll, torch.zeros_like(ll)))
+    fpin_y[:, :Y] = yv
+    z3in_y[:, :Y] = yv
+
+
+def ycont_bwd(dlogit, cfp, mu, ylab, has_y, logvar, c_yl, c_kld, dfpin_y, dz3in_y, B):
+    R, Y = mu.shape
+    if dlogit is None:
+        cfp[:R] = c_kld[:R]
+        return
+    i = torch.arange(R, device=mu.device) % B
+    lab = has_y[i].bool()
+    dmu = torch.where(lab[:, None], c_yl[:, None] * (ylab[i] - mu) / math.exp(logvar), dfpin_y[:, :Y] + dz3in_y[:, :Y])
+    dlogit[:, :Y] = dmu * mu * (1 - mu)
+
+
 def rows_gather(out, src, idx=None, *, noise=None, sigma=0.0, onehot_cls=None, n_classes=0, width=None):
     n = out.shape[0]
     W = (src.shape[1] if src is not None else 0) if width is None else width
@@ -583,7 +605,7 @@ def fill_normal(out, seed, ctr_dev=None):
     out.copy_(torch.randn(out.shape, generator=g).to(out.device))
 
 
-FUNCTIONS = ['adamax_l2', 'batch_feed', 'flag_publish', 'flag_wait', 'gemm', 'linear_fwd', 'linear_bwd_data', 'linear_bwd_weight', 'linear_bwd_pair', 'colsum', 'act_bwd_', 'wn_scale', 'wn_bwd',
+FUNCTIONS = ['adamax_l2', 'batch_feed', 'ycont_fwd', 'ycont_bwd', 'flag_publish', 'flag_wait', 'gemm', 'linear_fwd', 'linear_bwd_data', 'linear_bwd_weight', 'linear_bwd_pair', 'colsum', 'act_bwd_', 'wn_scale', 'wn_bwd',
              'reparam_fwd', 'reparam_bwd', 'reparam_bwd_seg', 'z2f_post_bwd', 'kl_rows_fwd', 'kl_rows_bwd', 'nll_rows_fwd', 'nll_rows_bwd', 'nll_rows_fwdbwd',
              'softmax_clamp_fwd', 'softmax_clamp_bwd', 'cat_terms_fwd', 'cat_terms_bwd', 'smalln_fwd', 'smalln_bwd_data',
              'smalln_bwd_weight', 'ymarg_fwd', 'ymarg_bwd',

@@ -17,7 +17,7 @@ def make_engine(spec, params, device='cpu'):
     cfg = E.StepConfig(**{k: getattr(spec, k) for k in E.StepConfig.__dataclass_fields__ if hasattr(spec, k)})
     shapes = E.param_shapes(cfg)
     assert list(shapes.items()) == [(k, tuple(v)) for k, v in M.param_shapes(spec).items()]
-    arena = ParamArena(shapes, device)
+    arena = ParamArena(shapes, device, frozen=E.frozen_params(cfg))
     arena.load(params)
     return E.FusedStep(cfg, arena), arena
 

@@ -52,6 +52,11 @@ def test_early_stopping_matches_reference_fit(G, name):
 def test_y_metrics_match_reference(G, tag):
     from drvae_amd import metrics as MET
     c = C.y_metric_cases()[tag]
+    if c.get('cont'):
+        got = MET.eval_y_regression(torch.from_numpy(c['pred']), torch.from_numpy(c['ylab']))
+        for k in ('rmse', 'r2', 'pearr'):
+            assert got[k] == pytest.approx(float(G['%s/%s' % (tag, k)]), rel=1e-6)
+        return
     got = MET.eval_y_prediction(torch.from_numpy(c['pred']), torch.from_numpy(c['proba']),
                                 torch.from_numpy(c['ylab']), c['proba'].shape[1])
     for k in ('acc', 'auroc', 'aupr'):
@@ -150,6 +155,34 @@ def test_fit_end_to_end_cpu(kind, monkeypatch, tmp_path):
     model.load_params_from_file(fn)
 
 
+def _cont_dataset(n, seed, device='cpu'):
+    from drvae_amd import data as D
+    ds = _tiny_dataset('drvae', n, seed, device)
+    rs = np.random.RandomState(seed + 10)
+    ycont = (0.5 + 0.3 * np.tanh(ds.x1.cpu().numpy()[:, 0]) + 0.05 * rs.standard_normal(n)).clip(0.02, 0.98)
+    return D.DrVAEDataset(ds.x1, ds.x2, ds.s, torch.from_numpy(ycont.astype(np.float32)).to(device), ds.has_x2, ds.has_y)
+
+
+def test_fit_regression_head_cpu(monkeypatch, tmp_path):
+    """type_y='cont' (src/DrVAE.py:159-169): sigmoid-constrained Gaussian head, RMSE/R2/Pearson report"""
+    kernel_ref.install(monkeypatch)
+    model = _tiny_model('drvae', device='cpu', type_y='cont', dim_y=1, epochs=4)
+    logs = []
+    model.w2log = lambda *a: logs.append(' '.join(str(e) for e in a))
+    tr, va = _cont_dataset(40, 1), _cont_dataset(24, 2)
+    perf0, _ = model.evaluate_performance_on_dataset(va)
+    lv0 = model.encoder_y.encoder_lv.linear_lv.weight.detach().clone()
+    model.fit(_loader(tr, 8), _loader(va, 8), add_noise=True, early_stop=True, model_filename=str(tmp_path / 'b.pth'))
+    perf1, txt = model.evaluate_performance_on_dataset(va, return_full_data=True)
+    assert {'y_rmse', 'y_r2', 'y_pearr', 'y_wI_rmse', 'pred', 'proba'} <= set(perf1) and 'y_acc' not in perf1
+    assert txt.startswith('Y: RMSE:') and perf1['y_rmse'] < perf0['y_rmse']
+    assert np.allclose(perf1['proba'], np.log(0.05 ** 2))             # the fixed log-variance
+    # the unused log-variance head is in the state_dict but never updated (torch's Adam skips grad-less params)
+    assert torch.equal(lv0, model.encoder_y.encoder_lv.linear_lv.weight.detach())
+    with pytest.raises(NotImplementedError):
+        _tiny_model('vfae', device='cpu', type_y='cont', dim_y=1)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('kind', ['drvae', 'pvae', 'vfae'])
 def test_fit_device_batcher_gpu(kind, tmp_path):
@@ -166,6 +199,13 @@ def test_fit_device_batcher_gpu(kind, tmp_path):
     assert perf1['x1_rmse'] < perf0['x1_rmse'] and np.isfinite(float(perf1['losses']['ELBO']))
     assert os.path.exists(fn)
     # same protocol through the tuple-loader path gives a working model too
+    if kind == 'drvae':          # regression head through the device batcher (targets fed per step)
+        mc = _tiny_model('drvae', device='cuda', type_y='cont', dim_y=1, epochs=3)
+        trc, vac = _cont_dataset(64, 1, 'cuda'), _cont_dataset(32, 2, 'cuda')
+        p0, _ = mc.evaluate_performance_on_dataset(vac)
+        mc.fit(D.DeviceBatcher(trc, w, 16, seed=3), _loader(vac, 8), add_noise=True, early_stop=True, model_filename=fn)
+        p1, _ = mc.evaluate_performance_on_dataset(vac)
+        assert mc.finished_training_iters == 3 * 4 and p1['y_rmse'] < p0['y_rmse']
     m2 = _tiny_model(kind, device='cuda', epochs=2)
     m2.fit(_loader(tr, 16), _loader(va, 8), add_noise=False, early_stop=False, model_filename=fn)
     assert m2.finished_training_iters == 2 * 4

@@ -24,7 +24,8 @@ def build_model(spec, dev):
                 anneal_perturb_rate_itermax=spec.anneal_perturb_rate_itermax,
                 anneal_perturb_rate_offset=spec.anneal_perturb_rate_offset)
     ycfg = dict(dim_h_de_z1=list(spec.h_de_z1), dim_h_clf=list(spec.h_clf), yloss_rate=spec.yloss_rate,
-                clf_1sig=spec.clf_1sig, prior_y='uniform' if spec.prior_y is None else np.asarray(spec.prior_y))
+                clf_1sig=spec.clf_1sig, prior_y='uniform' if spec.prior_y is None else np.asarray(spec.prior_y),
+                type_y=spec.type_y)
     if spec.kind == 'drvae':
         return DrVAE(dim_h_en_z3=list(spec.h_en_z3), dim_z3=spec.dim_z3, clf_z1z2=spec.clf_z1z2, **common, **pert,
                      **ycfg)
@@ -44,7 +45,7 @@ def kwargs_for(spec, batch, dev):
 
 
 @pytest.mark.parametrize('name', ['tiny_drvae', 'tiny_drvae_nolp', 'tiny_drvae_wn', 'tiny_drvae_adamax', 'tiny_drvae_prior',
-                                  'tiny_drvae_1sig', 'tiny_vfae_prior_1sig', 'tiny_pvae', 'tiny_vfae',
+                                  'tiny_drvae_1sig', 'tiny_vfae_prior_1sig', 'tiny_drvae_cont', 'tiny_pvae', 'tiny_vfae',
                                   'tiny_vfae_sup', 'cfg2_drvae'])
 def test_run_on_batch_matches_reference(name, dev):
     case, gold = C.model_case(name), C.load('model_' + name)
