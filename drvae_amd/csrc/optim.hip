@@ -79,6 +79,24 @@ __global__ void counter_add_kernel(int32_t* c, int n_words, int64_t inc) {
     }
 }
 
+__global__ void counters_add2_kernel(int32_t* c1, int n1, int64_t inc1, int32_t* c2, int n2, int64_t inc2) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int32_t* cs[2] = {c1, c2};
+    const int ns[2] = {n1, n2};
+    const int64_t incs[2] = {inc1, inc2};
+    for (int t = 0; t < 2; ++t) {
+        int32_t* c = cs[t];
+        if (ns[t] == 1) {
+            c[0] = (int32_t)(c[0] + incs[t]);
+        } else {
+            uint64_t v = ((uint64_t)(uint32_t)c[1] << 32) | (uint32_t)c[0];
+            v += (uint64_t)incs[t];
+            c[0] = (int32_t)(uint32_t)v;
+            c[1] = (int32_t)(uint32_t)(v >> 32);
+        }
+    }
+}
+
 // ------------------------------------------------------------------ Philox4x32-10
 __device__ __forceinline__ void philox_round(uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3, uint32_t k0,
                                              uint32_t k1) {
@@ -228,6 +246,13 @@ extern "C" int dv_flag_wait(int32_t* flag, const int32_t* ctr, int32_t add, int3
 extern "C" int dv_counter_add(int32_t* counter_lo_hi, int32_t n_words, int64_t inc, dv_stream_t stream) {
     DV_REQUIRE(counter_lo_hi && (n_words == 1 || n_words == 2));
     hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(64), 0, ST(stream), counter_lo_hi, n_words, inc);
+    DV_RETURN_LAUNCH();
+}
+
+extern "C" int dv_counters_add2(int32_t* c1, int32_t n1, int64_t inc1, int32_t* c2, int32_t n2, int64_t inc2,
+                                dv_stream_t stream) {
+    DV_REQUIRE(c1 && c2 && (n1 == 1 || n1 == 2) && (n2 == 1 || n2 == 2));
+    hipLaunchKernelGGL(counters_add2_kernel, dim3(1), dim3(64), 0, ST(stream), c1, n1, inc1, c2, n2, inc2);
     DV_RETURN_LAUNCH();
 }
 

@@ -477,10 +477,16 @@ class FusedStep:
         if cfg.has_y and cfg.cont:
             p.EY.copy_(t(np.asarray(noise['ey'])[:, rows].reshape(L * p.B, -1)))
 
-    def draw_noise(self):
-        """Fresh on-device N(0,1) for every draw of the step (Philox, one launch)."""
+    def draw_noise(self, bump=True):
+        """Fresh on-device N(0,1) for every draw of the step (Philox, one launch).  ``bump=False``: the
+        Philox counter is advanced later, together with the step counter, by ``optimizer_step`` (one
+        launch less on the train step's critical path)."""
         K.fill_normal(self.plan.noise, self.seed, self.rng_ctr)
-        K.counter_add(self.rng_ctr, (self.plan.noise.numel() + 3) // 4)
+        n = (self.plan.noise.numel() + 3) // 4
+        if bump:
+            K.counter_add(self.rng_ctr, n)
+        else:
+            self._rng_pending = n
 
     # ---------------------------------------------------------------------- forward
     def beta_pert(self):
@@ -814,7 +820,11 @@ class FusedStep:
     def optimizer_step(self, gscale=1.0):
         """torch.optim.Adam with coupled L2 on EVERY parameter (src/DGMMixin.py:36)."""
         cfg, a = self.cfg, self.arena
-        K.counter_add(self.step_dev, 1)
+        if getattr(self, '_rng_pending', 0):
+            K.counters_add2(self.step_dev, 1, self.rng_ctr, self._rng_pending)
+            self._rng_pending = 0
+        else:
+            K.counter_add(self.step_dev, 1)
         if self._rec == 'both' and self.sched == 5:
             K.counter_add(self.side_ctr, 1)      # eager step: the side chain's counter follows
         step = K.adamax_l2 if cfg.optim_alg == 'adamax' else K.adam_l2    # exp_avg_sq doubles as Adamax's exp_inf
@@ -829,7 +839,7 @@ class FusedStep:
         if noise is not None:
             self.set_noise(noise)
         else:
-            self.draw_noise()
+            self.draw_noise(bump=False)
         self.fuse_bwd = True
         try:
             self._step_begin()
@@ -848,7 +858,7 @@ class FusedStep:
         self.fuse_bwd = True
         try:
             self._step_begin()
-            self.draw_noise()
+            self.draw_noise(bump=False)
             self.forward()
             self.backward()
             if allreduce is not None:
@@ -1065,7 +1075,7 @@ class FusedStep:
                 try:
                     ga.capture_begin()
                     self._step_begin()
-                    self.draw_noise()
+                    self.draw_noise(bump=False)
                     self.forward()
                     self.backward()
                     self._step_end()
@@ -1084,7 +1094,7 @@ class FusedStep:
                 self.fuse_bwd = True
                 try:
                     self._step_begin()
-                    self.draw_noise()
+                    self.draw_noise(bump=False)
                     self.forward()
                     self.backward()
                     self._step_end()

@@ -447,6 +447,11 @@ def counter_add(counter, inc=1):
     _lib.check(_lib.load().dv_counter_add(_i32(counter), counter.numel(), inc, _stream()), 'dv_counter_add')
 
 
+def counters_add2(c1, inc1, c2, inc2):
+    _lib.check(_lib.load().dv_counters_add2(_i32(c1), c1.numel(), inc1, _i32(c2), c2.numel(), inc2, _stream()),
+               'dv_counters_add2')
+
+
 def fill_normal(out, seed, ctr_dev=None):
     assert out.is_contiguous()
     _lib.check(_lib.load().dv_fill_normal(_f32(out), out.numel(), seed, _i32(ctr_dev), _stream()),

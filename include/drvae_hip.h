@@ -370,6 +370,9 @@ int dv_adam_l2(float* p, const float* g, float* m, float* v, int64_t n, float lr
 int dv_adamax_l2(float* p, const float* g, float* m, float* u, int64_t n, float lr, float beta1, float beta2,
                  float eps, float weight_decay, float gscale, const int32_t* step_dev, dv_stream_t stream);
 int dv_counter_add(int32_t* counter_lo_hi, int32_t n_words, int64_t inc, dv_stream_t stream);
+/* two device counters in one launch (the optimiser step count and the Philox counter of a train step) */
+int dv_counters_add2(int32_t* c1, int32_t n1, int64_t inc1, int32_t* c2, int32_t n2, int64_t inc2,
+                     dv_stream_t stream);
 
 /* Device-side fork/join between two launch chains that run concurrently (two root branches of one
  * hipGraph; no reference counterpart -- replaces graph edges, which cost ~27 us per fork+join on the
