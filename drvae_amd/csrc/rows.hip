@@ -748,6 +748,39 @@ __global__ void ymarg_bwd_kernel(const float* __restrict__ qy, int64_t ldq, cons
     }
 }
 
+// forward and backward of the y-marginalisation in one pass (train step: the coefficients are known)
+__global__ void ymarg_fwdbwd_kernel(const float* __restrict__ qy, int64_t ldq, const int32_t* __restrict__ label,
+                                    const int32_t* __restrict__ fp_ptr, const float* __restrict__ klfp,
+                                    float log_prior, const float* __restrict__ log_prior_v,
+                                    const float* __restrict__ c_kld, const float* __restrict__ c_yl, int R, int Y,
+                                    float* __restrict__ yl, float* __restrict__ kld, float* __restrict__ cfp,
+                                    float* __restrict__ dqy, int64_t lddq) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const float* q = qy + (int64_t)r * ldq;
+    float* dq = dqy + (int64_t)r * lddq;
+    const int f0 = fp_ptr[r], nf = fp_ptr[r + 1] - f0;
+    const float ck = c_kld[r];
+    if (nf == 1) {
+        const int lab = label[r];
+        yl[r] = logf(q[lab]);
+        kld[r] = klfp[f0];
+        for (int j = 0; j < Y; ++j) dq[j] = (j == lab) ? c_yl[r] / q[j] : 0.f;
+        cfp[f0] = ck;
+    } else {
+        float a = 0.f, b = 0.f;
+        for (int j = 0; j < Y; ++j) {
+            const float lp = log_prior_v ? log_prior_v[j] : log_prior, lq = logf(q[j]), kf = klfp[f0 + j];
+            a += q[j] * kf;
+            b += -q[j] * (lp - lq);
+            cfp[f0 + j] = ck * q[j];
+            dq[j] = ck * (kf + lq - lp + 1.f);
+        }
+        yl[r] = 0.f;
+        kld[r] = a + b;
+    }
+}
+
 // ------------------------------------------------ regression head (type_y = 'cont')
 // q(y|.) = N(mu, var) with mu = sigmoid(.) and a FIXED variance (src/DrVAE.py:167-169).  Per classifier
 // row r = (l, i):  labeled -> yl[r] = log N(y_i; mu, var), the fprop input takes the true y;
@@ -1328,6 +1361,18 @@ extern "C" int dv_ymarg_fwd(const float* qy, int64_t ldq, const int32_t* label, 
     DV_REQUIRE(qy && label && fp_ptr && klfp && yl && kld);
     hipLaunchKernelGGL(ymarg_fwd_kernel, dim3((R + 255) / 256), dim3(256), 0, ST(stream), qy, ldq, label, fp_ptr,
                        klfp, log_prior, log_prior_v, R, Y, yl, kld);
+    DV_RETURN_LAUNCH();
+}
+
+extern "C" int dv_ymarg_fwdbwd(const float* qy, int64_t ldq, const int32_t* label, const int32_t* fp_ptr,
+                               const float* klfp, float log_prior, const float* log_prior_v, const float* c_kld,
+                               const float* c_yl, int32_t R, int32_t Y, float* yl, float* kld, float* cfp,
+                               float* dqy, int64_t lddq, dv_stream_t stream) {
+    DV_REQUIRE(R >= 0 && Y >= 1);
+    if (R == 0) return DV_OK;
+    DV_REQUIRE(qy && label && fp_ptr && klfp && c_kld && c_yl && yl && kld && cfp && dqy);
+    hipLaunchKernelGGL(ymarg_fwdbwd_kernel, dim3((R + 255) / 256), dim3(256), 0, ST(stream), qy, ldq, label, fp_ptr,
+                       klfp, log_prior, log_prior_v, c_kld, c_yl, R, Y, yl, kld, cfp, dqy, lddq);
     DV_RETURN_LAUNCH();
 }
 

@@ -596,7 +596,11 @@ class FusedStep:
                     K.smalln_fwd(p.QY, None, clf_in[0], lc.W, lc.b, clf_in[1] if len(clf_in) > 1 else None)
                 else:
                     K.softmax_clamp_fwd(p.QY, p.c_clf.forward(clf_in), sigmoid1=cfg.clf_1sig)
-                K.ymarg_fwd(p.YLrow, p.KLDrow, p.QY, p.label_r, p.fp_ptr, p.KLFP, p.log_prior)
+                if self.fuse_bwd:      # train step: CFP / DQY of the backward pass come out of the same launch
+                    K.ymarg_fwdbwd(p.YLrow, p.KLDrow, p.CFP, p.DQY, p.QY, p.label_r, p.fp_ptr, p.KLFP, p.log_prior,
+                                   p.c_kld, p.c_yl)
+                else:
+                    K.ymarg_fwd(p.YLrow, p.KLDrow, p.QY, p.label_r, p.fp_ptr, p.KLFP, p.log_prior)
         mode = self._mode()
         if mode == 5:
             two = cfg.has_pert                      # flag 0: z1 samples final; flag 2: z2Fz1 samples final
@@ -693,7 +697,8 @@ class FusedStep:
                     p.c_clf.backward(p.DLOG, [Z1blk], [[(p.DZ1B, 1.0, 1.0)]])
             elif cfg.has_y:
                 Y = cfg.dim_y
-                K.ymarg_bwd(p.CFP, p.DQY, p.QY, p.label_r, p.fp_ptr, p.KLFP, p.log_prior, p.c_kld, p.c_yl)
+                if not self.fuse_bwd:
+                    K.ymarg_bwd(p.CFP, p.DQY, p.QY, p.label_r, p.fp_ptr, p.KLFP, p.log_prior, p.c_kld, p.c_yl)
                 if p.Mf:
                     Z3 = cfg.dim_z3
                     PZ1, Q3 = p.c_dz1.out[-1], p.c_top.out[-1]

@@ -321,6 +321,15 @@ def ymarg_fwd(yl, kld, qy, label, fp_ptr, klfp, log_prior):
                                         _stream()), 'dv_ymarg_fwd')
 
 
+def ymarg_fwdbwd(yl, kld, cfp, dqy, qy, label, fp_ptr, klfp, log_prior, c_kld, c_yl):
+    R, Y = qy.shape
+    vec = log_prior if torch.is_tensor(log_prior) else None
+    _lib.check(_lib.load().dv_ymarg_fwdbwd(_f32(qy), _ld(qy), _i32(label), _i32(fp_ptr), _f32(klfp),
+                                           0.0 if vec is not None else log_prior, _f32(vec), _f32(c_kld), _f32(c_yl),
+                                           R, Y, _f32(yl), _f32(kld), _f32(cfp), _f32(dqy), _ld(dqy), _stream()),
+               'dv_ymarg_fwdbwd')
+
+
 def ymarg_bwd(cfp, dqy, qy, label, fp_ptr, klfp, log_prior, c_kld, c_yl):
     R, Y = qy.shape
     vec = log_prior if torch.is_tensor(log_prior) else None

@@ -276,6 +276,11 @@ int dv_ymarg_bwd(const float* qy, int64_t ldq, const int32_t* label, const int32
                  float log_prior, const float* log_prior_v, const float* c_kld, const float* c_yl, int32_t R,
                  int32_t Y, float* cfp, float* dqy, int64_t lddq, dv_stream_t stream);
 
+/* _fwd and _bwd in one launch (the train step knows the coefficients before the forward pass) */
+int dv_ymarg_fwdbwd(const float* qy, int64_t ldq, const int32_t* label, const int32_t* fp_ptr, const float* klfp,
+                    float log_prior, const float* log_prior_v, const float* c_kld, const float* c_yl, int32_t R,
+                    int32_t Y, float* yl, float* kld, float* cfp, float* dqy, int64_t lddq, dv_stream_t stream);
+
 /* Regression head (`type_y='cont'`, src/DrVAE.py:159-169,503-530): q(y|.) = N(sigmoid(.), fixed var).
  * Per classifier row r=(l,i), i = r % B:
  *   labeled   (has_y[i]): yl[r] = log N(ylab[i,:]; mu[r,:], var);  yv = ylab[i,:]

@@ -434,6 +434,11 @@ def ymarg_fwd(yl, kld, qy, label, fp_ptr, klfp, log_prior):
     kld.copy_(torch.where(lab, kf[:, 0], marg))
 
 
+def ymarg_fwdbwd(yl, kld, cfp, dqy, qy, label, fp_ptr, klfp, log_prior, c_kld, c_yl):
+    ymarg_fwd(yl, kld, qy, label, fp_ptr, klfp, log_prior)
+    ymarg_bwd(cfp, dqy, qy, label, fp_ptr, klfp, log_prior, c_kld, c_yl)
+
+
 def ymarg_bwd(cfp, dqy, qy, label, fp_ptr, klfp, log_prior, c_kld, c_yl):
     R, Y = qy.shape
     f0 = fp_ptr[:-1].long()
@@ -613,7 +618,7 @@ def fill_normal(out, seed, ctr_dev=None):
 FUNCTIONS = ['adamax_l2', 'batch_feed', 'counters_add2', 'ycont_fwd', 'ycont_bwd', 'flag_publish', 'flag_wait', 'gemm', 'linear_fwd', 'linear_bwd_data', 'linear_bwd_weight', 'linear_bwd_pair', 'colsum', 'act_bwd_', 'wn_scale', 'wn_bwd',
              'reparam_fwd', 'reparam_bwd', 'reparam_bwd_seg', 'z2f_post_bwd', 'kl_rows_fwd', 'kl_rows_bwd', 'nll_rows_fwd', 'nll_rows_bwd', 'nll_rows_fwdbwd',
              'softmax_clamp_fwd', 'softmax_clamp_bwd', 'cat_terms_fwd', 'cat_terms_bwd', 'smalln_fwd', 'smalln_bwd_data',
-             'smalln_bwd_weight', 'ymarg_fwd', 'ymarg_bwd',
+             'smalln_bwd_weight', 'ymarg_fwd', 'ymarg_bwd', 'ymarg_fwdbwd',
              'rows_gather', 'rows_segment_sum', 'weighted_sum', 'recon_row_stats', 'col_moments', 'loss_assemble', 'axpby', 'adam_l2', 'counter_add', 'fill_normal']
 
 

@@ -333,6 +333,37 @@ def test_ymarg(K, dev):
     R.ymarg_bwd(rcfp, rdqy, qy, label, fp_ptr, klfp, lp, ck, cy)
     close(cfp, rcfp, rtol=1e-5, atol=1e-6)
     close(dqy, rdqy, rtol=1e-5, atol=1e-5)
+    # one-launch forward+backward, also with a class prior given as data (log-prior vector)
+    for prior in (lp, torch.log(torch.tensor([0.2, 0.5, 0.3])).to(dev)):
+        o = [torch.empty(Rr, device=dev), torch.empty(Rr, device=dev), torch.empty(F_, device=dev),
+             torch.empty(Rr, Y, device=dev)]
+        ro = [torch.empty_like(t) for t in o]
+        K.ymarg_fwdbwd(*o, qy, label, fp_ptr, klfp, prior, ck, cy)
+        R.ymarg_fwd(ro[0], ro[1], qy, label, fp_ptr, klfp, prior)
+        R.ymarg_bwd(ro[2], ro[3], qy, label, fp_ptr, klfp, prior, ck, cy)
+        for a, b in zip(o, ro):
+            close(a, b, rtol=1e-5, atol=1e-5)
+
+
+def test_ycont(K, dev):
+    Rr, B, Y = 24, 12, 2
+    mu = torch.sigmoid(rnd(dev, Rr, Y + 2, seed=1))[:, :Y]
+    ylab, eps = torch.rand(B, Y).to(dev), rnd(dev, Rr, Y, seed=2)
+    has_y = (torch.arange(B) % 3 != 0).to(torch.int32).to(dev)
+    lv = float(np.log(0.05 ** 2))
+    outs = []
+    for mod in (K, R):
+        yl = torch.empty(Rr, device=dev)
+        f1, f2 = torch.zeros(Rr, 7 + Y, device=dev), torch.zeros(Rr, 5 + Y, device=dev)
+        mod.ycont_fwd(yl, f1[:, 7:], f2[:, 5:], mu, ylab, has_y, eps, lv, B)
+        c_yl, c_kld = rnd(dev, Rr, seed=3), rnd(dev, Rr, seed=4)
+        d1, d2 = rnd(dev, Rr, 7 + Y, seed=5), rnd(dev, Rr, 5 + Y, seed=6)
+        dl, cfp = torch.empty(Rr, Y, device=dev), torch.empty(Rr, device=dev)
+        mod.ycont_bwd(None, cfp, mu, ylab, has_y, lv, c_yl, c_kld, d1[:, 7:], d2[:, 5:], B)
+        mod.ycont_bwd(dl, None, mu, ylab, has_y, lv, c_yl, c_kld, d1[:, 7:], d2[:, 5:], B)
+        outs.append((yl, f1, f2, dl, cfp))
+    for a, b in zip(*outs):
+        close(a, b, rtol=2e-5, atol=1e-4)
 
 
 def test_row_movement(K, dev):
