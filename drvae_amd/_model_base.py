@@ -63,8 +63,10 @@ class ELBOModel(FitMixin, DeepGenerativeModelMixin, nn.Module):
             bad.append("type_y='cont' with a data prior")
         if getattr(self, 'clf_1sig', False) and self.dim_y != 2:
             raise ValueError('Invalid combination of clf_1sig and dim_y')      # src/DrVAE.py:161
-        if self.dropout_rate > 0 or getattr(self, 'input_x_dropout', 0.) > 0:
-            bad.append('dropout')
+        # input_x_dropout (--x-dropout) is accepted and has NO effect, exactly as in the reference: its MLP
+        # computes the dropped inputs and then concatenates the ORIGINAL ones (src/blocks.py:158-161)
+        if self.dropout_rate > 0:
+            bad.append('dropout_rate > 0 (hard-coded 0. by every reference driver)')
         pr = getattr(self, 'prior_y', 'uniform')
         if pr is not None and not isinstance(pr, str):       # a class prior given as data (src/DrVAE.py:83-85)
             assert isinstance(pr, np.ndarray) and len(pr) == self.dim_y

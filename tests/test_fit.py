@@ -155,6 +155,24 @@ def test_fit_end_to_end_cpu(kind, monkeypatch, tmp_path):
     model.load_params_from_file(fn)
 
 
+def test_input_dropout_is_a_noop_like_the_reference(monkeypatch):
+    """--x-dropout reaches MLP(input_dropout_rates=...), whose forward drops the inputs and then concatenates
+    the undropped ones (src/blocks.py:158-161): same losses with and without it"""
+    kernel_ref.install(monkeypatch)
+    from oracle import models_ref as M
+    ds = _tiny_dataset('drvae', 16, 3)
+    out = []
+    for rate in (0.0, 0.4):
+        model = _tiny_model('drvae', device='cpu', input_x_dropout=rate)
+        spec = M.ModelSpec(kind='drvae', dim_x=13, dim_z1=5, dim_z3=4, L=2)
+        noise = M.make_noise(spec, 16, seed=11)
+        model.add_noise = True
+        losses = model.run_on_batch(train_mode=True, noise=noise, x1=ds.x1, x2=ds.x2, s=ds.s, y=ds.y, has_x2=ds.has_x2,
+                                    has_y=ds.has_y)
+        out.append({k: float(v) for k, v in losses.items()})
+    assert out[0] == out[1]
+
+
 def _cont_dataset(n, seed, device='cpu'):
     from drvae_amd import data as D
     ds = _tiny_dataset('drvae', n, seed, device)
