@@ -1,0 +1,118 @@
+"""Linear layers bound to arena views and chains of them (trunk + head of one block) evaluated on stacked
+rows with pre-allocated buffers: the GEMM-level building block of the fused train step."""
+import torch
+
+from . import kernels as K
+
+
+def _pad4(n):
+    return (n + 3) // 4 * 4
+
+
+class _Lin:
+    """One Linear layer (or two fused heads) bound to arena views."""
+
+    def __init__(self, arena, wname, bname, gname=None, second=None, act='identity', act1=None, shift0=0.0,
+                 shift1=0.0):
+        if second is None:
+            self.W, self.dW = arena.p(wname), arena.g(wname)
+            self.b, self.db = arena.p(bname), arena.g(bname)
+            self.g = arena.p(gname) if gname else None
+            self.dg = arena.g(gname) if gname else None
+            self.split = self.W.shape[0]
+        else:
+            w2, b2, g2 = second
+            self.W, self.dW = arena.fused(arena.param, wname, w2), arena.fused(arena.grad, wname, w2)
+            self.b, self.db = arena.fused(arena.param, bname, b2), arena.fused(arena.grad, bname, b2)
+            self.g = arena.fused(arena.param, gname, g2) if gname and g2 else None
+            self.dg = arena.fused(arena.grad, gname, g2) if gname and g2 else None
+            self.split = arena.shapes[wname][0]
+        self.N, self.Kin = self.W.shape
+        self.act0, self.act1 = act, (act if act1 is None else act1)
+        self.shift0, self.shift1 = shift0, shift1
+        dev = self.W.device
+        if self.g is not None:
+            self.scale = torch.empty(self.N, device=dev)
+            self.norm = torch.empty(self.N, device=dev)
+            self.raw = torch.empty(self.N, self.Kin, device=dev)
+        else:
+            self.scale = self.norm = self.raw = None
+
+
+class _Chain:
+    """trunk layers + final layer of one block evaluated on M stacked rows, with buffers."""
+
+    def __init__(self, layers, M, device, resid_cols=0):
+        self.layers, self.M, self.resid_cols = layers, M, resid_cols
+        self.out = [torch.zeros(M, _pad4(l.N), device=device)[:, :l.N] for l in layers]
+        # gradient w.r.t. the pre-activation of every layer but the last (the caller owns that one)
+        self.dpre = [torch.zeros(M, _pad4(l.N), device=device)[:, :l.N] for l in layers[:-1]]
+
+    def forward(self, inputs, resid=None, publish=None):
+        """``publish`` = (flag, counter, add): the FIRST launch of the chain publishes on entry"""
+        x = list(inputs)
+        for li, l in enumerate(self.layers):
+            if l.g is not None:
+                K.wn_scale(l.scale, l.norm, l.W, l.g)
+            last = li == len(self.layers) - 1
+            K.linear_fwd(self.out[li], x[0], l.W, l.b, x2=x[1] if len(x) > 1 else None, scale=l.scale, split=l.split,
+                         act0=l.act0, act1=l.act1, shift0=l.shift0, shift1=l.shift1,
+                         resid=resid if last else None, resid_cols=self.resid_cols if (last and resid is not None) else 0,
+                         overread=True, publish=publish if (li == 0 and l.g is None) else None)
+            x = [self.out[li]]
+        return self.out[-1]
+
+    def backward(self, dpre_last, inputs, dinputs=None, wbranch=None):
+        """dpre_last: gradient w.r.t. the last layer's pre-activation.  ``dinputs``: per input
+        source a list of (dst, alpha, beta) destinations for its gradient (or None to skip).
+        ``wbranch``: optional side stream for the weight-gradient GEMMs (they are leaves: only
+        Adam reads them), so that they overlap the dx chain."""
+        dpre = dpre_last
+        for li in range(len(self.layers) - 1, -1, -1):
+            l = self.layers[li]
+            srcs = list(inputs) if li == 0 else [self.out[li - 1]]
+
+            def wgrad(l=l, srcs=srcs, dpre=dpre):
+                dW = l.raw if l.g is not None else l.dW
+                c0 = 0
+                for si, s in enumerate(srcs):
+                    w = s.shape[1]
+                    K.linear_bwd_weight(dW[:, c0:c0 + w], dpre, s, dbias=l.db if si == 0 else None, overread=True)
+                    c0 += w
+                if l.g is not None:
+                    K.wn_bwd(l.dW, l.dg, l.raw, l.W, l.g, l.norm)
+
+            # the layer's weight- and data-gradient both only need dpre: one paired launch when the
+            # layer has a single input source, no WeightNorm and a single data-gradient destination
+            single_dst = li > 0 or (dinputs is not None and len(srcs) == 1 and dinputs[0] is not None
+                                    and len(dinputs[0]) == 1)
+            if wbranch is None and l.g is None and len(srcs) == 1 and single_dst:
+                if li > 0:
+                    prev = self.layers[li - 1]
+                    K.linear_bwd_pair(l.dW, l.db, self.dpre[li - 1], dpre, srcs[0], l.W, yref=self.out[li - 1],
+                                      act=prev.act0, shift=prev.shift0, overread=True)
+                    dpre = self.dpre[li - 1]
+                else:
+                    dst, alpha, beta = dinputs[0][0]
+                    K.linear_bwd_pair(l.dW, l.db, dst, dpre, srcs[0], l.W, alpha=alpha, beta_x=beta, overread=True)
+                continue
+            if wbranch is not None:
+                with wbranch:
+                    wgrad()
+            else:
+                wgrad()
+            if li > 0:
+                prev = self.layers[li - 1]
+                K.linear_bwd_data(self.dpre[li - 1], dpre, l.W, kscale=l.scale, yref=self.out[li - 1], act=prev.act0,
+                                  shift=prev.shift0, overread=True)
+                dpre = self.dpre[li - 1]
+            elif dinputs is not None:
+                c0 = 0
+                for si, s in enumerate(srcs):
+                    w = s.shape[1]
+                    for (dst, alpha, beta) in (dinputs[si] or []):
+                        K.linear_bwd_data(dst, dpre, l.W[:, c0:c0 + w], kscale=l.scale, alpha=alpha, beta=beta,
+                                          overread=True)
+                    c0 += w
+        if wbranch is not None:
+            wbranch.join()

@@ -30,8 +30,10 @@ import torch
 from . import kernels as K
 from ._lib import GAUSS_LOGVAR, GAUSS_SIGMA
 from .arena import N_LOSS, ParamArena
+from .chain import _Chain, _Lin, _pad4
+from .plan import LOSS_IDX, _Plan
+from .schedule import StepSchedule, _Branch
 
-LOSS_IDX = {'RECL': 0, 'KLD': 1, 'PERT': 2, 'YL': 3, 'MMD': 4, 'ELBO': 5, 'CMPL': 6}
 
 
 @dataclass
@@ -146,184 +148,7 @@ def frozen_params(cfg):
     return ()
 
 
-def _pad4(n):
-    return (n + 3) // 4 * 4
-
-
-class _Lin:
-    """One Linear layer (or two fused heads) bound to arena views."""
-
-    def __init__(self, arena, wname, bname, gname=None, second=None, act='identity', act1=None, shift0=0.0,
-                 shift1=0.0):
-        if second is None:
-            self.W, self.dW = arena.p(wname), arena.g(wname)
-            self.b, self.db = arena.p(bname), arena.g(bname)
-            self.g = arena.p(gname) if gname else None
-            self.dg = arena.g(gname) if gname else None
-            self.split = self.W.shape[0]
-        else:
-            w2, b2, g2 = second
-            self.W, self.dW = arena.fused(arena.param, wname, w2), arena.fused(arena.grad, wname, w2)
-            self.b, self.db = arena.fused(arena.param, bname, b2), arena.fused(arena.grad, bname, b2)
-            self.g = arena.fused(arena.param, gname, g2) if gname and g2 else None
-            self.dg = arena.fused(arena.grad, gname, g2) if gname and g2 else None
-            self.split = arena.shapes[wname][0]
-        self.N, self.Kin = self.W.shape
-        self.act0, self.act1 = act, (act if act1 is None else act1)
-        self.shift0, self.shift1 = shift0, shift1
-        dev = self.W.device
-        if self.g is not None:
-            self.scale = torch.empty(self.N, device=dev)
-            self.norm = torch.empty(self.N, device=dev)
-            self.raw = torch.empty(self.N, self.Kin, device=dev)
-        else:
-            self.scale = self.norm = self.raw = None
-
-
-class _Chain:
-    """trunk layers + final layer of one block evaluated on M stacked rows, with buffers."""
-
-    def __init__(self, layers, M, device, resid_cols=0):
-        self.layers, self.M, self.resid_cols = layers, M, resid_cols
-        self.out = [torch.zeros(M, _pad4(l.N), device=device)[:, :l.N] for l in layers]
-        # gradient w.r.t. the pre-activation of every layer but the last (the caller owns that one)
-        self.dpre = [torch.zeros(M, _pad4(l.N), device=device)[:, :l.N] for l in layers[:-1]]
-
-    def forward(self, inputs, resid=None, publish=None):
-        """``publish`` = (flag, counter, add): the FIRST launch of the chain publishes on entry"""
-        x = list(inputs)
-        for li, l in enumerate(self.layers):
-            if l.g is not None:
-                K.wn_scale(l.scale, l.norm, l.W, l.g)
-            last = li == len(self.layers) - 1
-            K.linear_fwd(self.out[li], x[0], l.W, l.b, x2=x[1] if len(x) > 1 else None, scale=l.scale, split=l.split,
-                         act0=l.act0, act1=l.act1, shift0=l.shift0, shift1=l.shift1,
-                         resid=resid if last else None, resid_cols=self.resid_cols if (last and resid is not None) else 0,
-                         overread=True, publish=publish if (li == 0 and l.g is None) else None)
-            x = [self.out[li]]
-        return self.out[-1]
-
-    def backward(self, dpre_last, inputs, dinputs=None, wbranch=None):
-        """dpre_last: gradient w.r.t. the last layer's pre-activation.  ``dinputs``: per input
-        source a list of (dst, alpha, beta) destinations for its gradient (or None to skip).
-        ``wbranch``: optional side stream for the weight-gradient GEMMs (they are leaves: only
-        Adam reads them), so that they overlap the dx chain."""
-        dpre = dpre_last
-        for li in range(len(self.layers) - 1, -1, -1):
-            l = self.layers[li]
-            srcs = list(inputs) if li == 0 else [self.out[li - 1]]
-
-            def wgrad(l=l, srcs=srcs, dpre=dpre):
-                dW = l.raw if l.g is not None else l.dW
-                c0 = 0
-                for si, s in enumerate(srcs):
-                    w = s.shape[1]
-                    K.linear_bwd_weight(dW[:, c0:c0 + w], dpre, s, dbias=l.db if si == 0 else None, overread=True)
-                    c0 += w
-                if l.g is not None:
-                    K.wn_bwd(l.dW, l.dg, l.raw, l.W, l.g, l.norm)
-
-            # the layer's weight- and data-gradient both only need dpre: one paired launch when the
-            # layer has a single input source, no WeightNorm and a single data-gradient destination
-            single_dst = li > 0 or (dinputs is not None and len(srcs) == 1 and dinputs[0] is not None
-                                    and len(dinputs[0]) == 1)
-            if wbranch is None and l.g is None and len(srcs) == 1 and single_dst:
-                if li > 0:
-                    prev = self.layers[li - 1]
-                    K.linear_bwd_pair(l.dW, l.db, self.dpre[li - 1], dpre, srcs[0], l.W, yref=self.out[li - 1],
-                                      act=prev.act0, shift=prev.shift0, overread=True)
-                    dpre = self.dpre[li - 1]
-                else:
-                    dst, alpha, beta = dinputs[0][0]
-                    K.linear_bwd_pair(l.dW, l.db, dst, dpre, srcs[0], l.W, alpha=alpha, beta_x=beta, overread=True)
-                continue
-            if wbranch is not None:
-                with wbranch:
-                    wgrad()
-            else:
-                wgrad()
-            if li > 0:
-                prev = self.layers[li - 1]
-                K.linear_bwd_data(self.dpre[li - 1], dpre, l.W, kscale=l.scale, yref=self.out[li - 1], act=prev.act0,
-                                  shift=prev.shift0, overread=True)
-                dpre = self.dpre[li - 1]
-            elif dinputs is not None:
-                c0 = 0
-                for si, s in enumerate(srcs):
-                    w = s.shape[1]
-                    for (dst, alpha, beta) in (dinputs[si] or []):
-                        K.linear_bwd_data(dst, dpre, l.W[:, c0:c0 + w], kscale=l.scale, alpha=alpha, beta=beta,
-                                          overread=True)
-                    c0 += w
-        if wbranch is not None:
-            wbranch.join()
-
-
-def _masked_stream(bits, device):
-    """a HIP stream whose kernels only run on the CUs set in ``bits`` (hipExtStreamCreateWithCUMask),
-    wrapped for torch; lives for the rest of the process"""
-    import ctypes
-    hip = ctypes.CDLL('libamdhip64.so')
-    st = ctypes.c_void_p()
-    arr = (ctypes.c_uint32 * len(bits))(*bits)
-    with torch.cuda.device(device):
-        rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), len(bits), arr)
-    if rc != 0:
-        raise RuntimeError('hipExtStreamCreateWithCUMask failed: %d' % rc)
-    import atexit
-
-    def _destroy(handle=st.value):       # before the HIP runtime tears down (profilers crash otherwise)
-        try:
-            torch.cuda.synchronize()
-            hip.hipStreamDestroy(ctypes.c_void_p(handle))
-        except Exception:
-            pass
-    atexit.register(_destroy)
-    return torch.cuda.ExternalStream(st.value, device=device)
-
-
-class _Branch:
-    """Fork/join of an independent launch chain onto a side HIP stream.  Inside a hipGraph
-    capture the side stream joins the capture, so the chain becomes a parallel branch of the
-    graph; on CPU tensors (unit tests with stand-in launchers) it degrades to inline execution."""
-
-    def __init__(self, device, enabled=True):
-        self.on = enabled and torch.device(device).type == 'cuda'
-        self.side = torch.cuda.Stream(device=device) if self.on else None
-
-    def fork(self):
-        """mark the point of the current stream the side chain depends on; the chain itself may be
-        recorded later (``with branch:``).  Measured on MI355X (tools/graph_fork_probe.py): the hipGraph
-        executor runs a fork/join ~30 us faster when the MAIN continuation is recorded before the side
-        chain, so callers fork, record the main work, and only then the side chain."""
-        if self.on:
-            self.side.wait_stream(torch.cuda.current_stream())
-            self._forked = True
-
-    def wait_main(self):
-        """extra edge main -> side at the current point of the main stream"""
-        if self.on:
-            self.side.wait_stream(torch.cuda.current_stream())
-
-    def __enter__(self):
-        if self.on:
-            if not getattr(self, '_forked', False):
-                self.side.wait_stream(torch.cuda.current_stream())
-            self._forked = False
-            self._ctx = torch.cuda.stream(self.side)
-            self._ctx.__enter__()
-        return self
-
-    def __exit__(self, *exc):
-        if self.on:
-            self._ctx.__exit__(*exc)
-
-    def join(self):
-        if self.on:
-            torch.cuda.current_stream().wait_stream(self.side)
-
-
-class FusedStep:
+class FusedStep(StepSchedule):
     """Owns the arena views, the per-batch plan (index lists + buffers) and the launch
     sequence.  Typical use::
 
@@ -804,23 +629,6 @@ class FusedStep:
                           free_bits=True, kl_min=cfg.kl_min, beta=1.0)
         p.c_enc.backward(DQ, [p.XIN], None)
 
-    def _mode(self):
-        if not self.fuse_bwd:
-            return 0
-        if self._rec != 'both':
-            return 5
-        if self.sched == 5:
-            return 3                 # eager steps of the dual-graph schedule use plain stream edges
-        return self.sched if (self.sched != 4 or self.branch.on) else 1
-
-    def _step_begin(self):
-        if self._mode() == 4:
-            self.branch.fork()       # side chain = second root of the step (eager: waits for the previous step)
-
-    def _step_end(self):
-        if self.fuse_bwd and self.sched == 4 and self.branch.on:
-            self.branch.join()       # streams rejoin (required to end a capture); off the critical path
-
     # -------------------------------------------------------------------- optimiser
     def optimizer_step(self, gscale=1.0):
         """torch.optim.Adam with coupled L2 on EVERY parameter (src/DGMMixin.py:36)."""
@@ -858,285 +666,6 @@ class FusedStep:
             self.fuse_bwd = False
         self.iters += 1
 
-    # ------------------------------------------------------------------- hipGraph
-    def _launch_sequence(self, allreduce=None):
-        self.fuse_bwd = True
-        try:
-            self._step_begin()
-            self.draw_noise(bump=False)
-            self.forward()
-            self.backward()
-            if allreduce is not None:
-                allreduce(self.arena.xchg)
-            self.optimizer_step()
-            self._step_end()        # after Adam: the rejoin edge stays off the critical path
-        finally:
-            self.fuse_bwd = False
-
-    def capture(self, split_for_allreduce=False):
-        """Capture the train step (Philox noise + forward + backward + Adam: ~100 launches)
-        into hipGraph(s) for the current batch structure.  With ``split_for_allreduce`` the
-        step is captured as two graphs so that an (uncaptured) RCCL all-reduce of the
-        gradient arena can run between backward and Adam."""
-        assert self.plan is not None, 'set_batch first'
-        self.training = True
-        self.plan.set_beta(self.beta_pert())
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):         # warm-up on a side stream (loads code objects)
-            self.draw_noise()
-            self.forward()
-            self.backward()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        self._graphs = []
-        self._side_graph = None
-        dual = self.sched == 5 and self.branch.on and self.cfg.has_y and self._flags_usable()
-        if dual:
-            self._rec = 'main'
-        try:
-            self._capture_main(split_for_allreduce)
-            if dual:
-                self._rec = 'side'
-                self.side_ctr.copy_(self.step_dev)
-                self.flag_side.wait_stream(torch.cuda.current_stream())
-                gs = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gs, stream=self.flag_side):
-                    self.fuse_bwd = True
-                    try:
-                        self.forward()
-                        self.backward()
-                    finally:
-                        self.fuse_bwd = False
-                self._side_graph = gs
-        finally:
-            self._rec = 'both'
-        self._graph_key = self.plan.key
-        self._graph_feed = self.plan.feed
-        return self
-
-    # ------------------------------------------------------------ CU partition
-    def _partition_applicable(self):
-        # only for latency-bound steps: once the decoder products alone fill the chip many times over
-        # (wide configuration) the main chain needs every CU (measured: 52 ms -> 66 ms/step when masked)
-        small = self.plan is not None and self.plan.DPX.shape[0] * self.plan.DPX.shape[1] <= (4 << 20)
-        return bool(self.branch.on and self.sched == 5 and self.cfg.has_y and small and
-                    int(os.environ.get('DRVAE_SIDE_CUS', '64')) > 0)
-
-    def _part_streams(self, n_side):
-        """(main, side) CU-masked streams reserving ``n_side`` CUs for the side chain (cached)"""
-        cache = self.__dict__.setdefault('_parts', {})
-        if n_side not in cache:
-            n_cu = torch.cuda.get_device_properties(self.dev).multi_processor_count
-            words = (n_cu + 31) // 32
-            side_bits, all_bits = [0] * words, [0] * words
-            for i in range(n_cu):
-                all_bits[i // 32] |= 1 << (i % 32)
-                if i < min(n_side, n_cu - 1):
-                    side_bits[i // 32] |= 1 << (i % 32)
-            main_bits = [a & ~b for a, b in zip(all_bits, side_bits)]
-            try:
-                pair = (_masked_stream(main_bits, self.dev), _masked_stream(side_bits, self.dev))
-                with torch.cuda.stream(pair[0]):
-                    if not self._probe(pair[1]):         # must sit on different hardware queues
-                        pair = None
-            except (OSError, RuntimeError, AttributeError) as e:      # runtime without CU masking: plain streams
-                import warnings
-                warnings.warn('drvae_amd: CU partition unavailable (%s)' % e)
-                pair = None
-            cache[n_side] = pair
-        return cache[n_side]
-
-    def partition(self, n_side=None):
-        """Context manager: run the train step with the GPU's compute units split between the two
-        launch chains -- the side chain (many small launches) on ``n_side`` reserved CUs, the main
-        chain (the big GEMMs) on the rest -- via CU-masked HIP streams.  Inside the context the
-        masked main stream is the current stream, so everything the caller enqueues (batch feed,
-        loss accumulation, replays) is ordered with the step; on exit the outer stream waits for it.
-        Measured on MI355X (cfg 2): 64 reserved CUs take the step from 0.264 to 0.240 ms; without the
-        reservation the side chain's small kernels queue behind the GEMM workgroups and the main
-        chain waits ~32 us per step at the join.  ``tune_partition()`` picks the split by timing.
-        No-op when not applicable, disabled (DRVAE_SIDE_CUS=0) or off-GPU."""
-        import contextlib
-        if not self._partition_applicable():
-            return contextlib.nullcontext()
-        if n_side is None:
-            n_side = getattr(self, '_side_cus', None) or int(os.environ.get('DRVAE_SIDE_CUS', '64'))
-        pair = self._part_streams(n_side)
-        if pair is None:
-            return contextlib.nullcontext()
-        main, side = pair
-
-        @contextlib.contextmanager
-        def ctx():
-            outer = torch.cuda.current_stream()
-            prev = self._flag_side
-            main.wait_stream(outer)
-            side.wait_stream(outer)
-            self._flag_side = side
-            try:
-                with torch.cuda.stream(main):
-                    yield self
-            finally:
-                outer.wait_stream(main)
-                outer.wait_stream(side)
-                self._flag_side = prev
-        return ctx()
-
-    def tune_partition(self, candidates=(48, 64, 72, 80, 96), steps=24):
-        """Pick the CU split of ``partition()`` by timing replays of the captured step (the best split
-        depends on how the two chains balance, i.e. on the model and on the individual GPU).  Runs on a
-        scratch copy of the training state: parameters, Adam moments and all device counters are restored
-        afterwards.  Returns the chosen number of reserved CUs (None when partitioning does not apply)."""
-        if not (self._partition_applicable() and self._side_graph is not None and len(self._graphs) == 1) or \
-                'DRVAE_SIDE_CUS' in os.environ:       # (multi-rank: split graphs need the exchange; keep the default)
-            return None
-        a = self.arena
-        keep = [t.clone() for t in (a.param, a.exp_avg, a.exp_avg_sq, self.step_dev, self.side_ctr, self.rng_ctr,
-                                    self.flags)]
-        iters = self.iters
-        best = (None, float('inf'))
-        for n in candidates:
-            if self._part_streams(n) is None:
-                continue
-            with self.partition(n):
-                for _ in range(4):
-                    self.replay()
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(steps):
-                    self.replay()
-                e1.record()
-                e1.synchronize()
-                t = e0.elapsed_time(e1)
-            if t < best[1]:
-                best = (n, t)
-        torch.cuda.synchronize()
-        for dst, src in zip((a.param, a.exp_avg, a.exp_avg_sq, self.step_dev, self.side_ctr, self.rng_ctr,
-                             self.flags), keep):
-            dst.copy_(src)
-        self.iters = iters
-        self.plan.set_beta(self.beta_pert())
-        torch.cuda.synchronize()
-        self._side_cus = best[0]
-        return best[0]
-
-    @property
-    def flag_side(self):
-        """the stream the side-chain graph of the dual-graph schedule is launched on: CU-masked inside
-        ``partition()``, otherwise a plain stream that ``_flags_usable`` has verified to sit on a
-        different hardware queue than the launching stream."""
-        if self._flag_side is None:
-            self._flag_side = torch.cuda.Stream(device=self.dev)
-        return self._flag_side
-
-    def _probe(self, side):
-        """park a short wait on the launching stream, publish from ``side``: a timeout means the two
-        streams share a hardware queue (a parked wait kernel blocks everything behind it in its queue)"""
-        probe = torch.zeros(4, dtype=torch.int32, device=self.dev)      # flag, counter, error, ticks
-        torch.cuda.synchronize()
-        K.flag_wait(probe[0:1], probe[1:2], probe[2:4], add=1, max_spins=20000)
-        with torch.cuda.stream(side):
-            K.flag_publish(probe[0:1], probe[1:2], 1)
-        torch.cuda.synchronize()
-        return int(probe[2]) == 0
-
-    def _flags_usable(self):
-        """Device-flag ordering needs the two streams on DIFFERENT hardware queues.  HIP multiplexes its
-        streams onto a few queues, so probe candidates until one qualifies (the CU-masked stream of
-        ``partition()`` has a queue of its own); otherwise fall back to graph edges.  (High-priority
-        streams are avoided on purpose: with one in the process, captured fork/joins ran 2.4x slower.)"""
-        if getattr(self, '_flags_ok', None) is None:
-            ok = self._probe(self.flag_side)
-            tries = 0
-            while not ok and not getattr(self, '_part', None) and tries < 8:
-                self._flag_side = torch.cuda.Stream(device=self.dev)
-                ok = self._probe(self._flag_side)
-                tries += 1
-            self._flags_ok = ok
-            if not ok:
-                import warnings
-                warnings.warn('drvae_amd: no side stream on a hardware queue of its own; using graph edges')
-        return self._flags_ok
-
-    def check_sync(self):
-        """raise if a device-side wait of the dual-graph schedule ever timed out (results would be stale)"""
-        if int(self.sync_err[0::2].abs().sum()) != 0:
-            raise RuntimeError('drvae_amd: a device-side chain wait timed out (main / side stream ordering)')
-
-    def _capture_main(self, split_for_allreduce):
-        if split_for_allreduce == 'overlap' and self.arena.late_end < self.arena.xchg.numel():
-            # three graphs: [noise .. decoder backward] | [rest of backward] | [Adam]; the exchange of the
-            # decoder block is launched between the first two and travels while the second runs
-            ga, gb, gc = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            cap = torch.cuda.Stream(device=self.dev)
-            cap.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(cap):
-                def split():
-                    ga.capture_end()
-                    gb.capture_begin()
-                self._after_decoder_bwd = split
-                self.fuse_bwd = True
-                try:
-                    ga.capture_begin()
-                    self._step_begin()
-                    self.draw_noise(bump=False)
-                    self.forward()
-                    self.backward()
-                    self._step_end()
-                    gb.capture_end()
-                finally:
-                    self.fuse_bwd = False
-                    self._after_decoder_bwd = None
-                gc.capture_begin()
-                self.optimizer_step()
-                gc.capture_end()
-            torch.cuda.current_stream().wait_stream(cap)
-            self._graphs = [ga, gb, gc]
-        elif split_for_allreduce:
-            g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g1):
-                self.fuse_bwd = True
-                try:
-                    self._step_begin()
-                    self.draw_noise(bump=False)
-                    self.forward()
-                    self.backward()
-                    self._step_end()
-                finally:
-                    self.fuse_bwd = False
-            with torch.cuda.graph(g2):
-                self.optimizer_step()
-            self._graphs = [g1, g2]
-        else:
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self._launch_sequence()
-            self._graphs = [g]
-
-    def replay(self, allreduce=None):
-        """One captured train step.  New data is fed by copying into plan.x1 / plan.x2 in place."""
-        assert self._graph_key == self.plan.key, 'batch structure changed: capture again'
-        assert self._graph_feed is self.plan.feed, 'input feed changed: capture again'
-        self.plan.set_beta(self.beta_pert())      # 0.01 on iteration 0, 1.0 afterwards (device-side coefficients)
-        if self._side_graph is not None:         # first: its wait kernel is parked before the main chain publishes
-            with torch.cuda.stream(self.flag_side):
-                self._side_graph.replay()
-        self._graphs[0].replay()
-        if len(self._graphs) == 3:               # overlapped exchange: ``allreduce`` has start()/finish()
-            a = self.arena
-            w_early = allreduce.start(a.xchg[a.late_end:])
-            self._graphs[1].replay()
-            w_late = allreduce.start(a.xchg[:a.late_end])
-            allreduce.finish(w_early)
-            allreduce.finish(w_late)
-            self._graphs[2].replay()
-        elif len(self._graphs) == 2:
-            if allreduce is not None:
-                allreduce(self.arena.xchg)
-            self._graphs[1].replay()
-        self.iters += 1
-
     def losses(self):
         """OrderedDict of python floats (one device->host copy; the only sync of a step)."""
         v = self.arena.loss.detach().cpu().tolist()
@@ -1148,195 +677,3 @@ class FusedStep:
         if self.cfg.kind == 'vfae':
             keys.remove('PERT')
         return OrderedDict((k, v[LOSS_IDX[k]]) for k in keys)
-
-
-class _Plan:
-    """Index lists, coefficient vectors and buffers for one batch structure."""
-
-    def __init__(self, eng, rows, has_x2, has_y, counts, key):
-        cfg, dev = eng.cfg, eng.dev
-        self.key, self.rows = key, rows
-        L, Y, X, Z1, Z3 = cfg.L, cfg.dim_y, cfg.dim_x, cfg.dim_z1, cfg.dim_z3
-        B = self.B = len(rows)
-        self.pair_host = np.nonzero(has_x2)[0]
-        Np = self.Np = len(self.pair_host)
-        n_lab = int(has_y.sum())
-        if counts is None:
-            counts = (B, Np, n_lab)
-        self.n_tot, self.n_pairs, self.n_lab = [float(c) for c in counts]
-        i32 = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.int32, device=dev)
-        zf = lambda *s: torch.zeros(*s, device=dev)
-
-        def mat(rws, cols):      # row stride padded to 16 B so that rows allow vector access
-            return torch.zeros(rws, _pad4(cols), device=dev)[:, :cols]
-
-        self.pair_idx = i32(self.pair_host)
-        Me = B + Np
-        self.o2, self.o3 = L * B, L * B + L * Np            # ZDEC block offsets (z2 | z2Fz1-of-pairs)
-        Md = L * B + 2 * L * Np
-        tgt = np.concatenate([np.tile(np.arange(B), L), np.tile(B + np.arange(Np), L), np.tile(B + np.arange(Np), L)])
-        self.tgt = i32(tgt)
-        self.pidx = i32((np.arange(L)[:, None] * B + self.pair_host[None, :]).reshape(-1))
-        self.qz2_idx = i32(B + np.arange(Np))
-        # stacked input source [x1 ; x2] and the row list that builds XIN in one gather
-        self.XSRC = torch.zeros(2 * B, X, device=dev)
-        self.xin_idx = i32(np.concatenate([np.arange(B), B + self.pair_host]))
-        # q row of every sample row of ZDEC[:o3] (z1 samples, then z2 samples drawn from q(z1|x1) of the pairs)
-        self.z_src_idx = i32(np.concatenate([np.tile(np.arange(B), L), np.tile(self.pair_host, L)]))
-        slot = np.full(B, -1, np.int64)
-        slot[self.pair_host] = np.arange(Np)
-        self.pair_slot = i32(slot)
-        # ZDEC row that receives the z2Fz1 sample of (l, i) (pairs only)
-        self.pert_out_idx = i32(np.where(slot[None, :] >= 0, (L * B + L * Np) + np.arange(L)[:, None] * Np + slot[None, :],
-                                         -1).reshape(-1))
-        # CSR: q row i -> its sample rows in ZDEC[:o3]
-        zrows = [[l * B + i for l in range(L)] + ([L * B + l * Np + slot[i] for l in range(L)] if slot[i] >= 0 else [])
-                 for i in range(B)]
-        self.zseg_ptr = i32(np.concatenate([[0], np.cumsum([len(r) for r in zrows])]))
-        self.zseg_rows = i32(np.concatenate(zrows) if B else np.zeros(0))
-        self.z2_ptr = i32(np.arange(Np + 1) * L)
-        self.z2_rows = i32((np.arange(L)[None, :] * Np + np.arange(Np)[:, None]).reshape(-1))
-        # ---- noise arena: one flat buffer, one Philox launch per step
-        sizes = [Me * X, L * B * Z1, L * Np * Z1, L * B * Z1 if cfg.has_pert else 0]
-        # fprop rows
-        self.Mf = 0
-        if cfg.has_y:
-            # fprop rows per data row (per sample l): true class | every class; the regression head always
-            # conditions on ONE y (the target, or a sample of q(y|.))
-            nf_row = np.ones(B, np.int64) if cfg.cont else np.where(has_y, 1, Y)
-            fp_ptr = np.concatenate([[0], np.cumsum(np.tile(nf_row, L))])
-            self.Mf = int(fp_ptr[-1])
-            fl, fi, fslot, fcls = [], [], [], []
-            for l in range(L):
-                for i in range(B):
-                    if has_y[i] or cfg.cont:
-                        fl.append(l); fi.append(i); fslot.append(0); fcls.append(0)
-                    else:
-                        for j in range(Y):
-                            fl.append(l); fi.append(i); fslot.append(j); fcls.append(j)
-            self.fp_l_host, self.fp_i_host = np.asarray(fl, np.int64), np.asarray(fi, np.int64)
-            self.fp_slot_host = np.asarray(fslot, np.int64)
-            self.fp_ptr = i32(fp_ptr)
-            self.fp_src = i32(self.fp_l_host * B + self.fp_i_host)
-            self.fp_cls = i32(np.asarray(fcls, np.int64))
-            self.fp_q = i32(self.fp_i_host)
-            order = np.argsort(self.fp_i_host, kind='stable')
-            self.q_rows = i32(order)
-            self.q_ptr = i32(np.concatenate([[0], np.cumsum(np.bincount(self.fp_i_host, minlength=B))]))
-            self.label_r = i32(np.zeros(L * B, np.int64))
-            self._has_y_host = has_y.copy()
-            self._fp_lab_host = has_y[self.fp_i_host]
-            self.has_y_dev = torch.as_tensor(has_y, device=dev)
-            self.fp_i_dev = torch.as_tensor(self.fp_i_host, device=dev)
-            self.fp_lab_dev = torch.as_tensor(self._fp_lab_host, device=dev)
-            self.fp_slot_dev = i32(self.fp_slot_host)
-            self.has_y_i32, self.fp_lab_i32 = i32(has_y), i32(self._fp_lab_host)
-            sizes.append(self.Mf * Z3)
-            if cfg.cont:
-                sizes.append(L * B * Y)                      # eps of the y samples (unlabeled rows use them)
-        self.noise = zf(int(sum(sizes)))
-        views, o = [], 0
-        for s in sizes:
-            views.append(self.noise[o:o + s])
-            o += s
-        self.EX = views[0].view(Me, X)
-        self.E1 = views[1].view(L * B, Z1)
-        self.E2 = views[2].view(L * Np, Z1)
-        self.E12 = self.noise[sizes[0]:sizes[0] + sizes[1] + sizes[2]].view(L * B + L * Np, Z1)
-        self.E2F = views[3].view(L * B, Z1) if cfg.has_pert else None
-        self.E3 = views[4].view(self.Mf, Z3) if cfg.has_y else None
-        self.EY = views[5].view(L * B, Y) if (cfg.has_y and cfg.cont) else None
-        # ---- activations / gradients
-        self.XIN = mat(Me, X)
-        self.ZDEC, self.DZDEC = mat(Md, Z1), mat(Md, Z1)
-        self.c_enc = _Chain(eng.L_enc, Me, dev)
-        self.c_decx = _Chain(eng.L_decx, Md, dev)
-        self.DQ = zf(Me, 2 * Z1)
-        self.DPX = mat(Md, 2 * X)
-        self.NLL = zf(Md)
-        if cfg.has_pert:
-            self.c_z2F = _Chain(eng.L_z2F, L * B, dev, resid_cols=Z1)
-            self.Z2F, self.D, self.DZ2F = mat(L * B, Z1), mat(L * B, Z1), mat(L * B, Z1)
-            self.DP2 = zf(L * B, 2 * Z1)
-            self.KLZ2, self.KLZ2raw = zf(L * Np), zf(L * Np)
-            self.TQ, self.TP = zf(L * Np, 2 * Z1), zf(L * Np, 2 * Z1)
-        if cfg.kind == 'pvae':
-            self.KLP, self.KLPraw = zf(Me), zf(Me)
-        if cfg.has_y:
-            R, Mf = L * B, self.Mf
-            self.c_clf = _Chain(eng.L_clf, R, dev)
-            self.QY, self.DQY, self.DLOG = zf(R, Y), zf(R, Y), zf(R, 1 if cfg.clf_1sig else Y)
-            self.ylab = zf(B, Y)                            # regression targets (type_y='cont')
-            # log p(y): the uniform prior as a scalar, a class prior given as data as a device vector
-            self.log_prior = math.log(1.0 / Y) if cfg.prior_y is None else \
-                torch.log(torch.tensor(cfg.prior_y, dtype=torch.float64)).float().to(dev)
-            self.DZ1B = mat(R, Z1)
-            self.YLrow, self.KLDrow = zf(R), zf(R)
-            self.c_top = _Chain(eng.L_top, Mf, dev)
-            self.c_dz1 = _Chain(eng.L_dz1, Mf, dev)
-            self.FPIN, self.DFPIN = mat(Mf, Z1 + Y), mat(Mf, Z1 + Y)
-            self.Z3IN, self.DZ3IN = mat(Mf, Z3 + Y), mat(Mf, Z3 + Y)
-            self.DQ3, self.DPZ1, self.DQFP = zf(Mf, 2 * Z3), zf(Mf, 2 * Z1), zf(Mf, 2 * Z1)
-            self.KL3, self.KL3raw, self.KL1, self.KL1raw = zf(Mf), zf(Mf), zf(Mf), zf(Mf)
-            self.KLFP, self.CFP = zf(max(Mf, 1)), zf(max(Mf, 1))
-        # ---- per-row loss coefficients dCMPL/d(row term) (src/DrVAE.py:611-624)
-        self.beta = None
-        self.c_nll = zf(Md)
-        self.c_nll[:self.o3] = -1.0 / (L * self.n_tot)
-        if cfg.has_y:
-            self.c_kld = torch.full((L * B,), 1.0 / (L * self.n_tot), device=dev)
-            self.c_yl = torch.full((L * B,), -cfg.yloss_rate / (L * max(1., self.n_lab)), device=dev)
-        if cfg.kind == 'pvae':
-            self.c_klp = torch.full((Me,), 1.0 / self.n_tot, device=dev)
-        if cfg.has_pert:
-            self.c_klz2 = zf(L * Np)
-        self.w_elbo = zf(3)
-        self.w_cmpl = zf(N_LOSS)
-        self._cfg = cfg
-        self.x1 = self.x2 = None
-        self.feed = None        # graph-resident input feed (drvae_amd.data.DeviceBatcher.begin_epoch)
-
-    def set_labels_host(self, yv):
-        """class labels of this batch's rows (host ints; only the labeled rows' entries matter)"""
-        cfg = self._cfg
-        yv = np.asarray(yv).astype(np.int64).reshape(-1)
-        lab = np.where(self._has_y_host, yv, 0)
-        self.label_r.copy_(torch.as_tensor(np.tile(lab, cfg.L), dtype=torch.int32))
-        if self.Mf:
-            cls = np.where(self._fp_lab_host, yv[self.fp_i_host], self.fp_slot_host)
-            self.fp_cls.copy_(torch.as_tensor(cls, dtype=torch.int32))
-        self._refresh_onehot()
-
-    def set_labels_device(self, y_dev):
-        """same from a device tensor of B labels (device-resident input pipeline: no host sync)"""
-        cfg = self._cfg
-        y32 = y_dev.reshape(-1).to(torch.int32)
-        self.label_r.copy_(torch.where(self.has_y_dev, y32, torch.zeros_like(y32)).repeat(cfg.L))
-        if self.Mf:
-            self.fp_cls.copy_(torch.where(self.fp_lab_dev, y32[self.fp_i_dev], self.fp_slot_dev))
-        self._refresh_onehot()
-
-    def _refresh_onehot(self):
-        # one-hot class columns of the decoder_z1 input [z3 | onehot(y)] (src/DrVAE.py:355)
-        if self._cfg.has_y and self.Mf:
-            Z3, Y = self._cfg.dim_z3, self._cfg.dim_y
-            K.rows_gather(self.Z3IN[:, Z3:], None, None, onehot_cls=self.fp_cls, n_classes=Y, width=0)
-
-    def set_beta(self, beta):
-        """(re)write the coefficients that depend on the perturbation annealing coefficient
-        (0.01 on the very first iteration, 1.0 afterwards with the driver settings)."""
-        if self.beta == beta:
-            return
-        cfg, L = self._cfg, self._cfg.L
-        self.beta = beta
-        if cfg.has_pert:
-            self.c_nll[self.o3:] = -beta * cfg.pertloss_rate / (L * max(1., self.n_pairs))
-            self.c_klz2.fill_(beta * cfg.kl_qz2pz2_rate / (L * self.n_tot))
-            self.w_elbo.copy_(torch.tensor([1.0, -1.0, beta * cfg.pertloss_rate]))
-        else:
-            self.w_elbo.copy_(torch.tensor([1.0, -1.0, 0.0]))
-        w = [0.0] * N_LOSS
-        w[LOSS_IDX['ELBO']] = -1.0
-        if cfg.has_y:
-            w[LOSS_IDX['YL']] = -cfg.yloss_rate
-        self.w_cmpl.copy_(torch.tensor(w))

@@ -1,0 +1,373 @@
+"""How the launch sequence of the fused train step is put on the GPU: hipGraph capture / replay, the
+dual-graph schedule (main chain and side chain as two single-stream graphs ordered by device flags),
+the CU partition of the two chains, and the data-parallel graph splits.  Mixed into ``FusedStep``."""
+import os
+
+import torch
+
+from . import kernels as K
+
+
+def _masked_stream(bits, device):
+    """a HIP stream whose kernels only run on the CUs set in ``bits`` (hipExtStreamCreateWithCUMask),
+    wrapped for torch; lives for the rest of the process"""
+    import ctypes
+    hip = ctypes.CDLL('libamdhip64.so')
+    st = ctypes.c_void_p()
+    arr = (ctypes.c_uint32 * len(bits))(*bits)
+    with torch.cuda.device(device):
+        rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), len(bits), arr)
+    if rc != 0:
+        raise RuntimeError('hipExtStreamCreateWithCUMask failed: %d' % rc)
+    import atexit
+
+    def _destroy(handle=st.value):       # before the HIP runtime tears down (profilers crash otherwise)
+        try:
+            torch.cuda.synchronize()
+            hip.hipStreamDestroy(ctypes.c_void_p(handle))
+        except Exception:
+            pass
+    atexit.register(_destroy)
+    return torch.cuda.ExternalStream(st.value, device=device)
+
+
+class _Branch:
+    """Fork/join of an independent launch chain onto a side HIP stream.  Inside a hipGraph
+    capture the side stream joins the capture, so the chain becomes a parallel branch of the
+    graph; on CPU tensors (unit tests with stand-in launchers) it degrades to inline execution."""
+
+    def __init__(self, device, enabled=True):
+        self.on = enabled and torch.device(device).type == 'cuda'
+        self.side = torch.cuda.Stream(device=device) if self.on else None
+
+    def fork(self):
+        """mark the point of the current stream the side chain depends on; the chain itself may be
+        recorded later (``with branch:``).  Measured on MI355X (tools/graph_fork_probe.py): the hipGraph
+        executor runs a fork/join ~30 us faster when the MAIN continuation is recorded before the side
+        chain, so callers fork, record the main work, and only then the side chain."""
+        if self.on:
+            self.side.wait_stream(torch.cuda.current_stream())
+            self._forked = True
+
+    def wait_main(self):
+        """extra edge main -> side at the current point of the main stream"""
+        if self.on:
+            self.side.wait_stream(torch.cuda.current_stream())
+
+    def __enter__(self):
+        if self.on:
+            if not getattr(self, '_forked', False):
+                self.side.wait_stream(torch.cuda.current_stream())
+            self._forked = False
+            self._ctx = torch.cuda.stream(self.side)
+            self._ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            self._ctx.__exit__(*exc)
+
+    def join(self):
+        if self.on:
+            torch.cuda.current_stream().wait_stream(self.side)
+
+
+class StepSchedule:
+    """scheduling half of ``FusedStep`` (see the module docstring); relies on its forward / backward /
+    optimizer_step / draw_noise and on its plan, arena and counters"""
+
+    def _mode(self):
+        if not self.fuse_bwd:
+            return 0
+        if self._rec != 'both':
+            return 5
+        if self.sched == 5:
+            return 3                 # eager steps of the dual-graph schedule use plain stream edges
+        return self.sched if (self.sched != 4 or self.branch.on) else 1
+
+    def _step_begin(self):
+        if self._mode() == 4:
+            self.branch.fork()       # side chain = second root of the step (eager: waits for the previous step)
+
+    def _step_end(self):
+        if self.fuse_bwd and self.sched == 4 and self.branch.on:
+            self.branch.join()       # streams rejoin (required to end a capture); off the critical path
+
+    # ------------------------------------------------------------------- hipGraph
+    def _launch_sequence(self, allreduce=None):
+        self.fuse_bwd = True
+        try:
+            self._step_begin()
+            self.draw_noise(bump=False)
+            self.forward()
+            self.backward()
+            if allreduce is not None:
+                allreduce(self.arena.xchg)
+            self.optimizer_step()
+            self._step_end()        # after Adam: the rejoin edge stays off the critical path
+        finally:
+            self.fuse_bwd = False
+
+    def capture(self, split_for_allreduce=False):
+        """Capture the train step (Philox noise + forward + backward + Adam: ~100 launches)
+        into hipGraph(s) for the current batch structure.  With ``split_for_allreduce`` the
+        step is captured as two graphs so that an (uncaptured) RCCL all-reduce of the
+        gradient arena can run between backward and Adam."""
+        assert self.plan is not None, 'set_batch first'
+        self.training = True
+        self.plan.set_beta(self.beta_pert())
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):         # warm-up on a side stream (loads code objects)
+            self.draw_noise()
+            self.forward()
+            self.backward()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self._graphs = []
+        self._side_graph = None
+        dual = self.sched == 5 and self.branch.on and self.cfg.has_y and self._flags_usable()
+        if dual:
+            self._rec = 'main'
+        try:
+            self._capture_main(split_for_allreduce)
+            if dual:
+                self._rec = 'side'
+                self.side_ctr.copy_(self.step_dev)
+                self.flag_side.wait_stream(torch.cuda.current_stream())
+                gs = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gs, stream=self.flag_side):
+                    self.fuse_bwd = True
+                    try:
+                        self.forward()
+                        self.backward()
+                    finally:
+                        self.fuse_bwd = False
+                self._side_graph = gs
+        finally:
+            self._rec = 'both'
+        self._graph_key = self.plan.key
+        self._graph_feed = self.plan.feed
+        return self
+
+    # ------------------------------------------------------------ CU partition
+    def _partition_applicable(self):
+        # only for latency-bound steps: once the decoder products alone fill the chip many times over
+        # (wide configuration) the main chain needs every CU (measured: 52 ms -> 66 ms/step when masked)
+        small = self.plan is not None and self.plan.DPX.shape[0] * self.plan.DPX.shape[1] <= (4 << 20)
+        return bool(self.branch.on and self.sched == 5 and self.cfg.has_y and small and
+                    int(os.environ.get('DRVAE_SIDE_CUS', '64')) > 0)
+
+    def _part_streams(self, n_side):
+        """(main, side) CU-masked streams reserving ``n_side`` CUs for the side chain (cached)"""
+        cache = self.__dict__.setdefault('_parts', {})
+        if n_side not in cache:
+            n_cu = torch.cuda.get_device_properties(self.dev).multi_processor_count
+            words = (n_cu + 31) // 32
+            side_bits, all_bits = [0] * words, [0] * words
+            for i in range(n_cu):
+                all_bits[i // 32] |= 1 << (i % 32)
+                if i < min(n_side, n_cu - 1):
+                    side_bits[i // 32] |= 1 << (i % 32)
+            main_bits = [a & ~b for a, b in zip(all_bits, side_bits)]
+            try:
+                pair = (_masked_stream(main_bits, self.dev), _masked_stream(side_bits, self.dev))
+                with torch.cuda.stream(pair[0]):
+                    if not self._probe(pair[1]):         # must sit on different hardware queues
+                        pair = None
+            except (OSError, RuntimeError, AttributeError) as e:      # runtime without CU masking: plain streams
+                import warnings
+                warnings.warn('drvae_amd: CU partition unavailable (%s)' % e)
+                pair = None
+            cache[n_side] = pair
+        return cache[n_side]
+
+    def partition(self, n_side=None):
+        """Context manager: run the train step with the GPU's compute units split between the two
+        launch chains -- the side chain (many small launches) on ``n_side`` reserved CUs, the main
+        chain (the big GEMMs) on the rest -- via CU-masked HIP streams.  Inside the context the
+        masked main stream is the current stream, so everything the caller enqueues (batch feed,
+        loss accumulation, replays) is ordered with the step; on exit the outer stream waits for it.
+        Measured on MI355X (cfg 2): 64 reserved CUs take the step from 0.264 to 0.240 ms; without the
+        reservation the side chain's small kernels queue behind the GEMM workgroups and the main
+        chain waits ~32 us per step at the join.  ``tune_partition()`` picks the split by timing.
+        No-op when not applicable, disabled (DRVAE_SIDE_CUS=0) or off-GPU."""
+        import contextlib
+        if not self._partition_applicable():
+            return contextlib.nullcontext()
+        if n_side is None:
+            n_side = getattr(self, '_side_cus', None) or int(os.environ.get('DRVAE_SIDE_CUS', '64'))
+        pair = self._part_streams(n_side)
+        if pair is None:
+            return contextlib.nullcontext()
+        main, side = pair
+
+        @contextlib.contextmanager
+        def ctx():
+            outer = torch.cuda.current_stream()
+            prev = self._flag_side
+            main.wait_stream(outer)
+            side.wait_stream(outer)
+            self._flag_side = side
+            try:
+                with torch.cuda.stream(main):
+                    yield self
+            finally:
+                outer.wait_stream(main)
+                outer.wait_stream(side)
+                self._flag_side = prev
+        return ctx()
+
+    def tune_partition(self, candidates=(48, 64, 72, 80, 96), steps=24):
+        """Pick the CU split of ``partition()`` by timing replays of the captured step (the best split
+        depends on how the two chains balance, i.e. on the model and on the individual GPU).  Runs on a
+        scratch copy of the training state: parameters, Adam moments and all device counters are restored
+        afterwards.  Returns the chosen number of reserved CUs (None when partitioning does not apply)."""
+        if not (self._partition_applicable() and self._side_graph is not None and len(self._graphs) == 1) or \
+                'DRVAE_SIDE_CUS' in os.environ:       # (multi-rank: split graphs need the exchange; keep the default)
+            return None
+        a = self.arena
+        keep = [t.clone() for t in (a.param, a.exp_avg, a.exp_avg_sq, self.step_dev, self.side_ctr, self.rng_ctr,
+                                    self.flags)]
+        iters = self.iters
+        best = (None, float('inf'))
+        for n in candidates:
+            if self._part_streams(n) is None:
+                continue
+            with self.partition(n):
+                for _ in range(4):
+                    self.replay()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(steps):
+                    self.replay()
+                e1.record()
+                e1.synchronize()
+                t = e0.elapsed_time(e1)
+            if t < best[1]:
+                best = (n, t)
+        torch.cuda.synchronize()
+        for dst, src in zip((a.param, a.exp_avg, a.exp_avg_sq, self.step_dev, self.side_ctr, self.rng_ctr,
+                             self.flags), keep):
+            dst.copy_(src)
+        self.iters = iters
+        self.plan.set_beta(self.beta_pert())
+        torch.cuda.synchronize()
+        self._side_cus = best[0]
+        return best[0]
+
+    @property
+    def flag_side(self):
+        """the stream the side-chain graph of the dual-graph schedule is launched on: CU-masked inside
+        ``partition()``, otherwise a plain stream that ``_flags_usable`` has verified to sit on a
+        different hardware queue than the launching stream."""
+        if self._flag_side is None:
+            self._flag_side = torch.cuda.Stream(device=self.dev)
+        return self._flag_side
+
+    def _probe(self, side):
+        """park a short wait on the launching stream, publish from ``side``: a timeout means the two
+        streams share a hardware queue (a parked wait kernel blocks everything behind it in its queue)"""
+        probe = torch.zeros(4, dtype=torch.int32, device=self.dev)      # flag, counter, error, ticks
+        torch.cuda.synchronize()
+        K.flag_wait(probe[0:1], probe[1:2], probe[2:4], add=1, max_spins=20000)
+        with torch.cuda.stream(side):
+            K.flag_publish(probe[0:1], probe[1:2], 1)
+        torch.cuda.synchronize()
+        return int(probe[2]) == 0
+
+    def _flags_usable(self):
+        """Device-flag ordering needs the two streams on DIFFERENT hardware queues.  HIP multiplexes its
+        streams onto a few queues, so probe candidates until one qualifies (the CU-masked stream of
+        ``partition()`` has a queue of its own); otherwise fall back to graph edges.  (High-priority
+        streams are avoided on purpose: with one in the process, captured fork/joins ran 2.4x slower.)"""
+        if getattr(self, '_flags_ok', None) is None:
+            ok = self._probe(self.flag_side)
+            tries = 0
+            while not ok and not getattr(self, '_part', None) and tries < 8:
+                self._flag_side = torch.cuda.Stream(device=self.dev)
+                ok = self._probe(self._flag_side)
+                tries += 1
+            self._flags_ok = ok
+            if not ok:
+                import warnings
+                warnings.warn('drvae_amd: no side stream on a hardware queue of its own; using graph edges')
+        return self._flags_ok
+
+    def check_sync(self):
+        """raise if a device-side wait of the dual-graph schedule ever timed out (results would be stale)"""
+        if int(self.sync_err[0::2].abs().sum()) != 0:
+            raise RuntimeError('drvae_amd: a device-side chain wait timed out (main / side stream ordering)')
+
+    def _capture_main(self, split_for_allreduce):
+        if split_for_allreduce == 'overlap' and self.arena.late_end < self.arena.xchg.numel():
+            # three graphs: [noise .. decoder backward] | [rest of backward] | [Adam]; the exchange of the
+            # decoder block is launched between the first two and travels while the second runs
+            ga, gb, gc = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            cap = torch.cuda.Stream(device=self.dev)
+            cap.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(cap):
+                def split():
+                    ga.capture_end()
+                    gb.capture_begin()
+                self._after_decoder_bwd = split
+                self.fuse_bwd = True
+                try:
+                    ga.capture_begin()
+                    self._step_begin()
+                    self.draw_noise(bump=False)
+                    self.forward()
+                    self.backward()
+                    self._step_end()
+                    gb.capture_end()
+                finally:
+                    self.fuse_bwd = False
+                    self._after_decoder_bwd = None
+                gc.capture_begin()
+                self.optimizer_step()
+                gc.capture_end()
+            torch.cuda.current_stream().wait_stream(cap)
+            self._graphs = [ga, gb, gc]
+        elif split_for_allreduce:
+            g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g1):
+                self.fuse_bwd = True
+                try:
+                    self._step_begin()
+                    self.draw_noise(bump=False)
+                    self.forward()
+                    self.backward()
+                    self._step_end()
+                finally:
+                    self.fuse_bwd = False
+            with torch.cuda.graph(g2):
+                self.optimizer_step()
+            self._graphs = [g1, g2]
+        else:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._launch_sequence()
+            self._graphs = [g]
+
+    def replay(self, allreduce=None):
+        """One captured train step.  New data is fed by copying into plan.x1 / plan.x2 in place."""
+        assert self._graph_key == self.plan.key, 'batch structure changed: capture again'
+        assert self._graph_feed is self.plan.feed, 'input feed changed: capture again'
+        self.plan.set_beta(self.beta_pert())      # 0.01 on iteration 0, 1.0 afterwards (device-side coefficients)
+        if self._side_graph is not None:         # first: its wait kernel is parked before the main chain publishes
+            with torch.cuda.stream(self.flag_side):
+                self._side_graph.replay()
+        self._graphs[0].replay()
+        if len(self._graphs) == 3:               # overlapped exchange: ``allreduce`` has start()/finish()
+            a = self.arena
+            w_early = allreduce.start(a.xchg[a.late_end:])
+            self._graphs[1].replay()
+            w_late = allreduce.start(a.xchg[:a.late_end])
+            allreduce.finish(w_early)
+            allreduce.finish(w_late)
+            self._graphs[2].replay()
+        elif len(self._graphs) == 2:
+            if allreduce is not None:
+                allreduce(self.arena.xchg)
+            self._graphs[1].replay()
+        self.iters += 1
