@@ -45,8 +45,6 @@ struct LoadCfg {
     int vecA, vecB;   // widest aligned vector width (4, 2 or 1 floats) per operand
     int vecA_t, vecB_t;   // same for the ragged last K tile of a k-contiguous operand: also divides K
     int map;          // workgroup -> tile mapping: 0 linear, 1 XCD chunk-major (default)
-    int dbg;          // tuning only: bit0 skip in-loop global loads, bit1 skip MFMAs, bit2 skip in-loop LDS stores
-    unsigned long long* stamps;   // tuning only: per-phase s_memtime sums of block 0 / wave 0
 };
 
 // XCD-aware workgroup -> tile map.  Observed dispatch: blocks b and b+8 share an XCD and its
@@ -650,12 +648,6 @@ int launch_cfg(const dv_gemm_desc& g, const LoadCfg& lc, hipStream_t st) {
 
 static int g_force_tiling = 0;   // 0 = heuristic; 1 = T64, 2 = T32K, 3 = T128 (tests / tuning)
 static int g_opt[8] = {1, 0, 0, 0, 0, 0, 0, 0};   // [0] = tile map (0 linear, 1 XCD chunk-major)
-static unsigned long long* g_stamps = nullptr;
-
-extern "C" int dv_gemm_debug_stamps(unsigned long long* dev_buf) {   // tuning hook, not part of the ABI
-    g_stamps = dev_buf;
-    return DV_OK;
-}
 
 extern "C" int dv_gemm_set_option(int key, int value) {
     if (key < 0 || key >= 8) return DV_ERR_ARG;
@@ -696,8 +688,6 @@ static int gemm_prepare(const dv_gemm_desc* d, LoadCfg& lc, int& tiling) {
     while (g.K % lc.vecA_t) lc.vecA_t >>= 1;
     while (g.K % lc.vecB_t) lc.vecB_t >>= 1;
     lc.map = g_opt[0];
-    lc.dbg = g_opt[1];
-    lc.stamps = g_stamps;
     const int64_t t64 = (int64_t)((g.M + 63) / 64) * ((g.N + 63) / 64);
     const int64_t t128 = (int64_t)((g.M + 127) / 128) * ((g.N + 127) / 128);
     tiling = g_force_tiling;
