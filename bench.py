@@ -92,6 +92,38 @@ def cpu_baseline(workload, budget_s=12.0, threads=4):
                       '%.1f s of CPU work; host has %d logical cores' % (n, rows, L, threads, dt, os.cpu_count())}
 
 
+def parity_vs_cpu(workload, device, steps=2):
+    """'ELBO vs ref delta' of the metric: the same train steps (same parameters, same batch, same injected
+    N(0,1) draws) on the HIP path and on the CPU oracle; the largest relative difference over the loss
+    scalars (RECL, KLD, PERT, YL, ELBO, CMPL) of every step.  Part of the cpu_baseline leg."""
+    from oracle import models_ref as M
+    from drvae_amd import engine as E
+    from drvae_amd.arena import ParamArena
+    kind, rows, L, over, _ = WORKLOADS[workload]
+    spec = M.ModelSpec(kind=kind, L=L, **over)
+    cfg = E.StepConfig(kind=kind, L=L, **over)
+    params = M.init_params(spec, 123, as_numpy=True)
+    arena = ParamArena(E.param_shapes(cfg), device, frozen=E.frozen_params(cfg))
+    arena.load(params)
+    eng = E.FusedStep(cfg, arena)
+    batch = M.make_batch(spec, rows, seed=1234)
+    t = lambda k: torch.from_numpy(batch[k]).to(device)
+    eng.set_batch(t('x1'), t('x2'), batch['y'], batch['has_x2'], batch['has_y'])
+    tr = M.RefTrainer(spec, M.init_params(spec, 123))
+    worst = 0.0
+    for s_ in range(steps):
+        noise = M.make_noise(spec, rows, seed=100 + s_)
+        eng.train_step(noise)
+        got = eng.losses()
+        ref, _ = tr.step(batch, noise)
+        for k, v in got.items():
+            r = float(ref[k].detach()) if torch.is_tensor(ref[k]) else float(ref[k])
+            if k != 'MMD':
+                worst = max(worst, abs(v - r) / max(abs(r), 1e-6))
+    return {'max_rel_diff_losses': float('%.3g' % worst), 'steps': steps, 'tolerance': 1e-4,
+            'what': 'HIP train steps vs CPU oracle, identical parameters / batch / injected noise'}
+
+
 def gemm_roofline(eng, cfg, rows, frac_pair, frac_lab, repeats=20, traffic=None):
     """Roofline of the dominant kernel family: the fp32-MFMA GEMM (all tilings/layouts; 32
     launches per cfg-2 step).  Every GEMM launch of one train step is re-issued `repeats`
@@ -281,6 +313,7 @@ def main():
                                             traffic=PMC_TRAFFIC_BYTES_PER_GEMM_LAUNCH.get(args.workload))
         if not args.no_cpu_baseline and args.workload != 'wide' and world == 1:   # rank 0 at N=1 only
             out['cpu_baseline'] = cpu_baseline(args.workload)
+            out['elbo_vs_ref'] = parity_vs_cpu(args.workload, device)
     if world > 1:
         dist.barrier()
     if rank == 0:
