@@ -76,7 +76,7 @@ SIGNATURES = {
     'dv_ycont_bwd': [_p, _i64, _p, _p, _f, _p, _p, _p, _i64, _p, _i64, _i32, _i32, _i32, _p, _i64, _p, _p],
     'dv_rows_gather': [_p, _i64, _p, _i32, _i32, _p, _i64, _f, _p, _i32, _p, _i64, _p],
     'dv_batch_feed': [_p, _i64, _p, _i64, _p, _p, _i32, _p, _p, _i32, _p, _i32, _i32, _p, _i64, _f, _p, _i64, _p, _i32,
-                      _p, _p, _p, _p, _i32, _p, _p, _i64, _i32, _p],
+                      _p, _p, _p, _p, _i32, _p, _p, _i64, _i32, _p, _p, _i32, _p],
     'dv_rows_segment_sum': [_p, _i64, _p, _p, _p, _i32, _i32, _p, _p, _i64, _f, _p],
     'dv_weighted_sum': [_p, _p, _p, _i32, _f, _p, _f, _p],
     'dv_recon_row_stats': [_p, _i64, _p, _i64, _i32, _i32, _p, _p],

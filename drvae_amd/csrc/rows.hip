@@ -867,7 +867,8 @@ __global__ __launch_bounds__(256) void batch_feed_kernel(
     int Np, int X, const float* __restrict__ noise, int64_t ldn, float sigma, float* __restrict__ xin, int64_t ldo,
     const int32_t* __restrict__ has_y, int L, int32_t* __restrict__ label_r, const int32_t* __restrict__ fp_i,
     const int32_t* __restrict__ fp_lab, const int32_t* __restrict__ fp_slot, int Mf, int32_t* __restrict__ fp_cls,
-    float* __restrict__ onehot, int64_t ldh, int Y, int row_blocks, int vec4) {
+    float* __restrict__ onehot, int64_t ldh, int Y, int row_blocks, int vec4, const float* __restrict__ yf,
+    float* __restrict__ ylab, int Yc) {
     int b = ctr[0] - base[0];
     b = b < 0 ? 0 : (b >= n_batches ? n_batches - 1 : b);
     const int32_t* tb = table + (int64_t)b * B;
@@ -900,6 +901,10 @@ __global__ __launch_bounds__(256) void batch_feed_kernel(
     if (label_r && t < L * B) {
         const int i = t % B;
         label_r[t] = has_y[i] ? y[tb[i]] : 0;
+    }
+    if (ylab && t < B * Yc) {      // regression targets (type_y='cont'): ylab[i,:] = yf[row of slot i,:]
+        const int i = t / Yc, d = t % Yc;
+        ylab[t] = yf[(int64_t)tb[i] * Yc + d];
     }
     if (fp_cls && t < Mf) {
         const int cls = fp_lab[t] ? y[tb[fp_i[t]]] : fp_slot[t];
@@ -1429,21 +1434,23 @@ extern "C" int dv_batch_feed(const float* x1, int64_t ld1, const float* x2, int6
                              int32_t B, const int32_t* pair_rows, int32_t Np, int32_t X, const float* noise,
                              int64_t ldn, float sigma, float* xin, int64_t ldo, const int32_t* has_y, int32_t L,
                              int32_t* label_r, const int32_t* fp_i, const int32_t* fp_lab, const int32_t* fp_slot,
-                             int32_t Mf, int32_t* fp_cls, float* onehot, int64_t ldh, int32_t Y,
-                             dv_stream_t stream) {
-    DV_REQUIRE(B >= 0 && Np >= 0 && X >= 0 && n_batches >= 1 && L >= 1 && Mf >= 0 && Y >= 0);
+                             int32_t Mf, int32_t* fp_cls, float* onehot, int64_t ldh, int32_t Y, const float* yf,
+                             float* ylab, int32_t Yc, dv_stream_t stream) {
+    DV_REQUIRE(B >= 0 && Np >= 0 && X >= 0 && n_batches >= 1 && L >= 1 && Mf >= 0 && Y >= 0 && Yc >= 0);
+    DV_REQUIRE(!ylab || (yf && Yc >= 1));
     if (B == 0) return DV_OK;
     DV_REQUIRE(x1 && table && ctr && base && xin && (Np == 0 || (x2 && pair_rows)));
     DV_REQUIRE(!label_r || (y && has_y));
     DV_REQUIRE(!fp_cls || Mf == 0 || (y && fp_i && fp_lab && fp_slot));
     const int row_blocks = (B + Np + 3) / 4;
-    const int nlab = (label_r ? L * B : 0) > (fp_cls ? Mf : 0) ? (label_r ? L * B : 0) : (fp_cls ? Mf : 0);
+    int nlab = (label_r ? L * B : 0) > (fp_cls ? Mf : 0) ? (label_r ? L * B : 0) : (fp_cls ? Mf : 0);
+    if (ylab && B * Yc > nlab) nlab = B * Yc;
     const int lab_blocks = (nlab + 255) / 256;
     const bool v4 = aligned16(x1) && (Np == 0 || aligned16(x2)) && aligned16(xin) && (!noise || aligned16(noise)) &&
                     ld1 % 4 == 0 && (Np == 0 || ld2 % 4 == 0) && ldo % 4 == 0 && (!noise || ldn % 4 == 0);
     hipLaunchKernelGGL(batch_feed_kernel, dim3(row_blocks + lab_blocks), dim3(256), 0, ST(stream), x1, ld1, x2, ld2, y,
                        table, n_batches, ctr, base, B, pair_rows, Np, X, noise, ldn, sigma, xin, ldo, has_y, L,
-                       label_r, fp_i, fp_lab, fp_slot, Mf, fp_cls, onehot, ldh, Y, row_blocks, v4 ? 1 : 0);
+                       label_r, fp_i, fp_lab, fp_slot, Mf, fp_cls, onehot, ldh, Y, row_blocks, v4 ? 1 : 0, yf, ylab, Yc);
     DV_RETURN_LAUNCH();
 }
 

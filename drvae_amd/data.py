@@ -169,7 +169,8 @@ class DeviceBatcher:
             dev = self.ds.x1.device
             fd = types.SimpleNamespace(owner=self, n_batches=n_b, x1=self.ds.x1,
                                        x2=getattr(self.ds, 'x2', None) if eng.cfg.has_pert else None,
-                                       y32=self.ds.y.reshape(-1).to(torch.int32).contiguous(),
+                                       y32=None if eng.cfg.cont else self.ds.y.reshape(-1).to(torch.int32).contiguous(),
+                                       yf=self.ds.y.reshape(len(self.ds), -1).float().contiguous() if eng.cfg.cont else None,
                                        table=torch.zeros(n_b, self.batch_size, dtype=torch.int32, device=dev),
                                        base=torch.zeros(1, dtype=torch.int32, device=dev))
             p.feed = fd

@@ -336,13 +336,15 @@ class FusedStep(StepSchedule):
             if fd is not None:
                 # batch (optimiser step - epoch base) of the epoch's index table, straight from the
                 # HBM-resident dataset; also refreshes the label-dependent index buffers
-                lab = cfg.has_y
+                lab = cfg.has_y and not cfg.cont
                 K.batch_feed(p.XIN, fd.x1, fd.x2, fd.y32, fd.table, fd.n_batches, self.step_dev, fd.base,
                              pair_rows=p.pair_idx if Np else None, noise=p.EX if sigma else None, sigma=sigma,
                              has_y=p.has_y_i32 if lab else None, L=L, label_r=p.label_r if lab else None,
                              fp_i=p.fp_q if lab else None, fp_lab=p.fp_lab_i32 if lab else None,
                              fp_slot=p.fp_slot_dev if lab else None, fp_cls=p.fp_cls if (lab and p.Mf) else None,
-                             onehot=p.Z3IN[:, cfg.dim_z3:] if (lab and p.Mf) else None, n_classes=cfg.dim_y)
+                             onehot=p.Z3IN[:, cfg.dim_z3:] if (lab and p.Mf) else None, n_classes=cfg.dim_y,
+                             yf=fd.yf if (cfg.has_y and cfg.cont) else None,
+                             ylab=p.ylab if (cfg.has_y and cfg.cont) else None)
             else:
                 K.rows_gather(p.XIN, p.XSRC, p.xin_idx, noise=p.EX if sigma else None, sigma=sigma)
             # ---- q(z1|x1), q(z2|x2): one pass of the shared encoder

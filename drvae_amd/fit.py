@@ -220,7 +220,7 @@ class FitMixin:
         batcher.bind(eng, counts=getattr(self, '_global_counts', None))
         eng.add_noise = bool(self.add_noise)
         eng.iters = self.finished_training_iters
-        resident_feed = not eng.cfg.cont    # (regression targets are fed per step: the feed kernel moves int labels)
+        resident_feed = True
         if resident_feed:
             batcher.begin_epoch()           # this epoch's index table; the graph gathers batch b itself
         else:

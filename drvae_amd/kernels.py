@@ -363,7 +363,8 @@ def rows_gather(out, src, idx=None, *, noise=None, sigma=0.0, onehot_cls=None, n
 
 
 def batch_feed(xin, x1, x2, y32, table, n_batches, ctr, base, *, pair_rows=None, noise=None, sigma=0.0, has_y=None,
-               L=1, label_r=None, fp_i=None, fp_lab=None, fp_slot=None, fp_cls=None, onehot=None, n_classes=0):
+               L=1, label_r=None, fp_i=None, fp_lab=None, fp_slot=None, fp_cls=None, onehot=None, n_classes=0, yf=None,
+               ylab=None):
     """graph-resident minibatch feed: see dv_batch_feed in include/drvae_hip.h"""
     B = table.shape[1]
     Np = pair_rows.numel() if pair_rows is not None else 0
@@ -373,7 +374,8 @@ def batch_feed(xin, x1, x2, y32, table, n_batches, ctr, base, *, pair_rows=None,
                                          _i32(table), n_batches, _i32(ctr), _i32(base), B, _i32(pair_rows), Np,
                                          xin.shape[1], _f32(noise), _ld(noise), sigma, _f32(xin), _ld(xin),
                                          _i32(has_y), L, _i32(label_r), _i32(fp_i), _i32(fp_lab), _i32(fp_slot), Mf,
-                                         _i32(fp_cls), _f32(onehot), _ld(onehot), n_classes, _stream()),
+                                         _i32(fp_cls), _f32(onehot), _ld(onehot), n_classes, _f32(yf), _f32(ylab),
+                                         ylab.shape[1] if ylab is not None else 0, _stream()),
                'dv_batch_feed')
 
 

@@ -313,6 +313,7 @@ int dv_rows_gather(const float* src, int64_t lds, const int32_t* idx, int32_t n,
  *   xin[B + j] = x2[table[b,pair_rows[j]]]     (j <  Np)     }
  *   label_r[l*B+i] = has_y[i] ? y[table[b,i]] : 0
  *   fp_cls[m]  = fp_lab[m] ? y[table[b,fp_i[m]]] : fp_slot[m];  onehot[m,c] = (c == fp_cls[m])
+ *   ylab[i,:]  = yf[table[b,i],:]   (Yc floats per row; regression targets of type_y='cont', or NULL)
  * ctr/base are DEVICE scalars (ctr = the optimiser's step counter), so the launch arguments are
  * constant and the launch can live inside the captured train-step graph. */
 int dv_batch_feed(const float* x1, int64_t ld1, const float* x2, int64_t ld2, const int32_t* y, const int32_t* table,
@@ -320,7 +321,7 @@ int dv_batch_feed(const float* x1, int64_t ld1, const float* x2, int64_t ld2, co
                   int32_t Np, int32_t X, const float* noise, int64_t ldn, float sigma, float* xin, int64_t ldo,
                   const int32_t* has_y, int32_t L, int32_t* label_r, const int32_t* fp_i, const int32_t* fp_lab,
                   const int32_t* fp_slot, int32_t Mf, int32_t* fp_cls, float* onehot, int64_t ldh, int32_t Y,
-                  dv_stream_t stream);
+                  const float* yf, float* ylab, int32_t Yc, dv_stream_t stream);
 /* dst[di,:W] = beta*dst[di,:W] + sum_{t in [seg_ptr[i],seg_ptr[i+1])} w[t]*src[seg_rows[t],:W],
  * di = dst_idx?dst_idx[i]:i; seg_ptr==NULL: segment i is the single row (seg_rows?seg_rows[i]:i).
  * Deterministic (no atomics): the transpose of every gather above. */

@@ -489,7 +489,11 @@ def rows_gather(out, src, idx=None, *, noise=None, sigma=0.0, onehot_cls=None, n
 
 
 def batch_feed(xin, x1, x2, y32, table, n_batches, ctr, base, *, pair_rows=None, noise=None, sigma=0.0, has_y=None,
-               L=1, label_r=None, fp_i=None, fp_lab=None, fp_slot=None, fp_cls=None, onehot=None, n_classes=0):
+               L=1, label_r=None, fp_i=None, fp_lab=None, fp_slot=None, fp_cls=None, onehot=None, n_classes=0, yf=None,
+               ylab=None):
+    if ylab is not None:
+        bb = min(max(int(ctr[0]) - int(base[0]), 0), n_batches - 1)
+        ylab.copy_(yf.reshape(-1, ylab.shape[1])[table[bb].long()])
     b = min(max(int(ctr[0]) - int(base[0]), 0), n_batches - 1)
     tb = table[b].long()
     B = tb.numel()

@@ -628,6 +628,13 @@ def test_batch_feed(K, dev, X, pad, Np, Mf):
         close(outs[0][0], outs[1][0], rtol=1e-6, atol=1e-6)
         for a, b in zip(outs[0][1:], outs[1][1:]):
             assert torch.equal(a, b)
+    # regression targets (type_y='cont'): ylab[i,:] = yf[row of slot i,:]
+    yf = torch.rand(N, 2).to(dev)
+    yl, ryl = torch.empty(B, 2, device=dev), torch.empty(B, 2, device=dev)
+    xin, rin = torch.empty(B + Np, X, device=dev), torch.empty(B + Np, X, device=dev)
+    K.batch_feed(xin, x1, x2, None, table, nb, ctr, bs, pair_rows=pair_rows, yf=yf, ylab=yl)
+    R.batch_feed(rin, x1, x2, None, table, nb, ctr, bs, pair_rows=pair_rows, yf=yf, ylab=ryl)
+    assert torch.equal(yl, ryl) and torch.equal(xin, rin)
     # no noise / no labels (PVAE-style call)
     xin, rin = torch.empty(B + Np, X, device=dev), torch.empty(B + Np, X, device=dev)
     K.batch_feed(xin, x1, x2, None, table, nb, ctr, bs, pair_rows=pair_rows)
