@@ -55,10 +55,11 @@ class ELBOModel(FitMixin, DeepGenerativeModelMixin, nn.Module):
             bad.append('use_s=True (crashes in the reference too: torch.cat([z, s_raw]), src/DrVAE.py:438)')
         if getattr(self, 'type_y', 'discrete') not in ('discrete', 'cont'):
             raise ValueError('Invalid type_y')
-        if getattr(self, 'type_y', 'discrete') == 'cont' and self.kind == 'vfae':
+        if getattr(self, 'type_y', 'discrete') == 'cont' and self.kind == 'vfae' and getattr(self, 'semi_supervised', False):
             # the reference's own semi-supervised regression branch crashes (src/VFAE.py:386 passes the
-            # 1-tuple returned by sample() on to torch.cat): nothing to be identical to
-            bad.append("VFAE with type_y='cont'")
+            # 1-tuple returned by sample() on to torch.cat): nothing to be identical to.  Supervised-only
+            # (labeled rows, squared-error y-loss, src/VFAE.py:351) runs and is supported
+            bad.append("semi-supervised VFAE with type_y='cont'")
         if getattr(self, 'type_y', 'discrete') == 'cont' and not isinstance(getattr(self, 'prior_y', 'uniform'), str):
             bad.append("type_y='cont' with a data prior")
         if getattr(self, 'clf_1sig', False) and self.dim_y != 2:

@@ -788,7 +788,7 @@ __global__ void ymarg_fwdbwd_kernel(const float* __restrict__ qy, int64_t ldq, c
 // The y columns of the two fprop inputs [z1 | y] and [z3 | y] are written here.
 __global__ void ycont_fwd_kernel(const float* __restrict__ mu, int64_t ldm, const float* __restrict__ ylab,
                                  const int32_t* __restrict__ has_y, const float* __restrict__ eps, int64_t lde,
-                                 float logvar, int R, int B, int Y, float* __restrict__ yl,
+                                 float logvar, int sqerr, int R, int B, int Y, float* __restrict__ yl,
                                  float* __restrict__ fpin_y, int64_t ld1, float* __restrict__ z3in_y, int64_t ld2) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= R) return;
@@ -802,7 +802,7 @@ __global__ void ycont_fwd_kernel(const float* __restrict__ mu, int64_t ldm, cons
         if (lab) {
             yv = ylab[(int64_t)i * Y + d];
             const float df = yv - m;
-            acc += kLog2Pi + logvar + df * df * iv;
+            acc += sqerr ? 2.f * df * df : kLog2Pi + logvar + df * df * iv;    // (x -0.5 below)
         } else {
             yv = m + sd * eps[(int64_t)r * lde + d];
         }
@@ -815,8 +815,9 @@ __global__ void ycont_fwd_kernel(const float* __restrict__ mu, int64_t ldm, cons
 // dlogit[r,d] = dmu * mu(1-mu):  labeled dmu = c_yl[r]*(y-mu)/var;  unlabeled dmu = d/d(y columns of
 // the two fprop inputs) (the sample is mu + const*eps).  cfp[r] = c_kld[r] (one fprop row per row).
 __global__ void ycont_bwd_kernel(const float* __restrict__ mu, int64_t ldm, const float* __restrict__ ylab,
-                                 const int32_t* __restrict__ has_y, float logvar, const float* __restrict__ c_yl,
-                                 const float* __restrict__ c_kld, const float* __restrict__ dfpin_y, int64_t ld1,
+                                 const int32_t* __restrict__ has_y, float logvar, int sqerr,
+                                 const float* __restrict__ c_yl, const float* __restrict__ c_kld,
+                                 const float* __restrict__ dfpin_y, int64_t ld1,
                                  const float* __restrict__ dz3in_y, int64_t ld2, int R, int B, int Y,
                                  float* __restrict__ dlogit, int64_t ldd, float* __restrict__ cfp, int write_cfp) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -830,7 +831,7 @@ __global__ void ycont_bwd_kernel(const float* __restrict__ mu, int64_t ldm, cons
     }
     for (int d = 0; d < Y; ++d) {
         const float m = mu[(int64_t)r * ldm + d];
-        const float dmu = lab ? c_yl[r] * (ylab[(int64_t)i * Y + d] - m) * iv
+        const float dmu = lab ? c_yl[r] * (ylab[(int64_t)i * Y + d] - m) * (sqerr ? 2.f : iv)
                               : dfpin_y[(int64_t)r * ld1 + d] + dz3in_y[(int64_t)r * ld2 + d];
         dlogit[(int64_t)r * ldd + d] = dmu * m * (1.f - m);
     }
@@ -1394,25 +1395,25 @@ extern "C" int dv_ymarg_bwd(const float* qy, int64_t ldq, const int32_t* label, 
 }
 
 extern "C" int dv_ycont_fwd(const float* mu, int64_t ldm, const float* ylab, const int32_t* has_y, const float* eps,
-                            int64_t lde, float logvar, int32_t R, int32_t B, int32_t Y, float* yl, float* fpin_y,
-                            int64_t ld1, float* z3in_y, int64_t ld2, dv_stream_t stream) {
+                            int64_t lde, float logvar, int32_t sqerr, int32_t R, int32_t B, int32_t Y, float* yl,
+                            float* fpin_y, int64_t ld1, float* z3in_y, int64_t ld2, dv_stream_t stream) {
     DV_REQUIRE(R >= 0 && B >= 1 && Y >= 1);
     if (R == 0) return DV_OK;
     DV_REQUIRE(mu && ylab && has_y && eps && yl && fpin_y && z3in_y);
     hipLaunchKernelGGL(ycont_fwd_kernel, dim3((R + 255) / 256), dim3(256), 0, ST(stream), mu, ldm, ylab, has_y, eps, lde,
-                       logvar, R, B, Y, yl, fpin_y, ld1, z3in_y, ld2);
+                       logvar, sqerr, R, B, Y, yl, fpin_y, ld1, z3in_y, ld2);
     DV_RETURN_LAUNCH();
 }
 
 extern "C" int dv_ycont_bwd(const float* mu, int64_t ldm, const float* ylab, const int32_t* has_y, float logvar,
-                            const float* c_yl, const float* c_kld, const float* dfpin_y, int64_t ld1,
+                            int32_t sqerr, const float* c_yl, const float* c_kld, const float* dfpin_y, int64_t ld1,
                             const float* dz3in_y, int64_t ld2, int32_t R, int32_t B, int32_t Y, float* dlogit,
                             int64_t ldd, float* cfp, dv_stream_t stream) {
     DV_REQUIRE(R >= 0 && B >= 1 && Y >= 1);
     if (R == 0) return DV_OK;
     DV_REQUIRE(has_y && ((cfp && c_kld) || (mu && ylab && c_yl && dfpin_y && dz3in_y && dlogit)));
     hipLaunchKernelGGL(ycont_bwd_kernel, dim3((R + 255) / 256), dim3(256), 0, ST(stream), mu, ldm, ylab, has_y, logvar,
-                       c_yl, c_kld, dfpin_y, ld1, dz3in_y, ld2, R, B, Y, dlogit, ldd, cfp, dlogit == nullptr ? 1 : 0);
+                       sqerr, c_yl, c_kld, dfpin_y, ld1, dz3in_y, ld2, R, B, Y, dlogit, ldd, cfp, dlogit == nullptr ? 1 : 0);
     DV_RETURN_LAUNCH();
 }
 

@@ -385,7 +385,8 @@ class FusedStep(StepSchedule):
                     clf_in = [Z1blk]
                 QYm = p.c_clf.forward(clf_in)                         # sigmoid-constrained means
                 K.rows_gather(p.FPIN[:, :Z1], Z1blk, p.fp_src)
-                K.ycont_fwd(p.YLrow, p.FPIN[:, Z1:], p.Z3IN[:, Z3:], QYm, p.ylab, p.has_y_i32, p.EY, Y_LOGVAR_CONT, B)
+                K.ycont_fwd(p.YLrow, p.FPIN[:, Z1:], p.Z3IN[:, Z3:], QYm, p.ylab, p.has_y_i32, p.EY, Y_LOGVAR_CONT, B,
+                            sqerr=cfg.kind == 'vfae')       # VFAE scores by squared error (src/VFAE.py:351)
                 Q3 = p.c_top.forward([p.FPIN])
                 K.kl_rows_fwd(p.KL3, p.KL3raw, Q3[:, :Z3], Q3[:, Z3:], prior=(0.0, 0.0), free_bits=True,
                               kl_min=cfg.kl_min, eps=p.E3, zout=p.Z3IN[:, :Z3])
@@ -505,7 +506,7 @@ class FusedStep(StepSchedule):
                 Y, Z3 = cfg.dim_y, cfg.dim_z3
                 PZ1, Q3, QYm = p.c_dz1.out[-1], p.c_top.out[-1], p.c_clf.out[-1]
                 K.ycont_bwd(None, p.CFP, QYm, p.ylab, p.has_y_i32, Y_LOGVAR_CONT, p.c_yl, p.c_kld, p.DFPIN[:, Z1:],
-                            p.DZ3IN[:, Z3:], B)                    # cfp[r] = c_kld[r]: one fprop row per row
+                            p.DZ3IN[:, Z3:], B, sqerr=cfg.kind == 'vfae')     # cfp[r] = c_kld[r]: one fprop row per row
                 K.kl_rows_bwd(p.DQFP[:, :Z1], p.DQFP[:, Z1:], p.DPZ1[:, :Z1], p.DPZ1[:, Z1:], p.CFP, p.KL1raw,
                               Qmu, Qlv, PZ1[:, :Z1], PZ1[:, Z1:], qidx=p.fp_q, free_bits=True, kl_min=cfg.kl_min)
                 p.c_dz1.backward(p.DPZ1, [p.Z3IN], [[(p.DZ3IN, 1.0, 0.0)]])
@@ -515,7 +516,7 @@ class FusedStep(StepSchedule):
                 K.rows_segment_sum(p.DZ1B, p.DFPIN, seg_ptr=p.fp_ptr, beta=0.0, width=Z1)
                 # the y columns of both fprop inputs carry d/d(y sample); labeled rows: the log-likelihood
                 K.ycont_bwd(p.DLOG, None, QYm, p.ylab, p.has_y_i32, Y_LOGVAR_CONT, p.c_yl, p.c_kld, p.DFPIN[:, Z1:],
-                            p.DZ3IN[:, Z3:], B)
+                            p.DZ3IN[:, Z3:], B, sqerr=cfg.kind == 'vfae')
                 if cfg.kind == 'drvae' and cfg.clf_z1z2:
                     p.c_clf.backward(p.DLOG, [Z1blk, p.D], [[(p.DZ1B, 1.0, 1.0)], [(p.DZ2F, 1.0, 0.0), (p.DZ1B, -1.0, 1.0)]])
                 elif cfg.kind == 'drvae':

@@ -338,18 +338,19 @@ def ymarg_bwd(cfp, dqy, qy, label, fp_ptr, klfp, log_prior, c_kld, c_yl):
                                         _f32(cfp), _f32(dqy), _ld(dqy), _stream()), 'dv_ymarg_bwd')
 
 
-def ycont_fwd(yl, fpin_y, z3in_y, mu, ylab, has_y, eps, logvar, B):
+def ycont_fwd(yl, fpin_y, z3in_y, mu, ylab, has_y, eps, logvar, B, sqerr=False):
     """regression head forward, see ``dv_ycont_fwd``"""
     R, Y = mu.shape
-    _lib.check(_lib.load().dv_ycont_fwd(_f32(mu), _ld(mu), _f32(ylab), _i32(has_y), _f32(eps), _ld(eps), logvar, R, B, Y,
-                                        _f32(yl), _f32(fpin_y), _ld(fpin_y), _f32(z3in_y), _ld(z3in_y), _stream()),
+    _lib.check(_lib.load().dv_ycont_fwd(_f32(mu), _ld(mu), _f32(ylab), _i32(has_y), _f32(eps), _ld(eps), logvar, int(sqerr), R, B,
+                                        Y, _f32(yl), _f32(fpin_y), _ld(fpin_y), _f32(z3in_y), _ld(z3in_y), _stream()),
                'dv_ycont_fwd')
 
 
-def ycont_bwd(dlogit, cfp, mu, ylab, has_y, logvar, c_yl, c_kld, dfpin_y, dz3in_y, B):
+def ycont_bwd(dlogit, cfp, mu, ylab, has_y, logvar, c_yl, c_kld, dfpin_y, dz3in_y, B, sqerr=False):
     """``dlogit`` None: only cfp[r] = c_kld[r]; else the gradient w.r.t. the head's pre-sigmoid output"""
     R, Y = mu.shape
-    _lib.check(_lib.load().dv_ycont_bwd(_f32(mu), _ld(mu), _f32(ylab), _i32(has_y), logvar, _f32(c_yl), _f32(c_kld),
+    _lib.check(_lib.load().dv_ycont_bwd(_f32(mu), _ld(mu), _f32(ylab), _i32(has_y), logvar, int(sqerr), _f32(c_yl),
+                                        _f32(c_kld),
                                         _f32(dfpin_y), _ld(dfpin_y), _f32(dz3in_y), _ld(dz3in_y), R, B, Y,
                                         _f32(dlogit), _ld(dlogit), _f32(cfp), _stream()), 'dv_ycont_bwd')
 

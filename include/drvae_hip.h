@@ -288,10 +288,11 @@ int dv_ymarg_fwdbwd(const float* qy, int64_t ldq, const int32_t* label, const in
  * yv is written into the y columns of both fprop inputs (fpin_y, z3in_y point at column Z of [z | y]).
  * backward: dlogit = dmu * mu(1-mu) with dmu = c_yl*(y-mu)/var (labeled) or the sum of the gradients of
  * the two y columns (unlabeled); called with dlogit == NULL it only writes cfp[r] = c_kld[r]. */
+/* sqerr != 0: the labeled rows are scored by squared error instead, yl[r] = -sum_d (y-mu)^2 (VFAE.py:351). */
 int dv_ycont_fwd(const float* mu, int64_t ldm, const float* ylab, const int32_t* has_y, const float* eps, int64_t lde,
-                 float logvar, int32_t R, int32_t B, int32_t Y, float* yl, float* fpin_y, int64_t ld1,
+                 float logvar, int32_t sqerr, int32_t R, int32_t B, int32_t Y, float* yl, float* fpin_y, int64_t ld1,
                  float* z3in_y, int64_t ld2, dv_stream_t stream);
-int dv_ycont_bwd(const float* mu, int64_t ldm, const float* ylab, const int32_t* has_y, float logvar,
+int dv_ycont_bwd(const float* mu, int64_t ldm, const float* ylab, const int32_t* has_y, float logvar, int32_t sqerr,
                  const float* c_yl, const float* c_kld, const float* dfpin_y, int64_t ld1, const float* dz3in_y,
                  int64_t ld2, int32_t R, int32_t B, int32_t Y, float* dlogit, int64_t ldd, float* cfp,
                  dv_stream_t stream);

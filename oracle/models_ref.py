@@ -265,7 +265,10 @@ def _group_losses(spec, p, acc, idx, x1, x2, y, noise, iters, training):
         if cont:
             qy = B.diag_gaussian(clf_in, p, 'encoder_y', nhc, spec.nonlin, constrain_means=True,
                                  fixed_variance=0.05 ** 2)
-            if labeled:
+            if labeled and spec.kind == 'vfae':      # VFAE scores the regression head by squared error (VFAE.py:351)
+                acc.add('YL', idx, -((y1hot - qy[0]) ** 2).sum(1), 1. / Lf)
+                kld = _fprop(spec, p, z1, qz1, y1hot, nz('ez3', l, 0))
+            elif labeled:
                 acc.add('YL', idx, B.logp_logvar_rows(y1hot, *qy), 1. / Lf)          # DrVAE.py:506
                 kld = _fprop(spec, p, z1, qz1, y1hot, nz('ez3', l, 0))
             else:       # SGVB: sample y (DrVAE.py:527-530); the log-prior term only exists for a data prior

@@ -193,6 +193,8 @@ MODEL_CASES = OrderedDict([
     ('tiny_drvae_1sig', (lambda: tiny_spec('drvae', clf_1sig=True, h_clf=[3]), 'cadbcabdbca', 2, True)),
     ('tiny_vfae_prior_1sig', (lambda: tiny_spec('vfae', clf_1sig=True, prior_y=[0.7, 0.3]), 'abbabaabbb', 2, True)),
     ('tiny_drvae_cont', (lambda: tiny_spec('drvae', type_y='cont', dim_y=1), 'acbdaabcdbacab', 3, True)),
+    ('tiny_vfae_cont_sup', (lambda: tiny_spec('vfae', type_y='cont', dim_y=1, semi_supervised=False, h_clf=[3]),
+                            'aababaaa', 2, True)),
     ('tiny_pvae', (lambda: tiny_spec('pvae'), 'bdbbdddbdb', 3, True)),
     ('tiny_vfae', (lambda: tiny_spec('vfae', dim_y=3), 'abbabaabbb', 3, True)),
     ('tiny_vfae_sup', (lambda: tiny_spec('vfae', semi_supervised=False, add_noise_var=0.), 'aababaaa', 2, True)),

@@ -454,25 +454,27 @@ def ymarg_bwd(cfp, dqy, qy, label, fp_ptr, klfp, log_prior, c_kld, c_yl):
             dqy[r] = c_kld[r] * (klfp[sl] + qy[r].log() - log_prior + 1)
 
 
-def ycont_fwd(yl, fpin_y, z3in_y, mu, ylab, has_y, eps, logvar, B):
+def ycont_fwd(yl, fpin_y, z3in_y, mu, ylab, has_y, eps, logvar, B, sqerr=False):
     R, Y = mu.shape
     i = torch.arange(R, device=mu.device) % B
     lab = has_y[i].bool()
     yv = torch.where(lab[:, None], ylab[i], mu + math.exp(0.5 * logvar) * eps[:, :Y])
-    ll = -0.5 * (LOG_2PI + logvar + (ylab[i] - mu) ** 2 / math.exp(logvar)).sum(1)
+    ll = -((ylab[i] - mu) ** 2).sum(1) if sqerr else \
+        -0.5 * (LOG_2PI + logvar + (ylab[i] - mu) ** 2 / math.exp(logvar)).sum(1)
     yl.copy_(torch.where(lab, ll, torch.zeros_like(ll)))
     fpin_y[:, :Y] = yv
     z3in_y[:, :Y] = yv
 
 
-def ycont_bwd(dlogit, cfp, mu, ylab, has_y, logvar, c_yl, c_kld, dfpin_y, dz3in_y, B):
+def ycont_bwd(dlogit, cfp, mu, ylab, has_y, logvar, c_yl, c_kld, dfpin_y, dz3in_y, B, sqerr=False):
     R, Y = mu.shape
     if dlogit is None:
         cfp[:R] = c_kld[:R]
         return
     i = torch.arange(R, device=mu.device) % B
     lab = has_y[i].bool()
-    dmu = torch.where(lab[:, None], c_yl[:, None] * (ylab[i] - mu) / math.exp(logvar), dfpin_y[:, :Y] + dz3in_y[:, :Y])
+    dmu = torch.where(lab[:, None], c_yl[:, None] * (ylab[i] - mu) * (2.0 if sqerr else 1.0 / math.exp(logvar)),
+                      dfpin_y[:, :Y] + dz3in_y[:, :Y])
     dlogit[:, :Y] = dmu * mu * (1 - mu)
 
 

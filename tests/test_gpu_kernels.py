@@ -351,16 +351,21 @@ def test_ycont(K, dev):
     ylab, eps = torch.rand(B, Y).to(dev), rnd(dev, Rr, Y, seed=2)
     has_y = (torch.arange(B) % 3 != 0).to(torch.int32).to(dev)
     lv = float(np.log(0.05 ** 2))
+    for sq in (False, True):
+        _ycont_case(K, dev, mu, ylab, eps, has_y, lv, Rr, B, Y, sq)
+
+
+def _ycont_case(K, dev, mu, ylab, eps, has_y, lv, Rr, B, Y, sq):
     outs = []
     for mod in (K, R):
         yl = torch.empty(Rr, device=dev)
         f1, f2 = torch.zeros(Rr, 7 + Y, device=dev), torch.zeros(Rr, 5 + Y, device=dev)
-        mod.ycont_fwd(yl, f1[:, 7:], f2[:, 5:], mu, ylab, has_y, eps, lv, B)
+        mod.ycont_fwd(yl, f1[:, 7:], f2[:, 5:], mu, ylab, has_y, eps, lv, B, sqerr=sq)
         c_yl, c_kld = rnd(dev, Rr, seed=3), rnd(dev, Rr, seed=4)
         d1, d2 = rnd(dev, Rr, 7 + Y, seed=5), rnd(dev, Rr, 5 + Y, seed=6)
         dl, cfp = torch.empty(Rr, Y, device=dev), torch.empty(Rr, device=dev)
-        mod.ycont_bwd(None, cfp, mu, ylab, has_y, lv, c_yl, c_kld, d1[:, 7:], d2[:, 5:], B)
-        mod.ycont_bwd(dl, None, mu, ylab, has_y, lv, c_yl, c_kld, d1[:, 7:], d2[:, 5:], B)
+        mod.ycont_bwd(None, cfp, mu, ylab, has_y, lv, c_yl, c_kld, d1[:, 7:], d2[:, 5:], B, sqerr=sq)
+        mod.ycont_bwd(dl, None, mu, ylab, has_y, lv, c_yl, c_kld, d1[:, 7:], d2[:, 5:], B, sqerr=sq)
         outs.append((yl, f1, f2, dl, cfp))
     for a, b in zip(*outs):
         close(a, b, rtol=2e-5, atol=1e-4)

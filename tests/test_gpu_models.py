@@ -45,7 +45,8 @@ def kwargs_for(spec, batch, dev):
 
 
 @pytest.mark.parametrize('name', ['tiny_drvae', 'tiny_drvae_nolp', 'tiny_drvae_wn', 'tiny_drvae_adamax', 'tiny_drvae_prior',
-                                  'tiny_drvae_1sig', 'tiny_vfae_prior_1sig', 'tiny_drvae_cont', 'tiny_pvae', 'tiny_vfae',
+                                  'tiny_drvae_1sig', 'tiny_vfae_prior_1sig', 'tiny_drvae_cont', 'tiny_vfae_cont_sup', 'tiny_pvae',
+                                  'tiny_vfae',
                                   'tiny_vfae_sup', 'cfg2_drvae'])
 def test_run_on_batch_matches_reference(name, dev):
     case, gold = C.model_case(name), C.load('model_' + name)
