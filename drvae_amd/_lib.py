@@ -25,8 +25,7 @@ class GemmDesc(C.Structure):
                 ('epilogue', _i32), ('scale', _p), ('bias', _p), ('split', _i32), ('act0', _i32), ('act1', _i32),
                 ('shift0', _f), ('shift1', _f), ('resid', _p), ('ldr', _i64), ('resid_cols', _i32),
                 ('yref', _p), ('ldy', _i64), ('a_colsum', _p), ('colsum_beta', _f), ('flags', _i32),
-                ('pub_flag', _p), ('pub_ctr', _p), ('pub_add', _i32),
-                ('ws', _p), ('ws_floats', _i64), ('ws_ctr', _p), ('ws_ctrs', _i32), ('splitk', _i32)]
+                ('pub_flag', _p), ('pub_ctr', _p), ('pub_add', _i32)]
 
 
 class LossTerm(C.Structure):

@@ -47,9 +47,6 @@ class _Chain:
         self.out = [torch.zeros(M, _pad4(l.N), device=device)[:, :l.N] for l in layers]
         # gradient w.r.t. the pre-activation of every layer but the last (the caller owns that one)
         self.dpre = [torch.zeros(M, _pad4(l.N), device=device)[:, :l.N] for l in layers[:-1]]
-        # (split-K across workgroups, dv_gemm_desc.ws, was measured on these shapes and does not pay: the
-        # workspace round trip costs what the shorter K chains save -- no workspace is handed to the GEMMs)
-        self.ws = None
 
     def forward(self, inputs, resid=None, publish=None):
         """``publish`` = (flag, counter, add): the FIRST launch of the chain publishes on entry"""
@@ -61,7 +58,7 @@ class _Chain:
             K.linear_fwd(self.out[li], x[0], l.W, l.b, x2=x[1] if len(x) > 1 else None, scale=l.scale, split=l.split,
                          act0=l.act0, act1=l.act1, shift0=l.shift0, shift1=l.shift1,
                          resid=resid if last else None, resid_cols=self.resid_cols if (last and resid is not None) else 0,
-                         overread=True, publish=publish if (li == 0 and l.g is None) else None, ws=self.ws)
+                         overread=True, publish=publish if (li == 0 and l.g is None) else None)
             x = [self.out[li]]
         return self.out[-1]
 
@@ -80,8 +77,7 @@ class _Chain:
                 c0 = 0
                 for si, s in enumerate(srcs):
                     w = s.shape[1]
-                    K.linear_bwd_weight(dW[:, c0:c0 + w], dpre, s, dbias=l.db if si == 0 else None, overread=True,
-                                        ws=self.ws)
+                    K.linear_bwd_weight(dW[:, c0:c0 + w], dpre, s, dbias=l.db if si == 0 else None, overread=True)
                     c0 += w
                 if l.g is not None:
                     K.wn_bwd(l.dW, l.dg, l.raw, l.W, l.g, l.norm)
@@ -94,12 +90,11 @@ class _Chain:
                 if li > 0:
                     prev = self.layers[li - 1]
                     K.linear_bwd_pair(l.dW, l.db, self.dpre[li - 1], dpre, srcs[0], l.W, yref=self.out[li - 1],
-                                      act=prev.act0, shift=prev.shift0, overread=True, ws=self.ws)
+                                      act=prev.act0, shift=prev.shift0, overread=True)
                     dpre = self.dpre[li - 1]
                 else:
                     dst, alpha, beta = dinputs[0][0]
-                    K.linear_bwd_pair(l.dW, l.db, dst, dpre, srcs[0], l.W, alpha=alpha, beta_x=beta, overread=True,
-                                      ws=self.ws)
+                    K.linear_bwd_pair(l.dW, l.db, dst, dpre, srcs[0], l.W, alpha=alpha, beta_x=beta, overread=True)
                 continue
             if wbranch is not None:
                 with wbranch:

@@ -172,8 +172,7 @@ constexpr int gemm_smem_floats() {
 
 // One workgroup's share of one product: `bid` of `nwg` workgroups.
 template <int BM, int BN, int BK, int WM, int WN, int KS, bool AKC, bool BKC>
-__device__ __forceinline__ void gemm_body(const dv_gemm_desc& g, const LoadCfg& lc, float* smem, int bid, int nwg,
-                                          int sp = 0, int nsp = 1) {
+__device__ __forceinline__ void gemm_body(const dv_gemm_desc& g, const LoadCfg& lc, float* smem, int bid, int nwg) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int KW = BK / KS, KH = KW / 2;
     constexpr int LDA_S = (AKC ? BK : BM) + 4;
@@ -346,13 +345,10 @@ __device__ __forceinline__ void gemm_body(const dv_gemm_desc& g, const LoadCfg& 
         mma(fa, fb);
     };
 
-    // this workgroup's K tiles: all of them, or (split-K across workgroups) the sp-th of nsp ranges
-    const int nkt_all = (g.K + BK - 1) / BK, nfull = g.K / BK;
-    const int kt_per = (nkt_all + nsp - 1) / nsp, kt_lo = sp * kt_per;
-    const int nkt = (kt_lo + kt_per < nkt_all ? kt_lo + kt_per : nkt_all) - kt_lo;   // (>= 1 by construction)
+    const int nkt = (g.K + BK - 1) / BK, nfull = g.K / BK;
     float* const buf0 = smem;
     float* const buf1 = smem + STAGE;
-    if (wg_fast && nfull >= 1 && nkt >= 1) {
+    if (wg_fast && nfull >= 1) {
         // ---- interior workgroups: per-thread staging pointers advanced by one K tile per step,
         // unconditional vector loads, TWO register sets (two tiles in flight: each load has two
         // MFMA phases to land), LDS double buffer (one barrier per K tile).
@@ -364,7 +360,6 @@ __device__ __forceinline__ void gemm_body(const dv_gemm_desc& g, const LoadCfg& 
             int line = AKC ? (m0 + l) : l;
             if (AKC) line = line < g.M ? line : g.M - 1;
             pa[p] = g.A + (int64_t)line * g.lda + (AKC ? a_c * 4 : (m0 + a_c * 4 < g.M ? m0 + a_c * 4 : 0));
-            pa[p] += (int64_t)kt_lo * (AKC ? (int64_t)BK : (int64_t)BK * g.lda);
         }
 #pragma unroll
         for (int p = 0; p < B_NP; ++p) {
@@ -372,7 +367,6 @@ __device__ __forceinline__ void gemm_body(const dv_gemm_desc& g, const LoadCfg& 
             int line = BKC ? (n0 + l) : l;
             if (BKC) line = line < g.N ? line : g.N - 1;
             pb[p] = g.B + (int64_t)line * g.ldb + (BKC ? b_c * 4 : (n0 + b_c * 4 < g.N ? n0 + b_c * 4 : 0));
-            pb[p] += (int64_t)kt_lo * (BKC ? (int64_t)BK : (int64_t)BK * g.ldb);
         }
         const int64_t step_a = AKC ? (int64_t)BK : (int64_t)BK * g.lda;
         const int64_t step_b = BKC ? (int64_t)BK : (int64_t)BK * g.ldb;
@@ -398,7 +392,7 @@ __device__ __forceinline__ void gemm_body(const dv_gemm_desc& g, const LoadCfg& 
                                *(left >= 4 ? p + 3 : z));
         };
         auto fetch = [&](int t, float4 (&ra)[A_NP], float4 (&rb)[B_NP]) {
-            if (kt_lo + t < nfull) {
+            if (t < nfull) {
 #pragma unroll
                 for (int p = 0; p < A_NP; ++p) {
                     ra[p] = ldv(pa[p], va);
@@ -525,11 +519,11 @@ __device__ __forceinline__ void gemm_body(const dv_gemm_desc& g, const LoadCfg& 
     } else {
         // ---- edge tiles / concatenated sources / k-scaled operand: simple loop, generic loads
         float4 ra[A_NP], rb[B_NP];
-        gen_load(kt_lo * BK, ra, rb);
+        gen_load(0, ra, rb);
         stage_store(buf0, ra, rb);
         __syncthreads();
         for (int kt = 0; kt < nkt; ++kt) {
-            if (kt + 1 < nkt) gen_load((kt_lo + kt + 1) * BK, ra, rb);
+            if (kt + 1 < nkt) gen_load((kt + 1) * BK, ra, rb);
             compute((kt & 1) ? buf1 : buf0);
             if (kt + 1 < nkt) stage_store((kt & 1) ? buf0 : buf1, ra, rb);
             __syncthreads();
@@ -544,12 +538,7 @@ __device__ __forceinline__ void gemm_body(const dv_gemm_desc& g, const LoadCfg& 
             float s = 0.f;
             for (int l = 0; l < A_LPP; ++l) s += smem[(l * A_CPL + ch) * 4 + e];
             const int m = m0 + tid;
-            if (nsp > 1) {       // partial over this workgroup's K range: finished by the tile's last arriver
-                __hip_atomic_store(&g.ws[(int64_t)nsp * nwg * (BM * BN) + ((int64_t)sp * tiles_m + tm) * BM + tid], s,
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else if (m < g.M) {
-                g.a_colsum[m] = (g.colsum_beta != 0.f ? g.colsum_beta * g.a_colsum[m] : 0.f) + s;
-            }
+            if (m < g.M) g.a_colsum[m] = (g.colsum_beta != 0.f ? g.colsum_beta * g.a_colsum[m] : 0.f) + s;
         }
         __syncthreads();
     }
@@ -591,44 +580,6 @@ __device__ __forceinline__ void gemm_body(const dv_gemm_desc& g, const LoadCfg& 
             for (int w = 0; w < KS; ++w) v += red[(w * BM + r0 + e) * (BN + 1) + col];
             a4[e] = v;
         }
-        if (nsp > 1) {
-            // split-K across workgroups: park the partial tile in the workspace, count arrivals; the LAST
-            // arriver of the tile sums the nsp partials in split order (deterministic) and runs the epilogue
-            // The workspace traffic uses agent-scope ATOMIC stores/loads: they are performed at the device's
-            // coherence point, so no cache maintenance is needed -- an agent-scope fence here would write
-            // back the whole L2 of the XCD (measured: +15 us per launch).
-            float* wt = g.ws + ((int64_t)sp * nwg + bid) * (BM * BN);
-#pragma unroll
-            for (int e = 0; e < RPT; ++e)
-                __hip_atomic_store(&wt[(r0 + e) * BN + col], a4[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // this wave's stores are acknowledged
-            __syncthreads();
-            __shared__ int s_last;
-            if (tid == 0) {
-                const int old = __hip_atomic_fetch_add(&g.ws_ctr[bid], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                s_last = old == nsp - 1;
-                if (s_last)                          // everyone has arrived: re-arm for the next launch
-                    __hip_atomic_store(&g.ws_ctr[bid], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            __syncthreads();
-            if (!s_last) return;
-#pragma unroll
-            for (int e = 0; e < RPT; ++e) a4[e] = 0.f;
-            for (int q = 0; q < nsp; ++q) {
-                float* wq = g.ws + ((int64_t)q * nwg + bid) * (BM * BN);
-#pragma unroll
-                for (int e = 0; e < RPT; ++e)
-                    a4[e] += __hip_atomic_load(&wq[(r0 + e) * BN + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            if (do_colsum && tid < BM) {
-                float cs = 0.f;
-                for (int q = 0; q < nsp; ++q)
-                    cs += __hip_atomic_load(&g.ws[(int64_t)nsp * nwg * (BM * BN) + ((int64_t)q * tiles_m + tm) * BM + tid],
-                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const int m = m0 + tid;
-                if (m < g.M) g.a_colsum[m] = (g.colsum_beta != 0.f ? g.colsum_beta * g.a_colsum[m] : 0.f) + cs;
-            }
-        }
         const int rbase = m0 + r0;
         epi_store_col<RPT>(g, a4, n0 + col, [rbase](int r) { return rbase + r; });
     }
@@ -645,7 +596,6 @@ template <int BM, int BN, int BK, int WM, int WN, int KS, bool AKC, bool BKC>
 __global__ __launch_bounds__(64 * WM * WN * KS, (BM >= 128 || BK >= 128) ? 2 : (WM * WN * KS == 8 ? 2 : 4)) void gemm_kernel(const dv_gemm_desc g, const LoadCfg lc) {
     __shared__ __attribute__((aligned(16))) float smem[gemm_smem_floats<BM, BN, BK, KS, AKC, BKC>()];
     publish_on_entry(g);
-    const int nsp = g.splitk > 1 ? g.splitk : 1, ntile = gridDim.x / nsp;
 #if DV_STAGGER
     {   // tuning: de-phase the workgroups that share a CU (dispatch is round-robin over the CUs)
         const int ph = (blockIdx.x / DV_STAGGER) & 3;
@@ -654,7 +604,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (BM >= 128 || BK >= 128) ? 2 : (
         if (ph == 3) __builtin_amdgcn_s_sleep(18);
     }
 #endif
-    gemm_body<BM, BN, BK, WM, WN, KS, AKC, BKC>(g, lc, smem, blockIdx.x % ntile, ntile, blockIdx.x / ntile, nsp);
+    gemm_body<BM, BN, BK, WM, WN, KS, AKC, BKC>(g, lc, smem, blockIdx.x, gridDim.x);
 }
 
 // Two independent products in ONE launch (workgroups [0,tiles1) run the first, the rest the
@@ -666,11 +616,10 @@ __global__ __launch_bounds__(256, 4) void gemm_pair_kernel(const dv_gemm_desc g1
     constexpr int S1 = gemm_smem_floats<BM, BN, BK, KS, A1, B1>(), S2 = gemm_smem_floats<BM, BN, BK, KS, A2, B2>();
     __shared__ __attribute__((aligned(16))) float smem[S1 > S2 ? S1 : S2];
     publish_on_entry(g1);
-    const int nsp1 = g1.splitk > 1 ? g1.splitk : 1, wgs1 = tiles1 * nsp1;      // only the first product may be split
-    if ((int)blockIdx.x < wgs1)
-        gemm_body<BM, BN, BK, WM, WN, KS, A1, B1>(g1, lc1, smem, blockIdx.x % tiles1, tiles1, blockIdx.x / tiles1, nsp1);
+    if ((int)blockIdx.x < tiles1)
+        gemm_body<BM, BN, BK, WM, WN, KS, A1, B1>(g1, lc1, smem, blockIdx.x, tiles1);
     else
-        gemm_body<BM, BN, BK, WM, WN, KS, A2, B2>(g2, lc2, smem, blockIdx.x - wgs1, gridDim.x - wgs1);
+        gemm_body<BM, BN, BK, WM, WN, KS, A2, B2>(g2, lc2, smem, blockIdx.x - tiles1, gridDim.x - tiles1);
 }
 
 inline int vec_width(const void* p, int64_t ld) {
@@ -683,7 +632,7 @@ inline int vec_width(const void* p, int64_t ld) {
 template <int BM, int BN, int BK, int WM, int WN, int KS>
 int launch_cfg(const dv_gemm_desc& g, const LoadCfg& lc, hipStream_t st) {
     const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
-    dim3 grid(tiles * (g.splitk > 1 ? g.splitk : 1)), block(64 * WM * WN * KS);
+    dim3 grid(tiles), block(64 * WM * WN * KS);
     if (g.a_kcontig && g.b_kcontig)
         hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, WM, WN, KS, true, true>), grid, block, 0, st, g, lc);
     else if (g.a_kcontig && !g.b_kcontig)
@@ -750,27 +699,6 @@ static int gemm_prepare(const dv_gemm_desc* d, LoadCfg& lc, int& tiling) {
     return DV_OK;
 }
 
-// Split-K across workgroups for the 32x32 K-split tiling: a product with few output tiles and a long K
-// (encoder heads 224x200x800: 49 tiles, 13 K tiles) is a latency chain of K tiles on a mostly idle chip;
-// nsp workgroups per tile walk nsp shorter chains and the last arriver reduces them in a fixed order.
-// Returns the split to use (1 = none) given the caller's workspace.
-static int choose_splitk(const dv_gemm_desc& g, int tiling) {
-    if (tiling != 2 || g.splitk == 1 || g.ws == nullptr || g.ws_ctr == nullptr) return 1;
-    const int tiles_m = (g.M + 31) / 32, tiles = tiles_m * ((g.N + 31) / 32), nkt = (g.K + 63) / 64;
-    int nsp = g.splitk > 1 ? g.splitk : 0;
-    if (nsp == 0) {
-        if (tiles > 256 || nkt < 6) return 1;
-        nsp = nkt / 3;                                  // >= 3 K tiles per workgroup
-        if (nsp > 4) nsp = 4;
-        while (nsp > 1 && tiles * nsp > 640) --nsp;      // stay within ~2.5 workgroups per CU
-    }
-    while (nsp > 1 && ((nkt + nsp - 1) / nsp) * (nsp - 1) >= nkt) --nsp;   // no empty range
-    if (nsp <= 1) return 1;
-    const int64_t need = (int64_t)nsp * tiles * 1024 + (g.a_colsum ? (int64_t)nsp * tiles_m * 32 : 0);
-    if (need > g.ws_floats || tiles > g.ws_ctrs) return 1;
-    return nsp;
-}
-
 static int gemm_launch(const dv_gemm_desc& g, const LoadCfg& lc, int tiling, hipStream_t st) {
     if (tiling < 0) return DV_OK;
     if (tiling == 3) return launch_cfg<128, 128, 32, 2, 2, 1>(g, lc, st);
@@ -787,9 +715,7 @@ extern "C" int dv_gemm(const dv_gemm_desc* d, dv_stream_t stream) {
     int tiling = 0;
     const int rc = gemm_prepare(d, lc, tiling);
     if (rc != DV_OK) return rc;
-    dv_gemm_desc g = *d;
-    g.splitk = tiling < 0 ? 1 : choose_splitk(g, tiling);
-    return gemm_launch(g, lc, tiling, static_cast<hipStream_t>(stream));
+    return gemm_launch(*d, lc, tiling, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int dv_gemm_pair(const dv_gemm_desc* d1, const dv_gemm_desc* d2, dv_stream_t stream) {
@@ -807,16 +733,12 @@ extern "C" int dv_gemm_pair(const dv_gemm_desc* d1, const dv_gemm_desc* d2, dv_s
     // decoder-heads pair ran 66 us paired vs 29 + 29 us alone)
     const bool fuse = t1 == 2 && t2 == 2 && !d1->a_kcontig && !d1->b_kcontig && d2->a_kcontig && !d2->b_kcontig &&
                       g_opt[2] == 0 && tiles1 < 1024 && tiles2 < 1024;
-    dv_gemm_desc g1 = *d1, g2 = *d2;
-    g1.splitk = t1 < 0 ? 1 : choose_splitk(g1, t1);
     if (!fuse) {
-        g2.splitk = t2 < 0 ? 1 : choose_splitk(g2, t2);
-        rc = gemm_launch(g1, lc1, t1, st);
+        rc = gemm_launch(*d1, lc1, t1, st);
         if (rc != DV_OK) return rc;
-        return gemm_launch(g2, lc2, t2, st);
+        return gemm_launch(*d2, lc2, t2, st);
     }
-    g2.splitk = 1;                         // in the fused form only the first product (dy^T x: K = rows) is split
-    hipLaunchKernelGGL((gemm_pair_kernel<32, 32, 64, 1, 1, 4, false, false, true, false>),
-                       dim3(tiles1 * g1.splitk + tiles2), dim3(256), 0, st, g1, lc1, g2, lc2, tiles1);
+    hipLaunchKernelGGL((gemm_pair_kernel<32, 32, 64, 1, 1, 4, false, false, true, false>), dim3(tiles1 + tiles2),
+                       dim3(256), 0, st, *d1, lc1, *d2, lc2, tiles1);
     DV_RETURN_LAUNCH();
 }

@@ -52,7 +52,7 @@ def _act(a):
 # ------------------------------------------------------------------------------ GEMM
 def _gemm_desc(Cm, A, B, a_kc, b_kc, *, A2=None, a_kscale=None, alpha=1.0, beta=0.0, epi=EPI_PLAIN, scale=None,
                bias=None, split=None, act0=0, act1=0, shift0=0.0, shift1=0.0, resid=None, resid_cols=0, yref=None,
-               a_colsum=None, colsum_beta=0.0, overread=False, publish=None, ws=None, splitk=0):
+               a_colsum=None, colsum_beta=0.0, overread=False, publish=None):
     M, N = Cm.shape
     if a_kc:
         K = A.shape[1] + (A2.shape[1] if A2 is not None else 0)
@@ -81,9 +81,6 @@ def _gemm_desc(Cm, A, B, a_kc, b_kc, *, A2=None, a_kscale=None, alpha=1.0, beta=
     d.flags = 3 if overread else 0
     if publish is not None:                 # (flag, counter, add): publish on kernel entry, see dv_flag_publish
         d.pub_flag, d.pub_ctr, d.pub_add = _i32(publish[0]), _i32(publish[1]), publish[2]
-    if ws is not None:                      # (float workspace, int32 counters): split-K across workgroups
-        d.ws, d.ws_floats, d.ws_ctr, d.ws_ctrs = _f32(ws[0]), ws[0].numel(), _i32(ws[1]), ws[1].numel()
-    d.splitk = splitk
     return d
 
 
@@ -95,10 +92,10 @@ def gemm(Cm, A, B, a_kc, b_kc, **kw):
 
 
 def linear_bwd_pair(dW, dbias, dx, dpre, x, W, *, kscale=None, alpha=1.0, beta_x=0.0, yref=None, act=0, shift=0.0,
-                    overread=False, ws=None):
+                    overread=False):
     """dW = dpre^T x (+ dbias) and dx = beta_x*dx + alpha*(dpre W) * act'(yref) in ONE launch when both fit
     the fused form of ``dv_gemm_pair`` (otherwise two launches)."""
-    d1 = _gemm_desc(dW, dpre, x, False, False, a_colsum=dbias, overread=overread, ws=ws)
+    d1 = _gemm_desc(dW, dpre, x, False, False, a_colsum=dbias, overread=overread)
     if yref is None:
         d2 = _gemm_desc(dx, dpre, W, True, False, a_kscale=kscale, alpha=alpha, beta=beta_x, overread=overread)
     else:
@@ -108,10 +105,10 @@ def linear_bwd_pair(dW, dbias, dx, dpre, x, W, *, kscale=None, alpha=1.0, beta_x
 
 
 def linear_fwd(out, x, W, bias=None, *, x2=None, scale=None, split=None, act0=0, act1=0, shift0=0.0, shift1=0.0,
-               resid=None, resid_cols=0, overread=False, publish=None, ws=None):
+               resid=None, resid_cols=0, overread=False, publish=None):
     """out = act([x|x2] W^T * scale + bias) + shift (+ resid) -- one Linear (or two heads) forward."""
     gemm(out, x, W, True, True, A2=x2, epi=EPI_FWD, scale=scale, bias=bias, split=split, act0=act0, act1=act1,
-         shift0=shift0, shift1=shift1, resid=resid, resid_cols=resid_cols, overread=overread, publish=publish, ws=ws)
+         shift0=shift0, shift1=shift1, resid=resid, resid_cols=resid_cols, overread=overread, publish=publish)
 
 
 def linear_bwd_data(dx, dpre, W, *, kscale=None, alpha=1.0, beta=0.0, yref=None, act=0, shift=0.0, overread=False):
@@ -123,9 +120,9 @@ def linear_bwd_data(dx, dpre, W, *, kscale=None, alpha=1.0, beta=0.0, yref=None,
              act1=act, shift0=shift, shift1=shift, overread=overread)
 
 
-def linear_bwd_weight(dW, dpre, x, *, beta=0.0, dbias=None, overread=False, ws=None):
+def linear_bwd_weight(dW, dpre, x, *, beta=0.0, dbias=None, overread=False):
     """dW = beta*dW + dpre^T x ;  dbias = beta*dbias + colsum(dpre) fused in the same launch."""
-    gemm(dW, dpre, x, False, False, beta=beta, a_colsum=dbias, colsum_beta=beta, overread=overread, ws=ws)
+    gemm(dW, dpre, x, False, False, beta=beta, a_colsum=dbias, colsum_beta=beta, overread=overread)
 
 
 def colsum(out, X, beta=0.0):

@@ -111,18 +111,6 @@ typedef struct dv_gemm_desc {
     int32_t* pub_flag;
     const int32_t* pub_ctr;
     int32_t pub_add;
-    /* optional split-K across workgroups (32x32 tiling only): `ws` holds the partial tiles (and partial
-     * bias sums), `ws_ctr` one zero-initialised arrival counter per output tile (re-armed by the kernel).
-     * splitk: 0 = decide from the shape when a workspace is given, 1 = never, >= 2 = use that many
-     * ranges.  The reduction order is fixed (range 0,1,..), so results stay bitwise reproducible.
-     * Capacity needed: splitk*tiles*1024 (+ splitk*ceil(M/32)*32 with a_colsum) floats, `tiles` counters;
-     * a workspace that is too small just disables the split.  A workspace must not be shared by
-     * launches that can run concurrently. */
-    float* ws;
-    int64_t ws_floats;
-    int32_t* ws_ctr;
-    int32_t ws_ctrs;
-    int32_t splitk;
 } dv_gemm_desc;
 
 int dv_gemm(const dv_gemm_desc* desc, dv_stream_t stream);

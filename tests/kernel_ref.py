@@ -88,7 +88,7 @@ def _seg(N, split, a0, a1, v0, v1, dev):
 
 def gemm(Cm, A, B, a_kc, b_kc, *, A2=None, a_kscale=None, alpha=1.0, beta=0.0, epi=EPI_PLAIN, scale=None,
          bias=None, split=None, act0=0, act1=0, shift0=0.0, shift1=0.0, resid=None, resid_cols=0, yref=None,
-         a_colsum=None, colsum_beta=0.0, overread=False, publish=None, ws=None, splitk=0):
+         a_colsum=None, colsum_beta=0.0, overread=False, publish=None):
     if publish is not None:
         flag_publish(publish[0], publish[1], publish[2])
     M, N = Cm.shape
@@ -116,7 +116,7 @@ def gemm(Cm, A, B, a_kc, b_kc, *, A2=None, a_kscale=None, alpha=1.0, beta=0.0, e
 
 
 def linear_fwd(out, x, W, bias=None, *, x2=None, scale=None, split=None, act0=0, act1=0, shift0=0.0, shift1=0.0,
-               resid=None, resid_cols=0, overread=False, publish=None, ws=None):
+               resid=None, resid_cols=0, overread=False, publish=None):
     gemm(out, x, W, True, True, A2=x2, epi=EPI_FWD, scale=scale, bias=bias, split=split, act0=act0, act1=act1,
          shift0=shift0, shift1=shift1, resid=resid, resid_cols=resid_cols, publish=publish)
 
@@ -129,12 +129,12 @@ def linear_bwd_data(dx, dpre, W, *, kscale=None, alpha=1.0, beta=0.0, yref=None,
              act1=act, shift0=shift, shift1=shift)
 
 
-def linear_bwd_weight(dW, dpre, x, *, beta=0.0, dbias=None, overread=False, ws=None):
+def linear_bwd_weight(dW, dpre, x, *, beta=0.0, dbias=None, overread=False):
     gemm(dW, dpre, x, False, False, beta=beta, a_colsum=dbias, colsum_beta=beta)
 
 
 def linear_bwd_pair(dW, dbias, dx, dpre, x, W, *, kscale=None, alpha=1.0, beta_x=0.0, yref=None, act=0, shift=0.0,
-                    overread=False, ws=None):
+                    overread=False):
     linear_bwd_weight(dW, dpre, x, dbias=dbias)
     linear_bwd_data(dx, dpre, W, kscale=kscale, alpha=alpha, beta=beta_x, yref=yref, act=act, shift=shift)
 

@@ -645,26 +645,3 @@ def test_batch_feed(K, dev, X, pad, Np, Mf):
     K.batch_feed(xin, x1, x2, None, table, nb, ctr, bs, pair_rows=pair_rows)
     R.batch_feed(rin, x1, x2, None, table, nb, ctr, bs, pair_rows=pair_rows)
     assert torch.equal(xin, rin)
-
-
-@pytest.mark.parametrize('M,N,Kd,akc,bkc', [(224, 200, 800, 1, 1), (600, 100, 596, 0, 0), (450, 102, 700, 1, 0),
-                                           (33, 31, 1000, 1, 1), (224, 800, 978, 1, 1)])
-@pytest.mark.parametrize('splitk', [0, 2, 3, 4])
-def test_gemm_split_k_across_workgroups(K, dev, M, N, Kd, akc, bkc, splitk):
-    """partial tiles through a workspace, last-arriving workgroup reduces in a fixed order: same values as the
-    unsplit product (up to summation order), identical bits from run to run, counters re-armed"""
-    A = rnd(dev, *((M, Kd) if akc else (Kd, M)), seed=1)
-    B = rnd(dev, *((N, Kd) if bkc else (Kd, N)), seed=2)
-    ws = (torch.zeros(4 * 256 * 1024 + 4 * 64 * 32, device=dev), torch.zeros(256, dtype=torch.int32, device=dev))
-    ref, c1, c2 = (torch.empty(M, N, device=dev) for _ in range(3))
-    cs0, cs1 = torch.empty(M, device=dev), torch.empty(M, device=dev)
-    kw = dict(a_colsum=cs0) if not akc else {}
-    K.gemm(ref, A, B, akc, bkc, **kw)                                   # no workspace: never split
-    kw = dict(a_colsum=cs1) if not akc else {}
-    K.gemm(c1, A, B, akc, bkc, ws=ws, splitk=splitk, **kw)
-    K.gemm(c2, A, B, akc, bkc, ws=ws, splitk=splitk, **kw)
-    close(c1, ref, **gemm_tol(Kd))
-    assert torch.equal(c1, c2)
-    assert int(ws[1].abs().sum()) == 0
-    if not akc:
-        close(cs1, cs0, rtol=1e-4, atol=1e-3)
