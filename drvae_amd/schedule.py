@@ -31,6 +31,9 @@ def _masked_stream(bits, device):
     return torch.cuda.ExternalStream(st.value, device=device)
 
 
+_PARTITION_STREAMS = {}      # device index -> {reserved CUs -> (main stream, side stream) | None}
+
+
 class _Branch:
     """Fork/join of an independent launch chain onto a side HIP stream.  Inside a hipGraph
     capture the side stream joins the capture, so the chain becomes a parallel branch of the
@@ -160,8 +163,8 @@ class StepSchedule:
 
     def _part_streams(self, n_side):
         """(main, side) CU-masked streams reserving ``n_side`` CUs for the side chain (cached)"""
-        cache = self.__dict__.setdefault('_parts', {})
-        if n_side not in cache:
+        cache = _PARTITION_STREAMS.setdefault(torch.device(self.dev).index or 0, {})   # per device, process-wide:
+        if n_side not in cache:                    # masked streams own hardware queues, so engines share them
             n_cu = torch.cuda.get_device_properties(self.dev).multi_processor_count
             words = (n_cu + 31) // 32
             side_bits, all_bits = [0] * words, [0] * words
