@@ -74,6 +74,8 @@ SIGNATURES = {
     'dv_ymarg_bwd': [_p, _i64, _p, _p, _p, _f, _p, _p, _p, _i32, _i32, _p, _p, _i64, _p],
     'dv_ycont_fwd': [_p, _i64, _p, _p, _p, _i64, _f, _i32, _i32, _i32, _i32, _p, _p, _i64, _p, _i64, _p],
     'dv_ycont_bwd': [_p, _i64, _p, _p, _f, _i32, _p, _p, _p, _i64, _p, _i64, _i32, _i32, _i32, _p, _i64, _p, _p],
+    'dv_mmd_rff_fwd': [_p, _i64, _i32, _p, _i64, _i32, _i32, _f, _p, _p, _p],
+    'dv_mmd_rff_bwd': [_p, _i64, _i32, _i32, _p, _p, _f, _p, _i64, _p],
     'dv_rows_gather': [_p, _i64, _p, _i32, _i32, _p, _i64, _f, _p, _i32, _p, _i64, _p],
     'dv_batch_feed': [_p, _i64, _p, _i64, _p, _p, _i32, _p, _p, _i32, _p, _i32, _i32, _p, _i64, _f, _p, _i64, _p, _i32,
                       _p, _p, _p, _p, _i32, _p, _p, _i64, _i32, _p, _p, _i32, _p],

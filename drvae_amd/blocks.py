@@ -97,12 +97,8 @@ def mmd_fourier(x1, x2, bandwidth=2., dim_r=500):
     z = x1.size(1)
     rnd_a = torch.empty(z, dim_r, device=x1.device).normal_()
     rnd_b = torch.empty(dim_r, device=x1.device).uniform_()
-    w_t = (math.sqrt(2. / bandwidth) * rnd_a / math.sqrt(z)).t().contiguous()     # (dim_r, Z) Linear layout
-    rb = 2 * math.pi * rnd_b
-    c = math.sqrt(2. / dim_r)
-    rf0 = c * torch.cos(ops.linear_act([x1], w_t, rb))
-    rf1 = c * torch.cos(ops.linear_act([x2], w_t, rb))
-    return ((rf0.mean(0) - rf1.mean(0)) ** 2).sum()
+    a, c = math.sqrt(2. / bandwidth) / math.sqrt(z), math.sqrt(2. / dim_r)
+    return ops.MMDRff.apply(x1, x2, rnd_a, rnd_b, a, c)
 
 
 kernels = {'rbf': rbf, 'poly': poly, 'identity': identity, 'rbf_fourier': mmd_fourier}

@@ -837,6 +837,55 @@ __global__ void ycont_bwd_kernel(const float* __restrict__ mu, int64_t ldm, cons
     }
 }
 
+// --------------------------------------------------- random-Fourier-feature MMD (K10)
+// rf(x)[r] = c * cos(theta[i,r]), theta = a * x W + 2 pi b (the MFMA GEMM writes theta with its scale/bias
+// epilogue);  diff[r] = mean_i rf(x1_i)[r] - mean_j rf(x2_j)[r];  mmd2 = sum_r diff[r]^2  (src/blocks.py:40-55).
+// One block per 64 features, its 4 waves splitting the rows of theta1 then theta2 (lanes = consecutive r).
+__global__ __launch_bounds__(256) void mmd_cos_means_kernel(const float* __restrict__ th1, int64_t ld1, int n1,
+                                                            const float* __restrict__ th2, int64_t ld2, int n2, int R,
+                                                            float c, float* __restrict__ diff) {
+    __shared__ float part[2][4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = blockIdx.x * 64 + lane, rc = r < R ? r : R - 1;
+    for (int side = 0; side < 2; ++side) {
+        const float* th = side ? th2 : th1;
+        const int64_t ld = side ? ld2 : ld1;
+        const int n = side ? n2 : n1;
+        float acc = 0.f;
+        for (int i = wave; i < n; i += 4) acc += cosf(th[(int64_t)i * ld + rc]);
+        part[side][wave][lane] = acc;
+    }
+    __syncthreads();
+    if (wave == 0 && r < R) {
+        const float s1 = (part[0][0][lane] + part[0][1][lane]) + (part[0][2][lane] + part[0][3][lane]);
+        const float s2 = (part[1][0][lane] + part[1][1][lane]) + (part[1][2][lane] + part[1][3][lane]);
+        diff[r] = c * (s1 / (float)n1 - s2 / (float)n2);
+    }
+}
+
+// out[0] = sum_r diff[r]^2  (single block, fixed-order tree: deterministic)
+__global__ __launch_bounds__(256) void mmd_sumsq_kernel(const float* __restrict__ diff, int R, float* __restrict__ out) {
+    __shared__ float part[4];
+    float s = 0.f;
+    for (int r = threadIdx.x; r < R; r += 256) s += diff[r] * diff[r];
+    s = dv_wave_sum_all(s);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+
+// G[i,r] = coef * gout[0] * (-diff[r]) * sin(theta[i,r])   -- d mmd2 / d theta up to the caller's constant
+__global__ void mmd_dtheta_kernel(const float* __restrict__ th, int64_t ld, int n, int R,
+                                  const float* __restrict__ diff, const float* __restrict__ gout, float coef,
+                                  float* __restrict__ G, int64_t ldg) {
+    const int64_t total = (int64_t)n * R;
+    const float s = coef * gout[0];
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int i = (int)(e / R), r = (int)(e % R);
+        G[(int64_t)i * ldg + r] = -s * diff[r] * sinf(th[(int64_t)i * ld + r]);
+    }
+}
+
 // ---------------------------------------------------------------- row movement
 __global__ void rows_gather_kernel(const float* __restrict__ src, int64_t lds, const int32_t* __restrict__ idx,
                                    int n, int W, const float* __restrict__ noise, int64_t ldn, float sigma,
@@ -1414,6 +1463,25 @@ extern "C" int dv_ycont_bwd(const float* mu, int64_t ldm, const float* ylab, con
     DV_REQUIRE(has_y && ((cfp && c_kld) || (mu && ylab && c_yl && dfpin_y && dz3in_y && dlogit)));
     hipLaunchKernelGGL(ycont_bwd_kernel, dim3((R + 255) / 256), dim3(256), 0, ST(stream), mu, ldm, ylab, has_y, logvar,
                        sqerr, c_yl, c_kld, dfpin_y, ld1, dz3in_y, ld2, R, B, Y, dlogit, ldd, cfp, dlogit == nullptr ? 1 : 0);
+    DV_RETURN_LAUNCH();
+}
+
+extern "C" int dv_mmd_rff_fwd(const float* th1, int64_t ld1, int32_t n1, const float* th2, int64_t ld2, int32_t n2,
+                              int32_t R, float c, float* diff, float* mmd2, dv_stream_t stream) {
+    DV_REQUIRE(n1 >= 1 && n2 >= 1 && R >= 1);
+    DV_REQUIRE(th1 && th2 && diff && mmd2);
+    hipLaunchKernelGGL(mmd_cos_means_kernel, dim3((R + 63) / 64), dim3(256), 0, ST(stream), th1, ld1, n1, th2, ld2, n2, R,
+                       c, diff);
+    hipLaunchKernelGGL(mmd_sumsq_kernel, dim3(1), dim3(256), 0, ST(stream), diff, R, mmd2);
+    DV_RETURN_LAUNCH();
+}
+
+extern "C" int dv_mmd_rff_bwd(const float* th, int64_t ld, int32_t n, int32_t R, const float* diff, const float* gout,
+                              float coef, float* G, int64_t ldg, dv_stream_t stream) {
+    DV_REQUIRE(n >= 1 && R >= 1);
+    DV_REQUIRE(th && diff && gout && G);
+    hipLaunchKernelGGL(mmd_dtheta_kernel, dim3(grid_for((int64_t)n * R, 256)), dim3(256), 0, ST(stream), th, ld, n, R,
+                       diff, gout, coef, G, ldg);
     DV_RETURN_LAUNCH();
 }
 

@@ -355,6 +355,19 @@ def ycont_bwd(dlogit, cfp, mu, ylab, has_y, logvar, c_yl, c_kld, dfpin_y, dz3in_
                                         _f32(dlogit), _ld(dlogit), _f32(cfp), _stream()), 'dv_ycont_bwd')
 
 
+def mmd_rff_fwd(diff, mmd2, th1, th2, c):
+    """finish the random-Fourier-feature MMD^2 from the projections theta, see ``dv_mmd_rff_fwd``"""
+    R = th1.shape[1]
+    _lib.check(_lib.load().dv_mmd_rff_fwd(_f32(th1), _ld(th1), th1.shape[0], _f32(th2), _ld(th2), th2.shape[0], R, c,
+                                          _f32(diff), _f32(mmd2), _stream()), 'dv_mmd_rff_fwd')
+
+
+def mmd_rff_bwd(G, th, diff, gout, coef):
+    n, R = th.shape
+    _lib.check(_lib.load().dv_mmd_rff_bwd(_f32(th), _ld(th), n, R, _f32(diff), _f32(gout), coef, _f32(G), _ld(G),
+                                          _stream()), 'dv_mmd_rff_bwd')
+
+
 def rows_gather(out, src, idx=None, *, noise=None, sigma=0.0, onehot_cls=None, n_classes=0, width=None):
     n = out.shape[0]
     W = (src.shape[1] if src is not None else 0) if width is None else width

@@ -4,6 +4,8 @@ hand-written kernels (``drvae_amd.kernels``); autograd only routes tensors.
 
 (The fused train step in ``drvae_amd.engine`` does not go through autograd at all.)
 """
+import math
+
 import torch
 
 from . import kernels as K
@@ -21,6 +23,43 @@ def _c(t):
     if t.dim() == 2 and t.stride(1) == 1 and t.stride(0) >= t.size(1):
         return t
     return t.contiguous()
+
+
+class MMDRff(torch.autograd.Function):
+    """mmd^2 of two row sets under random Fourier features (src/blocks.py:40-55): projections and their
+    transposes on the MFMA GEMM, cos / column means / difference / sin on row kernels"""
+
+    @staticmethod
+    def forward(ctx, x1, x2, W, b, a, c):
+        x1, x2, W = x1.contiguous(), x2.contiguous(), W.contiguous()          # W: (Z, R) row-major
+        R = W.shape[1]
+        dev = x1.device
+        scale, bias = torch.full((R,), a, device=dev), (2 * math.pi) * b
+        th1, th2 = torch.empty(x1.shape[0], R, device=dev), torch.empty(x2.shape[0], R, device=dev)
+        K.gemm(th1, x1, W, True, False, epi=K.EPI_FWD, scale=scale, bias=bias)
+        K.gemm(th2, x2, W, True, False, epi=K.EPI_FWD, scale=scale, bias=bias)
+        diff, out = torch.empty(R, device=dev), torch.empty(1, device=dev)
+        K.mmd_rff_fwd(diff, out, th1, th2, c)
+        ctx.save_for_backward(th1, th2, W, diff)
+        ctx.ac = (a, c)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        th1, th2, W, diff = ctx.saved_tensors
+        a, c = ctx.ac
+        g = g.reshape(1).contiguous().float()
+        grads = []
+        for th, sign, need in ((th1, 1.0, ctx.needs_input_grad[0]), (th2, -1.0, ctx.needs_input_grad[1])):
+            if not need:
+                grads.append(None)
+                continue
+            G = torch.empty_like(th)
+            K.mmd_rff_bwd(G, th, diff, g, sign * 2.0 * c / th.shape[0])
+            dx = torch.empty(th.shape[0], W.shape[0], device=th.device)
+            K.gemm(dx, G, W, True, True, alpha=a)                 # (n,R) x (Z,R)^T
+            grads.append(dx)
+        return grads[0], grads[1], None, None, None, None
 
 
 class _LinearAct(torch.autograd.Function):

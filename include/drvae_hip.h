@@ -297,6 +297,17 @@ int dv_ycont_bwd(const float* mu, int64_t ldm, const float* ylab, const int32_t*
                  int64_t ld2, int32_t R, int32_t B, int32_t Y, float* dlogit, int64_t ldd, float* cfp,
                  dv_stream_t stream);
 
+/* ------------------------------------------- random-Fourier-feature MMD (K10)
+ * `mmd_fourier` of src/blocks.py:40-55.  The projections theta = a * x W + 2 pi b (a = sqrt(2/bandwidth)/sqrt(Z))
+ * come from dv_gemm (scale/bias epilogue); these finish the statistic:
+ *   _fwd: diff[r] = c*(mean_i cos(th1[i,r]) - mean_j cos(th2[j,r])),  mmd2[0] = sum_r diff[r]^2   (c = sqrt(2/R))
+ *   _bwd: G[i,r] = coef * gout[0] * (-diff[r]) * sin(th[i,r]) = d mmd2 / d theta for one input when
+ *         coef = +-2c/n (sign - for the second input); d/dx follows as a * G W^T (dv_gemm). */
+int dv_mmd_rff_fwd(const float* th1, int64_t ld1, int32_t n1, const float* th2, int64_t ld2, int32_t n2, int32_t R,
+                   float c, float* diff, float* mmd2, dv_stream_t stream);
+int dv_mmd_rff_bwd(const float* th, int64_t ld, int32_t n, int32_t R, const float* diff, const float* gout, float coef,
+                   float* G, int64_t ldg, dv_stream_t stream);
+
 /* ------------------------------------------------------------- row movement
  * out[r,:W] = src[idx?idx[r]:r, :W] (+ sigma*noise[r,:W])  -- the group gathers of
  *   src/DrVAE.py:585-608 and the training-noise augmentation of src/DrVAE.py:404-407

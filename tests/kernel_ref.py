@@ -478,6 +478,16 @@ def ycont_bwd(dlogit, cfp, mu, ylab, has_y, logvar, c_yl, c_kld, dfpin_y, dz3in_
     dlogit[:, :Y] = dmu * mu * (1 - mu)
 
 
+def mmd_rff_fwd(diff, mmd2, th1, th2, c):
+    d = c * (torch.cos(th1).mean(0) - torch.cos(th2).mean(0))
+    diff.copy_(d)
+    mmd2[0] = (d ** 2).sum()
+
+
+def mmd_rff_bwd(G, th, diff, gout, coef):
+    G.copy_(-coef * gout.reshape(-1)[0] * diff[None, :] * torch.sin(th))
+
+
 def rows_gather(out, src, idx=None, *, noise=None, sigma=0.0, onehot_cls=None, n_classes=0, width=None):
     n = out.shape[0]
     W = (src.shape[1] if src is not None else 0) if width is None else width
@@ -621,7 +631,7 @@ def fill_normal(out, seed, ctr_dev=None):
     out.copy_(torch.randn(out.shape, generator=g).to(out.device))
 
 
-FUNCTIONS = ['adamax_l2', 'batch_feed', 'counters_add2', 'ycont_fwd', 'ycont_bwd', 'flag_publish', 'flag_wait', 'gemm', 'linear_fwd', 'linear_bwd_data', 'linear_bwd_weight', 'linear_bwd_pair', 'colsum', 'act_bwd_', 'wn_scale', 'wn_bwd',
+FUNCTIONS = ['adamax_l2', 'batch_feed', 'mmd_rff_fwd', 'mmd_rff_bwd', 'counters_add2', 'ycont_fwd', 'ycont_bwd', 'flag_publish', 'flag_wait', 'gemm', 'linear_fwd', 'linear_bwd_data', 'linear_bwd_weight', 'linear_bwd_pair', 'colsum', 'act_bwd_', 'wn_scale', 'wn_bwd',
              'reparam_fwd', 'reparam_bwd', 'reparam_bwd_seg', 'z2f_post_bwd', 'kl_rows_fwd', 'kl_rows_bwd', 'nll_rows_fwd', 'nll_rows_bwd', 'nll_rows_fwdbwd',
              'softmax_clamp_fwd', 'softmax_clamp_bwd', 'cat_terms_fwd', 'cat_terms_bwd', 'smalln_fwd', 'smalln_bwd_data',
              'smalln_bwd_weight', 'ymarg_fwd', 'ymarg_bwd', 'ymarg_fwdbwd',

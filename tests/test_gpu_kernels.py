@@ -645,3 +645,34 @@ def test_batch_feed(K, dev, X, pad, Np, Mf):
     K.batch_feed(xin, x1, x2, None, table, nb, ctr, bs, pair_rows=pair_rows)
     R.batch_feed(rin, x1, x2, None, table, nb, ctr, bs, pair_rows=pair_rows)
     assert torch.equal(xin, rin)
+
+
+@pytest.mark.parametrize('n1,n2,Z,Rr', [(6, 9, 5, 500), (75, 75, 100, 500), (300, 33, 128, 130)])
+def test_mmd_rff(K, dev, n1, n2, Z, Rr):
+    from drvae_amd import ops
+    x1, x2 = strided(dev, n1, Z, 3, seed=1), rnd(dev, n2, Z, seed=2) * 0.5 + 0.3
+    W, b = rnd(dev, Z, Rr, seed=3), torch.rand(Rr).to(dev)
+    a, c = float(np.sqrt(2.0 / 2.0) / np.sqrt(Z)), float(np.sqrt(2.0 / Rr))
+    # row kernels against their stand-ins
+    th1, th2 = a * (x1 @ W) + 2 * np.pi * b, a * (x2 @ W) + 2 * np.pi * b
+    out = []
+    for mod in (K, R):
+        diff, m2 = torch.empty(Rr, device=dev), torch.empty(1, device=dev)
+        mod.mmd_rff_fwd(diff, m2, th1, th2, c)
+        G = torch.empty(n1, Rr, device=dev)
+        mod.mmd_rff_bwd(G, th1, diff, torch.tensor([0.7], device=dev), 2.0 * c / n1)
+        out.append((diff, m2, G))
+    for u, v in zip(*out):
+        close(u, v, rtol=2e-4, atol=2e-6)
+    # the whole op (GEMM projections + row kernels, forward and backward) against autograd on the formula
+    xa, xb = x1.clone().requires_grad_(True), x2.clone().requires_grad_(True)
+    m_hip = ops.MMDRff.apply(xa, xb, W, b, a, c)
+    (0.7 * m_hip).backward()
+    ga, gb = xa.grad.clone(), xb.grad.clone()
+    xa.grad = xb.grad = None
+    rf = lambda x: c * torch.cos(a * (x @ W) + 2 * np.pi * b[None, :])
+    m = ((rf(xa).mean(0) - rf(xb).mean(0)) ** 2).sum()
+    (0.7 * m).backward()
+    close(m_hip.detach().reshape(1), m.detach().reshape(1), rtol=5e-4, atol=1e-7)
+    close(ga, xa.grad, rtol=5e-3, atol=5e-6)
+    close(gb, xb.grad, rtol=5e-3, atol=5e-6)
