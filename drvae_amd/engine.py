@@ -170,12 +170,12 @@ class FusedStep(StepSchedule):
         self.seed = seed
         self.training = True
         self.fuse_bwd = False               # set by train_step/capture: forward is followed by backward
-        # train-step scheduling of the classifier/fprop side chain: 1 = graph fork/join per pass,
-        # 3 = one graph fork/join per step, 4 = the side chain is a ROOT branch of the graph and is
-        # ordered against the main chain by device flags (dv_flag_publish / dv_flag_wait)
+        # train-step scheduling of the classifier/fprop side chain (DRVAE_SCHED): 1 = graph fork/join per
+        # pass, 3 = one graph fork/join per step, 5 (default) = two single-stream graphs (main chain / side
+        # chain) launched on two streams per step and ordered ONLY by device flags (dv_flag_publish /
+        # dv_flag_wait): no graph edges, no events.  (Also tried and dropped: an extra cross edge, 0.37 ms;
+        # the side chain as a second ROOT of one graph with flags, 0.42 ms -- the executor starts it late.)
         self.sched = int(os.environ.get('DRVAE_SCHED', '5'))
-        #   5 = two single-stream graphs (main chain / side chain) launched on two streams per step
-        #       and ordered ONLY by the device flags: no graph edges, no events
         self._rec = 'both'
         self._side_graph = None
         self._flag_side = None
@@ -434,22 +434,18 @@ class FusedStep(StepSchedule):
             two = cfg.has_pert                      # flag 0: z1 samples final; flag 2: z2Fz1 samples final
             if rec == 'side':
                 K.flag_wait(self.flags[0:1], self.side_ctr, self.sync_err[2:4])
-                if not os.environ.get('DRVAE_SIDE_DUMMY'):
-                    side_forward((lambda: K.flag_wait(self.flags[2:3], self.side_ctr, self.sync_err[4:6])) if two else None)
+                side_forward((lambda: K.flag_wait(self.flags[2:3], self.side_ctr, self.sync_err[4:6])) if two else None)
                 return
             pub = (self.flags[2:3] if two else self.flags[0:1], self.step_dev, 1)
             if self.L_decx[0].g is not None:             # WeightNorm: the chain's first launch is not the GEMM
                 K.flag_publish(pub[0], pub[1], 1)
                 pub = None
-        elif mode == 4:
-            K.flag_publish(self.flags[0:1], self.step_dev)
         else:
             self.branch.fork()
-        if mode != 5:
             pub = None
         # ---- p(x|z): decoder over all stacked samples, then the NLL over genes
         X = cfg.dim_x
-        PX = p.c_decx.forward([p.ZDEC], publish=pub if mode == 5 else None)
+        PX = p.c_decx.forward([p.ZDEC], publish=pub)
         if self.fuse_bwd:      # train step: d/d(mu, pre-softplus) emitted in the same row pass
             K.nll_rows_fwdbwd(p.NLL, p.DPX[:, :X], p.DPX[:, X:], p.c_nll, p.XIN, PX[:, :X], PX[:, X:], mode=GAUSS_SIGMA,
                               xidx=p.tgt, sd_act='softplus', sd_shift=1e-3)
@@ -457,16 +453,9 @@ class FusedStep(StepSchedule):
             K.nll_rows_fwd(p.NLL, p.XIN, PX[:, :X], PX[:, X:], mode=GAUSS_SIGMA, xidx=p.tgt)
         if mode == 5:
             return             # main-chain graph: the side chain lives in its own graph on the side stream
-        if mode == 4:
-            self.branch._forked = True                  # forked at the start of the step: no new graph edge
         with self.branch:
-            if mode == 4:
-                K.flag_wait(self.flags[0:1], self.step_dev, self.sync_err)
-            if os.environ.get('DRVAE_SIDE_DUMMY'):      # tuning probe: one spinning kernel instead of the chain
-                torch.cuda._sleep(int(os.environ['DRVAE_SIDE_DUMMY']))
-            else:
-                side_forward()
-        if mode >= 2:
+            side_forward()
+        if mode == 3:
             return             # train step, single fork/join: the side chain runs on into its backward
         self.branch.join()
         if self.fuse_bwd:
@@ -500,7 +489,7 @@ class FusedStep(StepSchedule):
         mode = self._mode()
 
         def side_backward():
-            if self.fuse_bwd and mode < 2:
+            if self.fuse_bwd and mode == 1:
                 self._loss_scalars()         # leaf work, off the critical path
             if cfg.has_y and cfg.cont:
                 Y, Z3 = cfg.dim_y, cfg.dim_z3
@@ -575,37 +564,24 @@ class FusedStep(StepSchedule):
             K.nll_rows_bwd(p.DPX[:, :X], p.DPX[:, X:], p.c_nll, p.XIN, PX[:, :X], PX[:, X:], mode=GAUSS_SIGMA,
                            xidx=p.tgt, sd_act='softplus', sd_shift=1e-3)
         if mode == 5 and self._rec == 'side':
-            if not os.environ.get('DRVAE_SIDE_DUMMY'):
-                side_backward()
+            side_backward()
             K.flag_publish(self.flags[1:2], self.side_ctr)       # DZ1B / DZ2F / side gradients are final
             K.counter_add(self.side_ctr, 1)
             return
         if mode < 2:
             self.branch.fork()
-        elif mode == 5:
-            pass
-        else:
-            if mode == 2:
-                self.branch.wait_main()      # the loss scalars need the main chain's NLL rows
-            self.branch._forked = True       # the side chain simply continues: no new dependency
+        elif mode == 3:
+            self.branch._forked = True       # one fork/join per step: the side chain simply continues
         p.c_decx.backward(p.DPX, [p.ZDEC], [[(p.DZDEC, 1.0, 0.0)]], wbranch=self.wbranch if self.wbranch.on else None)
         if self._after_decoder_bwd is not None:
             self._after_decoder_bwd()        # decoder_x gradients are final: graph split point of the overlapped exchange
         if mode != 5:
             with self.branch:
-                if not os.environ.get('DRVAE_SIDE_DUMMY'):
-                    side_backward()
-                if mode == 2:
-                    self._loss_scalars()
-                if mode == 4:
-                    K.flag_publish(self.flags[1:2], self.step_dev)   # DZ1B / DZ2F / side gradients are final
-        if mode == 4:
-            K.flag_wait(self.flags[1:2], self.step_dev, self.sync_err[0:2])
-        elif mode < 4:
+                side_backward()
             self.branch.join()
         if mode == 5:      # the launch that assembles the loss scalars also parks on the side chain's flag
             self._loss_scalars(after=(self.flags[1:2], self.step_dev, self.sync_err[0:2], 1, 400000))
-        elif mode >= 3:
+        elif mode == 3:
             self._loss_scalars()
         if cfg.has_pert:
             if not cfg.has_y:
@@ -658,13 +634,11 @@ class FusedStep(StepSchedule):
             self.draw_noise(bump=False)
         self.fuse_bwd = True
         try:
-            self._step_begin()
             self.forward()
             self.backward()
             if allreduce is not None:
                 allreduce(self.arena.xchg)
             self.optimizer_step()
-            self._step_end()
         finally:
             self.fuse_bwd = False
         self.iters += 1

@@ -52,11 +52,6 @@ class _Branch:
             self.side.wait_stream(torch.cuda.current_stream())
             self._forked = True
 
-    def wait_main(self):
-        """extra edge main -> side at the current point of the main stream"""
-        if self.on:
-            self.side.wait_stream(torch.cuda.current_stream())
-
     def __enter__(self):
         if self.on:
             if not getattr(self, '_forked', False):
@@ -86,28 +81,18 @@ class StepSchedule:
             return 5
         if self.sched == 5:
             return 3                 # eager steps of the dual-graph schedule use plain stream edges
-        return self.sched if (self.sched != 4 or self.branch.on) else 1
-
-    def _step_begin(self):
-        if self._mode() == 4:
-            self.branch.fork()       # side chain = second root of the step (eager: waits for the previous step)
-
-    def _step_end(self):
-        if self.fuse_bwd and self.sched == 4 and self.branch.on:
-            self.branch.join()       # streams rejoin (required to end a capture); off the critical path
+        return 3 if self.sched == 3 else 1
 
     # ------------------------------------------------------------------- hipGraph
     def _launch_sequence(self, allreduce=None):
         self.fuse_bwd = True
         try:
-            self._step_begin()
             self.draw_noise(bump=False)
             self.forward()
             self.backward()
             if allreduce is not None:
                 allreduce(self.arena.xchg)
             self.optimizer_step()
-            self._step_end()        # after Adam: the rejoin edge stays off the critical path
         finally:
             self.fuse_bwd = False
 
@@ -317,11 +302,9 @@ class StepSchedule:
                 self.fuse_bwd = True
                 try:
                     ga.capture_begin()
-                    self._step_begin()
                     self.draw_noise(bump=False)
                     self.forward()
                     self.backward()
-                    self._step_end()
                     gb.capture_end()
                 finally:
                     self.fuse_bwd = False
@@ -336,11 +319,9 @@ class StepSchedule:
             with torch.cuda.graph(g1):
                 self.fuse_bwd = True
                 try:
-                    self._step_begin()
                     self.draw_noise(bump=False)
                     self.forward()
                     self.backward()
-                    self._step_end()
                 finally:
                     self.fuse_bwd = False
             with torch.cuda.graph(g2):
