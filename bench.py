@@ -282,6 +282,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    t_enq = time.perf_counter() - t0       # host time to enqueue the steps (if ~dt the host is the bound)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -303,7 +304,7 @@ def main():
                    'side_chain_cus': getattr(eng, '_side_cus', None),
                    'params': int(sum(int(np.prod(s)) for s in arena.shapes.values()))},
         'losses_last_step': {k: round(v, 4) for k, v in losses.items()}, 'finite': ok,
-        'chain_wait_ticks': waits,
+        'chain_wait_ticks': waits, 'host_enqueue_ms_per_step': round(1e3 * t_enq / args.steps, 4),
     }
     if rank == 0:
         hx, hy = batch['has_x2'].astype(bool), batch['has_y'].astype(bool)

@@ -1068,12 +1068,19 @@ struct LossTerms {
     int n;
 };
 
+struct CounterBump {
+    int32_t* c[2];
+    int n[2];
+    int64_t inc[2];
+};
+
 // all loss scalars of a step in ONE single-workgroup launch: loss[out] += scale * sum_i w[i]*x[i]
 // per term, then ELBO = <w_elbo, loss[0:3]>, CMPL = <w_cmpl, loss[0:8]>  (src/DrVAE.py:611-624)
 __global__ __launch_bounds__(256) void loss_assemble_kernel(LossTerms lt, const float* __restrict__ w_elbo,
                                                             const float* __restrict__ w_cmpl,
                                                             float* __restrict__ loss, int32_t* flag,
-                                                            const int32_t* ctr, int add, int32_t* err, int max_spins) {
+                                                            const int32_t* ctr, int add, int32_t* err, int max_spins,
+                                                            CounterBump bump) {
     __shared__ float part[4];
     __shared__ float acc[8];
     if (flag != nullptr) {      // park until the other launch chain has published its results
@@ -1111,6 +1118,20 @@ __global__ __launch_bounds__(256) void loss_assemble_kernel(LossTerms lt, const 
         for (int i = 0; i < 8; ++i) c += w_cmpl[i] * acc[i];
         acc[6] = c;
         for (int i = 0; i < 8; ++i) loss[i] = acc[i];
+        // end of the step's use of the device counters on this chain: advance them here (saves the
+        // separate counter launch in front of the optimiser)
+        for (int t = 0; t < 2; ++t) {
+            int32_t* c = bump.c[t];
+            if (c == nullptr) continue;
+            if (bump.n[t] == 1) {
+                c[0] = (int32_t)(c[0] + bump.inc[t]);
+            } else {
+                uint64_t v = ((uint64_t)(uint32_t)c[1] << 32) | (uint32_t)c[0];
+                v += (uint64_t)bump.inc[t];
+                c[0] = (int32_t)(uint32_t)v;
+                c[1] = (int32_t)(uint32_t)(v >> 32);
+            }
+        }
     }
 }
 
@@ -1571,15 +1592,18 @@ extern "C" int dv_loss_assemble(const dv_loss_term* terms, int32_t n_terms, cons
         lt.t[i] = terms[i];
     }
     hipLaunchKernelGGL(loss_assemble_kernel, dim3(1), dim3(256), 0, ST(stream), lt, w_elbo, w_cmpl, loss,
-                       (int32_t*)nullptr, (const int32_t*)nullptr, 0, (int32_t*)nullptr, 0);
+                       (int32_t*)nullptr, (const int32_t*)nullptr, 0, (int32_t*)nullptr, 0, CounterBump{});
     DV_RETURN_LAUNCH();
 }
 
 extern "C" int dv_loss_assemble_after(int32_t* flag, const int32_t* ctr, int32_t add, int32_t* err, int32_t max_spins,
                                       const dv_loss_term* terms, int32_t n_terms, const float* w_elbo,
-                                      const float* w_cmpl, float* loss, dv_stream_t stream) {
+                                      const float* w_cmpl, float* loss, int32_t* c1, int32_t n1, int64_t inc1,
+                                      int32_t* c2, int32_t n2, int64_t inc2, dv_stream_t stream) {
     DV_REQUIRE(n_terms >= 0 && n_terms <= DV_MAX_LOSS_TERMS && (terms || n_terms == 0));
     DV_REQUIRE(w_elbo && w_cmpl && loss && flag && ctr && err && max_spins > 0);
+    DV_REQUIRE((!c1 || n1 == 1 || n1 == 2) && (!c2 || n2 == 1 || n2 == 2));
+    CounterBump bump{{c1, c2}, {n1, n2}, {inc1, inc2}};
     LossTerms lt;
     lt.n = n_terms;
     for (int i = 0; i < n_terms; ++i) {
@@ -1587,7 +1611,7 @@ extern "C" int dv_loss_assemble_after(int32_t* flag, const int32_t* ctr, int32_t
         lt.t[i] = terms[i];
     }
     hipLaunchKernelGGL(loss_assemble_kernel, dim3(1), dim3(256), 0, ST(stream), lt, w_elbo, w_cmpl, loss, flag, ctr,
-                       add, err, max_spins);
+                       add, err, max_spins, bump);
     DV_RETURN_LAUNCH();
 }
 

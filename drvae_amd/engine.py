@@ -475,7 +475,12 @@ class FusedStep(StepSchedule):
         if cfg.has_y:
             terms.append((p.KLDrow, None, 1.0 / (L * p.n_tot), 1))
             terms.append((p.YLrow, None, 1.0 / (L * max(1., p.n_lab)), 3))
-        K.loss_assemble(self.arena.loss, terms, p.w_elbo, p.w_cmpl, after=after)
+        bump = ()
+        if after is not None:     # dual-graph train step: this launch also advances the step / Philox counters
+            bump = [(self.step_dev, 1)] + ([(self.rng_ctr, self._rng_pending)] if getattr(self, '_rng_pending', 0) else [])
+            self._rng_pending = 0
+            self._ctr_bumped = True
+        K.loss_assemble(self.arena.loss, terms, p.w_elbo, p.w_cmpl, after=after, bump=bump)
 
     # --------------------------------------------------------------------- backward
     def backward(self):
@@ -612,7 +617,9 @@ class FusedStep(StepSchedule):
     def optimizer_step(self, gscale=1.0):
         """torch.optim.Adam with coupled L2 on EVERY parameter (src/DGMMixin.py:36)."""
         cfg, a = self.cfg, self.arena
-        if getattr(self, '_rng_pending', 0):
+        if getattr(self, '_ctr_bumped', False):
+            self._ctr_bumped = False          # the loss-scalar launch of this step already advanced them
+        elif getattr(self, '_rng_pending', 0):
             K.counters_add2(self.step_dev, 1, self.rng_ctr, self._rng_pending)
             self._rng_pending = 0
         else:

@@ -426,9 +426,10 @@ def col_moments(out, x, r):
                'dv_col_moments')
 
 
-def loss_assemble(loss, terms, w_elbo, w_cmpl, after=None):
+def loss_assemble(loss, terms, w_elbo, w_cmpl, after=None, bump=()):
     """terms: list of (x, w_or_None, scale, out_index); see ``dv_loss_assemble``.  ``after`` =
-    (flag, counter, err, add, max_spins): park like ``flag_wait`` inside the same launch first."""
+    (flag, counter, err, add, max_spins): park like ``flag_wait`` inside the same launch first;
+    ``bump`` (with ``after`` only) = up to two (counter, inc): advanced at the end of the launch."""
     arr = (_lib.LossTerm * max(len(terms), 1))()
     for i, (x, w, scale, out) in enumerate(terms):
         arr[i].x, arr[i].w, arr[i].n, arr[i].scale, arr[i].out = _f32(x), _f32(w), x.numel(), scale, out
@@ -437,9 +438,11 @@ def loss_assemble(loss, terms, w_elbo, w_cmpl, after=None):
                    'dv_loss_assemble')
     else:
         flag, ctr, err, add, spins = after
-        _lib.check(_lib.load().dv_loss_assemble_after(_i32(flag), _i32(ctr), add, _i32(err), spins, arr, len(terms),
-                                                      _f32(w_elbo), _f32(w_cmpl), _f32(loss), _stream()),
-                   'dv_loss_assemble_after')
+        cs = list(bump) + [(None, 0)] * (2 - len(bump))
+        _lib.check(_lib.load().dv_loss_assemble_after(
+            _i32(flag), _i32(ctr), add, _i32(err), spins, arr, len(terms), _f32(w_elbo), _f32(w_cmpl), _f32(loss),
+            _i32(cs[0][0]), 0 if cs[0][0] is None else cs[0][0].numel(), cs[0][1],
+            _i32(cs[1][0]), 0 if cs[1][0] is None else cs[1][0].numel(), cs[1][1], _stream()), 'dv_loss_assemble_after')
 
 
 def axpby(y, x, a=1.0, b=0.0):

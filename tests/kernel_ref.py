@@ -560,9 +560,12 @@ def col_moments(out, x, r):
     out.copy_(torch.stack([xd.sum(0), (xd * xd).sum(0), ((xd - rd) ** 2).sum(0)], 0))
 
 
-def loss_assemble(loss, terms, w_elbo, w_cmpl, after=None):
+def loss_assemble(loss, terms, w_elbo, w_cmpl, after=None, bump=()):
     if after is not None:
         flag_wait(after[0], after[1], after[2], after[3], after[4])
+    for (c, inc) in bump:
+        if c is not None:
+            counter_add(c, inc)
     acc = torch.zeros(8, device=loss.device)
     for (x, w, scale, out) in terms:
         v = x.reshape(-1)

@@ -476,6 +476,18 @@ def test_loss_assemble(K, dev):
     K.loss_assemble(loss, terms, w_elbo, w_cmpl)
     R.loss_assemble(ref, terms, w_elbo, w_cmpl)
     close(loss, ref, rtol=1e-5, atol=1e-4)
+    # the parked variant: the flag is already published; the launch advances the counters at its end
+    # (the step counter doubles as the wait's reference: it is read before it is advanced)
+    flag = torch.tensor([5], dtype=torch.int32, device=dev)
+    step = torch.tensor([4], dtype=torch.int32, device=dev)
+    rng = torch.tensor([-3, 7], dtype=torch.int32, device=dev)          # 64-bit (lo, hi): the add carries
+    err = torch.zeros(2, dtype=torch.int32, device=dev)
+    loss.fill_(9.0)
+    K.loss_assemble(loss, terms, w_elbo, w_cmpl, after=(flag, step, err, 1, 1000), bump=[(step, 1), (rng, 5)])
+    close(loss, ref, rtol=1e-5, atol=1e-4)
+    assert step.tolist() == [5] and rng.tolist() == [2, 8] and int(err[0]) == 0
+    K.loss_assemble(loss, terms, w_elbo, w_cmpl, after=(flag, step, err, 1, 1000), bump=[(step, 1)])
+    assert int(err[0]) == 1 and step.tolist() == [6]                    # flag 5 < 5 + 1: bounded wait, reported
 
 
 @pytest.mark.parametrize('Y,two', [(2, True), (3, False), (8, True), (1, False)])
