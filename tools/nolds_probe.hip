@@ -136,14 +136,137 @@ __global__ __launch_bounds__(64 * KS) void gemm_nolds(const float* __restrict__ 
     }
 }
 
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+// same idea on v_mfma_f32_16x16x4_f32: lane (r = l%16, q = l/16) loads A[row r][16c + 4q .. +3] -- 4 lanes per
+// 64 B of a row (the 32x32x2 layout has 2 lanes per 32 B: twice the cache-line touches per byte)
 template <int TM, int TN, int KS, int PF>
+__global__ __launch_bounds__(64 * KS) void gemm_nolds16(const float* __restrict__ A, int lda, const float* __restrict__ B,
+                                                       int ldb, float* __restrict__ C, int ldc, int M, int N, int K,
+                                                       int tiles_n) {
+    constexpr int IM = TM / 16, JN = TN / 16;
+    __shared__ float red[(KS > 1 ? (KS / 2) : 1) * TM * TN];
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63, r = l & 15, q = l >> 4;
+    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+    const int m0 = tm * TM, n0 = tn * TN;
+    const float* pa[IM];
+    const float* pb[JN];
+#pragma unroll
+    for (int i = 0; i < IM; ++i) {
+        int row = m0 + 16 * i + r;
+        row = row < M ? row : M - 1;
+        pa[i] = A + (int64_t)row * lda + 16 * w + 4 * q;
+    }
+#pragma unroll
+    for (int j = 0; j < JN; ++j) {
+        int col = n0 + 16 * j + r;
+        col = col < N ? col : N - 1;
+        pb[j] = B + (int64_t)col * ldb + 16 * w + 4 * q;
+    }
+    v4f acc[IM][JN];
+#pragma unroll
+    for (int i = 0; i < IM; ++i)
+#pragma unroll
+        for (int j = 0; j < JN; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+    const int nchunk = K / 16;                      // probe: K % 16 == 0
+    const int mine = (nchunk - w + KS - 1) / KS;
+    float4 fa[PF][IM], fb[PF][JN];
+#pragma unroll
+    for (int s = 0; s < PF; ++s) {
+        const bool ok = s < mine;
+#pragma unroll
+        for (int i = 0; i < IM; ++i) fa[s][i] = *reinterpret_cast<const float4*>(ok ? pa[i] + (int64_t)s * 16 * KS : pa[i]);
+#pragma unroll
+        for (int j = 0; j < JN; ++j) fb[s][j] = *reinterpret_cast<const float4*>(ok ? pb[j] + (int64_t)s * 16 * KS : pb[j]);
+    }
+    int c = 0;
+    for (; c + PF <= mine; c += PF) {
+#pragma unroll
+        for (int s = 0; s < PF; ++s) {
+            float4 a[IM], b[JN];
+#pragma unroll
+            for (int i = 0; i < IM; ++i) a[i] = fa[s][i];
+#pragma unroll
+            for (int j = 0; j < JN; ++j) b[j] = fb[s][j];
+            const int nxt = c + s + PF;
+            const int64_t off = (int64_t)(nxt < mine ? nxt : 0) * 16 * KS;
+#pragma unroll
+            for (int i = 0; i < IM; ++i) fa[s][i] = *reinterpret_cast<const float4*>(pa[i] + off);
+#pragma unroll
+            for (int j = 0; j < JN; ++j) fb[s][j] = *reinterpret_cast<const float4*>(pb[j] + off);
+#pragma unroll
+            for (int i = 0; i < IM; ++i)
+#pragma unroll
+                for (int j = 0; j < JN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+                }
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < PF; ++s) {
+        if (c + s < mine) {
+#pragma unroll
+            for (int i = 0; i < IM; ++i)
+#pragma unroll
+                for (int j = 0; j < JN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[s][i].x, fb[s][j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[s][i].y, fb[s][j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[s][i].z, fb[s][j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[s][i].w, fb[s][j].w, acc[i][j], 0, 0, 0);
+                }
+        }
+    }
+    if (KS > 1) {
+        for (int half = KS / 2; half >= 1; half >>= 1) {
+            if (w >= half && w < 2 * half) {
+                float* dst = red + (w - half) * TM * TN;
+#pragma unroll
+                for (int i = 0; i < IM; ++i)
+#pragma unroll
+                    for (int j = 0; j < JN; ++j)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) dst[((i * JN + j) * 4 + e) * 64 + l] = acc[i][j][e];
+            }
+            __syncthreads();
+            if (w < half) {
+                const float* src = red + w * TM * TN;
+#pragma unroll
+                for (int i = 0; i < IM; ++i)
+#pragma unroll
+                    for (int j = 0; j < JN; ++j)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[i][j][e] += src[((i * JN + j) * 4 + e) * 64 + l];
+            }
+            __syncthreads();
+        }
+    }
+    if (w == 0) {
+#pragma unroll
+        for (int i = 0; i < IM; ++i)
+#pragma unroll
+            for (int j = 0; j < JN; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int row = m0 + 16 * i + 4 * q + e, col = n0 + 16 * j + r;
+                    if (row < M && col < N) C[(int64_t)row * ldc + col] = acc[i][j][e];
+                }
+    }
+}
+
+template <int TM, int TN, int KS, int PF, bool M16 = false>
 static void run(const char* name, const float* A, const float* B, float* C, int M, int N, int K, const std::vector<float>& ref,
                 int reps) {
     const int tiles_m = (M + TM - 1) / TM, tiles_n = (N + TN - 1) / TN;
     dim3 grid(tiles_m * tiles_n), block(64 * KS);
     const int lda = K, ldb = K, ldc = N;
     CK(hipMemset(C, 0, sizeof(float) * M * N));
-    hipLaunchKernelGGL((gemm_nolds<TM, TN, KS, PF>), grid, block, 0, 0, A, lda, B, ldb, C, ldc, M, N, K, tiles_n);
+    if constexpr (M16) hipLaunchKernelGGL((gemm_nolds16<TM, TN, KS, PF>), grid, block, 0, 0, A, lda, B, ldb, C, ldc, M, N, K, tiles_n);
+    else hipLaunchKernelGGL((gemm_nolds<TM, TN, KS, PF>), grid, block, 0, 0, A, lda, B, ldb, C, ldc, M, N, K, tiles_n);
     CK(hipDeviceSynchronize());
     std::vector<float> out((size_t)M * N);
     CK(hipMemcpy(out.data(), C, sizeof(float) * M * N, hipMemcpyDeviceToHost));
@@ -156,10 +279,12 @@ static void run(const char* name, const float* A, const float* B, float* C, int 
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
     for (int i = 0; i < 5; ++i)
-        hipLaunchKernelGGL((gemm_nolds<TM, TN, KS, PF>), grid, block, 0, 0, A, lda, B, ldb, C, ldc, M, N, K, tiles_n);
+        if constexpr (M16) hipLaunchKernelGGL((gemm_nolds16<TM, TN, KS, PF>), grid, block, 0, 0, A, lda, B, ldb, C, ldc, M, N, K, tiles_n);
+    else hipLaunchKernelGGL((gemm_nolds<TM, TN, KS, PF>), grid, block, 0, 0, A, lda, B, ldb, C, ldc, M, N, K, tiles_n);
     CK(hipEventRecord(e0));
     for (int i = 0; i < reps; ++i)
-        hipLaunchKernelGGL((gemm_nolds<TM, TN, KS, PF>), grid, block, 0, 0, A, lda, B, ldb, C, ldc, M, N, K, tiles_n);
+        if constexpr (M16) hipLaunchKernelGGL((gemm_nolds16<TM, TN, KS, PF>), grid, block, 0, 0, A, lda, B, ldb, C, ldc, M, N, K, tiles_n);
+    else hipLaunchKernelGGL((gemm_nolds<TM, TN, KS, PF>), grid, block, 0, 0, A, lda, B, ldb, C, ldc, M, N, K, tiles_n);
     CK(hipEventRecord(e1));
     CK(hipEventSynchronize(e1));
     float ms;
@@ -170,7 +295,7 @@ static void run(const char* name, const float* A, const float* B, float* C, int 
 }
 
 int main(int argc, char** argv) {
-    const int shapes[][3] = {{596, 1956, 600}, {596, 600, 1952}, {224, 800, 976}, {596, 600, 104}, {224, 200, 800},
+    const int shapes[][3] = {{596, 1956, 608}, {596, 600, 1952}, {224, 800, 976}, {596, 600, 112}, {224, 200, 800},
                              {4096, 4096, 2048}};
     for (auto& s : shapes) {
         const int M = s[0], N = s[1], K = s[2];
@@ -195,16 +320,18 @@ int main(int argc, char** argv) {
         printf("M=%d N=%d K=%d\n", M, N, K);
         const int reps = 50;
         run<32, 32, 4, 2>("32x32 KS4 PF2", A, B, C, M, N, K, ref, reps);
-        run<32, 32, 4, 4>("32x32 KS4 PF4", A, B, C, M, N, K, ref, reps);
-        run<64, 32, 4, 2>("64x32 KS4 PF2", A, B, C, M, N, K, ref, reps);
-        run<32, 64, 4, 2>("32x64 KS4 PF2", A, B, C, M, N, K, ref, reps);
-        run<64, 64, 4, 2>("64x64 KS4 PF2", A, B, C, M, N, K, ref, reps);
-        run<64, 64, 4, 3>("64x64 KS4 PF3", A, B, C, M, N, K, ref, reps);
-        run<64, 64, 8, 2>("64x64 KS8 PF2", A, B, C, M, N, K, ref, reps);
-        run<64, 64, 2, 3>("64x64 KS2 PF3", A, B, C, M, N, K, ref, reps);
         run<64, 64, 1, 4>("64x64 KS1 PF4", A, B, C, M, N, K, ref, reps);
-        run<64, 32, 8, 2>("64x32 KS8 PF2", A, B, C, M, N, K, ref, reps);
-        run<64, 32, 2, 4>("64x32 KS2 PF4", A, B, C, M, N, K, ref, reps);
+        run<32, 32, 4, 2, true>("m16 32x32 KS4 PF2", A, B, C, M, N, K, ref, reps);
+        run<32, 32, 4, 3, true>("m16 32x32 KS4 PF3", A, B, C, M, N, K, ref, reps);
+        run<64, 32, 4, 2, true>("m16 64x32 KS4 PF2", A, B, C, M, N, K, ref, reps);
+        run<32, 64, 4, 2, true>("m16 32x64 KS4 PF2", A, B, C, M, N, K, ref, reps);
+        run<64, 32, 2, 2, true>("m16 64x32 KS2 PF2", A, B, C, M, N, K, ref, reps);
+        run<64, 64, 4, 2, true>("m16 64x64 KS4 PF2", A, B, C, M, N, K, ref, reps);
+        run<64, 64, 2, 2, true>("m16 64x64 KS2 PF2", A, B, C, M, N, K, ref, reps);
+        run<64, 64, 1, 3, true>("m16 64x64 KS1 PF3", A, B, C, M, N, K, ref, reps);
+        run<48, 32, 4, 2, true>("m16 48x32 KS4 PF2", A, B, C, M, N, K, ref, reps);
+        run<80, 16, 4, 2, true>("m16 80x16 KS4 PF2", A, B, C, M, N, K, ref, reps);
+        run<80, 32, 4, 2, true>("m16 80x32 KS4 PF2", A, B, C, M, N, K, ref, reps);
         CK(hipFree(A));
         CK(hipFree(B));
         CK(hipFree(C));
