@@ -585,7 +585,7 @@ class FusedStep(StepSchedule):
                 side_backward()
             self.branch.join()
         if mode == 5:      # the launch that assembles the loss scalars also parks on the side chain's flag
-            self._loss_scalars(after=(self.flags[1:2], self.step_dev, self.sync_err[0:2], 1, 400000))
+            self._loss_scalars(after=(self.flags[1:2], self.step_dev, self.sync_err[0:2], 1, K.WAIT_SPINS))
         elif mode == 3:
             self._loss_scalars()
         if cfg.has_pert:

@@ -7,6 +7,7 @@ row-strided views (``stride(1) == 1``); the row stride is passed as the leading
 dimension.  There is no CPU path here: tensors must live on the GPU.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -467,7 +468,15 @@ def flag_publish(flag, ctr, add=1):
     _lib.check(_lib.load().dv_flag_publish(_i32(flag), _i32(ctr), add, _stream()), 'dv_flag_publish')
 
 
-def flag_wait(flag, ctr, err, add=1, max_spins=400000):
+# Bound of a device-side wait, in polls (~1 us each: an agent-scope load + s_sleep).  Inside one process
+# the chains are at most a step (~0.3 ms) apart; under data parallelism a chain may also sit out the skew
+# between the ranks (the next step's first publish follows the previous step's gradient exchange), hence
+# seconds rather than milliseconds.  A wait that still times out is reported (see ``check_sync``), never hung.
+WAIT_SPINS = int(os.environ.get('DRVAE_WAIT_SPINS', '4000000'))
+
+
+def flag_wait(flag, ctr, err, add=1, max_spins=None):
+    max_spins = WAIT_SPINS if max_spins is None else max_spins
     _lib.check(_lib.load().dv_flag_wait(_i32(flag), _i32(ctr), add, _i32(err), max_spins, _stream()), 'dv_flag_wait')
 
 

@@ -605,7 +605,7 @@ def flag_publish(flag, ctr, add=1):
     flag[0] = int(ctr[0]) + add
 
 
-def flag_wait(flag, ctr, err, add=1, max_spins=400000):
+def flag_wait(flag, ctr, err, add=1, max_spins=None):
     if int(flag[0]) < int(ctr[0]) + add:      # single-threaded stand-in: the producer must have run already
         err[0] = 1                            # (err[1], the parked-time statistic, stays 0)
 
