@@ -500,7 +500,24 @@ __device__ __forceinline__ void gemm_body(const dv_gemm_desc& g, const LoadCfg& 
         stage_store(buf0, a0, b0);
         if (nkt > 2) fetch(2, a0, b0);
         __syncthreads();
-        for (int kt = 0; kt < nkt; kt += 2) {
+        int kt = 0;
+#if DV_DBG == 0
+        // steady state (every tile touched is a full one): no conditionals, so each phase is ONE
+        // scheduling region -- hipcc then spreads the LDS stores and global loads of the phase over its
+        // MFMA chain instead of issuing them after it (they sat in a conditional block of their own);
+        // measured: decoder-head products 26.4 -> 25.1 us, 128x128 tiling 118 -> 122 TF/s
+        for (; kt + 4 < nfull; kt += 2) {
+            compute(buf0);
+            stage_store(buf1, a1, b1);
+            fetch(0, a1, b1);
+            __syncthreads();
+            compute(buf1);
+            stage_store(buf0, a0, b0);
+            fetch(0, a0, b0);
+            __syncthreads();
+        }
+#endif
+        for (; kt < nkt; kt += 2) {
             compute(buf0);
             if (kt + 1 < nkt) {
                 if (!(DV_DBG & 4)) stage_store(buf1, a1, b1);
