@@ -1,0 +1,23 @@
+#!/bin/bash
+# The committed evidence of a round (GPU box; run from the repo root, outputs under gpurun_out/final/):
+# the default bench line, the same command under rocprofv3 --kernel-trace --stats (cfg 2 and the wide
+# configuration) and the PMC passes (tools/pmc_collect.sh).  Copy the summaries into profiles/.
+cd /tmp && export TMPDIR=/tmp
+cd "$GRAFT_REPO_ROOT" || exit 1
+O=gpurun_out/final
+rm -rf $O && mkdir -p $O
+python3 bench.py --steps 300 --warmup 20 > $O/cfg2_bench.json 2> $O/cfg2_bench.err
+python3 bench.py --workload wide --steps 6 --warmup 2 --no-cpu-baseline > $O/wide_bench.json 2> $O/wide_bench.err
+export DRVAE_SIDE_CUS=64      # fixed split: no tuning replays in the profile
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/k2 -o p -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline > $O/cfg2_prof.log 2>&1
+cp $(find $O/k2 -name '*kernel_stats.csv' | head -1) $O/cfg2_kernel_stats.csv
+python3 tools/timeline.py $(find $O/k2 -name '*kernel_trace.csv' | head -1) > $O/cfg2_step_timeline.txt 2>&1
+rm -rf $O/k2
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kw -o p -- python3 bench.py --workload wide --steps 4 --warmup 2 --no-cpu-baseline --no-roofline > $O/wide_prof.log 2>&1
+cp $(find $O/kw -name '*kernel_stats.csv' | head -1) $O/wide_kernel_stats.csv
+rm -rf $O/kw
+unset DRVAE_SIDE_CUS
+bash tools/pmc_collect.sh > $O/pmc.log 2>&1
+python3 tools/pmc_summary.py gpurun_out/pmc_r1 > $O/cfg2_pmc_summary.txt 2>&1
+rm -rf gpurun_out/pmc_r1
+ls -la $O
