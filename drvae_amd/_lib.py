@@ -88,6 +88,7 @@ SIGNATURES = {
                                _i64, _p],
     'dv_axpby': [_p, _f, _p, _f, _i64, _p],
     'dv_adam_l2': [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _f, _p, _p],
+    'dv_adam_l2_gated': [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _f, _p, _p, _p, _i32, _p, _i32, _i64, _i64, _p],
     'dv_adamax_l2': [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _f, _p, _p],
     'dv_flag_publish': [_p, _p, _i32, _p],
     'dv_flag_wait': [_p, _p, _i32, _p, _i32, _p],

@@ -31,12 +31,48 @@ __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, 
     p = p + (-step_size) * (m / denom);
 }
 
+// optional gate of the optimiser sweep: the elements [lo, hi) of the arena (gradients another launch chain
+// still writes) are touched only after that chain has published `flag` (see dv_flag_publish)
+struct AdamGate {
+    int32_t* flag;
+    const int32_t* ctr;
+    int add;
+    int32_t* err;
+    int max_spins;
+    int64_t lo, hi;
+};
+
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, int64_t n, float lr,
                                                    float b1, float b2, float eps, float wd, float gscale,
-                                                   const int32_t* __restrict__ step_dev, int vec4) {
+                                                   const int32_t* __restrict__ step_dev, int vec4, AdamGate gate) {
     __shared__ float sc[2];
     if (threadIdx.x == 0) adam_consts(lr, b1, b2, step_dev, &sc[0], &sc[1]);
+    if (gate.flag != nullptr) {
+        // only the workgroups whose elements overlap the gated range park (typically one): a parked
+        // workgroup or two can never starve the chain that is to publish
+        const int64_t per = vec4 ? 4 : 1, span = (int64_t)blockDim.x * per;
+        const int64_t bstride = (int64_t)gridDim.x * span;
+        bool need = gate.hi > (vec4 ? ((n >> 2) << 2) : n) && gate.lo < n;       // the scalar tail (all workgroups sweep it)
+        for (int64_t e0 = blockIdx.x * span; e0 < n; e0 += bstride) need = need || (e0 < gate.hi && e0 + span > gate.lo);
+        if (need) {
+            if (threadIdx.x == 0) {
+                const int want = gate.ctr[0] + gate.add;
+                const long long t0 = wall_clock64();
+                int k = 0;
+                while (__hip_atomic_load(gate.flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - want < 0) {
+                    __builtin_amdgcn_s_sleep(4);
+                    if (++k > gate.max_spins) {
+                        atomicExch(gate.err, 1);
+                        break;
+                    }
+                }
+                atomicAdd(gate.err + 1, (int32_t)(wall_clock64() - t0));
+            }
+            __syncthreads();
+            (void)__hip_atomic_load(gate.flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);   // every wave acquires
+        }
+    }
     __syncthreads();
     const float step_size = sc[0], bc2_sqrt = sc[1];
     // (float)(1 - beta) computed in double first, as python does before the op sees it
@@ -178,9 +214,9 @@ extern "C" const char* dv_error_string(int code) {
     }
 }
 
-extern "C" int dv_adam_l2(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
-                          float beta2, float eps, float weight_decay, float gscale, const int32_t* step_dev,
-                          dv_stream_t stream) {
+static int adam_launch(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                       float eps, float weight_decay, float gscale, const int32_t* step_dev, const AdamGate& gate,
+                       dv_stream_t stream) {
     DV_REQUIRE(n >= 0);
     if (n == 0) return DV_OK;
     DV_REQUIRE(p && g && m && v && step_dev);
@@ -190,8 +226,23 @@ extern "C" int dv_adam_l2(float* p, const float* g, float* m, float* v, int64_t 
     if (blocks < 1) blocks = 1;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, ST(stream), p, g, m, v, n, lr, beta1,
-                       beta2, eps, weight_decay, gscale, step_dev, vec4);
+                       beta2, eps, weight_decay, gscale, step_dev, vec4, gate);
     DV_RETURN_LAUNCH();
+}
+
+extern "C" int dv_adam_l2(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                          float beta2, float eps, float weight_decay, float gscale, const int32_t* step_dev,
+                          dv_stream_t stream) {
+    return adam_launch(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, gscale, step_dev, AdamGate{}, stream);
+}
+
+extern "C" int dv_adam_l2_gated(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                                float beta2, float eps, float weight_decay, float gscale, const int32_t* step_dev,
+                                int32_t* flag, const int32_t* ctr, int32_t add, int32_t* err, int32_t max_spins,
+                                int64_t lo, int64_t hi, dv_stream_t stream) {
+    DV_REQUIRE(flag && ctr && err && max_spins > 0 && lo >= 0 && hi >= lo && hi <= n);
+    return adam_launch(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, gscale, step_dev,
+                       AdamGate{flag, ctr, add, err, max_spins, lo, hi}, stream);
 }
 
 extern "C" int dv_adamax_l2(float* p, const float* g, float* m, float* u, int64_t n, float lr, float beta1,

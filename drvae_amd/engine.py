@@ -177,12 +177,15 @@ class FusedStep(StepSchedule):
         # the side chain as a second ROOT of one graph with flags, 0.42 ms -- the executor starts it late.)
         self.sched = int(os.environ.get('DRVAE_SCHED', '5'))
         self._rec = 'both'
+        self.late_leaf = os.environ.get('DRVAE_LATE_LEAF', '1') != '0'
+        self._split_capture = False
+        self._adam_gate = None
         self._side_graph = None
         self._flag_side = None
         self._after_decoder_bwd = None
         self.side_ctr = torch.zeros(1, dtype=torch.int32, device=self.dev)   # the side chain's own step count
-        self.flags = torch.zeros(3, dtype=torch.int32, device=self.dev)
-        self.sync_err = torch.zeros(6, dtype=torch.int32, device=self.dev)   # (error, ticks parked) x 3 wait sites
+        self.flags = torch.zeros(4, dtype=torch.int32, device=self.dev)
+        self.sync_err = torch.zeros(8, dtype=torch.int32, device=self.dev)   # (error, ticks parked) x 4 wait sites
         self.add_noise = True               # `fit(add_noise=...)` flag of the reference (src/DrVAE.py:769)
         # classifier/fprop chain || decoder chain.  PVAE's side chain is one tiny KL kernel: a second stream
         # costs it far more than it hides (measured 0.19 ms single-stream vs 0.9 ms forked), so it runs serial
@@ -493,6 +496,19 @@ class FusedStep(StepSchedule):
         # ---- side chain: y-marginalisation, fprop, classifier -> DZ1B (its share of d/dz1), DZ2F
         mode = self._mode()
 
+        # (dual-graph schedule) the classifier's weight gradient is a leaf -- only the optimiser reads it --
+        # and the side chain is the one the join waits for: it runs AFTER the side chain has published its
+        # data gradients, and the optimiser launch gates that slice of the arena on a flag of its own
+        late = (mode == 5 and self.late_leaf and cfg.has_y and not cfg.cont and self.clf_small
+                and cfg.optim_alg == 'adam' and not self._split_capture)
+        leaf = []
+
+        def wgrad_clf(*args):
+            if late:
+                leaf.append(lambda: K.smalln_bwd_weight(*args))
+            else:
+                K.smalln_bwd_weight(*args)
+
         def side_backward():
             if self.fuse_bwd and mode == 1:
                 self._loss_scalars()         # leaf work, off the critical path
@@ -542,15 +558,15 @@ class FusedStep(StepSchedule):
                     lc = self.L_clf[0]
                     if two:      # input [z1, z2F - z1]: d/dz1 gets W1 - W2, d/dz2F gets W2
                         K.smalln_bwd_data([(p.DZ1B, 0, 1.0, b1, Z1, -1.0), (p.DZ2F, Z1, 1.0, 0.0)], p.DQY, p.QY, lc.W)
-                        K.smalln_bwd_weight(lc.dW, lc.db, p.DQY, p.QY, Z1blk, p.D)
+                        wgrad_clf(lc.dW, lc.db, p.DQY, p.QY, Z1blk, p.D)
                     elif cfg.kind == 'drvae':
                         K.smalln_bwd_data([(p.DZ2F, 0, 1.0, 0.0)], p.DQY, p.QY, lc.W)
-                        K.smalln_bwd_weight(lc.dW, lc.db, p.DQY, p.QY, p.Z2F)
+                        wgrad_clf(lc.dW, lc.db, p.DQY, p.QY, p.Z2F)
                         if not p.Mf:
                             p.DZ1B.zero_()
                     else:
                         K.smalln_bwd_data([(p.DZ1B, 0, 1.0, b1)], p.DQY, p.QY, lc.W)
-                        K.smalln_bwd_weight(lc.dW, lc.db, p.DQY, p.QY, Z1blk)
+                        wgrad_clf(lc.dW, lc.db, p.DQY, p.QY, Z1blk)
                 else:
                     K.softmax_clamp_bwd(p.DLOG, p.DQY, p.QY, sigmoid1=cfg.clf_1sig)
                     if two:
@@ -571,6 +587,10 @@ class FusedStep(StepSchedule):
         if mode == 5 and self._rec == 'side':
             side_backward()
             K.flag_publish(self.flags[1:2], self.side_ctr)       # DZ1B / DZ2F / side gradients are final
+            if late:
+                for fn in leaf:
+                    fn()
+                K.flag_publish(self.flags[3:4], self.side_ctr)   # ... and now the classifier's dW / db
             K.counter_add(self.side_ctr, 1)
             return
         if mode < 2:
@@ -586,6 +606,11 @@ class FusedStep(StepSchedule):
             self.branch.join()
         if mode == 5:      # the launch that assembles the loss scalars also parks on the side chain's flag
             self._loss_scalars(after=(self.flags[1:2], self.step_dev, self.sync_err[0:2], 1, K.WAIT_SPINS))
+            if late:       # (that launch has advanced the step counter: the flag carries counter + 0 by now)
+                lc, g0 = self.L_clf[0], self.arena.grad.storage_offset()
+                lo = min(lc.dW.storage_offset(), lc.db.storage_offset()) - g0
+                hi = max(lc.dW.storage_offset() + lc.dW.numel(), lc.db.storage_offset() + lc.db.numel()) - g0
+                self._adam_gate = (self.flags[3:4], self.step_dev, 0, self.sync_err[6:8], lo, hi)
         elif mode == 3:
             self._loss_scalars()
         if cfg.has_pert:
@@ -628,8 +653,11 @@ class FusedStep(StepSchedule):
             K.counter_add(self.side_ctr, 1)      # eager step: the side chain's counter follows
         step = K.adamax_l2 if cfg.optim_alg == 'adamax' else K.adam_l2    # exp_avg_sq doubles as Adamax's exp_inf
         n = a.n_live                      # parameters without gradients sit behind it (untouched, like torch)
+        kw = {}
+        if self._adam_gate is not None:   # dual-graph step: the classifier's dW may still be in flight on the side chain
+            kw['gate'], self._adam_gate = self._adam_gate, None
         step(a.param[:n], a.grad[:n], a.exp_avg[:n], a.exp_avg_sq[:n], self.step_dev, lr=cfg.learning_rate,
-             weight_decay=cfg.weight_decay, gscale=gscale)
+             weight_decay=cfg.weight_decay, gscale=gscale, **kw)
 
     def train_step(self, noise=None, allreduce=None):
         """forward + backward (+ gradient all-reduce) + Adam + iteration count: the body of

@@ -452,10 +452,17 @@ def axpby(y, x, a=1.0, b=0.0):
 
 
 # ------------------------------------------------------------------------- optimiser
-def adam_l2(p, g, m, v, step_dev, *, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, gscale=1.0):
+def adam_l2(p, g, m, v, step_dev, *, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, gscale=1.0, gate=None):
+    """``gate`` = (flag, counter, add, err, lo, hi): elements [lo, hi) wait for the flag (``dv_adam_l2_gated``)"""
     assert p.is_contiguous() and g.is_contiguous() and m.is_contiguous() and v.is_contiguous()
-    _lib.check(_lib.load().dv_adam_l2(_f32(p), _f32(g), _f32(m), _f32(v), p.numel(), lr, beta1, beta2, eps,
-                                      weight_decay, gscale, _i32(step_dev), _stream()), 'dv_adam_l2')
+    if gate is None:
+        _lib.check(_lib.load().dv_adam_l2(_f32(p), _f32(g), _f32(m), _f32(v), p.numel(), lr, beta1, beta2, eps,
+                                          weight_decay, gscale, _i32(step_dev), _stream()), 'dv_adam_l2')
+    else:
+        flag, ctr, add, err, lo, hi = gate
+        _lib.check(_lib.load().dv_adam_l2_gated(_f32(p), _f32(g), _f32(m), _f32(v), p.numel(), lr, beta1, beta2, eps,
+                                                weight_decay, gscale, _i32(step_dev), _i32(flag), _i32(ctr), add,
+                                                _i32(err), WAIT_SPINS, lo, hi, _stream()), 'dv_adam_l2_gated')
 
 
 def adamax_l2(p, g, m, u, step_dev, *, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, gscale=1.0):

@@ -115,6 +115,7 @@ class StepSchedule:
         self._graphs = []
         self._side_graph = None
         dual = self.sched == 5 and self.branch.on and self.cfg.has_y and self._flags_usable()
+        self._split_capture = bool(split_for_allreduce)
         if dual:
             self._rec = 'main'
         try:

@@ -386,6 +386,14 @@ int dv_axpby(const float* x, float a, float* y, float b, int64_t n, dv_stream_t 
  * multiplies g first (1/world_size style scaling; 1.0 for summed gradients). */
 int dv_adam_l2(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                float eps, float weight_decay, float gscale, const int32_t* step_dev, dv_stream_t stream);
+/* same sweep, but the elements [lo, hi) are touched only after another launch chain has published `flag`
+ * (flag[0] >= ctr[0] + add, see dv_flag_publish): only the workgroups overlapping the range park (bounded
+ * like dv_flag_wait: err[0] = 1 on time-out, err[1] += ticks parked), so gradients that are leaves of
+ * the backward pass may still be in flight on the other chain when the optimiser launch starts */
+int dv_adam_l2_gated(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                     float eps, float weight_decay, float gscale, const int32_t* step_dev, int32_t* flag,
+                     const int32_t* ctr, int32_t add, int32_t* err, int32_t max_spins, int64_t lo, int64_t hi,
+                     dv_stream_t stream);
 /* torch.optim.Adamax with coupled L2 (the `optim_alg='adamax'` branch of src/DGMMixin.py:37-38):
  * u is the exponentially weighted infinity norm; same conventions as dv_adam_l2. */
 int dv_adamax_l2(float* p, const float* g, float* m, float* u, int64_t n, float lr, float beta1, float beta2,

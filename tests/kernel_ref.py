@@ -579,7 +579,9 @@ def axpby(y, x, a=1.0, b=0.0):
     y.copy_(a * x + (b * y if b != 0.0 else 0))
 
 
-def adam_l2(p, g, m, v, step_dev, *, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, gscale=1.0):
+def adam_l2(p, g, m, v, step_dev, *, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, gscale=1.0, gate=None):
+    if gate is not None:
+        flag_wait(gate[0], gate[1], gate[3], gate[2])
     t = int(step_dev.reshape(-1)[0])
     gg = g * gscale
     if weight_decay != 0.0:

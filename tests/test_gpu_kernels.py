@@ -429,6 +429,31 @@ def test_adam_matches_torch_optim(K, dev):
     close(p, ref.detach(), rtol=1e-6, atol=1e-7)
 
 
+@pytest.mark.parametrize('n,lo,hi', [(100003, 5000, 5402), (100003, 99990, 100003), (4096, 0, 4096)])
+def test_adam_gated_sweep(K, dev, n, lo, hi):
+    """dv_adam_l2_gated: same result as the plain sweep; the gated slice is produced by ANOTHER stream that
+    publishes the flag afterwards (the optimiser launch is enqueued first and has to park)"""
+    p0, g_final = rnd(dev, n, seed=1), rnd(dev, n, seed=2)
+    step = torch.ones(1, dtype=torch.int32, device=dev)
+    want, m0, v0 = p0.clone(), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    K.adam_l2(want, g_final, m0, v0, step, lr=5e-4, weight_decay=0.05)
+    p, m, v = p0.clone(), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    g = g_final.clone()
+    g[lo:hi] = 777.0                                   # not final yet
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    err = torch.zeros(2, dtype=torch.int32, device=dev)
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    K.adam_l2(p, g, m, v, step, lr=5e-4, weight_decay=0.05, gate=(flag, step, 0, err, lo, hi))
+    with torch.cuda.stream(side):
+        torch.cuda._sleep(2000000)                     # ~1 ms: the sweep is parked on the gated slice by now
+        g[lo:hi] = g_final[lo:hi]
+        K.flag_publish(flag, step, 0)
+    torch.cuda.synchronize()
+    assert int(err[0]) == 0
+    close(p, want, rtol=0, atol=0)
+
+
 def test_adamax_matches_torch_optim(K, dev):
     n = 100003
     p0, g = rnd(dev, n, seed=1), rnd(dev, n, seed=2)
