@@ -429,6 +429,22 @@ def test_adam_matches_torch_optim(K, dev):
     close(p, ref.detach(), rtol=1e-6, atol=1e-7)
 
 
+def _other_queue_stream(K, dev):
+    """a stream on a different HARDWARE queue than the current one (HIP multiplexes its streams onto a few
+    queues; a parked kernel blocks everything behind it in its queue): probe candidates"""
+    for _ in range(16):
+        cand = torch.cuda.Stream()
+        probe = torch.zeros(4, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        K.flag_wait(probe[0:1], probe[1:2], probe[2:4], add=1, max_spins=20000)
+        with torch.cuda.stream(cand):
+            K.flag_publish(probe[0:1], probe[1:2], 1)
+        torch.cuda.synchronize()
+        if int(probe[2]) == 0:
+            return cand
+    pytest.skip('no second hardware queue')
+
+
 @pytest.mark.parametrize('n,lo,hi', [(100003, 5000, 5402), (100003, 99990, 100003), (4096, 0, 4096)])
 def test_adam_gated_sweep(K, dev, n, lo, hi):
     """dv_adam_l2_gated: same result as the plain sweep; the gated slice is produced by ANOTHER stream that
@@ -442,7 +458,7 @@ def test_adam_gated_sweep(K, dev, n, lo, hi):
     g[lo:hi] = 777.0                                   # not final yet
     flag = torch.zeros(1, dtype=torch.int32, device=dev)
     err = torch.zeros(2, dtype=torch.int32, device=dev)
-    side = torch.cuda.Stream()
+    side = _other_queue_stream(K, dev)
     torch.cuda.synchronize()
     K.adam_l2(p, g, m, v, step, lr=5e-4, weight_decay=0.05, gate=(flag, step, 0, err, lo, hi))
     with torch.cuda.stream(side):
