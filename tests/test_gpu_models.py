@@ -122,6 +122,35 @@ def test_graph_replay_equals_eager(dev):
     assert eager.losses() == graph.losses()
 
 
+@pytest.mark.parametrize('kind', ['drvae', 'vfae'])
+def test_partitioned_replay_equals_eager(kind, dev):
+    """the production launch mode of the train step -- dual graphs ordered by device flags, the split of the
+    compute units chosen by ``tune_partition`` (which must restore the training state), replays inside
+    ``partition()`` -- is bitwise the eager step, and no device-side wait ever timed out"""
+    from tests.test_engine_cpu import make_engine, set_batch
+    spec = M.ModelSpec(kind=kind, L=2)
+    params = M.init_params(spec, 3, as_numpy=True)
+    batch = M.make_batch(spec, 150, seed=5)
+    eager, a0 = make_engine(spec, params, dev)
+    graph, a1 = make_engine(spec, params, dev)
+    for e in (eager, graph):
+        set_batch(e, batch, dev)
+        e.train_step()
+    eager.draw_noise()                       # capture() spends one Philox draw on its warm-up
+    graph.capture()
+    graph.tune_partition(candidates=(48, 64), steps=4)
+    with graph.partition():
+        for _ in range(6):
+            graph.replay()
+    for _ in range(6):
+        eager.train_step()
+    torch.cuda.synchronize()
+    graph.check_sync()
+    assert graph.iters == eager.iters == 7
+    assert torch.equal(a0.param, a1.param) and torch.equal(a0.exp_avg_sq, a1.exp_avg_sq)
+    assert eager.losses() == graph.losses()
+
+
 def test_checkpoint_roundtrip_and_errors(dev, tmp_path):
     spec = C.tiny_spec('vfae', dim_y=3)
     m1, m2 = build_model(spec, dev), build_model(spec, dev)
