@@ -53,6 +53,28 @@ class DeepGenerativeModelMixin:
             self._engine = E.FusedStep(cfg, self._arena, seed=self.random_seed)
         return self._engine
 
+    # ------------------------------------------------------- model-level MMD penalty
+    def _get_mmd_criterion(self, z, sind):
+        """Minus the MMD (``blocks.mmd_objective`` with ``self.kernel_MMD``) between the latent rows of every
+        category of the nuisance variable s and the rows outside it, averaged over the categories; with two
+        categories only the first pair (src/DGMMixin.py:42-66).  ``sind``: one 0/1 indicator vector per
+        category.  A side without rows is replaced by one random N(0,1) row, like the reference.  As shipped
+        the reference function cannot run (two missing imports); with those supplied its values are the
+        golden vectors of tests/golden/mmd_criterion.npz.  The row selection is an index gather, so
+        one-member categories work too (the reference's ``len()`` of a 0-d tensor raises there)."""
+        from . import blocks as blk
+        mmd = 0.
+        for ind in sind:
+            flat = ind.reshape(-1)
+            ind0 = torch.nonzero(flat != 0).reshape(-1)
+            ind1 = torch.nonzero(flat == 0).reshape(-1)
+            z0 = z.index_select(0, ind0) if ind0.numel() else torch.empty(1, z.size(1), device=z.device).normal_()
+            z1 = z.index_select(0, ind1) if ind1.numel() else torch.empty(1, z.size(1), device=z.device).normal_()
+            mmd = mmd - blk.mmd_objective(z0, z1, kernel=self.kernel_MMD)
+            if len(sind) == 2:
+                return mmd
+        return mmd / len(sind)
+
     # --------------------------------------------------------------- small helpers
     def _use_free_bits(self, KL_perx, override_default_kl_min=None):
         """max(KL_row, kl_min) on the per-row KL (src/DGMMixin.py:68-75)."""

@@ -255,6 +255,29 @@ def mmd_objective(x1, x2, kernel='rbf', bandwidths=MMD_BANDWIDTHS, rnd_a=None, r
     return torch.sqrt(a.mean() - 2 * b.mean() + c.mean())
 
 
+def mmd_criterion(z, sind, kernel='rbf_fourier', normals=(), uniforms=()):
+    """DGMMixin.py:42-66: minus the MMD between the latent rows of every category of the nuisance variable
+    and the rows outside it, averaged over the categories (two categories: the first pair only).  A side
+    without rows is replaced by ONE random N(0,1) row.  ``normals`` / ``uniforms``: the draws in the order
+    the reference consumes them (per category: [the random row], W ~ N(0,1), b ~ U(0,1)).  The reference
+    needs two missing imports supplied to run at all (pinned by tests/golden/make_golden.py)."""
+    normals, uniforms = list(normals), list(uniforms)
+    total = 0.
+    for ind in sind:
+        i0 = torch.nonzero(ind.reshape(-1) != 0).reshape(-1)
+        i1 = torch.nonzero(ind.reshape(-1) == 0).reshape(-1)
+        z0 = z.index_select(0, i0) if i0.numel() else normals.pop(0)
+        z1 = z.index_select(0, i1) if i1.numel() else normals.pop(0)
+        if kernel == 'rbf_fourier':
+            m = mmd_objective(z0, z1, kernel, rnd_a=normals.pop(0), rnd_b=uniforms.pop(0))
+        else:
+            m = mmd_objective(z0, z1, kernel)
+        total = total - m
+        if len(sind) == 2:
+            return total
+    return total / len(sind)
+
+
 # ------------------------------------------------------------------- train-step bits
 def free_bits(kl_rows, kl_min=2.0):
     """DGMMixin.py:68-75: max(KL_row, kl_min) on the per-row KL."""

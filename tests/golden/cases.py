@@ -228,3 +228,35 @@ def model_case(name):
         batch['y'] = np.random.RandomState(seed + 2).rand(n, spec.dim_y).astype(np.float32)
     noises = [M.make_noise(spec, n, seed=seed + 100 + i) for i in range(steps)]
     return dict(name=name, spec=spec, batch=batch, noises=noises, param_seed=123, full=full)
+
+
+def mmd_criterion_cases():
+    """inputs of ``DGMMixin._get_mmd_criterion`` (src/DGMMixin.py:42-66): latent rows z, one 0/1 indicator
+    vector per category of the nuisance variable s, and the N(0,1) / U(0,1) draws in the order the reference
+    consumes them (per category: [a random row when the category or its complement is empty], W, b)."""
+    rs = np.random.RandomState(909)
+    n, z, dim_r = 12, 5, 500
+    out = OrderedDict()
+    lab2 = np.array([1, 0, 1, 1, 0, 0, 1, 1, 0, 1, 0, 1])
+    lab3 = np.array([0, 1, 2, 0, 1, 0, 2, 1, 0, 2, 1, 0])
+    lab3e = np.array([0, 1, 0, 0, 1, 0, 1, 1, 0, 0, 1, 0])       # category 2 has no rows
+
+    def draws(k, empties=()):
+        nor, uni = [], []
+        for c in range(k):
+            if c in empties:
+                nor.append(rs.standard_normal((1, z)).astype(np.float32))
+            nor.append(rs.standard_normal((z, dim_r)).astype(np.float32))
+            uni.append(rs.rand(dim_r).astype(np.float32))
+        return nor, uni
+    for tag, lab, k, kernel, empties, ndraw in (('two', lab2, 2, 'rbf_fourier', (), 1), ('three', lab3, 3, 'rbf_fourier', (), 3),
+                                                ('three_empty', lab3e, 3, 'rbf_fourier', (2,), 3),
+                                                ('three_identity', lab3, 3, 'identity', (), 0)):
+        nor, uni = draws(ndraw, tuple(e for e in empties)) if ndraw else ([], [])
+        if tag == 'two':        # (two categories: the reference returns after the first one)
+            sind = [(lab == 1).astype(np.int64), (lab == 0).astype(np.int64)]
+        else:
+            sind = [(lab == c).astype(np.int64) for c in range(k)]
+        out[tag] = dict(z=rs.standard_normal((n, z)).astype(np.float32), sind=sind, kernel=kernel, normals=nor,
+                        uniforms=uni)
+    return out

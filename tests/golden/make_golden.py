@@ -513,8 +513,41 @@ def run_inference_cases():
     return out
 
 
+def run_mmd_criterion_cases():
+    """the model-level MMD penalty of the reference, ``DGMMixin._get_mmd_criterion`` (src/DGMMixin.py:42-66),
+    called as a plain function with a duck-typed ``self`` (it only reads ``kernel_MMD``); value and d/dz"""
+    import types
+    import DGMMixin as rdgm
+    out = {}
+    # as shipped the function cannot run: src/DGMMixin.py uses ``Variable`` and ``blk`` without importing them
+    # (pinned below); with those two names supplied the body executes unchanged
+    try:
+        rdgm.DeepGenerativeModelMixin._get_mmd_criterion(types.SimpleNamespace(kernel_MMD='identity'), torch.zeros(4, 2),
+                                                         [torch.tensor([1, 0, 1, 0]), torch.tensor([0, 1, 0, 1])])
+        out['raises_as_shipped'] = np.int64(0)
+    except NameError:
+        out['raises_as_shipped'] = np.int64(1)
+    rdgm.Variable = torch.autograd.Variable
+    rdgm.blk = rblk
+    for tag, c in C.mmd_criterion_cases().items():
+        z = torch.from_numpy(c['z']).clone().requires_grad_(True)
+        sind = [torch.from_numpy(v) for v in c['sind']]
+        me = types.SimpleNamespace(kernel_MMD=c['kernel'])
+        with Replay(c['normals'], c['uniforms']):
+            val = rdgm.DeepGenerativeModelMixin._get_mmd_criterion(me, z, sind)
+        val.backward()
+        out['%s/value' % tag] = val.detach().numpy().astype(np.float64)
+        out['%s/grad_z' % tag] = z.grad.numpy().copy()
+    return out
+
+
 def main():
     os.makedirs(HERE, exist_ok=True)
+    mm = run_mmd_criterion_cases()
+    np.savez_compressed(os.path.join(HERE, 'mmd_criterion.npz'), **mm)
+    print('mmd_criterion.npz', len(mm), 'arrays', {k: float(v) for k, v in mm.items() if k.endswith('value')})
+    if '--mmd-only' in sys.argv:
+        return
     inf = run_inference_cases()
     np.savez_compressed(os.path.join(HERE, 'inference.npz'), **inf)
     print('inference.npz', len(inf), 'arrays')

@@ -1,6 +1,8 @@
 """-m gpu: the drop-in ``drvae_amd.blocks`` / ``drvae_amd.layers`` modules (HIP kernels via
 autograd wrappers) against the golden vectors produced by the reference's own blocks,
 and against the CPU oracle."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -235,3 +237,29 @@ def test_gradients_through_block_chain_vs_oracle(mods, dev):
         close(v.grad, p['e.' + k].grad.numpy(), rtol=2e-3, atol=2e-4)
     for k, v in dec.named_parameters():
         close(v.grad, p['d.' + k].grad.numpy(), rtol=2e-3, atol=2e-4)
+
+
+@pytest.mark.gpu
+def test_model_level_mmd_criterion(mods, dev):
+    """DGMMixin._get_mmd_criterion (src/DGMMixin.py:42-66) on the HIP MMD kernels: value and d/dz against the
+    reference's function (tests/golden/mmd_criterion.npz), draws replayed in the reference's order"""
+    import types
+    from drvae_amd.DGMMixin import DeepGenerativeModelMixin as Mix
+    G = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'mmd_criterion.npz'))
+    for tag, c in C.mmd_criterion_cases().items():
+        z = T(c['z'], dev).clone().requires_grad_(True)
+        sind = [torch.from_numpy(v).to(dev) for v in c['sind']]
+        me = types.SimpleNamespace(kernel_MMD=c['kernel'])
+        with Replay(c['normals'], c['uniforms']):
+            val = Mix._get_mmd_criterion(me, z, sind)
+        val.backward()
+        close(val.detach(), G['%s/value' % tag], rtol=2e-4)
+        close(z.grad, G['%s/grad_z' % tag], rtol=2e-3, atol=2e-6)
+    # a one-member category (the reference's len() of a 0-d tensor raises there): equals the direct call
+    z = T(C.mmd_criterion_cases()['three_identity']['z'], dev)
+    ind = torch.zeros(12, dtype=torch.int64, device=dev)
+    ind[3] = 1
+    blk, _ = mods
+    got = Mix._get_mmd_criterion(types.SimpleNamespace(kernel_MMD='identity'), z, [ind, 1 - ind])
+    keep = torch.arange(12, device=dev) != 3
+    close(got, (-blk.mmd_objective(z[3:4], z[keep], 'identity')).cpu().numpy(), rtol=1e-6)

@@ -1,5 +1,7 @@
 """Pin the CPU oracle (``oracle/``) against the golden vectors that
 ``tests/golden/make_golden.py`` produced by running the reference itself."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -193,3 +195,17 @@ def test_eval_x_reconstruction_metrics(G, tag):
     for k in ('rmse', 'r2', 'pearr'):
         np.testing.assert_allclose(got[k], float(G['%s/%s' % (tag, k)]), rtol=1e-9)
     np.testing.assert_allclose(got['ll'], float(G[tag + '/ll']), rtol=1e-6)
+
+
+def test_mmd_criterion_vs_reference():
+    """the model-level MMD penalty (src/DGMMixin.py:42-66): oracle restatement vs the reference's own function
+    (run with its two missing imports supplied; as shipped it raises, which is pinned too)"""
+    G = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'mmd_criterion.npz'))
+    assert int(G['raises_as_shipped']) == 1
+    for tag, c in C.mmd_criterion_cases().items():
+        z = torch.from_numpy(c['z']).clone().requires_grad_(True)
+        val = B.mmd_criterion(z, [torch.from_numpy(v) for v in c['sind']], c['kernel'],
+                              [torch.from_numpy(a) for a in c['normals']], [torch.from_numpy(a) for a in c['uniforms']])
+        val.backward()
+        close(val.detach(), G['%s/value' % tag], rtol=1e-5)
+        close(z.grad, G['%s/grad_z' % tag], rtol=1e-4, atol=1e-7)
