@@ -13,10 +13,31 @@ import torch
 import torch.distributed as dist
 
 
+def force_dp():
+    """DRVAE_FORCE_DP=1: run the data-parallel step path -- process group, split graphs, RCCL launches between
+    the graph replays -- in a single process (a one-rank communicator): a functional check of everything but
+    the peers on a one-GPU box"""
+    return os.environ.get('DRVAE_FORCE_DP') == '1'
+
+
+def _active():
+    return dist.is_initialized() and (dist.get_world_size() > 1 or force_dp())
+
+
 def init_from_env(backend=None):
     """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun).  Returns
     (rank, world_size, local_rank); a no-op (0, 1, 0) for single-process runs."""
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world <= 1 and force_dp():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        if not dist.is_initialized():
+            if torch.cuda.is_available():
+                torch.cuda.set_device(0)
+            dist.init_process_group(backend=backend or os.environ.get('DRVAE_DIST_BACKEND') or
+                                    ('nccl' if torch.cuda.is_available() else 'gloo'), rank=0, world_size=1)
+        return 0, 1, 0
     if world <= 1:
         return 0, 1, 0
     rank, local = int(os.environ['RANK']), int(os.environ.get('LOCAL_RANK', '0'))
@@ -33,7 +54,7 @@ def init_from_env(backend=None):
 
 def allreduce_sum(flat):
     """In-place sum over ranks of a flat fp32 tensor (the gradient arena)."""
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if _active():
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     return flat
 
@@ -46,7 +67,7 @@ class OverlappedAllReduce:
     step) travels while the encoder backward still runs."""
 
     def start(self, flat):
-        if dist.is_initialized() and dist.get_world_size() > 1:
+        if _active():
             return dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
         return None
 
@@ -80,5 +101,5 @@ def shard_rows(n_rows, rank, world):
 
 def broadcast_params(arena):
     """make every rank start from rank 0's parameters"""
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if _active():
         dist.broadcast(arena.param, src=0)
