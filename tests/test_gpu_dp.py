@@ -74,3 +74,31 @@ def test_two_rank_overlapped_exchange_matches_eager(dev):
     for o in out:
         assert o[1] != 'error', o[2]
         assert o[1] and o[2] and o[3], o
+
+
+def test_step_path_over_rccl_single_rank():
+    """the data-parallel step path over the REAL transport: a one-rank RCCL communicator in a child process
+    (process group, split graphs, collective launches and their stream events between the graph replays, CU
+    partition) -- single exchange and two overlapped pieces -- trains to exactly the losses of the plain
+    single-GPU step"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, 'bench.py'), '--steps', '12', '--warmup', '3', '--no-cpu-baseline',
+           '--no-roofline']
+
+    def run(**env):
+        e = dict(os.environ, DRVAE_SIDE_CUS='64', **env)
+        e.pop('RANK', None)
+        e.pop('WORLD_SIZE', None)
+        out = subprocess.run(cmd, env=e, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        line = [ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1]
+        return json.loads(line)
+    plain = run()
+    single = run(DRVAE_FORCE_DP='1', MASTER_PORT='29561')
+    pieces = run(DRVAE_FORCE_DP='1', DRVAE_DP_OVERLAP='1', MASTER_PORT='29562')
+    assert plain['finite'] and single['finite'] and pieces['finite']
+    assert single['losses_last_step'] == plain['losses_last_step'] == pieces['losses_last_step']
+    assert all(v == 0 for v in single['chain_wait_ticks'][0::2] + pieces['chain_wait_ticks'][0::2])
