@@ -62,15 +62,20 @@ class _Chain:
             x = [self.out[li]]
         return self.out[-1]
 
-    def backward(self, dpre_last, inputs, dinputs=None, wbranch=None):
+    def backward(self, dpre_last, inputs, dinputs=None, wbranch=None, publish_after_last=None):
         """dpre_last: gradient w.r.t. the last layer's pre-activation.  ``dinputs``: per input
         source a list of (dst, alpha, beta) destinations for its gradient (or None to skip).
         ``wbranch``: optional side stream for the weight-gradient GEMMs (they are leaves: only
-        Adam reads them), so that they overlap the dx chain."""
+        Adam reads them), so that they overlap the dx chain.  ``publish_after_last`` = (flag, counter, add):
+        the first launch AFTER the last layer's launches publishes the flag on entry (= both gradients of the
+        last layer are final and its weights are no longer read)."""
         dpre = dpre_last
+        pending_pub = None
         for li in range(len(self.layers) - 1, -1, -1):
             l = self.layers[li]
             srcs = list(inputs) if li == 0 else [self.out[li - 1]]
+            if li == len(self.layers) - 2:
+                pending_pub = publish_after_last
 
             def wgrad(l=l, srcs=srcs, dpre=dpre):
                 dW = l.raw if l.g is not None else l.dW
@@ -90,12 +95,17 @@ class _Chain:
                 if li > 0:
                     prev = self.layers[li - 1]
                     K.linear_bwd_pair(l.dW, l.db, self.dpre[li - 1], dpre, srcs[0], l.W, yref=self.out[li - 1],
-                                      act=prev.act0, shift=prev.shift0, overread=True)
+                                      act=prev.act0, shift=prev.shift0, overread=True, publish=pending_pub)
                     dpre = self.dpre[li - 1]
                 else:
                     dst, alpha, beta = dinputs[0][0]
-                    K.linear_bwd_pair(l.dW, l.db, dst, dpre, srcs[0], l.W, alpha=alpha, beta_x=beta, overread=True)
+                    K.linear_bwd_pair(l.dW, l.db, dst, dpre, srcs[0], l.W, alpha=alpha, beta_x=beta, overread=True,
+                                      publish=pending_pub)
+                pending_pub = None
                 continue
+            if pending_pub is not None:      # (no paired launch for this layer: a launch of its own)
+                K.flag_publish(*pending_pub)
+                pending_pub = None
             if wbranch is not None:
                 with wbranch:
                     wgrad()

@@ -178,14 +178,17 @@ class FusedStep(StepSchedule):
         self.sched = int(os.environ.get('DRVAE_SCHED', '5'))
         self._rec = 'both'
         self.late_leaf = os.environ.get('DRVAE_LATE_LEAF', '1') != '0'
+        self.side_adam = os.environ.get('DRVAE_SIDE_ADAM', '1') != '0'
+        self._adam_n = None
         self._split_capture = False
         self._adam_gate = None
         self._side_graph = None
         self._flag_side = None
         self._after_decoder_bwd = None
         self.side_ctr = torch.zeros(1, dtype=torch.int32, device=self.dev)   # the side chain's own step count
-        self.flags = torch.zeros(4, dtype=torch.int32, device=self.dev)
-        self.sync_err = torch.zeros(8, dtype=torch.int32, device=self.dev)   # (error, ticks parked) x 4 wait sites
+        self.side_t = torch.ones(1, dtype=torch.int32, device=self.dev)      # ... + 1: the optimiser step it works on
+        self.flags = torch.zeros(5, dtype=torch.int32, device=self.dev)
+        self.sync_err = torch.zeros(10, dtype=torch.int32, device=self.dev)  # (error, ticks parked) x 5 wait sites
         self.add_noise = True               # `fit(add_noise=...)` flag of the reference (src/DrVAE.py:769)
         # classifier/fprop chain || decoder chain.  PVAE's side chain is one tiny KL kernel: a second stream
         # costs it far more than it hides (measured 0.19 ms single-stream vs 0.9 ms forked), so it runs serial
@@ -502,6 +505,16 @@ class FusedStep(StepSchedule):
         late = (mode == 5 and self.late_leaf and cfg.has_y and not cfg.cont and self.clf_small
                 and cfg.optim_alg == 'adam' and not self._split_capture)
         leaf = []
+        # ... and HALF of the optimiser sweep moves there too: the decoder heads (the tail of the arena, half of
+        # all parameters) are final and no longer read once the heads' backward products are through -- the
+        # launch after them publishes that -- so the side chain updates them next to the main chain's tail
+        heads = self.L_decx[-1]
+        g0 = self.arena.grad.storage_offset()
+        hs = min(heads.dW.storage_offset(), heads.db.storage_offset()) - g0
+        side_adam = (late and self.side_adam and len(self.L_decx) > 1 and heads.g is None and not self.wbranch.on
+                     and hs % 4 == 0 and self.arena.n_live == self.arena.n_params
+                     and max(heads.dW.storage_offset() + heads.dW.numel(),
+                             heads.db.storage_offset() + heads.db.numel()) - g0 >= self.arena.n_live - 3)
 
         def wgrad_clf(*args):
             if late:
@@ -590,14 +603,20 @@ class FusedStep(StepSchedule):
             if late:
                 for fn in leaf:
                     fn()
-                K.flag_publish(self.flags[3:4], self.side_ctr)   # ... and now the classifier's dW / db
-            K.counter_add(self.side_ctr, 1)
+                if side_adam:
+                    a = self.arena
+                    K.flag_wait(self.flags[4:5], self.side_ctr, self.sync_err[8:10])
+                    K.adam_l2(a.param[hs:a.n_live], a.grad[hs:a.n_live], a.exp_avg[hs:a.n_live], a.exp_avg_sq[hs:a.n_live],
+                              self.side_t, lr=cfg.learning_rate, weight_decay=cfg.weight_decay)
+                K.flag_publish(self.flags[3:4], self.side_ctr)   # ... and now the side chain's late work is final
+            K.counters_add2(self.side_ctr, 1, self.side_t, 1)
             return
         if mode < 2:
             self.branch.fork()
         elif mode == 3:
             self.branch._forked = True       # one fork/join per step: the side chain simply continues
-        p.c_decx.backward(p.DPX, [p.ZDEC], [[(p.DZDEC, 1.0, 0.0)]], wbranch=self.wbranch if self.wbranch.on else None)
+        p.c_decx.backward(p.DPX, [p.ZDEC], [[(p.DZDEC, 1.0, 0.0)]], wbranch=self.wbranch if self.wbranch.on else None,
+                          publish_after_last=(self.flags[4:5], self.step_dev, 1) if side_adam else None)
         if self._after_decoder_bwd is not None:
             self._after_decoder_bwd()        # decoder_x gradients are final: graph split point of the overlapped exchange
         if mode != 5:
@@ -611,6 +630,7 @@ class FusedStep(StepSchedule):
                 lo = min(lc.dW.storage_offset(), lc.db.storage_offset()) - g0
                 hi = max(lc.dW.storage_offset() + lc.dW.numel(), lc.db.storage_offset() + lc.db.numel()) - g0
                 self._adam_gate = (self.flags[3:4], self.step_dev, 0, self.sync_err[6:8], lo, hi)
+                self._adam_n = hs if side_adam else None
         elif mode == 3:
             self._loss_scalars()
         if cfg.has_pert:
@@ -650,9 +670,11 @@ class FusedStep(StepSchedule):
         else:
             K.counter_add(self.step_dev, 1)
         if self._rec == 'both' and self.sched == 5:
-            K.counter_add(self.side_ctr, 1)      # eager step: the side chain's counter follows
+            K.counters_add2(self.side_ctr, 1, self.side_t, 1)      # eager step: the side chain's counters follow
         step = K.adamax_l2 if cfg.optim_alg == 'adamax' else K.adam_l2    # exp_avg_sq doubles as Adamax's exp_inf
         n = a.n_live                      # parameters without gradients sit behind it (untouched, like torch)
+        if self._adam_n is not None:      # dual-graph step: the side chain sweeps the rest (the decoder heads)
+            n, self._adam_n = self._adam_n, None
         kw = {}
         if self._adam_gate is not None:   # dual-graph step: the classifier's dW may still be in flight on the side chain
             kw['gate'], self._adam_gate = self._adam_gate, None

@@ -93,10 +93,10 @@ def gemm(Cm, A, B, a_kc, b_kc, **kw):
 
 
 def linear_bwd_pair(dW, dbias, dx, dpre, x, W, *, kscale=None, alpha=1.0, beta_x=0.0, yref=None, act=0, shift=0.0,
-                    overread=False):
+                    overread=False, publish=None):
     """dW = dpre^T x (+ dbias) and dx = beta_x*dx + alpha*(dpre W) * act'(yref) in ONE launch when both fit
     the fused form of ``dv_gemm_pair`` (otherwise two launches)."""
-    d1 = _gemm_desc(dW, dpre, x, False, False, a_colsum=dbias, overread=overread)
+    d1 = _gemm_desc(dW, dpre, x, False, False, a_colsum=dbias, overread=overread, publish=publish)
     if yref is None:
         d2 = _gemm_desc(dx, dpre, W, True, False, a_kscale=kscale, alpha=alpha, beta=beta_x, overread=overread)
     else:

@@ -123,6 +123,7 @@ class StepSchedule:
             if dual:
                 self._rec = 'side'
                 self.side_ctr.copy_(self.step_dev)
+                self.side_t.copy_(self.step_dev + 1)
                 self.flag_side.wait_stream(torch.cuda.current_stream())
                 gs = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(gs, stream=self.flag_side):
@@ -216,7 +217,7 @@ class StepSchedule:
                 'DRVAE_SIDE_CUS' in os.environ:       # (multi-rank: split graphs need the exchange; keep the default)
             return None
         a = self.arena
-        keep = [t.clone() for t in (a.param, a.exp_avg, a.exp_avg_sq, self.step_dev, self.side_ctr, self.rng_ctr,
+        keep = [t.clone() for t in (a.param, a.exp_avg, a.exp_avg_sq, self.step_dev, self.side_ctr, self.side_t, self.rng_ctr,
                                     self.flags)]
         iters = self.iters
         best = (None, float('inf'))
@@ -236,7 +237,7 @@ class StepSchedule:
             if t < best[1]:
                 best = (n, t)
         torch.cuda.synchronize()
-        for dst, src in zip((a.param, a.exp_avg, a.exp_avg_sq, self.step_dev, self.side_ctr, self.rng_ctr,
+        for dst, src in zip((a.param, a.exp_avg, a.exp_avg_sq, self.step_dev, self.side_ctr, self.side_t, self.rng_ctr,
                              self.flags), keep):
             dst.copy_(src)
         self.iters = iters

@@ -134,7 +134,9 @@ def linear_bwd_weight(dW, dpre, x, *, beta=0.0, dbias=None, overread=False):
 
 
 def linear_bwd_pair(dW, dbias, dx, dpre, x, W, *, kscale=None, alpha=1.0, beta_x=0.0, yref=None, act=0, shift=0.0,
-                    overread=False):
+                    overread=False, publish=None):
+    if publish is not None:
+        flag_publish(publish[0], publish[1], publish[2])
     linear_bwd_weight(dW, dpre, x, dbias=dbias)
     linear_bwd_data(dx, dpre, W, kscale=kscale, alpha=alpha, beta=beta_x, yref=yref, act=act, shift=shift)
 
