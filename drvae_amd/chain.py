@@ -62,19 +62,20 @@ class _Chain:
             x = [self.out[li]]
         return self.out[-1]
 
-    def backward(self, dpre_last, inputs, dinputs=None, wbranch=None, publish_after_last=None):
+    def backward(self, dpre_last, inputs, dinputs=None, wbranch=None, publish_after_last=None, publish_first=None):
         """dpre_last: gradient w.r.t. the last layer's pre-activation.  ``dinputs``: per input
         source a list of (dst, alpha, beta) destinations for its gradient (or None to skip).
         ``wbranch``: optional side stream for the weight-gradient GEMMs (they are leaves: only
         Adam reads them), so that they overlap the dx chain.  ``publish_after_last`` = (flag, counter, add):
         the first launch AFTER the last layer's launches publishes the flag on entry (= both gradients of the
-        last layer are final and its weights are no longer read)."""
+        last layer are final and its weights are no longer read); ``publish_first``: the chain's FIRST launch
+        does (= everything in front of this backward pass is complete)."""
         dpre = dpre_last
-        pending_pub = None
+        pending_pub = publish_first
         for li in range(len(self.layers) - 1, -1, -1):
             l = self.layers[li]
             srcs = list(inputs) if li == 0 else [self.out[li - 1]]
-            if li == len(self.layers) - 2:
+            if li == len(self.layers) - 2 and publish_after_last is not None:
                 pending_pub = publish_after_last
 
             def wgrad(l=l, srcs=srcs, dpre=dpre):

@@ -179,6 +179,8 @@ class FusedStep(StepSchedule):
         self._rec = 'both'
         self.late_leaf = os.environ.get('DRVAE_LATE_LEAF', '1') != '0'
         self.side_adam = os.environ.get('DRVAE_SIDE_ADAM', '1') != '0'
+        self.noise_ahead = False          # set by capture(): the side chain draws the NEXT step's noise behind the join
+        self._noise_stale = True          # (then) the noise buffer does not hold the draws of the current Philox counter
         self._adam_n = None
         self._split_capture = False
         self._adam_gate = None
@@ -187,8 +189,8 @@ class FusedStep(StepSchedule):
         self._after_decoder_bwd = None
         self.side_ctr = torch.zeros(1, dtype=torch.int32, device=self.dev)   # the side chain's own step count
         self.side_t = torch.ones(1, dtype=torch.int32, device=self.dev)      # ... + 1: the optimiser step it works on
-        self.flags = torch.zeros(5, dtype=torch.int32, device=self.dev)
-        self.sync_err = torch.zeros(10, dtype=torch.int32, device=self.dev)  # (error, ticks parked) x 5 wait sites
+        self.flags = torch.zeros(6, dtype=torch.int32, device=self.dev)
+        self.sync_err = torch.zeros(12, dtype=torch.int32, device=self.dev)  # (error, ticks parked) x 6 wait sites
         self.add_noise = True               # `fit(add_noise=...)` flag of the reference (src/DrVAE.py:769)
         # classifier/fprop chain || decoder chain.  PVAE's side chain is one tiny KL kernel: a second stream
         # costs it far more than it hides (measured 0.19 ms single-stream vs 0.9 ms forked), so it runs serial
@@ -292,6 +294,7 @@ class FusedStep(StepSchedule):
         """Inject explicit N(0,1) draws addressed by global row (``oracle.models_ref.make_noise``
         layout: nx1/nx2 (B,X); ez1/ez2/ez2F (L,B,Z1); ez3 (L,Y,B,Z3))."""
         p, cfg = self.plan, self.cfg
+        self._noise_stale = True
         t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32)
         rows, L = p.rows, cfg.L
         p.EX[:p.B].copy_(t(np.asarray(noise['nx1'])[rows]))
@@ -312,8 +315,12 @@ class FusedStep(StepSchedule):
         """Fresh on-device N(0,1) for every draw of the step (Philox, one launch).  ``bump=False``: the
         Philox counter is advanced later, together with the step counter, by ``optimizer_step`` (one
         launch less on the train step's critical path)."""
-        K.fill_normal(self.plan.noise, self.seed, self.rng_ctr)
         n = (self.plan.noise.numel() + 3) // 4
+        if self._rec == 'main' and self.noise_ahead:
+            self._rng_pending = n         # dual-graph step: the side chain of the PREVIOUS step has drawn them
+            return
+        K.fill_normal(self.plan.noise, self.seed, self.rng_ctr)
+        self._noise_stale = True          # (an eager draw: a later replay must draw for its own counter first)
         if bump:
             K.counter_add(self.rng_ctr, n)
         else:
@@ -608,6 +615,11 @@ class FusedStep(StepSchedule):
                     K.flag_wait(self.flags[4:5], self.side_ctr, self.sync_err[8:10])
                     K.adam_l2(a.param[hs:a.n_live], a.grad[hs:a.n_live], a.exp_avg[hs:a.n_live], a.exp_avg_sq[hs:a.n_live],
                               self.side_t, lr=cfg.learning_rate, weight_decay=cfg.weight_decay)
+                if self.noise_ahead:
+                    # the next step's N(0,1) draws: every reader of this step's is through once the encoder
+                    # backward has started (the main chain publishes that), and the Philox counter has advanced
+                    K.flag_wait(self.flags[5:6], self.side_ctr, self.sync_err[10:12])
+                    K.fill_normal(p.noise, self.seed, self.rng_ctr)
                 K.flag_publish(self.flags[3:4], self.side_ctr)   # ... and now the side chain's late work is final
             K.counters_add2(self.side_ctr, 1, self.side_t, 1)
             return
@@ -656,7 +668,8 @@ class FusedStep(StepSchedule):
         if cfg.kind == 'pvae':
             K.kl_rows_bwd(DQ[:, :Z1], DQ[:, Z1:], None, None, p.c_klp, p.KLPraw, Qmu, Qlv, prior=(0.0, 0.0),
                           free_bits=True, kl_min=cfg.kl_min, beta=1.0)
-        p.c_enc.backward(DQ, [p.XIN], None)
+        p.c_enc.backward(DQ, [p.XIN], None,
+                         publish_first=(self.flags[5:6], self.step_dev, 0) if (late and self.noise_ahead) else None)
 
     # -------------------------------------------------------------------- optimiser
     def optimizer_step(self, gscale=1.0):

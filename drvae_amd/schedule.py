@@ -116,6 +116,10 @@ class StepSchedule:
         self._side_graph = None
         dual = self.sched == 5 and self.branch.on and self.cfg.has_y and self._flags_usable()
         self._split_capture = bool(split_for_allreduce)
+        cfg = self.cfg
+        self.noise_ahead = bool(dual and not split_for_allreduce and self.late_leaf and not cfg.cont and self.clf_small
+                                and cfg.optim_alg == 'adam' and os.environ.get('DRVAE_NOISE_AHEAD', '1') != '0')
+        self._noise_stale = True
         if dual:
             self._rec = 'main'
         try:
@@ -241,6 +245,7 @@ class StepSchedule:
                              self.flags), keep):
             dst.copy_(src)
         self.iters = iters
+        self._noise_stale = True
         self.plan.set_beta(self.beta_pert())
         torch.cuda.synchronize()
         self._side_cus = best[0]
@@ -340,6 +345,9 @@ class StepSchedule:
         assert self._graph_key == self.plan.key, 'batch structure changed: capture again'
         assert self._graph_feed is self.plan.feed, 'input feed changed: capture again'
         self.plan.set_beta(self.beta_pert())      # 0.01 on iteration 0, 1.0 afterwards (device-side coefficients)
+        if self.noise_ahead and self._noise_stale:        # first replay (or an eager draw since): this step's noise
+            K.fill_normal(self.plan.noise, self.seed, self.rng_ctr)
+            self._noise_stale = False
         if self._side_graph is not None:         # first: its wait kernel is parked before the main chain publishes
             with torch.cuda.stream(self.flag_side):
                 self._side_graph.replay()
