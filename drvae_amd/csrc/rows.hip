@@ -1113,11 +1113,13 @@ __global__ __launch_bounds__(256) void loss_assemble_kernel(LossTerms lt, const 
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        acc[5] = w_elbo[0] * acc[0] + w_elbo[1] * acc[1] + w_elbo[2] * acc[2];
-        float c = 0.f;
-        for (int i = 0; i < 8; ++i) c += w_cmpl[i] * acc[i];
-        acc[6] = c;
-        for (int i = 0; i < 8; ++i) loss[i] = acc[i];
+        if (!(flag != nullptr && lt.n == 0)) {     // (parked variant without terms: only the wait and the counters)
+            acc[5] = w_elbo[0] * acc[0] + w_elbo[1] * acc[1] + w_elbo[2] * acc[2];
+            float c = 0.f;
+            for (int i = 0; i < 8; ++i) c += w_cmpl[i] * acc[i];
+            acc[6] = c;
+            for (int i = 0; i < 8; ++i) loss[i] = acc[i];
+        }
         // end of the step's use of the device counters on this chain: advance them here (saves the
         // separate counter launch in front of the optimiser)
         for (int t = 0; t < 2; ++t) {

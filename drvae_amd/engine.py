@@ -475,8 +475,10 @@ class FusedStep(StepSchedule):
             return             # the loss scalars are assembled on the side chain of backward()
         self._loss_scalars()
 
-    def _loss_scalars(self, after=None):
-        """RECL, KLD, PERT, YL, ELBO, CMPL (src/DrVAE.py:611-624) as device scalars."""
+    def _loss_scalars(self, after=None, terms_elsewhere=False):
+        """RECL, KLD, PERT, YL, ELBO, CMPL (src/DrVAE.py:611-624) as device scalars.  ``terms_elsewhere``
+        (with ``after``): this launch only parks on the flag and advances the counters; the caller has another
+        chain assemble the scalars (they are a leaf of the step: only the host reads them)."""
         cfg, p = self.cfg, self.plan
         L = cfg.L
         terms = [(p.NLL[:p.o3], None, 1.0 / (L * p.n_tot), 0)]
@@ -493,7 +495,7 @@ class FusedStep(StepSchedule):
             bump = [(self.step_dev, 1)] + ([(self.rng_ctr, self._rng_pending)] if getattr(self, '_rng_pending', 0) else [])
             self._rng_pending = 0
             self._ctr_bumped = True
-        K.loss_assemble(self.arena.loss, terms, p.w_elbo, p.w_cmpl, after=after, bump=bump)
+        K.loss_assemble(self.arena.loss, [] if terms_elsewhere else terms, p.w_elbo, p.w_cmpl, after=after, bump=bump)
 
     # --------------------------------------------------------------------- backward
     def backward(self):
@@ -615,6 +617,7 @@ class FusedStep(StepSchedule):
                     K.flag_wait(self.flags[4:5], self.side_ctr, self.sync_err[8:10])
                     K.adam_l2(a.param[hs:a.n_live], a.grad[hs:a.n_live], a.exp_avg[hs:a.n_live], a.exp_avg_sq[hs:a.n_live],
                               self.side_t, lr=cfg.learning_rate, weight_decay=cfg.weight_decay)
+                    self._loss_scalars()   # a leaf too; the wait above also covers the main chain's NLL rows
                 if self.noise_ahead:
                     # the next step's N(0,1) draws: every reader of this step's is through once the encoder
                     # backward has started (the main chain publishes that), and the Philox counter has advanced
@@ -636,7 +639,8 @@ class FusedStep(StepSchedule):
                 side_backward()
             self.branch.join()
         if mode == 5:      # the launch that assembles the loss scalars also parks on the side chain's flag
-            self._loss_scalars(after=(self.flags[1:2], self.step_dev, self.sync_err[0:2], 1, K.WAIT_SPINS))
+            self._loss_scalars(after=(self.flags[1:2], self.step_dev, self.sync_err[0:2], 1, K.WAIT_SPINS),
+                               terms_elsewhere=side_adam)
             if late:       # (that launch has advanced the step counter: the flag carries counter + 0 by now)
                 lc, g0 = self.L_clf[0], self.arena.grad.storage_offset()
                 lo = min(lc.dW.storage_offset(), lc.db.storage_offset()) - g0

@@ -568,6 +568,8 @@ def loss_assemble(loss, terms, w_elbo, w_cmpl, after=None, bump=()):
     for (c, inc) in bump:
         if c is not None:
             counter_add(c, inc)
+    if after is not None and not terms:
+        return
     acc = torch.zeros(8, device=loss.device)
     for (x, w, scale, out) in terms:
         v = x.reshape(-1)
