@@ -93,6 +93,8 @@ SIGNATURES = {
     'dv_flag_publish': [_p, _p, _i32, _p],
     'dv_flag_wait': [_p, _p, _i32, _p, _i32, _p],
     'dv_counter_add': [_p, _i32, _i64, _p],
+    'dv_arm_park': [_p, _p, _i32, _p, _i32],
+    'dv_arm_bump': [_p, _i32, _i64, _p, _i32, _i64],
     'dv_counters_add2': [_p, _i32, _i64, _p, _i32, _i64, _p],
     'dv_fill_normal': [_p, _i64, _u64, _p, _p],
 }

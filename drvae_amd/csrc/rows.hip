@@ -138,12 +138,65 @@ __global__ void reparam_bwd_kernel(const float* __restrict__ dz, int64_t ldz, co
 // draws per row, e.g. L z1-samples + L z2-samples of a paired row) plus, optionally, row-aligned
 // (dmu | dsd) contributions listed in a second CSR (the KL(q(z1|x)||p(z1|z3,y)) gradients of its
 // fprop rows).  One launch replaces reparam_bwd x2 + a segment sum; deterministic.
+// ---- joins folded into consumers (see dv_arm_park / dv_arm_bump): a launch may first park every workgroup
+// on another chain's flag (thread 0 polls, bounded), and may end by advancing device counters
+struct ParkArgs {
+    int32_t* flag;
+    const int32_t* ctr;
+    int add;
+    int32_t* err;
+    int max_spins;
+};
+
+struct CounterBump {
+    int32_t* c[2];
+    int n[2];
+    int64_t inc[2];
+};
+
+__device__ __forceinline__ void park_block(const ParkArgs& pk) {
+    if (pk.flag == nullptr) return;
+    if (threadIdx.x == 0) {
+        const int want = pk.ctr[0] + pk.add;
+        const long long t0 = wall_clock64();
+        int n = 0;
+        while (__hip_atomic_load(pk.flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - want < 0) {
+            __builtin_amdgcn_s_sleep(4);
+            if (++n > pk.max_spins) {
+                atomicExch(pk.err, 1);
+                break;
+            }
+        }
+        if (blockIdx.x == 0) pk.err[1] += (int32_t)(wall_clock64() - t0);
+    }
+    __syncthreads();
+    (void)__hip_atomic_load(pk.flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);   // every wave acquires
+}
+
+__device__ __forceinline__ void bump_counters(const CounterBump& bump) {
+    for (int t = 0; t < 2; ++t) {
+        int32_t* c = bump.c[t];
+        if (c == nullptr) continue;
+        if (bump.n[t] == 1) {
+            c[0] = (int32_t)(c[0] + bump.inc[t]);
+        } else {
+            uint64_t v = ((uint64_t)(uint32_t)c[1] << 32) | (uint32_t)c[0];
+            v += (uint64_t)bump.inc[t];
+            c[0] = (int32_t)(uint32_t)v;
+            c[1] = (int32_t)(uint32_t)(v >> 32);
+        }
+    }
+}
+
 __global__ void reparam_bwd_seg_kernel(const float* __restrict__ dz, int64_t ldz, const float* __restrict__ eps,
                                        int64_t lde, const float* __restrict__ sd, int64_t ldq,
                                        const int32_t* __restrict__ seg_ptr, const int32_t* __restrict__ seg_rows,
                                        int nq, int Z, int mode, const float* __restrict__ extra, int64_t ldx,
                                        const int32_t* __restrict__ ex_ptr, const int32_t* __restrict__ ex_rows,
-                                       float* __restrict__ dmu, float* __restrict__ dsd, int64_t lddq, float beta) {
+                                       float* __restrict__ dmu, float* __restrict__ dsd, int64_t lddq, float beta,
+                                       CounterBump bump) {
+    // (the counters are not read by this kernel: whoever starts first may advance them)
+    if (blockIdx.x == 0 && threadIdx.x == 0) bump_counters(bump);
     const int64_t total = (int64_t)nq * Z;
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         const int i = (int)(e / Z), d = (int)(e % Z);
@@ -190,7 +243,8 @@ struct Z2FArgs {
     int L, B, Np, Z;
 };
 
-__global__ void z2f_post_bwd_kernel(Z2FArgs a) {
+__global__ void z2f_post_bwd_kernel(Z2FArgs a, ParkArgs park) {
+    park_block(park);
     const int64_t total = (int64_t)a.B * a.Z;
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         const int i = (int)(e / a.Z), d = (int)(e % a.Z);
@@ -968,7 +1022,8 @@ __global__ void rows_segment_sum_kernel(const float* __restrict__ src, int64_t l
                                         const int32_t* __restrict__ seg_ptr, const int32_t* __restrict__ seg_rows,
                                         const float* __restrict__ w, int n, int W,
                                         const int32_t* __restrict__ dst_idx, float* __restrict__ dst, int64_t ldd,
-                                        float beta) {
+                                        float beta, ParkArgs park) {
+    park_block(park);
     const int64_t total = (int64_t)n * W;
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         const int i = (int)(e / W), d = (int)(e % W);
@@ -1068,12 +1123,6 @@ struct LossTerms {
     int n;
 };
 
-struct CounterBump {
-    int32_t* c[2];
-    int n[2];
-    int64_t inc[2];
-};
-
 // all loss scalars of a step in ONE single-workgroup launch: loss[out] += scale * sum_i w[i]*x[i]
 // per term, then ELBO = <w_elbo, loss[0:3]>, CMPL = <w_cmpl, loss[0:8]>  (src/DrVAE.py:611-624)
 __global__ __launch_bounds__(256) void loss_assemble_kernel(LossTerms lt, const float* __restrict__ w_elbo,
@@ -1122,18 +1171,7 @@ __global__ __launch_bounds__(256) void loss_assemble_kernel(LossTerms lt, const 
         }
         // end of the step's use of the device counters on this chain: advance them here (saves the
         // separate counter launch in front of the optimiser)
-        for (int t = 0; t < 2; ++t) {
-            int32_t* c = bump.c[t];
-            if (c == nullptr) continue;
-            if (bump.n[t] == 1) {
-                c[0] = (int32_t)(c[0] + bump.inc[t]);
-            } else {
-                uint64_t v = ((uint64_t)(uint32_t)c[1] << 32) | (uint32_t)c[0];
-                v += (uint64_t)bump.inc[t];
-                c[0] = (int32_t)(uint32_t)v;
-                c[1] = (int32_t)(uint32_t)(v >> 32);
-            }
-        }
+        bump_counters(bump);
     }
 }
 
@@ -1147,6 +1185,28 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 }  // namespace
 
 #define ST(s) static_cast<hipStream_t>(s)
+
+// armed by dv_arm_park / dv_arm_bump for the calling thread's NEXT supporting launch
+static thread_local ParkArgs g_park{};
+static thread_local CounterBump g_bump{};
+
+extern "C" int dv_arm_park(int32_t* flag, const int32_t* ctr, int32_t add, int32_t* err, int32_t max_spins) {
+    DV_REQUIRE(flag && ctr && err && max_spins > 0);
+    g_park = ParkArgs{flag, ctr, add, err, max_spins};
+    return DV_OK;
+}
+
+extern "C" int dv_arm_bump(int32_t* c1, int32_t n1, int64_t inc1, int32_t* c2, int32_t n2, int64_t inc2) {
+    DV_REQUIRE((!c1 || n1 == 1 || n1 == 2) && (!c2 || n2 == 1 || n2 == 2));
+    g_bump = CounterBump{{c1, c2}, {n1, n2}, {inc1, inc2}};
+    return DV_OK;
+}
+
+static ParkArgs take_park() {
+    const ParkArgs p = g_park;
+    g_park = ParkArgs{};
+    return p;
+}
 
 extern "C" int dv_colsum(const float* X, int64_t ldx, int32_t M, int32_t N, float* out, float beta,
                          dv_stream_t stream) {
@@ -1218,13 +1278,16 @@ extern "C" int dv_reparam_bwd_seg(const float* dz, int64_t ldz, const float* eps
                                   int32_t Z, int32_t mode, const float* extra, int64_t ldx, const int32_t* ex_ptr,
                                   const int32_t* ex_rows, float* dmu, float* dsd, int64_t lddq, float beta,
                                   dv_stream_t stream) {
+    const CounterBump bump = g_bump;
+    g_bump = CounterBump{};
     DV_REQUIRE(nq >= 0 && Z >= 0);
+    DV_REQUIRE(!(bump.c[0] || bump.c[1]) || (nq > 0 && Z > 0));      // an armed bump needs a launch to ride on
     if (nq == 0 || Z == 0) return DV_OK;
     DV_REQUIRE(dz && eps && sd && seg_ptr && seg_rows && dmu && dsd);
     DV_REQUIRE(extra == nullptr || (ex_ptr && ex_rows));
     hipLaunchKernelGGL(reparam_bwd_seg_kernel, dim3(grid_for((int64_t)nq * Z, 256)), dim3(256), 0, ST(stream), dz,
                        ldz, eps, lde, sd, ldq, seg_ptr, seg_rows, nq, Z, mode, extra, ldx, ex_ptr, ex_rows, dmu, dsd,
-                       lddq, beta);
+                       lddq, beta, bump);
     DV_RETURN_LAUNCH();
 }
 
@@ -1234,13 +1297,15 @@ extern "C" int dv_z2f_post_bwd(const float* dz2f, int64_t ld_dz2f, const float* 
                                const float* dz1b, int64_t ld_dz1b, float* dp2, int64_t ld_dp2, float* dz1,
                                int64_t ld_dz1, float* dq2, int64_t ld_dq2, int32_t L, int32_t B, int32_t Np, int32_t Z,
                                dv_stream_t stream) {
+    const ParkArgs park = take_park();
     DV_REQUIRE(L >= 0 && B >= 0 && Np >= 0 && Z >= 0);
+    DV_REQUIRE(park.flag == nullptr || (L > 0 && B > 0 && Z > 0));
     if (L == 0 || B == 0 || Z == 0) return DV_OK;
     DV_REQUIRE(dz2f && eps && p2 && dp2 && dz1);
     DV_REQUIRE(Np == 0 || (pair_slot && q2 && coef && raw));
     Z2FArgs a{dz2f, ld_dz2f, dzdec_pert, ld_pert, Np ? pair_slot : nullptr, eps, lde, p2, ldp2, q2, ldq2, coef, raw,
               kl_min, dz1b, ld_dz1b, dp2, ld_dp2, dz1, ld_dz1, dq2, ld_dq2, L, B, Np, Z};
-    hipLaunchKernelGGL(z2f_post_bwd_kernel, dim3(grid_for((int64_t)B * Z, 256)), dim3(256), 0, ST(stream), a);
+    hipLaunchKernelGGL(z2f_post_bwd_kernel, dim3(grid_for((int64_t)B * Z, 256)), dim3(256), 0, ST(stream), a, park);
     DV_RETURN_LAUNCH();
 }
 
@@ -1549,11 +1614,13 @@ extern "C" int dv_batch_feed(const float* x1, int64_t ld1, const float* x2, int6
 extern "C" int dv_rows_segment_sum(const float* src, int64_t lds, const int32_t* seg_ptr, const int32_t* seg_rows,
                                    const float* w, int32_t n, int32_t W, const int32_t* dst_idx, float* dst,
                                    int64_t ldd, float beta, dv_stream_t stream) {
+    const ParkArgs park = take_park();
     DV_REQUIRE(n >= 0 && W >= 0);
+    DV_REQUIRE(park.flag == nullptr || (n > 0 && W > 0));
     if (n == 0 || W == 0) return DV_OK;
     DV_REQUIRE(src && dst);
     hipLaunchKernelGGL(rows_segment_sum_kernel, dim3(grid_for((int64_t)n * W, 256)), dim3(256), 0, ST(stream), src,
-                       lds, seg_ptr, seg_rows, w, n, W, dst_idx, dst, ldd, beta);
+                       lds, seg_ptr, seg_rows, w, n, W, dst_idx, dst, ldd, beta, park);
     DV_RETURN_LAUNCH();
 }
 

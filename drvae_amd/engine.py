@@ -179,6 +179,7 @@ class FusedStep(StepSchedule):
         self._rec = 'both'
         self.late_leaf = os.environ.get('DRVAE_LATE_LEAF', '1') != '0'
         self.side_adam = os.environ.get('DRVAE_SIDE_ADAM', '1') != '0'
+        self.fold_join = os.environ.get('DRVAE_FOLD_JOIN', '1') != '0'
         self.noise_ahead = False          # set by capture(): the side chain draws the NEXT step's noise behind the join
         self._noise_stale = True          # (then) the noise buffer does not hold the draws of the current Philox counter
         self._adam_n = None
@@ -638,17 +639,27 @@ class FusedStep(StepSchedule):
             with self.branch:
                 side_backward()
             self.branch.join()
-        if mode == 5:      # the launch that assembles the loss scalars also parks on the side chain's flag
+        # (only where the join does not wait: every workgroup of the consumer polls the flag, and a long wait -- VFAE:
+        # its side chain is the longer one, 30 us/step -- slows the very chain it waits for: 0.184 -> 0.208 ms)
+        fold_join = mode == 5 and side_adam and self.fold_join and cfg.has_pert
+        if fold_join:
+            # no launch of its own for the join: the first consumer of the side chain's gradients (below) parks on
+            # the flag itself, and the counters ride on the sample-backward launch
+            K.arm_park(self.flags[1:2], self.step_dev, self.sync_err[0:2])
+            K.arm_bump(*([(self.step_dev, 1)] + ([(self.rng_ctr, self._rng_pending)] if getattr(self, '_rng_pending', 0) else [])))
+            self._rng_pending = 0
+            self._ctr_bumped = True
+        elif mode == 5:    # the launch that assembles the loss scalars also parks on the side chain's flag
             self._loss_scalars(after=(self.flags[1:2], self.step_dev, self.sync_err[0:2], 1, K.WAIT_SPINS),
                                terms_elsewhere=side_adam)
-            if late:       # (that launch has advanced the step counter: the flag carries counter + 0 by now)
-                lc, g0 = self.L_clf[0], self.arena.grad.storage_offset()
-                lo = min(lc.dW.storage_offset(), lc.db.storage_offset()) - g0
-                hi = max(lc.dW.storage_offset() + lc.dW.numel(), lc.db.storage_offset() + lc.db.numel()) - g0
-                self._adam_gate = (self.flags[3:4], self.step_dev, 0, self.sync_err[6:8], lo, hi)
-                self._adam_n = hs if side_adam else None
         elif mode == 3:
             self._loss_scalars()
+        if mode == 5 and late:      # (the step counter is advanced before the optimiser launch: counter + 0 by then)
+            lc = self.L_clf[0]
+            lo = min(lc.dW.storage_offset(), lc.db.storage_offset()) - g0
+            hi = max(lc.dW.storage_offset() + lc.dW.numel(), lc.db.storage_offset() + lc.db.numel()) - g0
+            self._adam_gate = (self.flags[3:4], self.step_dev, 0, self.sync_err[6:8], lo, hi)
+            self._adam_n = hs if side_adam else None
         if cfg.has_pert:
             if not cfg.has_y:
                 p.DZ2F.zero_()

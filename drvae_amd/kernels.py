@@ -487,6 +487,19 @@ def flag_wait(flag, ctr, err, add=1, max_spins=None):
     _lib.check(_lib.load().dv_flag_wait(_i32(flag), _i32(ctr), add, _i32(err), max_spins, _stream()), 'dv_flag_wait')
 
 
+def arm_park(flag, ctr, err, add=1, max_spins=None):
+    """the next ``z2f_post_bwd`` / ``rows_segment_sum`` launch parks on the flag first (``dv_arm_park``)"""
+    _lib.check(_lib.load().dv_arm_park(_i32(flag), _i32(ctr), add, _i32(err), WAIT_SPINS if max_spins is None else max_spins),
+               'dv_arm_park')
+
+
+def arm_bump(*counters):
+    """the next ``reparam_bwd_seg`` launch also advances up to two (counter, inc) (``dv_arm_bump``)"""
+    cs = list(counters) + [(None, 0)] * (2 - len(counters))
+    _lib.check(_lib.load().dv_arm_bump(_i32(cs[0][0]), 0 if cs[0][0] is None else cs[0][0].numel(), cs[0][1],
+                                       _i32(cs[1][0]), 0 if cs[1][0] is None else cs[1][0].numel(), cs[1][1]), 'dv_arm_bump')
+
+
 def counter_add(counter, inc=1):
     _lib.check(_lib.load().dv_counter_add(_i32(counter), counter.numel(), inc, _stream()), 'dv_counter_add')
 

@@ -400,6 +400,13 @@ int dv_adam_l2_gated(float* p, const float* g, float* m, float* v, int64_t n, fl
 int dv_adamax_l2(float* p, const float* g, float* m, float* u, int64_t n, float lr, float beta1, float beta2,
                  float eps, float weight_decay, float gscale, const int32_t* step_dev, dv_stream_t stream);
 int dv_counter_add(int32_t* counter_lo_hi, int32_t n_words, int64_t inc, dv_stream_t stream);
+/* Joins folded into their consumers.  dv_arm_park: the calling thread's NEXT dv_z2f_post_bwd or
+ * dv_rows_segment_sum launch first parks every workgroup like dv_flag_wait(flag, ctr, add, err, max_spins)
+ * (the first consumer of another chain's results waits for them itself: no separate wait launch).
+ * dv_arm_bump: its NEXT dv_reparam_bwd_seg launch also advances up to two device counters like
+ * dv_counters_add2 (c1 / c2 may be NULL).  Both are consumed by that one launch. */
+int dv_arm_park(int32_t* flag, const int32_t* ctr, int32_t add, int32_t* err, int32_t max_spins);
+int dv_arm_bump(int32_t* c1, int32_t n1, int64_t inc1, int32_t* c2, int32_t n2, int64_t inc2);
 /* two device counters in one launch (the optimiser step count and the Philox counter of a train step) */
 int dv_counters_add2(int32_t* c1, int32_t n1, int64_t inc1, int32_t* c2, int32_t n2, int64_t inc2,
                      dv_stream_t stream);

@@ -616,6 +616,16 @@ def flag_wait(flag, ctr, err, add=1, max_spins=None):
         err[0] = 1                            # (err[1], the parked-time statistic, stays 0)
 
 
+def arm_park(flag, ctr, err, add=1, max_spins=None):
+    flag_wait(flag, ctr, err, add)            # single-threaded stand-in: the producer has run already
+
+
+def arm_bump(*counters):
+    for (c, inc) in counters:
+        if c is not None:
+            counter_add(c, inc)
+
+
 def counters_add2(c1, inc1, c2, inc2):
     counter_add(c1, inc1)
     counter_add(c2, inc2)
@@ -640,7 +650,7 @@ def fill_normal(out, seed, ctr_dev=None):
     out.copy_(torch.randn(out.shape, generator=g).to(out.device))
 
 
-FUNCTIONS = ['adamax_l2', 'batch_feed', 'mmd_rff_fwd', 'mmd_rff_bwd', 'counters_add2', 'ycont_fwd', 'ycont_bwd', 'flag_publish', 'flag_wait', 'gemm', 'linear_fwd', 'linear_bwd_data', 'linear_bwd_weight', 'linear_bwd_pair', 'colsum', 'act_bwd_', 'wn_scale', 'wn_bwd',
+FUNCTIONS = ['arm_park', 'arm_bump', 'adamax_l2', 'batch_feed', 'mmd_rff_fwd', 'mmd_rff_bwd', 'counters_add2', 'ycont_fwd', 'ycont_bwd', 'flag_publish', 'flag_wait', 'gemm', 'linear_fwd', 'linear_bwd_data', 'linear_bwd_weight', 'linear_bwd_pair', 'colsum', 'act_bwd_', 'wn_scale', 'wn_bwd',
              'reparam_fwd', 'reparam_bwd', 'reparam_bwd_seg', 'z2f_post_bwd', 'kl_rows_fwd', 'kl_rows_bwd', 'nll_rows_fwd', 'nll_rows_bwd', 'nll_rows_fwdbwd',
              'softmax_clamp_fwd', 'softmax_clamp_bwd', 'cat_terms_fwd', 'cat_terms_bwd', 'smalln_fwd', 'smalln_bwd_data',
              'smalln_bwd_weight', 'ymarg_fwd', 'ymarg_bwd', 'ymarg_fwdbwd',

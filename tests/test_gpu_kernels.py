@@ -470,6 +470,51 @@ def test_adam_gated_sweep(K, dev, n, lo, hi):
     close(p, want, rtol=0, atol=0)
 
 
+def test_armed_park_and_bump(K, dev):
+    """dv_arm_park / dv_arm_bump: the next rows_segment_sum parks on a flag published later from another queue,
+    the next reparam_bwd_seg advances the counters; both are consumed by that one launch"""
+    n, W = 64, 100
+    src, want = rnd(dev, n, W, seed=1), torch.zeros(n, W, device=dev)
+    dst = torch.zeros(n, W, device=dev)
+    K.rows_segment_sum(want, src, beta=0.0, width=W, n=n)
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    ctr = torch.tensor([6], dtype=torch.int32, device=dev)
+    err = torch.zeros(2, dtype=torch.int32, device=dev)
+    stale = torch.full((n, W), 777.0, device=dev)
+    live = stale.clone()
+    side = _other_queue_stream(K, dev)
+    torch.cuda.synchronize()
+    K.arm_park(flag, ctr, err, add=1)
+    K.rows_segment_sum(dst, live, beta=0.0, width=W, n=n)        # parks: ``live`` is not final yet
+    with torch.cuda.stream(side):
+        torch.cuda._sleep(2000000)
+        live.copy_(src)
+        K.flag_publish(flag, ctr, 1)
+    torch.cuda.synchronize()
+    assert int(err[0]) == 0 and int(err[1]) > 0
+    close(dst, want, rtol=0, atol=0)
+    K.rows_segment_sum(dst, stale, beta=0.0, width=W, n=n)       # not armed any more: runs straight away
+    torch.cuda.synchronize()
+    assert float(dst[0, 0]) == 777.0
+    # bump on reparam_bwd_seg
+    nq, Z, L = 5, 8, 2
+    dz, eps = rnd(dev, nq * L, Z, seed=2), rnd(dev, nq * L, Z, seed=3)
+    lv = rnd(dev, nq, Z, seed=4)
+    ptr = torch.arange(0, nq * L + 1, L, dtype=torch.int32, device=dev)
+    rows_ = torch.arange(nq * L, dtype=torch.int32, device=dev)
+    dmu, dlv, dmu2, dlv2 = (torch.zeros(nq, Z, device=dev) for _ in range(4))
+    step = torch.tensor([3], dtype=torch.int32, device=dev)
+    rng = torch.tensor([-2, 0], dtype=torch.int32, device=dev)
+    K.reparam_bwd_seg(dmu2, dlv2, dz, eps, lv, ptr, rows_)
+    K.arm_bump((step, 1), (rng, 5))
+    K.reparam_bwd_seg(dmu, dlv, dz, eps, lv, ptr, rows_)
+    K.reparam_bwd_seg(dmu, dlv, dz, eps, lv, ptr, rows_)         # second launch: nothing armed
+    torch.cuda.synchronize()
+    assert step.tolist() == [4] and rng.tolist() == [3, 1]
+    close(dmu, dmu2, rtol=0, atol=0)
+    close(dlv, dlv2, rtol=0, atol=0)
+
+
 def test_adamax_matches_torch_optim(K, dev):
     n = 100003
     p0, g = rnd(dev, n, seed=1), rnd(dev, n, seed=2)
