@@ -44,7 +44,7 @@ __device__ __attribute__((aligned(16))) const float dv_zero_chunk[4] = {0.f, 0.f
 struct LoadCfg {
     int vecA, vecB;   // widest aligned vector width (4, 2 or 1 floats) per operand
     int vecA_t, vecB_t;   // same for the ragged last K tile of a k-contiguous operand: also divides K
-    int map;          // workgroup -> tile mapping: 0 linear, 1 XCD chunk-major (default)
+    int map;          // workgroup -> tile mapping: 0 linear, 1 XCD chunk-major, >= 2 bands of `map` tile rows
 };
 
 // XCD-aware workgroup -> tile map.  Observed dispatch: blocks b and b+8 share an XCD and its
@@ -69,6 +69,16 @@ __device__ __forceinline__ void tile_of_block(int bid, int nwg, int tiles_m, int
             tn = r / h;
             tm = c * ch + r % h;
         }
+        return;
+    }
+    if (map >= 2) {
+        // grouped order (map = group height in tiles): sweep the tile columns of a band of `map` tile rows before
+        // moving to the next band, so that the workgroups in flight together share both a few row panels of A
+        // and a few column panels of B
+        const int gm = map, per = gm * tiles_n, grp = t / per, first = grp * gm;
+        const int h = (tiles_m - first) < gm ? (tiles_m - first) : gm, r = t - grp * per;
+        tm = first + r % h;
+        tn = r / h;
         return;
     }
     tm = t / tiles_n;
@@ -664,7 +674,7 @@ int launch_cfg(const dv_gemm_desc& g, const LoadCfg& lc, hipStream_t st) {
 }  // namespace
 
 static int g_force_tiling = 0;   // 0 = heuristic; 1 = T64, 2 = T32K, 3 = T128 (tests / tuning)
-static int g_opt[8] = {1, 0, 0, 0, 0, 0, 0, 0};   // [0] = tile map (0 linear, 1 XCD chunk-major)
+static int g_opt[8] = {-1, 0, 0, 0, 0, 0, 0, 0};  // [0] = tile map (0 linear, 1 XCD chunk-major, >= 2 row bands, -1 by tiling)
 
 extern "C" int dv_gemm_set_option(int key, int value) {
     if (key < 0 || key >= 8) return DV_ERR_ARG;
@@ -704,7 +714,6 @@ static int gemm_prepare(const dv_gemm_desc* d, LoadCfg& lc, int& tiling) {
     lc.vecB_t = lc.vecB;
     while (g.K % lc.vecA_t) lc.vecA_t >>= 1;
     while (g.K % lc.vecB_t) lc.vecB_t >>= 1;
-    lc.map = g_opt[0];
     const int64_t t64 = (int64_t)((g.M + 63) / 64) * ((g.N + 63) / 64);
     const int64_t t128 = (int64_t)((g.M + 127) / 128) * ((g.N + 127) / 128);
     tiling = g_force_tiling;
@@ -713,6 +722,11 @@ static int gemm_prepare(const dv_gemm_desc* d, LoadCfg& lc, int& tiling) {
     // tiles only pay once their grids alone fill the chip several times over
     const int64_t t64_min = g_opt[3] > 0 ? g_opt[3] : 1024;
     if (tiling == 0) tiling = (t128 >= 1024) ? 3 : (t64 >= t64_min ? 1 : 2);
+    // workgroup -> tile map: XCD chunk-major for the small grids (each XCD keeps a compact band of the
+    // output, its panels stay in its L2); for the grids that fill the chip many times over, bands of 16 tile
+    // rows swept column by column (measured, wide configuration: chunk-major 121.5, linear 127.0, bands of 16
+    // 128.3 TF/s over the step's products; no difference at the cfg-2 sizes)
+    lc.map = g_opt[0] >= 0 ? g_opt[0] : (tiling == 3 ? 16 : 1);
     return DV_OK;
 }
 
