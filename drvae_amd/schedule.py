@@ -212,7 +212,7 @@ class StepSchedule:
                 self._flag_side = prev
         return ctx()
 
-    def tune_partition(self, candidates=(40, 48, 56, 64, 72, 80, 96, 112, 128), steps=24):
+    def tune_partition(self, candidates=(48, 64, 80, 96, 128), steps=24):
         """Pick the CU split of ``partition()`` by timing replays of the captured step (the best split
         depends on how the two chains balance, i.e. on the model and on the individual GPU).  Runs on a
         scratch copy of the training state: parameters, Adam moments and all device counters are restored
