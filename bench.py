@@ -57,7 +57,10 @@ def build(workload, device, rank, world, seed=123):
                 fan = shp[1]
             a = rs.uniform(-1, 1, shp) / np.sqrt(fan)
         arena.p(k).copy_(torch.as_tensor(a, dtype=torch.float32))
-    eng = E.FusedStep(cfg, arena, seed=1000 + rank, concurrent=os.environ.get('DRVAE_CONCURRENT', '1') != '0')
+    # one seed for all ranks: the Philox draws are keyed by (seed, step, draw, GLOBAL row), so the job's noise does
+    # not depend on the number of ranks; this rank owns rows [rank*rows, (rank+1)*rows)
+    eng = E.FusedStep(cfg, arena, seed=1000, concurrent=os.environ.get('DRVAE_CONCURRENT', '1') != '0',
+                      row0=rank * rows)
     batch = synth.make_batch(kind, rows, cfg.dim_x, cfg.dim_y, seed=1234, row0=rank * rows)
     hx, hy = batch['has_x2'].astype(bool), batch['has_y'].astype(bool)
     # weak scaling: every rank has the same group mix, so the global counts are world * local
@@ -247,6 +250,55 @@ def gemm_roofline(eng, cfg, rows, frac_pair, frac_lab, repeats=20, traffic=None)
                              for t, f, sh in top]}
 
 
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def self_launch(n, argv):
+    """``python bench.py --gpus N`` without a launcher: start N fresh rank processes (one per GPU, RANK /
+    LOCAL_RANK / WORLD_SIZE / MASTER_* set as torch.distributed.run would) and relay rank 0's JSON line and
+    the worst exit code.  This parent never touches the GPU (``import torch`` alone does not initialise
+    HIP), and nothing that has is ever re-exec'ed: the ranks are plain child processes."""
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1',
+               MASTER_PORT=os.environ.get('MASTER_PORT') or str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=e,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    import threading
+    chunks = []
+    rd = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    rd.start()                                      # (children's stderr goes straight to ours)
+    limit = time.time() + float(os.environ.get('DRVAE_BENCH_TIMEOUT', '1500'))
+    while any(p.poll() is None for p in procs):
+        failed = any(p.poll() not in (None, 0) for p in procs)
+        if failed or time.time() > limit:           # a rank died (its peers would sit in a collective for ever)
+            time.sleep(2.0 if failed else 0.0)
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()                        # exactly the processes started above
+            break
+        time.sleep(0.05)
+    codes = [p.wait() for p in procs]
+    rd.join(timeout=10)
+    out0 = b''.join(chunks).decode(errors='replace')
+    line = None
+    for ln in out0.splitlines():
+        if ln.startswith('{') and '"metric"' in ln:
+            line = ln
+    if line is not None:
+        print(line, flush=True)
+    else:
+        sys.stdout.write(out0)
+    bad = [c for c in codes if c != 0]
+    return (bad[0] if bad else 0) if line is not None else (bad[0] if bad else 1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -263,6 +315,9 @@ def main():
     ap.add_argument('--dataset-rows', type=int, default=16384)
     args = ap.parse_args()
 
+    if args.gpus > 1 and int(os.environ.get('WORLD_SIZE', '1')) <= 1:
+        return self_launch(args.gpus, sys.argv[1:])   # before anything initialises the GPU in this process
+
     from drvae_amd import _lib, dist as D
     _lib.load()                                       # fail loudly if the HIP library is missing
     if os.environ.get('DRVAE_GEMM_MAP'):              # tuning: workgroup->tile map (0 linear, 1 XCD chunk-major)
@@ -272,9 +327,8 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (no CPU fallback for the hot path)')
     rank, world, local = D.init_from_env()
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('launch with torch.distributed.run --nproc-per-node %d' % args.gpus)
+    if world != args.gpus and not (world == 1 and args.gpus == 1):
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
     local = local % torch.cuda.device_count()        # (one-GPU functional tests of the multi-rank path)
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
@@ -346,6 +400,22 @@ def main():
         tmax = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+    # SURVEY 8(d) asks for >= 200 timed steps: when the K requested ones took under half a second, a second,
+    # longer region (same step, same barriers) is timed as well and reported next to the contract's number
+    steady = None
+    if dt < 0.5 and os.environ.get('DRVAE_BENCH_STEADY', '1') != '0':
+        n2 = int(min(max(200, 0.5 * args.steps / max(dt, 1e-6)), 20000))
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(n2):
+            step()
+        barrier()
+        dt2 = time.perf_counter() - t1
+        if world > 1:
+            tm2 = torch.tensor([dt2], dtype=torch.float64, device=device)
+            dist.all_reduce(tm2, op=dist.ReduceOp.MAX)
+            dt2 = float(tm2.item())
+        steady = {'steps': n2, 'ms_per_step': round(1e3 * dt2 / n2, 4), 'value': round(world * rows * L * n2 / dt2, 1)}
     losses = eng.losses()
     part.__exit__(None, None, None)
     waits = eng.sync_err.cpu().tolist() if hasattr(eng, 'sync_err') else None
@@ -359,9 +429,13 @@ def main():
         'config': {'workload': '%s: %s' % (args.workload, desc), 'global_batch': world * rows, 'L': L,
                    'parallelism': 'dp%d' % world, 'launch': 'hipGraph replay' if use_graph else 'eager', 'feed': args.feed,
                    'side_chain_cus': getattr(eng, '_side_cus', None),
+                   'dist_backend': (dist.get_backend() if dist.is_initialized() else None),
+                   'rccl_ranks': (dist.get_world_size() if dist.is_initialized() and dist.get_backend() == 'nccl'
+                                  else 0),
                    'params': int(sum(int(np.prod(s)) for s in arena.shapes.values()))},
         'losses_last_step': {k: round(v, 4) for k, v in losses.items()}, 'finite': ok,
         'chain_wait_ticks': waits, 'host_enqueue_ms_per_step': round(1e3 * t_enq / args.steps, 4),
+        'steady_state': steady,
     }
     if rank == 0:
         hx, hy = batch['has_x2'].astype(bool), batch['has_y'].astype(bool)

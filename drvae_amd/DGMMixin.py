@@ -51,7 +51,60 @@ class DeepGenerativeModelMixin:
                                    % (set(shapes.items()) ^ set(want.items())))
             self._arena = ParamArena(shapes, dev, frozen=E.frozen_params(cfg)).adopt(self)
             self._engine = E.FusedStep(cfg, self._arena, seed=self.random_seed)
+            self._restore_optimizer_state()
         return self._engine
+
+    # ---- the nn.Parameters ALIAS the arena; anything that swaps ``prm.data`` (``.to()``, ``.cpu()``,
+    # ``load_state_dict(assign=True)``) would leave the fused step training a buffer nobody reads
+    def _arena_aliased(self):
+        a = self._arena
+        return all(prm.dtype == torch.float32 and prm.data_ptr() == a.p(name).data_ptr()
+                   for name, prm in self.named_parameters())
+
+    def _assert_arena_aliased(self):
+        if getattr(self, '_engine', None) is not None and not self._arena_aliased():
+            raise RuntimeError('drvae_amd: model parameters no longer alias the parameter arena of the fused step')
+
+    def _stash_optimizer_state(self):
+        eng, a = self._engine, self._arena
+        self._opt_stash = dict(exp_avg=a.exp_avg.detach().cpu().clone(), exp_avg_sq=a.exp_avg_sq.detach().cpu().clone(),
+                               step=eng.step_dev.cpu().clone(), rng=eng.rng_ctr.cpu().clone(), iters=eng.iters,
+                               offsets=dict(a.offsets))
+
+    def _restore_optimizer_state(self):
+        st = getattr(self, '_opt_stash', None)
+        if st is None:
+            return
+        eng, a = self._engine, self._arena
+        assert st['offsets'] == a.offsets
+        a.exp_avg.copy_(st['exp_avg'])
+        a.exp_avg_sq.copy_(st['exp_avg_sq'])
+        eng.step_dev.copy_(st['step'])
+        eng.rng_ctr.copy_(st['rng'])
+        eng.side_ctr.copy_(eng.step_dev)
+        eng.side_t.copy_(eng.step_dev + 1)
+        eng.iters = st['iters']
+        self._opt_stash = None
+
+    def _apply(self, fn, recurse=True):
+        """``.to()/.cuda()/.cpu()/.float()``: when the parameters were moved off the arena, carry the
+        optimiser state (Adam moments, step and Philox counters) over and rebuild the arena + engine on
+        the new device at the next use.  A dtype other than fp32 is refused: the hot path is fp32."""
+        if getattr(self, '_engine', None) is not None:
+            probe = next(self.parameters())
+            if fn(torch.empty(0, dtype=probe.dtype, device=probe.device)).dtype != torch.float32:
+                raise TypeError('drvae_amd: the fused train step is fp32; cast a copy of the model instead')
+        out = super()._apply(fn, recurse)
+        if getattr(self, '_engine', None) is not None and not self._arena_aliased():
+            self._stash_optimizer_state()
+            self._engine = self._arena = None      # rebuilt (and the parameters re-adopted) by engine()
+        return out
+
+    def load_state_dict(self, state_dict, strict=True, assign=False):
+        out = super().load_state_dict(state_dict, strict=strict, assign=assign)
+        if assign and getattr(self, '_engine', None) is not None and not self._arena_aliased():
+            self._arena.adopt(self)                # values copied into the arena, parameters aliased again
+        return out
 
     # ------------------------------------------------------- model-level MMD penalty
     def _get_mmd_criterion(self, z, sind):

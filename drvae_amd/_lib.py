@@ -28,6 +28,14 @@ class GemmDesc(C.Structure):
                 ('pub_flag', _p), ('pub_ctr', _p), ('pub_add', _i32)]
 
 
+class Wait(C.Structure):       # dv_wait: a device-side wait carried by a launch
+    _fields_ = [('flag', _p), ('ctr', _p), ('add', _i32), ('max_spins', _i32), ('err', _p)]
+
+
+class Bump(C.Structure):       # dv_bump: up to two device counters advanced by a launch
+    _fields_ = [('c', _p * 2), ('n', _i32 * 2), ('inc', _i64 * 2)]
+
+
 class LossTerm(C.Structure):
     _fields_ = [('x', _p), ('w', _p), ('n', _i32), ('scale', _f), ('out', _i32)]
 
@@ -47,9 +55,9 @@ SIGNATURES = {
     'dv_reparam_fwd': [_p, _p, _i64, _p, _i32, _i32, _i32, _p, _i64, _i32, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p,
                        _p],
     'dv_reparam_bwd_seg': [_p, _i64, _p, _i64, _p, _i64, _p, _p, _i32, _i32, _i32, _p, _i64, _p, _p, _p, _p, _i64, _f,
-                           _p],
+                           C.POINTER(Bump), _p],
     'dv_z2f_post_bwd': [_p, _i64, _p, _i64, _p, _p, _i64, _p, _i64, _p, _i64, _p, _p, _f, _p, _i64, _p, _i64, _p, _i64,
-                        _p, _i64, _i32, _i32, _i32, _i32, _p],
+                        _p, _i64, _i32, _i32, _i32, _i32, C.POINTER(Wait), _p],
     'dv_reparam_bwd': [_p, _i64, _p, _i64, _p, _i64, _p, _i32, _i32, _i32, _i32, _p, _p, _i64, _f, _p],
     'dv_kl_rows_fwd': [_p, _p, _i64, _p, _p, _p, _i64, _p, _f, _f, _i32, _i32, _i32, _i32, _i32, _f, _p, _p, _p, _p,
                        _i64, _p, _i64, _p],
@@ -79,27 +87,28 @@ SIGNATURES = {
     'dv_rows_gather': [_p, _i64, _p, _i32, _i32, _p, _i64, _f, _p, _i32, _p, _i64, _p],
     'dv_batch_feed': [_p, _i64, _p, _i64, _p, _p, _i32, _p, _p, _i32, _p, _i32, _i32, _p, _i64, _f, _p, _i64, _p, _i32,
                       _p, _p, _p, _p, _i32, _p, _p, _i64, _i32, _p, _p, _i32, _p],
-    'dv_rows_segment_sum': [_p, _i64, _p, _p, _p, _i32, _i32, _p, _p, _i64, _f, _p],
+    'dv_rows_segment_sum': [_p, _i64, _p, _p, _p, _i32, _i32, _p, _p, _i64, _f, C.POINTER(Wait), _p],
     'dv_weighted_sum': [_p, _p, _p, _i32, _f, _p, _f, _p],
     'dv_recon_row_stats': [_p, _i64, _p, _i64, _i32, _i32, _p, _p],
     'dv_col_moments': [_p, _i64, _p, _i64, _i32, _i32, _p, _p],
-    'dv_loss_assemble': [C.POINTER(LossTerm), _i32, _p, _p, _p, _p],
+    'dv_loss_assemble': [C.POINTER(LossTerm), _i32, _p, _p, _p, _p, _i32, _p],
     'dv_loss_assemble_after': [_p, _p, _i32, _p, _i32, C.POINTER(LossTerm), _i32, _p, _p, _p, _p, _i32, _i64, _p, _i32,
-                               _i64, _p],
+                               _i64, _p, _i32, _p],
     'dv_axpby': [_p, _f, _p, _f, _i64, _p],
-    'dv_adam_l2': [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _f, _p, _p],
-    'dv_adam_l2_gated': [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _f, _p, _p, _p, _i32, _p, _i32, _i64, _i64, _p],
-    'dv_adamax_l2': [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _f, _p, _p],
+    'dv_adam_l2': [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _f, _p, _p, _i32, _p],
+    'dv_adam_l2_gated': [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _f, _p, _p, _p, _i32, _p, _i32, _i64, _i64, _p,
+                         _i32, _p],
+    'dv_adamax_l2': [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _f, _p, _p, _i32, _p],
     'dv_flag_publish': [_p, _p, _i32, _p],
     'dv_flag_wait': [_p, _p, _i32, _p, _i32, _p],
     'dv_counter_add': [_p, _i32, _i64, _p],
-    'dv_arm_park': [_p, _p, _i32, _p, _i32],
-    'dv_arm_bump': [_p, _i32, _i64, _p, _i32, _i64],
     'dv_counters_add2': [_p, _i32, _i64, _p, _i32, _i64, _p],
     'dv_fill_normal': [_p, _i64, _u64, _p, _p],
+    'dv_fill_normal_rows': [_p, _p, _i32, _u64, _p, _p],
 }
 
 _lib = None
+ABI_VERSION = 2     # DV_ABI_VERSION of include/drvae_hip.h
 
 
 def load():
@@ -123,7 +132,7 @@ def load():
             raise RuntimeError('drvae_amd: symbol %s missing from %s (stale build?)' % (name, LIB_PATH)) from e
         fn.argtypes = argtypes
         fn.restype = C.c_char_p if name == 'dv_error_string' else C.c_int
-    if lib.dv_abi_version() != 1:
+    if lib.dv_abi_version() != ABI_VERSION:
         raise RuntimeError('drvae_amd: ABI version mismatch in %s' % LIB_PATH)
     _lib = lib
     return lib

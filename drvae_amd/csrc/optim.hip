@@ -31,6 +31,14 @@ __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, 
     p = p + (-step_size) * (m / denom);
 }
 
+// sticky error words of the step's device-side waits: (err, ticks) pairs, see dv_wait in drvae_hip.h
+__device__ __forceinline__ int any_halt(const int32_t* halt, int n_halt) {
+    int bad = 0;
+    for (int i = 0; i < n_halt; ++i)
+        bad |= __hip_atomic_load(halt + 2 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+    return bad;
+}
+
 // optional gate of the optimiser sweep: the elements [lo, hi) of the arena (gradients another launch chain
 // still writes) are touched only after that chain has published `flag` (see dv_flag_publish)
 struct AdamGate {
@@ -45,9 +53,14 @@ struct AdamGate {
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, int64_t n, float lr,
                                                    float b1, float b2, float eps, float wd, float gscale,
-                                                   const int32_t* __restrict__ step_dev, int vec4, AdamGate gate) {
+                                                   const int32_t* __restrict__ step_dev, int vec4, AdamGate gate,
+                                                   const int32_t* __restrict__ halt, int n_halt) {
     __shared__ float sc[2];
-    if (threadIdx.x == 0) adam_consts(lr, b1, b2, step_dev, &sc[0], &sc[1]);
+    __shared__ int halted;
+    if (threadIdx.x == 0) {
+        adam_consts(lr, b1, b2, step_dev, &sc[0], &sc[1]);
+        halted = any_halt(halt, n_halt);
+    }
     if (gate.flag != nullptr) {
         // only the workgroups whose elements overlap the gated range park (typically one): a parked
         // workgroup or two can never starve the chain that is to publish
@@ -74,6 +87,9 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
         }
     }
     __syncthreads();
+    // a chain wait has timed out (now or in an earlier step): the gradients may be built on stale data --
+    // leave parameters and moments as they are (the loss scalars come out NaN, the host raises)
+    if (halted || (gate.flag != nullptr && any_halt(halt, n_halt))) return;
     const float step_size = sc[0], bc2_sqrt = sc[1];
     // (float)(1 - beta) computed in double first, as python does before the op sees it
     const float w1 = (float)(1.0 - (double)b1), w2 = (float)(1.0 - (double)b2);
@@ -147,6 +163,60 @@ __device__ __forceinline__ void philox_round(uint32_t& c0, uint32_t& c1, uint32_
 
 __device__ __forceinline__ float u01(uint32_t x) { return ((float)x + 0.5f) * 2.3283064365386963e-10f; }
 
+__device__ __forceinline__ void philox_normal4(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                               uint32_t k1, float (&z)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        philox_round(c0, c1, c2, c3, k0, k1);
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    const float r0 = sqrtf(-2.f * logf(u01(c0))), r1 = sqrtf(-2.f * logf(u01(c2)));
+    float s0, co0, s1, co1;
+    sincosf(6.283185307179586f * u01(c1), &s0, &co0);
+    sincosf(6.283185307179586f * u01(c3), &s1, &co1);
+    z[0] = r0 * co0;
+    z[1] = r0 * s0;
+    z[2] = r1 * co1;
+    z[3] = r1 * s1;
+}
+
+// Row-keyed draws (SURVEY.md 8(e) "RNG under DP"): element (row, col) of the noise arena is
+// Philox(key = seed ^ step_hi, counter = (col/4, global row, draw id, step_lo))[col%4], so a value depends only
+// on WHICH draw of WHICH global minibatch row of WHICH step it is -- not on how rows are grouped into
+// buffers or sharded over ranks.  desc[r] = {offset into arena (floats), width, draw id, global row};
+// one wave per row.
+__global__ __launch_bounds__(256) void fill_normal_rows_kernel(float* __restrict__ arena,
+                                                               const int4* __restrict__ desc, int n_rows,
+                                                               uint64_t seed, const int32_t* __restrict__ ctr_dev) {
+    uint32_t step_lo = 0, step_hi = 0;
+    if (ctr_dev) {
+        step_lo = (uint32_t)ctr_dev[0];
+        step_hi = (uint32_t)ctr_dev[1];
+    }
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32) ^ step_hi;
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), nwave = gridDim.x * (blockDim.x >> 6);
+    for (int r = wave; r < n_rows; r += nwave) {
+        const int4 d = desc[r];
+        float* out = arena + d.x;
+        const int w = d.y, w4 = (w + 3) >> 2;
+        const bool al = ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+        for (int c = lane; c < w4; c += 64) {
+            float z[4];
+            philox_normal4((uint32_t)c, (uint32_t)d.w, (uint32_t)d.z, step_lo, k0, k1, z);
+            const int o = c << 2;
+            if (al && o + 4 <= w) {
+                *reinterpret_cast<float4*>(out + o) = make_float4(z[0], z[1], z[2], z[3]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (o + e < w) out[o + e] = z[e];
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void fill_normal_kernel(float* __restrict__ out, int64_t n, uint64_t seed,
                                                           const int32_t* __restrict__ ctr_dev) {
     uint64_t base = 0;
@@ -185,10 +255,16 @@ extern "C" int dv_abi_version(void) { return DV_ABI_VERSION; }
 __global__ __launch_bounds__(256) void adamax_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                      float* __restrict__ m, float* __restrict__ u, int64_t n, float lr,
                                                      float b1, float b2, float eps, float wd, float gscale,
-                                                     const int32_t* __restrict__ step_dev) {
+                                                     const int32_t* __restrict__ step_dev,
+                                                     const int32_t* __restrict__ halt, int n_halt) {
     __shared__ float sc[2];
-    if (threadIdx.x == 0) adam_consts(lr, b1, b2, step_dev, &sc[0], &sc[1]);
+    __shared__ int halted;
+    if (threadIdx.x == 0) {
+        adam_consts(lr, b1, b2, step_dev, &sc[0], &sc[1]);
+        halted = any_halt(halt, n_halt);
+    }
     __syncthreads();
+    if (halted) return;
     const float clr = sc[0];
     const float w1 = (float)(1.0 - (double)b1);
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -216,8 +292,8 @@ extern "C" const char* dv_error_string(int code) {
 
 static int adam_launch(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                        float eps, float weight_decay, float gscale, const int32_t* step_dev, const AdamGate& gate,
-                       dv_stream_t stream) {
-    DV_REQUIRE(n >= 0);
+                       const int32_t* halt, int32_t n_halt, dv_stream_t stream) {
+    DV_REQUIRE(n >= 0 && n_halt >= 0 && (halt || n_halt == 0));
     if (n == 0) return DV_OK;
     DV_REQUIRE(p && g && m && v && step_dev);
     auto al = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
@@ -226,35 +302,36 @@ static int adam_launch(float* p, const float* g, float* m, float* v, int64_t n, 
     if (blocks < 1) blocks = 1;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, ST(stream), p, g, m, v, n, lr, beta1,
-                       beta2, eps, weight_decay, gscale, step_dev, vec4, gate);
+                       beta2, eps, weight_decay, gscale, step_dev, vec4, gate, halt, n_halt);
     DV_RETURN_LAUNCH();
 }
 
 extern "C" int dv_adam_l2(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                           float beta2, float eps, float weight_decay, float gscale, const int32_t* step_dev,
-                          dv_stream_t stream) {
-    return adam_launch(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, gscale, step_dev, AdamGate{}, stream);
+                          const int32_t* halt, int32_t n_halt, dv_stream_t stream) {
+    return adam_launch(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, gscale, step_dev, AdamGate{}, halt, n_halt,
+                       stream);
 }
 
 extern "C" int dv_adam_l2_gated(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                                 float beta2, float eps, float weight_decay, float gscale, const int32_t* step_dev,
                                 int32_t* flag, const int32_t* ctr, int32_t add, int32_t* err, int32_t max_spins,
-                                int64_t lo, int64_t hi, dv_stream_t stream) {
+                                int64_t lo, int64_t hi, const int32_t* halt, int32_t n_halt, dv_stream_t stream) {
     DV_REQUIRE(flag && ctr && err && max_spins > 0 && lo >= 0 && hi >= lo && hi <= n);
     return adam_launch(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, gscale, step_dev,
-                       AdamGate{flag, ctr, add, err, max_spins, lo, hi}, stream);
+                       AdamGate{flag, ctr, add, err, max_spins, lo, hi}, halt, n_halt, stream);
 }
 
 extern "C" int dv_adamax_l2(float* p, const float* g, float* m, float* u, int64_t n, float lr, float beta1,
                             float beta2, float eps, float weight_decay, float gscale, const int32_t* step_dev,
-                            dv_stream_t stream) {
-    DV_REQUIRE(n >= 0);
+                            const int32_t* halt, int32_t n_halt, dv_stream_t stream) {
+    DV_REQUIRE(n >= 0 && n_halt >= 0 && (halt || n_halt == 0));
     if (n == 0) return DV_OK;
     DV_REQUIRE(p && g && m && u && step_dev);
     int64_t blocks = (n + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(adamax_kernel, dim3((unsigned)blocks), dim3(256), 0, ST(stream), p, g, m, u, n, lr, beta1, beta2,
-                       eps, weight_decay, gscale, step_dev);
+                       eps, weight_decay, gscale, step_dev, halt, n_halt);
     DV_RETURN_LAUNCH();
 }
 
@@ -304,6 +381,18 @@ extern "C" int dv_counters_add2(int32_t* c1, int32_t n1, int64_t inc1, int32_t* 
                                 dv_stream_t stream) {
     DV_REQUIRE(c1 && c2 && (n1 == 1 || n1 == 2) && (n2 == 1 || n2 == 2));
     hipLaunchKernelGGL(counters_add2_kernel, dim3(1), dim3(64), 0, ST(stream), c1, n1, inc1, c2, n2, inc2);
+    DV_RETURN_LAUNCH();
+}
+
+extern "C" int dv_fill_normal_rows(float* arena, const int32_t* desc, int32_t n_rows, uint64_t seed,
+                                   const int32_t* ctr_dev, dv_stream_t stream) {
+    DV_REQUIRE(n_rows >= 0);
+    if (n_rows == 0) return DV_OK;
+    DV_REQUIRE(arena && desc && (reinterpret_cast<uintptr_t>(desc) & 15) == 0);
+    int blocks = (n_rows + 3) / 4;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(fill_normal_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, ST(stream), arena,
+                       reinterpret_cast<const int4*>(desc), n_rows, seed, ctr_dev);
     DV_RETURN_LAUNCH();
 }
 

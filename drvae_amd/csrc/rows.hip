@@ -138,21 +138,11 @@ __global__ void reparam_bwd_kernel(const float* __restrict__ dz, int64_t ldz, co
 // draws per row, e.g. L z1-samples + L z2-samples of a paired row) plus, optionally, row-aligned
 // (dmu | dsd) contributions listed in a second CSR (the KL(q(z1|x)||p(z1|z3,y)) gradients of its
 // fprop rows).  One launch replaces reparam_bwd x2 + a segment sum; deterministic.
-// ---- joins folded into consumers (see dv_arm_park / dv_arm_bump): a launch may first park every workgroup
+// ---- joins folded into consumers (dv_wait / dv_bump arguments): a launch may first park every workgroup
 // on another chain's flag (thread 0 polls, bounded), and may end by advancing device counters
-struct ParkArgs {
-    int32_t* flag;
-    const int32_t* ctr;
-    int add;
-    int32_t* err;
-    int max_spins;
-};
-
-struct CounterBump {
-    int32_t* c[2];
-    int n[2];
-    int64_t inc[2];
-};
+#define DV_MAX_PARKED_GRID 512
+typedef dv_wait ParkArgs;
+typedef dv_bump CounterBump;
 
 __device__ __forceinline__ void park_block(const ParkArgs& pk) {
     if (pk.flag == nullptr) return;
@@ -1129,7 +1119,8 @@ __global__ __launch_bounds__(256) void loss_assemble_kernel(LossTerms lt, const 
                                                             const float* __restrict__ w_cmpl,
                                                             float* __restrict__ loss, int32_t* flag,
                                                             const int32_t* ctr, int add, int32_t* err, int max_spins,
-                                                            CounterBump bump) {
+                                                            CounterBump bump, const int32_t* __restrict__ halt,
+                                                            int n_halt) {
     __shared__ float part[4];
     __shared__ float acc[8];
     if (flag != nullptr) {      // park until the other launch chain has published its results
@@ -1167,7 +1158,12 @@ __global__ __launch_bounds__(256) void loss_assemble_kernel(LossTerms lt, const 
             float c = 0.f;
             for (int i = 0; i < 8; ++i) c += w_cmpl[i] * acc[i];
             acc[6] = c;
-            for (int i = 0; i < 8; ++i) loss[i] = acc[i];
+            // a device-side wait of this step's chains has timed out at some point (sticky error words):
+            // whatever was computed since is built on stale data -- poison the scalars the host reads
+            bool bad = false;
+            for (int i = 0; i < n_halt; ++i)
+                bad = bad || __hip_atomic_load(halt + 2 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+            for (int i = 0; i < 8; ++i) loss[i] = bad ? __builtin_nanf("") : acc[i];
         }
         // end of the step's use of the device counters on this chain: advance them here (saves the
         // separate counter launch in front of the optimiser)
@@ -1186,26 +1182,9 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 #define ST(s) static_cast<hipStream_t>(s)
 
-// armed by dv_arm_park / dv_arm_bump for the calling thread's NEXT supporting launch
-static thread_local ParkArgs g_park{};
-static thread_local CounterBump g_bump{};
-
-extern "C" int dv_arm_park(int32_t* flag, const int32_t* ctr, int32_t add, int32_t* err, int32_t max_spins) {
-    DV_REQUIRE(flag && ctr && err && max_spins > 0);
-    g_park = ParkArgs{flag, ctr, add, err, max_spins};
-    return DV_OK;
-}
-
-extern "C" int dv_arm_bump(int32_t* c1, int32_t n1, int64_t inc1, int32_t* c2, int32_t n2, int64_t inc2) {
-    DV_REQUIRE((!c1 || n1 == 1 || n1 == 2) && (!c2 || n2 == 1 || n2 == 2));
-    g_bump = CounterBump{{c1, c2}, {n1, n2}, {inc1, inc2}};
-    return DV_OK;
-}
-
-static ParkArgs take_park() {
-    const ParkArgs p = g_park;
-    g_park = ParkArgs{};
-    return p;
+static bool park_ok(const dv_wait* p) { return p == nullptr || p->flag == nullptr || (p->ctr && p->err && p->max_spins > 0); }
+static bool bump_ok(const dv_bump* b) {
+    return b == nullptr || ((!b->c[0] || b->n[0] == 1 || b->n[0] == 2) && (!b->c[1] || b->n[1] == 1 || b->n[1] == 2));
 }
 
 extern "C" int dv_colsum(const float* X, int64_t ldx, int32_t M, int32_t N, float* out, float beta,
@@ -1277,11 +1256,11 @@ extern "C" int dv_reparam_bwd_seg(const float* dz, int64_t ldz, const float* eps
                                   int64_t ldq, const int32_t* seg_ptr, const int32_t* seg_rows, int32_t nq,
                                   int32_t Z, int32_t mode, const float* extra, int64_t ldx, const int32_t* ex_ptr,
                                   const int32_t* ex_rows, float* dmu, float* dsd, int64_t lddq, float beta,
-                                  dv_stream_t stream) {
-    const CounterBump bump = g_bump;
-    g_bump = CounterBump{};
+                                  const dv_bump* bump_in, dv_stream_t stream) {
+    DV_REQUIRE(bump_ok(bump_in));
+    const CounterBump bump = bump_in ? *bump_in : CounterBump{};
     DV_REQUIRE(nq >= 0 && Z >= 0);
-    DV_REQUIRE(!(bump.c[0] || bump.c[1]) || (nq > 0 && Z > 0));      // an armed bump needs a launch to ride on
+    DV_REQUIRE(!(bump.c[0] || bump.c[1]) || (nq > 0 && Z > 0));      // a bump needs a launch to ride on
     if (nq == 0 || Z == 0) return DV_OK;
     DV_REQUIRE(dz && eps && sd && seg_ptr && seg_rows && dmu && dsd);
     DV_REQUIRE(extra == nullptr || (ex_ptr && ex_rows));
@@ -1296,10 +1275,14 @@ extern "C" int dv_z2f_post_bwd(const float* dz2f, int64_t ld_dz2f, const float* 
                                const float* q2, int64_t ldq2, const float* coef, const float* raw, float kl_min,
                                const float* dz1b, int64_t ld_dz1b, float* dp2, int64_t ld_dp2, float* dz1,
                                int64_t ld_dz1, float* dq2, int64_t ld_dq2, int32_t L, int32_t B, int32_t Np, int32_t Z,
-                               dv_stream_t stream) {
-    const ParkArgs park = take_park();
+                               const dv_wait* park_in, dv_stream_t stream) {
+    DV_REQUIRE(park_ok(park_in));
+    const ParkArgs park = park_in ? *park_in : ParkArgs{};
     DV_REQUIRE(L >= 0 && B >= 0 && Np >= 0 && Z >= 0);
     DV_REQUIRE(park.flag == nullptr || (L > 0 && B > 0 && Z > 0));
+    // every workgroup of a parked launch polls: keep such grids far below what the chip holds resident
+    // (256 CUs x 8 workgroups), or the chain that is to publish may find no slot to run in
+    if (park.flag != nullptr && grid_for((int64_t)B * Z, 256) > DV_MAX_PARKED_GRID) return DV_ERR_UNSUPPORTED;
     if (L == 0 || B == 0 || Z == 0) return DV_OK;
     DV_REQUIRE(dz2f && eps && p2 && dp2 && dz1);
     DV_REQUIRE(Np == 0 || (pair_slot && q2 && coef && raw));
@@ -1613,10 +1596,12 @@ extern "C" int dv_batch_feed(const float* x1, int64_t ld1, const float* x2, int6
 
 extern "C" int dv_rows_segment_sum(const float* src, int64_t lds, const int32_t* seg_ptr, const int32_t* seg_rows,
                                    const float* w, int32_t n, int32_t W, const int32_t* dst_idx, float* dst,
-                                   int64_t ldd, float beta, dv_stream_t stream) {
-    const ParkArgs park = take_park();
+                                   int64_t ldd, float beta, const dv_wait* park_in, dv_stream_t stream) {
+    DV_REQUIRE(park_ok(park_in));
+    const ParkArgs park = park_in ? *park_in : ParkArgs{};
     DV_REQUIRE(n >= 0 && W >= 0);
     DV_REQUIRE(park.flag == nullptr || (n > 0 && W > 0));
+    if (park.flag != nullptr && grid_for((int64_t)n * W, 256) > DV_MAX_PARKED_GRID) return DV_ERR_UNSUPPORTED;
     if (n == 0 || W == 0) return DV_OK;
     DV_REQUIRE(src && dst);
     hipLaunchKernelGGL(rows_segment_sum_kernel, dim3(grid_for((int64_t)n * W, 256)), dim3(256), 0, ST(stream), src,
@@ -1651,8 +1636,10 @@ extern "C" int dv_col_moments(const float* x, int64_t ldx, const float* r, int64
 }
 
 extern "C" int dv_loss_assemble(const dv_loss_term* terms, int32_t n_terms, const float* w_elbo,
-                                const float* w_cmpl, float* loss, dv_stream_t stream) {
+                                const float* w_cmpl, float* loss, const int32_t* halt, int32_t n_halt,
+                                dv_stream_t stream) {
     DV_REQUIRE(n_terms >= 0 && n_terms <= DV_MAX_LOSS_TERMS && (terms || n_terms == 0));
+    DV_REQUIRE(n_halt >= 0 && (halt || n_halt == 0));
     DV_REQUIRE(w_elbo && w_cmpl && loss);
     LossTerms lt;
     lt.n = n_terms;
@@ -1661,14 +1648,16 @@ extern "C" int dv_loss_assemble(const dv_loss_term* terms, int32_t n_terms, cons
         lt.t[i] = terms[i];
     }
     hipLaunchKernelGGL(loss_assemble_kernel, dim3(1), dim3(256), 0, ST(stream), lt, w_elbo, w_cmpl, loss,
-                       (int32_t*)nullptr, (const int32_t*)nullptr, 0, (int32_t*)nullptr, 0, CounterBump{});
+                       (int32_t*)nullptr, (const int32_t*)nullptr, 0, (int32_t*)nullptr, 0, CounterBump{}, halt, n_halt);
     DV_RETURN_LAUNCH();
 }
 
 extern "C" int dv_loss_assemble_after(int32_t* flag, const int32_t* ctr, int32_t add, int32_t* err, int32_t max_spins,
                                       const dv_loss_term* terms, int32_t n_terms, const float* w_elbo,
                                       const float* w_cmpl, float* loss, int32_t* c1, int32_t n1, int64_t inc1,
-                                      int32_t* c2, int32_t n2, int64_t inc2, dv_stream_t stream) {
+                                      int32_t* c2, int32_t n2, int64_t inc2, const int32_t* halt, int32_t n_halt,
+                                      dv_stream_t stream) {
+    DV_REQUIRE(n_halt >= 0 && (halt || n_halt == 0));
     DV_REQUIRE(n_terms >= 0 && n_terms <= DV_MAX_LOSS_TERMS && (terms || n_terms == 0));
     DV_REQUIRE(w_elbo && w_cmpl && loss && flag && ctr && err && max_spins > 0);
     DV_REQUIRE((!c1 || n1 == 1 || n1 == 2) && (!c2 || n2 == 1 || n2 == 2));
@@ -1680,7 +1669,7 @@ extern "C" int dv_loss_assemble_after(int32_t* flag, const int32_t* ctr, int32_t
         lt.t[i] = terms[i];
     }
     hipLaunchKernelGGL(loss_assemble_kernel, dim3(1), dim3(256), 0, ST(stream), lt, w_elbo, w_cmpl, loss, flag, ctr,
-                       add, err, max_spins, bump);
+                       add, err, max_spins, bump, halt, n_halt);
     DV_RETURN_LAUNCH();
 }
 

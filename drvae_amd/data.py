@@ -174,6 +174,7 @@ class DeviceBatcher:
                                        table=torch.zeros(n_b, self.batch_size, dtype=torch.int32, device=dev),
                                        base=torch.zeros(1, dtype=torch.int32, device=dev))
             p.feed = fd
+        p.feed_active = True
         parts = [m[torch.multinomial(w, c * n_b, replacement=True, generator=self.gen)].reshape(n_b, c)
                  for m, w, c in zip(self.members, self.gweights, self.group_counts) if c > 0]
         fd.table.copy_(torch.cat(parts, 1))
@@ -188,6 +189,7 @@ class DeviceBatcher:
     def feed(self, idx=None):
         """draw the next batch and write it into the bound engine's buffers (device to device)"""
         p = self.engine.plan
+        p.feed_active = False       # this batch is explicit data in XSRC, not a row of the epoch table
         idx = self.next_indices() if idx is None else idx
         self._idx32.copy_(idx)
         K.rows_gather(p.XSRC[:p.B], self.ds.x1, self._idx32)

@@ -158,8 +158,11 @@ class FusedStep(StepSchedule):
         eng.forward(); eng.backward(); eng.optimizer_step()
     """
 
-    def __init__(self, cfg, arena, seed=12345, concurrent=True):
+    def __init__(self, cfg, arena, seed=12345, concurrent=True, row0=0):
         self.cfg, self.arena = cfg, arena
+        # data parallelism: position of this rank's first row in the GLOBAL minibatch (the Philox draws are keyed
+        # by global row, SURVEY.md 8(e)); every rank uses the same ``seed``
+        self.row0 = int(row0)
         self.dev = arena.device
         self.iters = 0                      # finished_training_iters (src/DGMMixin.py:124)
         self.plan = None
@@ -255,7 +258,7 @@ class FusedStep(StepSchedule):
             rows = rows[has_y]               # supervised-only model ignores unlabeled rows (src/VFAE.py:445-450)
         # the plan (index lists, buffers, captured graph) depends on the group STRUCTURE only; the
         # class labels of the labeled rows are data and are refreshed in place
-        key = (len(rows), has_x2[rows].tobytes(), has_y[rows].tobytes(), counts)
+        key = (len(rows), has_x2[rows].tobytes(), has_y[rows].tobytes(), counts, self.row0)
         if self.plan is None or self.plan.key != key:
             self.plan = self._plans.get(key)
             if self.plan is None:
@@ -275,6 +278,8 @@ class FusedStep(StepSchedule):
         parallelism; default: this batch's own counts (src/DrVAE.py:611-616)."""
         cfg = self.cfg
         p, rows = self.set_structure(has_x2, has_y, counts)
+        p.feed_active = False       # explicit data supersedes an installed epoch feed (a captured step that
+        #                             gathers from the feed then refuses to replay: ``replay`` checks the source)
         n_in = len(np.asarray(has_y.cpu() if torch.is_tensor(has_y) else has_y).reshape(-1))
         sel = torch.as_tensor(rows, device=self.dev) if len(rows) != n_in else None
         p.XSRC[:p.B].copy_(x1.index_select(0, sel) if sel is not None else x1)
@@ -316,11 +321,11 @@ class FusedStep(StepSchedule):
         """Fresh on-device N(0,1) for every draw of the step (Philox, one launch).  ``bump=False``: the
         Philox counter is advanced later, together with the step counter, by ``optimizer_step`` (one
         launch less on the train step's critical path)."""
-        n = (self.plan.noise.numel() + 3) // 4
+        n = 1       # the Philox counter counts draw EVENTS (row-keyed draws: see ``_Plan.noise_desc``)
         if self._rec == 'main' and self.noise_ahead:
             self._rng_pending = n         # dual-graph step: the side chain of the PREVIOUS step has drawn them
             return
-        K.fill_normal(self.plan.noise, self.seed, self.rng_ctr)
+        K.fill_normal_rows(self.plan.noise, self.plan.noise_desc, self.seed, self.rng_ctr)
         self._noise_stale = True          # (an eager draw: a later replay must draw for its own counter first)
         if bump:
             K.counter_add(self.rng_ctr, n)
@@ -346,7 +351,7 @@ class FusedStep(StepSchedule):
             Qmu, Qlv = Q[:, :Z1], Q[:, Z1:]
         else:
             # ---- inputs (+ training noise N(0,1)*add_noise_var, src/DrVAE.py:404-407,414-417): one gather
-            fd = p.feed if (self.fuse_bwd and self.training) else None
+            fd = p.live_feed if (self.fuse_bwd and self.training) else None
             if fd is not None:
                 # batch (optimiser step - epoch base) of the epoch's index table, straight from the
                 # HBM-resident dataset; also refreshes the label-dependent index buffers
@@ -496,7 +501,8 @@ class FusedStep(StepSchedule):
             bump = [(self.step_dev, 1)] + ([(self.rng_ctr, self._rng_pending)] if getattr(self, '_rng_pending', 0) else [])
             self._rng_pending = 0
             self._ctr_bumped = True
-        K.loss_assemble(self.arena.loss, [] if terms_elsewhere else terms, p.w_elbo, p.w_cmpl, after=after, bump=bump)
+        K.loss_assemble(self.arena.loss, [] if terms_elsewhere else terms, p.w_elbo, p.w_cmpl, after=after, bump=bump,
+                        halt=self.sync_err)
 
     # --------------------------------------------------------------------- backward
     def backward(self):
@@ -617,13 +623,13 @@ class FusedStep(StepSchedule):
                     a = self.arena
                     K.flag_wait(self.flags[4:5], self.side_ctr, self.sync_err[8:10])
                     K.adam_l2(a.param[hs:a.n_live], a.grad[hs:a.n_live], a.exp_avg[hs:a.n_live], a.exp_avg_sq[hs:a.n_live],
-                              self.side_t, lr=cfg.learning_rate, weight_decay=cfg.weight_decay)
+                              self.side_t, lr=cfg.learning_rate, weight_decay=cfg.weight_decay, halt=self.sync_err)
                     self._loss_scalars()   # a leaf too; the wait above also covers the main chain's NLL rows
                 if self.noise_ahead:
                     # the next step's N(0,1) draws: every reader of this step's is through once the encoder
                     # backward has started (the main chain publishes that), and the Philox counter has advanced
                     K.flag_wait(self.flags[5:6], self.side_ctr, self.sync_err[10:12])
-                    K.fill_normal(p.noise, self.seed, self.rng_ctr)
+                    K.fill_normal_rows(p.noise, p.noise_desc, self.seed, self.rng_ctr)
                 K.flag_publish(self.flags[3:4], self.side_ctr)   # ... and now the side chain's late work is final
             K.counters_add2(self.side_ctr, 1, self.side_t, 1)
             return
@@ -641,12 +647,16 @@ class FusedStep(StepSchedule):
             self.branch.join()
         # (only where the join does not wait: every workgroup of the consumer polls the flag, and a long wait -- VFAE:
         # its side chain is the longer one, 30 us/step -- slows the very chain it waits for: 0.184 -> 0.208 ms)
-        fold_join = mode == 5 and side_adam and self.fold_join and cfg.has_pert
+        # ... and only where the parked grid is a small fraction of what the chip holds resident (256 CUs x 8
+        # workgroups): a consumer grid that filled the chip would leave the side chain nowhere to run
+        fold_join = (mode == 5 and side_adam and self.fold_join and cfg.has_pert
+                     and (B * Z1 + 255) // 256 <= 256)
+        park = bump = None
         if fold_join:
             # no launch of its own for the join: the first consumer of the side chain's gradients (below) parks on
             # the flag itself, and the counters ride on the sample-backward launch
-            K.arm_park(self.flags[1:2], self.step_dev, self.sync_err[0:2])
-            K.arm_bump(*([(self.step_dev, 1)] + ([(self.rng_ctr, self._rng_pending)] if getattr(self, '_rng_pending', 0) else [])))
+            park = (self.flags[1:2], self.step_dev, self.sync_err[0:2])
+            bump = [(self.step_dev, 1)] + ([(self.rng_ctr, self._rng_pending)] if getattr(self, '_rng_pending', 0) else [])
             self._rng_pending = 0
             self._ctr_bumped = True
         elif mode == 5:    # the launch that assembles the loss scalars also parks on the side chain's flag
@@ -669,7 +679,7 @@ class FusedStep(StepSchedule):
             # wrt both arguments, the residual path, and the side chain's share of d/dz1
             K.z2f_post_bwd(p.DP2, DZ1, DQ[B:] if Np else None, p.DZ2F, p.DZDEC[p.o3:] if Np else None, p.pair_slot,
                            p.E2F, P2, Q[B:] if Np else None, p.c_klz2, p.KLZ2raw, cfg.kl_min,
-                           p.DZ1B if cfg.has_y else None, L, B, Np)
+                           p.DZ1B if cfg.has_y else None, L, B, Np, park=park)
             # perturbation function: mu = z1 + z1 W^T + b, logvar head
             p.c_z2F.backward(p.DP2, [Z1blk], [[(DZ1, 1.0, 1.0)]])
         elif cfg.has_y:
@@ -679,7 +689,7 @@ class FusedStep(StepSchedule):
         fp = cfg.has_y and p.Mf
         K.reparam_bwd_seg(DQ[:B, :Z1], DQ[:B, Z1:], p.DZDEC, p.E12, Qlv, p.zseg_ptr, p.zseg_rows,
                           extra=p.DQFP if fp else None, ex_ptr=p.q_ptr if fp else None,
-                          ex_rows=p.q_rows if fp else None)
+                          ex_rows=p.q_rows if fp else None, bump=bump)
         if cfg.kind == 'pvae':
             K.kl_rows_bwd(DQ[:, :Z1], DQ[:, Z1:], None, None, p.c_klp, p.KLPraw, Qmu, Qlv, prior=(0.0, 0.0),
                           free_bits=True, kl_min=cfg.kl_min, beta=1.0)
@@ -707,7 +717,7 @@ class FusedStep(StepSchedule):
         if self._adam_gate is not None:   # dual-graph step: the classifier's dW may still be in flight on the side chain
             kw['gate'], self._adam_gate = self._adam_gate, None
         step(a.param[:n], a.grad[:n], a.exp_avg[:n], a.exp_avg_sq[:n], self.step_dev, lr=cfg.learning_rate,
-             weight_decay=cfg.weight_decay, gscale=gscale, **kw)
+             weight_decay=cfg.weight_decay, gscale=gscale, halt=self.sync_err, **kw)
 
     def train_step(self, noise=None, allreduce=None):
         """forward + backward (+ gradient all-reduce) + Adam + iteration count: the body of

@@ -217,6 +217,7 @@ class FitMixin:
     def _epoch_device(self, batcher, epoch, verbose):
         """one epoch of hipGraph replays fed by the device batcher; returns the mean train objective"""
         eng = self.engine()
+        self._assert_arena_aliased()
         batcher.bind(eng, counts=getattr(self, '_global_counts', None))
         eng.add_noise = bool(self.add_noise)
         eng.iters = self.finished_training_iters
@@ -226,7 +227,7 @@ class FitMixin:
         else:
             batcher.feed()
         if getattr(eng, '_graph_key', None) != eng.plan.key or getattr(eng, '_graph_noise', None) != eng.add_noise \
-                or getattr(eng, '_graph_feed', None) is not eng.plan.feed:
+                or getattr(eng, '_graph_feed', None) is not eng.plan.live_feed:
             eng.capture(split_for_allreduce=getattr(self, '_allreduce', None) is not None)
             eng._graph_noise = eng.add_noise
             if getattr(self, '_allreduce', None) is None:
@@ -241,7 +242,7 @@ class FitMixin:
         every = max(10, n_b / 10)
         total = torch.zeros((), device=eng.dev)
         for b in range(n_b):
-            if eng.plan.feed is None:
+            if eng.plan.live_feed is None:
                 batcher.feed()
             eng.replay(allreduce=getattr(self, '_allreduce', None))
             loss = self._loss_tensors(eng)
@@ -254,6 +255,7 @@ class FitMixin:
         return mean
 
     def _epoch_loader(self, loader, epoch, verbose):
+        self._assert_arena_aliased()
         n_b = len(loader)
         every = max(10, n_b / 10)
         total = None

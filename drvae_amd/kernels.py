@@ -173,25 +173,60 @@ def reparam_bwd(dmu, dsd, dz, eps, sd, *, mode=GAUSS_LOGVAR, src_idx=None, reps=
                'dv_reparam_bwd')
 
 
+def _wait(park):
+    """(flag, ctr, err[, add[, max_spins]]) -> dv_wait (None: no wait)"""
+    if park is None:
+        return None
+    flag, ctr, err = park[:3]
+    w = _lib.Wait()
+    w.flag, w.ctr, w.err = _i32(flag), _i32(ctr), _i32(err)
+    w.add = park[3] if len(park) > 3 else 1
+    w.max_spins = park[4] if len(park) > 4 and park[4] is not None else WAIT_SPINS
+    return C.byref(w)
+
+
+def _bump(counters):
+    """up to two (counter, inc) -> dv_bump (None / empty: nothing)"""
+    cs = [c for c in (counters or ()) if c[0] is not None]
+    if not cs:
+        return None
+    assert len(cs) <= 2
+    b = _lib.Bump()
+    for i, (c, inc) in enumerate(cs):
+        b.c[i], b.n[i], b.inc[i] = _i32(c), c.numel(), inc
+    return C.byref(b)
+
+
+def _halt(halt):
+    """the (err, ticks) pairs of a step's device-side waits -> (pointer, number of pairs)"""
+    if halt is None:
+        return None, 0
+    assert halt.numel() % 2 == 0
+    return _i32(halt), halt.numel() // 2
+
+
 def reparam_bwd_seg(dmu, dsd, dz, eps, sd, seg_ptr, seg_rows, *, mode=GAUSS_LOGVAR, extra=None, ex_ptr=None,
-                    ex_rows=None, beta=0.0):
-    """CSR backward of the reparameterisation (+ row-aligned extra (dmu|dsd) rows), see dv_reparam_bwd_seg."""
+                    ex_rows=None, beta=0.0, bump=None):
+    """CSR backward of the reparameterisation (+ row-aligned extra (dmu|dsd) rows), see dv_reparam_bwd_seg.
+    ``bump``: up to two (counter, inc) the launch advances as well."""
     nq, Z = seg_ptr.numel() - 1, dz.shape[1]
     assert _ld(dmu) == _ld(dsd)
     _lib.check(_lib.load().dv_reparam_bwd_seg(_f32(dz), _ld(dz), _f32(eps), _ld(eps), _f32(sd), _ld(sd),
                                               _i32(seg_ptr), _i32(seg_rows), nq, Z, mode, _f32(extra), _ld(extra),
                                               _i32(ex_ptr), _i32(ex_rows), _f32(dmu), _f32(dsd), _ld(dmu), beta,
-                                              _stream()), 'dv_reparam_bwd_seg')
+                                              _bump(bump), _stream()), 'dv_reparam_bwd_seg')
 
 
-def z2f_post_bwd(dp2, dz1, dq2, dz2f, dzdec_pert, pair_slot, eps, p2, q2, coef, raw, kl_min, dz1b, L, B, Np):
-    """fused backward of the z2Fz1 sample / KL(q(z2|x2)||p(z2|z1)) / residual block, see dv_z2f_post_bwd."""
+def z2f_post_bwd(dp2, dz1, dq2, dz2f, dzdec_pert, pair_slot, eps, p2, q2, coef, raw, kl_min, dz1b, L, B, Np,
+                 park=None):
+    """fused backward of the z2Fz1 sample / KL(q(z2|x2)||p(z2|z1)) / residual block, see dv_z2f_post_bwd.
+    ``park`` = (flag, ctr, err[, add[, max_spins]]): the launch first parks on another chain's flag."""
     Z = dz2f.shape[1]
     _lib.check(_lib.load().dv_z2f_post_bwd(_f32(dz2f), _ld(dz2f), _f32(dzdec_pert), _ld(dzdec_pert),
                                            _i32(pair_slot), _f32(eps), _ld(eps), _f32(p2), _ld(p2), _f32(q2),
                                            _ld(q2), _f32(coef), _f32(raw), kl_min, _f32(dz1b), _ld(dz1b),
                                            _f32(dp2), _ld(dp2), _f32(dz1), _ld(dz1), _f32(dq2), _ld(dq2), L, B, Np, Z,
-                                           _stream()), 'dv_z2f_post_bwd')
+                                           _wait(park), _stream()), 'dv_z2f_post_bwd')
 
 
 # --------------------------------------------------------------------------- KL rows
@@ -394,13 +429,14 @@ def batch_feed(xin, x1, x2, y32, table, n_batches, ctr, base, *, pair_rows=None,
                'dv_batch_feed')
 
 
-def rows_segment_sum(dst, src, *, seg_ptr=None, seg_rows=None, w=None, n=None, dst_idx=None, beta=0.0, width=None):
+def rows_segment_sum(dst, src, *, seg_ptr=None, seg_rows=None, w=None, n=None, dst_idx=None, beta=0.0, width=None,
+                     park=None):
     if n is None:
         n = seg_ptr.numel() - 1 if seg_ptr is not None else (seg_rows.numel() if seg_rows is not None else
                                                               src.shape[0])
     W = dst.shape[1] if width is None else width
     _lib.check(_lib.load().dv_rows_segment_sum(_f32(src), _ld(src), _i32(seg_ptr), _i32(seg_rows), _f32(w), n, W,
-                                               _i32(dst_idx), _f32(dst), _ld(dst), beta, _stream()),
+                                               _i32(dst_idx), _f32(dst), _ld(dst), beta, _wait(park), _stream()),
                'dv_rows_segment_sum')
 
 
@@ -427,23 +463,26 @@ def col_moments(out, x, r):
                'dv_col_moments')
 
 
-def loss_assemble(loss, terms, w_elbo, w_cmpl, after=None, bump=()):
+def loss_assemble(loss, terms, w_elbo, w_cmpl, after=None, bump=(), halt=None):
     """terms: list of (x, w_or_None, scale, out_index); see ``dv_loss_assemble``.  ``after`` =
     (flag, counter, err, add, max_spins): park like ``flag_wait`` inside the same launch first;
-    ``bump`` (with ``after`` only) = up to two (counter, inc): advanced at the end of the launch."""
+    ``bump`` (with ``after`` only) = up to two (counter, inc): advanced at the end of the launch;
+    ``halt``: the (err, ticks) pairs of the step's waits -- any error set: the scalars come out NaN."""
+    hp, hn = _halt(halt)
     arr = (_lib.LossTerm * max(len(terms), 1))()
     for i, (x, w, scale, out) in enumerate(terms):
         arr[i].x, arr[i].w, arr[i].n, arr[i].scale, arr[i].out = _f32(x), _f32(w), x.numel(), scale, out
     if after is None:
-        _lib.check(_lib.load().dv_loss_assemble(arr, len(terms), _f32(w_elbo), _f32(w_cmpl), _f32(loss), _stream()),
-                   'dv_loss_assemble')
+        _lib.check(_lib.load().dv_loss_assemble(arr, len(terms), _f32(w_elbo), _f32(w_cmpl), _f32(loss), hp, hn,
+                                                _stream()), 'dv_loss_assemble')
     else:
         flag, ctr, err, add, spins = after
         cs = list(bump) + [(None, 0)] * (2 - len(bump))
         _lib.check(_lib.load().dv_loss_assemble_after(
             _i32(flag), _i32(ctr), add, _i32(err), spins, arr, len(terms), _f32(w_elbo), _f32(w_cmpl), _f32(loss),
             _i32(cs[0][0]), 0 if cs[0][0] is None else cs[0][0].numel(), cs[0][1],
-            _i32(cs[1][0]), 0 if cs[1][0] is None else cs[1][0].numel(), cs[1][1], _stream()), 'dv_loss_assemble_after')
+            _i32(cs[1][0]), 0 if cs[1][0] is None else cs[1][0].numel(), cs[1][1], hp, hn, _stream()),
+            'dv_loss_assemble_after')
 
 
 def axpby(y, x, a=1.0, b=0.0):
@@ -452,23 +491,27 @@ def axpby(y, x, a=1.0, b=0.0):
 
 
 # ------------------------------------------------------------------------- optimiser
-def adam_l2(p, g, m, v, step_dev, *, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, gscale=1.0, gate=None):
-    """``gate`` = (flag, counter, add, err, lo, hi): elements [lo, hi) wait for the flag (``dv_adam_l2_gated``)"""
+def adam_l2(p, g, m, v, step_dev, *, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, gscale=1.0, gate=None,
+            halt=None):
+    """``gate`` = (flag, counter, add, err, lo, hi): elements [lo, hi) wait for the flag (``dv_adam_l2_gated``);
+    ``halt``: the (err, ticks) pairs of the step's waits -- any error set: nothing is updated"""
     assert p.is_contiguous() and g.is_contiguous() and m.is_contiguous() and v.is_contiguous()
+    hp, hn = _halt(halt)
     if gate is None:
         _lib.check(_lib.load().dv_adam_l2(_f32(p), _f32(g), _f32(m), _f32(v), p.numel(), lr, beta1, beta2, eps,
-                                          weight_decay, gscale, _i32(step_dev), _stream()), 'dv_adam_l2')
+                                          weight_decay, gscale, _i32(step_dev), hp, hn, _stream()), 'dv_adam_l2')
     else:
         flag, ctr, add, err, lo, hi = gate
         _lib.check(_lib.load().dv_adam_l2_gated(_f32(p), _f32(g), _f32(m), _f32(v), p.numel(), lr, beta1, beta2, eps,
                                                 weight_decay, gscale, _i32(step_dev), _i32(flag), _i32(ctr), add,
-                                                _i32(err), WAIT_SPINS, lo, hi, _stream()), 'dv_adam_l2_gated')
+                                                _i32(err), WAIT_SPINS, lo, hi, hp, hn, _stream()), 'dv_adam_l2_gated')
 
 
-def adamax_l2(p, g, m, u, step_dev, *, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, gscale=1.0):
+def adamax_l2(p, g, m, u, step_dev, *, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, gscale=1.0, halt=None):
     assert p.is_contiguous() and g.is_contiguous() and m.is_contiguous() and u.is_contiguous()
+    hp, hn = _halt(halt)
     _lib.check(_lib.load().dv_adamax_l2(_f32(p), _f32(g), _f32(m), _f32(u), p.numel(), lr, beta1, beta2, eps,
-                                        weight_decay, gscale, _i32(step_dev), _stream()), 'dv_adamax_l2')
+                                        weight_decay, gscale, _i32(step_dev), hp, hn, _stream()), 'dv_adamax_l2')
 
 
 def flag_publish(flag, ctr, add=1):
@@ -487,19 +530,6 @@ def flag_wait(flag, ctr, err, add=1, max_spins=None):
     _lib.check(_lib.load().dv_flag_wait(_i32(flag), _i32(ctr), add, _i32(err), max_spins, _stream()), 'dv_flag_wait')
 
 
-def arm_park(flag, ctr, err, add=1, max_spins=None):
-    """the next ``z2f_post_bwd`` / ``rows_segment_sum`` launch parks on the flag first (``dv_arm_park``)"""
-    _lib.check(_lib.load().dv_arm_park(_i32(flag), _i32(ctr), add, _i32(err), WAIT_SPINS if max_spins is None else max_spins),
-               'dv_arm_park')
-
-
-def arm_bump(*counters):
-    """the next ``reparam_bwd_seg`` launch also advances up to two (counter, inc) (``dv_arm_bump``)"""
-    cs = list(counters) + [(None, 0)] * (2 - len(counters))
-    _lib.check(_lib.load().dv_arm_bump(_i32(cs[0][0]), 0 if cs[0][0] is None else cs[0][0].numel(), cs[0][1],
-                                       _i32(cs[1][0]), 0 if cs[1][0] is None else cs[1][0].numel(), cs[1][1]), 'dv_arm_bump')
-
-
 def counter_add(counter, inc=1):
     _lib.check(_lib.load().dv_counter_add(_i32(counter), counter.numel(), inc, _stream()), 'dv_counter_add')
 
@@ -507,6 +537,14 @@ def counter_add(counter, inc=1):
 def counters_add2(c1, inc1, c2, inc2):
     _lib.check(_lib.load().dv_counters_add2(_i32(c1), c1.numel(), inc1, _i32(c2), c2.numel(), inc2, _stream()),
                'dv_counters_add2')
+
+
+def fill_normal_rows(arena, desc, seed, ctr_dev=None):
+    """row-keyed N(0,1) draws of a train step's noise arena: ``desc`` (R,4) int32 = {offset, width, draw id,
+    global row}; ``ctr_dev`` counts draw events (see ``dv_fill_normal_rows``)"""
+    assert arena.is_contiguous() and desc.dim() == 2 and desc.shape[1] == 4
+    _lib.check(_lib.load().dv_fill_normal_rows(_f32(arena), _i32(desc), desc.shape[0], seed, _i32(ctr_dev), _stream()),
+               'dv_fill_normal_rows')
 
 
 def fill_normal(out, seed, ctr_dev=None):

@@ -109,6 +109,34 @@ class _Plan:
         self.E2F = views[3].view(L * B, Z1) if cfg.has_pert else None
         self.E3 = views[4].view(self.Mf, Z3) if cfg.has_y else None
         self.EY = views[5].view(L * B, Y) if (cfg.has_y and cfg.cont) else None
+        # row descriptors of the on-device draws (dv_fill_normal_rows): {offset, width, draw id, GLOBAL row}.
+        # A draw is identified by what it is in the reference's order of draws (x1 / x2 input
+        # noise, then per sample l: z1, z2, z2Fz1 eps, then z3 eps per (l, class)) and by the row's position in
+        # the GLOBAL minibatch (``eng.row0`` + position in this rank's shard), never by where it sits in a
+        # buffer: the values do not depend on grouping, stacking or the number of ranks
+        grow = int(eng.row0) + np.asarray(rows, np.int64)
+        desc, off = [], 0
+
+        def seg(n_rows, width, draw, g):
+            nonlocal off
+            if n_rows:
+                r = np.arange(n_rows, dtype=np.int64)
+                desc.append(np.stack([off + r * width, np.full(n_rows, width), np.broadcast_to(draw, (n_rows,)),
+                                      np.broadcast_to(g, (n_rows,))], 1))
+            off += n_rows * width
+        lB, lN = np.repeat(np.arange(L), B), np.repeat(np.arange(L), Np)
+        seg(B, X, 0, grow)
+        seg(Np, X, 1, grow[self.pair_host])
+        seg(L * B, Z1, 2 + lB, np.tile(grow, L))
+        seg(L * Np, Z1, 2 + L + lN, np.tile(grow[self.pair_host], L))
+        if cfg.has_pert:
+            seg(L * B, Z1, 2 + 2 * L + lB, np.tile(grow, L))
+        if cfg.has_y:
+            seg(self.Mf, Z3, 2 + 3 * L + self.fp_l_host * Y + self.fp_slot_host, grow[self.fp_i_host])
+            if cfg.cont:
+                seg(L * B, Y, 2 + 3 * L + L * Y + lB, np.tile(grow, L))
+        assert off == self.noise.numel() and off < 2 ** 31
+        self.noise_desc = i32(np.concatenate(desc) if desc else np.zeros((0, 4)))
         # ---- activations / gradients
         self.XIN = mat(Me, X)
         self.ZDEC, self.DZDEC = mat(Md, Z1), mat(Md, Z1)
@@ -158,6 +186,13 @@ class _Plan:
         self._cfg = cfg
         self.x1 = self.x2 = None
         self.feed = None        # graph-resident input feed (drvae_amd.data.DeviceBatcher.begin_epoch)
+        self.feed_active = False   # ... and whether it is the source of the NEXT train step: explicit data
+        #                            (FusedStep.set_batch, DeviceBatcher.feed) switches it off, begin_epoch on
+
+    @property
+    def live_feed(self):
+        """the installed epoch feed if it is the current input source, else None (inputs come from XSRC)"""
+        return self.feed if self.feed_active else None
 
     def set_labels_host(self, yv):
         """class labels of this batch's rows (host ints; only the labeled rows' entries matter)"""

@@ -31,6 +31,8 @@ def _masked_stream(bits, device):
     return torch.cuda.ExternalStream(st.value, device=device)
 
 
+SYNC_POLL = int(os.environ.get('DRVAE_SYNC_POLL', '64'))     # steps between two polls of the wait-error words
+
 _PARTITION_STREAMS = {}      # device index -> {reserved CUs -> (main stream, side stream) | None}
 
 
@@ -141,7 +143,7 @@ class StepSchedule:
         finally:
             self._rec = 'both'
         self._graph_key = self.plan.key
-        self._graph_feed = self.plan.feed
+        self._graph_feed = self.plan.live_feed
         return self
 
     # ------------------------------------------------------------ CU partition
@@ -292,7 +294,36 @@ class StepSchedule:
     def check_sync(self):
         """raise if a device-side wait of the dual-graph schedule ever timed out (results would be stale)"""
         if int(self.sync_err[0::2].abs().sum()) != 0:
-            raise RuntimeError('drvae_amd: a device-side chain wait timed out (main / side stream ordering)')
+            self._raise_sync(self.sync_err.cpu().tolist())
+
+    @staticmethod
+    def _raise_sync(words):
+        sites = [i for i, v in enumerate(words[0::2]) if v != 0]
+        raise RuntimeError('drvae_amd: a device-side chain wait timed out (main / side stream ordering; wait site(s) %s). '
+                           'From that step on the loss scalars are NaN and the optimiser has left the parameters '
+                           'untouched: the state is that of the last good step.' % sites)
+
+    def _poll_sync(self):
+        """Called once per replayed step.  Every ``SYNC_POLL`` steps the sticky error words of the device-side
+        waits are copied to pinned host memory asynchronously; the copy issued one period earlier is checked
+        first (waiting for it bounds how far the host runs ahead to two periods of queued steps, so the device
+        never idles on it).  A timed-out wait therefore raises within two periods even in a ``replay()`` loop
+        that never reads the losses."""
+        self._since_poll = getattr(self, '_since_poll', 0) + 1
+        if self._since_poll < SYNC_POLL:
+            return
+        self._since_poll = 0
+        if getattr(self, '_sync_host', None) is None:
+            self._sync_host = torch.zeros(self.sync_err.numel(), dtype=torch.int32).pin_memory()
+            self._sync_event = None
+        if self._sync_event is not None:
+            self._sync_event.synchronize()
+            words = self._sync_host.tolist()
+            if any(words[0::2]):
+                self._raise_sync(words)
+        self._sync_host.copy_(self.sync_err, non_blocking=True)
+        self._sync_event = torch.cuda.Event()
+        self._sync_event.record()
 
     def _capture_main(self, split_for_allreduce):
         if split_for_allreduce == 'overlap' and self.arena.late_end < self.arena.xchg.numel():
@@ -343,10 +374,10 @@ class StepSchedule:
     def replay(self, allreduce=None):
         """One captured train step.  New data is fed by copying into plan.x1 / plan.x2 in place."""
         assert self._graph_key == self.plan.key, 'batch structure changed: capture again'
-        assert self._graph_feed is self.plan.feed, 'input feed changed: capture again'
+        assert self._graph_feed is self.plan.live_feed, 'input source changed (epoch feed <-> explicit batch): capture again'
         self.plan.set_beta(self.beta_pert())      # 0.01 on iteration 0, 1.0 afterwards (device-side coefficients)
         if self.noise_ahead and self._noise_stale:        # first replay (or an eager draw since): this step's noise
-            K.fill_normal(self.plan.noise, self.seed, self.rng_ctr)
+            K.fill_normal_rows(self.plan.noise, self.plan.noise_desc, self.seed, self.rng_ctr)
             self._noise_stale = False
         if self._side_graph is not None:         # first: its wait kernel is parked before the main chain publishes
             with torch.cuda.stream(self.flag_side):
@@ -365,3 +396,5 @@ class StepSchedule:
                 allreduce(self.arena.xchg)
             self._graphs[1].replay()
         self.iters += 1
+        if self._side_graph is not None:
+            self._poll_sync()

@@ -13,7 +13,9 @@
  *    `dv_stream_t` = hipStream_t passed as void*.  No torch types.
  *  - all matrices fp32 row-major with unit inner stride; index arrays int32.
  *  - every call only ENQUEUES work on `stream`: no allocation, no host sync, no
- *    hidden state -> re-entrant and hipGraph-capturable (SURVEY.md 8(b) threading).
+ *    hidden state (nothing is armed, cached or remembered between calls: whatever a launch
+ *    waits on or advances is an explicit argument of THAT call) -> re-entrant and
+ *    hipGraph-capturable (SURVEY.md 8(b) threading).
  *  - returns DV_OK (0) or a negative DV_ERR_* code; never throws, never aborts.
  *  - `beta` arguments: out = beta*out + result (beta == 0 never reads out).
  */
@@ -28,7 +30,7 @@ extern "C" {
 
 typedef void* dv_stream_t;
 
-#define DV_ABI_VERSION 1
+#define DV_ABI_VERSION 2
 
 enum { DV_OK = 0, DV_ERR_ARG = -1, DV_ERR_LAUNCH = -2, DV_ERR_UNSUPPORTED = -3 };
 
@@ -47,6 +49,28 @@ enum { DV_EPI_PLAIN = 0, DV_EPI_FWD = 1, DV_EPI_BWD = 2 };
 
 int dv_abi_version(void);
 const char* dv_error_string(int code);
+
+/* A device-side wait carried by a launch (see dv_flag_wait): the launch first parks until
+ * flag[0] >= ctr[0] + add.  Bounded: after max_spins polls it records err[0] = 1 (sticky: nothing on
+ * the device clears it) and goes on; err[1] accumulates the time parked (wall_clock64 ticks).  Every
+ * consumer of err words -- dv_loss_assemble*, dv_adam_l2*, dv_adamax_l2 through their `halt`
+ * argument -- then poisons the loss scalars with NaN and freezes the parameters, so a timed-out wait
+ * can never train on stale data silently.  flag == NULL: no wait. */
+typedef struct dv_wait {
+    int32_t* flag;
+    const int32_t* ctr;
+    int32_t add;
+    int32_t max_spins;
+    int32_t* err;
+} dv_wait;
+
+/* up to two device counters (1 or 2 int32 words each: int32 / uint64 little-endian) advanced by a
+ * launch that carries the bump (see dv_counters_add2); c == NULL: unused slot */
+typedef struct dv_bump {
+    int32_t* c[2];
+    int32_t n[2];
+    int64_t inc[2];
+} dv_bump;
 
 /* ------------------------------------------------------------------ GEMM family
  * C[M,N] = epilogue( alpha * sum_k Aop[m,k] * Bop[k,n] ) + beta*C      (fp32 MFMA,
@@ -161,7 +185,7 @@ int dv_reparam_bwd(const float* dz, int64_t ldz, const float* eps, int64_t lde, 
 int dv_reparam_bwd_seg(const float* dz, int64_t ldz, const float* eps, int64_t lde, const float* sd, int64_t ldq,
                        const int32_t* seg_ptr, const int32_t* seg_rows, int32_t nq, int32_t Z, int32_t mode,
                        const float* extra, int64_t ldx, const int32_t* ex_ptr, const int32_t* ex_rows, float* dmu,
-                       float* dsd, int64_t lddq, float beta, dv_stream_t stream);
+                       float* dsd, int64_t lddq, float beta, const dv_bump* bump, dv_stream_t stream);
 /* Backward of everything hanging on the z2Fz1 samples (src/DrVAE.py:431-433, 459-487) in one pass
  * over (row i < B, dim d < Z), looping the L samples r = l*B + i; jp = pair_slot[i] (-1: singleton):
  *   g       = dz2f[r] + (jp >= 0 ? dzdec_pert[l*Np + jp] : 0)
@@ -172,7 +196,8 @@ int dv_z2f_post_bwd(const float* dz2f, int64_t ld_dz2f, const float* dzdec_pert,
                     const int32_t* pair_slot, const float* eps, int64_t lde, const float* p2, int64_t ldp2,
                     const float* q2, int64_t ldq2, const float* coef, const float* raw, float kl_min,
                     const float* dz1b, int64_t ld_dz1b, float* dp2, int64_t ld_dp2, float* dz1, int64_t ld_dz1,
-                    float* dq2, int64_t ld_dq2, int32_t L, int32_t B, int32_t Np, int32_t Z, dv_stream_t stream);
+                    float* dq2, int64_t ld_dq2, int32_t L, int32_t B, int32_t Np, int32_t Z, const dv_wait* park,
+                    dv_stream_t stream);
 
 /* ------------------------------------------------ diagonal-Gaussian KL per row (K4)
  * row r = l*n + j: q row = qidx ? qidx[j] : j ; p row = pidx ? pidx[r] : r, or the
@@ -339,7 +364,7 @@ int dv_batch_feed(const float* x1, int64_t ld1, const float* x2, int64_t ld2, co
  * Deterministic (no atomics): the transpose of every gather above. */
 int dv_rows_segment_sum(const float* src, int64_t lds, const int32_t* seg_ptr, const int32_t* seg_rows,
                         const float* w, int32_t n, int32_t W, const int32_t* dst_idx, float* dst, int64_t ldd,
-                        float beta, dv_stream_t stream);
+                        float beta, const dv_wait* park, dv_stream_t stream);
 /* out[0] = beta*out[0] + scale * sum_i w[i]*x[idx?idx[i]:i]   (loss scalars; one workgroup) */
 int dv_weighted_sum(const float* x, const float* w, const int32_t* idx, int32_t n, float scale, float* out,
                     float beta, dv_stream_t stream);
@@ -366,7 +391,7 @@ typedef struct dv_loss_term {
     int32_t out; /* 0 RECL, 1 KLD, 2 PERT, 3 YL, 4 MMD */
 } dv_loss_term;
 int dv_loss_assemble(const dv_loss_term* terms, int32_t n_terms, const float* w_elbo, const float* w_cmpl,
-                     float* loss, dv_stream_t stream);
+                     float* loss, const int32_t* halt, int32_t n_halt, dv_stream_t stream);
 /* same, but first parks like dv_flag_wait(flag, ctr, add, err, max_spins) inside the launch (the terms
  * of another chain are read only after the wait; saves the separate wait launch), and last advances up
  * to two device counters like dv_counters_add2 (c1 / c2 may be NULL; c1 may alias ctr: it is read before;
@@ -375,7 +400,7 @@ int dv_loss_assemble(const dv_loss_term* terms, int32_t n_terms, const float* w_
 int dv_loss_assemble_after(int32_t* flag, const int32_t* ctr, int32_t add, int32_t* err, int32_t max_spins,
                            const dv_loss_term* terms, int32_t n_terms, const float* w_elbo, const float* w_cmpl,
                            float* loss, int32_t* c1, int32_t n1, int64_t inc1, int32_t* c2, int32_t n2,
-                           int64_t inc2, dv_stream_t stream);
+                           int64_t inc2, const int32_t* halt, int32_t n_halt, dv_stream_t stream);
 /* y[i] = a*x[i] + b*y[i] over n contiguous floats */
 int dv_axpby(const float* x, float a, float* y, float b, int64_t n, dv_stream_t stream);
 
@@ -386,7 +411,8 @@ int dv_axpby(const float* x, float a, float* y, float b, int64_t n, dv_stream_t 
  * read, not modified (bump it with dv_counter_add so graph replays advance). gscale
  * multiplies g first (1/world_size style scaling; 1.0 for summed gradients). */
 int dv_adam_l2(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
-               float eps, float weight_decay, float gscale, const int32_t* step_dev, dv_stream_t stream);
+               float eps, float weight_decay, float gscale, const int32_t* step_dev, const int32_t* halt,
+               int32_t n_halt, dv_stream_t stream);
 /* same sweep, but the elements [lo, hi) are touched only after another launch chain has published `flag`
  * (flag[0] >= ctr[0] + add, see dv_flag_publish): only the workgroups overlapping the range park (bounded
  * like dv_flag_wait: err[0] = 1 on time-out, err[1] += ticks parked), so gradients that are leaves of
@@ -394,19 +420,20 @@ int dv_adam_l2(float* p, const float* g, float* m, float* v, int64_t n, float lr
 int dv_adam_l2_gated(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                      float eps, float weight_decay, float gscale, const int32_t* step_dev, int32_t* flag,
                      const int32_t* ctr, int32_t add, int32_t* err, int32_t max_spins, int64_t lo, int64_t hi,
-                     dv_stream_t stream);
+                     const int32_t* halt, int32_t n_halt, dv_stream_t stream);
 /* torch.optim.Adamax with coupled L2 (the `optim_alg='adamax'` branch of src/DGMMixin.py:37-38):
  * u is the exponentially weighted infinity norm; same conventions as dv_adam_l2. */
 int dv_adamax_l2(float* p, const float* g, float* m, float* u, int64_t n, float lr, float beta1, float beta2,
-                 float eps, float weight_decay, float gscale, const int32_t* step_dev, dv_stream_t stream);
+                 float eps, float weight_decay, float gscale, const int32_t* step_dev, const int32_t* halt,
+                 int32_t n_halt, dv_stream_t stream);
 int dv_counter_add(int32_t* counter_lo_hi, int32_t n_words, int64_t inc, dv_stream_t stream);
-/* Joins folded into their consumers.  dv_arm_park: the calling thread's NEXT dv_z2f_post_bwd or
- * dv_rows_segment_sum launch first parks every workgroup like dv_flag_wait(flag, ctr, add, err, max_spins)
- * (the first consumer of another chain's results waits for them itself: no separate wait launch).
- * dv_arm_bump: its NEXT dv_reparam_bwd_seg launch also advances up to two device counters like
- * dv_counters_add2 (c1 / c2 may be NULL).  Both are consumed by that one launch. */
-int dv_arm_park(int32_t* flag, const int32_t* ctr, int32_t add, int32_t* err, int32_t max_spins);
-int dv_arm_bump(int32_t* c1, int32_t n1, int64_t inc1, int32_t* c2, int32_t n2, int64_t inc2);
+/* Joins folded into their consumers: dv_z2f_post_bwd and dv_rows_segment_sum take an optional `park`
+ * (every workgroup of the launch first parks like dv_flag_wait: the first consumer of another chain's
+ * results waits for them itself, no separate wait launch; keep such grids well below the chip's resident
+ * capacity), dv_reparam_bwd_seg an optional `bump` (the launch also advances up to two device counters
+ * like dv_counters_add2).  `halt` arguments (here and above): n_halt error words at halt[0], halt[2],
+ * halt[4] ... (the err[0] of the dv_wait sites of a step, laid out as (err, ticks) pairs); if any is
+ * non-zero the loss scalars come out NaN and the optimiser sweep leaves p / m / v untouched. */
 /* two device counters in one launch (the optimiser step count and the Philox counter of a train step) */
 int dv_counters_add2(int32_t* c1, int32_t n1, int64_t inc1, int32_t* c2, int32_t n2, int64_t inc2,
                      dv_stream_t stream);
@@ -424,6 +451,14 @@ int dv_flag_wait(int32_t* flag, const int32_t* ctr, int32_t add, int32_t* err, i
  * int32 words, device) + i/4, Box-Muller on the four outputs.  (the `normal_()` draws of
  * src/blocks.py:172,210 and src/DrVAE.py:405,415 moved on device). */
 int dv_fill_normal(float* out, int64_t n, uint64_t seed, const int32_t* ctr_dev, dv_stream_t stream);
+/* Row-keyed form for the train step's noise arena (SURVEY.md 8(e) "RNG under DP": results must not depend
+ * on the number of ranks).  desc = n_rows x {offset into arena (floats), width, draw id, GLOBAL minibatch
+ * row} (int32 x 4, 16-B aligned); element (row, col) = Philox(key = seed (^ ctr_dev[1] in the high word),
+ * counter = (col/4, global row, draw id, ctr_dev[0]))[col % 4] through Box-Muller.  ctr_dev counts draw
+ * EVENTS (one per train step: advance it by 1), so every rank holds the same value; a rank that owns rows
+ * [rB, (r+1)B) of the global minibatch draws exactly the values a single process would draw for them. */
+int dv_fill_normal_rows(float* arena, const int32_t* desc, int32_t n_rows, uint64_t seed, const int32_t* ctr_dev,
+                        dv_stream_t stream);
 
 #ifdef __cplusplus
 }

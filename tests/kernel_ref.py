@@ -203,7 +203,10 @@ def reparam_bwd(dmu, dsd, dz, eps, sd, *, mode=GAUSS_LOGVAR, src_idx=None, reps=
 
 
 def reparam_bwd_seg(dmu, dsd, dz, eps, sd, seg_ptr, seg_rows, *, mode=GAUSS_LOGVAR, extra=None, ex_ptr=None,
-                    ex_rows=None, beta=0.0):
+                    ex_rows=None, beta=0.0, bump=None):
+    for (c, inc) in (bump or ()):
+        if c is not None:
+            counter_add(c, inc)
     nq, Z = seg_ptr.numel() - 1, dz.shape[1]
     for i in range(nq):
         rows = seg_rows[int(seg_ptr[i]):int(seg_ptr[i + 1])].long()
@@ -219,7 +222,10 @@ def reparam_bwd_seg(dmu, dsd, dz, eps, sd, seg_ptr, seg_rows, *, mode=GAUSS_LOGV
         dsd[i] = (beta * dsd[i] if beta != 0.0 else 0) + b
 
 
-def z2f_post_bwd(dp2, dz1, dq2, dz2f, dzdec_pert, pair_slot, eps, p2, q2, coef, raw, kl_min, dz1b, L, B, Np):
+def z2f_post_bwd(dp2, dz1, dq2, dz2f, dzdec_pert, pair_slot, eps, p2, q2, coef, raw, kl_min, dz1b, L, B, Np,
+                 park=None):
+    if park is not None:
+        flag_wait(*park[:3])                  # single-threaded stand-in: the producer has run already
     Z = dz2f.shape[1]
     dev = dz2f.device
     slot = pair_slot.long() if (pair_slot is not None and Np) else torch.full((B,), -1, dtype=torch.long, device=dev)
@@ -525,7 +531,10 @@ def batch_feed(xin, x1, x2, y32, table, n_batches, ctr, base, *, pair_rows=None,
             onehot.copy_(torch.nn.functional.one_hot(cls.long(), n_classes).to(onehot.dtype))
 
 
-def rows_segment_sum(dst, src, *, seg_ptr=None, seg_rows=None, w=None, n=None, dst_idx=None, beta=0.0, width=None):
+def rows_segment_sum(dst, src, *, seg_ptr=None, seg_rows=None, w=None, n=None, dst_idx=None, beta=0.0, width=None,
+                     park=None):
+    if park is not None:
+        flag_wait(*park[:3])
     if n is None:
         n = seg_ptr.numel() - 1 if seg_ptr is not None else (seg_rows.numel() if seg_rows is not None else
                                                               src.shape[0])
@@ -562,7 +571,11 @@ def col_moments(out, x, r):
     out.copy_(torch.stack([xd.sum(0), (xd * xd).sum(0), ((xd - rd) ** 2).sum(0)], 0))
 
 
-def loss_assemble(loss, terms, w_elbo, w_cmpl, after=None, bump=()):
+def _halted(halt):
+    return halt is not None and bool((halt.reshape(-1)[0::2] != 0).any())
+
+
+def loss_assemble(loss, terms, w_elbo, w_cmpl, after=None, bump=(), halt=None):
     if after is not None:
         flag_wait(after[0], after[1], after[2], after[3], after[4])
     for (c, inc) in bump:
@@ -576,16 +589,19 @@ def loss_assemble(loss, terms, w_elbo, w_cmpl, after=None, bump=()):
         acc[out] = acc[out] + scale * ((v * w.reshape(-1)).sum() if w is not None else v.sum())
     acc[5] = (w_elbo[:3] * acc[:3]).sum()
     acc[6] = (w_cmpl[:8] * acc[:8]).sum()
-    loss[:8] = acc
+    loss[:8] = torch.full_like(acc, float('nan')) if _halted(halt) else acc
 
 
 def axpby(y, x, a=1.0, b=0.0):
     y.copy_(a * x + (b * y if b != 0.0 else 0))
 
 
-def adam_l2(p, g, m, v, step_dev, *, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, gscale=1.0, gate=None):
+def adam_l2(p, g, m, v, step_dev, *, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, gscale=1.0, gate=None,
+            halt=None):
     if gate is not None:
         flag_wait(gate[0], gate[1], gate[3], gate[2])
+    if _halted(halt):
+        return
     t = int(step_dev.reshape(-1)[0])
     gg = g * gscale
     if weight_decay != 0.0:
@@ -597,7 +613,9 @@ def adam_l2(p, g, m, v, step_dev, *, lr, beta1=0.9, beta2=0.999, eps=1e-8, weigh
     p.addcdiv_(m, denom, value=-(lr / bc1))
 
 
-def adamax_l2(p, g, m, u, step_dev, *, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, gscale=1.0):
+def adamax_l2(p, g, m, u, step_dev, *, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, gscale=1.0, halt=None):
+    if _halted(halt):
+        return
     t = int(step_dev.reshape(-1)[0])
     gg = g * gscale
     if weight_decay != 0.0:
@@ -616,16 +634,6 @@ def flag_wait(flag, ctr, err, add=1, max_spins=None):
         err[0] = 1                            # (err[1], the parked-time statistic, stays 0)
 
 
-def arm_park(flag, ctr, err, add=1, max_spins=None):
-    flag_wait(flag, ctr, err, add)            # single-threaded stand-in: the producer has run already
-
-
-def arm_bump(*counters):
-    for (c, inc) in counters:
-        if c is not None:
-            counter_add(c, inc)
-
-
 def counters_add2(c1, inc1, c2, inc2):
     counter_add(c1, inc1)
     counter_add(c2, inc2)
@@ -642,6 +650,16 @@ def counter_add(counter, inc=1):
         counter[1] = hi - (1 << 32) if hi >= (1 << 31) else hi
 
 
+def fill_normal_rows(arena, desc, seed, ctr_dev=None):
+    """Stand-in only (NOT bit-compatible with the device Philox stream), but keyed the same way: a value
+    depends on (seed, step, draw id, global row, column) only."""
+    base = 0 if ctr_dev is None else (int(ctr_dev[1]) << 32 | (int(ctr_dev[0]) & 0xffffffff))
+    g = torch.Generator(device='cpu')
+    for off, width, draw, grow in desc.cpu().tolist():
+        g.manual_seed((((seed * 1000003 + base) * 1000003 + draw) * 1000003 + grow) % (1 << 62))
+        arena[off:off + width] = torch.randn(width, generator=g).to(arena.device)
+
+
 def fill_normal(out, seed, ctr_dev=None):
     """Stand-in only (NOT bit-compatible with the device Philox stream)."""
     g = torch.Generator(device='cpu')
@@ -650,7 +668,7 @@ def fill_normal(out, seed, ctr_dev=None):
     out.copy_(torch.randn(out.shape, generator=g).to(out.device))
 
 
-FUNCTIONS = ['arm_park', 'arm_bump', 'adamax_l2', 'batch_feed', 'mmd_rff_fwd', 'mmd_rff_bwd', 'counters_add2', 'ycont_fwd', 'ycont_bwd', 'flag_publish', 'flag_wait', 'gemm', 'linear_fwd', 'linear_bwd_data', 'linear_bwd_weight', 'linear_bwd_pair', 'colsum', 'act_bwd_', 'wn_scale', 'wn_bwd',
+FUNCTIONS = ['fill_normal_rows', 'adamax_l2', 'batch_feed', 'mmd_rff_fwd', 'mmd_rff_bwd', 'counters_add2', 'ycont_fwd', 'ycont_bwd', 'flag_publish', 'flag_wait', 'gemm', 'linear_fwd', 'linear_bwd_data', 'linear_bwd_weight', 'linear_bwd_pair', 'colsum', 'act_bwd_', 'wn_scale', 'wn_bwd',
              'reparam_fwd', 'reparam_bwd', 'reparam_bwd_seg', 'z2f_post_bwd', 'kl_rows_fwd', 'kl_rows_bwd', 'nll_rows_fwd', 'nll_rows_bwd', 'nll_rows_fwdbwd',
              'softmax_clamp_fwd', 'softmax_clamp_bwd', 'cat_terms_fwd', 'cat_terms_bwd', 'smalln_fwd', 'smalln_bwd_data',
              'smalln_bwd_weight', 'ymarg_fwd', 'ymarg_bwd', 'ymarg_fwdbwd',

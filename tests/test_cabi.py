@@ -38,7 +38,9 @@ def test_header_declares_the_whole_abi():
 def test_library_exports_every_symbol(lib):
     for name in _header_decls():
         assert hasattr(lib, name), name
-    assert lib.dv_abi_version() == 1
+    from drvae_amd import _lib
+    assert lib.dv_abi_version() == _lib.ABI_VERSION == 2
+    assert 'dv_arm_park' not in _lib.SIGNATURES and not hasattr(lib, 'dv_arm_park')     # no armed (hidden) state
     assert lib.dv_error_string(0) == b'ok'
     assert lib.dv_error_string(-1) == b'invalid argument'
 
@@ -57,6 +59,16 @@ def test_gemm_desc_layout_matches_header():
         for part in stmt.split(','):
             names.append(re.sub(r'.*[\s\*]', '', part.strip()))
     assert names == [f[0] for f in GemmDesc._fields_]
+
+
+@pytest.mark.parametrize('cname,pyname', [('dv_wait', 'Wait'), ('dv_bump', 'Bump'), ('dv_loss_term', 'LossTerm')])
+def test_small_struct_layouts_match_header(cname, pyname):
+    from drvae_amd import _lib
+    src = open(os.path.join(ROOT, 'include', 'drvae_hip.h')).read()
+    body = re.search(r'typedef struct %s \{(.*?)\} %s;' % (cname, cname), src, flags=re.S).group(1)
+    body = re.sub(r'/\*.*?\*/', '', body, flags=re.S)
+    names = [re.sub(r'\[\d+\]', '', re.sub(r'.*[\s\*]', '', st.strip())) for st in body.split(';') if st.strip()]
+    assert names == [f[0] for f in getattr(_lib, pyname)._fields_]
 
 
 def test_argument_validation_without_gpu(lib):

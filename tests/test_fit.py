@@ -203,7 +203,7 @@ def test_fit_regression_head_cpu(monkeypatch, tmp_path):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('kind', ['drvae', 'pvae', 'vfae'])
-def test_fit_device_batcher_gpu(kind, tmp_path):
+def test_fit_device_batcher_gpu(kind, tmp_path, dev):
     from drvae_amd import data as D
     model = _tiny_model(kind, device='cuda', epochs=4)
     tr, va = _tiny_dataset(kind, 64, 1, 'cuda'), _tiny_dataset(kind, 32, 2, 'cuda')

@@ -76,7 +76,7 @@ def test_two_rank_overlapped_exchange_matches_eager(dev):
         assert o[1] and o[2] and o[3], o
 
 
-def test_step_path_over_rccl_single_rank():
+def test_step_path_over_rccl_single_rank(dev):
     """the data-parallel step path over the REAL transport: a one-rank RCCL communicator in a child process
     (process group, split graphs, collective launches and their stream events between the graph replays, CU
     partition) -- single exchange and two overlapped pieces -- trains to exactly the losses of the plain
@@ -102,3 +102,25 @@ def test_step_path_over_rccl_single_rank():
     assert plain['finite'] and single['finite'] and pieces['finite']
     assert single['losses_last_step'] == plain['losses_last_step'] == pieces['losses_last_step']
     assert all(v == 0 for v in single['chain_wait_ticks'][0::2] + pieces['chain_wait_ticks'][0::2])
+
+
+def test_bench_self_launch_two_ranks_one_gpu(dev):
+    """``python bench.py --gpus 2`` with no launcher: the parent starts two fresh rank processes before touching
+    the GPU and relays rank 0's line.  On the one-GPU test box the ranks share the device and exchange through
+    gloo (DRVAE_DIST_BACKEND); the weak-scaling job line must report both ranks' rows and finite losses."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ, DRVAE_DIST_BACKEND='gloo', DRVAE_SIDE_CUS='64')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT'):
+        e.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '10', '--warmup', '3',
+                          '--no-cpu-baseline', '--no-roofline'], env=e, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, out.stdout
+    r = json.loads(lines[0])
+    assert r['n_gpus'] == 2 and r['finite'] and r['config']['global_batch'] == 300
+    assert r['config']['dist_backend'] == 'gloo' and r['config']['rccl_ranks'] == 0
+    assert all(v == 0 for v in r['chain_wait_ticks'][0::2])

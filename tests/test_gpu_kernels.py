@@ -470,9 +470,9 @@ def test_adam_gated_sweep(K, dev, n, lo, hi):
     close(p, want, rtol=0, atol=0)
 
 
-def test_armed_park_and_bump(K, dev):
-    """dv_arm_park / dv_arm_bump: the next rows_segment_sum parks on a flag published later from another queue,
-    the next reparam_bwd_seg advances the counters; both are consumed by that one launch"""
+def test_park_and_bump_arguments(K, dev):
+    """dv_wait / dv_bump arguments: a rows_segment_sum given ``park`` parks on a flag published later from another
+    queue, a reparam_bwd_seg given ``bump`` advances the counters; nothing is remembered between calls"""
     n, W = 64, 100
     src, want = rnd(dev, n, W, seed=1), torch.zeros(n, W, device=dev)
     dst = torch.zeros(n, W, device=dev)
@@ -484,8 +484,7 @@ def test_armed_park_and_bump(K, dev):
     live = stale.clone()
     side = _other_queue_stream(K, dev)
     torch.cuda.synchronize()
-    K.arm_park(flag, ctr, err, add=1)
-    K.rows_segment_sum(dst, live, beta=0.0, width=W, n=n)        # parks: ``live`` is not final yet
+    K.rows_segment_sum(dst, live, beta=0.0, width=W, n=n, park=(flag, ctr, err, 1))   # parks: ``live`` is not final yet
     with torch.cuda.stream(side):
         torch.cuda._sleep(2000000)
         live.copy_(src)
@@ -493,7 +492,7 @@ def test_armed_park_and_bump(K, dev):
     torch.cuda.synchronize()
     assert int(err[0]) == 0 and int(err[1]) > 0
     close(dst, want, rtol=0, atol=0)
-    K.rows_segment_sum(dst, stale, beta=0.0, width=W, n=n)       # not armed any more: runs straight away
+    K.rows_segment_sum(dst, stale, beta=0.0, width=W, n=n)       # no park argument: runs straight away
     torch.cuda.synchronize()
     assert float(dst[0, 0]) == 777.0
     # bump on reparam_bwd_seg
@@ -506,9 +505,8 @@ def test_armed_park_and_bump(K, dev):
     step = torch.tensor([3], dtype=torch.int32, device=dev)
     rng = torch.tensor([-2, 0], dtype=torch.int32, device=dev)
     K.reparam_bwd_seg(dmu2, dlv2, dz, eps, lv, ptr, rows_)
-    K.arm_bump((step, 1), (rng, 5))
-    K.reparam_bwd_seg(dmu, dlv, dz, eps, lv, ptr, rows_)
-    K.reparam_bwd_seg(dmu, dlv, dz, eps, lv, ptr, rows_)         # second launch: nothing armed
+    K.reparam_bwd_seg(dmu, dlv, dz, eps, lv, ptr, rows_, bump=[(step, 1), (rng, 5)])
+    K.reparam_bwd_seg(dmu, dlv, dz, eps, lv, ptr, rows_)         # second launch: no bump
     torch.cuda.synchronize()
     assert step.tolist() == [4] and rng.tolist() == [3, 1]
     close(dmu, dmu2, rtol=0, atol=0)

@@ -263,3 +263,71 @@ def test_graph_resident_epoch_feed(kind, dev):
     torch.cuda.synchronize()
     assert torch.equal(a0.param, a1.param)
     assert eager.losses() == fed.losses()
+
+
+def test_explicit_batch_after_epoch_feed_uses_its_own_data(dev):
+    """after DeviceBatcher epochs (graph-resident feed installed on the plan) a train step given
+    explicit data of the SAME batch structure must train on that data, not on the stale epoch table -- and
+    the captured feed graph must refuse to replay for it."""
+    from drvae_amd import data as D
+    from tests.test_engine_cpu import make_engine
+    spec = M.ModelSpec(kind='pvae', L=1)          # pair-only PVAE: every batch has the same structure
+    params = M.init_params(spec, 3, as_numpy=True)
+    big = M.make_batch(spec, 600, seed=9)
+    big['has_x2'][:] = 1
+    t = lambda k: torch.from_numpy(big[k].copy())
+    ds = D.DrVAEDataset(t('x1'), t('x2'), t('s'), t('y'), t('has_x2'), t('has_y')).to(dev)
+    bat = D.DeviceBatcher(ds, torch.ones(600), 48, seed=5)
+    fed, a1 = make_engine(spec, params, dev)
+    bat.bind(fed)
+    bat.begin_epoch(n_batches=2)
+    fed.capture()
+    fed.replay(); fed.replay()
+    # same structure, explicit rows: must come out exactly like an engine that never saw a feed
+    rows = torch.arange(100, 148, device=dev)
+    noise = M.make_noise(spec, 48, seed=11)
+    plain, a0 = make_engine(spec, params, dev)
+    a0.param.copy_(a1.param); a0.exp_avg.copy_(a1.exp_avg); a0.exp_avg_sq.copy_(a1.exp_avg_sq)
+    plain.step_dev.copy_(fed.step_dev); plain.iters = fed.iters
+    for e in (fed, plain):
+        e.set_batch(ds.x1[rows], ds.x2[rows], None, bat.has_x2, bat.has_y)
+        e.train_step(noise)
+    torch.cuda.synchronize()
+    assert fed.plan.feed is not None and fed.plan.live_feed is None
+    assert fed.losses() == plain.losses() and torch.equal(a0.param, a1.param)
+    with pytest.raises(AssertionError):
+        fed.replay()                              # the captured graph reads the epoch table: wrong source now
+    bat.begin_epoch(n_batches=2)                  # ... and is valid again once an epoch feed is current
+    fed.replay()
+    torch.cuda.synchronize()
+
+
+def test_model_move_keeps_training_state(dev):
+    """``.cpu()`` / ``.to(dev)`` swap ``prm.data``; the model must notice, carry the Adam state over
+    and keep the parameters aliased to the arena the fused step updates (same results as a model never moved)."""
+    case = C.model_case('tiny_drvae')
+    spec = case['spec']
+    params = M.init_params(spec, case['param_seed'], as_numpy=True)
+    kw = kwargs_for(spec, case['batch'], dev)
+    out = []
+    for move in (False, True):
+        model = build_model(spec, dev)
+        model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in params.items()})
+        model.add_noise = spec.add_noise_var > 0
+        model.run_on_batch(train_mode=True, noise=case['noises'][1], **kw)
+        if move:
+            model.cpu()
+            assert model._engine is None and next(model.parameters()).device.type == 'cpu'
+            model.to(dev)
+        model.run_on_batch(train_mode=True, noise=case['noises'][2], **kw)
+        model._assert_arena_aliased()
+        assert model.finished_training_iters == 2
+        out.append({k: v.detach().cpu().clone() for k, v in model.state_dict().items()})
+        if move:
+            with pytest.raises(TypeError):
+                model.double()
+            sd = {k: v.clone() for k, v in model.state_dict().items()}
+            model.load_state_dict(sd, assign=True)
+            model._assert_arena_aliased()
+    for k in out[0]:
+        assert torch.equal(out[0][k], out[1][k]), k

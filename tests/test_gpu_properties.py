@@ -94,3 +94,159 @@ def test_backward_matches_finite_differences_at_baseline_size(kind, dev):
     fd = (cmpl(theta + eps * d) - cmpl(theta - eps * d)) / (2 * eps)
     arena.param.copy_(theta)
     assert abs(fd - lin) <= 3e-2 * max(1.0, abs(lin)), (fd, lin)
+
+
+def test_cfg5_full_size_shard_additivity_reproducibility_and_training(dev):
+    """BASELINE configs[4] at its stated per-GPU size: 20000 genes, z1=z3=200, enc/dec 2048, 1024 rows, L=4.
+    (a) grad(rows 0..511) + grad(rows 512..1023) with GLOBAL normalisers == grad(all 1024 rows), loss scalars
+    included (the data-parallel contract); (b) bitwise reproducibility; (c) a directional finite difference of
+    the hand-written backward; (d) three captured train steps with on-device Philox noise stay finite and move
+    the parameters."""
+    spec = M.ModelSpec(kind='drvae', dim_x=20000, dim_z1=200, dim_z3=200, h_en_z1=[2048], h_de_x=[2048], L=4)
+    n = 1024
+    params = _params(spec, 1)
+    batch = M.make_batch(spec, n, seed=3)
+    noise = _noise(spec, n, 4)
+    full, eng = _fwd_bwd(spec, params, batch, noise, dev)
+    assert bool(torch.isfinite(full).all())
+    # (c) finite difference along a random relative direction
+    arena = eng.arena
+    npar = arena.n_params
+    g = torch.Generator().manual_seed(0)
+    d = torch.randn(npar, generator=g).to(dev) * arena.param.abs().clamp(min=1e-3)
+    theta = arena.param.clone()
+    lin = float((full[8:8 + npar].double() * d.double()).sum()) if full.numel() != npar else \
+        float((full[:npar].double() * d.double()).sum())
+
+    def cmpl(t):
+        arena.param.copy_(t)
+        eng.set_noise(noise)
+        eng.forward()
+        return float(arena.loss[6])
+    eps = 1e-2
+    fd = (cmpl(theta + eps * d) - cmpl(theta - eps * d)) / (2 * eps)
+    arena.param.copy_(theta)
+    assert abs(fd - lin) <= 5e-2 * max(1.0, abs(lin)), (fd, lin)
+    del eng, arena
+    torch.cuda.empty_cache()
+    full2, _ = _fwd_bwd(spec, params, batch, noise, dev)
+    assert torch.equal(full, full2)                                   # (b)
+    del full2, _
+    counts = (n, int(batch['has_x2'].sum()), int(batch['has_y'].sum()))
+    g0, e0 = _fwd_bwd(spec, params, batch, noise, dev, counts, 0, 512)
+    l0 = e0.arena.loss.clone()
+    del e0
+    torch.cuda.empty_cache()
+    g1, e1 = _fwd_bwd(spec, params, batch, noise, dev, counts, 512, n)
+    l1 = e1.arena.loss.clone()
+    s = g0 + g1
+    rel = float((s - full).norm() / full.norm())
+    assert rel < 2e-5, rel                                            # (a)
+    # (d) captured steps on Philox noise
+    e1.train_step()
+    e1.capture()
+    p0 = e1.arena.param.clone()
+    for _ in range(3):
+        e1.replay()
+    torch.cuda.synchronize()
+    losses = e1.losses()
+    assert all(np.isfinite(v) for v in losses.values()), losses
+    assert float((e1.arena.param - p0).abs().max()) > 0 and bool(torch.isfinite(e1.arena.param).all())
+
+
+def test_timed_out_chain_wait_fails_loudly(dev, monkeypatch):
+    """a device-side wait that times out must never train on stale data silently.  The waits
+    are captured with a one-poll bound (the side chain's first wait then gives up before the main chain has
+    published): from that step on the loss scalars are NaN, the optimiser leaves the parameters untouched,
+    and a plain ``replay()`` loop that never reads the losses raises within two polling periods."""
+    import drvae_amd.kernels as K
+    import drvae_amd.schedule as S
+    spec = M.ModelSpec(kind='drvae', L=2)
+    params = M.init_params(spec, 3, as_numpy=True)
+    batch = M.make_batch(spec, 150, seed=5)
+    eng, arena = make_engine(spec, params, dev)
+    set_batch(eng, batch, dev)
+    eng.train_step()
+    monkeypatch.setattr(K, 'WAIT_SPINS', 1)
+    monkeypatch.setattr(S, 'SYNC_POLL', 8)
+    eng.capture()
+    assert eng._side_graph is not None, 'dual-graph schedule expected on the GPU'
+    torch.cuda.synchronize()
+    before = arena.param.clone()
+    with pytest.raises(RuntimeError, match='chain wait timed out'):
+        for _ in range(2 * 8 + 1):
+            eng.replay()
+    torch.cuda.synchronize()
+    assert int(eng.sync_err[0::2].abs().sum()) != 0
+    frozen = arena.param.clone()
+    eng._sync_event = None
+    try:
+        for _ in range(4):
+            eng.replay()
+    except RuntimeError:
+        pass
+    torch.cuda.synchronize()
+    assert torch.equal(arena.param, frozen)                # halted: the sweep no longer touches the parameters
+    assert all(np.isnan(v) for v in arena.loss[:7].cpu().tolist())
+    with pytest.raises(RuntimeError, match='chain wait timed out'):
+        eng.losses()
+    del before
+
+
+def test_philox_draws_are_keyed_by_global_row(dev):
+    """SURVEY 8(e) "RNG under DP": a rank that owns rows [rB, (r+1)B) of the global minibatch draws exactly the
+    values a single process draws for those rows -- for every draw of the step (input noise, z1 / z2 / z2Fz1 / z3
+    eps), whatever the stacking.  Then: two shards' Philox train-step gradients sum to the full batch's."""
+    spec = M.ModelSpec(kind='drvae', L=2)
+    params = M.init_params(spec, 3, as_numpy=True)
+    n, B = 300, 150
+    full_batch = M.make_batch(spec, n, seed=5)
+    counts = (n, int(full_batch['has_x2'].sum()), int(full_batch['has_y'].sum()))
+    engs = []
+    for (lo, hi) in ((0, n), (0, B), (B, n)):
+        eng, arena = make_engine(spec, params, dev)
+        eng.seed, eng.row0 = 77, lo
+        set_batch(eng, {k: v[lo:hi] for k, v in full_batch.items()}, dev, counts=counts)
+        eng.draw_noise()
+        engs.append((eng, arena, lo, hi))
+    torch.cuda.synchronize()
+    (ef, af, _, _) = engs[0]
+    pf = ef.plan
+    L, Y = spec.L, spec.dim_y
+    for (e, a, lo, hi) in engs[1:]:
+        p = e.plan
+        m = hi - lo
+        assert torch.equal(p.EX[:m], pf.EX[lo:hi])
+        pr_f = {int(r): k for k, r in enumerate(pf.pair_host)}
+        for k, r in enumerate(p.pair_host):
+            kf = pr_f[int(r) + lo]
+            assert torch.equal(p.EX[m + k], pf.EX[n + kf])
+            for l in range(L):
+                assert torch.equal(p.E2[l * p.Np + k], pf.E2[l * pf.Np + kf])
+        for l in range(L):
+            assert torch.equal(p.E1[l * m:(l + 1) * m], pf.E1[l * n + lo:l * n + hi])
+            assert torch.equal(p.E2F[l * m:(l + 1) * m], pf.E2F[l * n + lo:l * n + hi])
+        key_f = {(int(l_), int(i_), int(s_)): f for f, (l_, i_, s_) in
+                 enumerate(zip(pf.fp_l_host, pf.fp_i_host, pf.fp_slot_host))}
+        for f, (l_, i_, s_) in enumerate(zip(p.fp_l_host, p.fp_i_host, p.fp_slot_host)):
+            assert torch.equal(p.E3[f], pf.E3[key_f[(int(l_), int(i_) + lo, int(s_))]])
+    # a second draw event differs, and moments are those of N(0,1)
+    first = pf.noise.clone()
+    ef.draw_noise()
+    torch.cuda.synchronize()
+    assert float((pf.noise - first).abs().max()) > 0
+    assert abs(float(first.mean())) < 1e-2 and abs(float(first.std()) - 1) < 1e-2
+    assert abs(float((first ** 4).mean()) - 3) < 1e-1 and bool(torch.isfinite(first).all())
+    # Philox train step: shard gradients add up to the full batch's (same draws per global row)
+    grads = []
+    for (e, a, lo, hi) in engs:
+        e.rng_ctr.zero_()
+        e.training, e.fuse_bwd = True, False
+        e.draw_noise()
+        e.forward()
+        e.backward()
+        torch.cuda.synchronize()
+        grads.append(a.xchg.clone())
+    s = grads[1] + grads[2]
+    rel = float((s - grads[0]).norm() / grads[0].norm())
+    assert rel < 2e-5, rel
