@@ -1,7 +1,10 @@
 """How the launch sequence of the fused train step is put on the GPU: hipGraph capture / replay, the
 dual-graph schedule (main chain and side chain as two single-stream graphs ordered by device flags),
 the CU partition of the two chains, and the data-parallel graph splits.  Mixed into ``FusedStep``."""
+import ctypes
+import gc
 import os
+import weakref
 
 import torch
 
@@ -33,6 +36,7 @@ def _masked_stream(bits, device):
 
 SYNC_POLL = int(os.environ.get('DRVAE_SYNC_POLL', '64'))     # steps between two polls of the wait-error words
 
+_PINNED_POOL = []             # pinned int32 buffers of retired engines (see ``_poll_sync``)
 _PARTITION_STREAMS = {}      # device index -> {reserved CUs -> (main stream, side stream) | None}
 
 
@@ -124,6 +128,12 @@ class StepSchedule:
         self._noise_stale = True
         if dual:
             self._rec = 'main'
+        # no garbage collection while a stream is capturing: a collected cycle may own device or pinned memory,
+        # events or graphs of a retired engine, and releasing those calls HIP functions that are illegal
+        # during (global-mode) capture -- the process aborts
+        gc.collect()
+        gc_was_on = gc.isenabled()
+        gc.disable()
         try:
             self._capture_main(split_for_allreduce)
             if dual:
@@ -142,6 +152,8 @@ class StepSchedule:
                 self._side_graph = gs
         finally:
             self._rec = 'both'
+            if gc_was_on:
+                gc.enable()
         self._graph_key = self.plan.key
         self._graph_feed = self.plan.live_feed
         return self
@@ -314,7 +326,15 @@ class StepSchedule:
             return
         self._since_poll = 0
         if getattr(self, '_sync_host', None) is None:
-            self._sync_host = torch.zeros(self.sync_err.numel(), dtype=torch.int32).pin_memory()
+            # pinned landing buffers are pooled for the life of the process: returning one to torch's host
+            # allocator queries its events, which is illegal while ANY stream is capturing -- and garbage
+            # collection may run in the middle of a later capture
+            if _PINNED_POOL:
+                self._sync_host = _PINNED_POOL.pop()
+            else:
+                self._sync_host = torch.zeros(self.sync_err.numel(), dtype=torch.int32).pin_memory()
+                ctypes.pythonapi.Py_IncRef(ctypes.py_object(self._sync_host))   # never deallocated, not even at exit
+            weakref.finalize(self, _PINNED_POOL.append, self._sync_host).atexit = False
             self._sync_event = None
         if self._sync_event is not None:
             self._sync_event.synchronize()

@@ -89,7 +89,7 @@ def test_step_path_over_rccl_single_rank(dev):
            '--no-roofline']
 
     def run(**env):
-        e = dict(os.environ, DRVAE_SIDE_CUS='64', **env)
+        e = dict(os.environ, DRVAE_SIDE_CUS='64', DRVAE_BENCH_STEADY='0', **env)
         e.pop('RANK', None)
         e.pop('WORLD_SIZE', None)
         out = subprocess.run(cmd, env=e, capture_output=True, text=True, timeout=300)
@@ -112,7 +112,7 @@ def test_bench_self_launch_two_ranks_one_gpu(dev):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    e = dict(os.environ, DRVAE_DIST_BACKEND='gloo', DRVAE_SIDE_CUS='64')
+    e = dict(os.environ, DRVAE_DIST_BACKEND='gloo', DRVAE_SIDE_CUS='64', DRVAE_BENCH_STEADY='0')
     for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT'):
         e.pop(k, None)
     out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '10', '--warmup', '3',
