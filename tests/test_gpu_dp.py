@@ -50,6 +50,38 @@ def _worker(rank, world, port, q):
             eng.check_sync()
             res[mode] = (arena.param.clone().cpu(), arena.loss.clone().cpu())
         same = all(torch.equal(res['eager'][i], res[m][i]) for m in ('overlap', 'split') for i in (0, 1))
+        # cfg 2 size (150 rows per rank) on on-device Philox noise keyed by GLOBAL row: the two-rank job must train
+        # exactly like one process on the concatenated 300 rows (same seed, same draws per global row)
+        full = M.make_batch(spec, 300, seed=6)
+        lo, hi = D.shard_rows(300, rank, world)
+        shard = {k: v[lo:hi] for k, v in full.items()}
+        counts = D.global_counts(shard['has_x2'], shard['has_y'])
+        eng, arena = make_engine(spec, params, dev)
+        eng.seed, eng.row0 = 4242, lo
+        set_batch(eng, shard, dev, counts=counts)
+        eng.train_step(allreduce=D.allreduce_sum)
+        eng.capture(split_for_allreduce=True)     # (spends one draw event on its warm-up: ``one`` follows below)
+        for _ in range(3):
+            eng.replay(D.allreduce_sum)
+        torch.cuda.synchronize()
+        eng.check_sync()
+        one, a1 = make_engine(spec, params, dev)
+        one.seed = 4242
+        set_batch(one, full, dev)
+        one.train_step()
+        one.draw_noise()
+        for _ in range(3):
+            one.train_step()
+        torch.cuda.synchronize()
+        # (norm-wise: Adam turns a gradient that is pure summation-order noise into a full +-lr move of that element)
+        perr = float((arena.param - a1.param).norm() / a1.param.norm())
+        gerr = float((arena.grad - a1.grad).norm() / a1.grad.norm())
+        assert gerr < 1e-4, gerr
+        lerr = max(abs(a - b) / max(abs(b), 1e-6) for a, b in zip(eng.losses().values(), one.losses().values())
+                   if b != 0.0)
+        same = same and perr < 1e-4 and lerr < 1e-4
+        if not (perr < 1e-4 and lerr < 1e-4):
+            raise AssertionError('2-rank Philox job != 1-rank job on the concatenated batch: %g %g' % (perr, lerr))
         # replicas agree: compare rank 0's parameters with this rank's
         ref = res['overlap'][0].clone().to(dev)
         dist.broadcast(ref, src=0)
