@@ -36,6 +36,15 @@ class Bump(C.Structure):       # dv_bump: up to two device counters advanced by 
     _fields_ = [('c', _p * 2), ('n', _i32 * 2), ('inc', _i64 * 2)]
 
 
+class HeadsEpi(C.Structure):   # dv_heads_epi
+    _fields_ = [('mode', _i32), ('seg_ptr', _p), ('seg_rows', _p), ('n_src', _i32), ('eps', _p), ('lde', _i64),
+                ('out', _p), ('ldo', _i64), ('sub', _p), ('lds', _i64), ('out2', _p), ('ldo2', _i64), ('out3', _p),
+                ('ldo3', _i64), ('out3_idx', _p), ('x', _p), ('ldx', _i64), ('xidx', _p), ('coef', _p), ('part', _p)]
+
+
+HEADS_SAMPLE, HEADS_NLL = 1, 2
+
+
 class LossTerm(C.Structure):
     _fields_ = [('x', _p), ('w', _p), ('n', _i32), ('scale', _f), ('out', _i32)]
 
@@ -46,6 +55,8 @@ SIGNATURES = {
     'dv_error_string': [_i32],
     'dv_gemm': [C.POINTER(GemmDesc), _p],
     'dv_gemm_pair': [C.POINTER(GemmDesc), C.POINTER(GemmDesc), _p],
+    'dv_gemm_heads': [C.POINTER(GemmDesc), C.POINTER(HeadsEpi), _p],
+    'dv_gemm_heads_tiles': [_i32],
     'dv_gemm_force_tiling': [_i32],
     'dv_gemm_set_option': [_i32, _i32],
     'dv_colsum': [_p, _i64, _i32, _i32, _p, _f, _p],

@@ -48,13 +48,25 @@ class _Chain:
         # gradient w.r.t. the pre-activation of every layer but the last (the caller owns that one)
         self.dpre = [torch.zeros(M, _pad4(l.N), device=device)[:, :l.N] for l in layers[:-1]]
 
-    def forward(self, inputs, resid=None, publish=None):
-        """``publish`` = (flag, counter, add): the FIRST launch of the chain publishes on entry"""
+    def forward(self, inputs, resid=None, publish=None, heads=None):
+        """``publish`` = (flag, counter, add): the FIRST launch of the chain publishes on entry.
+        ``heads`` = dict(sample=...) | dict(nll=..., out=...): the dual-head last layer runs as ``K.linear_heads``
+        with that row work fused into its epilogue (with ``nll`` the heads themselves are NOT stored: ``out``
+        receives their gradients)."""
         x = list(inputs)
         for li, l in enumerate(self.layers):
             if l.g is not None:
                 K.wn_scale(l.scale, l.norm, l.W, l.g)
             last = li == len(self.layers) - 1
+            if last and heads is not None:
+                assert l.split * 2 == l.N
+                K.linear_heads(heads.get('out', self.out[li]), x[0], l.W, l.b, split=l.split,
+                               x2=x[1] if len(x) > 1 else None, scale=l.scale, act0=l.act0, act1=l.act1,
+                               shift0=l.shift0, shift1=l.shift1, resid=resid,
+                               resid_cols=self.resid_cols if resid is not None else 0, overread=True,
+                               publish=publish if (li == 0 and l.g is None) else None,
+                               sample=heads.get('sample'), nll=heads.get('nll'))
+                return self.out[-1]
             K.linear_fwd(self.out[li], x[0], l.W, l.b, x2=x[1] if len(x) > 1 else None, scale=l.scale, split=l.split,
                          act0=l.act0, act1=l.act1, shift0=l.shift0, shift1=l.shift1,
                          resid=resid if last else None, resid_cols=self.resid_cols if (last and resid is not None) else 0,

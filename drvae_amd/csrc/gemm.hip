@@ -35,11 +35,37 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef DV_STAGGER
 #define DV_STAGGER 0
 #endif
+// tuning builds only: DV_STAMP=1 makes wave 0 of every workgroup record shader-clock stamps around the phases of
+// the steady-state K loop into the buffer set with dv_gemm_set_option(5/6, lo/hi of its address): per workgroup
+// 64 x uint64 = [entry, loop start, then per phase: after compute, after stage_store, after fetch, after barrier]
+#ifndef DV_STAMP
+#define DV_STAMP 0
+#endif
+#ifndef DV_LB8
+#define DV_LB8 2
+#endif
+#if DV_STAMP
+__device__ unsigned long long* dv_stamp_buf = nullptr;
+#define STAMP(i)                                                                          \
+    do {                                                                                  \
+        if (stamp_on && (i) < 64) {                                                       \
+            unsigned long long t__;                                                       \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");   \
+            if (threadIdx.x == 0) dv_stamp_buf[(size_t)bid * 64 + (i)] = t__;             \
+        }                                                                                 \
+    } while (0)
+#else
+#define STAMP(i) \
+    do {         \
+    } while (0)
+#endif
 
 namespace {
 
 // what staging chunks past the end of K read (see the K tail of the fast path)
 __device__ __attribute__((aligned(16))) const float dv_zero_chunk[4] = {0.f, 0.f, 0.f, 0.f};
+
+constexpr float kLog2PiG = 1.8378770664093453f;   // log(2 pi), as rows.hip
 
 struct LoadCfg {
     int vecA, vecB;   // widest aligned vector width (4, 2 or 1 floats) per operand
@@ -173,6 +199,82 @@ __device__ __forceinline__ float4 ld_edge(const Operand& o, int line, int pos) {
     return make_float4(e[0], e[1], e[2], e[3]);
 }
 
+// Epilogue of a paired-heads tile: thread -> (column c of the half tile, RPT consecutive rows); both heads of
+// an element are reduced over the KS partial sums by the same thread, pass through the DV_EPI_FWD column
+// epilogue, and feed the row work of the mode (see dv_heads_epi in drvae_hip.h).
+template <int BM, int BN, int KS, int NT>
+__device__ __forceinline__ void heads_epilogue(const dv_gemm_desc& g, const dv_heads_epi& he, const float* red, int m0,
+                                               int tn, int tiles_n) {
+    constexpr int HB = BN / 2, RPT = BM / (NT / HB);
+    static_assert((HB == 32 || HB == 16) && RPT >= 1, "half tile = 16 or 32 adjacent lanes");
+    const int tid = threadIdx.x, c = tid % HB, r0 = (tid / HB) * RPT;
+    const int col0 = tn * HB + c, col1 = g.split + col0;
+    const bool ok = col0 < g.split && col1 < g.N;
+    const int cc0 = ok ? col0 : g.split - 1, cc1 = ok ? col1 : g.N - 1;
+    float sc0 = 1.f, sc1 = 1.f, bi0 = 0.f, bi1 = 0.f;
+    if (g.scale) {
+        sc0 = g.scale[cc0];
+        sc1 = g.scale[cc1];
+    }
+    if (g.bias) {
+        bi0 = g.bias[cc0];
+        bi1 = g.bias[cc1];
+    }
+    const bool use_res = g.resid != nullptr && col0 < g.resid_cols;
+#pragma unroll
+    for (int e = 0; e < RPT; ++e) {
+        const int row = m0 + r0 + e;
+        const bool rok = row < g.M;
+        const int rc = rok ? row : g.M - 1;
+        float v0 = 0.f, v1 = 0.f;
+#pragma unroll
+        for (int w = 0; w < KS; ++w) {
+            v0 += red[(w * BM + r0 + e) * (BN + 1) + c];
+            v1 += red[(w * BM + r0 + e) * (BN + 1) + HB + c];
+        }
+        float a0 = dv_act(g.act0, v0 * g.alpha * sc0 + bi0) + g.shift0;
+        const float a1 = dv_act(g.act1, v1 * g.alpha * sc1 + bi1) + g.shift1;
+        if (use_res) a0 += g.resid[(int64_t)rc * g.ldr + cc0];
+        if (he.mode == DV_HEADS_SAMPLE) {
+            if (ok && rok) {
+                g.C[(int64_t)row * g.ldc + col0] = a0;
+                g.C[(int64_t)row * g.ldc + col1] = a1;
+                if (row < he.n_src) {
+                    const float std_ = expf(0.5f * a1);
+                    const int s0 = he.seg_ptr ? he.seg_ptr[row] : row, s1 = he.seg_ptr ? he.seg_ptr[row + 1] : row + 1;
+                    for (int t = s0; t < s1; ++t) {
+                        const int64_t s = he.seg_rows ? he.seg_rows[t] : t;
+                        const float z = he.eps[s * he.lde + col0] * std_ + a0;
+                        he.out[s * he.ldo + col0] = z;
+                        if (he.out2) he.out2[s * he.ldo2 + col0] = z - he.sub[s * he.lds + col0];
+                        if (he.out3) {
+                            const int t3 = he.out3_idx[s];
+                            if (t3 >= 0) he.out3[(int64_t)t3 * he.ldo3 + col0] = z;
+                        }
+                    }
+                }
+            }
+        } else {   // DV_HEADS_NLL
+            const float xv = he.x[(int64_t)(he.xidx ? he.xidx[rc] : rc) * he.ldx + cc0];
+            const float cf = he.coef[rc];
+            const float d = xv - a0, v = a1 * a1;
+            float acc = ok ? kLog2PiG + logf(v) + d * d / v : 0.f;
+            float gm = d / v, gs = -1.f / a1 + d * d / (v * a1);
+            if (g.act1 != DV_ACT_IDENTITY) gs *= dv_dact_from_y(g.act1, a1 - g.shift1);
+            gm *= cf;
+            gs *= cf;
+            if (ok && rok) {
+                g.C[(int64_t)row * g.ldc + col0] = gm;
+                g.C[(int64_t)row * g.ldc + col1] = gs;
+            }
+            // sum over the 32 columns of the half tile = the 32 lanes of this half-wave, fixed order
+#pragma unroll
+            for (int off = HB / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+            if (c == 0 && rok) he.part[(int64_t)row * tiles_n + tn] = -0.5f * acc;
+        }
+    }
+}
+
 template <int BM, int BN, int BK, int KS, bool AKC, bool BKC>
 constexpr int gemm_smem_floats() {
     constexpr int stage = (AKC ? BM : BK) * ((AKC ? BK : BM) + 4) + (BKC ? BN : BK) * ((BKC ? BK : BN) + 4);
@@ -180,9 +282,14 @@ constexpr int gemm_smem_floats() {
     return 2 * stage > red ? 2 * stage : red;
 }
 
-// One workgroup's share of one product: `bid` of `nwg` workgroups.
-template <int BM, int BN, int BK, int WM, int WN, int KS, bool AKC, bool BKC>
-__device__ __forceinline__ void gemm_body(const dv_gemm_desc& g, const LoadCfg& lc, float* smem, int bid, int nwg) {
+// One workgroup's share of one product: `bid` of `nwg` workgroups.  PAIR (dv_gemm_heads): the BN staged B lines
+// are the head-0 rows [tn*BN/2, +BN/2) followed by the head-1 rows [split + tn*BN/2, +BN/2) of W, and the
+// epilogue sees both heads of an element in one thread.
+template <int BM, int BN, int BK, int WM, int WN, int KS, bool AKC, bool BKC, bool PAIR = false>
+__device__ __forceinline__ void gemm_body(const dv_gemm_desc& g, const LoadCfg& lc, float* smem, int bid, int nwg,
+                                          const dv_heads_epi* he = nullptr) {
+    static_assert(!PAIR || (AKC && BKC && KS > 1 && WM == 1 && WN == 1), "paired heads: forward layout, K-split tiling");
+    constexpr int HB = BN / 2;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int KW = BK / KS, KH = KW / 2;
     constexpr int LDA_S = (AKC ? BK : BM) + 4;
@@ -193,12 +300,20 @@ __device__ __forceinline__ void gemm_body(const dv_gemm_desc& g, const LoadCfg& 
     constexpr int RED_ELEMS = (KS > 1) ? KS * BM * (BN + 1) : 0;
     constexpr int NT = 64 * WM * WN * KS;   // threads per workgroup
     static_assert(2 * STAGE <= gemm_smem_floats<BM, BN, BK, KS, AKC, BKC>() && RED_ELEMS <= gemm_smem_floats<BM, BN, BK, KS, AKC, BKC>(), "smem");
-    static_assert(NT == 256 || NT == 512, "4 or 8 waves");
+    static_assert(NT == 256 || NT == 512 || NT == 1024, "4, 8 or 16 waves");
 
-    const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
+    const int tiles_m = (g.M + BM - 1) / BM, tiles_n = PAIR ? (g.split + HB - 1) / HB : (g.N + BN - 1) / BN;
     int tm, tn;
     tile_of_block(bid, nwg, tiles_m, tiles_n, lc.map, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
+    // row of B (= output column) staged as line l of the B tile, clamped into its head
+    auto bline = [&](int l) -> int {
+        if (PAIR) {
+            const int c = tn * HB + (l < HB ? l : l - HB);
+            return l < HB ? (c < g.split ? c : g.split - 1) : (g.split + c < g.N ? g.split + c : g.N - 1);
+        }
+        return n0 + l < g.N ? n0 + l : g.N - 1;
+    };
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
@@ -267,7 +382,7 @@ __device__ __forceinline__ void gemm_body(const dv_gemm_desc& g, const LoadCfg& 
 #pragma unroll
         for (int p = 0; p < B_NP; ++p) {
             const int l = b_l + p * B_LPP;
-            rb[p] = ld_edge(ob, BKC ? (n0 + l) : (k0 + l), BKC ? (k0 + b_c * 4) : (n0 + b_c * 4));
+            rb[p] = ld_edge(ob, BKC ? (PAIR ? bline(l) : n0 + l) : (k0 + l), BKC ? (k0 + b_c * 4) : (n0 + b_c * 4));
         }
     };
     auto stage_store = [&](float* buf, const float4 (&ra)[A_NP], const float4 (&rb)[B_NP]) {
@@ -374,8 +489,7 @@ __device__ __forceinline__ void gemm_body(const dv_gemm_desc& g, const LoadCfg& 
 #pragma unroll
         for (int p = 0; p < B_NP; ++p) {
             const int l = b_l + p * B_LPP;
-            int line = BKC ? (n0 + l) : l;
-            if (BKC) line = line < g.N ? line : g.N - 1;
+            const int line = BKC ? bline(l) : l;
             pb[p] = g.B + (int64_t)line * g.ldb + (BKC ? b_c * 4 : (n0 + b_c * 4 < g.N ? n0 + b_c * 4 : 0));
         }
         const int64_t step_a = AKC ? (int64_t)BK : (int64_t)BK * g.lda;
@@ -505,11 +619,17 @@ __device__ __forceinline__ void gemm_body(const dv_gemm_desc& g, const LoadCfg& 
         }
 #else
         float4 a0[A_NP], b0[B_NP], a1[A_NP], b1[B_NP];
+#if DV_STAMP
+        const bool stamp_on = dv_stamp_buf != nullptr && wave == 0;
+        int si = 2;
+#endif
+        STAMP(0);
         fetch(0, a0, b0);
         if (nkt > 1) fetch(1, a1, b1);
         stage_store(buf0, a0, b0);
         if (nkt > 2) fetch(2, a0, b0);
         __syncthreads();
+        STAMP(1);
         int kt = 0;
 #if DV_DBG == 0
         // steady state (every tile touched is a full one): no conditionals, so each phase is ONE
@@ -518,13 +638,37 @@ __device__ __forceinline__ void gemm_body(const dv_gemm_desc& g, const LoadCfg& 
         // measured: decoder-head products 26.4 -> 25.1 us, 128x128 tiling 118 -> 122 TF/s
         for (; kt + 4 < nfull; kt += 2) {
             compute(buf0);
+#if DV_STAMP
+            STAMP(si); ++si;
+#endif
             stage_store(buf1, a1, b1);
+#if DV_STAMP
+            STAMP(si); ++si;
+#endif
             fetch(0, a1, b1);
+#if DV_STAMP
+            STAMP(si); ++si;
+#endif
             __syncthreads();
+#if DV_STAMP
+            STAMP(si); ++si;
+#endif
             compute(buf1);
+#if DV_STAMP
+            STAMP(si); ++si;
+#endif
             stage_store(buf0, a0, b0);
+#if DV_STAMP
+            STAMP(si); ++si;
+#endif
             fetch(0, a0, b0);
+#if DV_STAMP
+            STAMP(si); ++si;
+#endif
             __syncthreads();
+#if DV_STAMP
+            STAMP(si); ++si;
+#endif
         }
 #endif
         for (; kt < nkt; kt += 2) {
@@ -585,6 +729,18 @@ __device__ __forceinline__ void gemm_body(const dv_gemm_desc& g, const LoadCfg& 
     } else {
         // the KS wave groups hold partial sums over disjoint k: reduce through LDS (tiles are dead now)
         float* red = smem;
+        if constexpr (PAIR) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    red[(ks_id * BM + row) * (BN + 1) + j * 32 + li] = acc[0][j][r];
+                }
+            __syncthreads();
+            heads_epilogue<BM, BN, KS, NT>(g, *he, red, m0, tn, tiles_n);
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -620,7 +776,7 @@ __device__ __forceinline__ void publish_on_entry(const dv_gemm_desc& g) {
 }
 
 template <int BM, int BN, int BK, int WM, int WN, int KS, bool AKC, bool BKC>
-__global__ __launch_bounds__(64 * WM * WN * KS, (BM >= 128 || BK >= 128) ? 2 : (WM * WN * KS == 8 ? 2 : 4)) void gemm_kernel(const dv_gemm_desc g, const LoadCfg lc) {
+__global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 16) ? 4 : (BM >= 128 || BK >= 128) ? 2 : (WM * WN * KS == 8 ? (BM * BN == 1024 ? DV_LB8 : 2) : 4)) void gemm_kernel(const dv_gemm_desc g, const LoadCfg lc) {
     __shared__ __attribute__((aligned(16))) float smem[gemm_smem_floats<BM, BN, BK, KS, AKC, BKC>()];
     publish_on_entry(g);
 #if DV_STAGGER
@@ -632,6 +788,14 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (BM >= 128 || BK >= 128) ? 2 : (
     }
 #endif
     gemm_body<BM, BN, BK, WM, WN, KS, AKC, BKC>(g, lc, smem, blockIdx.x, gridDim.x);
+}
+
+template <int BM, int BN, int BK, int KS>
+__global__ __launch_bounds__(64 * KS, KS == 8 ? 2 : 4) void gemm_heads_kernel(const dv_gemm_desc g, const LoadCfg lc,
+                                                               const dv_heads_epi he) {
+    __shared__ __attribute__((aligned(16))) float smem[gemm_smem_floats<BM, BN, BK, KS, true, true>()];
+    publish_on_entry(g);
+    gemm_body<BM, BN, BK, 1, 1, KS, true, true, true>(g, lc, smem, blockIdx.x, gridDim.x, &he);
 }
 
 // Two independent products in ONE launch (workgroups [0,tiles1) run the first, the rest the
@@ -679,6 +843,13 @@ static int g_opt[8] = {-1, 0, 0, 0, 0, 0, 0, 0};  // [0] = tile map (0 linear, 1
 extern "C" int dv_gemm_set_option(int key, int value) {
     if (key < 0 || key >= 8) return DV_ERR_ARG;
     g_opt[key] = value;
+#if DV_STAMP
+    if (key == 6) {
+        unsigned long long* p = reinterpret_cast<unsigned long long*>(((unsigned long long)(unsigned)g_opt[6] << 32) |
+                                                                      (unsigned)g_opt[5]);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(dv_stamp_buf), &p, sizeof(p));
+    }
+#endif
     return DV_OK;
 }
 
@@ -737,7 +908,14 @@ static int gemm_launch(const dv_gemm_desc& g, const LoadCfg& lc, int tiling, hip
     if (tiling == 5) return launch_cfg<64, 64, 64, 2, 2, 2>(g, lc, st);   // 8 waves: 2 per SIMD
     if (tiling == 6) return launch_cfg<64, 32, 64, 2, 1, 2>(g, lc, st);   // 2 row blocks x 2-way K split
     if (tiling == 7) return launch_cfg<32, 64, 64, 1, 2, 2>(g, lc, st);   // 2 column blocks x 2-way K split
+    if (tiling == 8) return launch_cfg<32, 32, 128, 1, 1, 8>(g, lc, st);   // 8-way K split: twice the waves, half the chain
+    if (tiling == 9) return launch_cfg<32, 32, 64, 1, 1, 8>(g, lc, st);
+    if (tiling == 10) return launch_cfg<32, 32, 128, 1, 1, 16>(g, lc, st);
     if (tiling == 1) return launch_cfg<64, 64, 32, 2, 2, 1>(g, lc, st);
+    // 32x32 K-split tiling: the k-contiguous-A layouts (x W^T, dy W) run with EIGHT waves splitting each 64-deep K
+    // tile (half the MFMA chain per wave, twice the waves to overlap its latency: 4-10 % faster on every cfg-2
+    // product of these layouts, tools/gemm_bench.py --tilings 2,9); dy^T x keeps four (its big products lose with eight)
+    if (g.a_kcontig && g_opt[7] == 0) return launch_cfg<32, 32, 64, 1, 1, 8>(g, lc, st);
     return launch_cfg<32, 32, 64, 1, 1, 4>(g, lc, st);
 }
 
@@ -747,6 +925,47 @@ extern "C" int dv_gemm(const dv_gemm_desc* d, dv_stream_t stream) {
     const int rc = gemm_prepare(d, lc, tiling);
     if (rc != DV_OK) return rc;
     return gemm_launch(*d, lc, tiling, static_cast<hipStream_t>(stream));
+}
+
+// half-tile width of the paired-heads launch: 16 (default: 32x(16+16) tiles = the workgroup count and MFMA chain of
+// the 32x32 K-split tiling) or 32 (g_opt[4] = 1 / 2: 32x(32+32) tiles with 4 / 8 waves; measured slower at cfg 2)
+static int heads_hb() { return g_opt[4] >= 1 ? 32 : 16; }
+extern "C" int dv_gemm_heads_tiles(int32_t split) { return split > 0 ? (split + heads_hb() - 1) / heads_hb() : 0; }
+
+extern "C" int dv_gemm_heads(const dv_gemm_desc* d, const dv_heads_epi* e, dv_stream_t stream) {
+    LoadCfg lc;
+    int tiling = 0;
+    DV_REQUIRE(d != nullptr && e != nullptr);
+    const int rc = gemm_prepare(d, lc, tiling);
+    if (rc != DV_OK) return rc;
+    if (tiling < 0) return DV_OK;
+    const dv_gemm_desc& g = *d;
+    DV_REQUIRE(g.a_kcontig && g.b_kcontig && g.epilogue == DV_EPI_FWD && g.beta == 0.f && g.a_colsum == nullptr);
+    DV_REQUIRE(g.split > 0 && g.N == 2 * g.split && g.resid_cols <= g.split);
+    DV_REQUIRE(e->mode == DV_HEADS_SAMPLE || e->mode == DV_HEADS_NLL);
+    if (e->mode == DV_HEADS_SAMPLE) {
+        DV_REQUIRE(e->eps && e->out && e->n_src >= 0 && e->n_src <= g.M);
+        DV_REQUIRE((e->seg_ptr == nullptr) == (e->seg_rows == nullptr));
+        DV_REQUIRE(e->out2 == nullptr || e->sub != nullptr);
+        DV_REQUIRE(e->out3 == nullptr || e->out3_idx != nullptr);
+    } else {
+        DV_REQUIRE(e->x && e->coef && e->part);
+    }
+    lc.map = g_opt[0] >= 0 ? g_opt[0] : 1;
+    const int tiles = ((g.M + 31) / 32) * dv_gemm_heads_tiles(g.split);
+    if (g_opt[4] == 1)
+        hipLaunchKernelGGL((gemm_heads_kernel<32, 64, 64, 4>), dim3(tiles), dim3(256), 0,
+                           static_cast<hipStream_t>(stream), g, lc, *e);
+    else if (g_opt[4] == 2)   // 8 waves split K: per wave the MFMA chain of the 32x32 K-split tiling, A staged once
+        hipLaunchKernelGGL((gemm_heads_kernel<32, 64, 64, 8>), dim3(tiles), dim3(512), 0,
+                           static_cast<hipStream_t>(stream), g, lc, *e);
+    else if (g_opt[4] == -1)
+        hipLaunchKernelGGL((gemm_heads_kernel<32, 32, 64, 4>), dim3(tiles), dim3(256), 0,
+                           static_cast<hipStream_t>(stream), g, lc, *e);
+    else   // default: the 32x32 tiling's eight-wave K split, B lines = 16 + 16 rows of the two heads
+        hipLaunchKernelGGL((gemm_heads_kernel<32, 32, 64, 8>), dim3(tiles), dim3(512), 0,
+                           static_cast<hipStream_t>(stream), g, lc, *e);
+    DV_RETURN_LAUNCH();
 }
 
 extern "C" int dv_gemm_pair(const dv_gemm_desc* d1, const dv_gemm_desc* d2, dv_stream_t stream) {

@@ -717,17 +717,27 @@ __global__ __launch_bounds__(1024) void smalln_bwd_weight_kernel(const float* __
 #pragma unroll
     for (int j = 0; j < kMaxSmallN; ++j) acc[j] = 0.f;
     if (k <= KT) {
-        for (int r = rg; r < M; r += kSnRG) {
-            float dl[kMaxSmallN];
-            if (from_probs) {
-                smalln_dlogits(dprobs + (int64_t)r * lddp, probs + (int64_t)r * ldp, N, dl);
-            } else {
-                for (int j = 0; j < N; ++j) dl[j] = dprobs[(int64_t)r * lddp + j];
-            }
-            const float x = k == KT ? 1.f : (k < K1 ? a1[(int64_t)r * lda1 + k] : a2[(int64_t)r * lda2 + (k - K1)]);
+        // four rows per trip with their loads issued together (rows past M read row M-1 and are masked out):
+        // the kernel is a chain of dependent-load round trips, so fewer trips is what shortens it
+        const float* xs = k < K1 ? a1 + k : a2 + (k - K1);
+        const int64_t ldx = k < K1 ? lda1 : lda2;
+        for (int r0 = rg; r0 < M; r0 += 4 * kSnRG) {
+            float x[4], dl[4][kMaxSmallN];
 #pragma unroll
-            for (int j = 0; j < kMaxSmallN; ++j)
-                if (j < N) acc[j] += dl[j] * x;
+            for (int u = 0; u < 4; ++u) {
+                const int r = r0 + u * kSnRG, rc = r < M ? r : M - 1;
+                x[u] = r < M ? (k == KT ? 1.f : xs[(int64_t)rc * ldx]) : 0.f;
+                if (from_probs) {
+                    smalln_dlogits(dprobs + (int64_t)rc * lddp, probs + (int64_t)rc * ldp, N, dl[u]);
+                } else {
+                    for (int j = 0; j < N; ++j) dl[u][j] = dprobs[(int64_t)rc * lddp + j];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < kMaxSmallN; ++j)
+                    if (j < N) acc[j] += dl[u][j] * x[u];
         }
     }
 #pragma unroll
@@ -1115,13 +1125,14 @@ struct LossTerms {
 
 // all loss scalars of a step in ONE single-workgroup launch: loss[out] += scale * sum_i w[i]*x[i]
 // per term, then ELBO = <w_elbo, loss[0:3]>, CMPL = <w_cmpl, loss[0:8]>  (src/DrVAE.py:611-624)
-__global__ __launch_bounds__(256) void loss_assemble_kernel(LossTerms lt, const float* __restrict__ w_elbo,
+constexpr int kLossThreads = 1024;
+__global__ __launch_bounds__(kLossThreads) void loss_assemble_kernel(LossTerms lt, const float* __restrict__ w_elbo,
                                                             const float* __restrict__ w_cmpl,
                                                             float* __restrict__ loss, int32_t* flag,
                                                             const int32_t* ctr, int add, int32_t* err, int max_spins,
                                                             CounterBump bump, const int32_t* __restrict__ halt,
                                                             int n_halt) {
-    __shared__ float part[4];
+    __shared__ float part[DV_MAX_LOSS_TERMS][kLossThreads / 64];
     __shared__ float acc[8];
     if (flag != nullptr) {      // park until the other launch chain has published its results
         if (threadIdx.x == 0) {
@@ -1140,17 +1151,57 @@ __global__ __launch_bounds__(256) void loss_assemble_kernel(LossTerms lt, const 
         __syncthreads();
         (void)__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);   // every wave acquires
     }
-    if (threadIdx.x < 8) acc[threadIdx.x] = 0.f;
-    __syncthreads();
-    for (int k = 0; k < lt.n; ++k) {
+    // every term's per-thread partial sum first -- all loads of all terms are independent and in flight together
+    // (this is ONE workgroup: its time is the number of dependent load round trips) -- then one reduction stage;
+    // fixed order throughout
+    float ps[DV_MAX_LOSS_TERMS];
+#pragma unroll
+    for (int k = 0; k < DV_MAX_LOSS_TERMS; ++k) {
+        ps[k] = 0.f;
+        if (k >= lt.n) continue;
         const dv_loss_term t = lt.t[k];
-        float s = 0.f;
-        for (int i = threadIdx.x; i < t.n; i += 256) s += (t.w ? t.w[i] : 1.f) * t.x[i];
-        s = dv_wave_sum_all(s);
-        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
-        __syncthreads();
-        if (threadIdx.x == 0) acc[t.out] += t.scale * ((part[0] + part[1]) + (part[2] + part[3]));
-        __syncthreads();
+        if (t.w == nullptr && t.n >= 4 * kLossThreads && (reinterpret_cast<uintptr_t>(t.x) & 15) == 0) {
+            // long unweighted terms (per-tile partial sums of dv_gemm_heads): 16-B loads, four per trip
+            const float4* x4 = reinterpret_cast<const float4*>(t.x);
+            const int n4 = t.n >> 2;
+            float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+            int i = threadIdx.x;
+            for (; i + 3 * kLossThreads < n4; i += 4 * kLossThreads) {
+                const float4 v0 = x4[i], v1 = x4[i + kLossThreads], v2 = x4[i + 2 * kLossThreads],
+                             v3 = x4[i + 3 * kLossThreads];
+                a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+                a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
+                a2.x += v2.x; a2.y += v2.y; a2.z += v2.z; a2.w += v2.w;
+                a3.x += v3.x; a3.y += v3.y; a3.z += v3.z; a3.w += v3.w;
+            }
+            for (; i < n4; i += kLossThreads) {
+                const float4 v0 = x4[i];
+                a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+            }
+            float q = ((a0.x + a0.y) + (a0.z + a0.w)) + ((a1.x + a1.y) + (a1.z + a1.w)) +
+                      (((a2.x + a2.y) + (a2.z + a2.w)) + ((a3.x + a3.y) + (a3.z + a3.w)));
+            for (int j = (n4 << 2) + threadIdx.x; j < t.n; j += kLossThreads) q += t.x[j];
+            ps[k] = q;
+        } else {
+            float q = 0.f;
+            for (int i = threadIdx.x; i < t.n; i += kLossThreads) q += (t.w ? t.w[i] : 1.f) * t.x[i];
+            ps[k] = q;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < DV_MAX_LOSS_TERMS; ++k) {
+        if (k >= lt.n) continue;
+        const float q = dv_wave_sum_all(ps[k]);
+        if ((threadIdx.x & 63) == 0) part[k][threadIdx.x >> 6] = q;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+        for (int k = 0; k < lt.n; ++k) {
+            float q = 0.f;
+            for (int w = 0; w < kLossThreads / 64; ++w) q += part[k][w];
+            acc[lt.t[k].out] += lt.t[k].scale * q;
+        }
     }
     if (threadIdx.x == 0) {
         if (!(flag != nullptr && lt.n == 0)) {     // (parked variant without terms: only the wait and the counters)
@@ -1647,7 +1698,7 @@ extern "C" int dv_loss_assemble(const dv_loss_term* terms, int32_t n_terms, cons
         DV_REQUIRE(terms[i].out >= 0 && terms[i].out < 5 && terms[i].n >= 0 && (terms[i].x || terms[i].n == 0));
         lt.t[i] = terms[i];
     }
-    hipLaunchKernelGGL(loss_assemble_kernel, dim3(1), dim3(256), 0, ST(stream), lt, w_elbo, w_cmpl, loss,
+    hipLaunchKernelGGL(loss_assemble_kernel, dim3(1), dim3(kLossThreads), 0, ST(stream), lt, w_elbo, w_cmpl, loss,
                        (int32_t*)nullptr, (const int32_t*)nullptr, 0, (int32_t*)nullptr, 0, CounterBump{}, halt, n_halt);
     DV_RETURN_LAUNCH();
 }
@@ -1668,7 +1719,7 @@ extern "C" int dv_loss_assemble_after(int32_t* flag, const int32_t* ctr, int32_t
         DV_REQUIRE(terms[i].out >= 0 && terms[i].out <= 4 && terms[i].n >= 0 && (terms[i].x || terms[i].n == 0));
         lt.t[i] = terms[i];
     }
-    hipLaunchKernelGGL(loss_assemble_kernel, dim3(1), dim3(256), 0, ST(stream), lt, w_elbo, w_cmpl, loss, flag, ctr,
+    hipLaunchKernelGGL(loss_assemble_kernel, dim3(1), dim3(kLossThreads), 0, ST(stream), lt, w_elbo, w_cmpl, loss, flag, ctr,
                        add, err, max_spins, bump, halt, n_halt);
     DV_RETURN_LAUNCH();
 }

@@ -183,6 +183,9 @@ class FusedStep(StepSchedule):
         self.late_leaf = os.environ.get('DRVAE_LATE_LEAF', '1') != '0'
         self.side_adam = os.environ.get('DRVAE_SIDE_ADAM', '1') != '0'
         self.fold_join = os.environ.get('DRVAE_FOLD_JOIN', '1') != '0'
+        # the row work that consumes both heads of a block (the reparameterised samples; forward AND backward of
+        # the reconstruction log-likelihood) leaves the heads' own GEMM launch (dv_gemm_heads)
+        self.fuse_heads = os.environ.get('DRVAE_FUSE_HEADS', '1') != '0'
         self.noise_ahead = False          # set by capture(): the side chain draws the NEXT step's noise behind the join
         self._noise_stale = True          # (then) the noise buffer does not hold the draws of the current Philox counter
         self._adam_n = None
@@ -333,6 +336,12 @@ class FusedStep(StepSchedule):
             self._rng_pending = n
 
     # ---------------------------------------------------------------------- forward
+    @staticmethod
+    def _heads_small(dpx):
+        """the paired-heads launch (32 x (32+32) tiles) is for the latency-bound sizes; once the decoder heads
+        alone fill the chip with 128x128 tiles many times over (wide configuration) the plain GEMM + row pass wins"""
+        return ((dpx.shape[0] + 127) // 128) * ((dpx.shape[1] + 127) // 128) < 1024
+
     def beta_pert(self):
         cfg = self.cfg
         if cfg.anneal_perturb_rate_itermax > 0:
@@ -366,21 +375,32 @@ class FusedStep(StepSchedule):
                              ylab=p.ylab if (cfg.has_y and cfg.cont) else None)
             else:
                 K.rows_gather(p.XIN, p.XSRC, p.xin_idx, noise=p.EX if sigma else None, sigma=sigma)
-            # ---- q(z1|x1), q(z2|x2): one pass of the shared encoder
-            Q = p.c_enc.forward([p.XIN])
-            Qmu, Qlv = Q[:, :Z1], Q[:, Z1:]
-            # ---- samples (src/blocks.py:170-174): z1 for every row and z2 for the pairs -- drawn from
-            # q(z1|x1), not q(z2|x2) (quirk 1, src/DrVAE.py:427) -- in one launch
+            # ---- q(z1|x1), q(z2|x2): one pass of the shared encoder; the samples (src/blocks.py:170-174) -- z1
+            # for every row and z2 for the pairs, drawn from q(z1|x1), not q(z2|x2) (quirk 1, src/DrVAE.py:427) --
+            # leave the heads' launch itself (``fuse_heads``) or one launch of their own
+            fuse = self.fuse_heads and self._heads_small(p.DPX)
             Z1blk = p.ZDEC[:L * B]
-            K.reparam_fwd(p.ZDEC[:p.o3], Qmu, Qlv, p.E12, src_idx=p.z_src_idx)
+            if fuse:
+                Q = p.c_enc.forward([p.XIN], heads=dict(sample=dict(
+                    eps=p.E12, out=p.ZDEC[:p.o3], n_src=B, seg_ptr=p.zseg_ptr, seg_rows=p.zseg_rows)))
+                Qmu, Qlv = Q[:, :Z1], Q[:, Z1:]
+            else:
+                Q = p.c_enc.forward([p.XIN])
+                Qmu, Qlv = Q[:, :Z1], Q[:, Z1:]
+                K.reparam_fwd(p.ZDEC[:p.o3], Qmu, Qlv, p.E12, src_idx=p.z_src_idx)
             if cfg.has_pert:
                 # (dual-graph schedule) entry of this launch = the z1 samples are final: lets the side
                 # chain's fprop start before the perturbation function has run
-                P2 = p.c_z2F.forward([Z1blk], resid=Z1blk,
-                                     publish=(self.flags[0:1], self.step_dev, 1) if rec == 'main' else None)
-                # z2Fz1 sample, the classifier input z2Fz1 - z1, and the decoder's copy for the pairs
-                K.reparam_fwd(p.Z2F, P2[:, :Z1], P2[:, Z1:], p.E2F, sub=Z1blk, out2=p.D,
-                              out3=p.ZDEC if Np else None, out3_idx=p.pert_out_idx if Np else None)
+                pub1 = (self.flags[0:1], self.step_dev, 1) if rec == 'main' else None
+                if fuse:
+                    # z2Fz1 sample, the classifier input z2Fz1 - z1, and the decoder's copy for the pairs
+                    p.c_z2F.forward([Z1blk], resid=Z1blk, publish=pub1, heads=dict(sample=dict(
+                        eps=p.E2F, out=p.Z2F, n_src=L * B, sub=Z1blk, out2=p.D, out3=p.ZDEC if Np else None,
+                        out3_idx=p.pert_out_idx if Np else None)))
+                else:
+                    P2 = p.c_z2F.forward([Z1blk], resid=Z1blk, publish=pub1)
+                    K.reparam_fwd(p.Z2F, P2[:, :Z1], P2[:, Z1:], p.E2F, sub=Z1blk, out2=p.D,
+                                  out3=p.ZDEC if Np else None, out3_idx=p.pert_out_idx if Np else None)
         # ---- two independent chains from here: the classifier / fprop chain (many small launches)
         # runs on a side stream next to the decoder chain (the big GEMMs)
         def side_forward(mid=None):
@@ -464,8 +484,16 @@ class FusedStep(StepSchedule):
             pub = None
         # ---- p(x|z): decoder over all stacked samples, then the NLL over genes
         X = cfg.dim_x
-        PX = p.c_decx.forward([p.ZDEC], publish=pub)
-        if self.fuse_bwd:      # train step: d/d(mu, pre-softplus) emitted in the same row pass
+        self._nll_fused = bool(self.fuse_bwd and self.fuse_heads and self._heads_small(p.DPX))
+        if self._nll_fused:    # train step: the heads' launch emits d/d(mu, pre-softplus) and the row sums' partials
+            p.c_decx.forward([p.ZDEC], publish=pub, heads=dict(out=p.DPX, nll=dict(
+                x=p.XIN, xidx=p.tgt, coef=p.c_nll, part=p.NLLP)))
+            PX = None
+        else:
+            PX = p.c_decx.forward([p.ZDEC], publish=pub)
+        if self._nll_fused:
+            pass
+        elif self.fuse_bwd:    # train step: d/d(mu, pre-softplus) emitted in the same row pass
             K.nll_rows_fwdbwd(p.NLL, p.DPX[:, :X], p.DPX[:, X:], p.c_nll, p.XIN, PX[:, :X], PX[:, X:], mode=GAUSS_SIGMA,
                               xidx=p.tgt, sd_act='softplus', sd_shift=1e-3)
         else:
@@ -487,9 +515,10 @@ class FusedStep(StepSchedule):
         chain assemble the scalars (they are a leaf of the step: only the host reads them)."""
         cfg, p = self.cfg, self.plan
         L = cfg.L
-        terms = [(p.NLL[:p.o3], None, 1.0 / (L * p.n_tot), 0)]
+        nll = p.NLLP if getattr(self, '_nll_fused', False) else p.NLL      # (per-tile partials: a row's sum is its term)
+        terms = [(nll[:p.o3], None, 1.0 / (L * p.n_tot), 0)]
         if cfg.has_pert and p.Np:
-            terms.append((p.NLL[p.o3:], None, 1.0 / (L * max(1., p.n_pairs)), 2))
+            terms.append((nll[p.o3:], None, 1.0 / (L * max(1., p.n_pairs)), 2))
             terms.append((p.KLZ2, p.c_klz2, 1.0, 1))           # beta_pert*rate/(L N) lives on the device
         if cfg.kind == 'pvae':
             terms.append((p.KLP, None, 1.0 / p.n_tot, 1))

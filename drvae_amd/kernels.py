@@ -112,6 +112,39 @@ def linear_fwd(out, x, W, bias=None, *, x2=None, scale=None, split=None, act0=0,
          shift0=shift0, shift1=shift1, resid=resid, resid_cols=resid_cols, overread=overread, publish=publish)
 
 
+def heads_tiles(split):
+    """column tiles of ``linear_heads`` (= floats per row of the NLL partial-sum buffer)"""
+    return _lib.load().dv_gemm_heads_tiles(split)
+
+
+def linear_heads(out, x, W, bias=None, *, split, x2=None, scale=None, act0=0, act1=0, shift0=0.0, shift1=0.0,
+                 resid=None, resid_cols=0, overread=False, publish=None, sample=None, nll=None):
+    """Dual-head Linear with the row work on both heads fused into its epilogue (``dv_gemm_heads``).
+    ``sample`` = dict(eps, out, n_src[, seg_ptr, seg_rows, sub, out2, out3, out3_idx]): ``out`` = (mu | logvar) is
+    written and the reparameterised samples of every source row leave the same launch;
+    ``nll`` = dict(x, coef, part[, xidx]): ``out`` receives d/d(mu | pre-activation of std) of the Gaussian
+    log-likelihood rows, ``part`` (M, heads_tiles(split)) their per-tile partial sums."""
+    assert (sample is None) != (nll is None)
+    d = _gemm_desc(out, x, W, True, True, A2=x2, epi=EPI_FWD, scale=scale, bias=bias, split=split, act0=act0, act1=act1,
+                   shift0=shift0, shift1=shift1, resid=resid, resid_cols=resid_cols, overread=overread, publish=publish)
+    e = _lib.HeadsEpi()
+    if sample is not None:
+        g = sample.get
+        e.mode = _lib.HEADS_SAMPLE
+        e.seg_ptr, e.seg_rows, e.n_src = _i32(g('seg_ptr')), _i32(g('seg_rows')), sample['n_src']
+        e.eps, e.lde = _f32(sample['eps'], 'eps'), _ld(sample['eps'])
+        e.out, e.ldo = _f32(sample['out'], 'out'), _ld(sample['out'])
+        e.sub, e.lds = _f32(g('sub'), 'sub'), _ld(g('sub'))
+        e.out2, e.ldo2 = _f32(g('out2'), 'out2'), _ld(g('out2'))
+        e.out3, e.ldo3, e.out3_idx = _f32(g('out3'), 'out3'), _ld(g('out3')), _i32(g('out3_idx'))
+    else:
+        e.mode = _lib.HEADS_NLL
+        e.x, e.ldx, e.xidx = _f32(nll['x'], 'x'), _ld(nll['x']), _i32(nll.get('xidx'))
+        e.coef, e.part = _f32(nll['coef'], 'coef'), _f32(nll['part'], 'part')
+        assert nll['part'].is_contiguous() and tuple(nll['part'].shape) == (out.shape[0], heads_tiles(split))
+    _lib.check(_lib.load().dv_gemm_heads(C.byref(d), C.byref(e), _stream()), 'dv_gemm_heads')
+
+
 def linear_bwd_data(dx, dpre, W, *, kscale=None, alpha=1.0, beta=0.0, yref=None, act=0, shift=0.0, overread=False):
     """dx = beta*dx + alpha*((dpre*kscale) W) * act'(yref)   (W may be a column slice view)."""
     if yref is None:

@@ -145,6 +145,9 @@ class _Plan:
         self.DQ = zf(Me, 2 * Z1)
         self.DPX = mat(Md, 2 * X)
         self.NLL = zf(Md)
+        # per-tile partial sums of the reconstruction rows when they come out of the decoder-heads launch itself
+        # (dv_gemm_heads, DV_HEADS_NLL): row r's log-likelihood = NLLP[r].sum()
+        self.NLLP = zf(Md, K.heads_tiles(X))
         if cfg.has_pert:
             self.c_z2F = _Chain(eng.L_z2F, L * B, dev, resid_cols=Z1)
             self.Z2F, self.D, self.DZ2F = mat(L * B, Z1), mat(L * B, Z1), mat(L * B, Z1)

@@ -142,6 +142,54 @@ int dv_gemm(const dv_gemm_desc* desc, dv_stream_t stream);
  * (dy^T x) and (dy W) layouts -- the weight- and data-gradient of one Linear layer, which both
  * only need dy; otherwise exactly dv_gemm(d1) followed by dv_gemm(d2). */
 int dv_gemm_pair(const dv_gemm_desc* d1, const dv_gemm_desc* d2, dv_stream_t stream);
+/* Dual-head Linear with the ROW work that consumes both heads fused into the epilogue (SURVEY.md K2+K3 /
+ * K2+K5): y = x W^T with W = [W_head0 ; W_head1] (desc->split = rows of head 0, desc->N = 2*split), forward
+ * layout (a_kcontig = b_kcontig = 1), epilogue DV_EPI_FWD exactly as dv_gemm (scale / bias / act0,shift0 |
+ * act1,shift1 / resid).  Each workgroup computes the tile of head-0 columns [c, c+32) TOGETHER with the
+ * head-1 columns [split+c, split+c+32) of the same rows, so element (m, c) sees a0 = head0(m,c) and
+ * a1 = head1(m,c) and neither has to round-trip through HBM for the per-element work that follows:
+ *
+ *  DV_HEADS_SAMPLE  (a0 = mu, a1 = logvar: `DiagGaussianModule.forward` + `sample`, src/blocks.py:291-301,
+ *    170-174; `DiagGaussianModuleLinear`, src/blocks.py:349-361): C = (mu | logvar) is written as by dv_gemm,
+ *    and for every destination row s of source row m (seg_rows[seg_ptr[m] .. seg_ptr[m+1]); seg_ptr == NULL:
+ *    s = m; rows m >= n_src emit nothing):   z = eps[s,c]*exp(logvar/2) + mu;   out[s,c] = z;
+ *    out2[s,c] = z - sub[s,c] (optional);  out3[out3_idx[s], c] = z where out3_idx[s] >= 0 (optional)
+ *    -- the L Monte-Carlo samples of a row (and the z2 samples of a pair, src/DrVAE.py:421-427) leave the
+ *    encoder-heads launch directly.
+ *  DV_HEADS_NLL  (a0 = mu, a1 = std = act1(.) + shift1: `DiagGaussianSigmaModule.forward` + `logp_perx`,
+ *    src/blocks.py:410-416, 233-234), train step only: with xv = x[xidx ? xidx[m] : m, c]
+ *      part[m*n_tiles + t] = -1/2 sum_{c in tile t} [log 2pi + log std^2 + (xv-mu)^2/std^2]   (row NLL = sum_t)
+ *      C[m, c]       = coef[m] * (xv-mu)/std^2                                   = d/d mu
+ *      C[m, split+c] = coef[m] * (-1/std + (xv-mu)^2/std^3) * act1'(.)           = d/d(pre-activation of std)
+ *    i.e. C receives the GRADIENTS (the loss is linear in the row terms with coefficients known up front);
+ *    mu / std themselves are never stored.  n_tiles = ceil(split/32) (dv_gemm_heads_tiles). */
+enum { DV_HEADS_SAMPLE = 1, DV_HEADS_NLL = 2 };
+typedef struct dv_heads_epi {
+    int32_t mode;
+    /* SAMPLE */
+    const int32_t* seg_ptr;
+    const int32_t* seg_rows;
+    int32_t n_src;
+    const float* eps;
+    int64_t lde;
+    float* out;
+    int64_t ldo;
+    const float* sub;
+    int64_t lds;
+    float* out2;
+    int64_t ldo2;
+    float* out3;
+    int64_t ldo3;
+    const int32_t* out3_idx;
+    /* NLL */
+    const float* x;
+    int64_t ldx;
+    const int32_t* xidx;
+    const float* coef;
+    float* part;
+} dv_heads_epi;
+int dv_gemm_heads(const dv_gemm_desc* desc, const dv_heads_epi* epi, dv_stream_t stream);
+int dv_gemm_heads_tiles(int32_t split);
 /* test/tuning hook: 0 = heuristic tiling, 1 = 64x64, 2 = 32x32 K-split, 3 = 128x128 */
 int dv_gemm_force_tiling(int tiling);
 /* test/tuning hook: key 0 = workgroup->tile map (0 linear, 1 XCD chunk-major [default]);

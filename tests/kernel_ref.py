@@ -121,6 +121,39 @@ def linear_fwd(out, x, W, bias=None, *, x2=None, scale=None, split=None, act0=0,
          shift0=shift0, shift1=shift1, resid=resid, resid_cols=resid_cols, publish=publish)
 
 
+def heads_tiles(split):
+    return (split + 15) // 16
+
+
+def linear_heads(out, x, W, bias=None, *, split, x2=None, scale=None, act0=0, act1=0, shift0=0.0, shift1=0.0,
+                 resid=None, resid_cols=0, overread=False, publish=None, sample=None, nll=None):
+    """the unfused sequence ``dv_gemm_heads`` replaces: heads GEMM, then reparam_fwd / nll_rows_fwdbwd"""
+    M, N = out.shape
+    heads = torch.zeros(M, N, device=out.device) if nll is not None else out
+    linear_fwd(heads, x, W, bias, x2=x2, scale=scale, split=split, act0=act0, act1=act1, shift0=shift0, shift1=shift1,
+               resid=resid, resid_cols=resid_cols, publish=publish)
+    mu, sd = heads[:, :split], heads[:, split:]
+    if sample is not None:
+        g = sample.get
+        n_src, eps, dst = sample['n_src'], sample['eps'], sample['out']
+        for r in range(n_src):
+            rows = [r] if g('seg_ptr') is None else \
+                g('seg_rows')[int(g('seg_ptr')[r]):int(g('seg_ptr')[r + 1])].long().tolist()
+            for s_ in rows:
+                z = eps[s_] * torch.exp(0.5 * sd[r]) + mu[r]
+                dst[s_] = z
+                if g('out2') is not None:
+                    g('out2')[s_] = z - g('sub')[s_]
+                if g('out3') is not None and int(g('out3_idx')[s_]) >= 0:
+                    g('out3')[int(g('out3_idx')[s_])] = z
+    else:
+        rows = torch.zeros(M, device=out.device)
+        nll_rows_fwdbwd(rows, out[:, :split], out[:, split:], nll['coef'], nll['x'], mu, sd, mode=GAUSS_SIGMA,
+                        xidx=nll.get('xidx'), sd_act=act1, sd_shift=shift1)
+        nll['part'].zero_()
+        nll['part'][:, 0] = rows              # (any split of a row's sum over the tiles is as good)
+
+
 def linear_bwd_data(dx, dpre, W, *, kscale=None, alpha=1.0, beta=0.0, yref=None, act=0, shift=0.0, overread=False):
     if yref is None:
         gemm(dx, dpre, W, True, False, a_kscale=kscale, alpha=alpha, beta=beta)
@@ -668,7 +701,7 @@ def fill_normal(out, seed, ctr_dev=None):
     out.copy_(torch.randn(out.shape, generator=g).to(out.device))
 
 
-FUNCTIONS = ['fill_normal_rows', 'adamax_l2', 'batch_feed', 'mmd_rff_fwd', 'mmd_rff_bwd', 'counters_add2', 'ycont_fwd', 'ycont_bwd', 'flag_publish', 'flag_wait', 'gemm', 'linear_fwd', 'linear_bwd_data', 'linear_bwd_weight', 'linear_bwd_pair', 'colsum', 'act_bwd_', 'wn_scale', 'wn_bwd',
+FUNCTIONS = ['fill_normal_rows', 'linear_heads', 'heads_tiles', 'adamax_l2', 'batch_feed', 'mmd_rff_fwd', 'mmd_rff_bwd', 'counters_add2', 'ycont_fwd', 'ycont_bwd', 'flag_publish', 'flag_wait', 'gemm', 'linear_fwd', 'linear_bwd_data', 'linear_bwd_weight', 'linear_bwd_pair', 'colsum', 'act_bwd_', 'wn_scale', 'wn_bwd',
              'reparam_fwd', 'reparam_bwd', 'reparam_bwd_seg', 'z2f_post_bwd', 'kl_rows_fwd', 'kl_rows_bwd', 'nll_rows_fwd', 'nll_rows_bwd', 'nll_rows_fwdbwd',
              'softmax_clamp_fwd', 'softmax_clamp_bwd', 'cat_terms_fwd', 'cat_terms_bwd', 'smalln_fwd', 'smalln_bwd_data',
              'smalln_bwd_weight', 'ymarg_fwd', 'ymarg_bwd', 'ymarg_fwdbwd',

@@ -772,3 +772,61 @@ def test_mmd_rff(K, dev, n1, n2, Z, Rr):
     close(m_hip.detach().reshape(1), m.detach().reshape(1), rtol=5e-4, atol=1e-7)
     close(ga, xa.grad, rtol=5e-3, atol=5e-6)
     close(gb, xb.grad, rtol=5e-3, atol=5e-6)
+
+
+@pytest.mark.parametrize('M,S,Kd', [(7, 5, 13), (224, 100, 800), (300, 100, 100), (65, 33, 70), (596, 978, 600)])
+def test_linear_heads_sample(K, dev, M, S, Kd):
+    """dv_gemm_heads / DV_HEADS_SAMPLE: (mu | logvar) + the reparameterised samples of every source row through a
+    CSR fan-out (several draws per row, some rows none) == heads GEMM followed by reparam_fwd; and the
+    identity fan-out with residual, ``out2 = z - sub`` and the scattered copy ``out3``"""
+    x, W, b = rnd(dev, M, Kd, seed=1), rnd(dev, 2 * S, Kd, seed=2, scale=Kd ** -0.5), rnd(dev, 2 * S, seed=3)
+    sc = rnd(dev, 2 * S, seed=4).abs() + 0.5
+    n_src = max(1, (2 * M) // 3)
+    cnt = [(i % 3) + (1 if i % 5 == 0 else 0) for i in range(n_src)]          # 0..3 draws per source row
+    ptr = torch.tensor(np.concatenate([[0], np.cumsum(cnt)]), dtype=torch.int32, device=dev)
+    R_ = int(ptr[-1])
+    rows_ = torch.randperm(R_, generator=torch.Generator().manual_seed(5)).to(torch.int32).to(dev)
+    eps = strided(dev, R_, S, 3, seed=6)
+    for kw in (dict(shift1=-2.0), dict(scale=sc, shift1=-2.0)):
+        outs = []
+        for L in (K, R):
+            q, z = torch.full((M, 2 * S), 7.0, device=dev), torch.full((R_, S), 9.0, device=dev)
+            L.linear_heads(q, x, W, b, split=S, sample=dict(eps=eps, out=z, n_src=n_src, seg_ptr=ptr, seg_rows=rows_), **kw)
+            outs.append((q, z))
+        close(outs[0][0], outs[1][0], **gemm_tol(Kd))
+        close(outs[0][1], outs[1][1], rtol=5e-4, atol=5e-5 * max(1.0, Kd ** 0.5))
+    if Kd == S:      # DiagGaussianModuleLinear shape: mu = x + x W^T + b (src/blocks.py:357)
+        sub = rnd(dev, M, S, seed=7)
+        idx3 = torch.tensor([(i // 2 if i % 2 == 0 else -1) for i in range(M)], dtype=torch.int32, device=dev)
+        outs = []
+        for L in (K, R):
+            q, z, d, o3 = (torch.full(s_, 7.0, device=dev) for s_ in ((M, 2 * S), (M, S), (M, S), ((M + 1) // 2, S)))
+            L.linear_heads(q, x, W, b, split=S, shift1=-2.0, resid=x, resid_cols=S,
+                           sample=dict(eps=eps[:M] if R_ >= M else rnd(dev, M, S, seed=8), out=z, n_src=M, sub=sub, out2=d,
+                                       out3=o3, out3_idx=idx3))
+            outs.append((q, z, d, o3))
+        for a, b_ in zip(*outs):
+            close(a, b_, rtol=5e-4, atol=5e-5 * max(1.0, Kd ** 0.5))
+
+
+@pytest.mark.parametrize('M,S,Kd', [(7, 5, 13), (65, 33, 70), (596, 978, 600), (150, 64, 128)])
+def test_linear_heads_nll(K, dev, M, S, Kd):
+    """dv_gemm_heads / DV_HEADS_NLL: gradients w.r.t. (mu | pre-softplus) and per-tile partial row sums of the Gaussian
+    log-likelihood == heads GEMM + nll_rows_fwdbwd, x rows addressed through an index list"""
+    x, W, b = rnd(dev, M, Kd, seed=1), rnd(dev, 2 * S, Kd, seed=2, scale=Kd ** -0.5), rnd(dev, 2 * S, seed=3)
+    nx = max(1, M // 2)
+    xt = strided(dev, nx, S, 2, seed=4)
+    xidx = torch.tensor([i % nx for i in range(M)], dtype=torch.int32, device=dev)
+    coef = rnd(dev, M, seed=5)
+    nt = K.heads_tiles(S)
+    got, ref = torch.full((M, 2 * S), 7.0, device=dev), torch.zeros(M, 2 * S, device=dev)
+    pg, pr = torch.full((M, nt), 3.0, device=dev), torch.zeros(M, nt, device=dev)
+    kw = dict(split=S, act0='identity', act1='softplus', shift1=1e-3)
+    K.linear_heads(got, x, W, b, nll=dict(x=xt, xidx=xidx, coef=coef, part=pg), **kw)
+    R.linear_heads(ref, x, W, b, nll=dict(x=xt, xidx=xidx, coef=coef, part=pr), **kw)
+    tol = gemm_tol(Kd)
+    # the gradients divide by std^2..std^3 (std >= 1e-3 + softplus): compare relative to their scale
+    scale_ = float(ref.abs().max())
+    close(got / scale_, ref / scale_, rtol=2e-3, atol=2e-5 * max(1.0, Kd ** 0.5))
+    close(pg.sum(1), pr.sum(1), rtol=2e-4, atol=1e-3 * S ** 0.5)
+    assert bool(torch.isfinite(got).all()) and bool(torch.isfinite(pg).all())
