@@ -146,6 +146,18 @@ def fit_policy_cases():
     return out
 
 
+def masked_linear_cases():
+    """stacks of (in_features, out_features, output_layer, rev_order); layer i > 0 is built on the ``get_m()`` of
+    layer i - 1 (the first on ``m_pre=None``)"""
+    out = OrderedDict()
+    out['made_6'] = [(6, 9, False, False), (9, 4, False, False), (4, 6, True, False)]
+    out['made_6_rev'] = [(6, 9, False, True), (9, 6, True, True)]
+    out['made_cond'] = [((5, 3), 12, False, False), (12, 7, False, False), (7, 5, True, False)]
+    out['made_cond_rev'] = [([4, 2, 1], 8, False, True), (8, 4, True, True)]
+    out['made_narrow'] = [(7, 3, False, False), (3, 7, True, False)]
+    return out
+
+
 def y_metric_cases():
     rs = np.random.RandomState(4242)
     out = OrderedDict()

@@ -29,6 +29,7 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
+OUT = os.environ.get('DRVAE_GOLDEN_OUT', HERE)     # (tests/test_golden_regen.py regenerates into a scratch directory)
 sys.path.insert(0, ROOT)
 sys.dont_write_bytecode = True
 
@@ -458,6 +459,15 @@ def run_fit_cases():
                 out[tag + '/ref_raises'] = np.int64(0)
             except NameError:
                 out[tag + '/ref_raises'] = np.int64(1)
+            # ... and with the one missing name supplied the reference's own branch runs: its values are pinned too
+            import DGMMixin as rdgm
+            rdgm.blk = rblk
+            try:
+                rr = model.eval_y_prediction(*args)
+                for k in ('acc', 'auroc', 'aupr'):
+                    out['%s/ref_with_blk/%s' % (tag, k)] = np.float64(float(rr[k]))
+            finally:
+                del rdgm.blk
             import sklearn.metrics as skm
             oh = _one_hot(args[2], c['proba'].shape[1]).numpy()
             res = dict(acc=float((args[0].int() == args[2].int()).float().mean()),
@@ -529,20 +539,48 @@ def run_mmd_criterion_cases():
         out['raises_as_shipped'] = np.int64(1)
     rdgm.Variable = torch.autograd.Variable
     rdgm.blk = rblk
-    for tag, c in C.mmd_criterion_cases().items():
-        z = torch.from_numpy(c['z']).clone().requires_grad_(True)
-        sind = [torch.from_numpy(v) for v in c['sind']]
-        me = types.SimpleNamespace(kernel_MMD=c['kernel'])
-        with Replay(c['normals'], c['uniforms']):
-            val = rdgm.DeepGenerativeModelMixin._get_mmd_criterion(me, z, sind)
-        val.backward()
-        out['%s/value' % tag] = val.detach().numpy().astype(np.float64)
-        out['%s/grad_z' % tag] = z.grad.numpy().copy()
+    try:
+        for tag, c in C.mmd_criterion_cases().items():
+            z = torch.from_numpy(c['z']).clone().requires_grad_(True)
+            sind = [torch.from_numpy(v) for v in c['sind']]
+            me = types.SimpleNamespace(kernel_MMD=c['kernel'])
+            with Replay(c['normals'], c['uniforms']):
+                val = rdgm.DeepGenerativeModelMixin._get_mmd_criterion(me, z, sind)
+            val.backward()
+            out['%s/value' % tag] = val.detach().numpy().astype(np.float64)
+            out['%s/grad_z' % tag] = z.grad.numpy().copy()
+    finally:
+        # leave the reference module as shipped: the fit section pins that its macro-averaged AUROC / AUPR branch
+        # raises for want of ``blk`` (one full run of this script must reproduce every fixture)
+        del rdgm.Variable, rdgm.blk
+    return out
+
+
+def run_masked_linear_cases():
+    """MADE masks of the reference's ``MaskedLinear`` (src/layers.py:44-133): ``mask``, ``m`` / ``get_m()`` and
+    ``m_pre`` for an input layer (int and tuple ``in_features``, natural and reversed order), hidden layers
+    stacked on ``get_m()`` (also wider than the cyclic 1..D-1 pattern) and output layers (both orders).
+    Integer / 0-1 work: pinned bit-exactly."""
+    out = {}
+    for tag, c in C.masked_linear_cases().items():
+        m_pre = None
+        for li, (in_f, out_f, output_layer, rev) in enumerate(c):
+            lay = rlyr.MaskedLinear(in_f, out_f, m_pre, output_layer, rev_order=rev)
+            out['%s/%d/mask' % (tag, li)] = lay.mask.data.numpy().astype(np.float32)
+            out['%s/%d/m' % (tag, li)] = np.asarray(lay.get_m()).astype(np.int64)
+            out['%s/%d/m_pre' % (tag, li)] = np.asarray(lay.m_pre).astype(np.int64)
+            out['%s/%d/weight_shape' % (tag, li)] = np.asarray(lay.weight.shape, np.int64)
+            m_pre = lay.get_m()
     return out
 
 
 def main():
+    global HERE
+    HERE = OUT
     os.makedirs(HERE, exist_ok=True)
+    ml = run_masked_linear_cases()
+    np.savez_compressed(os.path.join(HERE, 'masked_linear.npz'), **ml)
+    print('masked_linear.npz', len(ml), 'arrays')
     mm = run_mmd_criterion_cases()
     np.savez_compressed(os.path.join(HERE, 'mmd_criterion.npz'), **mm)
     print('mmd_criterion.npz', len(mm), 'arrays', {k: float(v) for k, v in mm.items() if k.endswith('value')})

@@ -65,6 +65,9 @@ def test_y_metrics_match_reference(G, tag):
             assert np.isnan(got[k])
         else:
             assert got[k] == pytest.approx(want, rel=1e-6 if k == 'acc' else 1e-12)
+        rb = '%s/ref_with_blk/%s' % (tag, k)       # the reference's own macro branch, run with its missing name supplied
+        if rb in G.files:
+            assert got[k] == pytest.approx(float(G[rb]), rel=1e-6 if k == 'acc' else 1e-12)
 
 
 def test_y_metrics_random_vs_sklearn():
