@@ -66,7 +66,7 @@ def test_y_metrics_match_reference(G, tag):
         else:
             assert got[k] == pytest.approx(want, rel=1e-6 if k == 'acc' else 1e-12)
         rb = '%s/ref_with_blk/%s' % (tag, k)       # the reference's own macro branch, run with its missing name supplied
-        if rb in G.files:
+        if rb in G:
             assert got[k] == pytest.approx(float(G[rb]), rel=1e-6 if k == 'acc' else 1e-12)
 
 
