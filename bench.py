@@ -34,9 +34,19 @@ WORKLOADS = {
              'DrVAE wide synthetic: 20000 genes, z1=z3=200, enc 2048, dec 2048 (assumed), batch 1024/GPU, L=4'),
 }
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak (dense, exact fp32)
-# HBM-side bytes per GEMM launch from the PMC passes (FETCH_SIZE x2 gfx950 wide-load correction +
-# WRITE_SIZE; rocprofv3 cannot run inside this process): profiles/r01_cfg2_pmc_summary.txt
-PMC_TRAFFIC_BYTES_PER_GEMM_LAUNCH = {'cfg2': 9.50e6}
+
+
+def profiled_roofline(workload):
+    """What the committed profiler output says about this workload: profiles/rNN_<workload>_roofline.json, written by
+    tools/roofline_from_profile.py from the rocprofv3 --kernel-trace --stats summary (GEMM time per step IN the
+    running step) and the --pmc passes (memory-side bytes).  rocprofv3 cannot run inside this process, so these are
+    the figures of the profiled run of the same command; nothing is baked into this file."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_%s_roofline.json' % workload)))
+    if not files:
+        return None, None
+    with open(files[-1]) as fh:
+        return json.load(fh), os.path.relpath(files[-1], ROOT)
 
 
 def build(workload, device, rank, world, seed=123):
@@ -179,7 +189,7 @@ def parity_vs_cpu(workload, device, steps=2):
             'what': 'HIP train steps vs CPU oracle, identical parameters / batch / injected noise'}
 
 
-def gemm_roofline(eng, cfg, rows, frac_pair, frac_lab, repeats=20, traffic=None):
+def gemm_roofline(eng, cfg, rows, frac_pair, frac_lab, repeats=20, workload='cfg2', n_params=0, input_bytes=0):
     """Roofline of the dominant kernel family: the fp32-MFMA GEMM (all tilings/layouts; 32
     launches per cfg-2 step).  Every GEMM launch of one train step is re-issued `repeats`
     times back to back from a small hipGraph and timed with HIP events recorded on the
@@ -189,33 +199,46 @@ def gemm_roofline(eng, cfg, rows, frac_pair, frac_lab, repeats=20, traffic=None)
     import drvae_amd.kernels as K
     from drvae_amd import synth
     calls = []
-    real_gemm, real_pair = K.gemm, K.linear_bwd_pair
+    real_gemm, real_pair, real_heads = K.gemm, K.linear_bwd_pair, K.linear_heads
+    nbytes = lambda *ts: 4.0 * sum(t.numel() for t in ts if t is not None)
 
     def rec_gemm(Cm, A, B, a_kc, b_kc, **kw):
         M_, N_ = Cm.shape
         K_ = (A.shape[1] + (kw['A2'].shape[1] if kw.get('A2') is not None else 0)) if a_kc else A.shape[0]
         calls.append((lambda: real_gemm(Cm, A, B, a_kc, b_kc, **kw), [Cm] if kw.get('beta', 0.0) != 0.0 else [],
-                      2.0 * M_ * N_ * K_, ('gemm', M_, N_, K_, int(bool(a_kc)), int(bool(b_kc)))))
+                      2.0 * M_ * N_ * K_, ('gemm', M_, N_, K_, int(bool(a_kc)), int(bool(b_kc))),
+                      nbytes(Cm, A, B, kw.get('A2'))))
         real_gemm(Cm, A, B, a_kc, b_kc, **kw)
+
+    def rec_heads(out, x, W, bias=None, **kw):       # dual-head product with its row work fused in (dv_gemm_heads)
+        M_, N_ = out.shape
+        K_ = x.shape[1] + (kw['x2'].shape[1] if kw.get('x2') is not None else 0)
+        calls.append((lambda: real_heads(out, x, W, bias, **kw), [], 2.0 * M_ * N_ * K_,
+                      ('heads ' + ('nll' if kw.get('nll') is not None else 'sample'), M_, N_, K_),
+                      nbytes(out, x, W, kw.get('x2'))))
+        real_heads(out, x, W, bias, **kw)
 
     def rec_pair(dW, dbias, dx, dpre, x, W, **kw):      # dW = dpre^T x and dx = dpre W share one launch
         Mb, Nw = dpre.shape
         calls.append((lambda: real_pair(dW, dbias, dx, dpre, x, W, **kw), [dx] if kw.get('beta_x', 0.0) != 0.0 else [],
                       2.0 * Mb * Nw * x.shape[1] + 2.0 * Mb * Nw * dx.shape[1],
-                      ('pair dW+dX', Mb, Nw, x.shape[1], dx.shape[1])))
+                      ('pair dW+dX', Mb, Nw, x.shape[1], dx.shape[1]), nbytes(dW, dx, dpre, x, W)))
         real_pair(dW, dbias, dx, dpre, x, W, **kw)
 
-    K.gemm, K.linear_bwd_pair = rec_gemm, rec_pair
+    K.gemm, K.linear_bwd_pair, K.linear_heads = rec_gemm, rec_pair, rec_heads
     try:
         eng.training = True
+        eng.fuse_bwd = True              # the launch sequence of the TRAIN step (fused heads epilogues included)
         eng.draw_noise()
         eng.forward()
         eng.backward()
         torch.cuda.synchronize()
     finally:
-        K.gemm, K.linear_bwd_pair = real_gemm, real_pair
+        eng.fuse_bwd = False
+        K.gemm, K.linear_bwd_pair, K.linear_heads = real_gemm, real_pair, real_heads
     per_call = []
-    for (fn, accum, flops, shape) in calls:
+    gemm_bytes = sum(c[4] for c in calls)
+    for (fn, accum, flops, shape, _) in calls:
         keep = [t.clone() for t in accum]
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
@@ -237,17 +260,46 @@ def gemm_roofline(eng, cfg, rows, frac_pair, frac_lab, repeats=20, traffic=None)
     algorithmic = synth.gemm_flops_per_step(cfg, rows, frac_pair, frac_lab)
     achieved = algorithmic / t_step / 1e12
     top = sorted(per_call, key=lambda r: -r[0])[:3]
-    return {'bound': 'mfma', 'achieved': round(achieved, 3), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-            'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': traffic,
-            'traffic_source': 'profiles/r01_cfg2_pmc_summary.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)'
-            if traffic else None,
-            'kernel': 'gemm_kernel / gemm_pair_kernel<...> (fp32 v_mfma_f32_32x32x2_f32; all tilings/layouts)',
-            'launches_per_step': len(per_call), 'avg_launch_us': round(1e6 * t_step / len(per_call), 2),
-            'gemm_us_per_step': round(1e6 * t_step, 1),
-            'algorithmic_gflop_per_step': round(algorithmic / 1e9, 3),
-            'executed_gflop_per_step': round(executed / 1e9, 3),
-            'top_launches': [{'shape': list(sh), 'us': round(1e6 * t, 2), 'tflops': round(f / t / 1e12, 2)}
-                             for t, f, sh in top]}
+    prof, prof_file = profiled_roofline(workload)
+    # inputs + parameters read forward and backward + gradient write + Adam's 7 words per parameter
+    alg_bytes = input_bytes + 4.0 * n_params * (2 + 1 + 7)
+    out = {'bound': 'mfma', 'achieved': round(achieved, 3), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+           'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+           'how': 'live: every GEMM-family launch of one step re-issued %dx back to back from a hipGraph on an idle chip, '
+                  'HIP events on the launch stream; achieved = algorithmic GEMM FLOPs per step / sum of the per-launch '
+                  'times (= avg FLOPs per launch / avg launch duration)' % repeats,
+           'kernel': 'gemm_kernel / gemm_pair_kernel / gemm_heads_kernel<...> (fp32 v_mfma_f32_32x32x2_f32; all tilings/layouts)',
+           'launches_per_step': len(per_call), 'avg_launch_us': round(1e6 * t_step / len(per_call), 2),
+           'gemm_us_per_step': round(1e6 * t_step, 1),
+           'algorithmic_gflop_per_step': round(algorithmic / 1e9, 3),
+           'executed_gflop_per_step': round(executed / 1e9, 3),
+           'algorithmic_mbytes_per_step': round(alg_bytes / 1e6, 2),
+           'algorithmic_gemm_mbytes_per_step': round(gemm_bytes / 1e6, 2),
+           'top_launches': [{'shape': list(sh), 'us': round(1e6 * t, 2), 'tflops': round(f / t / 1e12, 2)}
+                            for t, f, sh in top],
+           'traffic': None}
+    if prof is not None:
+        tr, ig = prof.get('traffic'), prof.get('gemm_in_graph')
+        out['profile'] = prof_file
+        if tr:      # memory-side bytes per GEMM launch (like `achieved`), and per step next to the algorithmic figure
+            out['traffic'] = round(1e6 * tr['gemm']['per_launch_corrected_upper_mb'])
+            out['traffic_unit'] = 'bytes per GEMM launch (FETCH_SIZE x2 gfx950 wide-load correction + WRITE_SIZE)'
+            out['traffic_per_step_mb'] = {k: tr[k] for k in ('fetch_reported', 'fetch_corrected_upper', 'write',
+                                                             'total_reported', 'total_corrected_upper') if k in tr}
+            out['traffic_per_step_mb']['gemm_total_corrected_upper'] = round(
+                tr['gemm']['fetch_corrected_upper'] + tr['gemm']['write'], 1)
+            out['wasted_ratio'] = {'step_upper': round(tr['total_corrected_upper'] * 1e6 / alg_bytes, 2),
+                                   'step_reported': round(tr['total_reported'] * 1e6 / alg_bytes, 2),
+                                   'gemm_upper': round((tr['gemm']['fetch_corrected_upper'] + tr['gemm']['write']) * 1e6
+                                                       / max(gemm_bytes, 1.0), 2)}
+        if ig and 'kernel_us_per_step' in ig:   # the same FLOPs over the GEMM kernel time of the RUNNING step
+            a2 = algorithmic / (ig['kernel_us_per_step'] * 1e-6) / 1e12
+            out['in_graph'] = {'gemm_us_per_step': ig['kernel_us_per_step'], 'launches_per_step': ig['launches_per_step'],
+                               'avg_launch_us': ig['avg_launch_us'], 'achieved': round(a2, 3),
+                               'frac': round(a2 / FP32_MFMA_PEAK_TFLOPS, 4),
+                               'how': 'rocprofv3 --kernel-trace --stats of this command (both chains running, main '
+                                      'chain on its CU partition): ' + prof_file}
+    return out
 
 
 def _free_port():
@@ -441,8 +493,9 @@ def main():
         hx, hy = batch['has_x2'].astype(bool), batch['has_y'].astype(bool)
         if not args.no_roofline:
             out['roofline'] = gemm_roofline(eng, cfg, rows, float(hx.mean()), float(hy.mean()),
-                                            repeats=20 if args.workload != 'wide' else 3,
-                                            traffic=PMC_TRAFFIC_BYTES_PER_GEMM_LAUNCH.get(args.workload))
+                                            repeats=20 if args.workload != 'wide' else 3, workload=args.workload,
+                                            n_params=out['config']['params'],
+                                            input_bytes=4.0 * rows * cfg.dim_x * (2 if cfg.has_pert else 1))
         if not args.no_cpu_baseline and args.workload != 'wide' and world == 1:   # rank 0 at N=1 only
             out['cpu_baseline'] = cpu_baseline(args.workload)
             out['elbo_vs_ref'] = parity_vs_cpu(args.workload, device)

@@ -9,7 +9,8 @@ rm -rf $O && mkdir -p $O
 python3 bench.py --steps 300 --warmup 20 > $O/cfg2_bench.json 2> $O/cfg2_bench.err
 python3 bench.py --workload wide --steps 6 --warmup 2 --no-cpu-baseline > $O/wide_bench.json 2> $O/wide_bench.err
 export DRVAE_SIDE_CUS=64      # fixed split: no tuning replays in the profile
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/k2 -o p -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline > $O/cfg2_prof.log 2>&1
+# (--no-roofline: the roofline leg re-issues every GEMM launch; the summary must hold the running step's launches only)
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/k2 -o p -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-roofline > $O/cfg2_prof.log 2>&1
 cp $(find $O/k2 -name '*kernel_stats.csv' | head -1) $O/cfg2_kernel_stats.csv
 python3 tools/timeline.py $(find $O/k2 -name '*kernel_trace.csv' | head -1) > $O/cfg2_step_timeline.txt 2>&1
 rm -rf $O/k2
@@ -20,4 +21,6 @@ unset DRVAE_SIDE_CUS
 bash tools/pmc_collect.sh > $O/pmc.log 2>&1
 python3 tools/pmc_summary.py gpurun_out/pmc_r1 > $O/cfg2_pmc_summary.txt 2>&1
 rm -rf gpurun_out/pmc_r1
+# every figure of bench.py's roofline block that a profiler has to supply, derived from the files above
+python3 tools/roofline_from_profile.py $O/cfg2 --out $O/cfg2_roofline.json > /dev/null 2>&1
 ls -la $O
