@@ -46,7 +46,7 @@ HEADS_SAMPLE, HEADS_NLL = 1, 2
 
 
 class LossTerm(C.Structure):
-    _fields_ = [('x', _p), ('w', _p), ('n', _i32), ('scale', _f), ('out', _i32)]
+    _fields_ = [('x', _p), ('w', _p), ('n', _i32), ('scale', _f), ('out', _i32), ('row_len', _i32)]
 
 
 # name -> argtypes (restype is int unless noted); mirrors include/drvae_hip.h one to one
@@ -98,6 +98,7 @@ SIGNATURES = {
     'dv_rows_gather': [_p, _i64, _p, _i32, _i32, _p, _i64, _f, _p, _i32, _p, _i64, _p],
     'dv_batch_feed': [_p, _i64, _p, _i64, _p, _p, _i32, _p, _p, _i32, _p, _i32, _i32, _p, _i64, _f, _p, _i64, _p, _i32,
                       _p, _p, _p, _p, _i32, _p, _p, _i64, _i32, _p, _p, _i32, _p],
+    'dv_batch_masks': [_p, _i32, _p, _p, _p, _p, _p, _i32, _i32, _f, _f, _f, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     'dv_rows_segment_sum': [_p, _i64, _p, _p, _p, _i32, _i32, _p, _p, _i64, _f, C.POINTER(Wait), _p],
     'dv_weighted_sum': [_p, _p, _p, _i32, _f, _p, _f, _p],
     'dv_recon_row_stats': [_p, _i64, _p, _i64, _i32, _i32, _p, _p],

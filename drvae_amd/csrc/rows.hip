@@ -768,6 +768,12 @@ __global__ void ymarg_fwd_kernel(const float* __restrict__ qy, int64_t ldq, cons
     if (nf == 1) {
         yl[r] = logf(q[label[r]]);
         kld[r] = klfp[f0];
+    } else if (label[r] <= -2) {
+        // labeled row of a batch-independent ("universal") plan: all Y class slots are materialised, the
+        // true class c = -2 - label[r] is the one that counts (see dv_batch_masks)
+        const int lab = -2 - label[r];
+        yl[r] = logf(q[lab]);
+        kld[r] = klfp[f0 + lab];
     } else {
         float a = 0.f, b = 0.f;
         for (int j = 0; j < Y; ++j) {
@@ -794,6 +800,12 @@ __global__ void ymarg_bwd_kernel(const float* __restrict__ qy, int64_t ldq, cons
         const int lab = label[r];
         for (int j = 0; j < Y; ++j) dq[j] = (j == lab) ? c_yl[r] / q[j] : 0.f;
         cfp[f0] = ck;
+    } else if (label[r] <= -2) {
+        const int lab = -2 - label[r];
+        for (int j = 0; j < Y; ++j) {
+            dq[j] = (j == lab) ? c_yl[r] / q[j] : 0.f;
+            cfp[f0 + j] = (j == lab) ? ck : 0.f;
+        }
     } else {
         for (int j = 0; j < Y; ++j) {
             cfp[f0 + j] = ck * q[j];
@@ -821,6 +833,14 @@ __global__ void ymarg_fwdbwd_kernel(const float* __restrict__ qy, int64_t ldq, c
         kld[r] = klfp[f0];
         for (int j = 0; j < Y; ++j) dq[j] = (j == lab) ? c_yl[r] / q[j] : 0.f;
         cfp[f0] = ck;
+    } else if (label[r] <= -2) {
+        const int lab = -2 - label[r];
+        yl[r] = logf(q[lab]);
+        kld[r] = klfp[f0 + lab];
+        for (int j = 0; j < Y; ++j) {
+            dq[j] = (j == lab) ? c_yl[r] / q[j] : 0.f;
+            cfp[f0 + j] = (j == lab) ? ck : 0.f;
+        }
     } else {
         float a = 0.f, b = 0.f;
         for (int j = 0; j < Y; ++j) {
@@ -1018,6 +1038,84 @@ __global__ __launch_bounds__(256) void batch_feed_kernel(
     }
 }
 
+// Per-batch masks of a batch-INDEPENDENT ("universal") step plan: the plan materialises every row as a pair with
+// every class slot, and which rows really are pairs / labeled is data -- coefficient and weight vectors computed
+// here, on the device, from the flags of the batch (src/DrVAE.py:565-624: group split + per-example normalisers
+// N_total / max(1, N_pairs) / max(1, N_labeled), with N_pairs and N_labeled counted per batch).  One workgroup.
+// Row i of the batch is dataset row table[b, i] (graph-resident epoch feed) or i itself (table == NULL).
+struct MaskArgs {
+    const int32_t* table;
+    int n_batches;
+    const int32_t* ctr;
+    const int32_t* base;
+    const int32_t* hx;
+    const int32_t* hy;
+    const int32_t* y;
+    int B, L;
+    float n_tot, kl_rate, pert_rate, yl_rate;
+    const float* beta;
+    float* c_nll;     // (3 L B): z1 rows | z2 rows | z2Fz1 rows
+    float* c_klz2;    // (L B)
+    float* c_yl;      // (L B)
+    float* w_recl;    // (2 L B)  weights of RECL over the z1 | z2 rows
+    float* w_pert;    // (L B)
+    float* w_yl;      // (L B)
+    int32_t* label;   // (L B): -2 - class for labeled rows, 0 otherwise (see ymarg_*_kernel)
+    float* c_klp;     // (2 B), optional: KL-to-prior rows of q(z1|x1) | q(z2|x2) (PVAE, src/PVAE.py:330-345)
+};
+
+__global__ __launch_bounds__(1024) void batch_masks_kernel(MaskArgs a) {
+    __shared__ int cnt[2];
+    if (threadIdx.x < 2) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const int32_t* tb = nullptr;
+    if (a.table) {
+        int b = a.ctr[0] - a.base[0];
+        b = b < 0 ? 0 : (b >= a.n_batches ? a.n_batches - 1 : b);
+        tb = a.table + (int64_t)b * a.B;
+    }
+    int np = 0, nl = 0;
+    for (int i = threadIdx.x; i < a.B; i += blockDim.x) {
+        const int src = tb ? tb[i] : i;
+        np += (a.hx && a.hx[src] != 0) ? 1 : 0;
+        nl += (a.hy && a.hy[src] != 0) ? 1 : 0;
+    }
+    // integer counts: order-independent, so atomics keep the step reproducible
+    if (np) atomicAdd(&cnt[0], np);
+    if (nl) atomicAdd(&cnt[1], nl);
+    __syncthreads();
+    const float Lf = (float)a.L, beta = a.beta ? a.beta[0] : 1.f;
+    const float n_pairs = cnt[0] > 0 ? (float)cnt[0] : 1.f, n_lab = cnt[1] > 0 ? (float)cnt[1] : 1.f;
+    const float c_tot = 1.f / (Lf * a.n_tot);
+    const int LB = a.L * a.B;
+    for (int r = threadIdx.x; r < LB; r += blockDim.x) {
+        const int i = r % a.B, src = tb ? tb[i] : i;
+        const bool px = a.hx && a.hx[src] != 0, py = a.hy && a.hy[src] != 0;
+        if (a.c_nll) {
+            a.c_nll[r] = -c_tot;
+            a.w_recl[r] = c_tot;
+            if (a.hx) {
+                a.c_nll[LB + r] = px ? -c_tot : 0.f;
+                a.w_recl[LB + r] = px ? c_tot : 0.f;
+                a.c_nll[2 * LB + r] = px ? -beta * a.pert_rate / (Lf * n_pairs) : 0.f;
+                a.w_pert[r] = px ? 1.f / (Lf * n_pairs) : 0.f;
+                a.c_klz2[r] = px ? beta * a.kl_rate * c_tot : 0.f;
+            }
+        }
+        if (a.hy) {
+            a.c_yl[r] = py ? -a.yl_rate / (Lf * n_lab) : 0.f;
+            a.w_yl[r] = 1.f / (Lf * n_lab);
+            a.label[r] = py ? -2 - a.y[src] : 0;
+        }
+    }
+    if (a.c_klp)
+        for (int i = threadIdx.x; i < a.B; i += blockDim.x) {
+            const int src = tb ? tb[i] : i;
+            a.c_klp[i] = 1.f / a.n_tot;
+            a.c_klp[a.B + i] = (a.hx && a.hx[src] != 0) ? 1.f / a.n_tot : 0.f;
+        }
+}
+
 __global__ void rows_segment_sum_kernel(const float* __restrict__ src, int64_t lds,
                                         const int32_t* __restrict__ seg_ptr, const int32_t* __restrict__ seg_rows,
                                         const float* __restrict__ w, int n, int W,
@@ -1184,7 +1282,12 @@ __global__ __launch_bounds__(kLossThreads) void loss_assemble_kernel(LossTerms l
             ps[k] = q;
         } else {
             float q = 0.f;
-            for (int i = threadIdx.x; i < t.n; i += kLossThreads) q += (t.w ? t.w[i] : 1.f) * t.x[i];
+            const int rl = t.row_len > 1 ? t.row_len : 1;     // x is (rows, row_len): one weight per ROW
+            if (rl == 1) {
+                for (int i = threadIdx.x; i < t.n; i += kLossThreads) q += (t.w ? t.w[i] : 1.f) * t.x[i];
+            } else {
+                for (int i = threadIdx.x; i < t.n; i += kLossThreads) q += (t.w ? t.w[i / rl] : 1.f) * t.x[i];
+            }
             ps[k] = q;
         }
     }
@@ -1642,6 +1745,21 @@ extern "C" int dv_batch_feed(const float* x1, int64_t ld1, const float* x2, int6
     hipLaunchKernelGGL(batch_feed_kernel, dim3(row_blocks + lab_blocks), dim3(256), 0, ST(stream), x1, ld1, x2, ld2, y,
                        table, n_batches, ctr, base, B, pair_rows, Np, X, noise, ldn, sigma, xin, ldo, has_y, L,
                        label_r, fp_i, fp_lab, fp_slot, Mf, fp_cls, onehot, ldh, Y, row_blocks, v4 ? 1 : 0, yf, ylab, Yc);
+    DV_RETURN_LAUNCH();
+}
+
+extern "C" int dv_batch_masks(const int32_t* table, int32_t n_batches, const int32_t* ctr, const int32_t* base,
+                              const int32_t* hx, const int32_t* hy, const int32_t* y, int32_t B, int32_t L,
+                              float n_tot, float kl_rate, float pert_rate, float yl_rate, const float* beta,
+                              float* c_nll, float* c_klz2, float* c_yl, float* w_recl, float* w_pert, float* w_yl,
+                              int32_t* label, float* c_klp, dv_stream_t stream) {
+    DV_REQUIRE(B >= 1 && L >= 1 && n_tot > 0.f && c_nll && w_recl);
+    DV_REQUIRE(table == nullptr || (ctr && base && n_batches >= 1));
+    DV_REQUIRE(hx == nullptr || (c_klz2 && w_pert));
+    DV_REQUIRE(hy == nullptr || (y && c_yl && w_yl && label));
+    MaskArgs a{table, n_batches, ctr, base, hx, hy, y, B, L, n_tot, kl_rate, pert_rate, yl_rate, beta, c_nll, c_klz2,
+               c_yl, w_recl, w_pert, w_yl, label, c_klp};
+    hipLaunchKernelGGL(batch_masks_kernel, dim3(1), dim3(1024), 0, ST(stream), a);
     DV_RETURN_LAUNCH();
 }
 

@@ -116,8 +116,19 @@ class DeviceBatcher:
     """Stratified, weighted, with-replacement minibatches drawn ON the device and written
     straight into the fused step's input buffers (see the module docstring)."""
 
-    def __init__(self, dataset, weights, batch_size, group_counts=None, seed=0):
+    def __init__(self, dataset, weights, batch_size, group_counts=None, seed=0, mode='stratified'):
+        """``mode='stratified'`` (default): every batch has the SAME composition (the expected counts of the four
+        groups under the weights, or ``group_counts``) -- rows within a group drawn with replacement by weight;
+        the step runs on the plan of exactly that structure.
+        ``mode='sampler'``: the reference's pipeline to the letter (src/run_drvae.py:150-166):
+        ``WeightedRandomSampler(weights, len(weights))`` -- len(dataset) i.i.d. draws with replacement by weight --
+        cut into consecutive batches with ``drop_last``; the composition of a batch is whatever the draws give, so
+        the step runs on the batch-independent ("universal") plan with on-device group masks."""
+        # a dataset shorter than one batch is ONE batch of all its rows: DataLoader(drop_last=(len >= batch_size))
+        batch_size = min(batch_size, len(dataset))
         self.ds, self.batch_size = dataset, batch_size
+        self.mode = mode
+        assert mode in ('stratified', 'sampler')
         dev = dataset.x1.device
         w = torch.as_tensor(weights, dtype=torch.float64).to(dev)
         hy = dataset.has_y.reshape(-1).bool()
@@ -141,6 +152,9 @@ class DeviceBatcher:
         self.gen = torch.Generator(device=dev)
         self.gen.manual_seed(seed)
         self._idx32 = torch.zeros(batch_size, dtype=torch.int32, device=dev)
+        if mode == 'sampler':
+            self.weights = w.float()
+            self.hx32, self.hy32 = hx.to(torch.int32).contiguous(), hy.to(torch.int32).contiguous()
 
     @property
     def dataset(self):
@@ -154,6 +168,10 @@ class DeviceBatcher:
     def bind(self, engine, counts=None):
         """build / select the step plan for this batcher's fixed batch structure"""
         self.engine = engine
+        if self.mode == 'sampler':
+            assert counts is None, 'the exact sampler composes batches per rank: use mode="stratified" under data parallelism'
+            engine.universal = True
+            return engine.set_structure_universal(self.batch_size)
         engine.set_structure(self.has_x2, self.has_y, counts)
         return engine.plan
 
@@ -173,8 +191,18 @@ class DeviceBatcher:
                                        yf=self.ds.y.reshape(len(self.ds), -1).float().contiguous() if eng.cfg.cont else None,
                                        table=torch.zeros(n_b, self.batch_size, dtype=torch.int32, device=dev),
                                        base=torch.zeros(1, dtype=torch.int32, device=dev))
+            if self.mode == 'sampler':
+                fd.hx32, fd.hy32 = self.hx32, self.hy32
+                if fd.y32 is None:
+                    fd.y32 = self.hy32
             p.feed = fd
         p.feed_active = True
+        if self.mode == 'sampler':
+            # WeightedRandomSampler: i.i.d. draws over ALL rows; DataLoader(drop_last): consecutive full batches
+            draws = torch.multinomial(self.weights, n_b * self.batch_size, replacement=True, generator=self.gen)
+            fd.table.copy_(draws.reshape(n_b, self.batch_size))
+            fd.base.copy_(eng.step_dev)
+            return fd.table
         parts = [m[torch.multinomial(w, c * n_b, replacement=True, generator=self.gen)].reshape(n_b, c)
                  for m, w, c in zip(self.members, self.gweights, self.group_counts) if c > 0]
         fd.table.copy_(torch.cat(parts, 1))
@@ -182,6 +210,8 @@ class DeviceBatcher:
         return fd.table
 
     def next_indices(self):
+        if self.mode == 'sampler':
+            return torch.multinomial(self.weights, self.batch_size, replacement=True, generator=self.gen)
         parts = [m[torch.multinomial(w, c, replacement=True, generator=self.gen)]
                  for m, w, c in zip(self.members, self.gweights, self.group_counts) if c > 0]
         return torch.cat(parts)
@@ -195,6 +225,13 @@ class DeviceBatcher:
         K.rows_gather(p.XSRC[:p.B], self.ds.x1, self._idx32)
         if self.engine.cfg.has_pert:
             K.rows_gather(p.XSRC[p.B:], self.ds.x2, self._idx32)
+        if self.mode == 'sampler':          # group membership of THIS batch: data for dv_batch_masks
+            if self.engine.cfg.has_pert:
+                p.hx_dev.copy_(self.hx32[idx])
+            if self.engine.cfg.has_y:
+                p.hy_dev.copy_(self.hy32[idx])
+                p.y_dev.copy_(self.ds.y.reshape(-1)[idx].to(torch.int32))
+            return idx
         if self.engine.cfg.has_y and self.engine.cfg.cont:
             p.ylab.copy_(self.ds.y.reshape(len(self.ds), -1)[idx].float())
         elif self.engine.cfg.has_y:

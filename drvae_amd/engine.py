@@ -165,6 +165,9 @@ class FusedStep(StepSchedule):
         self.row0 = int(row0)
         self.dev = arena.device
         self.iters = 0                      # finished_training_iters (src/DGMMixin.py:124)
+        # one batch-independent plan (and one captured graph) for ANY composition of pairs / labels in the batch:
+        # group membership becomes device-side masks (see ``_Plan.universal``); costs the rows of the worst case
+        self.universal = False
         self.plan = None
         self._plans = {}                    # plans by batch structure (a handful of signatures in practice)
         self.max_plans = 8
@@ -246,6 +249,25 @@ class FusedStep(StepSchedule):
             self.L_dz1 = self._gauss('decoder_z1', len(cfg.h_de_z1), 'lv', shift_second=-2.0)
 
     # ------------------------------------------------------------------------- plan
+    def universal_ok(self):
+        cfg = self.cfg
+        return not cfg.cont and not (cfg.kind == 'vfae' and not cfg.semi_supervised)
+
+    def set_structure_universal(self, n_rows):
+        """Select (or build) the batch-independent plan for ``n_rows`` rows."""
+        cfg = self.cfg
+        assert self.universal_ok(), 'universal plan: discrete labels, semi-supervised models'
+        key = ('universal', n_rows, self.row0)
+        if self.plan is None or self.plan.key != key:
+            self.plan = self._plans.get(key)
+            if self.plan is None:
+                ones, zeros = np.ones(n_rows, bool), np.zeros(n_rows, bool)
+                self.plan = self._plans[key] = _Plan(self, np.arange(n_rows), ones if cfg.has_pert else zeros, zeros,
+                                                      None, key, universal=True)
+                if cfg.has_y:
+                    self.plan.set_labels_host(np.zeros(n_rows, np.int64))      # class slots: static
+        return self.plan
+
     def set_structure(self, has_x2, has_y, counts=None):
         """Select (or build) the plan for a batch STRUCTURE: which rows are pairs / labeled.
         Returns (plan, rows) where ``rows`` are the participating row positions."""
@@ -280,6 +302,19 @@ class FusedStep(StepSchedule):
         arrays.  ``counts`` = (N_total, N_pairs, N_labeled) GLOBAL normalisers under data
         parallelism; default: this batch's own counts (src/DrVAE.py:611-616)."""
         cfg = self.cfg
+        if self.universal and counts is None and self.universal_ok():
+            hy = np.asarray(has_y.cpu() if torch.is_tensor(has_y) else has_y).reshape(-1)
+            p = self.set_structure_universal(len(hy))
+            p.feed_active = False
+            p.XSRC[:p.B].copy_(x1)
+            i32 = lambda a: torch.as_tensor(np.asarray(a.cpu() if torch.is_tensor(a) else a).reshape(-1).astype(np.int32))
+            if cfg.has_pert:
+                p.XSRC[p.B:].copy_(x2)
+                p.hx_dev.copy_(i32(has_x2))
+            if cfg.has_y:
+                p.hy_dev.copy_(i32(has_y))
+                p.y_dev.copy_(i32(y) if y is not None else torch.zeros(p.B, dtype=torch.int32))
+            return p
         p, rows = self.set_structure(has_x2, has_y, counts)
         p.feed_active = False       # explicit data supersedes an installed epoch feed (a captured step that
         #                             gathers from the feed then refuses to replay: ``replay`` checks the source)
@@ -316,7 +351,11 @@ class FusedStep(StepSchedule):
             p.E2F.copy_(t(np.asarray(noise['ez2F'])[:, rows].reshape(L * p.B, -1)))
         if cfg.has_y and p.Mf:
             ez3 = np.asarray(noise['ez3'])
-            p.E3.copy_(t(ez3[p.fp_l_host, p.fp_slot_host, rows[p.fp_i_host]]))
+            slot = p.fp_slot_host
+            if p.universal:     # a labeled row's one draw (the reference's, slot 0) belongs to its TRUE class slot
+                hy, yv, i = p.hy_dev.cpu().numpy().astype(bool), p.y_dev.cpu().numpy(), p.fp_i_host
+                slot = np.where(hy[i] & (slot == yv[i]), 0, slot)
+            p.E3.copy_(t(ez3[p.fp_l_host, slot, rows[p.fp_i_host]]))
         if cfg.has_y and cfg.cont:
             p.EY.copy_(t(np.asarray(noise['ey'])[:, rows].reshape(L * p.B, -1)))
 
@@ -361,10 +400,22 @@ class FusedStep(StepSchedule):
         else:
             # ---- inputs (+ training noise N(0,1)*add_noise_var, src/DrVAE.py:404-407,414-417): one gather
             fd = p.live_feed if (self.fuse_bwd and self.training) else None
+            if p.universal:
+                # which rows of THIS batch are pairs / labeled -> coefficient and weight vectors, on the device
+                K.batch_masks(B, L, n_tot=float(B), kl_rate=cfg.kl_qz2pz2_rate, pert_rate=cfg.pertloss_rate,
+                              yl_rate=cfg.yloss_rate, beta=p.beta_dev, c_nll=p.c_nll, w_recl=p.w_recl,
+                              hx=(fd.hx32 if fd is not None else p.hx_dev) if cfg.has_pert else None,
+                              hy=(fd.hy32 if fd is not None else p.hy_dev) if cfg.has_y else None,
+                              y=(fd.y32 if fd is not None else p.y_dev) if cfg.has_y else None,
+                              c_klz2=p.c_klz2 if cfg.has_pert else None, c_yl=p.c_yl, w_pert=p.w_pert, w_yl=p.w_yl,
+                              label=p.label_r if cfg.has_y else None, c_klp=p.c_klp if cfg.kind == 'pvae' else None,
+                              table=fd.table if fd is not None else None,
+                              n_batches=fd.n_batches if fd is not None else 0,
+                              ctr=self.step_dev if fd is not None else None, base=fd.base if fd is not None else None)
             if fd is not None:
                 # batch (optimiser step - epoch base) of the epoch's index table, straight from the
                 # HBM-resident dataset; also refreshes the label-dependent index buffers
-                lab = cfg.has_y and not cfg.cont
+                lab = cfg.has_y and not cfg.cont and not p.universal     # (universal plan: dv_batch_masks has the labels)
                 K.batch_feed(p.XIN, fd.x1, fd.x2, fd.y32, fd.table, fd.n_batches, self.step_dev, fd.base,
                              pair_rows=p.pair_idx if Np else None, noise=p.EX if sigma else None, sigma=sigma,
                              has_y=p.has_y_i32 if lab else None, L=L, label_r=p.label_r if lab else None,
@@ -516,15 +567,23 @@ class FusedStep(StepSchedule):
         cfg, p = self.cfg, self.plan
         L = cfg.L
         nll = p.NLLP if getattr(self, '_nll_fused', False) else p.NLL      # (per-tile partials: a row's sum is its term)
-        terms = [(nll[:p.o3], None, 1.0 / (L * p.n_tot), 0)]
-        if cfg.has_pert and p.Np:
-            terms.append((nll[p.o3:], None, 1.0 / (L * max(1., p.n_pairs)), 2))
-            terms.append((p.KLZ2, p.c_klz2, 1.0, 1))           # beta_pert*rate/(L N) lives on the device
+        rl = nll.shape[1] if nll.dim() == 2 else 1
+        if p.universal:      # normalisers and group masks are per-row weights written by dv_batch_masks
+            terms = [(nll[:p.o3], p.w_recl[:p.o3], 1.0, 0, rl)]
+            if cfg.has_pert:
+                terms.append((nll[p.o3:], p.w_pert, 1.0, 2, rl))
+                terms.append((p.KLZ2, p.c_klz2, 1.0, 1))
+        else:
+            terms = [(nll[:p.o3], None, 1.0 / (L * p.n_tot), 0)]
+            if cfg.has_pert and p.Np:
+                terms.append((nll[p.o3:], None, 1.0 / (L * max(1., p.n_pairs)), 2))
+                terms.append((p.KLZ2, p.c_klz2, 1.0, 1))           # beta_pert*rate/(L N) lives on the device
         if cfg.kind == 'pvae':
-            terms.append((p.KLP, None, 1.0 / p.n_tot, 1))
+            terms.append((p.KLP, p.c_klp, 1.0, 1) if p.universal else (p.KLP, None, 1.0 / p.n_tot, 1))
         if cfg.has_y:
             terms.append((p.KLDrow, None, 1.0 / (L * p.n_tot), 1))
-            terms.append((p.YLrow, None, 1.0 / (L * max(1., p.n_lab)), 3))
+            terms.append((p.YLrow, p.w_yl, 1.0, 3) if p.universal else
+                         (p.YLrow, None, 1.0 / (L * max(1., p.n_lab)), 3))
         bump = ()
         if after is not None:     # dual-graph train step: this launch also advances the step / Philox counters
             bump = [(self.step_dev, 1)] + ([(self.rng_ctr, self._rng_pending)] if getattr(self, '_rng_pending', 0) else [])

@@ -462,6 +462,18 @@ def batch_feed(xin, x1, x2, y32, table, n_batches, ctr, base, *, pair_rows=None,
                'dv_batch_feed')
 
 
+def batch_masks(B, L, *, n_tot, kl_rate, pert_rate, yl_rate, beta, c_nll, w_recl, hx=None, hy=None, y=None, c_klz2=None,
+                c_yl=None, w_pert=None, w_yl=None, label=None, c_klp=None, table=None, n_batches=0, ctr=None, base=None):
+    """per-batch coefficient / weight vectors of a batch-independent step plan from the batch's pair / label flags
+    (``dv_batch_masks``); ``hx`` / ``hy`` / ``y``: int32 device arrays indexed by dataset row (``table`` given) or by
+    batch row; ``beta``: 1-element device float"""
+    _lib.check(_lib.load().dv_batch_masks(_i32(table), n_batches, _i32(ctr), _i32(base), _i32(hx), _i32(hy), _i32(y), B, L,
+                                          n_tot, kl_rate, pert_rate, yl_rate, _f32(beta), _f32(c_nll), _f32(c_klz2),
+                                          _f32(c_yl), _f32(w_recl), _f32(w_pert), _f32(w_yl), _i32(label), _f32(c_klp),
+                                          _stream()),
+               'dv_batch_masks')
+
+
 def rows_segment_sum(dst, src, *, seg_ptr=None, seg_rows=None, w=None, n=None, dst_idx=None, beta=0.0, width=None,
                      park=None):
     if n is None:
@@ -503,8 +515,10 @@ def loss_assemble(loss, terms, w_elbo, w_cmpl, after=None, bump=(), halt=None):
     ``halt``: the (err, ticks) pairs of the step's waits -- any error set: the scalars come out NaN."""
     hp, hn = _halt(halt)
     arr = (_lib.LossTerm * max(len(terms), 1))()
-    for i, (x, w, scale, out) in enumerate(terms):
+    for i, term in enumerate(terms):      # (x, w, scale, out[, row_len]): row_len > 1 = one weight per row of x
+        x, w, scale, out = term[:4]
         arr[i].x, arr[i].w, arr[i].n, arr[i].scale, arr[i].out = _f32(x), _f32(w), x.numel(), scale, out
+        arr[i].row_len = term[4] if len(term) > 4 else 1
     if after is None:
         _lib.check(_lib.load().dv_loss_assemble(arr, len(terms), _f32(w_elbo), _f32(w_cmpl), _f32(loss), hp, hn,
                                                 _stream()), 'dv_loss_assemble')

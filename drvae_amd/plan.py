@@ -16,9 +16,13 @@ LOSS_IDX = {'RECL': 0, 'KLD': 1, 'PERT': 2, 'YL': 3, 'MMD': 4, 'ELBO': 5, 'CMPL'
 class _Plan:
     """Index lists, coefficient vectors and buffers for one batch structure."""
 
-    def __init__(self, eng, rows, has_x2, has_y, counts, key):
+    def __init__(self, eng, rows, has_x2, has_y, counts, key, universal=False):
         cfg, dev = eng.cfg, eng.dev
         self.key, self.rows = key, rows
+        # universal: the structure passed in is "every row a pair, every row unlabeled" (all class slots
+        # materialised); which rows really are pairs / labeled is per-batch DATA, turned into coefficient and weight
+        # vectors on the device by dv_batch_masks -- one plan and one captured graph for ANY batch composition
+        self.universal = bool(universal)
         L, Y, X, Z1, Z3 = cfg.L, cfg.dim_y, cfg.dim_x, cfg.dim_z1, cfg.dim_z3
         B = self.B = len(rows)
         self.pair_host = np.nonzero(has_x2)[0]
@@ -186,6 +190,15 @@ class _Plan:
             self.c_klz2 = zf(L * Np)
         self.w_elbo = zf(3)
         self.w_cmpl = zf(N_LOSS)
+        if self.universal:
+            assert Np == (B if cfg.has_pert else 0) and not cfg.cont
+            self.hx_dev = i32(np.zeros(B)) if cfg.has_pert else None      # flags / labels of an explicit batch
+            self.hy_dev = i32(np.zeros(B)) if cfg.has_y else None
+            self.y_dev = i32(np.zeros(B)) if cfg.has_y else None
+            self.w_recl, self.w_pert, self.w_yl = zf(2 * L * B), zf(L * B), zf(L * B)
+            self.beta_dev = zf(1)
+            if not cfg.has_y:
+                self.c_yl = None
         self._cfg = cfg
         self.x1 = self.x2 = None
         self.feed = None        # graph-resident input feed (drvae_amd.data.DeviceBatcher.begin_epoch)
@@ -230,7 +243,10 @@ class _Plan:
             return
         cfg, L = self._cfg, self._cfg.L
         self.beta = beta
-        if cfg.has_pert:
+        if self.universal:       # the per-row coefficients are rewritten every step by dv_batch_masks: it reads beta here
+            self.beta_dev.fill_(beta)
+            self.w_elbo.copy_(torch.tensor([1.0, -1.0, beta * cfg.pertloss_rate if cfg.has_pert else 0.0]))
+        elif cfg.has_pert:
             self.c_nll[self.o3:] = -beta * cfg.pertloss_rate / (L * max(1., self.n_pairs))
             self.c_klz2.fill_(beta * cfg.kl_qz2pz2_rate / (L * self.n_tot))
             self.w_elbo.copy_(torch.tensor([1.0, -1.0, beta * cfg.pertloss_rate]))

@@ -410,6 +410,22 @@ int dv_batch_feed(const float* x1, int64_t ld1, const float* x2, int64_t ld2, co
 /* dst[di,:W] = beta*dst[di,:W] + sum_{t in [seg_ptr[i],seg_ptr[i+1])} w[t]*src[seg_rows[t],:W],
  * di = dst_idx?dst_idx[i]:i; seg_ptr==NULL: segment i is the single row (seg_rows?seg_rows[i]:i).
  * Deterministic (no atomics): the transpose of every gather above. */
+/* Per-batch masks of a batch-independent ("universal") step plan -- every row materialised as a pair with all Y
+ * class slots; which rows really are pairs / labeled is DATA: the group split and the per-example normalisers of
+ * src/DrVAE.py:565-624 (N_total fixed = n_tot, N_pairs and N_labeled counted per batch, max(1, .)) become
+ * coefficient / weight vectors written on the device from the batch's flags.  Row i of the batch is dataset row
+ * table[b, i] with b = clamp(ctr[0] - base[0]) (graph-resident epoch feed, as dv_batch_feed) or row i itself
+ * (table == NULL: hx / hy / y are batch-local).  With r = l*B + i, px / py = the row is a pair / labeled:
+ *   c_nll[r] = -1/(L n_tot);  c_nll[LB + r] = px ? -1/(L n_tot) : 0;  c_nll[2LB + r] = px ? -beta pert_rate/(L N_pairs) : 0
+ *   w_recl = |c_nll[0 : 2LB]|;  w_pert[r] = px ? 1/(L N_pairs) : 0;  c_klz2[r] = px ? beta kl_rate/(L n_tot) : 0
+ *   c_yl[r] = py ? -yl_rate/(L N_labeled) : 0;  w_yl[r] = 1/(L N_labeled);  label[r] = py ? -2 - y : 0
+ *   c_klp[i] = 1/n_tot, c_klp[B + i] = px ? 1/n_tot : 0   (optional; B + B rows: KL to the prior of q(z1|x1) | q(z2|x2))
+ * (label <= -2 is what dv_ymarg_* read as "labeled row, all class slots materialised").  hx == NULL / hy == NULL:
+ * model without pairs / labels.  beta: DEVICE scalar (perturbation annealing coefficient).  One workgroup. */
+int dv_batch_masks(const int32_t* table, int32_t n_batches, const int32_t* ctr, const int32_t* base, const int32_t* hx,
+                   const int32_t* hy, const int32_t* y, int32_t B, int32_t L, float n_tot, float kl_rate,
+                   float pert_rate, float yl_rate, const float* beta, float* c_nll, float* c_klz2, float* c_yl,
+                   float* w_recl, float* w_pert, float* w_yl, int32_t* label, float* c_klp, dv_stream_t stream);
 int dv_rows_segment_sum(const float* src, int64_t lds, const int32_t* seg_ptr, const int32_t* seg_rows,
                         const float* w, int32_t n, int32_t W, const int32_t* dst_idx, float* dst, int64_t ldd,
                         float beta, const dv_wait* park, dv_stream_t stream);
@@ -436,7 +452,8 @@ typedef struct dv_loss_term {
     const float* w;
     int32_t n;
     float scale;
-    int32_t out; /* 0 RECL, 1 KLD, 2 PERT, 3 YL, 4 MMD */
+    int32_t out;     /* 0 RECL, 1 KLD, 2 PERT, 3 YL, 4 MMD */
+    int32_t row_len; /* > 1: x is (n / row_len, row_len) and w holds one weight per ROW (w[i / row_len]); else 0 / 1 */
 } dv_loss_term;
 int dv_loss_assemble(const dv_loss_term* terms, int32_t n_terms, const float* w_elbo, const float* w_cmpl,
                      float* loss, const int32_t* halt, int32_t n_halt, dv_stream_t stream);

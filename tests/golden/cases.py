@@ -146,6 +146,17 @@ def fit_policy_cases():
     return out
 
 
+def sampler_cases():
+    """imbalanced 'cell line' ids of a training set; batch sizes as the drivers use them"""
+    rs = np.random.RandomState(77)
+    out = OrderedDict()
+    cid = np.concatenate([np.full(n, c) for c, n in enumerate([3, 40, 7, 120, 25, 60, 11, 134])])
+    out['cid8'] = dict(cid=rs.permutation(cid).astype(np.int64), batch_size=48, epochs=300)
+    out['small'] = dict(cid=np.array([0, 0, 0, 1, 1, 2, 2, 2, 2, 2], np.int64), batch_size=16, epochs=50)     # len < batch
+    out['exact'] = dict(cid=(np.arange(96) % 5).astype(np.int64), batch_size=32, epochs=100)                    # len % batch == 0
+    return out
+
+
 def masked_linear_cases():
     """stacks of (in_features, out_features, output_layer, rev_order); layer i > 0 is built on the ``get_m()`` of
     layer i - 1 (the first on ``m_pre=None``)"""

@@ -556,6 +556,36 @@ def run_mmd_criterion_cases():
     return out
 
 
+def run_sampler_cases():
+    """the reference's training input pipeline (src/run_drvae.py:150-162): its own ``compute_balanced_weights``
+    (src/utils.py:292-327), ``WeightedRandomSampler(weights, len(weights))`` and a DataLoader with
+    ``drop_last=(len >= batch)``.  Recorded: the weights, the number of batches per epoch, and how often each cell
+    line was drawn over many epochs (the marginals the on-device sampler must reproduce)."""
+    import utils as rutl
+    from torch.utils.data import DataLoader, TensorDataset
+    from torch.utils.data.sampler import WeightedRandomSampler
+    out = {}
+    for tag, c in C.sampler_cases().items():
+        cid = c['cid']
+        w = rutl.compute_balanced_weights(cid, unlabeled_data_ratio=None)
+        ds = TensorDataset(torch.arange(len(cid)))
+        torch.manual_seed(1234)
+        sampler = WeightedRandomSampler(w, len(w))
+        loader = DataLoader(ds, batch_size=c['batch_size'], drop_last=(len(ds) >= c['batch_size']), sampler=sampler)
+        hist = np.zeros(int(cid.max()) + 1, np.int64)
+        sizes = set()
+        for _ in range(c['epochs']):
+            for (idx,) in loader:
+                sizes.add(len(idx))
+                np.add.at(hist, cid[idx.numpy()], 1)
+        out[tag + '/weights'] = w.numpy().astype(np.float64)
+        out[tag + '/n_batches'] = np.int64(len(loader))
+        out[tag + '/batch_rows'] = np.asarray(sorted(sizes), np.int64)
+        out[tag + '/class_hist'] = hist
+        out[tag + '/draws'] = np.int64(hist.sum())
+    return out
+
+
 def run_masked_linear_cases():
     """MADE masks of the reference's ``MaskedLinear`` (src/layers.py:44-133): ``mask``, ``m`` / ``get_m()`` and
     ``m_pre`` for an input layer (int and tuple ``in_features``, natural and reversed order), hidden layers
@@ -581,6 +611,9 @@ def main():
     ml = run_masked_linear_cases()
     np.savez_compressed(os.path.join(HERE, 'masked_linear.npz'), **ml)
     print('masked_linear.npz', len(ml), 'arrays')
+    sm = run_sampler_cases()
+    np.savez_compressed(os.path.join(HERE, 'sampler.npz'), **sm)
+    print('sampler.npz', len(sm), 'arrays', {k: v.tolist() for k, v in sm.items() if 'n_batches' in k or 'batch_rows' in k})
     mm = run_mmd_criterion_cases()
     np.savez_compressed(os.path.join(HERE, 'mmd_criterion.npz'), **mm)
     print('mmd_criterion.npz', len(mm), 'arrays', {k: float(v) for k, v in mm.items() if k.endswith('value')})

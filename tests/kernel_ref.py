@@ -466,13 +466,15 @@ def ymarg_fwd(yl, kld, qy, label, fp_ptr, klfp, log_prior):
     f0 = fp_ptr[:-1].long()
     nf = (fp_ptr[1:] - fp_ptr[:-1]).long()
     lab = nf == 1
+    slot = label.long() <= -2                 # labeled row with all Y class slots materialised (universal plan)
+    cls = torch.where(slot, -2 - label.long(), label.long().clamp(min=0))
     j = torch.arange(Y, device=qy.device)[None, :]
     fidx = torch.where(lab[:, None], f0[:, None].expand(R, Y), f0[:, None] + j).clamp(max=max(klfp.numel() - 1, 0))
     kf = klfp[fidx]
     lq = qy.log()
-    yl.copy_(torch.where(lab, lq.gather(1, label.long()[:, None])[:, 0], torch.zeros_like(yl)))
+    yl.copy_(torch.where(lab | slot, lq.gather(1, cls[:, None])[:, 0], torch.zeros_like(yl)))
     marg = (qy * kf).sum(1) + (-qy * (log_prior - lq)).sum(1)
-    kld.copy_(torch.where(lab, kf[:, 0], marg))
+    kld.copy_(torch.where(lab, kf[:, 0], torch.where(slot, kf.gather(1, cls[:, None])[:, 0], marg)))
 
 
 def ymarg_fwdbwd(yl, kld, cfp, dqy, qy, label, fp_ptr, klfp, log_prior, c_kld, c_yl):
@@ -489,6 +491,12 @@ def ymarg_bwd(cfp, dqy, qy, label, fp_ptr, klfp, log_prior, c_kld, c_yl):
             dqy[r].zero_()
             dqy[r, int(label[r])] = c_yl[r] / qy[r, int(label[r])]
             cfp[int(f0[r])] = c_kld[r]
+        elif int(label[r]) <= -2:
+            c = -2 - int(label[r])
+            dqy[r].zero_()
+            dqy[r, c] = c_yl[r] / qy[r, c]
+            cfp[int(f0[r]):int(f0[r]) + Y] = 0
+            cfp[int(f0[r]) + c] = c_kld[r]
         else:
             sl = slice(int(f0[r]), int(f0[r]) + Y)
             cfp[sl] = c_kld[r] * qy[r]
@@ -617,8 +625,12 @@ def loss_assemble(loss, terms, w_elbo, w_cmpl, after=None, bump=(), halt=None):
     if after is not None and not terms:
         return
     acc = torch.zeros(8, device=loss.device)
-    for (x, w, scale, out) in terms:
+    for term in terms:
+        x, w, scale, out = term[:4]
+        row_len = term[4] if len(term) > 4 else 1
         v = x.reshape(-1)
+        if w is not None and row_len > 1:
+            w = w.reshape(-1).repeat_interleave(row_len)
         acc[out] = acc[out] + scale * ((v * w.reshape(-1)).sum() if w is not None else v.sum())
     acc[5] = (w_elbo[:3] * acc[:3]).sum()
     acc[6] = (w_cmpl[:8] * acc[:8]).sum()
@@ -683,6 +695,37 @@ def counter_add(counter, inc=1):
         counter[1] = hi - (1 << 32) if hi >= (1 << 31) else hi
 
 
+def batch_masks(B, L, *, n_tot, kl_rate, pert_rate, yl_rate, beta, c_nll, w_recl, hx=None, hy=None, y=None, c_klz2=None,
+                c_yl=None, w_pert=None, w_yl=None, label=None, c_klp=None, table=None, n_batches=0, ctr=None, base=None):
+    if c_klp is not None:
+        s_ = table[min(max(int(ctr[0]) - int(base[0]), 0), n_batches - 1)].long() if table is not None else \
+            torch.arange(B, device=c_nll.device)
+        c_klp[:B] = 1.0 / n_tot
+        c_klp[B:2 * B] = torch.where(hx[s_] != 0, 1.0 / n_tot, 0.0) if hx is not None else 0.0
+    if table is not None:
+        b = min(max(int(ctr[0]) - int(base[0]), 0), n_batches - 1)
+        src = table[b].long()
+    else:
+        src = torch.arange(B, device=c_nll.device)
+    LB, ct, bt = L * B, 1.0 / (L * n_tot), float(beta[0]) if beta is not None else 1.0
+    c_nll[:LB] = -ct
+    w_recl[:LB] = ct
+    if hx is not None:
+        px = (hx[src] != 0).repeat(L)
+        npair = max(float((hx[src] != 0).sum()), 1.0)
+        c_nll[LB:2 * LB] = torch.where(px, -ct, 0.0)
+        w_recl[LB:2 * LB] = torch.where(px, ct, 0.0)
+        c_nll[2 * LB:3 * LB] = torch.where(px, -bt * pert_rate / (L * npair), 0.0)
+        w_pert[:LB] = torch.where(px, 1.0 / (L * npair), 0.0)
+        c_klz2[:LB] = torch.where(px, bt * kl_rate * ct, 0.0)
+    if hy is not None:
+        py = (hy[src] != 0).repeat(L)
+        nlab = max(float((hy[src] != 0).sum()), 1.0)
+        c_yl[:LB] = torch.where(py, -yl_rate / (L * nlab), 0.0)
+        w_yl[:LB] = 1.0 / (L * nlab)
+        label[:LB] = torch.where(py, -2 - y[src].to(label.dtype).repeat(L), torch.zeros_like(label[:LB]))
+
+
 def fill_normal_rows(arena, desc, seed, ctr_dev=None):
     """Stand-in only (NOT bit-compatible with the device Philox stream), but keyed the same way: a value
     depends on (seed, step, draw id, global row, column) only."""
@@ -701,7 +744,7 @@ def fill_normal(out, seed, ctr_dev=None):
     out.copy_(torch.randn(out.shape, generator=g).to(out.device))
 
 
-FUNCTIONS = ['fill_normal_rows', 'linear_heads', 'heads_tiles', 'adamax_l2', 'batch_feed', 'mmd_rff_fwd', 'mmd_rff_bwd', 'counters_add2', 'ycont_fwd', 'ycont_bwd', 'flag_publish', 'flag_wait', 'gemm', 'linear_fwd', 'linear_bwd_data', 'linear_bwd_weight', 'linear_bwd_pair', 'colsum', 'act_bwd_', 'wn_scale', 'wn_bwd',
+FUNCTIONS = ['batch_masks', 'fill_normal_rows', 'linear_heads', 'heads_tiles', 'adamax_l2', 'batch_feed', 'mmd_rff_fwd', 'mmd_rff_bwd', 'counters_add2', 'ycont_fwd', 'ycont_bwd', 'flag_publish', 'flag_wait', 'gemm', 'linear_fwd', 'linear_bwd_data', 'linear_bwd_weight', 'linear_bwd_pair', 'colsum', 'act_bwd_', 'wn_scale', 'wn_bwd',
              'reparam_fwd', 'reparam_bwd', 'reparam_bwd_seg', 'z2f_post_bwd', 'kl_rows_fwd', 'kl_rows_bwd', 'nll_rows_fwd', 'nll_rows_bwd', 'nll_rows_fwdbwd',
              'softmax_clamp_fwd', 'softmax_clamp_bwd', 'cat_terms_fwd', 'cat_terms_bwd', 'smalln_fwd', 'smalln_bwd_data',
              'smalln_bwd_weight', 'ymarg_fwd', 'ymarg_bwd', 'ymarg_fwdbwd',

@@ -65,3 +65,58 @@ def test_device_batcher_structure_and_marginals():
         m = (hy == bool(gy)) & (hx == bool(gx))
         if m.sum() > 1:
             np.testing.assert_allclose(counts[m] / counts[m].sum(), (w[m] / w[m].sum()).numpy(), atol=0.04)
+
+
+@pytest.mark.parametrize('tag', list(C.sampler_cases()))
+def test_sampler_mode_matches_reference_pipeline(tag):
+    """N2, mode='sampler': the reference's WeightedRandomSampler(weights, len) + DataLoader(drop_last=len>=batch)
+    (src/run_drvae.py:150-162), recorded in tests/golden/sampler.npz -- same weights, same number of batches per
+    epoch, same batch size, and the per-cell-line draw frequencies of both (the reference's recorded histogram and
+    the on-device sampler's) agree with the weights' marginals and with each other."""
+    G = C.load('sampler')
+    c = C.sampler_cases()[tag]
+    cid, n = c['cid'], len(c['cid'])
+    w = D.compute_balanced_weights(cid)
+    np.testing.assert_allclose(w.numpy(), G[tag + '/weights'], rtol=1e-12)
+    ds = D.DrVAEDataset(torch.zeros(n, 3), torch.zeros(n, 3), torch.zeros(n, dtype=torch.int64), torch.zeros(n, 1, dtype=torch.int64),
+                        torch.from_numpy((np.arange(n) % 2).astype(np.int32)), torch.from_numpy((np.arange(n) % 3 == 0).astype(np.int32)))
+    bat = D.DeviceBatcher(ds, w, c['batch_size'], seed=5, mode='sampler')
+    assert len(bat) == int(G[tag + '/n_batches'])
+    assert [bat.batch_size] == G[tag + '/batch_rows'].tolist()
+    ncls = int(cid.max()) + 1
+    hist = np.zeros(ncls, np.int64)
+    draws = int(G[tag + '/draws'])
+    for _ in range(draws // bat.batch_size):
+        np.add.at(hist, cid[bat.next_indices().numpy()], 1)
+    p = np.array([w.numpy()[cid == k].sum() for k in range(ncls)]) / float(w.sum())
+    for h, tot in ((hist, hist.sum()), (G[tag + '/class_hist'], draws)):
+        sd = np.sqrt(tot * p * (1 - p))
+        assert np.all(np.abs(h - tot * p) < 5 * sd + 1), (h, tot * p)
+    # balanced weights: every cell line equally likely (that is their purpose, src/utils.py:292-300)
+    np.testing.assert_allclose(p, 1.0 / ncls, rtol=1e-9)
+
+
+def test_sampler_mode_epoch_table(monkeypatch):
+    """the epoch's index table of mode='sampler': len(dataset) // batch rows of i.i.d. draws over ALL rows (any group
+    mix per batch), one batch-independent plan bound to the engine"""
+    from oracle import models_ref as M
+    from tests import kernel_ref
+    from tests.test_engine_cpu import make_engine
+    kernel_ref.install(monkeypatch)
+    spec = C.tiny_spec('drvae')
+    eng, _ = make_engine(spec, M.init_params(spec, 3, as_numpy=True))
+    big = M.make_batch(spec, 100, seed=4)
+    t = lambda k: torch.from_numpy(big[k].copy())
+    ds = D.DrVAEDataset(t('x1'), t('x2'), t('s'), t('y'), t('has_x2'), t('has_y'))
+    bat = D.DeviceBatcher(ds, D.compute_balanced_weights(np.arange(100) % 7), 16, seed=2, mode='sampler')
+    p = bat.bind(eng)
+    assert p.universal and eng.universal and len(bat) == 6
+    tab = bat.begin_epoch()
+    assert tuple(tab.shape) == (6, 16) and int(tab.min()) >= 0 and int(tab.max()) < 100
+    comp = {tuple(np.bincount(2 * big['has_y'][r] + big['has_x2'][r], minlength=4)) for r in tab.numpy()}
+    assert len(comp) > 1            # the composition varies from batch to batch
+    # explicit path: feed() hands the batch's own flags to the masks kernel
+    idx = bat.feed()
+    assert torch.equal(p.hx_dev.long(), ds.has_x2[idx].long()) and torch.equal(p.y_dev.long(), ds.y.reshape(-1)[idx].long())
+    eng.train_step()
+    assert all(np.isfinite(v) for v in eng.losses().values())

@@ -83,3 +83,75 @@ def test_engine_gradients_match_reference_golden(name, monkeypatch):
         else:
             close(np.sqrt((g.astype(np.float64) ** 2).sum()), gold['gradnorm/' + k], 1e-4, 1e-7)
             close(g.reshape(-1)[C.sample_index(g.size)], gold['gradsample/' + k], 2e-3, 2e-6)
+
+
+UNIVERSAL_CASES = [n for n in C.MODEL_CASES if 'cont' not in n and n not in ('tiny_vfae_sup',)]
+
+
+@pytest.mark.parametrize('name', UNIVERSAL_CASES)
+def test_universal_plan_matches_reference_golden(name, monkeypatch):
+    """N2: the batch-independent plan (every row materialised as a pair with all class slots; group membership as
+    device-side masks from dv_batch_masks) reproduces the reference's losses / gradients / parameters for every
+    batch composition of the golden cases -- incl. empty groups -- with ONE plan."""
+    kernel_ref.install(monkeypatch)
+    case, gold = C.model_case(name), C.load('model_' + name)
+    spec = case['spec']
+    eng, arena = make_engine(spec, M.init_params(spec, case['param_seed'], as_numpy=True))
+    eng.universal = True
+    p = set_batch(eng, case['batch'])
+    assert p.universal and p.key[0] == 'universal'
+    eng.training = False
+    eng.set_noise(case['noises'][0])
+    eng.forward()
+    for k, v in eng.losses().items():
+        close(v, gold['eval/' + k], 2e-5, 2e-6)
+    # gradients of the first train-mode pass
+    eng.training = True
+    eng.set_noise(case['noises'][0])
+    eng.forward()
+    eng.backward()
+    for k in arena.shapes:
+        g = arena.g(k).numpy()
+        if case['full']:
+            ref = gold['grad/' + k]
+            close(g, ref, 3e-4, 3e-6 * max(1.0, float(np.abs(ref).max())))
+        else:
+            close(np.sqrt((g.astype(np.float64) ** 2).sum()), gold['gradnorm/' + k], 1e-4, 1e-7)
+    nsteps = len(case['noises'])
+    for step, noise in enumerate(case['noises']):
+        eng.train_step(noise)
+        for k, v in eng.losses().items():
+            close(v, gold['step%d/%s' % (step, k)], 2e-5, 2e-6)
+    for k in arena.shapes:
+        a = arena.p(k).numpy()
+        if case['full']:
+            close(a, gold['param%d/%s' % (nsteps - 1, k)], 1e-4, 2e-5)
+        else:
+            close(a.astype(np.float64).sum(), gold['paramsum%d/%s' % (nsteps - 1, k)], 1e-4, 2e-3)
+    assert len(eng._plans) == 1
+
+
+def test_universal_plan_one_plan_for_any_composition(monkeypatch):
+    kernel_ref.install(monkeypatch)
+    spec = C.tiny_spec('drvae')
+    params = M.init_params(spec, 3, as_numpy=True)
+    uni, au = make_engine(spec, params)
+    uni.universal = True
+    for seed, pattern in enumerate(['aabbccdd', 'aaaaaaab', 'dddddddd', 'cdcdabab', 'bbbbaaaa']):
+        batch = M.make_batch(spec, 8, seed=seed)
+        fl = {'a': (1, 0), 'b': (0, 0), 'c': (1, 1), 'd': (0, 1)}
+        batch['has_y'] = np.array([fl[c][0] for c in pattern], np.int64)
+        batch['has_x2'] = np.array([fl[c][1] for c in pattern], np.int64)
+        batch['x2'] = batch['x2'] * batch['has_x2'][:, None].astype(np.float32)
+        noise = M.make_noise(spec, 8, seed=10 + seed)
+        one, a1 = make_engine(spec, params)
+        a1.param.copy_(au.param); a1.exp_avg.copy_(au.exp_avg); a1.exp_avg_sq.copy_(au.exp_avg_sq)
+        one.step_dev.copy_(uni.step_dev); one.iters = uni.iters
+        for e in (uni, one):
+            set_batch(e, batch)
+            e.train_step(noise)
+        for (k, a), b in zip(uni.losses().items(), one.losses().values()):
+            close(a, b, 2e-5, 2e-6)
+        close(au.grad, a1.grad.numpy(), 2e-4, 1e-6)
+        close(au.param, a1.param.numpy(), 1e-5, 1e-6)
+    assert len(uni._plans) == 1

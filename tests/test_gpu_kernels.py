@@ -830,3 +830,57 @@ def test_linear_heads_nll(K, dev, M, S, Kd):
     close(got / scale_, ref / scale_, rtol=2e-3, atol=2e-5 * max(1.0, Kd ** 0.5))
     close(pg.sum(1), pr.sum(1), rtol=2e-4, atol=1e-3 * S ** 0.5)
     assert bool(torch.isfinite(got).all()) and bool(torch.isfinite(pg).all())
+
+
+def test_batch_masks_and_labeled_slots(K, dev):
+    """dv_batch_masks against its reference (explicit flags and through an epoch table), the labeled-slot branch of
+    dv_ymarg_* (label <= -2), and row-weighted loss terms"""
+    B, L, Y = 37, 3, 3
+    g = torch.Generator().manual_seed(0)
+    hx = (torch.rand(200, generator=g) < 0.4).to(torch.int32).to(dev)
+    hy = (torch.rand(200, generator=g) < 0.6).to(torch.int32).to(dev)
+    y = torch.randint(0, Y, (200,), generator=g).to(torch.int32).to(dev)
+    table = torch.randint(0, 200, (5, B), generator=g).to(torch.int32).to(dev)
+    ctr, base = torch.tensor([9], dtype=torch.int32, device=dev), torch.tensor([7], dtype=torch.int32, device=dev)
+    beta = torch.tensor([0.01], device=dev)
+    outs = []
+    for Lb in (K, R):
+        for tab in (None, table):
+            bufs = dict(c_nll=torch.full((3 * L * B,), 9.0, device=dev), c_klz2=torch.full((L * B,), 9.0, device=dev),
+                        c_yl=torch.full((L * B,), 9.0, device=dev), w_recl=torch.full((2 * L * B,), 9.0, device=dev),
+                        w_pert=torch.full((L * B,), 9.0, device=dev), w_yl=torch.full((L * B,), 9.0, device=dev),
+                        label=torch.full((L * B,), 9, dtype=torch.int32, device=dev), c_klp=torch.full((2 * B,), 9.0, device=dev))
+            Lb.batch_masks(B, L, n_tot=float(B), kl_rate=0.7, pert_rate=0.05, yl_rate=1.3, beta=beta, hx=hx, hy=hy, y=y,
+                           table=tab, n_batches=5 if tab is not None else 0, ctr=ctr if tab is not None else None,
+                           base=base if tab is not None else None, **bufs)
+            outs.append(bufs)
+    for a, b in zip(outs[:2], outs[2:]):
+        for k in a:
+            close(a[k].float(), b[k].float(), rtol=1e-6, atol=1e-9)
+    assert int((outs[1]['label'] <= -2).sum()) == int(hy[table[2].long()].sum()) * L
+    # ymarg with materialised class slots
+    Rr = L * B
+    qy = torch.softmax(rnd(dev, Rr, Y, seed=1), 1)
+    fp_ptr = torch.arange(0, Rr * Y + 1, Y, dtype=torch.int32, device=dev)
+    klfp, c_kld, c_yl = rnd(dev, Rr * Y, seed=2).abs(), rnd(dev, Rr, seed=3), outs[0]['c_yl']
+    label = outs[0]['label']
+    res = []
+    for Lb in (K, R):
+        yl, kld, cfp, dqy = (torch.zeros(Rr, device=dev), torch.zeros(Rr, device=dev), torch.zeros(Rr * Y, device=dev),
+                             torch.zeros(Rr, Y, device=dev))
+        Lb.ymarg_fwdbwd(yl, kld, cfp, dqy, qy, label, fp_ptr, klfp, float(np.log(1.0 / Y)), c_kld, c_yl)
+        yl2, kld2, cfp2, dqy2 = torch.zeros_like(yl), torch.zeros_like(kld), torch.zeros_like(cfp), torch.zeros_like(dqy)
+        Lb.ymarg_fwd(yl2, kld2, qy, label, fp_ptr, klfp, float(np.log(1.0 / Y)))
+        Lb.ymarg_bwd(cfp2, dqy2, qy, label, fp_ptr, klfp, float(np.log(1.0 / Y)), c_kld, c_yl)
+        torch.cuda.synchronize()
+        assert torch.equal(yl, yl2) and torch.equal(kld, kld2) and torch.equal(cfp, cfp2) and torch.equal(dqy, dqy2)
+        res.append((yl, kld, cfp, dqy))
+    for a, b in zip(*res):
+        close(a, b, rtol=1e-5, atol=1e-6)
+    # loss terms with one weight per row of a (rows, row_len) array
+    x2d, wrow = rnd(dev, 50, 7, seed=4), rnd(dev, 50, seed=5)
+    w_elbo, w_cmpl = torch.tensor([1.0, -1.0, 0.0], device=dev), torch.zeros(8, device=dev)
+    la, lb = torch.zeros(8, device=dev), torch.zeros(8, device=dev)
+    K.loss_assemble(la, [(x2d, wrow, 0.5, 0, 7)], w_elbo, w_cmpl)
+    R.loss_assemble(lb, [(x2d, wrow, 0.5, 0, 7)], w_elbo, w_cmpl)
+    close(la, lb, rtol=1e-5, atol=1e-5)

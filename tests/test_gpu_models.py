@@ -331,3 +331,94 @@ def test_model_move_keeps_training_state(dev):
             model._assert_arena_aliased()
     for k in out[0]:
         assert torch.equal(out[0][k], out[1][k]), k
+
+
+@pytest.mark.parametrize('name', ['tiny_drvae', 'tiny_drvae_nolp', 'tiny_drvae_only_up', 'tiny_pvae', 'tiny_vfae', 'cfg2_drvae'])
+def test_universal_plan_matches_reference_gpu(name, dev):
+    """N2: the batch-independent plan on the real kernels (dv_batch_masks, the labeled-slot branch of dv_ymarg_*,
+    row-weighted loss terms) against the reference's golden losses, eager and captured"""
+    from tests.test_engine_cpu import make_engine, set_batch
+    case, gold = C.model_case(name), C.load('model_' + name)
+    spec = case['spec']
+    eng, arena = make_engine(spec, M.init_params(spec, case['param_seed'], as_numpy=True), dev)
+    eng.universal = True
+    p = set_batch(eng, case['batch'], dev)
+    assert p.universal
+    eng.training = False
+    eng.set_noise(case['noises'][0])
+    eng.forward()
+    for k, v in eng.losses().items():
+        np.testing.assert_allclose(v, gold['eval/' + k], rtol=1e-4, atol=2e-5)
+    for step, noise in enumerate(case['noises']):
+        eng.train_step(noise)
+        for k, v in eng.losses().items():
+            np.testing.assert_allclose(v, gold['step%d/%s' % (step, k)], rtol=1e-4, atol=2e-5)
+    nsteps = len(case['noises'])
+    for k in arena.shapes:
+        a = arena.p(k).cpu().numpy()
+        if case['full']:
+            np.testing.assert_allclose(a, gold['param%d/%s' % (nsteps - 1, k)], rtol=2e-4, atol=5e-5)
+
+
+@pytest.mark.parametrize('kind', ['drvae', 'pvae', 'vfae'])
+def test_sampler_mode_epoch_in_one_graph(kind, dev):
+    """N2, mode='sampler': an epoch of WeightedRandomSampler-style batches (i.i.d. rows, any group mix per batch) is
+    n replays of ONE captured graph -- the composition of each batch reaches the step as device-side masks read
+    through the epoch's index table -- and equals, bitwise, eager steps handed the same rows and flags explicitly;
+    against per-structure plans the same batches agree under injected noise."""
+    import drvae_amd.kernels as K
+    from drvae_amd import data as D
+    from tests.test_engine_cpu import make_engine
+    spec = M.ModelSpec(kind=kind, L=2)
+    params = M.init_params(spec, 3, as_numpy=True)
+    big = M.make_batch(spec, 640, seed=9)
+    t = lambda k: torch.from_numpy(big[k].copy())
+    ds = D.DrVAEDataset(t('x1'), t('x2'), t('s'), t('y'), t('has_x2'), t('has_y')).to(dev)
+    w = D.compute_balanced_weights(np.arange(640) % 7)
+    bat = D.DeviceBatcher(ds, w, 64, seed=5, mode='sampler')
+    fed, a1 = make_engine(spec, params, dev)
+    eager, a0 = make_engine(spec, params, dev)
+    eager.universal = True
+    bat.bind(fed)
+    tables = []
+    for epoch in range(2):
+        tables.append(bat.begin_epoch(n_batches=3).clone())
+        if epoch == 0:
+            fed.capture()
+        for _ in range(3):
+            fed.replay()
+    assert len(fed._plans) == 1 and fed.iters == 6
+    K.counter_add(eager.rng_ctr, 1)          # capture() spends one draw event on its warm-up
+    comps = set()
+    for tab in tables:
+        for b in range(3):
+            i = tab[b].long()
+            hx, hy = ds.has_x2[i].cpu().numpy(), ds.has_y[i].cpu().numpy()
+            comps.add((int(hx.sum()), int(hy.sum())))
+            eager.set_batch(ds.x1[i], ds.x2[i], ds.y[i].cpu(), hx, hy)
+            eager.train_step()
+    torch.cuda.synchronize()
+    assert len(comps) > 1 and len(eager._plans) == 1
+    assert eager.losses() == fed.losses()
+    assert torch.equal(a0.param, a1.param)
+    # one of these batches on its own per-structure plan, injected noise: same losses and gradients
+    i = tables[1][2].long()
+    hx, hy = ds.has_x2[i].cpu().numpy(), ds.has_y[i].cpu().numpy()
+    noise = M.make_noise(spec, 64, seed=21)
+    one, a2 = make_engine(spec, params, dev)
+    a2.param.copy_(a0.param)
+    one.iters = eager.iters                  # (same perturbation annealing coefficient)
+    res = []
+    for e in (eager, one):
+        e.set_batch(ds.x1[i], ds.x2[i], ds.y[i].cpu(), hx, hy)
+        e.training, e.fuse_bwd = True, False
+        e.set_noise(noise)
+        e.forward()
+        e.backward()
+        torch.cuda.synchronize()
+        res.append((e.losses(), e.arena.grad.clone()))
+    assert not one.plan.universal
+    for (k, a), b in zip(res[0][0].items(), res[1][0].values()):
+        np.testing.assert_allclose(a, b, rtol=1e-4, atol=2e-5)
+    rel = float((res[0][1] - res[1][1]).norm() / res[1][1].norm())
+    assert rel < 1e-4, rel
