@@ -360,10 +360,11 @@ def main():
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
-    ap.add_argument('--feed', default='resident', choices=['resident', 'batcher', 'epoch'],
+    ap.add_argument('--feed', default='resident', choices=['resident', 'batcher', 'epoch', 'sampler'],
                     help='resident: one batch parked in HBM (default); batcher: a fresh stratified minibatch drawn on '
                          'the device from an HBM-resident dataset before every step (host-driven gathers); epoch: the '
-                         "same, but the captured step gathers its batch itself from the epoch's index table")
+                         "same, but the captured step gathers its batch itself from the epoch's index table; sampler: "
+                         'as epoch, with the exact WeightedRandomSampler semantics (any group mix per batch: universal plan)')
     ap.add_argument('--dataset-rows', type=int, default=16384)
     args = ap.parse_args()
 
@@ -404,9 +405,13 @@ def main():
                              tt('y'), tt('has_x2'), tt('has_y'))
         hx, hy = batch['has_x2'].astype(bool), batch['has_y'].astype(bool)
         gc = [int(((hy == bool(gy)) & (hx == bool(gx))).sum()) for (gy, gx) in DD._GROUPS]
-        bat = DD.DeviceBatcher(ds, torch.ones(args.dataset_rows), rows, group_counts=gc, seed=5 + rank)
-        bat.bind(eng, counts=(world * rows, world * int(hx.sum()), world * int(hy.sum())))
-        if args.feed == 'epoch':
+        if args.feed == 'sampler':
+            bat = DD.DeviceBatcher(ds, torch.ones(args.dataset_rows), rows, seed=5 + rank, mode='sampler')
+            bat.bind(eng)
+        else:
+            bat = DD.DeviceBatcher(ds, torch.ones(args.dataset_rows), rows, group_counts=gc, seed=5 + rank)
+            bat.bind(eng, counts=(world * rows, world * int(hx.sum()), world * int(hy.sum())))
+        if args.feed in ('epoch', 'sampler'):
             bat.begin_epoch(n_batches=args.steps + args.warmup + 8)
         else:
             bat.feed()

@@ -116,17 +116,7 @@ class DeepGenerativeModelMixin:
         golden vectors of tests/golden/mmd_criterion.npz.  The row selection is an index gather, so
         one-member categories work too (the reference's ``len()`` of a 0-d tensor raises there)."""
         from . import blocks as blk
-        mmd = 0.
-        for ind in sind:
-            flat = ind.reshape(-1)
-            ind0 = torch.nonzero(flat != 0).reshape(-1)
-            ind1 = torch.nonzero(flat == 0).reshape(-1)
-            z0 = z.index_select(0, ind0) if ind0.numel() else torch.empty(1, z.size(1), device=z.device).normal_()
-            z1 = z.index_select(0, ind1) if ind1.numel() else torch.empty(1, z.size(1), device=z.device).normal_()
-            mmd = mmd - blk.mmd_objective(z0, z1, kernel=self.kernel_MMD)
-            if len(sind) == 2:
-                return mmd
-        return mmd / len(sind)
+        return blk.mmd_criterion(z, sind, self.kernel_MMD)
 
     # --------------------------------------------------------------- small helpers
     def _use_free_bits(self, KL_perx, override_default_kl_min=None):
@@ -148,7 +138,7 @@ class DeepGenerativeModelMixin:
         x2 = x2.to(dev, torch.float32).contiguous() if x2 is not None else None
         zeros = torch.zeros(n, dtype=torch.int64)
         eng.set_batch(x1, x2, y, has_x2 if has_x2 is not None else zeros, has_y if has_y is not None else zeros,
-                      counts=getattr(self, '_global_counts', None))
+                      counts=getattr(self, '_global_counts', None), s=s if eng.cfg.use_s else None)
         return eng
 
     def _loss_tensors(self, eng):

@@ -51,8 +51,12 @@ class ELBOModel(FitMixin, DeepGenerativeModelMixin, nn.Module):
             # exist in the reference either (src/DrVAE.py:124-131)
             raise ValueError("type_rec must be 'diag_gaussian'")
         bad = []
-        if getattr(self, 'use_s', False):
-            bad.append('use_s=True (crashes in the reference too: torch.cat([z, s_raw]), src/DrVAE.py:438)')
+        # use_s=True is an EXTENSION here: the reference crashes on it (torch.cat([z, s_raw]) of a float and an
+        # integer tensor, src/DrVAE.py:438), so it is built from the evident intent -- one_hot(s) appended to the
+        # inputs of encoder_z1 and decoder_x, and (use_MMD) the model-level MMD penalty -- and checked against the
+        # oracle's restatement of that intent only (no reference output exists)
+        if getattr(self, 'use_s', False) and (len(self.dim_h_en_z1) < 1 or len(self.dim_h_de_x) < 1):
+            bad.append('use_s=True without hidden layers in encoder_z1 / decoder_x')
         if getattr(self, 'type_y', 'discrete') not in ('discrete', 'cont'):
             raise ValueError('Invalid type_y')
         if getattr(self, 'type_y', 'discrete') == 'cont' and self.kind == 'vfae' and getattr(self, 'semi_supervised', False):
@@ -84,8 +88,9 @@ class ELBOModel(FitMixin, DeepGenerativeModelMixin, nn.Module):
         hp = dict(nonlin=self.nonlinearity, weight_norm=self.wn, batch_norm=self.bn, dropout_rate=self.dropout_rate)
         pri = dict(prior_mu=self.prior_mu, prior_sg=self.prior_sg)
         Z1 = self.dim_z1
-        self.encoder_z1 = blk.DiagGaussianModule([self.dim_x], self.dim_h_en_z1, Z1,
-                                                 input_dropout_rates=[self.input_x_dropout], **pri, **hp)
+        s_in = [self.dim_s] if getattr(self, 'use_s', False) else []       # src/DrVAE.py:134-135,179-180
+        self.encoder_z1 = blk.DiagGaussianModule([self.dim_x] + s_in, self.dim_h_en_z1, Z1,
+                                                 input_dropout_rates=[self.input_x_dropout] + [0.] * len(s_in), **pri, **hp)
         if self.kind in ('drvae', 'pvae'):
             self.dim_z2 = Z1
             self.decoder_z2Fz1 = blk.DiagGaussianModuleLinear([Z1], [], Z1, bias_only=False, **pri, **hp)
@@ -102,7 +107,7 @@ class ELBOModel(FitMixin, DeepGenerativeModelMixin, nn.Module):
             top = blk.DiagGaussianModule([Z1, self.dim_y], top_h, top_z, **pri, **hp)
             setattr(self, 'encoder_z3' if self.kind == 'drvae' else 'encoder_z2', top)
             self.decoder_z1 = blk.DiagGaussianModule([top_z, self.dim_y], self.dim_h_de_z1, Z1, **hp)
-        self.decoder_x = blk.DiagGaussianSigmaModule([Z1], self.dim_h_de_x, self.dim_x, **hp)
+        self.decoder_x = blk.DiagGaussianSigmaModule([Z1] + s_in, self.dim_h_de_x, self.dim_x, **hp)
 
     def _step_config(self):
         top = 'dim_z3' if self.kind == 'drvae' else 'dim_z2'
@@ -120,6 +125,9 @@ class ELBOModel(FitMixin, DeepGenerativeModelMixin, nn.Module):
             clf_z1z2=getattr(self, 'clf_z1z2', True), semi_supervised=getattr(self, 'semi_supervised', True),
             kl_min=self.kl_min, optim_alg=self.optim_alg, clf_1sig=bool(getattr(self, 'clf_1sig', False)),
             type_y=getattr(self, 'type_y', 'discrete'),
+            use_s=bool(getattr(self, 'use_s', False)), dim_s=int(getattr(self, 'dim_s', 2)),
+            use_MMD=bool(getattr(self, 'use_s', False) and getattr(self, 'use_MMD', False)),
+            mmd_rate=float(getattr(self, 'mmd_rate', 1.)), kernel_MMD=getattr(self, 'kernel_MMD', 'rbf_fourier'),
             prior_y=None if (getattr(self, 'prior_y', None) is None or isinstance(getattr(self, 'prior_y', None), str))
             else tuple(float(v) for v in self.prior_y))
 
@@ -130,7 +138,8 @@ class ELBOModel(FitMixin, DeepGenerativeModelMixin, nn.Module):
         src/PVAE.py:203-246, src/VFAE.py:178-215."""
         self.eval()
         x1 = x1.to(next(self.parameters()).device, torch.float32)
-        qz1 = self.encoder_z1([x1])
+        cond = self._s_inputs(s, x1)
+        qz1 = self.encoder_z1([x1] + cond)
         z1 = qz1[0]
         res = OrderedDict(z1=z1, qz1=qz1)
         if self.kind in ('drvae', 'pvae'):
@@ -144,12 +153,18 @@ class ELBOModel(FitMixin, DeepGenerativeModelMixin, nn.Module):
                 clf_in = [z1]
             qy = self.encoder_y(clf_in)
             res.update(**self._pred_proba(qy))
-        px1 = self.decoder_x([z1])
+        px1 = self.decoder_x([z1] + cond)
         res.update(px1=px1, x1_rec=px1[0])
         if self.kind in ('drvae', 'pvae'):
-            px2 = self.decoder_x([z2])
+            px2 = self.decoder_x([z2] + cond)
             res.update(px2=px2, x2_pert=px2[0])
         return res
+
+    def _s_inputs(self, s, like):
+        """[one_hot(s)] when the model conditions on the nuisance variable (src/DrVAE.py:265-268), else []"""
+        if not getattr(self, 'use_s', False):
+            return []
+        return [blk.one_hot(torch.as_tensor(s).to(like.device), self.dim_s)]
 
     @torch.no_grad()
     def forward_w_pert_identity(self, x1, x2, s=[]):
@@ -160,15 +175,16 @@ class ELBOModel(FitMixin, DeepGenerativeModelMixin, nn.Module):
         self.eval()
         dev = next(self.parameters()).device
         x1, x2 = x1.to(dev, torch.float32), x2.to(dev, torch.float32)
-        qz1 = self.encoder_z1([x1])
+        cond = self._s_inputs(s, x1)
+        qz1 = self.encoder_z1([x1] + cond)
         z1 = qz1[0]
         res = OrderedDict(z1=z1, qz1=qz1)
         if self.kind == 'drvae':
             qy = self.encoder_y([z1, z1 - z1] if self.clf_z1z2 else [z1])
             res.update(**self._pred_proba(qy))
-        px2 = self.decoder_x([z1])
-        qz2 = self.encoder_z1([x2])
-        px2_rec = self.decoder_x([qz2[0]])
+        px2 = self.decoder_x([z1] + cond)
+        qz2 = self.encoder_z1([x2] + cond)
+        px2_rec = self.decoder_x([qz2[0]] + cond)
         res.update(px2=px2, x2_pert=px2[0], z2=qz2[0], qz2=qz2, px2_rec=px2_rec, x2_rec=px2_rec[0])
         return res
 

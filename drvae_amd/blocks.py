@@ -80,6 +80,24 @@ def rbf(x1, x2, gamma=1.):
     return torch.exp(-d2 * gamma).t()
 
 
+def mmd_criterion(z, sind, kernel='rbf_fourier'):
+    """Minus the MMD (``mmd_objective`` with ``kernel``) between the latent rows of every category of the nuisance
+    variable and the rows outside it, averaged over the categories; with two categories only the first pair
+    (the body of src/DGMMixin.py:42-66).  ``sind``: one 0/1 indicator vector per category.  A side without rows is
+    replaced by one random N(0,1) row, like the reference."""
+    mmd = 0.
+    for ind in sind:
+        flat = ind.reshape(-1)
+        ind0 = torch.nonzero(flat != 0).reshape(-1)
+        ind1 = torch.nonzero(flat == 0).reshape(-1)
+        z0 = z.index_select(0, ind0) if ind0.numel() else torch.empty(1, z.size(1), device=z.device).normal_()
+        z1 = z.index_select(0, ind1) if ind1.numel() else torch.empty(1, z.size(1), device=z.device).normal_()
+        mmd = mmd - mmd_objective(z0, z1, kernel=kernel)
+        if len(sind) == 2:
+            return mmd
+    return mmd / len(sind)
+
+
 def poly(x1, x2, degree=2, gamma=1., bias=1.):
     """src/blocks.py:34-35 (the x1 x2^T product runs on the MFMA GEMM)."""
     gram = ops.linear_act([x1], x2.contiguous(), None)

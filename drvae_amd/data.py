@@ -168,6 +168,9 @@ class DeviceBatcher:
     def bind(self, engine, counts=None):
         """build / select the step plan for this batcher's fixed batch structure"""
         self.engine = engine
+        if engine.cfg.use_s:
+            raise NotImplementedError('DeviceBatcher: models conditioned on the nuisance variable (use_s extension) are '
+                                      'fed through run_on_batch / a tuple loader')
         if self.mode == 'sampler':
             assert counts is None, 'the exact sampler composes batches per rank: use mode="stratified" under data parallelism'
             engine.universal = True

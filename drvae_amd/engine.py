@@ -68,6 +68,14 @@ class StepConfig:
     prior_y: Optional[Tuple[float, ...]] = None    # None = 'uniform' (src/DrVAE.py:386-389)
     clf_1sig: bool = False                          # two classes from one sigmoid output (src/DrVAE.py:160-163)
     type_y: str = 'discrete'                        # 'cont': regression head N(sigmoid(.), 0.05^2) (src/DrVAE.py:167-169)
+    # EXTENSION (unreachable in the reference, which crashes at src/DrVAE.py:438): one_hot(s) appended
+    # to the inputs of encoder_z1 and decoder_x (src/DrVAE.py:134-135,179-180), and with use_MMD the model-level MMD
+    # penalty between the nuisance classes' latent samples (src/DrVAE.py:394-398,537-540,616,623-624)
+    use_s: bool = False
+    dim_s: int = 2
+    use_MMD: bool = False
+    mmd_rate: float = 1.0
+    kernel_MMD: str = 'rbf_fourier'
 
     @property
     def cont(self):
@@ -116,7 +124,8 @@ def param_shapes(cfg):
         lin('%s.encoder_%s.linear_%s' % (prefix, second, second), n, n_out)
 
     X, Y, Z1, Z3 = cfg.dim_x, cfg.dim_y, cfg.dim_z1, cfg.dim_z3
-    gauss('encoder_z1', X, cfg.h_en_z1, Z1)
+    S = cfg.dim_s if cfg.use_s else 0
+    gauss('encoder_z1', X + S, cfg.h_en_z1, Z1)
     if cfg.has_pert:
         out['decoder_z2Fz1.W_mu'] = (Z1, Z1)
         out['decoder_z2Fz1.bias_mu'] = (Z1,)
@@ -131,7 +140,7 @@ def param_shapes(cfg):
             lin('encoder_y.decoder_p.linear_p', n, 1 if cfg.clf_1sig else Y)
         gauss(cfg.top_name, Z1 + Y, cfg.h_en_z3, Z3)
         gauss('decoder_z1', Z3 + Y, cfg.h_de_z1, Z1)
-    gauss('decoder_x', Z1, cfg.h_de_x, X, second='sg')
+    gauss('decoder_x', Z1 + S, cfg.h_de_x, X, second='sg')
     return out
 
 
@@ -251,7 +260,7 @@ class FusedStep(StepSchedule):
     # ------------------------------------------------------------------------- plan
     def universal_ok(self):
         cfg = self.cfg
-        return not cfg.cont and not (cfg.kind == 'vfae' and not cfg.semi_supervised)
+        return not cfg.cont and not (cfg.kind == 'vfae' and not cfg.semi_supervised) and not cfg.use_s
 
     def set_structure_universal(self, n_rows):
         """Select (or build) the batch-independent plan for ``n_rows`` rows."""
@@ -297,10 +306,21 @@ class FusedStep(StepSchedule):
                         del self._plans[old]
         return self.plan, rows
 
-    def set_batch(self, x1, x2, y, has_x2, has_y, counts=None):
+    def set_batch(self, x1, x2, y, has_x2, has_y, counts=None, s=None):
         """x1,x2: (B,X) device fp32; y: (B,) or (B,1) ints (host or device); has_*: host bool/int
         arrays.  ``counts`` = (N_total, N_pairs, N_labeled) GLOBAL normalisers under data
-        parallelism; default: this batch's own counts (src/DrVAE.py:611-616)."""
+        parallelism; default: this batch's own counts (src/DrVAE.py:611-616).
+        ``s``: nuisance classes of the rows (``use_s`` extension)."""
+        cfg = self.cfg
+        if cfg.use_s:
+            assert s is not None, 'use_s: the nuisance classes of the batch are needed'
+            p = self._set_batch(x1, x2, y, has_x2, has_y, counts)
+            sv = np.asarray(s.cpu() if torch.is_tensor(s) else s).astype(np.int64).reshape(-1)
+            p.set_s_host(sv[p.rows])
+            return p
+        return self._set_batch(x1, x2, y, has_x2, has_y, counts)
+
+    def _set_batch(self, x1, x2, y, has_x2, has_y, counts=None):
         cfg = self.cfg
         if self.universal and counts is None and self.universal_ok():
             hy = np.asarray(has_y.cpu() if torch.is_tensor(has_y) else has_y).reshape(-1)
@@ -432,11 +452,11 @@ class FusedStep(StepSchedule):
             fuse = self.fuse_heads and self._heads_small(p.DPX)
             Z1blk = p.ZDEC[:L * B]
             if fuse:
-                Q = p.c_enc.forward([p.XIN], heads=dict(sample=dict(
+                Q = p.c_enc.forward(p.enc_in, heads=dict(sample=dict(
                     eps=p.E12, out=p.ZDEC[:p.o3], n_src=B, seg_ptr=p.zseg_ptr, seg_rows=p.zseg_rows)))
                 Qmu, Qlv = Q[:, :Z1], Q[:, Z1:]
             else:
-                Q = p.c_enc.forward([p.XIN])
+                Q = p.c_enc.forward(p.enc_in)
                 Qmu, Qlv = Q[:, :Z1], Q[:, Z1:]
                 K.reparam_fwd(p.ZDEC[:p.o3], Qmu, Qlv, p.E12, src_idx=p.z_src_idx)
             if cfg.has_pert:
@@ -452,6 +472,8 @@ class FusedStep(StepSchedule):
                     P2 = p.c_z2F.forward([Z1blk], resid=Z1blk, publish=pub1)
                     K.reparam_fwd(p.Z2F, P2[:, :Z1], P2[:, Z1:], p.E2F, sub=Z1blk, out2=p.D,
                                   out3=p.ZDEC if Np else None, out3_idx=p.pert_out_idx if Np else None)
+        if p.DZMMD is not None and rec != 'side':
+            self._mmd_penalty()
         # ---- two independent chains from here: the classifier / fprop chain (many small launches)
         # runs on a side stream next to the decoder chain (the big GEMMs)
         def side_forward(mid=None):
@@ -537,11 +559,11 @@ class FusedStep(StepSchedule):
         X = cfg.dim_x
         self._nll_fused = bool(self.fuse_bwd and self.fuse_heads and self._heads_small(p.DPX))
         if self._nll_fused:    # train step: the heads' launch emits d/d(mu, pre-softplus) and the row sums' partials
-            p.c_decx.forward([p.ZDEC], publish=pub, heads=dict(out=p.DPX, nll=dict(
+            p.c_decx.forward(p.dec_in, publish=pub, heads=dict(out=p.DPX, nll=dict(
                 x=p.XIN, xidx=p.tgt, coef=p.c_nll, part=p.NLLP)))
             PX = None
         else:
-            PX = p.c_decx.forward([p.ZDEC], publish=pub)
+            PX = p.c_decx.forward(p.dec_in, publish=pub)
         if self._nll_fused:
             pass
         elif self.fuse_bwd:    # train step: d/d(mu, pre-softplus) emitted in the same row pass
@@ -559,6 +581,26 @@ class FusedStep(StepSchedule):
         if self.fuse_bwd:
             return             # the loss scalars are assembled on the side chain of backward()
         self._loss_scalars()
+
+    def _mmd_penalty(self):
+        """Model-level MMD penalty of the ``use_s`` extension (src/DrVAE.py:394-398,537-540): minus the MMD between
+        the latent samples of each nuisance class and the rest, per data group and Monte-Carlo sample, on z1 and
+        (pairs) z2.  A cross-row term: evaluated with the block-level MMD operators (``blocks.mmd_criterion`` -> the
+        HIP MMD kernels, forward and backward) on the sample rows of the stacked decoder input; value -> the loss
+        tail, gradient -> ``DZMMD``, added to d/dz behind the decoder's backward pass.  Eager steps only."""
+        cfg, p = self.cfg, self.plan
+        if p.ZDEC.is_cuda and torch.cuda.is_current_stream_capturing():
+            raise NotImplementedError('use_MMD: the model-level MMD penalty runs in eager train steps only')
+        from . import blocks as blk
+        with torch.enable_grad():
+            z = p.ZDEC[:p.o3].detach().clone().requires_grad_(True)
+            total = z.new_zeros(())
+            for rows, sind in p.mmd_calls:
+                total = total + blk.mmd_criterion(z.index_select(0, rows), sind, cfg.kernel_MMD) / cfg.L
+            total.backward()
+        p.MMDval.copy_(total.detach().reshape(1))
+        # CMPL = ... - mmd_rate * MMD_sum / N_total  (src/DrVAE.py:616,623-624)
+        p.DZMMD.copy_(z.grad * (-cfg.mmd_rate / p.n_tot))
 
     def _loss_scalars(self, after=None, terms_elsewhere=False):
         """RECL, KLD, PERT, YL, ELBO, CMPL (src/DrVAE.py:611-624) as device scalars.  ``terms_elsewhere``
@@ -584,6 +626,8 @@ class FusedStep(StepSchedule):
             terms.append((p.KLDrow, None, 1.0 / (L * p.n_tot), 1))
             terms.append((p.YLrow, p.w_yl, 1.0, 3) if p.universal else
                          (p.YLrow, None, 1.0 / (L * max(1., p.n_lab)), 3))
+        if p.DZMMD is not None:
+            terms.append((p.MMDval, None, 1.0 / p.n_tot, 4))
         bump = ()
         if after is not None:     # dual-graph train step: this launch also advances the step / Philox counters
             bump = [(self.step_dev, 1)] + ([(self.rng_ctr, self._rng_pending)] if getattr(self, '_rng_pending', 0) else [])
@@ -725,8 +769,13 @@ class FusedStep(StepSchedule):
             self.branch.fork()
         elif mode == 3:
             self.branch._forked = True       # one fork/join per step: the side chain simply continues
-        p.c_decx.backward(p.DPX, [p.ZDEC], [[(p.DZDEC, 1.0, 0.0)]], wbranch=self.wbranch if self.wbranch.on else None,
+        p.c_decx.backward(p.DPX, p.dec_in, [[(p.DZDEC, 1.0, 0.0)]] + [None] * (len(p.dec_in) - 1),
+                          wbranch=self.wbranch if self.wbranch.on else None,
                           publish_after_last=(self.flags[4:5], self.step_dev, 1) if side_adam else None)
+        if p.DZMMD is not None:
+            # model-level MMD penalty (use_s extension): its gradient w.r.t. the z1 / z2 samples was computed in
+            # forward() through the block-level MMD kernels (see ``_mmd_penalty``)
+            p.DZDEC[:p.o3].add_(p.DZMMD)
         if self._after_decoder_bwd is not None:
             self._after_decoder_bwd()        # decoder_x gradients are final: graph split point of the overlapped exchange
         if mode != 5:
@@ -781,7 +830,7 @@ class FusedStep(StepSchedule):
         if cfg.kind == 'pvae':
             K.kl_rows_bwd(DQ[:, :Z1], DQ[:, Z1:], None, None, p.c_klp, p.KLPraw, Qmu, Qlv, prior=(0.0, 0.0),
                           free_bits=True, kl_min=cfg.kl_min, beta=1.0)
-        p.c_enc.backward(DQ, [p.XIN], None,
+        p.c_enc.backward(DQ, p.enc_in, None,
                          publish_first=(self.flags[5:6], self.step_dev, 0) if (late and self.noise_ahead) else None)
 
     # -------------------------------------------------------------------- optimiser

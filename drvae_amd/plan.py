@@ -146,6 +146,21 @@ class _Plan:
         self.ZDEC, self.DZDEC = mat(Md, Z1), mat(Md, Z1)
         self.c_enc = _Chain(eng.L_enc, Me, dev)
         self.c_decx = _Chain(eng.L_decx, Md, dev)
+        self.enc_in, self.dec_in = [self.XIN], [self.ZDEC]
+        self.DZMMD = None
+        if cfg.use_s:
+            # one_hot(s) columns of the encoder / decoder inputs: a second input source of their first layers
+            # (no concatenated copy: the GEMM reads [x | onehot] from two operands); the class of every stacked
+            # row is data, refreshed per batch by ``set_s_host``
+            S = cfg.dim_s
+            assert len(cfg.h_en_z1) >= 1 and len(cfg.h_de_x) >= 1, 'use_s: hidden layers in encoder_z1 and decoder_x'
+            self.SOHe, self.SOHd = mat(Me, S), mat(Md, S)
+            self.s_enc, self.s_dec = i32(np.zeros(Me)), i32(np.zeros(Md))
+            self.enc_in, self.dec_in = [self.XIN, self.SOHe], [self.ZDEC, self.SOHd]
+            self._hx_host = np.asarray(has_x2).astype(bool)
+            if cfg.use_MMD:
+                self.DZMMD = zf(self.o3, Z1)
+                self.MMDval = zf(1)
         self.DQ = zf(Me, 2 * Z1)
         self.DPX = mat(Md, 2 * X)
         self.NLL = zf(Md)
@@ -210,6 +225,45 @@ class _Plan:
         """the installed epoch feed if it is the current input source, else None (inputs come from XSRC)"""
         return self.feed if self.feed_active else None
 
+    def set_s_host(self, sv):
+        """nuisance classes of this batch's rows (``use_s`` extension): one-hot columns of the stacked encoder
+        and decoder rows, and the row lists of the model-level MMD penalty (per data group and sample)"""
+        cfg = self._cfg
+        L, B, Np = cfg.L, self.B, self.Np
+        sv = np.asarray(sv).astype(np.int64).reshape(-1)
+        assert sv.shape[0] == B and sv.min() >= 0 and sv.max() < cfg.dim_s
+        sp = sv[self.pair_host]
+        enc = np.concatenate([sv, sp])
+        dec = np.concatenate([np.tile(sv, L), np.tile(sp, L), np.tile(sp, L)])
+        self.s_enc.copy_(torch.as_tensor(enc, dtype=torch.int32))
+        self.s_dec.copy_(torch.as_tensor(dec, dtype=torch.int32))
+        K.rows_gather(self.SOHe, None, None, onehot_cls=self.s_enc, n_classes=cfg.dim_s, width=0)
+        K.rows_gather(self.SOHd, None, None, onehot_cls=self.s_dec, n_classes=cfg.dim_s, width=0)
+        if cfg.use_MMD:
+            # groups in the reference's order (src/DrVAE.py:585-608; src/PVAE.py:441-453; src/VFAE.py:421-433): the
+            # penalty is evaluated per group and Monte-Carlo sample, on z1 and (pairs) z2 (src/DrVAE.py:537-540)
+            hx = self._hx_host
+            hy = self._has_y_host.astype(bool) if cfg.has_y else np.zeros(B, bool)
+            if cfg.kind == 'drvae':
+                masks = [hy & ~hx, ~hy & ~hx, hy & hx, ~hy & hx]
+            elif cfg.kind == 'pvae':
+                masks = [~hx, hx]
+            else:
+                masks = [hy, ~hy]
+            slot = np.full(B, -1, np.int64)
+            slot[self.pair_host] = np.arange(Np)
+            dev = self.ZDEC.device
+            self.mmd_calls = []
+            for m in masks:
+                idx = np.nonzero(m)[0]
+                if len(idx) == 0:
+                    continue
+                sind = [torch.as_tensor((sv[idx] == k).astype(np.int64), device=dev) for k in range(cfg.dim_s)]
+                for l in range(L):
+                    self.mmd_calls.append((torch.as_tensor(l * B + idx, device=dev), sind))
+                    if hx[idx[0]]:
+                        self.mmd_calls.append((torch.as_tensor(self.o2 + l * Np + slot[idx], device=dev), sind))
+
     def set_labels_host(self, yv):
         """class labels of this batch's rows (host ints; only the labeled rows' entries matter)"""
         cfg = self._cfg
@@ -256,4 +310,6 @@ class _Plan:
         w[LOSS_IDX['ELBO']] = -1.0
         if cfg.has_y:
             w[LOSS_IDX['YL']] = -cfg.yloss_rate
+        if cfg.use_s and cfg.use_MMD:
+            w[LOSS_IDX['MMD']] = -cfg.mmd_rate         # src/DrVAE.py:623-624
         self.w_cmpl.copy_(torch.tensor(w))

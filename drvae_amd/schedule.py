@@ -108,6 +108,9 @@ class StepSchedule:
         step is captured as two graphs so that an (uncaptured) RCCL all-reduce of the
         gradient arena can run between backward and Adam."""
         assert self.plan is not None, 'set_batch first'
+        if self.plan.DZMMD is not None:
+            raise NotImplementedError('use_MMD: the model-level MMD penalty (a cross-row term evaluated through the '
+                                      'block-level MMD operators) runs in eager train steps only')
         self.training = True
         self.plan.set_beta(self.beta_pert())
         side = torch.cuda.Stream()

@@ -56,6 +56,16 @@ class ModelSpec:
     prior_y: Optional[List[float]] = None   # None = 'uniform'; else class prior of length dim_y (DrVAE.py:83-85)
     clf_1sig: bool = False              # 2 classes from ONE sigmoid output (DrVAE.py:160-163)
     type_y: str = 'discrete'            # 'discrete' | 'cont' (regression head, DrVAE.py:159-169)
+    # EXTENSION -- the reference crashes with use_s=True (torch.cat([z, s_raw]), DrVAE.py:438) and
+    # its MMD glue cannot run (DGMMixin.py:42-66), so there is no reference output to pin these to; the maths is
+    # what the code evidently intends: one_hot(s) appended to the inputs of encoder_z1 and decoder_x
+    # (DrVAE.py:134-135,179-180,400-402,436-438) and, with use_MMD, minus the MMD between the latent samples of
+    # each nuisance class and the rest, per data group and Monte-Carlo sample (DrVAE.py:394-398,537-540,616,623-624)
+    use_s: bool = False
+    dim_s: int = 2
+    use_MMD: bool = False
+    mmd_rate: float = 1.0
+    kernel_MMD: str = 'identity'
     top_name: str = ''                  # filled in __post_init__
 
     def __post_init__(self):
@@ -85,7 +95,8 @@ def param_shapes(spec):
         lin('%s.encoder_%s.linear_%s' % (prefix, second, second), n, n_out)
 
     X, Y, Z1, Z3 = spec.dim_x, spec.dim_y, spec.dim_z1, spec.dim_z3
-    gauss('encoder_z1', X, spec.h_en_z1, Z1)
+    S = spec.dim_s if spec.use_s else 0
+    gauss('encoder_z1', X + S, spec.h_en_z1, Z1)
     if spec.kind in ('drvae', 'pvae'):
         out['decoder_z2Fz1.W_mu'] = (Z1, Z1)
         out['decoder_z2Fz1.bias_mu'] = (Z1,)
@@ -100,7 +111,7 @@ def param_shapes(spec):
             lin('encoder_y.decoder_p.linear_p', n, 1 if spec.clf_1sig else Y)
         gauss(spec.top_name, Z1 + Y, spec.h_en_z3, Z3)
         gauss('decoder_z1', Z3 + Y, spec.h_de_z1, Z1)
-    gauss('decoder_x', Z1, spec.h_de_x, X, second='sg')
+    gauss('decoder_x', Z1 + S, spec.h_de_x, X, second='sg')
     return out
 
 
@@ -172,7 +183,8 @@ def make_batch(spec, n_rows, seed=1234, group_mod=None):
         has_y = (i % 2 == 0)
         has_x2 = np.zeros(n_rows, bool)
     x2 = x2 * has_x2[:, None].astype(np.float32)
-    return {'x1': x1, 'x2': x2, 's': np.zeros((n_rows, 1), np.int64), 'y': y,
+    s = rs.randint(0, spec.dim_s, (n_rows, 1)).astype(np.int64) if spec.use_s else np.zeros((n_rows, 1), np.int64)
+    return {'x1': x1, 'x2': x2, 's': s, 'y': y,
             'has_x2': has_x2.astype(np.int64), 'has_y': has_y.astype(np.int64)}
 
 
@@ -182,7 +194,7 @@ class _Acc:
 
     def __init__(self, n):
         self.rows = {k: torch.zeros(n) for k in ('RECL', 'KLD', 'PERT', 'YL')}
-        self.sums = {k: 0. for k in ('RECL', 'KLD', 'PERT', 'YL')}
+        self.sums = {k: 0. for k in ('RECL', 'KLD', 'PERT', 'YL', 'MMD')}
 
     def add(self, key, idx, row_values, scale):
         """sum += row_values.sum() * scale   (reference: ``X += f(...).sum() / Lf``)"""
@@ -207,7 +219,7 @@ def _beta_pert(spec, iters):
     return 1.
 
 
-def _group_losses(spec, p, acc, idx, x1, x2, y, noise, iters, training):
+def _group_losses(spec, p, acc, idx, x1, x2, y, noise, iters, training, s=None):
     """One ``_compute_losses`` call (DrVAE.py:367-543, PVAE.py:265-409, VFAE.py:268-401)
     on the rows ``idx``; ``x2``/``y`` are None for singleton / unlabeled groups."""
     L, Lf = spec.L, 1. * spec.L
@@ -221,12 +233,16 @@ def _group_losses(spec, p, acc, idx, x1, x2, y, noise, iters, training):
     x1 = x1.clone()
     if training and spec.add_noise_var > 0.:          # DrVAE.py:404-407 (N(0,1) * add_noise_var, in place)
         x1 = x1 + nz('nx1') * spec.add_noise_var
-    qz1 = B.diag_gaussian([x1], p, 'encoder_z1', nh1, spec.nonlin)
+    cond = []
+    if spec.use_s:                                    # one_hot(s) conditions encoder_z1 and decoder_x (extension)
+        cond = [B.one_hot(s, spec.dim_s)]
+        sind = [(s.reshape(-1) == k) for k in range(spec.dim_s)]
+    qz1 = B.diag_gaussian([x1] + cond, p, 'encoder_z1', nh1, spec.nonlin)
     if pair:
         x2 = x2.clone()
         if training and spec.add_noise_var > 0.:      # DrVAE.py:414-417
             x2 = x2 + nz('nx2') * spec.add_noise_var
-        qz2 = B.diag_gaussian([x2], p, 'encoder_z1', nh1, spec.nonlin)   # same encoder, DrVAE.py:418
+        qz2 = B.diag_gaussian([x2] + cond, p, 'encoder_z1', nh1, spec.nonlin)   # same encoder, DrVAE.py:418
     cont = spec.type_y == 'cont'
     if has_y and labeled:
         y1hot = y.float().reshape(n, -1) if cont else B.one_hot(y, spec.dim_y)      # DrVAE.py:511-515
@@ -239,16 +255,20 @@ def _group_losses(spec, p, acc, idx, x1, x2, y, noise, iters, training):
             pz2F = B.diag_gaussian_linear([z1], p, 'decoder_z2Fz1')
             z2F = B.sample_logvar(pz2F[0], pz2F[1], nz('ez2F', l))
 
-        px1 = B.diag_gaussian_sigma([z1], p, 'decoder_x', nhx, spec.nonlin)
+        px1 = B.diag_gaussian_sigma([z1] + cond, p, 'decoder_x', nhx, spec.nonlin)
         acc.add('RECL', idx, B.logp_sigma_rows(x1, *px1), 1. / Lf)        # DrVAE.py:441-442
+        if spec.use_s and spec.use_MMD:                                    # DrVAE.py:537-540
+            acc.sums['MMD'] = acc.sums['MMD'] + B.mmd_criterion(z1, sind, spec.kernel_MMD) / Lf
+            if pair and has_pert:
+                acc.sums['MMD'] = acc.sums['MMD'] + B.mmd_criterion(z2, sind, spec.kernel_MMD) / Lf
 
         if spec.kind == 'pvae':                                            # PVAE.py:330-339
             acc.add('KLD', idx, B.free_bits(B.kl_logvar_prior_rows(*qz1), spec.kl_min), 1. / Lf)
 
         if pair and has_pert:
-            px2 = B.diag_gaussian_sigma([z2], p, 'decoder_x', nhx, spec.nonlin)
+            px2 = B.diag_gaussian_sigma([z2] + cond, p, 'decoder_x', nhx, spec.nonlin)
             acc.add('RECL', idx, B.logp_sigma_rows(x2, *px2), 1. / Lf)    # DrVAE.py:451-452
-            px2p = B.diag_gaussian_sigma([z2F], p, 'decoder_x', nhx, spec.nonlin)
+            px2p = B.diag_gaussian_sigma([z2F] + cond, p, 'decoder_x', nhx, spec.nonlin)
             acc.add('PERT', idx, B.logp_sigma_rows(x2, *px2p), 1. / Lf)   # DrVAE.py:459-460
             if spec.kind == 'pvae':                                        # PVAE.py:363-372
                 acc.add('KLD', idx, B.free_bits(B.kl_logvar_prior_rows(*qz2), spec.kl_min), 1. / Lf)
@@ -317,7 +337,8 @@ def loss_function(spec, p, batch, noise, iters=0, training=True, counts=None):
         if idx.numel() == 0:
             continue              # reference: warnings.warn + zero dummy losses
         _group_losses(spec, p, acc, idx, x1[idx], x2[idx] if pair else None,
-                      y[idx] if labeled else None, noise, iters, training)
+                      y[idx] if labeled else None, noise, iters, training,
+                      s=_t(batch['s'])[idx] if spec.use_s else None)
 
     n_pairs, n_lab = int(hx.sum()), int(hy.sum())
     if counts is not None:
@@ -336,7 +357,8 @@ def loss_function(spec, p, batch, noise, iters=0, training=True, counts=None):
     if spec.kind != 'pvae':
         # DrVAE.py:615 divides by max(1, N_labeled); VFAE.py:443 by Nl (same when Nl>0)
         out['YL'] = S['YL'] / max(1., n_lab)
-    out['MMD'] = zero                                           # use_MMD glue is unreachable
+    # the reference's use_MMD glue is unreachable; with the use_s extension: DrVAE.py:616
+    out['MMD'] = S['MMD'] / n_tot if (spec.use_s and spec.use_MMD) else zero
     beta = _beta_pert(spec, iters)
     if spec.kind == 'vfae':
         out['ELBO'] = out['RECL'] - out['KLD']                  # VFAE.py:453
@@ -345,6 +367,8 @@ def loss_function(spec, p, batch, noise, iters=0, training=True, counts=None):
     out['CMPL'] = -out['ELBO']
     if spec.kind != 'pvae':
         out['CMPL'] = out['CMPL'] - spec.yloss_rate * out['YL']  # DrVAE.py:622
+    if spec.use_s and spec.use_MMD:
+        out['CMPL'] = out['CMPL'] - spec.mmd_rate * out['MMD']   # DrVAE.py:623-624
     return out, acc.rows
 
 

@@ -155,3 +155,52 @@ def test_universal_plan_one_plan_for_any_composition(monkeypatch):
         close(au.grad, a1.grad.numpy(), 2e-4, 1e-6)
         close(au.param, a1.param.numpy(), 1e-5, 1e-6)
     assert len(uni._plans) == 1
+
+
+def _use_s_case(kind, use_mmd, seed=0):
+    spec = C.tiny_spec(kind, use_s=True, dim_s=2, use_MMD=use_mmd, mmd_rate=0.7, kernel_MMD='identity')
+    for sd in range(seed, seed + 50):      # every data group must hold both nuisance classes (no random fill-in row)
+        batch = M.make_batch(spec, 24, seed=sd)
+        hx, hy, s = batch['has_x2'].astype(bool), batch['has_y'].astype(bool), batch['s'].reshape(-1)
+        groups = {'drvae': [hy & ~hx, ~hy & ~hx, hy & hx, ~hy & hx], 'pvae': [~hx, hx], 'vfae': [hy, ~hy]}[kind]
+        if all(len(set(s[g])) == 2 for g in groups):
+            return spec, batch
+    raise AssertionError('no suitable batch')
+
+
+@pytest.mark.parametrize('use_mmd', [False, True])
+@pytest.mark.parametrize('kind', ['drvae', 'pvae', 'vfae'])
+def test_use_s_extension_matches_oracle(kind, use_mmd, monkeypatch):
+    """N4 (extension, no reference output exists: the reference crashes with use_s=True): one_hot(s) conditioning of
+    encoder_z1 / decoder_x and the model-level MMD penalty against the oracle's restatement of the intended maths"""
+    kernel_ref.install(monkeypatch)
+    spec, batch = _use_s_case(kind, use_mmd)
+    params = M.init_params(spec, 9, as_numpy=True)
+    eng, arena = make_engine(spec, params)
+    assert eng.cfg.use_s and eng.cfg.use_MMD == use_mmd
+    tr = M.RefTrainer(spec, M.init_params(spec, 9))
+    t = lambda k: torch.from_numpy(batch[k].copy())
+    eng.set_batch(t('x1'), t('x2'), batch['y'], batch['has_x2'], batch['has_y'], s=batch['s'])
+    # gradients of a train-mode pass
+    noise = M.make_noise(spec, 24, seed=4)
+    ref, _ = tr.loss(batch, noise, True)
+    ref['CMPL'].backward()
+    eng.training = True
+    eng.set_noise(noise)
+    eng.forward()
+    eng.backward()
+    for k, v in eng.losses().items():
+        close(v, float(ref[k]), 2e-5, 2e-6)
+    if use_mmd:
+        assert abs(eng.losses()['MMD']) > 1e-4
+    for k, prm in tr.params.items():
+        close(arena.g(k), prm.grad.numpy(), 3e-4, 2e-6)
+        prm.grad = None
+    for step in range(3):
+        nz = M.make_noise(spec, 24, seed=10 + step)
+        want, _ = tr.step(batch, nz)
+        eng.train_step(nz)
+        for k, v in eng.losses().items():
+            close(v, float(want[k]), 2e-5, 2e-6)
+    for k, prm in tr.params.items():
+        close(arena.p(k), prm.detach().numpy(), 1e-4, 2e-5)
