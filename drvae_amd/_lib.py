@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, 'libdrvae_hip.so')
 ACT = {'identity': 0, 'elu': 1, 'softplus': 2, 'sigmoid': 3, 'tanh': 4, 'relu': 5, 'leaky_relu': 6, 'selu': 7,
        'softsign': 8, 'cos': 9}
 GAUSS_LOGVAR, GAUSS_SIGMA = 0, 1
+REC_KIND = {'binary': 0, 'poisson': 1}
 EPI_PLAIN, EPI_FWD, EPI_BWD = 0, 1, 2
 
 _f, _i32, _i64, _u64, _p = C.c_float, C.c_int32, C.c_int64, C.c_uint64, C.c_void_p
@@ -76,6 +77,7 @@ SIGNATURES = {
                        _p, _p, _i64, _p, _p, _i64, _f, _p, _i64, _p, _i64, _p],
     'dv_gauss_nll_rows_fwd': [_p, _i64, _p, _p, _p, _i64, _i32, _i32, _i32, _p, _p],
     'dv_gauss_nll_rows_fwdbwd': [_p, _p, _i64, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _f, _p, _p, _p, _i64, _p],
+    'dv_rec_nll_rows': [_i32, _f, _p, _p, _i64, _p, _p, _i64, _i32, _i32, _p, _p, _i64, _p],
     'dv_gauss_nll_rows_bwd': [_p, _p, _i64, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _f, _p, _p, _i64, _p, _i64,
                               _f, _p],
     'dv_softmax_clamp_fwd': [_p, _i64, _i32, _i32, _i32, _p, _i64, _p],

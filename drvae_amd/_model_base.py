@@ -46,10 +46,10 @@ class ELBOModel(FitMixin, DeepGenerativeModelMixin, nn.Module):
         self.to(device)
 
     def _check_supported(self):
-        if self.type_rec != 'diag_gaussian':
-            # 'binary'/'poisson' point at blk.BernoulliDecoder/PoissonDecoder, which do not
-            # exist in the reference either (src/DrVAE.py:124-131)
-            raise ValueError("type_rec must be 'diag_gaussian'")
+        if self.type_rec not in ('diag_gaussian', 'binary', 'poisson'):
+            raise ValueError("type_rec must be 'diag_gaussian', 'binary' or 'poisson'")      # src/DrVAE.py:124-131
+        # 'binary' / 'poisson' point at blk.BernoulliDecoder / blk.PoissonDecoder, which the reference's blocks.py
+        # does not define (its constructor raises AttributeError there): built here as labelled EXTENSIONS
         bad = []
         # use_s=True is an EXTENSION here: the reference crashes on it (torch.cat([z, s_raw]) of a float and an
         # integer tensor, src/DrVAE.py:438), so it is built from the evident intent -- one_hot(s) appended to the
@@ -107,7 +107,9 @@ class ELBOModel(FitMixin, DeepGenerativeModelMixin, nn.Module):
             top = blk.DiagGaussianModule([Z1, self.dim_y], top_h, top_z, **pri, **hp)
             setattr(self, 'encoder_z3' if self.kind == 'drvae' else 'encoder_z2', top)
             self.decoder_z1 = blk.DiagGaussianModule([top_z, self.dim_y], self.dim_h_de_z1, Z1, **hp)
-        self.decoder_x = blk.DiagGaussianSigmaModule([Z1] + s_in, self.dim_h_de_x, self.dim_x, **hp)
+        dec = {'diag_gaussian': blk.DiagGaussianSigmaModule, 'binary': blk.BernoulliDecoder,
+               'poisson': blk.PoissonDecoder}[self.type_rec]                 # src/DrVAE.py:124-129
+        self.decoder_x = dec([Z1] + s_in, self.dim_h_de_x, self.dim_x, **hp)
 
     def _step_config(self):
         top = 'dim_z3' if self.kind == 'drvae' else 'dim_z2'
@@ -124,7 +126,7 @@ class ELBOModel(FitMixin, DeepGenerativeModelMixin, nn.Module):
             anneal_perturb_rate_offset=getattr(self, 'anneal_perturb_rate_offset', 0),
             clf_z1z2=getattr(self, 'clf_z1z2', True), semi_supervised=getattr(self, 'semi_supervised', True),
             kl_min=self.kl_min, optim_alg=self.optim_alg, clf_1sig=bool(getattr(self, 'clf_1sig', False)),
-            type_y=getattr(self, 'type_y', 'discrete'),
+            type_y=getattr(self, 'type_y', 'discrete'), type_rec=self.type_rec,
             use_s=bool(getattr(self, 'use_s', False)), dim_s=int(getattr(self, 'dim_s', 2)),
             use_MMD=bool(getattr(self, 'use_s', False) and getattr(self, 'use_MMD', False)),
             mmd_rate=float(getattr(self, 'mmd_rate', 1.)), kernel_MMD=getattr(self, 'kernel_MMD', 'rbf_fourier'),

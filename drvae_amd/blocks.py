@@ -363,6 +363,68 @@ class DiagGaussianSigmaModule(GaussianSigmaMixin, nn.Module):
         return mu, std
 
 
+class _SingleHeadDecoder(nn.Module):
+    """MLP trunk ``nnet`` + one Linear head with a fused activation: the anatomy of ``CategoricalDecoder``
+    (src/blocks.py:419-455) for the two data decoders src/DrVAE.py:124-129 names and src/blocks.py never defines."""
+    head, lin, act, shift = None, None, 'identity', 0.0
+
+    def __init__(self, input_dims, hidden_dims, reconstruction_dim, nonlin='softplus', weight_norm=False,
+                 batch_norm=False, dropout_rate=0., input_dropout_rates=None):
+        super().__init__()
+        self.nnet = MLP(input_dims=input_dims, hidden_dims=hidden_dims, nonlin=nonlin, weight_norm=weight_norm,
+                        batch_norm=batch_norm, dropout_rate=dropout_rate, input_dropout_rates=input_dropout_rates)
+        self.reconstruction_dim = reconstruction_dim
+        make = lyr.WeightNormLinear if weight_norm else nn.Linear
+        mods = OrderedDict()
+        if dropout_rate > 0.:
+            mods['dropout'] = nn.Dropout(p=dropout_rate)
+        mods[self.lin] = make(_trunk_width(input_dims, hidden_dims), reconstruction_dim)
+        setattr(self, self.head, nn.Sequential(mods))
+
+    def _head_out(self, inputs):
+        h = self.nnet.features(inputs)
+        seq = getattr(self, self.head)
+        if hasattr(seq, 'dropout'):
+            h = [seq.dropout(h[0] if len(h) == 1 else torch.cat(h, 1))]
+        return _apply_linear(getattr(seq, self.lin), h, act=self.act, shift=self.shift)
+
+    def logp(self, x, v):
+        return torch.sum(self.logp_perx(x, v))
+
+
+class BernoulliDecoder(_SingleHeadDecoder):
+    """EXTENSION (``type_rec='binary'``, src/DrVAE.py:124-125; absent from the reference's blocks.py):
+    inputs -> [clamp(sigmoid(linear_p(h)), 1e-10, 1-1e-10)]; log p(x|.) = sum x log p + (1-x) log(1-p)."""
+    head, lin, act = 'decoder_p', 'linear_p', 'sigmoid'
+
+    def forward(self, inputs):
+        return [torch.clamp(self._head_out(inputs), min=1e-10, max=1. - 1e-10)]
+
+    def logp_perx(self, x, ps):
+        return (x * torch.log(ps) + (1. - x) * torch.log(1. - ps)).sum(1)
+
+    def sample(self, ps):
+        return torch.bernoulli(ps)
+
+    def most_probable(self, ps):
+        return (ps > 0.5).to(ps.dtype)
+
+
+class PoissonDecoder(_SingleHeadDecoder):
+    """EXTENSION (``type_rec='poisson'``, src/DrVAE.py:128-129; absent from the reference's blocks.py):
+    inputs -> [softplus(linear_r(h)) + 1e-6]; log p(x|.) = sum x log rate - rate - lgamma(x+1)."""
+    head, lin, act, shift = 'decoder_r', 'linear_r', 'softplus', 1e-6
+
+    def forward(self, inputs):
+        return [self._head_out(inputs)]
+
+    def logp_perx(self, x, rate):
+        return (x * torch.log(rate) - rate - torch.lgamma(x + 1.)).sum(1)
+
+    def sample(self, rate):
+        return torch.poisson(rate)
+
+
 class CategoricalDecoder(nn.Module):
     """inputs -> [clamped class probabilities] (a 1-element list), plus the categorical
     log-likelihood / KL / entropy helpers (src/blocks.py:419-486)."""

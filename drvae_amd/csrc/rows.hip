@@ -492,6 +492,50 @@ __global__ __launch_bounds__(256) void nll_rows_fwdbwd_kernel(const float* __res
     }
 }
 
+// Bernoulli / Poisson reconstruction rows (type_rec = 'binary' / 'poisson': the decoders src/DrVAE.py:124-129 names;
+// the reference ships neither class -- labelled extension).  v = the head's POST-activation output
+// (probability = sigmoid(a), or rate = softplus(a) + shift); out[r] = sum_g log p(x|v); with coef != NULL also
+// dpre[r,g] = coef[r] * d log p / d a (the gradient w.r.t. the head's pre-activation a).
+//   Bernoulli: pc = clamp(v, 1e-10, 1 - 1e-10) (the clamp of src/blocks.py:463 applied to this decoder's probabilities);
+//              log p = x log pc + (1-x) log(1-pc);  d/da = x - v inside the clamp, 0 outside
+//   Poisson  : log p = x log v - v - lgamma(x+1);   d/da = (x/v - 1) * (1 - exp(-(v - shift)))
+__device__ __forceinline__ float rec_term(int kind, float shift, float xv, float v, float& g) {
+    if (kind == DV_REC_BERNOULLI) {
+        const float lo = 1e-10f, hi = (float)(1.0 - 1e-10);
+        const float pc = fminf(fmaxf(v, lo), hi);
+        g = (v > lo && v < hi) ? xv - v : 0.f;
+        return xv * logf(pc) + (1.f - xv) * logf(1.f - pc);
+    }
+    g = (xv / v - 1.f) * (1.f - expf(-(v - shift)));
+    return xv * logf(v) - v - lgammaf(xv + 1.f);
+}
+
+__global__ __launch_bounds__(256) void rec_nll_rows_kernel(int kind, float shift, const float* __restrict__ coef,
+                                                           const float* __restrict__ x, int64_t ldx,
+                                                           const int32_t* __restrict__ xidx,
+                                                           const float* __restrict__ v, int64_t ldv, int M, int X,
+                                                           float* __restrict__ out, float* __restrict__ dpre,
+                                                           int64_t ldd) {
+    __shared__ float part[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int r = blockIdx.x; r < M; r += gridDim.x) {
+        const float* xr = x + (int64_t)(xidx ? xidx[r] : r) * ldx;
+        const float* vr = v + (int64_t)r * ldv;
+        const float c = coef ? coef[r] : 0.f;
+        float acc = 0.f;
+        for (int g = threadIdx.x; g < X; g += 256) {
+            float gr;
+            acc += rec_term(kind, shift, xr[g], vr[g], gr);
+            if (coef) dpre[(int64_t)r * ldd + g] = c * gr;
+        }
+        acc = dv_wave_sum_all(acc);
+        if (lane == 0) part[wave] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) out[r] = (part[0] + part[1]) + (part[2] + part[3]);
+        __syncthreads();
+    }
+}
+
 __global__ void nll_rows_bwd_kernel(const float* __restrict__ coef, const float* __restrict__ x, int64_t ldx,
                                     const int32_t* __restrict__ xidx, const float* __restrict__ mu,
                                     const float* __restrict__ sd, int64_t ldp, int M, int X, int mode, int sd_act,
@@ -1516,6 +1560,17 @@ extern "C" int dv_gauss_nll_rows_fwdbwd(const float* coef, const float* x, int64
     else
         hipLaunchKernelGGL(nll_rows_fwdbwd_kernel<false>, grid, block, 0, ST(stream), coef, x, ldx, xidx, mu, sd, ldp,
                            M, X, mode, sd_act, sd_shift, out, dmu, dsd, ldd);
+    DV_RETURN_LAUNCH();
+}
+
+extern "C" int dv_rec_nll_rows(int32_t kind, float shift, const float* coef, const float* x, int64_t ldx,
+                               const int32_t* xidx, const float* v, int64_t ldv, int32_t M, int32_t X, float* out,
+                               float* dpre, int64_t ldd, dv_stream_t stream) {
+    DV_REQUIRE(M >= 0 && X >= 1 && (kind == DV_REC_BERNOULLI || kind == DV_REC_POISSON));
+    if (M == 0) return DV_OK;
+    DV_REQUIRE(x && v && out && (coef == nullptr || dpre != nullptr));
+    hipLaunchKernelGGL(rec_nll_rows_kernel, dim3(grid_for(M, 1, 4096)), dim3(256), 0, ST(stream), kind, shift, coef, x,
+                       ldx, xidx, v, ldv, M, X, out, dpre, ldd);
     DV_RETURN_LAUNCH();
 }
 

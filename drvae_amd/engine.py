@@ -71,6 +71,10 @@ class StepConfig:
     # EXTENSION (unreachable in the reference, which crashes at src/DrVAE.py:438): one_hot(s) appended
     # to the inputs of encoder_z1 and decoder_x (src/DrVAE.py:134-135,179-180), and with use_MMD the model-level MMD
     # penalty between the nuisance classes' latent samples (src/DrVAE.py:394-398,537-540,616,623-624)
+    # type of p(x|z): 'diag_gaussian' (the only one the reference can build) | 'binary' | 'poisson' -- the Bernoulli /
+    # Poisson decoders src/DrVAE.py:124-129 names and blocks.py never defines: one Linear head, log-likelihood rows
+    # by dv_rec_nll_rows (EXTENSION)
+    type_rec: str = 'diag_gaussian'
     use_s: bool = False
     dim_s: int = 2
     use_MMD: bool = False
@@ -140,10 +144,16 @@ def param_shapes(cfg):
             lin('encoder_y.decoder_p.linear_p', n, 1 if cfg.clf_1sig else Y)
         gauss(cfg.top_name, Z1 + Y, cfg.h_en_z3, Z3)
         gauss('decoder_z1', Z3 + Y, cfg.h_de_z1, Z1)
-    gauss('decoder_x', Z1 + S, cfg.h_de_x, X, second='sg')
+    if cfg.type_rec == 'diag_gaussian':
+        gauss('decoder_x', Z1 + S, cfg.h_de_x, X, second='sg')
+    else:
+        n = trunk('decoder_x.nnet', Z1 + S, cfg.h_de_x)
+        lin(REC_HEAD[cfg.type_rec], n, X)
     return out
 
 
+REC_HEAD = {'binary': 'decoder_x.decoder_p.linear_p', 'poisson': 'decoder_x.decoder_r.linear_r'}
+REC_ACT = {'binary': ('sigmoid', 0.0), 'poisson': ('softplus', 1e-6)}
 Y_LOGVAR_CONT = math.log(0.05 ** 2)      # fixed variance of the regression head (src/DrVAE.py:168)
 
 
@@ -236,7 +246,17 @@ class FusedStep(StepSchedule):
         cfg, a = self.cfg, self.arena
         wn = cfg.weight_norm
         self.L_enc = self._gauss('encoder_z1', len(cfg.h_en_z1), 'lv', shift_second=-2.0)
-        self.L_decx = self._gauss('decoder_x', len(cfg.h_de_x), 'sg', 'softplus', 1e-3)
+        if cfg.type_rec == 'diag_gaussian':
+            self.L_decx = self._gauss('decoder_x', len(cfg.h_de_x), 'sg', 'softplus', 1e-3)
+        else:       # Bernoulli / Poisson decoder: trunk + ONE head (probabilities / rates)
+            layers = []
+            for i in range(1, len(cfg.h_de_x) + 1):
+                q = 'decoder_x.nnet.model.linear%d' % i
+                layers.append(_Lin(a, q + '.weight', q + '.bias', q + '.g' if wn else None, act=cfg.nonlin))
+            q = REC_HEAD[cfg.type_rec]
+            act, shift = REC_ACT[cfg.type_rec]
+            layers.append(_Lin(a, q + '.weight', q + '.bias', q + '.g' if wn else None, act=act, shift0=shift))
+            self.L_decx = layers
         if cfg.has_pert:
             p = 'decoder_z2Fz1.'
             self.L_z2F = [_Lin(a, p + 'W_mu', p + 'bias_mu', None,
@@ -557,7 +577,8 @@ class FusedStep(StepSchedule):
             pub = None
         # ---- p(x|z): decoder over all stacked samples, then the NLL over genes
         X = cfg.dim_x
-        self._nll_fused = bool(self.fuse_bwd and self.fuse_heads and self._heads_small(p.DPX))
+        gauss = cfg.type_rec == 'diag_gaussian'
+        self._nll_fused = bool(gauss and self.fuse_bwd and self.fuse_heads and self._heads_small(p.DPX))
         if self._nll_fused:    # train step: the heads' launch emits d/d(mu, pre-softplus) and the row sums' partials
             p.c_decx.forward(p.dec_in, publish=pub, heads=dict(out=p.DPX, nll=dict(
                 x=p.XIN, xidx=p.tgt, coef=p.c_nll, part=p.NLLP)))
@@ -566,6 +587,9 @@ class FusedStep(StepSchedule):
             PX = p.c_decx.forward(p.dec_in, publish=pub)
         if self._nll_fused:
             pass
+        elif not gauss:        # Bernoulli / Poisson rows (+ the gradient w.r.t. the head's pre-activation in a train step)
+            K.rec_nll_rows(p.NLL, p.XIN, PX, kind=cfg.type_rec, shift=REC_ACT[cfg.type_rec][1], xidx=p.tgt,
+                           coef=p.c_nll if self.fuse_bwd else None, dpre=p.DPX if self.fuse_bwd else None)
         elif self.fuse_bwd:    # train step: d/d(mu, pre-softplus) emitted in the same row pass
             K.nll_rows_fwdbwd(p.NLL, p.DPX[:, :X], p.DPX[:, X:], p.c_nll, p.XIN, PX[:, :X], PX[:, X:], mode=GAUSS_SIGMA,
                               xidx=p.tgt, sd_act='softplus', sd_shift=1e-3)
@@ -742,7 +766,10 @@ class FusedStep(StepSchedule):
         # ---- main chain: reconstruction terms, d/d(mu, pre-softplus) straight from the per-row
         # coefficients, then back through the decoder (the three big GEMMs)
         PX = p.c_decx.out[-1]
-        if not self.fuse_bwd:
+        if not self.fuse_bwd and cfg.type_rec != 'diag_gaussian':
+            K.rec_nll_rows(p.NLL, p.XIN, PX, kind=cfg.type_rec, shift=REC_ACT[cfg.type_rec][1], xidx=p.tgt, coef=p.c_nll,
+                           dpre=p.DPX)
+        elif not self.fuse_bwd:
             K.nll_rows_bwd(p.DPX[:, :X], p.DPX[:, X:], p.c_nll, p.XIN, PX[:, :X], PX[:, X:], mode=GAUSS_SIGMA,
                            xidx=p.tgt, sd_act='softplus', sd_shift=1e-3)
         if mode == 5 and self._rec == 'side':

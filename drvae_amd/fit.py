@@ -129,7 +129,7 @@ class FitMixin:
             x2idx = torch.nonzero(has_x2.reshape(-1)).reshape(-1)
             if len(x2idx) > 0:
                 x2p = x2[x2idx]
-                rp = self.eval_x_reconstruction(x2p, res['px2'][0][x2idx], res['px2'][1][x2idx])
+                rp = self.eval_x_reconstruction(x2p, *[t_[x2idx] for t_ in res['px2'][:2]])
                 for k, v in rp.items():
                     perf['x2_' + k] = v
                 parts.append('X2: ' + _REC.format(perf['x2_rmse'], perf['x2_r2'], perf['x2_pearr']))
@@ -161,7 +161,7 @@ class FitMixin:
         if len(x2idx) > 0:
             x2p = x2[x2idx]
             for tag, key in (('x2_wI_', 'px2'), ('x2_rec_', 'px2_rec')):
-                rp = self.eval_x_reconstruction(x2p, res2[key][0][x2idx], res2[key][1][x2idx])
+                rp = self.eval_x_reconstruction(x2p, *[t_[x2idx] for t_ in res2[key][:2]])
                 for k, v in rp.items():
                     perf[tag + k] = v
             q1, q2 = res2['z1'][x2idx].double(), res2['z2'][x2idx].double()

@@ -307,6 +307,14 @@ def nll_rows_fwdbwd(out, dmu, dsd, coef, x, mu, sd, *, mode=GAUSS_SIGMA, xidx=No
                'dv_gauss_nll_rows_fwdbwd')
 
 
+def rec_nll_rows(out, x, v, *, kind, shift=0.0, xidx=None, coef=None, dpre=None):
+    """log-likelihood rows of the Bernoulli ('binary') / Poisson decoders from the head's post-activation output
+    ``v``; with ``coef`` also the gradient w.r.t. the head's pre-activation (``dv_rec_nll_rows``)"""
+    M, X = v.shape
+    _lib.check(_lib.load().dv_rec_nll_rows(_lib.REC_KIND[kind], shift, _f32(coef), _f32(x), _ld(x), _i32(xidx), _f32(v),
+                                           _ld(v), M, X, _f32(out), _f32(dpre), _ld(dpre), _stream()), 'dv_rec_nll_rows')
+
+
 def nll_rows_bwd(dmu, dsd, coef, x, mu, sd, *, mode=GAUSS_SIGMA, xidx=None, sd_act=0, sd_shift=0.0, dx=None,
                  beta=0.0):
     M, X = mu.shape

@@ -162,7 +162,7 @@ class _Plan:
                 self.DZMMD = zf(self.o3, Z1)
                 self.MMDval = zf(1)
         self.DQ = zf(Me, 2 * Z1)
-        self.DPX = mat(Md, 2 * X)
+        self.DPX = mat(Md, 2 * X if cfg.type_rec == 'diag_gaussian' else X)
         self.NLL = zf(Md)
         # per-tile partial sums of the reconstruction rows when they come out of the decoder-heads launch itself
         # (dv_gemm_heads, DV_HEADS_NLL): row r's log-likelihood = NLLP[r].sum()

@@ -285,6 +285,17 @@ int dv_gauss_nll_rows_bwd(const float* coef, const float* x, int64_t ldx, const 
                           float sd_shift, float* dmu, float* dsd, int64_t ldd, float* dx, int64_t lddx, float beta,
                           dv_stream_t stream);
 
+/* EXTENSION: log-likelihood rows of the Bernoulli / Poisson data decoders that src/DrVAE.py:124-129
+ * names (`type_rec='binary'` / `'poisson'`; the reference ships neither class).  v = the head's post-activation output
+ * (probability = sigmoid(a), or rate = softplus(a) + shift); x row = xidx ? xidx[r] : r.
+ *   out[r] = sum_g log p(x[.,g] | v[r,g]);  coef != NULL: dpre[r,g] = coef[r] * d log p / d a  (a = pre-activation)
+ *   BERNOULLI: pc = clamp(v, 1e-10, 1 - 1e-10); log p = x log pc + (1-x) log(1-pc); d/da = x - v inside the clamp, else 0
+ *   POISSON  : log p = x log v - v - lgamma(x+1);  d/da = (x/v - 1) (1 - exp(-(v - shift))) */
+enum { DV_REC_BERNOULLI = 0, DV_REC_POISSON = 1 };
+int dv_rec_nll_rows(int32_t kind, float shift, const float* coef, const float* x, int64_t ldx, const int32_t* xidx,
+                    const float* v, int64_t ldv, int32_t M, int32_t X, float* out, float* dpre, int64_t ldd,
+                    dv_stream_t stream);
+
 /* forward + backward in one row pass (the loss is linear in the row terms with coefficients
  * known up front): out[r] as _fwd, dmu/dsd[r,:] = coef[r] * d out[r]/d(mu, pre-activation of sd). */
 int dv_gauss_nll_rows_fwdbwd(const float* coef, const float* x, int64_t ldx, const int32_t* xidx, const float* mu,

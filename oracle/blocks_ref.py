@@ -179,6 +179,31 @@ def diag_gaussian_sigma(inputs, p, prefix, n_hidden, nonlin, constrain_means=Fal
     return mu, std
 
 
+# EXTENSION (SURVEY 8(f) N4): the data decoders src/DrVAE.py:124-129 names but src/blocks.py never defines.  Same
+# anatomy as CategoricalDecoder (MLP trunk ``nnet`` + one Linear head + activation, a 1-element list returned):
+def bernoulli(inputs, p, prefix, n_hidden, nonlin):
+    """[clamp(sigmoid(linear_p(h)), 1e-10, 1-1e-10)] -- the probability clamp of blocks.py:463"""
+    h = mlp(inputs, p, prefix + '.nnet', n_hidden, nonlin)
+    return [torch.clamp(torch.sigmoid(linear(h, p, prefix + '.decoder_p.linear_p')), min=1e-10, max=1. - 1e-10)]
+
+
+def bernoulli_logp_rows(x, ps):
+    return (x * torch.log(ps) + (1. - x) * torch.log(1. - ps)).sum(1)
+
+
+POISSON_RATE_SHIFT = 1e-6
+
+
+def poisson(inputs, p, prefix, n_hidden, nonlin):
+    """[softplus(linear_r(h)) + 1e-6]: strictly positive rates"""
+    h = mlp(inputs, p, prefix + '.nnet', n_hidden, nonlin)
+    return [F.softplus(linear(h, p, prefix + '.decoder_r.linear_r')) + POISSON_RATE_SHIFT]
+
+
+def poisson_logp_rows(x, rate):
+    return (x * torch.log(rate) - rate - torch.lgamma(x + 1.)).sum(1)
+
+
 def categorical(inputs, p, prefix, n_hidden, nonlin, reconstruction_dim):
     """CategoricalDecoder.forward, blocks.py:456-463 -> clamped class probabilities."""
     h = mlp(inputs, p, prefix + '.nnet', n_hidden, nonlin)

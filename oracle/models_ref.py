@@ -61,6 +61,7 @@ class ModelSpec:
     # what the code evidently intends: one_hot(s) appended to the inputs of encoder_z1 and decoder_x
     # (DrVAE.py:134-135,179-180,400-402,436-438) and, with use_MMD, minus the MMD between the latent samples of
     # each nuisance class and the rest, per data group and Monte-Carlo sample (DrVAE.py:394-398,537-540,616,623-624)
+    type_rec: str = 'diag_gaussian'     # | 'binary' | 'poisson': decoders named at DrVAE.py:124-129, absent from blocks.py
     use_s: bool = False
     dim_s: int = 2
     use_MMD: bool = False
@@ -111,7 +112,11 @@ def param_shapes(spec):
             lin('encoder_y.decoder_p.linear_p', n, 1 if spec.clf_1sig else Y)
         gauss(spec.top_name, Z1 + Y, spec.h_en_z3, Z3)
         gauss('decoder_z1', Z3 + Y, spec.h_de_z1, Z1)
-    gauss('decoder_x', Z1 + S, spec.h_de_x, X, second='sg')
+    if spec.type_rec == 'diag_gaussian':
+        gauss('decoder_x', Z1 + S, spec.h_de_x, X, second='sg')
+    else:
+        n = mlp('decoder_x.nnet', Z1 + S, spec.h_de_x)
+        lin('decoder_x.decoder_p.linear_p' if spec.type_rec == 'binary' else 'decoder_x.decoder_r.linear_r', n, X)
     return out
 
 
@@ -182,6 +187,10 @@ def make_batch(spec, n_rows, seed=1234, group_mod=None):
     else:
         has_y = (i % 2 == 0)
         has_x2 = np.zeros(n_rows, bool)
+    if spec.type_rec == 'binary':        # 0/1 data for the Bernoulli decoder, counts for the Poisson decoder
+        x1, x2 = (x1 > 0).astype(np.float32), (x2 > 0.3).astype(np.float32)
+    elif spec.type_rec == 'poisson':
+        x1, x2 = np.floor(np.abs(3 * x1)).astype(np.float32), np.floor(np.abs(3 * x2)).astype(np.float32)
     x2 = x2 * has_x2[:, None].astype(np.float32)
     s = rs.randint(0, spec.dim_s, (n_rows, 1)).astype(np.int64) if spec.use_s else np.zeros((n_rows, 1), np.int64)
     return {'x1': x1, 'x2': x2, 's': s, 'y': y,
@@ -233,6 +242,14 @@ def _group_losses(spec, p, acc, idx, x1, x2, y, noise, iters, training, s=None):
     x1 = x1.clone()
     if training and spec.add_noise_var > 0.:          # DrVAE.py:404-407 (N(0,1) * add_noise_var, in place)
         x1 = x1 + nz('nx1') * spec.add_noise_var
+    def rec_logp(zin, x):
+        """log p(x|z) rows of the data decoder (DrVAE.py:441-442)"""
+        if spec.type_rec == 'binary':
+            return B.bernoulli_logp_rows(x, *B.bernoulli(zin, p, 'decoder_x', nhx, spec.nonlin))
+        if spec.type_rec == 'poisson':
+            return B.poisson_logp_rows(x, *B.poisson(zin, p, 'decoder_x', nhx, spec.nonlin))
+        return B.logp_sigma_rows(x, *B.diag_gaussian_sigma(zin, p, 'decoder_x', nhx, spec.nonlin))
+
     cond = []
     if spec.use_s:                                    # one_hot(s) conditions encoder_z1 and decoder_x (extension)
         cond = [B.one_hot(s, spec.dim_s)]
@@ -255,8 +272,7 @@ def _group_losses(spec, p, acc, idx, x1, x2, y, noise, iters, training, s=None):
             pz2F = B.diag_gaussian_linear([z1], p, 'decoder_z2Fz1')
             z2F = B.sample_logvar(pz2F[0], pz2F[1], nz('ez2F', l))
 
-        px1 = B.diag_gaussian_sigma([z1] + cond, p, 'decoder_x', nhx, spec.nonlin)
-        acc.add('RECL', idx, B.logp_sigma_rows(x1, *px1), 1. / Lf)        # DrVAE.py:441-442
+        acc.add('RECL', idx, rec_logp([z1] + cond, x1), 1. / Lf)          # DrVAE.py:441-442
         if spec.use_s and spec.use_MMD:                                    # DrVAE.py:537-540
             acc.sums['MMD'] = acc.sums['MMD'] + B.mmd_criterion(z1, sind, spec.kernel_MMD) / Lf
             if pair and has_pert:
@@ -266,10 +282,8 @@ def _group_losses(spec, p, acc, idx, x1, x2, y, noise, iters, training, s=None):
             acc.add('KLD', idx, B.free_bits(B.kl_logvar_prior_rows(*qz1), spec.kl_min), 1. / Lf)
 
         if pair and has_pert:
-            px2 = B.diag_gaussian_sigma([z2] + cond, p, 'decoder_x', nhx, spec.nonlin)
-            acc.add('RECL', idx, B.logp_sigma_rows(x2, *px2), 1. / Lf)    # DrVAE.py:451-452
-            px2p = B.diag_gaussian_sigma([z2F] + cond, p, 'decoder_x', nhx, spec.nonlin)
-            acc.add('PERT', idx, B.logp_sigma_rows(x2, *px2p), 1. / Lf)   # DrVAE.py:459-460
+            acc.add('RECL', idx, rec_logp([z2] + cond, x2), 1. / Lf)      # DrVAE.py:451-452
+            acc.add('PERT', idx, rec_logp([z2F] + cond, x2), 1. / Lf)     # DrVAE.py:459-460
             if spec.kind == 'pvae':                                        # PVAE.py:363-372
                 acc.add('KLD', idx, B.free_bits(B.kl_logvar_prior_rows(*qz2), spec.kl_min), 1. / Lf)
             klz2 = B.free_bits(B.kl_logvar_rows(qz2[0], qz2[1], pz2F[0], pz2F[1]), spec.kl_min)

@@ -10,6 +10,8 @@ Two uses, both test-only:
 """
 import math
 
+import numpy as np
+
 import torch
 import torch.nn.functional as F
 
@@ -372,6 +374,20 @@ def nll_rows_bwd(dmu, dsd, coef, x, mu, sd, *, mode=GAUSS_SIGMA, xidx=None, sd_a
     _acc(dsd, c * gs, beta)
     if dx is not None:
         _acc(dx, -c * gm, beta)
+
+
+def rec_nll_rows(out, x, v, *, kind, shift=0.0, xidx=None, coef=None, dpre=None):
+    xs = x[xidx.long()] if xidx is not None else x
+    if kind == 'binary':
+        lo, hi = 1e-10, float(np.float32(1.0 - 1e-10))
+        pc = v.clamp(lo, hi)
+        out.copy_((xs * pc.log() + (1 - xs) * (1 - pc).log()).sum(1))
+        g = torch.where((v > lo) & (v < hi), xs - v, torch.zeros_like(v))
+    else:
+        out.copy_((xs * v.log() - v - torch.lgamma(xs + 1)).sum(1))
+        g = (xs / v - 1) * (1 - torch.exp(-(v - shift)))
+    if coef is not None:
+        dpre.copy_(coef[:, None] * g)
 
 
 def nll_rows_fwdbwd(out, dmu, dsd, coef, x, mu, sd, *, mode=GAUSS_SIGMA, xidx=None, sd_act=0, sd_shift=0.0):
@@ -744,7 +760,7 @@ def fill_normal(out, seed, ctr_dev=None):
     out.copy_(torch.randn(out.shape, generator=g).to(out.device))
 
 
-FUNCTIONS = ['batch_masks', 'fill_normal_rows', 'linear_heads', 'heads_tiles', 'adamax_l2', 'batch_feed', 'mmd_rff_fwd', 'mmd_rff_bwd', 'counters_add2', 'ycont_fwd', 'ycont_bwd', 'flag_publish', 'flag_wait', 'gemm', 'linear_fwd', 'linear_bwd_data', 'linear_bwd_weight', 'linear_bwd_pair', 'colsum', 'act_bwd_', 'wn_scale', 'wn_bwd',
+FUNCTIONS = ['rec_nll_rows', 'batch_masks', 'fill_normal_rows', 'linear_heads', 'heads_tiles', 'adamax_l2', 'batch_feed', 'mmd_rff_fwd', 'mmd_rff_bwd', 'counters_add2', 'ycont_fwd', 'ycont_bwd', 'flag_publish', 'flag_wait', 'gemm', 'linear_fwd', 'linear_bwd_data', 'linear_bwd_weight', 'linear_bwd_pair', 'colsum', 'act_bwd_', 'wn_scale', 'wn_bwd',
              'reparam_fwd', 'reparam_bwd', 'reparam_bwd_seg', 'z2f_post_bwd', 'kl_rows_fwd', 'kl_rows_bwd', 'nll_rows_fwd', 'nll_rows_bwd', 'nll_rows_fwdbwd',
              'softmax_clamp_fwd', 'softmax_clamp_bwd', 'cat_terms_fwd', 'cat_terms_bwd', 'smalln_fwd', 'smalln_bwd_data',
              'smalln_bwd_weight', 'ymarg_fwd', 'ymarg_bwd', 'ymarg_fwdbwd',

@@ -204,3 +204,40 @@ def test_use_s_extension_matches_oracle(kind, use_mmd, monkeypatch):
             close(v, float(want[k]), 2e-5, 2e-6)
     for k, prm in tr.params.items():
         close(arena.p(k), prm.detach().numpy(), 1e-4, 2e-5)
+
+
+@pytest.mark.parametrize('type_rec', ['binary', 'poisson'])
+@pytest.mark.parametrize('kind', ['drvae', 'pvae', 'vfae'])
+def test_bernoulli_poisson_decoders_match_oracle(kind, type_rec, monkeypatch):
+    """N4 (extension: src/DrVAE.py:124-129 names BernoulliDecoder / PoissonDecoder, src/blocks.py defines neither):
+    the single-head data decoders in the fused step against the oracle's maths -- losses, gradients, 3 Adam steps"""
+    kernel_ref.install(monkeypatch)
+    spec = C.tiny_spec(kind, type_rec=type_rec, add_noise_var=0.0)
+    batch = M.make_batch(spec, 16, seed=3)
+    assert set(np.unique(batch['x1'])) <= {0.0, 1.0} if type_rec == 'binary' else batch['x1'].max() > 1
+    params = M.init_params(spec, 9, as_numpy=True)
+    head = 'decoder_x.decoder_p.linear_p.weight' if type_rec == 'binary' else 'decoder_x.decoder_r.linear_r.weight'
+    assert head in params and 'decoder_x.encoder_mu.linear_mu.weight' not in params
+    eng, arena = make_engine(spec, params)
+    tr = M.RefTrainer(spec, M.init_params(spec, 9))
+    set_batch(eng, batch)
+    noise = M.make_noise(spec, 16, seed=4)
+    ref, _ = tr.loss(batch, noise, True)
+    ref['CMPL'].backward()
+    eng.training = True
+    eng.set_noise(noise)
+    eng.forward()
+    eng.backward()
+    for k, v in eng.losses().items():
+        close(v, float(ref[k].detach()), 2e-5, 2e-6)
+    for k, prm in tr.params.items():
+        close(arena.g(k), prm.grad.numpy(), 3e-4, 2e-6)
+        prm.grad = None
+    for step in range(3):
+        nz = M.make_noise(spec, 16, seed=10 + step)
+        want, _ = tr.step(batch, nz)
+        eng.train_step(nz)
+        for k, v in eng.losses().items():
+            close(v, float(want[k].detach()), 2e-5, 2e-6)
+    for k, prm in tr.params.items():
+        close(arena.p(k), prm.detach().numpy(), 1e-4, 2e-5)

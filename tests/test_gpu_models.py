@@ -492,3 +492,71 @@ def test_use_s_model_api_with_fourier_mmd(dev):
     assert tuple(res['x1_rec'].shape) == (48, spec.dim_x) and bool(torch.isfinite(res['x1_rec']).all())
     ev = model.run_on_batch(train_mode=False, **kw)
     assert np.isfinite(float(ev['MMD']))
+
+
+@pytest.mark.parametrize('type_rec', ['binary', 'poisson'])
+@pytest.mark.parametrize('kind', ['drvae', 'vfae'])
+def test_bernoulli_poisson_decoders_gpu(kind, type_rec, dev):
+    """N4 extension on the real kernels (dv_rec_nll_rows + single-head decoder GEMMs): losses, gradients and Adam
+    steps vs the oracle, the captured step, and the model class through its reference-style API"""
+    import drvae_amd.kernels as K
+    from tests import kernel_ref as R
+    from tests.test_engine_cpu import make_engine, set_batch
+    # kernel vs its reference, odd sizes, gathered x rows
+    g = torch.Generator().manual_seed(1)
+    M_, X_ = 37, 101
+    a = torch.randn(M_, X_, generator=g).to(dev) * 3
+    v = torch.sigmoid(a) if type_rec == 'binary' else torch.nn.functional.softplus(a) + 1e-6
+    xs = ((torch.rand(20, X_, generator=g) > 0.5).float() if type_rec == 'binary' else
+          torch.poisson(torch.rand(20, X_, generator=g) * 4)).to(dev)
+    xi = torch.randint(0, 20, (M_,), generator=g).to(torch.int32).to(dev)
+    coef = torch.randn(M_, generator=g).to(dev)
+    outs = []
+    for L_ in (K, R):
+        o, d = torch.zeros(M_, device=dev), torch.zeros(M_, X_, device=dev)
+        L_.rec_nll_rows(o, xs, v, kind=type_rec, shift=1e-6 if type_rec == 'poisson' else 0.0, xidx=xi, coef=coef, dpre=d)
+        outs.append((o, d))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(outs[0][0].cpu().numpy(), outs[1][0].cpu().numpy(), rtol=2e-5, atol=1e-3)
+    np.testing.assert_allclose(outs[0][1].cpu().numpy(), outs[1][1].cpu().numpy(), rtol=2e-4, atol=1e-5)
+    # fused step vs oracle
+    spec = C.tiny_spec(kind, type_rec=type_rec, add_noise_var=0.0)
+    batch = M.make_batch(spec, 16, seed=3)
+    eng, arena = make_engine(spec, M.init_params(spec, 9, as_numpy=True), dev)
+    tr = M.RefTrainer(spec, M.init_params(spec, 9))
+    set_batch(eng, batch, dev)
+    for step in range(3):
+        nz = M.make_noise(spec, 16, seed=10 + step)
+        want, _ = tr.step(batch, nz)
+        eng.train_step(nz)
+        for k, val in eng.losses().items():
+            np.testing.assert_allclose(val, float(want[k].detach()), rtol=1e-4, atol=2e-5)
+    for k, prm in tr.params.items():
+        np.testing.assert_allclose(arena.p(k).cpu().numpy(), prm.detach().numpy(), rtol=2e-4, atol=5e-5)
+    eng.capture()
+    eng.replay()
+    torch.cuda.synchronize()
+    assert all(np.isfinite(val) for val in eng.losses().values())
+    # model class
+    spec2 = C.tiny_spec(kind, type_rec=type_rec)
+    model = build_model(spec2, dev) if False else None
+    from drvae_amd.DrVAE import DrVAE
+    from drvae_amd.VFAE import VFAE
+    common = dict(dim_x=spec.dim_x, dim_s=1, dim_y=2, dim_h_en_z1=[7], dim_h_de_z1=[6], dim_h_de_x=[8], dim_h_clf=[],
+                  dim_z1=5, type_rec=type_rec, nonlinearity='elu', learning_rate=5e-3, L=2, weight_decay=0.05,
+                  use_MMD=False, random_seed=1, device=dev)
+    model = DrVAE(dim_h_en_z3=[6], dim_z3=4, pertloss_rate=0.05, **common) if kind == 'drvae' else \
+        VFAE(dim_h_en_z2=[6], dim_z2=4, **common)
+    assert type(model.decoder_x).__name__ == ('BernoulliDecoder' if type_rec == 'binary' else 'PoissonDecoder')
+    t = lambda k: torch.from_numpy(batch[k].copy()).to(dev)
+    kw = dict(x1=t('x1'), s=t('s'), y=t('y'), has_y=t('has_y'))
+    if kind == 'drvae':
+        kw.update(x2=t('x2'), has_x2=t('has_x2'))
+    l0 = float(model.run_on_batch(train_mode=True, **kw)['CMPL'])
+    for _ in range(40):
+        l1 = float(model.run_on_batch(train_mode=True, **kw)['CMPL'])
+    assert np.isfinite(l1) and l1 < l0
+    res = model.forward(t('x1'))
+    assert tuple(res['x1_rec'].shape) == (16, spec.dim_x) and len(res['px1']) == 1
+    lp = model.decoder_x.logp_perx(t('x1'), *res['px1'])
+    assert tuple(lp.shape) == (16,) and bool(torch.isfinite(lp).all())
