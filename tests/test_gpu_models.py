@@ -164,7 +164,7 @@ def test_checkpoint_roundtrip_and_errors(dev, tmp_path):
         assert torch.equal(a, b), k
     from drvae_amd.DrVAE import DrVAE
     with pytest.raises(ValueError):
-        DrVAE(dim_x=5, dim_s=1, dim_y=2, type_rec='binary', device=dev)       # src/DrVAE.py:124-131
+        DrVAE(dim_x=5, dim_s=1, dim_y=2, type_rec='laplace', device=dev)      # src/DrVAE.py:124-131 ('binary' / 'poisson': extensions)
     with pytest.raises(ValueError):
         DrVAE(dim_x=5, dim_s=1, dim_y=2, type_rec='diag_gaussian', optim_alg='sgd', device=dev)
 
