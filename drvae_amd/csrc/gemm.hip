@@ -331,7 +331,9 @@ __device__ __forceinline__ void gemm_body(const dv_gemm_desc& g, const LoadCfg& 
     const int a_c = tid % A_CPL, a_l = tid / A_CPL;
     const int b_c = tid % B_CPL, b_l = tid / B_CPL;
     // fused bias gradient: the first column-tile of every row-panel sums its A tiles over k
-    const bool do_colsum = !AKC && g.a_colsum != nullptr && n0 == 0;
+    // (not in the 128x128 tiling: its dy^T x variant sits at the 256-register limit and the four extra registers
+    // spilled; there the dispatcher runs dv_colsum as a launch of its own, noise next to a product of that size)
+    const bool do_colsum = BM < 128 && !AKC && g.a_colsum != nullptr && n0 == 0;
     float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
 
     const Operand oa{g.A, g.lda, AKC ? g.M : g.K, AKC ? g.K : g.M};
@@ -790,6 +792,108 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 16) ? 4 : (BM >
     gemm_body<BM, BN, BK, WM, WN, KS, AKC, BKC>(g, lc, smem, blockIdx.x, gridDim.x);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// LDS-DMA variant of the 32x32 K-split tiling for the forward layout (both operands k-contiguous): the tiles go
+// global -> LDS directly (global_load_lds_dwordx4: no staging registers, no ds_write), one 1-KiB piece = 4 tile
+// rows x 256 B per wave-instruction.  The LDS image is the unpadded [32 rows][64 k] tile; the 16-B chunk c of row r
+// sits at chunk position c ^ (r & 15) -- the permutation is applied to the per-lane SOURCE address (the DMA writes
+// lane-linearly) and again when the fragments are read, which makes the ds_read_b128 fragment reads conflict-free.
+// Double buffer, one barrier per K tile: [wait own pieces of tile t] [barrier] [issue tile t+1] [MFMA on tile t].
+// Requires K % 4 == 0 and 16-B aligned rows (else the register-staged kernel runs).
+template <int KS>
+__global__ __launch_bounds__(64 * KS, KS == 8 ? 2 : 4) void gemm_dma_kernel(const dv_gemm_desc g, const LoadCfg lc) {
+    constexpr int BM = 32, BN = 32, BK = 64, NT = 64 * KS, KW = BK / KS, KH = KW / 2;
+    constexpr int TILE = 32 * BK, STAGE = 2 * TILE, RED = KS * BM * (BN + 1);
+    constexpr int PIECES = 16 / KS;                     // 1-KiB pieces per wave per K tile (8 of A, then 8 of B)
+    constexpr int NBUF = 3;      // two K tiles in flight behind the one being multiplied
+    __shared__ __attribute__((aligned(16))) float smem[NBUF * STAGE > RED ? NBUF * STAGE : RED];
+    publish_on_entry(g);
+    const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
+    int tm, tn;
+    tile_of_block(blockIdx.x, gridDim.x, tiles_m, tiles_n, lc.map, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+
+    // this wave's pieces: piece q in [0,16): operand = q / 8, rows 4*(q%8) .. +3
+    const float* src[PIECES];
+    int kofs[PIECES];          // k offset (floats) of this lane's chunk inside a K tile
+    int dst[PIECES];           // float offset of the piece inside a stage
+#pragma unroll
+    for (int i = 0; i < PIECES; ++i) {
+        const int q = wave + i * KS, o = q >> 3, row = 4 * (q & 7) + (lane >> 4), p = lane & 15;
+        const int c = p ^ (row & 15);
+        int line = (o == 0 ? m0 : n0) + row;
+        const int lim = o == 0 ? g.M : g.N;
+        line = line < lim ? line : lim - 1;
+        src[i] = (o == 0 ? g.A + (int64_t)line * g.lda : g.B + (int64_t)line * g.ldb) + c * 4;
+        kofs[i] = c * 4;
+        dst[i] = o * TILE + (q & 7) * 256;
+    }
+    auto issue = [&](int kt, float* stage) {
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) {
+            const float* p = (kt * BK + kofs[i] < g.K) ? src[i] + (int64_t)kt * BK : dv_zero_chunk;
+            __builtin_amdgcn_global_load_lds(p, (__attribute__((address_space(3))) float*)(stage + dst[i]), 16, 0, 0);
+        }
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int kb = wave * KW + lh * KH;
+    const int nkt = (g.K + BK - 1) / BK;
+    issue(0, smem);
+    if (nkt > 1) issue(1, smem + STAGE);
+    int bi = 0;
+    for (int kt = 0; kt < nkt; ++kt) {
+        float* cur = smem + bi * STAGE;
+        // this wave's pieces of tile kt have landed (the pieces of tile kt+1 may still be in flight: counted wait);
+        // raw barrier -- __syncthreads() would drain the DMA queue (vmcnt(0)) -- then everyone's pieces have landed
+        // and everyone is done reading tile kt-1, whose buffer the issue below overwrites
+        if (kt + 1 < nkt) {
+            if (PIECES == 2)
+                asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        asm volatile("s_barrier" ::: "memory");
+        int bn = bi + 2;
+        bn = bn >= NBUF ? bn - NBUF : bn;
+        if (kt + 2 < nkt) issue(kt + 2, smem + bn * STAGE);
+        bi = bi + 1 == NBUF ? 0 : bi + 1;
+        float fa[KH], fb[KH];
+#pragma unroll
+        for (int s = 0; s < KH; s += 4) {
+            const int pc = (((kb + s) >> 2) ^ (li & 15)) << 2;
+            const float4 va = *reinterpret_cast<const float4*>(&cur[li * BK + pc]);
+            const float4 vb = *reinterpret_cast<const float4*>(&cur[TILE + li * BK + pc]);
+            fa[s] = va.x; fa[s + 1] = va.y; fa[s + 2] = va.z; fa[s + 3] = va.w;
+            fb[s] = vb.x; fb[s + 1] = vb.y; fb[s + 2] = vb.z; fb[s + 3] = vb.w;
+        }
+#pragma unroll
+        for (int s = 0; s < KH; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s], fb[s], acc, 0, 0, 0);
+    }
+    __syncthreads();
+    float* red = smem;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[(wave * BM + (r & 3) + 8 * (r >> 2) + 4 * lh) * (BN + 1) + li] = acc[r];
+    __syncthreads();
+    constexpr int RPT = BM / (NT / BN);
+    const int col = tid % BN, r0 = (tid / BN) * RPT;
+    float a4[RPT];
+#pragma unroll
+    for (int e = 0; e < RPT; ++e) {
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < KS; ++w) v += red[(w * BM + r0 + e) * (BN + 1) + col];
+        a4[e] = v;
+    }
+    const int rbase = m0 + r0;
+    epi_store_col<RPT>(g, a4, n0 + col, [rbase](int r) { return rbase + r; });
+}
+
 template <int BM, int BN, int BK, int KS>
 __global__ __launch_bounds__(64 * KS, KS == 8 ? 2 : 4) void gemm_heads_kernel(const dv_gemm_desc g, const LoadCfg lc,
                                                                const dv_heads_epi he) {
@@ -903,7 +1007,13 @@ static int gemm_prepare(const dv_gemm_desc* d, LoadCfg& lc, int& tiling) {
 
 static int gemm_launch(const dv_gemm_desc& g, const LoadCfg& lc, int tiling, hipStream_t st) {
     if (tiling < 0) return DV_OK;
-    if (tiling == 3) return launch_cfg<128, 128, 32, 2, 2, 1>(g, lc, st);
+    if (tiling == 3) {
+        if (g.a_colsum != nullptr && !g.a_kcontig) {     // fused bias gradient: see do_colsum
+            const int rc = dv_colsum(g.A, g.lda, g.K, g.M, g.a_colsum, g.colsum_beta, st);
+            if (rc != DV_OK) return rc;
+        }
+        return launch_cfg<128, 128, 32, 2, 2, 1>(g, lc, st);
+    }
     if (tiling == 4) return launch_cfg<32, 32, 128, 1, 1, 4>(g, lc, st);
     if (tiling == 5) return launch_cfg<64, 64, 64, 2, 2, 2>(g, lc, st);   // 8 waves: 2 per SIMD
     if (tiling == 6) return launch_cfg<64, 32, 64, 2, 1, 2>(g, lc, st);   // 2 row blocks x 2-way K split
@@ -911,6 +1021,19 @@ static int gemm_launch(const dv_gemm_desc& g, const LoadCfg& lc, int tiling, hip
     if (tiling == 8) return launch_cfg<32, 32, 128, 1, 1, 8>(g, lc, st);   // 8-way K split: twice the waves, half the chain
     if (tiling == 9) return launch_cfg<32, 32, 64, 1, 1, 8>(g, lc, st);
     if (tiling == 10) return launch_cfg<32, 32, 128, 1, 1, 16>(g, lc, st);
+    if (tiling == 11 || tiling == 12) {   // LDS-DMA staging (forward layout, 16-B aligned rows, K % 4 == 0)
+        const bool ok = g.a_kcontig && g.b_kcontig && g.A2 == nullptr && g.a_kscale == nullptr && (g.K & 3) == 0 &&
+                        lc.vecA == 4 && lc.vecB == 4;
+        if (ok) {
+            const int tiles = ((g.M + 31) / 32) * ((g.N + 31) / 32);
+            if (tiling == 11)
+                hipLaunchKernelGGL((gemm_dma_kernel<8>), dim3(tiles), dim3(512), 0, st, g, lc);
+            else
+                hipLaunchKernelGGL((gemm_dma_kernel<4>), dim3(tiles), dim3(256), 0, st, g, lc);
+            DV_RETURN_LAUNCH();
+        }
+        return launch_cfg<32, 32, 64, 1, 1, 8>(g, lc, st);
+    }
     if (tiling == 1) return launch_cfg<64, 64, 32, 2, 2, 1>(g, lc, st);
     // 32x32 K-split tiling: the k-contiguous-A layouts (x W^T, dy W) run with EIGHT waves splitting each 64-deep K
     // tile (half the MFMA chain per wave, twice the waves to overlap its latency: 4-10 % faster on every cfg-2
