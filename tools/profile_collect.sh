@@ -19,8 +19,8 @@ cp $(find $O/kw -name '*kernel_stats.csv' | head -1) $O/wide_kernel_stats.csv
 rm -rf $O/kw
 unset DRVAE_SIDE_CUS
 bash tools/pmc_collect.sh > $O/pmc.log 2>&1
-python3 tools/pmc_summary.py gpurun_out/pmc_r1 > $O/cfg2_pmc_summary.txt 2>&1
-rm -rf gpurun_out/pmc_r1
+python3 tools/pmc_summary.py gpurun_out/pmc_rr > $O/cfg2_pmc_summary.txt 2>&1
+rm -rf gpurun_out/pmc_rr
 # every figure of bench.py's roofline block that a profiler has to supply, derived from the files above
 python3 tools/roofline_from_profile.py $O/cfg2 --out $O/cfg2_roofline.json > /dev/null 2>&1
 ls -la $O
