@@ -375,6 +375,8 @@ def main():
     _lib.load()                                       # fail loudly if the HIP library is missing
     if os.environ.get('DRVAE_GEMM_MAP'):              # tuning: workgroup->tile map (0 linear, 1 XCD chunk-major)
         _lib.load().dv_gemm_set_option(0, int(os.environ['DRVAE_GEMM_MAP']))
+    if os.environ.get('DRVAE_LDS_PAD'):               # tuning: extra dynamic LDS of the chip-filling 32x32-tile GEMM launches
+        _lib.load().dv_gemm_set_option(1, int(os.environ['DRVAE_LDS_PAD']))
     if os.environ.get('DRVAE_T64_MIN'):               # tuning: 64x64-tile threshold of the GEMM heuristic
         _lib.load().dv_gemm_set_option(3, int(os.environ['DRVAE_T64_MIN']))
     if not torch.cuda.is_available():
@@ -396,6 +398,7 @@ def main():
     # iteration 0 runs eagerly (beta_pert = 0.01 only there), then the steady-state step is captured
     eng.train_step(allreduce=allreduce)
     use_graph = not args.no_graph
+    dp_mode = None
     bat = None
     if args.feed != 'resident':
         from drvae_amd import data as DD, synth
@@ -419,7 +422,18 @@ def main():
         # one exchange between two graphs by default; DRVAE_DP_OVERLAP=1: two overlapped pieces between three
         # graphs (measured with a one-rank RCCL communicator: +49 us of launch/event overhead per step against +24 us)
         overlap = dp and os.environ.get('DRVAE_DP_OVERLAP', '0') == '1'
-        eng.capture(split_for_allreduce=('overlap' if overlap else dp))
+        dp_mode = 'overlap' if overlap else dp
+        if dp and not overlap and os.environ.get('DRVAE_DP_CAPTURE', '0') == '1':
+            # the exchange captured into the step's graph (needs stream-capturable RCCL: probed here, with the
+            # split graphs as the fallback)
+            try:
+                eng.capture(split_for_allreduce='captured', allreduce=D.allreduce_sum)
+                allreduce, dp_mode = None, 'captured'
+            except Exception as e:       # noqa: BLE001
+                print('bench.py: RCCL capture unavailable (%s); split graphs' % e, file=sys.stderr)
+                dp_mode = dp
+        if dp_mode != 'captured':
+            eng.capture(split_for_allreduce=dp_mode)
         if overlap and len(eng._graphs) == 3:
             allreduce = D.OverlappedAllReduce()      # decoder block travels while the encoder backward runs
         if args.feed == 'batcher':
@@ -487,6 +501,7 @@ def main():
                    'parallelism': 'dp%d' % world, 'launch': 'hipGraph replay' if use_graph else 'eager', 'feed': args.feed,
                    'side_chain_cus': getattr(eng, '_side_cus', None),
                    'dist_backend': (dist.get_backend() if dist.is_initialized() else None),
+                   'dp_exchange': (dp_mode if dp else None),
                    'rccl_ranks': (dist.get_world_size() if dist.is_initialized() and dist.get_backend() == 'nccl'
                                   else 0),
                    'params': int(sum(int(np.prod(s)) for s in arena.shapes.values()))},
@@ -507,6 +522,10 @@ def main():
     if world > 1:
         dist.barrier()
     if rank == 0:
+        try:        # RCCL writes a version banner through C stdio: flush it out FIRST, the JSON line stays the last one
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
         print(json.dumps(out), flush=True)
     if world > 1 or (dp and dist.is_initialized()):
         dist.destroy_process_group()

@@ -924,16 +924,22 @@ inline int vec_width(const void* p, int64_t ld) {
     return 1;
 }
 
+// tuning (dv_gemm_set_option(1, bytes)): extra dynamic LDS per workgroup of the 32x32-tile launches whose grids
+// fill the chip -- caps how many of them a CU holds, which leaves wave slots / registers on EVERY CU for the other
+// launch chain's small kernels (an alternative to the CU partition of the two chains)
+static int g_lds_pad = 0;
+inline int lds_pad(int bm, int tiles) { return (bm <= 32 && tiles >= 512) ? g_lds_pad : 0; }
+
 template <int BM, int BN, int BK, int WM, int WN, int KS>
 int launch_cfg(const dv_gemm_desc& g, const LoadCfg& lc, hipStream_t st) {
     const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
     dim3 grid(tiles), block(64 * WM * WN * KS);
     if (g.a_kcontig && g.b_kcontig)
-        hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, WM, WN, KS, true, true>), grid, block, 0, st, g, lc);
+        hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, WM, WN, KS, true, true>), grid, block, lds_pad(BM, tiles), st, g, lc);
     else if (g.a_kcontig && !g.b_kcontig)
-        hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, WM, WN, KS, true, false>), grid, block, 0, st, g, lc);
+        hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, WM, WN, KS, true, false>), grid, block, lds_pad(BM, tiles), st, g, lc);
     else if (!g.a_kcontig && !g.b_kcontig)
-        hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, WM, WN, KS, false, false>), grid, block, 0, st, g, lc);
+        hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, WM, WN, KS, false, false>), grid, block, lds_pad(BM, tiles), st, g, lc);
     else
         return DV_ERR_UNSUPPORTED;
     DV_RETURN_LAUNCH();
@@ -947,6 +953,7 @@ static int g_opt[8] = {-1, 0, 0, 0, 0, 0, 0, 0};  // [0] = tile map (0 linear, 1
 extern "C" int dv_gemm_set_option(int key, int value) {
     if (key < 0 || key >= 8) return DV_ERR_ARG;
     g_opt[key] = value;
+    if (key == 1) g_lds_pad = value;
 #if DV_STAMP
     if (key == 6) {
         unsigned long long* p = reinterpret_cast<unsigned long long*>(((unsigned long long)(unsigned)g_opt[6] << 32) |
@@ -1086,7 +1093,7 @@ extern "C" int dv_gemm_heads(const dv_gemm_desc* d, const dv_heads_epi* e, dv_st
         hipLaunchKernelGGL((gemm_heads_kernel<32, 32, 64, 4>), dim3(tiles), dim3(256), 0,
                            static_cast<hipStream_t>(stream), g, lc, *e);
     else   // default: the 32x32 tiling's eight-wave K split, B lines = 16 + 16 rows of the two heads
-        hipLaunchKernelGGL((gemm_heads_kernel<32, 32, 64, 8>), dim3(tiles), dim3(512), 0,
+        hipLaunchKernelGGL((gemm_heads_kernel<32, 32, 64, 8>), dim3(tiles), dim3(512), lds_pad(32, tiles),
                            static_cast<hipStream_t>(stream), g, lc, *e);
     DV_RETURN_LAUNCH();
 }

@@ -674,8 +674,13 @@ class FusedStep(StepSchedule):
         # (dual-graph schedule) the classifier's weight gradient is a leaf -- only the optimiser reads it --
         # and the side chain is the one the join waits for: it runs AFTER the side chain has published its
         # data gradients, and the optimiser launch gates that slice of the arena on a flag of its own
+        # Under data parallelism every gradient (and the loss tail) must be final before the exchange: with the plain
+        # two-graph split ``replay`` makes the launching stream wait for the side stream before the all-reduce, so the
+        # leaf work may still move behind the join (only the optimiser half cannot: it follows the exchange); the
+        # overlapped / captured exchanges keep everything in front of the join
+        split_kind = getattr(self, '_split_kind', False)
         late = (mode == 5 and self.late_leaf and cfg.has_y and not cfg.cont and self.clf_small
-                and cfg.optim_alg == 'adam' and not self._split_capture)
+                and cfg.optim_alg == 'adam' and split_kind in (False, True))
         leaf = []
         # ... and HALF of the optimiser sweep moves there too: the decoder heads (the tail of the arena, half of
         # all parameters) are final and no longer read once the heads' backward products are through -- the
@@ -683,10 +688,13 @@ class FusedStep(StepSchedule):
         heads = self.L_decx[-1]
         g0 = self.arena.grad.storage_offset()
         hs = min(heads.dW.storage_offset(), heads.db.storage_offset()) - g0
-        side_adam = (late and self.side_adam and len(self.L_decx) > 1 and heads.g is None and not self.wbranch.on
+        side_adam = (late and not split_kind and self.side_adam and len(self.L_decx) > 1 and heads.g is None and not self.wbranch.on
                      and hs % 4 == 0 and self.arena.n_live == self.arena.n_params
                      and max(heads.dW.storage_offset() + heads.dW.numel(),
                              heads.db.storage_offset() + heads.db.numel()) - g0 >= self.arena.n_live - 3)
+        # the loss scalars (a leaf: only the host / the exchange reads them) are assembled by the side chain behind
+        # the join, once the main chain has published that its reconstruction rows are final
+        side_loss = side_adam or (late and split_kind is True and len(self.L_decx) > 1 and not self.wbranch.on)
 
         def wgrad_clf(*args):
             if late:
@@ -778,11 +786,13 @@ class FusedStep(StepSchedule):
             if late:
                 for fn in leaf:
                     fn()
-                if side_adam:
+                if side_loss:
                     a = self.arena
                     K.flag_wait(self.flags[4:5], self.side_ctr, self.sync_err[8:10])
-                    K.adam_l2(a.param[hs:a.n_live], a.grad[hs:a.n_live], a.exp_avg[hs:a.n_live], a.exp_avg_sq[hs:a.n_live],
-                              self.side_t, lr=cfg.learning_rate, weight_decay=cfg.weight_decay, halt=self.sync_err)
+                    if side_adam:
+                        K.adam_l2(a.param[hs:a.n_live], a.grad[hs:a.n_live], a.exp_avg[hs:a.n_live],
+                                  a.exp_avg_sq[hs:a.n_live], self.side_t, lr=cfg.learning_rate,
+                                  weight_decay=cfg.weight_decay, halt=self.sync_err)
                     self._loss_scalars()   # a leaf too; the wait above also covers the main chain's NLL rows
                 if self.noise_ahead:
                     # the next step's N(0,1) draws: every reader of this step's is through once the encoder
@@ -798,7 +808,7 @@ class FusedStep(StepSchedule):
             self.branch._forked = True       # one fork/join per step: the side chain simply continues
         p.c_decx.backward(p.DPX, p.dec_in, [[(p.DZDEC, 1.0, 0.0)]] + [None] * (len(p.dec_in) - 1),
                           wbranch=self.wbranch if self.wbranch.on else None,
-                          publish_after_last=(self.flags[4:5], self.step_dev, 1) if side_adam else None)
+                          publish_after_last=(self.flags[4:5], self.step_dev, 1) if side_loss else None)
         if p.DZMMD is not None:
             # model-level MMD penalty (use_s extension): its gradient w.r.t. the z1 / z2 samples was computed in
             # forward() through the block-level MMD kernels (see ``_mmd_penalty``)
@@ -825,10 +835,10 @@ class FusedStep(StepSchedule):
             self._ctr_bumped = True
         elif mode == 5:    # the launch that assembles the loss scalars also parks on the side chain's flag
             self._loss_scalars(after=(self.flags[1:2], self.step_dev, self.sync_err[0:2], 1, K.WAIT_SPINS),
-                               terms_elsewhere=side_adam)
+                               terms_elsewhere=side_loss)
         elif mode == 3:
             self._loss_scalars()
-        if mode == 5 and late:      # (the step counter is advanced before the optimiser launch: counter + 0 by then)
+        if mode == 5 and late and not split_kind:      # (the step counter is advanced before the optimiser launch: counter + 0 by then)
             lc = self.L_clf[0]
             lo = min(lc.dW.storage_offset(), lc.db.storage_offset()) - g0
             hi = max(lc.dW.storage_offset() + lc.dW.numel(), lc.db.storage_offset() + lc.db.numel()) - g0

@@ -102,11 +102,14 @@ class StepSchedule:
         finally:
             self.fuse_bwd = False
 
-    def capture(self, split_for_allreduce=False):
+    def capture(self, split_for_allreduce=False, allreduce=None):
         """Capture the train step (Philox noise + forward + backward + Adam: ~100 launches)
         into hipGraph(s) for the current batch structure.  With ``split_for_allreduce`` the
         step is captured as two graphs so that an (uncaptured) RCCL all-reduce of the
-        gradient arena can run between backward and Adam."""
+        gradient arena can run between backward and Adam; ``split_for_allreduce='captured'`` with
+        ``allreduce``: the collective is captured INTO the step's graph (RCCL supports stream capture),
+        no graph boundary, no host-side launch of the exchange."""
+        self._captured_allreduce = allreduce if split_for_allreduce == 'captured' else None
         assert self.plan is not None, 'set_batch first'
         if self.plan.DZMMD is not None:
             raise NotImplementedError('use_MMD: the model-level MMD penalty (a cross-row term evaluated through the '
@@ -125,8 +128,9 @@ class StepSchedule:
         self._side_graph = None
         dual = self.sched == 5 and self.branch.on and self.cfg.has_y and self._flags_usable()
         self._split_capture = bool(split_for_allreduce)
+        self._split_kind = split_for_allreduce          # False | True (two graphs) | 'overlap' | 'captured'
         cfg = self.cfg
-        self.noise_ahead = bool(dual and not split_for_allreduce and self.late_leaf and not cfg.cont and self.clf_small
+        self.noise_ahead = bool(dual and split_for_allreduce in (False, True) and self.late_leaf and not cfg.cont and self.clf_small
                                 and cfg.optim_alg == 'adam' and os.environ.get('DRVAE_NOISE_AHEAD', '1') != '0')
         self._noise_stale = True
         if dual:
@@ -375,7 +379,7 @@ class StepSchedule:
                 gc.capture_end()
             torch.cuda.current_stream().wait_stream(cap)
             self._graphs = [ga, gb, gc]
-        elif split_for_allreduce:
+        elif split_for_allreduce and split_for_allreduce != 'captured':
             g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             with torch.cuda.graph(g1):
                 self.fuse_bwd = True
@@ -391,7 +395,7 @@ class StepSchedule:
         else:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                self._launch_sequence()
+                self._launch_sequence(allreduce=getattr(self, '_captured_allreduce', None))
             self._graphs = [g]
 
     def replay(self, allreduce=None):
@@ -415,6 +419,10 @@ class StepSchedule:
             allreduce.finish(w_late)
             self._graphs[2].replay()
         elif len(self._graphs) == 2:
+            if self._side_graph is not None:
+                # the side chain's work behind the join (leaf gradients, loss scalars) must be final before the
+                # exchange reads the buffer: order the side stream in front of it
+                torch.cuda.current_stream().wait_stream(self.flag_side)
             if allreduce is not None:
                 allreduce(self.arena.xchg)
             self._graphs[1].replay()
