@@ -521,14 +521,14 @@ def main():
             out['elbo_vs_ref'] = parity_vs_cpu(args.workload, device)
     if world > 1:
         dist.barrier()
+    if world > 1 or (dp and dist.is_initialized()):
+        dist.destroy_process_group()
     if rank == 0:
         try:        # RCCL writes a version banner through C stdio: flush it out FIRST, the JSON line stays the last one
             ctypes.CDLL(None).fflush(None)
         except OSError:
             pass
         print(json.dumps(out), flush=True)
-    if world > 1 or (dp and dist.is_initialized()):
-        dist.destroy_process_group()
     return 0 if ok else 1
 
 
