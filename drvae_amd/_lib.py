@@ -33,6 +33,11 @@ class Wait(C.Structure):       # dv_wait: a device-side wait carried by a launch
     _fields_ = [('flag', _p), ('ctr', _p), ('add', _i32), ('max_spins', _i32), ('err', _p)]
 
 
+class Ymarg(C.Structure):      # dv_ymarg: y-marginalisation riding on the classifier-head launch
+    _fields_ = [('label', _p), ('fp_ptr', _p), ('klfp', _p), ('log_prior', _f), ('log_prior_v', _p), ('c_kld', _p),
+                ('c_yl', _p), ('yl', _p), ('kld', _p), ('cfp', _p), ('dqy', _p), ('lddq', _i64)]
+
+
 class Bump(C.Structure):       # dv_bump: up to two device counters advanced by a launch
     _fields_ = [('c', _p * 2), ('n', _i32 * 2), ('inc', _i64 * 2)]
 
@@ -72,7 +77,7 @@ SIGNATURES = {
                         _p, _i64, _i32, _i32, _i32, _i32, C.POINTER(Wait), _p],
     'dv_reparam_bwd': [_p, _i64, _p, _i64, _p, _i64, _p, _i32, _i32, _i32, _i32, _p, _p, _i64, _f, _p],
     'dv_kl_rows_fwd': [_p, _p, _i64, _p, _p, _p, _i64, _p, _f, _f, _i32, _i32, _i32, _i32, _i32, _f, _p, _p, _p, _p,
-                       _i64, _p, _i64, _p],
+                       _i64, _p, _i64, C.POINTER(Wait), _p],
     'dv_kl_rows_bwd': [_p, _p, _i32, _f, _p, _p, _i64, _p, _p, _p, _i64, _p, _f, _f, _i32, _i32, _i32, _i32,
                        _p, _p, _i64, _p, _p, _i64, _f, _p, _i64, _p, _i64, _p],
     'dv_gauss_nll_rows_fwd': [_p, _i64, _p, _p, _p, _i64, _i32, _i32, _i32, _p, _p],
@@ -84,7 +89,8 @@ SIGNATURES = {
     'dv_softmax_clamp_bwd': [_p, _i64, _p, _i64, _i32, _i32, _i32, _p, _i64, _f, _p],
     'dv_cat_terms_fwd': [_p, _i64, _i32, _i32, _p, _p, _i64, _p, _p, _i64, _p, _p, _p],
     'dv_cat_terms_bwd': [_p, _i64, _i32, _i32, _p, _p, _i64, _p, _p, _i64, _p, _p, _i64, _f, _p],
-    'dv_smalln_linear_fwd': [_p, _i64, _i32, _p, _i64, _i32, _p, _i64, _p, _i32, _i32, _p, _i64, _p, _i64, _p],
+    'dv_smalln_linear_fwd': [_p, _i64, _i32, _p, _i64, _i32, _p, _i64, _p, _i32, _i32, _p, _i64, _p, _i64,
+                             C.POINTER(Ymarg), _p],
     'dv_smalln_linear_bwd_data': [_p, _i64, _p, _i64, _p, _i64, _i32, _i32, _i32, C.POINTER(_p), C.POINTER(_i64),
                                   C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_f), C.POINTER(_f), C.POINTER(_i32),
                                   C.POINTER(_f), _p],
@@ -97,7 +103,7 @@ SIGNATURES = {
     'dv_ycont_bwd': [_p, _i64, _p, _p, _f, _i32, _p, _p, _p, _i64, _p, _i64, _i32, _i32, _i32, _p, _i64, _p, _p],
     'dv_mmd_rff_fwd': [_p, _i64, _i32, _p, _i64, _i32, _i32, _f, _p, _p, _p],
     'dv_mmd_rff_bwd': [_p, _i64, _i32, _i32, _p, _p, _f, _p, _i64, _p],
-    'dv_rows_gather': [_p, _i64, _p, _i32, _i32, _p, _i64, _f, _p, _i32, _p, _i64, _p],
+    'dv_rows_gather': [_p, _i64, _p, _i32, _i32, _p, _i64, _f, _p, _i32, _p, _i64, C.POINTER(Wait), _p],
     'dv_batch_feed': [_p, _i64, _p, _i64, _p, _p, _i32, _p, _p, _i32, _p, _i32, _i32, _p, _i64, _f, _p, _i64, _p, _i32,
                       _p, _p, _p, _p, _i32, _p, _p, _i64, _i32, _p, _p, _i32, _p],
     'dv_batch_masks': [_p, _i32, _p, _p, _p, _p, _p, _i32, _i32, _f, _f, _f, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],

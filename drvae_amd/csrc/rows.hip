@@ -295,7 +295,8 @@ __global__ __launch_bounds__(256) void kl_rows_fwd_kernel(KlArgs a, int free_bit
                                                           float* __restrict__ raw_out, float* __restrict__ out,
                                                           const float* __restrict__ add,
                                                           const float* __restrict__ eps, int64_t lde,
-                                                          float* __restrict__ zout, int64_t ldz) {
+                                                          float* __restrict__ zout, int64_t ldz, ParkArgs park) {
+    park_block(park);
     const int lane = threadIdx.x & 63;
     const int rows = a.n * a.reps;
     for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += gridDim.x * 4) {
@@ -662,12 +663,44 @@ __global__ void cat_terms_bwd_kernel(const float* __restrict__ probs, int64_t ld
 // >90 % padding, so one wavefront per row does the N dot products, the softmax and the clamp.
 constexpr int kMaxSmallN = 8;
 
+// y-marginalisation of one row right behind its class probabilities (dv_smalln_linear_fwd with a dv_ymarg argument:
+// the classifier head and the labeled / marginalised KLD assembly of src/DrVAE.py:503-534 in one launch); same
+// arithmetic as ymarg_fwdbwd_kernel below
+__device__ __forceinline__ void ymarg_row(const dv_ymarg& y, int r, int Y, const float* q) {
+    const int f0 = y.fp_ptr[r], nf = y.fp_ptr[r + 1] - f0;
+    const float ck = y.c_kld[r];
+    float* dq = y.dqy + (int64_t)r * y.lddq;
+    const int lab0 = y.label[r];
+    if (nf == 1 || lab0 <= -2) {
+        const int lab = nf == 1 ? lab0 : -2 - lab0;
+        y.yl[r] = logf(q[lab]);
+        y.kld[r] = y.klfp[nf == 1 ? f0 : f0 + lab];
+        for (int j = 0; j < Y; ++j) dq[j] = (j == lab) ? y.c_yl[r] / q[j] : 0.f;
+        if (nf == 1) {
+            y.cfp[f0] = ck;
+        } else {
+            for (int j = 0; j < Y; ++j) y.cfp[f0 + j] = (j == lab) ? ck : 0.f;
+        }
+    } else {
+        float a = 0.f, b = 0.f;
+        for (int j = 0; j < Y; ++j) {
+            const float lp = y.log_prior_v ? y.log_prior_v[j] : y.log_prior, lq = logf(q[j]), kf = y.klfp[f0 + j];
+            a += q[j] * kf;
+            b += -q[j] * (lp - lq);
+            y.cfp[f0 + j] = ck * q[j];
+            dq[j] = ck * (kf + lq - lp + 1.f);
+        }
+        y.yl[r] = 0.f;
+        y.kld[r] = a + b;
+    }
+}
+
 __global__ __launch_bounds__(256) void smalln_fwd_kernel(const float* __restrict__ a1, int64_t lda1, int K1,
                                                          const float* __restrict__ a2, int64_t lda2, int K2,
                                                          const float* __restrict__ W, int64_t ldw,
                                                          const float* __restrict__ bias, int M, int N,
                                                          float* __restrict__ logits, int64_t ldl,
-                                                         float* __restrict__ probs, int64_t ldp) {
+                                                         float* __restrict__ probs, int64_t ldp, dv_ymarg ym) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= M) return;
@@ -692,8 +725,12 @@ __global__ __launch_bounds__(256) void smalln_fwd_kernel(const float* __restrict
         if (probs) {
             float den = 0.f;
             for (int j = 0; j < N; ++j) den += expf(acc[j] - mx);
-            for (int j = 0; j < N; ++j)
-                probs[(int64_t)r * ldp + j] = fminf(fmaxf(expf(acc[j] - mx) / den, kPMin), kPMax);
+            float q[kMaxSmallN];
+            for (int j = 0; j < N; ++j) {
+                q[j] = fminf(fmaxf(expf(acc[j] - mx) / den, kPMin), kPMax);
+                probs[(int64_t)r * ldp + j] = q[j];
+            }
+            if (ym.fp_ptr != nullptr) ymarg_row(ym, r, N, q);
         }
     }
 }
@@ -1008,7 +1045,8 @@ __global__ void mmd_dtheta_kernel(const float* __restrict__ th, int64_t ld, int 
 __global__ void rows_gather_kernel(const float* __restrict__ src, int64_t lds, const int32_t* __restrict__ idx,
                                    int n, int W, const float* __restrict__ noise, int64_t ldn, float sigma,
                                    const int32_t* __restrict__ onehot_cls, int Y, float* __restrict__ out,
-                                   int64_t ldo) {
+                                   int64_t ldo, ParkArgs park) {
+    park_block(park);
     const int WT = W + (onehot_cls ? Y : 0);
     const int64_t total = (int64_t)n * WT;
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
@@ -1494,15 +1532,19 @@ extern "C" int dv_kl_rows_fwd(const float* mu_q, const float* sd_q, int64_t ldq,
                               const float* mu_p, const float* sd_p, int64_t ldp, const int32_t* pidx,
                               float prior_mu, float prior_sd, int32_t n, int32_t reps, int32_t Z, int32_t mode,
                               int32_t free_bits, float kl_min, float* raw_out, float* out, const float* add,
-                              const float* eps, int64_t lde, float* zout, int64_t ldz, dv_stream_t stream) {
-    DV_REQUIRE(n >= 0 && reps >= 0 && Z >= 0);
+                              const float* eps, int64_t lde, float* zout, int64_t ldz, const dv_wait* park_in,
+                              dv_stream_t stream) {
+    DV_REQUIRE(n >= 0 && reps >= 0 && Z >= 0 && park_ok(park_in));
+    const ParkArgs park = park_in ? *park_in : ParkArgs{};
+    DV_REQUIRE(park.flag == nullptr || (n > 0 && reps > 0));
+    if (park.flag != nullptr && grid_for((int64_t)n * reps, 4) > DV_MAX_PARKED_GRID) return DV_ERR_UNSUPPORTED;
     if (n == 0 || reps == 0) return DV_OK;
     DV_REQUIRE(mu_q && sd_q && out);
     DV_REQUIRE((mu_p == nullptr) == (sd_p == nullptr));
     DV_REQUIRE(zout == nullptr || eps != nullptr);
     KlArgs a{mu_q, sd_q, ldq, qidx, mu_p, sd_p, ldp, pidx, prior_mu, prior_sd, n, reps, Z, mode};
     hipLaunchKernelGGL(kl_rows_fwd_kernel, dim3(grid_for((int64_t)n * reps, 4)), dim3(256), 0, ST(stream), a,
-                       free_bits, kl_min, raw_out, out, add, eps, lde, zout, ldz);
+                       free_bits, kl_min, raw_out, out, add, eps, lde, zout, ldz, park);
     DV_RETURN_LAUNCH();
 }
 
@@ -1638,12 +1680,18 @@ extern "C" int dv_cat_terms_bwd(const float* probs, int64_t ldp, int32_t M, int3
 
 extern "C" int dv_smalln_linear_fwd(const float* a1, int64_t lda1, int32_t K1, const float* a2, int64_t lda2,
                                     int32_t K2, const float* W, int64_t ldw, const float* bias, int32_t M, int32_t N,
-                                    float* logits, int64_t ldl, float* probs, int64_t ldp, dv_stream_t stream) {
+                                    float* logits, int64_t ldl, float* probs, int64_t ldp, const dv_ymarg* ymarg,
+                                    dv_stream_t stream) {
     DV_REQUIRE(M >= 0 && N >= 1 && N <= kMaxSmallN && K1 >= 0 && K2 >= 0);
     if (M == 0) return DV_OK;
     DV_REQUIRE(a1 && W && (a2 || K2 == 0) && (logits || probs));
+    dv_ymarg ym{};
+    if (ymarg != nullptr && ymarg->fp_ptr != nullptr) {
+        ym = *ymarg;
+        DV_REQUIRE(probs && ym.label && ym.klfp && ym.c_kld && ym.c_yl && ym.yl && ym.kld && ym.cfp && ym.dqy);
+    }
     hipLaunchKernelGGL(smalln_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, ST(stream), a1, lda1, K1, a2, lda2, K2, W,
-                       ldw, bias, M, N, logits, ldl, probs, ldp);
+                       ldw, bias, M, N, logits, ldl, probs, ldp, ym);
     DV_RETURN_LAUNCH();
 }
 
@@ -1767,14 +1815,17 @@ extern "C" int dv_mmd_rff_bwd(const float* th, int64_t ld, int32_t n, int32_t R,
 
 extern "C" int dv_rows_gather(const float* src, int64_t lds, const int32_t* idx, int32_t n, int32_t W,
                               const float* noise, int64_t ldn, float sigma, const int32_t* onehot_cls, int32_t Y,
-                              float* out, int64_t ldo, dv_stream_t stream) {
-    DV_REQUIRE(n >= 0 && W >= 0 && Y >= 0);
+                              float* out, int64_t ldo, const dv_wait* park_in, dv_stream_t stream) {
+    DV_REQUIRE(n >= 0 && W >= 0 && Y >= 0 && park_ok(park_in));
+    const ParkArgs park = park_in ? *park_in : ParkArgs{};
+    const int64_t total = (int64_t)n * (W + (onehot_cls ? Y : 0));
+    DV_REQUIRE(park.flag == nullptr || total > 0);
     if (n == 0) return DV_OK;
     DV_REQUIRE(out && (src || W == 0));
-    const int64_t total = (int64_t)n * (W + (onehot_cls ? Y : 0));
     if (total == 0) return DV_OK;
+    if (park.flag != nullptr && grid_for(total, 256) > DV_MAX_PARKED_GRID) return DV_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(rows_gather_kernel, dim3(grid_for(total, 256)), dim3(256), 0, ST(stream), src, lds, idx, n,
-                       W, noise, ldn, sigma, onehot_cls, Y, out, ldo);
+                       W, noise, ldn, sigma, onehot_cls, Y, out, ldo, park);
     DV_RETURN_LAUNCH();
 }
 

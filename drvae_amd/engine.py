@@ -208,6 +208,9 @@ class FusedStep(StepSchedule):
         # the row work that consumes both heads of a block (the reparameterised samples; forward AND backward of
         # the reconstruction log-likelihood) leaves the heads' own GEMM launch (dv_gemm_heads)
         self.fuse_heads = os.environ.get('DRVAE_FUSE_HEADS', '1') != '0'
+        # the side chain's second wait rides on the row kernel behind it (dv_wait argument of dv_kl_rows_fwd)
+        # instead of being a launch of its own
+        self.fold_waits = os.environ.get('DRVAE_FOLD_WAITS', '1') != '0'
         self.noise_ahead = False          # set by capture(): the side chain draws the NEXT step's noise behind the join
         self._noise_stale = True          # (then) the noise buffer does not hold the draws of the current Philox counter
         self._adam_n = None
@@ -496,9 +499,11 @@ class FusedStep(StepSchedule):
             self._mmd_penalty()
         # ---- two independent chains from here: the classifier / fprop chain (many small launches)
         # runs on a side stream next to the decoder chain (the big GEMMs)
-        def side_forward(mid=None):
+        def side_forward(mid=None, first_park=None, mid_park=None):
             """fprop first: it only needs the z1 samples, so (dual-graph schedule) it can start before
-            the perturbation function has run; ``mid`` then waits for the z2Fz1 samples"""
+            the perturbation function has run; ``mid`` then waits for the z2Fz1 samples.  ``first_park`` / ``mid_park``
+            (dual-graph schedule): the two waits ride on the launch that follows them where that is a row kernel
+            with a small grid (one launch less each); else ``mid`` / a wait launch of its own."""
             if cfg.kind == 'pvae':
                 K.kl_rows_fwd(p.KLP, p.KLPraw, Qmu, Qlv, prior=(0.0, 0.0), free_bits=True, kl_min=cfg.kl_min)
             if cfg.has_y and cfg.cont:
@@ -527,10 +532,15 @@ class FusedStep(StepSchedule):
                               kl_min=cfg.kl_min, add=p.KL3)
                 return
             # ---- fprop over (labeled: true class | unlabeled: every class)
+            # (a parked launch polls from every workgroup: small grids only -- the C side refuses more than 512)
+            if first_park is not None and not (cfg.has_y and p.Mf and (p.Mf * (Z1 + cfg.dim_y) + 255) // 256 <= 256):
+                K.flag_wait(*first_park)
+                first_park = None
             if cfg.has_y:
                 if p.Mf:
                     Z3, Y = cfg.dim_z3, cfg.dim_y
-                    K.rows_gather(p.FPIN, Z1blk, p.fp_src, onehot_cls=p.fp_cls, n_classes=Y)
+                    K.rows_gather(p.FPIN, Z1blk, p.fp_src, onehot_cls=p.fp_cls, n_classes=Y,
+                                  park=(first_park[0], first_park[1], first_park[2]) if first_park is not None else None)
                     Q3 = p.c_top.forward([p.FPIN])
                     # KL(q(z3|z1,y)||N(0,I)) with free bits + the z3 sample, one row pass
                     K.kl_rows_fwd(p.KL3, p.KL3raw, Q3[:, :Z3], Q3[:, Z3:], prior=(0.0, 0.0), free_bits=True,
@@ -539,24 +549,31 @@ class FusedStep(StepSchedule):
                     # KLFP = max(KL(q(z1|x)||p(z1|z3,y)), kl_min) + the z3 term   (src/DrVAE.py:347,358)
                     K.kl_rows_fwd(p.KLFP, p.KL1raw, Qmu, Qlv, PZ1[:, :Z1], PZ1[:, Z1:], qidx=p.fp_q, free_bits=True,
                                   kl_min=cfg.kl_min, add=p.KL3)
-            if mid is not None:
+            fold_mid = mid_park is not None and cfg.has_pert and Np and (L * Np + 3) // 4 <= 256
+            if mid is not None and not fold_mid:
                 mid()
             if cfg.has_pert and Np:
                 P2 = p.c_z2F.out[-1]
                 K.kl_rows_fwd(p.KLZ2, p.KLZ2raw, Qmu, Qlv, P2[:, :Z1], P2[:, Z1:], qidx=p.qz2_idx, pidx=p.pidx,
-                              reps=L, free_bits=True, kl_min=cfg.kl_min)
+                              reps=L, free_bits=True, kl_min=cfg.kl_min,
+                              park=(mid_park[0], mid_park[1], mid_park[2]) if fold_mid else None)
             # ---- q(y|.)
             if cfg.has_y:
                 if cfg.kind == 'drvae':
                     clf_in = [Z1blk, p.D] if cfg.clf_z1z2 else [p.Z2F]
                 else:
                     clf_in = [Z1blk]
+                ym = (p.YLrow, p.KLDrow, p.CFP, p.DQY, p.label_r, p.fp_ptr, p.KLFP, p.log_prior, p.c_kld, p.c_yl)
                 if self.clf_small:
                     lc = self.L_clf[0]
-                    K.smalln_fwd(p.QY, None, clf_in[0], lc.W, lc.b, clf_in[1] if len(clf_in) > 1 else None)
+                    # train step: the y-marginalisation (forward and backward) rides on the classifier's launch
+                    K.smalln_fwd(p.QY, None, clf_in[0], lc.W, lc.b, clf_in[1] if len(clf_in) > 1 else None,
+                                 ymarg=ym if self.fuse_bwd else None)
                 else:
                     K.softmax_clamp_fwd(p.QY, p.c_clf.forward(clf_in), sigmoid1=cfg.clf_1sig)
-                if self.fuse_bwd:      # train step: CFP / DQY of the backward pass come out of the same launch
+                if self.fuse_bwd and self.clf_small:
+                    pass
+                elif self.fuse_bwd:    # train step: CFP / DQY of the backward pass come out of the same launch
                     K.ymarg_fwdbwd(p.YLrow, p.KLDrow, p.CFP, p.DQY, p.QY, p.label_r, p.fp_ptr, p.KLFP, p.log_prior,
                                    p.c_kld, p.c_yl)
                 else:
@@ -565,8 +582,15 @@ class FusedStep(StepSchedule):
         if mode == 5:
             two = cfg.has_pert                      # flag 0: z1 samples final; flag 2: z2Fz1 samples final
             if rec == 'side':
-                K.flag_wait(self.flags[0:1], self.side_ctr, self.sync_err[2:4])
-                side_forward((lambda: K.flag_wait(self.flags[2:3], self.side_ctr, self.sync_err[4:6])) if two else None)
+                w0 = (self.flags[0:1], self.side_ctr, self.sync_err[2:4])
+                w2 = (self.flags[2:3], self.side_ctr, self.sync_err[4:6])
+                # the FIRST wait is long by design (the side graph is launched first and sits out the encoder): it
+                # stays a one-thread launch -- folded into the 180-workgroup gather behind it, the polling of 180
+                # workgroups for ~45 us slowed the main chain by 14 % (0.204 -> 0.233 ms).  The second wait has
+                # nothing left to wait for when the side chain reaches it: it rides on the KL row kernel behind it
+                K.flag_wait(*w0)
+                fold = self.fold_waits and not cfg.cont
+                side_forward((lambda: K.flag_wait(*w2)) if two else None, mid_park=w2 if (two and fold) else None)
                 return
             pub = (self.flags[2:3] if two else self.flags[0:1], self.step_dev, 1)
             if self.L_decx[0].g is not None:             # WeightNorm: the chain's first launch is not the GEMM

@@ -264,7 +264,7 @@ def z2f_post_bwd(dp2, dz1, dq2, dz2f, dzdec_pert, pair_slot, eps, p2, q2, coef, 
 
 # --------------------------------------------------------------------------- KL rows
 def kl_rows_fwd(out, raw, mu_q, sd_q, mu_p=None, sd_p=None, *, prior=(0.0, 0.0), mode=GAUSS_LOGVAR, qidx=None,
-                pidx=None, reps=1, free_bits=False, kl_min=0.0, add=None, eps=None, zout=None):
+                pidx=None, reps=1, free_bits=False, kl_min=0.0, add=None, eps=None, zout=None, park=None):
     R = out.numel()
     n = R // reps
     Z = mu_q.shape[1]
@@ -272,7 +272,7 @@ def kl_rows_fwd(out, raw, mu_q, sd_q, mu_p=None, sd_p=None, *, prior=(0.0, 0.0),
     _lib.check(_lib.load().dv_kl_rows_fwd(_f32(mu_q), _f32(sd_q), _ld(mu_q), _i32(qidx), _f32(mu_p), _f32(sd_p),
                                           _ld(mu_p), _i32(pidx), prior[0], prior[1], n, reps, Z, mode,
                                           int(free_bits), kl_min, _f32(raw), _f32(out), _f32(add), _f32(eps),
-                                          _ld(eps), _f32(zout), _ld(zout), _stream()), 'dv_kl_rows_fwd')
+                                          _ld(eps), _f32(zout), _ld(zout), _wait(park), _stream()), 'dv_kl_rows_fwd')
 
 
 def kl_rows_bwd(dq_mu, dq_sd, dp_mu, dp_sd, coef, raw, mu_q, sd_q, mu_p=None, sd_p=None, *, prior=(0.0, 0.0),
@@ -353,14 +353,26 @@ def cat_terms_bwd(dprobs, probs, *, labels=None, prior=None, c_logp=None, g_kl=N
                                             _ld(dprobs), beta, _stream()), 'dv_cat_terms_bwd')
 
 
-def smalln_fwd(probs, logits, a1, W, bias=None, a2=None):
-    """probs = clamp(softmax([a1|a2] W^T + b)) for N <= 8 outputs (either output may be None)."""
+def smalln_fwd(probs, logits, a1, W, bias=None, a2=None, ymarg=None):
+    """probs = clamp(softmax([a1|a2] W^T + b)) for N <= 8 outputs (either output may be None).
+    ``ymarg`` = (yl, kld, cfp, dqy, label, fp_ptr, klfp, log_prior, c_kld, c_yl): the y-marginalisation of every row
+    (the arguments of ``ymarg_fwdbwd``) rides on the same launch."""
     M = a1.shape[0]
     N = W.shape[0]
     K1, K2 = a1.shape[1], (a2.shape[1] if a2 is not None else 0)
+    ym = None
+    if ymarg is not None:
+        yl, kld, cfp, dqy, label, fp_ptr, klfp, log_prior, c_kld, c_yl = ymarg
+        vec = log_prior if torch.is_tensor(log_prior) else None
+        y = _lib.Ymarg()
+        y.label, y.fp_ptr, y.klfp = _i32(label), _i32(fp_ptr), _f32(klfp)
+        y.log_prior, y.log_prior_v = (0.0 if vec is not None else log_prior), _f32(vec)
+        y.c_kld, y.c_yl, y.yl, y.kld, y.cfp = _f32(c_kld), _f32(c_yl), _f32(yl), _f32(kld), _f32(cfp)
+        y.dqy, y.lddq = _f32(dqy), _ld(dqy)
+        ym = C.byref(y)
     _lib.check(_lib.load().dv_smalln_linear_fwd(_f32(a1), _ld(a1), K1, _f32(a2), _ld(a2), K2, _f32(W), _ld(W),
                                                 _f32(bias), M, N, _f32(logits), _ld(logits), _f32(probs),
-                                                _ld(probs), _stream()), 'dv_smalln_linear_fwd')
+                                                _ld(probs), ym, _stream()), 'dv_smalln_linear_fwd')
 
 
 def smalln_bwd_data(dsts, dprobs, probs, W):
@@ -445,11 +457,11 @@ def mmd_rff_bwd(G, th, diff, gout, coef):
                                           _stream()), 'dv_mmd_rff_bwd')
 
 
-def rows_gather(out, src, idx=None, *, noise=None, sigma=0.0, onehot_cls=None, n_classes=0, width=None):
+def rows_gather(out, src, idx=None, *, noise=None, sigma=0.0, onehot_cls=None, n_classes=0, width=None, park=None):
     n = out.shape[0]
     W = (src.shape[1] if src is not None else 0) if width is None else width
     _lib.check(_lib.load().dv_rows_gather(_f32(src), _ld(src), _i32(idx), n, W, _f32(noise), _ld(noise), sigma,
-                                          _i32(onehot_cls), n_classes, _f32(out), _ld(out), _stream()),
+                                          _i32(onehot_cls), n_classes, _f32(out), _ld(out), _wait(park), _stream()),
                'dv_rows_gather')
 
 

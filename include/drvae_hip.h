@@ -66,6 +66,23 @@ typedef struct dv_wait {
 
 /* up to two device counters (1 or 2 int32 words each: int32 / uint64 little-endian) advanced by a
  * launch that carries the bump (see dv_counters_add2); c == NULL: unused slot */
+/* y-marginalisation riding on the classifier-head launch (dv_smalln_linear_fwd): the arguments of dv_ymarg_fwdbwd
+ * (src/DrVAE.py:503-534); fp_ptr == NULL: none */
+typedef struct dv_ymarg {
+    const int32_t* label;
+    const int32_t* fp_ptr;
+    const float* klfp;
+    float log_prior;
+    const float* log_prior_v;
+    const float* c_kld;
+    const float* c_yl;
+    float* yl;
+    float* kld;
+    float* cfp;
+    float* dqy;
+    int64_t lddq;
+} dv_ymarg;
+
 typedef struct dv_bump {
     int32_t* c[2];
     int32_t n[2];
@@ -263,7 +280,7 @@ int dv_kl_rows_fwd(const float* mu_q, const float* sd_q, int64_t ldq, const int3
                    const float* sd_p, int64_t ldp, const int32_t* pidx, float prior_mu, float prior_sd, int32_t n,
                    int32_t reps, int32_t Z, int32_t mode, int32_t free_bits, float kl_min, float* raw_out,
                    float* out, const float* add, const float* eps, int64_t lde, float* zout, int64_t ldz,
-                   dv_stream_t stream);
+                   const dv_wait* park, dv_stream_t stream);
 int dv_kl_rows_bwd(const float* coef, const float* raw, int32_t free_bits, float kl_min, const float* mu_q,
                    const float* sd_q, int64_t ldq, const int32_t* qidx, const float* mu_p, const float* sd_p,
                    int64_t ldp, const int32_t* pidx, float prior_mu, float prior_sd, int32_t n, int32_t reps,
@@ -334,7 +351,7 @@ int dv_cat_terms_bwd(const float* probs, int64_t ldp, int32_t M, int32_t Y, cons
  * The pointer/size arrays of bwd_data are HOST arrays. */
 int dv_smalln_linear_fwd(const float* a1, int64_t lda1, int32_t K1, const float* a2, int64_t lda2, int32_t K2,
                          const float* W, int64_t ldw, const float* bias, int32_t M, int32_t N, float* logits,
-                         int64_t ldl, float* probs, int64_t ldp, dv_stream_t stream);
+                         int64_t ldl, float* probs, int64_t ldp, const dv_ymarg* ymarg, dv_stream_t stream);
 int dv_smalln_linear_bwd_data(const float* dprobs, int64_t lddp, const float* probs, int64_t ldp, const float* W,
                               int64_t ldw, int32_t M, int32_t N, int32_t n_dst, float* const* dst,
                               const int64_t* ld, const int32_t* col0, const int32_t* ncol, const float* alpha,
@@ -400,7 +417,7 @@ int dv_mmd_rff_bwd(const float* th, int64_t ld, int32_t n, int32_t R, const floa
  *   `torch.cat([z, one_hot(y)], 1)` of src/blocks.py:161 + src/blocks.py:78-92. */
 int dv_rows_gather(const float* src, int64_t lds, const int32_t* idx, int32_t n, int32_t W, const float* noise,
                    int64_t ldn, float sigma, const int32_t* onehot_cls, int32_t Y, float* out, int64_t ldo,
-                   dv_stream_t stream);
+                   const dv_wait* park, dv_stream_t stream);
 /* Graph-resident minibatch feed (input pipeline of src/run_drvae.py:150-166 + the group gathers of
  * src/DrVAE.py:585-608, kept on the device).  `table` holds the dataset row of every slot of every
  * batch of an epoch (n_batches x B, drawn by the weighted sampler on the device); batch

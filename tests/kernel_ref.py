@@ -304,7 +304,9 @@ def _kl_operands(mu_q, sd_q, mu_p, sd_p, prior, qidx, pidx, R, reps):
 
 
 def kl_rows_fwd(out, raw, mu_q, sd_q, mu_p=None, sd_p=None, *, prior=(0.0, 0.0), mode=GAUSS_LOGVAR, qidx=None,
-                pidx=None, reps=1, free_bits=False, kl_min=0.0, add=None, eps=None, zout=None):
+                pidx=None, reps=1, free_bits=False, kl_min=0.0, add=None, eps=None, zout=None, park=None):
+    if park is not None:
+        flag_wait(*park[:3])
     R = out.numel()
     mq, sq, mp, sp = _kl_operands(mu_q, sd_q, mu_p, sd_p, prior, qidx, pidx, R, reps)
     if zout is not None:
@@ -449,7 +451,12 @@ def _dlogits(dprobs, probs):
     return probs * (g - (g * probs).sum(1, keepdim=True))
 
 
-def smalln_fwd(probs, logits, a1, W, bias=None, a2=None):
+def smalln_fwd(probs, logits, a1, W, bias=None, a2=None, ymarg=None):
+    if ymarg is not None:
+        smalln_fwd(probs, logits, a1, W, bias, a2)
+        yl, kld, cfp, dqy, label, fp_ptr, klfp, log_prior, c_kld, c_yl = ymarg
+        ymarg_fwdbwd(yl, kld, cfp, dqy, probs, label, fp_ptr, klfp, log_prior, c_kld, c_yl)
+        return
     x = torch.cat([a1, a2], 1) if a2 is not None else a1
     z = x @ W.t() + (bias if bias is not None else 0)
     if logits is not None:
@@ -553,7 +560,9 @@ def mmd_rff_bwd(G, th, diff, gout, coef):
     G.copy_(-coef * gout.reshape(-1)[0] * diff[None, :] * torch.sin(th))
 
 
-def rows_gather(out, src, idx=None, *, noise=None, sigma=0.0, onehot_cls=None, n_classes=0, width=None):
+def rows_gather(out, src, idx=None, *, noise=None, sigma=0.0, onehot_cls=None, n_classes=0, width=None, park=None):
+    if park is not None:
+        flag_wait(*park[:3])
     n = out.shape[0]
     W = (src.shape[1] if src is not None else 0) if width is None else width
     if W > 0:
