@@ -254,13 +254,46 @@ class FitMixin:
         eng.check_sync()
         return mean
 
+    def _graph_step(self, kw):
+        """One train step of a tuple-loader batch through ONE captured graph whatever the batch's mix of pairs / labels
+        (the reference's own input pipeline yields a different mix every batch, src/run_drvae.py:150-162): the batch goes
+        into the buffers of the batch-independent plan (``set_batch``: device-to-device copies + its flags), the
+        captured step turns the flags into group masks itself (dv_batch_masks).  The first batch of a size runs
+        eagerly (iteration 0 carries beta_pert = 0.01) and the capture follows."""
+        eng = self._batch_to_engine(**kw)
+        eng.add_noise = bool(self.add_noise)
+        eng.iters = self.finished_training_iters
+        fresh = getattr(eng, '_graph_key', None) != eng.plan.key or getattr(eng, '_graph_noise', None) != eng.add_noise \
+            or getattr(eng, '_graph_feed', None) is not eng.plan.live_feed
+        if fresh and eng.iters == 0:
+            eng.train_step(allreduce=getattr(self, '_allreduce', None))
+        else:
+            if fresh:
+                eng.capture(split_for_allreduce=getattr(self, '_allreduce', None) is not None)
+                eng._graph_noise = eng.add_noise
+            with eng.partition():
+                eng.replay(allreduce=getattr(self, '_allreduce', None))
+        self.finished_training_iters = eng.iters
+        return self._loss_tensors(eng)
+
     def _epoch_loader(self, loader, epoch, verbose):
         self._assert_arena_aliased()
         n_b = len(loader)
         every = max(10, n_b / 10)
         total = None
+        eng = self.engine()
+        # tuple loaders: one batch-independent plan + one captured graph for every batch composition (opt out:
+        # ``model.universal_plan = False`` -> a plan per structure, eager launches)
+        mode = getattr(self, 'universal_plan', True)       # True | False | 'eager' (the universal plan, eager launches)
+        graph = bool(mode) and eng.universal_ok() and eng.dev.type == 'cuda' and \
+            getattr(self, '_global_counts', None) is None
+        if graph:
+            eng.universal = True
+            graph = mode != 'eager'
         for b, batch in enumerate(loader):
-            loss = self.run_on_batch(train_mode=True, **self._batch_kwargs(batch))
+            self.train()
+            loss = self._graph_step(self._batch_kwargs(batch)) if graph else \
+                self.run_on_batch(train_mode=True, **self._batch_kwargs(batch))
             v = self._train_objective(loss)
             total = v.clone() if total is None else total + v
             if verbose and b % every == 0:

@@ -119,7 +119,8 @@ class StepSchedule:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):         # warm-up on a side stream (loads code objects)
-            self.draw_noise()
+            self.draw_noise(bump=False)       # (the Philox counter is NOT advanced: capturing leaves the stream
+            self._rng_pending = 0             #  of draw events exactly where an eager step would find it)
             self.forward()
             self.backward()
         torch.cuda.current_stream().wait_stream(side)

@@ -230,3 +230,28 @@ def test_fit_device_batcher_gpu(kind, tmp_path, dev):
     m2 = _tiny_model(kind, device='cuda', epochs=2)
     m2.fit(_loader(tr, 16), _loader(va, 8), add_noise=False, early_stop=False, model_filename=fn)
     assert m2.finished_training_iters == 2 * 4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('kind', ['drvae', 'vfae'])
+def test_fit_tuple_loader_runs_one_captured_graph(kind, tmp_path, dev):
+    """fit() fed by a plain DataLoader whose batches differ in their mix of pairs / labels (what the reference's
+    WeightedRandomSampler pipeline yields): every batch goes through ONE batch-independent plan and ONE captured
+    graph, and trains exactly like eager launches on the same plan."""
+    tr, va = _tiny_dataset(kind, 64, 1, 'cuda'), _tiny_dataset(kind, 32, 2, 'cuda')
+    out = []
+    for mode in (True, 'eager'):
+        model = _tiny_model(kind, device='cuda', epochs=3)
+        model.universal_plan = mode
+        torch.manual_seed(0)
+        model.fit(_loader(tr, 16), _loader(va, 8), add_noise=True, verbose=False, early_stop=False,
+                  model_filename=str(tmp_path / 'm.pth'))
+        eng = model.engine()
+        # one plan per batch SIZE (16 training rows; the whole-set evaluations of fit use the 64- / 32-row ones), none per mix
+        assert eng.universal and all(k[0] == 'universal' for k in eng._plans) and len(eng._plans) == 3
+        assert model.finished_training_iters == 3 * 4
+        if mode is True:
+            assert eng._graphs and eng._graph_key == ('universal', 16, 0)
+        out.append({k: v.detach().cpu().clone() for k, v in model.state_dict().items()})
+    for k in out[0]:
+        assert torch.equal(out[0][k], out[1][k]), k

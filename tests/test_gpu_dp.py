@@ -37,7 +37,6 @@ def _worker(rank, world, port, q):
             set_batch(eng, batch, dev, counts=counts)
             eng.train_step(allreduce=D.allreduce_sum)
             if mode == 'eager':
-                eng.draw_noise()                      # capture() spends one Philox draw on its warm-up
                 for _ in range(3):
                     eng.train_step(allreduce=D.allreduce_sum)
             else:
@@ -60,7 +59,7 @@ def _worker(rank, world, port, q):
         eng.seed, eng.row0 = 4242, lo
         set_batch(eng, shard, dev, counts=counts)
         eng.train_step(allreduce=D.allreduce_sum)
-        eng.capture(split_for_allreduce=True)     # (spends one draw event on its warm-up: ``one`` follows below)
+        eng.capture(split_for_allreduce=True)
         for _ in range(3):
             eng.replay(D.allreduce_sum)
         torch.cuda.synchronize()
@@ -69,7 +68,6 @@ def _worker(rank, world, port, q):
         one.seed = 4242
         set_batch(one, full, dev)
         one.train_step()
-        one.draw_noise()
         for _ in range(3):
             one.train_step()
         torch.cuda.synchronize()

@@ -111,7 +111,6 @@ def test_graph_replay_equals_eager(dev):
     for e in (eager, graph):
         set_batch(e, batch, dev)
         e.train_step()                       # iteration 0 (beta_pert = 0.01) always eager
-    eager.draw_noise()                       # capture() spends one Philox draw on its warm-up
     graph.capture()
     for _ in range(4):
         eager.train_step()
@@ -136,7 +135,6 @@ def test_partitioned_replay_equals_eager(kind, dev):
     for e in (eager, graph):
         set_batch(e, batch, dev)
         e.train_step()
-    eager.draw_noise()                       # capture() spends one Philox draw on its warm-up
     graph.capture()
     graph.tune_partition(candidates=(48, 64), steps=4)
     with graph.partition():
@@ -219,8 +217,6 @@ def test_device_batcher_feeds_one_captured_graph(dev):
     for k, i in enumerate(idxs):
         ic = i.cpu()
         eager.set_batch(ds.x1[i], ds.x2[i], ds.y[i].cpu(), bat.has_x2, bat.has_y)
-        if k == 1:
-            eager.draw_noise()               # capture() spends one Philox draw on its warm-up
         eager.train_step()
     torch.cuda.synchronize()
     assert torch.equal(a0.param, a1.param)
@@ -254,7 +250,6 @@ def test_graph_resident_epoch_feed(kind, dev):
     assert len(fed._plans) == 1 and fed.iters == 6
     assert not torch.equal(tables[0], tables[1])
     eager.set_structure(bat.has_x2, bat.has_y)
-    eager.draw_noise()                       # capture() spends one Philox draw on its warm-up
     for tab in tables:
         for b in range(3):
             i = tab[b].long()
@@ -388,7 +383,6 @@ def test_sampler_mode_epoch_in_one_graph(kind, dev):
         for _ in range(3):
             fed.replay()
     assert len(fed._plans) == 1 and fed.iters == 6
-    K.counter_add(eager.rng_ctr, 1)          # capture() spends one draw event on its warm-up
     comps = set()
     for tab in tables:
         for b in range(3):
