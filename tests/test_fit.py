@@ -230,6 +230,14 @@ def test_fit_device_batcher_gpu(kind, tmp_path, dev):
     m2 = _tiny_model(kind, device='cuda', epochs=2)
     m2.fit(_loader(tr, 16), _loader(va, 8), add_noise=False, early_stop=False, model_filename=fn)
     assert m2.finished_training_iters == 2 * 4
+    # the reference's sampler semantics on the device (any group mix per batch): same protocol, one graph
+    m3 = _tiny_model(kind, device='cuda', epochs=3)
+    p0, _ = m3.evaluate_performance_on_dataset(va)
+    m3.fit(D.DeviceBatcher(tr, w, 16, seed=4, mode='sampler'), _loader(va, 8), add_noise=True, early_stop=False,
+           model_filename=fn)
+    p1, _ = m3.evaluate_performance_on_dataset(va)
+    assert m3.finished_training_iters == 3 * 4 and m3.engine().universal
+    assert p1['x1_rmse'] < p0['x1_rmse'] and np.isfinite(float(p1['losses']['ELBO']))
 
 
 @pytest.mark.gpu
