@@ -894,6 +894,119 @@ __global__ __launch_bounds__(64 * KS, KS == 8 ? 2 : 4) void gemm_dma_kernel(cons
     epi_store_col<RPT>(g, a4, n0 + col, [rbase](int r) { return rbase + r; });
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Wave-private variant of the 32x32 K-split tiling (lab tiling 13; forward layout): each of the four waves owns a
+// contiguous quarter of K and stages ITS OWN 16-deep slices of both tiles (global -> registers -> its private LDS
+// region, used only to transpose the coalesced loads into MFMA fragments), so the K loop has no workgroup barrier
+// at all -- the waves free-run, two slices of loads in flight each; one barrier for the final K-split reduction.
+__global__ __launch_bounds__(256, 4) void gemm_wp_kernel(const dv_gemm_desc g, const LoadCfg lc) {
+    constexpr int BM = 32, BN = 32, KS = 4, SK = 16, LD = SK + 4;       // slice depth, padded LDS row
+    constexpr int OPER = 32 * LD, STAGE = 2 * OPER, RED = KS * BM * (BN + 1);
+    __shared__ __attribute__((aligned(16))) float smem[KS * 2 * STAGE > RED ? KS * 2 * STAGE : RED];
+    publish_on_entry(g);
+    const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
+    int tm, tn;
+    tile_of_block(blockIdx.x, gridDim.x, tiles_m, tiles_n, lc.map, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    // this wave's K range: quarters rounded up to whole slices
+    const int nsl = (g.K + SK - 1) / SK, per = (nsl + KS - 1) / KS;
+    const int s0 = wave * per, s1 = (s0 + per < nsl) ? s0 + per : nsl;      // slices [s0, s1)
+    float* my = smem + wave * 2 * STAGE;
+    // staging: lane -> (row = lane/4 + 16 j, chunk = lane%4), j = 0,1, for A and for B.  Every load is unconditional:
+    // the slice index is clamped into the wave's range (a re-read slice is never multiplied) and a chunk past K reads
+    // the last valid chunk of its row and is multiplied by 0 (K % 4 == 0: a chunk is wholly inside or outside)
+    const int r_ = lane >> 2, c_ = lane & 3;
+    int ra0 = m0 + r_, ra1 = m0 + r_ + 16, rb0 = n0 + r_, rb1 = n0 + r_ + 16;
+    ra0 = ra0 < g.M ? ra0 : g.M - 1;
+    ra1 = ra1 < g.M ? ra1 : g.M - 1;
+    rb0 = rb0 < g.N ? rb0 : g.N - 1;
+    rb1 = rb1 < g.N ? rb1 : g.N - 1;
+    const float* pa0 = g.A + (int64_t)ra0 * g.lda;
+    const float* pa1 = g.A + (int64_t)ra1 * g.lda;
+    const float* pb0 = g.B + (int64_t)rb0 * g.ldb;
+    const float* pb1 = g.B + (int64_t)rb1 * g.ldb;
+    const int slast = s1 - 1, klast = g.K - 4;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float4 a00, a01, b00, b01, a10, a11, b10, b11;      // two register sets (x: set, y: row half)
+#define WP_FETCH(S, A0, A1, B0, B1)                                                        \
+    {                                                                                      \
+        const int ss = (S) < slast ? (S) : slast;                                          \
+        const int k = ss * SK + c_ * 4, kc = k < klast ? k : klast;                        \
+        const float mk = k < g.K ? 1.f : 0.f;                                              \
+        A0 = *reinterpret_cast<const float4*>(pa0 + kc);                                   \
+        A1 = *reinterpret_cast<const float4*>(pa1 + kc);                                   \
+        B0 = *reinterpret_cast<const float4*>(pb0 + kc);                                   \
+        B1 = *reinterpret_cast<const float4*>(pb1 + kc);                                   \
+        A0.x *= mk; A0.y *= mk; A0.z *= mk; A0.w *= mk;                                    \
+        A1.x *= mk; A1.y *= mk; A1.z *= mk; A1.w *= mk;                                    \
+    }
+#define WP_STASH(ST, A0, A1, B0, B1)                                                       \
+    {                                                                                      \
+        *reinterpret_cast<float4*>(&(ST)[r_ * LD + c_ * 4]) = A0;                          \
+        *reinterpret_cast<float4*>(&(ST)[(r_ + 16) * LD + c_ * 4]) = A1;                   \
+        *reinterpret_cast<float4*>(&(ST)[OPER + r_ * LD + c_ * 4]) = B0;                   \
+        *reinterpret_cast<float4*>(&(ST)[OPER + (r_ + 16) * LD + c_ * 4]) = B1;            \
+    }
+#define WP_MMA(ST)                                                                         \
+    {                                                                                      \
+        const float4 x0 = *reinterpret_cast<const float4*>(&(ST)[li * LD + lh * 8]);       \
+        const float4 x1 = *reinterpret_cast<const float4*>(&(ST)[li * LD + lh * 8 + 4]);   \
+        const float4 y0 = *reinterpret_cast<const float4*>(&(ST)[OPER + li * LD + lh * 8]);     \
+        const float4 y1 = *reinterpret_cast<const float4*>(&(ST)[OPER + li * LD + lh * 8 + 4]); \
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.x, y0.x, acc, 0, 0, 0);              \
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.y, y0.y, acc, 0, 0, 0);              \
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.z, y0.z, acc, 0, 0, 0);              \
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.w, y0.w, acc, 0, 0, 0);              \
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x1.x, y1.x, acc, 0, 0, 0);              \
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x1.y, y1.y, acc, 0, 0, 0);              \
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x1.z, y1.z, acc, 0, 0, 0);              \
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x1.w, y1.w, acc, 0, 0, 0);              \
+    }
+    if (s0 < s1) {
+        float* st0 = my;
+        float* st1 = my + STAGE;
+        WP_FETCH(s0, a00, a01, b00, b01);
+        WP_FETCH(s0 + 1, a10, a11, b10, b11);
+        WP_STASH(st0, a00, a01, b00, b01);
+        WP_FETCH(s0 + 2, a00, a01, b00, b01);
+        const int n = s1 - s0;
+        int s = s0;
+        for (int it = 0; it < n / 2; ++it, s += 2) {
+            WP_STASH(st1, a10, a11, b10, b11);
+            WP_FETCH(s + 3, a10, a11, b10, b11);
+            WP_MMA(st0);
+            WP_STASH(st0, a00, a01, b00, b01);
+            WP_FETCH(s + 4, a00, a01, b00, b01);
+            WP_MMA(st1);
+        }
+        if (n & 1) WP_MMA(st0);
+    }
+#undef WP_FETCH
+#undef WP_STASH
+#undef WP_MMA
+    __syncthreads();
+    float* red = smem;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[(wave * BM + (r & 3) + 8 * (r >> 2) + 4 * lh) * (BN + 1) + li] = acc[r];
+    __syncthreads();
+    constexpr int RPT = BM / (256 / BN);
+    const int col = tid % BN, r0 = (tid / BN) * RPT;
+    float a4[RPT];
+#pragma unroll
+    for (int e = 0; e < RPT; ++e) {
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < KS; ++w) v += red[(w * BM + r0 + e) * (BN + 1) + col];
+        a4[e] = v;
+    }
+    const int rbase = m0 + r0;
+    epi_store_col<RPT>(g, a4, n0 + col, [rbase](int r) { return rbase + r; });
+}
+
 template <int BM, int BN, int BK, int KS>
 __global__ __launch_bounds__(64 * KS, KS == 8 ? 2 : 4) void gemm_heads_kernel(const dv_gemm_desc g, const LoadCfg lc,
                                                                const dv_heads_epi he) {
@@ -1028,6 +1141,16 @@ static int gemm_launch(const dv_gemm_desc& g, const LoadCfg& lc, int tiling, hip
     if (tiling == 8) return launch_cfg<32, 32, 128, 1, 1, 8>(g, lc, st);   // 8-way K split: twice the waves, half the chain
     if (tiling == 9) return launch_cfg<32, 32, 64, 1, 1, 8>(g, lc, st);
     if (tiling == 10) return launch_cfg<32, 32, 128, 1, 1, 16>(g, lc, st);
+    if (tiling == 13) {                   // wave-private staging, no barrier in the K loop (same restrictions)
+        const bool ok = g.a_kcontig && g.b_kcontig && g.A2 == nullptr && g.a_kscale == nullptr && (g.K & 3) == 0 &&
+                        lc.vecA == 4 && lc.vecB == 4;
+        if (ok) {
+            const int tiles = ((g.M + 31) / 32) * ((g.N + 31) / 32);
+            hipLaunchKernelGGL(gemm_wp_kernel, dim3(tiles), dim3(256), 0, st, g, lc);
+            DV_RETURN_LAUNCH();
+        }
+        return launch_cfg<32, 32, 64, 1, 1, 8>(g, lc, st);
+    }
     if (tiling == 11 || tiling == 12) {   // LDS-DMA staging (forward layout, 16-B aligned rows, K % 4 == 0)
         const bool ok = g.a_kcontig && g.b_kcontig && g.A2 == nullptr && g.a_kscale == nullptr && (g.K & 3) == 0 &&
                         lc.vecA == 4 && lc.vecB == 4;
