@@ -82,6 +82,30 @@ def test_weightnorm_linear(G, mods, dev):
     close(m.bias.grad, G['G1/db'])
 
 
+def test_weightnorm_linear_data_init(mods, dev):
+    """``data_init=True`` (src/layers.py:17-35): g starts as NaN; the first forward draws W ~ N(0, 0.05^2) and sets
+    g, bias so that the layer's output on THAT batch has mean 0 and standard deviation ``init_scale`` per feature
+    (Salimans & Kingma 2016, eq. 6).  The reference's own expression only runs for square layers (its
+    ``expand_as`` of the row norms) and then divides by the wrong axis; this pins the intended semantics, and that
+    the initialisation runs exactly once."""
+    blk, lyr = mods
+    torch.manual_seed(11)
+    m = lyr.WeightNormLinear(17, 9, data_init=True, init_scale=0.5).to(dev)
+    assert bool(torch.isnan(m.g).all())
+    x = torch.randn(64, 17, device=dev) * 3.0 + 1.0
+    y = m(x)
+    assert not bool(torch.isnan(m.g).any())
+    assert float(y.mean(0).abs().max()) < 1e-4
+    assert float((y.std(0) - 0.5).abs().max()) < 1e-4
+    assert 0.03 < float(m.weight.std()) < 0.07
+    g0, w0 = m.g.detach().clone(), m.weight.detach().clone()
+    m(x * 2.0)                                       # second call: plain weight-normalised forward, nothing re-drawn
+    assert torch.equal(m.g, g0) and torch.equal(m.weight, w0)
+    # and the forward is the weight-normalised affine map of src/layers.py:38-41
+    ref = (x @ m.weight.t()) * (m.g / m.weight.norm(2, 1)) + m.bias
+    close(y, ref.detach().cpu().numpy())
+
+
 @pytest.mark.parametrize('tag,wn,nl', [('G2a', False, 'elu'), ('G2b', True, 'softplus'), ('G2c', True, 'elu')])
 def test_mlp(G, mods, dev, tag, wn, nl):
     blk, _ = mods
