@@ -33,6 +33,10 @@ class Wait(C.Structure):       # dv_wait: a device-side wait carried by a launch
     _fields_ = [('flag', _p), ('ctr', _p), ('add', _i32), ('max_spins', _i32), ('err', _p)]
 
 
+class Publish(C.Structure):    # dv_publish: "this launch has started", published on entry
+    _fields_ = [('flag', _p), ('ctr', _p), ('add', _i32)]
+
+
 class Ymarg(C.Structure):      # dv_ymarg: y-marginalisation riding on the classifier-head launch
     _fields_ = [('label', _p), ('fp_ptr', _p), ('klfp', _p), ('log_prior', _f), ('log_prior_v', _p), ('c_kld', _p),
                 ('c_yl', _p), ('yl', _p), ('kld', _p), ('cfp', _p), ('dqy', _p), ('lddq', _i64)]
@@ -95,7 +99,7 @@ SIGNATURES = {
                                   C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_f), C.POINTER(_f), C.POINTER(_i32),
                                   C.POINTER(_f), _p],
     'dv_smalln_linear_bwd_weight': [_p, _i64, _p, _i64, _p, _i64, _i32, _p, _i64, _i32, _i32, _i32, _p, _i64, _p, _f,
-                                    _p],
+                                    _p, _p],
     'dv_ymarg_fwd': [_p, _i64, _p, _p, _p, _f, _p, _i32, _i32, _p, _p, _p],
     'dv_ymarg_fwdbwd': [_p, _i64, _p, _p, _p, _f, _p, _p, _p, _i32, _i32, _p, _p, _p, _p, _i64, _p],
     'dv_ymarg_bwd': [_p, _i64, _p, _p, _p, _f, _p, _p, _p, _i32, _i32, _p, _p, _i64, _p],
@@ -122,13 +126,13 @@ SIGNATURES = {
     'dv_flag_publish': [_p, _p, _i32, _p],
     'dv_flag_wait': [_p, _p, _i32, _p, _i32, _p],
     'dv_counter_add': [_p, _i32, _i64, _p],
-    'dv_counters_add2': [_p, _i32, _i64, _p, _i32, _i64, _p],
+    'dv_counters_add2': [_p, _i32, _i64, _p, _i32, _i64, _p, _p],
     'dv_fill_normal': [_p, _i64, _u64, _p, _p],
-    'dv_fill_normal_rows': [_p, _p, _i32, _u64, _p, _p],
+    'dv_fill_normal_rows': [_p, _p, _i32, _u64, _p, _p, _p],
 }
 
 _lib = None
-ABI_VERSION = 2     # DV_ABI_VERSION of include/drvae_hip.h
+ABI_VERSION = 3     # DV_ABI_VERSION of include/drvae_hip.h
 
 
 def load():

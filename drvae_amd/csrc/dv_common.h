@@ -77,3 +77,32 @@ __device__ __forceinline__ float dv_wave_sum_all(float v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;   // valid in every lane
 }
+// ---- chain ordering carried by launches (dv_wait / dv_publish arguments)
+// every workgroup of the launch parks on another chain's flag first (thread 0 polls, bounded; see dv_flag_wait)
+__device__ __forceinline__ void park_block(const dv_wait& pk) {
+    if (pk.flag == nullptr) return;
+    if (threadIdx.x == 0) {
+        const int want = pk.ctr[0] + pk.add;
+        const long long t0 = wall_clock64();
+        int n = 0;
+        while (__hip_atomic_load(pk.flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - want < 0) {
+            __builtin_amdgcn_s_sleep(4);
+            if (++n > pk.max_spins) {
+                atomicExch(pk.err, 1);
+                break;
+            }
+        }
+        if (blockIdx.x == 0) pk.err[1] += (int32_t)(wall_clock64() - t0);
+    }
+    __syncthreads();
+    (void)__hip_atomic_load(pk.flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);   // every wave acquires
+}
+
+
+// "this launch has started": workgroup 0 publishes on entry (see dv_flag_publish)
+__device__ __forceinline__ void publish_block0(const dv_publish& pub) {
+    if (pub.flag != nullptr && blockIdx.x == 0 && threadIdx.x == 0)
+        __hip_atomic_store(pub.flag, pub.ctr[0] + pub.add, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+

@@ -131,8 +131,9 @@ __global__ void counter_add_kernel(int32_t* c, int n_words, int64_t inc) {
     }
 }
 
-__global__ void counters_add2_kernel(int32_t* c1, int n1, int64_t inc1, int32_t* c2, int n2, int64_t inc2) {
+__global__ void counters_add2_kernel(int32_t* c1, int n1, int64_t inc1, int32_t* c2, int n2, int64_t inc2, dv_publish pub) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    publish_block0(pub);      // (before the counters move: pub.ctr may be one of them)
     int32_t* cs[2] = {c1, c2};
     const int ns[2] = {n1, n2};
     const int64_t incs[2] = {inc1, inc2};
@@ -188,7 +189,8 @@ __device__ __forceinline__ void philox_normal4(uint32_t c0, uint32_t c1, uint32_
 // one wave per row.
 __global__ __launch_bounds__(256) void fill_normal_rows_kernel(float* __restrict__ arena,
                                                                const int4* __restrict__ desc, int n_rows,
-                                                               uint64_t seed, const int32_t* __restrict__ ctr_dev) {
+                                                               uint64_t seed, const int32_t* ctr_dev, dv_wait park) {
+    park_block(park);         // (the counter below is read behind the wait: its advance is part of what is waited for)
     uint32_t step_lo = 0, step_hi = 0;
     if (ctr_dev) {
         step_lo = (uint32_t)ctr_dev[0];
@@ -378,21 +380,26 @@ extern "C" int dv_counter_add(int32_t* counter_lo_hi, int32_t n_words, int64_t i
 }
 
 extern "C" int dv_counters_add2(int32_t* c1, int32_t n1, int64_t inc1, int32_t* c2, int32_t n2, int64_t inc2,
-                                dv_stream_t stream) {
+                                const dv_publish* pub_in, dv_stream_t stream) {
     DV_REQUIRE(c1 && c2 && (n1 == 1 || n1 == 2) && (n2 == 1 || n2 == 2));
-    hipLaunchKernelGGL(counters_add2_kernel, dim3(1), dim3(64), 0, ST(stream), c1, n1, inc1, c2, n2, inc2);
+    dv_publish pub = pub_in ? *pub_in : dv_publish{nullptr, nullptr, 0};
+    DV_REQUIRE(pub.flag == nullptr || pub.ctr != nullptr);
+    hipLaunchKernelGGL(counters_add2_kernel, dim3(1), dim3(64), 0, ST(stream), c1, n1, inc1, c2, n2, inc2, pub);
     DV_RETURN_LAUNCH();
 }
 
 extern "C" int dv_fill_normal_rows(float* arena, const int32_t* desc, int32_t n_rows, uint64_t seed,
-                                   const int32_t* ctr_dev, dv_stream_t stream) {
+                                   const int32_t* ctr_dev, const dv_wait* park_in, dv_stream_t stream) {
     DV_REQUIRE(n_rows >= 0);
-    if (n_rows == 0) return DV_OK;
+    dv_wait park = park_in ? *park_in : dv_wait{nullptr, nullptr, 0, 0, nullptr};
+    DV_REQUIRE(park.flag == nullptr || (park.ctr && park.err && park.max_spins > 0));
+    if (n_rows == 0) return park.flag ? DV_ERR_UNSUPPORTED : DV_OK;
     DV_REQUIRE(arena && desc && (reinterpret_cast<uintptr_t>(desc) & 15) == 0);
     int blocks = (n_rows + 3) / 4;
     if (blocks > 4096) blocks = 4096;
+    if (park.flag != nullptr && blocks > 512) blocks = 512;      // a parked grid stays well below the chip's resident capacity
     hipLaunchKernelGGL(fill_normal_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, ST(stream), arena,
-                       reinterpret_cast<const int4*>(desc), n_rows, seed, ctr_dev);
+                       reinterpret_cast<const int4*>(desc), n_rows, seed, ctr_dev, park);
     DV_RETURN_LAUNCH();
 }
 

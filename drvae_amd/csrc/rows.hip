@@ -144,25 +144,6 @@ __global__ void reparam_bwd_kernel(const float* __restrict__ dz, int64_t ldz, co
 typedef dv_wait ParkArgs;
 typedef dv_bump CounterBump;
 
-__device__ __forceinline__ void park_block(const ParkArgs& pk) {
-    if (pk.flag == nullptr) return;
-    if (threadIdx.x == 0) {
-        const int want = pk.ctr[0] + pk.add;
-        const long long t0 = wall_clock64();
-        int n = 0;
-        while (__hip_atomic_load(pk.flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - want < 0) {
-            __builtin_amdgcn_s_sleep(4);
-            if (++n > pk.max_spins) {
-                atomicExch(pk.err, 1);
-                break;
-            }
-        }
-        if (blockIdx.x == 0) pk.err[1] += (int32_t)(wall_clock64() - t0);
-    }
-    __syncthreads();
-    (void)__hip_atomic_load(pk.flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);   // every wave acquires
-}
-
 __device__ __forceinline__ void bump_counters(const CounterBump& bump) {
     for (int t = 0; t < 2; ++t) {
         int32_t* c = bump.c[t];
@@ -790,8 +771,9 @@ __global__ __launch_bounds__(1024) void smalln_bwd_weight_kernel(const float* __
                                                                  int64_t lda1, int K1, const float* __restrict__ a2,
                                                                  int64_t lda2, int K2, int M, int N,
                                                                  float* __restrict__ dW, int64_t ldd,
-                                                                 float* __restrict__ db, float beta) {
+                                                                 float* __restrict__ db, float beta, dv_publish pub) {
     __shared__ float part[kSnRG][kMaxSmallN][kSnCols];
+    publish_block0(pub);
     const int c = threadIdx.x % kSnCols, rg = threadIdx.x / kSnCols;
     const int k = blockIdx.x * kSnCols + c, KT = K1 + K2;   // k == KT is the bias column
     float acc[kMaxSmallN];
@@ -1727,12 +1709,14 @@ extern "C" int dv_smalln_linear_bwd_data(const float* dprobs, int64_t lddp, cons
 extern "C" int dv_smalln_linear_bwd_weight(const float* dprobs, int64_t lddp, const float* probs, int64_t ldp,
                                            const float* a1, int64_t lda1, int32_t K1, const float* a2,
                                            int64_t lda2, int32_t K2, int32_t M, int32_t N, float* dW, int64_t ldd,
-                                           float* db, float beta, dv_stream_t stream) {
+                                           float* db, float beta, const dv_publish* pub_in, dv_stream_t stream) {
     DV_REQUIRE(M >= 0 && N >= 1 && N <= kMaxSmallN && K1 >= 0 && K2 >= 0);
     DV_REQUIRE(dprobs && a1 && dW && (a2 || K2 == 0));
+    dv_publish pub = pub_in ? *pub_in : dv_publish{nullptr, nullptr, 0};
+    DV_REQUIRE(pub.flag == nullptr || pub.ctr != nullptr);
     hipLaunchKernelGGL(smalln_bwd_weight_kernel, dim3((K1 + K2 + 1 + kSnCols - 1) / kSnCols), dim3(1024), 0,
                        ST(stream), dprobs,
-                       lddp, probs, ldp, probs != nullptr, a1, lda1, K1, a2, lda2, K2, M, N, dW, ldd, db, beta);
+                       lddp, probs, ldp, probs != nullptr, a1, lda1, K1, a2, lda2, K2, M, N, dW, ldd, db, beta, pub);
     DV_RETURN_LAUNCH();
 }
 

@@ -211,6 +211,10 @@ class FusedStep(StepSchedule):
         # the side chain's second wait rides on the row kernel behind it (dv_wait argument of dv_kl_rows_fwd)
         # instead of being a launch of its own
         self.fold_waits = os.environ.get('DRVAE_FOLD_WAITS', '1') != '0'
+        # the side chain's tail (bit mask): 1 / 4 = its two publishes ride on the entry of the launch behind them
+        # (classifier dW; the counter launch), 2 = the wait in front of the next step's Philox draws is a park of the
+        # draw launch itself -- measured SLOWER (356 workgroups polling one flag: +10 us/step), hence off
+        self.fold_tail = int(os.environ.get('DRVAE_FOLD_TAIL', '5'))
         self.noise_ahead = False          # set by capture(): the side chain draws the NEXT step's noise behind the join
         self._noise_stale = True          # (then) the noise buffer does not hold the draws of the current Philox counter
         self._adam_n = None
@@ -722,7 +726,8 @@ class FusedStep(StepSchedule):
 
         def wgrad_clf(*args):
             if late:
-                leaf.append(lambda: K.smalln_bwd_weight(*args))
+                # (its entry also tells the main chain that the side chain's data gradients are final: see below)
+                leaf.append(lambda pub=None: K.smalln_bwd_weight(*args, publish=pub))
             else:
                 K.smalln_bwd_weight(*args)
 
@@ -806,10 +811,18 @@ class FusedStep(StepSchedule):
                            xidx=p.tgt, sd_act='softplus', sd_shift=1e-3)
         if mode == 5 and self._rec == 'side':
             side_backward()
-            K.flag_publish(self.flags[1:2], self.side_ctr)       # DZ1B / DZ2F / side gradients are final
-            if late:
+            # DZ1B / DZ2F / side gradients are final: published on entry of the first leaf launch behind them (the
+            # classifier's weight gradient) where there is one, else by a launch of its own
+            tail = (self.fold_tail & 1) and late and len(leaf) > 0
+            if tail:
+                leaf[0](pub=(self.flags[1:2], self.side_ctr, 1))
+                for fn in leaf[1:]:
+                    fn()
+            else:
+                K.flag_publish(self.flags[1:2], self.side_ctr)
                 for fn in leaf:
                     fn()
+            if late:
                 if side_loss:
                     a = self.arena
                     K.flag_wait(self.flags[4:5], self.side_ctr, self.sync_err[8:10])
@@ -820,10 +833,19 @@ class FusedStep(StepSchedule):
                     self._loss_scalars()   # a leaf too; the wait above also covers the main chain's NLL rows
                 if self.noise_ahead:
                     # the next step's N(0,1) draws: every reader of this step's is through once the encoder
-                    # backward has started (the main chain publishes that), and the Philox counter has advanced
-                    K.flag_wait(self.flags[5:6], self.side_ctr, self.sync_err[10:12])
-                    K.fill_normal_rows(p.noise, p.noise_desc, self.seed, self.rng_ctr)
-                K.flag_publish(self.flags[3:4], self.side_ctr)   # ... and now the side chain's late work is final
+                    # backward has started (the main chain publishes that), and the Philox counter has advanced;
+                    # the draw launch parks on that flag itself (``fold_tail``) or behind a wait launch
+                    w5 = (self.flags[5:6], self.side_ctr, self.sync_err[10:12])
+                    if self.fold_tail & 2:
+                        K.fill_normal_rows(p.noise, p.noise_desc, self.seed, self.rng_ctr, park=w5)
+                    else:
+                        K.flag_wait(*w5)
+                        K.fill_normal_rows(p.noise, p.noise_desc, self.seed, self.rng_ctr)
+                # ... and now the side chain's late work is final: published by the counter launch on entry
+                if self.fold_tail & 4:
+                    K.counters_add2(self.side_ctr, 1, self.side_t, 1, publish=(self.flags[3:4], self.side_ctr, 1))
+                    return
+                K.flag_publish(self.flags[3:4], self.side_ctr)
             K.counters_add2(self.side_ctr, 1, self.side_t, 1)
             return
         if mode < 2:

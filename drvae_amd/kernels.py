@@ -218,6 +218,16 @@ def _wait(park):
     return C.byref(w)
 
 
+def _publish(pub):
+    """(flag, ctr[, add]) -> dv_publish (None: nothing published)"""
+    if pub is None:
+        return None
+    w = _lib.Publish()
+    w.flag, w.ctr = _i32(pub[0]), _i32(pub[1])
+    w.add = pub[2] if len(pub) > 2 else 1
+    return C.byref(w)
+
+
 def _bump(counters):
     """up to two (counter, inc) -> dv_bump (None / empty: nothing)"""
     cs = [c for c in (counters or ()) if c[0] is not None]
@@ -393,12 +403,14 @@ def smalln_bwd_data(dsts, dprobs, probs, W):
                'dv_smalln_linear_bwd_data')
 
 
-def smalln_bwd_weight(dW, db, dprobs, probs, a1, a2=None, beta=0.0):
+def smalln_bwd_weight(dW, db, dprobs, probs, a1, a2=None, beta=0.0, publish=None):
+    """``publish`` = (flag, ctr[, add]): the launch publishes on entry that everything in front of it is complete"""
     M, N = dprobs.shape
     K1, K2 = a1.shape[1], (a2.shape[1] if a2 is not None else 0)
     _lib.check(_lib.load().dv_smalln_linear_bwd_weight(_f32(dprobs), _ld(dprobs), _f32(probs), _ld(probs), _f32(a1),
                                                        _ld(a1), K1, _f32(a2), _ld(a2), K2, M, N, _f32(dW), _ld(dW),
-                                                       _f32(db), beta, _stream()), 'dv_smalln_linear_bwd_weight')
+                                                       _f32(db), beta, _publish(publish), _stream()),
+               'dv_smalln_linear_bwd_weight')
 
 
 def ymarg_fwd(yl, kld, qy, label, fp_ptr, klfp, log_prior):
@@ -601,17 +613,18 @@ def counter_add(counter, inc=1):
     _lib.check(_lib.load().dv_counter_add(_i32(counter), counter.numel(), inc, _stream()), 'dv_counter_add')
 
 
-def counters_add2(c1, inc1, c2, inc2):
-    _lib.check(_lib.load().dv_counters_add2(_i32(c1), c1.numel(), inc1, _i32(c2), c2.numel(), inc2, _stream()),
-               'dv_counters_add2')
+def counters_add2(c1, inc1, c2, inc2, publish=None):
+    """``publish`` = (flag, ctr[, add]) goes out on entry, before the counters move (ctr may be one of them)"""
+    _lib.check(_lib.load().dv_counters_add2(_i32(c1), c1.numel(), inc1, _i32(c2), c2.numel(), inc2, _publish(publish),
+                                            _stream()), 'dv_counters_add2')
 
 
-def fill_normal_rows(arena, desc, seed, ctr_dev=None):
+def fill_normal_rows(arena, desc, seed, ctr_dev=None, park=None):
     """row-keyed N(0,1) draws of a train step's noise arena: ``desc`` (R,4) int32 = {offset, width, draw id,
     global row}; ``ctr_dev`` counts draw events (see ``dv_fill_normal_rows``)"""
     assert arena.is_contiguous() and desc.dim() == 2 and desc.shape[1] == 4
-    _lib.check(_lib.load().dv_fill_normal_rows(_f32(arena), _i32(desc), desc.shape[0], seed, _i32(ctr_dev), _stream()),
-               'dv_fill_normal_rows')
+    _lib.check(_lib.load().dv_fill_normal_rows(_f32(arena), _i32(desc), desc.shape[0], seed, _i32(ctr_dev), _wait(park),
+                                               _stream()), 'dv_fill_normal_rows')
 
 
 def fill_normal(out, seed, ctr_dev=None):

@@ -30,7 +30,7 @@ extern "C" {
 
 typedef void* dv_stream_t;
 
-#define DV_ABI_VERSION 2
+#define DV_ABI_VERSION 3
 
 enum { DV_OK = 0, DV_ERR_ARG = -1, DV_ERR_LAUNCH = -2, DV_ERR_UNSUPPORTED = -3 };
 
@@ -63,6 +63,15 @@ typedef struct dv_wait {
     int32_t max_spins;
     int32_t* err;
 } dv_wait;
+
+/* "this launch has started, so everything in front of it in its stream is complete": a launch that carries a
+ * dv_publish stores flag[0] = ctr[0] + add (release, agent scope) on entry, like dv_flag_publish but without a
+ * launch of its own (dv_gemm_desc has the same three fields).  flag == NULL / NULL pointer: nothing published */
+typedef struct dv_publish {
+    int32_t* flag;
+    const int32_t* ctr;
+    int32_t add;
+} dv_publish;
 
 /* up to two device counters (1 or 2 int32 words each: int32 / uint64 little-endian) advanced by a
  * launch that carries the bump (see dv_counters_add2); c == NULL: unused slot */
@@ -359,7 +368,7 @@ int dv_smalln_linear_bwd_data(const float* dprobs, int64_t lddp, const float* pr
 int dv_smalln_linear_bwd_weight(const float* dprobs, int64_t lddp, const float* probs, int64_t ldp,
                                 const float* a1, int64_t lda1, int32_t K1, const float* a2, int64_t lda2,
                                 int32_t K2, int32_t M, int32_t N, float* dW, int64_t ldd, float* db, float beta,
-                                dv_stream_t stream);
+                                const dv_publish* pub, dv_stream_t stream);
 
 /* y-marginalisation of src/DrVAE.py:503-534 / src/VFAE.py:331-390 over the stacked
  * "fprop" rows.  For every (l, i) classifier row r (R rows):
@@ -528,8 +537,9 @@ int dv_counter_add(int32_t* counter_lo_hi, int32_t n_words, int64_t inc, dv_stre
  * halt[4] ... (the err[0] of the dv_wait sites of a step, laid out as (err, ticks) pairs); if any is
  * non-zero the loss scalars come out NaN and the optimiser sweep leaves p / m / v untouched. */
 /* two device counters in one launch (the optimiser step count and the Philox counter of a train step) */
+/* `pub` (optional): published on entry, BEFORE the counters move (its ctr may be one of them) */
 int dv_counters_add2(int32_t* c1, int32_t n1, int64_t inc1, int32_t* c2, int32_t n2, int64_t inc2,
-                     dv_stream_t stream);
+                     const dv_publish* pub, dv_stream_t stream);
 
 /* Device-side fork/join between two launch chains that run concurrently (two root branches of one
  * hipGraph; no reference counterpart -- replaces graph edges, which cost ~27 us per fork+join on the
@@ -551,7 +561,7 @@ int dv_fill_normal(float* out, int64_t n, uint64_t seed, const int32_t* ctr_dev,
  * EVENTS (one per train step: advance it by 1), so every rank holds the same value; a rank that owns rows
  * [rB, (r+1)B) of the global minibatch draws exactly the values a single process would draw for them. */
 int dv_fill_normal_rows(float* arena, const int32_t* desc, int32_t n_rows, uint64_t seed, const int32_t* ctr_dev,
-                        dv_stream_t stream);
+                        const dv_wait* park, dv_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -476,7 +476,9 @@ def smalln_bwd_data(dsts, dprobs, probs, W):
         _acc(dst, v, beta)
 
 
-def smalln_bwd_weight(dW, db, dprobs, probs, a1, a2=None, beta=0.0):
+def smalln_bwd_weight(dW, db, dprobs, probs, a1, a2=None, beta=0.0, publish=None):
+    if publish is not None:
+        flag_publish(*publish)
     dl = _dlogits(dprobs, probs)
     x = torch.cat([a1, a2], 1) if a2 is not None else a1
     _acc(dW, dl.t() @ x, beta)
@@ -704,7 +706,9 @@ def flag_wait(flag, ctr, err, add=1, max_spins=None):
         err[0] = 1                            # (err[1], the parked-time statistic, stays 0)
 
 
-def counters_add2(c1, inc1, c2, inc2):
+def counters_add2(c1, inc1, c2, inc2, publish=None):
+    if publish is not None:
+        flag_publish(*publish)
     counter_add(c1, inc1)
     counter_add(c2, inc2)
 
@@ -751,9 +755,11 @@ def batch_masks(B, L, *, n_tot, kl_rate, pert_rate, yl_rate, beta, c_nll, w_recl
         label[:LB] = torch.where(py, -2 - y[src].to(label.dtype).repeat(L), torch.zeros_like(label[:LB]))
 
 
-def fill_normal_rows(arena, desc, seed, ctr_dev=None):
+def fill_normal_rows(arena, desc, seed, ctr_dev=None, park=None):
     """Stand-in only (NOT bit-compatible with the device Philox stream), but keyed the same way: a value
     depends on (seed, step, draw id, global row, column) only."""
+    if park is not None:
+        flag_wait(*park)
     base = 0 if ctr_dev is None else (int(ctr_dev[1]) << 32 | (int(ctr_dev[0]) & 0xffffffff))
     g = torch.Generator(device='cpu')
     for off, width, draw, grow in desc.cpu().tolist():

@@ -39,7 +39,7 @@ def test_library_exports_every_symbol(lib):
     for name in _header_decls():
         assert hasattr(lib, name), name
     from drvae_amd import _lib
-    assert lib.dv_abi_version() == _lib.ABI_VERSION == 2
+    assert lib.dv_abi_version() == _lib.ABI_VERSION == 3
     assert 'dv_arm_park' not in _lib.SIGNATURES and not hasattr(lib, 'dv_arm_park')     # no armed (hidden) state
     assert lib.dv_error_string(0) == b'ok'
     assert lib.dv_error_string(-1) == b'invalid argument'
@@ -61,7 +61,8 @@ def test_gemm_desc_layout_matches_header():
     assert names == [f[0] for f in GemmDesc._fields_]
 
 
-@pytest.mark.parametrize('cname,pyname', [('dv_wait', 'Wait'), ('dv_bump', 'Bump'), ('dv_loss_term', 'LossTerm')])
+@pytest.mark.parametrize('cname,pyname', [('dv_wait', 'Wait'), ('dv_bump', 'Bump'), ('dv_loss_term', 'LossTerm'),
+                                          ('dv_publish', 'Publish')])
 def test_small_struct_layouts_match_header(cname, pyname):
     from drvae_amd import _lib
     src = open(os.path.join(ROOT, 'include', 'drvae_hip.h')).read()

@@ -470,6 +470,55 @@ def test_adam_gated_sweep(K, dev, n, lo, hi):
     close(p, want, rtol=0, atol=0)
 
 
+def test_publish_and_park_on_side_tail_launches(K, dev):
+    """dv_publish on dv_smalln_linear_bwd_weight / dv_counters_add2 (published on entry, before the counters move) and
+    dv_wait on dv_fill_normal_rows (the draw launch parks, and reads the Philox counter behind the wait)"""
+    flag = torch.zeros(2, dtype=torch.int32, device=dev)
+    ctr = torch.tensor([6], dtype=torch.int32, device=dev)
+    t = torch.tensor([7], dtype=torch.int32, device=dev)
+    K.counters_add2(ctr, 1, t, 1, publish=(flag[0:1], ctr, 1))
+    torch.cuda.synchronize()
+    assert flag[0].item() == 7 and ctr.item() == 7 and t.item() == 8       # published 6 + 1, THEN advanced
+    K.counters_add2(ctr, 1, t, 1)
+    torch.cuda.synchronize()
+    assert flag[0].item() == 7 and ctr.item() == 8
+    # classifier weight gradient with a publish: same numbers as without
+    M, N, K1 = 37, 2, 50
+    dp, pr = rnd(dev, M, N, seed=1), torch.softmax(rnd(dev, M, N, seed=2), 1)
+    a1 = rnd(dev, M, K1, seed=3)
+    dW, db, dW2, db2 = (torch.zeros(N, K1, device=dev), torch.zeros(N, device=dev), torch.zeros(N, K1, device=dev),
+                        torch.zeros(N, device=dev))
+    K.smalln_bwd_weight(dW, db, dp, pr, a1)
+    K.smalln_bwd_weight(dW2, db2, dp, pr, a1, publish=(flag[1:2], ctr, 3))
+    torch.cuda.synchronize()
+    assert flag[1].item() == 11
+    close(dW2, dW, rtol=0, atol=0)
+    close(db2, db, rtol=0, atol=0)
+    # parked draws: the Philox counter is advanced by the publisher, on another queue, before it publishes
+    desc = torch.tensor([[0, 40, 0, 0], [40, 40, 0, 1], [80, 33, 1, 0]], dtype=torch.int32, device=dev)
+    rng = torch.tensor([5, 0], dtype=torch.int32, device=dev)
+    want, got = torch.zeros(113, device=dev), torch.zeros(113, device=dev)
+    rng6 = torch.tensor([6, 0], dtype=torch.int32, device=dev)
+    K.fill_normal_rows(want, desc, 99, rng6)
+    f2 = torch.zeros(1, dtype=torch.int32, device=dev)
+    err = torch.zeros(2, dtype=torch.int32, device=dev)
+    side = _other_queue_stream(K, dev)
+    torch.cuda.synchronize()
+    K.fill_normal_rows(got, desc, 99, rng, park=(f2, ctr, err, 1))
+    with torch.cuda.stream(side):
+        torch.cuda._sleep(2000000)
+        K.counter_add(rng, 1)
+        K.flag_publish(f2, ctr, 1)
+    torch.cuda.synchronize()
+    assert int(err[0]) == 0 and int(err[1]) > 0
+    close(got, want, rtol=0, atol=0)
+    # a wait nobody answers times out, sets the sticky word and still returns
+    err2 = torch.zeros(2, dtype=torch.int32, device=dev)
+    K.fill_normal_rows(got, desc, 99, rng, park=(f2, ctr, err2, 5, 50))
+    torch.cuda.synchronize()
+    assert int(err2[0]) == 1
+
+
 def test_park_and_bump_arguments(K, dev):
     """dv_wait / dv_bump arguments: a rows_segment_sum given ``park`` parks on a flag published later from another
     queue, a reparam_bwd_seg given ``bump`` advances the counters; nothing is remembered between calls"""

@@ -39,13 +39,13 @@ t = buf.cpu().numpy().reshape(nwg, 64)
 used = t[:, 0] != 0
 t = t[used]
 print('kernel %.1f us (stamped build), workgroups stamped: %d' % (e0.elapsed_time(e1) * 1e3, len(t)))
-t0 = t[:, 0].min()
-span = (t.max() - t0)
-print('first entry -> last stamp: %d ticks; entries spread over %d ticks' % (span, t[:, 0].max() - t0))
+# (s_memtime is a per-XCD counter with its own base: only differences inside one workgroup mean anything)
+last = t.max(axis=1)
+print('workgroup life (entry -> last stamp): median %d ticks, min %d, max %d' % (np.median(last - t[:, 0]), (last - t[:, 0]).min(), (last - t[:, 0]).max()))
 print('prologue (entry -> loop start): median %d ticks' % np.median(t[:, 1] - t[:, 0]))
 names = ['compute', 'stage_store', 'fetch', 'barrier']
 n_ph = 0
-for j in range(2, 64, 4):
+for j in range(2, 61, 4):
     if (t[:, j + 3] != 0).all():
         n_ph += 1
 d = {k: [] for k in names}
