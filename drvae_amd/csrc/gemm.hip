@@ -19,9 +19,12 @@
 //   T64 : 64x64x32 tile, 2x2 waves, one 32x32 accumulator each      (default)
 //   T32K: 32x32x64 tile, the 4 waves split K and reduce through LDS  (small M*N: 4x the workgroups)
 //   T128: 128x128x32 tile, 2x2 waves, 2x2 accumulators each          (wide config)
+#include <type_traits>
+
 #include "dv_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // tuning builds only (tools/gemm_lab.sh): knock out one phase of the fast-path K loop to see what
 // bounds it. 1: no global loads in the loop, 2: VALU fma instead of the MFMAs, 4: no LDS stores in
@@ -285,13 +288,18 @@ constexpr int gemm_smem_floats() {
 // One workgroup's share of one product: `bid` of `nwg` workgroups.  PAIR (dv_gemm_heads): the BN staged B lines
 // are the head-0 rows [tn*BN/2, +BN/2) followed by the head-1 rows [split + tn*BN/2, +BN/2) of W, and the
 // epilogue sees both heads of an element in one thread.
-template <int BM, int BN, int BK, int WM, int WN, int KS, bool AKC, bool BKC, bool PAIR = false>
+// MI16: the product runs on v_mfma_f32_16x16x4_f32 (16x16 accumulator tiles, four k-groups of lanes) instead of
+// v_mfma_f32_32x32x2_f32 -- the same matrix-pipe cycles, LDS reads and registers per output element.
+template <int BM, int BN, int BK, int WM, int WN, int KS, bool AKC, bool BKC, bool PAIR = false, bool MI16 = false>
 __device__ __forceinline__ void gemm_body(const dv_gemm_desc& g, const LoadCfg& lc, float* smem, int bid, int nwg,
                                           const dv_heads_epi* he = nullptr) {
     static_assert(!PAIR || (AKC && BKC && KS > 1 && WM == 1 && WN == 1), "paired heads: forward layout, K-split tiling");
     constexpr int HB = BN / 2;
-    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    constexpr int KW = BK / KS, KH = KW / 2;
+    static_assert(!MI16 || (KS == 1 && !PAIR), "16x16x4 tiles: unsplit K only");
+    constexpr int TS = MI16 ? 16 : 32;            // edge of an MFMA output tile
+    constexpr int AR = MI16 ? 4 : 16;             // accumulator registers per tile
+    constexpr int TM = BM / WM / TS, TN = BN / WN / TS;
+    constexpr int KW = BK / KS, KH = KW / (MI16 ? 4 : 2);     // consecutive k of a K tile held by one lane
     constexpr int LDA_S = (AKC ? BK : BM) + 4;
     constexpr int LDB_S = (BKC ? BK : BN) + 4;
     constexpr int A_ELEMS = (AKC ? BM : BK) * LDA_S;
@@ -316,7 +324,7 @@ __device__ __forceinline__ void gemm_body(const dv_gemm_desc& g, const LoadCfg& 
     };
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int li = lane & 31, lh = lane >> 5;
+    const int li = MI16 ? (lane & 15) : (lane & 31), lh = MI16 ? (lane >> 4) : (lane >> 5);
     const int ks_id = wave / (WM * WN);
     const int wm = (wave % (WM * WN)) / WN, wn = wave % WN;
 
@@ -405,13 +413,13 @@ __device__ __forceinline__ void gemm_body(const dv_gemm_desc& g, const LoadCfg& 
             *reinterpret_cast<float4*>(&sB[(b_l + p * B_LPP) * LDB_S + b_c * 4]) = rb[p];
     };
 
-    f32x16 acc[TM][TN];
+    typename std::conditional<MI16, f32x4, f32x16>::type acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < AR; ++r) acc[i][j][r] = 0.f;
 
     const int kb = ks_id * KW + lh * KH;   // this lane's first k inside the tile
     // all fragment reads of a tile are issued up front (in-order LDS returns: the first MFMA only
@@ -420,7 +428,7 @@ __device__ __forceinline__ void gemm_body(const dv_gemm_desc& g, const LoadCfg& 
         const float* sB = sA + A_ELEMS;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const int row = wm * TM * 32 + i * 32 + li;
+            const int row = wm * TM * TS + i * TS + li;
 #pragma unroll
             for (int s = 0; s < KH; s += 4) {
                 if (AKC) {
@@ -437,7 +445,7 @@ __device__ __forceinline__ void gemm_body(const dv_gemm_desc& g, const LoadCfg& 
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int col = wn * TN * 32 + j * 32 + li;
+            const int col = wn * TN * TS + j * TS + li;
 #pragma unroll
             for (int s = 0; s < KH; s += 4) {
                 if (BKC) {
@@ -460,7 +468,9 @@ __device__ __forceinline__ void gemm_body(const dv_gemm_desc& g, const LoadCfg& 
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    if (DV_DBG & 2)
+                    if constexpr (MI16)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][s], fb[j][s], acc[i][j], 0, 0, 0);
+                    else if (DV_DBG & 2)
                         acc[i][j][s & 15] += fa[i][s] * fb[j][s];
                     else
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s], fb[j][s], acc[i][j], 0, 0, 0);
@@ -716,7 +726,19 @@ __device__ __forceinline__ void gemm_body(const dv_gemm_desc& g, const LoadCfg& 
         __syncthreads();
     }
 
-    if (KS == 1) {
+    if constexpr (MI16) {
+        // a lane holds rows 4*(lane/16) .. +3 of column lane%16 of each 16x16 tile
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                float a4[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) a4[r] = acc[i][j][r];
+                const int rbase = m0 + wm * TM * TS + i * TS + 4 * lh;
+                epi_store_col<4>(g, a4, n0 + wn * TN * TS + j * TS + li, [rbase](int r) { return rbase + r; });
+            }
+    } else if constexpr (KS == 1) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -777,7 +799,7 @@ __device__ __forceinline__ void publish_on_entry(const dv_gemm_desc& g) {
         __hip_atomic_store(g.pub_flag, g.pub_ctr[0] + g.pub_add, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-template <int BM, int BN, int BK, int WM, int WN, int KS, bool AKC, bool BKC>
+template <int BM, int BN, int BK, int WM, int WN, int KS, bool AKC, bool BKC, bool MI16 = false>
 __global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 16) ? 4 : (BM >= 128 || BK >= 128) ? 2 : (WM * WN * KS == 8 ? (BM * BN == 1024 ? DV_LB8 : 2) : 4)) void gemm_kernel(const dv_gemm_desc g, const LoadCfg lc) {
     __shared__ __attribute__((aligned(16))) float smem[gemm_smem_floats<BM, BN, BK, KS, AKC, BKC>()];
     publish_on_entry(g);
@@ -789,7 +811,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 16) ? 4 : (BM >
         if (ph == 3) __builtin_amdgcn_s_sleep(18);
     }
 #endif
-    gemm_body<BM, BN, BK, WM, WN, KS, AKC, BKC>(g, lc, smem, blockIdx.x, gridDim.x);
+    gemm_body<BM, BN, BK, WM, WN, KS, AKC, BKC, false, MI16>(g, lc, smem, blockIdx.x, gridDim.x);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1043,16 +1065,16 @@ inline int vec_width(const void* p, int64_t ld) {
 static int g_lds_pad = 0;
 inline int lds_pad(int bm, int tiles) { return (bm <= 32 && tiles >= 512) ? g_lds_pad : 0; }
 
-template <int BM, int BN, int BK, int WM, int WN, int KS>
+template <int BM, int BN, int BK, int WM, int WN, int KS, bool MI16 = false>
 int launch_cfg(const dv_gemm_desc& g, const LoadCfg& lc, hipStream_t st) {
     const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
     dim3 grid(tiles), block(64 * WM * WN * KS);
     if (g.a_kcontig && g.b_kcontig)
-        hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, WM, WN, KS, true, true>), grid, block, lds_pad(BM, tiles), st, g, lc);
+        hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, WM, WN, KS, true, true, MI16>), grid, block, lds_pad(BM, tiles), st, g, lc);
     else if (g.a_kcontig && !g.b_kcontig)
-        hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, WM, WN, KS, true, false>), grid, block, lds_pad(BM, tiles), st, g, lc);
+        hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, WM, WN, KS, true, false, MI16>), grid, block, lds_pad(BM, tiles), st, g, lc);
     else if (!g.a_kcontig && !g.b_kcontig)
-        hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, WM, WN, KS, false, false>), grid, block, lds_pad(BM, tiles), st, g, lc);
+        hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, WM, WN, KS, false, false, MI16>), grid, block, lds_pad(BM, tiles), st, g, lc);
     else
         return DV_ERR_UNSUPPORTED;
     DV_RETURN_LAUNCH();
@@ -1133,6 +1155,13 @@ static int gemm_launch(const dv_gemm_desc& g, const LoadCfg& lc, int tiling, hip
             if (rc != DV_OK) return rc;
         }
         return launch_cfg<128, 128, 32, 2, 2, 1>(g, lc, st);
+    }
+    if (tiling == 16) {                   // the 128x128 tiling on v_mfma_f32_16x16x4_f32
+        if (g.a_colsum != nullptr && !g.a_kcontig) {
+            const int rc = dv_colsum(g.A, g.lda, g.K, g.M, g.a_colsum, g.colsum_beta, st);
+            if (rc != DV_OK) return rc;
+        }
+        return launch_cfg<128, 128, 32, 2, 2, 1, true>(g, lc, st);
     }
     if (tiling == 4) return launch_cfg<32, 32, 128, 1, 1, 4>(g, lc, st);
     if (tiling == 5) return launch_cfg<64, 64, 64, 2, 2, 2>(g, lc, st);   // 8 waves: 2 per SIMD
