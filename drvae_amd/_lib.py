@@ -94,7 +94,7 @@ SIGNATURES = {
     'dv_cat_terms_fwd': [_p, _i64, _i32, _i32, _p, _p, _i64, _p, _p, _i64, _p, _p, _p],
     'dv_cat_terms_bwd': [_p, _i64, _i32, _i32, _p, _p, _i64, _p, _p, _i64, _p, _p, _i64, _f, _p],
     'dv_smalln_linear_fwd': [_p, _i64, _i32, _p, _i64, _i32, _p, _i64, _p, _i32, _i32, _p, _i64, _p, _i64,
-                             C.POINTER(Ymarg), _p],
+                             C.POINTER(Ymarg), _p, _p],
     'dv_smalln_linear_bwd_data': [_p, _i64, _p, _i64, _p, _i64, _i32, _i32, _i32, C.POINTER(_p), C.POINTER(_i64),
                                   C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_f), C.POINTER(_f), C.POINTER(_i32),
                                   C.POINTER(_f), _p],

@@ -800,7 +800,7 @@ __device__ __forceinline__ void publish_on_entry(const dv_gemm_desc& g) {
 }
 
 template <int BM, int BN, int BK, int WM, int WN, int KS, bool AKC, bool BKC, bool MI16 = false>
-__global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 16) ? 4 : (BM >= 128 || BK >= 128) ? 2 : (WM * WN * KS == 8 ? (BM * BN == 1024 ? DV_LB8 : 2) : 4)) void gemm_kernel(const dv_gemm_desc g, const LoadCfg lc) {
+__global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 16) ? 4 : (BM >= 128 || BK >= 128) ? 2 : (WM * WN * KS == 8 ? (BM * BN == 1024 ? DV_LB8 : 2) : (BK == 32 && BM == 32 ? 7 : 4))) void gemm_kernel(const dv_gemm_desc g, const LoadCfg lc) {
     __shared__ __attribute__((aligned(16))) float smem[gemm_smem_floats<BM, BN, BK, KS, AKC, BKC>()];
     publish_on_entry(g);
 #if DV_STAGGER
@@ -1030,7 +1030,7 @@ __global__ __launch_bounds__(256, 4) void gemm_wp_kernel(const dv_gemm_desc g, c
 }
 
 template <int BM, int BN, int BK, int KS>
-__global__ __launch_bounds__(64 * KS, KS == 8 ? 2 : 4) void gemm_heads_kernel(const dv_gemm_desc g, const LoadCfg lc,
+__global__ __launch_bounds__(64 * KS, KS == 8 ? 2 : (BK == 32 ? 7 : 4)) void gemm_heads_kernel(const dv_gemm_desc g, const LoadCfg lc,
                                                                const dv_heads_epi he) {
     __shared__ __attribute__((aligned(16))) float smem[gemm_smem_floats<BM, BN, BK, KS, true, true>()];
     publish_on_entry(g);
@@ -1083,10 +1083,10 @@ int launch_cfg(const dv_gemm_desc& g, const LoadCfg& lc, hipStream_t st) {
 }  // namespace
 
 static int g_force_tiling = 0;   // 0 = heuristic; 1 = T64, 2 = T32K, 3 = T128 (tests / tuning)
-static int g_opt[8] = {-1, 0, 0, 0, 0, 0, 0, 0};  // [0] = tile map (0 linear, 1 XCD chunk-major, >= 2 row bands, -1 by tiling)
+static int g_opt[10] = {-1, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // [0] = tile map (0 linear, 1 XCD chunk-major, >= 2 row bands, -1 by tiling)
 
 extern "C" int dv_gemm_set_option(int key, int value) {
-    if (key < 0 || key >= 8) return DV_ERR_ARG;
+    if (key < 0 || key >= 10) return DV_ERR_ARG;
     g_opt[key] = value;
     if (key == 1) g_lds_pad = value;
 #if DV_STAMP
@@ -1147,6 +1147,9 @@ static int gemm_prepare(const dv_gemm_desc* d, LoadCfg& lc, int& tiling) {
     return DV_OK;
 }
 
+// tiles of 32x32 from which a product runs on the high-occupancy tiling (dv_gemm_set_option(8, n); 0 = default)
+static int dense_min_tiles() { return g_opt[8] > 0 ? g_opt[8] : 512; }
+
 static int gemm_launch(const dv_gemm_desc& g, const LoadCfg& lc, int tiling, hipStream_t st) {
     if (tiling < 0) return DV_OK;
     if (tiling == 3) {
@@ -1163,6 +1166,7 @@ static int gemm_launch(const dv_gemm_desc& g, const LoadCfg& lc, int tiling, hip
         }
         return launch_cfg<128, 128, 32, 2, 2, 1, true>(g, lc, st);
     }
+    if (tiling == 17) return launch_cfg<32, 32, 32, 1, 1, 4>(g, lc, st);    // lab: half the K tile, seven workgroups per CU
     if (tiling == 4) return launch_cfg<32, 32, 128, 1, 1, 4>(g, lc, st);
     if (tiling == 5) return launch_cfg<64, 64, 64, 2, 2, 2>(g, lc, st);   // 8 waves: 2 per SIMD
     if (tiling == 6) return launch_cfg<64, 32, 64, 2, 1, 2>(g, lc, st);   // 2 row blocks x 2-way K split
@@ -1197,6 +1201,12 @@ static int gemm_launch(const dv_gemm_desc& g, const LoadCfg& lc, int tiling, hip
     // 32x32 K-split tiling: the k-contiguous-A layouts (x W^T, dy W) run with EIGHT waves splitting each 64-deep K
     // tile (half the MFMA chain per wave, twice the waves to overlap its latency: 4-10 % faster on every cfg-2
     // product of these layouts, tools/gemm_bench.py --tilings 2,9); dy^T x keeps four (its big products lose with eight)
+    // grids that fill the chip (>= dense_min_tiles() tiles of 32x32): half the K tile and <= 72 registers, so that SEVEN
+    // workgroups fit a CU instead of four and the whole grid is resident in one round -- the 1178 workgroups of the
+    // decoder-head products took two rounds on 256 CUs (three on the main chain's 192): x W^T 24.3 -> 21.2 us,
+    // dy^T x 23.6 -> 21.0 us alone (tools/gemm_bench.py --tilings 2,9,17)
+    const int tiles32 = ((g.M + 31) / 32) * ((g.N + 31) / 32);
+    if (tiles32 >= dense_min_tiles()) return launch_cfg<32, 32, 32, 1, 1, 4>(g, lc, st);
     if (g.a_kcontig && g_opt[7] == 0) return launch_cfg<32, 32, 64, 1, 1, 8>(g, lc, st);
     return launch_cfg<32, 32, 64, 1, 1, 4>(g, lc, st);
 }
@@ -1211,7 +1221,7 @@ extern "C" int dv_gemm(const dv_gemm_desc* d, dv_stream_t stream) {
 
 // half-tile width of the paired-heads launch: 16 (default: 32x(16+16) tiles = the workgroup count and MFMA chain of
 // the 32x32 K-split tiling) or 32 (g_opt[4] = 1 / 2: 32x(32+32) tiles with 4 / 8 waves; measured slower at cfg 2)
-static int heads_hb() { return g_opt[4] >= 1 ? 32 : 16; }
+static int heads_hb() { return (g_opt[4] == 1 || g_opt[4] == 2) ? 32 : 16; }
 extern "C" int dv_gemm_heads_tiles(int32_t split) { return split > 0 ? (split + heads_hb() - 1) / heads_hb() : 0; }
 
 extern "C" int dv_gemm_heads(const dv_gemm_desc* d, const dv_heads_epi* e, dv_stream_t stream) {
@@ -1243,6 +1253,11 @@ extern "C" int dv_gemm_heads(const dv_gemm_desc* d, const dv_heads_epi* e, dv_st
                            static_cast<hipStream_t>(stream), g, lc, *e);
     else if (g_opt[4] == -1)
         hipLaunchKernelGGL((gemm_heads_kernel<32, 32, 64, 4>), dim3(tiles), dim3(256), 0,
+                           static_cast<hipStream_t>(stream), g, lc, *e);
+    else if (g_opt[4] == 3 || (g_opt[4] == 0 && tiles >= dense_min_tiles()))
+        // chip-filling grids: four waves, half the K tile, seven workgroups per CU (see gemm_launch): 29.1 -> 26.4 us
+        // for the decoder heads + NLL alone
+        hipLaunchKernelGGL((gemm_heads_kernel<32, 32, 32, 4>), dim3(tiles), dim3(256), 0,
                            static_cast<hipStream_t>(stream), g, lc, *e);
     else   // default: the 32x32 tiling's eight-wave K split, B lines = 16 + 16 rows of the two heads
         hipLaunchKernelGGL((gemm_heads_kernel<32, 32, 64, 8>), dim3(tiles), dim3(512), lds_pad(32, tiles),

@@ -681,7 +681,9 @@ __global__ __launch_bounds__(256) void smalln_fwd_kernel(const float* __restrict
                                                          const float* __restrict__ W, int64_t ldw,
                                                          const float* __restrict__ bias, int M, int N,
                                                          float* __restrict__ logits, int64_t ldl,
-                                                         float* __restrict__ probs, int64_t ldp, dv_ymarg ym) {
+                                                         float* __restrict__ probs, int64_t ldp, dv_ymarg ym,
+                                                         ParkArgs park) {
+    park_block(park);
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= M) return;
@@ -1663,8 +1665,11 @@ extern "C" int dv_cat_terms_bwd(const float* probs, int64_t ldp, int32_t M, int3
 extern "C" int dv_smalln_linear_fwd(const float* a1, int64_t lda1, int32_t K1, const float* a2, int64_t lda2,
                                     int32_t K2, const float* W, int64_t ldw, const float* bias, int32_t M, int32_t N,
                                     float* logits, int64_t ldl, float* probs, int64_t ldp, const dv_ymarg* ymarg,
-                                    dv_stream_t stream) {
-    DV_REQUIRE(M >= 0 && N >= 1 && N <= kMaxSmallN && K1 >= 0 && K2 >= 0);
+                                    const dv_wait* park_in, dv_stream_t stream) {
+    DV_REQUIRE(M >= 0 && N >= 1 && N <= kMaxSmallN && K1 >= 0 && K2 >= 0 && park_ok(park_in));
+    const ParkArgs park = park_in ? *park_in : ParkArgs{};
+    DV_REQUIRE(park.flag == nullptr || M > 0);
+    if (park.flag != nullptr && (M + 3) / 4 > DV_MAX_PARKED_GRID) return DV_ERR_UNSUPPORTED;
     if (M == 0) return DV_OK;
     DV_REQUIRE(a1 && W && (a2 || K2 == 0) && (logits || probs));
     dv_ymarg ym{};
@@ -1673,7 +1678,7 @@ extern "C" int dv_smalln_linear_fwd(const float* a1, int64_t lda1, int32_t K1, c
         DV_REQUIRE(probs && ym.label && ym.klfp && ym.c_kld && ym.c_yl && ym.yl && ym.kld && ym.cfp && ym.dqy);
     }
     hipLaunchKernelGGL(smalln_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, ST(stream), a1, lda1, K1, a2, lda2, K2, W,
-                       ldw, bias, M, N, logits, ldl, probs, ldp, ym);
+                       ldw, bias, M, N, logits, ldl, probs, ldp, ym, park);
     DV_RETURN_LAUNCH();
 }
 

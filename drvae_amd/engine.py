@@ -553,10 +553,17 @@ class FusedStep(StepSchedule):
                     # KLFP = max(KL(q(z1|x)||p(z1|z3,y)), kl_min) + the z3 term   (src/DrVAE.py:347,358)
                     K.kl_rows_fwd(p.KLFP, p.KL1raw, Qmu, Qlv, PZ1[:, :Z1], PZ1[:, Z1:], qidx=p.fp_q, free_bits=True,
                                   kl_min=cfg.kl_min, add=p.KL3)
-            fold_mid = mid_park is not None and cfg.has_pert and Np and (L * Np + 3) // 4 <= 256
-            if mid is not None and not fold_mid:
+            # KL(q(z2|x2)||p(z2|z1)) of the pairs: both arguments come from the main chain and its consumers are the
+            # main chain's z2Fz1 backward and the loss scalars -- in the dual-graph train step the MAIN chain computes
+            # it (it has time to spare in front of the join, the side chain has not); then the wait for the z2Fz1
+            # samples rides on the classifier launch
+            klz2_here = cfg.has_pert and Np and not self._klz2_on_main()
+            clf_park = (mid_park is not None and not klz2_here and cfg.has_y and self.clf_small
+                        and (L * B + 3) // 4 <= 256)
+            fold_mid = mid_park is not None and klz2_here and (L * Np + 3) // 4 <= 256
+            if mid is not None and not fold_mid and not clf_park:
                 mid()
-            if cfg.has_pert and Np:
+            if klz2_here:
                 P2 = p.c_z2F.out[-1]
                 K.kl_rows_fwd(p.KLZ2, p.KLZ2raw, Qmu, Qlv, P2[:, :Z1], P2[:, Z1:], qidx=p.qz2_idx, pidx=p.pidx,
                               reps=L, free_bits=True, kl_min=cfg.kl_min,
@@ -572,7 +579,8 @@ class FusedStep(StepSchedule):
                     lc = self.L_clf[0]
                     # train step: the y-marginalisation (forward and backward) rides on the classifier's launch
                     K.smalln_fwd(p.QY, None, clf_in[0], lc.W, lc.b, clf_in[1] if len(clf_in) > 1 else None,
-                                 ymarg=ym if self.fuse_bwd else None)
+                                 ymarg=ym if self.fuse_bwd else None,
+                                 park=(mid_park[0], mid_park[1], mid_park[2]) if clf_park else None)
                 else:
                     K.softmax_clamp_fwd(p.QY, p.c_clf.forward(clf_in), sigmoid1=cfg.clf_1sig)
                 if self.fuse_bwd and self.clf_small:
@@ -624,6 +632,10 @@ class FusedStep(StepSchedule):
         else:
             K.nll_rows_fwd(p.NLL, p.XIN, PX[:, :X], PX[:, X:], mode=GAUSS_SIGMA, xidx=p.tgt)
         if mode == 5:
+            if self._klz2_on_main() and cfg.has_pert and Np:
+                P2 = p.c_z2F.out[-1]
+                K.kl_rows_fwd(p.KLZ2, p.KLZ2raw, Qmu, Qlv, P2[:, :Z1], P2[:, Z1:], qidx=p.qz2_idx, pidx=p.pidx,
+                              reps=L, free_bits=True, kl_min=cfg.kl_min)
             return             # main-chain graph: the side chain lives in its own graph on the side stream
         with self.branch:
             side_forward()
@@ -633,6 +645,12 @@ class FusedStep(StepSchedule):
         if self.fuse_bwd:
             return             # the loss scalars are assembled on the side chain of backward()
         self._loss_scalars()
+
+    def _klz2_on_main(self):
+        """dual-graph train step: the pairs' KL(q(z2|x2)||p(z2|z1)) rows run on the main chain (DRVAE_KLZ2_MAIN=0: on
+        the side chain, as in every other schedule)"""
+        return (self._mode() == 5 and not self.cfg.cont and self.cfg.has_y
+                and os.environ.get('DRVAE_KLZ2_MAIN', '1') != '0')
 
     def _mmd_penalty(self):
         """Model-level MMD penalty of the ``use_s`` extension (src/DrVAE.py:394-398,537-540): minus the MMD between

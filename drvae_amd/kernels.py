@@ -363,10 +363,11 @@ def cat_terms_bwd(dprobs, probs, *, labels=None, prior=None, c_logp=None, g_kl=N
                                             _ld(dprobs), beta, _stream()), 'dv_cat_terms_bwd')
 
 
-def smalln_fwd(probs, logits, a1, W, bias=None, a2=None, ymarg=None):
+def smalln_fwd(probs, logits, a1, W, bias=None, a2=None, ymarg=None, park=None):
     """probs = clamp(softmax([a1|a2] W^T + b)) for N <= 8 outputs (either output may be None).
     ``ymarg`` = (yl, kld, cfp, dqy, label, fp_ptr, klfp, log_prior, c_kld, c_yl): the y-marginalisation of every row
-    (the arguments of ``ymarg_fwdbwd``) rides on the same launch."""
+    (the arguments of ``ymarg_fwdbwd``) rides on the same launch.  ``park`` = (flag, ctr, err[, add[, max_spins]]): every
+    workgroup first parks on another chain's flag (see ``flag_wait``)."""
     M = a1.shape[0]
     N = W.shape[0]
     K1, K2 = a1.shape[1], (a2.shape[1] if a2 is not None else 0)
@@ -382,7 +383,7 @@ def smalln_fwd(probs, logits, a1, W, bias=None, a2=None, ymarg=None):
         ym = C.byref(y)
     _lib.check(_lib.load().dv_smalln_linear_fwd(_f32(a1), _ld(a1), K1, _f32(a2), _ld(a2), K2, _f32(W), _ld(W),
                                                 _f32(bias), M, N, _f32(logits), _ld(logits), _f32(probs),
-                                                _ld(probs), ym, _stream()), 'dv_smalln_linear_fwd')
+                                                _ld(probs), ym, _wait(park), _stream()), 'dv_smalln_linear_fwd')
 
 
 def smalln_bwd_data(dsts, dprobs, probs, W):

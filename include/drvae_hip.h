@@ -360,7 +360,8 @@ int dv_cat_terms_bwd(const float* probs, int64_t ldp, int32_t M, int32_t Y, cons
  * The pointer/size arrays of bwd_data are HOST arrays. */
 int dv_smalln_linear_fwd(const float* a1, int64_t lda1, int32_t K1, const float* a2, int64_t lda2, int32_t K2,
                          const float* W, int64_t ldw, const float* bias, int32_t M, int32_t N, float* logits,
-                         int64_t ldl, float* probs, int64_t ldp, const dv_ymarg* ymarg, dv_stream_t stream);
+                         int64_t ldl, float* probs, int64_t ldp, const dv_ymarg* ymarg, const dv_wait* park,
+                         dv_stream_t stream);
 int dv_smalln_linear_bwd_data(const float* dprobs, int64_t lddp, const float* probs, int64_t ldp, const float* W,
                               int64_t ldw, int32_t M, int32_t N, int32_t n_dst, float* const* dst,
                               const int64_t* ld, const int32_t* col0, const int32_t* ncol, const float* alpha,

@@ -451,7 +451,9 @@ def _dlogits(dprobs, probs):
     return probs * (g - (g * probs).sum(1, keepdim=True))
 
 
-def smalln_fwd(probs, logits, a1, W, bias=None, a2=None, ymarg=None):
+def smalln_fwd(probs, logits, a1, W, bias=None, a2=None, ymarg=None, park=None):
+    if park is not None:
+        flag_wait(*park)
     if ymarg is not None:
         smalln_fwd(probs, logits, a1, W, bias, a2)
         yl, kld, cfp, dqy, label, fp_ptr, klfp, log_prior, c_kld, c_yl = ymarg
