@@ -81,7 +81,7 @@ SIGNATURES = {
                         _p, _i64, _i32, _i32, _i32, _i32, C.POINTER(Wait), _p],
     'dv_reparam_bwd': [_p, _i64, _p, _i64, _p, _i64, _p, _i32, _i32, _i32, _i32, _p, _p, _i64, _f, _p],
     'dv_kl_rows_fwd': [_p, _p, _i64, _p, _p, _p, _i64, _p, _f, _f, _i32, _i32, _i32, _i32, _i32, _f, _p, _p, _p, _p,
-                       _i64, _p, _i64, C.POINTER(Wait), _p],
+                       _i64, _p, _i64, C.POINTER(Wait), _p, _p, _i64, _i32, _p, _p],
     'dv_kl_rows_bwd': [_p, _p, _i32, _f, _p, _p, _i64, _p, _p, _p, _i64, _p, _f, _f, _i32, _i32, _i32, _i32,
                        _p, _p, _i64, _p, _p, _i64, _f, _p, _i64, _p, _i64, _p],
     'dv_gauss_nll_rows_fwd': [_p, _i64, _p, _p, _p, _i64, _i32, _i32, _i32, _p, _p],

@@ -1041,7 +1041,7 @@ __global__ __launch_bounds__(64 * KS, KS == 8 ? 2 : (BK == 32 ? 7 : 4)) void gem
 // second): the weight-gradient dW = dy^T x and the data-gradient dx = dy W of a layer both only
 // need dy, so they share a launch slot instead of paying the per-launch latency chain twice.
 template <int BM, int BN, int BK, int WM, int WN, int KS, bool A1, bool B1, bool A2, bool B2>
-__global__ __launch_bounds__(256, 4) void gemm_pair_kernel(const dv_gemm_desc g1, const LoadCfg lc1, const dv_gemm_desc g2,
+__global__ __launch_bounds__(256, BK == 32 ? 7 : 4) void gemm_pair_kernel(const dv_gemm_desc g1, const LoadCfg lc1, const dv_gemm_desc g2,
                                                         const LoadCfg lc2, int tiles1) {
     constexpr int S1 = gemm_smem_floats<BM, BN, BK, KS, A1, B1>(), S2 = gemm_smem_floats<BM, BN, BK, KS, A2, B2>();
     __shared__ __attribute__((aligned(16))) float smem[S1 > S2 ? S1 : S2];
@@ -1280,6 +1280,21 @@ extern "C" int dv_gemm_pair(const dv_gemm_desc* d1, const dv_gemm_desc* d2, dv_s
     // decoder-heads pair ran 66 us paired vs 29 + 29 us alone)
     const bool fuse = t1 == 2 && t2 == 2 && !d1->a_kcontig && !d1->b_kcontig && d2->a_kcontig && !d2->b_kcontig &&
                       g_opt[2] == 0 && tiles1 < 1024 && tiles2 < 1024;
+    // both products of a chip-filling layer in ONE launch of the high-occupancy tiling (g_opt[9] = 1, tuning): the
+    // long-K data-gradient tiles first, the weight-gradient tiles fill the CUs around them
+    if (!fuse && g_opt[9] == 1 && t1 == 2 && t2 == 2 && !d1->a_kcontig && !d1->b_kcontig && d2->a_kcontig &&
+        !d2->b_kcontig && tiles1 >= dense_min_tiles() && tiles1 + tiles2 < 4096) {
+        dv_gemm_desc first = *d2, second = *d1;
+        if (first.pub_flag == nullptr && second.pub_flag != nullptr) {      // the kernel publishes for its first product
+            first.pub_flag = second.pub_flag;
+            first.pub_ctr = second.pub_ctr;
+            first.pub_add = second.pub_add;
+            second.pub_flag = nullptr;
+        }
+        hipLaunchKernelGGL((gemm_pair_kernel<32, 32, 32, 1, 1, 4, true, false, false, false>), dim3(tiles1 + tiles2),
+                           dim3(256), 0, st, first, lc2, second, lc1, tiles2);
+        DV_RETURN_LAUNCH();
+    }
     if (!fuse) {
         rc = gemm_launch(*d1, lc1, t1, st);
         if (rc != DV_OK) return rc;

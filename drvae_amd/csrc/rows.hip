@@ -276,7 +276,9 @@ __global__ __launch_bounds__(256) void kl_rows_fwd_kernel(KlArgs a, int free_bit
                                                           float* __restrict__ raw_out, float* __restrict__ out,
                                                           const float* __restrict__ add,
                                                           const float* __restrict__ eps, int64_t lde,
-                                                          float* __restrict__ zout, int64_t ldz, ParkArgs park) {
+                                                          float* __restrict__ zout, int64_t ldz, ParkArgs park,
+                                                          const float* __restrict__ mu2, const float* __restrict__ sd2,
+                                                          int64_t ld2, int Z2, float* __restrict__ raw2_out) {
     park_block(park);
     const int lane = threadIdx.x & 63;
     const int rows = a.n * a.reps;
@@ -284,7 +286,10 @@ __global__ __launch_bounds__(256) void kl_rows_fwd_kernel(KlArgs a, int free_bit
         const int j = r % a.n;
         const int64_t qi = a.qidx ? a.qidx[j] : j;
         const int64_t pi = a.pidx ? a.pidx[r] : r;
-        float s = 0.f;
+        float s = 0.f, s2 = 0.f;
+        if (mu2)   // second term of the same row: KL(N(mu2, sd2) || N(prior_mu, prior_sd)), row-aligned
+            for (int d = lane; d < Z2; d += 64)
+                s2 += kl_term(a.mode, mu2[(int64_t)r * ld2 + d], sd2[(int64_t)r * ld2 + d], a.prior_mu, a.prior_sd);
         for (int d = lane; d < a.Z; d += 64) {
             const float mq = a.mu_q[qi * a.ldq + d], sq = a.sd_q[qi * a.ldq + d];
             const float mp = a.mu_p ? a.mu_p[pi * a.ldp + d] : a.prior_mu;
@@ -295,10 +300,17 @@ __global__ __launch_bounds__(256) void kl_rows_fwd_kernel(KlArgs a, int free_bit
                     mq + eps[(int64_t)r * lde + d] * (a.mode == DV_GAUSS_LOGVAR ? expf(0.5f * sq) : sq);
         }
         s = dv_wave_sum_all(s);
+        if (mu2) s2 = dv_wave_sum_all(s2);
         if (lane == 0) {
             const float raw = -0.5f * s;
             if (raw_out) raw_out[r] = raw;
-            out[r] = (free_bits ? fmaxf(raw, kl_min) : raw) + (add ? add[r] : 0.f);
+            float v = (free_bits ? fmaxf(raw, kl_min) : raw) + (add ? add[r] : 0.f);
+            if (mu2) {
+                const float raw2 = -0.5f * s2;
+                if (raw2_out) raw2_out[r] = raw2;
+                v += free_bits ? fmaxf(raw2, kl_min) : raw2;
+            }
+            out[r] = v;
         }
     }
 }
@@ -1517,8 +1529,10 @@ extern "C" int dv_kl_rows_fwd(const float* mu_q, const float* sd_q, int64_t ldq,
                               float prior_mu, float prior_sd, int32_t n, int32_t reps, int32_t Z, int32_t mode,
                               int32_t free_bits, float kl_min, float* raw_out, float* out, const float* add,
                               const float* eps, int64_t lde, float* zout, int64_t ldz, const dv_wait* park_in,
+                              const float* mu2, const float* sd2, int64_t ld2, int32_t Z2, float* raw2_out,
                               dv_stream_t stream) {
     DV_REQUIRE(n >= 0 && reps >= 0 && Z >= 0 && park_ok(park_in));
+    DV_REQUIRE((mu2 == nullptr) == (sd2 == nullptr) && (mu2 == nullptr || Z2 >= 0));
     const ParkArgs park = park_in ? *park_in : ParkArgs{};
     DV_REQUIRE(park.flag == nullptr || (n > 0 && reps > 0));
     if (park.flag != nullptr && grid_for((int64_t)n * reps, 4) > DV_MAX_PARKED_GRID) return DV_ERR_UNSUPPORTED;
@@ -1528,7 +1542,7 @@ extern "C" int dv_kl_rows_fwd(const float* mu_q, const float* sd_q, int64_t ldq,
     DV_REQUIRE(zout == nullptr || eps != nullptr);
     KlArgs a{mu_q, sd_q, ldq, qidx, mu_p, sd_p, ldp, pidx, prior_mu, prior_sd, n, reps, Z, mode};
     hipLaunchKernelGGL(kl_rows_fwd_kernel, dim3(grid_for((int64_t)n * reps, 4)), dim3(256), 0, ST(stream), a,
-                       free_bits, kl_min, raw_out, out, add, eps, lde, zout, ldz, park);
+                       free_bits, kl_min, raw_out, out, add, eps, lde, zout, ldz, park, mu2, sd2, ld2, Z2, raw2_out);
     DV_RETURN_LAUNCH();
 }
 

@@ -545,14 +545,23 @@ class FusedStep(StepSchedule):
                     Z3, Y = cfg.dim_z3, cfg.dim_y
                     K.rows_gather(p.FPIN, Z1blk, p.fp_src, onehot_cls=p.fp_cls, n_classes=Y,
                                   park=(first_park[0], first_park[1], first_park[2]) if first_park is not None else None)
-                    Q3 = p.c_top.forward([p.FPIN])
-                    # KL(q(z3|z1,y)||N(0,I)) with free bits + the z3 sample, one row pass
-                    K.kl_rows_fwd(p.KL3, p.KL3raw, Q3[:, :Z3], Q3[:, Z3:], prior=(0.0, 0.0), free_bits=True,
-                                  kl_min=cfg.kl_min, eps=p.E3, zout=p.Z3IN[:, :Z3])
-                    PZ1 = p.c_dz1.forward([p.Z3IN])
-                    # KLFP = max(KL(q(z1|x)||p(z1|z3,y)), kl_min) + the z3 term   (src/DrVAE.py:347,358)
-                    K.kl_rows_fwd(p.KLFP, p.KL1raw, Qmu, Qlv, PZ1[:, :Z1], PZ1[:, Z1:], qidx=p.fp_q, free_bits=True,
-                                  kl_min=cfg.kl_min, add=p.KL3)
+                    if self.fuse_heads:
+                        # the z3 sample leaves the heads' launch of q(z3|z1,y); its KL term against N(0,I) (with its
+                        # own free bits) is evaluated next to the z1 term below: one launch less
+                        Q3 = p.c_top.forward([p.FPIN], heads=dict(sample=dict(eps=p.E3, out=p.Z3IN[:, :Z3], n_src=p.Mf)))
+                        PZ1 = p.c_dz1.forward([p.Z3IN])
+                        # KLFP = max(KL(q(z1|x)||p(z1|z3,y)), kl_min) + max(KL(q(z3|.)||N(0,I)), kl_min)  (src/DrVAE.py:347,358)
+                        K.kl_rows_fwd(p.KLFP, p.KL1raw, Qmu, Qlv, PZ1[:, :Z1], PZ1[:, Z1:], qidx=p.fp_q, free_bits=True,
+                                      kl_min=cfg.kl_min, prior=(0.0, 0.0), second=(Q3[:, :Z3], Q3[:, Z3:], p.KL3raw))
+                    else:
+                        Q3 = p.c_top.forward([p.FPIN])
+                        # KL(q(z3|z1,y)||N(0,I)) with free bits + the z3 sample, one row pass
+                        K.kl_rows_fwd(p.KL3, p.KL3raw, Q3[:, :Z3], Q3[:, Z3:], prior=(0.0, 0.0), free_bits=True,
+                                      kl_min=cfg.kl_min, eps=p.E3, zout=p.Z3IN[:, :Z3])
+                        PZ1 = p.c_dz1.forward([p.Z3IN])
+                        # KLFP = max(KL(q(z1|x)||p(z1|z3,y)), kl_min) + the z3 term   (src/DrVAE.py:347,358)
+                        K.kl_rows_fwd(p.KLFP, p.KL1raw, Qmu, Qlv, PZ1[:, :Z1], PZ1[:, Z1:], qidx=p.fp_q, free_bits=True,
+                                      kl_min=cfg.kl_min, add=p.KL3)
             # KL(q(z2|x2)||p(z2|z1)) of the pairs: both arguments come from the main chain and its consumers are the
             # main chain's z2Fz1 backward and the loss scalars -- in the dual-graph train step the MAIN chain computes
             # it (it has time to spare in front of the join, the side chain has not); then the wait for the z2Fz1

@@ -274,15 +274,21 @@ def z2f_post_bwd(dp2, dz1, dq2, dz2f, dzdec_pert, pair_slot, eps, p2, q2, coef, 
 
 # --------------------------------------------------------------------------- KL rows
 def kl_rows_fwd(out, raw, mu_q, sd_q, mu_p=None, sd_p=None, *, prior=(0.0, 0.0), mode=GAUSS_LOGVAR, qidx=None,
-                pidx=None, reps=1, free_bits=False, kl_min=0.0, add=None, eps=None, zout=None, park=None):
+                pidx=None, reps=1, free_bits=False, kl_min=0.0, add=None, eps=None, zout=None, park=None, second=None):
+    """``second`` = (mu2, sd2, raw2): a second, row-aligned term KL(N(mu2, sd2) || N(prior)) with its own free bits is
+    added to ``out`` and its raw value written to ``raw2`` (same launch)"""
     R = out.numel()
     n = R // reps
     Z = mu_q.shape[1]
     assert _ld(mu_q) == _ld(sd_q) and (mu_p is None or _ld(mu_p) == _ld(sd_p))
+    assert second is None or (_ld(second[0]) == _ld(second[1]) and second[0].shape[0] == R)
     _lib.check(_lib.load().dv_kl_rows_fwd(_f32(mu_q), _f32(sd_q), _ld(mu_q), _i32(qidx), _f32(mu_p), _f32(sd_p),
                                           _ld(mu_p), _i32(pidx), prior[0], prior[1], n, reps, Z, mode,
                                           int(free_bits), kl_min, _f32(raw), _f32(out), _f32(add), _f32(eps),
-                                          _ld(eps), _f32(zout), _ld(zout), _wait(park), _stream()), 'dv_kl_rows_fwd')
+                                          _ld(eps), _f32(zout), _ld(zout), _wait(park),
+                                          _f32(second[0]) if second else None, _f32(second[1]) if second else None,
+                                          _ld(second[0]) if second else 0, second[0].shape[1] if second else 0,
+                                          _f32(second[2]) if second else None, _stream()), 'dv_kl_rows_fwd')
 
 
 def kl_rows_bwd(dq_mu, dq_sd, dp_mu, dp_sd, coef, raw, mu_q, sd_q, mu_p=None, sd_p=None, *, prior=(0.0, 0.0),

@@ -282,6 +282,9 @@ int dv_z2f_post_bwd(const float* dz2f, int64_t ld_dz2f, const float* dzdec_pert,
  *   out = free_bits ? max(raw, kl_min) : raw      (per-ROW free bits, src/DGMMixin.py:68-75)
  *   out[r] += add[r] (optional);  zout[r,d] = mu_q + eps[r,d]*std_q (optional): the reparameterised
  *   sample of q drawn in the same row pass (q(z3|z1,y): src/DrVAE.py:341-347).
+ *   mu2 != NULL: a second term of the same row, KL(N(mu2[r], sd2[r]) || the scalar prior) over Z2 columns, with its
+ *   own free bits: out[r] += max(raw2, kl_min), raw2_out[r] = raw2 (the z3 term of an fprop row, src/DrVAE.py:347,358,
+ *   evaluated next to the z1 term instead of in a launch of its own).
  * backward: coef[r] = dLoss/d out[r]; gradients are written ROW-ALIGNED (row r of
  * dq_* / dp_*); callers reduce duplicates with dv_rows_segment_sum.  With dz != NULL the
  * backward of that fused sample (dq_mu += dz, dq_sd += dz*eps*dstd/dsd) rides along. */
@@ -289,7 +292,8 @@ int dv_kl_rows_fwd(const float* mu_q, const float* sd_q, int64_t ldq, const int3
                    const float* sd_p, int64_t ldp, const int32_t* pidx, float prior_mu, float prior_sd, int32_t n,
                    int32_t reps, int32_t Z, int32_t mode, int32_t free_bits, float kl_min, float* raw_out,
                    float* out, const float* add, const float* eps, int64_t lde, float* zout, int64_t ldz,
-                   const dv_wait* park, dv_stream_t stream);
+                   const dv_wait* park, const float* mu2, const float* sd2, int64_t ld2, int32_t Z2,
+                   float* raw2_out, dv_stream_t stream);
 int dv_kl_rows_bwd(const float* coef, const float* raw, int32_t free_bits, float kl_min, const float* mu_q,
                    const float* sd_q, int64_t ldq, const int32_t* qidx, const float* mu_p, const float* sd_p,
                    int64_t ldp, const int32_t* pidx, float prior_mu, float prior_sd, int32_t n, int32_t reps,

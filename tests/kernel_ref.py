@@ -304,7 +304,7 @@ def _kl_operands(mu_q, sd_q, mu_p, sd_p, prior, qidx, pidx, R, reps):
 
 
 def kl_rows_fwd(out, raw, mu_q, sd_q, mu_p=None, sd_p=None, *, prior=(0.0, 0.0), mode=GAUSS_LOGVAR, qidx=None,
-                pidx=None, reps=1, free_bits=False, kl_min=0.0, add=None, eps=None, zout=None, park=None):
+                pidx=None, reps=1, free_bits=False, kl_min=0.0, add=None, eps=None, zout=None, park=None, second=None):
     if park is not None:
         flag_wait(*park[:3])
     R = out.numel()
@@ -319,7 +319,20 @@ def kl_rows_fwd(out, raw, mu_q, sd_q, mu_p=None, sd_p=None, *, prior=(0.0, 0.0),
     if raw is not None:
         raw.copy_(r)
     v = torch.clamp(r, min=kl_min) if free_bits else r
-    out.copy_(v + add if add is not None else v)
+    if add is not None:
+        v = v + add
+    if second is not None:
+        m2, s2, raw2 = second
+        pm, ps = torch.full_like(m2, prior[0]), torch.full_like(s2, prior[1])
+        if mode == GAUSS_LOGVAR:
+            t2 = 1 - ps + s2 - ((m2 - pm) ** 2 + s2.exp()) / ps.exp()
+        else:
+            t2 = 1 - torch.log(ps ** 2) + torch.log(s2 ** 2) - ((m2 - pm) ** 2 + s2 ** 2) / ps ** 2
+        r2 = -0.5 * t2.sum(1)
+        if raw2 is not None:
+            raw2.copy_(r2)
+        v = v + (torch.clamp(r2, min=kl_min) if free_bits else r2)
+    out.copy_(v)
 
 
 def kl_rows_bwd(dq_mu, dq_sd, dp_mu, dp_sd, coef, raw, mu_q, sd_q, mu_p=None, sd_p=None, *, prior=(0.0, 0.0),
