@@ -97,7 +97,7 @@ SIGNATURES = {
                              C.POINTER(Ymarg), _p, _p],
     'dv_smalln_linear_bwd_data': [_p, _i64, _p, _i64, _p, _i64, _i32, _i32, _i32, C.POINTER(_p), C.POINTER(_i64),
                                   C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_f), C.POINTER(_f), C.POINTER(_i32),
-                                  C.POINTER(_f), _p],
+                                  C.POINTER(_f), _p, _i64, _p, _p],
     'dv_smalln_linear_bwd_weight': [_p, _i64, _p, _i64, _p, _i64, _i32, _p, _i64, _i32, _i32, _i32, _p, _i64, _p, _f,
                                     _p, _p],
     'dv_ymarg_fwd': [_p, _i64, _p, _p, _p, _f, _p, _i32, _i32, _p, _p, _p],

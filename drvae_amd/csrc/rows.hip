@@ -744,6 +744,10 @@ struct SmallNDst {
     int col1[3];              // optional second column block (alpha2 != 0): `[z1, z2F - z1]` inputs
     float alpha[3], alpha2[3], beta[3];
     int n;
+    // destination 0 may start from a segment sum instead of beta*dst: sum of rows [seg_ptr[r], seg_ptr[r+1]) of seg_src
+    const float* seg_src;
+    int64_t ld_seg;
+    const int32_t* seg_ptr;
 };
 
 // dst_t[r, c] = beta*dst_t[r, c] + sum_j dlogit[r,j] * (alpha*W[j, col0_t + c] + alpha2*W[j, col1_t + c])
@@ -771,7 +775,14 @@ __global__ void smalln_bwd_data_kernel(const float* __restrict__ dprobs, int64_t
         if (d.alpha2[t] != 0.f)
             for (int j = 0; j < N; ++j) s2 += dl[j] * W[(int64_t)j * ldw + d.col1[t] + c];
         float* o = d.dst[t] + (int64_t)r * d.ld[t] + c;
-        *o = (d.beta[t] != 0.f ? d.beta[t] * *o : 0.f) + d.alpha[t] * s + d.alpha2[t] * s2;
+        float base;
+        if (t == 0 && d.seg_src != nullptr) {      // (dv_rows_segment_sum's sum, in its order)
+            base = 0.f;
+            for (int u = d.seg_ptr[r]; u < d.seg_ptr[r + 1]; ++u) base += d.seg_src[(int64_t)u * d.ld_seg + c];
+        } else {
+            base = d.beta[t] != 0.f ? d.beta[t] * *o : 0.f;
+        }
+        *o = base + d.alpha[t] * s + d.alpha2[t] * s2;
     }
 }
 
@@ -1700,12 +1711,17 @@ extern "C" int dv_smalln_linear_bwd_data(const float* dprobs, int64_t lddp, cons
                                          const float* W, int64_t ldw, int32_t M, int32_t N, int32_t n_dst,
                                          float* const* dst, const int64_t* ld, const int32_t* col0,
                                          const int32_t* ncol, const float* alpha, const float* beta,
-                                         const int32_t* col1, const float* alpha2, dv_stream_t stream) {
+                                         const int32_t* col1, const float* alpha2, const float* seg_src,
+                                         int64_t ld_seg, const int32_t* seg_ptr, dv_stream_t stream) {
     DV_REQUIRE(M >= 0 && N >= 1 && N <= kMaxSmallN && n_dst >= 1 && n_dst <= 3);
+    DV_REQUIRE((seg_src == nullptr) == (seg_ptr == nullptr));
     if (M == 0) return DV_OK;
     DV_REQUIRE(dprobs && W && dst && ld && col0 && ncol && alpha && beta);
     SmallNDst d;
     d.n = n_dst;
+    d.seg_src = seg_src;
+    d.ld_seg = ld_seg;
+    d.seg_ptr = seg_ptr;
     int cols = 0;
     for (int t = 0; t < n_dst; ++t) {
         DV_REQUIRE(dst[t] != nullptr && ncol[t] >= 0);

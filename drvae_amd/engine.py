@@ -798,15 +798,20 @@ class FusedStep(StepSchedule):
                     K.kl_rows_bwd(p.DQ3[:, :Z3], p.DQ3[:, Z3:], None, None, p.CFP, p.KL3raw, Q3[:, :Z3], Q3[:, Z3:],
                                   prior=(0.0, 0.0), free_bits=True, kl_min=cfg.kl_min, dz=p.DZ3IN[:, :Z3], eps=p.E3)
                     p.c_top.backward(p.DQ3, [p.FPIN], [[(p.DFPIN, 1.0, 0.0)]])
-                    # z1 feeds one (labeled) or Y (unlabeled) fprop rows
-                    K.rows_segment_sum(p.DZ1B, p.DFPIN, seg_ptr=p.fp_ptr, beta=0.0, width=Z1)
+                    # z1 feeds one (labeled) or Y (unlabeled) fprop rows: their d/dz1 is summed per z1 row -- inside
+                    # the classifier's data-gradient launch where that launch writes DZ1B anyway, else on its own
+                    seg_in_clf = self.clf_small and not (cfg.kind == 'drvae' and not cfg.clf_z1z2)
+                    if not seg_in_clf:
+                        K.rows_segment_sum(p.DZ1B, p.DFPIN, seg_ptr=p.fp_ptr, beta=0.0, width=Z1)
                 # classifier
                 b1 = 1.0 if p.Mf else 0.0
+                seg = (p.DFPIN, p.fp_ptr) if p.Mf else None
                 two = cfg.kind == 'drvae' and cfg.clf_z1z2
                 if self.clf_small:
                     lc = self.L_clf[0]
                     if two:      # input [z1, z2F - z1]: d/dz1 gets W1 - W2, d/dz2F gets W2
-                        K.smalln_bwd_data([(p.DZ1B, 0, 1.0, b1, Z1, -1.0), (p.DZ2F, Z1, 1.0, 0.0)], p.DQY, p.QY, lc.W)
+                        K.smalln_bwd_data([(p.DZ1B, 0, 1.0, b1, Z1, -1.0), (p.DZ2F, Z1, 1.0, 0.0)], p.DQY, p.QY, lc.W,
+                                          seg=seg)
                         wgrad_clf(lc.dW, lc.db, p.DQY, p.QY, Z1blk, p.D)
                     elif cfg.kind == 'drvae':
                         K.smalln_bwd_data([(p.DZ2F, 0, 1.0, 0.0)], p.DQY, p.QY, lc.W)
@@ -814,7 +819,7 @@ class FusedStep(StepSchedule):
                         if not p.Mf:
                             p.DZ1B.zero_()
                     else:
-                        K.smalln_bwd_data([(p.DZ1B, 0, 1.0, b1)], p.DQY, p.QY, lc.W)
+                        K.smalln_bwd_data([(p.DZ1B, 0, 1.0, b1)], p.DQY, p.QY, lc.W, seg=seg)
                         wgrad_clf(lc.dW, lc.db, p.DQY, p.QY, Z1blk)
                 else:
                     K.softmax_clamp_bwd(p.DLOG, p.DQY, p.QY, sigmoid1=cfg.clf_1sig)

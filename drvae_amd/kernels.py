@@ -392,9 +392,11 @@ def smalln_fwd(probs, logits, a1, W, bias=None, a2=None, ymarg=None, park=None):
                                                 _ld(probs), ym, _wait(park), _stream()), 'dv_smalln_linear_fwd')
 
 
-def smalln_bwd_data(dsts, dprobs, probs, W):
+def smalln_bwd_data(dsts, dprobs, probs, W, seg=None):
     """dsts: list of (dst, col0, alpha, beta[, col1, alpha2]);
-    dst = beta*dst + dlogit @ (alpha*W[:, col0:col0+w] + alpha2*W[:, col1:col1+w]), w = dst.shape[1]."""
+    dst = beta*dst + dlogit @ (alpha*W[:, col0:col0+w] + alpha2*W[:, col1:col1+w]), w = dst.shape[1].
+    ``seg`` = (src, seg_ptr): the FIRST destination starts from the segment sum of ``src`` rows
+    [seg_ptr[r], seg_ptr[r+1]) (its first w columns) instead of beta*dst."""
     M, N = dprobs.shape
     n = len(dsts)
     P = (C.c_void_p * n)(*[_f32(d[0]) for d in dsts])
@@ -406,7 +408,9 @@ def smalln_bwd_data(dsts, dprobs, probs, W):
     C1 = (C.c_int32 * n)(*[(d[4] if len(d) > 4 else 0) for d in dsts])
     A2 = (C.c_float * n)(*[(d[5] if len(d) > 5 else 0.0) for d in dsts])
     _lib.check(_lib.load().dv_smalln_linear_bwd_data(_f32(dprobs), _ld(dprobs), _f32(probs), _ld(probs), _f32(W),
-                                                     _ld(W), M, N, n, P, LD, C0, NC, AL, BE, C1, A2, _stream()),
+                                                     _ld(W), M, N, n, P, LD, C0, NC, AL, BE, C1, A2,
+                                                     _f32(seg[0]) if seg else None, _ld(seg[0]) if seg else 0,
+                                                     _i32(seg[1]) if seg else None, _stream()),
                'dv_smalln_linear_bwd_data')
 
 

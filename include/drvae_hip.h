@@ -361,6 +361,9 @@ int dv_cat_terms_bwd(const float* probs, int64_t ldp, int32_t M, int32_t Y, cons
  *               for up to 3 destinations; col1/alpha2 may be NULL (the `[z1, z2F - z1]` input of
  *               src/DrVAE.py:495 sends W1 - W2 to z1 and W2 to z2F)
  *   bwd_weight: dW[j,k] = beta*dW + sum_r dlogit[r,j] [a1|a2][r,k];  db[j] likewise (db may be NULL)
+ *               seg_src != NULL: destination 0 starts from the segment sum sum_{u in [seg_ptr[r], seg_ptr[r+1])}
+ *               seg_src[u, c] instead of beta_0*dst_0[r,c] (the fprop rows' d/dz1 of src/DrVAE.py:337-358 folded into
+ *               the classifier's data gradient: one launch instead of dv_rows_segment_sum + this one)
  * The pointer/size arrays of bwd_data are HOST arrays. */
 int dv_smalln_linear_fwd(const float* a1, int64_t lda1, int32_t K1, const float* a2, int64_t lda2, int32_t K2,
                          const float* W, int64_t ldw, const float* bias, int32_t M, int32_t N, float* logits,
@@ -369,7 +372,8 @@ int dv_smalln_linear_fwd(const float* a1, int64_t lda1, int32_t K1, const float*
 int dv_smalln_linear_bwd_data(const float* dprobs, int64_t lddp, const float* probs, int64_t ldp, const float* W,
                               int64_t ldw, int32_t M, int32_t N, int32_t n_dst, float* const* dst,
                               const int64_t* ld, const int32_t* col0, const int32_t* ncol, const float* alpha,
-                              const float* beta, const int32_t* col1, const float* alpha2, dv_stream_t stream);
+                              const float* beta, const int32_t* col1, const float* alpha2, const float* seg_src, int64_t ld_seg,
+                              const int32_t* seg_ptr, dv_stream_t stream);
 int dv_smalln_linear_bwd_weight(const float* dprobs, int64_t lddp, const float* probs, int64_t ldp,
                                 const float* a1, int64_t lda1, int32_t K1, const float* a2, int64_t lda2,
                                 int32_t K2, int32_t M, int32_t N, float* dW, int64_t ldd, float* db, float beta,

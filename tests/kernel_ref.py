@@ -480,11 +480,14 @@ def smalln_fwd(probs, logits, a1, W, bias=None, a2=None, ymarg=None, park=None):
         probs.copy_(torch.clamp(torch.softmax(z, -1), min=P_MIN, max=1. - 1e-10))
 
 
-def smalln_bwd_data(dsts, dprobs, probs, W):
+def smalln_bwd_data(dsts, dprobs, probs, W, seg=None):
     dl = _dlogits(dprobs, probs)
-    for d in dsts:
+    for di, d in enumerate(dsts):
         dst, col0, alpha, beta = d[:4]
         w = dst.shape[1]
+        if di == 0 and seg is not None:
+            rows_segment_sum(dst, seg[0], seg_ptr=seg[1], beta=0.0, width=w)
+            beta = 1.0
         v = alpha * (dl @ W[:, col0:col0 + w])
         if len(d) > 5 and d[5] != 0.0:
             v = v + d[5] * (dl @ W[:, d[4]:d[4] + w])

@@ -647,12 +647,45 @@ def test_smalln_linear_head(K, dev, Y, two):
         R.smalln_bwd_data(rds, g, rp if probs is not None else None, W)
         close(d1, r1, rtol=1e-4, atol=1e-5)
         close(d2, r2, rtol=1e-4, atol=1e-5)
+        # destination 0 started from a segment sum (1 or Y source rows per row): bitwise the two-launch sequence
+        cnt = [1 if i % 3 else Y for i in range(M)]
+        ptr = torch.tensor(np.concatenate([[0], np.cumsum(cnt)]), dtype=torch.int32, device=dev)
+        src = strided(dev, int(ptr[-1]), K1, 2, seed=10)
+        K.smalln_bwd_data(dsts, g, probs, W, seg=(src, ptr))
+        K.rows_segment_sum(r1, src, seg_ptr=ptr, beta=0.0, width=K1)
+        two_step = [(r1,) + tuple(dsts[0][1:3]) + (1.0,) + tuple(dsts[0][4:])] + [(r2,) + tuple(d[1:]) for d in dsts[1:]]
+        K.smalln_bwd_data(two_step, g, probs, W)
+        close(d1, r1, rtol=0, atol=0)
+        close(d2, r2, rtol=0, atol=0)
         dW, db = rnd(dev, Y, K1 + K2, seed=8), rnd(dev, Y, seed=9)
         rW, rb = dW.clone(), db.clone()
         K.smalln_bwd_weight(dW, db, g, probs, a1, a2, beta=1.0)
         R.smalln_bwd_weight(rW, rb, g, rp if probs is not None else None, a1, a2, beta=1.0)
         close(dW, rW, rtol=1e-4, atol=1e-4)
         close(db, rb, rtol=1e-4, atol=1e-4)
+
+
+def test_kl_rows_second_term(K, dev):
+    """dv_kl_rows_fwd with a second, row-aligned term against the scalar prior (own free bits, own raw output) ==
+    two launches chained through ``add``"""
+    n, Z, Z2 = 45, 100, 37
+    Q, P, Q2 = rnd(dev, 20, 2 * Z, seed=1, scale=0.5), rnd(dev, n, 2 * Z, seed=2, scale=0.5), rnd(dev, n, 2 * Z2, seed=3)
+    qidx = torch.tensor([i % 20 for i in range(n)], dtype=torch.int32, device=dev)
+    for kl_min in (0.0, 40.0):
+        one, raw1, raw2 = (torch.empty(n, device=dev) for _ in range(3))
+        K.kl_rows_fwd(one, raw1, Q[:, :Z], Q[:, Z:], P[:, :Z], P[:, Z:], qidx=qidx, free_bits=True, kl_min=kl_min,
+                      prior=(0.0, 0.0), second=(Q2[:, :Z2], Q2[:, Z2:], raw2))
+        t3, r3, two, r1 = (torch.empty(n, device=dev) for _ in range(4))
+        K.kl_rows_fwd(t3, r3, Q2[:, :Z2], Q2[:, Z2:], prior=(0.0, 0.0), free_bits=True, kl_min=kl_min)
+        K.kl_rows_fwd(two, r1, Q[:, :Z], Q[:, Z:], P[:, :Z], P[:, Z:], qidx=qidx, free_bits=True, kl_min=kl_min, add=t3)
+        close(raw1, r1, rtol=1e-6, atol=1e-5)     # (the two-term loop may contract its fmas differently: 1 ulp)
+        close(raw2, r3, rtol=1e-6, atol=1e-5)
+        close(one, two, rtol=1e-6, atol=1e-5)
+        ref, rr1, rr2 = (torch.empty(n, device=dev) for _ in range(3))
+        R.kl_rows_fwd(ref, rr1, Q[:, :Z], Q[:, Z:], P[:, :Z], P[:, Z:], qidx=qidx, free_bits=True, kl_min=kl_min,
+                      prior=(0.0, 0.0), second=(Q2[:, :Z2], Q2[:, Z2:], rr2))
+        close(one, ref, rtol=1e-5, atol=1e-4)
+        close(raw2, rr2, rtol=1e-5, atol=1e-4)
 
 
 def test_fused_extensions_reparam_kl(K, dev):
