@@ -378,7 +378,7 @@ def main():
     if os.environ.get('DRVAE_LDS_PAD'):               # tuning: extra dynamic LDS of the chip-filling 32x32-tile GEMM launches
         _lib.load().dv_gemm_set_option(1, int(os.environ['DRVAE_LDS_PAD']))
     if os.environ.get('DRVAE_DENSE_PAIR'):            # tuning: dW and dX of a chip-filling layer in one launch
-        _lib.load().dv_gemm_set_option(9, int(os.environ['DRVAE_DENSE_PAIR']))
+        _lib.load().dv_gemm_set_option(9, 0 if os.environ['DRVAE_DENSE_PAIR'] != '0' else 1)
     if os.environ.get('DRVAE_DENSE_MIN'):             # tuning: 32x32-tile count from which the 7-per-CU tiling runs
         _lib.load().dv_gemm_set_option(8, int(os.environ['DRVAE_DENSE_MIN']))
     if os.environ.get('DRVAE_T64_MIN'):               # tuning: 64x64-tile threshold of the GEMM heuristic

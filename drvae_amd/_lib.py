@@ -49,7 +49,8 @@ class Bump(C.Structure):       # dv_bump: up to two device counters advanced by 
 class HeadsEpi(C.Structure):   # dv_heads_epi
     _fields_ = [('mode', _i32), ('seg_ptr', _p), ('seg_rows', _p), ('n_src', _i32), ('eps', _p), ('lde', _i64),
                 ('out', _p), ('ldo', _i64), ('sub', _p), ('lds', _i64), ('out2', _p), ('ldo2', _i64), ('out3', _p),
-                ('ldo3', _i64), ('out3_idx', _p), ('x', _p), ('ldx', _i64), ('xidx', _p), ('coef', _p), ('part', _p)]
+                ('ldo3', _i64), ('out3_idx', _p), ('out4', _p), ('ldo4', _i64), ('out4_ptr', _p), ('x', _p),
+                ('ldx', _i64), ('xidx', _p), ('coef', _p), ('part', _p)]
 
 
 HEADS_SAMPLE, HEADS_NLL = 1, 2
@@ -109,7 +110,7 @@ SIGNATURES = {
     'dv_mmd_rff_bwd': [_p, _i64, _i32, _i32, _p, _p, _f, _p, _i64, _p],
     'dv_rows_gather': [_p, _i64, _p, _i32, _i32, _p, _i64, _f, _p, _i32, _p, _i64, C.POINTER(Wait), _p],
     'dv_batch_feed': [_p, _i64, _p, _i64, _p, _p, _i32, _p, _p, _i32, _p, _i32, _i32, _p, _i64, _f, _p, _i64, _p, _i32,
-                      _p, _p, _p, _p, _i32, _p, _p, _i64, _i32, _p, _p, _i32, _p],
+                      _p, _p, _p, _p, _i32, _p, _p, _i64, _i32, _p, _p, _i32, _p, _i64, _p],
     'dv_batch_masks': [_p, _i32, _p, _p, _p, _p, _p, _i32, _i32, _f, _f, _f, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     'dv_rows_segment_sum': [_p, _i64, _p, _p, _p, _i32, _i32, _p, _p, _i64, _f, C.POINTER(Wait), _p],
     'dv_weighted_sum': [_p, _p, _p, _i32, _f, _p, _f, _p],

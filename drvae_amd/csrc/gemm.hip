@@ -254,6 +254,8 @@ __device__ __forceinline__ void heads_epilogue(const dv_gemm_desc& g, const dv_h
                             const int t3 = he.out3_idx[s];
                             if (t3 >= 0) he.out3[(int64_t)t3 * he.ldo3 + col0] = z;
                         }
+                        if (he.out4)      // CSR fan-out of sample row s: rows [out4_ptr[s], out4_ptr[s+1]) of out4
+                            for (int u = he.out4_ptr[s]; u < he.out4_ptr[s + 1]; ++u) he.out4[(int64_t)u * he.ldo4 + col0] = z;
                     }
                 }
             }
@@ -1240,6 +1242,7 @@ extern "C" int dv_gemm_heads(const dv_gemm_desc* d, const dv_heads_epi* e, dv_st
         DV_REQUIRE((e->seg_ptr == nullptr) == (e->seg_rows == nullptr));
         DV_REQUIRE(e->out2 == nullptr || e->sub != nullptr);
         DV_REQUIRE(e->out3 == nullptr || e->out3_idx != nullptr);
+        DV_REQUIRE(e->out4 == nullptr || e->out4_ptr != nullptr);
     } else {
         DV_REQUIRE(e->x && e->coef && e->part);
     }
@@ -1280,9 +1283,11 @@ extern "C" int dv_gemm_pair(const dv_gemm_desc* d1, const dv_gemm_desc* d2, dv_s
     // decoder-heads pair ran 66 us paired vs 29 + 29 us alone)
     const bool fuse = t1 == 2 && t2 == 2 && !d1->a_kcontig && !d1->b_kcontig && d2->a_kcontig && !d2->b_kcontig &&
                       g_opt[2] == 0 && tiles1 < 1024 && tiles2 < 1024;
-    // both products of a chip-filling layer in ONE launch of the high-occupancy tiling (g_opt[9] = 1, tuning): the
-    // long-K data-gradient tiles first, the weight-gradient tiles fill the CUs around them
-    if (!fuse && g_opt[9] == 1 && t1 == 2 && t2 == 2 && !d1->a_kcontig && !d1->b_kcontig && d2->a_kcontig &&
+    // both products of a chip-filling layer in ONE launch of the high-occupancy tiling (dv_gemm_set_option(9, 1)
+    // switches it off): the long-K data-gradient tiles first, the weight-gradient tiles fill the CUs around them --
+    // with seven workgroups per CU the two grids really overlap (decoder heads at cfg 2: 21 + 25 us as two launches,
+    // ~32 us as one; the old four-per-CU pairing of two chip-filling products was SLOWER than two launches)
+    if (!fuse && g_opt[9] != 1 && t1 == 2 && t2 == 2 && !d1->a_kcontig && !d1->b_kcontig && d2->a_kcontig &&
         !d2->b_kcontig && tiles1 >= dense_min_tiles() && tiles1 + tiles2 < 4096) {
         dv_gemm_desc first = *d2, second = *d1;
         if (first.pub_flag == nullptr && second.pub_flag != nullptr) {      // the kernel publishes for its first product

@@ -1081,7 +1081,7 @@ __global__ __launch_bounds__(256) void batch_feed_kernel(
     const int32_t* __restrict__ has_y, int L, int32_t* __restrict__ label_r, const int32_t* __restrict__ fp_i,
     const int32_t* __restrict__ fp_lab, const int32_t* __restrict__ fp_slot, int Mf, int32_t* __restrict__ fp_cls,
     float* __restrict__ onehot, int64_t ldh, int Y, int row_blocks, int vec4, const float* __restrict__ yf,
-    float* __restrict__ ylab, int Yc) {
+    float* __restrict__ ylab, int Yc, float* __restrict__ onehot2, int64_t ldh2) {
     int b = ctr[0] - base[0];
     b = b < 0 ? 0 : (b >= n_batches ? n_batches - 1 : b);
     const int32_t* tb = table + (int64_t)b * B;
@@ -1124,6 +1124,8 @@ __global__ __launch_bounds__(256) void batch_feed_kernel(
         fp_cls[t] = cls;
         if (onehot)
             for (int c = 0; c < Y; ++c) onehot[(int64_t)t * ldh + c] = c == cls ? 1.f : 0.f;
+        if (onehot2)     // (a second copy of the block: the class columns of both fprop inputs)
+            for (int c = 0; c < Y; ++c) onehot2[(int64_t)t * ldh2 + c] = c == cls ? 1.f : 0.f;
     }
 }
 
@@ -1854,7 +1856,7 @@ extern "C" int dv_batch_feed(const float* x1, int64_t ld1, const float* x2, int6
                              int64_t ldn, float sigma, float* xin, int64_t ldo, const int32_t* has_y, int32_t L,
                              int32_t* label_r, const int32_t* fp_i, const int32_t* fp_lab, const int32_t* fp_slot,
                              int32_t Mf, int32_t* fp_cls, float* onehot, int64_t ldh, int32_t Y, const float* yf,
-                             float* ylab, int32_t Yc, dv_stream_t stream) {
+                             float* ylab, int32_t Yc, float* onehot2, int64_t ldh2, dv_stream_t stream) {
     DV_REQUIRE(B >= 0 && Np >= 0 && X >= 0 && n_batches >= 1 && L >= 1 && Mf >= 0 && Y >= 0 && Yc >= 0);
     DV_REQUIRE(!ylab || (yf && Yc >= 1));
     if (B == 0) return DV_OK;
@@ -1869,7 +1871,8 @@ extern "C" int dv_batch_feed(const float* x1, int64_t ld1, const float* x2, int6
                     ld1 % 4 == 0 && (Np == 0 || ld2 % 4 == 0) && ldo % 4 == 0 && (!noise || ldn % 4 == 0);
     hipLaunchKernelGGL(batch_feed_kernel, dim3(row_blocks + lab_blocks), dim3(256), 0, ST(stream), x1, ld1, x2, ld2, y,
                        table, n_batches, ctr, base, B, pair_rows, Np, X, noise, ldn, sigma, xin, ldo, has_y, L,
-                       label_r, fp_i, fp_lab, fp_slot, Mf, fp_cls, onehot, ldh, Y, row_blocks, v4 ? 1 : 0, yf, ylab, Yc);
+                       label_r, fp_i, fp_lab, fp_slot, Mf, fp_cls, onehot, ldh, Y, row_blocks, v4 ? 1 : 0, yf, ylab, Yc,
+                       onehot2, ldh2);
     DV_RETURN_LAUNCH();
 }
 

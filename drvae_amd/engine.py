@@ -469,6 +469,7 @@ class FusedStep(StepSchedule):
                              fp_i=p.fp_q if lab else None, fp_lab=p.fp_lab_i32 if lab else None,
                              fp_slot=p.fp_slot_dev if lab else None, fp_cls=p.fp_cls if (lab and p.Mf) else None,
                              onehot=p.Z3IN[:, cfg.dim_z3:] if (lab and p.Mf) else None, n_classes=cfg.dim_y,
+                             onehot2=p.FPIN[:, Z1:] if (lab and p.Mf) else None,
                              yf=fd.yf if (cfg.has_y and cfg.cont) else None,
                              ylab=p.ylab if (cfg.has_y and cfg.cont) else None)
             else:
@@ -479,8 +480,12 @@ class FusedStep(StepSchedule):
             fuse = self.fuse_heads and self._heads_small(p.DPX)
             Z1blk = p.ZDEC[:L * B]
             if fuse:
+                # (... and every z1 sample is copied into the z1 columns of its fprop rows on the way out: the side
+                # chain's gather is gone)
+                fp4 = self._fprop_from_heads()
                 Q = p.c_enc.forward(p.enc_in, heads=dict(sample=dict(
-                    eps=p.E12, out=p.ZDEC[:p.o3], n_src=B, seg_ptr=p.zseg_ptr, seg_rows=p.zseg_rows)))
+                    eps=p.E12, out=p.ZDEC[:p.o3], n_src=B, seg_ptr=p.zseg_ptr, seg_rows=p.zseg_rows,
+                    out4=p.FPIN[:, :Z1] if fp4 else None, out4_ptr=p.fp_ptr_ext if fp4 else None)))
                 Qmu, Qlv = Q[:, :Z1], Q[:, Z1:]
             else:
                 Q = p.c_enc.forward(p.enc_in)
@@ -543,8 +548,12 @@ class FusedStep(StepSchedule):
             if cfg.has_y:
                 if p.Mf:
                     Z3, Y = cfg.dim_z3, cfg.dim_y
-                    K.rows_gather(p.FPIN, Z1blk, p.fp_src, onehot_cls=p.fp_cls, n_classes=Y,
-                                  park=(first_park[0], first_park[1], first_park[2]) if first_park is not None else None)
+                    if self._fprop_from_heads():
+                        if first_park is not None:
+                            K.flag_wait(*first_park)
+                    else:
+                        K.rows_gather(p.FPIN, Z1blk, p.fp_src, onehot_cls=p.fp_cls, n_classes=Y,
+                                      park=(first_park[0], first_park[1], first_park[2]) if first_park is not None else None)
                     if self.fuse_heads:
                         # the z3 sample leaves the heads' launch of q(z3|z1,y); its KL term against N(0,I) (with its
                         # own free bits) is evaluated next to the z1 term below: one launch less
@@ -654,6 +663,13 @@ class FusedStep(StepSchedule):
         if self.fuse_bwd:
             return             # the loss scalars are assembled on the side chain of backward()
         self._loss_scalars()
+
+    def _fprop_from_heads(self):
+        """the encoder heads' sample epilogue also fills the z1 columns of the fprop input (the class columns are
+        written when the labels are: ``_Plan._refresh_onehot`` / ``dv_batch_feed``)"""
+        cfg, p = self.cfg, self.plan
+        return bool(self.fuse_heads and self._heads_small(p.DPX) and cfg.has_y and not cfg.cont and p.Mf
+                    and os.environ.get('DRVAE_FPROP_HEADS', '1') != '0')
 
     def _klz2_on_main(self):
         """dual-graph train step: the pairs' KL(q(z2|x2)||p(z2|z1)) rows run on the main chain (DRVAE_KLZ2_MAIN=0: on

@@ -120,8 +120,9 @@ def heads_tiles(split):
 def linear_heads(out, x, W, bias=None, *, split, x2=None, scale=None, act0=0, act1=0, shift0=0.0, shift1=0.0,
                  resid=None, resid_cols=0, overread=False, publish=None, sample=None, nll=None):
     """Dual-head Linear with the row work on both heads fused into its epilogue (``dv_gemm_heads``).
-    ``sample`` = dict(eps, out, n_src[, seg_ptr, seg_rows, sub, out2, out3, out3_idx]): ``out`` = (mu | logvar) is
-    written and the reparameterised samples of every source row leave the same launch;
+    ``sample`` = dict(eps, out, n_src[, seg_ptr, seg_rows, sub, out2, out3, out3_idx, out4, out4_ptr]): ``out`` =
+    (mu | logvar) is written and the reparameterised samples of every source row leave the same launch (``out4``:
+    sample row s is also copied to rows [out4_ptr[s], out4_ptr[s+1]) of out4);
     ``nll`` = dict(x, coef, part[, xidx]): ``out`` receives d/d(mu | pre-activation of std) of the Gaussian
     log-likelihood rows, ``part`` (M, heads_tiles(split)) their per-tile partial sums."""
     assert (sample is None) != (nll is None)
@@ -137,6 +138,7 @@ def linear_heads(out, x, W, bias=None, *, split, x2=None, scale=None, act0=0, ac
         e.sub, e.lds = _f32(g('sub'), 'sub'), _ld(g('sub'))
         e.out2, e.ldo2 = _f32(g('out2'), 'out2'), _ld(g('out2'))
         e.out3, e.ldo3, e.out3_idx = _f32(g('out3'), 'out3'), _ld(g('out3')), _i32(g('out3_idx'))
+        e.out4, e.ldo4, e.out4_ptr = _f32(g('out4'), 'out4'), _ld(g('out4')), _i32(g('out4_ptr'))
     else:
         e.mode = _lib.HEADS_NLL
         e.x, e.ldx, e.xidx = _f32(nll['x'], 'x'), _ld(nll['x']), _i32(nll.get('xidx'))
@@ -490,7 +492,7 @@ def rows_gather(out, src, idx=None, *, noise=None, sigma=0.0, onehot_cls=None, n
 
 def batch_feed(xin, x1, x2, y32, table, n_batches, ctr, base, *, pair_rows=None, noise=None, sigma=0.0, has_y=None,
                L=1, label_r=None, fp_i=None, fp_lab=None, fp_slot=None, fp_cls=None, onehot=None, n_classes=0, yf=None,
-               ylab=None):
+               ylab=None, onehot2=None):
     """graph-resident minibatch feed: see dv_batch_feed in include/drvae_hip.h"""
     B = table.shape[1]
     Np = pair_rows.numel() if pair_rows is not None else 0
@@ -501,8 +503,8 @@ def batch_feed(xin, x1, x2, y32, table, n_batches, ctr, base, *, pair_rows=None,
                                          xin.shape[1], _f32(noise), _ld(noise), sigma, _f32(xin), _ld(xin),
                                          _i32(has_y), L, _i32(label_r), _i32(fp_i), _i32(fp_lab), _i32(fp_slot), Mf,
                                          _i32(fp_cls), _f32(onehot), _ld(onehot), n_classes, _f32(yf), _f32(ylab),
-                                         ylab.shape[1] if ylab is not None else 0, _stream()),
-               'dv_batch_feed')
+                                         ylab.shape[1] if ylab is not None else 0, _f32(onehot2), _ld(onehot2),
+                                         _stream()), 'dv_batch_feed')
 
 
 def batch_masks(B, L, *, n_tot, kl_rate, pert_rate, yl_rate, beta, c_nll, w_recl, hx=None, hy=None, y=None, c_klz2=None,

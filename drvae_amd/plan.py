@@ -84,6 +84,9 @@ class _Plan:
             self.fp_l_host, self.fp_i_host = np.asarray(fl, np.int64), np.asarray(fi, np.int64)
             self.fp_slot_host = np.asarray(fslot, np.int64)
             self.fp_ptr = i32(fp_ptr)
+            # the same CSR over ALL sample rows of ZDEC[:o3] (the z2 samples of the pairs feed no fprop row): fan-out of
+            # the encoder heads' sample epilogue straight into the z1 columns of the fprop input
+            self.fp_ptr_ext = i32(np.concatenate([fp_ptr, np.full(L * Np, fp_ptr[-1])]))
             self.fp_src = i32(self.fp_l_host * B + self.fp_i_host)
             self.fp_cls = i32(np.asarray(fcls, np.int64))
             self.fp_q = i32(self.fp_i_host)
@@ -289,6 +292,8 @@ class _Plan:
         if self._cfg.has_y and self.Mf:
             Z3, Y = self._cfg.dim_z3, self._cfg.dim_y
             K.rows_gather(self.Z3IN[:, Z3:], None, None, onehot_cls=self.fp_cls, n_classes=Y, width=0)
+            if not self._cfg.cont:      # ... and of the encoder_z3 input [z1 | onehot(y)] (src/DrVAE.py:341)
+                K.rows_gather(self.FPIN[:, self._cfg.dim_z1:], None, None, onehot_cls=self.fp_cls, n_classes=Y, width=0)
 
     def set_beta(self, beta):
         """(re)write the coefficients that depend on the perturbation annealing coefficient

@@ -207,6 +207,9 @@ typedef struct dv_heads_epi {
     float* out3;
     int64_t ldo3;
     const int32_t* out3_idx;
+    float* out4;               /* optional: sample row s is also copied to rows [out4_ptr[s], out4_ptr[s+1]) of out4 */
+    int64_t ldo4;              /* (the z1 columns of the fprop rows of that sample, src/DrVAE.py:337-341) */
+    const int32_t* out4_ptr;
     /* NLL */
     const float* x;
     int64_t ldx;
@@ -452,7 +455,7 @@ int dv_batch_feed(const float* x1, int64_t ld1, const float* x2, int64_t ld2, co
                   int32_t Np, int32_t X, const float* noise, int64_t ldn, float sigma, float* xin, int64_t ldo,
                   const int32_t* has_y, int32_t L, int32_t* label_r, const int32_t* fp_i, const int32_t* fp_lab,
                   const int32_t* fp_slot, int32_t Mf, int32_t* fp_cls, float* onehot, int64_t ldh, int32_t Y,
-                  const float* yf, float* ylab, int32_t Yc, dv_stream_t stream);
+                  const float* yf, float* ylab, int32_t Yc, float* onehot2, int64_t ldh2, dv_stream_t stream);
 /* dst[di,:W] = beta*dst[di,:W] + sum_{t in [seg_ptr[i],seg_ptr[i+1])} w[t]*src[seg_rows[t],:W],
  * di = dst_idx?dst_idx[i]:i; seg_ptr==NULL: segment i is the single row (seg_rows?seg_rows[i]:i).
  * Deterministic (no atomics): the transpose of every gather above. */

@@ -148,6 +148,8 @@ def linear_heads(out, x, W, bias=None, *, split, x2=None, scale=None, act0=0, ac
                     g('out2')[s_] = z - g('sub')[s_]
                 if g('out3') is not None and int(g('out3_idx')[s_]) >= 0:
                     g('out3')[int(g('out3_idx')[s_])] = z
+                if g('out4') is not None:
+                    g('out4')[int(g('out4_ptr')[s_]):int(g('out4_ptr')[s_ + 1])] = z
     else:
         rows = torch.zeros(M, device=out.device)
         nll_rows_fwdbwd(rows, out[:, :split], out[:, split:], nll['coef'], nll['x'], mu, sd, mode=GAUSS_SIGMA,
@@ -596,7 +598,7 @@ def rows_gather(out, src, idx=None, *, noise=None, sigma=0.0, onehot_cls=None, n
 
 def batch_feed(xin, x1, x2, y32, table, n_batches, ctr, base, *, pair_rows=None, noise=None, sigma=0.0, has_y=None,
                L=1, label_r=None, fp_i=None, fp_lab=None, fp_slot=None, fp_cls=None, onehot=None, n_classes=0, yf=None,
-               ylab=None):
+               ylab=None, onehot2=None):
     if ylab is not None:
         bb = min(max(int(ctr[0]) - int(base[0]), 0), n_batches - 1)
         ylab.copy_(yf.reshape(-1, ylab.shape[1])[table[bb].long()])
@@ -615,6 +617,8 @@ def batch_feed(xin, x1, x2, y32, table, n_batches, ctr, base, *, pair_rows=None,
         fp_cls.copy_(cls)
         if onehot is not None:
             onehot.copy_(torch.nn.functional.one_hot(cls.long(), n_classes).to(onehot.dtype))
+        if onehot2 is not None:
+            onehot2.copy_(torch.nn.functional.one_hot(cls.long(), n_classes).to(onehot2.dtype))
 
 
 def rows_segment_sum(dst, src, *, seg_ptr=None, seg_rows=None, w=None, n=None, dst_idx=None, beta=0.0, width=None,

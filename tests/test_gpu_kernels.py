@@ -881,12 +881,15 @@ def test_linear_heads_sample(K, dev, M, S, Kd):
         sub = rnd(dev, M, S, seed=7)
         idx3 = torch.tensor([(i // 2 if i % 2 == 0 else -1) for i in range(M)], dtype=torch.int32, device=dev)
         outs = []
+        cnt4 = [(i % 3) for i in range(M)]                       # 0..2 extra copies of sample row i (out4: CSR fan-out)
+        ptr4 = torch.tensor(np.concatenate([[0], np.cumsum(cnt4)]), dtype=torch.int32, device=dev)
         for L in (K, R):
             q, z, d, o3 = (torch.full(s_, 7.0, device=dev) for s_ in ((M, 2 * S), (M, S), (M, S), ((M + 1) // 2, S)))
+            o4 = torch.full((int(ptr4[-1]), S + 3), 7.0, device=dev)
             L.linear_heads(q, x, W, b, split=S, shift1=-2.0, resid=x, resid_cols=S,
                            sample=dict(eps=eps[:M] if R_ >= M else rnd(dev, M, S, seed=8), out=z, n_src=M, sub=sub, out2=d,
-                                       out3=o3, out3_idx=idx3))
-            outs.append((q, z, d, o3))
+                                       out3=o3, out3_idx=idx3, out4=o4[:, :S], out4_ptr=ptr4))
+            outs.append((q, z, d, o3, o4))
         for a, b_ in zip(*outs):
             close(a, b_, rtol=5e-4, atol=5e-5 * max(1.0, Kd ** 0.5))
 
