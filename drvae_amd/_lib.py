@@ -37,6 +37,12 @@ class Publish(C.Structure):    # dv_publish: "this launch has started", publishe
     _fields_ = [('flag', _p), ('ctr', _p), ('add', _i32)]
 
 
+class FpropKl(C.Structure):    # dv_fprop_kl: KL rows of the fprop rows riding on the classifier-head launch
+    _fields_ = [('mu_q', _p), ('ldq', _i64), ('qidx', _p), ('mu_p', _p), ('ldp', _i64), ('mu3', _p), ('ld3', _i64),
+                ('Z1', _i32), ('Z3', _i32), ('kl_min', _f), ('klfp', _p), ('raw1', _p), ('raw3', _p), ('dq', _p),
+                ('lddq', _i64), ('dp', _p), ('lddp', _i64)]
+
+
 class Ymarg(C.Structure):      # dv_ymarg: y-marginalisation riding on the classifier-head launch
     _fields_ = [('label', _p), ('fp_ptr', _p), ('klfp', _p), ('log_prior', _f), ('log_prior_v', _p), ('c_kld', _p),
                 ('c_yl', _p), ('yl', _p), ('kld', _p), ('cfp', _p), ('dqy', _p), ('lddq', _i64)]
@@ -95,7 +101,7 @@ SIGNATURES = {
     'dv_cat_terms_fwd': [_p, _i64, _i32, _i32, _p, _p, _i64, _p, _p, _i64, _p, _p, _p],
     'dv_cat_terms_bwd': [_p, _i64, _i32, _i32, _p, _p, _i64, _p, _p, _i64, _p, _p, _i64, _f, _p],
     'dv_smalln_linear_fwd': [_p, _i64, _i32, _p, _i64, _i32, _p, _i64, _p, _i32, _i32, _p, _i64, _p, _i64,
-                             C.POINTER(Ymarg), _p, _p],
+                             C.POINTER(Ymarg), _p, _p, _p],
     'dv_smalln_linear_bwd_data': [_p, _i64, _p, _i64, _p, _i64, _i32, _i32, _i32, C.POINTER(_p), C.POINTER(_i64),
                                   C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_f), C.POINTER(_f), C.POINTER(_i32),
                                   C.POINTER(_f), _p, _i64, _p, _p],

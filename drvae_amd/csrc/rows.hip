@@ -659,7 +659,8 @@ constexpr int kMaxSmallN = 8;
 // y-marginalisation of one row right behind its class probabilities (dv_smalln_linear_fwd with a dv_ymarg argument:
 // the classifier head and the labeled / marginalised KLD assembly of src/DrVAE.py:503-534 in one launch); same
 // arithmetic as ymarg_fwdbwd_kernel below
-__device__ __forceinline__ void ymarg_row(const dv_ymarg& y, int r, int Y, const float* q) {
+// (cfp_out != NULL: the coefficients written to y.cfp are also returned, slot by slot)
+__device__ __forceinline__ void ymarg_row(const dv_ymarg& y, int r, int Y, const float* q, float* cfp_out = nullptr) {
     const int f0 = y.fp_ptr[r], nf = y.fp_ptr[r + 1] - f0;
     const float ck = y.c_kld[r];
     float* dq = y.dqy + (int64_t)r * y.lddq;
@@ -671,8 +672,12 @@ __device__ __forceinline__ void ymarg_row(const dv_ymarg& y, int r, int Y, const
         for (int j = 0; j < Y; ++j) dq[j] = (j == lab) ? y.c_yl[r] / q[j] : 0.f;
         if (nf == 1) {
             y.cfp[f0] = ck;
+            if (cfp_out) cfp_out[0] = ck;
         } else {
-            for (int j = 0; j < Y; ++j) y.cfp[f0 + j] = (j == lab) ? ck : 0.f;
+            for (int j = 0; j < Y; ++j) {
+                y.cfp[f0 + j] = (j == lab) ? ck : 0.f;
+                if (cfp_out) cfp_out[j] = (j == lab) ? ck : 0.f;
+            }
         }
     } else {
         float a = 0.f, b = 0.f;
@@ -681,6 +686,7 @@ __device__ __forceinline__ void ymarg_row(const dv_ymarg& y, int r, int Y, const
             a += q[j] * kf;
             b += -q[j] * (lp - lq);
             y.cfp[f0 + j] = ck * q[j];
+            if (cfp_out) cfp_out[j] = ck * q[j];
             dq[j] = ck * (kf + lq - lp + 1.f);
         }
         y.yl[r] = 0.f;
@@ -694,11 +700,37 @@ __global__ __launch_bounds__(256) void smalln_fwd_kernel(const float* __restrict
                                                          const float* __restrict__ bias, int M, int N,
                                                          float* __restrict__ logits, int64_t ldl,
                                                          float* __restrict__ probs, int64_t ldp, dv_ymarg ym,
-                                                         ParkArgs park) {
+                                                         ParkArgs park, dv_fprop_kl kf) {
     park_block(park);
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= M) return;
+    // (fprop rows of this classifier row: their KL terms first -- the y-marginalisation below consumes them)
+    float raw1[kMaxSmallN];
+    int f0 = 0, nf = 0;
+    if (kf.mu_q != nullptr) {
+        f0 = ym.fp_ptr[r];
+        nf = ym.fp_ptr[r + 1] - f0;
+#pragma unroll
+        for (int u = 0; u < kMaxSmallN; ++u) {
+            if (u >= nf) break;
+            const int t = f0 + u;
+            const float* q = kf.mu_q + (int64_t)kf.qidx[t] * kf.ldq;
+            const float* pp = kf.mu_p + (int64_t)t * kf.ldp;
+            const float* q3 = kf.mu3 + (int64_t)t * kf.ld3;
+            float s1 = 0.f, s3 = 0.f;
+            for (int d = lane; d < kf.Z1; d += 64) s1 += kl_term(DV_GAUSS_LOGVAR, q[d], q[kf.Z1 + d], pp[d], pp[kf.Z1 + d]);
+            for (int d = lane; d < kf.Z3; d += 64) s3 += kl_term(DV_GAUSS_LOGVAR, q3[d], q3[kf.Z3 + d], 0.f, 0.f);
+            s1 = dv_wave_sum_all(s1);
+            s3 = dv_wave_sum_all(s3);
+            raw1[u] = -0.5f * s1;
+            if (lane == 0) {
+                kf.raw1[t] = raw1[u];
+                kf.raw3[t] = -0.5f * s3;
+                kf.klfp[t] = fmaxf(raw1[u], kf.kl_min) + fmaxf(-0.5f * s3, kf.kl_min);
+            }
+        }
+    }
     float acc[kMaxSmallN];
 #pragma unroll
     for (int j = 0; j < kMaxSmallN; ++j) acc[j] = 0.f;
@@ -725,7 +757,30 @@ __global__ __launch_bounds__(256) void smalln_fwd_kernel(const float* __restrict
                 q[j] = fminf(fmaxf(expf(acc[j] - mx) / den, kPMin), kPMax);
                 probs[(int64_t)r * ldp + j] = q[j];
             }
-            if (ym.fp_ptr != nullptr) ymarg_row(ym, r, N, q);
+            if (ym.fp_ptr != nullptr) ymarg_row(ym, r, N, q, kf.mu_q != nullptr ? acc : nullptr);   // (acc: reused for cfp)
+        }
+    }
+    if (kf.mu_q != nullptr) {
+        // backward of the z1 term with the coefficients of the y-marginalisation (lane 0 holds them): dv_kl_rows_bwd
+#pragma unroll
+        for (int u = 0; u < kMaxSmallN; ++u) {
+            if (u >= nf) break;
+            const int t = f0 + u;
+            float c = __shfl(acc[u], 0, 64);
+            c *= raw1[u] > kf.kl_min ? 1.f : (raw1[u] == kf.kl_min ? 0.5f : 0.f);
+            const float* q = kf.mu_q + (int64_t)kf.qidx[t] * kf.ldq;
+            const float* pp = kf.mu_p + (int64_t)t * kf.ldp;
+            float* dq = kf.dq + (int64_t)t * kf.lddq;
+            float* dp = kf.dp + (int64_t)t * kf.lddp;
+            for (int d = lane; d < kf.Z1; d += 64) {
+                const float mq = q[d], sq = q[kf.Z1 + d], mp = pp[d], sp = pp[kf.Z1 + d];
+                const float dm = mq - mp, ivp = expf(-sp), vq = expf(sq);
+                const float gmq = dm * ivp, gsq = -0.5f * (1.f - vq * ivp);
+                dq[d] = c * gmq;
+                dq[kf.Z1 + d] = c * gsq;
+                dp[d] = c * -gmq;
+                dp[kf.Z1 + d] = c * (-0.5f * (-1.f + (dm * dm + vq) * ivp));
+            }
         }
     }
 }
@@ -1692,7 +1747,7 @@ extern "C" int dv_cat_terms_bwd(const float* probs, int64_t ldp, int32_t M, int3
 extern "C" int dv_smalln_linear_fwd(const float* a1, int64_t lda1, int32_t K1, const float* a2, int64_t lda2,
                                     int32_t K2, const float* W, int64_t ldw, const float* bias, int32_t M, int32_t N,
                                     float* logits, int64_t ldl, float* probs, int64_t ldp, const dv_ymarg* ymarg,
-                                    const dv_wait* park_in, dv_stream_t stream) {
+                                    const dv_wait* park_in, const dv_fprop_kl* kf_in, dv_stream_t stream) {
     DV_REQUIRE(M >= 0 && N >= 1 && N <= kMaxSmallN && K1 >= 0 && K2 >= 0 && park_ok(park_in));
     const ParkArgs park = park_in ? *park_in : ParkArgs{};
     DV_REQUIRE(park.flag == nullptr || M > 0);
@@ -1704,8 +1759,14 @@ extern "C" int dv_smalln_linear_fwd(const float* a1, int64_t lda1, int32_t K1, c
         ym = *ymarg;
         DV_REQUIRE(probs && ym.label && ym.klfp && ym.c_kld && ym.c_yl && ym.yl && ym.kld && ym.cfp && ym.dqy);
     }
+    dv_fprop_kl kf{};
+    if (kf_in != nullptr && kf_in->mu_q != nullptr) {
+        kf = *kf_in;
+        DV_REQUIRE(ym.fp_ptr != nullptr && kf.klfp == ym.klfp && kf.qidx && kf.mu_p && kf.mu3 && kf.raw1 && kf.raw3 &&
+                   kf.dq && kf.dp && kf.Z1 >= 0 && kf.Z3 >= 0);
+    }
     hipLaunchKernelGGL(smalln_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, ST(stream), a1, lda1, K1, a2, lda2, K2, W,
-                       ldw, bias, M, N, logits, ldl, probs, ldp, ym, park);
+                       ldw, bias, M, N, logits, ldl, probs, ldp, ym, park, kf);
     DV_RETURN_LAUNCH();
 }
 

@@ -560,8 +560,11 @@ class FusedStep(StepSchedule):
                         Q3 = p.c_top.forward([p.FPIN], heads=dict(sample=dict(eps=p.E3, out=p.Z3IN[:, :Z3], n_src=p.Mf)))
                         PZ1 = p.c_dz1.forward([p.Z3IN])
                         # KLFP = max(KL(q(z1|x)||p(z1|z3,y)), kl_min) + max(KL(q(z3|.)||N(0,I)), kl_min)  (src/DrVAE.py:347,358)
-                        K.kl_rows_fwd(p.KLFP, p.KL1raw, Qmu, Qlv, PZ1[:, :Z1], PZ1[:, Z1:], qidx=p.fp_q, free_bits=True,
-                                      kl_min=cfg.kl_min, prior=(0.0, 0.0), second=(Q3[:, :Z3], Q3[:, Z3:], p.KL3raw))
+                        # -- in the train step inside the classifier-head launch below (``_fprop_tail``)
+                        if not self._fprop_tail():
+                            K.kl_rows_fwd(p.KLFP, p.KL1raw, Qmu, Qlv, PZ1[:, :Z1], PZ1[:, Z1:], qidx=p.fp_q,
+                                          free_bits=True, kl_min=cfg.kl_min, prior=(0.0, 0.0),
+                                          second=(Q3[:, :Z3], Q3[:, Z3:], p.KL3raw))
                     else:
                         Q3 = p.c_top.forward([p.FPIN])
                         # KL(q(z3|z1,y)||N(0,I)) with free bits + the z3 sample, one row pass
@@ -596,9 +599,15 @@ class FusedStep(StepSchedule):
                 if self.clf_small:
                     lc = self.L_clf[0]
                     # train step: the y-marginalisation (forward and backward) rides on the classifier's launch
+                    fk = None
+                    if self._fprop_tail():
+                        # the fprop rows' KL terms in front of the y-marginalisation and the backward of the z1 term
+                        # (with the coefficients it has just produced) behind it: same launch
+                        fk = dict(Q=p.c_enc.out[-1], qidx=p.fp_q, P=p.c_dz1.out[-1], Q3=p.c_top.out[-1], Z1=Z1,
+                                  Z3=cfg.dim_z3, kl_min=cfg.kl_min, raw1=p.KL1raw, raw3=p.KL3raw, dq=p.DQFP, dp=p.DPZ1)
                     K.smalln_fwd(p.QY, None, clf_in[0], lc.W, lc.b, clf_in[1] if len(clf_in) > 1 else None,
                                  ymarg=ym if self.fuse_bwd else None,
-                                 park=(mid_park[0], mid_park[1], mid_park[2]) if clf_park else None)
+                                 park=(mid_park[0], mid_park[1], mid_park[2]) if clf_park else None, fprop_kl=fk)
                 else:
                     K.softmax_clamp_fwd(p.QY, p.c_clf.forward(clf_in), sigmoid1=cfg.clf_1sig)
                 if self.fuse_bwd and self.clf_small:
@@ -670,6 +679,13 @@ class FusedStep(StepSchedule):
         cfg, p = self.cfg, self.plan
         return bool(self.fuse_heads and self._heads_small(p.DPX) and cfg.has_y and not cfg.cont and p.Mf
                     and os.environ.get('DRVAE_FPROP_HEADS', '1') != '0')
+
+    def _fprop_tail(self):
+        """train step: the fprop rows' KL forward and the z1 term's backward ride on the classifier-head launch
+        (``dv_fprop_kl``)"""
+        cfg, p = self.cfg, self.plan
+        return bool(self.fuse_bwd and self.fuse_heads and self.clf_small and cfg.has_y and not cfg.cont and p.Mf
+                    and os.environ.get('DRVAE_FPROP_TAIL', '1') != '0')
 
     def _klz2_on_main(self):
         """dual-graph train step: the pairs' KL(q(z2|x2)||p(z2|z1)) rows run on the main chain (DRVAE_KLZ2_MAIN=0: on
@@ -806,9 +822,10 @@ class FusedStep(StepSchedule):
                     Z3 = cfg.dim_z3
                     PZ1, Q3 = p.c_dz1.out[-1], p.c_top.out[-1]
                     # KL(q(z1|x) || p(z1|z3,y)): gradient to p (decoder_z1 heads) and, row-aligned, to q
-                    K.kl_rows_bwd(p.DQFP[:, :Z1], p.DQFP[:, Z1:], p.DPZ1[:, :Z1], p.DPZ1[:, Z1:], p.CFP, p.KL1raw,
-                                  Qmu, Qlv, PZ1[:, :Z1], PZ1[:, Z1:], qidx=p.fp_q, free_bits=True,
-                                  kl_min=cfg.kl_min)
+                    if not self._fprop_tail():       # (else: left the classifier-head launch of the forward pass)
+                        K.kl_rows_bwd(p.DQFP[:, :Z1], p.DQFP[:, Z1:], p.DPZ1[:, :Z1], p.DPZ1[:, Z1:], p.CFP, p.KL1raw,
+                                      Qmu, Qlv, PZ1[:, :Z1], PZ1[:, Z1:], qidx=p.fp_q, free_bits=True,
+                                      kl_min=cfg.kl_min)
                     p.c_dz1.backward(p.DPZ1, [p.Z3IN], [[(p.DZ3IN, 1.0, 0.0)]])
                     # KL(q(z3|z1,y) || N(0,I)) + the sample path
                     K.kl_rows_bwd(p.DQ3[:, :Z3], p.DQ3[:, Z3:], None, None, p.CFP, p.KL3raw, Q3[:, :Z3], Q3[:, Z3:],

@@ -371,11 +371,13 @@ def cat_terms_bwd(dprobs, probs, *, labels=None, prior=None, c_logp=None, g_kl=N
                                             _ld(dprobs), beta, _stream()), 'dv_cat_terms_bwd')
 
 
-def smalln_fwd(probs, logits, a1, W, bias=None, a2=None, ymarg=None, park=None):
+def smalln_fwd(probs, logits, a1, W, bias=None, a2=None, ymarg=None, park=None, fprop_kl=None):
     """probs = clamp(softmax([a1|a2] W^T + b)) for N <= 8 outputs (either output may be None).
     ``ymarg`` = (yl, kld, cfp, dqy, label, fp_ptr, klfp, log_prior, c_kld, c_yl): the y-marginalisation of every row
     (the arguments of ``ymarg_fwdbwd``) rides on the same launch.  ``park`` = (flag, ctr, err[, add[, max_spins]]): every
-    workgroup first parks on another chain's flag (see ``flag_wait``)."""
+    workgroup first parks on another chain's flag (see ``flag_wait``).  ``fprop_kl`` = dict(Q, qidx, P, Q3, Z1, Z3,
+    kl_min, raw1, raw3, dq, dp) with ``ymarg``: the KL rows of the fprop rows (forward in front of the
+    y-marginalisation, the z1 term's backward behind it) ride on the same launch (``dv_fprop_kl``)."""
     M = a1.shape[0]
     N = W.shape[0]
     K1, K2 = a1.shape[1], (a2.shape[1] if a2 is not None else 0)
@@ -389,9 +391,21 @@ def smalln_fwd(probs, logits, a1, W, bias=None, a2=None, ymarg=None, park=None):
         y.c_kld, y.c_yl, y.yl, y.kld, y.cfp = _f32(c_kld), _f32(c_yl), _f32(yl), _f32(kld), _f32(cfp)
         y.dqy, y.lddq = _f32(dqy), _ld(dqy)
         ym = C.byref(y)
+    kf = None
+    if fprop_kl is not None:
+        assert ymarg is not None
+        f = _lib.FpropKl()
+        Q, P, Q3 = fprop_kl['Q'], fprop_kl['P'], fprop_kl['Q3']
+        f.Z1, f.Z3, f.kl_min = fprop_kl['Z1'], fprop_kl['Z3'], fprop_kl['kl_min']
+        assert Q.shape[1] == 2 * f.Z1 and P.shape[1] == 2 * f.Z1 and Q3.shape[1] == 2 * f.Z3
+        f.mu_q, f.ldq, f.qidx = _f32(Q), _ld(Q), _i32(fprop_kl['qidx'])
+        f.mu_p, f.ldp, f.mu3, f.ld3 = _f32(P), _ld(P), _f32(Q3), _ld(Q3)
+        f.klfp, f.raw1, f.raw3 = _f32(ymarg[6]), _f32(fprop_kl['raw1']), _f32(fprop_kl['raw3'])
+        f.dq, f.lddq, f.dp, f.lddp = _f32(fprop_kl['dq']), _ld(fprop_kl['dq']), _f32(fprop_kl['dp']), _ld(fprop_kl['dp'])
+        kf = C.byref(f)
     _lib.check(_lib.load().dv_smalln_linear_fwd(_f32(a1), _ld(a1), K1, _f32(a2), _ld(a2), K2, _f32(W), _ld(W),
                                                 _f32(bias), M, N, _f32(logits), _ld(logits), _f32(probs),
-                                                _ld(probs), ym, _wait(park), _stream()), 'dv_smalln_linear_fwd')
+                                                _ld(probs), ym, _wait(park), kf, _stream()), 'dv_smalln_linear_fwd')
 
 
 def smalln_bwd_data(dsts, dprobs, probs, W, seg=None):

@@ -73,6 +73,31 @@ typedef struct dv_publish {
     int32_t add;
 } dv_publish;
 
+/* The KL rows of the fprop rows riding on the classifier-head launch, in front of and behind its y-marginalisation
+ * (dv_smalln_linear_fwd with a dv_ymarg AND a dv_fprop_kl argument; train step): for every fprop row t of classifier
+ * row r (fp_ptr of the dv_ymarg): raw1[t] = KL(q(z1|x)[qidx[t]] || p(z1|z3,y)[t]), raw3[t] = KL(q(z3|z1,y)[t] || N(0,I)),
+ * klfp[t] = max(raw1, kl_min) + max(raw3, kl_min) (dv_kl_rows_fwd with its second term; LOGVAR parametrisation), then the
+ * classifier head and the y-marginalisation, then the backward of the z1 term with the coefficient the y-marginalisation
+ * has just produced: row-aligned d/d(q) -> dq, d/d(p) -> dp (dv_kl_rows_bwd, free bits, beta = 0).  mu_q == NULL: none */
+typedef struct dv_fprop_kl {
+    const float* mu_q;         /* (mu | logvar) rows of q(z1|x), ld = ldq; logvar at column offset Z1 of the same row */
+    int64_t ldq;
+    const int32_t* qidx;
+    const float* mu_p;         /* (mu | logvar) of p(z1|z3,y), row t */
+    int64_t ldp;
+    const float* mu3;          /* (mu | logvar) of q(z3|z1,y), row t; Z3 columns each */
+    int64_t ld3;
+    int32_t Z1, Z3;
+    float kl_min;
+    float* klfp;               /* out, per fprop row (the dv_ymarg's klfp must be this buffer) */
+    float* raw1;
+    float* raw3;
+    float* dq;                 /* out (Mf, 2*Z1): d/d(mu_q | logvar_q), row-aligned */
+    int64_t lddq;
+    float* dp;                 /* out (Mf, 2*Z1): d/d(mu_p | logvar_p) */
+    int64_t lddp;
+} dv_fprop_kl;
+
 /* up to two device counters (1 or 2 int32 words each: int32 / uint64 little-endian) advanced by a
  * launch that carries the bump (see dv_counters_add2); c == NULL: unused slot */
 /* y-marginalisation riding on the classifier-head launch (dv_smalln_linear_fwd): the arguments of dv_ymarg_fwdbwd
@@ -371,7 +396,7 @@ int dv_cat_terms_bwd(const float* probs, int64_t ldp, int32_t M, int32_t Y, cons
 int dv_smalln_linear_fwd(const float* a1, int64_t lda1, int32_t K1, const float* a2, int64_t lda2, int32_t K2,
                          const float* W, int64_t ldw, const float* bias, int32_t M, int32_t N, float* logits,
                          int64_t ldl, float* probs, int64_t ldp, const dv_ymarg* ymarg, const dv_wait* park,
-                         dv_stream_t stream);
+                         const dv_fprop_kl* fprop_kl, dv_stream_t stream);
 int dv_smalln_linear_bwd_data(const float* dprobs, int64_t lddp, const float* probs, int64_t ldp, const float* W,
                               int64_t ldw, int32_t M, int32_t N, int32_t n_dst, float* const* dst,
                               const int64_t* ld, const int32_t* col0, const int32_t* ncol, const float* alpha,

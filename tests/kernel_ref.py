@@ -466,13 +466,23 @@ def _dlogits(dprobs, probs):
     return probs * (g - (g * probs).sum(1, keepdim=True))
 
 
-def smalln_fwd(probs, logits, a1, W, bias=None, a2=None, ymarg=None, park=None):
+def smalln_fwd(probs, logits, a1, W, bias=None, a2=None, ymarg=None, park=None, fprop_kl=None):
     if park is not None:
         flag_wait(*park)
     if ymarg is not None:
-        smalln_fwd(probs, logits, a1, W, bias, a2)
         yl, kld, cfp, dqy, label, fp_ptr, klfp, log_prior, c_kld, c_yl = ymarg
+        f = fprop_kl
+        if f is not None:      # the unfused sequence the fused launch replaces
+            Z1, Z3 = f['Z1'], f['Z3']
+            kl_rows_fwd(klfp, f['raw1'], f['Q'][:, :Z1], f['Q'][:, Z1:], f['P'][:, :Z1], f['P'][:, Z1:], qidx=f['qidx'],
+                        free_bits=True, kl_min=f['kl_min'], prior=(0.0, 0.0),
+                        second=(f['Q3'][:, :Z3], f['Q3'][:, Z3:], f['raw3']))
+        smalln_fwd(probs, logits, a1, W, bias, a2)
         ymarg_fwdbwd(yl, kld, cfp, dqy, probs, label, fp_ptr, klfp, log_prior, c_kld, c_yl)
+        if f is not None:
+            kl_rows_bwd(f['dq'][:, :Z1], f['dq'][:, Z1:], f['dp'][:, :Z1], f['dp'][:, Z1:], cfp, f['raw1'],
+                        f['Q'][:, :Z1], f['Q'][:, Z1:], f['P'][:, :Z1], f['P'][:, Z1:], qidx=f['qidx'], free_bits=True,
+                        kl_min=f['kl_min'])
         return
     x = torch.cat([a1, a2], 1) if a2 is not None else a1
     z = x @ W.t() + (bias if bias is not None else 0)
