@@ -87,7 +87,8 @@ typedef struct dv_fprop_kl {
     int64_t ldp;
     const float* mu3;          /* (mu | logvar) of q(z3|z1,y), row t; Z3 columns each */
     int64_t ld3;
-    int32_t Z1, Z3;
+    int32_t Z1;
+    int32_t Z3;
     float kl_min;
     float* klfp;               /* out, per fprop row (the dv_ymarg's klfp must be this buffer) */
     float* raw1;

@@ -62,7 +62,8 @@ def test_gemm_desc_layout_matches_header():
 
 
 @pytest.mark.parametrize('cname,pyname', [('dv_wait', 'Wait'), ('dv_bump', 'Bump'), ('dv_loss_term', 'LossTerm'),
-                                          ('dv_publish', 'Publish')])
+                                          ('dv_publish', 'Publish'), ('dv_heads_epi', 'HeadsEpi'),
+                                          ('dv_fprop_kl', 'FpropKl'), ('dv_ymarg', 'Ymarg')])
 def test_small_struct_layouts_match_header(cname, pyname):
     from drvae_amd import _lib
     src = open(os.path.join(ROOT, 'include', 'drvae_hip.h')).read()
