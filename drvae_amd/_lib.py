@@ -122,9 +122,9 @@ SIGNATURES = {
     'dv_weighted_sum': [_p, _p, _p, _i32, _f, _p, _f, _p],
     'dv_recon_row_stats': [_p, _i64, _p, _i64, _i32, _i32, _p, _p],
     'dv_col_moments': [_p, _i64, _p, _i64, _i32, _i32, _p, _p],
-    'dv_loss_assemble': [C.POINTER(LossTerm), _i32, _p, _p, _p, _p, _i32, _p],
+    'dv_loss_assemble': [C.POINTER(LossTerm), _i32, _p, _p, _p, _p, _i32, _p, _p],
     'dv_loss_assemble_after': [_p, _p, _i32, _p, _i32, C.POINTER(LossTerm), _i32, _p, _p, _p, _p, _i32, _i64, _p, _i32,
-                               _i64, _p, _i32, _p],
+                               _i64, _p, _i32, _p, _p],
     'dv_axpby': [_p, _f, _p, _f, _i64, _p],
     'dv_adam_l2': [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _f, _p, _p, _i32, _p],
     'dv_adam_l2_gated': [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _f, _p, _p, _p, _i32, _p, _i32, _i64, _i64, _p,

@@ -1995,7 +1995,7 @@ extern "C" int dv_col_moments(const float* x, int64_t ldx, const float* r, int64
 
 extern "C" int dv_loss_assemble(const dv_loss_term* terms, int32_t n_terms, const float* w_elbo,
                                 const float* w_cmpl, float* loss, const int32_t* halt, int32_t n_halt,
-                                dv_stream_t stream) {
+                                float* accum, dv_stream_t stream) {
     DV_REQUIRE(n_terms >= 0 && n_terms <= DV_MAX_LOSS_TERMS && (terms || n_terms == 0));
     DV_REQUIRE(n_halt >= 0 && (halt || n_halt == 0));
     DV_REQUIRE(w_elbo && w_cmpl && loss);
@@ -2014,7 +2014,7 @@ extern "C" int dv_loss_assemble_after(int32_t* flag, const int32_t* ctr, int32_t
                                       const dv_loss_term* terms, int32_t n_terms, const float* w_elbo,
                                       const float* w_cmpl, float* loss, int32_t* c1, int32_t n1, int64_t inc1,
                                       int32_t* c2, int32_t n2, int64_t inc2, const int32_t* halt, int32_t n_halt,
-                                      dv_stream_t stream) {
+                                      float* accum, dv_stream_t stream) {
     DV_REQUIRE(n_halt >= 0 && (halt || n_halt == 0));
     DV_REQUIRE(n_terms >= 0 && n_terms <= DV_MAX_LOSS_TERMS && (terms || n_terms == 0));
     DV_REQUIRE(w_elbo && w_cmpl && loss && flag && ctr && err && max_spins > 0);

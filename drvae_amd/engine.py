@@ -191,6 +191,7 @@ class FusedStep(StepSchedule):
         self._plans = {}                    # plans by batch structure (a handful of signatures in practice)
         self.max_plans = 8
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=self.dev)       # Adam step (device side)
+        self.loss_sum = torch.zeros(8, device=self.dev)      # running sums of the loss scalars over train steps
         self.rng_ctr = torch.zeros(2, dtype=torch.int32, device=self.dev)        # Philox counter (device side)
         self.seed = seed
         self.training = True
@@ -744,8 +745,9 @@ class FusedStep(StepSchedule):
             bump = [(self.step_dev, 1)] + ([(self.rng_ctr, self._rng_pending)] if getattr(self, '_rng_pending', 0) else [])
             self._rng_pending = 0
             self._ctr_bumped = True
+        # (train steps also add their scalars to ``loss_sum``: a ``fit`` epoch reads the sums once, at its end)
         K.loss_assemble(self.arena.loss, [] if terms_elsewhere else terms, p.w_elbo, p.w_cmpl, after=after, bump=bump,
-                        halt=self.sync_err)
+                        halt=self.sync_err, accum=self.loss_sum if self.fuse_bwd else None)
 
     # --------------------------------------------------------------------- backward
     def backward(self):

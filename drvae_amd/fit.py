@@ -15,6 +15,7 @@ from collections import OrderedDict
 import numpy as np
 import torch
 
+from . import engine as E
 from . import metrics as MET
 
 
@@ -241,15 +242,29 @@ class FitMixin:
         n_b = len(batcher)
         every = max(10, n_b / 10)
         total = torch.zeros((), device=eng.dev)
+        # single process: the launch that assembles a step's loss scalars also adds them to ``eng.loss_sum`` -- nothing
+        # sits between two replays on the critical chain's stream (three tiny torch launches per step did: 54 steps x
+        # ~40 us per epoch at cfg 2).  Under data parallelism the step's scalars are the exchanged ones: summed here
+        in_graph = getattr(self, '_allreduce', None) is None
+        side = eng.flag_side if getattr(eng, '_side_graph', None) is not None else None
+        if in_graph:
+            eng.loss_sum.zero_()
+            if side is not None:           # (the side chain's stream runs the assembling launch)
+                side.wait_stream(torch.cuda.current_stream())
         for b in range(n_b):
             if eng.plan.live_feed is None:
                 batcher.feed()
             eng.replay(allreduce=getattr(self, '_allreduce', None))
-            loss = self._loss_tensors(eng)
-            total += self._train_objective(loss)
+            if not in_graph:
+                total += self._train_objective(self._loss_tensors(eng))
             if verbose and b % every == 0:
-                self._log_losses(epoch, b * batcher.batch_size, len(batcher.dataset), b / n_b, loss)
+                self._log_losses(epoch, b * batcher.batch_size, len(batcher.dataset), b / n_b, self._loss_tensors(eng))
         self.finished_training_iters = eng.iters
+        if in_graph:
+            if side is not None:
+                torch.cuda.current_stream().wait_stream(side)
+            sums = OrderedDict((k, eng.loss_sum[E.LOSS_IDX[k]]) for k in self._loss_tensors(eng))
+            total = self._train_objective(sums)
         mean = float(total) / n_b          # the epoch's one host sync
         eng.check_sync()
         return mean

@@ -567,11 +567,12 @@ def col_moments(out, x, r):
                'dv_col_moments')
 
 
-def loss_assemble(loss, terms, w_elbo, w_cmpl, after=None, bump=(), halt=None):
+def loss_assemble(loss, terms, w_elbo, w_cmpl, after=None, bump=(), halt=None, accum=None):
     """terms: list of (x, w_or_None, scale, out_index); see ``dv_loss_assemble``.  ``after`` =
     (flag, counter, err, add, max_spins): park like ``flag_wait`` inside the same launch first;
     ``bump`` (with ``after`` only) = up to two (counter, inc): advanced at the end of the launch;
-    ``halt``: the (err, ticks) pairs of the step's waits -- any error set: the scalars come out NaN."""
+    ``halt``: the (err, ticks) pairs of the step's waits -- any error set: the scalars come out NaN;
+    ``accum`` (8 floats): running sums, ``accum += loss`` in the same launch."""
     hp, hn = _halt(halt)
     arr = (_lib.LossTerm * max(len(terms), 1))()
     for i, term in enumerate(terms):      # (x, w, scale, out[, row_len]): row_len > 1 = one weight per row of x
@@ -580,14 +581,14 @@ def loss_assemble(loss, terms, w_elbo, w_cmpl, after=None, bump=(), halt=None):
         arr[i].row_len = term[4] if len(term) > 4 else 1
     if after is None:
         _lib.check(_lib.load().dv_loss_assemble(arr, len(terms), _f32(w_elbo), _f32(w_cmpl), _f32(loss), hp, hn,
-                                                _stream()), 'dv_loss_assemble')
+                                                _f32(accum), _stream()), 'dv_loss_assemble')
     else:
         flag, ctr, err, add, spins = after
         cs = list(bump) + [(None, 0)] * (2 - len(bump))
         _lib.check(_lib.load().dv_loss_assemble_after(
             _i32(flag), _i32(ctr), add, _i32(err), spins, arr, len(terms), _f32(w_elbo), _f32(w_cmpl), _f32(loss),
             _i32(cs[0][0]), 0 if cs[0][0] is None else cs[0][0].numel(), cs[0][1],
-            _i32(cs[1][0]), 0 if cs[1][0] is None else cs[1][0].numel(), cs[1][1], hp, hn, _stream()),
+            _i32(cs[1][0]), 0 if cs[1][0] is None else cs[1][0].numel(), cs[1][1], hp, hn, _f32(accum), _stream()),
             'dv_loss_assemble_after')
 
 

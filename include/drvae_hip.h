@@ -530,8 +530,10 @@ typedef struct dv_loss_term {
     int32_t out;     /* 0 RECL, 1 KLD, 2 PERT, 3 YL, 4 MMD */
     int32_t row_len; /* > 1: x is (n / row_len, row_len) and w holds one weight per ROW (w[i / row_len]); else 0 / 1 */
 } dv_loss_term;
+/* accum (optional, 8 floats): accum[i] += loss[i] in the same launch -- the running sums of a training epoch
+ * (src/DrVAE.py:787-795 averages the per-batch objective), read by the host once per epoch */
 int dv_loss_assemble(const dv_loss_term* terms, int32_t n_terms, const float* w_elbo, const float* w_cmpl,
-                     float* loss, const int32_t* halt, int32_t n_halt, dv_stream_t stream);
+                     float* loss, const int32_t* halt, int32_t n_halt, float* accum, dv_stream_t stream);
 /* same, but first parks like dv_flag_wait(flag, ctr, add, err, max_spins) inside the launch (the terms
  * of another chain are read only after the wait; saves the separate wait launch), and last advances up
  * to two device counters like dv_counters_add2 (c1 / c2 may be NULL; c1 may alias ctr: it is read before;
@@ -540,7 +542,7 @@ int dv_loss_assemble(const dv_loss_term* terms, int32_t n_terms, const float* w_
 int dv_loss_assemble_after(int32_t* flag, const int32_t* ctr, int32_t add, int32_t* err, int32_t max_spins,
                            const dv_loss_term* terms, int32_t n_terms, const float* w_elbo, const float* w_cmpl,
                            float* loss, int32_t* c1, int32_t n1, int64_t inc1, int32_t* c2, int32_t n2,
-                           int64_t inc2, const int32_t* halt, int32_t n_halt, dv_stream_t stream);
+                           int64_t inc2, const int32_t* halt, int32_t n_halt, float* accum, dv_stream_t stream);
 /* y[i] = a*x[i] + b*y[i] over n contiguous floats */
 int dv_axpby(const float* x, float a, float* y, float b, int64_t n, dv_stream_t stream);
 

@@ -675,7 +675,7 @@ def _halted(halt):
     return halt is not None and bool((halt.reshape(-1)[0::2] != 0).any())
 
 
-def loss_assemble(loss, terms, w_elbo, w_cmpl, after=None, bump=(), halt=None):
+def loss_assemble(loss, terms, w_elbo, w_cmpl, after=None, bump=(), halt=None, accum=None):
     if after is not None:
         flag_wait(after[0], after[1], after[2], after[3], after[4])
     for (c, inc) in bump:
@@ -694,6 +694,8 @@ def loss_assemble(loss, terms, w_elbo, w_cmpl, after=None, bump=(), halt=None):
     acc[5] = (w_elbo[:3] * acc[:3]).sum()
     acc[6] = (w_cmpl[:8] * acc[:8]).sum()
     loss[:8] = torch.full_like(acc, float('nan')) if _halted(halt) else acc
+    if accum is not None:
+        accum[:8] += loss[:8]
 
 
 def axpby(y, x, a=1.0, b=0.0):
