@@ -96,6 +96,65 @@ def test_gemm_backward_products(K, dev, tiling, M, N, Kd):
         _lib.load().dv_gemm_force_tiling(0)
 
 
+def test_gemm_random_shapes_all_products(K, dev):
+    """Random shapes around the tile edges (M, N, K not multiples of 32 / 64 / 4, leading dimensions padded or not),
+    every product of a layer -- x W^T with a dual-head epilogue, dy W with the activation backward, dy^T x with the
+    fused bias gradient, the paired dW+dX launch -- on the dispatcher's own choice and on the seven-per-CU tiling,
+    against the plain-PyTorch reference"""
+    from hypothesis import given, settings, strategies as st, HealthCheck
+    from drvae_amd import _lib
+    lib = _lib.load()
+
+    @settings(max_examples=40, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+    @given(M=st.integers(1, 700), N=st.integers(1, 700), Kd=st.integers(1, 400), pad=st.sampled_from([0, 1, 2, 4]),
+           tiling=st.sampled_from([0, 17]))
+    def run(M, N, Kd, pad, tiling):
+        lib.dv_gemm_force_tiling(tiling)
+        try:
+            x, W = strided(dev, M, Kd, pad, seed=1), strided(dev, N, Kd, pad, seed=2)
+            b, dpre, yprev = rnd(dev, N, seed=3), strided(dev, M, N, pad, seed=5), rnd(dev, M, Kd, seed=6)
+            out, ref = torch.full((M, N), 7.0, device=dev), torch.zeros(M, N, device=dev)
+            kw = dict(bias=b, split=N // 2, act0='identity', act1='softplus', shift1=1e-3) if N > 1 else dict(bias=b)
+            K.linear_fwd(out, x, W, overread=False, **kw)
+            R.linear_fwd(ref, x, W, **kw)
+            close(out, ref, **gemm_tol(Kd))
+            dx, rx = torch.empty(M, Kd, device=dev), torch.empty(M, Kd, device=dev)
+            K.linear_bwd_data(dx, dpre, W, yref=yprev, act='elu')
+            R.linear_bwd_data(rx, dpre, W, yref=yprev, act='elu')
+            close(dx, rx, **gemm_tol(N))
+            dW, db, rW, rb = (torch.empty(N, Kd, device=dev), torch.empty(N, device=dev), torch.empty(N, Kd, device=dev),
+                              torch.empty(N, device=dev))
+            K.linear_bwd_weight(dW, dpre, x, dbias=db)
+            R.linear_bwd_weight(rW, dpre, x, dbias=rb)
+            close(dW, rW, **gemm_tol(M))
+            close(db, rb, **gemm_tol(M))
+            if tiling == 0:
+                dW2, db2, dx2 = torch.empty_like(dW), torch.empty_like(db), torch.empty_like(dx)
+                K.linear_bwd_pair(dW2, db2, dx2, dpre, x, W, yref=yprev, act='elu')
+                close(dW2, rW, **gemm_tol(M))
+                close(db2, rb, **gemm_tol(M))
+                close(dx2, rx, **gemm_tol(N))
+        finally:
+            lib.dv_gemm_force_tiling(0)
+    run()
+
+    # chip-filling layers (>= 512 tiles of 32x32 in dy^T x): the paired launch of the seven-per-CU tiling
+    @settings(max_examples=8, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+    @given(M=st.integers(33, 900), N=st.integers(1200, 2100), Kd=st.integers(450, 700), pad=st.sampled_from([0, 2]))
+    def run_big(M, N, Kd, pad):
+        x, W = strided(dev, M, Kd, pad, seed=1), strided(dev, N, Kd, pad, seed=2)
+        dpre, yprev = strided(dev, M, N, pad, seed=5), rnd(dev, M, Kd, seed=6)
+        outs = []
+        for L in (K, R):
+            dW, db, dx = torch.empty(N, Kd, device=dev), torch.empty(N, device=dev), torch.full((M, Kd), 3.0, device=dev)
+            L.linear_bwd_pair(dW, db, dx, dpre, x, W, alpha=0.5, beta_x=1.0, yref=yprev, act='elu')
+            outs.append((dW, db, dx))
+        close(outs[0][0], outs[1][0], **gemm_tol(M))
+        close(outs[0][1], outs[1][1], **gemm_tol(M))
+        close(outs[0][2], outs[1][2], **gemm_tol(N))
+    run_big()
+
+
 def test_gemm_mfma_layout_asymmetric(K, dev):
     """A = I with an asymmetric B: catches a transposed C/D register map (guide section 3)."""
     n = 96
