@@ -691,8 +691,11 @@ class FusedStep(StepSchedule):
     def _klz2_on_main(self):
         """dual-graph train step: the pairs' KL(q(z2|x2)||p(z2|z1)) rows run on the main chain (DRVAE_KLZ2_MAIN=0: on
         the side chain, as in every other schedule)"""
+        # (not with the batch-independent plan: its worst-case decoder rows make the main chain the longer one again,
+        # the side chain parks ~13 us per step behind it -- sampler feed 0.250 -> 0.248 ms with the rows on the side chain)
+        dflt = '0' if (self.plan is not None and self.plan.universal) else '1'
         return (self._mode() == 5 and not self.cfg.cont and self.cfg.has_y
-                and os.environ.get('DRVAE_KLZ2_MAIN', '1') != '0')
+                and os.environ.get('DRVAE_KLZ2_MAIN', dflt) != '0')
 
     def _mmd_penalty(self):
         """Model-level MMD penalty of the ``use_s`` extension (src/DrVAE.py:394-398,537-540): minus the MMD between
