@@ -105,3 +105,40 @@ def test_philox_step_runs_and_is_reproducible(dev):
     assert out[0][0] == out[1][0]
     assert torch.equal(out[0][1], out[1][1])            # no atomics anywhere: bitwise reproducible
     assert all(np.isfinite(v) for v in out[0][0].values())
+
+
+@pytest.mark.parametrize('kind,most', [('drvae', 34), ('vfae', 32), ('pvae', 21)])
+def test_launch_count_of_the_captured_step(dev, kind, most, monkeypatch):
+    """The captured train step at the benchmark's batch shape: how many launches it is made of (every C-ABI call of
+    the capture = one launch; round 1: 47 for DrVAE).  A regression guard for the fusions of the step: samples / NLL
+    in the heads' epilogues, paired dW||dX launches, waits / publishes / counters riding on neighbours, the fprop
+    block's KL rows inside the classifier-head launch."""
+    from drvae_amd import _lib
+    spec = M.ModelSpec(kind=kind, L=1 if kind == 'pvae' else 2)
+    params = M.init_params(spec, 3, as_numpy=True)
+    eng, arena = make_engine(spec, params, dev)
+    set_batch(eng, M.make_batch(spec, 150, seed=5), dev)
+    eng.train_step()
+    counts = {'n': 0, 'on': False}
+    real = _lib.check
+
+    def counting(code, what):
+        if counts['on'] and not what.startswith('dv_gemm_set_option'):
+            counts['n'] += 1
+        return real(code, what)
+    monkeypatch.setattr(_lib, 'check', counting)
+    real_capture_main = eng._capture_main
+
+    def capture_main(*a, **k):          # (the warm-up pass in front of the capture is not part of the step)
+        counts['on'] = True
+        return real_capture_main(*a, **k)
+    monkeypatch.setattr(eng, '_capture_main', capture_main)
+    eng.capture()
+    counts['on'] = False
+    print('launch calls of the captured step:', kind, counts['n'])
+    assert 0 < counts['n'] <= most, counts
+    for _ in range(3):
+        eng.replay()
+    torch.cuda.synchronize()
+    eng.check_sync()
+    assert all(np.isfinite(v) for v in eng.losses().values())
