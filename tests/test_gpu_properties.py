@@ -249,3 +249,59 @@ def test_philox_draws_are_keyed_by_global_row(dev):
     s = grads[1] + grads[2]
     rel = float((s - grads[0]).norm() / grads[0].norm())
     assert rel < 2e-5, rel
+
+
+def test_random_model_shapes_captured_step_vs_oracle(dev):
+    """Random model shapes (odd gene counts, latent sizes that are no multiple of a tile or of 4, 2-4 classes, 1-3
+    Monte-Carlo samples, random group mixes) -- three train steps with injected noise: the eager fused step against
+    the CPU oracle (losses 1e-4 relative, parameters after the optimiser), and the captured dual-graph step (Philox
+    noise) bitwise against the eager one.  Covers every fusion of the step at sizes the golden cases do not."""
+    from hypothesis import given, settings, strategies as st, HealthCheck, Phase
+    from tests.test_engine_cpu import make_engine, set_batch
+
+    @settings(max_examples=6, deadline=None, derandomize=True, database=None, phases=[Phase.generate],
+              suppress_health_check=list(HealthCheck))
+    @given(kind=st.sampled_from(['drvae', 'vfae', 'pvae']), X=st.integers(37, 300), Z1=st.integers(5, 70),
+           Z3=st.integers(5, 70), Y=st.integers(2, 4), L=st.integers(1, 3), B=st.integers(9, 70),
+           seed=st.integers(0, 1000))
+    def run(kind, X, Z1, Z3, Y, L, B, seed):
+        spec = M.ModelSpec(kind=kind, dim_x=X, dim_y=Y, dim_z1=Z1, dim_z3=Z3, h_en_z1=[2 * Z1 + 3], h_de_z1=[Z1 + 7],
+                           h_en_z3=[Z3 + 5], h_de_x=[3 * Z1 + 1], L=L)
+        rs = np.random.RandomState(seed)
+        batch = M.make_batch(spec, B, seed=seed)
+        if kind != 'vfae':
+            batch['has_x2'] = (rs.rand(B) < 0.5).astype(np.int64)
+            batch['x2'] = batch['x2'] * batch['has_x2'][:, None].astype(np.float32)
+        if kind != 'pvae':
+            batch['has_y'] = (rs.rand(B) < 0.6).astype(np.int64)
+        params = M.init_params(spec, seed + 1, as_numpy=True)
+        tr = M.RefTrainer(spec, M.init_params(spec, seed + 1))
+        eng, arena = make_engine(spec, params, dev)
+        set_batch(eng, batch, dev)
+        for it in range(3):
+            noise = M.make_noise(spec, B, seed=seed + 10 + it)
+            ref, _ = tr.step(batch, noise)
+            eng.train_step(noise)
+            got = eng.losses()
+            for k, v in got.items():
+                np.testing.assert_allclose(v, float(ref[k].detach()), rtol=2e-4, atol=2e-5, err_msg='%s %s it%d' % (kind, k, it))
+        # (norm-wise per tensor: Adam turns a gradient element that is pure summation-order noise into a full +-lr move)
+        for k in arena.shapes:
+            a, b = arena.p(k).cpu().numpy().ravel(), tr.params[k].detach().numpy().ravel()
+            err = np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-12)
+            assert err < 2e-3, '%s param %s: %g' % (kind, k, err)
+        # captured (dual-graph where the model has a side chain) == eager, bitwise, on on-device noise
+        e0, a0 = make_engine(spec, params, dev)
+        e1, a1 = make_engine(spec, params, dev)
+        for e in (e0, e1):
+            set_batch(e, batch, dev)
+            e.train_step()
+        e1.capture()
+        for _ in range(3):
+            e0.train_step()
+            e1.replay()
+        torch.cuda.synchronize()
+        e1.check_sync()
+        assert torch.equal(a0.param, a1.param), kind
+        assert e0.losses() == e1.losses()
+    run()
