@@ -802,7 +802,7 @@ __device__ __forceinline__ void publish_on_entry(const dv_gemm_desc& g) {
 }
 
 template <int BM, int BN, int BK, int WM, int WN, int KS, bool AKC, bool BKC, bool MI16 = false>
-__global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 16) ? 4 : (BM >= 128 || BK >= 128) ? 2 : (WM * WN * KS == 8 ? (BM * BN == 1024 ? DV_LB8 : 2) : (BK == 32 && BM == 32 ? 7 : 4))) void gemm_kernel(const dv_gemm_desc g, const LoadCfg lc) {
+__global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 16) ? 4 : (BM >= 128 || BK >= 128) ? 2 : (BM * BN >= 6144) ? (WM * WN * KS) / 4 : (WM * WN * KS == 8 ? (BM * BN == 1024 ? DV_LB8 : 2) : (BK == 32 && BM == 32 ? 7 : 4))) void gemm_kernel(const dv_gemm_desc g, const LoadCfg lc) {
     __shared__ __attribute__((aligned(16))) float smem[gemm_smem_floats<BM, BN, BK, KS, AKC, BKC>()];
     publish_on_entry(g);
 #if DV_STAGGER
@@ -824,12 +824,13 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 16) ? 4 : (BM >
 // lane-linearly) and again when the fragments are read, which makes the ds_read_b128 fragment reads conflict-free.
 // Double buffer, one barrier per K tile: [wait own pieces of tile t] [barrier] [issue tile t+1] [MFMA on tile t].
 // Requires K % 4 == 0 and 16-B aligned rows (else the register-staged kernel runs).
-template <int KS>
-__global__ __launch_bounds__(64 * KS, KS == 8 ? 2 : 4) void gemm_dma_kernel(const dv_gemm_desc g, const LoadCfg lc) {
+template <int KS, int NBUF = 3>
+__global__ __launch_bounds__(64 * KS, NBUF > 4 ? KS / 4 : (KS == 8 ? 2 : 4)) void gemm_dma_kernel(const dv_gemm_desc g, const LoadCfg lc) {
     constexpr int BM = 32, BN = 32, BK = 64, NT = 64 * KS, KW = BK / KS, KH = KW / 2;
     constexpr int TILE = 32 * BK, STAGE = 2 * TILE, RED = KS * BM * (BN + 1);
     constexpr int PIECES = 16 / KS;                     // 1-KiB pieces per wave per K tile (8 of A, then 8 of B)
-    constexpr int NBUF = 3;      // two K tiles in flight behind the one being multiplied
+    // NBUF - 1 K tiles in flight behind the one being multiplied (the loop is bound by the latency of its loads)
+    static_assert((NBUF - 2) * PIECES <= 63, "vmcnt is a 6-bit counter");
     __shared__ __attribute__((aligned(16))) float smem[NBUF * STAGE > RED ? NBUF * STAGE : RED];
     publish_on_entry(g);
     const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
@@ -866,26 +867,21 @@ __global__ __launch_bounds__(64 * KS, KS == 8 ? 2 : 4) void gemm_dma_kernel(cons
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     const int kb = wave * KW + lh * KH;
     const int nkt = (g.K + BK - 1) / BK;
-    issue(0, smem);
-    if (nkt > 1) issue(1, smem + STAGE);
+    // tiles past the end of K are issued too (they read the zero block into a buffer nobody multiplies): the number
+    // of pieces in flight is then the same at every iteration and ONE counted wait serves the whole loop
+#pragma unroll
+    for (int t = 0; t < NBUF - 1; ++t) issue(t, smem + t * STAGE);
     int bi = 0;
     for (int kt = 0; kt < nkt; ++kt) {
         float* cur = smem + bi * STAGE;
-        // this wave's pieces of tile kt have landed (the pieces of tile kt+1 may still be in flight: counted wait);
-        // raw barrier -- __syncthreads() would drain the DMA queue (vmcnt(0)) -- then everyone's pieces have landed
-        // and everyone is done reading tile kt-1, whose buffer the issue below overwrites
-        if (kt + 1 < nkt) {
-            if (PIECES == 2)
-                asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            else
-                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+        // this wave's pieces of tile kt have landed (the pieces of the NBUF - 2 tiles behind it may still be in
+        // flight: counted wait); raw barrier -- __syncthreads() would drain the DMA queue (vmcnt(0)) -- then
+        // everyone's pieces have landed and everyone is done reading tile kt-1, whose buffer the issue below overwrites
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * PIECES) : "memory");
         asm volatile("s_barrier" ::: "memory");
-        int bn = bi + 2;
+        int bn = bi + NBUF - 1;
         bn = bn >= NBUF ? bn - NBUF : bn;
-        if (kt + 2 < nkt) issue(kt + 2, smem + bn * STAGE);
+        issue(kt + NBUF - 1, smem + bn * STAGE);
         bi = bi + 1 == NBUF ? 0 : bi + 1;
         float fa[KH], fb[KH];
 #pragma unroll
@@ -1169,6 +1165,9 @@ static int gemm_launch(const dv_gemm_desc& g, const LoadCfg& lc, int tiling, hip
         return launch_cfg<128, 128, 32, 2, 2, 1, true>(g, lc, st);
     }
     if (tiling == 17) return launch_cfg<32, 32, 32, 1, 1, 4>(g, lc, st);    // lab: half the K tile, seven workgroups per CU
+    if (tiling == 30 && g.a_kcontig && g.b_kcontig) return launch_cfg<96, 64, 64, 1, 2, 4>(g, lc, st);   // lab: one round of big tiles
+    if (tiling == 32 && g.a_kcontig && g.b_kcontig) return launch_cfg<96, 64, 32, 1, 2, 2>(g, lc, st);
+    if (tiling == 34 && g.a_kcontig) return launch_cfg<64, 32, 64, 2, 1, 4>(g, lc, st);
     if (tiling == 4) return launch_cfg<32, 32, 128, 1, 1, 4>(g, lc, st);
     if (tiling == 5) return launch_cfg<64, 64, 64, 2, 2, 2>(g, lc, st);   // 8 waves: 2 per SIMD
     if (tiling == 6) return launch_cfg<64, 32, 64, 2, 1, 2>(g, lc, st);   // 2 row blocks x 2-way K split
@@ -1186,15 +1185,23 @@ static int gemm_launch(const dv_gemm_desc& g, const LoadCfg& lc, int tiling, hip
         }
         return launch_cfg<32, 32, 64, 1, 1, 8>(g, lc, st);
     }
-    if (tiling == 11 || tiling == 12) {   // LDS-DMA staging (forward layout, 16-B aligned rows, K % 4 == 0)
+    if (tiling == 11 || tiling == 12 || (tiling >= 21 && tiling <= 24)) {   // LDS-DMA staging (forward layout, 16-B aligned rows, K % 4 == 0)
         const bool ok = g.a_kcontig && g.b_kcontig && g.A2 == nullptr && g.a_kscale == nullptr && (g.K & 3) == 0 &&
                         lc.vecA == 4 && lc.vecB == 4;
         if (ok) {
             const int tiles = ((g.M + 31) / 32) * ((g.N + 31) / 32);
             if (tiling == 11)
                 hipLaunchKernelGGL((gemm_dma_kernel<8>), dim3(tiles), dim3(512), 0, st, g, lc);
-            else
+            else if (tiling == 12)
                 hipLaunchKernelGGL((gemm_dma_kernel<4>), dim3(tiles), dim3(256), 0, st, g, lc);
+            else if (tiling == 21)
+                hipLaunchKernelGGL((gemm_dma_kernel<8, 5>), dim3(tiles), dim3(512), 0, st, g, lc);
+            else if (tiling == 22)
+                hipLaunchKernelGGL((gemm_dma_kernel<8, 9>), dim3(tiles), dim3(512), 0, st, g, lc);
+            else if (tiling == 23)
+                hipLaunchKernelGGL((gemm_dma_kernel<4, 5>), dim3(tiles), dim3(256), 0, st, g, lc);
+            else
+                hipLaunchKernelGGL((gemm_dma_kernel<4, 9>), dim3(tiles), dim3(256), 0, st, g, lc);
             DV_RETURN_LAUNCH();
         }
         return launch_cfg<32, 32, 64, 1, 1, 8>(g, lc, st);
@@ -1276,6 +1283,9 @@ extern "C" int dv_gemm_pair(const dv_gemm_desc* d1, const dv_gemm_desc* d2, dv_s
     rc = gemm_prepare(d2, lc2, t2);
     if (rc != DV_OK) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    // a paired launch publishes once, on entry, for its first descriptor: at most one of the two may carry a publish
+    // (it is moved to whichever runs first); two would silently drop one and leave its consumer chain spinning
+    DV_REQUIRE(!(d1->pub_flag != nullptr && d2->pub_flag != nullptr));
     // fused form: both products on the 32x32 K-split tiling, (dy^T x) + (dy W) layouts
     const int tiles1 = ((d1->M + 31) / 32) * ((d1->N + 31) / 32), tiles2 = ((d2->M + 31) / 32) * ((d2->N + 31) / 32);
     // pairing pays for the latency-bound small products; a product that already fills the chip
@@ -1305,7 +1315,13 @@ extern "C" int dv_gemm_pair(const dv_gemm_desc* d1, const dv_gemm_desc* d2, dv_s
         if (rc != DV_OK) return rc;
         return gemm_launch(*d2, lc2, t2, st);
     }
+    dv_gemm_desc first = *d1;
+    if (first.pub_flag == nullptr && d2->pub_flag != nullptr) {
+        first.pub_flag = d2->pub_flag;
+        first.pub_ctr = d2->pub_ctr;
+        first.pub_add = d2->pub_add;
+    }
     hipLaunchKernelGGL((gemm_pair_kernel<32, 32, 64, 1, 1, 4, false, false, true, false>), dim3(tiles1 + tiles2),
-                       dim3(256), 0, st, *d1, lc1, *d2, lc2, tiles1);
+                       dim3(256), 0, st, first, lc1, *d2, lc2, tiles1);
     DV_RETURN_LAUNCH();
 }

@@ -82,14 +82,19 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
                 }
                 atomicAdd(gate.err + 1, (int32_t)(wall_clock64() - t0));
             }
+            // one decision per workgroup, taken by the thread that waited (a per-thread re-read of the error words
+            // could split a workgroup between updated and untouched elements)
+            if (threadIdx.x == 0) halted = halted || any_halt(halt, n_halt);
             __syncthreads();
             (void)__hip_atomic_load(gate.flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);   // every wave acquires
         }
     }
     __syncthreads();
     // a chain wait has timed out (now or in an earlier step): the gradients may be built on stale data --
-    // leave parameters and moments as they are (the loss scalars come out NaN, the host raises)
-    if (halted || (gate.flag != nullptr && any_halt(halt, n_halt))) return;
+    // leave parameters and moments as they are (the loss scalars come out NaN, the host raises).  In the one step in
+    // which THIS launch's gate times out only the parked workgroups (the gated slice) see it: the others have swept
+    // their elements already -- that step is applied everywhere but on the gated slice, every later one nowhere
+    if (halted) return;
     const float step_size = sc[0], bc2_sqrt = sc[1];
     // (float)(1 - beta) computed in double first, as python does before the op sees it
     const float w1 = (float)(1.0 - (double)b1), w2 = (float)(1.0 - (double)b2);

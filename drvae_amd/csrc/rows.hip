@@ -1375,7 +1375,7 @@ __global__ __launch_bounds__(kLossThreads) void loss_assemble_kernel(LossTerms l
                                                             float* __restrict__ loss, int32_t* flag,
                                                             const int32_t* ctr, int add, int32_t* err, int max_spins,
                                                             CounterBump bump, const int32_t* __restrict__ halt,
-                                                            int n_halt) {
+                                                            int n_halt, float* __restrict__ accum) {
     __shared__ float part[DV_MAX_LOSS_TERMS][kLossThreads / 64];
     __shared__ float acc[8];
     if (flag != nullptr) {      // park until the other launch chain has published its results
@@ -1464,6 +1464,10 @@ __global__ __launch_bounds__(kLossThreads) void loss_assemble_kernel(LossTerms l
             for (int i = 0; i < n_halt; ++i)
                 bad = bad || __hip_atomic_load(halt + 2 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
             for (int i = 0; i < 8; ++i) loss[i] = bad ? __builtin_nanf("") : acc[i];
+            // running sums of a training epoch (only the launch that assembled the scalars adds them: the parked
+            // variant without terms of the dual-graph step must not add a second time)
+            if (accum != nullptr)
+                for (int i = 0; i < 8; ++i) accum[i] += bad ? __builtin_nanf("") : acc[i];
         }
         // end of the step's use of the device counters on this chain: advance them here (saves the
         // separate counter launch in front of the optimiser)
@@ -2006,7 +2010,8 @@ extern "C" int dv_loss_assemble(const dv_loss_term* terms, int32_t n_terms, cons
         lt.t[i] = terms[i];
     }
     hipLaunchKernelGGL(loss_assemble_kernel, dim3(1), dim3(kLossThreads), 0, ST(stream), lt, w_elbo, w_cmpl, loss,
-                       (int32_t*)nullptr, (const int32_t*)nullptr, 0, (int32_t*)nullptr, 0, CounterBump{}, halt, n_halt);
+                       (int32_t*)nullptr, (const int32_t*)nullptr, 0, (int32_t*)nullptr, 0, CounterBump{}, halt, n_halt,
+                       accum);
     DV_RETURN_LAUNCH();
 }
 
@@ -2027,7 +2032,7 @@ extern "C" int dv_loss_assemble_after(int32_t* flag, const int32_t* ctr, int32_t
         lt.t[i] = terms[i];
     }
     hipLaunchKernelGGL(loss_assemble_kernel, dim3(1), dim3(kLossThreads), 0, ST(stream), lt, w_elbo, w_cmpl, loss, flag, ctr,
-                       add, err, max_spins, bump, halt, n_halt);
+                       add, err, max_spins, bump, halt, n_halt, accum);
     DV_RETURN_LAUNCH();
 }
 

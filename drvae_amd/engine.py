@@ -303,7 +303,17 @@ class FusedStep(StepSchedule):
                                                       None, key, universal=True)
                 if cfg.has_y:
                     self.plan.set_labels_host(np.zeros(n_rows, np.int64))      # class slots: static
+                self._evict_plans(key)
         return self.plan
+
+    def _evict_plans(self, keep):
+        """keep the plan cache bounded (randomly composed minibatches rarely repeat a structure; whole-set
+        evaluations come in a few sizes), never dropping the plan a captured graph points into"""
+        for old in list(self._plans):
+            if len(self._plans) <= self.max_plans:
+                break
+            if old != keep and old != getattr(self, '_graph_key', None):
+                del self._plans[old]
 
     def set_structure(self, has_x2, has_y, counts=None):
         """Select (or build) the plan for a batch STRUCTURE: which rows are pairs / labeled.
@@ -325,13 +335,7 @@ class FusedStep(StepSchedule):
             self.plan = self._plans.get(key)
             if self.plan is None:
                 self.plan = self._plans[key] = _Plan(self, rows, has_x2[rows], has_y[rows], counts, key)
-                # randomly composed minibatches (plain DataLoader) rarely repeat a structure: keep the
-                # cache bounded, never dropping the plan a captured graph points into
-                for old in list(self._plans):
-                    if len(self._plans) <= self.max_plans:
-                        break
-                    if old != key and old != getattr(self, '_graph_key', None):
-                        del self._plans[old]
+                self._evict_plans(key)
         return self.plan, rows
 
     def set_batch(self, x1, x2, y, has_x2, has_y, counts=None, s=None):
@@ -357,8 +361,14 @@ class FusedStep(StepSchedule):
             p.XSRC[:p.B].copy_(x1)
             i32 = lambda a: torch.as_tensor(np.asarray(a.cpu() if torch.is_tensor(a) else a).reshape(-1).astype(np.int32))
             if cfg.has_pert:
-                p.XSRC[p.B:].copy_(x2)
-                p.hx_dev.copy_(i32(has_x2))
+                if x2 is None:      # no second profiles at all (e.g. a whole-set evaluation of singletons)
+                    assert has_x2 is None or not np.asarray(has_x2.cpu() if torch.is_tensor(has_x2) else has_x2).any(), \
+                        'has_x2 marks pairs but x2 is None'
+                    p.XSRC[p.B:].zero_()
+                    p.hx_dev.zero_()
+                else:
+                    p.XSRC[p.B:].copy_(x2)
+                    p.hx_dev.copy_(i32(has_x2))
             if cfg.has_y:
                 p.hy_dev.copy_(i32(has_y))
                 p.y_dev.copy_(i32(y) if y is not None else torch.zeros(p.B, dtype=torch.int32))

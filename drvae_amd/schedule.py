@@ -320,8 +320,10 @@ class StepSchedule:
     def _raise_sync(words):
         sites = [i for i, v in enumerate(words[0::2]) if v != 0]
         raise RuntimeError('drvae_amd: a device-side chain wait timed out (main / side stream ordering; wait site(s) %s). '
-                           'From that step on the loss scalars are NaN and the optimiser has left the parameters '
-                           'untouched: the state is that of the last good step.' % sites)
+                           'From that step on the loss scalars are NaN and the optimiser leaves the parameters '
+                           'untouched: the state is that of the last good step -- except when the timed-out wait was the '
+                           'optimiser gate itself (site 3): that one step is applied to every parameter but the gated '
+                           'slice (the classifier head).  Restore from the last checkpoint.' % sites)
 
     def _poll_sync(self):
         """Called once per replayed step.  Every ``SYNC_POLL`` steps the sticky error words of the device-side

@@ -192,7 +192,8 @@ typedef struct dv_gemm_desc {
 int dv_gemm(const dv_gemm_desc* desc, dv_stream_t stream);
 /* Two independent products in one launch when both take the 32x32 K-split tiling with the
  * (dy^T x) and (dy W) layouts -- the weight- and data-gradient of one Linear layer, which both
- * only need dy; otherwise exactly dv_gemm(d1) followed by dv_gemm(d2). */
+ * only need dy; otherwise exactly dv_gemm(d1) followed by dv_gemm(d2).  At most ONE of the two descriptors may
+ * carry a publish (pub_flag): the launch publishes once, on entry (DV_ERR_ARG when both do). */
 int dv_gemm_pair(const dv_gemm_desc* d1, const dv_gemm_desc* d2, dv_stream_t stream);
 /* Dual-head Linear with the ROW work that consumes both heads fused into the epilogue (SURVEY.md K2+K3 /
  * K2+K5): y = x W^T with W = [W_head0 ; W_head1] (desc->split = rows of head 0, desc->N = 2*split), forward

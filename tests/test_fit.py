@@ -241,6 +241,39 @@ def test_fit_device_batcher_gpu(kind, tmp_path, dev):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('kind', ['drvae', 'pvae', 'vfae'])
+def test_device_epoch_mean_is_the_mean_of_the_step_objectives(kind, dev):
+    """the epoch's 'Avg train loss' of the device-batcher path comes from the running sums the loss-scalar launch keeps
+    on the device (``FusedStep.loss_sum``): it must equal the mean of the per-step objectives read one step at a time"""
+    from drvae_amd import data as D
+    w = D.compute_balanced_weights(np.arange(64) % 5)
+    means = []
+    for per_step in (False, True):
+        model = _tiny_model(kind, device='cuda', epochs=1)
+        tr = _tiny_dataset(kind, 64, 1, 'cuda')
+        batcher = D.DeviceBatcher(tr, w, 16, seed=3)
+        if not per_step:
+            means.append([model._epoch_device(batcher, e, False) for e in range(3)])
+            continue
+        got = []
+        orig = model._epoch_device_body
+
+        def body(eng, bat, epoch, verbose):      # the same replays, scalars read after every step
+            tot = 0.0
+            for b in range(len(bat)):
+                eng.replay()
+                torch.cuda.synchronize()
+                tot += float(model._train_objective(model._loss_tensors(eng)))
+            model.finished_training_iters = eng.iters
+            return tot / len(bat)
+        model._epoch_device_body = body
+        means.append([model._epoch_device(batcher, e, False) for e in range(3)])
+    a, b = np.array(means[0]), np.array(means[1])
+    assert np.all(np.isfinite(a)) and np.all(np.abs(a) > 1e-3)
+    np.testing.assert_allclose(a, b, rtol=1e-5)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('kind', ['drvae', 'vfae'])
 def test_fit_tuple_loader_runs_one_captured_graph(kind, tmp_path, dev):
     """fit() fed by a plain DataLoader whose batches differ in their mix of pairs / labels (what the reference's

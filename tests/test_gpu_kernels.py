@@ -680,6 +680,19 @@ def test_loss_assemble(K, dev):
     assert step.tolist() == [5] and rng.tolist() == [2, 8] and int(err[0]) == 0
     K.loss_assemble(loss, terms, w_elbo, w_cmpl, after=(flag, step, err, 1, 1000), bump=[(step, 1)])
     assert int(err[0]) == 1 and step.tolist() == [6]                    # flag 5 < 5 + 1: bounded wait, reported
+    # running sums (``accum``): every launch that assembles terms adds its scalars; the parked launch WITHOUT terms
+    # (the dual-graph step's join, whose scalars another chain assembles) must not add anything
+    acc, racc = torch.full((8,), 0.5, device=dev), torch.full((8,), 0.5, device=dev)
+    err.zero_()
+    for _ in range(3):
+        K.loss_assemble(loss, terms, w_elbo, w_cmpl, accum=acc)
+        R.loss_assemble(ref, terms, w_elbo, w_cmpl, accum=racc)
+    close(acc, racc, rtol=1e-5, atol=1e-4)
+    close(acc, 0.5 + 3 * ref, rtol=1e-5, atol=1e-4)
+    flag.fill_(100)
+    K.loss_assemble(loss, [], w_elbo, w_cmpl, after=(flag, step, err, 1, 1000), bump=[(step, 1)], accum=acc)
+    K.loss_assemble(loss, terms, w_elbo, w_cmpl, after=(flag, step, err, 1, 1000), accum=acc)
+    close(acc, 0.5 + 4 * ref, rtol=1e-5, atol=1e-4)
 
 
 @pytest.mark.parametrize('Y,two', [(2, True), (3, False), (8, True), (1, False)])

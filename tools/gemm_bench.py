@@ -16,7 +16,7 @@ SHAPES = [  # (M, N, K, a_kc, b_kc, tag)
     (1956, 600, 596, 0, 0, 'decx heads dW'), (224, 800, 978, 1, 1, 'enc L1 fwd'), (800, 978, 224, 0, 0, 'enc L1 dW'),
     (224, 200, 800, 1, 1, 'enc heads fwd'), (596, 600, 100, 1, 1, 'decx L1 fwd'), (600, 100, 596, 0, 0, 'decx L1 dW'),
     (450, 200, 102, 1, 1, 'fp L1 fwd'), (200, 102, 450, 0, 0, 'fp L1 dW'), (450, 102, 200, 1, 0, 'fp L1 dX'),
-    (300, 2, 200, 1, 1, 'clf fwd'),
+    (300, 2, 200, 1, 1, 'clf fwd'), (596, 600, 1956, 1, 1, 'long-K fwd layout'),
 ]
 
 
@@ -42,6 +42,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--tilings', default='0,1,2,3')
     ap.add_argument('--opts', default='', help='comma list key=value for dv_gemm_set_option')
+    ap.add_argument('--check', action='store_true', help='compare every result with torch (max abs error printed)')
     args = ap.parse_args()
     lib = _lib.load()
     dev = torch.device('cuda:0')
@@ -59,6 +60,9 @@ def main():
             lib.dv_gemm_force_tiling(t)
             us = time_call(lambda: K.gemm(Cm, A, B, akc, bkc, overread=True))
             row += '  %7.2f / %6.2f   ' % (us, 2.0 * M * N * Kd / us / 1e6)
+            if args.check:
+                ref = (A if akc else A.t()).double() @ (B.t() if bkc else B).double()
+                row += '[%.1e] ' % float((Cm.double() - ref).abs().max() / ref.abs().max())
         lib.dv_gemm_force_tiling(0)
         print(row, flush=True)
 
