@@ -47,6 +47,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef DV_LB8
 #define DV_LB8 2
 #endif
+// workgroups per CU the high-occupancy 32x32x32 tiling is compiled for (register budget 512 / this many waves per SIMD)
+#ifndef DV_DENSE_WG
+#define DV_DENSE_WG 7
+#endif
 #if DV_STAMP
 __device__ unsigned long long* dv_stamp_buf = nullptr;
 #define STAMP(i)                                                                          \
@@ -802,7 +806,7 @@ __device__ __forceinline__ void publish_on_entry(const dv_gemm_desc& g) {
 }
 
 template <int BM, int BN, int BK, int WM, int WN, int KS, bool AKC, bool BKC, bool MI16 = false>
-__global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 16) ? 4 : (BM >= 128 || BK >= 128) ? 2 : (BM * BN >= 6144) ? (WM * WN * KS) / 4 : (WM * WN * KS == 8 ? (BM * BN == 1024 ? DV_LB8 : 2) : (BK == 32 && BM == 32 ? 7 : 4))) void gemm_kernel(const dv_gemm_desc g, const LoadCfg lc) {
+__global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 16) ? 4 : (BM >= 128 || BK >= 128) ? 2 : (BM * BN >= 6144) ? (WM * WN * KS) / 4 : (WM * WN * KS == 8 ? (BM * BN == 1024 ? DV_LB8 : 2) : (BK == 32 && BM == 32 ? DV_DENSE_WG : 4))) void gemm_kernel(const dv_gemm_desc g, const LoadCfg lc) {
     __shared__ __attribute__((aligned(16))) float smem[gemm_smem_floats<BM, BN, BK, KS, AKC, BKC>()];
     publish_on_entry(g);
 #if DV_STAGGER
@@ -1028,7 +1032,7 @@ __global__ __launch_bounds__(256, 4) void gemm_wp_kernel(const dv_gemm_desc g, c
 }
 
 template <int BM, int BN, int BK, int KS>
-__global__ __launch_bounds__(64 * KS, KS == 8 ? 2 : (BK == 32 ? 7 : 4)) void gemm_heads_kernel(const dv_gemm_desc g, const LoadCfg lc,
+__global__ __launch_bounds__(64 * KS, KS == 8 ? 2 : (BK == 32 ? DV_DENSE_WG : 4)) void gemm_heads_kernel(const dv_gemm_desc g, const LoadCfg lc,
                                                                const dv_heads_epi he) {
     __shared__ __attribute__((aligned(16))) float smem[gemm_smem_floats<BM, BN, BK, KS, true, true>()];
     publish_on_entry(g);
@@ -1039,7 +1043,7 @@ __global__ __launch_bounds__(64 * KS, KS == 8 ? 2 : (BK == 32 ? 7 : 4)) void gem
 // second): the weight-gradient dW = dy^T x and the data-gradient dx = dy W of a layer both only
 // need dy, so they share a launch slot instead of paying the per-launch latency chain twice.
 template <int BM, int BN, int BK, int WM, int WN, int KS, bool A1, bool B1, bool A2, bool B2>
-__global__ __launch_bounds__(256, BK == 32 ? 7 : 4) void gemm_pair_kernel(const dv_gemm_desc g1, const LoadCfg lc1, const dv_gemm_desc g2,
+__global__ __launch_bounds__(256, BK == 32 ? DV_DENSE_WG : 4) void gemm_pair_kernel(const dv_gemm_desc g1, const LoadCfg lc1, const dv_gemm_desc g2,
                                                         const LoadCfg lc2, int tiles1) {
     constexpr int S1 = gemm_smem_floats<BM, BN, BK, KS, A1, B1>(), S2 = gemm_smem_floats<BM, BN, BK, KS, A2, B2>();
     __shared__ __attribute__((aligned(16))) float smem[S1 > S2 ? S1 : S2];

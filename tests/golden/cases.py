@@ -224,7 +224,14 @@ MODEL_CASES = OrderedDict([
     ('cfg1_pvae', (lambda: M.ModelSpec(kind='pvae', L=1), 150, 3, False)),
     ('cfg2_drvae', (lambda: M.ModelSpec(kind='drvae', L=2), 150, 3, False)),
     ('cfg4_vfae', (lambda: M.ModelSpec(kind='vfae', L=2, add_noise_var=0.), 150, 3, False)),
+    # BASELINE.json configs[4] at its per-GPU size (the MFMA-bound stress configuration; ~25 s per step on the CPU)
+    ('cfg5_wide', (lambda: M.ModelSpec(kind='drvae', L=4, dim_x=20000, dim_z1=200, dim_z3=200, h_en_z1=[2048],
+                                       h_de_x=[2048]), 1024, 2, False)),
 ])
+
+
+# the cases small enough for the CPU stand-in kernels of tests/test_engine_cpu.py (python loops over rows)
+SMALL_MODEL_CASES = [n for n in MODEL_CASES if n != 'cfg5_wide']
 
 
 def model_case(name):

@@ -608,6 +608,13 @@ def main():
     global HERE
     HERE = OUT
     os.makedirs(HERE, exist_ok=True)
+    only = [a.split('=', 1)[1] for a in sys.argv if a.startswith('--only-model=')]
+    if only:                      # one model case by name (the wide configuration takes a minute)
+        for name in only:
+            out = run_model_case(C.model_case(name))
+            np.savez_compressed(os.path.join(HERE, 'model_%s.npz' % name), **out)
+            print('model_%s.npz' % name, len(out), 'arrays;', {k: float(v) for k, v in out.items() if k.startswith('step0/')})
+        return
     ml = run_masked_linear_cases()
     np.savez_compressed(os.path.join(HERE, 'masked_linear.npz'), **ml)
     print('masked_linear.npz', len(ml), 'arrays')

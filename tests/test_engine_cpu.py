@@ -32,7 +32,7 @@ def close(a, b, rtol, atol):
     np.testing.assert_allclose(a, b, rtol=rtol, atol=atol)
 
 
-@pytest.mark.parametrize('name', list(C.MODEL_CASES))
+@pytest.mark.parametrize('name', C.SMALL_MODEL_CASES)
 def test_engine_matches_reference_golden(name, monkeypatch):
     kernel_ref.install(monkeypatch)
     case, gold = C.model_case(name), C.load('model_' + name)
@@ -64,7 +64,7 @@ def test_engine_matches_reference_golden(name, monkeypatch):
     assert eng.iters == nsteps
 
 
-@pytest.mark.parametrize('name', list(C.MODEL_CASES))
+@pytest.mark.parametrize('name', C.SMALL_MODEL_CASES)
 def test_engine_gradients_match_reference_golden(name, monkeypatch):
     kernel_ref.install(monkeypatch)
     case, gold = C.model_case(name), C.load('model_' + name)
@@ -85,7 +85,7 @@ def test_engine_gradients_match_reference_golden(name, monkeypatch):
             close(g.reshape(-1)[C.sample_index(g.size)], gold['gradsample/' + k], 2e-3, 2e-6)
 
 
-UNIVERSAL_CASES = [n for n in C.MODEL_CASES if 'cont' not in n and n not in ('tiny_vfae_sup',)]
+UNIVERSAL_CASES = [n for n in C.SMALL_MODEL_CASES if 'cont' not in n and n not in ('tiny_vfae_sup',)]
 
 
 @pytest.mark.parametrize('name', UNIVERSAL_CASES)

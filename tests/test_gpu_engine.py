@@ -12,6 +12,9 @@ from tests.test_engine_cpu import make_engine, set_batch
 pytestmark = pytest.mark.gpu
 
 LOSS_RTOL = 1e-4          # BASELINE.json north_star: 1e-4 relative, fp32
+# element-wise gradients: fp32 sums in another order than the reference's (K up to 20000 products per element); the
+# absolute term covers elements that are differences of large terms
+GRAD_RTOL = 5e-4
 
 
 def close(a, b, rtol, atol):
@@ -39,11 +42,11 @@ def test_train_steps_match_reference_golden(name, dev):
         g = arena.g(k).cpu().numpy()
         if case['full']:
             ref = gold['grad/' + k]
-            close(g, ref, 2e-3, 2e-5 * max(1.0, float(np.abs(ref).max())))
+            close(g, ref, GRAD_RTOL, 2e-5 * max(1.0, float(np.abs(ref).max())))
         else:
             close(np.sqrt((g.astype(np.float64) ** 2).sum()), gold['gradnorm/' + k], 2e-4, 1e-7)
             ref = gold['gradsample/' + k]
-            close(g.reshape(-1)[C.sample_index(g.size)], ref, 5e-3, 1e-4 * max(1e-3, float(np.abs(ref).max())))
+            close(g.reshape(-1)[C.sample_index(g.size)], ref, GRAD_RTOL, 1e-4 * max(1e-3, float(np.abs(ref).max())))
     nsteps = len(case['noises'])
     for step, noise in enumerate(case['noises']):
         eng.train_step(noise)
