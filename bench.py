@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the Dr.VAE ELBO train step on MI355X (contract: see the task brief).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg1|cfg4|wide]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg1|cfg4|wide(=cfg5)]
 
 One "step" = one full train step (Philox noise + stacked forward + hand-written backward
 + gradient all-reduce + fused Adam) over one synthetic minibatch per GPU, inputs resident
@@ -33,6 +33,7 @@ WORKLOADS = {
                                 'h_de_x': [2048]},
              'DrVAE wide synthetic: 20000 genes, z1=z3=200, enc 2048, dec 2048 (assumed), batch 1024/GPU, L=4'),
 }
+WORKLOADS['cfg5'] = WORKLOADS['wide']         # BASELINE.json's name for it
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak (dense, exact fp32)
 
 
@@ -69,8 +70,8 @@ def build(workload, device, rank, world, seed=123):
         arena.p(k).copy_(torch.as_tensor(a, dtype=torch.float32))
     # one seed for all ranks: the Philox draws are keyed by (seed, step, draw, GLOBAL row), so the job's noise does
     # not depend on the number of ranks; this rank owns rows [rank*rows, (rank+1)*rows)
-    eng = E.FusedStep(cfg, arena, seed=1000, concurrent=os.environ.get('DRVAE_CONCURRENT', '1') != '0',
-                      row0=rank * rows)
+    from drvae_amd import tuning
+    eng = E.FusedStep(cfg, arena, seed=1000, concurrent=bool(tuning.get('concurrent')), row0=rank * rows)
     batch = synth.make_batch(kind, rows, cfg.dim_x, cfg.dim_y, seed=1234, row0=rank * rows)
     hx, hy = batch['has_x2'].astype(bool), batch['has_y'].astype(bool)
     # weak scaling: every rank has the same group mix, so the global counts are world * local
@@ -189,7 +190,8 @@ def parity_vs_cpu(workload, device, steps=2):
             'what': 'HIP train steps vs CPU oracle, identical parameters / batch / injected noise'}
 
 
-def gemm_roofline(eng, cfg, rows, frac_pair, frac_lab, repeats=20, workload='cfg2', n_params=0, input_bytes=0):
+def gemm_roofline(eng, cfg, rows, frac_pair, frac_lab, repeats=20, workload='cfg2', n_params=0, input_bytes=0,
+                  ms_per_step=None, brief=False):
     """Roofline of the dominant kernel family: the fp32-MFMA GEMM (all tilings/layouts; 32
     launches per cfg-2 step).  Every GEMM launch of one train step is re-issued `repeats`
     times back to back from a small hipGraph and timed with HIP events recorded on the
@@ -263,21 +265,30 @@ def gemm_roofline(eng, cfg, rows, frac_pair, frac_lab, repeats=20, workload='cfg
     prof, prof_file = profiled_roofline(workload)
     # inputs + parameters read forward and backward + gradient write + Adam's 7 words per parameter
     alg_bytes = input_bytes + 4.0 * n_params * (2 + 1 + 7)
-    out = {'bound': 'mfma', 'achieved': round(achieved, 3), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-           'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
-           'how': 'live: every GEMM-family launch of one step re-issued %dx back to back from a hipGraph on an idle chip, '
-                  'HIP events on the launch stream; achieved = algorithmic GEMM FLOPs per step / sum of the per-launch '
-                  'times (= avg FLOPs per launch / avg launch duration)' % repeats,
-           'kernel': 'gemm_kernel / gemm_pair_kernel / gemm_heads_kernel<...> (fp32 v_mfma_f32_32x32x2_f32; all tilings/layouts)',
+    iso = {'achieved': round(achieved, 3), 'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
            'launches_per_step': len(per_call), 'avg_launch_us': round(1e6 * t_step / len(per_call), 2),
            'gemm_us_per_step': round(1e6 * t_step, 1),
+           'how': 'live: every GEMM-family launch of one step re-issued %dx back to back from a hipGraph on an idle, '
+                  'un-partitioned chip, HIP events on the launch stream; achieved = algorithmic GEMM FLOPs per step / sum '
+                  'of the per-launch times (= avg FLOPs per launch / avg launch duration)' % repeats}
+    out = {'bound': 'mfma', 'achieved': iso['achieved'], 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+           'frac': iso['frac'], 'source': 'isolated (no committed profile of this workload)',
+           'kernel': 'gemm_kernel / gemm_pair_kernel / gemm_heads_kernel<...> (fp32 v_mfma_f32_32x32x2_f32; all tilings/layouts)',
            'algorithmic_gflop_per_step': round(algorithmic / 1e9, 3),
            'executed_gflop_per_step': round(executed / 1e9, 3),
-           'algorithmic_mbytes_per_step': round(alg_bytes / 1e6, 2),
-           'algorithmic_gemm_mbytes_per_step': round(gemm_bytes / 1e6, 2),
-           'top_launches': [{'shape': list(sh), 'us': round(1e6 * t, 2), 'tflops': round(f / t / 1e12, 2)}
-                            for t, f, sh in top],
-           'traffic': None}
+           'isolated': iso, 'traffic': None}
+    if ms_per_step:      # the same FLOPs over the whole step's wall time (everything that is not a GEMM included)
+        a3 = algorithmic / (ms_per_step * 1e-3) / 1e12
+        out['step_level'] = {'achieved': round(a3, 3), 'frac': round(a3 / FP32_MFMA_PEAK_TFLOPS, 4),
+                             'ms_per_step': ms_per_step}
+    if brief:
+        out['top_launches'] = [{'shape': list(sh), 'us': round(1e6 * t, 2), 'tflops': round(f / t / 1e12, 2)}
+                               for t, f, sh in top]
+        return out
+    out.update({'algorithmic_mbytes_per_step': round(alg_bytes / 1e6, 2),
+                'algorithmic_gemm_mbytes_per_step': round(gemm_bytes / 1e6, 2),
+                'top_launches': [{'shape': list(sh), 'us': round(1e6 * t, 2), 'tflops': round(f / t / 1e12, 2)}
+                                 for t, f, sh in top]})
     if prof is not None:
         tr, ig = prof.get('traffic'), prof.get('gemm_in_graph')
         out['profile'] = prof_file
@@ -292,14 +303,167 @@ def gemm_roofline(eng, cfg, rows, frac_pair, frac_lab, repeats=20, workload='cfg
                                    'step_reported': round(tr['total_reported'] * 1e6 / alg_bytes, 2),
                                    'gemm_upper': round((tr['gemm']['fetch_corrected_upper'] + tr['gemm']['write']) * 1e6
                                                        / max(gemm_bytes, 1.0), 2)}
-        if ig and 'kernel_us_per_step' in ig:   # the same FLOPs over the GEMM kernel time of the RUNNING step
+        if ig and 'kernel_us_per_step' in ig:
+            # THE figure of the line: the same FLOPs over the GEMM-family kernel time of the RUNNING step (both chains
+            # running, main chain on its CU partition), i.e. avg FLOPs per launch / avg in-situ launch duration, from
+            # the committed rocprofv3 --kernel-trace --stats summary of this command
             a2 = algorithmic / (ig['kernel_us_per_step'] * 1e-6) / 1e12
+            out['achieved'], out['frac'] = round(a2, 3), round(a2 / FP32_MFMA_PEAK_TFLOPS, 4)
+            out['source'] = 'in situ: GEMM-family kernel time per step of the running step, ' + prof_file
             out['in_graph'] = {'gemm_us_per_step': ig['kernel_us_per_step'], 'launches_per_step': ig['launches_per_step'],
                                'avg_launch_us': ig['avg_launch_us'], 'achieved': round(a2, 3),
-                               'frac': round(a2 / FP32_MFMA_PEAK_TFLOPS, 4),
-                               'how': 'rocprofv3 --kernel-trace --stats of this command (both chains running, main '
-                                      'chain on its CU partition): ' + prof_file}
+                               'frac': round(a2 / FP32_MFMA_PEAK_TFLOPS, 4)}
     return out
+
+
+def measure(args, workload, feed, steps, warmup, device, rank, world, steady_s=0.0, exchange_probe=False):
+    """Build the workload, capture its train step and time exactly ``steps`` replays (barrier + synchronize on both
+    sides, MAX over ranks); with ``steady_s`` a second, longer region of about that many seconds is timed as well.
+    Returns (result dict, context for the roofline leg)."""
+    from drvae_amd import dist as D
+    import torch.distributed as dist
+    cfg, eng, arena, batch, desc = build(workload, device, rank, world)
+    kind, rows, L = WORKLOADS[workload][:3]
+    D.broadcast_params(arena)
+    dp = world > 1 or D.force_dp()          # (DRVAE_FORCE_DP=1: the multi-rank step path with a one-rank communicator)
+    allreduce = D.allreduce_sum if dp else None
+
+    # iteration 0 runs eagerly (beta_pert = 0.01 only there), then the steady-state step is captured
+    eng.train_step(allreduce=allreduce)
+    use_graph = not args.no_graph
+    dp_mode = None
+    bat = None
+    n_table = [steps + warmup + 8]
+    if feed != 'resident':
+        from drvae_amd import data as DD, synth
+        big = synth.make_batch(kind, args.dataset_rows, cfg.dim_x, cfg.dim_y, seed=77 + rank)
+        tt = lambda k: torch.from_numpy(big[k]).to(device)
+        ds = DD.DrVAEDataset(tt('x1'), tt('x2'), torch.zeros(args.dataset_rows, dtype=torch.int64, device=device),
+                             tt('y'), tt('has_x2'), tt('has_y'))
+        hx, hy = batch['has_x2'].astype(bool), batch['has_y'].astype(bool)
+        gc = [int(((hy == bool(gy)) & (hx == bool(gx))).sum()) for (gy, gx) in DD._GROUPS]
+        if feed == 'sampler':
+            bat = DD.DeviceBatcher(ds, torch.ones(args.dataset_rows), rows, seed=5 + rank, mode='sampler')
+            bat.bind(eng)
+        else:
+            bat = DD.DeviceBatcher(ds, torch.ones(args.dataset_rows), rows, group_counts=gc, seed=5 + rank)
+            bat.bind(eng, counts=(world * rows, world * int(hx.sum()), world * int(hy.sum())))
+        if feed in ('epoch', 'sampler'):
+            bat.begin_epoch(n_batches=n_table[0])
+        else:
+            bat.feed()
+
+    def rebase(n):
+        """graph-resident feeds: a fresh index table that covers the next ``n`` replays (the feed clamps past its
+        end: a region longer than the table would re-train on the last batch instead of a fresh draw per step)"""
+        if bat is not None and feed in ('epoch', 'sampler'):
+            bat.begin_epoch(n_batches=n + 8)
+    if use_graph:
+        # one exchange between two graphs by default; --dp-exchange overlap: two overlapped pieces between three
+        # graphs (measured with a one-rank RCCL communicator: +49 us of launch/event overhead per step against +24 us)
+        overlap = dp and args.dp_exchange == 'overlap'
+        dp_mode = 'overlap' if overlap else dp
+        if dp and not overlap and args.dp_exchange == 'captured':
+            # the exchange captured into the step's graph (needs stream-capturable RCCL: probed here, with the
+            # split graphs as the fallback)
+            try:
+                eng.capture(split_for_allreduce='captured', allreduce=D.allreduce_sum)
+                allreduce, dp_mode = None, 'captured'
+            except Exception as e:       # noqa: BLE001
+                print('bench.py: RCCL capture unavailable (%s); split graphs' % e, file=sys.stderr)
+                dp_mode = dp
+        if dp_mode != 'captured':
+            eng.capture(split_for_allreduce=dp_mode)
+        if overlap and len(eng._graphs) == 3:
+            allreduce = D.OverlappedAllReduce()      # decoder block travels while the encoder backward runs
+        if feed == 'batcher':
+            def step():
+                bat.feed()
+                eng.replay(allreduce)
+        else:
+            step = lambda: eng.replay(allreduce)
+    else:
+        step = lambda: eng.train_step(allreduce=allreduce)
+    import contextlib
+    part = contextlib.nullcontext()
+    if use_graph:
+        eng.tune_partition()             # reserved CUs for the side chain, chosen by timing (state restored)
+        part = eng.partition()           # side chain on reserved CUs (dual-graph schedule); no-op otherwise
+        rebase(steps + warmup)           # (the tuning replays advanced the step counter past the table's start)
+    part.__enter__()
+    if world > 1:
+        dist.barrier()          # ranks leave capture together: the first exchanges do not sit out capture skew
+    for _ in range(max(warmup - 1, 0)):
+        step()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def over_ranks(dt):
+        if world > 1:
+            tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            return float(tmax.item())
+        return dt
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    t_enq = time.perf_counter() - t0       # host time to enqueue the steps (if ~dt the host is the bound)
+    barrier()
+    dt = over_ranks(time.perf_counter() - t0)
+    # a second, longer region (same step, same barriers) next to the contract's K steps: >= ``steady_s`` seconds of
+    # back-to-back replays, so that the driver's utilisation sampler sees the device busy and the number does not
+    # hang on a few milliseconds
+    steady = None
+    if steady_s > 0 and dt < steady_s:
+        n2 = int(min(max(200, steady_s * steps / max(dt, 1e-6)), 60000))
+        rebase(n2)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(n2):
+            step()
+        barrier()
+        dt2 = over_ranks(time.perf_counter() - t1)
+        steady = {'steps': n2, 'seconds': round(dt2, 3), 'ms_per_step': round(1e3 * dt2 / n2, 4),
+                  'value': round(world * rows * L * n2 / dt2, 1)}
+    losses = eng.losses()                  # (of the last measured step: read before the probe below trains on)
+    exchange = None
+    if dp and exchange_probe and use_graph and len(getattr(eng, '_graphs', [])) == 2:
+        # what the gradient exchange costs a step: the same replays without the collective between the two graphs
+        # (every rank's own gradients only -- a timing probe on scratch state, after the measured regions)
+        barrier()
+        t2 = time.perf_counter()
+        for _ in range(steps):
+            eng.replay(None)
+        barrier()
+        dt3 = over_ranks(time.perf_counter() - t2)
+        exchange = {'us_per_step': round(1e6 * (dt - dt3) / steps, 2), 'ms_per_step_without': round(1e3 * dt3 / steps, 4),
+                    'bytes': int(arena.xchg.numel() * 4), 'mode': str(dp_mode)}
+    part.__exit__(None, None, None)
+    waits = eng.sync_err.cpu().tolist() if hasattr(eng, 'sync_err') else None
+    ok = all(np.isfinite(v) for v in losses.values())
+    out = {
+        'value': round(world * rows * L * steps / dt, 1), 'steps': steps, 'warmup': warmup,
+        'ms_per_step': round(1e3 * dt / steps, 4),
+        'config': {'workload': '%s: %s' % (workload, desc), 'global_batch': world * rows, 'L': L,
+                   'parallelism': 'dp%d' % world, 'launch': 'hipGraph replay' if use_graph else 'eager', 'feed': feed,
+                   'side_chain_cus': getattr(eng, '_side_cus', None),
+                   'dist_backend': (dist.get_backend() if dist.is_initialized() else None),
+                   'dp_exchange': (dp_mode if dp else None),
+                   'rccl_ranks': (dist.get_world_size() if dist.is_initialized() and dist.get_backend() == 'nccl'
+                                  else 0),
+                   'params': int(sum(int(np.prod(s)) for s in arena.shapes.values()))},
+        'losses_last_step': {k: round(v, 4) for k, v in losses.items()}, 'finite': ok,
+        'chain_wait_ticks': waits, 'host_enqueue_ms_per_step': round(1e3 * t_enq / steps, 4),
+        'steady_state': steady,
+    }
+    if exchange is not None:
+        out['exchange'] = exchange
+    return out, dict(eng=eng, cfg=cfg, batch=batch, rows=rows, dp=dp)
 
 
 def _free_port():
@@ -309,7 +473,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def self_launch(n, argv):
+def self_launch(n, argv, timeout=1500.0):
     """``python bench.py --gpus N`` without a launcher: start N fresh rank processes (one per GPU, RANK /
     LOCAL_RANK / WORLD_SIZE / MASTER_* set as torch.distributed.run would) and relay rank 0's JSON line and
     the worst exit code.  This parent never touches the GPU (``import torch`` alone does not initialise
@@ -326,7 +490,7 @@ def self_launch(n, argv):
     chunks = []
     rd = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
     rd.start()                                      # (children's stderr goes straight to ours)
-    limit = time.time() + float(os.environ.get('DRVAE_BENCH_TIMEOUT', '1500'))
+    limit = time.time() + timeout
     while any(p.poll() is None for p in procs):
         failed = any(p.poll() not in (None, 0) for p in procs)
         if failed or time.time() > limit:           # a rank died (its peers would sit in a collective for ever)
@@ -366,23 +530,26 @@ def main():
                          "same, but the captured step gathers its batch itself from the epoch's index table; sampler: "
                          'as epoch, with the exact WeightedRandomSampler semantics (any group mix per batch: universal plan)')
     ap.add_argument('--dataset-rows', type=int, default=16384)
+    ap.add_argument('--gemm-opts', default='', help='tuning: comma list key=value for dv_gemm_set_option')
+    ap.add_argument('--dp-exchange', default='single', choices=['single', 'overlap', 'captured'],
+                    help='data-parallel gradient exchange: one all-reduce between two graphs (default), two overlapped '
+                         'pieces between three graphs, or the collective captured into the step graph')
+    ap.add_argument('--no-steady', action='store_true', help='skip the second, longer timed region')
+    ap.add_argument('--no-extras', action='store_true',
+                    help='skip the realistic-feed and other-workload measurements that follow the headline (cfg2 only)')
+    ap.add_argument('--timeout', type=float, default=1500.0, help='self-launched ranks: seconds before they are ended')
     args = ap.parse_args()
+    if args.workload == 'cfg5':
+        args.workload = 'wide'
 
     if args.gpus > 1 and int(os.environ.get('WORLD_SIZE', '1')) <= 1:
-        return self_launch(args.gpus, sys.argv[1:])   # before anything initialises the GPU in this process
+        return self_launch(args.gpus, sys.argv[1:], args.timeout)   # before anything initialises the GPU in this process
 
     from drvae_amd import _lib, dist as D
     _lib.load()                                       # fail loudly if the HIP library is missing
-    if os.environ.get('DRVAE_GEMM_MAP'):              # tuning: workgroup->tile map (0 linear, 1 XCD chunk-major)
-        _lib.load().dv_gemm_set_option(0, int(os.environ['DRVAE_GEMM_MAP']))
-    if os.environ.get('DRVAE_LDS_PAD'):               # tuning: extra dynamic LDS of the chip-filling 32x32-tile GEMM launches
-        _lib.load().dv_gemm_set_option(1, int(os.environ['DRVAE_LDS_PAD']))
-    if os.environ.get('DRVAE_DENSE_PAIR'):            # tuning: dW and dX of a chip-filling layer in one launch
-        _lib.load().dv_gemm_set_option(9, 0 if os.environ['DRVAE_DENSE_PAIR'] != '0' else 1)
-    if os.environ.get('DRVAE_DENSE_MIN'):             # tuning: 32x32-tile count from which the 7-per-CU tiling runs
-        _lib.load().dv_gemm_set_option(8, int(os.environ['DRVAE_DENSE_MIN']))
-    if os.environ.get('DRVAE_T64_MIN'):               # tuning: 64x64-tile threshold of the GEMM heuristic
-        _lib.load().dv_gemm_set_option(3, int(os.environ['DRVAE_T64_MIN']))
+    for kv in filter(None, args.gemm_opts.split(',')):     # tuning: dv_gemm_set_option keys (include/drvae_hip.h)
+        k, v = kv.split('=')
+        _lib.load().dv_gemm_set_option(int(k), int(v))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (no CPU fallback for the hot path)')
     rank, world, local = D.init_from_env()
@@ -393,136 +560,61 @@ def main():
     device = torch.device('cuda', local)
     import torch.distributed as dist
 
-    cfg, eng, arena, batch, desc = build(args.workload, device, rank, world)
-    kind, rows, L = WORKLOADS[args.workload][:3]
-    D.broadcast_params(arena)
-    dp = world > 1 or D.force_dp()          # (DRVAE_FORCE_DP=1: the multi-rank step path with a one-rank communicator)
-    allreduce = D.allreduce_sum if dp else None
-
-    # iteration 0 runs eagerly (beta_pert = 0.01 only there), then the steady-state step is captured
-    eng.train_step(allreduce=allreduce)
-    use_graph = not args.no_graph
-    dp_mode = None
-    bat = None
-    if args.feed != 'resident':
-        from drvae_amd import data as DD, synth
-        big = synth.make_batch(kind, args.dataset_rows, cfg.dim_x, cfg.dim_y, seed=77 + rank)
-        tt = lambda k: torch.from_numpy(big[k]).to(device)
-        ds = DD.DrVAEDataset(tt('x1'), tt('x2'), torch.zeros(args.dataset_rows, dtype=torch.int64, device=device),
-                             tt('y'), tt('has_x2'), tt('has_y'))
-        hx, hy = batch['has_x2'].astype(bool), batch['has_y'].astype(bool)
-        gc = [int(((hy == bool(gy)) & (hx == bool(gx))).sum()) for (gy, gx) in DD._GROUPS]
-        if args.feed == 'sampler':
-            bat = DD.DeviceBatcher(ds, torch.ones(args.dataset_rows), rows, seed=5 + rank, mode='sampler')
-            bat.bind(eng)
-        else:
-            bat = DD.DeviceBatcher(ds, torch.ones(args.dataset_rows), rows, group_counts=gc, seed=5 + rank)
-            bat.bind(eng, counts=(world * rows, world * int(hx.sum()), world * int(hy.sum())))
-        if args.feed in ('epoch', 'sampler'):
-            bat.begin_epoch(n_batches=args.steps + args.warmup + 8)
-        else:
-            bat.feed()
-    if use_graph:
-        # one exchange between two graphs by default; DRVAE_DP_OVERLAP=1: two overlapped pieces between three
-        # graphs (measured with a one-rank RCCL communicator: +49 us of launch/event overhead per step against +24 us)
-        overlap = dp and os.environ.get('DRVAE_DP_OVERLAP', '0') == '1'
-        dp_mode = 'overlap' if overlap else dp
-        if dp and not overlap and os.environ.get('DRVAE_DP_CAPTURE', '0') == '1':
-            # the exchange captured into the step's graph (needs stream-capturable RCCL: probed here, with the
-            # split graphs as the fallback)
-            try:
-                eng.capture(split_for_allreduce='captured', allreduce=D.allreduce_sum)
-                allreduce, dp_mode = None, 'captured'
-            except Exception as e:       # noqa: BLE001
-                print('bench.py: RCCL capture unavailable (%s); split graphs' % e, file=sys.stderr)
-                dp_mode = dp
-        if dp_mode != 'captured':
-            eng.capture(split_for_allreduce=dp_mode)
-        if overlap and len(eng._graphs) == 3:
-            allreduce = D.OverlappedAllReduce()      # decoder block travels while the encoder backward runs
-        if args.feed == 'batcher':
-            def step():
-                bat.feed()
-                eng.replay(allreduce)
-        else:
-            step = lambda: eng.replay(allreduce)
-    else:
-        step = lambda: eng.train_step(allreduce=allreduce)
-    import contextlib
-    part = contextlib.nullcontext()
-    if use_graph:
-        tuned = eng.tune_partition()     # reserved CUs for the side chain, chosen by timing (state restored)
-        part = eng.partition()           # side chain on reserved CUs (dual-graph schedule); no-op otherwise
-    part.__enter__()
-    if world > 1:
-        dist.barrier()          # ranks leave capture together: the first exchanges do not sit out capture skew
-    for _ in range(max(args.warmup - 1, 0)):
-        step()
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    t_enq = time.perf_counter() - t0       # host time to enqueue the steps (if ~dt the host is the bound)
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-    # SURVEY 8(d) asks for >= 200 timed steps: when the K requested ones took under half a second, a second,
-    # longer region (same step, same barriers) is timed as well and reported next to the contract's number
-    steady = None
-    if dt < 0.5 and os.environ.get('DRVAE_BENCH_STEADY', '1') != '0':
-        n2 = int(min(max(200, 0.5 * args.steps / max(dt, 1e-6)), 20000))
-        barrier()
-        t1 = time.perf_counter()
-        for _ in range(n2):
-            step()
-        barrier()
-        dt2 = time.perf_counter() - t1
-        if world > 1:
-            tm2 = torch.tensor([dt2], dtype=torch.float64, device=device)
-            dist.all_reduce(tm2, op=dist.ReduceOp.MAX)
-            dt2 = float(tm2.item())
-        steady = {'steps': n2, 'ms_per_step': round(1e3 * dt2 / n2, 4), 'value': round(world * rows * L * n2 / dt2, 1)}
-    losses = eng.losses()
-    part.__exit__(None, None, None)
-    waits = eng.sync_err.cpu().tolist() if hasattr(eng, 'sync_err') else None
-    ok = all(np.isfinite(v) for v in losses.values())
-
-    out = {
-        'metric': 'DrVAE ELBO training samples/sec (batch x L)', 'value': round(world * rows * L * args.steps / dt, 1),
-        'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-        'ms_per_step': round(1e3 * dt / args.steps, 4), 'higher_is_better': True, 'scaling': 'weak',
-        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': '%s: %s' % (args.workload, desc), 'global_batch': world * rows, 'L': L,
-                   'parallelism': 'dp%d' % world, 'launch': 'hipGraph replay' if use_graph else 'eager', 'feed': args.feed,
-                   'side_chain_cus': getattr(eng, '_side_cus', None),
-                   'dist_backend': (dist.get_backend() if dist.is_initialized() else None),
-                   'dp_exchange': (dp_mode if dp else None),
-                   'rccl_ranks': (dist.get_world_size() if dist.is_initialized() and dist.get_backend() == 'nccl'
-                                  else 0),
-                   'params': int(sum(int(np.prod(s)) for s in arena.shapes.values()))},
-        'losses_last_step': {k: round(v, 4) for k, v in losses.items()}, 'finite': ok,
-        'chain_wait_ticks': waits, 'host_enqueue_ms_per_step': round(1e3 * t_enq / args.steps, 4),
-        'steady_state': steady,
-    }
+    res, ctx = measure(args, args.workload, args.feed, args.steps, args.warmup, device, rank, world,
+                       steady_s=0.0 if args.no_steady else 3.2, exchange_probe=True)
+    ok, dp = res['finite'], ctx['dp']
+    out = {'metric': 'DrVAE ELBO training samples/sec (batch x L)', 'value': res['value'], 'unit': 'samples/s',
+           'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': res['ms_per_step'],
+           'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic'}
+    out.update({k: v for k, v in res.items() if k not in out})
     if rank == 0:
+        from drvae_amd import synth
+        eng, cfg, batch, rows = ctx['eng'], ctx['cfg'], ctx['batch'], ctx['rows']
         hx, hy = batch['has_x2'].astype(bool), batch['has_y'].astype(bool)
         if not args.no_roofline:
             out['roofline'] = gemm_roofline(eng, cfg, rows, float(hx.mean()), float(hy.mean()),
                                             repeats=20 if args.workload != 'wide' else 3, workload=args.workload,
                                             n_params=out['config']['params'],
-                                            input_bytes=4.0 * rows * cfg.dim_x * (2 if cfg.has_pert else 1))
+                                            input_bytes=4.0 * rows * cfg.dim_x * (2 if cfg.has_pert else 1),
+                                            ms_per_step=(res['steady_state'] or res)['ms_per_step'])
         if not args.no_cpu_baseline and args.workload != 'wide' and world == 1:   # rank 0 at N=1 only
             out['cpu_baseline'] = cpu_baseline(args.workload)
             out['elbo_vs_ref'] = parity_vs_cpu(args.workload, device)
+    del ctx
+    if world == 1 and not args.no_extras and args.workload == 'cfg2' and args.feed == 'resident' and not args.no_graph:
+        # next to the headline (inputs resident in HBM, stratified batch): (1) the same step fed the way the
+        # reference's own pipeline feeds it -- WeightedRandomSampler batches of any group mix, drawn from an
+        # HBM-resident dataset by the captured step itself (universal plan); (2) the other configurations of
+        # BASELINE.json, a few steps each, with their own roofline block
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        r2, c2 = measure(args, 'cfg2', 'sampler', 400, 20, device, rank, world)
+        out['realistic_feed'] = {'feed': 'sampler', 'ms_per_step': r2['ms_per_step'], 'value': r2['value'],
+                                 'steps': r2['steps'], 'finite': r2['finite'],
+                                 'what': 'exact WeightedRandomSampler batches (any mix of pairs / labels per batch) gathered '
+                                         'by the captured step from a %d-row HBM-resident dataset' % args.dataset_rows}
+        ok = ok and r2['finite']
+        del c2
+        out['other_workloads'] = {}
+        for wl, (k_, w_) in (('wide', (10, 3)), ('cfg1', (200, 20)), ('cfg4', (200, 20))):
+            gc.collect()
+            torch.cuda.empty_cache()
+            r3, c3 = measure(args, wl, 'resident', k_, w_, device, rank, world)
+            entry = {'ms_per_step': r3['ms_per_step'], 'value': r3['value'], 'steps': k_, 'warmup': w_,
+                     'finite': r3['finite'], 'workload': r3['config']['workload'],
+                     'side_chain_cus': r3['config']['side_chain_cus']}
+            if not args.no_roofline:
+                b3 = c3['batch']
+                entry['roofline'] = gemm_roofline(c3['eng'], c3['cfg'], c3['rows'], float(b3['has_x2'].astype(bool).mean()),
+                                                  float(b3['has_y'].astype(bool).mean()), repeats=3 if wl == 'wide' else 20,
+                                                  workload=wl, n_params=r3['config']['params'],
+                                                  input_bytes=4.0 * c3['rows'] * c3['cfg'].dim_x * (2 if c3['cfg'].has_pert else 1),
+                                                  ms_per_step=r3['ms_per_step'], brief=True)
+            out['other_workloads'][{'wide': 'cfg5'}.get(wl, wl)] = entry
+            ok = ok and r3['finite']
+            del c3
+    import torch.distributed as dist
     if world > 1:
         dist.barrier()
     if world > 1 or (dp and dist.is_initialized()):

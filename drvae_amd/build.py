@@ -25,15 +25,23 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True):
-    """Compile every HIP source for gfx950 into one shared object next to the package."""
-    if not force and not needs_build():
+LAB_LIB = os.path.join(os.path.dirname(HERE), 'build_lab', 'libdrvae_lab.so')
+
+
+def build(force=False, verbose=True, lab=False):
+    """Compile every HIP source for gfx950 into one shared object next to the package.  ``lab``: the tuning build
+    (-DDV_LAB: the GEMM tilings and probe kernels the dispatcher never selects) into build_lab/libdrvae_lab.so --
+    load it with DRVAE_HIP_LIB; the product library does not carry them."""
+    if lab:
+        os.makedirs(os.path.dirname(LAB_LIB), exist_ok=True)
+    elif not force and not needs_build():
         return LIB
     objs = []
     procs = []
     for s in SOURCES:
-        o = os.path.join(CSRC, s.replace('.hip', '.o'))
-        cmd = [_hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-c', os.path.join(CSRC, s), '-o', o]
+        o = os.path.join(os.path.dirname(LAB_LIB) if lab else CSRC, s.replace('.hip', '.o'))
+        cmd = [_hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC'] + (['-DDV_LAB'] if lab else []) + \
+              ['-c', os.path.join(CSRC, s), '-o', o]
         if verbose:
             print(' '.join(cmd), flush=True)
         procs.append((cmd, subprocess.Popen(cmd)))
@@ -41,13 +49,13 @@ def build(force=False, verbose=True):
     for cmd, p in procs:
         if p.wait() != 0:
             raise RuntimeError('hipcc failed: ' + ' '.join(cmd))
-    cmd = [_hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+    out = LAB_LIB if lab else LIB
+    cmd = [_hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', out] + objs
     if verbose:
         print(' '.join(cmd), flush=True)
     subprocess.check_call(cmd)
-    return LIB
+    return out
 
 
 if __name__ == '__main__':
-    build(force='--force' in sys.argv)
-    print(LIB)
+    print(build(force='--force' in sys.argv, lab='--lab' in sys.argv))

@@ -32,9 +32,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef DV_DBG
 #define DV_DBG 0
 #endif
-#ifndef DV_LOOP
-#define DV_LOOP 0
-#endif
 #ifndef DV_STAGGER
 #define DV_STAGGER 0
 #endif
@@ -67,10 +64,15 @@ __device__ unsigned long long* dv_stamp_buf = nullptr;
     } while (0)
 #endif
 
+// internal bit of dv_gemm_desc.flags (the launchers set it; callers pass bits 1 | 2 only): the bias gradient of a
+// dy^T x product is the accumulator column N, produced by staging B's column N as ones
+#define DV_FLAG_ONES_COL 4
+
 namespace {
 
 // what staging chunks past the end of K read (see the K tail of the fast path)
 __device__ __attribute__((aligned(16))) const float dv_zero_chunk[4] = {0.f, 0.f, 0.f, 0.f};
+
 
 constexpr float kLog2PiG = 1.8378770664093453f;   // log(2 pi), as rows.hip
 
@@ -122,10 +124,21 @@ __device__ __forceinline__ void tile_of_block(int bid, int nwg, int tiles_m, int
 // Everything that depends only on the column (scale, bias, activation id, shift) is fetched
 // ONCE; the optional per-element operands (residual / yref / old C) are loaded as one batch
 // before any store, so no load ever waits behind a store's vmcnt.
-template <int NR, typename RowOf>
+template <int NR, bool ONES = true, typename RowOf>
 __device__ __forceinline__ void epi_store_col(const dv_gemm_desc& g, const float (&acc)[NR], int col, RowOf row_of) {
     const bool cok = col < g.N;
     const int cc = cok ? col : g.N - 1;
+    if (ONES && (g.flags & DV_FLAG_ONES_COL) && col == g.N) {
+        // the bias gradient: B's first column past N is staged as ones (see gemm_body), so this accumulator column is
+        // sum_k A[k, row] -- the column sums of dy ride on the matrix core instead of in four extra registers
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int row = row_of(r);
+            if (row < g.M)
+                g.a_colsum[row] = (g.colsum_beta != 0.f ? g.colsum_beta * g.a_colsum[row] : 0.f) + acc[r];
+        }
+        return;
+    }
     const bool first = col < g.split;
     const int act = first ? g.act0 : g.act1;
     const float shift = first ? g.shift0 : g.shift1;
@@ -316,7 +329,9 @@ __device__ __forceinline__ void gemm_body(const dv_gemm_desc& g, const LoadCfg& 
     static_assert(2 * STAGE <= gemm_smem_floats<BM, BN, BK, KS, AKC, BKC>() && RED_ELEMS <= gemm_smem_floats<BM, BN, BK, KS, AKC, BKC>(), "smem");
     static_assert(NT == 256 || NT == 512 || NT == 1024, "4, 8 or 16 waves");
 
-    const int tiles_m = (g.M + BM - 1) / BM, tiles_n = PAIR ? (g.split + HB - 1) / HB : (g.N + BN - 1) / BN;
+    const bool ones_col = BM < 128 && !AKC && !BKC && (g.flags & DV_FLAG_ONES_COL);
+    const int tiles_m = (g.M + BM - 1) / BM;
+    const int tiles_n = PAIR ? (g.split + HB - 1) / HB : (g.N + (ones_col ? 1 : 0) + BN - 1) / BN;
     int tm, tn;
     tile_of_block(bid, nwg, tiles_m, tiles_n, lc.map, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
@@ -344,11 +359,11 @@ __device__ __forceinline__ void gemm_body(const dv_gemm_desc& g, const LoadCfg& 
     static_assert(A_NP >= 1 && B_NP >= 1, "tile too small for the workgroup");
     const int a_c = tid % A_CPL, a_l = tid / A_CPL;
     const int b_c = tid % B_CPL, b_l = tid / B_CPL;
-    // fused bias gradient: the first column-tile of every row-panel sums its A tiles over k
-    // (not in the 128x128 tiling: its dy^T x variant sits at the 256-register limit and the four extra registers
-    // spilled; there the dispatcher runs dv_colsum as a launch of its own, noise next to a product of that size)
-    const bool do_colsum = BM < 128 && !AKC && g.a_colsum != nullptr && n0 == 0;
-    float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
+    // fused bias gradient (dy^T x layout, 32- and 64-wide tiles): the staged B column N -- the first one past the
+    // matrix: padding of the last column tile, or the single useful column of one extra tile per row panel -- is
+    // overwritten with ones on its way into LDS, so the accumulator column N comes out as sum_k A[k, m];
+    // `oc` = which element of this thread's B chunk that column is (-1: none)
+    const int oc = (ones_col && n0 <= g.N && g.N < n0 + BN) ? g.N - n0 - b_c * 4 : -1;
 
     const Operand oa{g.A, g.lda, AKC ? g.M : g.K, AKC ? g.K : g.M};
     const Operand ob{g.B, g.ldb, BKC ? g.N : g.K, BKC ? g.K : g.N};
@@ -407,16 +422,18 @@ __device__ __forceinline__ void gemm_body(const dv_gemm_desc& g, const LoadCfg& 
 #pragma unroll
         for (int p = 0; p < A_NP; ++p) {
             *reinterpret_cast<float4*>(&sA[(a_l + p * A_LPP) * LDA_S + a_c * 4]) = ra[p];
-            if (do_colsum) {
-                csum.x += ra[p].x;
-                csum.y += ra[p].y;
-                csum.z += ra[p].z;
-                csum.w += ra[p].w;
-            }
         }
 #pragma unroll
-        for (int p = 0; p < B_NP; ++p)
-            *reinterpret_cast<float4*>(&sB[(b_l + p * B_LPP) * LDB_S + b_c * 4]) = rb[p];
+        for (int p = 0; p < B_NP; ++p) {
+            float4 v = rb[p];
+            if (BM < 128 && !AKC && !BKC) {
+                v.x = oc == 0 ? 1.f : v.x;
+                v.y = oc == 1 ? 1.f : v.y;
+                v.z = oc == 2 ? 1.f : v.z;
+                v.w = oc == 3 ? 1.f : v.w;
+            }
+            *reinterpret_cast<float4*>(&sB[(b_l + p * B_LPP) * LDB_S + b_c * 4]) = v;
+        }
     };
 
     typename std::conditional<MI16, f32x4, f32x16>::type acc[TM][TN];
@@ -568,74 +585,6 @@ __device__ __forceinline__ void gemm_body(const dv_gemm_desc& g, const LoadCfg& 
                 }
             }
         };
-#if DV_LOOP == 1
-        // one staging set; the next tile's LDS stores and the global loads of the one after are
-        // issued BEFORE the MFMA chain of the current tile, so they complete in its shadow
-        float4 sa[A_NP], sb[B_NP];
-        fetch(0, sa, sb);
-        stage_store(buf0, sa, sb);
-        if (nkt > 1) fetch(1, sa, sb);
-        __syncthreads();
-        for (int kt = 0; kt < nkt; kt += 2) {
-            {
-                float fa[TM][KH], fb[TN][KH];
-                read_frags(buf0, fa, fb);
-                if (kt + 1 < nkt) {
-                    stage_store(buf1, sa, sb);
-                    if (kt + 2 < nkt) fetch(kt + 2, sa, sb);
-                }
-                mma(fa, fb);
-            }
-            __syncthreads();
-            if (kt + 1 >= nkt) break;
-            {
-                float fa[TM][KH], fb[TN][KH];
-                read_frags(buf1, fa, fb);
-                if (kt + 2 < nkt) {
-                    stage_store(buf0, sa, sb);
-                    if (kt + 3 < nkt) fetch(kt + 3, sa, sb);
-                }
-                mma(fa, fb);
-            }
-            __syncthreads();
-        }
-#elif DV_LOOP == 2
-        // fragment registers double-buffered as well: at the top of iteration kt the fragments of
-        // tile kt are already in registers, tile kt+1 is complete in LDS and tile kt+2 is in flight
-        // from global memory.  The iteration issues the fragment reads of tile kt+1, the LDS stores
-        // of tile kt+2 and the global loads of tile kt+3, and only then runs the MFMA chain of tile
-        // kt: every memory operation of the loop completes in the shadow of matrix-core work.
-        float4 sa[A_NP], sb[B_NP];
-        float f0a[TM][KH], f0b[TN][KH], f1a[TM][KH], f1b[TN][KH];
-        {
-            float4 ta[A_NP], tb[B_NP];
-            fetch(0, sa, sb);
-            if (nkt > 1) fetch(1, ta, tb);
-            stage_store(buf0, sa, sb);
-            if (nkt > 1) stage_store(buf1, ta, tb);
-            if (nkt > 2) fetch(2, sa, sb);
-        }
-        __syncthreads();
-        read_frags(buf0, f0a, f0b);
-        __syncthreads();
-        for (int kt = 0; kt < nkt; kt += 2) {
-            if (kt + 1 < nkt) read_frags(buf1, f1a, f1b);
-            if (kt + 2 < nkt) {
-                stage_store(buf0, sa, sb);
-                if (kt + 3 < nkt) fetch(kt + 3, sa, sb);
-            }
-            mma(f0a, f0b);
-            __syncthreads();
-            if (kt + 1 >= nkt) break;
-            if (kt + 2 < nkt) read_frags(buf0, f0a, f0b);
-            if (kt + 3 < nkt) {
-                stage_store(buf1, sa, sb);
-                if (kt + 4 < nkt) fetch(kt + 4, sa, sb);
-            }
-            mma(f1a, f1b);
-            __syncthreads();
-        }
-#else
         float4 a0[A_NP], b0[B_NP], a1[A_NP], b1[B_NP];
 #if DV_STAMP
         const bool stamp_on = dv_stamp_buf != nullptr && wave == 0;
@@ -704,7 +653,6 @@ __device__ __forceinline__ void gemm_body(const dv_gemm_desc& g, const LoadCfg& 
             }
             if (!(DV_DBG & 8)) __syncthreads();
         }
-#endif
     } else {
         // ---- edge tiles / concatenated sources / k-scaled operand: simple loop, generic loads
         float4 ra[A_NP], rb[B_NP];
@@ -719,19 +667,6 @@ __device__ __forceinline__ void gemm_body(const dv_gemm_desc& g, const LoadCfg& 
         }
     }
 
-    if (do_colsum) {   // block-uniform; the main loop ended on a barrier, the tiles are dead
-        reinterpret_cast<float4*>(smem)[tid] = csum;
-        __syncthreads();
-        if (tid < BM) {
-            const int ch = tid >> 2, e = tid & 3;
-            float s = 0.f;
-            for (int l = 0; l < A_LPP; ++l) s += smem[(l * A_CPL + ch) * 4 + e];
-            const int m = m0 + tid;
-            if (m < g.M) g.a_colsum[m] = (g.colsum_beta != 0.f ? g.colsum_beta * g.a_colsum[m] : 0.f) + s;
-        }
-        __syncthreads();
-    }
-
     if constexpr (MI16) {
         // a lane holds rows 4*(lane/16) .. +3 of column lane%16 of each 16x16 tile
 #pragma unroll
@@ -742,7 +677,7 @@ __device__ __forceinline__ void gemm_body(const dv_gemm_desc& g, const LoadCfg& 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) a4[r] = acc[i][j][r];
                 const int rbase = m0 + wm * TM * TS + i * TS + 4 * lh;
-                epi_store_col<4>(g, a4, n0 + wn * TN * TS + j * TS + li, [rbase](int r) { return rbase + r; });
+                epi_store_col<4, (BM < 128)>(g, a4, n0 + wn * TN * TS + j * TS + li, [rbase](int r) { return rbase + r; });
             }
     } else if constexpr (KS == 1) {
 #pragma unroll
@@ -753,7 +688,7 @@ __device__ __forceinline__ void gemm_body(const dv_gemm_desc& g, const LoadCfg& 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) a16[r] = acc[i][j][r];
                 const int rbase = m0 + wm * TM * 32 + i * 32 + 4 * lh;
-                epi_store_col<16>(g, a16, n0 + wn * TN * 32 + j * 32 + li,
+                epi_store_col<16, (BM < 128)>(g, a16, n0 + wn * TN * 32 + j * 32 + li,
                                   [rbase](int r) { return rbase + (r & 3) + 8 * (r >> 2); });
             }
     } else {
@@ -806,7 +741,7 @@ __device__ __forceinline__ void publish_on_entry(const dv_gemm_desc& g) {
 }
 
 template <int BM, int BN, int BK, int WM, int WN, int KS, bool AKC, bool BKC, bool MI16 = false>
-__global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 16) ? 4 : (BM >= 128 || BK >= 128) ? 2 : (BM * BN >= 6144) ? (WM * WN * KS) / 4 : (WM * WN * KS == 8 ? (BM * BN == 1024 ? DV_LB8 : 2) : (BK == 32 && BM == 32 ? DV_DENSE_WG : 4))) void gemm_kernel(const dv_gemm_desc g, const LoadCfg lc) {
+__global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 16) ? 4 : (BM >= 128 || BK >= 128) ? 2 : (BM * BN >= 6144) ? (WM * WN * KS) / 4 : (WM * WN * KS == 8 ? (BM * BN == 1024 ? DV_LB8 : 2) : (BK == 32 && BM == 32 ? ((AKC || BKC) ? DV_DENSE_WG : DV_DENSE_WG - 1) : 4))) void gemm_kernel(const dv_gemm_desc g, const LoadCfg lc) {
     __shared__ __attribute__((aligned(16))) float smem[gemm_smem_floats<BM, BN, BK, KS, AKC, BKC>()];
     publish_on_entry(g);
 #if DV_STAGGER
@@ -820,6 +755,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 16) ? 4 : (BM >
     gemm_body<BM, BN, BK, WM, WN, KS, AKC, BKC, false, MI16>(g, lc, smem, blockIdx.x, gridDim.x);
 }
 
+#ifdef DV_LAB   // probe kernels of the tuning build (tools/gemm_lab.sh): never selected by the dispatcher
 // ---------------------------------------------------------------------------------------------------------------
 // LDS-DMA variant of the 32x32 K-split tiling for the forward layout (both operands k-contiguous): the tiles go
 // global -> LDS directly (global_load_lds_dwordx4: no staging registers, no ds_write), one 1-KiB piece = 4 tile
@@ -1031,6 +967,8 @@ __global__ __launch_bounds__(256, 4) void gemm_wp_kernel(const dv_gemm_desc g, c
     epi_store_col<RPT>(g, a4, n0 + col, [rbase](int r) { return rbase + r; });
 }
 
+#endif   // DV_LAB
+
 template <int BM, int BN, int BK, int KS>
 __global__ __launch_bounds__(64 * KS, KS == 8 ? 2 : (BK == 32 ? DV_DENSE_WG : 4)) void gemm_heads_kernel(const dv_gemm_desc g, const LoadCfg lc,
                                                                const dv_heads_epi he) {
@@ -1067,9 +1005,12 @@ inline int vec_width(const void* p, int64_t ld) {
 static int g_lds_pad = 0;
 inline int lds_pad(int bm, int tiles) { return (bm <= 32 && tiles >= 512) ? g_lds_pad : 0; }
 
+// output columns incl. the ones column of the fused bias gradient (see gemm_body)
+inline int cols_eff(const dv_gemm_desc& g) { return g.N + ((g.flags & DV_FLAG_ONES_COL) ? 1 : 0); }
+
 template <int BM, int BN, int BK, int WM, int WN, int KS, bool MI16 = false>
 int launch_cfg(const dv_gemm_desc& g, const LoadCfg& lc, hipStream_t st) {
-    const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
+    const int tiles = ((g.M + BM - 1) / BM) * ((cols_eff(g) + BN - 1) / BN);
     dim3 grid(tiles), block(64 * WM * WN * KS);
     if (g.a_kcontig && g.b_kcontig)
         hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, WM, WN, KS, true, true, MI16>), grid, block, lds_pad(BM, tiles), st, g, lc);
@@ -1102,6 +1043,9 @@ extern "C" int dv_gemm_set_option(int key, int value) {
 }
 
 extern "C" int dv_gemm_force_tiling(int t) {
+#ifndef DV_LAB
+    if ((t < 0 || t > 3) && t != 17) return DV_ERR_UNSUPPORTED;      // the lab tilings exist in the tuning build only (-DDV_LAB)
+#endif
     g_force_tiling = t;
     return DV_OK;
 }
@@ -1152,23 +1096,32 @@ static int gemm_prepare(const dv_gemm_desc* d, LoadCfg& lc, int& tiling) {
 // tiles of 32x32 from which a product runs on the high-occupancy tiling (dv_gemm_set_option(8, n); 0 = default)
 static int dense_min_tiles() { return g_opt[8] > 0 ? g_opt[8] : 512; }
 
-static int gemm_launch(const dv_gemm_desc& g, const LoadCfg& lc, int tiling, hipStream_t st) {
+// fused bias gradient of a dy^T x product: the ones column (DV_FLAG_ONES_COL) -- free where the last column tile has
+// padding, one extra tile per row panel where N is a multiple of the tile width.  Not in the 128x128 tiling (its
+// kernels sit at the 256-register limit; an extra tile would cost 1/(N/128) of the product): there the column sums
+// are a launch of their own, noise next to a product of that size
+static int colsum_setup(dv_gemm_desc& g, int tiling, hipStream_t st) {
+    g.flags &= 3;
+    if (g.a_colsum == nullptr || g.a_kcontig) return DV_OK;
+    if (tiling == 3 || tiling == 16) {
+        const int rc = dv_colsum(g.A, g.lda, g.K, g.M, g.a_colsum, g.colsum_beta, st);
+        g.a_colsum = nullptr;
+        return rc;
+    }
+    g.flags |= DV_FLAG_ONES_COL;
+    return DV_OK;
+}
+
+static int gemm_launch(const dv_gemm_desc& g_in, const LoadCfg& lc, int tiling, hipStream_t st) {
     if (tiling < 0) return DV_OK;
-    if (tiling == 3) {
-        if (g.a_colsum != nullptr && !g.a_kcontig) {     // fused bias gradient: see do_colsum
-            const int rc = dv_colsum(g.A, g.lda, g.K, g.M, g.a_colsum, g.colsum_beta, st);
-            if (rc != DV_OK) return rc;
-        }
-        return launch_cfg<128, 128, 32, 2, 2, 1>(g, lc, st);
+    dv_gemm_desc g = g_in;
+    {
+        const int rc = colsum_setup(g, tiling, st);
+        if (rc != DV_OK) return rc;
     }
-    if (tiling == 16) {                   // the 128x128 tiling on v_mfma_f32_16x16x4_f32
-        if (g.a_colsum != nullptr && !g.a_kcontig) {
-            const int rc = dv_colsum(g.A, g.lda, g.K, g.M, g.a_colsum, g.colsum_beta, st);
-            if (rc != DV_OK) return rc;
-        }
-        return launch_cfg<128, 128, 32, 2, 2, 1, true>(g, lc, st);
-    }
-    if (tiling == 17) return launch_cfg<32, 32, 32, 1, 1, 4>(g, lc, st);    // lab: half the K tile, seven workgroups per CU
+    if (tiling == 3) return launch_cfg<128, 128, 32, 2, 2, 1>(g, lc, st);
+#ifdef DV_LAB
+    if (tiling == 16) return launch_cfg<128, 128, 32, 2, 2, 1, true>(g, lc, st);   // the 128x128 tiling on v_mfma_f32_16x16x4_f32
     if (tiling == 30 && g.a_kcontig && g.b_kcontig) return launch_cfg<96, 64, 64, 1, 2, 4>(g, lc, st);   // lab: one round of big tiles
     if (tiling == 32 && g.a_kcontig && g.b_kcontig) return launch_cfg<96, 64, 32, 1, 2, 2>(g, lc, st);
     if (tiling == 34 && g.a_kcontig) return launch_cfg<64, 32, 64, 2, 1, 4>(g, lc, st);
@@ -1210,6 +1163,9 @@ static int gemm_launch(const dv_gemm_desc& g, const LoadCfg& lc, int tiling, hip
         }
         return launch_cfg<32, 32, 64, 1, 1, 8>(g, lc, st);
     }
+#endif   // DV_LAB
+    if (tiling == 17) return launch_cfg<32, 32, 32, 1, 1, 4>(g, lc, st);    // forced: the seven-per-CU tiling (below)
+    if (tiling != 1 && tiling != 2) return DV_ERR_UNSUPPORTED;
     if (tiling == 1) return launch_cfg<64, 64, 32, 2, 2, 1>(g, lc, st);
     // 32x32 K-split tiling: the k-contiguous-A layouts (x W^T, dy W) run with EIGHT waves splitting each 64-deep K
     // tile (half the MFMA chain per wave, twice the waves to overlap its latency: 4-10 % faster on every cfg-2
@@ -1218,7 +1174,7 @@ static int gemm_launch(const dv_gemm_desc& g, const LoadCfg& lc, int tiling, hip
     // workgroups fit a CU instead of four and the whole grid is resident in one round -- the 1178 workgroups of the
     // decoder-head products took two rounds on 256 CUs (three on the main chain's 192): x W^T 24.3 -> 21.2 us,
     // dy^T x 23.6 -> 21.0 us alone (tools/gemm_bench.py --tilings 2,9,17)
-    const int tiles32 = ((g.M + 31) / 32) * ((g.N + 31) / 32);
+    const int tiles32 = ((g.M + 31) / 32) * ((cols_eff(g) + 31) / 32);
     if (tiles32 >= dense_min_tiles()) return launch_cfg<32, 32, 32, 1, 1, 4>(g, lc, st);
     if (g.a_kcontig && g_opt[7] == 0) return launch_cfg<32, 32, 64, 1, 1, 8>(g, lc, st);
     return launch_cfg<32, 32, 64, 1, 1, 4>(g, lc, st);
@@ -1234,7 +1190,11 @@ extern "C" int dv_gemm(const dv_gemm_desc* d, dv_stream_t stream) {
 
 // half-tile width of the paired-heads launch: 16 (default: 32x(16+16) tiles = the workgroup count and MFMA chain of
 // the 32x32 K-split tiling) or 32 (g_opt[4] = 1 / 2: 32x(32+32) tiles with 4 / 8 waves; measured slower at cfg 2)
+#ifdef DV_LAB
 static int heads_hb() { return (g_opt[4] == 1 || g_opt[4] == 2) ? 32 : 16; }
+#else
+static int heads_hb() { return 16; }
+#endif
 extern "C" int dv_gemm_heads_tiles(int32_t split) { return split > 0 ? (split + heads_hb() - 1) / heads_hb() : 0; }
 
 extern "C" int dv_gemm_heads(const dv_gemm_desc* d, const dv_heads_epi* e, dv_stream_t stream) {
@@ -1259,16 +1219,24 @@ extern "C" int dv_gemm_heads(const dv_gemm_desc* d, const dv_heads_epi* e, dv_st
     }
     lc.map = g_opt[0] >= 0 ? g_opt[0] : 1;
     const int tiles = ((g.M + 31) / 32) * dv_gemm_heads_tiles(g.split);
-    if (g_opt[4] == 1)
+#ifdef DV_LAB
+    if (g_opt[4] == 1) {
         hipLaunchKernelGGL((gemm_heads_kernel<32, 64, 64, 4>), dim3(tiles), dim3(256), 0,
                            static_cast<hipStream_t>(stream), g, lc, *e);
-    else if (g_opt[4] == 2)   // 8 waves split K: per wave the MFMA chain of the 32x32 K-split tiling, A staged once
+        DV_RETURN_LAUNCH();
+    }
+    if (g_opt[4] == 2) {   // 8 waves split K: per wave the MFMA chain of the 32x32 K-split tiling, A staged once
         hipLaunchKernelGGL((gemm_heads_kernel<32, 64, 64, 8>), dim3(tiles), dim3(512), 0,
                            static_cast<hipStream_t>(stream), g, lc, *e);
-    else if (g_opt[4] == -1)
+        DV_RETURN_LAUNCH();
+    }
+    if (g_opt[4] == -1) {
         hipLaunchKernelGGL((gemm_heads_kernel<32, 32, 64, 4>), dim3(tiles), dim3(256), 0,
                            static_cast<hipStream_t>(stream), g, lc, *e);
-    else if (g_opt[4] == 3 || (g_opt[4] == 0 && tiles >= dense_min_tiles()))
+        DV_RETURN_LAUNCH();
+    }
+#endif
+    if (g_opt[4] == 3 || (g_opt[4] == 0 && tiles >= dense_min_tiles()))
         // chip-filling grids: four waves, half the K tile, seven workgroups per CU (see gemm_launch): 29.1 -> 26.4 us
         // for the decoder heads + NLL alone
         hipLaunchKernelGGL((gemm_heads_kernel<32, 32, 32, 4>), dim3(tiles), dim3(256), 0,
@@ -1291,7 +1259,13 @@ extern "C" int dv_gemm_pair(const dv_gemm_desc* d1, const dv_gemm_desc* d2, dv_s
     // (it is moved to whichever runs first); two would silently drop one and leave its consumer chain spinning
     DV_REQUIRE(!(d1->pub_flag != nullptr && d2->pub_flag != nullptr));
     // fused form: both products on the 32x32 K-split tiling, (dy^T x) + (dy W) layouts
-    const int tiles1 = ((d1->M + 31) / 32) * ((d1->N + 31) / 32), tiles2 = ((d2->M + 31) / 32) * ((d2->N + 31) / 32);
+    dv_gemm_desc e1 = *d1, e2 = *d2;
+    e2.flags &= 3;
+    if (t1 == 2 && t2 == 2) {      // (32-wide tiles: the bias gradient rides on the ones column)
+        rc = colsum_setup(e1, 2, st);
+        if (rc != DV_OK) return rc;
+    }
+    const int tiles1 = ((e1.M + 31) / 32) * ((cols_eff(e1) + 31) / 32), tiles2 = ((e2.M + 31) / 32) * ((e2.N + 31) / 32);
     // pairing pays for the latency-bound small products; a product that already fills the chip
     // several times over (>= 4 workgroups per CU) gains nothing from a partner (measured: the
     // decoder-heads pair ran 66 us paired vs 29 + 29 us alone)
@@ -1303,7 +1277,7 @@ extern "C" int dv_gemm_pair(const dv_gemm_desc* d1, const dv_gemm_desc* d2, dv_s
     // ~32 us as one; the old four-per-CU pairing of two chip-filling products was SLOWER than two launches)
     if (!fuse && g_opt[9] != 1 && t1 == 2 && t2 == 2 && !d1->a_kcontig && !d1->b_kcontig && d2->a_kcontig &&
         !d2->b_kcontig && tiles1 >= dense_min_tiles() && tiles1 + tiles2 < 4096) {
-        dv_gemm_desc first = *d2, second = *d1;
+        dv_gemm_desc first = e2, second = e1;
         if (first.pub_flag == nullptr && second.pub_flag != nullptr) {      // the kernel publishes for its first product
             first.pub_flag = second.pub_flag;
             first.pub_ctr = second.pub_ctr;
@@ -1319,13 +1293,13 @@ extern "C" int dv_gemm_pair(const dv_gemm_desc* d1, const dv_gemm_desc* d2, dv_s
         if (rc != DV_OK) return rc;
         return gemm_launch(*d2, lc2, t2, st);
     }
-    dv_gemm_desc first = *d1;
+    dv_gemm_desc first = e1;
     if (first.pub_flag == nullptr && d2->pub_flag != nullptr) {
         first.pub_flag = d2->pub_flag;
         first.pub_ctr = d2->pub_ctr;
         first.pub_add = d2->pub_add;
     }
     hipLaunchKernelGGL((gemm_pair_kernel<32, 32, 64, 1, 1, 4, false, false, true, false>), dim3(tiles1 + tiles2),
-                       dim3(256), 0, st, first, lc1, *d2, lc2, tiles1);
+                       dim3(256), 0, st, first, lc1, e2, lc2, tiles1);
     DV_RETURN_LAUNCH();
 }

@@ -28,6 +28,7 @@ import numpy as np
 import torch
 
 from . import kernels as K
+from . import tuning as T
 from ._lib import GAUSS_LOGVAR, GAUSS_SIGMA
 from .arena import N_LOSS, ParamArena
 from .chain import _Chain, _Lin, _pad4
@@ -196,26 +197,26 @@ class FusedStep(StepSchedule):
         self.seed = seed
         self.training = True
         self.fuse_bwd = False               # set by train_step/capture: forward is followed by backward
-        # train-step scheduling of the classifier/fprop side chain (DRVAE_SCHED): 1 = graph fork/join per
+        # train-step scheduling of the classifier/fprop side chain (tuning 'sched'): 1 = graph fork/join per
         # pass, 3 = one graph fork/join per step, 5 (default) = two single-stream graphs (main chain / side
         # chain) launched on two streams per step and ordered ONLY by device flags (dv_flag_publish /
         # dv_flag_wait): no graph edges, no events.  (Also tried and dropped: an extra cross edge, 0.37 ms;
         # the side chain as a second ROOT of one graph with flags, 0.42 ms -- the executor starts it late.)
-        self.sched = int(os.environ.get('DRVAE_SCHED', '5'))
+        self.sched = T.get('sched')
         self._rec = 'both'
-        self.late_leaf = os.environ.get('DRVAE_LATE_LEAF', '1') != '0'
-        self.side_adam = os.environ.get('DRVAE_SIDE_ADAM', '1') != '0'
-        self.fold_join = os.environ.get('DRVAE_FOLD_JOIN', '1') != '0'
+        self.late_leaf = bool(T.get('late_leaf'))
+        self.side_adam = bool(T.get('side_adam'))
+        self.fold_join = bool(T.get('fold_join'))
         # the row work that consumes both heads of a block (the reparameterised samples; forward AND backward of
         # the reconstruction log-likelihood) leaves the heads' own GEMM launch (dv_gemm_heads)
-        self.fuse_heads = os.environ.get('DRVAE_FUSE_HEADS', '1') != '0'
+        self.fuse_heads = bool(T.get('fuse_heads'))
         # the side chain's second wait rides on the row kernel behind it (dv_wait argument of dv_kl_rows_fwd)
         # instead of being a launch of its own
-        self.fold_waits = os.environ.get('DRVAE_FOLD_WAITS', '1') != '0'
+        self.fold_waits = bool(T.get('fold_waits'))
         # the side chain's tail (bit mask): 1 / 4 = its two publishes ride on the entry of the launch behind them
         # (classifier dW; the counter launch), 2 = the wait in front of the next step's Philox draws is a park of the
         # draw launch itself -- measured SLOWER (356 workgroups polling one flag: +10 us/step), hence off
-        self.fold_tail = int(os.environ.get('DRVAE_FOLD_TAIL', '5'))
+        self.fold_tail = T.get('fold_tail')
         self.noise_ahead = False          # set by capture(): the side chain draws the NEXT step's noise behind the join
         self._noise_stale = True          # (then) the noise buffer does not hold the draws of the current Philox counter
         self._adam_n = None
@@ -232,7 +233,7 @@ class FusedStep(StepSchedule):
         # classifier/fprop chain || decoder chain.  PVAE's side chain is one tiny KL kernel: a second stream
         # costs it far more than it hides (measured 0.19 ms single-stream vs 0.9 ms forked), so it runs serial
         self.branch = _Branch(self.dev, enabled=concurrent and cfg.has_y)
-        self.wbranch = _Branch(self.dev, enabled=concurrent and os.environ.get('DRVAE_WBRANCH', '0') == '1')   # measured slower on MI355X (third graph branch): off
+        self.wbranch = _Branch(self.dev, enabled=concurrent and bool(T.get('wbranch')))   # measured slower on MI355X (third graph branch): off
         self._build_layers()
 
     # ------------------------------------------------------------------ layer table
@@ -281,7 +282,7 @@ class FusedStep(StepSchedule):
             self.L_clf = layers
             # single Linear with <= 8 classes: dedicated wave-per-row kernels instead of MFMA tiles
             self.clf_small = (not cfg.h_clf) and cfg.dim_y <= 8 and not wn and not cfg.clf_1sig and not cfg.cont and \
-                os.environ.get('DRVAE_CLF_SMALL', '1') != '0'
+                bool(T.get('clf_small'))
             self.L_top = self._gauss(cfg.top_name, len(cfg.h_en_z3), 'lv', shift_second=-2.0)
             self.L_dz1 = self._gauss('decoder_z1', len(cfg.h_de_z1), 'lv', shift_second=-2.0)
 
@@ -689,23 +690,24 @@ class FusedStep(StepSchedule):
         written when the labels are: ``_Plan._refresh_onehot`` / ``dv_batch_feed``)"""
         cfg, p = self.cfg, self.plan
         return bool(self.fuse_heads and self._heads_small(p.DPX) and cfg.has_y and not cfg.cont and p.Mf
-                    and os.environ.get('DRVAE_FPROP_HEADS', '1') != '0')
+                    and T.get('fprop_heads'))
 
     def _fprop_tail(self):
         """train step: the fprop rows' KL forward and the z1 term's backward ride on the classifier-head launch
         (``dv_fprop_kl``)"""
         cfg, p = self.cfg, self.plan
         return bool(self.fuse_bwd and self.fuse_heads and self.clf_small and cfg.has_y and not cfg.cont and p.Mf
-                    and os.environ.get('DRVAE_FPROP_TAIL', '1') != '0')
+                    and T.get('fprop_tail'))
 
     def _klz2_on_main(self):
-        """dual-graph train step: the pairs' KL(q(z2|x2)||p(z2|z1)) rows run on the main chain (DRVAE_KLZ2_MAIN=0: on
+        """dual-graph train step: the pairs' KL(q(z2|x2)||p(z2|z1)) rows run on the main chain (tuning klz2_main=0: on
         the side chain, as in every other schedule)"""
         # (not with the batch-independent plan: its worst-case decoder rows make the main chain the longer one again,
         # the side chain parks ~13 us per step behind it -- sampler feed 0.250 -> 0.248 ms with the rows on the side chain)
-        dflt = '0' if (self.plan is not None and self.plan.universal) else '1'
-        return (self._mode() == 5 and not self.cfg.cont and self.cfg.has_y
-                and os.environ.get('DRVAE_KLZ2_MAIN', dflt) != '0')
+        on = T.get('klz2_main')
+        if on < 0:
+            on = 0 if (self.plan is not None and self.plan.universal) else 1
+        return bool(self._mode() == 5 and not self.cfg.cont and self.cfg.has_y and on)
 
     def _mmd_penalty(self):
         """Model-level MMD penalty of the ``use_s`` extension (src/DrVAE.py:394-398,537-540): minus the MMD between

@@ -9,6 +9,7 @@ import weakref
 import torch
 
 from . import kernels as K
+from . import tuning as T
 
 
 def _masked_stream(bits, device):
@@ -34,7 +35,7 @@ def _masked_stream(bits, device):
     return torch.cuda.ExternalStream(st.value, device=device)
 
 
-SYNC_POLL = int(os.environ.get('DRVAE_SYNC_POLL', '64'))     # steps between two polls of the wait-error words
+SYNC_POLL = T.get('sync_poll')     # steps between two polls of the wait-error words
 
 _PINNED_POOL = []             # pinned int32 buffers of retired engines (see ``_poll_sync``)
 _PARTITION_STREAMS = {}      # device index -> {reserved CUs -> (main stream, side stream) | None}
@@ -132,7 +133,7 @@ class StepSchedule:
         self._split_kind = split_for_allreduce          # False | True (two graphs) | 'overlap' | 'captured'
         cfg = self.cfg
         self.noise_ahead = bool(dual and split_for_allreduce in (False, True) and self.late_leaf and not cfg.cont and self.clf_small
-                                and cfg.optim_alg == 'adam' and os.environ.get('DRVAE_NOISE_AHEAD', '1') != '0')
+                                and cfg.optim_alg == 'adam' and T.get('noise_ahead'))
         self._noise_stale = True
         if dual:
             self._rec = 'main'

@@ -1,0 +1,56 @@
+"""Developer switches of the train step's launch schedule.  NOT part of the user surface: every default is the
+measured best on MI355X ("Step scheduling"), and the alternatives exist so that tools/ (A/B runs, the
+soak test) can still reach them.  One variable carries them all::
+
+    DRVAE_TUNE="sched=3,fold_tail=1" python bench.py
+
+User-facing environment variables (the whole list): DRVAE_HIP_LIB (another build of the library), DRVAE_SIDE_CUS
+(compute units reserved for the side chain; 0 = no partition), DRVAE_WAIT_SPINS (bound of a device-side wait),
+DRVAE_DIST_BACKEND (torch.distributed backend of the data-parallel step; default nccl = RCCL on a GPU),
+DRVAE_FORCE_DP=1 (the multi-rank step path over a one-rank communicator: functional check on a one-GPU box)."""
+import os
+
+DEFAULTS = {
+    'sched': 5,          # 1 graph fork/join per pass | 3 one fork/join per step | 5 two graphs ordered by device flags
+    'late_leaf': 1,      # classifier dW behind the side chain's publish (gated optimiser sweep)
+    'side_adam': 1,      # the decoder-heads half of the optimiser sweep on the side chain
+    'fold_join': 1,      # the join parks on its first consumer instead of a launch of its own
+    'fuse_heads': 1,     # samples / NLL forward+backward in the epilogue of the heads' GEMM (dv_gemm_heads)
+    'fold_waits': 1,     # the side chain's second wait rides on the row kernel behind it
+    'fold_tail': 5,      # bit mask: 1 / 4 the side chain's publishes ride on the next launch, 2 the noise draw parks itself
+    'klz2_main': -1,     # pairs' KL rows on the main chain: -1 = by plan kind (structured: yes, universal: no)
+    'fprop_tail': 1,     # fprop KL rows + z1 term's backward on the classifier-head launch
+    'fprop_heads': 1,    # z1 samples copied into the fprop input by the encoder heads' epilogue
+    'clf_small': 1,      # single-Linear classifier with <= 8 classes as wave-per-row kernels
+    'wbranch': 0,        # weight gradients on a third graph branch (measured slower)
+    'noise_ahead': 1,    # the side chain draws the NEXT step's noise behind the join
+    'concurrent': 1,     # side chain at all (0: one stream)
+    'sync_poll': 64,     # replays between two polls of the sticky wait-error words
+}
+
+
+def _parse():
+    out = dict(DEFAULTS)
+    for kv in filter(None, os.environ.get('DRVAE_TUNE', '').split(',')):
+        k, _, v = kv.partition('=')
+        k = k.strip()
+        if k not in DEFAULTS:
+            raise ValueError('DRVAE_TUNE: unknown switch %r (known: %s)' % (k, ', '.join(sorted(DEFAULTS))))
+        out[k] = int(v)
+    return out
+
+
+_VALUES = None
+
+
+def get(name):
+    global _VALUES
+    if _VALUES is None:
+        _VALUES = _parse()
+    return _VALUES[name]
+
+
+def reload():
+    """re-read DRVAE_TUNE (tests that change the environment)"""
+    global _VALUES
+    _VALUES = None

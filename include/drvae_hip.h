@@ -246,7 +246,8 @@ typedef struct dv_heads_epi {
 } dv_heads_epi;
 int dv_gemm_heads(const dv_gemm_desc* desc, const dv_heads_epi* epi, dv_stream_t stream);
 int dv_gemm_heads_tiles(int32_t split);
-/* test/tuning hook: 0 = heuristic tiling, 1 = 64x64, 2 = 32x32 K-split, 3 = 128x128 */
+/* test/tuning hook: 0 = heuristic tiling, 1 = 64x64, 2 = 32x32 K-split, 3 = 128x128, 17 = 32x32x32 seven-per-CU;
+ * any other code names a lab tiling of the tuning build (-DDV_LAB): DV_ERR_UNSUPPORTED in the product library */
 int dv_gemm_force_tiling(int tiling);
 /* test/tuning hook: key 0 = workgroup->tile map (0 linear, 1 XCD chunk-major [default]);
  * key 2 = 1 disables the fused form of dv_gemm_pair */

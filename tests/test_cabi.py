@@ -93,3 +93,41 @@ def test_kernels_refuse_cpu_tensors():
     import drvae_amd.kernels as K
     with pytest.raises(RuntimeError, match='no CPU'):
         K.colsum(torch.zeros(3), torch.zeros(2, 3))
+
+
+def _kernel_metadata(tmp_path):
+    """(name, vgpr_count, vgpr_spill_count, sgpr_spill_count) of every gfx950 kernel in the built library"""
+    import shutil
+    import subprocess
+    from drvae_amd import _lib
+    llvm = '/opt/rocm/lib/llvm/bin'
+    if not (os.path.exists(os.path.join(llvm, 'llvm-objdump')) and os.path.exists(_lib.LIB_PATH)):
+        pytest.skip('needs the ROCm llvm tools and the built library')
+    so = shutil.copy(_lib.LIB_PATH, str(tmp_path))
+    subprocess.run([os.path.join(llvm, 'llvm-objdump'), '--offloading', so], cwd=str(tmp_path), capture_output=True, check=True)
+    out = []
+    for f in sorted(os.listdir(str(tmp_path))):
+        if 'gfx950' not in f:
+            continue
+        notes = subprocess.run([os.path.join(llvm, 'llvm-readelf'), '--notes', os.path.join(str(tmp_path), f)],
+                               capture_output=True, text=True, check=True).stdout
+        cur = {}
+        for line in notes.splitlines():
+            m = re.match(r'\s+\.(name|vgpr_count|vgpr_spill_count|sgpr_spill_count):\s+(\S+)', line)
+            if m:
+                cur[m.group(1)] = m.group(2)
+                if len(cur) == 4:
+                    out.append((cur['name'], int(cur['vgpr_count']), int(cur['vgpr_spill_count']), int(cur['sgpr_spill_count'])))
+                    cur = {}
+    return out
+
+
+def test_no_kernel_of_the_product_library_spills_vector_registers(tmp_path):
+    """every kernel the dispatcher can select keeps its vector registers out of scratch memory (gfx950 code-object
+    metadata of the built library), and the library carries no lab kernels (they live behind -DDV_LAB)"""
+    meta = _kernel_metadata(tmp_path)
+    assert len(meta) > 40, 'no gfx950 kernels found in the library'
+    spilled = [(n, s) for (n, v, s, g) in meta if s != 0]
+    assert not spilled, spilled
+    assert not [n for (n, v, s, g) in meta if 'gemm_dma_kernel' in n or 'gemm_wp_kernel' in n]
+    assert max(v for (n, v, s, g) in meta) <= 256

@@ -116,19 +116,19 @@ def test_step_path_over_rccl_single_rank(dev):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, os.path.join(root, 'bench.py'), '--steps', '12', '--warmup', '3', '--no-cpu-baseline',
-           '--no-roofline']
+           '--no-roofline', '--no-steady', '--no-extras']
 
-    def run(**env):
-        e = dict(os.environ, DRVAE_SIDE_CUS='64', DRVAE_BENCH_STEADY='0', **env)
+    def run(*args, **env):
+        e = dict(os.environ, DRVAE_SIDE_CUS='64', **env)
         e.pop('RANK', None)
         e.pop('WORLD_SIZE', None)
-        out = subprocess.run(cmd, env=e, capture_output=True, text=True, timeout=300)
+        out = subprocess.run(cmd + list(args), env=e, capture_output=True, text=True, timeout=300)
         assert out.returncode == 0, out.stderr[-2000:]
         line = [ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1]
         return json.loads(line)
     plain = run()
     single = run(DRVAE_FORCE_DP='1', MASTER_PORT='29561')
-    pieces = run(DRVAE_FORCE_DP='1', DRVAE_DP_OVERLAP='1', MASTER_PORT='29562')
+    pieces = run('--dp-exchange', 'overlap', DRVAE_FORCE_DP='1', MASTER_PORT='29562')
     assert plain['finite'] and single['finite'] and pieces['finite']
     assert single['losses_last_step'] == plain['losses_last_step'] == pieces['losses_last_step']
     assert all(v == 0 for v in single['chain_wait_ticks'][0::2] + pieces['chain_wait_ticks'][0::2])
@@ -142,11 +142,12 @@ def test_bench_self_launch_two_ranks_one_gpu(dev):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    e = dict(os.environ, DRVAE_DIST_BACKEND='gloo', DRVAE_SIDE_CUS='64', DRVAE_BENCH_STEADY='0')
+    e = dict(os.environ, DRVAE_DIST_BACKEND='gloo', DRVAE_SIDE_CUS='64')
     for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT'):
         e.pop(k, None)
     out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '10', '--warmup', '3',
-                          '--no-cpu-baseline', '--no-roofline'], env=e, capture_output=True, text=True, timeout=600)
+                          '--no-cpu-baseline', '--no-roofline', '--no-steady', '--no-extras'], env=e, capture_output=True,
+                         text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
     assert len(lines) == 1, out.stdout

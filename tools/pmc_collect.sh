@@ -4,8 +4,8 @@
 export TMPDIR=/tmp
 # counter collection serializes kernel dispatches: use the single-graph schedule (same kernels; a parked
 # device-side wait of the dual-graph schedule could only time out there)
-export DRVAE_SCHED=3 DRVAE_SIDE_CUS=0
-CMD="python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline"
+export DRVAE_TUNE=sched=3 DRVAE_SIDE_CUS=0
+CMD="python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-steady --no-extras"
 mkdir -p gpurun_out/pmc_rr
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_rr/fetch -o p -- $CMD > gpurun_out/pmc_rr/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_rr/write -o p -- $CMD > gpurun_out/pmc_rr/write.log 2>&1
