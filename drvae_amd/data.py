@@ -116,14 +116,19 @@ class DeviceBatcher:
     """Stratified, weighted, with-replacement minibatches drawn ON the device and written
     straight into the fused step's input buffers (see the module docstring)."""
 
-    def __init__(self, dataset, weights, batch_size, group_counts=None, seed=0, mode='stratified'):
+    def __init__(self, dataset, weights, batch_size, group_counts=None, seed=0, mode='stratified', generator='device'):
         """``mode='stratified'`` (default): every batch has the SAME composition (the expected counts of the four
         groups under the weights, or ``group_counts``) -- rows within a group drawn with replacement by weight;
         the step runs on the plan of exactly that structure.
         ``mode='sampler'``: the reference's pipeline to the letter (src/run_drvae.py:150-166):
         ``WeightedRandomSampler(weights, len(weights))`` -- len(dataset) i.i.d. draws with replacement by weight --
         cut into consecutive batches with ``drop_last``; the composition of a batch is whatever the draws give, so
-        the step runs on the batch-independent ("universal") plan with on-device group masks."""
+        the step runs on the batch-independent ("universal") plan with on-device group masks.
+        ``generator='cpu'`` (sampler mode): the epoch's index table is drawn exactly as the reference's pipeline draws
+        it -- torch's DEFAULT CPU generator (``torch.manual_seed``): per epoch one int64 draw (the DataLoader iterator's
+        base seed) followed by ``torch.multinomial(weights.double(), len(dataset), True)``, full batches kept -- so the
+        index stream equals ``list(DataLoader(ds, sampler=WeightedRandomSampler(w, len(w)), drop_last=...))`` bit for
+        bit (tests/golden/sampler.npz); the default draws on the device from the batcher's own generator."""
         # a dataset shorter than one batch is ONE batch of all its rows: DataLoader(drop_last=(len >= batch_size))
         batch_size = min(batch_size, len(dataset))
         self.ds, self.batch_size = dataset, batch_size
@@ -152,9 +157,13 @@ class DeviceBatcher:
         self.gen = torch.Generator(device=dev)
         self.gen.manual_seed(seed)
         self._idx32 = torch.zeros(batch_size, dtype=torch.int32, device=dev)
+        assert generator in ('device', 'cpu') and (generator == 'device' or mode == 'sampler')
+        self.cpu_stream = generator == 'cpu'
         if mode == 'sampler':
             self.weights = w.float()
+            self.weights_cpu = torch.as_tensor(weights, dtype=torch.float64).cpu().reshape(-1)
             self.hx32, self.hy32 = hx.to(torch.int32).contiguous(), hy.to(torch.int32).contiguous()
+            self._pending = None          # (cpu stream) rows of the current epoch not handed out yet
 
     @property
     def dataset(self):
@@ -202,7 +211,13 @@ class DeviceBatcher:
         p.feed_active = True
         if self.mode == 'sampler':
             # WeightedRandomSampler: i.i.d. draws over ALL rows; DataLoader(drop_last): consecutive full batches
-            draws = torch.multinomial(self.weights, n_b * self.batch_size, replacement=True, generator=self.gen)
+            if self.cpu_stream:
+                rows = []
+                while sum(len(r) for r in rows) < n_b:
+                    rows.append(self._reference_epoch())
+                draws = torch.cat(rows)[:n_b].to(fd.table.device)
+            else:
+                draws = torch.multinomial(self.weights, n_b * self.batch_size, replacement=True, generator=self.gen)
             fd.table.copy_(draws.reshape(n_b, self.batch_size))
             fd.base.copy_(eng.step_dev)
             return fd.table
@@ -212,7 +227,22 @@ class DeviceBatcher:
         fd.base.copy_(eng.step_dev)         # device to device: batch index = optimiser step - base
         return fd.table
 
+    def _reference_epoch(self):
+        """(len(self), batch_size) int64 on the host: one epoch of the reference's loader, drawn from torch's default
+        CPU generator in the reference's order (src/run_drvae.py:150-162 on torch.utils.data): the DataLoader iterator
+        takes its base seed first, the sampler then draws len(dataset) rows at once; the incomplete last batch is
+        dropped"""
+        torch.empty((), dtype=torch.int64).random_()
+        draws = torch.multinomial(self.weights_cpu, len(self.weights_cpu), True)
+        n_b = len(self)
+        return draws[:n_b * self.batch_size].reshape(n_b, self.batch_size)
+
     def next_indices(self):
+        if self.mode == 'sampler' and self.cpu_stream:
+            if self._pending is None or len(self._pending) == 0:
+                self._pending = self._reference_epoch()
+            idx, self._pending = self._pending[0], self._pending[1:]
+            return idx.to(self.ds.x1.device)
         if self.mode == 'sampler':
             return torch.multinomial(self.weights, self.batch_size, replacement=True, generator=self.gen)
         parts = [m[torch.multinomial(w, c, replacement=True, generator=self.gen)]

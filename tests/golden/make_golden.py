@@ -574,10 +574,14 @@ def run_sampler_cases():
         loader = DataLoader(ds, batch_size=c['batch_size'], drop_last=(len(ds) >= c['batch_size']), sampler=sampler)
         hist = np.zeros(int(cid.max()) + 1, np.int64)
         sizes = set()
-        for _ in range(c['epochs']):
+        for ep in range(c['epochs']):
+            table = []
             for (idx,) in loader:
                 sizes.add(len(idx))
                 np.add.at(hist, cid[idx.numpy()], 1)
+                table.append(idx.numpy().astype(np.int64))
+            if ep < 2:          # the index stream itself: batches of the first two epochs after torch.manual_seed(1234)
+                out['%s/epoch%d_idx' % (tag, ep)] = np.stack(table)
         out[tag + '/weights'] = w.numpy().astype(np.float64)
         out[tag + '/n_batches'] = np.int64(len(loader))
         out[tag + '/batch_rows'] = np.asarray(sorted(sizes), np.int64)

@@ -96,6 +96,30 @@ def test_sampler_mode_matches_reference_pipeline(tag):
     np.testing.assert_allclose(p, 1.0 / ncls, rtol=1e-9)
 
 
+@pytest.mark.parametrize('tag', list(C.sampler_cases()))
+def test_cpu_generator_reproduces_the_reference_index_stream(tag):
+    """N2, DeviceBatcher(mode='sampler', generator='cpu'): under torch.manual_seed the epoch tables equal, bit for bit,
+    the batches the reference's DataLoader + WeightedRandomSampler pipeline yielded (first two epochs recorded in
+    tests/golden/sampler.npz by tests/golden/make_golden.py) -- through begin_epoch (graph-resident feed) and through
+    next_indices (host-driven feed) alike"""
+    G = C.load('sampler')
+    c = C.sampler_cases()[tag]
+    cid, n = c['cid'], len(c['cid'])
+    w = D.compute_balanced_weights(cid)
+    ds = D.DrVAEDataset(torch.zeros(n, 3), torch.zeros(n, 3), torch.zeros(n, dtype=torch.int64), torch.zeros(n, 1, dtype=torch.int64),
+                        torch.from_numpy((np.arange(n) % 2).astype(np.int32)), torch.from_numpy((np.arange(n) % 3 == 0).astype(np.int32)))
+    want = [G['%s/epoch%d_idx' % (tag, e)] for e in range(2)]
+    bat = D.DeviceBatcher(ds, w, c['batch_size'], seed=5, mode='sampler', generator='cpu')
+    torch.manual_seed(1234)
+    for e in range(2):
+        got = bat._reference_epoch().numpy()
+        np.testing.assert_array_equal(got, want[e])
+    torch.manual_seed(1234)
+    bat2 = D.DeviceBatcher(ds, w, c['batch_size'], seed=5, mode='sampler', generator='cpu')
+    stream = np.stack([bat2.next_indices().numpy() for _ in range(2 * len(bat2))])
+    np.testing.assert_array_equal(stream, np.concatenate(want))
+
+
 def test_sampler_mode_epoch_table(monkeypatch):
     """the epoch's index table of mode='sampler': len(dataset) // batch rows of i.i.d. draws over ALL rows (any group
     mix per batch), one batch-independent plan bound to the engine"""
