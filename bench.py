@@ -316,6 +316,40 @@ def gemm_roofline(eng, cfg, rows, frac_pair, frac_lab, repeats=20, workload='cfg
     return out
 
 
+class _Watchdog:
+    """multi-rank runs: a daemon thread that ends THIS rank (exit code 5) when the measurement makes no progress for
+    ``timeout`` seconds -- a peer that died inside a collective, a hung exchange -- so that the launcher (torchrun, or
+    ``self_launch``) sees a failure instead of a job that never ends"""
+
+    def __init__(self):
+        self.t = None
+        self.beat = time.time()
+
+    def start(self, timeout, rank):
+        import threading
+        self.beat = time.time()
+        self.on = True
+
+        def run():
+            while self.on:
+                time.sleep(1.0)
+                if time.time() - self.beat > timeout:
+                    print('bench.py: rank %d made no progress for %.0f s: giving up' % (rank, timeout), file=sys.stderr,
+                          flush=True)
+                    os._exit(5)
+        self.t = threading.Thread(target=run, daemon=True)
+        self.t.start()
+
+    def kick(self):
+        self.beat = time.time()
+
+    def stop(self):
+        self.on = False
+
+
+_WATCHDOG = _Watchdog()
+
+
 def measure(args, workload, feed, steps, warmup, device, rank, world, steady_s=0.0, exchange_probe=False):
     """Build the workload, capture its train step and time exactly ``steps`` replays (barrier + synchronize on both
     sides, MAX over ranks); with ``steady_s`` a second, longer region of about that many seconds is timed as well.
@@ -400,6 +434,7 @@ def measure(args, workload, feed, steps, warmup, device, rank, world, steady_s=0
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+        _WATCHDOG.kick()
 
     def over_ranks(dt):
         if world > 1:
@@ -538,6 +573,9 @@ def main():
     ap.add_argument('--no-extras', action='store_true',
                     help='skip the realistic-feed and other-workload measurements that follow the headline (cfg2 only)')
     ap.add_argument('--timeout', type=float, default=1500.0, help='self-launched ranks: seconds before they are ended')
+    ap.add_argument('--stall-timeout', type=float, default=300.0,
+                    help='multi-rank: a rank that makes no progress for this many seconds exits with code 5')
+    ap.add_argument('--fail-rank', type=int, default=-1, help='test hook: this rank exits (code 3) right after joining')
     args = ap.parse_args()
     if args.workload == 'cfg5':
         args.workload = 'wide'
@@ -555,13 +593,18 @@ def main():
     rank, world, local = D.init_from_env()
     if world != args.gpus and not (world == 1 and args.gpus == 1):
         raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
+    if args.fail_rank == rank and world > 1:
+        os._exit(3)              # (its peers now sit in their first collective: the launcher has to end them)
     local = local % torch.cuda.device_count()        # (one-GPU functional tests of the multi-rank path)
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
     import torch.distributed as dist
 
+    if world > 1:
+        _WATCHDOG.start(args.stall_timeout, rank)
     res, ctx = measure(args, args.workload, args.feed, args.steps, args.warmup, device, rank, world,
                        steady_s=0.0 if args.no_steady else 3.2, exchange_probe=True)
+    _WATCHDOG.stop()
     ok, dp = res['finite'], ctx['dp']
     out = {'metric': 'DrVAE ELBO training samples/sec (batch x L)', 'value': res['value'], 'unit': 'samples/s',
            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': res['ms_per_step'],

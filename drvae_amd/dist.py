@@ -24,6 +24,15 @@ def _active():
     return dist.is_initialized() and (dist.get_world_size() > 1 or force_dp())
 
 
+def _pg_timeout():
+    """bound of every collective (DRVAE_DIST_TIMEOUT seconds, default 180): a rank that never arrives must end the job
+    with a non-zero exit code, not hang it -- gloo raises in the blocked call, RCCL's watchdog thread tears the process
+    down (TORCH_NCCL_ASYNC_ERROR_HANDLING=1)"""
+    import datetime
+    os.environ.setdefault('TORCH_NCCL_ASYNC_ERROR_HANDLING', '1')
+    return datetime.timedelta(seconds=float(os.environ.get('DRVAE_DIST_TIMEOUT', '180')))
+
+
 def init_from_env(backend=None):
     """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun).  Returns
     (rank, world_size, local_rank); a no-op (0, 1, 0) for single-process runs."""
@@ -36,7 +45,8 @@ def init_from_env(backend=None):
             if torch.cuda.is_available():
                 torch.cuda.set_device(0)
             dist.init_process_group(backend=backend or os.environ.get('DRVAE_DIST_BACKEND') or
-                                    ('nccl' if torch.cuda.is_available() else 'gloo'), rank=0, world_size=1)
+                                    ('nccl' if torch.cuda.is_available() else 'gloo'), rank=0, world_size=1,
+                                    timeout=_pg_timeout())
         return 0, 1, 0
     if world <= 1:
         return 0, 1, 0
@@ -48,7 +58,7 @@ def init_from_env(backend=None):
     if backend == 'nccl':
         torch.cuda.set_device(local % max(torch.cuda.device_count(), 1))
     if not dist.is_initialized():
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=_pg_timeout())
     return rank, world, local
 
 

@@ -155,3 +155,49 @@ def test_bench_self_launch_two_ranks_one_gpu(dev):
     assert r['n_gpus'] == 2 and r['finite'] and r['config']['global_batch'] == 300
     assert r['config']['dist_backend'] == 'gloo' and r['config']['rccl_ranks'] == 0
     assert all(v == 0 for v in r['chain_wait_ticks'][0::2])
+
+
+def _bench_env():
+    e = dict(os.environ, DRVAE_DIST_BACKEND='gloo', DRVAE_SIDE_CUS='64')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT'):
+        e.pop(k, None)
+    return e
+
+
+def test_bench_self_launch_eight_ranks_one_gpu(dev):
+    """the launch path of the 8-GPU scaling run on the one-GPU box: ``python bench.py --gpus 8`` starts eight fresh
+    rank processes (a free port, RANK / LOCAL_RANK / WORLD_SIZE set, rank -> device modulo the devices present, gloo
+    since RCCL refuses two ranks per device), relays rank 0's single JSON line and exits 0"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '8', '--steps', '6', '--warmup', '2',
+                          '--no-cpu-baseline', '--no-roofline', '--no-steady', '--no-extras'], env=_bench_env(),
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, out.stdout
+    r = json.loads(lines[0])
+    assert r['n_gpus'] == 8 and r['finite'] and r['config']['global_batch'] == 1200 and r['scaling'] == 'weak'
+    assert r['config']['parallelism'] == 'dp8' and r['config']['dist_backend'] == 'gloo'
+    assert r['value'] == pytest.approx(1200 * 2 * 6 / (r['ms_per_step'] * 6e-3), rel=1e-3)      # whole-job samples/s
+    assert r['exchange'] is not None and r['exchange']['bytes'] > 9e6
+    assert all(v == 0 for v in r['chain_wait_ticks'][0::2])
+
+
+def test_bench_self_launch_ends_the_job_when_a_rank_dies(dev):
+    """a rank that dies (test hook --fail-rank) must end the whole job with a non-zero exit code well inside the
+    time-out: the launcher ends the surviving ranks (they sit in a collective that can never complete) -- plain child
+    processes, nothing is ever re-exec'ed"""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '4', '--steps', '6', '--warmup', '2',
+                          '--no-cpu-baseline', '--no-roofline', '--no-steady', '--no-extras', '--fail-rank', '2'],
+                         env=_bench_env(), capture_output=True, text=True, timeout=600)
+    assert out.returncode != 0
+    assert not [ln for ln in out.stdout.splitlines() if ln.startswith('{') and '"metric"' in ln]
+    assert time.time() - t0 < 300
