@@ -80,16 +80,21 @@ def rbf(x1, x2, gamma=1.):
     return torch.exp(-d2 * gamma).t()
 
 
-def mmd_criterion(z, sind, kernel='rbf_fourier'):
+def mmd_criterion(z, sind, kernel='rbf_fourier', pairs=None):
     """Minus the MMD (``mmd_objective`` with ``kernel``) between the latent rows of every category of the nuisance
     variable and the rows outside it, averaged over the categories; with two categories only the first pair
     (the body of src/DGMMixin.py:42-66).  ``sind``: one 0/1 indicator vector per category.  A side without rows is
-    replaced by one random N(0,1) row, like the reference."""
+    replaced by one random N(0,1) row, like the reference.  ``pairs``: the (rows in, rows out) index lists of the
+    categories when the caller has them already (``torch.nonzero`` synchronises with the host: not inside a hipGraph
+    capture)."""
     mmd = 0.
-    for ind in sind:
-        flat = ind.reshape(-1)
-        ind0 = torch.nonzero(flat != 0).reshape(-1)
-        ind1 = torch.nonzero(flat == 0).reshape(-1)
+    for k, ind in enumerate(sind):
+        if pairs is not None:
+            ind0, ind1 = pairs[k]
+        else:
+            flat = ind.reshape(-1)
+            ind0 = torch.nonzero(flat != 0).reshape(-1)
+            ind1 = torch.nonzero(flat == 0).reshape(-1)
         z0 = z.index_select(0, ind0) if ind0.numel() else torch.empty(1, z.size(1), device=z.device).normal_()
         z1 = z.index_select(0, ind1) if ind1.numel() else torch.empty(1, z.size(1), device=z.device).normal_()
         mmd = mmd - mmd_objective(z0, z1, kernel=kernel)

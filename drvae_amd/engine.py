@@ -714,16 +714,17 @@ class FusedStep(StepSchedule):
         the latent samples of each nuisance class and the rest, per data group and Monte-Carlo sample, on z1 and
         (pairs) z2.  A cross-row term: evaluated with the block-level MMD operators (``blocks.mmd_criterion`` -> the
         HIP MMD kernels, forward and backward) on the sample rows of the stacked decoder input; value -> the loss
-        tail, gradient -> ``DZMMD``, added to d/dz behind the decoder's backward pass.  Eager steps only."""
+        tail, gradient -> ``DZMMD``, added to d/dz behind the decoder's backward pass.  Capturable: the row lists of
+        every category are plan data (``_Plan.set_s_host``), the random Fourier features come from torch's
+        graph-safe device generator; a captured step is valid for the composition of nuisance classes it was
+        captured with (``replay`` checks)."""
         cfg, p = self.cfg, self.plan
-        if p.ZDEC.is_cuda and torch.cuda.is_current_stream_capturing():
-            raise NotImplementedError('use_MMD: the model-level MMD penalty runs in eager train steps only')
         from . import blocks as blk
         with torch.enable_grad():
             z = p.ZDEC[:p.o3].detach().clone().requires_grad_(True)
             total = z.new_zeros(())
-            for rows, sind in p.mmd_calls:
-                total = total + blk.mmd_criterion(z.index_select(0, rows), sind, cfg.kernel_MMD) / cfg.L
+            for rows, sind, pairs in p.mmd_calls:
+                total = total + blk.mmd_criterion(z.index_select(0, rows), sind, cfg.kernel_MMD, pairs=pairs) / cfg.L
             total.backward()
         p.MMDval.copy_(total.detach().reshape(1))
         # CMPL = ... - mmd_rate * MMD_sum / N_total  (src/DrVAE.py:616,623-624)

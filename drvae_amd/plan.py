@@ -262,10 +262,15 @@ class _Plan:
                 if len(idx) == 0:
                     continue
                 sind = [torch.as_tensor((sv[idx] == k).astype(np.int64), device=dev) for k in range(cfg.dim_s)]
+                # (rows in / rows out of every category as index lists: host knowledge, so that the step itself
+                # needs no torch.nonzero -- it would synchronise, which a hipGraph capture cannot)
+                pairs = [(torch.as_tensor(np.nonzero(sv[idx] == k)[0], device=dev),
+                          torch.as_tensor(np.nonzero(sv[idx] != k)[0], device=dev)) for k in range(cfg.dim_s)]
                 for l in range(L):
-                    self.mmd_calls.append((torch.as_tensor(l * B + idx, device=dev), sind))
+                    self.mmd_calls.append((torch.as_tensor(l * B + idx, device=dev), sind, pairs))
                     if hx[idx[0]]:
-                        self.mmd_calls.append((torch.as_tensor(self.o2 + l * Np + slot[idx], device=dev), sind))
+                        self.mmd_calls.append((torch.as_tensor(self.o2 + l * Np + slot[idx], device=dev), sind, pairs))
+            self.mmd_sig = sv.tobytes()          # a captured step is valid for THIS composition of nuisance classes
 
     def set_labels_host(self, yv):
         """class labels of this batch's rows (host ints; only the labeled rows' entries matter)"""

@@ -112,9 +112,9 @@ class StepSchedule:
         no graph boundary, no host-side launch of the exchange."""
         self._captured_allreduce = allreduce if split_for_allreduce == 'captured' else None
         assert self.plan is not None, 'set_batch first'
-        if self.plan.DZMMD is not None:
-            raise NotImplementedError('use_MMD: the model-level MMD penalty (a cross-row term evaluated through the '
-                                      'block-level MMD operators) runs in eager train steps only')
+        if self.plan.DZMMD is not None and split_for_allreduce:
+            raise NotImplementedError('use_MMD: the model-level MMD penalty is a cross-row term (every row of a nuisance '
+                                      'class against every other row): it cannot be sharded over ranks')
         self.training = True
         self.plan.set_beta(self.beta_pert())
         side = torch.cuda.Stream()
@@ -128,7 +128,10 @@ class StepSchedule:
         torch.cuda.synchronize()
         self._graphs = []
         self._side_graph = None
-        dual = self.sched == 5 and self.branch.on and self.cfg.has_y and self._flags_usable()
+        # two flag-ordered graphs only for the latency-bound steps: once the decoder products alone fill the chip many
+        # times over (wide configuration) the side chain's small kernels, squeezed in between the resident GEMM
+        # workgroups of a second queue, cost more than they hide (36.7 ms dual, 35.9 ms as one graph with a fork/join)
+        dual = self.sched == 5 and self.branch.on and self.cfg.has_y and self._latency_bound() and self._flags_usable()
         self._split_capture = bool(split_for_allreduce)
         self._split_kind = split_for_allreduce          # False | True (two graphs) | 'overlap' | 'captured'
         cfg = self.cfg
@@ -165,13 +168,18 @@ class StepSchedule:
                 gc.enable()
         self._graph_key = self.plan.key
         self._graph_feed = self.plan.live_feed
+        self._graph_mmd_sig = getattr(self.plan, 'mmd_sig', None)
         return self
 
     # ------------------------------------------------------------ CU partition
+    def _latency_bound(self):
+        """the step's big products do not fill the chip many times over (<= 4 M elements of decoder output)"""
+        return self.plan is not None and self.plan.DPX.shape[0] * self.plan.DPX.shape[1] <= (4 << 20)
+
     def _partition_applicable(self):
         # only for latency-bound steps: once the decoder products alone fill the chip many times over
         # (wide configuration) the main chain needs every CU (measured: 52 ms -> 66 ms/step when masked)
-        small = self.plan is not None and self.plan.DPX.shape[0] * self.plan.DPX.shape[1] <= (4 << 20)
+        small = self._latency_bound()
         return bool(self.branch.on and self.sched == 5 and self.cfg.has_y and small and
                     int(os.environ.get('DRVAE_SIDE_CUS', '64')) > 0)
 
@@ -406,6 +414,8 @@ class StepSchedule:
         """One captured train step.  New data is fed by copying into plan.x1 / plan.x2 in place."""
         assert self._graph_key == self.plan.key, 'batch structure changed: capture again'
         assert self._graph_feed is self.plan.live_feed, 'input source changed (epoch feed <-> explicit batch): capture again'
+        assert getattr(self, '_graph_mmd_sig', None) == getattr(self.plan, 'mmd_sig', None), \
+            'use_MMD: the nuisance classes of the batch changed (the penalty compares row sets): capture again'
         self.plan.set_beta(self.beta_pert())      # 0.01 on iteration 0, 1.0 afterwards (device-side coefficients)
         if self.noise_ahead and self._noise_stale:        # first replay (or an eager draw since): this step's noise
             K.fill_normal_rows(self.plan.noise, self.plan.noise_desc, self.seed, self.rng_ctr)

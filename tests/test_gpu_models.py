@@ -450,14 +450,26 @@ def test_use_s_extension_matches_oracle_gpu(kind, use_mmd, dev):
             np.testing.assert_allclose(v, float(want[k].detach()), rtol=1e-4, atol=2e-5)
     for k, prm in tr.params.items():
         np.testing.assert_allclose(arena.p(k).cpu().numpy(), prm.detach().numpy(), rtol=2e-4, atol=5e-5)
-    if use_mmd:
-        with pytest.raises(NotImplementedError):
-            eng.capture()
-    else:
-        eng.capture()                      # conditioning alone is part of the captured step
-        eng.replay()
-        torch.cuda.synchronize()
-        assert all(np.isfinite(v) for v in eng.losses().values())
+    # the captured step (conditioning AND the cross-row MMD penalty: its row lists are plan data) == eager launches
+    twin, arena2 = make_engine(spec, params, dev)
+    twin.set_batch(t('x1'), t('x2'), batch['y'], batch['has_x2'], batch['has_y'], s=batch['s'])
+    twin.iters = eng.iters
+    for dst, src in ((arena2.param, arena.param), (arena2.exp_avg, arena.exp_avg), (arena2.exp_avg_sq, arena.exp_avg_sq),
+                     (twin.step_dev, eng.step_dev), (twin.rng_ctr, eng.rng_ctr), (twin.side_ctr, eng.side_ctr),
+                     (twin.side_t, eng.side_t)):
+        dst.copy_(src)
+    twin.capture()
+    for _ in range(3):
+        eng.train_step()
+        twin.replay()
+    torch.cuda.synchronize()
+    twin.check_sync()
+    assert torch.equal(arena.param, arena2.param)
+    assert eng.losses() == twin.losses() and all(np.isfinite(v) for v in eng.losses().values())
+    if use_mmd:                             # another composition of nuisance classes: the captured row lists are stale
+        twin.plan.set_s_host(1 - np.asarray(batch['s']).reshape(-1)[twin.plan.rows])
+        with pytest.raises(AssertionError, match='capture again'):
+            twin.replay()
 
 
 def test_use_s_model_api_with_fourier_mmd(dev):
