@@ -177,9 +177,10 @@ class DeviceBatcher:
     def bind(self, engine, counts=None):
         """build / select the step plan for this batcher's fixed batch structure"""
         self.engine = engine
-        if engine.cfg.use_s:
-            raise NotImplementedError('DeviceBatcher: models conditioned on the nuisance variable (use_s extension) are '
-                                      'fed through run_on_batch / a tuple loader')
+        if engine.cfg.use_s and (engine.cfg.use_MMD or self.mode == 'sampler'):
+            raise NotImplementedError('DeviceBatcher: models conditioned on the nuisance variable (use_s extension) run on '
+                                      'stratified device batches without the MMD penalty (its row lists are host knowledge); '
+                                      'otherwise feed them through run_on_batch / a tuple loader')
         if self.mode == 'sampler':
             assert counts is None, 'the exact sampler composes batches per rank: use mode="stratified" under data parallelism'
             engine.universal = True
@@ -193,6 +194,8 @@ class DeviceBatcher:
         gathers its own minibatch (``dv_batch_feed``), i.e. an epoch is ``len(self)`` graph replays
         with no other host work.  Returns the table (n_batches, batch_size) int32."""
         eng, p = self.engine, self.engine.plan
+        if eng.cfg.use_s:
+            raise NotImplementedError('use_s: the graph-resident epoch feed does not carry the nuisance classes; use feed()')
         n_b = len(self) if n_batches is None else n_batches
         fd = p.feed
         if fd is None or fd.owner is not self or fd.n_batches != n_b:
@@ -258,6 +261,8 @@ class DeviceBatcher:
         K.rows_gather(p.XSRC[:p.B], self.ds.x1, self._idx32)
         if self.engine.cfg.has_pert:
             K.rows_gather(p.XSRC[p.B:], self.ds.x2, self._idx32)
+        if self.engine.cfg.use_s:           # one-hot(s) columns of the encoder / decoder inputs (device to device)
+            p.set_s_device(self.ds.s.reshape(-1)[idx])
         if self.mode == 'sampler':          # group membership of THIS batch: data for dv_batch_masks
             if self.engine.cfg.has_pert:
                 p.hx_dev.copy_(self.hx32[idx])

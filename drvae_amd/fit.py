@@ -222,7 +222,7 @@ class FitMixin:
         batcher.bind(eng, counts=getattr(self, '_global_counts', None))
         eng.add_noise = bool(self.add_noise)
         eng.iters = self.finished_training_iters
-        resident_feed = True
+        resident_feed = not eng.cfg.use_s      # (the nuisance classes travel with host-driven gathers: feed())
         if resident_feed:
             batcher.begin_epoch()           # this epoch's index table; the graph gathers batch b itself
         else:

@@ -272,6 +272,20 @@ class _Plan:
                         self.mmd_calls.append((torch.as_tensor(self.o2 + l * Np + slot[idx], device=dev), sind, pairs))
             self.mmd_sig = sv.tobytes()          # a captured step is valid for THIS composition of nuisance classes
 
+    def set_s_device(self, s_dev):
+        """nuisance classes of this batch's rows from a DEVICE tensor (``DeviceBatcher.feed``: rows drawn on the device):
+        the one-hot columns of the stacked encoder / decoder rows are rebuilt device to device, no host round trip.
+        Not with the model-level MMD penalty, whose row lists are host knowledge (``set_s_host``)."""
+        cfg = self._cfg
+        assert not cfg.use_MMD, 'use_MMD: the penalty needs the nuisance classes on the host (set_s_host)'
+        L = cfg.L
+        sv = s_dev.reshape(-1).to(torch.int32)
+        sp = sv.index_select(0, self.pair_idx.long()) if self.Np else sv[:0]
+        self.s_enc.copy_(torch.cat([sv, sp]))
+        self.s_dec.copy_(torch.cat([sv.repeat(L), sp.repeat(L), sp.repeat(L)]))
+        K.rows_gather(self.SOHe, None, None, onehot_cls=self.s_enc, n_classes=cfg.dim_s, width=0)
+        K.rows_gather(self.SOHd, None, None, onehot_cls=self.s_dec, n_classes=cfg.dim_s, width=0)
+
     def set_labels_host(self, yv):
         """class labels of this batch's rows (host ints; only the labeled rows' entries matter)"""
         cfg = self._cfg

@@ -223,6 +223,39 @@ def test_device_batcher_feeds_one_captured_graph(dev):
     assert eager.losses() == fed.losses()
 
 
+def test_device_batcher_feeds_nuisance_conditioned_models(dev):
+    """N4 + N2: a ``use_s`` model on device-drawn batches -- the one-hot(s) columns of the encoder / decoder inputs are
+    rebuilt device to device by ``DeviceBatcher.feed`` -- through ONE captured graph == eager steps fed the same rows
+    and nuisance classes from the host"""
+    from drvae_amd import data as D
+    from tests.test_engine_cpu import make_engine
+    spec = C.tiny_spec('drvae', use_s=True, dim_s=2)
+    params = M.init_params(spec, 3, as_numpy=True)
+    big = M.make_batch(spec, 400, seed=9)
+    t = lambda k: torch.from_numpy(big[k].copy())
+    ds = D.DrVAEDataset(t('x1'), t('x2'), t('s'), t('y'), t('has_x2'), t('has_y')).to(dev)
+    bat = D.DeviceBatcher(ds, D.compute_balanced_weights(np.arange(400) % 7), 24, seed=5)
+    fed, a1 = make_engine(spec, params, dev)
+    eager, a0 = make_engine(spec, params, dev)
+    bat.bind(fed)
+    idxs = [bat.next_indices() for _ in range(5)]
+    bat.feed(idxs[0])
+    fed.train_step()
+    fed.capture()
+    for i in idxs[1:]:
+        bat.feed(i)
+        fed.replay()
+    for i in idxs:
+        eager.set_batch(ds.x1[i], ds.x2[i], ds.y[i].cpu(), bat.has_x2, bat.has_y, s=ds.s[i].cpu())
+        eager.train_step()
+    torch.cuda.synchronize()
+    assert len({int(v) for i in idxs for v in ds.s.reshape(-1)[i].tolist()}) == 2      # both classes occur
+    assert torch.equal(a0.param, a1.param)
+    assert eager.losses() == fed.losses()
+    with pytest.raises(NotImplementedError):
+        bat.begin_epoch()
+
+
 @pytest.mark.parametrize('kind', ['drvae', 'pvae', 'vfae'])
 def test_graph_resident_epoch_feed(kind, dev):
     """N2/N3: the epoch's index table lives on the device and the captured step gathers batch
