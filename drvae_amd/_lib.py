@@ -74,6 +74,9 @@ SIGNATURES = {
     'dv_gemm_pair': [C.POINTER(GemmDesc), C.POINTER(GemmDesc), _p],
     'dv_gemm_heads': [C.POINTER(GemmDesc), C.POINTER(HeadsEpi), _p],
     'dv_gemm_heads_tiles': [_i32],
+    'dv_bn_fwd': [_p, _i64, _i32, _i32, _p, _p, _f, _p, _p, _p, _i64, _p, _p, _f, _i32, _p],
+    'dv_bn_bwd': [_p, _i64, _p, _i64, _p, _p, _p, _i32, _i32, _p, _i64, _p, _p, _i32, _p],
+    'dv_mask_scale': [_p, _i64, _p, _i64, _f, _i32, _i32, _p, _i64, _p],
     'dv_gemm_force_tiling': [_i32],
     'dv_gemm_set_option': [_i32, _i32],
     'dv_colsum': [_p, _i64, _i32, _i32, _p, _f, _p],
@@ -139,7 +142,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 3     # DV_ABI_VERSION of include/drvae_hip.h
+ABI_VERSION = 4     # DV_ABI_VERSION of include/drvae_hip.h
 
 
 def load():

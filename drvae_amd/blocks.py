@@ -154,6 +154,40 @@ def one_hot(y, max_dim):
     return out
 
 
+def _keep_mask_like(t, keep):
+    """Bernoulli(keep) 0/1 mask, drawn on the tensor's device from torch's generator (tests inject the reference's)"""
+    return torch.empty_like(t, memory_format=torch.contiguous_format).bernoulli_(keep)
+
+
+class BatchNorm1d(nn.BatchNorm1d):
+    """``nn.BatchNorm1d`` of the reference's MLP (src/blocks.py:137-149: ``bn_input`` / ``bn{i}``, affine, momentum 0.1,
+    eps 1e-5) with forward and backward on the HIP kernels; state_dict keys and running-statistics semantics are the
+    parent's (incl. ``num_batches_tracked``)."""
+
+    def forward(self, x):
+        if x.dim() != 2 or self.momentum is None or not self.affine or not self.track_running_stats:
+            raise NotImplementedError('BatchNorm1d: (rows, features) input, affine, tracked statistics, fixed momentum')
+        if self.training:
+            if x.shape[0] < 2:      # (torch: "Expected more than 1 value per channel when training")
+                raise ValueError('Expected more than 1 value per channel when training, got input size %s' % (tuple(x.shape),))
+            self.num_batches_tracked.add_(1)
+        return ops.batch_norm(x, self.weight, self.bias, self.running_mean, self.running_var, self.training,
+                              self.momentum, self.eps)
+
+
+class Dropout(nn.Dropout):
+    """``nn.Dropout`` between hidden layers of the reference's MLP (src/blocks.py:140-141): keep mask drawn on the
+    device, applied (forward and backward) by ``dv_mask_scale``; identity in eval mode."""
+
+    def forward(self, x):
+        if not self.training or self.p == 0.:
+            return x
+        keep = 1.0 - self.p
+        if keep <= 0.:
+            return x * 0.
+        return ops.dropout(x, _keep_mask_like(x, keep), keep)
+
+
 # -------------------------------------------------------------------------------- MLP
 class MLP(nn.Module):
     """Deterministic MLP over the concatenation of its inputs, returning the last hidden
@@ -178,14 +212,14 @@ class MLP(nn.Module):
         mods = OrderedDict()
         width = int(np.asarray(input_dims).sum())
         if batch_norm:
-            mods['bn_input'] = nn.BatchNorm1d(width, affine=True)
+            mods['bn_input'] = BatchNorm1d(width, affine=True)
         for i, h in enumerate(hidden_dims, start=1):
             if i > 1 and dropout_rate > 0.:
-                mods['dropout%d' % i] = nn.Dropout(p=dropout_rate)
+                mods['dropout%d' % i] = Dropout(p=dropout_rate)
             mods['linear%d' % i] = make(width, h)
             mods['activ%d' % i] = nonlinearities[nonlin]
             if batch_norm:
-                mods['bn%d' % i] = nn.BatchNorm1d(h, affine=True)
+                mods['bn%d' % i] = BatchNorm1d(h, affine=True)
             width = h
         self.model = nn.Sequential(mods)
 
@@ -265,7 +299,7 @@ class GaussianSigmaMixin(_DiagGaussianOps):
 def _head(suffix, make, n_in, n_out, dropout_rate, activation=None):
     mods = OrderedDict()
     if dropout_rate > 0.:
-        mods['dropout_' + suffix] = nn.Dropout(p=dropout_rate)
+        mods['dropout_' + suffix] = Dropout(p=dropout_rate)
     mods['linear_' + suffix] = make(n_in, n_out)
     if activation is not None:
         mods['activ_' + suffix] = nonlinearities[activation]
@@ -382,7 +416,7 @@ class _SingleHeadDecoder(nn.Module):
         make = lyr.WeightNormLinear if weight_norm else nn.Linear
         mods = OrderedDict()
         if dropout_rate > 0.:
-            mods['dropout'] = nn.Dropout(p=dropout_rate)
+            mods['dropout'] = Dropout(p=dropout_rate)
         mods[self.lin] = make(_trunk_width(input_dims, hidden_dims), reconstruction_dim)
         setattr(self, self.head, nn.Sequential(mods))
 
@@ -444,7 +478,7 @@ class CategoricalDecoder(nn.Module):
         width = _trunk_width(input_dims, hidden_dims)
         mods = OrderedDict()
         if dropout_rate > 0.:
-            mods['dropout_p'] = nn.Dropout(p=dropout_rate)
+            mods['dropout_p'] = Dropout(p=dropout_rate)
         mods['linear_p'] = make(width, reconstruction_dim)
         mods['activ_p'] = nn.Softmax(dim=-1) if reconstruction_dim > 1 else nn.Sigmoid()
         self.decoder_p = nn.Sequential(mods)

@@ -1362,6 +1362,114 @@ __global__ __launch_bounds__(256) void col_moments_kernel(const float* __restric
             out[(int64_t)k * X + g] = (part[0][k][c] + part[1][k][c]) + (part[2][k][c] + part[3][k][c]);
 }
 
+// ---------------------------------------------------------------------- BatchNorm1d / Dropout (blocks.MLP options)
+// nn.BatchNorm1d(affine=True) over the rows of x (M, N) (src/blocks.py:137-149): one workgroup per 64 columns,
+// 4 row groups; training: batch mean and biased variance (two passes: mean, then sum of squared deviations), the
+// running statistics move by `momentum` (running_var takes the UNBIASED variance, like torch); eval: the running
+// statistics.  mean / rstd of the batch are kept for the backward pass.
+__global__ __launch_bounds__(256) void bn_fwd_kernel(const float* __restrict__ x, int64_t ldx, int M, int N,
+                                                     const float* __restrict__ w, const float* __restrict__ b, float eps,
+                                                     float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                     float* __restrict__ y, int64_t ldy, float* __restrict__ rmean,
+                                                     float* __restrict__ rvar, float momentum, int training) {
+    __shared__ float part[4][64];
+    __shared__ float stat[2][64];
+    const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int g = blockIdx.x * 64 + c;
+    const bool ok = g < N;
+    if (training) {
+        float s = 0.f;
+        if (ok)
+            for (int i = rg; i < M; i += 4) s += x[(int64_t)i * ldx + g];
+        part[rg][c] = s;
+        __syncthreads();
+        if (rg == 0) stat[0][c] = ((part[0][c] + part[1][c]) + (part[2][c] + part[3][c])) / (float)M;
+        __syncthreads();
+        const float mu = stat[0][c];
+        float q = 0.f;
+        if (ok)
+            for (int i = rg; i < M; i += 4) {
+                const float d = x[(int64_t)i * ldx + g] - mu;
+                q += d * d;
+            }
+        __syncthreads();
+        part[rg][c] = q;
+        __syncthreads();
+        if (rg == 0) {
+            const float var = ((part[0][c] + part[1][c]) + (part[2][c] + part[3][c])) / (float)M;
+            stat[1][c] = 1.f / sqrtf(var + eps);
+            if (ok) {
+                mean_out[g] = mu;
+                rstd_out[g] = stat[1][c];
+                if (rmean) rmean[g] = (1.f - momentum) * rmean[g] + momentum * mu;
+                if (rvar) rvar[g] = (1.f - momentum) * rvar[g] + momentum * (M > 1 ? var * (float)M / (float)(M - 1) : var);
+            }
+        }
+        __syncthreads();
+    } else {
+        if (rg == 0) {
+            stat[0][c] = ok ? rmean[g] : 0.f;
+            stat[1][c] = ok ? 1.f / sqrtf(rvar[g] + eps) : 0.f;
+            if (ok) {
+                mean_out[g] = stat[0][c];
+                rstd_out[g] = stat[1][c];
+            }
+        }
+        __syncthreads();
+    }
+    if (ok) {
+        const float mu = stat[0][c], rs = stat[1][c], ww = w ? w[g] : 1.f, bb = b ? b[g] : 0.f;
+        for (int i = rg; i < M; i += 4) y[(int64_t)i * ldy + g] = (x[(int64_t)i * ldx + g] - mu) * rs * ww + bb;
+    }
+}
+
+// backward: dw = sum dy*xhat, db = sum dy; training: dx = w*rstd*(dy - db/M - xhat*dw/M); eval: dx = dy*w*rstd
+__global__ __launch_bounds__(256) void bn_bwd_kernel(const float* __restrict__ dy, int64_t ldd, const float* __restrict__ x,
+                                                     int64_t ldx, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, const float* __restrict__ w, int M,
+                                                     int N, float* __restrict__ dx, int64_t lddx, float* __restrict__ dw,
+                                                     float* __restrict__ db, int training) {
+    __shared__ float p1[4][64], p2[4][64];
+    const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int g = blockIdx.x * 64 + c;
+    const bool ok = g < N;
+    const float mu = ok ? mean[g] : 0.f, rs = ok ? rstd[g] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+    if (ok)
+        for (int i = rg; i < M; i += 4) {
+            const float d = dy[(int64_t)i * ldd + g];
+            s1 += d;
+            s2 += d * ((x[(int64_t)i * ldx + g] - mu) * rs);
+        }
+    p1[rg][c] = s1;
+    p2[rg][c] = s2;
+    __syncthreads();
+    const float sd = (p1[0][c] + p1[1][c]) + (p1[2][c] + p1[3][c]);
+    const float sx = (p2[0][c] + p2[1][c]) + (p2[2][c] + p2[3][c]);
+    if (!ok) return;
+    if (rg == 0) {
+        if (dw) dw[g] = sx;
+        if (db) db[g] = sd;
+    }
+    if (dx == nullptr) return;
+    const float ww = w ? w[g] : 1.f, im = 1.f / (float)M;
+    for (int i = rg; i < M; i += 4) {
+        const float d = dy[(int64_t)i * ldd + g];
+        const float xh = (x[(int64_t)i * ldx + g] - mu) * rs;
+        dx[(int64_t)i * lddx + g] = training ? ww * rs * (d - sd * im - xh * sx * im) : d * ww * rs;
+    }
+}
+
+// y = x * mask * scale (nn.Dropout forward with its keep mask, and its backward: the same map on dy)
+__global__ void mask_scale_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ mask, int64_t ldm,
+                                  float scale, int M, int N, float* __restrict__ y, int64_t ldy) {
+    const int64_t total = (int64_t)M * N;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = e / N, j = e - i * N;
+        y[i * ldy + j] = x[i * ldx + j] * mask[i * ldm + j] * scale;
+    }
+}
+
 struct LossTerms {
     dv_loss_term t[DV_MAX_LOSS_TERMS];
     int n;
@@ -1994,6 +2102,35 @@ extern "C" int dv_col_moments(const float* x, int64_t ldx, const float* r, int64
     DV_REQUIRE(M >= 0 && X >= 1);
     DV_REQUIRE(x && r && out);
     hipLaunchKernelGGL(col_moments_kernel, dim3((X + 63) / 64), dim3(256), 0, ST(stream), x, ldx, r, ldr, M, X, out);
+    DV_RETURN_LAUNCH();
+}
+
+extern "C" int dv_bn_fwd(const float* x, int64_t ldx, int32_t M, int32_t N, const float* w, const float* b, float eps,
+                         float* mean_out, float* rstd_out, float* y, int64_t ldy, float* running_mean,
+                         float* running_var, float momentum, int32_t training, dv_stream_t stream) {
+    DV_REQUIRE(M >= 1 && N >= 1 && x && y && mean_out && rstd_out && eps >= 0.f);
+    DV_REQUIRE(training || (running_mean && running_var));
+    hipLaunchKernelGGL(bn_fwd_kernel, dim3((N + 63) / 64), dim3(256), 0, ST(stream), x, ldx, M, N, w, b, eps, mean_out,
+                       rstd_out, y, ldy, running_mean, running_var, momentum, training);
+    DV_RETURN_LAUNCH();
+}
+
+extern "C" int dv_bn_bwd(const float* dy, int64_t ldd, const float* x, int64_t ldx, const float* mean, const float* rstd,
+                         const float* w, int32_t M, int32_t N, float* dx, int64_t lddx, float* dw, float* db,
+                         int32_t training, dv_stream_t stream) {
+    DV_REQUIRE(M >= 1 && N >= 1 && dy && x && mean && rstd);
+    hipLaunchKernelGGL(bn_bwd_kernel, dim3((N + 63) / 64), dim3(256), 0, ST(stream), dy, ldd, x, ldx, mean, rstd, w, M, N,
+                       dx, lddx, dw, db, training);
+    DV_RETURN_LAUNCH();
+}
+
+extern "C" int dv_mask_scale(const float* x, int64_t ldx, const float* mask, int64_t ldm, float scale, int32_t M,
+                             int32_t N, float* y, int64_t ldy, dv_stream_t stream) {
+    DV_REQUIRE(M >= 0 && N >= 0);
+    if (M == 0 || N == 0) return DV_OK;
+    DV_REQUIRE(x && mask && y);
+    hipLaunchKernelGGL(mask_scale_kernel, dim3(grid_for((int64_t)M * N, 256)), dim3(256), 0, ST(stream), x, ldx, mask,
+                       ldm, scale, M, N, y, ldy);
     DV_RETURN_LAUNCH();
 }
 

@@ -161,6 +161,26 @@ def linear_bwd_weight(dW, dpre, x, *, beta=0.0, dbias=None, overread=False):
     gemm(dW, dpre, x, False, False, beta=beta, a_colsum=dbias, colsum_beta=beta, overread=overread)
 
 
+def bn_fwd(y, x, w, b, mean, rstd, running_mean, running_var, eps=1e-5, momentum=0.1, training=True):
+    """nn.BatchNorm1d forward over the rows of x, see ``dv_bn_fwd`` (mean / rstd: saved for the backward pass)"""
+    M, N = x.shape
+    _lib.check(_lib.load().dv_bn_fwd(_f32(x), _ld(x), M, N, _f32(w), _f32(b), eps, _f32(mean), _f32(rstd), _f32(y), _ld(y),
+                                     _f32(running_mean), _f32(running_var), momentum, int(bool(training)), _stream()),
+               'dv_bn_fwd')
+
+
+def bn_bwd(dx, dw, db, dy, x, mean, rstd, w, training=True):
+    M, N = x.shape
+    _lib.check(_lib.load().dv_bn_bwd(_f32(dy), _ld(dy), _f32(x), _ld(x), _f32(mean), _f32(rstd), _f32(w), M, N, _f32(dx),
+                                     _ld(dx), _f32(dw), _f32(db), int(bool(training)), _stream()), 'dv_bn_bwd')
+
+
+def mask_scale(y, x, mask, scale):
+    M, N = x.shape
+    _lib.check(_lib.load().dv_mask_scale(_f32(x), _ld(x), _f32(mask), _ld(mask), scale, M, N, _f32(y), _ld(y), _stream()),
+               'dv_mask_scale')
+
+
 def colsum(out, X, beta=0.0):
     M, N = X.shape
     _lib.check(_lib.load().dv_colsum(_f32(X), _ld(X), M, N, _f32(out), beta, _stream()), 'dv_colsum')

@@ -310,3 +310,58 @@ def cat_most_probable(probs):
     best = torch.empty(probs.shape[0], dtype=torch.int32, device=probs.device)
     K.cat_terms_fwd(probs, best=best)
     return best.long()
+
+
+class _BatchNorm(torch.autograd.Function):
+    """nn.BatchNorm1d(affine=True) forward / backward on the HIP kernels (``dv_bn_fwd`` / ``dv_bn_bwd``); the
+    running statistics are updated in place by the forward launch when training."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps):
+        x = _c(x)
+        M, N = x.shape
+        y = torch.empty(M, N, device=x.device, dtype=torch.float32)
+        mean, rstd = torch.empty(N, device=x.device), torch.empty(N, device=x.device)
+        K.bn_fwd(y, x, weight, bias, mean, rstd, running_mean, running_var, eps=eps, momentum=momentum, training=training)
+        ctx.save_for_backward(x, weight, mean, rstd)
+        ctx.training = bool(training)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, mean, rstd = ctx.saved_tensors
+        dy = _c(dy)
+        N = x.shape[1]
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dw, db = torch.empty(N, device=x.device), torch.empty(N, device=x.device)
+        K.bn_bwd(dx, dw, db, dy, x, mean, rstd, weight, training=ctx.training)
+        return dx, dw, db, None, None, None, None, None
+
+
+def batch_norm(x, weight, bias, running_mean, running_var, training, momentum=0.1, eps=1e-5):
+    return _BatchNorm.apply(x, weight, bias, running_mean, running_var, training, momentum, eps)
+
+
+class _MaskScale(torch.autograd.Function):
+    """y = x * mask / keep: nn.Dropout with its keep mask; the backward is the same map on dy"""
+
+    @staticmethod
+    def forward(ctx, x, mask, scale):
+        x, mask = _c(x), _c(mask)
+        y = torch.empty_like(x)
+        K.mask_scale(y, x, mask, scale)
+        ctx.save_for_backward(mask)
+        ctx.scale = scale
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (mask,) = ctx.saved_tensors
+        dy = _c(dy)
+        dx = torch.empty_like(dy)
+        K.mask_scale(dx, dy, mask, ctx.scale)
+        return dx, None, None
+
+
+def dropout(x, mask, keep):
+    return _MaskScale.apply(x, mask, 1.0 / keep)

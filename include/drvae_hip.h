@@ -30,7 +30,7 @@ extern "C" {
 
 typedef void* dv_stream_t;
 
-#define DV_ABI_VERSION 3
+#define DV_ABI_VERSION 4
 
 enum { DV_OK = 0, DV_ERR_ARG = -1, DV_ERR_LAUNCH = -2, DV_ERR_UNSUPPORTED = -3 };
 
@@ -545,6 +545,22 @@ int dv_loss_assemble_after(int32_t* flag, const int32_t* ctr, int32_t add, int32
                            const dv_loss_term* terms, int32_t n_terms, const float* w_elbo, const float* w_cmpl,
                            float* loss, int32_t* c1, int32_t n1, int64_t inc1, int32_t* c2, int32_t n2,
                            int64_t inc2, const int32_t* halt, int32_t n_halt, float* accum, dv_stream_t stream);
+/* nn.BatchNorm1d(N, affine=True) over the rows of x (M, N) -- the `batch_norm=True` option of blocks.MLP
+ * (src/blocks.py:137-149).  training != 0: batch statistics (biased variance for the normalisation; running_mean /
+ * running_var, when given, move by `momentum`, running_var with the unbiased variance, as torch); training == 0: the
+ * running statistics.  mean_out / rstd_out (N each) keep what the backward pass needs. */
+int dv_bn_fwd(const float* x, int64_t ldx, int32_t M, int32_t N, const float* w, const float* b, float eps,
+              float* mean_out, float* rstd_out, float* y, int64_t ldy, float* running_mean, float* running_var,
+              float momentum, int32_t training, dv_stream_t stream);
+/* dw = sum_i dy*xhat, db = sum_i dy, dx = w*rstd*(dy - db/M - xhat*dw/M) (training) | dy*w*rstd (eval); dx, dw, db
+ * optional */
+int dv_bn_bwd(const float* dy, int64_t ldd, const float* x, int64_t ldx, const float* mean, const float* rstd,
+              const float* w, int32_t M, int32_t N, float* dx, int64_t lddx, float* dw, float* db, int32_t training,
+              dv_stream_t stream);
+/* y = x * mask * scale: nn.Dropout with its keep mask (forward, and backward on dy) -- hidden-layer dropout of
+ * blocks.MLP (src/blocks.py:140-141) */
+int dv_mask_scale(const float* x, int64_t ldx, const float* mask, int64_t ldm, float scale, int32_t M, int32_t N,
+                  float* y, int64_t ldy, dv_stream_t stream);
 /* y[i] = a*x[i] + b*y[i] over n contiguous floats */
 int dv_axpby(const float* x, float a, float* y, float b, int64_t n, dv_stream_t stream);
 

@@ -86,6 +86,45 @@ def mlp(inputs, p, prefix, n_hidden, nonlin):
     return h
 
 
+def batch_norm_rows(x, p, prefix, training, momentum=0.1, eps=1e-5):
+    """nn.BatchNorm1d(affine=True) as blocks.py:137-149 instantiates it, written out: training normalises by the batch
+    mean and BIASED variance and moves the running statistics by ``momentum`` (running_var with the unbiased
+    variance); eval normalises by the running statistics.  Returns (y, new running_mean, new running_var)."""
+    w, b = p[prefix + '.weight'], p[prefix + '.bias']
+    rm, rv = p[prefix + '.running_mean'], p[prefix + '.running_var']
+    if training:
+        n = x.shape[0]
+        mu = x.mean(0)
+        var = ((x - mu) ** 2).mean(0)
+        y = (x - mu) / torch.sqrt(var + eps) * w + b
+        return y, (1 - momentum) * rm + momentum * mu.detach(), (1 - momentum) * rv + momentum * var.detach() * n / (n - 1)
+    return (x - rm) / torch.sqrt(rv + eps) * w + b, rm, rv
+
+
+def mlp_options(inputs, p, prefix, n_hidden, nonlin, batch_norm=False, dropout_masks=None, training=True):
+    """blocks.py:135-164 with the options every model hard-codes off: ``bn_input``, then per layer [dropout{i} (i > 1)]
+    linear{i} activ{i} [bn{i}].  ``dropout_masks``: {i: keep mask} of a train-mode pass (rate 0.5 -> scale 2).
+    Returns (output, {bn prefix: (running_mean, running_var)})."""
+    h = torch.cat(inputs, 1)
+    stats = {}
+
+    def bn(name, h):
+        q = '%s.model.%s' % (prefix, name)
+        y, rm, rv = batch_norm_rows(h, p, q, training)
+        stats[q] = (rm, rv)
+        return y
+    if batch_norm:
+        h = bn('bn_input', h)
+    for i in range(1, n_hidden + 1):
+        if dropout_masks and i in dropout_masks and training:
+            m = dropout_masks[i]
+            h = h * m / float(m.mean().new_tensor(0.5))
+        h = activation(nonlin, linear(h, p, '%s.model.linear%d' % (prefix, i)))
+        if batch_norm:
+            h = bn('bn%d' % i, h)
+    return h, stats
+
+
 def one_hot(y, max_dim):
     """blocks.py:78-92 (intended semantics: (n,)|(n,1) ints -> (n,max_dim) floats)."""
     if y is None or len(y) == 0:

@@ -57,6 +57,28 @@ def block_inputs(tag):
         _lin(sh, '', 13, 5, True)
         sh = OrderedDict((k[1:], v) for k, v in sh.items())
         return dict(params=_fill(sh, seed), x=f(n, 13), dy=f(n, 5))
+    if tag in ('G2d', 'G2e'):      # the MLP's batch_norm / hidden-dropout options (src/blocks.py:135-151)
+        prm = OrderedDict()
+
+        def bn(prefix, width):
+            prm[prefix + '.weight'] = rs.uniform(0.5, 1.5, width).astype(np.float32)
+            prm[prefix + '.bias'] = (0.3 * rs.standard_normal(width)).astype(np.float32)
+            prm[prefix + '.running_mean'] = (0.2 * rs.standard_normal(width)).astype(np.float32)
+            prm[prefix + '.running_var'] = rs.uniform(0.5, 2.0, width).astype(np.float32)
+            prm[prefix + '.num_batches_tracked'] = np.asarray(3, np.int64)
+
+        def lin(prefix, n_in, n_out):
+            prm[prefix + '.weight'] = (rs.uniform(-1, 1, (n_out, n_in)) / np.sqrt(n_in)).astype(np.float32)
+            prm[prefix + '.bias'] = (rs.uniform(-1, 1, n_out) / np.sqrt(n_in)).astype(np.float32)
+        if tag == 'G2d':
+            bn('model.bn_input', 13)
+        lin('model.linear1', 13, 11)
+        if tag == 'G2d':
+            bn('model.bn1', 11)
+        lin('model.linear2', 11, 6)
+        if tag == 'G2d':
+            bn('model.bn2', 6)
+        return dict(params=prm, xa=f(n, 9), xb=f(n, 4), dy=f(n, 6), seed=seed)
     if tag.startswith('G2'):
         wn = tag in ('G2b', 'G2c')
         _lin(sh, 'model.linear1', 13, 11, wn)

@@ -249,6 +249,38 @@ def run_block_cases():
         put(tag, y=y, dxa=xs[0].grad, dxb=xs[1].grad,
             **{'d_' + k: v.grad for k, v in m.named_parameters()})
 
+    # G2d MLP(batch_norm=True): train-mode forward + gradients + running statistics, then eval-mode forward
+    c = C.block_inputs('G2d')
+    m = rblk.MLP([9, 4], [11, 6], nonlin='elu', batch_norm=True)
+    load_sd(m, c['params'])
+    m.train()
+    xs = [T(c['xa']).requires_grad_(True), T(c['xb']).requires_grad_(True)]
+    y = m(xs)
+    (y * T(c['dy'])).sum().backward()
+    put('G2d', y=y, dxa=xs[0].grad, dxb=xs[1].grad, **{'d_' + k: v.grad for k, v in m.named_parameters()})
+    put('G2d', **{'after_' + k: v for k, v in m.state_dict().items() if 'running' in k or 'tracked' in k})
+    m.eval()
+    put('G2d', y_eval=m([T(c['xa']), T(c['xb'])]))
+    # G2e MLP(dropout_rate=0.5): hidden dropout in front of linear2 (train mode; the keep mask the module drew is
+    # read off its output: elu activations are never exactly zero), identity in eval mode
+    c = C.block_inputs('G2e')
+    m = rblk.MLP([9, 4], [11, 6], nonlin='elu', dropout_rate=0.5)
+    load_sd(m, c['params'])
+    m.train()
+    xs = [T(c['xa']).requires_grad_(True), T(c['xb']).requires_grad_(True)]
+    seen = {}
+    hook = m.model.dropout2.register_forward_hook(
+        lambda mod, inp, outp: seen.update(mask=(outp.detach() != 0).float(), ok=bool((inp[0] != 0).all())))
+    torch.manual_seed(c['seed'])
+    y = m(xs)
+    hook.remove()
+    assert seen['ok']
+    (y * T(c['dy'])).sum().backward()
+    put('G2e', y=y, dxa=xs[0].grad, dxb=xs[1].grad, mask=seen['mask'],
+        **{'d_' + k: v.grad for k, v in m.named_parameters()})
+    m.eval()
+    put('G2e', y_eval=m([T(c['xa']), T(c['xb'])]))
+
     # G3 DiagGaussianModule + logvar mixin
     for tag, wn in (('G3a', False), ('G3b', True)):
         c = C.block_inputs(tag)

@@ -125,6 +125,61 @@ def test_mlp(G, mods, dev, tag, wn, nl):
         blk.MLP([9, 4], [3], input_dropout_rates=[0.1])  # src/blocks.py:128-130
 
 
+def test_mlp_batch_norm(G, mods, dev):
+    """a7: MLP(batch_norm=True) -- bn_input / bn{i} on the HIP kernels (dv_bn_fwd / dv_bn_bwd): train-mode forward,
+    every gradient, the running statistics after the pass, eval-mode forward, vs the reference's module"""
+    blk, _ = mods
+    c = C.block_inputs('G2d')
+    m = load_sd(blk.MLP([9, 4], [11, 6], nonlin='elu', batch_norm=True), c['params'], dev)
+    assert type(m.model.bn_input) is blk.BatchNorm1d and type(m.model.bn2) is blk.BatchNorm1d
+    m.train()
+    xs = [T(c['xa'], dev).requires_grad_(True), T(c['xb'], dev).requires_grad_(True)]
+    y = m(xs)
+    (y * T(c['dy'], dev)).sum().backward()
+    close(y, G['G2d/y'])
+    close(xs[0].grad, G['G2d/dxa'])
+    close(xs[1].grad, G['G2d/dxb'])
+    for k, v in m.named_parameters():
+        close(v.grad, G['G2d/d_' + k])
+    for k, v in m.state_dict().items():
+        if 'running' in k:
+            close(v, G['G2d/after_' + k])
+        elif 'tracked' in k:
+            assert int(v) == int(G['G2d/after_' + k])
+    m.eval()
+    close(m([T(c['xa'], dev), T(c['xb'], dev)]), G['G2d/y_eval'])
+    with pytest.raises(ValueError):
+        m.train()
+        m([T(c['xa'][:1], dev), T(c['xb'][:1], dev)])         # one row in training mode: torch's own error
+
+
+def test_mlp_hidden_dropout(G, mods, dev, monkeypatch):
+    """a7: MLP(dropout_rate=0.5) -- the hidden-layer dropout (dv_mask_scale forward and backward) with the keep mask the
+    reference's module drew; identity in eval mode; a fresh on-device mask otherwise"""
+    blk, _ = mods
+    c = C.block_inputs('G2e')
+    m = load_sd(blk.MLP([9, 4], [11, 6], nonlin='elu', dropout_rate=0.5), c['params'], dev)
+    assert type(m.model.dropout2) is blk.Dropout
+    mask = T(G['G2e/mask'], dev)
+    monkeypatch.setattr(blk, '_keep_mask_like', lambda t, keep: mask.clone())
+    m.train()
+    xs = [T(c['xa'], dev).requires_grad_(True), T(c['xb'], dev).requires_grad_(True)]
+    y = m(xs)
+    (y * T(c['dy'], dev)).sum().backward()
+    close(y, G['G2e/y'])
+    close(xs[0].grad, G['G2e/dxa'])
+    close(xs[1].grad, G['G2e/dxb'])
+    for k, v in m.named_parameters():
+        close(v.grad, G['G2e/d_' + k])
+    m.eval()
+    close(m([T(c['xa'], dev), T(c['xb'], dev)]), G['G2e/y_eval'])
+    monkeypatch.undo()
+    m.train()
+    big = [torch.ones(400, 9, device=dev), torch.ones(400, 4, device=dev)]
+    h = m.model.dropout2(torch.ones(400, 11, device=dev))
+    assert set(h.unique().tolist()) == {0.0, 2.0} and 0.4 < float((h > 0).float().mean()) < 0.6
+
+
 @pytest.mark.parametrize('tag,wn', [('G3a', False), ('G3b', True)])
 def test_diag_gaussian_module(G, mods, dev, tag, wn):
     blk, _ = mods

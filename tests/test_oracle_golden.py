@@ -58,6 +58,51 @@ def test_mlp(G, tag, nl):
         close(v.grad, G['%s/d_%s' % (tag, k)])
 
 
+def test_mlp_batch_norm(G):
+    c = C.block_inputs('G2d')
+    p = {'m.' + k: (torch.from_numpy(np.asarray(v).copy()).requires_grad_(v.dtype == np.float32 and 'running' not in k))
+         for k, v in c['params'].items()}
+    xa, xb = T(c['xa']).requires_grad_(True), T(c['xb']).requires_grad_(True)
+    y, stats = B.mlp_options([xa, xb], p, 'm', 2, 'elu', batch_norm=True, training=True)
+    (y * T(c['dy'])).sum().backward()
+    close(y, G['G2d/y'])
+    close(xa.grad, G['G2d/dxa'])
+    close(xb.grad, G['G2d/dxb'])
+    for k, v in p.items():
+        if v.requires_grad:
+            close(v.grad, G['G2d/d_' + k[2:]])
+    for q, (rm, rv) in stats.items():
+        close(rm, G['G2d/after_%s.running_mean' % q[2:]])
+        close(rv, G['G2d/after_%s.running_var' % q[2:]])
+        assert int(G['G2d/after_%s.num_batches_tracked' % q[2:]]) == 4
+    ye, _ = B.mlp_options([T(c['xa']), T(c['xb'])], {k: v.detach() for k, v in p.items()}, 'm', 2, 'elu', batch_norm=True,
+                          training=False)
+    # (eval after the train pass uses the UPDATED statistics)
+    p2 = {k: v.detach() for k, v in p.items()}
+    for q, (rm, rv) in stats.items():
+        p2[q + '.running_mean'], p2[q + '.running_var'] = rm, rv
+    ye, _ = B.mlp_options([T(c['xa']), T(c['xb'])], p2, 'm', 2, 'elu', batch_norm=True, training=False)
+    close(ye, G['G2d/y_eval'])
+
+
+def test_mlp_hidden_dropout(G):
+    c = C.block_inputs('G2e')
+    p = P(c['params'], True)
+    pm = {'m.' + k: v for k, v in p.items()}
+    xa, xb = T(c['xa']).requires_grad_(True), T(c['xb']).requires_grad_(True)
+    mask = T(G['G2e/mask'])
+    assert set(np.unique(G['G2e/mask'])) <= {0.0, 1.0} and 0 < G['G2e/mask'].mean() < 1
+    y, _ = B.mlp_options([xa, xb], pm, 'm', 2, 'elu', dropout_masks={2: mask}, training=True)
+    (y * T(c['dy'])).sum().backward()
+    close(y, G['G2e/y'])
+    close(xa.grad, G['G2e/dxa'])
+    close(xb.grad, G['G2e/dxb'])
+    for k, v in p.items():
+        close(v.grad, G['G2e/d_' + k])
+    ye, _ = B.mlp_options([T(c['xa']), T(c['xb'])], {k: v.detach() for k, v in pm.items()}, 'm', 2, 'elu', training=False)
+    close(ye, G['G2e/y_eval'])
+
+
 def _pref(params, prefix):
     return {prefix + '.' + k: v for k, v in P(params).items()}
 
