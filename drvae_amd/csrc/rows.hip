@@ -25,8 +25,22 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X
     const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int col = blockIdx.x * 64 + c;
     float s = 0.f;
-    if (col < N)
-        for (int m = rl; m < M; m += 4) s += X[(int64_t)m * ldx + col];
+    if (col < N) {
+        // eight independent loads per trip (the loop is a chain of memory round trips otherwise: 0.88 ms for the
+        // 4096 x 40000 gradient of the wide configuration's decoder heads, i.e. 0.7 TB/s); fixed summation order
+        const float* p = X + (int64_t)rl * ldx + col;
+        const int64_t st = 4 * ldx;
+        int m = rl;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f, a5 = 0.f, a6 = 0.f, a7 = 0.f;
+        for (; m + 28 < M; m += 32, p += 8 * st) {
+            const float v0 = p[0], v1 = p[st], v2 = p[2 * st], v3 = p[3 * st];
+            const float v4 = p[4 * st], v5 = p[5 * st], v6 = p[6 * st], v7 = p[7 * st];
+            a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+            a4 += v4; a5 += v5; a6 += v6; a7 += v7;
+        }
+        s = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
+        for (; m < M; m += 4, p += st) s += p[0];
+    }
     part[rl][c] = s;
     __syncthreads();
     if (rl == 0 && col < N) {
