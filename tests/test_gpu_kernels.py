@@ -3,9 +3,52 @@ import numpy as np
 import pytest
 import torch
 
-from tests import kernel_ref as R
+from tests import kernel_ref
 
 pytestmark = pytest.mark.gpu
+
+
+class _OnHost:
+    """``tests/kernel_ref.py`` with every call evaluated on HOST copies of its tensor arguments: the reference arithmetic
+    is plain PyTorch fp32 on the CPU (no GPU library in it).  Views keep their aliasing -- every distinct device storage
+    is mirrored once and each argument re-created as the same strided view of the mirror -- and whatever the reference
+    wrote is copied back into the device tensors it was handed."""
+
+    def __getattr__(self, name):
+        fn = getattr(kernel_ref, name)
+        if not callable(fn):
+            return fn
+
+        def call(*args, **kw):
+            mirrors = {}
+
+            def host(t):
+                if not (torch.is_tensor(t) and t.is_cuda):
+                    return t
+                st = t.untyped_storage()
+                key = st.data_ptr()
+                if key not in mirrors:
+                    flat = torch.empty(0, dtype=torch.uint8, device=t.device).set_(st)
+                    mirrors[key] = (flat, flat.cpu())
+                cpu_flat = mirrors[key][1]
+                base = torch.empty(0, dtype=t.dtype).set_(cpu_flat.untyped_storage())
+                return torch.as_strided(base, t.size(), t.stride(), t.storage_offset())
+
+            def walk(a):
+                if isinstance(a, (list, tuple)):
+                    return type(a)(walk(v) for v in a)
+                if isinstance(a, dict):
+                    return {k: walk(v) for k, v in a.items()}
+                return host(a)
+            torch.cuda.synchronize()
+            out = fn(*walk(list(args)), **walk(kw))
+            for dev_flat, cpu_flat in mirrors.values():
+                dev_flat.copy_(cpu_flat)
+            return out
+        return call
+
+
+R = _OnHost()
 
 
 @pytest.fixture(scope='module')
@@ -211,8 +254,8 @@ def test_activations(K, dev, act):
     R.linear_fwd(ry, x, W, b, act0=act, act1=act)
     close(y, ry, rtol=1e-5, atol=1e-5)
     # derivative from the output agrees with autograd through the torch activation
-    pre = (x @ W.t() + b).requires_grad_(True)
-    R.act_fwd(act, pre).backward(torch.ones_like(pre))
+    pre = (x.cpu() @ W.cpu().t() + b.cpu()).requires_grad_(True)
+    kernel_ref.act_fwd(act, pre).backward(torch.ones_like(pre))
     dY = torch.ones(M, N, device=dev)
     K.act_bwd_(dY, y, act0=act, act1=act)
     close(dY, pre.grad, rtol=2e-4, atol=2e-5)
@@ -350,7 +393,7 @@ def test_categorical(K, dev, Y, sig):
     p, rp = torch.empty(M, Y, device=dev), torch.empty(M, Y, device=dev)
     K.softmax_clamp_fwd(p, logits, sig)
     R.softmax_clamp_fwd(rp, logits, sig)
-    close(p, rp, rtol=1e-5, atol=1e-12)
+    close(p, rp, rtol=3e-5, atol=1e-12)          # (device expf against the host's: ~1e-5 relative on probabilities of 1e-4)
     assert float(p.min()) >= 1e-10 * 0.999
     g = rnd(dev, M, Y, seed=2)
     dl, rdl = rnd(dev, M, logits.shape[1], seed=3), None
