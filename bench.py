@@ -377,7 +377,8 @@ def measure(args, workload, feed, steps, warmup, device, rank, world, steady_s=0
         hx, hy = batch['has_x2'].astype(bool), batch['has_y'].astype(bool)
         gc = [int(((hy == bool(gy)) & (hx == bool(gx))).sum()) for (gy, gx) in DD._GROUPS]
         if feed == 'sampler':
-            bat = DD.DeviceBatcher(ds, torch.ones(args.dataset_rows), rows, seed=5 + rank, mode='sampler')
+            bat = DD.DeviceBatcher(ds, torch.ones(args.dataset_rows), rows, seed=5 + rank, mode='sampler',
+                                   pair_bucket=args.pair_bucket or None)
             bat.bind(eng)
         else:
             bat = DD.DeviceBatcher(ds, torch.ones(args.dataset_rows), rows, group_counts=gc, seed=5 + rank)
@@ -391,7 +392,8 @@ def measure(args, workload, feed, steps, warmup, device, rank, world, steady_s=0
         """graph-resident feeds: a fresh index table that covers the next ``n`` replays (the feed clamps past its
         end: a region longer than the table would re-train on the last batch instead of a fresh draw per step)"""
         if bat is not None and feed in ('epoch', 'sampler'):
-            bat.begin_epoch(n_batches=n + 8)
+            bat.begin_epoch(n_batches=n_table[0] if bat.pair_bucket else n + 8)
+            bat.select(0)                # (bucketed: the first batch's plan; rare new buckets run on the next larger plan)
     if use_graph:
         # one exchange between two graphs by default; --dp-exchange overlap: two overlapped pieces between three
         # graphs (measured with a one-rank RCCL communicator: +49 us of launch/event overhead per step against +24 us)
@@ -408,11 +410,19 @@ def measure(args, workload, feed, steps, warmup, device, rank, world, steady_s=0
                 dp_mode = dp
         if dp_mode != 'captured':
             eng.capture(split_for_allreduce=dp_mode)
+        if bat is not None and bat.pair_bucket:
+            # one captured step per number-of-pairs bucket of the table's batches; each replay picks its batch's
+            eng.stash_capture()
+            bat.prepare_epoch(lambda e: e.capture(split_for_allreduce=dp_mode))
         if overlap and len(eng._graphs) == 3:
             allreduce = D.OverlappedAllReduce()      # decoder block travels while the encoder backward runs
         if feed == 'batcher':
             def step():
                 bat.feed()
+                eng.replay(allreduce)
+        elif bat is not None and bat.pair_bucket:
+            def step():
+                bat.select()
                 eng.replay(allreduce)
         else:
             step = lambda: eng.replay(allreduce)
@@ -465,6 +475,8 @@ def measure(args, workload, feed, steps, warmup, device, rank, world, steady_s=0
         dt2 = over_ranks(time.perf_counter() - t1)
         steady = {'steps': n2, 'seconds': round(dt2, 3), 'ms_per_step': round(1e3 * dt2 / n2, 4),
                   'value': round(world * rows * L * n2 / dt2, 1)}
+    if bat is not None and getattr(bat, 'pair_bucket', None):
+        print('bench.py: sampler feed, %d captured plans, %d plan switches' % (len(eng._captures), bat.n_switch), file=sys.stderr)
     losses = eng.losses()                  # (of the last measured step: read before the probe below trains on)
     exchange = None
     if dp and exchange_probe and use_graph and len(getattr(eng, '_graphs', [])) == 2:
@@ -559,6 +571,9 @@ def main():
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--pair-bucket', type=int, default=16,
+                    help="--feed sampler: batches are re-ordered pairs first and run on the plan whose pair slots are "
+                         "the batch's number of pairs rounded up to a multiple of this (0: one plan sized for B pairs)")
     ap.add_argument('--feed', default='resident', choices=['resident', 'batcher', 'epoch', 'sampler'],
                     help='resident: one batch parked in HBM (default); batcher: a fresh stratified minibatch drawn on '
                          'the device from an HBM-resident dataset before every step (host-driven gathers); epoch: the '

@@ -62,6 +62,14 @@ class HeadsEpi(C.Structure):   # dv_heads_epi
 HEADS_SAMPLE, HEADS_NLL = 1, 2
 
 
+class BatchMasks(C.Structure):   # dv_batch_masks_desc
+    _fields_ = [('hx', C.c_void_p), ('hy', C.c_void_p), ('y', C.c_void_p), ('Np', C.c_int32),
+                ('n_tot', C.c_float), ('kl_rate', C.c_float), ('pert_rate', C.c_float), ('yl_rate', C.c_float),
+                ('beta', C.c_void_p), ('c_nll', C.c_void_p), ('c_klz2', C.c_void_p), ('c_yl', C.c_void_p),
+                ('w_recl', C.c_void_p), ('w_pert', C.c_void_p), ('w_yl', C.c_void_p), ('label', C.c_void_p),
+                ('c_klp', C.c_void_p)]
+
+
 class LossTerm(C.Structure):
     _fields_ = [('x', _p), ('w', _p), ('n', _i32), ('scale', _f), ('out', _i32), ('row_len', _i32)]
 
@@ -119,8 +127,8 @@ SIGNATURES = {
     'dv_mmd_rff_bwd': [_p, _i64, _i32, _i32, _p, _p, _f, _p, _i64, _p],
     'dv_rows_gather': [_p, _i64, _p, _i32, _i32, _p, _i64, _f, _p, _i32, _p, _i64, C.POINTER(Wait), _p],
     'dv_batch_feed': [_p, _i64, _p, _i64, _p, _p, _i32, _p, _p, _i32, _p, _i32, _i32, _p, _i64, _f, _p, _i64, _p, _i32,
-                      _p, _p, _p, _p, _i32, _p, _p, _i64, _i32, _p, _p, _i32, _p, _i64, _p],
-    'dv_batch_masks': [_p, _i32, _p, _p, _p, _p, _p, _i32, _i32, _f, _f, _f, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
+                      _p, _p, _p, _p, _i32, _p, _p, _i64, _i32, _p, _p, _i32, _p, _i64, C.POINTER(BatchMasks), _p],
+    'dv_batch_masks': [_p, _i32, _p, _p, _p, _p, _p, _i32, _i32, _i32, _f, _f, _f, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     'dv_rows_segment_sum': [_p, _i64, _p, _p, _p, _i32, _i32, _p, _p, _i64, _f, C.POINTER(Wait), _p],
     'dv_weighted_sum': [_p, _p, _p, _i32, _f, _p, _f, _p],
     'dv_recon_row_stats': [_p, _i64, _p, _i64, _i32, _i32, _p, _p],
@@ -142,7 +150,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 4     # DV_ABI_VERSION of include/drvae_hip.h
+ABI_VERSION = 5     # DV_ABI_VERSION of include/drvae_hip.h
 
 
 def load():

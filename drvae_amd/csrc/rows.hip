@@ -1138,6 +1138,91 @@ __global__ void rows_gather_kernel(const float* __restrict__ src, int64_t lds, c
     }
 }
 
+// Per-batch masks of a batch-INDEPENDENT ("universal") step plan: the plan materialises every row as a pair with
+// every class slot, and which rows really are pairs / labeled is data -- coefficient and weight vectors computed
+// here, on the device, from the flags of the batch (src/DrVAE.py:565-624: group split + per-example normalisers
+// N_total / max(1, N_pairs) / max(1, N_labeled), with N_pairs and N_labeled counted per batch).  One workgroup.
+// Row i of the batch is dataset row table[b, i] (graph-resident epoch feed) or i itself (table == NULL).
+struct MaskArgs {
+    const int32_t* table;
+    int n_batches;
+    const int32_t* ctr;
+    const int32_t* base;
+    const int32_t* hx;
+    const int32_t* hy;
+    const int32_t* y;
+    int B, L, Np;     // Np: rows [0, Np) of the batch have pair slots (the batch-independent plan: Np == B)
+    float n_tot, kl_rate, pert_rate, yl_rate;
+    const float* beta;
+    float* c_nll;     // (3 L B): z1 rows | z2 rows | z2Fz1 rows
+    float* c_klz2;    // (L B)
+    float* c_yl;      // (L B)
+    float* w_recl;    // (2 L B)  weights of RECL over the z1 | z2 rows
+    float* w_pert;    // (L B)
+    float* w_yl;      // (L B)
+    int32_t* label;   // (L B): -2 - class for labeled rows, 0 otherwise (see ymarg_*_kernel)
+    float* c_klp;     // (2 B), optional: KL-to-prior rows of q(z1|x1) | q(z2|x2) (PVAE, src/PVAE.py:330-345)
+};
+
+__device__ __forceinline__ void batch_masks_body(const MaskArgs& a) {
+    __shared__ int cnt[2];
+    if (threadIdx.x < 2) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const int32_t* tb = nullptr;
+    if (a.table) {
+        int b = a.ctr[0] - a.base[0];
+        b = b < 0 ? 0 : (b >= a.n_batches ? a.n_batches - 1 : b);
+        tb = a.table + (int64_t)b * a.B;
+    }
+    int np = 0, nl = 0;
+    for (int i = threadIdx.x; i < a.B; i += blockDim.x) {
+        const int src = tb ? tb[i] : i;
+        np += (a.hx && a.hx[src] != 0) ? 1 : 0;
+        nl += (a.hy && a.hy[src] != 0) ? 1 : 0;
+    }
+    // integer counts: order-independent, so atomics keep the step reproducible
+    if (np) atomicAdd(&cnt[0], np);
+    if (nl) atomicAdd(&cnt[1], nl);
+    __syncthreads();
+    const float Lf = (float)a.L, beta = a.beta ? a.beta[0] : 1.f;
+    const float n_pairs = cnt[0] > 0 ? (float)cnt[0] : 1.f, n_lab = cnt[1] > 0 ? (float)cnt[1] : 1.f;
+    const float c_tot = 1.f / (Lf * a.n_tot);
+    const int LB = a.L * a.B, LP = a.L * a.Np;
+    // pair slots: slot q = (l, j) belongs to batch row j < Np (rows from Np on have no x2 / z2 rows in this plan:
+    // the feed puts the batch's pairs first)
+    if (a.c_nll && a.hx)
+        for (int q = threadIdx.x; q < LP; q += blockDim.x) {
+            const int j = q % a.Np, src = tb ? tb[j] : j;
+            const bool px = a.hx[src] != 0;
+            a.c_nll[LB + q] = px ? -c_tot : 0.f;
+            a.w_recl[LB + q] = px ? c_tot : 0.f;
+            a.c_nll[LB + LP + q] = px ? -beta * a.pert_rate / (Lf * n_pairs) : 0.f;
+            a.w_pert[q] = px ? 1.f / (Lf * n_pairs) : 0.f;
+            a.c_klz2[q] = px ? beta * a.kl_rate * c_tot : 0.f;
+        }
+    for (int r = threadIdx.x; r < LB; r += blockDim.x) {
+        const int i = r % a.B, src = tb ? tb[i] : i;
+        const bool py = a.hy && a.hy[src] != 0;
+        if (a.c_nll) {
+            a.c_nll[r] = -c_tot;
+            a.w_recl[r] = c_tot;
+        }
+        if (a.hy) {
+            a.c_yl[r] = py ? -a.yl_rate / (Lf * n_lab) : 0.f;
+            a.w_yl[r] = 1.f / (Lf * n_lab);
+            a.label[r] = py ? -2 - a.y[src] : 0;
+        }
+    }
+    if (a.c_klp)
+        for (int i = threadIdx.x; i < a.B; i += blockDim.x) {
+            const int src = tb ? tb[i] : i;
+            a.c_klp[i] = 1.f / a.n_tot;
+            if (i < a.Np) a.c_klp[a.B + i] = (a.hx && a.hx[src] != 0) ? 1.f / a.n_tot : 0.f;
+        }
+}
+
+__global__ __launch_bounds__(1024) void batch_masks_kernel(MaskArgs a) { batch_masks_body(a); }
+
 // Graph-resident input feed: batch `b = ctr - base` of an epoch's index table is gathered from
 // the HBM-resident dataset straight into the step's input rows ([x1 rows ; x2 rows of the pairs],
 // + training noise), and the label-dependent index buffers of the step are refreshed, in ONE
@@ -1150,7 +1235,11 @@ __global__ __launch_bounds__(256) void batch_feed_kernel(
     const int32_t* __restrict__ has_y, int L, int32_t* __restrict__ label_r, const int32_t* __restrict__ fp_i,
     const int32_t* __restrict__ fp_lab, const int32_t* __restrict__ fp_slot, int Mf, int32_t* __restrict__ fp_cls,
     float* __restrict__ onehot, int64_t ldh, int Y, int row_blocks, int vec4, const float* __restrict__ yf,
-    float* __restrict__ ylab, int Yc, float* __restrict__ onehot2, int64_t ldh2) {
+    float* __restrict__ ylab, int Yc, float* __restrict__ onehot2, int64_t ldh2, int mask_block, MaskArgs masks) {
+    if ((int)blockIdx.x == mask_block) {        // (batch-independent plan: the batch's masks ride on this launch)
+        batch_masks_body(masks);
+        return;
+    }
     int b = ctr[0] - base[0];
     b = b < 0 ? 0 : (b >= n_batches ? n_batches - 1 : b);
     const int32_t* tb = table + (int64_t)b * B;
@@ -1196,84 +1285,6 @@ __global__ __launch_bounds__(256) void batch_feed_kernel(
         if (onehot2)     // (a second copy of the block: the class columns of both fprop inputs)
             for (int c = 0; c < Y; ++c) onehot2[(int64_t)t * ldh2 + c] = c == cls ? 1.f : 0.f;
     }
-}
-
-// Per-batch masks of a batch-INDEPENDENT ("universal") step plan: the plan materialises every row as a pair with
-// every class slot, and which rows really are pairs / labeled is data -- coefficient and weight vectors computed
-// here, on the device, from the flags of the batch (src/DrVAE.py:565-624: group split + per-example normalisers
-// N_total / max(1, N_pairs) / max(1, N_labeled), with N_pairs and N_labeled counted per batch).  One workgroup.
-// Row i of the batch is dataset row table[b, i] (graph-resident epoch feed) or i itself (table == NULL).
-struct MaskArgs {
-    const int32_t* table;
-    int n_batches;
-    const int32_t* ctr;
-    const int32_t* base;
-    const int32_t* hx;
-    const int32_t* hy;
-    const int32_t* y;
-    int B, L;
-    float n_tot, kl_rate, pert_rate, yl_rate;
-    const float* beta;
-    float* c_nll;     // (3 L B): z1 rows | z2 rows | z2Fz1 rows
-    float* c_klz2;    // (L B)
-    float* c_yl;      // (L B)
-    float* w_recl;    // (2 L B)  weights of RECL over the z1 | z2 rows
-    float* w_pert;    // (L B)
-    float* w_yl;      // (L B)
-    int32_t* label;   // (L B): -2 - class for labeled rows, 0 otherwise (see ymarg_*_kernel)
-    float* c_klp;     // (2 B), optional: KL-to-prior rows of q(z1|x1) | q(z2|x2) (PVAE, src/PVAE.py:330-345)
-};
-
-__global__ __launch_bounds__(1024) void batch_masks_kernel(MaskArgs a) {
-    __shared__ int cnt[2];
-    if (threadIdx.x < 2) cnt[threadIdx.x] = 0;
-    __syncthreads();
-    const int32_t* tb = nullptr;
-    if (a.table) {
-        int b = a.ctr[0] - a.base[0];
-        b = b < 0 ? 0 : (b >= a.n_batches ? a.n_batches - 1 : b);
-        tb = a.table + (int64_t)b * a.B;
-    }
-    int np = 0, nl = 0;
-    for (int i = threadIdx.x; i < a.B; i += blockDim.x) {
-        const int src = tb ? tb[i] : i;
-        np += (a.hx && a.hx[src] != 0) ? 1 : 0;
-        nl += (a.hy && a.hy[src] != 0) ? 1 : 0;
-    }
-    // integer counts: order-independent, so atomics keep the step reproducible
-    if (np) atomicAdd(&cnt[0], np);
-    if (nl) atomicAdd(&cnt[1], nl);
-    __syncthreads();
-    const float Lf = (float)a.L, beta = a.beta ? a.beta[0] : 1.f;
-    const float n_pairs = cnt[0] > 0 ? (float)cnt[0] : 1.f, n_lab = cnt[1] > 0 ? (float)cnt[1] : 1.f;
-    const float c_tot = 1.f / (Lf * a.n_tot);
-    const int LB = a.L * a.B;
-    for (int r = threadIdx.x; r < LB; r += blockDim.x) {
-        const int i = r % a.B, src = tb ? tb[i] : i;
-        const bool px = a.hx && a.hx[src] != 0, py = a.hy && a.hy[src] != 0;
-        if (a.c_nll) {
-            a.c_nll[r] = -c_tot;
-            a.w_recl[r] = c_tot;
-            if (a.hx) {
-                a.c_nll[LB + r] = px ? -c_tot : 0.f;
-                a.w_recl[LB + r] = px ? c_tot : 0.f;
-                a.c_nll[2 * LB + r] = px ? -beta * a.pert_rate / (Lf * n_pairs) : 0.f;
-                a.w_pert[r] = px ? 1.f / (Lf * n_pairs) : 0.f;
-                a.c_klz2[r] = px ? beta * a.kl_rate * c_tot : 0.f;
-            }
-        }
-        if (a.hy) {
-            a.c_yl[r] = py ? -a.yl_rate / (Lf * n_lab) : 0.f;
-            a.w_yl[r] = 1.f / (Lf * n_lab);
-            a.label[r] = py ? -2 - a.y[src] : 0;
-        }
-    }
-    if (a.c_klp)
-        for (int i = threadIdx.x; i < a.B; i += blockDim.x) {
-            const int src = tb ? tb[i] : i;
-            a.c_klp[i] = 1.f / a.n_tot;
-            a.c_klp[a.B + i] = (a.hx && a.hx[src] != 0) ? 1.f / a.n_tot : 0.f;
-        }
 }
 
 __global__ void rows_segment_sum_kernel(const float* __restrict__ src, int64_t lds,
@@ -2043,7 +2054,8 @@ extern "C" int dv_batch_feed(const float* x1, int64_t ld1, const float* x2, int6
                              int64_t ldn, float sigma, float* xin, int64_t ldo, const int32_t* has_y, int32_t L,
                              int32_t* label_r, const int32_t* fp_i, const int32_t* fp_lab, const int32_t* fp_slot,
                              int32_t Mf, int32_t* fp_cls, float* onehot, int64_t ldh, int32_t Y, const float* yf,
-                             float* ylab, int32_t Yc, float* onehot2, int64_t ldh2, dv_stream_t stream) {
+                             float* ylab, int32_t Yc, float* onehot2, int64_t ldh2, const dv_batch_masks_desc* masks,
+                             dv_stream_t stream) {
     DV_REQUIRE(B >= 0 && Np >= 0 && X >= 0 && n_batches >= 1 && L >= 1 && Mf >= 0 && Y >= 0 && Yc >= 0);
     DV_REQUIRE(!ylab || (yf && Yc >= 1));
     if (B == 0) return DV_OK;
@@ -2056,23 +2068,33 @@ extern "C" int dv_batch_feed(const float* x1, int64_t ld1, const float* x2, int6
     const int lab_blocks = (nlab + 255) / 256;
     const bool v4 = aligned16(x1) && (Np == 0 || aligned16(x2)) && aligned16(xin) && (!noise || aligned16(noise)) &&
                     ld1 % 4 == 0 && (Np == 0 || ld2 % 4 == 0) && ldo % 4 == 0 && (!noise || ldn % 4 == 0);
-    hipLaunchKernelGGL(batch_feed_kernel, dim3(row_blocks + lab_blocks), dim3(256), 0, ST(stream), x1, ld1, x2, ld2, y,
-                       table, n_batches, ctr, base, B, pair_rows, Np, X, noise, ldn, sigma, xin, ldo, has_y, L,
+    MaskArgs ma{};
+    if (masks) {
+        const dv_batch_masks_desc& m = *masks;
+        DV_REQUIRE(m.Np >= 0 && m.Np <= B && m.n_tot > 0.f && m.c_nll && m.w_recl);
+        DV_REQUIRE(m.hx == nullptr || (m.c_klz2 && m.w_pert));
+        DV_REQUIRE(m.hy == nullptr || (m.y && m.c_yl && m.w_yl && m.label));
+        ma = MaskArgs{table, n_batches, ctr, base, m.hx, m.hy, m.y, B, L, m.Np, m.n_tot, m.kl_rate, m.pert_rate, m.yl_rate,
+                      m.beta, m.c_nll, m.c_klz2, m.c_yl, m.w_recl, m.w_pert, m.w_yl, m.label, m.c_klp};
+    }
+    const int feed_blocks = row_blocks + lab_blocks;
+    hipLaunchKernelGGL(batch_feed_kernel, dim3(feed_blocks + (masks ? 1 : 0)), dim3(256), 0, ST(stream), x1, ld1, x2, ld2,
+                       y, table, n_batches, ctr, base, B, pair_rows, Np, X, noise, ldn, sigma, xin, ldo, has_y, L,
                        label_r, fp_i, fp_lab, fp_slot, Mf, fp_cls, onehot, ldh, Y, row_blocks, v4 ? 1 : 0, yf, ylab, Yc,
-                       onehot2, ldh2);
+                       onehot2, ldh2, masks ? feed_blocks : -1, ma);
     DV_RETURN_LAUNCH();
 }
 
 extern "C" int dv_batch_masks(const int32_t* table, int32_t n_batches, const int32_t* ctr, const int32_t* base,
-                              const int32_t* hx, const int32_t* hy, const int32_t* y, int32_t B, int32_t L,
+                              const int32_t* hx, const int32_t* hy, const int32_t* y, int32_t B, int32_t L, int32_t Np,
                               float n_tot, float kl_rate, float pert_rate, float yl_rate, const float* beta,
                               float* c_nll, float* c_klz2, float* c_yl, float* w_recl, float* w_pert, float* w_yl,
                               int32_t* label, float* c_klp, dv_stream_t stream) {
-    DV_REQUIRE(B >= 1 && L >= 1 && n_tot > 0.f && c_nll && w_recl);
+    DV_REQUIRE(B >= 1 && L >= 1 && Np >= 0 && Np <= B && n_tot > 0.f && c_nll && w_recl);
     DV_REQUIRE(table == nullptr || (ctr && base && n_batches >= 1));
     DV_REQUIRE(hx == nullptr || (c_klz2 && w_pert));
     DV_REQUIRE(hy == nullptr || (y && c_yl && w_yl && label));
-    MaskArgs a{table, n_batches, ctr, base, hx, hy, y, B, L, n_tot, kl_rate, pert_rate, yl_rate, beta, c_nll, c_klz2,
+    MaskArgs a{table, n_batches, ctr, base, hx, hy, y, B, L, Np, n_tot, kl_rate, pert_rate, yl_rate, beta, c_nll, c_klz2,
                c_yl, w_recl, w_pert, w_yl, label, c_klp};
     hipLaunchKernelGGL(batch_masks_kernel, dim3(1), dim3(1024), 0, ST(stream), a);
     DV_RETURN_LAUNCH();

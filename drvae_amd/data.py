@@ -116,7 +116,8 @@ class DeviceBatcher:
     """Stratified, weighted, with-replacement minibatches drawn ON the device and written
     straight into the fused step's input buffers (see the module docstring)."""
 
-    def __init__(self, dataset, weights, batch_size, group_counts=None, seed=0, mode='stratified', generator='device'):
+    def __init__(self, dataset, weights, batch_size, group_counts=None, seed=0, mode='stratified', generator='device',
+                 pair_bucket=None):
         """``mode='stratified'`` (default): every batch has the SAME composition (the expected counts of the four
         groups under the weights, or ``group_counts``) -- rows within a group drawn with replacement by weight;
         the step runs on the plan of exactly that structure.
@@ -128,7 +129,12 @@ class DeviceBatcher:
         it -- torch's DEFAULT CPU generator (``torch.manual_seed``): per epoch one int64 draw (the DataLoader iterator's
         base seed) followed by ``torch.multinomial(weights.double(), len(dataset), True)``, full batches kept -- so the
         index stream equals ``list(DataLoader(ds, sampler=WeightedRandomSampler(w, len(w)), drop_last=...))`` bit for
-        bit (tests/golden/sampler.npz); the default draws on the device from the batcher's own generator."""
+        bit (tests/golden/sampler.npz); the default draws on the device from the batcher's own generator.
+        ``pair_bucket`` = w (sampler mode, models with pairs): the batch-independent plan pays for the worst case --
+        every row a pair: 3 L B decoder rows.  With buckets the epoch's batches are re-ordered pairs first (the loss is
+        a sum over rows: the order inside a batch means nothing) and every batch runs on the plan whose number of pair
+        slots is its number of pairs rounded up to a multiple of w -- a handful of plans, each captured once
+        (``prepare_epoch`` / ``select``); the decoder then runs L B + 2 L ceil_w(N_pairs) rows."""
         # a dataset shorter than one batch is ONE batch of all its rows: DataLoader(drop_last=(len >= batch_size))
         batch_size = min(batch_size, len(dataset))
         self.ds, self.batch_size = dataset, batch_size
@@ -158,6 +164,11 @@ class DeviceBatcher:
         self.gen.manual_seed(seed)
         self._idx32 = torch.zeros(batch_size, dtype=torch.int32, device=dev)
         assert generator in ('device', 'cpu') and (generator == 'device' or mode == 'sampler')
+        assert pair_bucket is None or (mode == 'sampler' and int(pair_bucket) >= 1)
+        self.pair_bucket = int(pair_bucket) if pair_bucket else None
+        self.batch_slots = None           # (bucketed) pair slots of every batch of the current epoch table
+        self._k = 0                       # (bucketed) batches handed out since begin_epoch
+        self.n_switch = 0                 # (bucketed) how many times a step ran on another plan than the one before
         self.cpu_stream = generator == 'cpu'
         if mode == 'sampler':
             self.weights = w.float()
@@ -184,6 +195,8 @@ class DeviceBatcher:
         if self.mode == 'sampler':
             assert counts is None, 'the exact sampler composes batches per rank: use mode="stratified" under data parallelism'
             engine.universal = True
+            if self.pair_bucket and not engine.cfg.has_pert:
+                self.pair_bucket = None                      # (no pairs in this model: nothing to bucket)
             return engine.set_structure_universal(self.batch_size)
         engine.set_structure(self.has_x2, self.has_y, counts)
         return engine.plan
@@ -221,14 +234,65 @@ class DeviceBatcher:
                 draws = torch.cat(rows)[:n_b].to(fd.table.device)
             else:
                 draws = torch.multinomial(self.weights, n_b * self.batch_size, replacement=True, generator=self.gen)
-            fd.table.copy_(draws.reshape(n_b, self.batch_size))
+            tab = draws.reshape(n_b, self.batch_size)
+            if self.pair_bucket:
+                # pairs first inside every batch (stable), and how many each batch has -- the epoch's ONE host sync
+                hx = self.hx32[tab.long()]
+                order = torch.argsort(-hx, dim=1, stable=True)
+                tab = tab.gather(1, order)
+                w = self.pair_bucket
+                npairs = hx.sum(1).cpu().numpy()
+                self.batch_slots = np.clip(((npairs + w - 1) // w) * w, min(w, self.batch_size), self.batch_size).astype(np.int64)
+                self._k = 0
+            fd.table.copy_(tab)
             fd.base.copy_(eng.step_dev)
+            if self.pair_bucket:                 # the same table feeds whichever of the bucket plans a batch runs on
+                self._feed = fd
+                for slots in sorted(set(self.batch_slots.tolist()) | {self.batch_size}):
+                    q = eng.set_structure_universal(self.batch_size, slots)
+                    q.feed, q.feed_active = fd, True
+                eng.set_structure_universal(self.batch_size, int(self.batch_slots[0]))
             return fd.table
         parts = [m[torch.multinomial(w, c * n_b, replacement=True, generator=self.gen)].reshape(n_b, c)
                  for m, w, c in zip(self.members, self.gweights, self.group_counts) if c > 0]
         fd.table.copy_(torch.cat(parts, 1))
         fd.base.copy_(eng.step_dev)         # device to device: batch index = optimiser step - base
         return fd.table
+
+    def prepare_epoch(self, capture):
+        """(bucketed sampler feed) capture the plans this epoch's batches run on that are not captured yet --
+        ``capture(engine)`` is called with each selected (a handful per run, ~0.1 s each, in the first epochs only) --
+        and the every-row-may-be-a-pair plan, which serves any batch"""
+        if not self.pair_bucket:
+            return
+        eng = self.engine
+        for slots in sorted(set(self.batch_slots.tolist()) | {self.batch_size}):
+            p = eng.set_structure_universal(self.batch_size, int(slots))
+            if not eng.use_capture(p.key):
+                capture(eng)
+                eng.stash_capture()
+        self.select(0)
+
+    def select(self, k=None):
+        """(bucketed sampler feed) make the plan of the epoch's batch ``k`` (default: the next one) current -- the
+        smallest captured one with room for the batch's pairs; the caller replays right after.  Without buckets:
+        nothing to do."""
+        if not self.pair_bucket:
+            return
+        if k is None:
+            k = self._k
+        self._k = k + 1
+        eng, w = self.engine, self.pair_bucket
+        slots = int(self.batch_slots[min(k, len(self.batch_slots) - 1)])
+        cur = eng.plan
+        while True:
+            p = eng.set_structure_universal(self.batch_size, slots)
+            if eng.use_capture(p.key):
+                self.n_switch += p is not cur
+                return
+            if slots >= self.batch_size:
+                raise RuntimeError('DeviceBatcher: no captured step for this feed (call prepare_epoch after begin_epoch)')
+            slots = min(slots + w, self.batch_size)
 
     def _reference_epoch(self):
         """(len(self), batch_size) int64 on the host: one epoch of the reference's loader, drawn from torch's default

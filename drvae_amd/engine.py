@@ -188,6 +188,7 @@ class FusedStep(StepSchedule):
         # one batch-independent plan (and one captured graph) for ANY composition of pairs / labels in the batch:
         # group membership becomes device-side masks (see ``_Plan.universal``); costs the rows of the worst case
         self.universal = False
+        self.universal_pair_slots = None      # (set_batch on the universal plan) only the first so many rows may be pairs
         self.plan = None
         self._plans = {}                    # plans by batch structure (a handful of signatures in practice)
         self.max_plans = 8
@@ -291,15 +292,20 @@ class FusedStep(StepSchedule):
         cfg = self.cfg
         return not cfg.cont and not (cfg.kind == 'vfae' and not cfg.semi_supervised) and not cfg.use_s
 
-    def set_structure_universal(self, n_rows):
-        """Select (or build) the batch-independent plan for ``n_rows`` rows."""
+    def set_structure_universal(self, n_rows, n_pair_slots=None):
+        """Select (or build) the batch-independent plan for ``n_rows`` rows.  ``n_pair_slots`` < n_rows: only the FIRST
+        so many rows of a batch have pair slots (x2 row, z2 / z2Fz1 sample rows) -- for feeds that put a batch's pairs
+        first and choose the plan by the batch's number of pairs (``DeviceBatcher(mode='sampler', pair_bucket=...)``):
+        the decoder then runs L*B + 2*L*n_pair_slots rows instead of 3*L*B."""
         cfg = self.cfg
         assert self.universal_ok(), 'universal plan: discrete labels, semi-supervised models'
-        key = ('universal', n_rows, self.row0)
+        nps = n_rows if (n_pair_slots is None or not cfg.has_pert) else int(n_pair_slots)
+        assert 0 <= nps <= n_rows
+        key = ('universal', n_rows, self.row0) if nps == n_rows else ('universal', n_rows, self.row0, nps)
         if self.plan is None or self.plan.key != key:
             self.plan = self._plans.get(key)
             if self.plan is None:
-                ones, zeros = np.ones(n_rows, bool), np.zeros(n_rows, bool)
+                ones, zeros = np.arange(n_rows) < nps, np.zeros(n_rows, bool)
                 self.plan = self._plans[key] = _Plan(self, np.arange(n_rows), ones if cfg.has_pert else zeros, zeros,
                                                       None, key, universal=True)
                 if cfg.has_y:
@@ -313,7 +319,7 @@ class FusedStep(StepSchedule):
         for old in list(self._plans):
             if len(self._plans) <= self.max_plans:
                 break
-            if old != keep and old != getattr(self, '_graph_key', None):
+            if old != keep and old != getattr(self, '_graph_key', None) and old not in getattr(self, '_captures', {}):
                 del self._plans[old]
 
     def set_structure(self, has_x2, has_y, counts=None):
@@ -357,7 +363,7 @@ class FusedStep(StepSchedule):
         cfg = self.cfg
         if self.universal and counts is None and self.universal_ok():
             hy = np.asarray(has_y.cpu() if torch.is_tensor(has_y) else has_y).reshape(-1)
-            p = self.set_structure_universal(len(hy))
+            p = self.set_structure_universal(len(hy), self.universal_pair_slots)
             p.feed_active = False
             p.XSRC[:p.B].copy_(x1)
             i32 = lambda a: torch.as_tensor(np.asarray(a.cpu() if torch.is_tensor(a) else a).reshape(-1).astype(np.int32))
@@ -368,6 +374,7 @@ class FusedStep(StepSchedule):
                     p.XSRC[p.B:].zero_()
                     p.hx_dev.zero_()
                 else:
+                    assert p.Np == p.B or not np.asarray(i32(has_x2))[p.Np:].any(), 'a pair beyond the plan\'s pair slots'
                     p.XSRC[p.B:].copy_(x2)
                     p.hx_dev.copy_(i32(has_x2))
             if cfg.has_y:
@@ -459,18 +466,20 @@ class FusedStep(StepSchedule):
         else:
             # ---- inputs (+ training noise N(0,1)*add_noise_var, src/DrVAE.py:404-407,414-417): one gather
             fd = p.live_feed if (self.fuse_bwd and self.training) else None
+            masks = None
             if p.universal:
-                # which rows of THIS batch are pairs / labeled -> coefficient and weight vectors, on the device
-                K.batch_masks(B, L, n_tot=float(B), kl_rate=cfg.kl_qz2pz2_rate, pert_rate=cfg.pertloss_rate,
-                              yl_rate=cfg.yloss_rate, beta=p.beta_dev, c_nll=p.c_nll, w_recl=p.w_recl,
-                              hx=(fd.hx32 if fd is not None else p.hx_dev) if cfg.has_pert else None,
-                              hy=(fd.hy32 if fd is not None else p.hy_dev) if cfg.has_y else None,
-                              y=(fd.y32 if fd is not None else p.y_dev) if cfg.has_y else None,
-                              c_klz2=p.c_klz2 if cfg.has_pert else None, c_yl=p.c_yl, w_pert=p.w_pert, w_yl=p.w_yl,
-                              label=p.label_r if cfg.has_y else None, c_klp=p.c_klp if cfg.kind == 'pvae' else None,
-                              table=fd.table if fd is not None else None,
-                              n_batches=fd.n_batches if fd is not None else 0,
-                              ctr=self.step_dev if fd is not None else None, base=fd.base if fd is not None else None)
+                # which rows of THIS batch are pairs / labeled -> coefficient and weight vectors, on the device (with
+                # the graph-resident feed: by one more workgroup of the feed's launch)
+                masks = dict(n_tot=float(B), kl_rate=cfg.kl_qz2pz2_rate, pert_rate=cfg.pertloss_rate,
+                             yl_rate=cfg.yloss_rate, beta=p.beta_dev, c_nll=p.c_nll, w_recl=p.w_recl,
+                             hx=(fd.hx32 if fd is not None else p.hx_dev) if cfg.has_pert else None,
+                             hy=(fd.hy32 if fd is not None else p.hy_dev) if cfg.has_y else None,
+                             y=(fd.y32 if fd is not None else p.y_dev) if cfg.has_y else None,
+                             c_klz2=p.c_klz2 if cfg.has_pert else None, c_yl=p.c_yl, w_pert=p.w_pert, w_yl=p.w_yl,
+                             label=p.label_r if cfg.has_y else None, c_klp=p.c_klp if cfg.kind == 'pvae' else None,
+                             Np=Np if cfg.has_pert else 0)
+                if fd is None:
+                    K.batch_masks(B, L, **masks)
             if fd is not None:
                 # batch (optimiser step - epoch base) of the epoch's index table, straight from the
                 # HBM-resident dataset; also refreshes the label-dependent index buffers
@@ -483,7 +492,7 @@ class FusedStep(StepSchedule):
                              onehot=p.Z3IN[:, cfg.dim_z3:] if (lab and p.Mf) else None, n_classes=cfg.dim_y,
                              onehot2=p.FPIN[:, Z1:] if (lab and p.Mf) else None,
                              yf=fd.yf if (cfg.has_y and cfg.cont) else None,
-                             ylab=p.ylab if (cfg.has_y and cfg.cont) else None)
+                             ylab=p.ylab if (cfg.has_y and cfg.cont) else None, masks=masks)
             else:
                 K.rows_gather(p.XIN, p.XSRC, p.xin_idx, noise=p.EX if sigma else None, sigma=sigma)
             # ---- q(z1|x1), q(z2|x2): one pass of the shared encoder; the samples (src/blocks.py:170-174) -- z1
@@ -741,7 +750,7 @@ class FusedStep(StepSchedule):
         if p.universal:      # normalisers and group masks are per-row weights written by dv_batch_masks
             terms = [(nll[:p.o3], p.w_recl[:p.o3], 1.0, 0, rl)]
             if cfg.has_pert:
-                terms.append((nll[p.o3:], p.w_pert, 1.0, 2, rl))
+                terms.append((nll[p.o3:], p.w_pert[:L * p.Np], 1.0, 2, rl))
                 terms.append((p.KLZ2, p.c_klz2, 1.0, 1))
         else:
             terms = [(nll[:p.o3], None, 1.0 / (L * p.n_tot), 0)]

@@ -225,6 +225,8 @@ class FitMixin:
         resident_feed = not eng.cfg.use_s      # (the nuisance classes travel with host-driven gathers: feed())
         if resident_feed:
             batcher.begin_epoch()           # this epoch's index table; the graph gathers batch b itself
+            if getattr(batcher, 'pair_bucket', None):
+                eng.use_capture(eng.plan.key)      # (one captured step per number-of-pairs bucket: this one's, if any)
         else:
             batcher.feed()
         if getattr(eng, '_graph_key', None) != eng.plan.key or getattr(eng, '_graph_noise', None) != eng.add_noise \
@@ -235,6 +237,13 @@ class FitMixin:
                 eng.tune_partition()        # CU split of the two launch chains, by timing (state restored)
             if resident_feed:
                 batcher.begin_epoch()       # (the tuning replays advanced the step counter: re-base the table)
+            if getattr(batcher, 'pair_bucket', None):
+                eng.stash_capture()
+        if getattr(batcher, 'pair_bucket', None):         # a plan per number-of-pairs bucket: capture the missing ones
+            def cap(e):
+                e.capture()
+                e._graph_noise = e.add_noise
+            batcher.prepare_epoch(cap)
         with eng.partition():
             return self._epoch_device_body(eng, batcher, epoch, verbose)
 
@@ -254,6 +263,8 @@ class FitMixin:
         for b in range(n_b):
             if eng.plan.live_feed is None:
                 batcher.feed()
+            else:
+                batcher.select(b)              # (bucketed sampler feed: this batch's plan; otherwise nothing)
             eng.replay(allreduce=getattr(self, '_allreduce', None))
             if not in_graph:
                 total += self._train_objective(self._loss_tensors(eng))

@@ -526,9 +526,18 @@ def rows_gather(out, src, idx=None, *, noise=None, sigma=0.0, onehot_cls=None, n
 
 def batch_feed(xin, x1, x2, y32, table, n_batches, ctr, base, *, pair_rows=None, noise=None, sigma=0.0, has_y=None,
                L=1, label_r=None, fp_i=None, fp_lab=None, fp_slot=None, fp_cls=None, onehot=None, n_classes=0, yf=None,
-               ylab=None, onehot2=None):
-    """graph-resident minibatch feed: see dv_batch_feed in include/drvae_hip.h"""
+               ylab=None, onehot2=None, masks=None):
+    """graph-resident minibatch feed: see dv_batch_feed in include/drvae_hip.h; ``masks``: keyword arguments of
+    ``batch_masks`` (minus table / ctr / base / B / L): the batch's masks written by the same launch"""
     B = table.shape[1]
+    md = None
+    if masks is not None:
+        m = dict(hx=None, hy=None, y=None, c_klz2=None, c_yl=None, w_pert=None, w_yl=None, label=None, c_klp=None, Np=None)
+        m.update(masks)
+        md = _lib.BatchMasks(_i32(m['hx']), _i32(m['hy']), _i32(m['y']), B if m['Np'] is None else m['Np'],
+                             m['n_tot'], m['kl_rate'], m['pert_rate'], m['yl_rate'], _f32(m['beta']), _f32(m['c_nll']),
+                             _f32(m['c_klz2']), _f32(m['c_yl']), _f32(m['w_recl']), _f32(m['w_pert']), _f32(m['w_yl']),
+                             _i32(m['label']), _f32(m['c_klp']))
     Np = pair_rows.numel() if pair_rows is not None else 0
     assert xin.shape[0] == B + Np and table.shape[0] == n_batches and table.is_contiguous()
     Mf = fp_cls.numel() if fp_cls is not None else 0
@@ -538,16 +547,17 @@ def batch_feed(xin, x1, x2, y32, table, n_batches, ctr, base, *, pair_rows=None,
                                          _i32(has_y), L, _i32(label_r), _i32(fp_i), _i32(fp_lab), _i32(fp_slot), Mf,
                                          _i32(fp_cls), _f32(onehot), _ld(onehot), n_classes, _f32(yf), _f32(ylab),
                                          ylab.shape[1] if ylab is not None else 0, _f32(onehot2), _ld(onehot2),
-                                         _stream()), 'dv_batch_feed')
+                                         C.byref(md) if md is not None else None, _stream()), 'dv_batch_feed')
 
 
 def batch_masks(B, L, *, n_tot, kl_rate, pert_rate, yl_rate, beta, c_nll, w_recl, hx=None, hy=None, y=None, c_klz2=None,
-                c_yl=None, w_pert=None, w_yl=None, label=None, c_klp=None, table=None, n_batches=0, ctr=None, base=None):
+                c_yl=None, w_pert=None, w_yl=None, label=None, c_klp=None, table=None, n_batches=0, ctr=None, base=None,
+                Np=None):
     """per-batch coefficient / weight vectors of a batch-independent step plan from the batch's pair / label flags
     (``dv_batch_masks``); ``hx`` / ``hy`` / ``y``: int32 device arrays indexed by dataset row (``table`` given) or by
-    batch row; ``beta``: 1-element device float"""
+    batch row; ``beta``: 1-element device float; ``Np``: rows [0, Np) have pair slots (default: all B)"""
     _lib.check(_lib.load().dv_batch_masks(_i32(table), n_batches, _i32(ctr), _i32(base), _i32(hx), _i32(hy), _i32(y), B, L,
-                                          n_tot, kl_rate, pert_rate, yl_rate, _f32(beta), _f32(c_nll), _f32(c_klz2),
+                                          B if Np is None else Np, n_tot, kl_rate, pert_rate, yl_rate, _f32(beta), _f32(c_nll), _f32(c_klz2),
                                           _f32(c_yl), _f32(w_recl), _f32(w_pert), _f32(w_yl), _i32(label), _f32(c_klp),
                                           _stream()),
                'dv_batch_masks')

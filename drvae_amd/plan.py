@@ -209,7 +209,7 @@ class _Plan:
         self.w_elbo = zf(3)
         self.w_cmpl = zf(N_LOSS)
         if self.universal:
-            assert Np == (B if cfg.has_pert else 0) and not cfg.cont
+            assert (Np <= B if cfg.has_pert else Np == 0) and not cfg.cont     # (Np < B: pairs-first feeds, bucketed)
             self.hx_dev = i32(np.zeros(B)) if cfg.has_pert else None      # flags / labels of an explicit batch
             self.hy_dev = i32(np.zeros(B)) if cfg.has_y else None
             self.y_dev = i32(np.zeros(B)) if cfg.has_y else None

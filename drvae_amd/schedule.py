@@ -77,9 +77,35 @@ class _Branch:
             torch.cuda.current_stream().wait_stream(self.side)
 
 
+# what ``capture()`` leaves on the engine: kept per plan by ``stash_capture`` / swapped back in by ``use_capture``
+_CAPTURE_STATE = ('_graphs', '_side_graph', '_split_capture', '_split_kind', 'noise_ahead', '_graph_key', '_graph_feed',
+                  '_graph_mmd_sig', '_captured_allreduce', '_graph_noise')
+
+
 class StepSchedule:
     """scheduling half of ``FusedStep`` (see the module docstring); relies on its forward / backward /
     optimizer_step / draw_noise and on its plan, arena and counters"""
+
+    # ------------------------------------------------ several captured plans side by side
+    def stash_capture(self):
+        """remember the graphs just captured for the current plan (a feed that switches between a few plans from step
+        to step -- ``DeviceBatcher(pair_bucket=...)`` -- captures each once and swaps them with ``use_capture``)"""
+        if not hasattr(self, '_captures'):
+            self._captures = {}
+        self._captures[self.plan.key] = {k: getattr(self, k, None) for k in _CAPTURE_STATE}
+
+    def use_capture(self, key):
+        """make the plan ``key`` and its captured graphs current; False when it has not been captured yet"""
+        cap = getattr(self, '_captures', {}).get(key)
+        if cap is None or cap['_graph_feed'] is not self._plans[key].live_feed or \
+                cap['_graph_noise'] not in (None, self.add_noise):
+            return False
+        if getattr(self, '_graph_key', None) != key:
+            for k, v in cap.items():
+                setattr(self, k, v)
+            self.plan = self._plans[key]
+            self._noise_stale = True         # (the side chain drew ahead into the OTHER plan's noise buffer)
+        return True
 
     def _mode(self):
         if not self.fuse_bwd:

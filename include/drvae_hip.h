@@ -30,7 +30,7 @@ extern "C" {
 
 typedef void* dv_stream_t;
 
-#define DV_ABI_VERSION 4
+#define DV_ABI_VERSION 5
 
 enum { DV_OK = 0, DV_ERR_ARG = -1, DV_ERR_LAUNCH = -2, DV_ERR_UNSUPPORTED = -3 };
 
@@ -478,12 +478,31 @@ int dv_rows_gather(const float* src, int64_t lds, const int32_t* idx, int32_t n,
  *   ylab[i,:]  = yf[table[b,i],:]   (Yc floats per row; regression targets of type_y='cont', or NULL)
  * ctr/base are DEVICE scalars (ctr = the optimiser's step counter), so the launch arguments are
  * constant and the launch can live inside the captured train-step graph. */
+/* `masks` (optional): the per-batch masks of a batch-independent plan (dv_batch_masks below, same table / ctr / base /
+ * B / L) written by one more workgroup of this launch instead of a launch of their own. */
+typedef struct dv_batch_masks_desc {
+    const int32_t* hx;
+    const int32_t* hy;
+    const int32_t* y;
+    int32_t Np;
+    float n_tot, kl_rate, pert_rate, yl_rate;
+    const float* beta;
+    float* c_nll;
+    float* c_klz2;
+    float* c_yl;
+    float* w_recl;
+    float* w_pert;
+    float* w_yl;
+    int32_t* label;
+    float* c_klp;
+} dv_batch_masks_desc;
 int dv_batch_feed(const float* x1, int64_t ld1, const float* x2, int64_t ld2, const int32_t* y, const int32_t* table,
                   int32_t n_batches, const int32_t* ctr, const int32_t* base, int32_t B, const int32_t* pair_rows,
                   int32_t Np, int32_t X, const float* noise, int64_t ldn, float sigma, float* xin, int64_t ldo,
                   const int32_t* has_y, int32_t L, int32_t* label_r, const int32_t* fp_i, const int32_t* fp_lab,
                   const int32_t* fp_slot, int32_t Mf, int32_t* fp_cls, float* onehot, int64_t ldh, int32_t Y,
-                  const float* yf, float* ylab, int32_t Yc, float* onehot2, int64_t ldh2, dv_stream_t stream);
+                  const float* yf, float* ylab, int32_t Yc, float* onehot2, int64_t ldh2,
+                  const dv_batch_masks_desc* masks, dv_stream_t stream);
 /* dst[di,:W] = beta*dst[di,:W] + sum_{t in [seg_ptr[i],seg_ptr[i+1])} w[t]*src[seg_rows[t],:W],
  * di = dst_idx?dst_idx[i]:i; seg_ptr==NULL: segment i is the single row (seg_rows?seg_rows[i]:i).
  * Deterministic (no atomics): the transpose of every gather above. */
@@ -498,9 +517,13 @@ int dv_batch_feed(const float* x1, int64_t ld1, const float* x2, int64_t ld2, co
  *   c_yl[r] = py ? -yl_rate/(L N_labeled) : 0;  w_yl[r] = 1/(L N_labeled);  label[r] = py ? -2 - y : 0
  *   c_klp[i] = 1/n_tot, c_klp[B + i] = px ? 1/n_tot : 0   (optional; B + B rows: KL to the prior of q(z1|x1) | q(z2|x2))
  * (label <= -2 is what dv_ymarg_* read as "labeled row, all class slots materialised").  hx == NULL / hy == NULL:
- * model without pairs / labels.  beta: DEVICE scalar (perturbation annealing coefficient).  One workgroup. */
+ * model without pairs / labels.  beta: DEVICE scalar (perturbation annealing coefficient).  One workgroup.
+ * Np <= B: only rows [0, Np) of the batch have pair slots (a plan with fewer x2 / z2 rows for feeds that put a
+ * batch's pairs first: DeviceBatcher(mode='sampler', pair_bucket=...)); the pair-indexed vectors then have L*Np
+ * entries, slot q = l*Np + j, and sit behind the L*B row entries: c_nll[LB + q], c_nll[LB + L*Np + q], w_recl[LB + q],
+ * w_pert[q], c_klz2[q], c_klp[B + j].  Np == B is the layout written out above. */
 int dv_batch_masks(const int32_t* table, int32_t n_batches, const int32_t* ctr, const int32_t* base, const int32_t* hx,
-                   const int32_t* hy, const int32_t* y, int32_t B, int32_t L, float n_tot, float kl_rate,
+                   const int32_t* hy, const int32_t* y, int32_t B, int32_t L, int32_t Np, float n_tot, float kl_rate,
                    float pert_rate, float yl_rate, const float* beta, float* c_nll, float* c_klz2, float* c_yl,
                    float* w_recl, float* w_pert, float* w_yl, int32_t* label, float* c_klp, dv_stream_t stream);
 int dv_rows_segment_sum(const float* src, int64_t lds, const int32_t* seg_ptr, const int32_t* seg_rows,

@@ -608,7 +608,9 @@ def rows_gather(out, src, idx=None, *, noise=None, sigma=0.0, onehot_cls=None, n
 
 def batch_feed(xin, x1, x2, y32, table, n_batches, ctr, base, *, pair_rows=None, noise=None, sigma=0.0, has_y=None,
                L=1, label_r=None, fp_i=None, fp_lab=None, fp_slot=None, fp_cls=None, onehot=None, n_classes=0, yf=None,
-               ylab=None, onehot2=None):
+               ylab=None, onehot2=None, masks=None):
+    if masks is not None:
+        batch_masks(table.shape[1], L, table=table, n_batches=n_batches, ctr=ctr, base=base, **masks)
     if ylab is not None:
         bb = min(max(int(ctr[0]) - int(base[0]), 0), n_batches - 1)
         ylab.copy_(yf.reshape(-1, ylab.shape[1])[table[bb].long()])
@@ -759,12 +761,14 @@ def counter_add(counter, inc=1):
 
 
 def batch_masks(B, L, *, n_tot, kl_rate, pert_rate, yl_rate, beta, c_nll, w_recl, hx=None, hy=None, y=None, c_klz2=None,
-                c_yl=None, w_pert=None, w_yl=None, label=None, c_klp=None, table=None, n_batches=0, ctr=None, base=None):
+                c_yl=None, w_pert=None, w_yl=None, label=None, c_klp=None, table=None, n_batches=0, ctr=None, base=None,
+                Np=None):
+    Np = B if Np is None else Np
     if c_klp is not None:
         s_ = table[min(max(int(ctr[0]) - int(base[0]), 0), n_batches - 1)].long() if table is not None else \
             torch.arange(B, device=c_nll.device)
         c_klp[:B] = 1.0 / n_tot
-        c_klp[B:2 * B] = torch.where(hx[s_] != 0, 1.0 / n_tot, 0.0) if hx is not None else 0.0
+        c_klp[B:B + Np] = torch.where(hx[s_[:Np]] != 0, 1.0 / n_tot, 0.0) if hx is not None else 0.0
     if table is not None:
         b = min(max(int(ctr[0]) - int(base[0]), 0), n_batches - 1)
         src = table[b].long()
@@ -774,13 +778,14 @@ def batch_masks(B, L, *, n_tot, kl_rate, pert_rate, yl_rate, beta, c_nll, w_recl
     c_nll[:LB] = -ct
     w_recl[:LB] = ct
     if hx is not None:
-        px = (hx[src] != 0).repeat(L)
+        LP = L * Np
+        px = (hx[src[:Np]] != 0).repeat(L)
         npair = max(float((hx[src] != 0).sum()), 1.0)
-        c_nll[LB:2 * LB] = torch.where(px, -ct, 0.0)
-        w_recl[LB:2 * LB] = torch.where(px, ct, 0.0)
-        c_nll[2 * LB:3 * LB] = torch.where(px, -bt * pert_rate / (L * npair), 0.0)
-        w_pert[:LB] = torch.where(px, 1.0 / (L * npair), 0.0)
-        c_klz2[:LB] = torch.where(px, bt * kl_rate * ct, 0.0)
+        c_nll[LB:LB + LP] = torch.where(px, -ct, 0.0)
+        w_recl[LB:LB + LP] = torch.where(px, ct, 0.0)
+        c_nll[LB + LP:LB + 2 * LP] = torch.where(px, -bt * pert_rate / (L * npair), 0.0)
+        w_pert[:LP] = torch.where(px, 1.0 / (L * npair), 0.0)
+        c_klz2[:LP] = torch.where(px, bt * kl_rate * ct, 0.0)
     if hy is not None:
         py = (hy[src] != 0).repeat(L)
         nlab = max(float((hy[src] != 0).sum()), 1.0)

@@ -144,3 +144,43 @@ def test_sampler_mode_epoch_table(monkeypatch):
     assert torch.equal(p.hx_dev.long(), ds.has_x2[idx].long()) and torch.equal(p.y_dev.long(), ds.y.reshape(-1)[idx].long())
     eng.train_step()
     assert all(np.isfinite(v) for v in eng.losses().values())
+
+
+def test_sampler_mode_pair_buckets(monkeypatch):
+    """pair_bucket: the same draws as the plain sampler feed, every batch re-ordered pairs first; every batch gets the
+    plan whose pair slots are its number of pairs rounded up to the bucket width (and the table feeds all of them)"""
+    from oracle import models_ref as M
+    from tests import kernel_ref
+    from tests.test_engine_cpu import make_engine
+    kernel_ref.install(monkeypatch)
+    spec = C.tiny_spec('drvae')
+    big = M.make_batch(spec, 100, seed=4)
+    t = lambda k: torch.from_numpy(big[k].copy())
+    ds = D.DrVAEDataset(t('x1'), t('x2'), t('s'), t('y'), t('has_x2'), t('has_y'))
+    w = D.compute_balanced_weights(np.arange(100) % 7)
+    tabs = []
+    for bucket in (None, 4):
+        eng, _ = make_engine(spec, M.init_params(spec, 3, as_numpy=True))
+        bat = D.DeviceBatcher(ds, w, 16, seed=2, mode='sampler', pair_bucket=bucket)
+        bat.bind(eng)
+        tabs.append(bat.begin_epoch().numpy().copy())
+    plain, sorted_ = tabs
+    hx = big['has_x2'].reshape(-1)
+    np.testing.assert_array_equal(np.sort(plain, 1), np.sort(sorted_, 1))
+    for k, row in enumerate(sorted_):
+        n = int(hx[row].sum())
+        assert hx[row][:n].all() and not hx[row][n:].any()
+        assert bat.batch_slots[k] == min(16, max(4, -(-n // 4) * 4))
+        # stable: pairs and singletons each keep the order they were drawn in
+        np.testing.assert_array_equal(row[:n], plain[k][hx[plain[k]] == 1])
+        np.testing.assert_array_equal(row[n:], plain[k][hx[plain[k]] == 0])
+    keys = {('universal', 16, 0) if s == 16 else ('universal', 16, 0, int(s)) for s in set(bat.batch_slots.tolist()) | {16}}
+    assert keys <= set(eng._plans) and all(eng._plans[k].live_feed is eng._plans[('universal', 16, 0)].feed for k in keys)
+    with pytest.raises(RuntimeError):
+        bat.select(0)               # nothing captured yet
+    # no pairs in the model: buckets are switched off
+    spec_v = C.tiny_spec('vfae')
+    eng_v, _ = make_engine(spec_v, M.init_params(spec_v, 3, as_numpy=True))
+    bat_v = D.DeviceBatcher(ds, w, 16, seed=2, mode='sampler', pair_bucket=4)
+    bat_v.bind(eng_v)
+    assert bat_v.pair_bucket is None

@@ -157,6 +157,38 @@ def test_universal_plan_one_plan_for_any_composition(monkeypatch):
     assert len(uni._plans) == 1
 
 
+@pytest.mark.parametrize('kind', ['drvae', 'pvae'])
+def test_universal_plan_with_pair_slots(kind, monkeypatch):
+    """the bucketed sampler feed's plans: pairs first, pair slots for the first n rows only (n >= the batch's pairs) --
+    same losses / gradients / update as the plan built for the batch's exact composition"""
+    kernel_ref.install(monkeypatch)
+    spec = C.tiny_spec(kind)
+    params = M.init_params(spec, 3, as_numpy=True)
+    uni, au = make_engine(spec, params)
+    uni.universal = True
+    for seed, (pattern, slots) in enumerate([('ccddabab', 4), ('cdcaabbb', 4), ('dcbbaabb', 2), ('aabbaabb', 2),
+                                             ('dddddddc', 8), ('cdabbbaa', 6)]):
+        batch = M.make_batch(spec, 8, seed=seed)
+        fl = {'a': (1, 0), 'b': (0, 0), 'c': (1, 1), 'd': (0, 1)}
+        batch['has_y'] = np.array([fl[c][0] for c in pattern], np.int64)
+        batch['has_x2'] = np.array([fl[c][1] for c in pattern], np.int64)
+        batch['x2'] = batch['x2'] * batch['has_x2'][:, None].astype(np.float32)
+        noise = M.make_noise(spec, 8, seed=10 + seed)
+        one, a1 = make_engine(spec, params)
+        a1.param.copy_(au.param); a1.exp_avg.copy_(au.exp_avg); a1.exp_avg_sq.copy_(au.exp_avg_sq)
+        one.step_dev.copy_(uni.step_dev); one.iters = uni.iters
+        uni.universal_pair_slots = slots
+        for e in (uni, one):
+            p = set_batch(e, batch)
+            e.train_step(noise)
+        assert uni.plan.universal and uni.plan.Np == slots and uni.plan.DPX.shape[0] == uni.cfg.L * (8 + 2 * slots)
+        for (k, a), b in zip(uni.losses().items(), one.losses().values()):
+            close(a, b, 2e-5, 2e-6)
+        close(au.grad, a1.grad.numpy(), 2e-4, 1e-6)
+        close(au.param, a1.param.numpy(), 1e-5, 1e-6)
+    assert len(uni._plans) == 4
+
+
 def _use_s_case(kind, use_mmd, seed=0):
     spec = C.tiny_spec(kind, use_s=True, dim_s=2, use_MMD=use_mmd, mmd_rate=0.7, kernel_MMD='identity')
     for sd in range(seed, seed + 50):      # every data group must hold both nuisance classes (no random fill-in row)

@@ -1065,6 +1065,31 @@ def test_batch_masks_and_labeled_slots(K, dev):
         for k in a:
             close(a[k].float(), b[k].float(), rtol=1e-6, atol=1e-9)
     assert int((outs[1]['label'] <= -2).sum()) == int(hy[table[2].long()].sum()) * L
+    # pair slots for the first Np rows only (pairs-first feeds), standalone and riding on the feed's launch
+    Np, X = 16, 12
+    x1, x2 = rnd(dev, 200, X, seed=11), rnd(dev, 200, X, seed=12)
+    pair_rows = torch.arange(Np, dtype=torch.int32, device=dev)
+    got = []
+    for Lb in (K, R, 'feed'):
+        bufs = dict(c_nll=torch.full((L * (B + 2 * Np),), 9.0, device=dev), c_klz2=torch.full((L * Np,), 9.0, device=dev),
+                    c_yl=torch.full((L * B,), 9.0, device=dev), w_recl=torch.full((2 * L * B,), 9.0, device=dev),
+                    w_pert=torch.full((L * B,), 9.0, device=dev), w_yl=torch.full((L * B,), 9.0, device=dev),
+                    label=torch.full((L * B,), 9, dtype=torch.int32, device=dev), c_klp=torch.full((2 * B,), 9.0, device=dev))
+        kw = dict(n_tot=float(B), kl_rate=0.7, pert_rate=0.05, yl_rate=1.3, beta=beta, hx=hx, hy=hy, y=y, Np=Np, **bufs)
+        if Lb == 'feed':
+            xin, rin = torch.zeros(B + Np, X, device=dev), torch.zeros(B + Np, X, device=dev)
+            K.batch_feed(xin, x1, x2, y, table, 5, ctr, base, pair_rows=pair_rows, L=L, masks=kw)
+            R.batch_feed(rin, x1, x2, y, table, 5, ctr, base, pair_rows=pair_rows, L=L)
+            assert torch.equal(xin, rin)
+        else:
+            Lb.batch_masks(B, L, table=table, n_batches=5, ctr=ctr, base=base, **kw)
+        got.append(bufs)
+    for k in got[0]:
+        close(got[0][k].float(), got[1][k].float(), rtol=1e-6, atol=1e-9)
+        assert torch.equal(got[0][k], got[2][k]), k
+    px = hx[table[2].long()][:Np].bool()
+    assert torch.equal(got[0]['c_klz2'].reshape(L, Np) != 0, px.expand(L, Np))
+    assert (got[0]['w_recl'][L * B + L * Np:] == 9.0).all() and (got[0]['c_klp'][B + Np:] == 9.0).all()
     # ymarg with materialised class slots
     Rr = L * B
     qy = torch.softmax(rnd(dev, Rr, Y, seed=1), 1)

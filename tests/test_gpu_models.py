@@ -388,6 +388,46 @@ def test_universal_plan_matches_reference_gpu(name, dev):
             np.testing.assert_allclose(a, gold['param%d/%s' % (nsteps - 1, k)], rtol=2e-4, atol=5e-5)
 
 
+@pytest.mark.parametrize('kind', ['drvae', 'pvae'])
+def test_sampler_mode_pair_buckets_gpu(kind, dev):
+    """N2, mode='sampler' with pair_bucket: batches re-ordered pairs first, each replayed on the captured plan of its
+    number-of-pairs bucket (a few graphs, switched from step to step; plans first met in the second epoch are captured
+    then) -- bitwise the eager steps of the same plans handed the same rows explicitly."""
+    from drvae_amd import data as D
+    from tests.test_engine_cpu import make_engine
+    spec = M.ModelSpec(kind=kind, L=2)
+    params = M.init_params(spec, 3, as_numpy=True)
+    big = M.make_batch(spec, 640, seed=9)
+    t = lambda k: torch.from_numpy(big[k].copy())
+    ds = D.DrVAEDataset(t('x1'), t('x2'), t('s'), t('y'), t('has_x2'), t('has_y')).to(dev)
+    w = D.compute_balanced_weights(np.arange(640) % 7)
+    bat = D.DeviceBatcher(ds, w, 64, seed=5, mode='sampler', pair_bucket=4)
+    fed, a1 = make_engine(spec, params, dev)
+    eager, a0 = make_engine(spec, params, dev)
+    eager.universal = True
+    bat.bind(fed)
+    used, n_cap = set(), []
+    for epoch in range(2):
+        tab = bat.begin_epoch(n_batches=5).clone()
+        bat.prepare_epoch(lambda e: (n_cap.append(e.plan.key), e.capture()))
+        for k in range(5):
+            bat.select(k)
+            used.add(fed.plan.key)
+            fed.replay()
+            i = tab[k].long()
+            hx, hy = ds.has_x2[i].cpu().numpy(), ds.has_y[i].cpu().numpy()
+            n = int(hx.sum())
+            assert hx[:n].all() and n <= fed.plan.Np < n + 4 or fed.plan.Np == 4
+            eager.universal_pair_slots = fed.plan.Np
+            eager.set_batch(ds.x1[i], ds.x2[i], ds.y[i].cpu(), hx, hy)
+            eager.train_step()
+    torch.cuda.synchronize()
+    assert len(used) > 1 and len(n_cap) == len(set(n_cap)) and used <= set(n_cap)
+    assert eager.losses() == fed.losses()
+    assert torch.equal(a0.param, a1.param)
+    fed.check_sync()
+
+
 @pytest.mark.parametrize('kind', ['drvae', 'pvae', 'vfae'])
 def test_sampler_mode_epoch_in_one_graph(kind, dev):
     """N2, mode='sampler': an epoch of WeightedRandomSampler-style batches (i.i.d. rows, any group mix per batch) is

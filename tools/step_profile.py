@@ -28,6 +28,15 @@ def main():
     wl = sys.argv[1] if len(sys.argv) > 1 else 'cfg2'
     dev = torch.device('cuda:0')
     cfg, eng, arena, batch, desc = bench.build(wl, dev, 0, 1)
+    if len(sys.argv) > 2 and sys.argv[2].startswith('universal'):
+        # the batch-independent plan of the sampler feed on the same batch (universal:N = N pair slots, pairs first)
+        import numpy as np
+        hx = batch['has_x2'].astype(bool)
+        order = np.argsort(~hx, kind='stable')
+        t = lambda k: torch.from_numpy(batch[k][order]).to(dev)
+        eng.universal = True
+        eng.universal_pair_slots = int(sys.argv[2].split(':')[1]) if ':' in sys.argv[2] else None
+        eng.set_batch(t('x1'), t('x2'), batch['y'][order], hx[order], batch['has_y'][order])
     eng.train_step()
     rec = []
     main_stream = torch.cuda.current_stream().cuda_stream

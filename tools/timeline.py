@@ -9,7 +9,9 @@ rows.sort(key=lambda r: int(r['Start_Timestamp']))
 names = [r['Kernel_Name'] for r in rows]
 # one period of the replayed step: from one input gather of the main chain to the next (the Philox draw is no
 # anchor any more: it belongs to the previous step's side chain); take the last complete one before the tail
-gath = [i for i, n in enumerate(names) if 'rows_gather' in n or 'batch_feed' in n]
+gath = [i for i, n in enumerate(names) if 'batch_feed' in n]            # (graph-resident feeds)
+if len(gath) < 8:
+    gath = [i for i, n in enumerate(names) if 'rows_gather' in n or 'batch_feed' in n]
 grids = [rows[i].get('Grid_Size', rows[i].get('Grid_Size_X', '0')) for i in gath]
 big = max(grids, key=lambda g: int(g)) if grids else '0'
 starts = [i for i, g in zip(gath, grids) if g == big][:-3]
