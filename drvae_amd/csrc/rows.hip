@@ -2195,7 +2195,7 @@ extern "C" int dv_loss_assemble_after(int32_t* flag, const int32_t* ctr, int32_t
                                       float* accum, dv_stream_t stream) {
     DV_REQUIRE(n_halt >= 0 && (halt || n_halt == 0));
     DV_REQUIRE(n_terms >= 0 && n_terms <= DV_MAX_LOSS_TERMS && (terms || n_terms == 0));
-    DV_REQUIRE(w_elbo && w_cmpl && loss && flag && ctr && err && max_spins > 0);
+    DV_REQUIRE(w_elbo && w_cmpl && loss && (!flag || (ctr && err && max_spins > 0)));     // flag == NULL: no wait
     DV_REQUIRE((!c1 || n1 == 1 || n1 == 2) && (!c2 || n2 == 1 || n2 == 2));
     CounterBump bump{{c1, c2}, {n1, n2}, {inc1, inc2}};
     LossTerms lt;

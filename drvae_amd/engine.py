@@ -233,6 +233,9 @@ class FusedStep(StepSchedule):
         self.add_noise = True               # `fit(add_noise=...)` flag of the reference (src/DrVAE.py:769)
         # classifier/fprop chain || decoder chain.  PVAE's side chain is one tiny KL kernel: a second stream
         # costs it far more than it hides (measured 0.19 ms single-stream vs 0.9 ms forked), so it runs serial
+        # (models without a classifier have no second chain: a graph branch for the step's leaf work alone -- two KL row
+        # launches, the loss scalars -- was measured: the main chain shrinks by 18 us, the fork/join costs as much;
+        # PVAE cfg 1: 0.1742 -> 0.1763 ms)
         self.branch = _Branch(self.dev, enabled=concurrent and cfg.has_y)
         self.wbranch = _Branch(self.dev, enabled=concurrent and bool(T.get('wbranch')))   # measured slower on MI355X (third graph branch): off
         self._build_layers()
@@ -739,7 +742,7 @@ class FusedStep(StepSchedule):
         # CMPL = ... - mmd_rate * MMD_sum / N_total  (src/DrVAE.py:616,623-624)
         p.DZMMD.copy_(z.grad * (-cfg.mmd_rate / p.n_tot))
 
-    def _loss_scalars(self, after=None, terms_elsewhere=False):
+    def _loss_scalars(self, after=None, terms_elsewhere=False, bump_counters=False):
         """RECL, KLD, PERT, YL, ELBO, CMPL (src/DrVAE.py:611-624) as device scalars.  ``terms_elsewhere``
         (with ``after``): this launch only parks on the flag and advances the counters; the caller has another
         chain assemble the scalars (they are a leaf of the step: only the host reads them)."""
@@ -766,7 +769,7 @@ class FusedStep(StepSchedule):
         if p.DZMMD is not None:
             terms.append((p.MMDval, None, 1.0 / p.n_tot, 4))
         bump = ()
-        if after is not None:     # dual-graph train step: this launch also advances the step / Philox counters
+        if after is not None or bump_counters:     # this launch also advances the step / Philox counters
             bump = [(self.step_dev, 1)] + ([(self.rng_ctr, self._rng_pending)] if getattr(self, '_rng_pending', 0) else [])
             self._rng_pending = 0
             self._ctr_bumped = True
@@ -974,8 +977,8 @@ class FusedStep(StepSchedule):
         elif mode == 5:    # the launch that assembles the loss scalars also parks on the side chain's flag
             self._loss_scalars(after=(self.flags[1:2], self.step_dev, self.sync_err[0:2], 1, K.WAIT_SPINS),
                                terms_elsewhere=side_loss)
-        elif mode == 3:
-            self._loss_scalars()
+        elif mode == 3:         # (the step / Philox counters ride on this launch: two launches less in front of the optimiser)
+            self._loss_scalars(bump_counters=True)
         if mode == 5 and late and not split_kind:      # (the step counter is advanced before the optimiser launch: counter + 0 by then)
             lc = self.L_clf[0]
             lo = min(lc.dW.storage_offset(), lc.db.storage_offset()) - g0

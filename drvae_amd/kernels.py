@@ -600,7 +600,7 @@ def col_moments(out, x, r):
 def loss_assemble(loss, terms, w_elbo, w_cmpl, after=None, bump=(), halt=None, accum=None):
     """terms: list of (x, w_or_None, scale, out_index); see ``dv_loss_assemble``.  ``after`` =
     (flag, counter, err, add, max_spins): park like ``flag_wait`` inside the same launch first;
-    ``bump`` (with ``after`` only) = up to two (counter, inc): advanced at the end of the launch;
+    ``bump`` = up to two (counter, inc): advanced at the end of the launch;
     ``halt``: the (err, ticks) pairs of the step's waits -- any error set: the scalars come out NaN;
     ``accum`` (8 floats): running sums, ``accum += loss`` in the same launch."""
     hp, hn = _halt(halt)
@@ -609,6 +609,8 @@ def loss_assemble(loss, terms, w_elbo, w_cmpl, after=None, bump=(), halt=None, a
         x, w, scale, out = term[:4]
         arr[i].x, arr[i].w, arr[i].n, arr[i].scale, arr[i].out = _f32(x), _f32(w), x.numel(), scale, out
         arr[i].row_len = term[4] if len(term) > 4 else 1
+    if after is None and bump:
+        after = (None, None, None, 0, 1)      # no wait: only the counters ride on the launch
     if after is None:
         _lib.check(_lib.load().dv_loss_assemble(arr, len(terms), _f32(w_elbo), _f32(w_cmpl), _f32(loss), hp, hn,
                                                 _f32(accum), _stream()), 'dv_loss_assemble')

@@ -563,7 +563,8 @@ int dv_loss_assemble(const dv_loss_term* terms, int32_t n_terms, const float* w_
  * of another chain are read only after the wait; saves the separate wait launch), and last advances up
  * to two device counters like dv_counters_add2 (c1 / c2 may be NULL; c1 may alias ctr: it is read before;
  * saves the counter launch in front of the optimiser).  With n_terms == 0 `loss` is left untouched: the launch
- * only parks and advances the counters (another chain assembles the scalars) */
+ * only parks and advances the counters (another chain assembles the scalars).  flag == NULL: no wait (ctr / err /
+ * max_spins unused): the launch assembles the scalars and advances the counters */
 int dv_loss_assemble_after(int32_t* flag, const int32_t* ctr, int32_t add, int32_t* err, int32_t max_spins,
                            const dv_loss_term* terms, int32_t n_terms, const float* w_elbo, const float* w_cmpl,
                            float* loss, int32_t* c1, int32_t n1, int64_t inc1, int32_t* c2, int32_t n2,
