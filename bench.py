@@ -378,7 +378,8 @@ def measure(args, workload, feed, steps, warmup, device, rank, world, steady_s=0
         gc = [int(((hy == bool(gy)) & (hx == bool(gx))).sum()) for (gy, gx) in DD._GROUPS]
         if feed == 'sampler':
             bat = DD.DeviceBatcher(ds, torch.ones(args.dataset_rows), rows, seed=5 + rank, mode='sampler',
-                                   pair_bucket=args.pair_bucket or None)
+                                   pair_bucket=args.pair_bucket or None,
+                                   label_bucket=(max(8, rows // 3 // 8 * 8) if args.label_bucket < 0 else args.label_bucket) or None)
             bat.bind(eng)
         else:
             bat = DD.DeviceBatcher(ds, torch.ones(args.dataset_rows), rows, group_counts=gc, seed=5 + rank)
@@ -392,7 +393,7 @@ def measure(args, workload, feed, steps, warmup, device, rank, world, steady_s=0
         """graph-resident feeds: a fresh index table that covers the next ``n`` replays (the feed clamps past its
         end: a region longer than the table would re-train on the last batch instead of a fresh draw per step)"""
         if bat is not None and feed in ('epoch', 'sampler'):
-            bat.begin_epoch(n_batches=n_table[0] if bat.pair_bucket else n + 8)
+            bat.begin_epoch(n_batches=n_table[0] if bat.bucketed else n + 8)
             bat.select(0)                # (bucketed: the first batch's plan; rare new buckets run on the next larger plan)
     if use_graph:
         # one exchange between two graphs by default; --dp-exchange overlap: two overlapped pieces between three
@@ -410,7 +411,7 @@ def measure(args, workload, feed, steps, warmup, device, rank, world, steady_s=0
                 dp_mode = dp
         if dp_mode != 'captured':
             eng.capture(split_for_allreduce=dp_mode)
-        if bat is not None and bat.pair_bucket:
+        if bat is not None and bat.bucketed:
             # one captured step per number-of-pairs bucket of the table's batches; each replay picks its batch's
             eng.stash_capture()
             bat.prepare_epoch(lambda e: e.capture(split_for_allreduce=dp_mode))
@@ -420,7 +421,7 @@ def measure(args, workload, feed, steps, warmup, device, rank, world, steady_s=0
             def step():
                 bat.feed()
                 eng.replay(allreduce)
-        elif bat is not None and bat.pair_bucket:
+        elif bat is not None and bat.bucketed:
             def step():
                 bat.select()
                 eng.replay(allreduce)
@@ -475,7 +476,7 @@ def measure(args, workload, feed, steps, warmup, device, rank, world, steady_s=0
         dt2 = over_ranks(time.perf_counter() - t1)
         steady = {'steps': n2, 'seconds': round(dt2, 3), 'ms_per_step': round(1e3 * dt2 / n2, 4),
                   'value': round(world * rows * L * n2 / dt2, 1)}
-    if bat is not None and getattr(bat, 'pair_bucket', None):
+    if bat is not None and getattr(bat, 'bucketed', False):
         print('bench.py: sampler feed, %d captured plans, %d plan switches' % (len(eng._captures), bat.n_switch), file=sys.stderr)
     losses = eng.losses()                  # (of the last measured step: read before the probe below trains on)
     exchange = None
@@ -574,6 +575,9 @@ def main():
     ap.add_argument('--pair-bucket', type=int, default=16,
                     help="--feed sampler: batches are re-ordered pairs first and run on the plan whose pair slots are "
                          "the batch's number of pairs rounded up to a multiple of this (0: one plan sized for B pairs)")
+    ap.add_argument('--label-bucket', type=int, default=-1,
+                    help="--feed sampler: the same for the labels -- rows a batch's plan knows to be labeled get one "
+                         "fprop row instead of one per class (0: off; default: about a third of the batch)")
     ap.add_argument('--feed', default='resident', choices=['resident', 'batcher', 'epoch', 'sampler'],
                     help='resident: one batch parked in HBM (default); batcher: a fresh stratified minibatch drawn on '
                          'the device from an HBM-resident dataset before every step (host-driven gathers); epoch: the '

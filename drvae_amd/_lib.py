@@ -67,7 +67,7 @@ class BatchMasks(C.Structure):   # dv_batch_masks_desc
                 ('n_tot', C.c_float), ('kl_rate', C.c_float), ('pert_rate', C.c_float), ('yl_rate', C.c_float),
                 ('beta', C.c_void_p), ('c_nll', C.c_void_p), ('c_klz2', C.c_void_p), ('c_yl', C.c_void_p),
                 ('w_recl', C.c_void_p), ('w_pert', C.c_void_p), ('w_yl', C.c_void_p), ('label', C.c_void_p),
-                ('c_klp', C.c_void_p)]
+                ('c_klp', C.c_void_p), ('one_slot', C.c_void_p)]
 
 
 class LossTerm(C.Structure):
@@ -128,7 +128,7 @@ SIGNATURES = {
     'dv_rows_gather': [_p, _i64, _p, _i32, _i32, _p, _i64, _f, _p, _i32, _p, _i64, C.POINTER(Wait), _p],
     'dv_batch_feed': [_p, _i64, _p, _i64, _p, _p, _i32, _p, _p, _i32, _p, _i32, _i32, _p, _i64, _f, _p, _i64, _p, _i32,
                       _p, _p, _p, _p, _i32, _p, _p, _i64, _i32, _p, _p, _i32, _p, _i64, C.POINTER(BatchMasks), _p],
-    'dv_batch_masks': [_p, _i32, _p, _p, _p, _p, _p, _i32, _i32, _i32, _f, _f, _f, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
+    'dv_batch_masks': [_p, _i32, _p, _p, _p, _p, _p, _i32, _i32, _i32, _f, _f, _f, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     'dv_rows_segment_sum': [_p, _i64, _p, _p, _p, _i32, _i32, _p, _p, _i64, _f, C.POINTER(Wait), _p],
     'dv_weighted_sum': [_p, _p, _p, _i32, _f, _p, _f, _p],
     'dv_recon_row_stats': [_p, _i64, _p, _i64, _i32, _i32, _p, _p],
@@ -150,7 +150,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 5     # DV_ABI_VERSION of include/drvae_hip.h
+ABI_VERSION = 6     # DV_ABI_VERSION of include/drvae_hip.h
 
 
 def load():

@@ -1162,6 +1162,7 @@ struct MaskArgs {
     float* w_yl;      // (L B)
     int32_t* label;   // (L B): -2 - class for labeled rows, 0 otherwise (see ymarg_*_kernel)
     float* c_klp;     // (2 B), optional: KL-to-prior rows of q(z1|x1) | q(z2|x2) (PVAE, src/PVAE.py:330-345)
+    const int32_t* one_slot;   // (B), optional: rows of the plan with ONE class slot (labeled for sure): label = class
 };
 
 __device__ __forceinline__ void batch_masks_body(const MaskArgs& a) {
@@ -1210,7 +1211,7 @@ __device__ __forceinline__ void batch_masks_body(const MaskArgs& a) {
         if (a.hy) {
             a.c_yl[r] = py ? -a.yl_rate / (Lf * n_lab) : 0.f;
             a.w_yl[r] = 1.f / (Lf * n_lab);
-            a.label[r] = py ? -2 - a.y[src] : 0;
+            a.label[r] = (a.one_slot && a.one_slot[i]) ? a.y[src] : (py ? -2 - a.y[src] : 0);
         }
     }
     if (a.c_klp)
@@ -2075,7 +2076,7 @@ extern "C" int dv_batch_feed(const float* x1, int64_t ld1, const float* x2, int6
         DV_REQUIRE(m.hx == nullptr || (m.c_klz2 && m.w_pert));
         DV_REQUIRE(m.hy == nullptr || (m.y && m.c_yl && m.w_yl && m.label));
         ma = MaskArgs{table, n_batches, ctr, base, m.hx, m.hy, m.y, B, L, m.Np, m.n_tot, m.kl_rate, m.pert_rate, m.yl_rate,
-                      m.beta, m.c_nll, m.c_klz2, m.c_yl, m.w_recl, m.w_pert, m.w_yl, m.label, m.c_klp};
+                      m.beta, m.c_nll, m.c_klz2, m.c_yl, m.w_recl, m.w_pert, m.w_yl, m.label, m.c_klp, m.one_slot};
     }
     const int feed_blocks = row_blocks + lab_blocks;
     hipLaunchKernelGGL(batch_feed_kernel, dim3(feed_blocks + (masks ? 1 : 0)), dim3(256), 0, ST(stream), x1, ld1, x2, ld2,
@@ -2089,13 +2090,13 @@ extern "C" int dv_batch_masks(const int32_t* table, int32_t n_batches, const int
                               const int32_t* hx, const int32_t* hy, const int32_t* y, int32_t B, int32_t L, int32_t Np,
                               float n_tot, float kl_rate, float pert_rate, float yl_rate, const float* beta,
                               float* c_nll, float* c_klz2, float* c_yl, float* w_recl, float* w_pert, float* w_yl,
-                              int32_t* label, float* c_klp, dv_stream_t stream) {
+                              int32_t* label, float* c_klp, const int32_t* one_slot, dv_stream_t stream) {
     DV_REQUIRE(B >= 1 && L >= 1 && Np >= 0 && Np <= B && n_tot > 0.f && c_nll && w_recl);
     DV_REQUIRE(table == nullptr || (ctr && base && n_batches >= 1));
     DV_REQUIRE(hx == nullptr || (c_klz2 && w_pert));
     DV_REQUIRE(hy == nullptr || (y && c_yl && w_yl && label));
     MaskArgs a{table, n_batches, ctr, base, hx, hy, y, B, L, Np, n_tot, kl_rate, pert_rate, yl_rate, beta, c_nll, c_klz2,
-               c_yl, w_recl, w_pert, w_yl, label, c_klp};
+               c_yl, w_recl, w_pert, w_yl, label, c_klp, one_slot};
     hipLaunchKernelGGL(batch_masks_kernel, dim3(1), dim3(1024), 0, ST(stream), a);
     DV_RETURN_LAUNCH();
 }

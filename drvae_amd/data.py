@@ -117,7 +117,7 @@ class DeviceBatcher:
     straight into the fused step's input buffers (see the module docstring)."""
 
     def __init__(self, dataset, weights, batch_size, group_counts=None, seed=0, mode='stratified', generator='device',
-                 pair_bucket=None):
+                 pair_bucket=None, label_bucket=None):
         """``mode='stratified'`` (default): every batch has the SAME composition (the expected counts of the four
         groups under the weights, or ``group_counts``) -- rows within a group drawn with replacement by weight;
         the step runs on the plan of exactly that structure.
@@ -134,7 +134,11 @@ class DeviceBatcher:
         every row a pair: 3 L B decoder rows.  With buckets the epoch's batches are re-ordered pairs first (the loss is
         a sum over rows: the order inside a batch means nothing) and every batch runs on the plan whose number of pair
         slots is its number of pairs rounded up to a multiple of w -- a handful of plans, each captured once
-        (``prepare_epoch`` / ``select``); the decoder then runs L B + 2 L ceil_w(N_pairs) rows."""
+        (``prepare_epoch`` / ``select``); the decoder then runs L B + 2 L ceil_w(N_pairs) rows.
+        ``label_bucket`` = v: the same for the labels.  Rows go in the order unlabeled pairs, labeled pairs, labeled
+        singles, unlabeled singles -- the pairs stay a prefix, the labeled rows are ONE run [N_up, N_up + N_l) -- and the
+        plan gives the rows [ceil_v(N_up), floor_v(N_up + N_l)), labeled for sure, one fprop row (their class) instead
+        of one per class."""
         # a dataset shorter than one batch is ONE batch of all its rows: DataLoader(drop_last=(len >= batch_size))
         batch_size = min(batch_size, len(dataset))
         self.ds, self.batch_size = dataset, batch_size
@@ -164,9 +168,10 @@ class DeviceBatcher:
         self.gen.manual_seed(seed)
         self._idx32 = torch.zeros(batch_size, dtype=torch.int32, device=dev)
         assert generator in ('device', 'cpu') and (generator == 'device' or mode == 'sampler')
-        assert pair_bucket is None or (mode == 'sampler' and int(pair_bucket) >= 1)
+        assert not (pair_bucket or label_bucket) or (mode == 'sampler' and int(pair_bucket or 1) >= 1 and int(label_bucket or 1) >= 1)
         self.pair_bucket = int(pair_bucket) if pair_bucket else None
-        self.batch_slots = None           # (bucketed) pair slots of every batch of the current epoch table
+        self.label_bucket = int(label_bucket) if label_bucket else None
+        self.batch_specs = None           # (bucketed) plan of every batch of the current epoch table: (pair slots, a, b)
         self._k = 0                       # (bucketed) batches handed out since begin_epoch
         self.n_switch = 0                 # (bucketed) how many times a step ran on another plan than the one before
         self.cpu_stream = generator == 'cpu'
@@ -197,6 +202,8 @@ class DeviceBatcher:
             engine.universal = True
             if self.pair_bucket and not engine.cfg.has_pert:
                 self.pair_bucket = None                      # (no pairs in this model: nothing to bucket)
+            if self.label_bucket and not engine.cfg.has_y:
+                self.label_bucket = None
             return engine.set_structure_universal(self.batch_size)
         engine.set_structure(self.has_x2, self.has_y, counts)
         return engine.plan
@@ -235,23 +242,17 @@ class DeviceBatcher:
             else:
                 draws = torch.multinomial(self.weights, n_b * self.batch_size, replacement=True, generator=self.gen)
             tab = draws.reshape(n_b, self.batch_size)
-            if self.pair_bucket:
-                # pairs first inside every batch (stable), and how many each batch has -- the epoch's ONE host sync
-                hx = self.hx32[tab.long()]
-                order = torch.argsort(-hx, dim=1, stable=True)
-                tab = tab.gather(1, order)
-                w = self.pair_bucket
-                npairs = hx.sum(1).cpu().numpy()
-                self.batch_slots = np.clip(((npairs + w - 1) // w) * w, min(w, self.batch_size), self.batch_size).astype(np.int64)
-                self._k = 0
+            if self.bucketed:
+                self._order_and_specs(tab)
+                tab = self._tab_sorted
             fd.table.copy_(tab)
             fd.base.copy_(eng.step_dev)
-            if self.pair_bucket:                 # the same table feeds whichever of the bucket plans a batch runs on
+            if self.bucketed:                    # the same table feeds whichever of the bucket plans a batch runs on
                 self._feed = fd
-                for slots in sorted(set(self.batch_slots.tolist()) | {self.batch_size}):
-                    q = eng.set_structure_universal(self.batch_size, slots)
+                for spec in sorted(set(self.batch_specs) | {self._full_spec}):
+                    q = self._plan(spec)
                     q.feed, q.feed_active = fd, True
-                eng.set_structure_universal(self.batch_size, int(self.batch_slots[0]))
+                self._plan(self.batch_specs[0])
             return fd.table
         parts = [m[torch.multinomial(w, c * n_b, replacement=True, generator=self.gen)].reshape(n_b, c)
                  for m, w, c in zip(self.members, self.gweights, self.group_counts) if c > 0]
@@ -259,40 +260,88 @@ class DeviceBatcher:
         fd.base.copy_(eng.step_dev)         # device to device: batch index = optimiser step - base
         return fd.table
 
+    @property
+    def bucketed(self):
+        return bool(self.pair_bucket or self.label_bucket)
+
+    @property
+    def batch_slots(self):
+        """pair slots of every batch of the current epoch table"""
+        return np.asarray([sp[0] for sp in self.batch_specs], np.int64)
+
+    @property
+    def _full_spec(self):
+        return (self.batch_size, 0, 0)
+
+    def _plan(self, spec):
+        p = self.engine.set_structure_universal(self.batch_size, spec[0], spec[1:])
+        self.engine.pinned_plans.add(p.key)       # (the plan cache is small and drops what is not captured)
+        return p
+
+    def _order_and_specs(self, tab):
+        """re-order every batch of the epoch table (stable inside a group) and choose its plan: the epoch's ONE host sync"""
+        B, eng = self.batch_size, self.engine
+        hx = self.hx32[tab.long()] if eng.cfg.has_pert else torch.zeros_like(tab)
+        hy = self.hy32[tab.long()] if eng.cfg.has_y else torch.zeros_like(tab)
+        if self.label_bucket:        # unlabeled pairs | labeled pairs | labeled singles | unlabeled singles
+            grp = torch.where(hx != 0, hy, 3 - hy)
+        else:                        # pairs | singles
+            grp = 1 - hx
+        self._tab_sorted = tab.gather(1, torch.argsort(grp, dim=1, stable=True))
+        cnt = torch.stack([hx.sum(1), (hx * (1 - hy)).sum(1), hy.sum(1)], 1).cpu().numpy().astype(np.int64)
+        specs = []
+        for n_p, n_up, n_l in cnt:
+            P = B
+            if self.pair_bucket:
+                w = self.pair_bucket
+                P = int(np.clip(-(-n_p // w) * w, min(w, B), B))
+            a = b = 0
+            if self.label_bucket:
+                v = self.label_bucket
+                a, b = int(min(-(-n_up // v) * v, B)), int((n_up + n_l) // v * v)
+                if b <= a:
+                    a = b = 0
+            specs.append((P, a, b))
+        self.batch_specs = specs
+        self._k = 0
+
     def prepare_epoch(self, capture):
         """(bucketed sampler feed) capture the plans this epoch's batches run on that are not captured yet --
         ``capture(engine)`` is called with each selected (a handful per run, ~0.1 s each, in the first epochs only) --
-        and the every-row-may-be-a-pair plan, which serves any batch"""
-        if not self.pair_bucket:
+        and the every-row-may-be-anything plan, which serves any batch"""
+        if not self.bucketed:
             return
         eng = self.engine
-        for slots in sorted(set(self.batch_slots.tolist()) | {self.batch_size}):
-            p = eng.set_structure_universal(self.batch_size, int(slots))
+        for spec in sorted(set(self.batch_specs) | {self._full_spec}):
+            p = self._plan(spec)
             if not eng.use_capture(p.key):
+                assert p.live_feed is self._feed
                 capture(eng)
                 eng.stash_capture()
+        self._ready = {sp for sp in getattr(self, '_ready', set()) | set(self.batch_specs) | {self._full_spec}
+                       if eng.use_capture(self._plan(sp).key)}
         self.select(0)
 
     def select(self, k=None):
-        """(bucketed sampler feed) make the plan of the epoch's batch ``k`` (default: the next one) current -- the
-        smallest captured one with room for the batch's pairs; the caller replays right after.  Without buckets:
-        nothing to do."""
-        if not self.pair_bucket:
+        """(bucketed sampler feed) make the plan of the epoch's batch ``k`` (default: the next one) current -- its own
+        if captured, else the cheapest captured one that serves it (at least its pairs' slots, a labeled range inside
+        its labeled run); the caller replays right after.  Without buckets: nothing to do."""
+        if not self.bucketed:
             return
         if k is None:
             k = self._k
         self._k = k + 1
-        eng, w = self.engine, self.pair_bucket
-        slots = int(self.batch_slots[min(k, len(self.batch_slots) - 1)])
+        eng = self.engine
+        want = self.batch_specs[min(k, len(self.batch_specs) - 1)]
         cur = eng.plan
-        while True:
-            p = eng.set_structure_universal(self.batch_size, slots)
-            if eng.use_capture(p.key):
-                self.n_switch += p is not cur
-                return
-            if slots >= self.batch_size:
+        if want not in getattr(self, '_ready', ()) or not eng.use_capture(self._plan(want).key):
+            # (a composition first met after the captures were made, e.g. a re-drawn table)
+            ok = [sp for sp in getattr(self, '_ready', ())
+                  if sp[0] >= want[0] and (sp[1] == sp[2] or (sp[1] >= want[1] and sp[2] <= want[2]))]
+            ok.sort(key=lambda sp: 2 * sp[0] - (sp[2] - sp[1]))
+            if not (ok and eng.use_capture(self._plan(ok[0]).key)):
                 raise RuntimeError('DeviceBatcher: no captured step for this feed (call prepare_epoch after begin_epoch)')
-            slots = min(slots + w, self.batch_size)
+        self.n_switch += eng.plan is not cur
 
     def _reference_epoch(self):
         """(len(self), batch_size) int64 on the host: one epoch of the reference's loader, drawn from torch's default

@@ -189,9 +189,11 @@ class FusedStep(StepSchedule):
         # group membership becomes device-side masks (see ``_Plan.universal``); costs the rows of the worst case
         self.universal = False
         self.universal_pair_slots = None      # (set_batch on the universal plan) only the first so many rows may be pairs
+        self.universal_labeled_range = None   # ... and rows [a, b) are labeled for sure (one fprop row each)
         self.plan = None
         self._plans = {}                    # plans by batch structure (a handful of signatures in practice)
         self.max_plans = 8
+        self.pinned_plans = set()     # keys the cache never drops (a feed's bucket plans: DeviceBatcher)
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=self.dev)       # Adam step (device side)
         self.loss_sum = torch.zeros(8, device=self.dev)      # running sums of the loss scalars over train steps
         self.rng_ctr = torch.zeros(2, dtype=torch.int32, device=self.dev)        # Philox counter (device side)
@@ -295,22 +297,31 @@ class FusedStep(StepSchedule):
         cfg = self.cfg
         return not cfg.cont and not (cfg.kind == 'vfae' and not cfg.semi_supervised) and not cfg.use_s
 
-    def set_structure_universal(self, n_rows, n_pair_slots=None):
+    def set_structure_universal(self, n_rows, n_pair_slots=None, labeled_range=None):
         """Select (or build) the batch-independent plan for ``n_rows`` rows.  ``n_pair_slots`` < n_rows: only the FIRST
         so many rows of a batch have pair slots (x2 row, z2 / z2Fz1 sample rows) -- for feeds that put a batch's pairs
         first and choose the plan by the batch's number of pairs (``DeviceBatcher(mode='sampler', pair_bucket=...)``):
-        the decoder then runs L*B + 2*L*n_pair_slots rows instead of 3*L*B."""
+        the decoder then runs L*B + 2*L*n_pair_slots rows instead of 3*L*B.  ``labeled_range`` = (a, b): the feed
+        guarantees that rows [a, b) of every batch are labeled -- they get ONE fprop row (their class, as in a plan
+        built for the batch's structure) instead of a row per class."""
         cfg = self.cfg
         assert self.universal_ok(), 'universal plan: discrete labels, semi-supervised models'
         nps = n_rows if (n_pair_slots is None or not cfg.has_pert) else int(n_pair_slots)
         assert 0 <= nps <= n_rows
-        key = ('universal', n_rows, self.row0) if nps == n_rows else ('universal', n_rows, self.row0, nps)
+        lab = (0, 0) if (labeled_range is None or not cfg.has_y) else (int(labeled_range[0]), int(labeled_range[1]))
+        if lab[1] <= lab[0]:
+            lab = (0, 0)
+        assert 0 <= lab[0] <= lab[1] <= n_rows
+        key = ('universal', n_rows, self.row0)
+        if nps != n_rows or lab != (0, 0):
+            key = key + (nps,) + (lab if lab != (0, 0) else ())
         if self.plan is None or self.plan.key != key:
             self.plan = self._plans.get(key)
             if self.plan is None:
-                ones, zeros = np.arange(n_rows) < nps, np.zeros(n_rows, bool)
-                self.plan = self._plans[key] = _Plan(self, np.arange(n_rows), ones if cfg.has_pert else zeros, zeros,
-                                                      None, key, universal=True)
+                ar = np.arange(n_rows)
+                ones, zeros = ar < nps, np.zeros(n_rows, bool)
+                self.plan = self._plans[key] = _Plan(self, ar, ones if cfg.has_pert else zeros,
+                                                      (ar >= lab[0]) & (ar < lab[1]), None, key, universal=True)
                 if cfg.has_y:
                     self.plan.set_labels_host(np.zeros(n_rows, np.int64))      # class slots: static
                 self._evict_plans(key)
@@ -322,7 +333,8 @@ class FusedStep(StepSchedule):
         for old in list(self._plans):
             if len(self._plans) <= self.max_plans:
                 break
-            if old != keep and old != getattr(self, '_graph_key', None) and old not in getattr(self, '_captures', {}):
+            if old != keep and old != getattr(self, '_graph_key', None) and old not in getattr(self, '_captures', {}) \
+                    and old not in self.pinned_plans:
                 del self._plans[old]
 
     def set_structure(self, has_x2, has_y, counts=None):
@@ -366,7 +378,7 @@ class FusedStep(StepSchedule):
         cfg = self.cfg
         if self.universal and counts is None and self.universal_ok():
             hy = np.asarray(has_y.cpu() if torch.is_tensor(has_y) else has_y).reshape(-1)
-            p = self.set_structure_universal(len(hy), self.universal_pair_slots)
+            p = self.set_structure_universal(len(hy), self.universal_pair_slots, self.universal_labeled_range)
             p.feed_active = False
             p.XSRC[:p.B].copy_(x1)
             i32 = lambda a: torch.as_tensor(np.asarray(a.cpu() if torch.is_tensor(a) else a).reshape(-1).astype(np.int32))
@@ -383,6 +395,9 @@ class FusedStep(StepSchedule):
             if cfg.has_y:
                 p.hy_dev.copy_(i32(has_y))
                 p.y_dev.copy_(i32(y) if y is not None else torch.zeros(p.B, dtype=torch.int32))
+                if p.one_slot is not None:       # rows with one fprop row: their class columns
+                    assert np.asarray(i32(has_y))[p._has_y_host.astype(bool)].all(), 'an unlabeled row in the labeled range'
+                    p.set_labels_host(np.asarray(i32(y)).astype(np.int64))
             return p
         p, rows = self.set_structure(has_x2, has_y, counts)
         p.feed_active = False       # explicit data supersedes an installed epoch feed (a captured step that
@@ -480,16 +495,18 @@ class FusedStep(StepSchedule):
                              y=(fd.y32 if fd is not None else p.y_dev) if cfg.has_y else None,
                              c_klz2=p.c_klz2 if cfg.has_pert else None, c_yl=p.c_yl, w_pert=p.w_pert, w_yl=p.w_yl,
                              label=p.label_r if cfg.has_y else None, c_klp=p.c_klp if cfg.kind == 'pvae' else None,
-                             Np=Np if cfg.has_pert else 0)
+                             Np=Np if cfg.has_pert else 0, one_slot=p.one_slot)
                 if fd is None:
                     K.batch_masks(B, L, **masks)
             if fd is not None:
                 # batch (optimiser step - epoch base) of the epoch's index table, straight from the
                 # HBM-resident dataset; also refreshes the label-dependent index buffers
-                lab = cfg.has_y and not cfg.cont and not p.universal     # (universal plan: dv_batch_masks has the labels)
+                # (universal plan: dv_batch_masks has the labels; its rows with ONE fprop row get their class columns here)
+                lab = cfg.has_y and not cfg.cont and (not p.universal or p.one_slot is not None)
                 K.batch_feed(p.XIN, fd.x1, fd.x2, fd.y32, fd.table, fd.n_batches, self.step_dev, fd.base,
                              pair_rows=p.pair_idx if Np else None, noise=p.EX if sigma else None, sigma=sigma,
-                             has_y=p.has_y_i32 if lab else None, L=L, label_r=p.label_r if lab else None,
+                             has_y=p.has_y_i32 if (lab and not p.universal) else None, L=L,
+                             label_r=p.label_r if (lab and not p.universal) else None,
                              fp_i=p.fp_q if lab else None, fp_lab=p.fp_lab_i32 if lab else None,
                              fp_slot=p.fp_slot_dev if lab else None, fp_cls=p.fp_cls if (lab and p.Mf) else None,
                              onehot=p.Z3IN[:, cfg.dim_z3:] if (lab and p.Mf) else None, n_classes=cfg.dim_y,

@@ -225,7 +225,7 @@ class FitMixin:
         resident_feed = not eng.cfg.use_s      # (the nuisance classes travel with host-driven gathers: feed())
         if resident_feed:
             batcher.begin_epoch()           # this epoch's index table; the graph gathers batch b itself
-            if getattr(batcher, 'pair_bucket', None):
+            if getattr(batcher, 'bucketed', False):
                 eng.use_capture(eng.plan.key)      # (one captured step per number-of-pairs bucket: this one's, if any)
         else:
             batcher.feed()
@@ -233,13 +233,14 @@ class FitMixin:
                 or getattr(eng, '_graph_feed', None) is not eng.plan.live_feed:
             eng.capture(split_for_allreduce=getattr(self, '_allreduce', None) is not None)
             eng._graph_noise = eng.add_noise
-            if getattr(self, '_allreduce', None) is None:
+            bucketed = getattr(batcher, 'bucketed', False)
+            if bucketed:
+                eng.stash_capture()         # (under this plan's key: begin_epoch below selects another)
+            if getattr(self, '_allreduce', None) is None and not (bucketed and getattr(eng, '_side_cus', None)):
                 eng.tune_partition()        # CU split of the two launch chains, by timing (state restored)
             if resident_feed:
                 batcher.begin_epoch()       # (the tuning replays advanced the step counter: re-base the table)
-            if getattr(batcher, 'pair_bucket', None):
-                eng.stash_capture()
-        if getattr(batcher, 'pair_bucket', None):         # a plan per number-of-pairs bucket: capture the missing ones
+        if getattr(batcher, 'bucketed', False):         # a plan per number-of-pairs bucket: capture the missing ones
             def cap(e):
                 e.capture()
                 e._graph_noise = e.add_noise

@@ -532,12 +532,13 @@ def batch_feed(xin, x1, x2, y32, table, n_batches, ctr, base, *, pair_rows=None,
     B = table.shape[1]
     md = None
     if masks is not None:
-        m = dict(hx=None, hy=None, y=None, c_klz2=None, c_yl=None, w_pert=None, w_yl=None, label=None, c_klp=None, Np=None)
+        m = dict(hx=None, hy=None, y=None, c_klz2=None, c_yl=None, w_pert=None, w_yl=None, label=None, c_klp=None, Np=None,
+                 one_slot=None)
         m.update(masks)
         md = _lib.BatchMasks(_i32(m['hx']), _i32(m['hy']), _i32(m['y']), B if m['Np'] is None else m['Np'],
                              m['n_tot'], m['kl_rate'], m['pert_rate'], m['yl_rate'], _f32(m['beta']), _f32(m['c_nll']),
                              _f32(m['c_klz2']), _f32(m['c_yl']), _f32(m['w_recl']), _f32(m['w_pert']), _f32(m['w_yl']),
-                             _i32(m['label']), _f32(m['c_klp']))
+                             _i32(m['label']), _f32(m['c_klp']), _i32(m['one_slot']))
     Np = pair_rows.numel() if pair_rows is not None else 0
     assert xin.shape[0] == B + Np and table.shape[0] == n_batches and table.is_contiguous()
     Mf = fp_cls.numel() if fp_cls is not None else 0
@@ -552,14 +553,14 @@ def batch_feed(xin, x1, x2, y32, table, n_batches, ctr, base, *, pair_rows=None,
 
 def batch_masks(B, L, *, n_tot, kl_rate, pert_rate, yl_rate, beta, c_nll, w_recl, hx=None, hy=None, y=None, c_klz2=None,
                 c_yl=None, w_pert=None, w_yl=None, label=None, c_klp=None, table=None, n_batches=0, ctr=None, base=None,
-                Np=None):
+                Np=None, one_slot=None):
     """per-batch coefficient / weight vectors of a batch-independent step plan from the batch's pair / label flags
     (``dv_batch_masks``); ``hx`` / ``hy`` / ``y``: int32 device arrays indexed by dataset row (``table`` given) or by
     batch row; ``beta``: 1-element device float; ``Np``: rows [0, Np) have pair slots (default: all B)"""
     _lib.check(_lib.load().dv_batch_masks(_i32(table), n_batches, _i32(ctr), _i32(base), _i32(hx), _i32(hy), _i32(y), B, L,
                                           B if Np is None else Np, n_tot, kl_rate, pert_rate, yl_rate, _f32(beta), _f32(c_nll), _f32(c_klz2),
                                           _f32(c_yl), _f32(w_recl), _f32(w_pert), _f32(w_yl), _i32(label), _f32(c_klp),
-                                          _stream()),
+                                          _i32(one_slot), _stream()),
                'dv_batch_masks')
 
 

@@ -217,6 +217,8 @@ class _Plan:
             self.beta_dev = zf(1)
             if not cfg.has_y:
                 self.c_yl = None
+            # rows the feed guarantees to be labeled (one fprop row, the structure's own label path): a static flag
+            self.one_slot = i32(has_y.astype(np.int32)) if (cfg.has_y and has_y.any()) else None
         self._cfg = cfg
         self.x1 = self.x2 = None
         self.feed = None        # graph-resident input feed (drvae_amd.data.DeviceBatcher.begin_epoch)

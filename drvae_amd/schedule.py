@@ -92,6 +92,7 @@ class StepSchedule:
         to step -- ``DeviceBatcher(pair_bucket=...)`` -- captures each once and swaps them with ``use_capture``)"""
         if not hasattr(self, '_captures'):
             self._captures = {}
+        assert self._graph_key == self.plan.key, 'stash_capture right after capture(): another plan is current'
         self._captures[self.plan.key] = {k: getattr(self, k, None) for k in _CAPTURE_STATE}
 
     def use_capture(self, key):
@@ -104,7 +105,9 @@ class StepSchedule:
             for k, v in cap.items():
                 setattr(self, k, v)
             self.plan = self._plans[key]
-            self._noise_stale = True         # (the side chain drew ahead into the OTHER plan's noise buffer)
+            # the side chain drew ahead into the OTHER plan's noise buffer: the replay draws for this one first (in front
+            # of the main graph; drawn on the side stream with an event edge instead, the step is 2 % slower)
+            self._noise_stale = True
         return True
 
     def _mode(self):

@@ -30,7 +30,7 @@ extern "C" {
 
 typedef void* dv_stream_t;
 
-#define DV_ABI_VERSION 5
+#define DV_ABI_VERSION 6
 
 enum { DV_OK = 0, DV_ERR_ARG = -1, DV_ERR_LAUNCH = -2, DV_ERR_UNSUPPORTED = -3 };
 
@@ -495,6 +495,7 @@ typedef struct dv_batch_masks_desc {
     float* w_yl;
     int32_t* label;
     float* c_klp;
+    const int32_t* one_slot;
 } dv_batch_masks_desc;
 int dv_batch_feed(const float* x1, int64_t ld1, const float* x2, int64_t ld2, const int32_t* y, const int32_t* table,
                   int32_t n_batches, const int32_t* ctr, const int32_t* base, int32_t B, const int32_t* pair_rows,
@@ -521,11 +522,14 @@ int dv_batch_feed(const float* x1, int64_t ld1, const float* x2, int64_t ld2, co
  * Np <= B: only rows [0, Np) of the batch have pair slots (a plan with fewer x2 / z2 rows for feeds that put a
  * batch's pairs first: DeviceBatcher(mode='sampler', pair_bucket=...)); the pair-indexed vectors then have L*Np
  * entries, slot q = l*Np + j, and sit behind the L*B row entries: c_nll[LB + q], c_nll[LB + L*Np + q], w_recl[LB + q],
- * w_pert[q], c_klz2[q], c_klp[B + j].  Np == B is the layout written out above. */
+ * w_pert[q], c_klz2[q], c_klp[B + j].  Np == B is the layout written out above.
+ * one_slot (B flags, optional): rows the plan gives ONE class slot because the feed guarantees they are labeled
+ * (DeviceBatcher(label_bucket=...)): label[r] = y, the form dv_ymarg_* read for a single-slot row. */
 int dv_batch_masks(const int32_t* table, int32_t n_batches, const int32_t* ctr, const int32_t* base, const int32_t* hx,
                    const int32_t* hy, const int32_t* y, int32_t B, int32_t L, int32_t Np, float n_tot, float kl_rate,
                    float pert_rate, float yl_rate, const float* beta, float* c_nll, float* c_klz2, float* c_yl,
-                   float* w_recl, float* w_pert, float* w_yl, int32_t* label, float* c_klp, dv_stream_t stream);
+                   float* w_recl, float* w_pert, float* w_yl, int32_t* label, float* c_klp, const int32_t* one_slot,
+                   dv_stream_t stream);
 int dv_rows_segment_sum(const float* src, int64_t lds, const int32_t* seg_ptr, const int32_t* seg_rows,
                         const float* w, int32_t n, int32_t W, const int32_t* dst_idx, float* dst, int64_t ldd,
                         float beta, const dv_wait* park, dv_stream_t stream);

@@ -762,7 +762,7 @@ def counter_add(counter, inc=1):
 
 def batch_masks(B, L, *, n_tot, kl_rate, pert_rate, yl_rate, beta, c_nll, w_recl, hx=None, hy=None, y=None, c_klz2=None,
                 c_yl=None, w_pert=None, w_yl=None, label=None, c_klp=None, table=None, n_batches=0, ctr=None, base=None,
-                Np=None):
+                Np=None, one_slot=None):
     Np = B if Np is None else Np
     if c_klp is not None:
         s_ = table[min(max(int(ctr[0]) - int(base[0]), 0), n_batches - 1)].long() if table is not None else \
@@ -792,6 +792,8 @@ def batch_masks(B, L, *, n_tot, kl_rate, pert_rate, yl_rate, beta, c_nll, w_recl
         c_yl[:LB] = torch.where(py, -yl_rate / (L * nlab), 0.0)
         w_yl[:LB] = 1.0 / (L * nlab)
         label[:LB] = torch.where(py, -2 - y[src].to(label.dtype).repeat(L), torch.zeros_like(label[:LB]))
+        if one_slot is not None:
+            label[:LB] = torch.where(one_slot.repeat(L) != 0, y[src].to(label.dtype).repeat(L), label[:LB])
 
 
 def fill_normal_rows(arena, desc, seed, ctr_dev=None, park=None):

@@ -184,3 +184,44 @@ def test_sampler_mode_pair_buckets(monkeypatch):
     bat_v = D.DeviceBatcher(ds, w, 16, seed=2, mode='sampler', pair_bucket=4)
     bat_v.bind(eng_v)
     assert bat_v.pair_bucket is None
+
+
+def test_sampler_mode_label_buckets(monkeypatch):
+    """label_bucket: every batch in the order unlabeled pairs | labeled pairs | labeled singles | unlabeled singles;
+    its plan has pair slots for (at least) its pairs and a labeled range inside its run of labeled rows"""
+    from oracle import models_ref as M
+    from tests import kernel_ref
+    from tests.test_engine_cpu import make_engine
+    kernel_ref.install(monkeypatch)
+    spec = C.tiny_spec('drvae')
+    big = M.make_batch(spec, 100, seed=4)
+    t = lambda k: torch.from_numpy(big[k].copy())
+    ds = D.DrVAEDataset(t('x1'), t('x2'), t('s'), t('y'), t('has_x2'), t('has_y'))
+    w = D.compute_balanced_weights(np.arange(100) % 7)
+    eng, _ = make_engine(spec, M.init_params(spec, 3, as_numpy=True))
+    bat = D.DeviceBatcher(ds, w, 16, seed=2, mode='sampler', pair_bucket=4, label_bucket=2)
+    plain = D.DeviceBatcher(ds, w, 16, seed=2, mode='sampler')
+    eng2, _ = make_engine(spec, M.init_params(spec, 3, as_numpy=True))
+    bat.bind(eng)
+    plain.bind(eng2)
+    tab, ref = bat.begin_epoch().numpy(), plain.begin_epoch().numpy()
+    hx, hy = big['has_x2'].reshape(-1), big['has_y'].reshape(-1)
+    np.testing.assert_array_equal(np.sort(tab, 1), np.sort(ref, 1))
+    some_range = False
+    for row, (P, a, b) in zip(tab, bat.batch_specs):
+        px, py = hx[row].astype(bool), hy[row].astype(bool)
+        n_p, n_up, n_l = int(px.sum()), int((px & ~py).sum()), int(py.sum())
+        grp = np.where(px, py.astype(int), 3 - py.astype(int))
+        assert (np.diff(grp) >= 0).all()                      # the four groups in order
+        assert n_p <= P <= max(4, n_p + 3) and px[:n_p].all() and not px[n_p:].any()
+        assert py[n_up:n_up + n_l].all() and n_l == py.sum()
+        assert (a, b) == (0, 0) or (n_up <= a < b <= n_up + n_l and a % 2 == 0 and b % 2 == 0 and b - a > n_l - 4)
+        some_range |= b > a
+        assert eng._plans[eng.set_structure_universal(16, P, (a, b)).key].live_feed is not None
+    assert some_range
+    # models without labels: the label buckets are switched off
+    spec_p = C.tiny_spec('pvae')
+    eng_p, _ = make_engine(spec_p, M.init_params(spec_p, 3, as_numpy=True))
+    bat_p = D.DeviceBatcher(ds, w, 16, seed=2, mode='sampler', pair_bucket=4, label_bucket=2)
+    bat_p.bind(eng_p)
+    assert bat_p.label_bucket is None and bat_p.pair_bucket == 4

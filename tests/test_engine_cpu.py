@@ -189,6 +189,45 @@ def test_universal_plan_with_pair_slots(kind, monkeypatch):
     assert len(uni._plans) == 4
 
 
+@pytest.mark.parametrize('kind', ['drvae', 'vfae'])
+def test_universal_plan_with_labeled_range(kind, monkeypatch):
+    """the bucketed sampler feed's plans, label dimension: rows [a, b) of the batch are labeled for sure and get one
+    fprop row (their class) instead of one per class -- same losses / gradients / update as the plan built for the
+    batch's exact composition.  Row order of the feed: unlabeled pairs, labeled pairs, labeled singles, unlabeled
+    singles (pairs are a prefix, labeled rows one contiguous run)."""
+    kernel_ref.install(monkeypatch)
+    spec = C.tiny_spec(kind)
+    params = M.init_params(spec, 3, as_numpy=True)
+    uni, au = make_engine(spec, params)
+    uni.universal = True
+    fl = {'a': (1, 0), 'b': (0, 0), 'c': (1, 1), 'd': (0, 1)}        # (labeled, pair)
+    cases = [('dccaabbb', 4, (1, 5)), ('ddccabbb', 4, (2, 4)), ('dcccaaab', 4, (2, 6)), ('ccccaaaa', 4, (0, 8)),
+             ('ddddbbbb', 4, (0, 0)), ('dccaabbb', 8, (2, 4))]
+    for seed, (pattern, slots, lab) in enumerate(cases):
+        batch = M.make_batch(spec, 8, seed=seed)
+        batch['has_y'] = np.array([fl[c][0] for c in pattern], np.int64)
+        batch['has_x2'] = np.array([fl[c][1] for c in pattern], np.int64)
+        batch['x2'] = batch['x2'] * batch['has_x2'][:, None].astype(np.float32)
+        noise = M.make_noise(spec, 8, seed=10 + seed)
+        one, a1 = make_engine(spec, params)
+        a1.param.copy_(au.param); a1.exp_avg.copy_(au.exp_avg); a1.exp_avg_sq.copy_(au.exp_avg_sq)
+        one.step_dev.copy_(uni.step_dev); one.iters = uni.iters
+        uni.universal_pair_slots, uni.universal_labeled_range = slots, lab
+        for e in (uni, one):
+            set_batch(e, batch)
+            e.train_step(noise)
+        Y = uni.cfg.dim_y
+        assert uni.plan.universal and uni.plan.Mf == uni.cfg.L * (8 * Y - (lab[1] - lab[0]) * (Y - 1))
+        for (k, a), b in zip(uni.losses().items(), one.losses().values()):
+            close(a, b, 2e-5, 2e-6)
+        close(au.grad, a1.grad.numpy(), 2e-4, 1e-6)
+        close(au.param, a1.param.numpy(), 1e-5, 1e-6)
+    with pytest.raises(AssertionError):           # an unlabeled row inside the labeled range
+        batch['has_y'][:] = 0
+        uni.universal_labeled_range = (1, 5)
+        set_batch(uni, batch)
+
+
 def _use_s_case(kind, use_mmd, seed=0):
     spec = C.tiny_spec(kind, use_s=True, dim_s=2, use_MMD=use_mmd, mmd_rate=0.7, kernel_MMD='identity')
     for sd in range(seed, seed + 50):      # every data group must hold both nuisance classes (no random fill-in row)

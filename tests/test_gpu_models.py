@@ -388,8 +388,8 @@ def test_universal_plan_matches_reference_gpu(name, dev):
             np.testing.assert_allclose(a, gold['param%d/%s' % (nsteps - 1, k)], rtol=2e-4, atol=5e-5)
 
 
-@pytest.mark.parametrize('kind', ['drvae', 'pvae'])
-def test_sampler_mode_pair_buckets_gpu(kind, dev):
+@pytest.mark.parametrize('kind,label_bucket', [('drvae', None), ('pvae', None), ('drvae', 4), ('vfae', 8)])
+def test_sampler_mode_pair_buckets_gpu(kind, label_bucket, dev):
     """N2, mode='sampler' with pair_bucket: batches re-ordered pairs first, each replayed on the captured plan of its
     number-of-pairs bucket (a few graphs, switched from step to step; plans first met in the second epoch are captured
     then) -- bitwise the eager steps of the same plans handed the same rows explicitly."""
@@ -401,7 +401,7 @@ def test_sampler_mode_pair_buckets_gpu(kind, dev):
     t = lambda k: torch.from_numpy(big[k].copy())
     ds = D.DrVAEDataset(t('x1'), t('x2'), t('s'), t('y'), t('has_x2'), t('has_y')).to(dev)
     w = D.compute_balanced_weights(np.arange(640) % 7)
-    bat = D.DeviceBatcher(ds, w, 64, seed=5, mode='sampler', pair_bucket=4)
+    bat = D.DeviceBatcher(ds, w, 64, seed=5, mode='sampler', pair_bucket=4, label_bucket=label_bucket)
     fed, a1 = make_engine(spec, params, dev)
     eager, a0 = make_engine(spec, params, dev)
     eager.universal = True
@@ -417,8 +417,14 @@ def test_sampler_mode_pair_buckets_gpu(kind, dev):
             i = tab[k].long()
             hx, hy = ds.has_x2[i].cpu().numpy(), ds.has_y[i].cpu().numpy()
             n = int(hx.sum())
-            assert hx[:n].all() and n <= fed.plan.Np < n + 4 or fed.plan.Np == 4
+            if spec.kind != 'vfae':
+                assert hx[:n].all() and n <= fed.plan.Np < n + 4 or fed.plan.Np == 4
             eager.universal_pair_slots = fed.plan.Np
+            eager.universal_labeled_range = bat.batch_specs[k][1:] if label_bucket else None
+            if label_bucket:
+                a, b = bat.batch_specs[k][1:]
+                assert hy[a:b].all() and (b - a > int(hy.sum()) - 2 * label_bucket or (a, b) == (0, 0))
+                assert fed.plan.Mf == spec.L * (64 * spec.dim_y - (b - a) * (spec.dim_y - 1))
             eager.set_batch(ds.x1[i], ds.x2[i], ds.y[i].cpu(), hx, hy)
             eager.train_step()
     torch.cuda.synchronize()
