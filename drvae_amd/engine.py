@@ -472,192 +472,25 @@ class FusedStep(StepSchedule):
         return 1.
 
     def forward(self):
+        """The forward pass as a launch sequence; this function only schedules its phases: ``_encoder_forward`` (inputs,
+        q(z1|x1), q(z2|x2), perturbation function, samples), then two independent chains -- ``_decoder_forward`` (the big
+        GEMMs + NLL) and ``_side_forward`` (fprop / classifier: many small launches).  How the two chains are ordered
+        depends on ``_mode()``: 5 = each chain is recorded into its own graph (``_rec`` says which one is being recorded)
+        and device flags order them; 3 / 1 = one graph, fork/join per step / per pass; 0 = plain evaluation."""
         cfg, p = self.cfg, self.plan
         p.set_beta(self.beta_pert())
         B, Np, L, Z1 = p.B, p.Np, cfg.L, cfg.dim_z1
-        sigma = cfg.add_noise_var if (self.training and self.add_noise and cfg.add_noise_var > 0) else 0.0
         rec = self._rec
         Z1blk = p.ZDEC[:L * B]
         if rec == 'side':           # side-chain graph: the main graph launches these; only the views are needed
             Q = p.c_enc.out[-1]
             Qmu, Qlv = Q[:, :Z1], Q[:, Z1:]
         else:
-            # ---- inputs (+ training noise N(0,1)*add_noise_var, src/DrVAE.py:404-407,414-417): one gather
-            fd = p.live_feed if (self.fuse_bwd and self.training) else None
-            masks = None
-            if p.universal:
-                # which rows of THIS batch are pairs / labeled -> coefficient and weight vectors, on the device (with
-                # the graph-resident feed: by one more workgroup of the feed's launch)
-                masks = dict(n_tot=float(B), kl_rate=cfg.kl_qz2pz2_rate, pert_rate=cfg.pertloss_rate,
-                             yl_rate=cfg.yloss_rate, beta=p.beta_dev, c_nll=p.c_nll, w_recl=p.w_recl,
-                             hx=(fd.hx32 if fd is not None else p.hx_dev) if cfg.has_pert else None,
-                             hy=(fd.hy32 if fd is not None else p.hy_dev) if cfg.has_y else None,
-                             y=(fd.y32 if fd is not None else p.y_dev) if cfg.has_y else None,
-                             c_klz2=p.c_klz2 if cfg.has_pert else None, c_yl=p.c_yl, w_pert=p.w_pert, w_yl=p.w_yl,
-                             label=p.label_r if cfg.has_y else None, c_klp=p.c_klp if cfg.kind == 'pvae' else None,
-                             Np=Np if cfg.has_pert else 0, one_slot=p.one_slot)
-                if fd is None:
-                    K.batch_masks(B, L, **masks)
-            if fd is not None:
-                # batch (optimiser step - epoch base) of the epoch's index table, straight from the
-                # HBM-resident dataset; also refreshes the label-dependent index buffers
-                # (universal plan: dv_batch_masks has the labels; its rows with ONE fprop row get their class columns here)
-                lab = cfg.has_y and not cfg.cont and (not p.universal or p.one_slot is not None)
-                K.batch_feed(p.XIN, fd.x1, fd.x2, fd.y32, fd.table, fd.n_batches, self.step_dev, fd.base,
-                             pair_rows=p.pair_idx if Np else None, noise=p.EX if sigma else None, sigma=sigma,
-                             has_y=p.has_y_i32 if (lab and not p.universal) else None, L=L,
-                             label_r=p.label_r if (lab and not p.universal) else None,
-                             fp_i=p.fp_q if lab else None, fp_lab=p.fp_lab_i32 if lab else None,
-                             fp_slot=p.fp_slot_dev if lab else None, fp_cls=p.fp_cls if (lab and p.Mf) else None,
-                             onehot=p.Z3IN[:, cfg.dim_z3:] if (lab and p.Mf) else None, n_classes=cfg.dim_y,
-                             onehot2=p.FPIN[:, Z1:] if (lab and p.Mf) else None,
-                             yf=fd.yf if (cfg.has_y and cfg.cont) else None,
-                             ylab=p.ylab if (cfg.has_y and cfg.cont) else None, masks=masks)
-            else:
-                K.rows_gather(p.XIN, p.XSRC, p.xin_idx, noise=p.EX if sigma else None, sigma=sigma)
-            # ---- q(z1|x1), q(z2|x2): one pass of the shared encoder; the samples (src/blocks.py:170-174) -- z1
-            # for every row and z2 for the pairs, drawn from q(z1|x1), not q(z2|x2) (quirk 1, src/DrVAE.py:427) --
-            # leave the heads' launch itself (``fuse_heads``) or one launch of their own
-            fuse = self.fuse_heads and self._heads_small(p.DPX)
-            Z1blk = p.ZDEC[:L * B]
-            if fuse:
-                # (... and every z1 sample is copied into the z1 columns of its fprop rows on the way out: the side
-                # chain's gather is gone)
-                fp4 = self._fprop_from_heads()
-                Q = p.c_enc.forward(p.enc_in, heads=dict(sample=dict(
-                    eps=p.E12, out=p.ZDEC[:p.o3], n_src=B, seg_ptr=p.zseg_ptr, seg_rows=p.zseg_rows,
-                    out4=p.FPIN[:, :Z1] if fp4 else None, out4_ptr=p.fp_ptr_ext if fp4 else None)))
-                Qmu, Qlv = Q[:, :Z1], Q[:, Z1:]
-            else:
-                Q = p.c_enc.forward(p.enc_in)
-                Qmu, Qlv = Q[:, :Z1], Q[:, Z1:]
-                K.reparam_fwd(p.ZDEC[:p.o3], Qmu, Qlv, p.E12, src_idx=p.z_src_idx)
-            if cfg.has_pert:
-                # (dual-graph schedule) entry of this launch = the z1 samples are final: lets the side
-                # chain's fprop start before the perturbation function has run
-                pub1 = (self.flags[0:1], self.step_dev, 1) if rec == 'main' else None
-                if fuse:
-                    # z2Fz1 sample, the classifier input z2Fz1 - z1, and the decoder's copy for the pairs
-                    p.c_z2F.forward([Z1blk], resid=Z1blk, publish=pub1, heads=dict(sample=dict(
-                        eps=p.E2F, out=p.Z2F, n_src=L * B, sub=Z1blk, out2=p.D, out3=p.ZDEC if Np else None,
-                        out3_idx=p.pert_out_idx if Np else None)))
-                else:
-                    P2 = p.c_z2F.forward([Z1blk], resid=Z1blk, publish=pub1)
-                    K.reparam_fwd(p.Z2F, P2[:, :Z1], P2[:, Z1:], p.E2F, sub=Z1blk, out2=p.D,
-                                  out3=p.ZDEC if Np else None, out3_idx=p.pert_out_idx if Np else None)
+            Qmu, Qlv = self._encoder_forward(rec)
         if p.DZMMD is not None and rec != 'side':
             self._mmd_penalty()
         # ---- two independent chains from here: the classifier / fprop chain (many small launches)
         # runs on a side stream next to the decoder chain (the big GEMMs)
-        def side_forward(mid=None, first_park=None, mid_park=None):
-            """fprop first: it only needs the z1 samples, so (dual-graph schedule) it can start before
-            the perturbation function has run; ``mid`` then waits for the z2Fz1 samples.  ``first_park`` / ``mid_park``
-            (dual-graph schedule): the two waits ride on the launch that follows them where that is a row kernel
-            with a small grid (one launch less each); else ``mid`` / a wait launch of its own."""
-            if cfg.kind == 'pvae':
-                K.kl_rows_fwd(p.KLP, p.KLPraw, Qmu, Qlv, prior=(0.0, 0.0), free_bits=True, kl_min=cfg.kl_min)
-            if cfg.has_y and cfg.cont:
-                # regression head (src/DrVAE.py:159-169,503-530): q(y|.) first -- the fprop of an unlabeled
-                # row conditions on a SAMPLE of it -- then one fprop row per classifier row
-                if mid is not None:
-                    mid()
-                if cfg.has_pert and Np:
-                    P2 = p.c_z2F.out[-1]
-                    K.kl_rows_fwd(p.KLZ2, p.KLZ2raw, Qmu, Qlv, P2[:, :Z1], P2[:, Z1:], qidx=p.qz2_idx, pidx=p.pidx,
-                                  reps=L, free_bits=True, kl_min=cfg.kl_min)
-                Z3, Y = cfg.dim_z3, cfg.dim_y
-                if cfg.kind == 'drvae':
-                    clf_in = [Z1blk, p.D] if cfg.clf_z1z2 else [p.Z2F]
-                else:
-                    clf_in = [Z1blk]
-                QYm = p.c_clf.forward(clf_in)                         # sigmoid-constrained means
-                K.rows_gather(p.FPIN[:, :Z1], Z1blk, p.fp_src)
-                K.ycont_fwd(p.YLrow, p.FPIN[:, Z1:], p.Z3IN[:, Z3:], QYm, p.ylab, p.has_y_i32, p.EY, Y_LOGVAR_CONT, B,
-                            sqerr=cfg.kind == 'vfae')       # VFAE scores by squared error (src/VFAE.py:351)
-                Q3 = p.c_top.forward([p.FPIN])
-                K.kl_rows_fwd(p.KL3, p.KL3raw, Q3[:, :Z3], Q3[:, Z3:], prior=(0.0, 0.0), free_bits=True,
-                              kl_min=cfg.kl_min, eps=p.E3, zout=p.Z3IN[:, :Z3])
-                PZ1 = p.c_dz1.forward([p.Z3IN])
-                K.kl_rows_fwd(p.KLDrow, p.KL1raw, Qmu, Qlv, PZ1[:, :Z1], PZ1[:, Z1:], qidx=p.fp_q, free_bits=True,
-                              kl_min=cfg.kl_min, add=p.KL3)
-                return
-            # ---- fprop over (labeled: true class | unlabeled: every class)
-            # (a parked launch polls from every workgroup: small grids only -- the C side refuses more than 512)
-            if first_park is not None and not (cfg.has_y and p.Mf and (p.Mf * (Z1 + cfg.dim_y) + 255) // 256 <= 256):
-                K.flag_wait(*first_park)
-                first_park = None
-            if cfg.has_y:
-                if p.Mf:
-                    Z3, Y = cfg.dim_z3, cfg.dim_y
-                    if self._fprop_from_heads():
-                        if first_park is not None:
-                            K.flag_wait(*first_park)
-                    else:
-                        K.rows_gather(p.FPIN, Z1blk, p.fp_src, onehot_cls=p.fp_cls, n_classes=Y,
-                                      park=(first_park[0], first_park[1], first_park[2]) if first_park is not None else None)
-                    if self.fuse_heads:
-                        # the z3 sample leaves the heads' launch of q(z3|z1,y); its KL term against N(0,I) (with its
-                        # own free bits) is evaluated next to the z1 term below: one launch less
-                        Q3 = p.c_top.forward([p.FPIN], heads=dict(sample=dict(eps=p.E3, out=p.Z3IN[:, :Z3], n_src=p.Mf)))
-                        PZ1 = p.c_dz1.forward([p.Z3IN])
-                        # KLFP = max(KL(q(z1|x)||p(z1|z3,y)), kl_min) + max(KL(q(z3|.)||N(0,I)), kl_min)  (src/DrVAE.py:347,358)
-                        # -- in the train step inside the classifier-head launch below (``_fprop_tail``)
-                        if not self._fprop_tail():
-                            K.kl_rows_fwd(p.KLFP, p.KL1raw, Qmu, Qlv, PZ1[:, :Z1], PZ1[:, Z1:], qidx=p.fp_q,
-                                          free_bits=True, kl_min=cfg.kl_min, prior=(0.0, 0.0),
-                                          second=(Q3[:, :Z3], Q3[:, Z3:], p.KL3raw))
-                    else:
-                        Q3 = p.c_top.forward([p.FPIN])
-                        # KL(q(z3|z1,y)||N(0,I)) with free bits + the z3 sample, one row pass
-                        K.kl_rows_fwd(p.KL3, p.KL3raw, Q3[:, :Z3], Q3[:, Z3:], prior=(0.0, 0.0), free_bits=True,
-                                      kl_min=cfg.kl_min, eps=p.E3, zout=p.Z3IN[:, :Z3])
-                        PZ1 = p.c_dz1.forward([p.Z3IN])
-                        # KLFP = max(KL(q(z1|x)||p(z1|z3,y)), kl_min) + the z3 term   (src/DrVAE.py:347,358)
-                        K.kl_rows_fwd(p.KLFP, p.KL1raw, Qmu, Qlv, PZ1[:, :Z1], PZ1[:, Z1:], qidx=p.fp_q, free_bits=True,
-                                      kl_min=cfg.kl_min, add=p.KL3)
-            # KL(q(z2|x2)||p(z2|z1)) of the pairs: both arguments come from the main chain and its consumers are the
-            # main chain's z2Fz1 backward and the loss scalars -- in the dual-graph train step the MAIN chain computes
-            # it (it has time to spare in front of the join, the side chain has not); then the wait for the z2Fz1
-            # samples rides on the classifier launch
-            klz2_here = cfg.has_pert and Np and not self._klz2_on_main()
-            clf_park = (mid_park is not None and not klz2_here and cfg.has_y and self.clf_small
-                        and (L * B + 3) // 4 <= 256)
-            fold_mid = mid_park is not None and klz2_here and (L * Np + 3) // 4 <= 256
-            if mid is not None and not fold_mid and not clf_park:
-                mid()
-            if klz2_here:
-                P2 = p.c_z2F.out[-1]
-                K.kl_rows_fwd(p.KLZ2, p.KLZ2raw, Qmu, Qlv, P2[:, :Z1], P2[:, Z1:], qidx=p.qz2_idx, pidx=p.pidx,
-                              reps=L, free_bits=True, kl_min=cfg.kl_min,
-                              park=(mid_park[0], mid_park[1], mid_park[2]) if fold_mid else None)
-            # ---- q(y|.)
-            if cfg.has_y:
-                if cfg.kind == 'drvae':
-                    clf_in = [Z1blk, p.D] if cfg.clf_z1z2 else [p.Z2F]
-                else:
-                    clf_in = [Z1blk]
-                ym = (p.YLrow, p.KLDrow, p.CFP, p.DQY, p.label_r, p.fp_ptr, p.KLFP, p.log_prior, p.c_kld, p.c_yl)
-                if self.clf_small:
-                    lc = self.L_clf[0]
-                    # train step: the y-marginalisation (forward and backward) rides on the classifier's launch
-                    fk = None
-                    if self._fprop_tail():
-                        # the fprop rows' KL terms in front of the y-marginalisation and the backward of the z1 term
-                        # (with the coefficients it has just produced) behind it: same launch
-                        fk = dict(Q=p.c_enc.out[-1], qidx=p.fp_q, P=p.c_dz1.out[-1], Q3=p.c_top.out[-1], Z1=Z1,
-                                  Z3=cfg.dim_z3, kl_min=cfg.kl_min, raw1=p.KL1raw, raw3=p.KL3raw, dq=p.DQFP, dp=p.DPZ1)
-                    K.smalln_fwd(p.QY, None, clf_in[0], lc.W, lc.b, clf_in[1] if len(clf_in) > 1 else None,
-                                 ymarg=ym if self.fuse_bwd else None,
-                                 park=(mid_park[0], mid_park[1], mid_park[2]) if clf_park else None, fprop_kl=fk)
-                else:
-                    K.softmax_clamp_fwd(p.QY, p.c_clf.forward(clf_in), sigmoid1=cfg.clf_1sig)
-                if self.fuse_bwd and self.clf_small:
-                    pass
-                elif self.fuse_bwd:    # train step: CFP / DQY of the backward pass come out of the same launch
-                    K.ymarg_fwdbwd(p.YLrow, p.KLDrow, p.CFP, p.DQY, p.QY, p.label_r, p.fp_ptr, p.KLFP, p.log_prior,
-                                   p.c_kld, p.c_yl)
-                else:
-                    K.ymarg_fwd(p.YLrow, p.KLDrow, p.QY, p.label_r, p.fp_ptr, p.KLFP, p.log_prior)
         mode = self._mode()
         if mode == 5:
             two = cfg.has_pert                      # flag 0: z1 samples final; flag 2: z2Fz1 samples final
@@ -670,7 +503,8 @@ class FusedStep(StepSchedule):
                 # nothing left to wait for when the side chain reaches it: it rides on the KL row kernel behind it
                 K.flag_wait(*w0)
                 fold = self.fold_waits and not cfg.cont
-                side_forward((lambda: K.flag_wait(*w2)) if two else None, mid_park=w2 if (two and fold) else None)
+                self._side_forward(Qmu, Qlv, Z1blk, (lambda: K.flag_wait(*w2)) if two else None,
+                                   mid_park=w2 if (two and fold) else None)
                 return
             pub = (self.flags[2:3] if two else self.flags[0:1], self.step_dev, 1)
             if self.L_decx[0].g is not None:             # WeightNorm: the chain's first launch is not the GEMM
@@ -679,6 +513,98 @@ class FusedStep(StepSchedule):
         else:
             self.branch.fork()
             pub = None
+        self._decoder_forward(pub)
+        if mode == 5:
+            if self._klz2_on_main() and cfg.has_pert and Np:
+                P2 = p.c_z2F.out[-1]
+                K.kl_rows_fwd(p.KLZ2, p.KLZ2raw, Qmu, Qlv, P2[:, :Z1], P2[:, Z1:], qidx=p.qz2_idx, pidx=p.pidx,
+                              reps=L, free_bits=True, kl_min=cfg.kl_min)
+            return             # main-chain graph: the side chain lives in its own graph on the side stream
+        with self.branch:
+            self._side_forward(Qmu, Qlv, Z1blk)
+        if mode == 3:
+            return             # train step, single fork/join: the side chain runs on into its backward
+        self.branch.join()
+        if self.fuse_bwd:
+            return             # the loss scalars are assembled on the side chain of backward()
+        self._loss_scalars()
+
+    def _encoder_forward(self, rec):
+        """inputs (explicit batch or the graph-resident feed, + the per-batch masks of a universal plan), q(z1|x1) / q(z2|x2) with
+        their samples, the perturbation function q(z2Fz1|z1) with its samples; returns the heads' (mu, logvar) views"""
+        cfg, p = self.cfg, self.plan
+        B, Np, L, Z1 = p.B, p.Np, cfg.L, cfg.dim_z1
+        sigma = cfg.add_noise_var if (self.training and self.add_noise and cfg.add_noise_var > 0) else 0.0
+        Z1blk = p.ZDEC[:L * B]
+        # ---- inputs (+ training noise N(0,1)*add_noise_var, src/DrVAE.py:404-407,414-417): one gather
+        fd = p.live_feed if (self.fuse_bwd and self.training) else None
+        masks = None
+        if p.universal:
+            # which rows of THIS batch are pairs / labeled -> coefficient and weight vectors, on the device (with
+            # the graph-resident feed: by one more workgroup of the feed's launch)
+            masks = dict(n_tot=float(B), kl_rate=cfg.kl_qz2pz2_rate, pert_rate=cfg.pertloss_rate,
+                         yl_rate=cfg.yloss_rate, beta=p.beta_dev, c_nll=p.c_nll, w_recl=p.w_recl,
+                         hx=(fd.hx32 if fd is not None else p.hx_dev) if cfg.has_pert else None,
+                         hy=(fd.hy32 if fd is not None else p.hy_dev) if cfg.has_y else None,
+                         y=(fd.y32 if fd is not None else p.y_dev) if cfg.has_y else None,
+                         c_klz2=p.c_klz2 if cfg.has_pert else None, c_yl=p.c_yl, w_pert=p.w_pert, w_yl=p.w_yl,
+                         label=p.label_r if cfg.has_y else None, c_klp=p.c_klp if cfg.kind == 'pvae' else None,
+                         Np=Np if cfg.has_pert else 0, one_slot=p.one_slot)
+            if fd is None:
+                K.batch_masks(B, L, **masks)
+        if fd is not None:
+            # batch (optimiser step - epoch base) of the epoch's index table, straight from the
+            # HBM-resident dataset; also refreshes the label-dependent index buffers
+            # (universal plan: dv_batch_masks has the labels; its rows with ONE fprop row get their class columns here)
+            lab = cfg.has_y and not cfg.cont and (not p.universal or p.one_slot is not None)
+            K.batch_feed(p.XIN, fd.x1, fd.x2, fd.y32, fd.table, fd.n_batches, self.step_dev, fd.base,
+                         pair_rows=p.pair_idx if Np else None, noise=p.EX if sigma else None, sigma=sigma,
+                         has_y=p.has_y_i32 if (lab and not p.universal) else None, L=L,
+                         label_r=p.label_r if (lab and not p.universal) else None,
+                         fp_i=p.fp_q if lab else None, fp_lab=p.fp_lab_i32 if lab else None,
+                         fp_slot=p.fp_slot_dev if lab else None, fp_cls=p.fp_cls if (lab and p.Mf) else None,
+                         onehot=p.Z3IN[:, cfg.dim_z3:] if (lab and p.Mf) else None, n_classes=cfg.dim_y,
+                         onehot2=p.FPIN[:, Z1:] if (lab and p.Mf) else None,
+                         yf=fd.yf if (cfg.has_y and cfg.cont) else None,
+                         ylab=p.ylab if (cfg.has_y and cfg.cont) else None, masks=masks)
+        else:
+            K.rows_gather(p.XIN, p.XSRC, p.xin_idx, noise=p.EX if sigma else None, sigma=sigma)
+        # ---- q(z1|x1), q(z2|x2): one pass of the shared encoder; the samples (src/blocks.py:170-174) -- z1
+        # for every row and z2 for the pairs, drawn from q(z1|x1), not q(z2|x2) (quirk 1, src/DrVAE.py:427) --
+        # leave the heads' launch itself (``fuse_heads``) or one launch of their own
+        fuse = self.fuse_heads and self._heads_small(p.DPX)
+        Z1blk = p.ZDEC[:L * B]
+        if fuse:
+            # (... and every z1 sample is copied into the z1 columns of its fprop rows on the way out: the side
+            # chain's gather is gone)
+            fp4 = self._fprop_from_heads()
+            Q = p.c_enc.forward(p.enc_in, heads=dict(sample=dict(
+                eps=p.E12, out=p.ZDEC[:p.o3], n_src=B, seg_ptr=p.zseg_ptr, seg_rows=p.zseg_rows,
+                out4=p.FPIN[:, :Z1] if fp4 else None, out4_ptr=p.fp_ptr_ext if fp4 else None)))
+            Qmu, Qlv = Q[:, :Z1], Q[:, Z1:]
+        else:
+            Q = p.c_enc.forward(p.enc_in)
+            Qmu, Qlv = Q[:, :Z1], Q[:, Z1:]
+            K.reparam_fwd(p.ZDEC[:p.o3], Qmu, Qlv, p.E12, src_idx=p.z_src_idx)
+        if cfg.has_pert:
+            # (dual-graph schedule) entry of this launch = the z1 samples are final: lets the side
+            # chain's fprop start before the perturbation function has run
+            pub1 = (self.flags[0:1], self.step_dev, 1) if rec == 'main' else None
+            if fuse:
+                # z2Fz1 sample, the classifier input z2Fz1 - z1, and the decoder's copy for the pairs
+                p.c_z2F.forward([Z1blk], resid=Z1blk, publish=pub1, heads=dict(sample=dict(
+                    eps=p.E2F, out=p.Z2F, n_src=L * B, sub=Z1blk, out2=p.D, out3=p.ZDEC if Np else None,
+                    out3_idx=p.pert_out_idx if Np else None)))
+            else:
+                P2 = p.c_z2F.forward([Z1blk], resid=Z1blk, publish=pub1)
+                K.reparam_fwd(p.Z2F, P2[:, :Z1], P2[:, Z1:], p.E2F, sub=Z1blk, out2=p.D,
+                              out3=p.ZDEC if Np else None, out3_idx=p.pert_out_idx if Np else None)
+        return Qmu, Qlv
+
+    def _decoder_forward(self, pub=None):
+        """p(x|z): the decoder over all stacked sample rows, then the NLL over genes -- in a train step inside the heads'
+        launch, together with its gradient (``dv_gemm_heads``, NLL epilogue); ``pub``: flag published on entry of the first launch"""
+        cfg, p = self.cfg, self.plan
         # ---- p(x|z): decoder over all stacked samples, then the NLL over genes
         X = cfg.dim_x
         gauss = cfg.type_rec == 'diag_gaussian'
@@ -699,20 +625,118 @@ class FusedStep(StepSchedule):
                               xidx=p.tgt, sd_act='softplus', sd_shift=1e-3)
         else:
             K.nll_rows_fwd(p.NLL, p.XIN, PX[:, :X], PX[:, X:], mode=GAUSS_SIGMA, xidx=p.tgt)
-        if mode == 5:
-            if self._klz2_on_main() and cfg.has_pert and Np:
+
+    def _side_forward(self, Qmu, Qlv, Z1blk, mid=None, first_park=None, mid_park=None):
+        """fprop first: it only needs the z1 samples, so (dual-graph schedule) it can start before
+        the perturbation function has run; ``mid`` then waits for the z2Fz1 samples.  ``first_park`` / ``mid_park``
+        (dual-graph schedule): the two waits ride on the launch that follows them where that is a row kernel
+        with a small grid (one launch less each); else ``mid`` / a wait launch of its own."""
+        cfg, p = self.cfg, self.plan
+        B, Np, L, Z1 = p.B, p.Np, cfg.L, cfg.dim_z1
+        if cfg.kind == 'pvae':
+            K.kl_rows_fwd(p.KLP, p.KLPraw, Qmu, Qlv, prior=(0.0, 0.0), free_bits=True, kl_min=cfg.kl_min)
+        if cfg.has_y and cfg.cont:
+            # regression head (src/DrVAE.py:159-169,503-530): q(y|.) first -- the fprop of an unlabeled
+            # row conditions on a SAMPLE of it -- then one fprop row per classifier row
+            if mid is not None:
+                mid()
+            if cfg.has_pert and Np:
                 P2 = p.c_z2F.out[-1]
                 K.kl_rows_fwd(p.KLZ2, p.KLZ2raw, Qmu, Qlv, P2[:, :Z1], P2[:, Z1:], qidx=p.qz2_idx, pidx=p.pidx,
                               reps=L, free_bits=True, kl_min=cfg.kl_min)
-            return             # main-chain graph: the side chain lives in its own graph on the side stream
-        with self.branch:
-            side_forward()
-        if mode == 3:
-            return             # train step, single fork/join: the side chain runs on into its backward
-        self.branch.join()
-        if self.fuse_bwd:
-            return             # the loss scalars are assembled on the side chain of backward()
-        self._loss_scalars()
+            Z3, Y = cfg.dim_z3, cfg.dim_y
+            if cfg.kind == 'drvae':
+                clf_in = [Z1blk, p.D] if cfg.clf_z1z2 else [p.Z2F]
+            else:
+                clf_in = [Z1blk]
+            QYm = p.c_clf.forward(clf_in)                         # sigmoid-constrained means
+            K.rows_gather(p.FPIN[:, :Z1], Z1blk, p.fp_src)
+            K.ycont_fwd(p.YLrow, p.FPIN[:, Z1:], p.Z3IN[:, Z3:], QYm, p.ylab, p.has_y_i32, p.EY, Y_LOGVAR_CONT, B,
+                        sqerr=cfg.kind == 'vfae')       # VFAE scores by squared error (src/VFAE.py:351)
+            Q3 = p.c_top.forward([p.FPIN])
+            K.kl_rows_fwd(p.KL3, p.KL3raw, Q3[:, :Z3], Q3[:, Z3:], prior=(0.0, 0.0), free_bits=True,
+                          kl_min=cfg.kl_min, eps=p.E3, zout=p.Z3IN[:, :Z3])
+            PZ1 = p.c_dz1.forward([p.Z3IN])
+            K.kl_rows_fwd(p.KLDrow, p.KL1raw, Qmu, Qlv, PZ1[:, :Z1], PZ1[:, Z1:], qidx=p.fp_q, free_bits=True,
+                          kl_min=cfg.kl_min, add=p.KL3)
+            return
+        # ---- fprop over (labeled: true class | unlabeled: every class)
+        # (a parked launch polls from every workgroup: small grids only -- the C side refuses more than 512)
+        if first_park is not None and not (cfg.has_y and p.Mf and (p.Mf * (Z1 + cfg.dim_y) + 255) // 256 <= 256):
+            K.flag_wait(*first_park)
+            first_park = None
+        if cfg.has_y:
+            if p.Mf:
+                Z3, Y = cfg.dim_z3, cfg.dim_y
+                if self._fprop_from_heads():
+                    if first_park is not None:
+                        K.flag_wait(*first_park)
+                else:
+                    K.rows_gather(p.FPIN, Z1blk, p.fp_src, onehot_cls=p.fp_cls, n_classes=Y,
+                                  park=(first_park[0], first_park[1], first_park[2]) if first_park is not None else None)
+                if self.fuse_heads:
+                    # the z3 sample leaves the heads' launch of q(z3|z1,y); its KL term against N(0,I) (with its
+                    # own free bits) is evaluated next to the z1 term below: one launch less
+                    Q3 = p.c_top.forward([p.FPIN], heads=dict(sample=dict(eps=p.E3, out=p.Z3IN[:, :Z3], n_src=p.Mf)))
+                    PZ1 = p.c_dz1.forward([p.Z3IN])
+                    # KLFP = max(KL(q(z1|x)||p(z1|z3,y)), kl_min) + max(KL(q(z3|.)||N(0,I)), kl_min)  (src/DrVAE.py:347,358)
+                    # -- in the train step inside the classifier-head launch below (``_fprop_tail``)
+                    if not self._fprop_tail():
+                        K.kl_rows_fwd(p.KLFP, p.KL1raw, Qmu, Qlv, PZ1[:, :Z1], PZ1[:, Z1:], qidx=p.fp_q,
+                                      free_bits=True, kl_min=cfg.kl_min, prior=(0.0, 0.0),
+                                      second=(Q3[:, :Z3], Q3[:, Z3:], p.KL3raw))
+                else:
+                    Q3 = p.c_top.forward([p.FPIN])
+                    # KL(q(z3|z1,y)||N(0,I)) with free bits + the z3 sample, one row pass
+                    K.kl_rows_fwd(p.KL3, p.KL3raw, Q3[:, :Z3], Q3[:, Z3:], prior=(0.0, 0.0), free_bits=True,
+                                  kl_min=cfg.kl_min, eps=p.E3, zout=p.Z3IN[:, :Z3])
+                    PZ1 = p.c_dz1.forward([p.Z3IN])
+                    # KLFP = max(KL(q(z1|x)||p(z1|z3,y)), kl_min) + the z3 term   (src/DrVAE.py:347,358)
+                    K.kl_rows_fwd(p.KLFP, p.KL1raw, Qmu, Qlv, PZ1[:, :Z1], PZ1[:, Z1:], qidx=p.fp_q, free_bits=True,
+                                  kl_min=cfg.kl_min, add=p.KL3)
+        # KL(q(z2|x2)||p(z2|z1)) of the pairs: both arguments come from the main chain and its consumers are the
+        # main chain's z2Fz1 backward and the loss scalars -- in the dual-graph train step the MAIN chain computes
+        # it (it has time to spare in front of the join, the side chain has not); then the wait for the z2Fz1
+        # samples rides on the classifier launch
+        klz2_here = cfg.has_pert and Np and not self._klz2_on_main()
+        clf_park = (mid_park is not None and not klz2_here and cfg.has_y and self.clf_small
+                    and (L * B + 3) // 4 <= 256)
+        fold_mid = mid_park is not None and klz2_here and (L * Np + 3) // 4 <= 256
+        if mid is not None and not fold_mid and not clf_park:
+            mid()
+        if klz2_here:
+            P2 = p.c_z2F.out[-1]
+            K.kl_rows_fwd(p.KLZ2, p.KLZ2raw, Qmu, Qlv, P2[:, :Z1], P2[:, Z1:], qidx=p.qz2_idx, pidx=p.pidx,
+                          reps=L, free_bits=True, kl_min=cfg.kl_min,
+                          park=(mid_park[0], mid_park[1], mid_park[2]) if fold_mid else None)
+        # ---- q(y|.)
+        if cfg.has_y:
+            if cfg.kind == 'drvae':
+                clf_in = [Z1blk, p.D] if cfg.clf_z1z2 else [p.Z2F]
+            else:
+                clf_in = [Z1blk]
+            ym = (p.YLrow, p.KLDrow, p.CFP, p.DQY, p.label_r, p.fp_ptr, p.KLFP, p.log_prior, p.c_kld, p.c_yl)
+            if self.clf_small:
+                lc = self.L_clf[0]
+                # train step: the y-marginalisation (forward and backward) rides on the classifier's launch
+                fk = None
+                if self._fprop_tail():
+                    # the fprop rows' KL terms in front of the y-marginalisation and the backward of the z1 term
+                    # (with the coefficients it has just produced) behind it: same launch
+                    fk = dict(Q=p.c_enc.out[-1], qidx=p.fp_q, P=p.c_dz1.out[-1], Q3=p.c_top.out[-1], Z1=Z1,
+                              Z3=cfg.dim_z3, kl_min=cfg.kl_min, raw1=p.KL1raw, raw3=p.KL3raw, dq=p.DQFP, dp=p.DPZ1)
+                K.smalln_fwd(p.QY, None, clf_in[0], lc.W, lc.b, clf_in[1] if len(clf_in) > 1 else None,
+                             ymarg=ym if self.fuse_bwd else None,
+                             park=(mid_park[0], mid_park[1], mid_park[2]) if clf_park else None, fprop_kl=fk)
+            else:
+                K.softmax_clamp_fwd(p.QY, p.c_clf.forward(clf_in), sigmoid1=cfg.clf_1sig)
+            if self.fuse_bwd and self.clf_small:
+                pass
+            elif self.fuse_bwd:    # train step: CFP / DQY of the backward pass come out of the same launch
+                K.ymarg_fwdbwd(p.YLrow, p.KLDrow, p.CFP, p.DQY, p.QY, p.label_r, p.fp_ptr, p.KLFP, p.log_prior,
+                               p.c_kld, p.c_yl)
+            else:
+                K.ymarg_fwd(p.YLrow, p.KLDrow, p.QY, p.label_r, p.fp_ptr, p.KLFP, p.log_prior)
 
     def _fprop_from_heads(self):
         """the encoder heads' sample epilogue also fills the z1 columns of the fprop input (the class columns are
@@ -796,6 +820,9 @@ class FusedStep(StepSchedule):
 
     # --------------------------------------------------------------------- backward
     def backward(self):
+        """The hand-written backward pass, scheduled like ``forward``: the side chain's share (``_side_backward``; in the
+        dual-graph schedule followed by ``_side_graph_tail``) next to the main chain -- decoder, perturbation function,
+        samples, encoder -- which joins the side chain's d/dz contributions where it first needs them."""
         cfg, p = self.cfg, self.plan
         B, Np, L, Z1, X = p.B, p.Np, cfg.L, cfg.dim_z1, cfg.dim_x
         Q = p.c_enc.out[-1]
@@ -830,88 +857,6 @@ class FusedStep(StepSchedule):
         # the join, once the main chain has published that its reconstruction rows are final
         side_loss = side_adam or (late and split_kind is True and len(self.L_decx) > 1 and not self.wbranch.on)
 
-        def wgrad_clf(*args):
-            if late:
-                # (its entry also tells the main chain that the side chain's data gradients are final: see below)
-                leaf.append(lambda pub=None: K.smalln_bwd_weight(*args, publish=pub))
-            else:
-                K.smalln_bwd_weight(*args)
-
-        def side_backward():
-            if self.fuse_bwd and mode == 1:
-                self._loss_scalars()         # leaf work, off the critical path
-            if cfg.has_y and cfg.cont:
-                Y, Z3 = cfg.dim_y, cfg.dim_z3
-                PZ1, Q3, QYm = p.c_dz1.out[-1], p.c_top.out[-1], p.c_clf.out[-1]
-                K.ycont_bwd(None, p.CFP, QYm, p.ylab, p.has_y_i32, Y_LOGVAR_CONT, p.c_yl, p.c_kld, p.DFPIN[:, Z1:],
-                            p.DZ3IN[:, Z3:], B, sqerr=cfg.kind == 'vfae')     # cfp[r] = c_kld[r]: one fprop row per row
-                K.kl_rows_bwd(p.DQFP[:, :Z1], p.DQFP[:, Z1:], p.DPZ1[:, :Z1], p.DPZ1[:, Z1:], p.CFP, p.KL1raw,
-                              Qmu, Qlv, PZ1[:, :Z1], PZ1[:, Z1:], qidx=p.fp_q, free_bits=True, kl_min=cfg.kl_min)
-                p.c_dz1.backward(p.DPZ1, [p.Z3IN], [[(p.DZ3IN, 1.0, 0.0)]])
-                K.kl_rows_bwd(p.DQ3[:, :Z3], p.DQ3[:, Z3:], None, None, p.CFP, p.KL3raw, Q3[:, :Z3], Q3[:, Z3:],
-                              prior=(0.0, 0.0), free_bits=True, kl_min=cfg.kl_min, dz=p.DZ3IN[:, :Z3], eps=p.E3)
-                p.c_top.backward(p.DQ3, [p.FPIN], [[(p.DFPIN, 1.0, 0.0)]])
-                K.rows_segment_sum(p.DZ1B, p.DFPIN, seg_ptr=p.fp_ptr, beta=0.0, width=Z1)
-                # the y columns of both fprop inputs carry d/d(y sample); labeled rows: the log-likelihood
-                K.ycont_bwd(p.DLOG, None, QYm, p.ylab, p.has_y_i32, Y_LOGVAR_CONT, p.c_yl, p.c_kld, p.DFPIN[:, Z1:],
-                            p.DZ3IN[:, Z3:], B, sqerr=cfg.kind == 'vfae')
-                if cfg.kind == 'drvae' and cfg.clf_z1z2:
-                    p.c_clf.backward(p.DLOG, [Z1blk, p.D], [[(p.DZ1B, 1.0, 1.0)], [(p.DZ2F, 1.0, 0.0), (p.DZ1B, -1.0, 1.0)]])
-                elif cfg.kind == 'drvae':
-                    p.c_clf.backward(p.DLOG, [p.Z2F], [[(p.DZ2F, 1.0, 0.0)]])
-                else:
-                    p.c_clf.backward(p.DLOG, [Z1blk], [[(p.DZ1B, 1.0, 1.0)]])
-            elif cfg.has_y:
-                Y = cfg.dim_y
-                if not self.fuse_bwd:
-                    K.ymarg_bwd(p.CFP, p.DQY, p.QY, p.label_r, p.fp_ptr, p.KLFP, p.log_prior, p.c_kld, p.c_yl)
-                if p.Mf:
-                    Z3 = cfg.dim_z3
-                    PZ1, Q3 = p.c_dz1.out[-1], p.c_top.out[-1]
-                    # KL(q(z1|x) || p(z1|z3,y)): gradient to p (decoder_z1 heads) and, row-aligned, to q
-                    if not self._fprop_tail():       # (else: left the classifier-head launch of the forward pass)
-                        K.kl_rows_bwd(p.DQFP[:, :Z1], p.DQFP[:, Z1:], p.DPZ1[:, :Z1], p.DPZ1[:, Z1:], p.CFP, p.KL1raw,
-                                      Qmu, Qlv, PZ1[:, :Z1], PZ1[:, Z1:], qidx=p.fp_q, free_bits=True,
-                                      kl_min=cfg.kl_min)
-                    p.c_dz1.backward(p.DPZ1, [p.Z3IN], [[(p.DZ3IN, 1.0, 0.0)]])
-                    # KL(q(z3|z1,y) || N(0,I)) + the sample path
-                    K.kl_rows_bwd(p.DQ3[:, :Z3], p.DQ3[:, Z3:], None, None, p.CFP, p.KL3raw, Q3[:, :Z3], Q3[:, Z3:],
-                                  prior=(0.0, 0.0), free_bits=True, kl_min=cfg.kl_min, dz=p.DZ3IN[:, :Z3], eps=p.E3)
-                    p.c_top.backward(p.DQ3, [p.FPIN], [[(p.DFPIN, 1.0, 0.0)]])
-                    # z1 feeds one (labeled) or Y (unlabeled) fprop rows: their d/dz1 is summed per z1 row -- inside
-                    # the classifier's data-gradient launch where that launch writes DZ1B anyway, else on its own
-                    seg_in_clf = self.clf_small and not (cfg.kind == 'drvae' and not cfg.clf_z1z2)
-                    if not seg_in_clf:
-                        K.rows_segment_sum(p.DZ1B, p.DFPIN, seg_ptr=p.fp_ptr, beta=0.0, width=Z1)
-                # classifier
-                b1 = 1.0 if p.Mf else 0.0
-                seg = (p.DFPIN, p.fp_ptr) if p.Mf else None
-                two = cfg.kind == 'drvae' and cfg.clf_z1z2
-                if self.clf_small:
-                    lc = self.L_clf[0]
-                    if two:      # input [z1, z2F - z1]: d/dz1 gets W1 - W2, d/dz2F gets W2
-                        K.smalln_bwd_data([(p.DZ1B, 0, 1.0, b1, Z1, -1.0), (p.DZ2F, Z1, 1.0, 0.0)], p.DQY, p.QY, lc.W,
-                                          seg=seg)
-                        wgrad_clf(lc.dW, lc.db, p.DQY, p.QY, Z1blk, p.D)
-                    elif cfg.kind == 'drvae':
-                        K.smalln_bwd_data([(p.DZ2F, 0, 1.0, 0.0)], p.DQY, p.QY, lc.W)
-                        wgrad_clf(lc.dW, lc.db, p.DQY, p.QY, p.Z2F)
-                        if not p.Mf:
-                            p.DZ1B.zero_()
-                    else:
-                        K.smalln_bwd_data([(p.DZ1B, 0, 1.0, b1)], p.DQY, p.QY, lc.W, seg=seg)
-                        wgrad_clf(lc.dW, lc.db, p.DQY, p.QY, Z1blk)
-                else:
-                    K.softmax_clamp_bwd(p.DLOG, p.DQY, p.QY, sigmoid1=cfg.clf_1sig)
-                    if two:
-                        p.c_clf.backward(p.DLOG, [Z1blk, p.D],
-                                         [[(p.DZ1B, 1.0, b1)], [(p.DZ2F, 1.0, 0.0), (p.DZ1B, -1.0, 1.0)]])
-                    elif cfg.kind == 'drvae':
-                        p.c_clf.backward(p.DLOG, [p.Z2F], [[(p.DZ2F, 1.0, 0.0)]])
-                        if not p.Mf:
-                            p.DZ1B.zero_()
-                    else:
-                        p.c_clf.backward(p.DLOG, [Z1blk], [[(p.DZ1B, 1.0, b1)]])
         # ---- main chain: reconstruction terms, d/d(mu, pre-softplus) straight from the per-row
         # coefficients, then back through the decoder (the three big GEMMs)
         PX = p.c_decx.out[-1]
@@ -922,43 +867,8 @@ class FusedStep(StepSchedule):
             K.nll_rows_bwd(p.DPX[:, :X], p.DPX[:, X:], p.c_nll, p.XIN, PX[:, :X], PX[:, X:], mode=GAUSS_SIGMA,
                            xidx=p.tgt, sd_act='softplus', sd_shift=1e-3)
         if mode == 5 and self._rec == 'side':
-            side_backward()
-            # DZ1B / DZ2F / side gradients are final: published on entry of the first leaf launch behind them (the
-            # classifier's weight gradient) where there is one, else by a launch of its own
-            tail = (self.fold_tail & 1) and late and len(leaf) > 0
-            if tail:
-                leaf[0](pub=(self.flags[1:2], self.side_ctr, 1))
-                for fn in leaf[1:]:
-                    fn()
-            else:
-                K.flag_publish(self.flags[1:2], self.side_ctr)
-                for fn in leaf:
-                    fn()
-            if late:
-                if side_loss:
-                    a = self.arena
-                    K.flag_wait(self.flags[4:5], self.side_ctr, self.sync_err[8:10])
-                    if side_adam:
-                        K.adam_l2(a.param[hs:a.n_live], a.grad[hs:a.n_live], a.exp_avg[hs:a.n_live],
-                                  a.exp_avg_sq[hs:a.n_live], self.side_t, lr=cfg.learning_rate,
-                                  weight_decay=cfg.weight_decay, halt=self.sync_err)
-                    self._loss_scalars()   # a leaf too; the wait above also covers the main chain's NLL rows
-                if self.noise_ahead:
-                    # the next step's N(0,1) draws: every reader of this step's is through once the encoder
-                    # backward has started (the main chain publishes that), and the Philox counter has advanced;
-                    # the draw launch parks on that flag itself (``fold_tail``) or behind a wait launch
-                    w5 = (self.flags[5:6], self.side_ctr, self.sync_err[10:12])
-                    if self.fold_tail & 2:
-                        K.fill_normal_rows(p.noise, p.noise_desc, self.seed, self.rng_ctr, park=w5)
-                    else:
-                        K.flag_wait(*w5)
-                        K.fill_normal_rows(p.noise, p.noise_desc, self.seed, self.rng_ctr)
-                # ... and now the side chain's late work is final: published by the counter launch on entry
-                if self.fold_tail & 4:
-                    K.counters_add2(self.side_ctr, 1, self.side_t, 1, publish=(self.flags[3:4], self.side_ctr, 1))
-                    return
-                K.flag_publish(self.flags[3:4], self.side_ctr)
-            K.counters_add2(self.side_ctr, 1, self.side_t, 1)
+            self._side_backward(Qmu, Qlv, Z1blk, mode, late, leaf)
+            self._side_graph_tail(late, leaf, side_loss, side_adam, hs)
             return
         if mode < 2:
             self.branch.fork()
@@ -975,7 +885,7 @@ class FusedStep(StepSchedule):
             self._after_decoder_bwd()        # decoder_x gradients are final: graph split point of the overlapped exchange
         if mode != 5:
             with self.branch:
-                side_backward()
+                self._side_backward(Qmu, Qlv, Z1blk, mode, late, leaf)
             self.branch.join()
         # (only where the join does not wait: every workgroup of the consumer polls the flag, and a long wait -- VFAE:
         # its side chain is the longer one, 30 us/step -- slows the very chain it waits for: 0.184 -> 0.208 ms)
@@ -1027,6 +937,137 @@ class FusedStep(StepSchedule):
                           free_bits=True, kl_min=cfg.kl_min, beta=1.0)
         p.c_enc.backward(DQ, p.enc_in, None,
                          publish_first=(self.flags[5:6], self.step_dev, 0) if (late and self.noise_ahead) else None)
+
+    def _side_backward(self, Qmu, Qlv, Z1blk, mode, late, leaf):
+        """the side chain's share of the backward pass: y-marginalisation, fprop blocks, classifier -> ``DZ1B`` (its share
+        of d/dz1) and ``DZ2F``.  ``late``: the classifier's weight gradient is deferred (appended to ``leaf``: a leaf of the step
+        -- only the optimiser reads it -- that runs behind the side chain's publish)"""
+        cfg, p = self.cfg, self.plan
+        B, Np, L, Z1 = p.B, p.Np, cfg.L, cfg.dim_z1
+
+        def wgrad_clf(*args):
+            if late:
+                # (its entry also tells the main chain that the side chain's data gradients are final: see below)
+                leaf.append(lambda pub=None: K.smalln_bwd_weight(*args, publish=pub))
+            else:
+                K.smalln_bwd_weight(*args)
+
+        if self.fuse_bwd and mode == 1:
+            self._loss_scalars()         # leaf work, off the critical path
+        if cfg.has_y and cfg.cont:
+            Y, Z3 = cfg.dim_y, cfg.dim_z3
+            PZ1, Q3, QYm = p.c_dz1.out[-1], p.c_top.out[-1], p.c_clf.out[-1]
+            K.ycont_bwd(None, p.CFP, QYm, p.ylab, p.has_y_i32, Y_LOGVAR_CONT, p.c_yl, p.c_kld, p.DFPIN[:, Z1:],
+                        p.DZ3IN[:, Z3:], B, sqerr=cfg.kind == 'vfae')     # cfp[r] = c_kld[r]: one fprop row per row
+            K.kl_rows_bwd(p.DQFP[:, :Z1], p.DQFP[:, Z1:], p.DPZ1[:, :Z1], p.DPZ1[:, Z1:], p.CFP, p.KL1raw,
+                          Qmu, Qlv, PZ1[:, :Z1], PZ1[:, Z1:], qidx=p.fp_q, free_bits=True, kl_min=cfg.kl_min)
+            p.c_dz1.backward(p.DPZ1, [p.Z3IN], [[(p.DZ3IN, 1.0, 0.0)]])
+            K.kl_rows_bwd(p.DQ3[:, :Z3], p.DQ3[:, Z3:], None, None, p.CFP, p.KL3raw, Q3[:, :Z3], Q3[:, Z3:],
+                          prior=(0.0, 0.0), free_bits=True, kl_min=cfg.kl_min, dz=p.DZ3IN[:, :Z3], eps=p.E3)
+            p.c_top.backward(p.DQ3, [p.FPIN], [[(p.DFPIN, 1.0, 0.0)]])
+            K.rows_segment_sum(p.DZ1B, p.DFPIN, seg_ptr=p.fp_ptr, beta=0.0, width=Z1)
+            # the y columns of both fprop inputs carry d/d(y sample); labeled rows: the log-likelihood
+            K.ycont_bwd(p.DLOG, None, QYm, p.ylab, p.has_y_i32, Y_LOGVAR_CONT, p.c_yl, p.c_kld, p.DFPIN[:, Z1:],
+                        p.DZ3IN[:, Z3:], B, sqerr=cfg.kind == 'vfae')
+            if cfg.kind == 'drvae' and cfg.clf_z1z2:
+                p.c_clf.backward(p.DLOG, [Z1blk, p.D], [[(p.DZ1B, 1.0, 1.0)], [(p.DZ2F, 1.0, 0.0), (p.DZ1B, -1.0, 1.0)]])
+            elif cfg.kind == 'drvae':
+                p.c_clf.backward(p.DLOG, [p.Z2F], [[(p.DZ2F, 1.0, 0.0)]])
+            else:
+                p.c_clf.backward(p.DLOG, [Z1blk], [[(p.DZ1B, 1.0, 1.0)]])
+        elif cfg.has_y:
+            Y = cfg.dim_y
+            if not self.fuse_bwd:
+                K.ymarg_bwd(p.CFP, p.DQY, p.QY, p.label_r, p.fp_ptr, p.KLFP, p.log_prior, p.c_kld, p.c_yl)
+            if p.Mf:
+                Z3 = cfg.dim_z3
+                PZ1, Q3 = p.c_dz1.out[-1], p.c_top.out[-1]
+                # KL(q(z1|x) || p(z1|z3,y)): gradient to p (decoder_z1 heads) and, row-aligned, to q
+                if not self._fprop_tail():       # (else: left the classifier-head launch of the forward pass)
+                    K.kl_rows_bwd(p.DQFP[:, :Z1], p.DQFP[:, Z1:], p.DPZ1[:, :Z1], p.DPZ1[:, Z1:], p.CFP, p.KL1raw,
+                                  Qmu, Qlv, PZ1[:, :Z1], PZ1[:, Z1:], qidx=p.fp_q, free_bits=True,
+                                  kl_min=cfg.kl_min)
+                p.c_dz1.backward(p.DPZ1, [p.Z3IN], [[(p.DZ3IN, 1.0, 0.0)]])
+                # KL(q(z3|z1,y) || N(0,I)) + the sample path
+                K.kl_rows_bwd(p.DQ3[:, :Z3], p.DQ3[:, Z3:], None, None, p.CFP, p.KL3raw, Q3[:, :Z3], Q3[:, Z3:],
+                              prior=(0.0, 0.0), free_bits=True, kl_min=cfg.kl_min, dz=p.DZ3IN[:, :Z3], eps=p.E3)
+                p.c_top.backward(p.DQ3, [p.FPIN], [[(p.DFPIN, 1.0, 0.0)]])
+                # z1 feeds one (labeled) or Y (unlabeled) fprop rows: their d/dz1 is summed per z1 row -- inside
+                # the classifier's data-gradient launch where that launch writes DZ1B anyway, else on its own
+                seg_in_clf = self.clf_small and not (cfg.kind == 'drvae' and not cfg.clf_z1z2)
+                if not seg_in_clf:
+                    K.rows_segment_sum(p.DZ1B, p.DFPIN, seg_ptr=p.fp_ptr, beta=0.0, width=Z1)
+            # classifier
+            b1 = 1.0 if p.Mf else 0.0
+            seg = (p.DFPIN, p.fp_ptr) if p.Mf else None
+            two = cfg.kind == 'drvae' and cfg.clf_z1z2
+            if self.clf_small:
+                lc = self.L_clf[0]
+                if two:      # input [z1, z2F - z1]: d/dz1 gets W1 - W2, d/dz2F gets W2
+                    K.smalln_bwd_data([(p.DZ1B, 0, 1.0, b1, Z1, -1.0), (p.DZ2F, Z1, 1.0, 0.0)], p.DQY, p.QY, lc.W,
+                                      seg=seg)
+                    wgrad_clf(lc.dW, lc.db, p.DQY, p.QY, Z1blk, p.D)
+                elif cfg.kind == 'drvae':
+                    K.smalln_bwd_data([(p.DZ2F, 0, 1.0, 0.0)], p.DQY, p.QY, lc.W)
+                    wgrad_clf(lc.dW, lc.db, p.DQY, p.QY, p.Z2F)
+                    if not p.Mf:
+                        p.DZ1B.zero_()
+                else:
+                    K.smalln_bwd_data([(p.DZ1B, 0, 1.0, b1)], p.DQY, p.QY, lc.W, seg=seg)
+                    wgrad_clf(lc.dW, lc.db, p.DQY, p.QY, Z1blk)
+            else:
+                K.softmax_clamp_bwd(p.DLOG, p.DQY, p.QY, sigmoid1=cfg.clf_1sig)
+                if two:
+                    p.c_clf.backward(p.DLOG, [Z1blk, p.D],
+                                     [[(p.DZ1B, 1.0, b1)], [(p.DZ2F, 1.0, 0.0), (p.DZ1B, -1.0, 1.0)]])
+                elif cfg.kind == 'drvae':
+                    p.c_clf.backward(p.DLOG, [p.Z2F], [[(p.DZ2F, 1.0, 0.0)]])
+                    if not p.Mf:
+                        p.DZ1B.zero_()
+                else:
+                    p.c_clf.backward(p.DLOG, [Z1blk], [[(p.DZ1B, 1.0, b1)]])
+
+    def _side_graph_tail(self, late, leaf, side_loss, side_adam, hs):
+        """(dual-graph schedule) what the side chain's graph runs behind its backward pass: publish its data gradients, the
+        deferred leaf launches, the decoder heads' half of the optimiser sweep, the loss scalars, the NEXT step's noise, its
+        own counters"""
+        cfg, p = self.cfg, self.plan
+        # DZ1B / DZ2F / side gradients are final: published on entry of the first leaf launch behind them (the
+        # classifier's weight gradient) where there is one, else by a launch of its own
+        tail = (self.fold_tail & 1) and late and len(leaf) > 0
+        if tail:
+            leaf[0](pub=(self.flags[1:2], self.side_ctr, 1))
+            for fn in leaf[1:]:
+                fn()
+        else:
+            K.flag_publish(self.flags[1:2], self.side_ctr)
+            for fn in leaf:
+                fn()
+        if late:
+            if side_loss:
+                a = self.arena
+                K.flag_wait(self.flags[4:5], self.side_ctr, self.sync_err[8:10])
+                if side_adam:
+                    K.adam_l2(a.param[hs:a.n_live], a.grad[hs:a.n_live], a.exp_avg[hs:a.n_live],
+                              a.exp_avg_sq[hs:a.n_live], self.side_t, lr=cfg.learning_rate,
+                              weight_decay=cfg.weight_decay, halt=self.sync_err)
+                self._loss_scalars()   # a leaf too; the wait above also covers the main chain's NLL rows
+            if self.noise_ahead:
+                # the next step's N(0,1) draws: every reader of this step's is through once the encoder
+                # backward has started (the main chain publishes that), and the Philox counter has advanced;
+                # the draw launch parks on that flag itself (``fold_tail``) or behind a wait launch
+                w5 = (self.flags[5:6], self.side_ctr, self.sync_err[10:12])
+                if self.fold_tail & 2:
+                    K.fill_normal_rows(p.noise, p.noise_desc, self.seed, self.rng_ctr, park=w5)
+                else:
+                    K.flag_wait(*w5)
+                    K.fill_normal_rows(p.noise, p.noise_desc, self.seed, self.rng_ctr)
+            # ... and now the side chain's late work is final: published by the counter launch on entry
+            if self.fold_tail & 4:
+                K.counters_add2(self.side_ctr, 1, self.side_t, 1, publish=(self.flags[3:4], self.side_ctr, 1))
+                return
+            K.flag_publish(self.flags[3:4], self.side_ctr)
+        K.counters_add2(self.side_ctr, 1, self.side_t, 1)
 
     # -------------------------------------------------------------------- optimiser
     def optimizer_step(self, gscale=1.0):
