@@ -272,11 +272,15 @@ class StepSchedule:
                 self._flag_side = prev
         return ctx()
 
-    def tune_partition(self, candidates=(48, 64, 80, 96, 128), steps=24):
+    def tune_partition(self, candidates=(32, 64, 96, 128), steps=24):
         """Pick the CU split of ``partition()`` by timing replays of the captured step (the best split
         depends on how the two chains balance, i.e. on the model and on the individual GPU).  Runs on a
         scratch copy of the training state: parameters, Adam moments and all device counters are restored
-        afterwards.  Returns the chosen number of reserved CUs (None when partitioning does not apply)."""
+        afterwards.  Returns the chosen number of reserved CUs (None when partitioning does not apply).
+        Candidates are multiples of 32: bit i of a CU mask is a CU of shader engine i % 32 (8 XCDs x 4), and the dispatcher
+        hands every shader engine the same share of a grid -- a reserve that gives some engines one CU less makes those
+        the pace of the whole side chain (cfg 2: 56 reserved CUs 0.249 ms, 64: 0.1975, 72: 0.2125; every 8th / 4th / 2nd
+        bit instead of the first 64: 0.236; masks that overlap -- CUs open to both chains: 0.216-0.258)."""
         if not (self._partition_applicable() and self._side_graph is not None and len(self._graphs) == 1) or \
                 'DRVAE_SIDE_CUS' in os.environ:       # (multi-rank: split graphs need the exchange; keep the default)
             return None
