@@ -340,7 +340,8 @@ class DeviceBatcher:
                   if sp[0] >= want[0] and (sp[1] == sp[2] or (sp[1] >= want[1] and sp[2] <= want[2]))]
             ok.sort(key=lambda sp: 2 * sp[0] - (sp[2] - sp[1]))
             if not (ok and eng.use_capture(self._plan(ok[0]).key)):
-                raise RuntimeError('DeviceBatcher: no captured step for this feed (call prepare_epoch after begin_epoch)')
+                raise RuntimeError('DeviceBatcher: no captured step for this feed (call prepare_epoch after begin_epoch; '
+                                   'a table of another size is a new feed: its steps are captured again)')
         self.n_switch += eng.plan is not cur
 
     def _reference_epoch(self):

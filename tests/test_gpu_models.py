@@ -427,8 +427,24 @@ def test_sampler_mode_pair_buckets_gpu(kind, label_bucket, dev):
                 assert fed.plan.Mf == spec.L * (64 * spec.dim_y - (b - a) * (spec.dim_y - 1))
             eager.set_batch(ds.x1[i], ds.x2[i], ds.y[i].cpu(), hx, hy)
             eager.train_step()
+    # a re-drawn table WITHOUT new captures: a composition not met before runs on the cheapest captured plan that
+    # serves it (pair slots for all its pairs, a labeled range inside its run of labeled rows)
+    tab = bat.begin_epoch(n_batches=5).clone()          # (same table size: the captured steps read this table)
+    n_before, fell_back = len(n_cap), 0
+    for k in range(5):
+        bat.select(k)
+        fed.replay()
+        i = tab[k].long()
+        hx, hy = ds.has_x2[i].cpu().numpy(), ds.has_y[i].cpu().numpy()
+        key = fed.plan.key
+        slots, lab = (key[3] if len(key) > 3 else 64), (key[4:6] if len(key) > 4 else (0, 0))
+        fell_back += (slots,) + tuple(lab) != tuple(bat.batch_specs[k])
+        assert key in set(n_cap) and (spec.kind == 'vfae' or int(hx.sum()) <= slots) and hy[lab[0]:lab[1]].all()
+        eager.universal_pair_slots, eager.universal_labeled_range = slots, lab
+        eager.set_batch(ds.x1[i], ds.x2[i], ds.y[i].cpu(), hx, hy)
+        eager.train_step()
     torch.cuda.synchronize()
-    assert len(used) > 1 and len(n_cap) == len(set(n_cap)) and used <= set(n_cap)
+    assert len(used) > 1 and len(n_cap) == len(set(n_cap)) == n_before and used <= set(n_cap)
     assert eager.losses() == fed.losses()
     assert torch.equal(a0.param, a1.param)
     fed.check_sync()
