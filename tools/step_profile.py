@@ -27,6 +27,10 @@ def timed_graph(fns, reps=1):
 def main():
     wl = sys.argv[1] if len(sys.argv) > 1 else 'cfg2'
     dev = torch.device('cuda:0')
+    for kv in filter(None, os.environ.get('STEP_PROFILE_GEMM_OPTS', '').split(',')):       # dv_gemm_set_option keys
+        k, v = kv.split('=')
+        from drvae_amd import _lib
+        _lib.load().dv_gemm_set_option(int(k), int(v))
     cfg, eng, arena, batch, desc = bench.build(wl, dev, 0, 1)
     if len(sys.argv) > 2 and sys.argv[2].startswith('universal'):
         # the batch-independent plan of the sampler feed on the same batch (universal:N = N pair slots, pairs first)
@@ -67,6 +71,22 @@ def main():
     print('single-stream graph, main-stream launches only : %.1f us' % timed_graph([f for _, s, f in rec if not s]))
     print('single-stream graph, side-stream launches only : %.1f us' % timed_graph([f for _, s, f in rec if s]))
     print('single-stream graph, all launches in order     : %.1f us' % timed_graph([f for _, _, f in rec]))
+    if os.environ.get('STEP_PROFILE_MASKS'):
+        # the side chain's launches under a CU mask (the reserve of partition()): per launch and as one graph
+        for n in [int(x) for x in os.environ['STEP_PROFILE_MASKS'].split(',')]:
+            pair = eng._part_streams(n)
+            if pair is None:
+                continue
+            with torch.cuda.stream(pair[1]):
+                side = [(nm, f) for (nm, sd, f) in rec if sd]
+                ts = [timed_graph([f], reps=10) for _, f in side]
+                print('side chain on %d CUs: one graph %.1f us; per launch: %s' % (
+                    n, timed_graph([f for _, f in side]), ' '.join('%s=%.1f' % (nm[:14], t) for (nm, _), t in zip(side, ts))))
+            with torch.cuda.stream(pair[0]):
+                mainl = [(nm, f) for (nm, sd, f) in rec if not sd]
+                ts = [timed_graph([f], reps=10) for _, f in mainl]
+                print('main chain on %d CUs: one graph %.1f us; per launch: %s' % (
+                    256 - n, timed_graph([f for _, f in mainl]), ' '.join('%s=%.1f' % (nm[:14], t) for (nm, _), t in zip(mainl, ts))))
     print('\nsequence:')
     for (name, side, _), t in zip(rec, per):
         print('  %s %-18s %7.1f' % ('S' if side else 'M', name, t))
