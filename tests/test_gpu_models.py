@@ -136,7 +136,7 @@ def test_partitioned_replay_equals_eager(kind, dev):
         set_batch(e, batch, dev)
         e.train_step()
     graph.capture()
-    graph.tune_partition(candidates=(48, 64), steps=4)
+    graph.tune_partition(candidates=(32, 64), steps=4)
     with graph.partition():
         for _ in range(6):
             graph.replay()
