@@ -388,6 +388,50 @@ def test_universal_plan_matches_reference_gpu(name, dev):
             np.testing.assert_allclose(a, gold['param%d/%s' % (nsteps - 1, k)], rtol=2e-4, atol=5e-5)
 
 
+@pytest.mark.parametrize('name', ['tiny_drvae', 'cfg2_drvae', 'tiny_vfae'])
+def test_bucketed_universal_plan_matches_reference_gpu(name, dev):
+    """N2, the bucketed sampler feed's plans against the reference's golden losses: the golden batch with its rows in the
+    feed's order (unlabeled pairs | labeled pairs | labeled singles | unlabeled singles; the loss is a sum over rows and
+    the injected noise is addressed by row, so the reference values stand), pair slots and labeled range rounded the way
+    ``DeviceBatcher(pair_bucket=16, label_bucket=8)`` rounds them -- cfg 2 at its full size: 150 rows, L=2"""
+    from tests.test_engine_cpu import make_engine, set_batch
+    case, gold = C.model_case(name), C.load('model_' + name)
+    spec = case['spec']
+    batch = {k: np.asarray(v) for k, v in case['batch'].items()}
+    hx, hy = batch['has_x2'].reshape(-1).astype(bool), batch['has_y'].reshape(-1).astype(bool)
+    if spec.kind == 'vfae':
+        hx = np.zeros_like(hy)
+    grp = np.where(hx, hy.astype(int), 3 - hy.astype(int))
+    order = np.argsort(grp, kind='stable')
+    B, w, v = len(order), 16, 8
+    n_p, n_up, n_l = int(hx.sum()), int((hx & ~hy).sum()), int(hy.sum())
+    slots = min(B, max(min(w, B), -(-n_p // w) * w)) if spec.kind != 'vfae' else None
+    a, b = min(-(-n_up // v) * v, B), (n_up + n_l) // v * v
+    lab = (a, b) if b > a else None
+    pb = {k: (x[order] if (hasattr(x, 'shape') and x.shape[:1] == (B,)) else x) for k, x in batch.items()}
+    perm = lambda nz: {k: (x[order] if k in ('nx1', 'nx2') else x[..., order, :]) for k, x in nz.items()}
+    eng, arena = make_engine(spec, M.init_params(spec, case['param_seed'], as_numpy=True), dev)
+    eng.universal, eng.universal_pair_slots, eng.universal_labeled_range = True, slots, lab
+    p = set_batch(eng, pb, dev)
+    assert p.universal and (slots is None or p.Np == slots) and (lab is None or p.Mf < spec.L * B * spec.dim_y)
+    eng.training = False
+    eng.set_noise(perm(case['noises'][0]))
+    eng.forward()
+    for k, val in eng.losses().items():
+        np.testing.assert_allclose(val, gold['eval/' + k], rtol=1e-4, atol=2e-5)
+    for step, noise in enumerate(case['noises']):
+        eng.train_step(perm(noise))
+        for k, val in eng.losses().items():
+            np.testing.assert_allclose(val, gold['step%d/%s' % (step, k)], rtol=1e-4, atol=2e-5)
+    nsteps = len(case['noises'])
+    for k in arena.shapes:
+        got = arena.p(k).cpu().numpy()
+        if case['full']:
+            np.testing.assert_allclose(got, gold['param%d/%s' % (nsteps - 1, k)], rtol=2e-4, atol=5e-5)
+        else:
+            np.testing.assert_allclose(got.astype(np.float64).sum(), gold['paramsum%d/%s' % (nsteps - 1, k)], rtol=1e-4, atol=2e-3)
+
+
 @pytest.mark.parametrize('kind,label_bucket', [('drvae', None), ('pvae', None), ('drvae', 4), ('vfae', 8)])
 def test_sampler_mode_pair_buckets_gpu(kind, label_bucket, dev):
     """N2, mode='sampler' with pair_bucket: batches re-ordered pairs first, each replayed on the captured plan of its
