@@ -368,6 +368,9 @@ class DeviceBatcher:
 
     def feed(self, idx=None):
         """draw the next batch and write it into the bound engine's buffers (device to device)"""
+        if self.mode == 'sampler' and self.bucketed:
+            # explicit batches come in the order they were drawn: the plan without assumptions about the row order
+            self.engine.set_structure_universal(self.batch_size)
         p = self.engine.plan
         p.feed_active = False       # this batch is explicit data in XSRC, not a row of the epoch table
         idx = self.next_indices() if idx is None else idx
