@@ -103,7 +103,7 @@ SIGNATURES = {
     'dv_kl_rows_bwd': [_p, _p, _i32, _f, _p, _p, _i64, _p, _p, _p, _i64, _p, _f, _f, _i32, _i32, _i32, _i32,
                        _p, _p, _i64, _p, _p, _i64, _f, _p, _i64, _p, _i64, _p],
     'dv_gauss_nll_rows_fwd': [_p, _i64, _p, _p, _p, _i64, _i32, _i32, _i32, _p, _p],
-    'dv_gauss_nll_rows_fwdbwd': [_p, _p, _i64, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _f, _p, _p, _p, _i64, _p],
+    'dv_gauss_nll_rows_fwdbwd': [_p, _p, _i64, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _f, _p, _p, _p, _i64, _p, _p, _p],
     'dv_rec_nll_rows': [_i32, _f, _p, _p, _i64, _p, _p, _i64, _i32, _i32, _p, _p, _i64, _p],
     'dv_gauss_nll_rows_bwd': [_p, _p, _i64, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _f, _p, _p, _i64, _p, _i64,
                               _f, _p],
@@ -150,7 +150,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 6     # DV_ABI_VERSION of include/drvae_hip.h
+ABI_VERSION = 7     # DV_ABI_VERSION of include/drvae_hip.h
 
 
 def load():

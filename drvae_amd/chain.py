@@ -48,8 +48,15 @@ class _Chain:
         # gradient w.r.t. the pre-activation of every layer but the last (the caller owns that one)
         self.dpre = [torch.zeros(M, _pad4(l.N), device=device)[:, :l.N] for l in layers[:-1]]
 
-    def forward(self, inputs, resid=None, publish=None, heads=None):
+    def raw_last_ok(self):
+        """may the last layer run as a plain product (no bias, no activation), finished by its consumer?"""
+        l = self.layers[-1]
+        return l.g is None and l.split * 2 == l.N and l.act0 == 'identity' and self.resid_cols == 0
+
+    def forward(self, inputs, resid=None, publish=None, heads=None, raw_last=False):
         """``publish`` = (flag, counter, add): the FIRST launch of the chain publishes on entry.
+        ``raw_last``: the last layer's launch is the plain product x W^T -- bias, the second head's activation and its
+        shift are left to the consumer (``K.nll_rows_fwdbwd(bias=...)``: chip-filling heads, plain GEMM epilogue).
         ``heads`` = dict(sample=...) | dict(nll=..., out=...): the dual-head last layer runs as ``K.linear_heads``
         with that row work fused into its epilogue (with ``nll`` the heads themselves are NOT stored: ``out``
         receives their gradients)."""
@@ -66,6 +73,11 @@ class _Chain:
                                resid_cols=self.resid_cols if resid is not None else 0, overread=True,
                                publish=publish if (li == 0 and l.g is None) else None,
                                sample=heads.get('sample'), nll=heads.get('nll'))
+                return self.out[-1]
+            if last and raw_last:
+                assert self.raw_last_ok() and resid is None
+                K.gemm(self.out[li], x[0], l.W, True, True, A2=x[1] if len(x) > 1 else None, overread=True,
+                       publish=publish if li == 0 else None)
                 return self.out[-1]
             K.linear_fwd(self.out[li], x[0], l.W, l.b, x2=x[1] if len(x) > 1 else None, scale=l.scale, split=l.split,
                          act0=l.act0, act1=l.act1, shift0=l.shift0, shift1=l.shift1,

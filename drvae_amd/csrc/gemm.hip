@@ -1084,7 +1084,9 @@ static int gemm_prepare(const dv_gemm_desc* d, LoadCfg& lc, int& tiling) {
     // tiling wins (more resident workgroups hide the per-K-tile latency chain); the larger
     // tiles only pay once their grids alone fill the chip several times over
     const int64_t t64_min = g_opt[3] > 0 ? g_opt[3] : 1024;
-    if (tiling == 0) tiling = (t128 >= 1024) ? 3 : (t64 >= t64_min ? 1 : 2);
+    // ... or once K is long enough to amortise a tile's prologue over many K steps: 1536 x 2048 x 20000 (encoder L1 of
+    // the wide configuration, 768 tiles of 64x64) runs 956 us on the 64x64 tiling, 1090 us on 32x32, 1336 us on 128x128
+    if (tiling == 0) tiling = (t128 >= 1024) ? 3 : ((t64 >= t64_min || (t64 >= 512 && g.K >= 8192)) ? 1 : 2);
     // workgroup -> tile map: XCD chunk-major for the small grids (each XCD keeps a compact band of the
     // output, its panels stay in its L2); for the grids that fill the chip many times over, bands of 16 tile
     // rows swept column by column (measured, wide configuration: chunk-major 121.5, linear 127.0, bands of 16

@@ -452,7 +452,9 @@ __global__ __launch_bounds__(256) void nll_rows_fwdbwd_kernel(const float* __res
                                                               const float* __restrict__ sd, int64_t ldp, int M, int X,
                                                               int mode, int sd_act, float sd_shift,
                                                               float* __restrict__ out, float* __restrict__ dmu,
-                                                              float* __restrict__ dsd, int64_t ldd) {
+                                                              float* __restrict__ dsd, int64_t ldd,
+                                                              const float* __restrict__ bias_mu,
+                                                              const float* __restrict__ bias_sd) {
     // one WORKGROUP per row, its four waves splitting the genes: a few hundred rows of ~1000 genes is
     // too little for wave-per-row to fill the chip (596 waves = 149 workgroups), and each wave's
     // dependent load->store chain is then 4x shorter
@@ -466,12 +468,22 @@ __global__ __launch_bounds__(256) void nll_rows_fwdbwd_kernel(const float* __res
         float* gsr = dsd + (int64_t)r * ldd;
         const float c = coef[r];
         float acc = 0.f;
+        // bias_mu != NULL: mu / sd hold the heads' RAW products (x W^T, no bias, no activation) -- the chip-filling
+        // heads product then runs with the plain epilogue (8192 x 40000 x 2048: 9.97 ms instead of 10.87 with bias +
+        // softplus in its 128x128 tiles' epilogue) and this HBM-bound pass applies them on its way
+        const bool raw = bias_mu != nullptr;
+        auto fin_m = [&](float v, int g) { return raw ? v + bias_mu[g] : v; };
+        auto fin_s = [&](float v, int g) { return raw ? dv_act(sd_act, v + bias_sd[g]) + sd_shift : v; };
         if (VEC2) {
             const int X2 = X >> 1;
             for (int q = threadIdx.x; q < X2; q += 256) {
                 const float2 xv = reinterpret_cast<const float2*>(xr)[q];
-                const float2 mv = reinterpret_cast<const float2*>(mr)[q];
-                const float2 sv = reinterpret_cast<const float2*>(sr)[q];
+                float2 mv = reinterpret_cast<const float2*>(mr)[q];
+                float2 sv = reinterpret_cast<const float2*>(sr)[q];
+                mv.x = fin_m(mv.x, 2 * q);
+                mv.y = fin_m(mv.y, 2 * q + 1);
+                sv.x = fin_s(sv.x, 2 * q);
+                sv.y = fin_s(sv.y, 2 * q + 1);
                 float2 gm, gs;
                 nll_fb_elem(mode, sd_act, sd_shift, c, xv.x, mv.x, sv.x, acc, gm.x, gs.x);
                 nll_fb_elem(mode, sd_act, sd_shift, c, xv.y, mv.y, sv.y, acc, gm.y, gs.y);
@@ -480,17 +492,73 @@ __global__ __launch_bounds__(256) void nll_rows_fwdbwd_kernel(const float* __res
             }
             if ((X & 1) && threadIdx.x == 0) {
                 float gm, gs;
-                nll_fb_elem(mode, sd_act, sd_shift, c, xr[X - 1], mr[X - 1], sr[X - 1], acc, gm, gs);
+                nll_fb_elem(mode, sd_act, sd_shift, c, xr[X - 1], fin_m(mr[X - 1], X - 1), fin_s(sr[X - 1], X - 1), acc, gm, gs);
                 gmr[X - 1] = gm;
                 gsr[X - 1] = gs;
             }
         } else {
             for (int g = threadIdx.x; g < X; g += 256) {
                 float gm, gs;
-                nll_fb_elem(mode, sd_act, sd_shift, c, xr[g], mr[g], sr[g], acc, gm, gs);
+                nll_fb_elem(mode, sd_act, sd_shift, c, xr[g], fin_m(mr[g], g), fin_s(sr[g], g), acc, gm, gs);
                 gmr[g] = gm;
                 gsr[g] = gs;
             }
+        }
+        acc = dv_wave_sum_all(acc);
+        if (lane == 0) part[wave] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) out[r] = -0.5f * ((part[0] + part[1]) + (part[2] + part[3]));
+        __syncthreads();
+    }
+}
+
+// The raw-heads case of the pass above for the decoder the models build (sigma head = softplus + shift), written for
+// the size it exists for (wide configuration: 8192 rows x 20000 genes, 2.9 GB of traffic): four genes per lane and the
+// hardware transcendentals -- one exp, two logs, two reciprocals per gene instead of the library softplus / log / exp /
+// divisions, which made the pass compute-bound (1.0 ms; this form 0.6 ms = the HBM time).
+//   a = sd_raw + b_sd;  e = exp(-|a|);  softplus(a) = max(a, 0) + log(1 + e);  sigmoid(a) = (a >= 0 ? 1 : e) / (1 + e)
+__device__ __forceinline__ void nll_raw_sp_elem(float c, float shift, float xv, float mraw, float sraw, float bm, float bs,
+                                                float& acc, float& gm, float& gs) {
+    const float m = mraw + bm, a = sraw + bs;
+    const float e = __expf(-fabsf(a));
+    const float r1 = __frcp_rn(1.f + e);
+    const float s = fmaxf(a, 0.f) + __logf(1.f + e) + shift;
+    const float sig = (a >= 0.f ? 1.f : e) * r1;
+    const float is = __frcp_rn(s), d = xv - m, t = d * is;
+    acc += kLog2Pi + 2.f * __logf(s) + t * t;
+    gm = c * t * is;
+    gs = c * (t * t - 1.f) * is * sig;
+}
+
+__global__ __launch_bounds__(256) void nll_rows_raw_sp_kernel(const float* __restrict__ coef, const float* __restrict__ x,
+                                                              int64_t ldx, const int32_t* __restrict__ xidx,
+                                                              const float* __restrict__ mu, const float* __restrict__ sd,
+                                                              int64_t ldp, int M, int X, float shift,
+                                                              float* __restrict__ out, float* __restrict__ dmu,
+                                                              float* __restrict__ dsd, int64_t ldd,
+                                                              const float* __restrict__ bias_mu,
+                                                              const float* __restrict__ bias_sd) {
+    __shared__ float part[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int X4 = X >> 2;
+    for (int r = blockIdx.x; r < M; r += gridDim.x) {
+        const float4* xr = reinterpret_cast<const float4*>(x + (int64_t)(xidx ? xidx[r] : r) * ldx);
+        const float4* mr = reinterpret_cast<const float4*>(mu + (int64_t)r * ldp);
+        const float4* sr = reinterpret_cast<const float4*>(sd + (int64_t)r * ldp);
+        float4* gmr = reinterpret_cast<float4*>(dmu + (int64_t)r * ldd);
+        float4* gsr = reinterpret_cast<float4*>(dsd + (int64_t)r * ldd);
+        const float c = coef[r];
+        float acc = 0.f;
+        for (int q = threadIdx.x; q < X4; q += 256) {
+            const float4 xv = xr[q], mv = mr[q], sv = sr[q];
+            const float4 bm = reinterpret_cast<const float4*>(bias_mu)[q], bs = reinterpret_cast<const float4*>(bias_sd)[q];
+            float4 gm, gs;
+            nll_raw_sp_elem(c, shift, xv.x, mv.x, sv.x, bm.x, bs.x, acc, gm.x, gs.x);
+            nll_raw_sp_elem(c, shift, xv.y, mv.y, sv.y, bm.y, bs.y, acc, gm.y, gs.y);
+            nll_raw_sp_elem(c, shift, xv.z, mv.z, sv.z, bm.z, bs.z, acc, gm.z, gs.z);
+            nll_raw_sp_elem(c, shift, xv.w, mv.w, sv.w, bm.w, bs.w, acc, gm.w, gs.w);
+            gmr[q] = gm;
+            gsr[q] = gs;
         }
         acc = dv_wave_sum_all(acc);
         if (lane == 0) part[wave] = acc;
@@ -1793,19 +1861,27 @@ extern "C" int dv_gauss_nll_rows_fwd(const float* x, int64_t ldx, const int32_t*
 extern "C" int dv_gauss_nll_rows_fwdbwd(const float* coef, const float* x, int64_t ldx, const int32_t* xidx,
                                         const float* mu, const float* sd, int64_t ldp, int32_t M, int32_t X,
                                         int32_t mode, int32_t sd_act, float sd_shift, float* out, float* dmu,
-                                        float* dsd, int64_t ldd, dv_stream_t stream) {
+                                        float* dsd, int64_t ldd, const float* bias_mu, const float* bias_sd,
+                                        dv_stream_t stream) {
     DV_REQUIRE(M >= 0 && X >= 0);
     if (M == 0) return DV_OK;
-    DV_REQUIRE(coef && x && mu && sd && out && dmu && dsd);
+    DV_REQUIRE(coef && x && mu && sd && out && dmu && dsd && ((bias_mu == nullptr) == (bias_sd == nullptr)));
     auto a8 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7) == 0; };
     const bool v2 = a8(x) && a8(mu) && a8(sd) && a8(dmu) && a8(dsd) && (ldx % 2 == 0) && (ldp % 2 == 0) && (ldd % 2 == 0);
     const dim3 grid(M < 16384 ? M : 16384), block(256);
+    auto a16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    if (bias_mu && mode == DV_GAUSS_SIGMA && sd_act == DV_ACT_SOFTPLUS && X % 4 == 0 && ldx % 4 == 0 && ldp % 4 == 0 &&
+        ldd % 4 == 0 && a16(x) && a16(mu) && a16(sd) && a16(dmu) && a16(dsd) && a16(bias_mu) && a16(bias_sd)) {
+        hipLaunchKernelGGL(nll_rows_raw_sp_kernel, grid, block, 0, ST(stream), coef, x, ldx, xidx, mu, sd, ldp, M, X,
+                           sd_shift, out, dmu, dsd, ldd, bias_mu, bias_sd);
+        DV_RETURN_LAUNCH();
+    }
     if (v2)
         hipLaunchKernelGGL(nll_rows_fwdbwd_kernel<true>, grid, block, 0, ST(stream), coef, x, ldx, xidx, mu, sd, ldp, M,
-                           X, mode, sd_act, sd_shift, out, dmu, dsd, ldd);
+                           X, mode, sd_act, sd_shift, out, dmu, dsd, ldd, bias_mu, bias_sd);
     else
         hipLaunchKernelGGL(nll_rows_fwdbwd_kernel<false>, grid, block, 0, ST(stream), coef, x, ldx, xidx, mu, sd, ldp,
-                           M, X, mode, sd_act, sd_shift, out, dmu, dsd, ldd);
+                           M, X, mode, sd_act, sd_shift, out, dmu, dsd, ldd, bias_mu, bias_sd);
     DV_RETURN_LAUNCH();
 }
 

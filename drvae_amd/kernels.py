@@ -335,13 +335,16 @@ def nll_rows_fwd(out, x, mu, sd, *, mode=GAUSS_SIGMA, xidx=None):
                                                  mode, _f32(out), _stream()), 'dv_gauss_nll_rows_fwd')
 
 
-def nll_rows_fwdbwd(out, dmu, dsd, coef, x, mu, sd, *, mode=GAUSS_SIGMA, xidx=None, sd_act=0, sd_shift=0.0):
-    """row log-likelihoods AND coef-weighted gradients w.r.t. (mu, pre-activation of sd) in one pass"""
+def nll_rows_fwdbwd(out, dmu, dsd, coef, x, mu, sd, *, mode=GAUSS_SIGMA, xidx=None, sd_act=0, sd_shift=0.0, bias=None):
+    """row log-likelihoods AND coef-weighted gradients w.r.t. (mu, pre-activation of sd) in one pass; ``bias`` =
+    (bias_mu, bias_sd): ``mu`` / ``sd`` are the heads' raw products, finished here (+ bias, activation of sd, shift)"""
     M, X = mu.shape
     assert _ld(mu) == _ld(sd) and _ld(dmu) == _ld(dsd)
     _lib.check(_lib.load().dv_gauss_nll_rows_fwdbwd(_f32(coef), _f32(x), _ld(x), _i32(xidx), _f32(mu), _f32(sd),
                                                     _ld(mu), M, X, mode, _act(sd_act), sd_shift, _f32(out),
-                                                    _f32(dmu), _f32(dsd), _ld(dmu), _stream()),
+                                                    _f32(dmu), _f32(dsd), _ld(dmu),
+                                                    _f32(bias[0]) if bias is not None else None,
+                                                    _f32(bias[1]) if bias is not None else None, _stream()),
                'dv_gauss_nll_rows_fwdbwd')
 
 

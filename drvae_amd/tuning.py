@@ -24,6 +24,7 @@ DEFAULTS = {
     'clf_small': 1,      # single-Linear classifier with <= 8 classes as wave-per-row kernels
     'wbranch': 0,        # weight gradients on a third graph branch (measured slower)
     'noise_ahead': 1,    # the side chain draws the NEXT step's noise behind the join
+    'raw_heads': 1,      # chip-filling decoder heads (train step) as a plain product, finished by the NLL row pass
     'concurrent': 1,     # side chain at all (0: one stream)
     'sync_poll': 64,     # replays between two polls of the sticky wait-error words
 }

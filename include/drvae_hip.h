@@ -30,7 +30,7 @@ extern "C" {
 
 typedef void* dv_stream_t;
 
-#define DV_ABI_VERSION 6
+#define DV_ABI_VERSION 7
 
 enum { DV_OK = 0, DV_ERR_ARG = -1, DV_ERR_LAUNCH = -2, DV_ERR_UNSUPPORTED = -3 };
 
@@ -358,10 +358,14 @@ int dv_rec_nll_rows(int32_t kind, float shift, const float* coef, const float* x
                     dv_stream_t stream);
 
 /* forward + backward in one row pass (the loss is linear in the row terms with coefficients
- * known up front): out[r] as _fwd, dmu/dsd[r,:] = coef[r] * d out[r]/d(mu, pre-activation of sd). */
+ * known up front): out[r] as _fwd, dmu/dsd[r,:] = coef[r] * d out[r]/d(mu, pre-activation of sd).
+ * bias_mu / bias_sd (both or neither; X floats each): mu / sd then hold the heads' RAW products (x W^T without bias and
+ * activation) and this pass finishes them on its way: mu = mu_raw + bias_mu, sd = act(sd_raw + bias_sd) + sd_shift --
+ * for heads whose product fills the chip, where the plain GEMM epilogue is the faster one (wide configuration). */
 int dv_gauss_nll_rows_fwdbwd(const float* coef, const float* x, int64_t ldx, const int32_t* xidx, const float* mu,
                              const float* sd, int64_t ldp, int32_t M, int32_t X, int32_t mode, int32_t sd_act,
-                             float sd_shift, float* out, float* dmu, float* dsd, int64_t ldd, dv_stream_t stream);
+                             float sd_shift, float* out, float* dmu, float* dsd, int64_t ldd, const float* bias_mu,
+                             const float* bias_sd, dv_stream_t stream);
 
 /* --------------------------------------------------------- categorical head (K6/K7)
  * probs = clamp(softmax(logits), 1e-10, 1-1e-10)   (src/blocks.py:446-463); with

@@ -407,7 +407,10 @@ def rec_nll_rows(out, x, v, *, kind, shift=0.0, xidx=None, coef=None, dpre=None)
         dpre.copy_(coef[:, None] * g)
 
 
-def nll_rows_fwdbwd(out, dmu, dsd, coef, x, mu, sd, *, mode=GAUSS_SIGMA, xidx=None, sd_act=0, sd_shift=0.0):
+def nll_rows_fwdbwd(out, dmu, dsd, coef, x, mu, sd, *, mode=GAUSS_SIGMA, xidx=None, sd_act=0, sd_shift=0.0, bias=None):
+    if bias is not None:          # raw heads: finished here
+        mu = mu + bias[0]
+        sd = act_fwd(sd_act, sd + bias[1]) + sd_shift
     nll_rows_fwd(out, x, mu, sd, mode=mode, xidx=xidx)
     nll_rows_bwd(dmu, dsd, coef, x, mu, sd, mode=mode, xidx=xidx, sd_act=sd_act, sd_shift=sd_shift)
 

@@ -85,6 +85,35 @@ def test_engine_gradients_match_reference_golden(name, monkeypatch):
             close(g.reshape(-1)[C.sample_index(g.size)], gold['gradsample/' + k], 2e-3, 2e-6)
 
 
+@pytest.mark.parametrize('name', ['tiny_drvae', 'tiny_pvae'])
+def test_raw_decoder_heads_match_reference_golden(name, monkeypatch):
+    """the wide configuration's train-step path at a size the CPU mirror handles: the decoder heads as a plain product,
+    bias + softplus + shift applied by the NLL row pass (``nll_rows_fwdbwd(bias=...)``) -- same golden losses / updates"""
+    from drvae_amd import tuning as T
+    monkeypatch.setenv('DRVAE_TUNE', 'fuse_heads=0,raw_heads=2')
+    T.reload()
+    try:
+        kernel_ref.install(monkeypatch)
+        calls = []
+        real = kernel_ref.nll_rows_fwdbwd
+        monkeypatch.setattr('drvae_amd.kernels.nll_rows_fwdbwd', lambda *a, **k: (calls.append(k.get('bias') is not None), real(*a, **k))[1])
+        case, gold = C.model_case(name), C.load('model_' + name)
+        spec = case['spec']
+        eng, arena = make_engine(spec, M.init_params(spec, case['param_seed'], as_numpy=True))
+        set_batch(eng, case['batch'])
+        for step, noise in enumerate(case['noises']):
+            eng.train_step(noise)
+            for k, v in eng.losses().items():
+                close(v, gold['step%d/%s' % (step, k)], 2e-5, 2e-6)
+        nsteps = len(case['noises'])
+        for k in arena.shapes:
+            close(arena.p(k).numpy(), gold['param%d/%s' % (nsteps - 1, k)], 1e-4, 2e-5)
+        assert calls and all(calls)
+    finally:
+        monkeypatch.delenv('DRVAE_TUNE')
+        T.reload()
+
+
 UNIVERSAL_CASES = [n for n in C.SMALL_MODEL_CASES if 'cont' not in n and n not in ('tiny_vfae_sup',)]
 
 

@@ -383,6 +383,17 @@ def test_nll_rows(K, dev, mode, X, pad):
     R.nll_rows_bwd(RD2[:, :X], RD2[:, X:], coef, x, mu, sd, **kw)
     close(o2, ro, rtol=2e-5, atol=1e-3)
     close(D2, RD2, rtol=2e-4, atol=2e-4)
+    if mode == 1:
+        # raw heads: mu / sd hold x W^T, the pass adds the bias and applies softplus + shift itself
+        raw = rnd(dev, M, 2 * (X + pad), seed=5)
+        rmu, rsd = raw[:, :X], raw[:, X + pad:2 * X + pad]
+        b = rnd(dev, 2 * X, seed=6)
+        o3, D3, o4, D4 = torch.empty(M, device=dev), torch.full((M, 2 * X), 7.0, device=dev), torch.empty(M, device=dev), \
+            torch.empty(M, 2 * X, device=dev)
+        K.nll_rows_fwdbwd(o3, D3[:, :X], D3[:, X:], coef, x, rmu, rsd, bias=(b[:X], b[X:]), **kw)
+        R.nll_rows_fwdbwd(o4, D4[:, :X], D4[:, X:], coef, x, rmu, rsd, bias=(b[:X], b[X:]), **kw)
+        close(o3, o4, rtol=2e-5, atol=1e-3)
+        close(D3, D4, rtol=3e-4, atol=3e-4)
 
 
 @pytest.mark.parametrize('Y,sig', [(2, False), (3, False), (7, False), (2, True)])
