@@ -253,8 +253,30 @@ __device__ __forceinline__ void heads_epilogue(const dv_gemm_desc& g, const dv_h
             v1 += red[(w * BM + r0 + e) * (BN + 1) + HB + c];
         }
         float a0 = dv_act(g.act0, v0 * g.alpha * sc0 + bi0) + g.shift0;
-        const float a1 = dv_act(g.act1, v1 * g.alpha * sc1 + bi1) + g.shift1;
         if (use_res) a0 += g.resid[(int64_t)rc * g.ldr + cc0];
+        if (he.mode == DV_HEADS_NLL && g.act1 == DV_ACT_SOFTPLUS) {
+            // the decoder's sigma head on hardware transcendentals (one exp, two logs, two reciprocals per element):
+            //   p = pre-activation, e = exp(-|p|): softplus(p) = max(p, 0) + log(1 + e), sigmoid(p) = (p >= 0 ? 1 : e) / (1 + e)
+            const float pre = v1 * g.alpha * sc1 + bi1;
+            const float e_ = __expf(-fabsf(pre));
+            const float r1 = __frcp_rn(1.f + e_);
+            const float sd = fmaxf(pre, 0.f) + __logf(1.f + e_) + g.shift1;
+            const float sig = (pre >= 0.f ? 1.f : e_) * r1;
+            const float is = __frcp_rn(sd);
+            const float xv = he.x[(int64_t)(he.xidx ? he.xidx[rc] : rc) * he.ldx + cc0];
+            const float cf = he.coef[rc];
+            const float t = (xv - a0) * is;
+            float acc = ok ? kLog2PiG + 2.f * __logf(sd) + t * t : 0.f;
+            if (ok && rok) {
+                g.C[(int64_t)row * g.ldc + col0] = cf * t * is;
+                g.C[(int64_t)row * g.ldc + col1] = cf * (t * t - 1.f) * is * sig;
+            }
+#pragma unroll
+            for (int off = HB / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+            if (c == 0 && rok) he.part[(int64_t)row * tiles_n + tn] = -0.5f * acc;
+            continue;
+        }
+        const float a1 = dv_act(g.act1, v1 * g.alpha * sc1 + bi1) + g.shift1;
         if (he.mode == DV_HEADS_SAMPLE) {
             if (ok && rok) {
                 g.C[(int64_t)row * g.ldc + col0] = a0;
