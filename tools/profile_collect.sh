@@ -25,6 +25,10 @@ python3 tools/pmc_summary.py gpurun_out/pmc_rr > $O/cfg2_pmc_summary.txt 2>&1
 rm -rf gpurun_out/pmc_rr
 # every figure of bench.py's roofline block that a profiler has to supply, derived from the files above
 python3 tools/roofline_from_profile.py $O/cfg2 --out $O/cfg2_roofline.json > /dev/null 2>&1
+# ... and the bench line once more WITH that file in place (its roofline.frac is read from profiles/<round>_cfg2_roofline.json):
+# this is the line to commit as profiles/<round>_cfg2_bench.json
+cp $O/cfg2_roofline.json profiles/${ROUND:-r03}_cfg2_roofline.json
+python3 bench.py --steps 300 --warmup 20 > $O/cfg2_bench_final.json 2> $O/cfg2_bench_final.err
 python3 tools/step_profile.py cfg2 > $O/cfg2_step_isolated.txt 2>&1
 python3 tools/step_profile.py wide > $O/wide_step_isolated.txt 2>&1
 python3 tools/gemm_bench.py --tilings 0 > $O/gemm_ours.txt 2>&1
