@@ -224,8 +224,10 @@ __device__ __forceinline__ float4 ld_edge(const Operand& o, int line, int pos) {
 // epilogue, and feed the row work of the mode (see dv_heads_epi in drvae_hip.h).
 template <int BM, int BN, int KS, int NT>
 __device__ __forceinline__ void heads_epilogue(const dv_gemm_desc& g, const dv_heads_epi& he, const float* red, int m0,
-                                               int tn, int tiles_n) {
+                                               int tn, int tiles_n, int pre_s0, int pre_s1) {
     constexpr int HB = BN / 2, RPT = BM / (NT / HB);
+    constexpr bool PRE = (KS == 8 && BN == 32);      // (segment bounds of the thread's one row loaded by the caller)
+    static_assert(!PRE || RPT == 1, "prefetched bounds: one row per thread");
     static_assert((HB == 32 || HB == 16) && RPT >= 1, "half tile = 16 or 32 adjacent lanes");
     const int tid = threadIdx.x, c = tid % HB, r0 = (tid / HB) * RPT;
     const int col0 = tn * HB + c, col1 = g.split + col0;
@@ -283,7 +285,8 @@ __device__ __forceinline__ void heads_epilogue(const dv_gemm_desc& g, const dv_h
                 g.C[(int64_t)row * g.ldc + col1] = a1;
                 if (row < he.n_src) {
                     const float std_ = expf(0.5f * a1);
-                    const int s0 = he.seg_ptr ? he.seg_ptr[row] : row, s1 = he.seg_ptr ? he.seg_ptr[row + 1] : row + 1;
+                    const int s0 = he.seg_ptr ? (PRE ? pre_s0 : he.seg_ptr[row]) : row;
+                    const int s1 = he.seg_ptr ? (PRE ? pre_s1 : he.seg_ptr[row + 1]) : row + 1;
                     for (int t = s0; t < s1; ++t) {
                         const int64_t s = he.seg_rows ? he.seg_rows[t] : t;
                         const float z = he.eps[s * he.lde + col0] * std_ + a0;
@@ -466,6 +469,19 @@ __device__ __forceinline__ void gemm_body(const dv_gemm_desc& g, const LoadCfg& 
 #pragma unroll
             for (int r = 0; r < AR; ++r) acc[i][j][r] = 0.f;
 
+    // (paired heads, sample epilogue, one output row per thread: the row's segment bounds are loaded HERE, under the K
+    // loop, instead of at the head of the epilogue's dependent chain bounds -> sample rows -> noise -> stores: cfg 2
+    // 0.1945 -> 0.1925 ms in a same-box A/B.  Fetching the sample rows behind the first barrier as well gave it back)
+    int pre_s0 = 0, pre_s1 = 0;
+    if constexpr (PAIR && KS == 8 && BN == 32) {
+        if (he->mode == DV_HEADS_SAMPLE && he->seg_ptr != nullptr) {
+            const int prow = m0 + tid / (BN / 2);
+            if (prow < he->n_src && prow < g.M) {
+                pre_s0 = he->seg_ptr[prow];
+                pre_s1 = he->seg_ptr[prow + 1];
+            }
+        }
+    }
     const int kb = ks_id * KW + lh * KH;   // this lane's first k inside the tile
     // all fragment reads of a tile are issued up front (in-order LDS returns: the first MFMA only
     // waits for the first read, the rest land under the MFMA chain)
@@ -725,7 +741,7 @@ __device__ __forceinline__ void gemm_body(const dv_gemm_desc& g, const LoadCfg& 
                     red[(ks_id * BM + row) * (BN + 1) + j * 32 + li] = acc[0][j][r];
                 }
             __syncthreads();
-            heads_epilogue<BM, BN, KS, NT>(g, *he, red, m0, tn, tiles_n);
+            heads_epilogue<BM, BN, KS, NT>(g, *he, red, m0, tn, tiles_n, pre_s0, pre_s1);
             return;
         }
 #pragma unroll
