@@ -1633,8 +1633,26 @@ __global__ __launch_bounds__(kLossThreads) void loss_assemble_kernel(LossTerms l
             const int rl = t.row_len > 1 ? t.row_len : 1;     // x is (rows, row_len): one weight per ROW
             if (rl == 1) {
                 for (int i = threadIdx.x; i < t.n; i += kLossThreads) q += (t.w ? t.w[i] : 1.f) * t.x[i];
+            } else if (t.w != nullptr) {
+                // one thread per ROW: its weight once, its row_len partials as independent loads (the element loop
+                // below pays an integer division and a dependent weight load per element: 38 trips per thread for the
+                // 620 x 62 per-tile partials of a bucketed sampler plan)
+                const int rows = t.n / rl;
+                for (int r = threadIdx.x; r < rows; r += kLossThreads) {
+                    const float* xr = t.x + (int64_t)r * rl;
+                    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+                    int j = 0;
+                    for (; j + 3 < rl; j += 4) {
+                        s0 += xr[j];
+                        s1 += xr[j + 1];
+                        s2 += xr[j + 2];
+                        s3 += xr[j + 3];
+                    }
+                    for (; j < rl; ++j) s0 += xr[j];
+                    q += t.w[r] * ((s0 + s1) + (s2 + s3));
+                }
             } else {
-                for (int i = threadIdx.x; i < t.n; i += kLossThreads) q += (t.w ? t.w[i / rl] : 1.f) * t.x[i];
+                for (int i = threadIdx.x; i < t.n; i += kLossThreads) q += t.x[i];
             }
             ps[k] = q;
         }
