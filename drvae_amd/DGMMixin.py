@@ -81,8 +81,7 @@ class DeepGenerativeModelMixin:
         a.exp_avg_sq.copy_(st['exp_avg_sq'])
         eng.step_dev.copy_(st['step'])
         eng.rng_ctr.copy_(st['rng'])
-        eng.side_ctr.copy_(eng.step_dev)
-        eng.side_t.copy_(eng.step_dev + 1)
+        eng.sync_side_counters()
         eng.iters = st['iters']
         self._opt_stash = None
 

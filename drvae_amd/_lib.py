@@ -127,7 +127,7 @@ SIGNATURES = {
     'dv_mmd_rff_bwd': [_p, _i64, _i32, _i32, _p, _p, _f, _p, _i64, _p],
     'dv_rows_gather': [_p, _i64, _p, _i32, _i32, _p, _i64, _f, _p, _i32, _p, _i64, C.POINTER(Wait), _p],
     'dv_batch_feed': [_p, _i64, _p, _i64, _p, _p, _i32, _p, _p, _i32, _p, _i32, _i32, _p, _i64, _f, _p, _i64, _p, _i32,
-                      _p, _p, _p, _p, _i32, _p, _p, _i64, _i32, _p, _p, _i32, _p, _i64, C.POINTER(BatchMasks), _p],
+                      _p, _p, _p, _p, _i32, _p, _p, _i64, _i32, _p, _p, _i32, _p, _i64, C.POINTER(BatchMasks), C.POINTER(Wait), _p],
     'dv_batch_masks': [_p, _i32, _p, _p, _p, _p, _p, _i32, _i32, _i32, _f, _f, _f, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     'dv_rows_segment_sum': [_p, _i64, _p, _p, _p, _i32, _i32, _p, _p, _i64, _f, C.POINTER(Wait), _p],
     'dv_weighted_sum': [_p, _p, _p, _i32, _f, _p, _f, _p],
@@ -142,7 +142,7 @@ SIGNATURES = {
                          _i32, _p],
     'dv_adamax_l2': [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _f, _p, _p, _i32, _p],
     'dv_flag_publish': [_p, _p, _i32, _p],
-    'dv_flag_wait': [_p, _p, _i32, _p, _i32, _p],
+    'dv_flag_wait': [_p, _p, _i32, _p, _i32, C.POINTER(Publish), _p],
     'dv_counter_add': [_p, _i32, _i64, _p],
     'dv_counters_add2': [_p, _i32, _i64, _p, _i32, _i64, _p, _p],
     'dv_fill_normal': [_p, _i64, _u64, _p, _p],
@@ -150,7 +150,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 7     # DV_ABI_VERSION of include/drvae_hip.h
+ABI_VERSION = 8     # DV_ABI_VERSION of include/drvae_hip.h
 
 
 def load():

@@ -350,8 +350,10 @@ __global__ void flag_publish_kernel(int32_t* flag, const int32_t* ctr, int add) 
     if (threadIdx.x == 0) __hip_atomic_store(flag, ctr[0] + add, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__global__ void flag_wait_kernel(int32_t* flag, const int32_t* ctr, int add, int32_t* err, int max_spins) {
+__global__ void flag_wait_kernel(int32_t* flag, const int32_t* ctr, int add, int32_t* err, int max_spins, dv_publish pub) {
     if (threadIdx.x != 0) return;
+    // (pub: published on entry, like dv_flag_publish -- everything before this launch in its stream is complete)
+    if (pub.flag != nullptr) __hip_atomic_store(pub.flag, pub.ctr[0] + pub.add, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     const int want = ctr[0] + add;
     const long long t0 = wall_clock64();
     int n = 0;
@@ -372,9 +374,11 @@ extern "C" int dv_flag_publish(int32_t* flag, const int32_t* ctr, int32_t add, d
 }
 
 extern "C" int dv_flag_wait(int32_t* flag, const int32_t* ctr, int32_t add, int32_t* err, int32_t max_spins,
-                            dv_stream_t stream) {
+                            const dv_publish* pub_in, dv_stream_t stream) {
     DV_REQUIRE(flag && ctr && err && max_spins > 0);
-    hipLaunchKernelGGL(flag_wait_kernel, dim3(1), dim3(64), 0, ST(stream), flag, ctr, add, err, max_spins);
+    const dv_publish pub = pub_in ? *pub_in : dv_publish{nullptr, nullptr, 0};
+    DV_REQUIRE(pub.flag == nullptr || pub.ctr != nullptr);
+    hipLaunchKernelGGL(flag_wait_kernel, dim3(1), dim3(64), 0, ST(stream), flag, ctr, add, err, max_spins, pub);
     DV_RETURN_LAUNCH();
 }
 

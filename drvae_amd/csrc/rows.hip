@@ -1304,7 +1304,9 @@ __global__ __launch_bounds__(256) void batch_feed_kernel(
     const int32_t* __restrict__ has_y, int L, int32_t* __restrict__ label_r, const int32_t* __restrict__ fp_i,
     const int32_t* __restrict__ fp_lab, const int32_t* __restrict__ fp_slot, int Mf, int32_t* __restrict__ fp_cls,
     float* __restrict__ onehot, int64_t ldh, int Y, int row_blocks, int vec4, const float* __restrict__ yf,
-    float* __restrict__ ylab, int Yc, float* __restrict__ onehot2, int64_t ldh2, int mask_block, MaskArgs masks) {
+    float* __restrict__ ylab, int Yc, float* __restrict__ onehot2, int64_t ldh2, int mask_block, MaskArgs masks,
+    ParkArgs park) {
+    park_block(park);
     if ((int)blockIdx.x == mask_block) {        // (batch-independent plan: the batch's masks ride on this launch)
         batch_masks_body(masks);
         return;
@@ -2137,9 +2139,10 @@ extern "C" int dv_rows_gather(const float* src, int64_t lds, const int32_t* idx,
     if (n == 0) return DV_OK;
     DV_REQUIRE(out && (src || W == 0));
     if (total == 0) return DV_OK;
-    if (park.flag != nullptr && grid_for(total, 256) > DV_MAX_PARKED_GRID) return DV_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(rows_gather_kernel, dim3(grid_for(total, 256)), dim3(256), 0, ST(stream), src, lds, idx, n,
-                       W, noise, ldn, sigma, onehot_cls, Y, out, ldo, park);
+    // (a parked launch polls from every workgroup: its grid stays small -- 128 workgroups, the element loop strides --
+    // so that the polling does not crowd the chain it waits for)
+    hipLaunchKernelGGL(rows_gather_kernel, dim3(grid_for(total, 256, park.flag != nullptr ? 128 : 4096)),
+                       dim3(256), 0, ST(stream), src, lds, idx, n, W, noise, ldn, sigma, onehot_cls, Y, out, ldo, park);
     DV_RETURN_LAUNCH();
 }
 
@@ -2150,7 +2153,9 @@ extern "C" int dv_batch_feed(const float* x1, int64_t ld1, const float* x2, int6
                              int32_t* label_r, const int32_t* fp_i, const int32_t* fp_lab, const int32_t* fp_slot,
                              int32_t Mf, int32_t* fp_cls, float* onehot, int64_t ldh, int32_t Y, const float* yf,
                              float* ylab, int32_t Yc, float* onehot2, int64_t ldh2, const dv_batch_masks_desc* masks,
-                             dv_stream_t stream) {
+                             const dv_wait* park_in, dv_stream_t stream) {
+    DV_REQUIRE(park_ok(park_in));
+    const ParkArgs park = park_in ? *park_in : ParkArgs{};
     DV_REQUIRE(B >= 0 && Np >= 0 && X >= 0 && n_batches >= 1 && L >= 1 && Mf >= 0 && Y >= 0 && Yc >= 0);
     DV_REQUIRE(!ylab || (yf && Yc >= 1));
     if (B == 0) return DV_OK;
@@ -2173,10 +2178,11 @@ extern "C" int dv_batch_feed(const float* x1, int64_t ld1, const float* x2, int6
                       m.beta, m.c_nll, m.c_klz2, m.c_yl, m.w_recl, m.w_pert, m.w_yl, m.label, m.c_klp, m.one_slot};
     }
     const int feed_blocks = row_blocks + lab_blocks;
+    if (park.flag != nullptr && feed_blocks + 1 > DV_MAX_PARKED_GRID) return DV_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(batch_feed_kernel, dim3(feed_blocks + (masks ? 1 : 0)), dim3(256), 0, ST(stream), x1, ld1, x2, ld2,
                        y, table, n_batches, ctr, base, B, pair_rows, Np, X, noise, ldn, sigma, xin, ldo, has_y, L,
                        label_r, fp_i, fp_lab, fp_slot, Mf, fp_cls, onehot, ldh, Y, row_blocks, v4 ? 1 : 0, yf, ylab, Yc,
-                       onehot2, ldh2, masks ? feed_blocks : -1, ma);
+                       onehot2, ldh2, masks ? feed_blocks : -1, ma, park);
     DV_RETURN_LAUNCH();
 }
 

@@ -230,8 +230,8 @@ class FusedStep(StepSchedule):
         self._after_decoder_bwd = None
         self.side_ctr = torch.zeros(1, dtype=torch.int32, device=self.dev)   # the side chain's own step count
         self.side_t = torch.ones(1, dtype=torch.int32, device=self.dev)      # ... + 1: the optimiser step it works on
-        self.flags = torch.zeros(6, dtype=torch.int32, device=self.dev)
-        self.sync_err = torch.zeros(12, dtype=torch.int32, device=self.dev)  # (error, ticks parked) x 6 wait sites
+        self.flags = torch.zeros(8, dtype=torch.int32, device=self.dev)
+        self.sync_err = torch.zeros(14, dtype=torch.int32, device=self.dev)  # (error, ticks parked) x 7 wait sites
         self.add_noise = True               # `fit(add_noise=...)` flag of the reference (src/DrVAE.py:769)
         # classifier/fprop chain || decoder chain.  PVAE's side chain is one tiny KL kernel: a second stream
         # costs it far more than it hides (measured 0.19 ms single-stream vs 0.9 ms forked), so it runs serial
@@ -538,6 +538,14 @@ class FusedStep(StepSchedule):
         Z1blk = p.ZDEC[:L * B]
         # ---- inputs (+ training noise N(0,1)*add_noise_var, src/DrVAE.py:404-407,414-417): one gather
         fd = p.live_feed if (self.fuse_bwd and self.training) else None
+        # (dual-graph schedule) the step's first launch is where the main chain meets the PREVIOUS step's side chain: its
+        # tail (its half of the optimiser sweep, the loss scalars, this step's noise, its counters) must be through --
+        # flag 3, published by the tail's last launch.  The optimiser launch used to park on that flag (4.3 us per step
+        # at cfg 2, 7.6 us with the sampler feed: the tail is 44-49 us of serial launches against 35 us of main-chain
+        # launches behind the join); it only needs the classifier's gradient (flag 6)
+        start_park = None
+        if rec == 'main' and self._tail_gated():
+            start_park = (self.flags[3:4], self.step_dev, self.sync_err[12:14], 0)
         masks = None
         if p.universal:
             # which rows of THIS batch are pairs / labeled -> coefficient and weight vectors, on the device (with
@@ -557,7 +565,7 @@ class FusedStep(StepSchedule):
             # HBM-resident dataset; also refreshes the label-dependent index buffers
             # (universal plan: dv_batch_masks has the labels; its rows with ONE fprop row get their class columns here)
             lab = cfg.has_y and not cfg.cont and (not p.universal or p.one_slot is not None)
-            K.batch_feed(p.XIN, fd.x1, fd.x2, fd.y32, fd.table, fd.n_batches, self.step_dev, fd.base,
+            K.batch_feed(p.XIN, fd.x1, fd.x2, fd.y32, fd.table, fd.n_batches, self.step_dev, fd.base, park=start_park,
                          pair_rows=p.pair_idx if Np else None, noise=p.EX if sigma else None, sigma=sigma,
                          has_y=p.has_y_i32 if (lab and not p.universal) else None, L=L,
                          label_r=p.label_r if (lab and not p.universal) else None,
@@ -568,7 +576,7 @@ class FusedStep(StepSchedule):
                          yf=fd.yf if (cfg.has_y and cfg.cont) else None,
                          ylab=p.ylab if (cfg.has_y and cfg.cont) else None, masks=masks)
         else:
-            K.rows_gather(p.XIN, p.XSRC, p.xin_idx, noise=p.EX if sigma else None, sigma=sigma)
+            K.rows_gather(p.XIN, p.XSRC, p.xin_idx, noise=p.EX if sigma else None, sigma=sigma, park=start_park)
         # ---- q(z1|x1), q(z2|x2): one pass of the shared encoder; the samples (src/blocks.py:170-174) -- z1
         # for every row and z2 for the pairs, drawn from q(z1|x1), not q(z2|x2) (quirk 1, src/DrVAE.py:427) --
         # leave the heads' launch itself (``fuse_heads``) or one launch of their own
@@ -745,6 +753,39 @@ class FusedStep(StepSchedule):
             else:
                 K.ymarg_fwd(p.YLrow, p.KLDrow, p.QY, p.label_r, p.fp_ptr, p.KLFP, p.log_prior)
 
+    def _tail_gated(self):
+        """dual-graph train step (ONE pair of graphs) whose side chain runs its half of the optimiser sweep and the loss
+        scalars behind the join: the optimiser launch gates on the classifier's gradient only, and the NEXT step's first
+        launch waits for the tail's end"""
+        cfg = self.cfg
+        if not (self._mode() == 5 and self.late_leaf and cfg.has_y and not cfg.cont and self.clf_small
+                and cfg.optim_alg == 'adam' and not getattr(self, '_split_kind', False) and T.get('tail_gate')):
+            return False
+        if not self._side_adam_layout()[0]:     # (= ``side_adam`` of backward(): the tail then holds the flag-4 wait launch)
+            return False
+        # ... where the step's first launch is the graph-resident feed (a few dozen workgroups that can park): sampler feed
+        # 0.213 -> 0.2074 ms.  With the resident batch the first launch is the input gather (856 workgroups; parked with
+        # 128 it is slower by itself and waits the 4 us the optimiser launch used to wait: 0.1932 -> 0.198 ms)
+        return self.plan.live_feed is not None or T.get('tail_gate') == 2
+
+    def _side_adam_layout(self):
+        """(may the side chain sweep the decoder heads' half of the arena?, first element of that half)"""
+        heads = self.L_decx[-1]
+        g0 = self.arena.grad.storage_offset()
+        hs = min(heads.dW.storage_offset(), heads.db.storage_offset()) - g0
+        ok = bool(self.side_adam and len(self.L_decx) > 1 and heads.g is None and not self.wbranch.on
+                  and hs % 4 == 0 and self.arena.n_live == self.arena.n_params
+                  and max(heads.dW.storage_offset() + heads.dW.numel(),
+                          heads.db.storage_offset() + heads.db.numel()) - g0 >= self.arena.n_live - 3)
+        return ok, hs
+
+    def sync_side_counters(self):
+        """the side chain's counters and its tail flag follow the step counter (after it was set from outside: a
+        restored checkpoint, a capture)"""
+        self.side_ctr.copy_(self.step_dev)
+        self.side_t.copy_(self.step_dev + 1)
+        self.flags[3:4].copy_(self.step_dev)
+
     def _fprop_from_heads(self):
         """the encoder heads' sample epilogue also fills the z1 columns of the fprop input (the class columns are
         written when the labels are: ``_Plan._refresh_onehot`` / ``dv_batch_feed``)"""
@@ -856,13 +897,9 @@ class FusedStep(StepSchedule):
         # ... and HALF of the optimiser sweep moves there too: the decoder heads (the tail of the arena, half of
         # all parameters) are final and no longer read once the heads' backward products are through -- the
         # launch after them publishes that -- so the side chain updates them next to the main chain's tail
-        heads = self.L_decx[-1]
         g0 = self.arena.grad.storage_offset()
-        hs = min(heads.dW.storage_offset(), heads.db.storage_offset()) - g0
-        side_adam = (late and not split_kind and self.side_adam and len(self.L_decx) > 1 and heads.g is None and not self.wbranch.on
-                     and hs % 4 == 0 and self.arena.n_live == self.arena.n_params
-                     and max(heads.dW.storage_offset() + heads.dW.numel(),
-                             heads.db.storage_offset() + heads.db.numel()) - g0 >= self.arena.n_live - 3)
+        side_ok, hs = self._side_adam_layout()
+        side_adam = late and not split_kind and side_ok
         # the loss scalars (a leaf: only the host / the exchange reads them) are assembled by the side chain behind
         # the join, once the main chain has published that its reconstruction rows are final
         side_loss = side_adam or (late and split_kind is True and len(self.L_decx) > 1 and not self.wbranch.on)
@@ -920,7 +957,8 @@ class FusedStep(StepSchedule):
             lc = self.L_clf[0]
             lo = min(lc.dW.storage_offset(), lc.db.storage_offset()) - g0
             hi = max(lc.dW.storage_offset() + lc.dW.numel(), lc.db.storage_offset() + lc.db.numel()) - g0
-            self._adam_gate = (self.flags[3:4], self.step_dev, 0, self.sync_err[6:8], lo, hi)
+            self._adam_gate = (self.flags[6:7] if self._tail_gated() else self.flags[3:4], self.step_dev, 0,
+                               self.sync_err[6:8], lo, hi)
             self._adam_n = hs if side_adam else None
         if cfg.has_pert:
             if not cfg.has_y:
@@ -1056,7 +1094,10 @@ class FusedStep(StepSchedule):
         if late:
             if side_loss:
                 a = self.arena
-                K.flag_wait(self.flags[4:5], self.side_ctr, self.sync_err[8:10])
+                # (entry of this launch = the deferred leaf launches, i.e. the classifier's weight gradient, are through:
+                # flag 6, what the main chain's optimiser launch gates its classifier slice on)
+                K.flag_wait(self.flags[4:5], self.side_ctr, self.sync_err[8:10],
+                            publish=(self.flags[6:7], self.side_ctr, 1) if self._tail_gated() else None)
                 if side_adam:
                     K.adam_l2(a.param[hs:a.n_live], a.grad[hs:a.n_live], a.exp_avg[hs:a.n_live],
                               a.exp_avg_sq[hs:a.n_live], self.side_t, lr=cfg.learning_rate,
@@ -1091,7 +1132,9 @@ class FusedStep(StepSchedule):
         else:
             K.counter_add(self.step_dev, 1)
         if self._rec == 'both' and self.sched == 5:
-            K.counters_add2(self.side_ctr, 1, self.side_t, 1)      # eager step: the side chain's counters follow
+            # eager step: the side chain's counters follow, and so does the "side chain's tail is through" flag that the
+            # NEXT captured step's first launch waits for (published on entry: counter + 1 = the advanced value)
+            K.counters_add2(self.side_ctr, 1, self.side_t, 1, publish=(self.flags[3:4], self.side_ctr, 1))
         step = K.adamax_l2 if cfg.optim_alg == 'adamax' else K.adam_l2    # exp_avg_sq doubles as Adamax's exp_inf
         n = a.n_live                      # parameters without gradients sit behind it (untouched, like torch)
         if self._adam_n is not None:      # dual-graph step: the side chain sweeps the rest (the decoder heads)

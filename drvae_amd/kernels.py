@@ -529,7 +529,7 @@ def rows_gather(out, src, idx=None, *, noise=None, sigma=0.0, onehot_cls=None, n
 
 def batch_feed(xin, x1, x2, y32, table, n_batches, ctr, base, *, pair_rows=None, noise=None, sigma=0.0, has_y=None,
                L=1, label_r=None, fp_i=None, fp_lab=None, fp_slot=None, fp_cls=None, onehot=None, n_classes=0, yf=None,
-               ylab=None, onehot2=None, masks=None):
+               ylab=None, onehot2=None, masks=None, park=None):
     """graph-resident minibatch feed: see dv_batch_feed in include/drvae_hip.h; ``masks``: keyword arguments of
     ``batch_masks`` (minus table / ctr / base / B / L): the batch's masks written by the same launch"""
     B = table.shape[1]
@@ -551,7 +551,7 @@ def batch_feed(xin, x1, x2, y32, table, n_batches, ctr, base, *, pair_rows=None,
                                          _i32(has_y), L, _i32(label_r), _i32(fp_i), _i32(fp_lab), _i32(fp_slot), Mf,
                                          _i32(fp_cls), _f32(onehot), _ld(onehot), n_classes, _f32(yf), _f32(ylab),
                                          ylab.shape[1] if ylab is not None else 0, _f32(onehot2), _ld(onehot2),
-                                         C.byref(md) if md is not None else None, _stream()), 'dv_batch_feed')
+                                         C.byref(md) if md is not None else None, _wait(park), _stream()), 'dv_batch_feed')
 
 
 def batch_masks(B, L, *, n_tot, kl_rate, pert_rate, yl_rate, beta, c_nll, w_recl, hx=None, hy=None, y=None, c_klz2=None,
@@ -668,9 +668,11 @@ def flag_publish(flag, ctr, add=1):
 WAIT_SPINS = int(os.environ.get('DRVAE_WAIT_SPINS', '4000000'))
 
 
-def flag_wait(flag, ctr, err, add=1, max_spins=None):
+def flag_wait(flag, ctr, err, add=1, max_spins=None, publish=None):
+    """``publish`` = (flag, counter[, add]): published on entry of the wait launch"""
     max_spins = WAIT_SPINS if max_spins is None else max_spins
-    _lib.check(_lib.load().dv_flag_wait(_i32(flag), _i32(ctr), add, _i32(err), max_spins, _stream()), 'dv_flag_wait')
+    _lib.check(_lib.load().dv_flag_wait(_i32(flag), _i32(ctr), add, _i32(err), max_spins, _publish(publish), _stream()),
+               'dv_flag_wait')
 
 
 def counter_add(counter, inc=1):

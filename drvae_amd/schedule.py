@@ -179,8 +179,7 @@ class StepSchedule:
             self._capture_main(split_for_allreduce)
             if dual:
                 self._rec = 'side'
-                self.side_ctr.copy_(self.step_dev)
-                self.side_t.copy_(self.step_dev + 1)
+                self.sync_side_counters()
                 self.flag_side.wait_stream(torch.cuda.current_stream())
                 gs = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(gs, stream=self.flag_side):

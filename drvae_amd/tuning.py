@@ -25,6 +25,7 @@ DEFAULTS = {
     'wbranch': 0,        # weight gradients on a third graph branch (measured slower)
     'noise_ahead': 1,    # the side chain draws the NEXT step's noise behind the join
     'raw_heads': 1,      # chip-filling decoder heads (train step) as a plain product, finished by the NLL row pass
+    'tail_gate': 1,      # the side chain's tail is awaited by the NEXT step's first launch (0: by this step's optimiser launch)
     'concurrent': 1,     # side chain at all (0: one stream)
     'sync_poll': 64,     # replays between two polls of the sticky wait-error words
 }

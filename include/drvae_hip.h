@@ -30,7 +30,7 @@ extern "C" {
 
 typedef void* dv_stream_t;
 
-#define DV_ABI_VERSION 7
+#define DV_ABI_VERSION 8
 
 enum { DV_OK = 0, DV_ERR_ARG = -1, DV_ERR_LAUNCH = -2, DV_ERR_UNSUPPORTED = -3 };
 
@@ -484,6 +484,8 @@ int dv_rows_gather(const float* src, int64_t lds, const int32_t* idx, int32_t n,
  * constant and the launch can live inside the captured train-step graph. */
 /* `masks` (optional): the per-batch masks of a batch-independent plan (dv_batch_masks below, same table / ctr / base /
  * B / L) written by one more workgroup of this launch instead of a launch of their own. */
+/* `park` (optional): the launch first parks like dv_flag_wait -- the first launch of a step waiting for the previous
+ * step's other launch chain (DV_ERR_UNSUPPORTED for grids above DV_MAX_PARKED_GRID workgroups). */
 typedef struct dv_batch_masks_desc {
     const int32_t* hx;
     const int32_t* hy;
@@ -507,7 +509,7 @@ int dv_batch_feed(const float* x1, int64_t ld1, const float* x2, int64_t ld2, co
                   const int32_t* has_y, int32_t L, int32_t* label_r, const int32_t* fp_i, const int32_t* fp_lab,
                   const int32_t* fp_slot, int32_t Mf, int32_t* fp_cls, float* onehot, int64_t ldh, int32_t Y,
                   const float* yf, float* ylab, int32_t Yc, float* onehot2, int64_t ldh2,
-                  const dv_batch_masks_desc* masks, dv_stream_t stream);
+                  const dv_batch_masks_desc* masks, const dv_wait* park, dv_stream_t stream);
 /* dst[di,:W] = beta*dst[di,:W] + sum_{t in [seg_ptr[i],seg_ptr[i+1])} w[t]*src[seg_rows[t],:W],
  * di = dst_idx?dst_idx[i]:i; seg_ptr==NULL: segment i is the single row (seg_rows?seg_rows[i]:i).
  * Deterministic (no atomics): the transpose of every gather above. */
@@ -638,7 +640,9 @@ int dv_counters_add2(int32_t* c1, int32_t n1, int64_t inc1, int32_t* c2, int32_t
  * after it in ITS stream see the producer's results.  It never hangs: after max_spins polls (~0.1 us
  * each) it sets err[0] = 1 and returns.  err[1] accumulates the time spent parked (wall_clock64 ticks). */
 int dv_flag_publish(int32_t* flag, const int32_t* ctr, int32_t add, dv_stream_t stream);
-int dv_flag_wait(int32_t* flag, const int32_t* ctr, int32_t add, int32_t* err, int32_t max_spins, dv_stream_t stream);
+/* (pub, optional: published on entry of the wait launch, before it starts to poll) */
+int dv_flag_wait(int32_t* flag, const int32_t* ctr, int32_t add, int32_t* err, int32_t max_spins, const dv_publish* pub,
+                 dv_stream_t stream);
 
 /* out[i] ~ N(0,1), Philox4x32-10 keyed by `seed`, counter = ctr_dev[0..1] (uint64 as two
  * int32 words, device) + i/4, Box-Muller on the four outputs.  (the `normal_()` draws of

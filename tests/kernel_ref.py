@@ -262,7 +262,7 @@ def reparam_bwd_seg(dmu, dsd, dz, eps, sd, seg_ptr, seg_rows, *, mode=GAUSS_LOGV
 def z2f_post_bwd(dp2, dz1, dq2, dz2f, dzdec_pert, pair_slot, eps, p2, q2, coef, raw, kl_min, dz1b, L, B, Np,
                  park=None):
     if park is not None:
-        flag_wait(*park[:3])                  # single-threaded stand-in: the producer has run already
+        flag_wait(park[0], park[1], park[2], park[3] if len(park) > 3 else 1)                  # single-threaded stand-in: the producer has run already
     Z = dz2f.shape[1]
     dev = dz2f.device
     slot = pair_slot.long() if (pair_slot is not None and Np) else torch.full((B,), -1, dtype=torch.long, device=dev)
@@ -308,7 +308,7 @@ def _kl_operands(mu_q, sd_q, mu_p, sd_p, prior, qidx, pidx, R, reps):
 def kl_rows_fwd(out, raw, mu_q, sd_q, mu_p=None, sd_p=None, *, prior=(0.0, 0.0), mode=GAUSS_LOGVAR, qidx=None,
                 pidx=None, reps=1, free_bits=False, kl_min=0.0, add=None, eps=None, zout=None, park=None, second=None):
     if park is not None:
-        flag_wait(*park[:3])
+        flag_wait(park[0], park[1], park[2], park[3] if len(park) > 3 else 1)
     R = out.numel()
     mq, sq, mp, sp = _kl_operands(mu_q, sd_q, mu_p, sd_p, prior, qidx, pidx, R, reps)
     if zout is not None:
@@ -597,7 +597,7 @@ def mmd_rff_bwd(G, th, diff, gout, coef):
 
 def rows_gather(out, src, idx=None, *, noise=None, sigma=0.0, onehot_cls=None, n_classes=0, width=None, park=None):
     if park is not None:
-        flag_wait(*park[:3])
+        flag_wait(park[0], park[1], park[2], park[3] if len(park) > 3 else 1)
     n = out.shape[0]
     W = (src.shape[1] if src is not None else 0) if width is None else width
     if W > 0:
@@ -611,7 +611,9 @@ def rows_gather(out, src, idx=None, *, noise=None, sigma=0.0, onehot_cls=None, n
 
 def batch_feed(xin, x1, x2, y32, table, n_batches, ctr, base, *, pair_rows=None, noise=None, sigma=0.0, has_y=None,
                L=1, label_r=None, fp_i=None, fp_lab=None, fp_slot=None, fp_cls=None, onehot=None, n_classes=0, yf=None,
-               ylab=None, onehot2=None, masks=None):
+               ylab=None, onehot2=None, masks=None, park=None):
+    if park is not None:
+        flag_wait(park[0], park[1], park[2], park[3] if len(park) > 3 else 1)
     if masks is not None:
         batch_masks(table.shape[1], L, table=table, n_batches=n_batches, ctr=ctr, base=base, **masks)
     if ylab is not None:
@@ -639,7 +641,7 @@ def batch_feed(xin, x1, x2, y32, table, n_batches, ctr, base, *, pair_rows=None,
 def rows_segment_sum(dst, src, *, seg_ptr=None, seg_rows=None, w=None, n=None, dst_idx=None, beta=0.0, width=None,
                      park=None):
     if park is not None:
-        flag_wait(*park[:3])
+        flag_wait(park[0], park[1], park[2], park[3] if len(park) > 3 else 1)
     if n is None:
         n = seg_ptr.numel() - 1 if seg_ptr is not None else (seg_rows.numel() if seg_rows is not None else
                                                               src.shape[0])
@@ -740,7 +742,9 @@ def flag_publish(flag, ctr, add=1):
     flag[0] = int(ctr[0]) + add
 
 
-def flag_wait(flag, ctr, err, add=1, max_spins=None):
+def flag_wait(flag, ctr, err, add=1, max_spins=None, publish=None):
+    if publish is not None:
+        flag_publish(*publish)
     if int(flag[0]) < int(ctr[0]) + add:      # single-threaded stand-in: the producer must have run already
         err[0] = 1                            # (err[1], the parked-time statistic, stays 0)
 
