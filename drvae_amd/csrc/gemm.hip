@@ -19,167 +19,10 @@
 //   T64 : 64x64x32 tile, 2x2 waves, one 32x32 accumulator each      (default)
 //   T32K: 32x32x64 tile, the 4 waves split K and reduce through LDS  (small M*N: 4x the workgroups)
 //   T128: 128x128x32 tile, 2x2 waves, 2x2 accumulators each          (wide config)
-#include <type_traits>
-
-#include "dv_common.h"
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-// tuning builds only (tools/gemm_lab.sh): knock out one phase of the fast-path K loop to see what
-// bounds it. 1: no global loads in the loop, 2: VALU fma instead of the MFMAs, 4: no LDS stores in
-// the loop, 8: no barriers in the loop.  Results are wrong for any value but 0.
-#ifndef DV_DBG
-#define DV_DBG 0
-#endif
-#ifndef DV_STAGGER
-#define DV_STAGGER 0
-#endif
-// tuning builds only: DV_STAMP=1 makes wave 0 of every workgroup record shader-clock stamps around the phases of
-// the steady-state K loop into the buffer set with dv_gemm_set_option(5/6, lo/hi of its address): per workgroup
-// 64 x uint64 = [entry, loop start, then per phase: after compute, after stage_store, after fetch, after barrier]
-#ifndef DV_STAMP
-#define DV_STAMP 0
-#endif
-#ifndef DV_LB8
-#define DV_LB8 2
-#endif
-// workgroups per CU the high-occupancy 32x32x32 tiling is compiled for (register budget 512 / this many waves per SIMD)
-#ifndef DV_DENSE_WG
-#define DV_DENSE_WG 7
-#endif
-#if DV_STAMP
-__device__ unsigned long long* dv_stamp_buf = nullptr;
-#define STAMP(i)                                                                          \
-    do {                                                                                  \
-        if (stamp_on && (i) < 64) {                                                       \
-            unsigned long long t__;                                                       \
-            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");   \
-            if (threadIdx.x == 0) dv_stamp_buf[(size_t)bid * 64 + (i)] = t__;             \
-        }                                                                                 \
-    } while (0)
-#else
-#define STAMP(i) \
-    do {         \
-    } while (0)
-#endif
-
-// internal bit of dv_gemm_desc.flags (the launchers set it; callers pass bits 1 | 2 only): the bias gradient of a
-// dy^T x product is the accumulator column N, produced by staging B's column N as ones
-#define DV_FLAG_ONES_COL 4
+#include "gemm_common.inc"
 
 namespace {
 
-// what staging chunks past the end of K read (see the K tail of the fast path)
-__device__ __attribute__((aligned(16))) const float dv_zero_chunk[4] = {0.f, 0.f, 0.f, 0.f};
-
-
-constexpr float kLog2PiG = 1.8378770664093453f;   // log(2 pi), as rows.hip
-
-struct LoadCfg {
-    int vecA, vecB;   // widest aligned vector width (4, 2 or 1 floats) per operand
-    int vecA_t, vecB_t;   // same for the ragged last K tile of a k-contiguous operand: also divides K
-    int map;          // workgroup -> tile mapping: 0 linear, 1 XCD chunk-major, >= 2 bands of `map` tile rows
-};
-
-// XCD-aware workgroup -> tile map.  Observed dispatch: blocks b and b+8 share an XCD and its
-// 4 MiB L2 (placement is a speed matter only).  XCD x = b&7 owns cnt_x = nwg/8 (+1) blocks;
-// give it a CONTIGUOUS range of the tile list ordered chunk-major along the longer tile
-// dimension, i.e. a compact column (or row) band of the output: its A/B panels then stay in
-// that XCD's L2 instead of every XCD streaming every panel from the Infinity Cache.
-__device__ __forceinline__ void tile_of_block(int bid, int nwg, int tiles_m, int tiles_n, int map, int& tm,
-                                              int& tn) {
-    int t = bid;
-    if (map == 1 && nwg >= 16) {
-        const int x = bid & 7, j = bid >> 3, base = nwg >> 3, rem = nwg & 7;
-        t = x * base + (x < rem ? x : rem) + j;
-        if (tiles_n >= tiles_m) {
-            const int cw = (tiles_n + 7) >> 3, per = cw * tiles_m, c = t / per, r = t - c * per;
-            const int w = (tiles_n - c * cw) < cw ? (tiles_n - c * cw) : cw;
-            tm = r / w;
-            tn = c * cw + r % w;
-        } else {
-            const int ch = (tiles_m + 7) >> 3, per = ch * tiles_n, c = t / per, r = t - c * per;
-            const int h = (tiles_m - c * ch) < ch ? (tiles_m - c * ch) : ch;
-            tn = r / h;
-            tm = c * ch + r % h;
-        }
-        return;
-    }
-    if (map >= 2) {
-        // grouped order (map = group height in tiles): sweep the tile columns of a band of `map` tile rows before
-        // moving to the next band, so that the workgroups in flight together share both a few row panels of A
-        // and a few column panels of B
-        const int gm = map, per = gm * tiles_n, grp = t / per, first = grp * gm;
-        const int h = (tiles_m - first) < gm ? (tiles_m - first) : gm, r = t - grp * per;
-        tm = first + r % h;
-        tn = r / h;
-        return;
-    }
-    tm = t / tiles_n;
-    tn = t % tiles_n;
-}
-
-// Epilogue of one 16-register accumulator column (fixed `col`, 16 rows `row0 + rmap(r)`).
-// Everything that depends only on the column (scale, bias, activation id, shift) is fetched
-// ONCE; the optional per-element operands (residual / yref / old C) are loaded as one batch
-// before any store, so no load ever waits behind a store's vmcnt.
-template <int NR, bool ONES = true, typename RowOf>
-__device__ __forceinline__ void epi_store_col(const dv_gemm_desc& g, const float (&acc)[NR], int col, RowOf row_of) {
-    const bool cok = col < g.N;
-    const int cc = cok ? col : g.N - 1;
-    if (ONES && (g.flags & DV_FLAG_ONES_COL) && col == g.N) {
-        // the bias gradient: B's first column past N is staged as ones (see gemm_body), so this accumulator column is
-        // sum_k A[k, row] -- the column sums of dy ride on the matrix core instead of in four extra registers
-#pragma unroll
-        for (int r = 0; r < NR; ++r) {
-            const int row = row_of(r);
-            if (row < g.M)
-                g.a_colsum[row] = (g.colsum_beta != 0.f ? g.colsum_beta * g.a_colsum[row] : 0.f) + acc[r];
-        }
-        return;
-    }
-    const bool first = col < g.split;
-    const int act = first ? g.act0 : g.act1;
-    const float shift = first ? g.shift0 : g.shift1;
-    float sc = 1.f, bi = 0.f;
-    if (g.epilogue == DV_EPI_FWD) {
-        if (g.scale) sc = g.scale[cc];
-        if (g.bias) bi = g.bias[cc];
-    }
-    float ex[NR], old[NR];
-    const float* exsrc = nullptr;
-    int64_t exld = 0;
-    if (g.epilogue == DV_EPI_FWD && g.resid) {
-        exsrc = g.resid;
-        exld = g.ldr;
-    } else if (g.epilogue == DV_EPI_BWD) {
-        exsrc = g.yref;
-        exld = g.ldy;
-    }
-    const bool use_ex = exsrc != nullptr;
-    const bool use_old = g.beta != 0.f;
-    const int exc = (g.epilogue == DV_EPI_FWD && use_ex) ? (col < g.resid_cols ? col : 0) : cc;
-#pragma unroll
-    for (int r = 0; r < NR; ++r) {
-        const int row = row_of(r), rc = row < g.M ? row : g.M - 1;
-        ex[r] = use_ex ? exsrc[(int64_t)rc * exld + exc] : 0.f;
-        old[r] = use_old ? g.C[(int64_t)rc * g.ldc + cc] : 0.f;
-    }
-#pragma unroll
-    for (int r = 0; r < NR; ++r) {
-        const int row = row_of(r);
-        float v = acc[r] * g.alpha;
-        if (g.epilogue == DV_EPI_FWD) {
-            v = dv_act(act, v * sc + bi) + shift;
-            if (use_ex && col < g.resid_cols) v += ex[r];
-        } else if (g.epilogue == DV_EPI_BWD) {
-            v *= dv_dact_from_y(act, ex[r] - shift);
-        }
-        if (use_old) v += g.beta * old[r];
-        if (cok && row < g.M) g.C[(int64_t)row * g.ldc + col] = v;
-    }
-}
 
 // One staged operand.  Element (line, pos) lives at base[line*ld + pos]:
 //   k-contiguous operand  : line = output row (m or n), pos = k
@@ -771,12 +614,6 @@ __device__ __forceinline__ void gemm_body(const dv_gemm_desc& g, const LoadCfg& 
     }
 }
 
-// this launch started => everything before it in its stream is complete: a free place to tell another
-// launch chain so (see dv_flag_publish)
-__device__ __forceinline__ void publish_on_entry(const dv_gemm_desc& g) {
-    if (g.pub_flag != nullptr && blockIdx.x == 0 && threadIdx.x == 0)
-        __hip_atomic_store(g.pub_flag, g.pub_ctr[0] + g.pub_add, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-}
 
 template <int BM, int BN, int BK, int WM, int WN, int KS, bool AKC, bool BKC, bool MI16 = false>
 __global__ __launch_bounds__(64 * WM * WN * KS, (WM * WN * KS == 16) ? 4 : (BM >= 128 || BK >= 128) ? 2 : (BM * BN >= 6144) ? (WM * WN * KS) / 4 : (WM * WN * KS == 8 ? (BM * BN == 1024 ? DV_LB8 : 2) : (BK == 32 && BM == 32 ? ((AKC || BKC) ? DV_DENSE_WG : DV_DENSE_WG - 1) : 4))) void gemm_kernel(const dv_gemm_desc g, const LoadCfg lc) {
@@ -1030,6 +867,8 @@ __global__ __launch_bounds__(256, BK == 32 ? DV_DENSE_WG : 4) void gemm_pair_ker
         gemm_body<BM, BN, BK, WM, WN, KS, A2, B2>(g2, lc2, smem, blockIdx.x - tiles1, gridDim.x - tiles1);
 }
 
+#include "gemm_pipe.inc"
+
 inline int vec_width(const void* p, int64_t ld) {
     const uintptr_t a = reinterpret_cast<uintptr_t>(p);
     if ((a & 15) == 0 && (ld & 3) == 0) return 4;
@@ -1082,7 +921,7 @@ extern "C" int dv_gemm_set_option(int key, int value) {
 
 extern "C" int dv_gemm_force_tiling(int t) {
 #ifndef DV_LAB
-    if ((t < 0 || t > 3) && t != 17) return DV_ERR_UNSUPPORTED;      // the lab tilings exist in the tuning build only (-DDV_LAB)
+    if ((t < 0 || t > 3) && t != 17 && t != 40) return DV_ERR_UNSUPPORTED;      // the lab tilings exist in the tuning build only (-DDV_LAB)
 #endif
     g_force_tiling = t;
     return DV_OK;
@@ -1143,7 +982,7 @@ static int dense_min_tiles() { return g_opt[8] > 0 ? g_opt[8] : 512; }
 static int colsum_setup(dv_gemm_desc& g, int tiling, hipStream_t st) {
     g.flags &= 3;
     if (g.a_colsum == nullptr || g.a_kcontig) return DV_OK;
-    if (tiling == 3 || tiling == 16) {
+    if (tiling == 3 || tiling == 16 || (tiling >= 40 && tiling < 50)) {
         const int rc = dv_colsum(g.A, g.lda, g.K, g.M, g.a_colsum, g.colsum_beta, st);
         g.a_colsum = nullptr;
         return rc;
@@ -1160,6 +999,14 @@ static int gemm_launch(const dv_gemm_desc& g_in, const LoadCfg& lc, int tiling, 
         if (rc != DV_OK) return rc;
     }
     if (tiling == 3) return launch_cfg<128, 128, 32, 2, 2, 1>(g, lc, st);
+    if (tiling >= 40 && tiling < 50 && !pipe_ok(g, lc)) return launch_cfg<128, 128, 32, 2, 2, 1>(g, lc, st);
+    if (tiling == 40) return launch_pipe<128, 256, 16, 2, 2, 3, 2>(g, lc, st);
+#ifdef DV_LAB
+    if (tiling == 41) return launch_pipe<128, 128, 16, 2, 2, 3, 3>(g, lc, st);
+    if (tiling == 42) return launch_pipe<128, 256, 16, 2, 2, 4, 1>(g, lc, st);
+    if (tiling == 43) return launch_pipe<256, 128, 16, 2, 2, 3, 2>(g, lc, st);
+    if (tiling == 44) return launch_pipe<128, 128, 32, 2, 2, 2, 2>(g, lc, st);
+#endif
 #ifdef DV_LAB
     if (tiling == 16) return launch_cfg<128, 128, 32, 2, 2, 1, true>(g, lc, st);   // the 128x128 tiling on v_mfma_f32_16x16x4_f32
     if (tiling == 30 && g.a_kcontig && g.b_kcontig) return launch_cfg<96, 64, 64, 1, 2, 4>(g, lc, st);   // lab: one round of big tiles
