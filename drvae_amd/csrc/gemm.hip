@@ -23,6 +23,8 @@
 
 namespace {
 
+#include "gemm_pipe.inc"
+
 
 // One staged operand.  Element (line, pos) lives at base[line*ld + pos]:
 //   k-contiguous operand  : line = output row (m or n), pos = k
@@ -165,8 +167,9 @@ __device__ __forceinline__ void heads_epilogue(const dv_gemm_desc& g, const dv_h
     }
 }
 
-template <int BM, int BN, int BK, int KS, bool AKC, bool BKC>
+template <int BM, int BN, int BK, int KS, bool AKC, bool BKC, int PS = 0>
 constexpr int gemm_smem_floats() {
+    if constexpr (PS > 0) return PipeGeom<BM, BN, BK, BM / 32, BN / 32, KS, PS, AKC, BKC>::SMEM_FL;
     constexpr int stage = (AKC ? BM : BK) * ((AKC ? BK : BM) + 4) + (BKC ? BN : BK) * ((BKC ? BK : BN) + 4);
     constexpr int red = (KS > 1) ? KS * BM * (BN + 1) : 0;
     return 2 * stage > red ? 2 * stage : red;
@@ -177,7 +180,8 @@ constexpr int gemm_smem_floats() {
 // epilogue sees both heads of an element in one thread.
 // MI16: the product runs on v_mfma_f32_16x16x4_f32 (16x16 accumulator tiles, four k-groups of lanes) instead of
 // v_mfma_f32_32x32x2_f32 -- the same matrix-pipe cycles, LDS reads and registers per output element.
-template <int BM, int BN, int BK, int WM, int WN, int KS, bool AKC, bool BKC, bool PAIR = false, bool MI16 = false>
+// PS > 0: the K loop is the hand-pipelined LDS-DMA ring of PS slots (gemm_pipe.inc; the launcher has checked pipe_ok)
+template <int BM, int BN, int BK, int WM, int WN, int KS, bool AKC, bool BKC, bool PAIR = false, bool MI16 = false, int PS = 0>
 __device__ __forceinline__ void gemm_body(const dv_gemm_desc& g, const LoadCfg& lc, float* smem, int bid, int nwg,
                                           const dv_heads_epi* he = nullptr) {
     static_assert(!PAIR || (AKC && BKC && KS > 1 && WM == 1 && WN == 1), "paired heads: forward layout, K-split tiling");
@@ -194,12 +198,13 @@ __device__ __forceinline__ void gemm_body(const dv_gemm_desc& g, const LoadCfg& 
     constexpr int STAGE = A_ELEMS + B_ELEMS;
     constexpr int RED_ELEMS = (KS > 1) ? KS * BM * (BN + 1) : 0;
     constexpr int NT = 64 * WM * WN * KS;   // threads per workgroup
-    static_assert(2 * STAGE <= gemm_smem_floats<BM, BN, BK, KS, AKC, BKC>() && RED_ELEMS <= gemm_smem_floats<BM, BN, BK, KS, AKC, BKC>(), "smem");
+    static_assert(PS > 0 || (2 * STAGE <= gemm_smem_floats<BM, BN, BK, KS, AKC, BKC>() && RED_ELEMS <= gemm_smem_floats<BM, BN, BK, KS, AKC, BKC>()), "smem");
+    static_assert(PS == 0 || (!MI16 && TM == 1 && TN == 1), "pipe loop inside gemm_body: one 32x32 tile per wave");
     static_assert(NT == 256 || NT == 512 || NT == 1024, "4, 8 or 16 waves");
 
     const bool ones_col = BM < 128 && !AKC && !BKC && (g.flags & DV_FLAG_ONES_COL);
     const int tiles_m = (g.M + BM - 1) / BM;
-    const int tiles_n = PAIR ? (g.split + HB - 1) / HB : (g.N + (ones_col ? 1 : 0) + BN - 1) / BN;
+    const int tiles_n = PAIR ? (g.split + HB - 1) / HB : (g.N + (ones_col ? DV_ONES_OFF(g) + 1 : 0) + BN - 1) / BN;
     int tm, tn;
     tile_of_block(bid, nwg, tiles_m, tiles_n, lc.map, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
@@ -389,7 +394,11 @@ __device__ __forceinline__ void gemm_body(const dv_gemm_desc& g, const LoadCfg& 
     const int nkt = (g.K + BK - 1) / BK, nfull = g.K / BK;
     float* const buf0 = smem;
     float* const buf1 = smem + STAGE;
-    if (wg_fast && nfull >= 1) {
+    if constexpr (PS > 0) {
+        pipe_loop<BM, BN, BK, WM, WN, KS, PS, AKC, BKC, (BM < 128 && !AKC && !BKC)>(
+            g, smem, m0, n0, [&](int l) { return m0 + l < g.M ? m0 + l : g.M - 1; }, bline, acc);
+        __syncthreads();      // (K-split reduction below reuses the ring)
+    } else if (wg_fast && nfull >= 1) {
         // ---- interior workgroups: per-thread staging pointers advanced by one K tile per step,
         // unconditional vector loads, TWO register sets (two tiles in flight: each load has two
         // MFMA phases to land), LDS double buffer (one barrier per K tile).
@@ -867,7 +876,33 @@ __global__ __launch_bounds__(256, BK == 32 ? DV_DENSE_WG : 4) void gemm_pair_ker
         gemm_body<BM, BN, BK, WM, WN, KS, A2, B2>(g2, lc2, smem, blockIdx.x - tiles1, gridDim.x - tiles1);
 }
 
-#include "gemm_pipe.inc"
+// ---- the same three launch shapes with the hand-pipelined K loop (gemm_pipe.inc): PS ring slots, WPS workgroups' worth
+// of waves per SIMD the register allocation is held to
+template <int BM, int BN, int BK, int KS, bool AKC, bool BKC, int PS, int WPS>
+__global__ __launch_bounds__(64 * KS, WPS) void gemm_kpipe_kernel(const dv_gemm_desc g, const LoadCfg lc) {
+    __shared__ __attribute__((aligned(1024))) float smem[gemm_smem_floats<BM, BN, BK, KS, AKC, BKC, PS>()];
+    publish_on_entry(g);
+    gemm_body<BM, BN, BK, BM / 32, BN / 32, KS, AKC, BKC, false, false, PS>(g, lc, smem, blockIdx.x, gridDim.x);
+}
+
+template <int BM, int BN, int BK, int KS, int PS, int WPS>
+__global__ __launch_bounds__(64 * KS, WPS) void gemm_heads_pipe_kernel(const dv_gemm_desc g, const LoadCfg lc, const dv_heads_epi he) {
+    __shared__ __attribute__((aligned(1024))) float smem[gemm_smem_floats<BM, BN, BK, KS, true, true, PS>()];
+    publish_on_entry(g);
+    gemm_body<BM, BN, BK, 1, 1, KS, true, true, true, false, PS>(g, lc, smem, blockIdx.x, gridDim.x, &he);
+}
+
+template <int BM, int BN, int BK, int KS, bool A1, bool B1, bool A2, bool B2, int PS, int WPS>
+__global__ __launch_bounds__(256, WPS) void gemm_pair_pipe_kernel(const dv_gemm_desc g1, const LoadCfg lc1, const dv_gemm_desc g2,
+                                                                    const LoadCfg lc2, int tiles1) {
+    constexpr int S1 = gemm_smem_floats<BM, BN, BK, KS, A1, B1, PS>(), S2 = gemm_smem_floats<BM, BN, BK, KS, A2, B2, PS>();
+    __shared__ __attribute__((aligned(1024))) float smem[S1 > S2 ? S1 : S2];
+    publish_on_entry(g1);
+    if ((int)blockIdx.x < tiles1)
+        gemm_body<BM, BN, BK, 1, 1, KS, A1, B1, false, false, PS>(g1, lc1, smem, blockIdx.x, tiles1);
+    else
+        gemm_body<BM, BN, BK, 1, 1, KS, A2, B2, false, false, PS>(g2, lc2, smem, blockIdx.x - tiles1, gridDim.x - tiles1);
+}
 
 inline int vec_width(const void* p, int64_t ld) {
     const uintptr_t a = reinterpret_cast<uintptr_t>(p);
@@ -883,7 +918,7 @@ static int g_lds_pad = 0;
 inline int lds_pad(int bm, int tiles) { return (bm <= 32 && tiles >= 512) ? g_lds_pad : 0; }
 
 // output columns incl. the ones column of the fused bias gradient (see gemm_body)
-inline int cols_eff(const dv_gemm_desc& g) { return g.N + ((g.flags & DV_FLAG_ONES_COL) ? 1 : 0); }
+inline int cols_eff(const dv_gemm_desc& g) { return g.N + ((g.flags & DV_FLAG_ONES_COL) ? DV_ONES_OFF(g) + 1 : 0); }
 
 template <int BM, int BN, int BK, int WM, int WN, int KS, bool MI16 = false>
 int launch_cfg(const dv_gemm_desc& g, const LoadCfg& lc, hipStream_t st) {
@@ -895,6 +930,28 @@ int launch_cfg(const dv_gemm_desc& g, const LoadCfg& lc, hipStream_t st) {
         hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, WM, WN, KS, true, false, MI16>), grid, block, lds_pad(BM, tiles), st, g, lc);
     else if (!g.a_kcontig && !g.b_kcontig)
         hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, WM, WN, KS, false, false, MI16>), grid, block, lds_pad(BM, tiles), st, g, lc);
+    else
+        return DV_ERR_UNSUPPORTED;
+    DV_RETURN_LAUNCH();
+}
+
+// the bias-gradient column of the LDS-DMA kernels: the first multiple of 4 at or past N (see DV_ONES_OFF)
+inline void pipe_ones_off(dv_gemm_desc& g) {
+    if (g.flags & DV_FLAG_ONES_COL) g.flags = (g.flags & ~0x300) | (((4 - (g.N & 3)) & 3) << 8);
+}
+
+template <int BM, int BN, int BK, int KS, int PS, int WPS>
+int launch_kpipe(const dv_gemm_desc& g_in, const LoadCfg& lc, hipStream_t st) {
+    dv_gemm_desc g = g_in;
+    pipe_ones_off(g);
+    const int tiles = ((g.M + BM - 1) / BM) * ((cols_eff(g) + BN - 1) / BN);
+    dim3 grid(tiles), block(64 * KS);
+    if (g.a_kcontig && g.b_kcontig)
+        hipLaunchKernelGGL((gemm_kpipe_kernel<BM, BN, BK, KS, true, true, PS, WPS>), grid, block, 0, st, g, lc);
+    else if (g.a_kcontig && !g.b_kcontig)
+        hipLaunchKernelGGL((gemm_kpipe_kernel<BM, BN, BK, KS, true, false, PS, WPS>), grid, block, 0, st, g, lc);
+    else if (!g.a_kcontig && !g.b_kcontig)
+        hipLaunchKernelGGL((gemm_kpipe_kernel<BM, BN, BK, KS, false, false, PS, WPS>), grid, block, 0, st, g, lc);
     else
         return DV_ERR_UNSUPPORTED;
     DV_RETURN_LAUNCH();
@@ -964,16 +1021,20 @@ static int gemm_prepare(const dv_gemm_desc* d, LoadCfg& lc, int& tiling) {
     // ... or once K is long enough to amortise a tile's prologue over many K steps: 1536 x 2048 x 20000 (encoder L1 of
     // the wide configuration, 768 tiles of 64x64) runs 956 us on the 64x64 tiling, 1090 us on 32x32, 1336 us on 128x128
     if (tiling == 0) tiling = (t128 >= 1024) ? 3 : ((t64 >= t64_min || (t64 >= 512 && g.K >= 8192)) ? 1 : 2);
+    // the chip-filling products run on the hand-pipelined LDS-DMA tiling (gemm_pipe.inc) when their operands allow it
+    // (16-B aligned rows, K % 4 == 0 ...): 8192 x 8192 x 2048 134 -> 144-149 TFLOP/s (dv_gemm_set_option(3, -1): off)
+    if (tiling == 3 && g_force_tiling == 0 && g_opt[3] != -1 && pipe_ok(g, lc)) tiling = 40;
     // workgroup -> tile map: XCD chunk-major for the small grids (each XCD keeps a compact band of the
     // output, its panels stay in its L2); for the grids that fill the chip many times over, bands of 16 tile
     // rows swept column by column (measured, wide configuration: chunk-major 121.5, linear 127.0, bands of 16
     // 128.3 TF/s over the step's products; no difference at the cfg-2 sizes)
-    lc.map = g_opt[0] >= 0 ? g_opt[0] : (tiling == 3 ? 16 : 1);
+    lc.map = g_opt[0] >= 0 ? g_opt[0] : (tiling == 3 ? 16 : (tiling == 40 ? 32 : 1));
     return DV_OK;
 }
 
 // tiles of 32x32 from which a product runs on the high-occupancy tiling (dv_gemm_set_option(8, n); 0 = default)
 static int dense_min_tiles() { return g_opt[8] > 0 ? g_opt[8] : 512; }
+static bool pipe_on() { return g_opt[3] != -1; }
 
 // fused bias gradient of a dy^T x product: the ones column (DV_FLAG_ONES_COL) -- free where the last column tile has
 // padding, one extra tile per row panel where N is a multiple of the tile width.  Not in the 128x128 tiling (its
@@ -1062,9 +1123,11 @@ static int gemm_launch(const dv_gemm_desc& g_in, const LoadCfg& lc, int tiling, 
     // decoder-head products took two rounds on 256 CUs (three on the main chain's 192): x W^T 24.3 -> 21.2 us,
     // dy^T x 23.6 -> 21.0 us alone (tools/gemm_bench.py --tilings 2,9,17)
     const int tiles32 = ((g.M + 31) / 32) * ((cols_eff(g) + 31) / 32);
-    if (tiles32 >= dense_min_tiles()) return launch_cfg<32, 32, 32, 1, 1, 4>(g, lc, st);
-    if (g.a_kcontig && g_opt[7] == 0) return launch_cfg<32, 32, 64, 1, 1, 8>(g, lc, st);
-    return launch_cfg<32, 32, 64, 1, 1, 4>(g, lc, st);
+    // each of the three on the hand-pipelined LDS-DMA loop where the operands allow it (pipe_ok; dv_gemm_set_option(3, -1): never)
+    const bool pipe = pipe_on() && pipe_ok(g, lc);
+    if (tiles32 >= dense_min_tiles()) return pipe ? launch_kpipe<32, 32, 32, 4, 2, DV_DENSE_WG>(g, lc, st) : launch_cfg<32, 32, 32, 1, 1, 4>(g, lc, st);
+    if (g.a_kcontig && g_opt[7] == 0) return pipe ? launch_kpipe<32, 32, 64, 8, 2, 2>(g, lc, st) : launch_cfg<32, 32, 64, 1, 1, 8>(g, lc, st);
+    return pipe ? launch_kpipe<32, 32, 64, 4, 2, 4>(g, lc, st) : launch_cfg<32, 32, 64, 1, 1, 4>(g, lc, st);
 }
 
 extern "C" int dv_gemm(const dv_gemm_desc* d, dv_stream_t stream) {
@@ -1123,14 +1186,23 @@ extern "C" int dv_gemm_heads(const dv_gemm_desc* d, const dv_heads_epi* e, dv_st
         DV_RETURN_LAUNCH();
     }
 #endif
-    if (g_opt[4] == 3 || (g_opt[4] == 0 && tiles >= dense_min_tiles()))
+    const bool pipe = pipe_on() && pipe_ok(g, lc);
+    if (g_opt[4] == 3 || (g_opt[4] == 0 && tiles >= dense_min_tiles())) {
         // chip-filling grids: four waves, half the K tile, seven workgroups per CU (see gemm_launch): 29.1 -> 26.4 us
         // for the decoder heads + NLL alone
-        hipLaunchKernelGGL((gemm_heads_kernel<32, 32, 32, 4>), dim3(tiles), dim3(256), 0,
+        if (pipe)
+            hipLaunchKernelGGL((gemm_heads_pipe_kernel<32, 32, 32, 4, 2, DV_DENSE_WG>), dim3(tiles), dim3(256), 0,
+                               static_cast<hipStream_t>(stream), g, lc, *e);
+        else
+            hipLaunchKernelGGL((gemm_heads_kernel<32, 32, 32, 4>), dim3(tiles), dim3(256), 0,
+                               static_cast<hipStream_t>(stream), g, lc, *e);
+    } else if (pipe) {
+        hipLaunchKernelGGL((gemm_heads_pipe_kernel<32, 32, 64, 8, 2, 2>), dim3(tiles), dim3(512), 0,
                            static_cast<hipStream_t>(stream), g, lc, *e);
-    else   // default: the 32x32 tiling's eight-wave K split, B lines = 16 + 16 rows of the two heads
+    } else {  // default: the 32x32 tiling's eight-wave K split, B lines = 16 + 16 rows of the two heads
         hipLaunchKernelGGL((gemm_heads_kernel<32, 32, 64, 8>), dim3(tiles), dim3(512), lds_pad(32, tiles),
                            static_cast<hipStream_t>(stream), g, lc, *e);
+    }
     DV_RETURN_LAUNCH();
 }
 
@@ -1152,6 +1224,8 @@ extern "C" int dv_gemm_pair(const dv_gemm_desc* d1, const dv_gemm_desc* d2, dv_s
         rc = colsum_setup(e1, 2, st);
         if (rc != DV_OK) return rc;
     }
+    const bool pipe = pipe_on() && t1 == 2 && t2 == 2 && pipe_ok(e1, lc1) && pipe_ok(e2, lc2);
+    if (pipe) pipe_ones_off(e1);
     const int tiles1 = ((e1.M + 31) / 32) * ((cols_eff(e1) + 31) / 32), tiles2 = ((e2.M + 31) / 32) * ((e2.N + 31) / 32);
     // pairing pays for the latency-bound small products; a product that already fills the chip
     // several times over (>= 4 workgroups per CU) gains nothing from a partner (measured: the
@@ -1171,11 +1245,16 @@ extern "C" int dv_gemm_pair(const dv_gemm_desc* d1, const dv_gemm_desc* d2, dv_s
             first.pub_add = second.pub_add;
             second.pub_flag = nullptr;
         }
-        hipLaunchKernelGGL((gemm_pair_kernel<32, 32, 32, 1, 1, 4, true, false, false, false>), dim3(tiles1 + tiles2),
-                           dim3(256), 0, st, first, lc2, second, lc1, tiles2);
+        if (pipe)
+            hipLaunchKernelGGL((gemm_pair_pipe_kernel<32, 32, 32, 4, true, false, false, false, 2, DV_DENSE_WG>), dim3(tiles1 + tiles2),
+                               dim3(256), 0, st, first, lc2, second, lc1, tiles2);
+        else
+            hipLaunchKernelGGL((gemm_pair_kernel<32, 32, 32, 1, 1, 4, true, false, false, false>), dim3(tiles1 + tiles2),
+                               dim3(256), 0, st, first, lc2, second, lc1, tiles2);
         DV_RETURN_LAUNCH();
     }
     if (!fuse) {
+        // (gemm_launch runs its own colsum_setup / ones offset on the caller's descriptors)
         rc = gemm_launch(*d1, lc1, t1, st);
         if (rc != DV_OK) return rc;
         return gemm_launch(*d2, lc2, t2, st);
@@ -1186,7 +1265,11 @@ extern "C" int dv_gemm_pair(const dv_gemm_desc* d1, const dv_gemm_desc* d2, dv_s
         first.pub_ctr = d2->pub_ctr;
         first.pub_add = d2->pub_add;
     }
-    hipLaunchKernelGGL((gemm_pair_kernel<32, 32, 64, 1, 1, 4, false, false, true, false>), dim3(tiles1 + tiles2),
-                       dim3(256), 0, st, first, lc1, e2, lc2, tiles1);
+    if (pipe)
+        hipLaunchKernelGGL((gemm_pair_pipe_kernel<32, 32, 64, 4, false, false, true, false, 2, 4>), dim3(tiles1 + tiles2),
+                           dim3(256), 0, st, first, lc1, e2, lc2, tiles1);
+    else
+        hipLaunchKernelGGL((gemm_pair_kernel<32, 32, 64, 1, 1, 4, false, false, true, false>), dim3(tiles1 + tiles2),
+                           dim3(256), 0, st, first, lc1, e2, lc2, tiles1);
     DV_RETURN_LAUNCH();
 }
