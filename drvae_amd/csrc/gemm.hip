@@ -978,7 +978,7 @@ extern "C" int dv_gemm_set_option(int key, int value) {
 
 extern "C" int dv_gemm_force_tiling(int t) {
 #ifndef DV_LAB
-    if ((t < 0 || t > 3) && t != 17 && t != 40) return DV_ERR_UNSUPPORTED;      // the lab tilings exist in the tuning build only (-DDV_LAB)
+    if ((t < 0 || t > 3) && t != 17 && t != 40 && t != 46) return DV_ERR_UNSUPPORTED;      // the lab tilings exist in the tuning build only (-DDV_LAB)
 #endif
     g_force_tiling = t;
     return DV_OK;
@@ -1024,6 +1024,9 @@ static int gemm_prepare(const dv_gemm_desc* d, LoadCfg& lc, int& tiling) {
     // the chip-filling products run on the hand-pipelined LDS-DMA tiling (gemm_pipe.inc) when their operands allow it
     // (16-B aligned rows, K % 4 == 0 ...): 8192 x 8192 x 2048 134 -> 144-149 TFLOP/s (dv_gemm_set_option(3, -1): off)
     if (tiling == 3 && g_force_tiling == 0 && g_opt[3] != -1 && pipe_ok(g, lc)) tiling = 40;
+    // (64x64 tiles, three workgroups per CU: one resident round up to 768 tiles; measured 1536 x 2048 x 20000: 983 -> 962 us,
+    // but 2048 x 2048 x 4096 = 1024 tiles: 271 -> 323 us)
+    if (tiling == 1 && g_force_tiling == 0 && g_opt[3] != -1 && g.K >= 1024 && t64 <= 768 && pipe_ok(g, lc)) tiling = 46;
     // workgroup -> tile map: XCD chunk-major for the small grids (each XCD keeps a compact band of the
     // output, its panels stay in its L2); for the grids that fill the chip many times over, bands of 16 tile
     // rows swept column by column (measured, wide configuration: chunk-major 121.5, linear 127.0, bands of 16
@@ -1062,6 +1065,10 @@ static int gemm_launch(const dv_gemm_desc& g_in, const LoadCfg& lc, int tiling, 
     if (tiling == 3) return launch_cfg<128, 128, 32, 2, 2, 1>(g, lc, st);
     if (tiling >= 40 && tiling < 50 && !pipe_ok(g, lc)) return launch_cfg<128, 128, 32, 2, 2, 1>(g, lc, st);
     if (tiling == 40) return launch_pipe<128, 256, 16, 2, 2, 3, 2>(g, lc, st);
+    // few output tiles, long K (encoder layer 1 of the wide configuration: 1536 x 2048 x 20000 = 768 tiles of 64 x 64 =
+    // three per CU, all resident): the 64x64 tiling's pipelined form
+    if (tiling == 46 && pipe_ok(g, lc)) return launch_pipe<64, 64, 32, 2, 2, 3, 3>(g, lc, st);
+    if (tiling == 46) return launch_cfg<64, 64, 32, 2, 2, 1>(g, lc, st);
 #ifdef DV_LAB
     if (tiling == 41) return launch_pipe<128, 128, 16, 2, 2, 3, 3>(g, lc, st);
     if (tiling == 42) return launch_pipe<128, 256, 16, 2, 2, 4, 1>(g, lc, st);

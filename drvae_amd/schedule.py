@@ -175,6 +175,13 @@ class StepSchedule:
         gc.collect()
         gc_was_on = gc.isenabled()
         gc.disable()
+        # a chip-filling step (wide configuration) is captured on ONE stream: its side chain is 0.5 ms of small launches
+        # next to 31 ms of products that want every CU; as a graph branch they squeeze in between the resident GEMM
+        # workgroups of the other queue and cost more than they hide (measured, round 4: 32.0 ms with the fork/join,
+        # 31.5 ms in order on one stream)
+        branch_on = self.branch.on
+        if branch_on and not dual and not self._latency_bound() and T.get('wide_single'):
+            self.branch.on = False
         try:
             self._capture_main(split_for_allreduce)
             if dual:
@@ -192,6 +199,7 @@ class StepSchedule:
                 self._side_graph = gs
         finally:
             self._rec = 'both'
+            self.branch.on = branch_on
             if gc_was_on:
                 gc.enable()
         self._graph_key = self.plan.key

@@ -93,7 +93,7 @@ SHAPES = [(7, 5, 13), (64, 64, 32), (65, 33, 31), (225, 800, 978), (150, 200, 10
           (260, 516, 200), (128, 256, 48), (1000, 300, 64)]
 
 
-@pytest.mark.parametrize('tiling', [0, 1, 2, 3, 5, 9, 11, 12, 13, 16, 17, 40])
+@pytest.mark.parametrize('tiling', [0, 1, 2, 3, 5, 9, 11, 12, 13, 16, 17, 40, 46])
 @pytest.mark.parametrize('M,N,Kd', SHAPES)
 def test_gemm_forward_epilogue(K, dev, tiling, M, N, Kd):
     from drvae_amd import _lib
@@ -112,7 +112,7 @@ def test_gemm_forward_epilogue(K, dev, tiling, M, N, Kd):
         _lib.load().dv_gemm_force_tiling(0)
 
 
-@pytest.mark.parametrize('tiling', [0, 1, 2, 3, 5, 16, 17, 40])
+@pytest.mark.parametrize('tiling', [0, 1, 2, 3, 5, 16, 17, 40, 46])
 @pytest.mark.parametrize('M,N,Kd', SHAPES)
 def test_gemm_backward_products(K, dev, tiling, M, N, Kd):
     from drvae_amd import _lib

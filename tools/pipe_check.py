@@ -15,7 +15,7 @@ from drvae_amd import _lib  # noqa: E402
 from tools.gemm_bench import time_call  # noqa: E402
 
 CHECK = [(128, 256, 16), (128, 256, 64), (130, 260, 100), (1000, 516, 200), (257, 1028, 36), (64, 40, 20), (513, 300, 1024)]
-BIG = [(8192, 8192, 2048), (8192, 40000, 2048), (8192, 2048, 40000), (40000, 2048, 8192), (4096, 2048, 20000)]
+BIG = [(1536, 2048, 20000), (2048, 2048, 4096), (8192, 8192, 2048), (8192, 40000, 2048), (8192, 2048, 40000), (40000, 2048, 8192), (4096, 2048, 20000)]
 
 
 def operands(M, N, Kd, akc, bkc, dev, pad=0):
@@ -57,6 +57,11 @@ def main():
                         b = torch.randn(N, device=dev)
                         K.gemm(C2, A, B, akc, bkc, overread=True, epi=K.EPI_FWD, bias=b, act0='elu', act1='elu')
                         ref2 = torch.nn.functional.elu(ref + b.double())
+                    elif akc:        # activation backward of the layer below fused into dy W, accumulating
+                        y = torch.nn.functional.elu(torch.randn(M, N, device=dev))
+                        K.gemm(C2, A, B, akc, bkc, overread=True, alpha=-0.5, beta=1.0, epi=K.EPI_BWD, yref=y, act0='elu', act1='elu')
+                        dact = torch.where(y > 0, torch.ones_like(y), y + 1.0).double()
+                        ref2 = -0.5 * ref * dact + old.double()
                     else:
                         K.gemm(C2, A, B, akc, bkc, overread=True, alpha=-0.5, beta=1.0)
                         ref2 = -0.5 * ref + old.double()
@@ -74,7 +79,7 @@ def main():
                 A, B = operands(M, N, Kd, akc, bkc, dev)
                 Cm = torch.empty(M, N, device=dev)
                 row = '%dx%dx%d (%d%d):' % (M, N, Kd, akc, bkc)
-                for t in [3] + tilings:
+                for t in [3, 1] + tilings:
                     if lib.dv_gemm_force_tiling(t) != 0:
                         continue
                     for mp in maps:
