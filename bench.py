@@ -272,7 +272,7 @@ def gemm_roofline(eng, cfg, rows, frac_pair, frac_lab, repeats=20, workload='cfg
                   'un-partitioned chip, HIP events on the launch stream; achieved = algorithmic GEMM FLOPs per step / sum '
                   'of the per-launch times (= avg FLOPs per launch / avg launch duration)' % repeats}
     out = {'bound': 'mfma', 'achieved': iso['achieved'], 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-           'frac': iso['frac'], 'source': 'isolated (no committed profile of this workload)',
+           'frac': iso['frac'], 'source': 'live, isolated launches (see isolated.how); in_graph: the committed profile of the running step',
            'kernel': 'gemm_kernel / gemm_pair_kernel / gemm_heads_kernel<...> (fp32 v_mfma_f32_32x32x2_f32; all tilings/layouts)',
            'algorithmic_gflop_per_step': round(algorithmic / 1e9, 3),
            'executed_gflop_per_step': round(executed / 1e9, 3),
@@ -307,12 +307,14 @@ def gemm_roofline(eng, cfg, rows, frac_pair, frac_lab, repeats=20, workload='cfg
             # THE figure of the line: the same FLOPs over the GEMM-family kernel time of the RUNNING step (both chains
             # running, main chain on its CU partition), i.e. avg FLOPs per launch / avg in-situ launch duration, from
             # the committed rocprofv3 --kernel-trace --stats summary of this command
+            # (a PROFILE of an earlier run of this command, not a measurement of the build being run: its own key, with
+            # the commit it was collected at; `achieved` / `frac` above are this run's live figures)
             a2 = algorithmic / (ig['kernel_us_per_step'] * 1e-6) / 1e12
-            out['achieved'], out['frac'] = round(a2, 3), round(a2 / FP32_MFMA_PEAK_TFLOPS, 4)
-            out['source'] = 'in situ: GEMM-family kernel time per step of the running step, ' + prof_file
             out['in_graph'] = {'gemm_us_per_step': ig['kernel_us_per_step'], 'launches_per_step': ig['launches_per_step'],
                                'avg_launch_us': ig['avg_launch_us'], 'achieved': round(a2, 3),
-                               'frac': round(a2 / FP32_MFMA_PEAK_TFLOPS, 4)}
+                               'frac': round(a2 / FP32_MFMA_PEAK_TFLOPS, 4), 'profiled_at': prof.get('commit'),
+                               'what': 'GEMM-family kernel time per step of the RUNNING step (both chains, main chain on '
+                                       'its CU partition) from the committed rocprofv3 --kernel-trace --stats summary'}
     return out
 
 
@@ -367,7 +369,8 @@ def measure(args, workload, feed, steps, warmup, device, rank, world, steady_s=0
     use_graph = not args.no_graph
     dp_mode = None
     bat = None
-    n_table = [steps + warmup + 8]
+    n_table = [max(steps + warmup + 8, 1024)]      # batches per index table of the graph-resident feeds (re-drawn in place)
+    k_batch = [0]                                    # batch of the table the NEXT replay gathers
     if feed != 'resident':
         from drvae_amd import data as DD, synth
         big = synth.make_batch(kind, args.dataset_rows, cfg.dim_x, cfg.dim_y, seed=77 + rank)
@@ -389,12 +392,13 @@ def measure(args, workload, feed, steps, warmup, device, rank, world, steady_s=0
         else:
             bat.feed()
 
-    def rebase(n):
-        """graph-resident feeds: a fresh index table that covers the next ``n`` replays (the feed clamps past its
-        end: a region longer than the table would re-train on the last batch instead of a fresh draw per step)"""
+    def rebase(n=None):
+        """graph-resident feeds: a fresh index table, drawn IN PLACE (same number of batches: the captured feed object
+        stays the one the graphs were captured with); a region longer than the table re-draws it every ``n_table - 8``
+        replays (``run``) instead of re-training on the clamped last batch"""
         if bat is not None and feed in ('epoch', 'sampler'):
-            bat.begin_epoch(n_batches=n_table[0] if bat.bucketed else n + 8)
-            bat.select(0)                # (bucketed: the first batch's plan; rare new buckets run on the next larger plan)
+            bat.begin_epoch(n_batches=n_table[0])
+        k_batch[0] = 0
     if use_graph:
         # one exchange between two graphs by default; --dp-exchange overlap: two overlapped pieces between three
         # graphs (measured with a one-rank RCCL communicator: +49 us of launch/event overhead per step against +24 us)
@@ -423,8 +427,13 @@ def measure(args, workload, feed, steps, warmup, device, rank, world, steady_s=0
                 eng.replay(allreduce)
         elif bat is not None and bat.bucketed:
             def step():
-                bat.select()
+                # the plan of the batch THIS replay gathers (the device feed takes batch step_dev - epoch base)
+                bat.select(k_batch[0])
+                k_batch[0] += 1
                 eng.replay(allreduce)
+                if args.check_feed:      # (tests) the batch the device just gathered is the one whose plan was selected
+                    got = int(eng.step_dev) - int(eng.plan.feed.base) - 1
+                    assert got == k_batch[0] - 1, 'replay gathered batch %d on the plan of batch %d' % (got, k_batch[0] - 1)
         else:
             step = lambda: eng.replay(allreduce)
     else:
@@ -434,12 +443,23 @@ def measure(args, workload, feed, steps, warmup, device, rank, world, steady_s=0
     if use_graph:
         eng.tune_partition()             # reserved CUs for the side chain, chosen by timing (state restored)
         part = eng.partition()           # side chain on reserved CUs (dual-graph schedule); no-op otherwise
-        rebase(steps + warmup)           # (the tuning replays advanced the step counter past the table's start)
+        rebase()                         # (the tuning replays advanced the step counter past the table's start)
     part.__enter__()
     if world > 1:
         dist.barrier()          # ranks leave capture together: the first exchanges do not sit out capture skew
-    for _ in range(max(warmup - 1, 0)):
-        step()
+    def run(n):
+        """n replays; graph-resident feeds get a fresh table whenever the current one is used up"""
+        chunk = n_table[0] - 8 if (bat is not None and feed in ('epoch', 'sampler')) else n
+        done = 0
+        while done < n:
+            m = min(chunk, n - done)
+            if done:
+                rebase()
+            for _ in range(m):
+                step()
+            done += m
+
+    run(max(warmup - 1, 0))
 
     def barrier():
         if world > 1:
@@ -456,8 +476,7 @@ def measure(args, workload, feed, steps, warmup, device, rank, world, steady_s=0
 
     barrier()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
+    run(steps)
     t_enq = time.perf_counter() - t0       # host time to enqueue the steps (if ~dt the host is the bound)
     barrier()
     dt = over_ranks(time.perf_counter() - t0)
@@ -467,11 +486,10 @@ def measure(args, workload, feed, steps, warmup, device, rank, world, steady_s=0
     steady = None
     if steady_s > 0 and dt < steady_s:
         n2 = int(min(max(200, steady_s * steps / max(dt, 1e-6)), 60000))
-        rebase(n2)
+        rebase()
         barrier()
         t1 = time.perf_counter()
-        for _ in range(n2):
-            step()
+        run(n2)
         barrier()
         dt2 = over_ranks(time.perf_counter() - t1)
         steady = {'steps': n2, 'seconds': round(dt2, 3), 'ms_per_step': round(1e3 * dt2 / n2, 4),
@@ -569,6 +587,9 @@ def main():
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--workload', default='cfg2', choices=list(WORKLOADS))
+    ap.add_argument('--check-feed', action='store_true', help='(tests) bucketed sampler feed: assert after every replay that the '
+                    'batch gathered on the device is the one whose plan was selected')
+    ap.add_argument('--strict', action='store_true', help='exit code 3 when a leg next to the headline (realistic_feed, other_workloads) raised')
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
@@ -666,6 +687,7 @@ def main():
         except Exception as e:       # noqa: BLE001
             print('bench.py: realistic_feed leg failed: %r' % (e,), file=sys.stderr)
             out['realistic_feed'] = {'feed': 'sampler', 'error': repr(e)}
+            out.setdefault('extras_failed', []).append('realistic_feed')
         out['other_workloads'] = {}
         for wl, (k_, w_) in (('wide', (10, 3)), ('cfg1', (200, 20)), ('cfg4', (200, 20))):
             gc.collect()
@@ -675,6 +697,7 @@ def main():
             except Exception as e:       # noqa: BLE001
                 print('bench.py: other_workloads leg %s failed: %r' % (wl, e), file=sys.stderr)
                 out['other_workloads'][{'wide': 'cfg5'}.get(wl, wl)] = {'error': repr(e)}
+                out.setdefault('extras_failed', []).append(wl)
                 continue
             entry = {'ms_per_step': r3['ms_per_step'], 'value': r3['value'], 'steps': k_, 'warmup': w_,
                      'finite': r3['finite'], 'workload': r3['config']['workload'],
@@ -700,6 +723,8 @@ def main():
         except OSError:
             pass
         print(json.dumps(out), flush=True)
+    if args.strict and out.get('extras_failed'):
+        return 3        # (the headline line is out; a leg next to it raised: see its 'error' entry)
     return 0 if ok else 1
 
 

@@ -478,6 +478,8 @@ class FusedStep(StepSchedule):
         depends on ``_mode()``: 5 = each chain is recorded into its own graph (``_rec`` says which one is being recorded)
         and device flags order them; 3 / 1 = one graph, fork/join per step / per pass; 0 = plain evaluation."""
         cfg, p = self.cfg, self.plan
+        if not self.fuse_bwd and self.dev.type == 'cuda' and not torch.cuda.is_current_stream_capturing():
+            self.join_side()        # an evaluation forward reads parameters the side chain's tail may still be updating
         p.set_beta(self.beta_pert())
         B, Np, L, Z1 = p.B, p.Np, cfg.L, cfg.dim_z1
         rec = self._rec
@@ -752,6 +754,15 @@ class FusedStep(StepSchedule):
                                p.c_kld, p.c_yl)
             else:
                 K.ymarg_fwd(p.YLrow, p.KLDrow, p.QY, p.label_r, p.fp_ptr, p.KLFP, p.log_prior)
+
+    def join_side(self):
+        """Order the CURRENT stream behind everything the side chain has been given so far.  After a ``replay()`` of the
+        dual-graph step the side chain's tail (its half of the optimiser sweep, the loss scalars, the next step's noise) is
+        awaited only by the NEXT captured step (tail gating), so whatever else touches parameters, moments or loss scalars
+        on the current stream -- ``losses()``, an eager ``train_step``, an evaluation forward, ``capture()``, a checkpoint
+        -- goes through here first (one event record + wait; no host sync)."""
+        if getattr(self, '_side_graph', None) is not None and self.dev.type == 'cuda':
+            torch.cuda.current_stream().wait_stream(self.flag_side)
 
     def _tail_gated(self):
         """dual-graph train step (ONE pair of graphs) whose side chain runs its half of the optimiser sweep and the loss
@@ -1149,6 +1160,7 @@ class FusedStep(StepSchedule):
         """forward + backward (+ gradient all-reduce) + Adam + iteration count: the body of
         ``run_on_batch(train_mode=True)`` (src/DGMMixin.py:91-126)."""
         self.training = True
+        self.join_side()
         if noise is not None:
             self.set_noise(noise)
         else:
@@ -1166,6 +1178,7 @@ class FusedStep(StepSchedule):
 
     def losses(self):
         """OrderedDict of python floats (one device->host copy; the only sync of a step)."""
+        self.join_side()         # (the loss scalars are assembled by the side chain's tail: see join_side)
         v = self.arena.loss.detach().cpu().tolist()
         if self._side_graph is not None:
             self.check_sync()

@@ -141,6 +141,7 @@ class StepSchedule:
         no graph boundary, no host-side launch of the exchange."""
         self._captured_allreduce = allreduce if split_for_allreduce == 'captured' else None
         assert self.plan is not None, 'set_batch first'
+        self.join_side()
         if self.plan.DZMMD is not None and split_for_allreduce:
             raise NotImplementedError('use_MMD: the model-level MMD penalty is a cross-row term (every row of a nuisance '
                                       'class against every other row): it cannot be sharded over ranks')
@@ -362,6 +363,7 @@ class StepSchedule:
 
     def check_sync(self):
         """raise if a device-side wait of the dual-graph schedule ever timed out (results would be stale)"""
+        self.join_side()
         if int(self.sync_err[0::2].abs().sum()) != 0:
             self._raise_sync(self.sync_err.cpu().tolist())
 

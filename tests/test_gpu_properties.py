@@ -192,6 +192,47 @@ def test_timed_out_chain_wait_fails_loudly(dev, monkeypatch):
     del before
 
 
+def test_losses_and_eager_steps_after_replay_need_no_host_sync(dev, monkeypatch):
+    """round-3 advisor: with tail gating nothing on the main stream is ordered behind the side chain's tail (its half of
+    the optimiser sweep, the loss scalars) -- ``losses()``, an eager ``train_step`` and an evaluation forward join the
+    side stream themselves now.  Two engines run the same captured steps; one reads its losses / parameters right after
+    ``replay()`` (no ``torch.cuda.synchronize()``), the other after a full device sync: identical."""
+    import drvae_amd.tuning as T
+    vals = T._parse()
+    vals['tail_gate'] = 2            # the gated tail also with a resident batch (default: graph-resident feeds only)
+    monkeypatch.setattr(T, '_VALUES', vals)
+    spec = M.ModelSpec(kind='drvae', L=2)
+    params = M.init_params(spec, 3, as_numpy=True)
+    batch = M.make_batch(spec, 150, seed=5)
+    outs = []
+    for synced in (False, True):
+        eng, arena = make_engine(spec, params, dev)
+        eng.seed = 11
+        set_batch(eng, batch, dev)
+        eng.train_step()
+        eng.capture()
+        assert eng._side_graph is not None, 'dual-graph schedule expected on the GPU'
+        with eng.partition(64):
+            got = []
+            for _ in range(6):
+                eng.replay()
+                if synced:
+                    torch.cuda.synchronize()
+                got.append(tuple(eng.losses().values()))
+            eng.replay()
+            if synced:
+                torch.cuda.synchronize()
+            eng.train_step()                       # eager step straight behind a replay
+            if synced:
+                torch.cuda.synchronize()
+            got.append(tuple(eng.losses().values()))
+        torch.cuda.synchronize()
+        outs.append((got, arena.param.clone()))
+        del eng, arena
+    assert outs[0][0] == outs[1][0]
+    assert torch.equal(outs[0][1], outs[1][1])
+
+
 def test_philox_draws_are_keyed_by_global_row(dev):
     """SURVEY 8(e) "RNG under DP": a rank that owns rows [rB, (r+1)B) of the global minibatch draws exactly the
     values a single process draws for those rows -- for every draw of the step (input noise, z1 / z2 / z2Fz1 / z3
