@@ -132,7 +132,7 @@ SIGNATURES = {
     'dv_rows_segment_sum': [_p, _i64, _p, _p, _p, _i32, _i32, _p, _p, _i64, _f, C.POINTER(Wait), _p],
     'dv_weighted_sum': [_p, _p, _p, _i32, _f, _p, _f, _p],
     'dv_recon_row_stats': [_p, _i64, _p, _i64, _i32, _i32, _p, _p],
-    'dv_col_moments': [_p, _i64, _p, _i64, _i32, _i32, _p, _p],
+    'dv_col_moments': [_p, _i64, _p, _i64, _i32, _i32, _p, _i32, _p],
     'dv_loss_assemble': [C.POINTER(LossTerm), _i32, _p, _p, _p, _p, _i32, _p, _p],
     'dv_loss_assemble_after': [_p, _p, _i32, _p, _i32, C.POINTER(LossTerm), _i32, _p, _p, _p, _p, _i32, _i64, _p, _i32,
                                _i64, _p, _i32, _p, _p],
@@ -150,7 +150,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 8     # DV_ABI_VERSION of include/drvae_hip.h
+ABI_VERSION = 9     # DV_ABI_VERSION of include/drvae_hip.h
 
 
 def load():

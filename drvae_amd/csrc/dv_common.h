@@ -30,7 +30,14 @@
 __device__ __forceinline__ float dv_act(int act, float x) {
     switch (act) {
         case DV_ACT_ELU: return x > 0.f ? x : expm1f(x);
-        case DV_ACT_SOFTPLUS: return x > 20.f ? x : log1pf(expf(x));
+        case DV_ACT_SOFTPLUS: {
+            // max(x, 0) + log1p(exp(-|x|)) on the hardware transcendentals (one v_exp, one v_log, one v_rcp instead of the
+            // ~50 instructions of log1pf(expf(x)): the decoder's sigma head runs this on every (row, gene)); log1p by
+            // Kahan's quotient, log(u) * e / (u - 1) with u = 1 + e, which keeps it accurate to a few ulp for tiny e
+            const float e = __expf(-fabsf(x)), u = 1.f + e, d = u - 1.f;
+            const float l = d == 0.f ? e : __logf(u) * __fdividef(e, d);
+            return x > 20.f ? x : fmaxf(x, 0.f) + l;
+        }
         case DV_ACT_SIGMOID: return 1.f / (1.f + expf(-x));
         case DV_ACT_TANH: return tanhf(x);
         case DV_ACT_RELU: return x > 0.f ? x : 0.f;

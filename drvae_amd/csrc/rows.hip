@@ -1437,13 +1437,16 @@ __global__ __launch_bounds__(256) void recon_row_stats_kernel(const float* __res
 // the ingredients of the variance-weighted R^2 (sklearn r2_score, src/DGMMixin.py:137)
 __global__ __launch_bounds__(256) void col_moments_kernel(const float* __restrict__ x, int64_t ldx,
                                                           const float* __restrict__ r, int64_t ldr, int M, int X,
-                                                          double* __restrict__ out) {
+                                                          double* __restrict__ out, int rows_per_block) {
+    // workgroup = (64 columns, one row block): 4 row groups of 64 lanes walk the block's rows, coalesced along the
+    // columns; partial sums of the block go to out[blockIdx.y] (the caller adds the blocks up in a fixed order)
     __shared__ double part[4][3][64];
     const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int g = blockIdx.x * 64 + c;
+    const int i0 = blockIdx.y * rows_per_block, i1 = min(M, i0 + rows_per_block);
     double s1 = 0., s2 = 0., se = 0.;
     if (g < X)
-        for (int i = rg; i < M; i += 4) {
+        for (int i = i0 + rg; i < i1; i += 4) {
             const double a = x[(int64_t)i * ldx + g], b = r[(int64_t)i * ldr + g];
             s1 += a;
             s2 += a * a;
@@ -1455,7 +1458,7 @@ __global__ __launch_bounds__(256) void col_moments_kernel(const float* __restric
     __syncthreads();
     if (rg == 0 && g < X)
         for (int k = 0; k < 3; ++k)
-            out[(int64_t)k * X + g] = (part[0][k][c] + part[1][k][c]) + (part[2][k][c] + part[3][k][c]);
+            out[((int64_t)blockIdx.y * 3 + k) * X + g] = (part[0][k][c] + part[1][k][c]) + (part[2][k][c] + part[3][k][c]);
 }
 
 // ---------------------------------------------------------------------- BatchNorm1d / Dropout (blocks.MLP options)
@@ -2235,10 +2238,12 @@ extern "C" int dv_recon_row_stats(const float* x, int64_t ldx, const float* r, i
 }
 
 extern "C" int dv_col_moments(const float* x, int64_t ldx, const float* r, int64_t ldr, int32_t M, int32_t X,
-                              double* out, dv_stream_t stream) {
-    DV_REQUIRE(M >= 0 && X >= 1);
+                              double* out, int32_t row_blocks, dv_stream_t stream) {
+    DV_REQUIRE(M >= 0 && X >= 1 && row_blocks >= 1 && row_blocks <= 65535);
     DV_REQUIRE(x && r && out);
-    hipLaunchKernelGGL(col_moments_kernel, dim3((X + 63) / 64), dim3(256), 0, ST(stream), x, ldx, r, ldr, M, X, out);
+    const int rpb = (M + row_blocks - 1) / row_blocks;
+    hipLaunchKernelGGL(col_moments_kernel, dim3((X + 63) / 64, row_blocks), dim3(256), 0, ST(stream), x, ldx, r, ldr, M, X, out,
+                       rpb > 0 ? rpb : 1);
     DV_RETURN_LAUNCH();
 }
 

@@ -182,7 +182,15 @@ class FitMixin:
                 perf[k] = np.nan
 
     def evaluate_performance_on_dataset(self, ds, return_full_data=False):
+        """Whole-set evaluation (src/DrVAE.py:797,821 call it on the train and on the validation set every epoch).  For
+        an HBM-resident dataset it is ONE hipGraph replay and ONE device->host copy: eval-mode losses, means-only
+        inference, reconstruction statistics and the prediction metrics captured once per (model, dataset) -- see
+        ``_EvalGraph``.  ``return_full_data`` (arrays for the caller), ``use_s`` models, continuous targets and host
+        datasets take the step-by-step path."""
         g = lambda k: getattr(ds, k, None)
+        ev = None if return_full_data else _EvalGraph.get(self, ds)
+        if ev is not None:
+            return ev.run()
         return self._evaluate(g('x1'), g('x2'), g('s'), g('y'), g('has_x2'), g('has_y'), return_full_data)
 
     # ------------------------------------------------------------- the objective
@@ -374,3 +382,191 @@ class FitMixin:
         self.w2log('Finished training at: {}'.format(time.strftime('%c')))
         self._fit_controller = ctl
         return
+
+
+class _EvalGraph:
+    """The whole-set evaluation of one dataset as a captured launch sequence (round 4).
+
+    What ``_evaluate`` does step by step -- with a host round trip behind nearly every number: index lists from
+    ``torch.nonzero``, numpy combinations of the reconstruction partials, ``float()`` of every metric -- is recorded
+    here ONCE into a hipGraph over the dataset's own HBM-resident tensors:
+      * the evaluation-mode loss scalars of the fused step's forward (Philox draws from the device counter) on a plan of
+        the whole set, its inputs gathered device-to-device from the dataset;
+      * the means-only inference ``forward`` (block level: the same HIP kernels);
+      * ``dv_recon_row_stats`` / ``dv_col_moments`` and their float64 combination, the Gaussian log-likelihood mean;
+      * accuracy / AUROC / AUPR by sort + scan on the device (``metrics.*_dev``: no compaction, no host decisions);
+    every scalar lands in one float64 vector.  ``run()`` = set the annealing coefficient, replay, ONE copy to the host.
+    The group index lists (rows with a second profile / a label) are data of the DATASET, taken once; the arrays
+    themselves are read by the replay, so a dataset edited in place is evaluated as edited."""
+
+    @staticmethod
+    def get(model, ds):
+        x1 = getattr(ds, 'x1', None)
+        if not (torch.is_tensor(x1) and x1.is_cuda) or getattr(model, 'use_s', False) \
+                or getattr(model, 'type_y', 'discrete') != 'discrete' or getattr(model, 'type_rec', 'diag_gaussian') != 'diag_gaussian':
+            return None
+        if next(model.parameters()).device != x1.device:
+            return None
+        cache = model.__dict__.setdefault('_eval_graphs', {})
+        sig = tuple(int(t.data_ptr()) if torch.is_tensor(t) else 0
+                    for t in (getattr(ds, k, None) for k in ('x1', 'x2', 'y', 'has_x2', 'has_y'))) + (int(x1.shape[0]),)
+        ev = cache.get(id(ds))
+        if ev is None or ev.sig != sig:
+            ev = cache[id(ds)] = _EvalGraph(model, ds, sig)
+        return ev
+
+    def __init__(self, model, ds, sig):
+        self.model, self.ds, self.sig = model, ds, sig
+        self.graph = None
+        kind = model.kind
+        dev = ds.x1.device
+        g = lambda k: getattr(ds, k, None)
+        # rows of the groups (once per dataset: a host sync each)
+        self.x2idx = torch.nonzero(g('has_x2').reshape(-1).to(dev)).reshape(-1) if kind != 'vfae' else None
+        self.yidx = torch.nonzero(g('has_y').reshape(-1).to(dev)).reshape(-1) if kind != 'pvae' else None
+        # the loss plan of the whole set: built by the ordinary path (host index lists), then reused
+        eng = model.engine()
+        keep = eng.plan
+        model.eval()
+        kw = dict(x1=g('x1'), s=g('s'))
+        if kind != 'vfae':
+            kw.update(x2=g('x2'), has_x2=g('has_x2'))
+        if kind != 'pvae':
+            kw.update(y=g('y'), has_y=g('has_y'))
+        self.kw = kw
+        model.run_on_batch(train_mode=False, **kw)          # (also the warm-up of every kernel of the sequence)
+        self.plan = eng.plan
+        n_in = int(ds.x1.shape[0])
+        rows = np.asarray(self.plan.rows)
+        self.sel = None if (len(rows) == n_in and (rows == np.arange(n_in)).all()) else torch.as_tensor(rows, device=dev)
+        self._sequence()                                    # warm-up of the rest (allocations, code objects)
+        torch.cuda.synchronize()
+        gph = torch.cuda.CUDAGraph()
+        eng.join_side()
+        try:
+            with torch.cuda.graph(gph):
+                self.names, self.vec, self.loss_keys = self._sequence()
+            self.graph = gph
+        finally:
+            eng.plan = keep
+
+    def _sequence(self):
+        """the launch sequence (eager for the warm-up, then under capture); -> (names, float64 vector, loss keys)"""
+        m, ds, kind = self.model, self.ds, self.model.kind
+        eng, p = m.engine(), self.plan
+        eng.plan = p
+        # --- evaluation-mode losses on the whole set: the fused forward on this plan, inputs from the dataset
+        p.feed_active = False
+        x1 = ds.x1.to(torch.float32)
+        p.XSRC[:p.B].copy_(x1.index_select(0, self.sel) if self.sel is not None else x1)
+        if eng.cfg.has_pert:
+            x2 = ds.x2.to(torch.float32)
+            p.XSRC[p.B:].copy_(x2.index_select(0, self.sel) if self.sel is not None else x2)
+        eng.training = False
+        eng.draw_noise()
+        eng.forward()
+        losses = m._loss_tensors(eng)
+        vals = OrderedDict(('loss_' + k, v.double()) for k, v in losses.items())
+        # --- means-only inference + metrics
+        res = self._infer()
+        if kind != 'pvae':
+            y = ds.y.to(ds.x1.device)
+            ylab = y.reshape(-1).index_select(0, self.yidx)
+            for k, v in MET.eval_y_prediction_dev(res['pred'].index_select(0, self.yidx), res['proba'].index_select(0, self.yidx),
+                                                  ylab, m.dim_y).items():
+                vals['y_' + k] = v
+        for k, v in self._recon(ds.x1, *res['px1']).items():
+            vals['x1_' + k] = v
+        if kind != 'vfae' and len(self.x2idx) > 0:
+            x2p = ds.x2.index_select(0, self.x2idx)
+            for k, v in self._recon(x2p, res['px2'][0].index_select(0, self.x2idx), res['px2'][1].index_select(0, self.x2idx)).items():
+                vals['x2_' + k] = v
+        names = list(vals)
+        return names, torch.stack([v.reshape(()) for v in vals.values()]), list(losses)
+
+    def _infer(self):
+        """``forward`` (means-only inference, src/DrVAE.py:253-311) with its two heavy blocks on the fused step's layer
+        chains: the encoder's heads as ONE (mu | logvar) product, and the decoder ONCE over the stacked rows [z1; z2]
+        with its (mu | std) heads as one product -- 3 launches of 2n rows instead of 6 of n (the block modules compute
+        every head with a launch of its own).  The small blocks in between are the model's own modules."""
+        from .chain import _Chain
+        m, ds, kind = self.model, self.ds, self.model.kind
+        eng = m.engine()
+        n, Z, X = int(ds.x1.shape[0]), eng.cfg.dim_z1, eng.cfg.dim_x
+        dev = ds.x1.device
+        if not hasattr(self, 'c_enc'):
+            self.c_enc = _Chain(eng.L_enc, n, dev)
+            self.c_dec = _Chain(eng.L_decx, n * (2 if kind != 'vfae' else 1), dev)
+            self.zd = torch.zeros(n * (2 if kind != 'vfae' else 1), (Z + 3) // 4 * 4, device=dev)[:, :Z]
+        x1 = ds.x1.to(torch.float32)
+        Q = self.c_enc.forward([x1])
+        z1 = Q[:, :Z]
+        res = OrderedDict(z1=z1, qz1=(z1, Q[:, Z:2 * Z]))
+        if kind != 'vfae':
+            pz2 = m.decoder_z2Fz1([z1])
+            z2 = pz2[0]
+            res.update(z2=z2, pz2=pz2)
+        if kind != 'pvae':
+            if kind == 'drvae':
+                clf_in = [z1, z2 - z1] if m.clf_z1z2 else [z2]
+            else:
+                clf_in = [z1]
+            res.update(**m._pred_proba(m.encoder_y(clf_in)))
+        self.zd[:n].copy_(z1)
+        if kind != 'vfae':
+            self.zd[n:].copy_(z2)
+        PX = self.c_dec.forward([self.zd])
+        res['px1'] = (PX[:n, :X], PX[:n, X:2 * X])
+        if kind != 'vfae':
+            res['px2'] = (PX[n:, :X], PX[n:, X:2 * X])
+        return res
+
+    def _recon(self, x, x_rec, x_std):
+        """``eval_x_reconstruction`` (src/DGMMixin.py:128-156) with its float64 combination on the device"""
+        from . import kernels as K
+        m = self.model
+        x = x.to(torch.float32)
+        M, X = x.shape
+        rows = torch.empty(M, 6, device=x.device)
+        cols = torch.empty(3, X, dtype=torch.float64, device=x.device)
+        K.recon_row_stats(rows, x, x_rec)
+        K.col_moments(cols, x, x_rec)
+        r = rows.double()
+        out = OrderedDict()
+        out['rmse'] = torch.sqrt(r[:, 0].sum() / (M * X))
+        ss_tot = cols[1] - cols[0] ** 2 / M
+        out['r2'] = 1.0 - cols[2].sum() / ss_tot.sum()
+        out['pearr'] = (r[:, 5] / torch.sqrt(r[:, 3] * r[:, 4])).mean()
+        out['ll'] = m.decoder_x.logp_perx(x, x_rec, x_std).double().mean()
+        return out
+
+    def run(self):
+        m, kind = self.model, self.model.kind
+        eng = m.engine()
+        eng.join_side()
+        eng.iters = m.finished_training_iters
+        self.plan.set_beta(eng.beta_pert())                 # (the annealing coefficient is data of the plan, not of the graph)
+        self.graph.replay()
+        eng._noise_stale = True      # (the replay drew from the Philox counter: a train step drawn ahead re-draws, as after any eager draw)
+        v = dict(zip(self.names, self.vec.cpu().tolist()))  # THE host sync of the evaluation
+        perf = OrderedDict()
+        perf['losses'] = OrderedDict((k, torch.tensor(v['loss_' + k])) for k in self.loss_keys)
+        parts = []
+        if kind != 'pvae':
+            for k in ('acc', 'auroc', 'aupr'):
+                perf['y_' + k] = v['y_' + k]
+            parts.append('Y: Accuracy: {:.3f}% AUROC: {:.3f} AUPR: {:.3f}'.format(perf['y_acc'] * 100., perf['y_auroc'], perf['y_aupr']))
+        for k in _NAN4:
+            perf['x1_' + k] = v['x1_' + k]
+        parts.append('X1: ' + _REC.format(perf['x1_rmse'], perf['x1_r2'], perf['x1_pearr']))
+        if kind != 'vfae':
+            if 'x2_rmse' in v:
+                for k in _NAN4:
+                    perf['x2_' + k] = v['x2_' + k]
+                parts.append('X2: ' + _REC.format(perf['x2_rmse'], perf['x2_r2'], perf['x2_pearr']))
+            else:
+                for k in _NAN4:
+                    perf['x2_' + k] = np.nan
+                parts.append('X2: no x2 data')
+        perf['model_class'] = m.__class__.__name__
+        return perf, '\t '.join(parts)

@@ -597,8 +597,12 @@ def col_moments(out, x, r):
     """out (3,X) float64: per-column sum x, sum x^2, sum (x-r)^2."""
     M, X = x.shape
     assert out.dtype == torch.float64 and out.is_cuda and out.is_contiguous() and tuple(out.shape) == (3, X)
-    _lib.check(_lib.load().dv_col_moments(_f32(x), _ld(x), _f32(r), _ld(r), M, X, out.data_ptr(), _stream()),
+    nb = max(1, min(64, (M + 63) // 64))          # row blocks: partial sums per block, added up here in a fixed order
+    part = out.unsqueeze(0) if nb == 1 else torch.empty(nb, 3, X, dtype=torch.float64, device=out.device)
+    _lib.check(_lib.load().dv_col_moments(_f32(x), _ld(x), _f32(r), _ld(r), M, X, part.data_ptr(), nb, _stream()),
                'dv_col_moments')
+    if nb > 1:
+        torch.sum(part, 0, out=out)
 
 
 def loss_assemble(loss, terms, w_elbo, w_cmpl, after=None, bump=(), halt=None, accum=None):

@@ -83,3 +83,66 @@ def eval_y_prediction(pred, proba, ylab, dim_y):
         out['auroc'] = macro(roc_auc, ylab, proba)
         out['aupr'] = macro(average_precision, ylab, proba)
     return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The same metrics as 0-d float64 DEVICE tensors, fixed shapes and no host synchronisation anywhere (no ``int(...)``, no
+# boolean-mask compaction): what the whole-set evaluation of ``fit`` captures into ONE hipGraph per dataset and reads
+# back with a single copy (drvae_amd/fit.py).  Same float64 arithmetic per tie group as above; the degenerate cases
+# (one class only, empty) come out as nan / 0 through ``torch.where`` instead of early returns.
+
+def _tie_groups(score, positive):
+    """sorted-by-descending-score views: (last-of-its-tie-group mask, cumulative positives, cumulative count, and the
+    two cumulative values at the END OF THE PREVIOUS tie group -- 0 for the first)"""
+    s, order = torch.sort(score.reshape(-1).double(), descending=True)
+    pos = positive.reshape(-1)[order].double()
+    last = torch.ones_like(s, dtype=torch.bool)
+    last[:-1] = s[1:] != s[:-1]
+    ctp = torch.cumsum(pos, 0)
+    cnt = torch.arange(1, s.numel() + 1, device=s.device, dtype=torch.float64)
+    zero = torch.zeros((), dtype=torch.float64, device=s.device)
+
+    def prev_end(c):       # c is non-decreasing: the running max of its group-end values IS the latest group end's
+        run = torch.cummax(torch.where(last, c, zero), 0).values
+        return torch.cat([zero.reshape(1), run[:-1]])
+    return last, ctp, cnt, prev_end(ctp), prev_end(cnt - ctp)
+
+
+def roc_auc_dev(y_true, score):
+    positive = y_true.reshape(-1) > 0
+    n = positive.numel()
+    nan = torch.full((), float('nan'), dtype=torch.float64, device=score.device)
+    if n == 0:
+        return nan
+    n_pos = positive.sum().double()
+    last, ctp, cnt, ptp, pfp = _tie_groups(score, positive)
+    cfp = cnt - ctp
+    area = torch.where(last, (cfp - pfp) * (ctp + ptp), torch.zeros_like(ctp)).sum() * 0.5
+    return torch.where((n_pos == 0) | (n_pos == n), nan, area / (n_pos * (n - n_pos)))
+
+
+def average_precision_dev(y_true, score):
+    positive = y_true.reshape(-1) > 0
+    zero = torch.zeros((), dtype=torch.float64, device=score.device)
+    if positive.numel() == 0:
+        return zero
+    n_pos = positive.sum().double()
+    last, ctp, cnt, ptp, _ = _tie_groups(score, positive)
+    ap = torch.where(last, (ctp - ptp) * (ctp / cnt), torch.zeros_like(ctp)).sum() / torch.clamp(n_pos, min=1.0)
+    return torch.where(n_pos == 0, zero, ap)
+
+
+def eval_y_prediction_dev(pred, proba, ylab, dim_y):
+    """``eval_y_prediction`` as a dict of 0-d float64 device tensors"""
+    ylab = ylab.reshape(-1)
+    dev = proba.device
+    nan = torch.full((), float('nan'), dtype=torch.float64, device=dev)
+    out = dict()
+    out['acc'] = ((pred.reshape(-1).int() == ylab.int()).float().sum() / max(ylab.numel(), 1)).double() if ylab.numel() else nan
+    if dim_y == 2:
+        out['auroc'] = roc_auc_dev(ylab, proba[:, 1])
+        out['aupr'] = average_precision_dev(ylab, proba[:, 1])
+    else:       # macro average: nan as soon as one class's value is (the mean propagates it)
+        out['auroc'] = torch.stack([roc_auc_dev(ylab == j, proba[:, j]) for j in range(proba.shape[1])]).mean()
+        out['aupr'] = torch.stack([average_precision_dev(ylab == j, proba[:, j]) for j in range(proba.shape[1])]).mean()
+    return out

@@ -306,3 +306,41 @@ def test_fit_tuple_loader_runs_one_captured_graph(kind, tmp_path, dev):
         out.append({k: v.detach().cpu().clone() for k, v in model.state_dict().items()})
     for k in out[0]:
         assert torch.equal(out[0][k], out[1][k]), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('kind', ['drvae', 'pvae', 'vfae'])
+def test_captured_evaluation_equals_step_by_step(kind, dev):
+    """round 4 (N1 off the host): ``evaluate_performance_on_dataset`` of an HBM-resident dataset is one graph replay +
+    one copy; every number equals the step-by-step path's (same kernels; the loss scalars draw fresh Philox noise in both,
+    so they are compared on a model whose losses do not depend on the draw: means-only terms exactly, the rest loosely),
+    it follows the parameters (a train step between two evaluations changes the result), and it is re-captured when the
+    dataset's tensors are replaced."""
+    from drvae_amd import fit as F
+    model = _tiny_model(kind, device='cuda', epochs=2)
+    va = _tiny_dataset(kind, 48, 2, 'cuda')
+    g = lambda k: getattr(va, k, None)
+    ref, txt_ref = model._evaluate(g('x1'), g('x2'), g('s'), g('y'), g('has_x2'), g('has_y'))
+    got, txt = model.evaluate_performance_on_dataset(va)
+    ev = F._EvalGraph.get(model, va)
+    assert ev is not None and ev.graph is not None, 'the captured path was not taken'
+    assert txt == txt_ref
+    for k, v in ref.items():
+        if k in ('losses', 'model_class'):
+            continue
+        assert (np.isnan(v) and np.isnan(got[k])) or abs(got[k] - v) <= 1e-6 * max(1.0, abs(v)), (k, got[k], v)
+    for k, v in ref['losses'].items():           # sampled terms: same distribution, another draw
+        assert abs(float(got['losses'][k]) - float(v)) <= 0.2 * max(1.0, abs(float(v))), (k, float(got['losses'][k]), float(v))
+    again, _ = model.evaluate_performance_on_dataset(va)
+    assert again['x1_rmse'] == got['x1_rmse'] and F._EvalGraph.get(model, va) is ev
+    # parameters move -> the replay sees them
+    kw = dict(zip(va.FIELDS if hasattr(va, 'FIELDS') else ('x1', 's', 'y', 'has_y'),
+                  (getattr(va, f) for f in (va.FIELDS if hasattr(va, 'FIELDS') else ('x1', 's', 'y', 'has_y')))))
+    for _ in range(5):
+        model.run_on_batch(train_mode=True, **model._batch_kwargs(tuple(kw.values())))
+    moved, _ = model.evaluate_performance_on_dataset(va)
+    ref2, _ = model._evaluate(g('x1'), g('x2'), g('s'), g('y'), g('has_x2'), g('has_y'))
+    assert moved['x1_rmse'] != got['x1_rmse'] and abs(moved['x1_rmse'] - ref2['x1_rmse']) <= 1e-6 * max(1.0, ref2['x1_rmse'])
+    # a dataset whose tensors were replaced is captured again
+    va.x1 = va.x1.clone()
+    assert F._EvalGraph.get(model, va) is not ev
