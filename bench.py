@@ -318,6 +318,49 @@ def gemm_roofline(eng, cfg, rows, frac_pair, frac_lab, repeats=20, workload='cfg
     return out
 
 
+def fit_epoch(device, n_train=8192, n_valid=2048, batch=150, epochs=3):
+    """One steady-state epoch of the reference's ``fit`` protocol at cfg-2 size (SURVEY.md 8(f) N1 + N3): ``n_train // batch``
+    train steps drawn by the graph-resident feed from an HBM-resident training set, then the whole-set evaluation of the
+    training and of the validation set (src/DrVAE.py:797,821) -- each ONE captured graph replay and one device->host copy.
+    The evaluation's roofline: its forward FLOPs (eval-mode loss pass with L samples + means-only inference,
+    src/DrVAE.py:367-543 and 253-311, per row as in ``tools/eval_bench.eval_gflop``) over its wall time."""
+    from drvae_amd.DrVAE import DrVAE
+    from drvae_amd import data as DD
+    from tools.eval_bench import dataset, eval_gflop
+    model = DrVAE(dim_x=978, dim_s=1, dim_y=2, dim_h_en_z1=[800], dim_h_de_z1=[200], dim_h_en_z3=[200], dim_h_de_x=[600],
+                  dim_h_clf=[], dim_z1=100, dim_z3=100, type_rec='diag_gaussian', nonlinearity='elu', learning_rate=5e-4, L=2,
+                  weight_decay=0.05, add_noise_var=0.01, pertloss_rate=0.05, use_MMD=False, random_seed=123, epochs=1,
+                  batch_size=batch).to(device)
+    model.w2log = lambda *a: None
+    model.add_noise = True
+    tr, va = dataset(n_train, 1, device), dataset(n_valid, 2, device)
+    bat = DD.DeviceBatcher(tr, torch.ones(n_train), batch, seed=1)
+    t = [0.0, 0.0, 0.0]
+    for ep in range(epochs):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        model._epoch_device(bat, ep, False)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        ptr, _ = model.evaluate_performance_on_dataset(tr)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        pva, _ = model.evaluate_performance_on_dataset(va)
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        t = [t1 - t0, t2 - t1, t3 - t2]          # (the last epoch's: the first pays for captures and the CU-split tuning)
+    gf = eval_gflop(tr) + eval_gflop(va)
+    ev_ms = 1e3 * (t[1] + t[2])
+    return {'train_ms': round(1e3 * t[0], 3), 'steps': len(bat), 'ms_per_step': round(1e3 * t[0] / len(bat), 4),
+            'eval_train_ms': round(1e3 * t[1], 3), 'eval_valid_ms': round(1e3 * t[2], 3),
+            'epoch_ms': round(1e3 * sum(t), 3), 'rows': [n_train, n_valid],
+            'finite': bool(np.isfinite(ptr['x1_rmse']) and np.isfinite(pva['x1_rmse'])),
+            'eval_roofline': {'bound': 'mfma', 'achieved': round(gf / ev_ms, 2), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                              'frac': round(gf / ev_ms / FP32_MFMA_PEAK_TFLOPS, 4), 'gflop': round(gf, 1),
+                              'what': 'forward FLOPs of both whole-set evaluations (loss pass with L = 2 samples + means-only '
+                                      'inference) / their wall time incl. the metrics and the one host copy each'}}
+
+
 class _Watchdog:
     """multi-rank runs: a daemon thread that ends THIS rank (exit code 5) when the measurement makes no progress for
     ``timeout`` seconds -- a peer that died inside a collective, a hung exchange -- so that the launcher (torchrun, or
@@ -688,6 +731,15 @@ def main():
             print('bench.py: realistic_feed leg failed: %r' % (e,), file=sys.stderr)
             out['realistic_feed'] = {'feed': 'sampler', 'error': repr(e)}
             out.setdefault('extras_failed', []).append('realistic_feed')
+        gc.collect()
+        torch.cuda.empty_cache()
+        try:
+            out['fit_epoch'] = fit_epoch(device)
+            ok = ok and out['fit_epoch']['finite']
+        except Exception as e:       # noqa: BLE001
+            print('bench.py: fit_epoch leg failed: %r' % (e,), file=sys.stderr)
+            out['fit_epoch'] = {'error': repr(e)}
+            out.setdefault('extras_failed', []).append('fit_epoch')
         out['other_workloads'] = {}
         for wl, (k_, w_) in (('wide', (10, 3)), ('cfg1', (200, 20)), ('cfg4', (200, 20))):
             gc.collect()

@@ -11,6 +11,7 @@ from drvae_amd import data as D, synth
 
 
 def dataset(n, seed, dev='cuda'):
+    dev = str(dev)
     b = synth.make_batch('drvae', n, 978, 2, seed=seed)
     t = lambda k: torch.from_numpy(b[k]).to(dev)
     return D.DrVAEDataset(t('x1'), t('x2'), torch.zeros(n, dtype=torch.int64, device=dev), t('y'), t('has_x2'), t('has_y'))
