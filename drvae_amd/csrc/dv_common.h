@@ -29,7 +29,14 @@
 // (reference table: src/blocks.py:21-24)
 __device__ __forceinline__ float dv_act(int act, float x) {
     switch (act) {
-        case DV_ACT_ELU: return x > 0.f ? x : expm1f(x);
+        case DV_ACT_ELU: {
+            // expm1 by Kahan's quotient on the hardware transcendentals: (u - 1) * x / log(u), u = exp(x) -- a few ulp
+            // everywhere (u == 1: x itself; u == 0: -1), a handful of instructions instead of expm1f's long polynomial path
+            // (the hidden layers' epilogues run it on every element; with few waves per SIMD its latency was the epilogue)
+            if (x > 0.f) return x;
+            const float u = __expf(x), d = u - 1.f;
+            return d == 0.f ? x : (d == -1.f ? -1.f : d * __fdividef(x, __logf(u)));
+        }
         case DV_ACT_SOFTPLUS: {
             // max(x, 0) + log1p(exp(-|x|)) on the hardware transcendentals (one v_exp, one v_log, one v_rcp instead of the
             // ~50 instructions of log1pf(expf(x)): the decoder's sigma head runs this on every (row, gene)); log1p by
