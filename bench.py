@@ -648,7 +648,7 @@ def main():
                          "same, but the captured step gathers its batch itself from the epoch's index table; sampler: "
                          'as epoch, with the exact WeightedRandomSampler semantics (any group mix per batch: universal plan)')
     ap.add_argument('--dataset-rows', type=int, default=16384)
-    ap.add_argument('--gemm-opts', default='', help='tuning: comma list key=value for dv_gemm_set_option')
+    ap.add_argument('--gemm-opts', default='', help='tuning: comma list key=value of dv_gemm_tune.opt')
     ap.add_argument('--dp-exchange', default='single', choices=['single', 'overlap', 'captured'],
                     help='data-parallel gradient exchange: one all-reduce between two graphs (default), two overlapped '
                          'pieces between three graphs, or the collective captured into the step graph')
@@ -668,9 +668,10 @@ def main():
 
     from drvae_amd import _lib, dist as D
     _lib.load()                                       # fail loudly if the HIP library is missing
-    for kv in filter(None, args.gemm_opts.split(',')):     # tuning: dv_gemm_set_option keys (include/drvae_hip.h)
+    for kv in filter(None, args.gemm_opts.split(',')):     # tuning: dv_gemm_tune.opt keys (include/drvae_hip.h)
+        import drvae_amd.kernels as K_
         k, v = kv.split('=')
-        _lib.load().dv_gemm_set_option(int(k), int(v))
+        K_.gemm_set_option(int(k), int(v))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (no CPU fallback for the hot path)')
     rank, world, local = D.init_from_env()

@@ -26,7 +26,11 @@ class GemmDesc(C.Structure):
                 ('epilogue', _i32), ('scale', _p), ('bias', _p), ('split', _i32), ('act0', _i32), ('act1', _i32),
                 ('shift0', _f), ('shift1', _f), ('resid', _p), ('ldr', _i64), ('resid_cols', _i32),
                 ('yref', _p), ('ldy', _i64), ('a_colsum', _p), ('colsum_beta', _f), ('flags', _i32),
-                ('pub_flag', _p), ('pub_ctr', _p), ('pub_add', _i32)]
+                ('pub_flag', _p), ('pub_ctr', _p), ('pub_add', _i32), ('tune', _p)]
+
+
+class GemmTune(C.Structure):   # dv_gemm_tune: per-call steering of the GEMM dispatcher (tests / tuning)
+    _fields_ = [('tiling', _i32), ('opt', _i32 * 10)]
 
 
 class Wait(C.Structure):       # dv_wait: a device-side wait carried by a launch
@@ -85,8 +89,7 @@ SIGNATURES = {
     'dv_bn_fwd': [_p, _i64, _i32, _i32, _p, _p, _f, _p, _p, _p, _i64, _p, _p, _f, _i32, _p],
     'dv_bn_bwd': [_p, _i64, _p, _i64, _p, _p, _p, _i32, _i32, _p, _i64, _p, _p, _i32, _p],
     'dv_mask_scale': [_p, _i64, _p, _i64, _f, _i32, _i32, _p, _i64, _p],
-    'dv_gemm_force_tiling': [_i32],
-    'dv_gemm_set_option': [_i32, _i32],
+    'dv_gemm_has_tiling': [_i32],
     'dv_colsum': [_p, _i64, _i32, _i32, _p, _f, _p],
     'dv_act_bwd': [_p, _i64, _p, _i64, _i32, _i32, _i32, _i32, _i32, _f, _f, _p],
     'dv_wn_scale': [_p, _i64, _p, _i32, _i32, _p, _p, _p],

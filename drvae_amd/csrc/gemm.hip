@@ -914,8 +914,11 @@ inline int vec_width(const void* p, int64_t ld) {
 // tuning (dv_gemm_set_option(1, bytes)): extra dynamic LDS per workgroup of the 32x32-tile launches whose grids
 // fill the chip -- caps how many of them a CU holds, which leaves wave slots / registers on EVERY CU for the other
 // launch chain's small kernels (an alternative to the CU partition of the two chains)
-static int g_lds_pad = 0;
-inline int lds_pad(int bm, int tiles) { return (bm <= 32 && tiles >= 512) ? g_lds_pad : 0; }
+// the caller's tuning block (dv_gemm_desc.tune; NULL = the defaults): read at launch time, per call -- the library keeps
+// no tuning state of its own
+const dv_gemm_tune k_default_tune = {0, {-1, 0, 0, 0, 0, 0, 0, 0, 0, 0}};
+inline const dv_gemm_tune& tune_of(const dv_gemm_desc& g) { return g.tune != nullptr ? *g.tune : k_default_tune; }
+inline int lds_pad(const dv_gemm_desc& g, int bm, int tiles) { return (bm <= 32 && tiles >= 512) ? tune_of(g).opt[1] : 0; }
 
 // output columns incl. the ones column of the fused bias gradient (see gemm_body)
 inline int cols_eff(const dv_gemm_desc& g) { return g.N + ((g.flags & DV_FLAG_ONES_COL) ? DV_ONES_OFF(g) + 1 : 0); }
@@ -925,11 +928,11 @@ int launch_cfg(const dv_gemm_desc& g, const LoadCfg& lc, hipStream_t st) {
     const int tiles = ((g.M + BM - 1) / BM) * ((cols_eff(g) + BN - 1) / BN);
     dim3 grid(tiles), block(64 * WM * WN * KS);
     if (g.a_kcontig && g.b_kcontig)
-        hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, WM, WN, KS, true, true, MI16>), grid, block, lds_pad(BM, tiles), st, g, lc);
+        hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, WM, WN, KS, true, true, MI16>), grid, block, lds_pad(g, BM, tiles), st, g, lc);
     else if (g.a_kcontig && !g.b_kcontig)
-        hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, WM, WN, KS, true, false, MI16>), grid, block, lds_pad(BM, tiles), st, g, lc);
+        hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, WM, WN, KS, true, false, MI16>), grid, block, lds_pad(g, BM, tiles), st, g, lc);
     else if (!g.a_kcontig && !g.b_kcontig)
-        hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, WM, WN, KS, false, false, MI16>), grid, block, lds_pad(BM, tiles), st, g, lc);
+        hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, WM, WN, KS, false, false, MI16>), grid, block, lds_pad(g, BM, tiles), st, g, lc);
     else
         return DV_ERR_UNSUPPORTED;
     DV_RETURN_LAUNCH();
@@ -959,30 +962,21 @@ int launch_kpipe(const dv_gemm_desc& g_in, const LoadCfg& lc, hipStream_t st) {
 
 }  // namespace
 
-static int g_force_tiling = 0;   // 0 = heuristic; 1 = T64, 2 = T32K, 3 = T128 (tests / tuning)
-static int g_opt[10] = {-1, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // [0] = tile map (0 linear, 1 XCD chunk-major, >= 2 row bands, -1 by tiling)
-
-extern "C" int dv_gemm_set_option(int key, int value) {
-    if (key < 0 || key >= 10) return DV_ERR_ARG;
-    g_opt[key] = value;
-    if (key == 1) g_lds_pad = value;
-#if DV_STAMP
-    if (key == 6) {
-        unsigned long long* p = reinterpret_cast<unsigned long long*>(((unsigned long long)(unsigned)g_opt[6] << 32) |
-                                                                      (unsigned)g_opt[5]);
-        (void)hipMemcpyToSymbol(HIP_SYMBOL(dv_stamp_buf), &p, sizeof(p));
-    }
-#endif
-    return DV_OK;
-}
-
-extern "C" int dv_gemm_force_tiling(int t) {
+// which tilings this build of the library carries (tests / tuning: dv_gemm_tune.tiling); the lab tilings exist in the
+// tuning build only (-DDV_LAB)
+extern "C" int dv_gemm_has_tiling(int t) {
 #ifndef DV_LAB
-    if ((t < 0 || t > 3) && t != 17 && t != 40 && t != 46) return DV_ERR_UNSUPPORTED;      // the lab tilings exist in the tuning build only (-DDV_LAB)
+    return ((t >= 0 && t <= 3) || t == 17 || t == 40 || t == 46) ? 1 : 0;
+#else
+    return t >= 0 ? 1 : 0;
 #endif
-    g_force_tiling = t;
-    return DV_OK;
 }
+
+#if DV_STAMP
+extern "C" int dv_gemm_stamp_buffer(unsigned long long* p) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(dv_stamp_buf), &p, sizeof(p)) == hipSuccess ? DV_OK : DV_ERR_LAUNCH;
+}
+#endif
 
 static int gemm_prepare(const dv_gemm_desc* d, LoadCfg& lc, int& tiling) {
     DV_REQUIRE(d != nullptr);
@@ -1013,31 +1007,33 @@ static int gemm_prepare(const dv_gemm_desc* d, LoadCfg& lc, int& tiling) {
     while (g.K % lc.vecB_t) lc.vecB_t >>= 1;
     const int64_t t64 = (int64_t)((g.M + 63) / 64) * ((g.N + 63) / 64);
     const int64_t t128 = (int64_t)((g.M + 127) / 128) * ((g.N + 127) / 128);
-    tiling = g_force_tiling;
+    const dv_gemm_tune& T = tune_of(g);
+    if (!dv_gemm_has_tiling(T.tiling)) return DV_ERR_UNSUPPORTED;
+    tiling = T.tiling;
     // measured on MI355X (tools/gemm_bench.py): below ~4 workgroups per CU the 32x32 K-split
     // tiling wins (more resident workgroups hide the per-K-tile latency chain); the larger
     // tiles only pay once their grids alone fill the chip several times over
-    const int64_t t64_min = g_opt[3] > 0 ? g_opt[3] : 1024;
+    const int64_t t64_min = T.opt[3] > 0 ? T.opt[3] : 1024;
     // ... or once K is long enough to amortise a tile's prologue over many K steps: 1536 x 2048 x 20000 (encoder L1 of
     // the wide configuration, 768 tiles of 64x64) runs 956 us on the 64x64 tiling, 1090 us on 32x32, 1336 us on 128x128
     if (tiling == 0) tiling = (t128 >= 1024) ? 3 : ((t64 >= t64_min || (t64 >= 512 && g.K >= 8192)) ? 1 : 2);
     // the chip-filling products run on the hand-pipelined LDS-DMA tiling (gemm_pipe.inc) when their operands allow it
     // (16-B aligned rows, K % 4 == 0 ...): 8192 x 8192 x 2048 134 -> 144-149 TFLOP/s (dv_gemm_set_option(3, -1): off)
-    if (tiling == 3 && g_force_tiling == 0 && g_opt[3] != -1 && pipe_ok(g, lc)) tiling = 40;
+    if (tiling == 3 && T.tiling == 0 && T.opt[3] != -1 && pipe_ok(g, lc)) tiling = 40;
     // (64x64 tiles, three workgroups per CU: one resident round up to 768 tiles; measured 1536 x 2048 x 20000: 983 -> 962 us,
     // but 2048 x 2048 x 4096 = 1024 tiles: 271 -> 323 us)
-    if (tiling == 1 && g_force_tiling == 0 && g_opt[3] != -1 && g.K >= 1024 && t64 <= 768 && pipe_ok(g, lc)) tiling = 46;
+    if (tiling == 1 && T.tiling == 0 && T.opt[3] != -1 && g.K >= 1024 && t64 <= 768 && pipe_ok(g, lc)) tiling = 46;
     // workgroup -> tile map: XCD chunk-major for the small grids (each XCD keeps a compact band of the
     // output, its panels stay in its L2); for the grids that fill the chip many times over, bands of 16 tile
     // rows swept column by column (measured, wide configuration: chunk-major 121.5, linear 127.0, bands of 16
     // 128.3 TF/s over the step's products; no difference at the cfg-2 sizes)
-    lc.map = g_opt[0] >= 0 ? g_opt[0] : (tiling == 3 ? 16 : (tiling == 40 ? 32 : 1));
+    lc.map = T.opt[0] >= 0 ? T.opt[0] : (tiling == 3 ? 16 : (tiling == 40 ? 32 : 1));
     return DV_OK;
 }
 
 // tiles of 32x32 from which a product runs on the high-occupancy tiling (dv_gemm_set_option(8, n); 0 = default)
-static int dense_min_tiles() { return g_opt[8] > 0 ? g_opt[8] : 512; }
-static bool pipe_on() { return g_opt[3] != -1; }
+static int dense_min_tiles(const dv_gemm_desc& g) { return tune_of(g).opt[8] > 0 ? tune_of(g).opt[8] : 512; }
+static bool pipe_on(const dv_gemm_desc& g) { return tune_of(g).opt[3] != -1; }
 
 // fused bias gradient of a dy^T x product: the ones column (DV_FLAG_ONES_COL) -- free where the last column tile has
 // padding, one extra tile per row panel where N is a multiple of the tile width.  Not in the 128x128 tiling (its
@@ -1131,9 +1127,9 @@ static int gemm_launch(const dv_gemm_desc& g_in, const LoadCfg& lc, int tiling, 
     // dy^T x 23.6 -> 21.0 us alone (tools/gemm_bench.py --tilings 2,9,17)
     const int tiles32 = ((g.M + 31) / 32) * ((cols_eff(g) + 31) / 32);
     // each of the three on the hand-pipelined LDS-DMA loop where the operands allow it (pipe_ok; dv_gemm_set_option(3, -1): never)
-    const bool pipe = pipe_on() && pipe_ok(g, lc);
-    if (tiles32 >= dense_min_tiles()) return pipe ? launch_kpipe<32, 32, 32, 4, 2, DV_DENSE_WG>(g, lc, st) : launch_cfg<32, 32, 32, 1, 1, 4>(g, lc, st);
-    if (g.a_kcontig && g_opt[7] == 0) return pipe ? launch_kpipe<32, 32, 64, 8, 2, 2>(g, lc, st) : launch_cfg<32, 32, 64, 1, 1, 8>(g, lc, st);
+    const bool pipe = pipe_on(g) && pipe_ok(g, lc);
+    if (tiles32 >= dense_min_tiles(g)) return pipe ? launch_kpipe<32, 32, 32, 4, 2, DV_DENSE_WG>(g, lc, st) : launch_cfg<32, 32, 32, 1, 1, 4>(g, lc, st);
+    if (g.a_kcontig && tune_of(g).opt[7] == 0) return pipe ? launch_kpipe<32, 32, 64, 8, 2, 2>(g, lc, st) : launch_cfg<32, 32, 64, 1, 1, 8>(g, lc, st);
     return pipe ? launch_kpipe<32, 32, 64, 4, 2, 4>(g, lc, st) : launch_cfg<32, 32, 64, 1, 1, 4>(g, lc, st);
 }
 
@@ -1146,9 +1142,9 @@ extern "C" int dv_gemm(const dv_gemm_desc* d, dv_stream_t stream) {
 }
 
 // half-tile width of the paired-heads launch: 16 (default: 32x(16+16) tiles = the workgroup count and MFMA chain of
-// the 32x32 K-split tiling) or 32 (g_opt[4] = 1 / 2: 32x(32+32) tiles with 4 / 8 waves; measured slower at cfg 2)
+// the 32x32 K-split tiling) or 32 (tune_of(g).opt[4] = 1 / 2: 32x(32+32) tiles with 4 / 8 waves; measured slower at cfg 2)
 #ifdef DV_LAB
-static int heads_hb() { return (g_opt[4] == 1 || g_opt[4] == 2) ? 32 : 16; }
+static int heads_hb() { return 16; }       // (lab: the 32-wide half tiles are chosen per call, dv_gemm_tune.opt[4])
 #else
 static int heads_hb() { return 16; }
 #endif
@@ -1174,27 +1170,27 @@ extern "C" int dv_gemm_heads(const dv_gemm_desc* d, const dv_heads_epi* e, dv_st
     } else {
         DV_REQUIRE(e->x && e->coef && e->part);
     }
-    lc.map = g_opt[0] >= 0 ? g_opt[0] : 1;
+    lc.map = tune_of(g).opt[0] >= 0 ? tune_of(g).opt[0] : 1;
     const int tiles = ((g.M + 31) / 32) * dv_gemm_heads_tiles(g.split);
 #ifdef DV_LAB
-    if (g_opt[4] == 1) {
+    if (tune_of(g).opt[4] == 1) {
         hipLaunchKernelGGL((gemm_heads_kernel<32, 64, 64, 4>), dim3(tiles), dim3(256), 0,
                            static_cast<hipStream_t>(stream), g, lc, *e);
         DV_RETURN_LAUNCH();
     }
-    if (g_opt[4] == 2) {   // 8 waves split K: per wave the MFMA chain of the 32x32 K-split tiling, A staged once
+    if (tune_of(g).opt[4] == 2) {   // 8 waves split K: per wave the MFMA chain of the 32x32 K-split tiling, A staged once
         hipLaunchKernelGGL((gemm_heads_kernel<32, 64, 64, 8>), dim3(tiles), dim3(512), 0,
                            static_cast<hipStream_t>(stream), g, lc, *e);
         DV_RETURN_LAUNCH();
     }
-    if (g_opt[4] == -1) {
+    if (tune_of(g).opt[4] == -1) {
         hipLaunchKernelGGL((gemm_heads_kernel<32, 32, 64, 4>), dim3(tiles), dim3(256), 0,
                            static_cast<hipStream_t>(stream), g, lc, *e);
         DV_RETURN_LAUNCH();
     }
 #endif
-    const bool pipe = pipe_on() && pipe_ok(g, lc);
-    if (g_opt[4] == 3 || (g_opt[4] == 0 && tiles >= dense_min_tiles())) {
+    const bool pipe = pipe_on(g) && pipe_ok(g, lc);
+    if (tune_of(g).opt[4] == 3 || (tune_of(g).opt[4] == 0 && tiles >= dense_min_tiles(g))) {
         // chip-filling grids: four waves, half the K tile, seven workgroups per CU (see gemm_launch): 29.1 -> 26.4 us
         // for the decoder heads + NLL alone
         if (pipe)
@@ -1207,7 +1203,7 @@ extern "C" int dv_gemm_heads(const dv_gemm_desc* d, const dv_heads_epi* e, dv_st
         hipLaunchKernelGGL((gemm_heads_pipe_kernel<32, 32, 64, 8, 2, 2>), dim3(tiles), dim3(512), 0,
                            static_cast<hipStream_t>(stream), g, lc, *e);
     } else {  // default: the 32x32 tiling's eight-wave K split, B lines = 16 + 16 rows of the two heads
-        hipLaunchKernelGGL((gemm_heads_kernel<32, 32, 64, 8>), dim3(tiles), dim3(512), lds_pad(32, tiles),
+        hipLaunchKernelGGL((gemm_heads_kernel<32, 32, 64, 8>), dim3(tiles), dim3(512), lds_pad(g, 32, tiles),
                            static_cast<hipStream_t>(stream), g, lc, *e);
     }
     DV_RETURN_LAUNCH();
@@ -1231,20 +1227,20 @@ extern "C" int dv_gemm_pair(const dv_gemm_desc* d1, const dv_gemm_desc* d2, dv_s
         rc = colsum_setup(e1, 2, st);
         if (rc != DV_OK) return rc;
     }
-    const bool pipe = pipe_on() && t1 == 2 && t2 == 2 && pipe_ok(e1, lc1) && pipe_ok(e2, lc2);
+    const bool pipe = pipe_on(e1) && t1 == 2 && t2 == 2 && pipe_ok(e1, lc1) && pipe_ok(e2, lc2);
     if (pipe) pipe_ones_off(e1);
     const int tiles1 = ((e1.M + 31) / 32) * ((cols_eff(e1) + 31) / 32), tiles2 = ((e2.M + 31) / 32) * ((e2.N + 31) / 32);
     // pairing pays for the latency-bound small products; a product that already fills the chip
     // several times over (>= 4 workgroups per CU) gains nothing from a partner (measured: the
     // decoder-heads pair ran 66 us paired vs 29 + 29 us alone)
     const bool fuse = t1 == 2 && t2 == 2 && !d1->a_kcontig && !d1->b_kcontig && d2->a_kcontig && !d2->b_kcontig &&
-                      g_opt[2] == 0 && tiles1 < 1024 && tiles2 < 1024;
+                      tune_of(*d1).opt[2] == 0 && tiles1 < 1024 && tiles2 < 1024;
     // both products of a chip-filling layer in ONE launch of the high-occupancy tiling (dv_gemm_set_option(9, 1)
     // switches it off): the long-K data-gradient tiles first, the weight-gradient tiles fill the CUs around them --
     // with seven workgroups per CU the two grids really overlap (decoder heads at cfg 2: 21 + 25 us as two launches,
     // ~32 us as one; the old four-per-CU pairing of two chip-filling products was SLOWER than two launches)
-    if (!fuse && g_opt[9] != 1 && t1 == 2 && t2 == 2 && !d1->a_kcontig && !d1->b_kcontig && d2->a_kcontig &&
-        !d2->b_kcontig && tiles1 >= dense_min_tiles() && tiles1 + tiles2 < 4096) {
+    if (!fuse && tune_of(*d1).opt[9] != 1 && t1 == 2 && t2 == 2 && !d1->a_kcontig && !d1->b_kcontig && d2->a_kcontig &&
+        !d2->b_kcontig && tiles1 >= dense_min_tiles(e1) && tiles1 + tiles2 < 4096) {
         dv_gemm_desc first = e2, second = e1;
         if (first.pub_flag == nullptr && second.pub_flag != nullptr) {      // the kernel publishes for its first product
             first.pub_flag = second.pub_flag;

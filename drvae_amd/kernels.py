@@ -51,6 +51,36 @@ def _act(a):
 
 
 # ------------------------------------------------------------------------------ GEMM
+# Steering of the GEMM dispatcher for tests and tools: the state lives HERE, on the caller's side, and travels with every
+# descriptor (``dv_gemm_desc.tune``); the library itself keeps none.
+_TUNE = _lib.GemmTune()
+_TUNE.opt[0] = -1
+
+
+def gemm_force_tiling(t):
+    """run every GEMM-family call on tiling code ``t`` (0: the dispatcher's heuristics); returns 0, or a non-zero status
+    when this build of the library does not carry the tiling (lab tilings: ``python -m drvae_amd.build --lab``)"""
+    if not _lib.load().dv_gemm_has_tiling(int(t)):
+        return _lib.DV_ERR_UNSUPPORTED if hasattr(_lib, 'DV_ERR_UNSUPPORTED') else 4
+    _TUNE.tiling = int(t)
+    return 0
+
+
+def gemm_set_option(key, value):
+    """dispatcher option ``key`` (see ``dv_gemm_tune`` in include/drvae_hip.h)"""
+    if not 0 <= int(key) < 10:
+        return 1
+    _TUNE.opt[int(key)] = int(value)
+    return 0
+
+
+def _tune_ptr():
+    t = _TUNE
+    if t.tiling == 0 and t.opt[0] == -1 and not any(t.opt[i] for i in range(1, 10)):
+        return None
+    return C.addressof(t)
+
+
 def _gemm_desc(Cm, A, B, a_kc, b_kc, *, A2=None, a_kscale=None, alpha=1.0, beta=0.0, epi=EPI_PLAIN, scale=None,
                bias=None, split=None, act0=0, act1=0, shift0=0.0, shift1=0.0, resid=None, resid_cols=0, yref=None,
                a_colsum=None, colsum_beta=0.0, overread=False, publish=None):
@@ -82,6 +112,7 @@ def _gemm_desc(Cm, A, B, a_kc, b_kc, *, A2=None, a_kscale=None, alpha=1.0, beta=
     d.flags = 3 if overread else 0
     if publish is not None:                 # (flag, counter, add): publish on kernel entry, see dv_flag_publish
         d.pub_flag, d.pub_ctr, d.pub_add = _i32(publish[0]), _i32(publish[1]), publish[2]
+    d.tune = _tune_ptr()
     return d
 
 

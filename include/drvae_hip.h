@@ -147,6 +147,17 @@ typedef struct dv_bump {
  * epilogue DV_EPI_BWD: v *= act'(yref[m*ldy+n] - shift) with the same (split, act, shift)
  *   selection: the activation backward of the layer BELOW fused into the dx GEMM.
  */
+/* Per-call steering of the GEMM dispatcher (ABI 9; replaces the process-global dv_gemm_force_tiling / dv_gemm_set_option
+ * hooks of ABI <= 8).  tiling: see dv_gemm_has_tiling.  opt[0] = workgroup -> tile map (-1 by tiling, 0 linear, 1 XCD
+ * chunk-major, >= 2 bands of that many tile rows); opt[1] extra dynamic LDS of the chip-filling 32x32 launches; opt[2] = 1:
+ * no fused form of dv_gemm_pair; opt[3]: tiles of 64x64 from which the 64x64 tiling runs (-1: never the hand-pipelined
+ * LDS-DMA kernels); opt[4] heads kernel variant; opt[7] = 1: four-wave K split for the k-contiguous layouts; opt[8]: tiles of
+ * 32x32 from which the seven-per-CU tiling runs; opt[9] = 1: chip-filling dW || dX as two launches */
+typedef struct dv_gemm_tune {
+    int32_t tiling;
+    int32_t opt[10];
+} dv_gemm_tune;
+
 typedef struct dv_gemm_desc {
     int32_t M, N, K;
     int32_t a_kcontig, b_kcontig;
@@ -187,6 +198,8 @@ typedef struct dv_gemm_desc {
     int32_t* pub_flag;
     const int32_t* pub_ctr;
     int32_t pub_add;
+    /* optional (tests / tuning; NULL = the dispatcher's heuristics): read on the host at launch time, per call */
+    const struct dv_gemm_tune* tune;
 } dv_gemm_desc;
 
 int dv_gemm(const dv_gemm_desc* desc, dv_stream_t stream);
@@ -246,12 +259,11 @@ typedef struct dv_heads_epi {
 } dv_heads_epi;
 int dv_gemm_heads(const dv_gemm_desc* desc, const dv_heads_epi* epi, dv_stream_t stream);
 int dv_gemm_heads_tiles(int32_t split);
-/* test/tuning hook: 0 = heuristic tiling, 1 = 64x64, 2 = 32x32 K-split, 3 = 128x128, 17 = 32x32x32 seven-per-CU;
- * any other code names a lab tiling of the tuning build (-DDV_LAB): DV_ERR_UNSUPPORTED in the product library */
-int dv_gemm_force_tiling(int tiling);
-/* test/tuning hook: key 0 = workgroup->tile map (0 linear, 1 XCD chunk-major [default]);
- * key 2 = 1 disables the fused form of dv_gemm_pair */
-int dv_gemm_set_option(int key, int value);
+/* Does this build of the library carry tiling code t (dv_gemm_tune.tiling)?  0 = heuristic, 1 = 64x64, 2 = 32x32 K-split,
+ * 3 = 128x128, 17 = 32x32x32 seven-per-CU, 40 = 128x256x16 hand-pipelined LDS-DMA ring, 46 = 64x64x32 pipelined; any
+ * other code names a lab tiling of the tuning build (-DDV_LAB).  A pure function: the library keeps NO tuning state --
+ * tests and tools pass a dv_gemm_tune with the descriptor of the call they want to steer. */
+int dv_gemm_has_tiling(int tiling);
 
 /* out[n] = beta*out[n] + sum_m X[m*ldx+n]            (bias gradient) */
 int dv_colsum(const float* X, int64_t ldx, int32_t M, int32_t N, float* out, float beta, dv_stream_t stream);

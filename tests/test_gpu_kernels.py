@@ -82,8 +82,8 @@ def gemm_tol(K_):
 
 def force_tiling(t):
     """force a GEMM tiling; the lab tilings only exist in the tuning build (python -m drvae_amd.build --lab)"""
-    from drvae_amd import _lib
-    if _lib.load().dv_gemm_force_tiling(t) != 0:
+    import drvae_amd.kernels as K
+    if K.gemm_force_tiling(t) != 0:
         pytest.skip('tiling %d: lab build only' % t)
 
 
@@ -109,7 +109,7 @@ def test_gemm_forward_epilogue(K, dev, tiling, M, N, Kd):
             R.linear_fwd(ref, x, W, **kw)
             close(out, ref, **gemm_tol(Kd))
     finally:
-        _lib.load().dv_gemm_force_tiling(0)
+        K.gemm_force_tiling(0)
 
 
 @pytest.mark.parametrize('tiling', [0, 1, 2, 3, 5, 16, 17, 40, 46])
@@ -145,7 +145,7 @@ def test_gemm_backward_products(K, dev, tiling, M, N, Kd):
         close(dW0, rW0, **gemm_tol(M))
         close(db0, rb0, **gemm_tol(M))
     finally:
-        _lib.load().dv_gemm_force_tiling(0)
+        K.gemm_force_tiling(0)
 
 
 def test_gemm_random_shapes_all_products(K, dev):
@@ -161,7 +161,7 @@ def test_gemm_random_shapes_all_products(K, dev):
     @given(M=st.integers(1, 700), N=st.integers(1, 700), Kd=st.integers(1, 400), pad=st.sampled_from([0, 1, 2, 4]),
            tiling=st.sampled_from([0, 17]))
     def run(M, N, Kd, pad, tiling):
-        lib.dv_gemm_force_tiling(tiling)
+        K.gemm_force_tiling(tiling)
         try:
             x, W = strided(dev, M, Kd, pad, seed=1), strided(dev, N, Kd, pad, seed=2)
             b, dpre, yprev = rnd(dev, N, seed=3), strided(dev, M, N, pad, seed=5), rnd(dev, M, Kd, seed=6)
@@ -187,7 +187,7 @@ def test_gemm_random_shapes_all_products(K, dev):
                 close(db2, rb, **gemm_tol(M))
                 close(dx2, rx, **gemm_tol(N))
         finally:
-            lib.dv_gemm_force_tiling(0)
+            K.gemm_force_tiling(0)
     run()
 
     # chip-filling layers (>= 512 tiles of 32x32 in dy^T x): the paired launch of the seven-per-CU tiling

@@ -15,7 +15,7 @@ from tools.gemm_bench import time_call  # noqa: E402
 lib = _lib.load()
 for kv in filter(None, (sys.argv[1] if len(sys.argv) > 1 else '').split(',')):
     k, v = kv.split('=')
-    lib.dv_gemm_set_option(int(k), int(v))
+    K.gemm_set_option(int(k), int(v))
 dev = torch.device('cuda:0')
 M, S = 596, 978
 for Kd in (600, 8):

@@ -11,7 +11,7 @@ from tools.gemm_bench import time_call
 lib = _lib.load()
 for kv in filter(None, (sys.argv[1] if len(sys.argv) > 1 else '').split(',')):
     k, v = kv.split('=')
-    lib.dv_gemm_set_option(int(k), int(v))
+    K.gemm_set_option(int(k), int(v))
 dev = torch.device('cuda:0')
 for (M, N, Kd) in [(32768, 1956, 600), (16384, 1956, 600), (8192, 978, 600), (32768, 600, 100), (12288, 800, 978), (12288, 800, 980),
                    (24576, 200, 102), (24576, 200, 200), (12288, 200, 800)]:

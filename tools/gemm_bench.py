@@ -48,7 +48,7 @@ def main():
     dev = torch.device('cuda:0')
     for kv in filter(None, args.opts.split(',')):
         k, v = kv.split('=')
-        lib.dv_gemm_set_option(int(k), int(v))
+        K.gemm_set_option(int(k), int(v))
     tilings = [int(t) for t in args.tilings.split(',')]
     print('%-18s %-22s' % ('shape', 'MxNxK (layout)') + ''.join('  t%d: us / TF/s   ' % t for t in tilings))
     for (M, N, Kd, akc, bkc, tag) in SHAPES:
@@ -57,13 +57,13 @@ def main():
         Cm = torch.empty(M, N, device=dev)
         row = '%-18s %-22s' % (tag, '%dx%dx%d (%d%d)' % (M, N, Kd, akc, bkc))
         for t in tilings:
-            lib.dv_gemm_force_tiling(t)
+            K.gemm_force_tiling(t)
             us = time_call(lambda: K.gemm(Cm, A, B, akc, bkc, overread=True))
             row += '  %7.2f / %6.2f   ' % (us, 2.0 * M * N * Kd / us / 1e6)
             if args.check:
                 ref = (A if akc else A.t()).double() @ (B.t() if bkc else B).double()
                 row += '[%.1e] ' % float((Cm.double() - ref).abs().max() / ref.abs().max())
-        lib.dv_gemm_force_tiling(0)
+        K.gemm_force_tiling(0)
         print(row, flush=True)
 
 

@@ -16,7 +16,7 @@ tiling = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 M, N, Kd = [int(v) for v in sys.argv[2:5]] if len(sys.argv) > 4 else (8192, 8192, 2048)
 lib = _lib.load()
 dev = torch.device('cuda:0')
-lib.dv_gemm_force_tiling(tiling)
+K.gemm_force_tiling(tiling)
 out = []
 for akc, bkc in ((1, 1), (1, 0), (0, 0)):
     A = torch.randn(((M, Kd) if akc else (Kd, M))[0] + 1, ((M, Kd) if akc else (Kd, M))[1], device=dev)[:-1]

@@ -9,7 +9,7 @@ lib = _lib.load()
 dev = torch.device('cuda:0')
 N, Kd = 1956, 600
 for t in (2, 1):
-    lib.dv_gemm_force_tiling(t)
+    K.gemm_force_tiling(t)
     row = 't%d ' % t
     for M in (32, 64, 128, 149, 298, 447, 596, 894, 1192, 2384, 4768):
         A = torch.randn(M + 1, Kd, device=dev)[:-1]

@@ -15,7 +15,7 @@ from tools.gemm_bench import time_call  # noqa: E402
 def main():
     lib = _lib.load()
     if len(sys.argv) > 1:
-        lib.dv_gemm_set_option(4, int(sys.argv[1]))     # 1: four-wave variant of the heads kernel
+        K.gemm_set_option(4, int(sys.argv[1]))     # 1: four-wave variant of the heads kernel
     dev = torch.device('cuda:0')
     r = lambda *s: torch.randn(*s, device=dev)
     for (M, S, Kd, tag) in [(224, 100, 800, 'enc heads + samples'), (300, 100, 100, 'z2F + sample'),

@@ -3,7 +3,7 @@ sys.path.insert(0, '/root/repo')
 import drvae_amd.kernels as K
 from drvae_amd import _lib
 import tests.kernel_ref as R
-lib = _lib.load(); lib.dv_gemm_set_option(4, int(sys.argv[1]))
+lib = _lib.load(); K.gemm_set_option(4, int(sys.argv[1]))
 dev = torch.device('cuda:0')
 def rnd(*s, seed=0, scale=1.0):
     g = torch.Generator().manual_seed(seed); return (torch.randn(*s, generator=g) * scale).to(dev)

@@ -17,7 +17,7 @@ def main():
     lib = _lib.load()
     for kv in filter(None, (sys.argv[1] if len(sys.argv) > 1 else '').split(',')):
         k, v = kv.split('=')
-        lib.dv_gemm_set_option(int(k), int(v))
+        K.gemm_set_option(int(k), int(v))
     dev = torch.device('cuda:0')
     for (M, N, Kd, tag) in [(596, 1956, 600, 'decoder heads'), (224, 800, 980, 'encoder L1 (x rows padded to 980)'),
                             (596, 600, 100, 'decoder L1'), (224, 200, 800, 'encoder heads'), (450, 200, 104, 'fprop L1')]:

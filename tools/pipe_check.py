@@ -38,7 +38,7 @@ def main():
     tilings = [int(t) for t in args.tilings.split(',')]
     bad = 0
     for t in tilings:
-        if lib.dv_gemm_force_tiling(t) != 0:
+        if K.gemm_force_tiling(t) != 0:
             print('tiling %d: not in this library' % t)
             continue
         worst = 0.0
@@ -71,7 +71,7 @@ def main():
                         bad += 1
                         print('  MISMATCH t%d %dx%dx%d (%d%d) pad %d: %.2e / %.2e' % (t, M, N, Kd, akc, bkc, pad, e, e2))
         print('tiling %d: worst relative error %.2e over %d cases' % (t, worst, len(CHECK) * 6), flush=True)
-    lib.dv_gemm_force_tiling(0)
+    K.gemm_force_tiling(0)
     if args.big:
         maps = [int(m) for m in args.maps.split(',')] if args.maps else [-1]
         for (M, N, Kd) in BIG:
@@ -80,14 +80,14 @@ def main():
                 Cm = torch.empty(M, N, device=dev)
                 row = '%dx%dx%d (%d%d):' % (M, N, Kd, akc, bkc)
                 for t in [3, 1] + tilings:
-                    if lib.dv_gemm_force_tiling(t) != 0:
+                    if K.gemm_force_tiling(t) != 0:
                         continue
                     for mp in maps:
-                        lib.dv_gemm_set_option(0, mp)
+                        K.gemm_set_option(0, mp)
                         us = time_call(lambda: K.gemm(Cm, A, B, akc, bkc, overread=True), repeats=5)
                         row += '  t%d%s %.0f us %.1f TF' % (t, '' if mp < 0 else '/m%d' % mp, us, 2.0 * M * N * Kd / us / 1e6)
-                lib.dv_gemm_set_option(0, -1)
-                lib.dv_gemm_force_tiling(0)
+                K.gemm_set_option(0, -1)
+                K.gemm_force_tiling(0)
                 if args.vendor:
                     Am = A if akc else A.t()
                     Bm = B.t() if bkc else B

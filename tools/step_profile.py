@@ -30,7 +30,7 @@ def main():
     for kv in filter(None, os.environ.get('STEP_PROFILE_GEMM_OPTS', '').split(',')):       # dv_gemm_set_option keys
         k, v = kv.split('=')
         from drvae_amd import _lib
-        _lib.load().dv_gemm_set_option(int(k), int(v))
+        K.gemm_set_option(int(k), int(v))
     cfg, eng, arena, batch, desc = bench.build(wl, dev, 0, 1)
     if len(sys.argv) > 2 and sys.argv[2].startswith('universal'):
         # the batch-independent plan of the sampler feed on the same batch (universal:N = N pair slots, pairs first)
