@@ -281,9 +281,20 @@ def gemm_roofline(eng, cfg, rows, frac_pair, frac_lab, repeats=20, workload='cfg
         a3 = algorithmic / (ms_per_step * 1e-3) / 1e12
         out['step_level'] = {'achieved': round(a3, 3), 'frac': round(a3 / FP32_MFMA_PEAK_TFLOPS, 4),
                              'ms_per_step': ms_per_step}
+    def in_graph(ig):
+        # (a PROFILE of an earlier run of this command, not a measurement of the build being run: its own key, with the
+        # commit it was collected at; `achieved` / `frac` above are this run's live figures)
+        a2 = algorithmic / (ig['kernel_us_per_step'] * 1e-6) / 1e12
+        return {'gemm_us_per_step': ig['kernel_us_per_step'], 'launches_per_step': ig['launches_per_step'],
+                'avg_launch_us': ig['avg_launch_us'], 'achieved': round(a2, 3),
+                'frac': round(a2 / FP32_MFMA_PEAK_TFLOPS, 4), 'profiled_at': prof.get('commit'), 'profile': prof_file,
+                'what': 'GEMM-family kernel time per step of the RUNNING step (both chains, main chain on its CU partition) '
+                        'from the committed rocprofv3 --kernel-trace --stats summary'}
     if brief:
         out['top_launches'] = [{'shape': list(sh), 'us': round(1e6 * t, 2), 'tflops': round(f / t / 1e12, 2)}
                                for t, f, sh in top]
+        if prof is not None and 'kernel_us_per_step' in (prof.get('gemm_in_graph') or {}):
+            out['in_graph'] = in_graph(prof['gemm_in_graph'])
         return out
     out.update({'algorithmic_mbytes_per_step': round(alg_bytes / 1e6, 2),
                 'algorithmic_gemm_mbytes_per_step': round(gemm_bytes / 1e6, 2),
@@ -307,14 +318,7 @@ def gemm_roofline(eng, cfg, rows, frac_pair, frac_lab, repeats=20, workload='cfg
             # THE figure of the line: the same FLOPs over the GEMM-family kernel time of the RUNNING step (both chains
             # running, main chain on its CU partition), i.e. avg FLOPs per launch / avg in-situ launch duration, from
             # the committed rocprofv3 --kernel-trace --stats summary of this command
-            # (a PROFILE of an earlier run of this command, not a measurement of the build being run: its own key, with
-            # the commit it was collected at; `achieved` / `frac` above are this run's live figures)
-            a2 = algorithmic / (ig['kernel_us_per_step'] * 1e-6) / 1e12
-            out['in_graph'] = {'gemm_us_per_step': ig['kernel_us_per_step'], 'launches_per_step': ig['launches_per_step'],
-                               'avg_launch_us': ig['avg_launch_us'], 'achieved': round(a2, 3),
-                               'frac': round(a2 / FP32_MFMA_PEAK_TFLOPS, 4), 'profiled_at': prof.get('commit'),
-                               'what': 'GEMM-family kernel time per step of the RUNNING step (both chains, main chain on '
-                                       'its CU partition) from the committed rocprofv3 --kernel-trace --stats summary'}
+            out['in_graph'] = in_graph(ig)
     return out
 
 

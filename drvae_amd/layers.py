@@ -30,7 +30,7 @@ class WeightNormLinear(nn.Linear):
         # intended semantics of src/layers.py:27-35 (its expand_as is shape-buggy unless in==out)
         self.weight.normal_().mul_(0.05)
         wn = self.weight / torch.norm(self.weight, 2, 1, keepdim=True)
-        out = x.float() @ wn.t()
+        out = ops.linear_act([x.float().contiguous()], wn.contiguous(), None)      # (the product on the MFMA GEMM: dv_gemm)
         scale = self.init_scale / torch.sqrt(out.var(0) + 1e-10)
         self.g.copy_(scale)
         self.bias.copy_(-out.mean(0) * scale)

@@ -34,16 +34,19 @@ print('#   python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-rooflin
 print('#   single-graph schedule: counter collection serializes dispatches).  Per-STEP averages over %d steps.' % steps)
 print('# FETCH_SIZE/WRITE_SIZE in KB as reported; gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE counts')
 print('# 1/2 of the bytes of wide (16 B/lane) coalesced reads.')
-print('%-46s %6s %10s %10s %6s %8s %8s %8s %12s' % ('kernel', 'calls', 'FETCH_KB', 'WRITE_KB', 'L2hit', 'waitAny', 'waitInst',
-                                                   'active', 'mfmaBusyCyc'))
+print('# ldsConfl = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE (extra LDS-array cycles per LDS cycle); mfma/wave = SQ_VALU_MFMA_BUSY_CYCLES /')
+print('# (4 x SQ_WAVE_CYCLES): matrix-pipe cycles per cycle of wave lifetime (SQ_WAVE_CYCLES counts quad-cycles)')
+print('%-46s %6s %10s %10s %6s %8s %8s %8s %12s %9s %9s' % ('kernel', 'calls', 'FETCH_KB', 'WRITE_KB', 'L2hit', 'waitAny', 'waitInst',
+                                                   'active', 'mfmaBusyCyc', 'ldsConfl', 'mfma/wave'))
 tot_f = tot_w = gf = gw = gc = 0
 for k in sorted(fetch, key=lambda k: -fetch[k]['FETCH_SIZE']):
     f, w = fetch[k]['FETCH_SIZE'] / steps, write[k]['WRITE_SIZE'] / s2
     h, m = tcc[k]['TCC_HIT_sum'], tcc[k]['TCC_MISS_sum']
     wc = max(sq[k]['SQ_WAVE_CYCLES'], 1)
-    print('%-46s %6.1f %10.0f %10.0f %6.2f %8.2f %8.2f %8.2f %12.0f' % (
+    print('%-46s %6.1f %10.0f %10.0f %6.2f %8.2f %8.2f %8.2f %12.0f %9.3f %9.3f' % (
         k[:46], calls[k] / steps, f, w, h / max(h + m, 1), sq[k]['SQ_WAIT_ANY'] / wc, sq[k]['SQ_WAIT_INST_ANY'] / wc,
-        sq[k]['SQ_ACTIVE_INST_ANY'] / wc, sq[k]['SQ_VALU_MFMA_BUSY_CYCLES'] / s3))
+        sq[k]['SQ_ACTIVE_INST_ANY'] / wc, sq[k]['SQ_VALU_MFMA_BUSY_CYCLES'] / s3,
+        sq[k]['SQ_LDS_BANK_CONFLICT'] / max(sq[k]['SQ_LDS_IDX_ACTIVE'], 1), sq[k]['SQ_VALU_MFMA_BUSY_CYCLES'] / (4 * wc)))
     tot_f += f
     tot_w += w
     if 'gemm' in k:

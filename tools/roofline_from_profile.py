@@ -40,6 +40,14 @@ def kernel_stats(path):
     return out
 
 
+def _isnum(v):
+    try:
+        float(v)
+        return True
+    except ValueError:
+        return False
+
+
 def pmc_table(path):
     """-> ({kernel: dict(calls, fetch_kb, write_kb, l2hit)}, steps) from tools/pmc_summary.py's table"""
     rows, steps = {}, None
@@ -54,11 +62,13 @@ def pmc_table(path):
             parts = line.rstrip('\n').split()
             if len(parts) < 9:
                 continue
+            # (round 4 added two trailing columns: ldsConfl, mfma/wave)
+            ncol = 10 if len(parts) >= 11 and _isnum(parts[-10]) else 8
             try:
-                nums = [float(v) for v in parts[-8:]]
+                nums = [float(v) for v in parts[-ncol:]][:8]
             except ValueError:
                 continue
-            name = ' '.join(parts[:-8])
+            name = ' '.join(parts[:-ncol])
             rows[name] = dict(calls=nums[0], fetch_kb=nums[1], write_kb=nums[2], l2hit=nums[3], wait_any=nums[4],
                               wait_inst=nums[5], active=nums[6], mfma_busy_cycles=nums[7])
     return rows, steps
@@ -72,11 +82,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('prefix', help='e.g. profiles/r02_cfg2')
     ap.add_argument('--out', default=None)
+    ap.add_argument('--commit', default=None, help='commit the profile was collected at (recorded in the JSON)')
     ap.add_argument('--step-kernel', default='fill_normal_rows_kernel',
                     help='a kernel launched exactly once per train step (counts the profiled steps)')
     args = ap.parse_args()
     pre = args.prefix
-    out = {'source': {}}
+    out = {'source': {}, 'commit': args.commit}
     bench = None
     bj = pre + '_bench.json'
     if os.path.exists(bj):
