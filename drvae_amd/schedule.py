@@ -223,13 +223,19 @@ class StepSchedule:
     def _part_streams(self, n_side):
         """(main, side) CU-masked streams reserving ``n_side`` CUs for the side chain (cached)"""
         cache = _PARTITION_STREAMS.setdefault(torch.device(self.dev).index or 0, {})   # per device, process-wide:
-        if n_side not in cache:                    # masked streams own hardware queues, so engines share them
+        n_side = int(n_side)
+        if (n_side, bool(T.get('part_xcd'))) not in cache:                    # masked streams own hardware queues, so engines share them
             n_cu = torch.cuda.get_device_properties(self.dev).multi_processor_count
             words = (n_cu + 31) // 32
             side_bits, all_bits = [0] * words, [0] * words
+            # bit i of a CU mask = XCD i % 8, shader engine (i / 8) % 4 of it, CU i / 32 of that engine (tools/cumask_probe.hip).
+            # 'part_xcd': the reserve is WHOLE XCDs (the last n_side / 32 of the eight) -- the side chain then has L2s of its
+            # own, the main chain keeps six (five, ...) undivided ones; default: the first n_side bits = n_side / 32 CUs of
+            # every shader engine of every XCD
+            by_xcd = bool(T.get('part_xcd')) and n_side % 32 == 0 and 0 < n_side < n_cu and n_cu == 256
             for i in range(n_cu):
                 all_bits[i // 32] |= 1 << (i % 32)
-                if i < min(n_side, n_cu - 1):
+                if (i % 8 >= 8 - n_side // 32) if by_xcd else (i < min(n_side, n_cu - 1)):
                     side_bits[i // 32] |= 1 << (i % 32)
             main_bits = [a & ~b for a, b in zip(all_bits, side_bits)]
             try:
@@ -241,8 +247,8 @@ class StepSchedule:
                 import warnings
                 warnings.warn('drvae_amd: CU partition unavailable (%s)' % e)
                 pair = None
-            cache[n_side] = pair
-        return cache[n_side]
+            cache[(n_side, bool(T.get('part_xcd')))] = pair
+        return cache[(n_side, bool(T.get('part_xcd')))]
 
     def partition(self, n_side=None):
         """Context manager: run the train step with the GPU's compute units split between the two

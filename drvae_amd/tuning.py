@@ -27,6 +27,7 @@ DEFAULTS = {
     'raw_heads': 1,      # chip-filling decoder heads (train step) as a plain product, finished by the NLL row pass
     'tail_gate': 1,      # the side chain's tail is awaited by the NEXT step's first launch (0: by this step's optimiser launch)
     'concurrent': 1,     # side chain at all (0: one stream)
+    'part_xcd': 0,       # the side chain's CU reserve as whole XCDs (1) instead of n/32 CUs of every shader engine (0)
     'wide_single': 1,    # chip-filling steps (wide configuration) are captured on one stream, no fork/join
     'sync_poll': 64,     # replays between two polls of the sticky wait-error words
 }
