@@ -7,7 +7,11 @@ exchange is an RCCL all-reduce of ``xchg`` = [loss scalars | gradients] (in two 
 overlapped with backward); (3) the two heads of every Gaussian block are laid out back to back so that one
 GEMM with a split epilogue evaluates both.  Names, shapes and (out,in)
 row-major layout of the reference ``state_dict`` are preserved: the nn.Parameters
-simply alias the arena.
+simply alias the arena.  A weight matrix whose inner dimension is no multiple of 4 (W1: 800 x 978, the
+fprop blocks' 200 x 102) is stored with its rows padded to 16 B -- the nn.Parameter is the
+``[:, :in]`` view of it, the pad columns are zero and stay zero (their gradient is never written, and
+Adam / Adamax with L2 leave a zero parameter with a zero gradient where it is) -- so that every
+product of the step has 16-B aligned operand rows (the LDS-DMA GEMM kernels need them).
 """
 from collections import OrderedDict
 
@@ -47,6 +51,20 @@ def _fusion_groups(names, frozen=()):
     return groups
 
 
+def row_stride(shape):
+    """floats between consecutive rows of a parameter of this shape inside the arena"""
+    if len(shape) == 2 and shape[1] >= 16 and shape[1] % 4:
+        return (shape[1] + 3) // 4 * 4
+    return shape[-1] if len(shape) else 1
+
+
+def span(t):
+    """floats from the first to one past the last element of a (row-padded) arena view"""
+    if t.dim() == 2 and t.numel():
+        return (t.shape[0] - 1) * t.stride(0) + t.shape[1]
+    return t.numel()
+
+
 class ParamArena:
     def __init__(self, named_shapes, device, frozen=()):
         """named_shapes: OrderedDict name -> shape (reference state_dict names).  ``frozen``: parameters
@@ -62,10 +80,7 @@ class ParamArena:
             off = (off + 3) // 4 * 4                       # 16-B aligned group start
             for n in grp:
                 self.offsets[n] = off
-                numel = 1
-                for s in self.shapes[n]:
-                    numel *= s
-                off += numel
+                off += self.numel(n)
         self.n_params = (off + 3) // 4 * 4
         if not hasattr(self, 'n_live'):
             self.n_live = self.n_params
@@ -89,14 +104,20 @@ class ParamArena:
         self.late_end = N_LOSS + (first if tail_ok else self.n_params)
 
     def numel(self, name):
+        """floats the parameter occupies in the arena (rows padded to 16 B: see ``row_stride``)"""
+        s = self.shapes[name]
+        if len(s) == 2:
+            return s[0] * row_stride(s)
         n = 1
-        for s in self.shapes[name]:
-            n *= s
+        for d in s:
+            n *= d
         return n
 
     def _view(self, buf, name):
-        o = self.offsets[name]
-        return buf[o:o + self.numel(name)].view(self.shapes[name])
+        o, s = self.offsets[name], self.shapes[name]
+        if len(s) == 2 and row_stride(s) != s[1]:
+            return buf[o:o + self.numel(name)].view(s[0], row_stride(s))[:, :s[1]]
+        return buf[o:o + self.numel(name)].view(s)
 
     def p(self, name):
         return self._view(self.param, name)
@@ -111,6 +132,8 @@ class ParamArena:
         s1, s2 = self.shapes[first], self.shapes[second]
         assert s1[1:] == s2[1:]
         shape = (s1[0] + s2[0],) + s1[1:]
+        if len(s1) == 2 and row_stride(s1) != s1[1]:
+            return buf[o:o + self.numel(first) + self.numel(second)].view(shape[0], row_stride(s1))[:, :s1[1]]
         return buf[o:o + self.numel(first) + self.numel(second)].view(shape)
 
     def adopt(self, module):

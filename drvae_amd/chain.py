@@ -40,7 +40,11 @@ class _Lin:
 
 
 class _Chain:
-    """trunk layers + final layer of one block evaluated on M stacked rows, with buffers."""
+    """trunk layers + final layer of one block evaluated on M stacked rows, with buffers.
+
+    Inputs handed to ``forward`` whose width is no multiple of 4 must either have unpadded rows (row stride == width)
+    or be WHOLE row-padded buffers with zero pads (``plan.mat``): the products then run over the padded K (``kpad`` of
+    ``kernels._gemm_desc``; the arena's weights are row-padded the same way)."""
 
     def __init__(self, layers, M, device, resid_cols=0):
         self.layers, self.M, self.resid_cols = layers, M, resid_cols
@@ -72,17 +76,17 @@ class _Chain:
                                shift0=l.shift0, shift1=l.shift1, resid=resid,
                                resid_cols=self.resid_cols if resid is not None else 0, overread=True,
                                publish=publish if (li == 0 and l.g is None) else None,
-                               sample=heads.get('sample'), nll=heads.get('nll'))
+                               sample=heads.get('sample'), nll=heads.get('nll'), kpad=True)
                 return self.out[-1]
             if last and raw_last:
                 assert self.raw_last_ok() and resid is None
                 K.gemm(self.out[li], x[0], l.W, True, True, A2=x[1] if len(x) > 1 else None, overread=True,
-                       publish=publish if li == 0 else None)
+                       publish=publish if li == 0 else None, kpad=True)
                 return self.out[-1]
             K.linear_fwd(self.out[li], x[0], l.W, l.b, x2=x[1] if len(x) > 1 else None, scale=l.scale, split=l.split,
                          act0=l.act0, act1=l.act1, shift0=l.shift0, shift1=l.shift1,
                          resid=resid if last else None, resid_cols=self.resid_cols if (last and resid is not None) else 0,
-                         overread=True, publish=publish if (li == 0 and l.g is None) else None)
+                         overread=True, publish=publish if (li == 0 and l.g is None) else None, kpad=True)
             x = [self.out[li]]
         return self.out[-1]
 

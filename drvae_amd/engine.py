@@ -30,7 +30,7 @@ import torch
 from . import kernels as K
 from . import tuning as T
 from ._lib import GAUSS_LOGVAR, GAUSS_SIGMA
-from .arena import N_LOSS, ParamArena
+from .arena import N_LOSS, ParamArena, span
 from .chain import _Chain, _Lin, _pad4
 from .plan import LOSS_IDX, _Plan
 from .schedule import StepSchedule, _Branch
@@ -786,7 +786,7 @@ class FusedStep(StepSchedule):
         hs = min(heads.dW.storage_offset(), heads.db.storage_offset()) - g0
         ok = bool(self.side_adam and len(self.L_decx) > 1 and heads.g is None and not self.wbranch.on
                   and hs % 4 == 0 and self.arena.n_live == self.arena.n_params
-                  and max(heads.dW.storage_offset() + heads.dW.numel(),
+                  and max(heads.dW.storage_offset() + span(heads.dW),
                           heads.db.storage_offset() + heads.db.numel()) - g0 >= self.arena.n_live - 3)
         return ok, hs
 
@@ -967,7 +967,7 @@ class FusedStep(StepSchedule):
         if mode == 5 and late and not split_kind:      # (the step counter is advanced before the optimiser launch: counter + 0 by then)
             lc = self.L_clf[0]
             lo = min(lc.dW.storage_offset(), lc.db.storage_offset()) - g0
-            hi = max(lc.dW.storage_offset() + lc.dW.numel(), lc.db.storage_offset() + lc.db.numel()) - g0
+            hi = max(lc.dW.storage_offset() + span(lc.dW), lc.db.storage_offset() + lc.db.numel()) - g0
             self._adam_gate = (self.flags[6:7] if self._tail_gated() else self.flags[3:4], self.step_dev, 0,
                                self.sync_err[6:8], lo, hi)
             self._adam_n = hs if side_adam else None

@@ -499,6 +499,12 @@ class _EvalGraph:
             self.c_dec = _Chain(eng.L_decx, n * (2 if kind != 'vfae' else 1), dev)
             self.zd = torch.zeros(n * (2 if kind != 'vfae' else 1), (Z + 3) // 4 * 4, device=dev)[:, :Z]
         x1 = ds.x1.to(torch.float32)
+        if X % 4:
+            # rows padded to 16 B (zero pads): the first layer's product then runs on the LDS-DMA kernels (``_Chain``)
+            if not hasattr(self, 'x1p'):
+                self.x1p = torch.zeros(n, (X + 3) // 4 * 4, device=dev)[:, :X]
+            self.x1p.copy_(x1)
+            x1 = self.x1p
         Q = self.c_enc.forward([x1])
         z1 = Q[:, :Z]
         res = OrderedDict(z1=z1, qz1=(z1, Q[:, Z:2 * Z]))

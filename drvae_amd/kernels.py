@@ -83,7 +83,7 @@ def _tune_ptr():
 
 def _gemm_desc(Cm, A, B, a_kc, b_kc, *, A2=None, a_kscale=None, alpha=1.0, beta=0.0, epi=EPI_PLAIN, scale=None,
                bias=None, split=None, act0=0, act1=0, shift0=0.0, shift1=0.0, resid=None, resid_cols=0, yref=None,
-               a_colsum=None, colsum_beta=0.0, overread=False, publish=None):
+               a_colsum=None, colsum_beta=0.0, overread=False, publish=None, kpad=False):
     M, N = Cm.shape
     if a_kc:
         K = A.shape[1] + (A2.shape[1] if A2 is not None else 0)
@@ -98,6 +98,12 @@ def _gemm_desc(Cm, A, B, a_kc, b_kc, *, A2=None, a_kscale=None, alpha=1.0, beta=
     d = GemmDesc()
     d.M, d.N, d.K, d.a_kcontig, d.b_kcontig = M, N, K, int(bool(a_kc)), int(bool(b_kc))
     d.A, d.lda = _f32(A, 'A'), _ld(A)
+    if kpad and a_kc and b_kc and A2 is None and (K & 3) and min(_ld(A), _ld(B)) >= ((K + 3) & ~3) \
+            and not ((A.data_ptr() | B.data_ptr()) & 15) and not ((_ld(A) | _ld(B)) & 3):
+        # ``kpad``: the caller guarantees that the rows of both operands are ZERO from K up to the next multiple of 4
+        # (row-padded activation buffers, the arena's row-padded weights): the product over the padded K is the same
+        # number, and its operands qualify for the LDS-DMA kernels (16-B chunks along k)
+        d.K = K = (K + 3) & ~3
     d.A2, d.lda2, d.K1 = _f32(A2, 'A2'), _ld(A2), (A.shape[1] if A2 is not None else K)
     d.a_kscale = _f32(a_kscale, 'a_kscale')
     d.B, d.ldb = _f32(B, 'B'), _ld(B)
@@ -137,10 +143,10 @@ def linear_bwd_pair(dW, dbias, dx, dpre, x, W, *, kscale=None, alpha=1.0, beta_x
 
 
 def linear_fwd(out, x, W, bias=None, *, x2=None, scale=None, split=None, act0=0, act1=0, shift0=0.0, shift1=0.0,
-               resid=None, resid_cols=0, overread=False, publish=None):
+               resid=None, resid_cols=0, overread=False, publish=None, kpad=False):
     """out = act([x|x2] W^T * scale + bias) + shift (+ resid) -- one Linear (or two heads) forward."""
     gemm(out, x, W, True, True, A2=x2, epi=EPI_FWD, scale=scale, bias=bias, split=split, act0=act0, act1=act1,
-         shift0=shift0, shift1=shift1, resid=resid, resid_cols=resid_cols, overread=overread, publish=publish)
+         shift0=shift0, shift1=shift1, resid=resid, resid_cols=resid_cols, overread=overread, publish=publish, kpad=kpad)
 
 
 def heads_tiles(split):
@@ -149,7 +155,7 @@ def heads_tiles(split):
 
 
 def linear_heads(out, x, W, bias=None, *, split, x2=None, scale=None, act0=0, act1=0, shift0=0.0, shift1=0.0,
-                 resid=None, resid_cols=0, overread=False, publish=None, sample=None, nll=None):
+                 resid=None, resid_cols=0, overread=False, publish=None, sample=None, nll=None, kpad=False):
     """Dual-head Linear with the row work on both heads fused into its epilogue (``dv_gemm_heads``).
     ``sample`` = dict(eps, out, n_src[, seg_ptr, seg_rows, sub, out2, out3, out3_idx, out4, out4_ptr]): ``out`` =
     (mu | logvar) is written and the reparameterised samples of every source row leave the same launch (``out4``:
@@ -158,7 +164,8 @@ def linear_heads(out, x, W, bias=None, *, split, x2=None, scale=None, act0=0, ac
     log-likelihood rows, ``part`` (M, heads_tiles(split)) their per-tile partial sums."""
     assert (sample is None) != (nll is None)
     d = _gemm_desc(out, x, W, True, True, A2=x2, epi=EPI_FWD, scale=scale, bias=bias, split=split, act0=act0, act1=act1,
-                   shift0=shift0, shift1=shift1, resid=resid, resid_cols=resid_cols, overread=overread, publish=publish)
+                   shift0=shift0, shift1=shift1, resid=resid, resid_cols=resid_cols, overread=overread, publish=publish,
+                   kpad=kpad)
     e = _lib.HeadsEpi()
     if sample is not None:
         g = sample.get

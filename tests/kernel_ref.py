@@ -90,7 +90,7 @@ def _seg(N, split, a0, a1, v0, v1, dev):
 
 def gemm(Cm, A, B, a_kc, b_kc, *, A2=None, a_kscale=None, alpha=1.0, beta=0.0, epi=EPI_PLAIN, scale=None,
          bias=None, split=None, act0=0, act1=0, shift0=0.0, shift1=0.0, resid=None, resid_cols=0, yref=None,
-         a_colsum=None, colsum_beta=0.0, overread=False, publish=None):
+         a_colsum=None, colsum_beta=0.0, overread=False, publish=None, kpad=False):
     if publish is not None:
         flag_publish(publish[0], publish[1], publish[2])
     M, N = Cm.shape
@@ -118,7 +118,7 @@ def gemm(Cm, A, B, a_kc, b_kc, *, A2=None, a_kscale=None, alpha=1.0, beta=0.0, e
 
 
 def linear_fwd(out, x, W, bias=None, *, x2=None, scale=None, split=None, act0=0, act1=0, shift0=0.0, shift1=0.0,
-               resid=None, resid_cols=0, overread=False, publish=None):
+               resid=None, resid_cols=0, overread=False, publish=None, kpad=False):
     gemm(out, x, W, True, True, A2=x2, epi=EPI_FWD, scale=scale, bias=bias, split=split, act0=act0, act1=act1,
          shift0=shift0, shift1=shift1, resid=resid, resid_cols=resid_cols, publish=publish)
 
@@ -128,7 +128,7 @@ def heads_tiles(split):
 
 
 def linear_heads(out, x, W, bias=None, *, split, x2=None, scale=None, act0=0, act1=0, shift0=0.0, shift1=0.0,
-                 resid=None, resid_cols=0, overread=False, publish=None, sample=None, nll=None):
+                 resid=None, resid_cols=0, overread=False, publish=None, sample=None, nll=None, kpad=False):
     """the unfused sequence ``dv_gemm_heads`` replaces: heads GEMM, then reparam_fwd / nll_rows_fwdbwd"""
     M, N = out.shape
     heads = torch.zeros(M, N, device=out.device) if nll is not None else out
