@@ -119,6 +119,15 @@ class ParamArena:
             return buf[o:o + self.numel(name)].view(s[0], row_stride(s))[:, :s[1]]
         return buf[o:o + self.numel(name)].view(s)
 
+    def pads(self, buf):
+        """the pad columns of every row-padded parameter inside ``buf`` (param / grad / a moment): zero, always"""
+        out = []
+        for name, s in self.shapes.items():
+            if len(s) == 2 and row_stride(s) != s[1]:
+                o = self.offsets[name]
+                out.append(buf[o:o + self.numel(name)].view(s[0], row_stride(s))[:, s[1]:])
+        return out
+
     def p(self, name):
         return self._view(self.param, name)
 

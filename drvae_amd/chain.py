@@ -9,6 +9,13 @@ def _pad4(n):
     return (n + 3) // 4 * 4
 
 
+def _whole_rows(t):
+    """is ``t`` made of whole rows of a row-padded 2-D buffer (``zeros(r, pad4(c))[:, :c]`` or a row range of one)?"""
+    b = t._base
+    return (b is not None and b.dim() == 2 and t.dim() == 2 and b.is_contiguous() and t.stride() == (b.shape[1], 1)
+            and b.shape[1] == _pad4(t.shape[1]) and (t.storage_offset() - b.storage_offset()) % b.shape[1] == 0)
+
+
 class _Lin:
     """One Linear layer (or two fused heads) bound to arena views."""
 
@@ -44,7 +51,9 @@ class _Chain:
 
     Inputs handed to ``forward`` whose width is no multiple of 4 must either have unpadded rows (row stride == width)
     or be WHOLE row-padded buffers with zero pads (``plan.mat``): the products then run over the padded K (``kpad`` of
-    ``kernels._gemm_desc``; the arena's weights are row-padded the same way)."""
+    ``kernels._gemm_desc``; the arena's weights are row-padded the same way).  ``backward`` likewise runs the weight
+    gradient of a single-source layer and the data gradients into its own buffers (or into a destination made of whole
+    padded rows) over the padded N (``npad``): the pad columns receive the zeros they hold anyway."""
 
     def __init__(self, layers, M, device, resid_cols=0):
         self.layers, self.M, self.resid_cols = layers, M, resid_cols
@@ -111,7 +120,8 @@ class _Chain:
                 c0 = 0
                 for si, s in enumerate(srcs):
                     w = s.shape[1]
-                    K.linear_bwd_weight(dW[:, c0:c0 + w], dpre, s, dbias=l.db if si == 0 else None, overread=True)
+                    K.linear_bwd_weight(dW[:, c0:c0 + w], dpre, s, dbias=l.db if si == 0 else None, overread=True,
+                                        npad=len(srcs) == 1 and l.g is None)
                     c0 += w
                 if l.g is not None:
                     K.wn_bwd(l.dW, l.dg, l.raw, l.W, l.g, l.norm)
@@ -124,12 +134,13 @@ class _Chain:
                 if li > 0:
                     prev = self.layers[li - 1]
                     K.linear_bwd_pair(l.dW, l.db, self.dpre[li - 1], dpre, srcs[0], l.W, yref=self.out[li - 1],
-                                      act=prev.act0, shift=prev.shift0, overread=True, publish=pending_pub)
+                                      act=prev.act0, shift=prev.shift0, overread=True, publish=pending_pub, npad=True,
+                                      npad_x=True)
                     dpre = self.dpre[li - 1]
                 else:
                     dst, alpha, beta = dinputs[0][0]
                     K.linear_bwd_pair(l.dW, l.db, dst, dpre, srcs[0], l.W, alpha=alpha, beta_x=beta, overread=True,
-                                      publish=pending_pub)
+                                      publish=pending_pub, npad=True, npad_x=_whole_rows(dst))
                 pending_pub = None
                 continue
             if pending_pub is not None:      # (no paired launch for this layer: a launch of its own)
@@ -143,7 +154,7 @@ class _Chain:
             if li > 0:
                 prev = self.layers[li - 1]
                 K.linear_bwd_data(self.dpre[li - 1], dpre, l.W, kscale=l.scale, yref=self.out[li - 1], act=prev.act0,
-                                  shift=prev.shift0, overread=True)
+                                  shift=prev.shift0, overread=True, npad=True)
                 dpre = self.dpre[li - 1]
             elif dinputs is not None:
                 c0 = 0

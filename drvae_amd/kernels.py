@@ -83,7 +83,7 @@ def _tune_ptr():
 
 def _gemm_desc(Cm, A, B, a_kc, b_kc, *, A2=None, a_kscale=None, alpha=1.0, beta=0.0, epi=EPI_PLAIN, scale=None,
                bias=None, split=None, act0=0, act1=0, shift0=0.0, shift1=0.0, resid=None, resid_cols=0, yref=None,
-               a_colsum=None, colsum_beta=0.0, overread=False, publish=None, kpad=False):
+               a_colsum=None, colsum_beta=0.0, overread=False, publish=None, kpad=False, npad=False):
     M, N = Cm.shape
     if a_kc:
         K = A.shape[1] + (A2.shape[1] if A2 is not None else 0)
@@ -104,6 +104,13 @@ def _gemm_desc(Cm, A, B, a_kc, b_kc, *, A2=None, a_kscale=None, alpha=1.0, beta=
         # (row-padded activation buffers, the arena's row-padded weights): the product over the padded K is the same
         # number, and its operands qualify for the LDS-DMA kernels (16-B chunks along k)
         d.K = K = (K + 3) & ~3
+    if npad and not b_kc and (N & 3) and min(_ld(B), _ld(Cm)) >= ((N + 3) & ~3) and not ((B.data_ptr() | Cm.data_ptr()) & 15) \
+            and not ((_ld(B) | _ld(Cm)) & 3) and resid is None and scale is None and bias is None \
+            and (yref is None or _ld(yref) >= ((N + 3) & ~3)):
+        # ``npad``: the caller guarantees that the rows of B are ZERO from N up to the next multiple of 4 and that C's rows
+        # are padded the same way: the product over the padded N writes zeros into C's pad columns (they are zero
+        # anyway) and every output row ends on a 16-B store
+        d.N = N = (N + 3) & ~3
     d.A2, d.lda2, d.K1 = _f32(A2, 'A2'), _ld(A2), (A.shape[1] if A2 is not None else K)
     d.a_kscale = _f32(a_kscale, 'a_kscale')
     d.B, d.ldb = _f32(B, 'B'), _ld(B)
@@ -130,15 +137,15 @@ def gemm(Cm, A, B, a_kc, b_kc, **kw):
 
 
 def linear_bwd_pair(dW, dbias, dx, dpre, x, W, *, kscale=None, alpha=1.0, beta_x=0.0, yref=None, act=0, shift=0.0,
-                    overread=False, publish=None):
+                    overread=False, publish=None, npad=False, npad_x=False):
     """dW = dpre^T x (+ dbias) and dx = beta_x*dx + alpha*(dpre W) * act'(yref) in ONE launch when both fit
     the fused form of ``dv_gemm_pair`` (otherwise two launches)."""
-    d1 = _gemm_desc(dW, dpre, x, False, False, a_colsum=dbias, overread=overread, publish=publish)
+    d1 = _gemm_desc(dW, dpre, x, False, False, a_colsum=dbias, overread=overread, publish=publish, npad=npad)
     if yref is None:
-        d2 = _gemm_desc(dx, dpre, W, True, False, a_kscale=kscale, alpha=alpha, beta=beta_x, overread=overread)
+        d2 = _gemm_desc(dx, dpre, W, True, False, a_kscale=kscale, alpha=alpha, beta=beta_x, overread=overread, npad=npad_x)
     else:
         d2 = _gemm_desc(dx, dpre, W, True, False, a_kscale=kscale, alpha=alpha, beta=beta_x, epi=EPI_BWD, yref=yref,
-                        act0=act, act1=act, shift0=shift, shift1=shift, overread=overread)
+                        act0=act, act1=act, shift0=shift, shift1=shift, overread=overread, npad=npad_x)
     _lib.check(_lib.load().dv_gemm_pair(C.byref(d1), C.byref(d2), _stream()), 'dv_gemm_pair')
 
 
@@ -185,18 +192,19 @@ def linear_heads(out, x, W, bias=None, *, split, x2=None, scale=None, act0=0, ac
     _lib.check(_lib.load().dv_gemm_heads(C.byref(d), C.byref(e), _stream()), 'dv_gemm_heads')
 
 
-def linear_bwd_data(dx, dpre, W, *, kscale=None, alpha=1.0, beta=0.0, yref=None, act=0, shift=0.0, overread=False):
+def linear_bwd_data(dx, dpre, W, *, kscale=None, alpha=1.0, beta=0.0, yref=None, act=0, shift=0.0, overread=False,
+                    npad=False):
     """dx = beta*dx + alpha*((dpre*kscale) W) * act'(yref)   (W may be a column slice view)."""
     if yref is None:
-        gemm(dx, dpre, W, True, False, a_kscale=kscale, alpha=alpha, beta=beta, overread=overread)
+        gemm(dx, dpre, W, True, False, a_kscale=kscale, alpha=alpha, beta=beta, overread=overread, npad=npad)
     else:
         gemm(dx, dpre, W, True, False, a_kscale=kscale, alpha=alpha, beta=beta, epi=EPI_BWD, yref=yref, act0=act,
-             act1=act, shift0=shift, shift1=shift, overread=overread)
+             act1=act, shift0=shift, shift1=shift, overread=overread, npad=npad)
 
 
-def linear_bwd_weight(dW, dpre, x, *, beta=0.0, dbias=None, overread=False):
+def linear_bwd_weight(dW, dpre, x, *, beta=0.0, dbias=None, overread=False, npad=False):
     """dW = beta*dW + dpre^T x ;  dbias = beta*dbias + colsum(dpre) fused in the same launch."""
-    gemm(dW, dpre, x, False, False, beta=beta, a_colsum=dbias, colsum_beta=beta, overread=overread)
+    gemm(dW, dpre, x, False, False, beta=beta, a_colsum=dbias, colsum_beta=beta, overread=overread, npad=npad)
 
 
 def bn_fwd(y, x, w, b, mean, rstd, running_mean, running_var, eps=1e-5, momentum=0.1, training=True):

@@ -90,7 +90,7 @@ def _seg(N, split, a0, a1, v0, v1, dev):
 
 def gemm(Cm, A, B, a_kc, b_kc, *, A2=None, a_kscale=None, alpha=1.0, beta=0.0, epi=EPI_PLAIN, scale=None,
          bias=None, split=None, act0=0, act1=0, shift0=0.0, shift1=0.0, resid=None, resid_cols=0, yref=None,
-         a_colsum=None, colsum_beta=0.0, overread=False, publish=None, kpad=False):
+         a_colsum=None, colsum_beta=0.0, overread=False, publish=None, kpad=False, npad=False):
     if publish is not None:
         flag_publish(publish[0], publish[1], publish[2])
     M, N = Cm.shape
@@ -158,7 +158,8 @@ def linear_heads(out, x, W, bias=None, *, split, x2=None, scale=None, act0=0, ac
         nll['part'][:, 0] = rows              # (any split of a row's sum over the tiles is as good)
 
 
-def linear_bwd_data(dx, dpre, W, *, kscale=None, alpha=1.0, beta=0.0, yref=None, act=0, shift=0.0, overread=False):
+def linear_bwd_data(dx, dpre, W, *, kscale=None, alpha=1.0, beta=0.0, yref=None, act=0, shift=0.0, overread=False,
+                    npad=False):
     if yref is None:
         gemm(dx, dpre, W, True, False, a_kscale=kscale, alpha=alpha, beta=beta)
     else:
@@ -166,12 +167,12 @@ def linear_bwd_data(dx, dpre, W, *, kscale=None, alpha=1.0, beta=0.0, yref=None,
              act1=act, shift0=shift, shift1=shift)
 
 
-def linear_bwd_weight(dW, dpre, x, *, beta=0.0, dbias=None, overread=False):
+def linear_bwd_weight(dW, dpre, x, *, beta=0.0, dbias=None, overread=False, npad=False):
     gemm(dW, dpre, x, False, False, beta=beta, a_colsum=dbias, colsum_beta=beta)
 
 
 def linear_bwd_pair(dW, dbias, dx, dpre, x, W, *, kscale=None, alpha=1.0, beta_x=0.0, yref=None, act=0, shift=0.0,
-                    overread=False, publish=None):
+                    overread=False, publish=None, npad=False, npad_x=False):
     if publish is not None:
         flag_publish(publish[0], publish[1], publish[2])
     linear_bwd_weight(dW, dpre, x, dbias=dbias)

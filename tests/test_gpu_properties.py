@@ -345,4 +345,10 @@ def test_random_model_shapes_captured_step_vs_oracle(dev):
         e1.check_sync()
         assert torch.equal(a0.param, a1.param), kind
         assert e0.losses() == e1.losses()
+        # the pad columns of the row-padded weights (inner dimension no multiple of 4) are zero and stay zero: the
+        # forward products run over the padded K
+        for a in (arena, a0, a1):
+            for buf in (a.param, a.grad, a.exp_avg, a.exp_avg_sq):
+                for pad in a.pads(buf):
+                    assert not pad.any(), kind
     run()
