@@ -33,9 +33,11 @@ __device__ __forceinline__ float dv_act(int act, float x) {
             // expm1 by Kahan's quotient on the hardware transcendentals: (u - 1) * x / log(u), u = exp(x) -- a few ulp
             // everywhere (u == 1: x itself; u == 0: -1), a handful of instructions instead of expm1f's long polynomial path
             // (the hidden layers' epilogues run it on every element; with few waves per SIMD its latency was the epilogue)
-            if (x > 0.f) return x;
-            const float u = __expf(x), d = u - 1.f;
-            return d == 0.f ? x : (d == -1.f ? -1.f : d * __fdividef(x, __logf(u)));
+            // (branch-free: on min(x, 0), selected at the end)
+            const float xm = fminf(x, 0.f);
+            const float u = __expf(xm), d = u - 1.f;
+            const float r = d == 0.f ? xm : (d == -1.f ? -1.f : d * __fdividef(xm, __logf(u)));
+            return x > 0.f ? x : r;
         }
         case DV_ACT_SOFTPLUS: {
             // max(x, 0) + log1p(exp(-|x|)) on the hardware transcendentals (one v_exp, one v_log, one v_rcp instead of the
