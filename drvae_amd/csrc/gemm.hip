@@ -1016,14 +1016,14 @@ static int gemm_prepare(const dv_gemm_desc* d, LoadCfg& lc, int& tiling) {
     const int64_t t64_min = T.opt[3] > 0 ? T.opt[3] : 1024;
     // ... or once K is long enough to amortise a tile's prologue over many K steps: 1536 x 2048 x 20000 (encoder L1 of
     // the wide configuration, 768 tiles of 64x64) runs 956 us on the 64x64 tiling, 1090 us on 32x32, 1336 us on 128x128
-    // (whole-set evaluation, tools/eval_gemm_bench.py) K <= 256 -- a product that is all prologue and epilogue: the 32x32
-    // tiling whatever the grid (32768 x 600 x 100: 122 -> 81 us, 24576 x 200 x 102: 36 -> 27 us); the 128-class tiles only
-    // where N fills its 256-wide tiles to 7/8 (N = 600 / 800: 78 % -- 12288 x 800 x 978 runs 265 us there, 184-188 on
-    // the smaller tiles)
+    // (whole-set evaluation, tools/eval_gemm_bench.py) the 128-class tiles only where N fills its 256-wide tiles to 7/8
+    // (N = 600 / 800: 78 % -- 12288 x 800 x 978 runs 265 us there, 184-188 on the smaller tiles; 32768 x 600 x 100:
+    // 122 -> 81 us); below them K <= 256 -- a product that is all prologue and epilogue -- takes the 32x32 tiling
+    // whatever the grid (24576 x 200 x 102: 36 -> 27 us)
     const int n256 = (g.N + 255) / 256 * 256;
     const bool n_fills = (int64_t)g.N * 8 >= (int64_t)n256 * 7;
     if (tiling == 0)
-        tiling = g.K <= 256 ? 2 : ((t128 >= 1024 && n_fills) ? 3 : ((t64 >= t64_min || (t64 >= 512 && g.K >= 8192)) ? 1 : 2));
+        tiling = (t128 >= 1024 && n_fills) ? 3 : ((g.K > 256 && (t64 >= t64_min || (t64 >= 512 && g.K >= 8192))) ? 1 : 2);
     // the chip-filling products run on the hand-pipelined LDS-DMA tiling (gemm_pipe.inc) when their operands allow it
     // (16-B aligned rows, K % 4 == 0 ...): 8192 x 8192 x 2048 134 -> 144-149 TFLOP/s (dv_gemm_set_option(3, -1): off)
     if (tiling == 3 && T.tiling == 0 && T.opt[3] != -1 && pipe_ok(g, lc)) tiling = 40;

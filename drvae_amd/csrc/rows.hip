@@ -242,7 +242,7 @@ __global__ void z2f_post_bwd_kernel(Z2FArgs a, ParkArgs park) {
         for (int l = 0; l < a.L; ++l) {
             const int64_t r = (int64_t)l * a.B + i;
             const float mp = a.p2[r * a.ldp2 + d], lp = a.p2[r * a.ldp2 + a.Z + d];
-            float g = a.dz2f[r * a.ld_dz2f + d];
+            float g = a.dz2f ? a.dz2f[r * a.ld_dz2f + d] : 0.f;
             if (jp >= 0 && a.dzdec_pert) g += a.dzdec_pert[((int64_t)l * a.Np + jp) * a.ld_pert + d];
             float dmu = g, dlv = g * a.eps[r * a.lde + d] * 0.5f * expf(0.5f * lp);
             if (jp >= 0) {
@@ -1611,6 +1611,20 @@ __global__ __launch_bounds__(kLossThreads) void loss_assemble_kernel(LossTerms l
     // every term's per-thread partial sum first -- all loads of all terms are independent and in flight together
     // (this is ONE workgroup: its time is the number of dependent load round trips) -- then one reduction stage;
     // fixed order throughout
+    // (the weights and the running sums thread 0 combines at the end travel together with the terms' loads)
+    float we[3] = {0.f, 0.f, 0.f}, wc[8], ac[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) wc[i] = ac[i] = 0.f;
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) we[i] = w_elbo[i];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) wc[i] = w_cmpl[i];
+        if (accum != nullptr) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) ac[i] = accum[i];
+        }
+    }
     float ps[DV_MAX_LOSS_TERMS];
 #pragma unroll
     for (int k = 0; k < DV_MAX_LOSS_TERMS; ++k) {
@@ -1651,8 +1665,19 @@ __global__ __launch_bounds__(kLossThreads) void loss_assemble_kernel(LossTerms l
                 const int rows = t.n / rl;
                 for (int r = threadIdx.x; r < rows; r += kLossThreads) {
                     const float* xr = t.x + (int64_t)r * rl;
+                    // (sixteen loads per trip: this is one workgroup, its time is the number of dependent round trips --
+                    // the 62 per-tile partials of a row in four trips instead of sixteen)
                     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
                     int j = 0;
+                    for (; j + 15 < rl; j += 16) {
+                        float v[16];
+#pragma unroll
+                        for (int u = 0; u < 16; ++u) v[u] = xr[j + u];
+                        s0 += (v[0] + v[4]) + (v[8] + v[12]);
+                        s1 += (v[1] + v[5]) + (v[9] + v[13]);
+                        s2 += (v[2] + v[6]) + (v[10] + v[14]);
+                        s3 += (v[3] + v[7]) + (v[11] + v[15]);
+                    }
                     for (; j + 3 < rl; j += 4) {
                         s0 += xr[j];
                         s1 += xr[j + 1];
@@ -1685,9 +1710,10 @@ __global__ __launch_bounds__(kLossThreads) void loss_assemble_kernel(LossTerms l
     }
     if (threadIdx.x == 0) {
         if (!(flag != nullptr && lt.n == 0)) {     // (parked variant without terms: only the wait and the counters)
-            acc[5] = w_elbo[0] * acc[0] + w_elbo[1] * acc[1] + w_elbo[2] * acc[2];
+            acc[5] = we[0] * acc[0] + we[1] * acc[1] + we[2] * acc[2];
             float c = 0.f;
-            for (int i = 0; i < 8; ++i) c += w_cmpl[i] * acc[i];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) c += wc[i] * acc[i];
             acc[6] = c;
             // a device-side wait of this step's chains has timed out at some point (sticky error words):
             // whatever was computed since is built on stale data -- poison the scalars the host reads
@@ -1697,8 +1723,10 @@ __global__ __launch_bounds__(kLossThreads) void loss_assemble_kernel(LossTerms l
             for (int i = 0; i < 8; ++i) loss[i] = bad ? __builtin_nanf("") : acc[i];
             // running sums of a training epoch (only the launch that assembled the scalars adds them: the parked
             // variant without terms of the dual-graph step must not add a second time)
-            if (accum != nullptr)
-                for (int i = 0; i < 8; ++i) accum[i] += bad ? __builtin_nanf("") : acc[i];
+            if (accum != nullptr) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) accum[i] = ac[i] + (bad ? __builtin_nanf("") : acc[i]);
+            }
         }
         // end of the step's use of the device counters on this chain: advance them here (saves the
         // separate counter launch in front of the optimiser)
@@ -1819,7 +1847,7 @@ extern "C" int dv_z2f_post_bwd(const float* dz2f, int64_t ld_dz2f, const float* 
     // (256 CUs x 8 workgroups), or the chain that is to publish may find no slot to run in
     if (park.flag != nullptr && grid_for((int64_t)B * Z, 256) > DV_MAX_PARKED_GRID) return DV_ERR_UNSUPPORTED;
     if (L == 0 || B == 0 || Z == 0) return DV_OK;
-    DV_REQUIRE(dz2f && eps && p2 && dp2 && dz1);
+    DV_REQUIRE(eps && p2 && dp2 && dz1);       // dz2f == NULL: nothing flows into the z2Fz1 samples from a classifier
     DV_REQUIRE(Np == 0 || (pair_slot && q2 && coef && raw));
     Z2FArgs a{dz2f, ld_dz2f, dzdec_pert, ld_pert, Np ? pair_slot : nullptr, eps, lde, p2, ldp2, q2, ldq2, coef, raw,
               kl_min, dz1b, ld_dz1b, dp2, ld_dp2, dz1, ld_dz1, dq2, ld_dq2, L, B, Np, Z};

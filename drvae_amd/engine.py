@@ -238,6 +238,8 @@ class FusedStep(StepSchedule):
         # (models without a classifier have no second chain: a graph branch for the step's leaf work alone -- two KL row
         # launches, the loss scalars -- was measured: the main chain shrinks by 18 us, the fork/join costs as much;
         # PVAE cfg 1: 0.1742 -> 0.1763 ms)
+        # (PVAE: its side chain would be the two KL row launches; as a graph branch next to the decoder they cost more
+        # than they hide: cfg 1 0.167 -> 0.175 ms)
         self.branch = _Branch(self.dev, enabled=concurrent and cfg.has_y)
         self.wbranch = _Branch(self.dev, enabled=concurrent and bool(T.get('wbranch')))   # measured slower on MI355X (third graph branch): off
         self._build_layers()
@@ -972,13 +974,12 @@ class FusedStep(StepSchedule):
                                self.sync_err[6:8], lo, hi)
             self._adam_n = hs if side_adam else None
         if cfg.has_pert:
-            if not cfg.has_y:
-                p.DZ2F.zero_()
             P2 = p.c_z2F.out[-1]
             # everything that hangs on the z2Fz1 samples, one launch: scatter-back of the decoded
             # copies, reparam backward, KL(q(z2|x2)||p(z2|z1)) with free bits (src/DrVAE.py:466,482-487)
             # wrt both arguments, the residual path, and the side chain's share of d/dz1
-            K.z2f_post_bwd(p.DP2, DZ1, DQ[B:] if Np else None, p.DZ2F, p.DZDEC[p.o3:] if Np else None, p.pair_slot,
+            K.z2f_post_bwd(p.DP2, DZ1, DQ[B:] if Np else None, p.DZ2F if cfg.has_y else None,     # (no classifier: no gradient into the z2Fz1 samples but the decoder's)
+                           p.DZDEC[p.o3:] if Np else None, p.pair_slot,
                            p.E2F, P2, Q[B:] if Np else None, p.c_klz2, p.KLZ2raw, cfg.kl_min,
                            p.DZ1B if cfg.has_y else None, L, B, Np, park=park)
             # perturbation function: mu = z1 + z1 W^T + b, logvar head
@@ -1142,7 +1143,7 @@ class FusedStep(StepSchedule):
             self._rng_pending = 0
         else:
             K.counter_add(self.step_dev, 1)
-        if self._rec == 'both' and self.sched == 5:
+        if self._rec == 'both' and self.sched == 5 and cfg.has_y:       # (no classifier: never a dual-graph step)
             # eager step: the side chain's counters follow, and so does the "side chain's tail is through" flag that the
             # NEXT captured step's first launch waits for (published on entry: counter + 1 = the advanced value)
             K.counters_add2(self.side_ctr, 1, self.side_t, 1, publish=(self.flags[3:4], self.side_ctr, 1))

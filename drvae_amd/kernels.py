@@ -332,7 +332,7 @@ def z2f_post_bwd(dp2, dz1, dq2, dz2f, dzdec_pert, pair_slot, eps, p2, q2, coef, 
                  park=None):
     """fused backward of the z2Fz1 sample / KL(q(z2|x2)||p(z2|z1)) / residual block, see dv_z2f_post_bwd.
     ``park`` = (flag, ctr, err[, add[, max_spins]]): the launch first parks on another chain's flag."""
-    Z = dz2f.shape[1]
+    Z = dp2.shape[1] // 2
     _lib.check(_lib.load().dv_z2f_post_bwd(_f32(dz2f), _ld(dz2f), _f32(dzdec_pert), _ld(dzdec_pert),
                                            _i32(pair_slot), _f32(eps), _ld(eps), _f32(p2), _ld(p2), _f32(q2),
                                            _ld(q2), _f32(coef), _f32(raw), kl_min, _f32(dz1b), _ld(dz1b),

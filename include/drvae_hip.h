@@ -305,7 +305,7 @@ int dv_reparam_bwd_seg(const float* dz, int64_t ldz, const float* eps, int64_t l
                        float* dsd, int64_t lddq, float beta, const dv_bump* bump, dv_stream_t stream);
 /* Backward of everything hanging on the z2Fz1 samples (src/DrVAE.py:431-433, 459-487) in one pass
  * over (row i < B, dim d < Z), looping the L samples r = l*B + i; jp = pair_slot[i] (-1: singleton):
- *   g       = dz2f[r] + (jp >= 0 ? dzdec_pert[l*Np + jp] : 0)
+ *   g       = dz2f[r] (0 when dz2f == NULL: a model without a classifier) + (jp >= 0 ? dzdec_pert[l*Np + jp] : 0)
  *   dp2[r]  = (g | g*eps*0.5*exp(0.5*lv2)) + [jp >= 0] d KL(q2[jp] || p2[r]) / d p2 * coef[l*Np+jp]*mask
  *   dz1[r] += dp2[r].mu (residual mu2 = z1 + ..., src/blocks.py:357) + (dz1b ? dz1b[r] : 0)
  *   dq2[jp] = sum_l d KL / d q2 * coef*mask                      (mask = free-bits gate on raw)      */

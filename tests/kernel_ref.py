@@ -264,8 +264,10 @@ def z2f_post_bwd(dp2, dz1, dq2, dz2f, dzdec_pert, pair_slot, eps, p2, q2, coef, 
                  park=None):
     if park is not None:
         flag_wait(park[0], park[1], park[2], park[3] if len(park) > 3 else 1)                  # single-threaded stand-in: the producer has run already
-    Z = dz2f.shape[1]
-    dev = dz2f.device
+    Z = dp2.shape[1] // 2
+    dev = dp2.device
+    if dz2f is None:
+        dz2f = torch.zeros(L * B, Z, device=dev)
     slot = pair_slot.long() if (pair_slot is not None and Np) else torch.full((B,), -1, dtype=torch.long, device=dev)
     is_pair = slot >= 0
     if Np and dq2 is not None:
