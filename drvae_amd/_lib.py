@@ -56,6 +56,10 @@ class Bump(C.Structure):       # dv_bump: up to two device counters advanced by 
     _fields_ = [('c', _p * 2), ('n', _i32 * 2), ('inc', _i64 * 2)]
 
 
+class SegAdd(C.Structure):     # dv_seg_add: second gradient source of dv_reparam_bwd_seg
+    _fields_ = [('dz', _p), ('ld', _i64), ('n', _i32)]
+
+
 class HeadsEpi(C.Structure):   # dv_heads_epi
     _fields_ = [('mode', _i32), ('seg_ptr', _p), ('seg_rows', _p), ('n_src', _i32), ('eps', _p), ('lde', _i64),
                 ('out', _p), ('ldo', _i64), ('sub', _p), ('lds', _i64), ('out2', _p), ('ldo2', _i64), ('out3', _p),
@@ -97,7 +101,7 @@ SIGNATURES = {
     'dv_reparam_fwd': [_p, _p, _i64, _p, _i32, _i32, _i32, _p, _i64, _i32, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p,
                        _p],
     'dv_reparam_bwd_seg': [_p, _i64, _p, _i64, _p, _i64, _p, _p, _i32, _i32, _i32, _p, _i64, _p, _p, _p, _p, _i64, _f,
-                           C.POINTER(Bump), _p],
+                           C.POINTER(Bump), C.POINTER(SegAdd), C.POINTER(Wait), _p],
     'dv_z2f_post_bwd': [_p, _i64, _p, _i64, _p, _p, _i64, _p, _i64, _p, _i64, _p, _p, _f, _p, _i64, _p, _i64, _p, _i64,
                         _p, _i64, _i32, _i32, _i32, _i32, C.POINTER(Wait), _p],
     'dv_reparam_bwd': [_p, _i64, _p, _i64, _p, _i64, _p, _i32, _i32, _i32, _i32, _p, _p, _i64, _f, _p],
@@ -153,7 +157,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 9     # DV_ABI_VERSION of include/drvae_hip.h
+ABI_VERSION = 10    # DV_ABI_VERSION of include/drvae_hip.h
 
 
 def load():

@@ -179,7 +179,9 @@ __global__ void reparam_bwd_seg_kernel(const float* __restrict__ dz, int64_t ldz
                                        int nq, int Z, int mode, const float* __restrict__ extra, int64_t ldx,
                                        const int32_t* __restrict__ ex_ptr, const int32_t* __restrict__ ex_rows,
                                        float* __restrict__ dmu, float* __restrict__ dsd, int64_t lddq, float beta,
-                                       CounterBump bump) {
+                                       CounterBump bump, const float* __restrict__ dz2, int64_t ldz2, int n2,
+                                       ParkArgs park) {
+    park_block(park);
     // (the counters are not read by this kernel: whoever starts first may advance them)
     if (blockIdx.x == 0 && threadIdx.x == 0) bump_counters(bump);
     const int64_t total = (int64_t)nq * Z;
@@ -188,7 +190,8 @@ __global__ void reparam_bwd_seg_kernel(const float* __restrict__ dz, int64_t ldz
         float a = 0.f, b = 0.f;
         for (int t = seg_ptr[i]; t < seg_ptr[i + 1]; ++t) {
             const int64_t r = seg_rows[t];
-            const float g = dz[r * ldz + d];
+            float g = dz[r * ldz + d];
+            if (r < n2) g += dz2[r * ldz2 + d];
             a += g;
             b += g * eps[r * lde + d];
         }
@@ -1819,17 +1822,21 @@ extern "C" int dv_reparam_bwd_seg(const float* dz, int64_t ldz, const float* eps
                                   int64_t ldq, const int32_t* seg_ptr, const int32_t* seg_rows, int32_t nq,
                                   int32_t Z, int32_t mode, const float* extra, int64_t ldx, const int32_t* ex_ptr,
                                   const int32_t* ex_rows, float* dmu, float* dsd, int64_t lddq, float beta,
-                                  const dv_bump* bump_in, dv_stream_t stream) {
-    DV_REQUIRE(bump_ok(bump_in));
+                                  const dv_bump* bump_in, const dv_seg_add* add, const dv_wait* park_in,
+                                  dv_stream_t stream) {
+    DV_REQUIRE(bump_ok(bump_in) && park_ok(park_in));
     const CounterBump bump = bump_in ? *bump_in : CounterBump{};
+    const ParkArgs park = park_in ? *park_in : ParkArgs{};
     DV_REQUIRE(nq >= 0 && Z >= 0);
-    DV_REQUIRE(!(bump.c[0] || bump.c[1]) || (nq > 0 && Z > 0));      // a bump needs a launch to ride on
+    DV_REQUIRE(!(bump.c[0] || bump.c[1] || park.flag) || (nq > 0 && Z > 0));      // a bump / a wait needs a launch to ride on
+    DV_REQUIRE(add == nullptr || add->n == 0 || (add->dz && add->n > 0));
+    if (park.flag != nullptr && grid_for((int64_t)nq * Z, 256) > DV_MAX_PARKED_GRID) return DV_ERR_UNSUPPORTED;
     if (nq == 0 || Z == 0) return DV_OK;
     DV_REQUIRE(dz && eps && sd && seg_ptr && seg_rows && dmu && dsd);
     DV_REQUIRE(extra == nullptr || (ex_ptr && ex_rows));
     hipLaunchKernelGGL(reparam_bwd_seg_kernel, dim3(grid_for((int64_t)nq * Z, 256)), dim3(256), 0, ST(stream), dz,
                        ldz, eps, lde, sd, ldq, seg_ptr, seg_rows, nq, Z, mode, extra, ldx, ex_ptr, ex_rows, dmu, dsd,
-                       lddq, beta, bump);
+                       lddq, beta, bump, add ? add->dz : nullptr, add ? add->ld : 0, add ? add->n : 0, park);
     DV_RETURN_LAUNCH();
 }
 

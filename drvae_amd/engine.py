@@ -984,14 +984,16 @@ class FusedStep(StepSchedule):
                            p.DZ1B if cfg.has_y else None, L, B, Np, park=park)
             # perturbation function: mu = z1 + z1 W^T + b, logvar head
             p.c_z2F.backward(p.DP2, [Z1blk], [[(DZ1, 1.0, 1.0)]])
-        elif cfg.has_y:
-            K.rows_segment_sum(DZ1, p.DZ1B, beta=1.0, width=Z1, n=L * B)
+        # (VFAE: the side chain's share of d/dz1 is a second source of the sample backward below, no summing launch of
+        # its own.  The join stays the one-workgroup launch above: VFAE's side chain is the longer one, and 59 parked
+        # workgroups polling for it slow the very chain they wait for -- cfg 4 0.164 -> 0.170 ms)
+        add1 = p.DZ1B if (cfg.has_y and not cfg.has_pert) else None
         # ---- back through the samples into q(z1|x1): L z1-samples (+ L z2-samples for pairs) per row,
         # plus the row-aligned KL(q(z1|x)||p(z1|z3,y)) gradients of the row's fprop rows
         fp = cfg.has_y and p.Mf
         K.reparam_bwd_seg(DQ[:B, :Z1], DQ[:B, Z1:], p.DZDEC, p.E12, Qlv, p.zseg_ptr, p.zseg_rows,
                           extra=p.DQFP if fp else None, ex_ptr=p.q_ptr if fp else None,
-                          ex_rows=p.q_rows if fp else None, bump=bump)
+                          ex_rows=p.q_rows if fp else None, bump=bump, dz_add=add1)
         if cfg.kind == 'pvae':
             K.kl_rows_bwd(DQ[:, :Z1], DQ[:, Z1:], None, None, p.c_klp, p.KLPraw, Qmu, Qlv, prior=(0.0, 0.0),
                           free_bits=True, kl_min=cfg.kl_min, beta=1.0)

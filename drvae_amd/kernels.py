@@ -317,15 +317,20 @@ def _halt(halt):
 
 
 def reparam_bwd_seg(dmu, dsd, dz, eps, sd, seg_ptr, seg_rows, *, mode=GAUSS_LOGVAR, extra=None, ex_ptr=None,
-                    ex_rows=None, beta=0.0, bump=None):
+                    ex_rows=None, beta=0.0, bump=None, dz_add=None, park=None):
     """CSR backward of the reparameterisation (+ row-aligned extra (dmu|dsd) rows), see dv_reparam_bwd_seg.
-    ``bump``: up to two (counter, inc) the launch advances as well."""
+    ``bump``: up to two (counter, inc) the launch advances as well; ``dz_add``: a second gradient source for the first
+    ``dz_add.shape[0]`` sample rows; ``park`` = (flag, ctr, err[, add[, max_spins]]): the launch parks on another chain's flag"""
     nq, Z = seg_ptr.numel() - 1, dz.shape[1]
     assert _ld(dmu) == _ld(dsd)
+    add = None
+    if dz_add is not None:
+        add = _lib.SegAdd(_f32(dz_add), _ld(dz_add), dz_add.shape[0])
     _lib.check(_lib.load().dv_reparam_bwd_seg(_f32(dz), _ld(dz), _f32(eps), _ld(eps), _f32(sd), _ld(sd),
                                               _i32(seg_ptr), _i32(seg_rows), nq, Z, mode, _f32(extra), _ld(extra),
                                               _i32(ex_ptr), _i32(ex_rows), _f32(dmu), _f32(dsd), _ld(dmu), beta,
-                                              _bump(bump), _stream()), 'dv_reparam_bwd_seg')
+                                              _bump(bump), C.byref(add) if add is not None else None, _wait(park),
+                                              _stream()), 'dv_reparam_bwd_seg')
 
 
 def z2f_post_bwd(dp2, dz1, dq2, dz2f, dzdec_pert, pair_slot, eps, p2, q2, coef, raw, kl_min, dz1b, L, B, Np,

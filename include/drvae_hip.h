@@ -30,7 +30,7 @@ extern "C" {
 
 typedef void* dv_stream_t;
 
-#define DV_ABI_VERSION 9
+#define DV_ABI_VERSION 10
 
 enum { DV_OK = 0, DV_ERR_ARG = -1, DV_ERR_LAUNCH = -2, DV_ERR_UNSUPPORTED = -3 };
 
@@ -298,11 +298,20 @@ int dv_reparam_bwd(const float* dz, int64_t ldz, const float* eps, int64_t lde, 
                    int64_t lddq, float beta, dv_stream_t stream);
 /* CSR form of the backward: q row i (nq rows) sums the sample rows seg_rows[seg_ptr[i]..seg_ptr[i+1])
  * of dz/eps (any number of draws per q row), and optionally the row-aligned (dmu|dsd) contributions
- * `extra[ex_rows[t], :2Z]`, t in [ex_ptr[i], ex_ptr[i+1]).  dmu/dsd[i] = beta*old + sums. */
+ * `extra[ex_rows[t], :2Z]`, t in [ex_ptr[i], ex_ptr[i+1]).  dmu/dsd[i] = beta*old + sums.
+ * `add` (optional, ABI 10): a second gradient source for the first add->n sample rows, g[r] = dz[r] + add->dz[r] for
+ * r < add->n (VFAE: the classifier / fprop chain's share of d/dz1, which used to be summed into dz by a launch of its
+ * own); `park` (optional): the launch parks on another chain's flag first, like dv_z2f_post_bwd. */
+typedef struct dv_seg_add {
+    const float* dz;
+    int64_t ld;
+    int32_t n;
+} dv_seg_add;
 int dv_reparam_bwd_seg(const float* dz, int64_t ldz, const float* eps, int64_t lde, const float* sd, int64_t ldq,
                        const int32_t* seg_ptr, const int32_t* seg_rows, int32_t nq, int32_t Z, int32_t mode,
                        const float* extra, int64_t ldx, const int32_t* ex_ptr, const int32_t* ex_rows, float* dmu,
-                       float* dsd, int64_t lddq, float beta, const dv_bump* bump, dv_stream_t stream);
+                       float* dsd, int64_t lddq, float beta, const dv_bump* bump, const dv_seg_add* add,
+                       const dv_wait* park, dv_stream_t stream);
 /* Backward of everything hanging on the z2Fz1 samples (src/DrVAE.py:431-433, 459-487) in one pass
  * over (row i < B, dim d < Z), looping the L samples r = l*B + i; jp = pair_slot[i] (-1: singleton):
  *   g       = dz2f[r] (0 when dz2f == NULL: a model without a classifier) + (jp >= 0 ? dzdec_pert[l*Np + jp] : 0)
@@ -636,7 +645,7 @@ int dv_adamax_l2(float* p, const float* g, float* m, float* u, int64_t n, float 
                  float eps, float weight_decay, float gscale, const int32_t* step_dev, const int32_t* halt,
                  int32_t n_halt, dv_stream_t stream);
 int dv_counter_add(int32_t* counter_lo_hi, int32_t n_words, int64_t inc, dv_stream_t stream);
-/* Joins folded into their consumers: dv_z2f_post_bwd and dv_rows_segment_sum take an optional `park`
+/* Joins folded into their consumers: dv_z2f_post_bwd, dv_reparam_bwd_seg and dv_rows_segment_sum take an optional `park`
  * (every workgroup of the launch first parks like dv_flag_wait: the first consumer of another chain's
  * results waits for them itself, no separate wait launch; keep such grids well below the chip's resident
  * capacity), dv_reparam_bwd_seg an optional `bump` (the launch also advances up to two device counters

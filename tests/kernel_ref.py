@@ -241,10 +241,15 @@ def reparam_bwd(dmu, dsd, dz, eps, sd, *, mode=GAUSS_LOGVAR, src_idx=None, reps=
 
 
 def reparam_bwd_seg(dmu, dsd, dz, eps, sd, seg_ptr, seg_rows, *, mode=GAUSS_LOGVAR, extra=None, ex_ptr=None,
-                    ex_rows=None, beta=0.0, bump=None):
+                    ex_rows=None, beta=0.0, bump=None, dz_add=None, park=None):
+    if park is not None:
+        flag_wait(park[0], park[1], park[2], park[3] if len(park) > 3 else 1)
     for (c, inc) in (bump or ()):
         if c is not None:
             counter_add(c, inc)
+    if dz_add is not None:
+        dz = dz.clone()
+        dz[:dz_add.shape[0]] += dz_add
     nq, Z = seg_ptr.numel() - 1, dz.shape[1]
     for i in range(nq):
         rows = seg_rows[int(seg_ptr[i]):int(seg_ptr[i + 1])].long()

@@ -39,7 +39,7 @@ def test_library_exports_every_symbol(lib):
     for name in _header_decls():
         assert hasattr(lib, name), name
     from drvae_amd import _lib
-    assert lib.dv_abi_version() == _lib.ABI_VERSION == 9
+    assert lib.dv_abi_version() == _lib.ABI_VERSION == 10
     assert 'dv_arm_park' not in _lib.SIGNATURES and not hasattr(lib, 'dv_arm_park')     # no armed (hidden) state
     assert lib.dv_error_string(0) == b'ok'
     assert lib.dv_error_string(-1) == b'invalid argument'
