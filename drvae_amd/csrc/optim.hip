@@ -57,37 +57,45 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
                                                    const int32_t* __restrict__ halt, int n_halt) {
     __shared__ float sc[2];
     __shared__ int halted;
-    if (threadIdx.x == 0) {
-        adam_consts(lr, b1, b2, step_dev, &sc[0], &sc[1]);
-        halted = any_halt(halt, n_halt);
-    }
+    // only the workgroups whose elements overlap the gated range park (typically one): a parked
+    // workgroup or two can never starve the chain that is to publish
+    bool need = false;
     if (gate.flag != nullptr) {
-        // only the workgroups whose elements overlap the gated range park (typically one): a parked
-        // workgroup or two can never starve the chain that is to publish
         const int64_t per = vec4 ? 4 : 1, span = (int64_t)blockDim.x * per;
         const int64_t bstride = (int64_t)gridDim.x * span;
-        bool need = gate.hi > (vec4 ? ((n >> 2) << 2) : n) && gate.lo < n;       // the scalar tail (all workgroups sweep it)
+        need = gate.hi > (vec4 ? ((n >> 2) << 2) : n) && gate.lo < n;       // the scalar tail (all workgroups sweep it)
         for (int64_t e0 = blockIdx.x * span; e0 < n; e0 += bstride) need = need || (e0 < gate.hi && e0 + span > gate.lo);
+    }
+    if (threadIdx.x == 0) {
+        // (the gate's counter and flag and the error words are loaded FIRST: their round trips run under the two
+        // double-precision pow() of the bias corrections instead of behind them)
+        int want = 0, seen = 0;
         if (need) {
-            if (threadIdx.x == 0) {
-                const int want = gate.ctr[0] + gate.add;
-                const long long t0 = wall_clock64();
-                int k = 0;
-                while (__hip_atomic_load(gate.flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - want < 0) {
-                    __builtin_amdgcn_s_sleep(4);
-                    if (++k > gate.max_spins) {
-                        atomicExch(gate.err, 1);
-                        break;
-                    }
+            want = gate.ctr[0] + gate.add;
+            seen = __hip_atomic_load(gate.flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        int h = any_halt(halt, n_halt);
+        adam_consts(lr, b1, b2, step_dev, &sc[0], &sc[1]);
+        if (need && seen - want < 0) {
+            const long long t0 = wall_clock64();
+            int k = 0;
+            while (__hip_atomic_load(gate.flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - want < 0) {
+                __builtin_amdgcn_s_sleep(4);
+                if (++k > gate.max_spins) {
+                    atomicExch(gate.err, 1);
+                    break;
                 }
-                atomicAdd(gate.err + 1, (int32_t)(wall_clock64() - t0));
             }
+            atomicAdd(gate.err + 1, (int32_t)(wall_clock64() - t0));
             // one decision per workgroup, taken by the thread that waited (a per-thread re-read of the error words
             // could split a workgroup between updated and untouched elements)
-            if (threadIdx.x == 0) halted = halted || any_halt(halt, n_halt);
-            __syncthreads();
-            (void)__hip_atomic_load(gate.flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);   // every wave acquires
+            h = h || any_halt(halt, n_halt);
         }
+        halted = h;
+    }
+    if (need) {
+        __syncthreads();
+        (void)__hip_atomic_load(gate.flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);   // every wave acquires
     }
     __syncthreads();
     // a chain wait has timed out (now or in an earlier step): the gradients may be built on stale data --

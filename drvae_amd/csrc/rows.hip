@@ -1331,16 +1331,24 @@ __global__ __launch_bounds__(256) void batch_feed_kernel(
         const float* nz = noise ? noise + (int64_t)r * ldn : nullptr;
         float* dst = xin + (int64_t)r * ldo;
         if (vec4) {
-            for (int q = lane; q < (X >> 2); q += 64) {
-                float4 v = reinterpret_cast<const float4*>(src)[q];
-                if (nz) {
-                    const float4 e = reinterpret_cast<const float4*>(nz)[q];
-                    v.x = fmaf(sigma, e.x, v.x);
-                    v.y = fmaf(sigma, e.y, v.y);
-                    v.z = fmaf(sigma, e.z, v.z);
-                    v.w = fmaf(sigma, e.w, v.w);
+            // (a wave per row: four 16-B groups per lane in flight at a time -- a 978-gene row is ONE round trip of loads,
+            // not four load -> store iterations; this launch is the head of the step's critical path)
+            const int X4 = X >> 2;
+            for (int q0 = 0; q0 < X4; q0 += 256) {
+                float4 v[4], e[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int q = q0 + lane + 64 * u, qc = q < X4 ? q : X4 - 1;
+                    v[u] = reinterpret_cast<const float4*>(src)[qc];
+                    e[u] = nz ? reinterpret_cast<const float4*>(nz)[qc] : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
-                reinterpret_cast<float4*>(dst)[q] = v;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int q = q0 + lane + 64 * u;
+                    if (q < X4)
+                        reinterpret_cast<float4*>(dst)[q] = make_float4(fmaf(sigma, e[u].x, v[u].x), fmaf(sigma, e[u].y, v[u].y),
+                                                                        fmaf(sigma, e[u].z, v[u].z), fmaf(sigma, e[u].w, v[u].w));
+                }
             }
             for (int g = (X & ~3) + lane; g < X; g += 64) dst[g] = nz ? fmaf(sigma, nz[g], src[g]) : src[g];
         } else {
