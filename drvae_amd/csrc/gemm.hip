@@ -879,7 +879,7 @@ __global__ __launch_bounds__(256, BK == 32 ? DV_DENSE_WG : 4) void gemm_pair_ker
 // ---- the same three launch shapes with the hand-pipelined K loop (gemm_pipe.inc): PS ring slots, WPS workgroups' worth
 // of waves per SIMD the register allocation is held to
 template <int BM, int BN, int BK, int KS, bool AKC, bool BKC, int PS, int WPS>
-__global__ __launch_bounds__(64 * KS, WPS) void gemm_kpipe_kernel(const dv_gemm_desc g, const LoadCfg lc) {
+__global__ __launch_bounds__(64 * KS * (BM / 32) * (BN / 32), WPS) void gemm_kpipe_kernel(const dv_gemm_desc g, const LoadCfg lc) {
     __shared__ __attribute__((aligned(1024))) float smem[gemm_smem_floats<BM, BN, BK, KS, AKC, BKC, PS>()];
     publish_on_entry(g);
     gemm_body<BM, BN, BK, BM / 32, BN / 32, KS, AKC, BKC, false, false, PS>(g, lc, smem, blockIdx.x, gridDim.x);
@@ -948,7 +948,7 @@ int launch_kpipe(const dv_gemm_desc& g_in, const LoadCfg& lc, hipStream_t st) {
     dv_gemm_desc g = g_in;
     pipe_ones_off(g);
     const int tiles = ((g.M + BM - 1) / BM) * ((cols_eff(g) + BN - 1) / BN);
-    dim3 grid(tiles), block(64 * KS);
+    dim3 grid(tiles), block(64 * KS * (BM / 32) * (BN / 32));
     if (g.a_kcontig && g.b_kcontig)
         hipLaunchKernelGGL((gemm_kpipe_kernel<BM, BN, BK, KS, true, true, PS, WPS>), grid, block, 0, st, g, lc);
     else if (g.a_kcontig && !g.b_kcontig)
@@ -1073,6 +1073,12 @@ static int gemm_launch(const dv_gemm_desc& g_in, const LoadCfg& lc, int tiling, 
     if (tiling == 46 && pipe_ok(g, lc)) return launch_pipe<64, 64, 32, 2, 2, 3, 3>(g, lc, st);
     if (tiling == 46) return launch_cfg<64, 64, 32, 2, 2, 1>(g, lc, st);
 #ifdef DV_LAB
+    // 64-row / 64-column tiles of the K-split family: half / two thirds of the L2 -> LDS bytes per flop of the 32 x 32 tile
+    if (tiling == 60 && pipe_ok(g, lc)) return launch_kpipe<64, 32, 32, 2, 3, 4>(g, lc, st);
+    if (tiling == 61 && pipe_ok(g, lc)) return launch_kpipe<64, 32, 32, 2, 2, 6>(g, lc, st);
+    if (tiling == 62 && pipe_ok(g, lc)) return launch_kpipe<64, 32, 64, 4, 2, 3>(g, lc, st);
+    if (tiling == 63 && pipe_ok(g, lc)) return launch_kpipe<32, 64, 32, 2, 3, 4>(g, lc, st);
+    if (tiling == 64 && pipe_ok(g, lc)) return launch_kpipe<64, 64, 32, 2, 3, 2>(g, lc, st);
     if (tiling == 41) return launch_pipe<128, 128, 16, 2, 2, 3, 3>(g, lc, st);
     if (tiling == 42) return launch_pipe<128, 256, 16, 2, 2, 4, 1>(g, lc, st);
     if (tiling == 43) return launch_pipe<256, 128, 16, 2, 2, 3, 2>(g, lc, st);
