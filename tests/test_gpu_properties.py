@@ -351,4 +351,17 @@ def test_random_model_shapes_captured_step_vs_oracle(dev):
             for buf in (a.param, a.grad, a.exp_avg, a.exp_avg_sq):
                 for pad in a.pads(buf):
                     assert not pad.any(), kind
+        # ... and so are the pad columns of every row-padded activation buffer of the plan and of its layer chains
+        # (nothing may write past a row's live columns: the next product reads them as part of K)
+        from drvae_amd.chain import _Chain, _whole_rows
+        for e in (eng, e0, e1):
+            bufs = [v for v in vars(e.plan).values() if torch.is_tensor(v)]
+            for c in (v for v in vars(e.plan).values() if isinstance(v, _Chain)):
+                bufs += list(c.out) + list(c.dpre)
+            n_pad = 0
+            for t in bufs:
+                if t.dim() == 2 and t.dtype == torch.float32 and _whole_rows(t) and t._base.shape[1] != t.shape[1]:
+                    n_pad += 1
+                    assert not t._base[:, t.shape[1]:].any(), (kind, tuple(t.shape))
+            assert n_pad > 0
     run()

@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""What a fused epilogue (bias, ELU, identity | softplus heads) costs the 128 x 256 LDS-DMA kernel next to the plain one,
+per shape (GPU box only)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import drvae_amd.kernels as K
