@@ -247,6 +247,50 @@ def test_gemm_split_sources_residual_strided(K, dev):
         close(dW, rW, rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize('M,N,Kd', [(224, 800, 978), (450, 200, 102), (37, 50, 18), (600, 1956, 601), (8192, 800, 978)])
+def test_gemm_over_padded_k_and_n(K, dev, M, N, Kd):
+    """``kpad`` / ``npad``: operands whose rows are zero-padded to 16 B (the plan's activation buffers, the arena's
+    weights) multiply over the padded K / N -- the LDS-DMA kernels take them -- with the result of the unpadded product;
+    pad columns of the outputs receive zeros only."""
+    pad4 = lambda n: (n + 3) // 4 * 4
+    def mat(r, c, seed, scale=1.0):
+        t = torch.zeros(r, pad4(c), device=dev)
+        t[:, :c] = rnd(dev, r, c, seed=seed, scale=scale)
+        return t[:, :c]
+    x, W, b = mat(M, Kd, 1), mat(N, Kd, 2, scale=Kd ** -0.5), rnd(dev, N, seed=3)       # (heads of O(1): the sample is mu + eps exp(lv / 2))
+    out, ref = mat(M, N, 4), torch.empty(M, N, device=dev)
+    tol = gemm_tol(Kd)
+    K.linear_fwd(out, x, W, b, act0='elu', act1='elu', overread=True, kpad=True)
+    R.linear_fwd(ref, x, W, b, act0='elu', act1='elu')
+    close(out, ref, **tol)
+    K.gemm(out, x, W, True, True, overread=True, kpad=True)
+    R.gemm(ref, x, W, True, True)
+    close(out, ref, **tol)
+    if N % 2 == 0:        # the dual-head launch with samples in its epilogue
+        eps, z, rz = rnd(dev, M, N // 2, seed=5), mat(M, N // 2, 6), torch.empty(M, N // 2, device=dev)
+        kw = dict(split=N // 2, act0='identity', act1='identity', sample=dict(eps=eps, out=z, n_src=M))
+        K.linear_heads(out, x, W, b, overread=True, kpad=True, **kw)
+        kw['sample'] = dict(eps=eps, out=rz, n_src=M)
+        R.linear_heads(ref, x, W, b, **kw)
+        close(out, ref, **tol)
+        close(z, rz, **tol)
+    # backward: dW = dpre^T x and dx = dpre W over the padded N (N here = Kd, the layer's input width)
+    dpre = mat(M, N, 7)
+    dW, rW, db, rdb = mat(N, Kd, 8), torch.empty(N, Kd, device=dev), torch.zeros(N, device=dev), torch.zeros(N, device=dev)
+    dx, rx = mat(M, Kd, 9), torch.empty(M, Kd, device=dev)
+    K.linear_bwd_pair(dW, db, dx, dpre, x, W, overread=True, npad=True, npad_x=True)
+    R.linear_bwd_pair(rW, rdb, rx, dpre, x, W)
+    close(dW, rW, **gemm_tol(M))
+    close(db, rdb, **gemm_tol(M))
+    close(dx, rx, **gemm_tol(N))
+    K.linear_bwd_weight(dW, dpre, x, dbias=db, overread=True, npad=True)
+    close(dW, rW, **gemm_tol(M))
+    K.linear_bwd_data(dx, dpre, W, overread=True, npad=True)
+    close(dx, rx, **gemm_tol(N))
+    for t in (out, dW, dx, z if N % 2 == 0 else out):
+        assert not t._base[:, t.shape[1]:].any()
+
+
 @pytest.mark.parametrize('act', ['elu', 'softplus', 'sigmoid', 'tanh', 'relu', 'leaky_relu', 'selu', 'softsign'])
 def test_activations(K, dev, act):
     M, N, Kd = 33, 47, 8
