@@ -951,7 +951,7 @@ class FusedStep(StepSchedule):
         # its side chain is the longer one, 30 us/step -- slows the very chain it waits for: 0.184 -> 0.208 ms)
         # ... and only where the parked grid is a small fraction of what the chip holds resident (256 CUs x 8
         # workgroups): a consumer grid that filled the chip would leave the side chain nowhere to run
-        fold_join = (mode == 5 and side_adam and self.fold_join and cfg.has_pert
+        fold_join = (mode == 5 and side_loss and self.fold_join and cfg.has_pert
                      and (B * Z1 + 255) // 256 <= 256)
         park = bump = None
         if fold_join:
