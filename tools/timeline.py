@@ -15,6 +15,20 @@ if len(gath) < 8:
 grids = [rows[i].get('Grid_Size', rows[i].get('Grid_Size_X', '0')) for i in gath]
 big = max(grids, key=lambda g: int(g)) if grids else '0'
 starts = [i for i, g in zip(gath, grids) if g == big][:-3]
+# (feed-ahead: two feed launches per step -- the side chain's, which feeds, and the main chain's check; a period is from one
+# feed launch on the main chain's queue to the next one there)
+q_main = rows[gath[0]]['Queue_Id'] if gath else None
+if starts and len(set(rows[i]['Queue_Id'] for i in starts)) > 1:
+    cnt = {}
+    for i in starts:
+        cnt[rows[i]['Queue_Id']] = cnt.get(rows[i]['Queue_Id'], 0) + 1
+    # the main chain's queue is the one that also runs the optimiser launch right in front of its feed launch
+    for q in cnt:
+        idx = [i for i in starts if rows[i]['Queue_Id'] == q]
+        prev = [r['Kernel_Name'] for r in rows[:idx[-1]] if r['Queue_Id'] == q][-1:]
+        if prev and 'adam' in prev[0]:
+            starts = idx
+            break
 a, b = starts[-2], starts[-1]
 step = rows[a:b]
 t0 = int(step[0]['Start_Timestamp'])
