@@ -108,10 +108,14 @@ __device__ __forceinline__ void park_block(const dv_wait& pk) {
                 break;
             }
         }
-        if (blockIdx.x == 0) pk.err[1] += (int32_t)(wall_clock64() - t0);
+        // (ticks parked: a no-return atomic -- a read-modify-write here would put one more round trip in front of the barrier)
+        if (blockIdx.x == 0) atomicAdd(pk.err + 1, (int32_t)(wall_clock64() - t0));
     }
     __syncthreads();
-    (void)__hip_atomic_load(pk.flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);   // every wave acquires
+    // every wave acquires: thread 0's acquire load has seen the flag (and invalidated this CU's vector L1 behind it); an
+    // acquire FENCE for the others -- the cache invalidate without another trip to memory (the acquire load it replaces was
+    // a round trip of ~1 us at the head of every parked launch)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
 
 

@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     }
     if (need) {
         __syncthreads();
-        (void)__hip_atomic_load(gate.flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);   // every wave acquires
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // every wave acquires (see park_block)
     }
     __syncthreads();
     // a chain wait has timed out (now or in an earlier step): the gradients may be built on stale data --
@@ -433,7 +433,7 @@ __global__ void flag_wait_kernel(int32_t* flag, const int32_t* ctr, int add, int
             break;
         }
     }
-    err[1] += (int32_t)(wall_clock64() - t0);   // time parked, in constant-clock ticks (tuning statistic)
+    atomicAdd(err + 1, (int32_t)(wall_clock64() - t0));   // time parked, in constant-clock ticks (tuning statistic; no-return atomic)
 }
 
 extern "C" int dv_flag_publish(int32_t* flag, const int32_t* ctr, int32_t add, dv_stream_t stream) {

@@ -1614,10 +1614,10 @@ __global__ __launch_bounds__(kLossThreads) void loss_assemble_kernel(LossTerms l
                     break;
                 }
             }
-            err[1] += (int32_t)(wall_clock64() - t0);
+            atomicAdd(err + 1, (int32_t)(wall_clock64() - t0));
         }
         __syncthreads();
-        (void)__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);   // every wave acquires
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // every wave acquires (see park_block)
     }
     // every term's per-thread partial sum first -- all loads of all terms are independent and in flight together
     // (this is ONE workgroup: its time is the number of dependent load round trips) -- then one reduction stage;
