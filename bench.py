@@ -191,7 +191,7 @@ def parity_vs_cpu(workload, device, steps=2):
 
 
 def gemm_roofline(eng, cfg, rows, frac_pair, frac_lab, repeats=20, workload='cfg2', n_params=0, input_bytes=0,
-                  ms_per_step=None, brief=False):
+                  ms_per_step=None, brief=False, steady_ms=None):
     """Roofline of the dominant kernel family: the fp32-MFMA GEMM (all tilings/layouts; 32
     launches per cfg-2 step).  Every GEMM launch of one train step is re-issued `repeats`
     times back to back from a small hipGraph and timed with HIP events recorded on the
@@ -271,16 +271,22 @@ def gemm_roofline(eng, cfg, rows, frac_pair, frac_lab, repeats=20, workload='cfg
            'how': 'live: every GEMM-family launch of one step re-issued %dx back to back from a hipGraph on an idle, '
                   'un-partitioned chip, HIP events on the launch stream; achieved = algorithmic GEMM FLOPs per step / sum '
                   'of the per-launch times (= avg FLOPs per launch / avg launch duration)' % repeats}
-    out = {'bound': 'mfma', 'achieved': iso['achieved'], 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-           'frac': iso['frac'], 'source': 'live, isolated launches (see isolated.how); in_graph: the committed profile of the running step',
-           'kernel': 'gemm_kernel / gemm_pair_kernel / gemm_heads_kernel<...> (fp32 v_mfma_f32_32x32x2_f32; all tilings/layouts)',
+    # ONE definition of the headline figure (round 5): the step's algorithmic GEMM FLOPs over THIS LINE's ms_per_step --
+    # the contract's timed region, everything that is not a GEMM included -- over the fp32-MFMA peak; a reader recomputes
+    # it from the line: frac = algorithmic_gflop_per_step / ms_per_step / 1e3 / peak.  The kernel-level figures keep keys of
+    # their own: `isolated` (this run, launches re-issued alone), `in_graph` (the committed profile of the running step)
+    a_line = algorithmic / (ms_per_step * 1e-3) / 1e12
+    out = {'bound': 'mfma', 'achieved': round(a_line, 3), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+           'frac': round(a_line / FP32_MFMA_PEAK_TFLOPS, 4), 'ms_per_step': ms_per_step,
+           'definition': 'achieved = algorithmic_gflop_per_step / ms_per_step (this line\'s timed region, whole step); '
+                         'frac = achieved / peak',
+           'kernel': 'gemm_pipe_kernel / gemm_pair_pipe_kernel / gemm_heads_pipe_kernel<...> (fp32 v_mfma_f32_32x32x2_f32; all tilings/layouts)',
            'algorithmic_gflop_per_step': round(algorithmic / 1e9, 3),
            'executed_gflop_per_step': round(executed / 1e9, 3),
            'isolated': iso, 'traffic': None}
-    if ms_per_step:      # the same FLOPs over the whole step's wall time (everything that is not a GEMM included)
-        a3 = algorithmic / (ms_per_step * 1e-3) / 1e12
-        out['step_level'] = {'achieved': round(a3, 3), 'frac': round(a3 / FP32_MFMA_PEAK_TFLOPS, 4),
-                             'ms_per_step': ms_per_step}
+    if steady_ms:        # the longer region of the same replays (>= 3 s): its own key, never the headline
+        a3 = algorithmic / (steady_ms * 1e-3) / 1e12
+        out['steady'] = {'achieved': round(a3, 3), 'frac': round(a3 / FP32_MFMA_PEAK_TFLOPS, 4), 'ms_per_step': steady_ms}
     def in_graph(ig):
         # (a PROFILE of an earlier run of this command, not a measurement of the build being run: its own key, with the
         # commit it was collected at; `achieved` / `frac` above are this run's live figures)
@@ -420,20 +426,22 @@ def measure(args, workload, feed, steps, warmup, device, rank, world, steady_s=0
     k_batch = [0]                                    # batch of the table the NEXT replay gathers
     if feed != 'resident':
         from drvae_amd import data as DD, synth
-        big = synth.make_batch(kind, args.dataset_rows, cfg.dim_x, cfg.dim_y, seed=77 + rank)
+        # (data parallelism: every rank holds the same dataset and batcher seed -- they draw the same global index
+        # table and run their own columns of it)
+        big = synth.make_batch(kind, args.dataset_rows, cfg.dim_x, cfg.dim_y, seed=77)
         tt = lambda k: torch.from_numpy(big[k]).to(device)
         ds = DD.DrVAEDataset(tt('x1'), tt('x2'), torch.zeros(args.dataset_rows, dtype=torch.int64, device=device),
                              tt('y'), tt('has_x2'), tt('has_y'))
         hx, hy = batch['has_x2'].astype(bool), batch['has_y'].astype(bool)
         gc = [int(((hy == bool(gy)) & (hx == bool(gx))).sum()) for (gy, gx) in DD._GROUPS]
         if feed == 'sampler':
-            bat = DD.DeviceBatcher(ds, torch.ones(args.dataset_rows), rows, seed=5 + rank, mode='sampler',
+            bat = DD.DeviceBatcher(ds, torch.ones(args.dataset_rows), rows, seed=5, mode='sampler',
                                    pair_bucket=args.pair_bucket or None,
                                    label_bucket=(max(8, rows // 3 // 8 * 8) if args.label_bucket < 0 else args.label_bucket) or None)
-            bat.bind(eng)
+            bat.bind(eng, dp=(rank, world) if dp else None)
         else:
-            bat = DD.DeviceBatcher(ds, torch.ones(args.dataset_rows), rows, group_counts=gc, seed=5 + rank)
-            bat.bind(eng, counts=(world * rows, world * int(hx.sum()), world * int(hy.sum())))
+            bat = DD.DeviceBatcher(ds, torch.ones(args.dataset_rows), rows, group_counts=gc, seed=5)
+            bat.bind(eng, dp=(rank, world) if dp else None)
         if feed in ('epoch', 'sampler'):
             bat.begin_epoch(n_batches=n_table[0])
         else:
@@ -707,7 +715,8 @@ def main():
                                             repeats=20 if args.workload != 'wide' else 3, workload=args.workload,
                                             n_params=out['config']['params'],
                                             input_bytes=4.0 * rows * cfg.dim_x * (2 if cfg.has_pert else 1),
-                                            ms_per_step=(res['steady_state'] or res)['ms_per_step'])
+                                            ms_per_step=res['ms_per_step'],
+                                            steady_ms=(res['steady_state'] or {}).get('ms_per_step'))
         if not args.no_cpu_baseline and args.workload != 'wide' and world == 1:   # rank 0 at N=1 only
             out['cpu_baseline'] = cpu_baseline(args.workload)
             out['elbo_vs_ref'] = parity_vs_cpu(args.workload, device)
@@ -766,7 +775,15 @@ def main():
                                                   workload=wl, n_params=r3['config']['params'],
                                                   input_bytes=4.0 * c3['rows'] * c3['cfg'].dim_x * (2 if c3['cfg'].has_pert else 1),
                                                   ms_per_step=r3['ms_per_step'], brief=True)
-            out['other_workloads'][{'wide': 'cfg5'}.get(wl, wl)] = entry
+            name = {'wide': 'cfg5'}.get(wl, wl)
+            out['other_workloads'][name] = entry
+            if 'roofline' in entry and 'roofline' in out:
+                # the driver keeps `roofline` whole: every configuration's step-level figure rides in it, same definition
+                rf = entry['roofline']
+                out['roofline'].setdefault('workloads', {})[name] = {
+                    'ms_per_step': r3['ms_per_step'], 'steps': k_, 'frac': rf['frac'], 'achieved': rf['achieved'],
+                    'algorithmic_gflop_per_step': rf['algorithmic_gflop_per_step'],
+                    'isolated_frac': rf['isolated']['frac'], 'value': r3['value']}
             ok = ok and r3['finite']
             del c3
     import torch.distributed as dist

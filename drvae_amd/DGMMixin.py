@@ -19,6 +19,8 @@ from .arena import ParamArena
 class DeepGenerativeModelMixin:
     def w2log(self, *args):
         """print, and append to logs/<log_txt> when set (src/DGMMixin.py:20-29)."""
+        if self.dp_rank != 0:          # data parallelism: rank 0 speaks for the job
+            return
         if getattr(self, 'verbose_log', False):
             print(*args)
         if getattr(self, 'log_txt', None) is not None:
@@ -35,9 +37,62 @@ class DeepGenerativeModelMixin:
             raise ValueError('Selected unknown optimizer: ' + str(self.optim_alg))
         self.optimizer = None          # kept for attribute parity; the state lives in the arena
         self._engine = None
+        self.__dict__.pop('_eval_graphs', None)
 
     def _step_config(self):
         raise NotImplementedError
+
+    # ------------------------------------------------------------ data parallelism
+    _dp = None            # (rank, world) once ``enable_data_parallel`` has been called
+    _allreduce = None     # the gradient exchange of a train step: callable(flat exchange buffer) | None
+
+    def enable_data_parallel(self, rank=None, world=None, backend=None, broadcast=True):
+        """Train this model data-parallel, one process per GPU (the reference has no distributed code).
+        ``rank`` / ``world`` default to the environment of the launcher (RANK / WORLD_SIZE / MASTER_*: ``torchrun`` or
+        ``python -m torch.distributed.run``); the process group is created if there is none (``backend``: 'nccl' = RCCL
+        on GPUs, 'gloo' elsewhere).  From here on
+
+        * ``run_on_batch(train_mode=True, ...)`` takes THIS RANK's rows of the global minibatch: the loss normalisers
+          (N_total, N_pairs, N_labeled, src/DrVAE.py:611-616) are the global batch's (one tiny host all-reduce of the
+          three counts), the flat buffer [loss scalars | gradients] is summed over the ranks by ONE all-reduce and every
+          rank applies the identical fused Adam step -- the job trains like one process on the concatenated batch;
+        * ``fit(DeviceBatcher(..., batch_size=rows per rank), ...)`` binds the batcher with ``dp=(rank, world)``: every
+          rank draws the same global index table from the shared seed and runs its columns; the global counts of every
+          batch are table data (no collective but the gradient exchange); captured split graphs + the exchange per step;
+        * evaluation (``run_on_batch(train_mode=False)``, ``evaluate_performance_on_dataset``) is NOT sharded: every rank
+          evaluates what it is given with the same draws, so early stopping decides the same on every rank; only rank 0
+          writes snapshots and log lines.
+
+        ``broadcast``: parameters, Adam moments and the step / Philox counters of rank 0 go to every rank first.
+        Returns (rank, world).  A one-rank world (or none) leaves the model single-process unless DRVAE_FORCE_DP=1."""
+        from . import dist as D
+        if rank is None or world is None:
+            rank, world, _ = D.init_from_env(backend)
+        rank, world = int(rank), int(world)
+        assert 0 <= rank < max(world, 1)
+        if getattr(self, 'use_MMD', False) and world > 1:
+            raise NotImplementedError('use_MMD: the model-level MMD penalty compares every row of a nuisance class with '
+                                      'every other row of the batch: it cannot be sharded over ranks')
+        active = world > 1 or D.force_dp()
+        self._dp = (rank, world) if active else None
+        self._allreduce = D.allreduce_sum if active else None
+        if active and broadcast:
+            eng = self.engine()
+            eng.join_side()
+            for t in (eng.arena.param, eng.arena.exp_avg, eng.arena.exp_avg_sq, eng.step_dev, eng.rng_ctr):
+                D.broadcast(t)
+            eng.sync_side_counters()
+            self.finished_training_iters = int(D.broadcast_int(self.finished_training_iters))
+        return rank, world
+
+    def disable_data_parallel(self):
+        self._dp = self._allreduce = None
+        if getattr(self, '_engine', None) is not None:
+            self._engine.row0 = 0
+
+    @property
+    def dp_rank(self):
+        return self._dp[0] if self._dp else 0
 
     def engine(self):
         """Build (once) the parameter arena + fused step engine on the model's device."""
@@ -97,6 +152,7 @@ class DeepGenerativeModelMixin:
         if getattr(self, '_engine', None) is not None and not self._arena_aliased():
             self._stash_optimizer_state()
             self._engine = self._arena = None      # rebuilt (and the parameters re-adopted) by engine()
+            self.__dict__.pop('_eval_graphs', None)    # (captured evaluations point into the retired arena / plans)
         return out
 
     def load_state_dict(self, state_dict, strict=True, assign=False):
@@ -129,15 +185,27 @@ class DeepGenerativeModelMixin:
         return E.anneal_coef(iter_num, iter_max, iter_offset)
 
     # -------------------------------------------------------------------- the step
-    def _batch_to_engine(self, x1, x2=None, s=None, y=None, has_x2=None, has_y=None):
+    def _batch_to_engine(self, x1, x2=None, s=None, y=None, has_x2=None, has_y=None, dp=False):
+        """``dp``: the rows are this rank's share of a global minibatch (train steps under ``enable_data_parallel``):
+        global normalisers, Philox draws keyed by the row's global position; otherwise a batch of its own"""
         eng = self.engine()
         n = x1.shape[0]
         dev = eng.dev
         x1 = x1.to(dev, torch.float32).contiguous()
         x2 = x2.to(dev, torch.float32).contiguous() if x2 is not None else None
         zeros = torch.zeros(n, dtype=torch.int64)
-        eng.set_batch(x1, x2, y, has_x2 if has_x2 is not None else zeros, has_y if has_y is not None else zeros,
-                      counts=getattr(self, '_global_counts', None), s=s if eng.cfg.use_s else None)
+        has_x2 = has_x2 if has_x2 is not None else zeros
+        has_y = has_y if has_y is not None else zeros
+        counts = getattr(self, '_global_counts', None)
+        eng.row0 = 0
+        if dp and self._dp is not None:
+            from . import dist as D
+            eng.row0 = self._dp[0] * n          # (every rank feeds the same number of rows: ``shard_rows``)
+            if counts is None:
+                counts = D.global_counts(has_x2.cpu() if torch.is_tensor(has_x2) else has_x2,
+                                         has_y.cpu() if torch.is_tensor(has_y) else has_y, eng.cfg.kind,
+                                         eng.cfg.semi_supervised)
+        eng.set_batch(x1, x2, y, has_x2, has_y, counts=counts, s=s if eng.cfg.use_s else None)
         return eng
 
     def _loss_tensors(self, eng):
@@ -170,10 +238,10 @@ class DeepGenerativeModelMixin:
             self.eval()
             return self.loss_function(noise=noise, **kwargs)
         self.train()
-        eng = self._batch_to_engine(**kwargs)
+        eng = self._batch_to_engine(dp=True, **kwargs)
         eng.add_noise = bool(getattr(self, 'add_noise', False))
         eng.iters = self.finished_training_iters
-        eng.train_step(noise, allreduce=getattr(self, '_allreduce', None))
+        eng.train_step(noise, allreduce=self._allreduce)
         self.finished_training_iters = eng.iters
         return self._loss_tensors(eng)
 

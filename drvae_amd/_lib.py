@@ -75,7 +75,22 @@ class BatchMasks(C.Structure):   # dv_batch_masks_desc
                 ('n_tot', C.c_float), ('kl_rate', C.c_float), ('pert_rate', C.c_float), ('yl_rate', C.c_float),
                 ('beta', C.c_void_p), ('c_nll', C.c_void_p), ('c_klz2', C.c_void_p), ('c_yl', C.c_void_p),
                 ('w_recl', C.c_void_p), ('w_pert', C.c_void_p), ('w_yl', C.c_void_p), ('label', C.c_void_p),
-                ('c_klp', C.c_void_p), ('one_slot', C.c_void_p)]
+                ('c_klp', C.c_void_p), ('one_slot', C.c_void_p), ('gcounts', C.c_void_p)]
+
+
+class BatchFeed(C.Structure):    # dv_batch_feed_desc
+    _fields_ = [('x1', _p), ('ld1', _i64), ('x2', _p), ('ld2', _i64), ('y', _p), ('table', _p), ('n_batches', _i32),
+                ('ctr', _p), ('base', _p), ('B', _i32), ('pair_rows', _p), ('Np', _i32), ('X', _i32), ('noise', _p),
+                ('ldn', _i64), ('sigma', _f), ('xin', _p), ('ldo', _i64), ('has_y', _p), ('L', _i32), ('label_r', _p),
+                ('fp_i', _p), ('fp_lab', _p), ('fp_slot', _p), ('Mf', _i32), ('fp_cls', _p), ('onehot', _p),
+                ('ldh', _i64), ('Y', _i32), ('yf', _p), ('ylab', _p), ('Yc', _i32), ('onehot2', _p), ('ldh2', _i64)]
+
+
+class KlRows(C.Structure):       # dv_kl_rows_desc
+    _fields_ = [('mu_q', _p), ('sd_q', _p), ('ldq', _i64), ('qidx', _p), ('mu_p', _p), ('sd_p', _p), ('ldp', _i64),
+                ('pidx', _p), ('prior_mu', _f), ('prior_sd', _f), ('n', _i32), ('reps', _i32), ('Z', _i32), ('mode', _i32),
+                ('free_bits', _i32), ('kl_min', _f), ('raw_out', _p), ('out', _p), ('add', _p), ('eps', _p), ('lde', _i64),
+                ('zout', _p), ('ldz', _i64), ('mu2', _p), ('sd2', _p), ('ld2', _i64), ('Z2', _i32), ('raw2_out', _p)]
 
 
 class LossTerm(C.Structure):
@@ -105,8 +120,7 @@ SIGNATURES = {
     'dv_z2f_post_bwd': [_p, _i64, _p, _i64, _p, _p, _i64, _p, _i64, _p, _i64, _p, _p, _f, _p, _i64, _p, _i64, _p, _i64,
                         _p, _i64, _i32, _i32, _i32, _i32, C.POINTER(Wait), _p],
     'dv_reparam_bwd': [_p, _i64, _p, _i64, _p, _i64, _p, _i32, _i32, _i32, _i32, _p, _p, _i64, _f, _p],
-    'dv_kl_rows_fwd': [_p, _p, _i64, _p, _p, _p, _i64, _p, _f, _f, _i32, _i32, _i32, _i32, _i32, _f, _p, _p, _p, _p,
-                       _i64, _p, _i64, C.POINTER(Wait), _p, _p, _i64, _i32, _p, _p],
+    'dv_kl_rows_fwd': [C.POINTER(KlRows), C.POINTER(Wait), _p],
     'dv_kl_rows_bwd': [_p, _p, _i32, _f, _p, _p, _i64, _p, _p, _p, _i64, _p, _f, _f, _i32, _i32, _i32, _i32,
                        _p, _p, _i64, _p, _p, _i64, _f, _p, _i64, _p, _i64, _p],
     'dv_gauss_nll_rows_fwd': [_p, _i64, _p, _p, _p, _i64, _i32, _i32, _i32, _p, _p],
@@ -133,16 +147,14 @@ SIGNATURES = {
     'dv_mmd_rff_fwd': [_p, _i64, _i32, _p, _i64, _i32, _i32, _f, _p, _p, _p],
     'dv_mmd_rff_bwd': [_p, _i64, _i32, _i32, _p, _p, _f, _p, _i64, _p],
     'dv_rows_gather': [_p, _i64, _p, _i32, _i32, _p, _i64, _f, _p, _i32, _p, _i64, C.POINTER(Wait), _p],
-    'dv_batch_feed': [_p, _i64, _p, _i64, _p, _p, _i32, _p, _p, _i32, _p, _i32, _i32, _p, _i64, _f, _p, _i64, _p, _i32,
-                      _p, _p, _p, _p, _i32, _p, _p, _i64, _i32, _p, _p, _i32, _p, _i64, C.POINTER(BatchMasks), C.POINTER(Wait), _p],
-    'dv_batch_masks': [_p, _i32, _p, _p, _p, _p, _p, _i32, _i32, _i32, _f, _f, _f, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
+    'dv_batch_feed': [C.POINTER(BatchFeed), C.POINTER(BatchMasks), C.POINTER(Wait), _p],
+    'dv_batch_masks': [C.POINTER(BatchMasks), _p, _i32, _p, _p, _i32, _i32, _p],
     'dv_rows_segment_sum': [_p, _i64, _p, _p, _p, _i32, _i32, _p, _p, _i64, _f, C.POINTER(Wait), _p],
     'dv_weighted_sum': [_p, _p, _p, _i32, _f, _p, _f, _p],
     'dv_recon_row_stats': [_p, _i64, _p, _i64, _i32, _i32, _p, _p],
     'dv_col_moments': [_p, _i64, _p, _i64, _i32, _i32, _p, _i32, _p],
     'dv_loss_assemble': [C.POINTER(LossTerm), _i32, _p, _p, _p, _p, _i32, _p, _p],
-    'dv_loss_assemble_after': [_p, _p, _i32, _p, _i32, C.POINTER(LossTerm), _i32, _p, _p, _p, _p, _i32, _i64, _p, _i32,
-                               _i64, _p, _i32, _p, _p],
+    'dv_loss_assemble_after': [C.POINTER(Wait), C.POINTER(LossTerm), _i32, _p, _p, _p, C.POINTER(Bump), _p, _i32, _p, _p],
     'dv_axpby': [_p, _f, _p, _f, _i64, _p],
     'dv_adam_l2': [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _f, _p, _p, _i32, _p],
     'dv_adam_l2_gated': [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _f, _p, _p, _p, _i32, _p, _i32, _i64, _i64, _p,
@@ -157,7 +169,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 10    # DV_ABI_VERSION of include/drvae_hip.h
+ABI_VERSION = 11    # DV_ABI_VERSION of include/drvae_hip.h
 
 
 def load():

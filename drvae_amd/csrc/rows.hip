@@ -1240,6 +1240,7 @@ struct MaskArgs {
     int32_t* label;   // (L B): -2 - class for labeled rows, 0 otherwise (see ymarg_*_kernel)
     float* c_klp;     // (2 B), optional: KL-to-prior rows of q(z1|x1) | q(z2|x2) (PVAE, src/PVAE.py:330-345)
     const int32_t* one_slot;   // (B), optional: rows of the plan with ONE class slot (labeled for sure): label = class
+    const int32_t* gcounts;    // (n_batches, 2), optional: GLOBAL (N_pairs, N_labeled) of every batch (data parallelism)
 };
 
 __device__ __forceinline__ void batch_masks_body(const MaskArgs& a) {
@@ -1247,20 +1248,27 @@ __device__ __forceinline__ void batch_masks_body(const MaskArgs& a) {
     if (threadIdx.x < 2) cnt[threadIdx.x] = 0;
     __syncthreads();
     const int32_t* tb = nullptr;
+    int b = 0;
     if (a.table) {
-        int b = a.ctr[0] - a.base[0];
+        b = a.ctr[0] - a.base[0];
         b = b < 0 ? 0 : (b >= a.n_batches ? a.n_batches - 1 : b);
         tb = a.table + (int64_t)b * a.B;
     }
-    int np = 0, nl = 0;
-    for (int i = threadIdx.x; i < a.B; i += blockDim.x) {
-        const int src = tb ? tb[i] : i;
-        np += (a.hx && a.hx[src] != 0) ? 1 : 0;
-        nl += (a.hy && a.hy[src] != 0) ? 1 : 0;
+    if (a.gcounts) {
+        // data parallelism: this rank runs a slice of the global batch; the normalisers are the GLOBAL counts of the batch
+        // (table data: every rank drew the same global table), not this slice's own
+        if (threadIdx.x < 2) cnt[threadIdx.x] = a.gcounts[2 * b + threadIdx.x];
+    } else {
+        int np = 0, nl = 0;
+        for (int i = threadIdx.x; i < a.B; i += blockDim.x) {
+            const int src = tb ? tb[i] : i;
+            np += (a.hx && a.hx[src] != 0) ? 1 : 0;
+            nl += (a.hy && a.hy[src] != 0) ? 1 : 0;
+        }
+        // integer counts: order-independent, so atomics keep the step reproducible
+        if (np) atomicAdd(&cnt[0], np);
+        if (nl) atomicAdd(&cnt[1], nl);
     }
-    // integer counts: order-independent, so atomics keep the step reproducible
-    if (np) atomicAdd(&cnt[0], np);
-    if (nl) atomicAdd(&cnt[1], nl);
     __syncthreads();
     const float Lf = (float)a.L, beta = a.beta ? a.beta[0] : 1.f;
     const float n_pairs = cnt[0] > 0 ? (float)cnt[0] : 1.f, n_lab = cnt[1] > 0 ? (float)cnt[1] : 1.f;
@@ -1870,25 +1878,22 @@ extern "C" int dv_z2f_post_bwd(const float* dz2f, int64_t ld_dz2f, const float* 
     DV_RETURN_LAUNCH();
 }
 
-extern "C" int dv_kl_rows_fwd(const float* mu_q, const float* sd_q, int64_t ldq, const int32_t* qidx,
-                              const float* mu_p, const float* sd_p, int64_t ldp, const int32_t* pidx,
-                              float prior_mu, float prior_sd, int32_t n, int32_t reps, int32_t Z, int32_t mode,
-                              int32_t free_bits, float kl_min, float* raw_out, float* out, const float* add,
-                              const float* eps, int64_t lde, float* zout, int64_t ldz, const dv_wait* park_in,
-                              const float* mu2, const float* sd2, int64_t ld2, int32_t Z2, float* raw2_out,
-                              dv_stream_t stream) {
-    DV_REQUIRE(n >= 0 && reps >= 0 && Z >= 0 && park_ok(park_in));
-    DV_REQUIRE((mu2 == nullptr) == (sd2 == nullptr) && (mu2 == nullptr || Z2 >= 0));
+extern "C" int dv_kl_rows_fwd(const dv_kl_rows_desc* dsc, const dv_wait* park_in, dv_stream_t stream) {
+    DV_REQUIRE(dsc != nullptr);
+    const dv_kl_rows_desc& d = *dsc;
+    DV_REQUIRE(d.n >= 0 && d.reps >= 0 && d.Z >= 0 && park_ok(park_in));
+    DV_REQUIRE((d.mu2 == nullptr) == (d.sd2 == nullptr) && (d.mu2 == nullptr || d.Z2 >= 0));
     const ParkArgs park = park_in ? *park_in : ParkArgs{};
-    DV_REQUIRE(park.flag == nullptr || (n > 0 && reps > 0));
-    if (park.flag != nullptr && grid_for((int64_t)n * reps, 4) > DV_MAX_PARKED_GRID) return DV_ERR_UNSUPPORTED;
-    if (n == 0 || reps == 0) return DV_OK;
-    DV_REQUIRE(mu_q && sd_q && out);
-    DV_REQUIRE((mu_p == nullptr) == (sd_p == nullptr));
-    DV_REQUIRE(zout == nullptr || eps != nullptr);
-    KlArgs a{mu_q, sd_q, ldq, qidx, mu_p, sd_p, ldp, pidx, prior_mu, prior_sd, n, reps, Z, mode};
-    hipLaunchKernelGGL(kl_rows_fwd_kernel, dim3(grid_for((int64_t)n * reps, 4)), dim3(256), 0, ST(stream), a,
-                       free_bits, kl_min, raw_out, out, add, eps, lde, zout, ldz, park, mu2, sd2, ld2, Z2, raw2_out);
+    DV_REQUIRE(park.flag == nullptr || (d.n > 0 && d.reps > 0));
+    if (park.flag != nullptr && grid_for((int64_t)d.n * d.reps, 4) > DV_MAX_PARKED_GRID) return DV_ERR_UNSUPPORTED;
+    if (d.n == 0 || d.reps == 0) return DV_OK;
+    DV_REQUIRE(d.mu_q && d.sd_q && d.out);
+    DV_REQUIRE((d.mu_p == nullptr) == (d.sd_p == nullptr));
+    DV_REQUIRE(d.zout == nullptr || d.eps != nullptr);
+    KlArgs a{d.mu_q, d.sd_q, d.ldq, d.qidx, d.mu_p, d.sd_p, d.ldp, d.pidx, d.prior_mu, d.prior_sd, d.n, d.reps, d.Z, d.mode};
+    hipLaunchKernelGGL(kl_rows_fwd_kernel, dim3(grid_for((int64_t)d.n * d.reps, 4)), dim3(256), 0, ST(stream), a,
+                       d.free_bits, d.kl_min, d.raw_out, d.out, d.add, d.eps, d.lde, d.zout, d.ldz, park, d.mu2, d.sd2,
+                       d.ld2, d.Z2, d.raw2_out);
     DV_RETURN_LAUNCH();
 }
 
@@ -2198,57 +2203,55 @@ extern "C" int dv_rows_gather(const float* src, int64_t lds, const int32_t* idx,
     DV_RETURN_LAUNCH();
 }
 
-extern "C" int dv_batch_feed(const float* x1, int64_t ld1, const float* x2, int64_t ld2, const int32_t* y,
-                             const int32_t* table, int32_t n_batches, const int32_t* ctr, const int32_t* base,
-                             int32_t B, const int32_t* pair_rows, int32_t Np, int32_t X, const float* noise,
-                             int64_t ldn, float sigma, float* xin, int64_t ldo, const int32_t* has_y, int32_t L,
-                             int32_t* label_r, const int32_t* fp_i, const int32_t* fp_lab, const int32_t* fp_slot,
-                             int32_t Mf, int32_t* fp_cls, float* onehot, int64_t ldh, int32_t Y, const float* yf,
-                             float* ylab, int32_t Yc, float* onehot2, int64_t ldh2, const dv_batch_masks_desc* masks,
-                             const dv_wait* park_in, dv_stream_t stream) {
-    DV_REQUIRE(park_ok(park_in));
+static bool masks_ok(const dv_batch_masks_desc& m, int B) {
+    return m.Np >= 0 && m.Np <= B && m.n_tot > 0.f && m.c_nll && m.w_recl && (m.hx == nullptr || (m.c_klz2 && m.w_pert)) &&
+           (m.hy == nullptr || (m.y && m.c_yl && m.w_yl && m.label));
+}
+
+static MaskArgs mask_args(const dv_batch_masks_desc& m, const int32_t* table, int n_batches, const int32_t* ctr,
+                          const int32_t* base, int B, int L) {
+    return MaskArgs{table, n_batches, ctr, base, m.hx, m.hy, m.y, B, L, m.Np, m.n_tot, m.kl_rate, m.pert_rate, m.yl_rate,
+                    m.beta, m.c_nll, m.c_klz2, m.c_yl, m.w_recl, m.w_pert, m.w_yl, m.label, m.c_klp, m.one_slot, m.gcounts};
+}
+
+extern "C" int dv_batch_feed(const dv_batch_feed_desc* dsc, const dv_batch_masks_desc* masks, const dv_wait* park_in,
+                             dv_stream_t stream) {
+    DV_REQUIRE(dsc != nullptr && park_ok(park_in));
+    const dv_batch_feed_desc& d = *dsc;
     const ParkArgs park = park_in ? *park_in : ParkArgs{};
-    DV_REQUIRE(B >= 0 && Np >= 0 && X >= 0 && n_batches >= 1 && L >= 1 && Mf >= 0 && Y >= 0 && Yc >= 0);
-    DV_REQUIRE(!ylab || (yf && Yc >= 1));
+    const int B = d.B, Np = d.Np, L = d.L, Mf = d.Mf;
+    DV_REQUIRE(B >= 0 && Np >= 0 && d.X >= 0 && d.n_batches >= 1 && L >= 1 && Mf >= 0 && d.Y >= 0 && d.Yc >= 0);
+    DV_REQUIRE(!d.ylab || (d.yf && d.Yc >= 1));
     if (B == 0) return DV_OK;
-    DV_REQUIRE(x1 && table && ctr && base && xin && (Np == 0 || (x2 && pair_rows)));
-    DV_REQUIRE(!label_r || (y && has_y));
-    DV_REQUIRE(!fp_cls || Mf == 0 || (y && fp_i && fp_lab && fp_slot));
+    DV_REQUIRE(d.x1 && d.table && d.ctr && d.base && d.xin && (Np == 0 || (d.x2 && d.pair_rows)));
+    DV_REQUIRE(!d.label_r || (d.y && d.has_y));
+    DV_REQUIRE(!d.fp_cls || Mf == 0 || (d.y && d.fp_i && d.fp_lab && d.fp_slot));
     const int row_blocks = (B + Np + 3) / 4;
-    int nlab = (label_r ? L * B : 0) > (fp_cls ? Mf : 0) ? (label_r ? L * B : 0) : (fp_cls ? Mf : 0);
-    if (ylab && B * Yc > nlab) nlab = B * Yc;
+    int nlab = (d.label_r ? L * B : 0) > (d.fp_cls ? Mf : 0) ? (d.label_r ? L * B : 0) : (d.fp_cls ? Mf : 0);
+    if (d.ylab && B * d.Yc > nlab) nlab = B * d.Yc;
     const int lab_blocks = (nlab + 255) / 256;
-    const bool v4 = aligned16(x1) && (Np == 0 || aligned16(x2)) && aligned16(xin) && (!noise || aligned16(noise)) &&
-                    ld1 % 4 == 0 && (Np == 0 || ld2 % 4 == 0) && ldo % 4 == 0 && (!noise || ldn % 4 == 0);
+    const bool v4 = aligned16(d.x1) && (Np == 0 || aligned16(d.x2)) && aligned16(d.xin) && (!d.noise || aligned16(d.noise)) &&
+                    d.ld1 % 4 == 0 && (Np == 0 || d.ld2 % 4 == 0) && d.ldo % 4 == 0 && (!d.noise || d.ldn % 4 == 0);
     MaskArgs ma{};
     if (masks) {
-        const dv_batch_masks_desc& m = *masks;
-        DV_REQUIRE(m.Np >= 0 && m.Np <= B && m.n_tot > 0.f && m.c_nll && m.w_recl);
-        DV_REQUIRE(m.hx == nullptr || (m.c_klz2 && m.w_pert));
-        DV_REQUIRE(m.hy == nullptr || (m.y && m.c_yl && m.w_yl && m.label));
-        ma = MaskArgs{table, n_batches, ctr, base, m.hx, m.hy, m.y, B, L, m.Np, m.n_tot, m.kl_rate, m.pert_rate, m.yl_rate,
-                      m.beta, m.c_nll, m.c_klz2, m.c_yl, m.w_recl, m.w_pert, m.w_yl, m.label, m.c_klp, m.one_slot};
+        DV_REQUIRE(masks_ok(*masks, B));
+        ma = mask_args(*masks, d.table, d.n_batches, d.ctr, d.base, B, L);
     }
     const int feed_blocks = row_blocks + lab_blocks;
     if (park.flag != nullptr && feed_blocks + 1 > DV_MAX_PARKED_GRID) return DV_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(batch_feed_kernel, dim3(feed_blocks + (masks ? 1 : 0)), dim3(256), 0, ST(stream), x1, ld1, x2, ld2,
-                       y, table, n_batches, ctr, base, B, pair_rows, Np, X, noise, ldn, sigma, xin, ldo, has_y, L,
-                       label_r, fp_i, fp_lab, fp_slot, Mf, fp_cls, onehot, ldh, Y, row_blocks, v4 ? 1 : 0, yf, ylab, Yc,
-                       onehot2, ldh2, masks ? feed_blocks : -1, ma, park);
+    hipLaunchKernelGGL(batch_feed_kernel, dim3(feed_blocks + (masks ? 1 : 0)), dim3(256), 0, ST(stream), d.x1, d.ld1, d.x2,
+                       d.ld2, d.y, d.table, d.n_batches, d.ctr, d.base, B, d.pair_rows, Np, d.X, d.noise, d.ldn, d.sigma,
+                       d.xin, d.ldo, d.has_y, L, d.label_r, d.fp_i, d.fp_lab, d.fp_slot, Mf, d.fp_cls, d.onehot, d.ldh,
+                       d.Y, row_blocks, v4 ? 1 : 0, d.yf, d.ylab, d.Yc, d.onehot2, d.ldh2, masks ? feed_blocks : -1, ma,
+                       park);
     DV_RETURN_LAUNCH();
 }
 
-extern "C" int dv_batch_masks(const int32_t* table, int32_t n_batches, const int32_t* ctr, const int32_t* base,
-                              const int32_t* hx, const int32_t* hy, const int32_t* y, int32_t B, int32_t L, int32_t Np,
-                              float n_tot, float kl_rate, float pert_rate, float yl_rate, const float* beta,
-                              float* c_nll, float* c_klz2, float* c_yl, float* w_recl, float* w_pert, float* w_yl,
-                              int32_t* label, float* c_klp, const int32_t* one_slot, dv_stream_t stream) {
-    DV_REQUIRE(B >= 1 && L >= 1 && Np >= 0 && Np <= B && n_tot > 0.f && c_nll && w_recl);
+extern "C" int dv_batch_masks(const dv_batch_masks_desc* m, const int32_t* table, int32_t n_batches, const int32_t* ctr,
+                              const int32_t* base, int32_t B, int32_t L, dv_stream_t stream) {
+    DV_REQUIRE(m != nullptr && B >= 1 && L >= 1 && masks_ok(*m, B));
     DV_REQUIRE(table == nullptr || (ctr && base && n_batches >= 1));
-    DV_REQUIRE(hx == nullptr || (c_klz2 && w_pert));
-    DV_REQUIRE(hy == nullptr || (y && c_yl && w_yl && label));
-    MaskArgs a{table, n_batches, ctr, base, hx, hy, y, B, L, Np, n_tot, kl_rate, pert_rate, yl_rate, beta, c_nll, c_klz2,
-               c_yl, w_recl, w_pert, w_yl, label, c_klp, one_slot};
+    MaskArgs a = mask_args(*m, table, n_batches, ctr, base, B, L);
     hipLaunchKernelGGL(batch_masks_kernel, dim3(1), dim3(1024), 0, ST(stream), a);
     DV_RETURN_LAUNCH();
 }
@@ -2343,24 +2346,23 @@ extern "C" int dv_loss_assemble(const dv_loss_term* terms, int32_t n_terms, cons
     DV_RETURN_LAUNCH();
 }
 
-extern "C" int dv_loss_assemble_after(int32_t* flag, const int32_t* ctr, int32_t add, int32_t* err, int32_t max_spins,
-                                      const dv_loss_term* terms, int32_t n_terms, const float* w_elbo,
-                                      const float* w_cmpl, float* loss, int32_t* c1, int32_t n1, int64_t inc1,
-                                      int32_t* c2, int32_t n2, int64_t inc2, const int32_t* halt, int32_t n_halt,
-                                      float* accum, dv_stream_t stream) {
+extern "C" int dv_loss_assemble_after(const dv_wait* wait, const dv_loss_term* terms, int32_t n_terms,
+                                      const float* w_elbo, const float* w_cmpl, float* loss, const dv_bump* bump_in,
+                                      const int32_t* halt, int32_t n_halt, float* accum, dv_stream_t stream) {
     DV_REQUIRE(n_halt >= 0 && (halt || n_halt == 0));
     DV_REQUIRE(n_terms >= 0 && n_terms <= DV_MAX_LOSS_TERMS && (terms || n_terms == 0));
-    DV_REQUIRE(w_elbo && w_cmpl && loss && (!flag || (ctr && err && max_spins > 0)));     // flag == NULL: no wait
-    DV_REQUIRE((!c1 || n1 == 1 || n1 == 2) && (!c2 || n2 == 1 || n2 == 2));
-    CounterBump bump{{c1, c2}, {n1, n2}, {inc1, inc2}};
+    const dv_wait w = wait ? *wait : dv_wait{};
+    DV_REQUIRE(w_elbo && w_cmpl && loss && (!w.flag || (w.ctr && w.err && w.max_spins > 0)));     // flag == NULL: no wait
+    const CounterBump bump = bump_in ? *bump_in : CounterBump{};
+    for (int i = 0; i < 2; ++i) DV_REQUIRE(!bump.c[i] || bump.n[i] == 1 || bump.n[i] == 2);
     LossTerms lt;
     lt.n = n_terms;
     for (int i = 0; i < n_terms; ++i) {
         DV_REQUIRE(terms[i].out >= 0 && terms[i].out <= 4 && terms[i].n >= 0 && (terms[i].x || terms[i].n == 0));
         lt.t[i] = terms[i];
     }
-    hipLaunchKernelGGL(loss_assemble_kernel, dim3(1), dim3(kLossThreads), 0, ST(stream), lt, w_elbo, w_cmpl, loss, flag, ctr,
-                       add, err, max_spins, bump, halt, n_halt, accum);
+    hipLaunchKernelGGL(loss_assemble_kernel, dim3(1), dim3(kLossThreads), 0, ST(stream), lt, w_elbo, w_cmpl, loss, w.flag,
+                       w.ctr, w.add, w.err, w.max_spins, bump, halt, n_halt, accum);
     DV_RETURN_LAUNCH();
 }
 

@@ -175,6 +175,7 @@ class DeviceBatcher:
         self._k = 0                       # (bucketed) batches handed out since begin_epoch
         self.n_switch = 0                 # (bucketed) how many times a step ran on another plan than the one before
         self.cpu_stream = generator == 'cpu'
+        self.dp = None                    # (rank, world) under data parallelism: set by ``bind(dp=...)``
         if mode == 'sampler':
             self.weights = w.float()
             self.weights_cpu = torch.as_tensor(weights, dtype=torch.float64).cpu().reshape(-1)
@@ -188,44 +189,80 @@ class DeviceBatcher:
     def __len__(self):
         """batches per epoch: what the reference's DataLoader yields with a len(dataset)-draw
         weighted sampler and drop_last (src/run_drvae.py:150-162)"""
-        return max(1, len(self.ds) // self.batch_size)
+        return max(1, len(self.ds) // self.global_batch)
 
-    def bind(self, engine, counts=None):
-        """build / select the step plan for this batcher's fixed batch structure"""
+    @property
+    def world(self):
+        return self.dp[1] if self.dp else 1
+
+    @property
+    def rank(self):
+        return self.dp[0] if self.dp else 0
+
+    @property
+    def global_batch(self):
+        """rows of one optimiser step over all ranks: ``batch_size`` is PER RANK (weak scaling)"""
+        return self.batch_size * self.world
+
+    def _n_tot(self):
+        return self.global_batch if self.dp else None
+
+    def bind(self, engine, counts=None, dp=None):
+        """build / select the step plan for this batcher's fixed batch structure.  ``dp`` = (rank, world): data
+        parallelism -- ``batch_size`` rows per rank, a global batch of world x batch_size rows per step.
+        Every rank holds the same dataset, weights and seed and therefore draws the SAME global index table; it runs
+        columns [rank B, (rank + 1) B) of it.  The loss normalisers are the global batch's: N_total = world B, and
+        N_pairs / N_labeled of every batch are counted over the global table (``gcounts``, read by the feed launch) --
+        no communication.  The Philox draws are keyed by the row's position in the global batch (``engine.row0``)."""
         self.engine = engine
+        self.dp = None if dp is None else (int(dp[0]), int(dp[1]))
+        assert self.dp is None or 0 <= self.dp[0] < self.dp[1]
+        if self.dp is not None:
+            assert not engine.cfg.use_MMD, 'use_MMD: the MMD penalty is a cross-row term, it cannot be sharded over ranks'
+            engine.row0 = self.rank * self.batch_size
         if engine.cfg.use_s and (engine.cfg.use_MMD or self.mode == 'sampler'):
             raise NotImplementedError('DeviceBatcher: models conditioned on the nuisance variable (use_s extension) run on '
                                       'stratified device batches without the MMD penalty (its row lists are host knowledge); '
                                       'otherwise feed them through run_on_batch / a tuple loader')
         if self.mode == 'sampler':
-            assert counts is None, 'the exact sampler composes batches per rank: use mode="stratified" under data parallelism'
+            assert counts is None, 'sampler feed: the global counts of every batch come from the shared index table (dp=...)'
             engine.universal = True
             if self.pair_bucket and not engine.cfg.has_pert:
                 self.pair_bucket = None                      # (no pairs in this model: nothing to bucket)
             if self.label_bucket and not engine.cfg.has_y:
                 self.label_bucket = None
-            return engine.set_structure_universal(self.batch_size)
+            return engine.set_structure_universal(self.batch_size, n_tot=self._n_tot())
+        if counts is None and self.dp is not None:      # every rank's batch has the same composition
+            cfg = engine.cfg
+            n_lab = int(self.has_y.sum()) if cfg.has_y else 0
+            n_tot = n_lab if (cfg.kind == 'vfae' and not cfg.semi_supervised) else self.batch_size
+            counts = tuple(self.world * c for c in (n_tot, int(self.has_x2.sum()) if cfg.has_pert else 0, n_lab))
         engine.set_structure(self.has_x2, self.has_y, counts)
         return engine.plan
 
-    def begin_epoch(self, n_batches=None):
+    def begin_epoch(self, n_batches=None, table=None):
         """Draw the index table of a whole epoch on the device (one multinomial per group) and
         install it as the bound plan's graph-resident feed: from here on every captured train step
         gathers its own minibatch (``dv_batch_feed``), i.e. an epoch is ``len(self)`` graph replays
-        with no other host work.  Returns the table (n_batches, batch_size) int32."""
+        with no other host work.  Returns the table (n_batches, batch_size) int32 -- under data parallelism this
+        rank's columns of the global table.  ``table``: the GLOBAL table (n_batches, world x batch_size) given instead of
+        drawn (tests; replaying a recorded epoch)."""
         eng, p = self.engine, self.engine.plan
         if eng.cfg.use_s:
             raise NotImplementedError('use_s: the graph-resident epoch feed does not carry the nuisance classes; use feed()')
         n_b = len(self) if n_batches is None else n_batches
         fd = p.feed
-        if fd is None or fd.owner is not self or fd.n_batches != n_b:
+        want_gc = self.dp is not None and self.mode == 'sampler'
+        if fd is None or fd.owner is not self or fd.n_batches != n_b or (getattr(fd, 'gcounts', None) is not None) != want_gc:
             dev = self.ds.x1.device
             fd = types.SimpleNamespace(owner=self, n_batches=n_b, x1=self._feed_rows(self.ds.x1),
                                        x2=self._feed_rows(getattr(self.ds, 'x2', None)) if eng.cfg.has_pert else None,
                                        y32=None if eng.cfg.cont else self.ds.y.reshape(-1).to(torch.int32).contiguous(),
                                        yf=self.ds.y.reshape(len(self.ds), -1).float().contiguous() if eng.cfg.cont else None,
                                        table=torch.zeros(n_b, self.batch_size, dtype=torch.int32, device=dev),
-                                       base=torch.zeros(1, dtype=torch.int32, device=dev))
+                                       base=torch.zeros(1, dtype=torch.int32, device=dev),
+                                       gcounts=torch.zeros(n_b, 2, dtype=torch.int32, device=dev)
+                                       if (self.dp is not None and self.mode == 'sampler') else None)
             if self.mode == 'sampler':
                 fd.hx32, fd.hy32 = self.hx32, self.hy32
                 if fd.y32 is None:
@@ -234,14 +271,26 @@ class DeviceBatcher:
         p.feed_active = True
         if self.mode == 'sampler':
             # WeightedRandomSampler: i.i.d. draws over ALL rows; DataLoader(drop_last): consecutive full batches
-            if self.cpu_stream:
+            if table is not None:
+                draws = torch.as_tensor(table).to(fd.table.device)
+                assert tuple(draws.shape) == (n_b, self.global_batch)
+            elif self.cpu_stream:
                 rows = []
                 while sum(len(r) for r in rows) < n_b:
                     rows.append(self._reference_epoch())
                 draws = torch.cat(rows)[:n_b].to(fd.table.device)
             else:
-                draws = torch.multinomial(self.weights, n_b * self.batch_size, replacement=True, generator=self.gen)
-            tab = draws.reshape(n_b, self.batch_size)
+                draws = torch.multinomial(self.weights, n_b * self.global_batch, replacement=True, generator=self.gen)
+            tab = draws.reshape(n_b, self.global_batch)
+            self.global_table = tab
+            if self.dp is not None:
+                # the batch's normalisers are those of the GLOBAL batch: counted here over the shared table, read by the
+                # step's first launch (dv_batch_feed: masks.gcounts) -- no collective, no host round trip
+                g = tab.long()
+                zero = torch.zeros(n_b, dtype=torch.int64, device=tab.device)
+                fd.gcounts.copy_(torch.stack([self.hx32[g].sum(1) if eng.cfg.has_pert else zero,
+                                              self.hy32[g].sum(1) if eng.cfg.has_y else zero], 1))
+                tab = tab[:, self.rank * self.batch_size:(self.rank + 1) * self.batch_size]
             if self.bucketed:
                 self._order_and_specs(tab)
                 tab = self._tab_sorted
@@ -254,9 +303,15 @@ class DeviceBatcher:
                     q.feed, q.feed_active = fd, True
                 self._plan(self.batch_specs[0])
             return fd.table
-        parts = [m[torch.multinomial(w, c * n_b, replacement=True, generator=self.gen)].reshape(n_b, c)
-                 for m, w, c in zip(self.members, self.gweights, self.group_counts) if c > 0]
-        fd.table.copy_(torch.cat(parts, 1))
+        if table is not None:
+            tab = torch.as_tensor(table).to(fd.table.device).reshape(n_b, self.world, self.batch_size)[:, self.rank]
+        else:
+            # (data parallelism: world x c draws per group and batch from the shared generator; this rank's c of them)
+            R, r = self.world, self.rank
+            parts = [m[torch.multinomial(w, c * R * n_b, replacement=True, generator=self.gen)].reshape(n_b, R, c)[:, r]
+                     for m, w, c in zip(self.members, self.gweights, self.group_counts) if c > 0]
+            tab = torch.cat(parts, 1)
+        fd.table.copy_(tab)
         fd.base.copy_(eng.step_dev)         # device to device: batch index = optimiser step - base
         return fd.table
 
@@ -294,7 +349,7 @@ class DeviceBatcher:
         return (self.batch_size, 0, 0)
 
     def _plan(self, spec):
-        p = self.engine.set_structure_universal(self.batch_size, spec[0], spec[1:])
+        p = self.engine.set_structure_universal(self.batch_size, spec[0], spec[1:], n_tot=self._n_tot())
         self.engine.pinned_plans.add(p.key)       # (the plan cache is small and drops what is not captured)
         return p
 
@@ -372,28 +427,37 @@ class DeviceBatcher:
         torch.empty((), dtype=torch.int64).random_()
         draws = torch.multinomial(self.weights_cpu, len(self.weights_cpu), True)
         n_b = len(self)
-        return draws[:n_b * self.batch_size].reshape(n_b, self.batch_size)
+        return draws[:n_b * self.global_batch].reshape(n_b, self.global_batch)
 
     def next_indices(self):
+        """the next batch's dataset rows -- under data parallelism the GLOBAL batch (world x batch_size rows, the same
+        on every rank); ``feed`` takes this rank's share"""
         if self.mode == 'sampler' and self.cpu_stream:
             if self._pending is None or len(self._pending) == 0:
                 self._pending = self._reference_epoch()
             idx, self._pending = self._pending[0], self._pending[1:]
             return idx.to(self.ds.x1.device)
         if self.mode == 'sampler':
-            return torch.multinomial(self.weights, self.batch_size, replacement=True, generator=self.gen)
-        parts = [m[torch.multinomial(w, c, replacement=True, generator=self.gen)]
+            return torch.multinomial(self.weights, self.global_batch, replacement=True, generator=self.gen)
+        R = self.world
+        parts = [m[torch.multinomial(w, c * R, replacement=True, generator=self.gen)].reshape(R, c)
                  for m, w, c in zip(self.members, self.gweights, self.group_counts) if c > 0]
-        return torch.cat(parts)
+        return torch.cat(parts, 1).reshape(-1)
 
     def feed(self, idx=None):
         """draw the next batch and write it into the bound engine's buffers (device to device)"""
         if self.mode == 'sampler' and self.bucketed:
             # explicit batches come in the order they were drawn: the plan without assumptions about the row order
-            self.engine.set_structure_universal(self.batch_size)
+            self.engine.set_structure_universal(self.batch_size, n_tot=self._n_tot())
         p = self.engine.plan
         p.feed_active = False       # this batch is explicit data in XSRC, not a row of the epoch table
         idx = self.next_indices() if idx is None else idx
+        if self.dp is not None and idx.numel() == self.global_batch:
+            if self.mode == 'sampler':      # the global batch's (N_pairs, N_labeled): data of dv_batch_masks
+                zero = torch.zeros((), dtype=torch.int32, device=idx.device)
+                p.gcounts_dev.copy_(torch.stack([self.hx32[idx].sum() if self.engine.cfg.has_pert else zero,
+                                                 self.hy32[idx].sum() if self.engine.cfg.has_y else zero]))
+            idx = idx.reshape(self.world, self.batch_size)[self.rank]
         self._idx32.copy_(idx)
         K.rows_gather(p.XSRC[:p.B], self.ds.x1, self._idx32)
         if self.engine.cfg.has_pert:

@@ -109,7 +109,23 @@ def shard_rows(n_rows, rank, world):
     return rank * per, (rank + 1) * per
 
 
+def broadcast(t, src=0):
+    """rank ``src``'s tensor to every rank, in place (a CPU tensor travels through the device under RCCL)"""
+    if not _active():
+        return t
+    if dist.get_backend() == 'nccl' and not t.is_cuda:
+        d = t.cuda()
+        dist.broadcast(d, src=src)
+        t.copy_(d.cpu())
+    else:
+        dist.broadcast(t, src=src)
+    return t
+
+
+def broadcast_int(v, src=0):
+    return int(broadcast(torch.tensor([int(v)], dtype=torch.int64), src)[0])
+
+
 def broadcast_params(arena):
     """make every rank start from rank 0's parameters"""
-    if _active():
-        dist.broadcast(arena.param, src=0)
+    broadcast(arena.param)

@@ -299,13 +299,16 @@ class FusedStep(StepSchedule):
         cfg = self.cfg
         return not cfg.cont and not (cfg.kind == 'vfae' and not cfg.semi_supervised) and not cfg.use_s
 
-    def set_structure_universal(self, n_rows, n_pair_slots=None, labeled_range=None):
+    def set_structure_universal(self, n_rows, n_pair_slots=None, labeled_range=None, n_tot=None):
         """Select (or build) the batch-independent plan for ``n_rows`` rows.  ``n_pair_slots`` < n_rows: only the FIRST
         so many rows of a batch have pair slots (x2 row, z2 / z2Fz1 sample rows) -- for feeds that put a batch's pairs
         first and choose the plan by the batch's number of pairs (``DeviceBatcher(mode='sampler', pair_bucket=...)``):
         the decoder then runs L*B + 2*L*n_pair_slots rows instead of 3*L*B.  ``labeled_range`` = (a, b): the feed
         guarantees that rows [a, b) of every batch are labeled -- they get ONE fprop row (their class, as in a plan
-        built for the batch's structure) instead of a row per class."""
+        built for the batch's structure) instead of a row per class.  ``n_tot`` (data parallelism): the
+        rows are one rank's slice of a GLOBAL batch of ``n_tot`` rows; N_pairs / N_labeled of every batch then are the
+        global counts, handed over as data (``set_batch(counts=...)``, the feed's ``gcounts`` table) instead of being
+        counted over this slice by dv_batch_masks."""
         cfg = self.cfg
         assert self.universal_ok(), 'universal plan: discrete labels, semi-supervised models'
         nps = n_rows if (n_pair_slots is None or not cfg.has_pert) else int(n_pair_slots)
@@ -317,13 +320,16 @@ class FusedStep(StepSchedule):
         key = ('universal', n_rows, self.row0)
         if nps != n_rows or lab != (0, 0):
             key = key + (nps,) + (lab if lab != (0, 0) else ())
+        if n_tot is not None:
+            key = key + (('n_tot', int(n_tot)),)
         if self.plan is None or self.plan.key != key:
             self.plan = self._plans.get(key)
             if self.plan is None:
                 ar = np.arange(n_rows)
                 ones, zeros = ar < nps, np.zeros(n_rows, bool)
                 self.plan = self._plans[key] = _Plan(self, ar, ones if cfg.has_pert else zeros,
-                                                      (ar >= lab[0]) & (ar < lab[1]), None, key, universal=True)
+                                                      (ar >= lab[0]) & (ar < lab[1]),
+                                                      None if n_tot is None else (int(n_tot), 0, 0), key, universal=True)
                 if cfg.has_y:
                     self.plan.set_labels_host(np.zeros(n_rows, np.int64))      # class slots: static
                 self._evict_plans(key)
@@ -378,10 +384,13 @@ class FusedStep(StepSchedule):
 
     def _set_batch(self, x1, x2, y, has_x2, has_y, counts=None):
         cfg = self.cfg
-        if self.universal and counts is None and self.universal_ok():
+        if self.universal and self.universal_ok():
             hy = np.asarray(has_y.cpu() if torch.is_tensor(has_y) else has_y).reshape(-1)
-            p = self.set_structure_universal(len(hy), self.universal_pair_slots, self.universal_labeled_range)
+            p = self.set_structure_universal(len(hy), self.universal_pair_slots, self.universal_labeled_range,
+                                             n_tot=None if counts is None else counts[0])
             p.feed_active = False
+            if counts is not None:       # this rank's slice of a global batch: the GLOBAL (N_pairs, N_labeled) are data
+                p.gcounts_dev.copy_(torch.tensor([int(counts[1]), int(counts[2])], dtype=torch.int32))
             p.XSRC[:p.B].copy_(x1)
             i32 = lambda a: torch.as_tensor(np.asarray(a.cpu() if torch.is_tensor(a) else a).reshape(-1).astype(np.int32))
             if cfg.has_pert:
@@ -554,7 +563,11 @@ class FusedStep(StepSchedule):
         if p.universal:
             # which rows of THIS batch are pairs / labeled -> coefficient and weight vectors, on the device (with
             # the graph-resident feed: by one more workgroup of the feed's launch)
-            masks = dict(n_tot=float(B), kl_rate=cfg.kl_qz2pz2_rate, pert_rate=cfg.pertloss_rate,
+            gc = None
+            if p.global_counts:      # data parallelism: the normalisers are the global batch's counts (table data / set_batch)
+                gc = getattr(fd, 'gcounts', None) if fd is not None else p.gcounts_dev
+                assert gc is not None, 'this plan normalises by global counts: the feed carries none (DeviceBatcher.bind(dp=...))'
+            masks = dict(n_tot=p.n_tot, gcounts=gc, kl_rate=cfg.kl_qz2pz2_rate, pert_rate=cfg.pertloss_rate,
                          yl_rate=cfg.yloss_rate, beta=p.beta_dev, c_nll=p.c_nll, w_recl=p.w_recl,
                          hx=(fd.hx32 if fd is not None else p.hx_dev) if cfg.has_pert else None,
                          hy=(fd.hy32 if fd is not None else p.hy_dev) if cfg.has_y else None,

@@ -227,7 +227,7 @@ class FitMixin:
         """one epoch of hipGraph replays fed by the device batcher; returns the mean train objective"""
         eng = self.engine()
         self._assert_arena_aliased()
-        batcher.bind(eng, counts=getattr(self, '_global_counts', None))
+        batcher.bind(eng, counts=getattr(self, '_global_counts', None), dp=self._dp)
         eng.add_noise = bool(self.add_noise)
         eng.iters = self.finished_training_iters
         resident_feed = not eng.cfg.use_s      # (the nuisance classes travel with host-driven gathers: feed())
@@ -239,18 +239,18 @@ class FitMixin:
             batcher.feed()
         if getattr(eng, '_graph_key', None) != eng.plan.key or getattr(eng, '_graph_noise', None) != eng.add_noise \
                 or getattr(eng, '_graph_feed', None) is not eng.plan.live_feed:
-            eng.capture(split_for_allreduce=getattr(self, '_allreduce', None) is not None)
+            eng.capture(split_for_allreduce=self._allreduce is not None)
             eng._graph_noise = eng.add_noise
             bucketed = getattr(batcher, 'bucketed', False)
             if bucketed:
                 eng.stash_capture()         # (under this plan's key: begin_epoch below selects another)
-            if getattr(self, '_allreduce', None) is None and not (bucketed and getattr(eng, '_side_cus', None)):
+            if self._allreduce is None and not (bucketed and getattr(eng, '_side_cus', None)):
                 eng.tune_partition()        # CU split of the two launch chains, by timing (state restored)
             if resident_feed:
                 batcher.begin_epoch()       # (the tuning replays advanced the step counter: re-base the table)
         if getattr(batcher, 'bucketed', False):         # a plan per number-of-pairs bucket: capture the missing ones
             def cap(e):
-                e.capture()
+                e.capture(split_for_allreduce=self._allreduce is not None)
                 e._graph_noise = e.add_noise
             batcher.prepare_epoch(cap)
         with eng.partition():
@@ -263,7 +263,7 @@ class FitMixin:
         # single process: the launch that assembles a step's loss scalars also adds them to ``eng.loss_sum`` -- nothing
         # sits between two replays on the critical chain's stream (three tiny torch launches per step did: 54 steps x
         # ~40 us per epoch at cfg 2).  Under data parallelism the step's scalars are the exchanged ones: summed here
-        in_graph = getattr(self, '_allreduce', None) is None
+        in_graph = self._allreduce is None
         side = eng.flag_side if getattr(eng, '_side_graph', None) is not None else None
         if in_graph:
             eng.loss_sum.zero_()
@@ -274,7 +274,7 @@ class FitMixin:
                 batcher.feed()
             else:
                 batcher.select(b)              # (bucketed sampler feed: this batch's plan; otherwise nothing)
-            eng.replay(allreduce=getattr(self, '_allreduce', None))
+            eng.replay(allreduce=self._allreduce)
             if not in_graph:
                 total += self._train_objective(self._loss_tensors(eng))
             if verbose and b % every == 0:
@@ -295,19 +295,19 @@ class FitMixin:
         into the buffers of the batch-independent plan (``set_batch``: device-to-device copies + its flags), the
         captured step turns the flags into group masks itself (dv_batch_masks).  The first batch of a size runs
         eagerly (iteration 0 carries beta_pert = 0.01) and the capture follows."""
-        eng = self._batch_to_engine(**kw)
+        eng = self._batch_to_engine(dp=True, **kw)
         eng.add_noise = bool(self.add_noise)
         eng.iters = self.finished_training_iters
         fresh = getattr(eng, '_graph_key', None) != eng.plan.key or getattr(eng, '_graph_noise', None) != eng.add_noise \
             or getattr(eng, '_graph_feed', None) is not eng.plan.live_feed
         if fresh and eng.iters == 0:
-            eng.train_step(allreduce=getattr(self, '_allreduce', None))
+            eng.train_step(allreduce=self._allreduce)
         else:
             if fresh:
-                eng.capture(split_for_allreduce=getattr(self, '_allreduce', None) is not None)
+                eng.capture(split_for_allreduce=self._allreduce is not None)
                 eng._graph_noise = eng.add_noise
             with eng.partition():
-                eng.replay(allreduce=getattr(self, '_allreduce', None))
+                eng.replay(allreduce=self._allreduce)
         self.finished_training_iters = eng.iters
         return self._loss_tensors(eng)
 
@@ -365,7 +365,8 @@ class FitMixin:
                 self.w2log('Valid rolling mem: {}\tmean: {:.4f}\tbest: {:.4f}'.format(d['rolling'], d['rolling_mean'],
                                                                                     d['best_before']))
                 if d['snapshot']:
-                    self.save_to_file(model_filename)
+                    if self.dp_rank == 0:        # (data parallelism: the replicas are identical; one writer)
+                        self.save_to_file(model_filename)
                     self.w2log('* Snapshotting at epoch {}'.format(epoch))
                 if d['patience_hit']:
                     self.w2log('Early stopping at: {} with train: {:.4f} valid: {:.4f} evaluate_valid_obj: {:.4f} '
@@ -376,7 +377,7 @@ class FitMixin:
                     self.w2log('Continuing')
         except KeyboardInterrupt:
             self.w2log('KeyboardInterrupt')
-            if ctl.on_interrupt():
+            if ctl.on_interrupt() and self.dp_rank == 0:
                 self.save_to_file(model_filename)
                 self.w2log('* Snapshotting at epoch {}'.format(epoch))
         self.w2log('Finished training at: {}'.format(time.strftime('%c')))
@@ -407,13 +408,31 @@ class _EvalGraph:
             return None
         if next(model.parameters()).device != x1.device:
             return None
+        need = ('x1',) + (('x2', 'has_x2') if model.kind != 'vfae' else ()) + (('y', 'has_y') if model.kind != 'pvae' else ())
+        parts = [getattr(ds, k, None) for k in need]
+        if not all(torch.is_tensor(t) and t.device == x1.device for t in parts):
+            return None          # (a host-resident label / flag array would be a pageable copy under capture)
         cache = model.__dict__.setdefault('_eval_graphs', {})
+        # the captured launches point into the engine's arena, plan and layer chains: ``.cpu().cuda()`` / ``.to()`` retire
+        # the engine (DGMMixin._apply) and a graph of the old one would read freed parameters -- the engine's identity is
+        # part of the signature (and ``_apply`` drops the cache)
+        eng = model.engine()
         sig = tuple(int(t.data_ptr()) if torch.is_tensor(t) else 0
-                    for t in (getattr(ds, k, None) for k in ('x1', 'x2', 'y', 'has_x2', 'has_y'))) + (int(x1.shape[0]),)
+                    for t in (getattr(ds, k, None) for k in ('x1', 'x2', 'y', 'has_x2', 'has_y'))) + \
+            (int(x1.shape[0]), id(eng), int(eng.arena.param.data_ptr()))
         ev = cache.get(id(ds))
         if ev is None or ev.sig != sig:
-            ev = cache[id(ds)] = _EvalGraph(model, ds, sig)
-        return ev
+            if len(cache) > 8:
+                cache.clear()
+            try:
+                ev = cache[id(ds)] = _EvalGraph(model, ds, sig)
+            except Exception as e:      # the reference evaluates on regardless of a failing loss pass (src/DrVAE.py:647-654):
+                import warnings         # so does the step-by-step path, which this dataset now takes
+                warnings.warn('drvae_amd: the captured whole-set evaluation could not be built (%s: %s); evaluating step '
+                              'by step' % (type(e).__name__, e))
+                ev = cache[id(ds)] = _EvalGraph.__new__(_EvalGraph)
+                ev.sig, ev.graph = sig, None
+        return ev if ev.graph is not None else None
 
     def __init__(self, model, ds, sig):
         self.model, self.ds, self.sig = model, ds, sig
@@ -426,29 +445,30 @@ class _EvalGraph:
         self.yidx = torch.nonzero(g('has_y').reshape(-1).to(dev)).reshape(-1) if kind != 'pvae' else None
         # the loss plan of the whole set: built by the ordinary path (host index lists), then reused
         eng = model.engine()
-        keep = eng.plan
-        model.eval()
-        kw = dict(x1=g('x1'), s=g('s'))
-        if kind != 'vfae':
-            kw.update(x2=g('x2'), has_x2=g('has_x2'))
-        if kind != 'pvae':
-            kw.update(y=g('y'), has_y=g('has_y'))
-        self.kw = kw
-        model.run_on_batch(train_mode=False, **kw)          # (also the warm-up of every kernel of the sequence)
-        self.plan = eng.plan
-        n_in = int(ds.x1.shape[0])
-        rows = np.asarray(self.plan.rows)
-        self.sel = None if (len(rows) == n_in and (rows == np.arange(n_in)).all()) else torch.as_tensor(rows, device=dev)
-        self._sequence()                                    # warm-up of the rest (allocations, code objects)
-        torch.cuda.synchronize()
-        gph = torch.cuda.CUDAGraph()
-        eng.join_side()
+        keep, keep_training, was_training = eng.plan, eng.training, model.training
         try:
+            model.eval()
+            kw = dict(x1=g('x1'), s=g('s'))
+            if kind != 'vfae':
+                kw.update(x2=g('x2'), has_x2=g('has_x2'))
+            if kind != 'pvae':
+                kw.update(y=g('y'), has_y=g('has_y'))
+            self.kw = kw
+            model.run_on_batch(train_mode=False, **kw)          # (also the warm-up of every kernel of the sequence)
+            self.plan = eng.plan
+            n_in = int(ds.x1.shape[0])
+            rows = np.asarray(self.plan.rows)
+            self.sel = None if (len(rows) == n_in and (rows == np.arange(n_in)).all()) else torch.as_tensor(rows, device=dev)
+            self._sequence()                                    # warm-up of the rest (allocations, code objects)
+            torch.cuda.synchronize()
+            gph = torch.cuda.CUDAGraph()
+            eng.join_side()
             with torch.cuda.graph(gph):
                 self.names, self.vec, self.loss_keys = self._sequence()
             self.graph = gph
         finally:
-            eng.plan = keep
+            eng.plan, eng.training = keep, keep_training
+            model.train(was_training)
 
     def _sequence(self):
         """the launch sequence (eager for the warm-up, then under capture); -> (names, float64 vector, loss keys)"""

@@ -355,13 +355,13 @@ def kl_rows_fwd(out, raw, mu_q, sd_q, mu_p=None, sd_p=None, *, prior=(0.0, 0.0),
     Z = mu_q.shape[1]
     assert _ld(mu_q) == _ld(sd_q) and (mu_p is None or _ld(mu_p) == _ld(sd_p))
     assert second is None or (_ld(second[0]) == _ld(second[1]) and second[0].shape[0] == R)
-    _lib.check(_lib.load().dv_kl_rows_fwd(_f32(mu_q), _f32(sd_q), _ld(mu_q), _i32(qidx), _f32(mu_p), _f32(sd_p),
-                                          _ld(mu_p), _i32(pidx), prior[0], prior[1], n, reps, Z, mode,
-                                          int(free_bits), kl_min, _f32(raw), _f32(out), _f32(add), _f32(eps),
-                                          _ld(eps), _f32(zout), _ld(zout), _wait(park),
-                                          _f32(second[0]) if second else None, _f32(second[1]) if second else None,
-                                          _ld(second[0]) if second else 0, second[0].shape[1] if second else 0,
-                                          _f32(second[2]) if second else None, _stream()), 'dv_kl_rows_fwd')
+    d = _lib.KlRows(_f32(mu_q), _f32(sd_q), _ld(mu_q), _i32(qidx), _f32(mu_p), _f32(sd_p), _ld(mu_p), _i32(pidx),
+                    prior[0], prior[1], n, reps, Z, mode, int(free_bits), kl_min, _f32(raw), _f32(out), _f32(add),
+                    _f32(eps), _ld(eps), _f32(zout), _ld(zout),
+                    _f32(second[0]) if second else None, _f32(second[1]) if second else None,
+                    _ld(second[0]) if second else 0, second[0].shape[1] if second else 0,
+                    _f32(second[2]) if second else None)
+    _lib.check(_lib.load().dv_kl_rows_fwd(C.byref(d), _wait(park), _stream()), 'dv_kl_rows_fwd')
 
 
 def kl_rows_bwd(dq_mu, dq_sd, dp_mu, dp_sd, coef, raw, mu_q, sd_q, mu_p=None, sd_p=None, *, prior=(0.0, 0.0),
@@ -578,43 +578,47 @@ def rows_gather(out, src, idx=None, *, noise=None, sigma=0.0, onehot_cls=None, n
                'dv_rows_gather')
 
 
+def _masks_desc(m, B):
+    """keyword arguments of ``batch_masks`` -> dv_batch_masks_desc"""
+    d = dict(hx=None, hy=None, y=None, c_klz2=None, c_yl=None, w_pert=None, w_yl=None, label=None, c_klp=None, Np=None,
+             one_slot=None, gcounts=None)
+    d.update(m)
+    assert d['gcounts'] is None or (d['gcounts'].dtype == torch.int32 and d['gcounts'].is_contiguous())
+    return _lib.BatchMasks(_i32(d['hx']), _i32(d['hy']), _i32(d['y']), B if d['Np'] is None else d['Np'],
+                           d['n_tot'], d['kl_rate'], d['pert_rate'], d['yl_rate'], _f32(d['beta']), _f32(d['c_nll']),
+                           _f32(d['c_klz2']), _f32(d['c_yl']), _f32(d['w_recl']), _f32(d['w_pert']), _f32(d['w_yl']),
+                           _i32(d['label']), _f32(d['c_klp']), _i32(d['one_slot']), _i32(d['gcounts']))
+
+
 def batch_feed(xin, x1, x2, y32, table, n_batches, ctr, base, *, pair_rows=None, noise=None, sigma=0.0, has_y=None,
                L=1, label_r=None, fp_i=None, fp_lab=None, fp_slot=None, fp_cls=None, onehot=None, n_classes=0, yf=None,
                ylab=None, onehot2=None, masks=None, park=None):
     """graph-resident minibatch feed: see dv_batch_feed in include/drvae_hip.h; ``masks``: keyword arguments of
     ``batch_masks`` (minus table / ctr / base / B / L): the batch's masks written by the same launch"""
     B = table.shape[1]
-    md = None
-    if masks is not None:
-        m = dict(hx=None, hy=None, y=None, c_klz2=None, c_yl=None, w_pert=None, w_yl=None, label=None, c_klp=None, Np=None,
-                 one_slot=None)
-        m.update(masks)
-        md = _lib.BatchMasks(_i32(m['hx']), _i32(m['hy']), _i32(m['y']), B if m['Np'] is None else m['Np'],
-                             m['n_tot'], m['kl_rate'], m['pert_rate'], m['yl_rate'], _f32(m['beta']), _f32(m['c_nll']),
-                             _f32(m['c_klz2']), _f32(m['c_yl']), _f32(m['w_recl']), _f32(m['w_pert']), _f32(m['w_yl']),
-                             _i32(m['label']), _f32(m['c_klp']), _i32(m['one_slot']))
+    md = _masks_desc(masks, B) if masks is not None else None
+    assert masks is None or masks.get('gcounts') is None or masks['gcounts'].shape[0] == n_batches
     Np = pair_rows.numel() if pair_rows is not None else 0
     assert xin.shape[0] == B + Np and table.shape[0] == n_batches and table.is_contiguous()
     Mf = fp_cls.numel() if fp_cls is not None else 0
-    _lib.check(_lib.load().dv_batch_feed(_f32(x1), _ld(x1), _f32(x2) if Np else None, _ld(x2) if Np else 0, _i32(y32),
-                                         _i32(table), n_batches, _i32(ctr), _i32(base), B, _i32(pair_rows), Np,
-                                         xin.shape[1], _f32(noise), _ld(noise), sigma, _f32(xin), _ld(xin),
-                                         _i32(has_y), L, _i32(label_r), _i32(fp_i), _i32(fp_lab), _i32(fp_slot), Mf,
-                                         _i32(fp_cls), _f32(onehot), _ld(onehot), n_classes, _f32(yf), _f32(ylab),
-                                         ylab.shape[1] if ylab is not None else 0, _f32(onehot2), _ld(onehot2),
-                                         C.byref(md) if md is not None else None, _wait(park), _stream()), 'dv_batch_feed')
+    d = _lib.BatchFeed(x1=_f32(x1), ld1=_ld(x1), x2=_f32(x2) if Np else None, ld2=_ld(x2) if Np else 0, y=_i32(y32),
+                       table=_i32(table), n_batches=n_batches, ctr=_i32(ctr), base=_i32(base), B=B,
+                       pair_rows=_i32(pair_rows), Np=Np, X=xin.shape[1], noise=_f32(noise), ldn=_ld(noise), sigma=sigma,
+                       xin=_f32(xin), ldo=_ld(xin), has_y=_i32(has_y), L=L, label_r=_i32(label_r), fp_i=_i32(fp_i),
+                       fp_lab=_i32(fp_lab), fp_slot=_i32(fp_slot), Mf=Mf, fp_cls=_i32(fp_cls), onehot=_f32(onehot),
+                       ldh=_ld(onehot), Y=n_classes, yf=_f32(yf), ylab=_f32(ylab),
+                       Yc=ylab.shape[1] if ylab is not None else 0, onehot2=_f32(onehot2), ldh2=_ld(onehot2))
+    _lib.check(_lib.load().dv_batch_feed(C.byref(d), C.byref(md) if md is not None else None, _wait(park), _stream()),
+               'dv_batch_feed')
 
 
-def batch_masks(B, L, *, n_tot, kl_rate, pert_rate, yl_rate, beta, c_nll, w_recl, hx=None, hy=None, y=None, c_klz2=None,
-                c_yl=None, w_pert=None, w_yl=None, label=None, c_klp=None, table=None, n_batches=0, ctr=None, base=None,
-                Np=None, one_slot=None):
+def batch_masks(B, L, *, table=None, n_batches=0, ctr=None, base=None, **masks):
     """per-batch coefficient / weight vectors of a batch-independent step plan from the batch's pair / label flags
     (``dv_batch_masks``); ``hx`` / ``hy`` / ``y``: int32 device arrays indexed by dataset row (``table`` given) or by
-    batch row; ``beta``: 1-element device float; ``Np``: rows [0, Np) have pair slots (default: all B)"""
-    _lib.check(_lib.load().dv_batch_masks(_i32(table), n_batches, _i32(ctr), _i32(base), _i32(hx), _i32(hy), _i32(y), B, L,
-                                          B if Np is None else Np, n_tot, kl_rate, pert_rate, yl_rate, _f32(beta), _f32(c_nll), _f32(c_klz2),
-                                          _f32(c_yl), _f32(w_recl), _f32(w_pert), _f32(w_yl), _i32(label), _f32(c_klp),
-                                          _i32(one_slot), _stream()),
+    batch row; ``beta``: 1-element device float; ``Np``: rows [0, Np) have pair slots (default: all B); ``gcounts``
+    (int32, (n_batches | 1, 2)): the GLOBAL (N_pairs, N_labeled) per batch under data parallelism"""
+    md = _masks_desc(masks, B)
+    _lib.check(_lib.load().dv_batch_masks(C.byref(md), _i32(table), n_batches, _i32(ctr), _i32(base), B, L, _stream()),
                'dv_batch_masks')
 
 
@@ -675,12 +679,9 @@ def loss_assemble(loss, terms, w_elbo, w_cmpl, after=None, bump=(), halt=None, a
                                                 _f32(accum), _stream()), 'dv_loss_assemble')
     else:
         flag, ctr, err, add, spins = after
-        cs = list(bump) + [(None, 0)] * (2 - len(bump))
         _lib.check(_lib.load().dv_loss_assemble_after(
-            _i32(flag), _i32(ctr), add, _i32(err), spins, arr, len(terms), _f32(w_elbo), _f32(w_cmpl), _f32(loss),
-            _i32(cs[0][0]), 0 if cs[0][0] is None else cs[0][0].numel(), cs[0][1],
-            _i32(cs[1][0]), 0 if cs[1][0] is None else cs[1][0].numel(), cs[1][1], hp, hn, _f32(accum), _stream()),
-            'dv_loss_assemble_after')
+            _wait((flag, ctr, err, add, spins)) if flag is not None else None, arr, len(terms), _f32(w_elbo),
+            _f32(w_cmpl), _f32(loss), _bump(bump), hp, hn, _f32(accum), _stream()), 'dv_loss_assemble_after')
 
 
 def axpby(y, x, a=1.0, b=0.0):

@@ -28,6 +28,8 @@ class _Plan:
         self.pair_host = np.nonzero(has_x2)[0]
         Np = self.Np = len(self.pair_host)
         n_lab = int(has_y.sum())
+        # (universal plans) normalisers handed over as data -- this rank's rows are a slice of a global batch
+        self.global_counts = bool(universal and counts is not None)
         if counts is None:
             counts = (B, Np, n_lab)
         self.n_tot, self.n_pairs, self.n_lab = [float(c) for c in counts]
@@ -215,6 +217,7 @@ class _Plan:
             self.y_dev = i32(np.zeros(B)) if cfg.has_y else None
             self.w_recl, self.w_pert, self.w_yl = zf(2 * L * B), zf(L * B), zf(L * B)
             self.beta_dev = zf(1)
+            self.gcounts_dev = i32(np.zeros(2)) if self.global_counts else None    # (N_pairs, N_labeled) of an explicit batch
             if not cfg.has_y:
                 self.c_yl = None
             # rows the feed guarantees to be labeled (one fprop row, the structure's own label path): a static flag

@@ -30,7 +30,7 @@ extern "C" {
 
 typedef void* dv_stream_t;
 
-#define DV_ABI_VERSION 10
+#define DV_ABI_VERSION 11
 
 enum { DV_OK = 0, DV_ERR_ARG = -1, DV_ERR_LAUNCH = -2, DV_ERR_UNSUPPORTED = -3 };
 
@@ -340,12 +340,39 @@ int dv_z2f_post_bwd(const float* dz2f, int64_t ld_dz2f, const float* dzdec_pert,
  * backward: coef[r] = dLoss/d out[r]; gradients are written ROW-ALIGNED (row r of
  * dq_* / dp_*); callers reduce duplicates with dv_rows_segment_sum.  With dz != NULL the
  * backward of that fused sample (dq_mu += dz, dq_sd += dz*eps*dstd/dsd) rides along. */
-int dv_kl_rows_fwd(const float* mu_q, const float* sd_q, int64_t ldq, const int32_t* qidx, const float* mu_p,
-                   const float* sd_p, int64_t ldp, const int32_t* pidx, float prior_mu, float prior_sd, int32_t n,
-                   int32_t reps, int32_t Z, int32_t mode, int32_t free_bits, float kl_min, float* raw_out,
-                   float* out, const float* add, const float* eps, int64_t lde, float* zout, int64_t ldz,
-                   const dv_wait* park, const float* mu2, const float* sd2, int64_t ld2, int32_t Z2,
-                   float* raw2_out, dv_stream_t stream);
+/* ABI 11: the forward's operands travel in a descriptor (29 positional arguments before: one transposed int64 away
+ * from silent corruption); field names as in the comment above */
+typedef struct dv_kl_rows_desc {
+    const float* mu_q;
+    const float* sd_q;
+    int64_t ldq;
+    const int32_t* qidx;
+    const float* mu_p;
+    const float* sd_p;
+    int64_t ldp;
+    const int32_t* pidx;
+    float prior_mu;
+    float prior_sd;
+    int32_t n;
+    int32_t reps;
+    int32_t Z;
+    int32_t mode;
+    int32_t free_bits;
+    float kl_min;
+    float* raw_out;
+    float* out;
+    const float* add;
+    const float* eps;
+    int64_t lde;
+    float* zout;
+    int64_t ldz;
+    const float* mu2;
+    const float* sd2;
+    int64_t ld2;
+    int32_t Z2;
+    float* raw2_out;
+} dv_kl_rows_desc;
+int dv_kl_rows_fwd(const dv_kl_rows_desc* d, const dv_wait* park, dv_stream_t stream);
 int dv_kl_rows_bwd(const float* coef, const float* raw, int32_t free_bits, float kl_min, const float* mu_q,
                    const float* sd_q, int64_t ldq, const int32_t* qidx, const float* mu_p, const float* sd_p,
                    int64_t ldp, const int32_t* pidx, float prior_mu, float prior_sd, int32_t n, int32_t reps,
@@ -523,14 +550,47 @@ typedef struct dv_batch_masks_desc {
     int32_t* label;
     float* c_klp;
     const int32_t* one_slot;
+    const int32_t* gcounts;
 } dv_batch_masks_desc;
-int dv_batch_feed(const float* x1, int64_t ld1, const float* x2, int64_t ld2, const int32_t* y, const int32_t* table,
-                  int32_t n_batches, const int32_t* ctr, const int32_t* base, int32_t B, const int32_t* pair_rows,
-                  int32_t Np, int32_t X, const float* noise, int64_t ldn, float sigma, float* xin, int64_t ldo,
-                  const int32_t* has_y, int32_t L, int32_t* label_r, const int32_t* fp_i, const int32_t* fp_lab,
-                  const int32_t* fp_slot, int32_t Mf, int32_t* fp_cls, float* onehot, int64_t ldh, int32_t Y,
-                  const float* yf, float* ylab, int32_t Yc, float* onehot2, int64_t ldh2,
-                  const dv_batch_masks_desc* masks, const dv_wait* park, dv_stream_t stream);
+/* ABI 11: the feed's operands as a descriptor (names as in the comment above; 37 positional arguments before) */
+typedef struct dv_batch_feed_desc {
+    const float* x1;
+    int64_t ld1;
+    const float* x2;
+    int64_t ld2;
+    const int32_t* y;
+    const int32_t* table;
+    int32_t n_batches;
+    const int32_t* ctr;
+    const int32_t* base;
+    int32_t B;
+    const int32_t* pair_rows;
+    int32_t Np;
+    int32_t X;
+    const float* noise;
+    int64_t ldn;
+    float sigma;
+    float* xin;
+    int64_t ldo;
+    const int32_t* has_y;
+    int32_t L;
+    int32_t* label_r;
+    const int32_t* fp_i;
+    const int32_t* fp_lab;
+    const int32_t* fp_slot;
+    int32_t Mf;
+    int32_t* fp_cls;
+    float* onehot;
+    int64_t ldh;
+    int32_t Y;
+    const float* yf;
+    float* ylab;
+    int32_t Yc;
+    float* onehot2;
+    int64_t ldh2;
+} dv_batch_feed_desc;
+int dv_batch_feed(const dv_batch_feed_desc* d, const dv_batch_masks_desc* masks, const dv_wait* park,
+                  dv_stream_t stream);
 /* dst[di,:W] = beta*dst[di,:W] + sum_{t in [seg_ptr[i],seg_ptr[i+1])} w[t]*src[seg_rows[t],:W],
  * di = dst_idx?dst_idx[i]:i; seg_ptr==NULL: segment i is the single row (seg_rows?seg_rows[i]:i).
  * Deterministic (no atomics): the transpose of every gather above. */
@@ -552,11 +612,13 @@ int dv_batch_feed(const float* x1, int64_t ld1, const float* x2, int64_t ld2, co
  * w_pert[q], c_klz2[q], c_klp[B + j].  Np == B is the layout written out above.
  * one_slot (B flags, optional): rows the plan gives ONE class slot because the feed guarantees they are labeled
  * (DeviceBatcher(label_bucket=...)): label[r] = y, the form dv_ymarg_* read for a single-slot row. */
-int dv_batch_masks(const int32_t* table, int32_t n_batches, const int32_t* ctr, const int32_t* base, const int32_t* hx,
-                   const int32_t* hy, const int32_t* y, int32_t B, int32_t L, int32_t Np, float n_tot, float kl_rate,
-                   float pert_rate, float yl_rate, const float* beta, float* c_nll, float* c_klz2, float* c_yl,
-                   float* w_recl, float* w_pert, float* w_yl, int32_t* label, float* c_klp, const int32_t* one_slot,
-                   dv_stream_t stream);
+/* gcounts (optional; data parallelism): the GLOBAL (N_pairs, N_labeled) of batch b as two int32 per batch
+ * of the table (table == NULL: one pair) -- every rank draws the same global index table from the shared seed and runs its
+ * slice of each batch, so the global counts are table data; with them the normalisers above use the global counts instead
+ * of this shard's own (n_tot is then the global number of rows): summed shard gradients == the gradient of the
+ * concatenated batch. */
+int dv_batch_masks(const dv_batch_masks_desc* m, const int32_t* table, int32_t n_batches, const int32_t* ctr,
+                   const int32_t* base, int32_t B, int32_t L, dv_stream_t stream);
 int dv_rows_segment_sum(const float* src, int64_t lds, const int32_t* seg_ptr, const int32_t* seg_rows,
                         const float* w, int32_t n, int32_t W, const int32_t* dst_idx, float* dst, int64_t ldd,
                         float beta, const dv_wait* park, dv_stream_t stream);
@@ -593,16 +655,15 @@ typedef struct dv_loss_term {
  * (src/DrVAE.py:787-795 averages the per-batch objective), read by the host once per epoch */
 int dv_loss_assemble(const dv_loss_term* terms, int32_t n_terms, const float* w_elbo, const float* w_cmpl,
                      float* loss, const int32_t* halt, int32_t n_halt, float* accum, dv_stream_t stream);
-/* same, but first parks like dv_flag_wait(flag, ctr, add, err, max_spins) inside the launch (the terms
- * of another chain are read only after the wait; saves the separate wait launch), and last advances up
- * to two device counters like dv_counters_add2 (c1 / c2 may be NULL; c1 may alias ctr: it is read before;
- * saves the counter launch in front of the optimiser).  With n_terms == 0 `loss` is left untouched: the launch
- * only parks and advances the counters (another chain assembles the scalars).  flag == NULL: no wait (ctr / err /
- * max_spins unused): the launch assembles the scalars and advances the counters */
-int dv_loss_assemble_after(int32_t* flag, const int32_t* ctr, int32_t add, int32_t* err, int32_t max_spins,
-                           const dv_loss_term* terms, int32_t n_terms, const float* w_elbo, const float* w_cmpl,
-                           float* loss, int32_t* c1, int32_t n1, int64_t inc1, int32_t* c2, int32_t n2,
-                           int64_t inc2, const int32_t* halt, int32_t n_halt, float* accum, dv_stream_t stream);
+/* same, but first parks on `wait` (a dv_wait, like dv_flag_wait) inside the launch (the terms of another chain are
+ * read only after the wait; saves the separate wait launch), and last advances the counters of `bump` (a dv_bump, like
+ * dv_counters_add2; a counter may alias wait->ctr: it is read before; saves the counter launch in front of the
+ * optimiser).  With n_terms == 0 `loss` is left untouched: the launch only parks and advances the counters (another
+ * chain assembles the scalars).  wait == NULL / wait->flag == NULL: no wait: the launch assembles the scalars and
+ * advances the counters; bump == NULL: no counters.  (ABI 11: the wait and the counters were ten positional scalars) */
+int dv_loss_assemble_after(const dv_wait* wait, const dv_loss_term* terms, int32_t n_terms, const float* w_elbo,
+                           const float* w_cmpl, float* loss, const dv_bump* bump, const int32_t* halt, int32_t n_halt,
+                           float* accum, dv_stream_t stream);
 /* nn.BatchNorm1d(N, affine=True) over the rows of x (M, N) -- the `batch_norm=True` option of blocks.MLP
  * (src/blocks.py:137-149).  training != 0: batch statistics (biased variance for the normalisation; running_mean /
  * running_var, when given, move by `momentum`, running_var with the unbiased variance, as torch); training == 0: the

@@ -777,8 +777,11 @@ def counter_add(counter, inc=1):
 
 def batch_masks(B, L, *, n_tot, kl_rate, pert_rate, yl_rate, beta, c_nll, w_recl, hx=None, hy=None, y=None, c_klz2=None,
                 c_yl=None, w_pert=None, w_yl=None, label=None, c_klp=None, table=None, n_batches=0, ctr=None, base=None,
-                Np=None, one_slot=None):
+                Np=None, one_slot=None, gcounts=None):
     Np = B if Np is None else Np
+    gc = None
+    if gcounts is not None:       # data parallelism: the GLOBAL (N_pairs, N_labeled) of the batch are table data
+        gc = gcounts[min(max(int(ctr[0]) - int(base[0]), 0), n_batches - 1) if table is not None else 0]
     if c_klp is not None:
         s_ = table[min(max(int(ctr[0]) - int(base[0]), 0), n_batches - 1)].long() if table is not None else \
             torch.arange(B, device=c_nll.device)
@@ -795,7 +798,7 @@ def batch_masks(B, L, *, n_tot, kl_rate, pert_rate, yl_rate, beta, c_nll, w_recl
     if hx is not None:
         LP = L * Np
         px = (hx[src[:Np]] != 0).repeat(L)
-        npair = max(float((hx[src] != 0).sum()), 1.0)
+        npair = max(float((hx[src] != 0).sum()) if gc is None else float(gc[0]), 1.0)
         c_nll[LB:LB + LP] = torch.where(px, -ct, 0.0)
         w_recl[LB:LB + LP] = torch.where(px, ct, 0.0)
         c_nll[LB + LP:LB + 2 * LP] = torch.where(px, -bt * pert_rate / (L * npair), 0.0)
@@ -803,7 +806,7 @@ def batch_masks(B, L, *, n_tot, kl_rate, pert_rate, yl_rate, beta, c_nll, w_recl
         c_klz2[:LP] = torch.where(px, bt * kl_rate * ct, 0.0)
     if hy is not None:
         py = (hy[src] != 0).repeat(L)
-        nlab = max(float((hy[src] != 0).sum()), 1.0)
+        nlab = max(float((hy[src] != 0).sum()) if gc is None else float(gc[1]), 1.0)
         c_yl[:LB] = torch.where(py, -yl_rate / (L * nlab), 0.0)
         w_yl[:LB] = 1.0 / (L * nlab)
         label[:LB] = torch.where(py, -2 - y[src].to(label.dtype).repeat(L), torch.zeros_like(label[:LB]))

@@ -39,7 +39,7 @@ def test_library_exports_every_symbol(lib):
     for name in _header_decls():
         assert hasattr(lib, name), name
     from drvae_amd import _lib
-    assert lib.dv_abi_version() == _lib.ABI_VERSION == 10
+    assert lib.dv_abi_version() == _lib.ABI_VERSION == 11
     assert 'dv_arm_park' not in _lib.SIGNATURES and not hasattr(lib, 'dv_arm_park')     # no armed (hidden) state
     assert lib.dv_error_string(0) == b'ok'
     assert lib.dv_error_string(-1) == b'invalid argument'
@@ -63,14 +63,44 @@ def test_gemm_desc_layout_matches_header():
 
 @pytest.mark.parametrize('cname,pyname', [('dv_wait', 'Wait'), ('dv_bump', 'Bump'), ('dv_loss_term', 'LossTerm'),
                                           ('dv_publish', 'Publish'), ('dv_heads_epi', 'HeadsEpi'),
-                                          ('dv_fprop_kl', 'FpropKl'), ('dv_ymarg', 'Ymarg')])
+                                          ('dv_fprop_kl', 'FpropKl'), ('dv_ymarg', 'Ymarg'), ('dv_seg_add', 'SegAdd'),
+                                          ('dv_batch_masks_desc', 'BatchMasks'), ('dv_batch_feed_desc', 'BatchFeed'),
+                                          ('dv_kl_rows_desc', 'KlRows')])
 def test_small_struct_layouts_match_header(cname, pyname):
     from drvae_amd import _lib
     src = open(os.path.join(ROOT, 'include', 'drvae_hip.h')).read()
     body = re.search(r'typedef struct %s \{(.*?)\} %s;' % (cname, cname), src, flags=re.S).group(1)
     body = re.sub(r'/\*.*?\*/', '', body, flags=re.S)
-    names = [re.sub(r'\[\d+\]', '', re.sub(r'.*[\s\*]', '', st.strip())) for st in body.split(';') if st.strip()]
-    assert names == [f[0] for f in getattr(_lib, pyname)._fields_]
+    names = [re.sub(r'\[\d+\]', '', re.sub(r'.*[\s\*]', '', part.strip())) for st in body.split(';') if st.strip()
+             for part in st.split(',')]
+    py = getattr(_lib, pyname)
+    assert names == [f[0] for f in py._fields_]
+    # ... and the field TYPES: pointer / int32 / int64 / float, declaration by declaration
+    import ctypes as C
+    kinds = []
+    for st in body.split(';'):
+        st = st.strip()
+        if not st:
+            continue
+        for j, part in enumerate(st.split(',')):
+            decl = part.strip() if j == 0 else re.match(r'(?:const\s+)?\w+', st).group(0) + ' ' + part.strip()
+            arr = re.search(r'\[(\d+)\]', decl)
+            if '*' in decl:
+                k = C.c_void_p
+            elif decl.startswith('int64_t'):
+                k = C.c_int64
+            elif decl.startswith('int32_t'):
+                k = C.c_int32
+            elif decl.startswith('float'):
+                k = C.c_float
+            else:
+                raise AssertionError(decl)
+            kinds.append(k * int(arr.group(1)) if arr else k)
+    assert [C.sizeof(k) for k in kinds] == [C.sizeof(f[1]) for f in py._fields_], cname
+    for k, f in zip(kinds, py._fields_):
+        base_k = getattr(k, '_type_', k) if hasattr(k, '_length_') else k
+        base_f = getattr(f[1], '_type_', f[1]) if hasattr(f[1], '_length_') else f[1]
+        assert (base_k is C.c_float) == (base_f is C.c_float), (cname, f[0])
 
 
 def test_argument_validation_without_gpu(lib):

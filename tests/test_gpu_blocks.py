@@ -342,3 +342,32 @@ def test_model_level_mmd_criterion(mods, dev):
     got = Mix._get_mmd_criterion(types.SimpleNamespace(kernel_MMD='identity'), z, [ind, 1 - ind])
     keep = torch.arange(12, device=dev) != 3
     close(got, (-blk.mmd_objective(z[3:4], z[keep], 'identity')).cpu().numpy(), rtol=1e-6)
+
+
+@pytest.mark.parametrize('tag', list(C.masked_linear_cases()))
+def test_masked_linear_on_the_hip_gemm(mods, dev, tag):
+    """a3 on the GPU (src/layers.py:44-139): the class acts as nn.Linear in the reference (its masked ``forward`` is
+    unreachable), so ``MaskedLinear(...)(x)`` is x W^T + b through ``ops.linear_act`` -- forward and all three gradients
+    from the HIP GEMM against the host fp32 reference -- and a stacked MADE built through ``get_m()`` keeps the masks of
+    the reference's own layers (tests/golden/masked_linear.npz, bit-exact) after the move to the device"""
+    blk, lyr = mods
+    gold = C.load('masked_linear')
+    m_pre, x, h_ref = None, None, None
+    g = torch.Generator().manual_seed(5)
+    for li, (in_f, out_f, output_layer, rev) in enumerate(C.masked_linear_cases()[tag]):
+        lay = lyr.MaskedLinear(in_f, out_f, m_pre, output_layer, rev_order=rev).to(dev)
+        assert np.array_equal(lay.mask.cpu().numpy(), gold['%s/%d/mask' % (tag, li)])
+        assert np.array_equal(np.asarray(lay.get_m()).astype(np.int64), gold['%s/%d/m' % (tag, li)])
+        n_in = lay.weight.shape[1]
+        xin = torch.randn(19, n_in, generator=g).to(dev).requires_grad_(True)
+        dy = torch.randn(19, out_f, generator=g).to(dev)
+        y = lay(xin)
+        (y * dy).sum().backward()
+        W, b = lay.weight.detach().cpu(), lay.bias.detach().cpu()
+        xr = xin.detach().cpu()
+        close(y, (xr @ W.t() + b).numpy())
+        close(xin.grad, (dy.cpu() @ W).numpy())
+        close(lay.weight.grad, (dy.cpu().t() @ xr).numpy())
+        close(lay.bias.grad, dy.cpu().sum(0).numpy())
+        assert list(lay.state_dict()) == ['weight', 'bias']          # mask / m are attributes, not state (reference)
+        m_pre = lay.get_m()

@@ -201,3 +201,153 @@ def test_bench_self_launch_ends_the_job_when_a_rank_dies(dev):
     assert out.returncode != 0
     assert not [ln for ln in out.stdout.splitlines() if ln.startswith('{') and '"metric"' in ln]
     assert time.time() - t0 < 300
+
+
+
+# ------------------------------------------------------------- data parallelism above the engine (round 5)
+def _fit_case(kind, dev, n=512):
+    """a small model + an HBM-resident dataset whose group mix varies from batch to batch"""
+    from tests.test_fit import _tiny_dataset, _tiny_model
+    model = _tiny_model(kind, device=dev, epochs=2, dim_x=40, dim_h_en_z1=[32], dim_h_de_x=[24], dim_z1=8)
+    rs = np.random.RandomState(3)
+    from drvae_amd import data as D
+    y = rs.randint(0, 2, n)
+    x1 = (rs.standard_normal((n, 40)) + 0.8 * (2 * y[:, None] - 1) * (np.arange(40) % 3 == 0)).astype(np.float32)
+    hx = (rs.rand(n) < 0.45).astype(np.int64)
+    hy = (rs.rand(n) < 0.6).astype(np.int64)
+    x2 = ((x1 * 0.7 + 0.2) * hx[:, None]).astype(np.float32)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    if kind == 'vfae':
+        ds = D.VFAEDataset(t(x1), t(np.zeros(n, np.int64)), t(y), t(hy))
+    else:
+        ds = D.DrVAEDataset(t(x1), t(x2), t(np.zeros(n, np.int64)), t(y), t(hx), t(hy))
+    w = D.compute_balanced_weights(np.arange(n) % 7)
+    return model, ds, w
+
+
+def _fit_epochs(model, ds, w, bs, buckets, n_epochs=2):
+    """``fit``'s training half: ``_epoch_device`` per epoch (bind with the model's dp state, epoch table, captured
+    graphs, replays); returns per-epoch mean objectives and the tables this rank ran"""
+    from drvae_amd import data as D
+    bat = D.DeviceBatcher(ds, w, bs, seed=11, mode='sampler', **buckets)
+    model.add_noise = True
+    means, tabs = [], []
+    for ep in range(n_epochs):
+        means.append(model._epoch_device(bat, ep + 1, False))
+        tabs.append(model.engine().plan.feed.table.clone().cpu().numpy())
+    return means, tabs, bat
+
+
+def _fit_worker(rank, world, port, kind, buckets, backend, q):
+    try:
+        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                          LOCAL_RANK='0', DRVAE_DIST_BACKEND=backend, DRVAE_SIDE_CUS='64')
+        if world == 1:
+            os.environ['DRVAE_FORCE_DP'] = '1'
+        import torch.distributed as dist
+        torch.cuda.set_device(0)
+        dev = torch.device('cuda', 0)
+        model, ds, w = _fit_case(kind, dev)
+        assert model.enable_data_parallel() == (rank, world)
+        assert model._allreduce is not None and model._dp == (rank, world)
+        means, tabs, bat = _fit_epochs(model, ds, w, 32 // world, buckets)
+        eng = model.engine()
+        torch.cuda.synchronize()
+        eng.check_sync()
+        assert len(eng._graphs) == 2                     # split graphs around the exchange
+        perf, _ = model.evaluate_performance_on_dataset(ds)
+        q.put((rank, dict(means=means, tabs=tabs, gtab=bat.global_table.cpu().numpy(), param=eng.arena.param.cpu().numpy(),
+                          iters=model.finished_training_iters, x1_pearr=perf['x1_pearr'],
+                          elbo=float(perf['losses']['ELBO']))))
+        if dist.is_initialized():
+            dist.barrier()
+            dist.destroy_process_group()
+    except Exception:
+        import traceback
+        q.put((rank, traceback.format_exc()))
+
+
+def _run_fit_ranks(world, kind, buckets, backend='gloo'):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29300 + (os.getpid() * 7 + world) % 300
+    procs = [ctx.Process(target=_fit_worker, args=(r, world, port, kind, buckets, backend, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=420) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=90)
+    for r, o in got:
+        assert isinstance(o, dict), o
+    return [o for _, o in got]
+
+
+@pytest.mark.parametrize('kind', ['drvae', 'vfae'])
+def test_fit_epochs_sampler_feed_two_ranks_equal_one_rank(dev, kind):
+    """``model.enable_data_parallel()`` + ``fit``'s device epochs on the exact-sampler feed.  Two ranks
+    (one GPU, gloo) with 16 rows each: every rank draws the same global table (device generator, shared seed), runs its
+    columns on the batch-independent plan, takes the batch's global (N_pairs, N_labeled) from the table (dv_batch_feed:
+    masks.gcounts), replays split graphs around ONE exchange -- and trains like one process on 32-row batches of the same
+    table with the Philox draws keyed by global row: losses 1e-4, parameters 1e-4 norm-wise, replicas bit-identical"""
+    model, ds, w = _fit_case(kind, dev)
+    means, tabs, bat = _fit_epochs(model, ds, w, 32, {})
+    torch.cuda.synchronize()
+    single = model.engine().arena.param.cpu().numpy()
+    perf, _ = model.evaluate_performance_on_dataset(ds)
+    r0, r1 = _run_fit_ranks(2, kind, {})
+    np.testing.assert_array_equal(r0['gtab'], r1['gtab'])
+    for ep in range(2):
+        np.testing.assert_array_equal(np.concatenate([r0['tabs'][ep], r1['tabs'][ep]], 1), tabs[ep])
+    assert r0['iters'] == r1['iters'] == model.finished_training_iters == 2 * (512 // 32)
+    for r in (r0, r1):
+        np.testing.assert_allclose(r['means'], means, rtol=1e-4)
+        err = np.linalg.norm(r['param'] - single) / np.linalg.norm(single)
+        assert err < 1e-4, err
+        assert abs(r['x1_pearr'] - perf['x1_pearr']) < 1e-3
+    np.testing.assert_array_equal(r0['param'], r1['param'])
+    assert r0['x1_pearr'] == r1['x1_pearr'] and r0['elbo'] == r1['elbo']      # same evaluation draws on every rank
+
+
+def test_fit_epochs_bucketed_sampler_feed_two_ranks(dev):
+    """the same with bucketed plans (every rank re-orders ITS columns pairs first and switches between its own captured
+    plans; the exchange sits between the graphs, so ranks on different plans still meet in it): replicas bit-identical,
+    and the job trains like one process given the ranks' re-ordered columns as its table"""
+    kind, buckets = 'drvae', dict(pair_bucket=4, label_bucket=4)
+    r0, r1 = _run_fit_ranks(2, kind, buckets)
+    np.testing.assert_array_equal(r0['param'], r1['param'])
+    np.testing.assert_array_equal(np.sort(np.concatenate([r0['tabs'][1], r1['tabs'][1]], 1), 1), np.sort(r0['gtab'], 1))
+    from drvae_amd import data as D
+    model, ds, w = _fit_case(kind, dev)
+    bat = D.DeviceBatcher(ds, w, 32, seed=11, mode='sampler')
+    model.add_noise = True
+    eng = model.engine()
+    means = []
+    for ep in range(2):
+        # one process, 32-row batches = [rank 0's re-ordered 16 | rank 1's]: same rows at the same global positions
+        tab = torch.from_numpy(np.concatenate([r0['tabs'][ep], r1['tabs'][ep]], 1)).to(dev)
+        bat.bind(eng)
+        eng.add_noise, eng.iters = True, model.finished_training_iters
+        bat.begin_epoch(table=tab)
+        for _ in range(len(bat)):
+            eng.train_step()
+        model.finished_training_iters = eng.iters
+    torch.cuda.synchronize()
+    single = eng.arena.param.cpu().numpy()
+    err = np.linalg.norm(r0['param'] - single) / np.linalg.norm(single)
+    assert err < 1e-4, err
+
+
+def test_fit_epochs_over_rccl_single_rank(dev):
+    """the model-level DP path over the REAL transport: a one-rank RCCL communicator (DRVAE_FORCE_DP=1) in a child
+    process -- enable_data_parallel, sampler feed with global counts, split graphs, the collective between them -- trains
+    exactly like the plain single-process epochs on the same table"""
+    kind = 'drvae'
+    model, ds, w = _fit_case(kind, dev)
+    means, tabs, bat = _fit_epochs(model, ds, w, 32, {})
+    torch.cuda.synchronize()
+    single = model.engine().arena.param.cpu().numpy()
+    (r0,) = _run_fit_ranks(1, kind, {}, backend='nccl')
+    np.testing.assert_array_equal(r0['tabs'][1], tabs[1])
+    np.testing.assert_allclose(r0['means'], means, rtol=1e-4)
+    err = np.linalg.norm(r0['param'] - single) / np.linalg.norm(single)
+    assert err < 1e-4, err

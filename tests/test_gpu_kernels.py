@@ -80,10 +80,20 @@ def gemm_tol(K_):
     return dict(rtol=2e-4, atol=2e-5 * max(1.0, K_ ** 0.5))
 
 
+PRODUCT_TILINGS = (0, 1, 2, 3, 17, 40, 46)      # dv_gemm_has_tiling of the product library
+
+
+def tilings(*ts):
+    """parametrisation over GEMM tilings: the product library's run by default, the lab ones (tuning build only:
+    python -m drvae_amd.build --lab) carry the ``lab`` marker and are deselected unless asked for (tests/conftest.py)"""
+    return [t if t in PRODUCT_TILINGS else pytest.param(t, marks=pytest.mark.lab) for t in ts]
+
+
 def force_tiling(t):
-    """force a GEMM tiling; the lab tilings only exist in the tuning build (python -m drvae_amd.build --lab)"""
+    """force a GEMM tiling; a product tiling the library does not have is a failure, not a skip"""
     import drvae_amd.kernels as K
     if K.gemm_force_tiling(t) != 0:
+        assert t not in PRODUCT_TILINGS, 'product tiling %d missing from the library' % t
         pytest.skip('tiling %d: lab build only' % t)
 
 
@@ -93,7 +103,7 @@ SHAPES = [(7, 5, 13), (64, 64, 32), (65, 33, 31), (225, 800, 978), (150, 200, 10
           (260, 516, 200), (128, 256, 48), (1000, 300, 64)]
 
 
-@pytest.mark.parametrize('tiling', [0, 1, 2, 3, 5, 9, 11, 12, 13, 16, 17, 40, 46])
+@pytest.mark.parametrize('tiling', tilings(0, 1, 2, 3, 5, 9, 11, 12, 13, 16, 17, 40, 46))
 @pytest.mark.parametrize('M,N,Kd', SHAPES)
 def test_gemm_forward_epilogue(K, dev, tiling, M, N, Kd):
     from drvae_amd import _lib
@@ -112,7 +122,7 @@ def test_gemm_forward_epilogue(K, dev, tiling, M, N, Kd):
         K.gemm_force_tiling(0)
 
 
-@pytest.mark.parametrize('tiling', [0, 1, 2, 3, 5, 16, 17, 40, 46])
+@pytest.mark.parametrize('tiling', tilings(0, 1, 2, 3, 5, 16, 17, 40, 46))
 @pytest.mark.parametrize('M,N,Kd', SHAPES)
 def test_gemm_backward_products(K, dev, tiling, M, N, Kd):
     from drvae_amd import _lib
@@ -1173,3 +1183,49 @@ def test_batch_masks_and_labeled_slots(K, dev):
     K.loss_assemble(la, [(x2d, wrow, 0.5, 0, 7)], w_elbo, w_cmpl)
     R.loss_assemble(lb, [(x2d, wrow, 0.5, 0, 7)], w_elbo, w_cmpl)
     close(la, lb, rtol=1e-5, atol=1e-5)
+
+
+def test_batch_masks_global_counts(K, dev):
+    """ABI 11, data parallelism: with ``gcounts`` the normalisers N_pairs / N_labeled are the GLOBAL batch's, read from
+    the table's per-batch counts (explicit batch: one pair) instead of being counted over this rank's rows -- standalone,
+    and riding on the feed's launch"""
+    B, L, Y, nb = 24, 2, 2, 4
+    g = torch.Generator().manual_seed(3)
+    hx = (torch.rand(90, generator=g) < 0.4).to(torch.int32).to(dev)
+    hy = (torch.rand(90, generator=g) < 0.6).to(torch.int32).to(dev)
+    y = torch.randint(0, Y, (90,), generator=g).to(torch.int32).to(dev)
+    gtab = torch.randint(0, 90, (nb, 3 * B), generator=g).to(torch.int32).to(dev)       # three ranks' columns
+    table = gtab[:, B:2 * B].contiguous()                                                  # rank 1's
+    gc = torch.stack([hx[gtab.long()].sum(1), hy[gtab.long()].sum(1)], 1).to(torch.int32).contiguous()
+    ctr, base = torch.tensor([12], dtype=torch.int32, device=dev), torch.tensor([10], dtype=torch.int32, device=dev)
+    beta = torch.tensor([1.0], device=dev)
+    x1, x2 = rnd(dev, 90, 8, seed=1), rnd(dev, 90, 8, seed=2)
+    pair_rows = torch.arange(B, dtype=torch.int32, device=dev)
+    got = []
+    for how in ('kernel', 'ref', 'feed', 'explicit', 'explicit_ref'):
+        bufs = dict(c_nll=torch.full((3 * L * B,), 9.0, device=dev), c_klz2=torch.full((L * B,), 9.0, device=dev),
+                    c_yl=torch.full((L * B,), 9.0, device=dev), w_recl=torch.full((2 * L * B,), 9.0, device=dev),
+                    w_pert=torch.full((L * B,), 9.0, device=dev), w_yl=torch.full((L * B,), 9.0, device=dev),
+                    label=torch.full((L * B,), 9, dtype=torch.int32, device=dev))
+        kw = dict(n_tot=float(3 * B), kl_rate=0.7, pert_rate=0.05, yl_rate=1.3, beta=beta, **bufs)
+        if how == 'feed':
+            xin = torch.zeros(2 * B, 8, device=dev)
+            K.batch_feed(xin, x1, x2, y, table, nb, ctr, base, pair_rows=pair_rows, L=L,
+                         masks=dict(hx=hx, hy=hy, y=y, gcounts=gc, **kw))
+        elif how.startswith('explicit'):
+            tb = table[2].long()
+            (K if how == 'explicit' else R).batch_masks(B, L, hx=hx[tb].contiguous(), hy=hy[tb].contiguous(),
+                                                        y=y[tb].contiguous(), gcounts=gc[2:3].contiguous(), **kw)
+        else:
+            (K if how == 'kernel' else R).batch_masks(B, L, table=table, n_batches=nb, ctr=ctr, base=base, hx=hx, hy=hy, y=y,
+                                                      gcounts=gc, **kw)
+        got.append(bufs)
+    for k in got[0]:
+        for other in got[1:]:
+            close(got[0][k].float(), other[k].float(), rtol=1e-6, atol=1e-9)
+    n_p, n_l = float(gc[2, 0]), float(gc[2, 1])
+    assert n_p > float(hx[table[2].long()].sum()) and n_l > float(hy[table[2].long()].sum())      # really the global ones
+    nz = got[0]['w_pert'][got[0]['w_pert'] != 0]
+    assert nz.numel() and torch.allclose(nz, torch.full_like(nz, 1.0 / (L * n_p)))
+    assert torch.allclose(got[0]['w_yl'], torch.full_like(got[0]['w_yl'], 1.0 / (L * n_l)))
+    assert torch.allclose(got[0]['w_recl'][:L * B], torch.full((L * B,), 1.0 / (L * 3 * B), device=dev))
