@@ -315,6 +315,14 @@ class DeviceBatcher:
         fd.base.copy_(eng.step_dev)         # device to device: batch index = optimiser step - base
         return fd.table
 
+    def rebase(self):
+        """the current epoch table again from its first batch: batch index = optimiser step - base (after replays that
+        were not training steps of the epoch: CU-split tuning, a capture's warm-up).  No draw: under data parallelism
+        every rank must consume the shared generator alike, whatever it captures or tunes"""
+        fd = self.engine.plan.feed
+        fd.base.copy_(self.engine.step_dev)
+        self._k = 0
+
     def _feed_rows(self, x):
         """the dataset as the graph-resident feed reads it: fp32 rows 16-B aligned -- a copy with padded rows when the gene
         count is no multiple of 4 (978): the feed's row gather is then 16-B loads instead of 4-B ones (epoch feed 0.1932 ->

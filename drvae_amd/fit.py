@@ -247,7 +247,7 @@ class FitMixin:
             if self._allreduce is None and not (bucketed and getattr(eng, '_side_cus', None)):
                 eng.tune_partition()        # CU split of the two launch chains, by timing (state restored)
             if resident_feed:
-                batcher.begin_epoch()       # (the tuning replays advanced the step counter: re-base the table)
+                batcher.rebase()            # (the tuning replays advanced the step counter: re-base the table)
         if getattr(batcher, 'bucketed', False):         # a plan per number-of-pairs bucket: capture the missing ones
             def cap(e):
                 e.capture(split_for_allreduce=self._allreduce is not None)
