@@ -273,7 +273,7 @@ def gemm_roofline(eng, cfg, rows, frac_pair, frac_lab, repeats=20, workload='cfg
                   'of the per-launch times (= avg FLOPs per launch / avg launch duration)' % repeats}
     # ONE definition of the headline figure (round 5): the step's algorithmic GEMM FLOPs over THIS LINE's ms_per_step --
     # the contract's timed region, everything that is not a GEMM included -- over the fp32-MFMA peak; a reader recomputes
-    # it from the line: frac = algorithmic_gflop_per_step / ms_per_step / 1e3 / peak.  The kernel-level figures keep keys of
+    # it from the line: frac = algorithmic_gflop_per_step / ms_per_step / peak (GFLOP per ms = TFLOP/s).  The kernel-level figures keep keys of
     # their own: `isolated` (this run, launches re-issued alone), `in_graph` (the committed profile of the running step)
     a_line = algorithmic / (ms_per_step * 1e-3) / 1e12
     out = {'bound': 'mfma', 'achieved': round(a_line, 3), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',

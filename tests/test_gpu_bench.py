@@ -48,13 +48,13 @@ def test_headline_roofline_follows_from_the_line_and_carries_every_workload():
     r = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1])
     rf = r['roofline']
     assert rf['bound'] == 'mfma' and rf['peak'] == 157.3 and rf['ms_per_step'] == r['ms_per_step']
-    want = rf['algorithmic_gflop_per_step'] / r['ms_per_step'] / 1e3 / rf['peak']
+    want = rf['algorithmic_gflop_per_step'] / r['ms_per_step'] / rf['peak']
     assert rf['frac'] == pytest.approx(want, rel=2e-3)
     assert rf['achieved'] == pytest.approx(want * rf['peak'], rel=2e-3)
     assert 'step_level' not in rf and rf['isolated']['frac'] > 0 and rf['steady']['ms_per_step'] == r['steady_state']['ms_per_step']
     for name in ('cfg1', 'cfg4', 'cfg5'):
         w = rf['workloads'][name]
-        assert w['frac'] == pytest.approx(w['algorithmic_gflop_per_step'] / w['ms_per_step'] / 1e3 / rf['peak'], rel=2e-3)
+        assert w['frac'] == pytest.approx(w['algorithmic_gflop_per_step'] / w['ms_per_step'] / rf['peak'], rel=2e-3)
         assert w['ms_per_step'] == r['other_workloads'][name]['ms_per_step'] and w['steps'] > 0
     assert rf['workloads']['cfg5']['frac'] > 0.5          # the one configuration where the MFMA roofline binds
     assert r['finite'] and not r.get('extras_failed')

@@ -308,14 +308,19 @@ def test_fit_epochs_sampler_feed_two_ranks_equal_one_rank(dev, kind):
     assert r0['x1_pearr'] == r1['x1_pearr'] and r0['elbo'] == r1['elbo']      # same evaluation draws on every rank
 
 
-def test_fit_epochs_bucketed_sampler_feed_two_ranks(dev):
+@pytest.mark.parametrize('buckets', [dict(pair_bucket=4), dict(pair_bucket=4, label_bucket=4)], ids=['pairs', 'pairs+labels'])
+def test_fit_epochs_bucketed_sampler_feed_two_ranks(dev, buckets):
     """the same with bucketed plans (every rank re-orders ITS columns pairs first and switches between its own captured
     plans; the exchange sits between the graphs, so ranks on different plans still meet in it): replicas bit-identical,
-    and the job trains like one process given the ranks' re-ordered columns as its table"""
-    kind, buckets = 'drvae', dict(pair_bucket=4, label_bucket=4)
+    the ranks' columns are a permutation of the shared global table, and (pair buckets) the job trains like one process
+    given the ranks' re-ordered columns as its table.  With label buckets a row that is labeled for sure has ONE fprop
+    row, whose z3 draw is another Philox draw than the true-class slot's of the every-slot plan: equal in distribution,
+    not in value -- there the objective has to agree statistically"""
+    kind = 'drvae'
     r0, r1 = _run_fit_ranks(2, kind, buckets)
     np.testing.assert_array_equal(r0['param'], r1['param'])
     np.testing.assert_array_equal(np.sort(np.concatenate([r0['tabs'][1], r1['tabs'][1]], 1), 1), np.sort(r0['gtab'], 1))
+    assert np.all(np.isfinite(r0['means'])) and r0['means'] == r1['means']
     from drvae_amd import data as D
     model, ds, w = _fit_case(kind, dev)
     bat = D.DeviceBatcher(ds, w, 32, seed=11, mode='sampler')
@@ -334,7 +339,10 @@ def test_fit_epochs_bucketed_sampler_feed_two_ranks(dev):
     torch.cuda.synchronize()
     single = eng.arena.param.cpu().numpy()
     err = np.linalg.norm(r0['param'] - single) / np.linalg.norm(single)
-    assert err < 1e-4, err
+    if 'label_bucket' in buckets:
+        assert err < 0.05, err
+    else:
+        assert err < 1e-4, err
 
 
 def test_fit_epochs_over_rccl_single_rank(dev):
