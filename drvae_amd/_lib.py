@@ -93,6 +93,12 @@ class KlRows(C.Structure):       # dv_kl_rows_desc
                 ('zout', _p), ('ldz', _i64), ('mu2', _p), ('sd2', _p), ('ld2', _i64), ('Z2', _i32), ('raw2_out', _p)]
 
 
+class NllRawCs(C.Structure):     # dv_nll_raw_cs_desc
+    _fields_ = [('coef', _p), ('x', _p), ('ldx', _i64), ('xidx', _p), ('mu', _p), ('sd', _p), ('ldp', _i64), ('M', _i32),
+                ('X', _i32), ('shift', _f), ('out_part', _p), ('chunks', _i32), ('dmu', _p), ('dsd', _p), ('ldd', _i64),
+                ('bias_mu', _p), ('bias_sd', _p), ('ws', _p), ('ldw', _i64), ('sd_off', _i64), ('row_blocks', _i32)]
+
+
 class LossTerm(C.Structure):
     _fields_ = [('x', _p), ('w', _p), ('n', _i32), ('scale', _f), ('out', _i32), ('row_len', _i32)]
 
@@ -125,6 +131,9 @@ SIGNATURES = {
                        _p, _p, _i64, _p, _p, _i64, _f, _p, _i64, _p, _i64, _p],
     'dv_gauss_nll_rows_fwd': [_p, _i64, _p, _p, _p, _i64, _i32, _i32, _i32, _p, _p],
     'dv_gauss_nll_rows_fwdbwd': [_p, _p, _i64, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _f, _p, _p, _p, _i64, _p, _p, _p],
+    'dv_gauss_nll_rows_raw_cs': [C.POINTER(NllRawCs), _p],
+    'dv_nll_raw_cs_chunks': [_i32],
+    'dv_nll_raw_cs_row_blocks': [_i32],
     'dv_rec_nll_rows': [_i32, _f, _p, _p, _i64, _p, _p, _i64, _i32, _i32, _p, _p, _i64, _p],
     'dv_gauss_nll_rows_bwd': [_p, _p, _i64, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _f, _p, _p, _i64, _p, _i64,
                               _f, _p],

@@ -99,28 +99,36 @@ class _Chain:
             x = [self.out[li]]
         return self.out[-1]
 
-    def backward(self, dpre_last, inputs, dinputs=None, wbranch=None, publish_after_last=None, publish_first=None):
+    def backward(self, dpre_last, inputs, dinputs=None, wbranch=None, publish_after_last=None, publish_first=None,
+                 after_last=None, db_last_done=False):
         """dpre_last: gradient w.r.t. the last layer's pre-activation.  ``dinputs``: per input
         source a list of (dst, alpha, beta) destinations for its gradient (or None to skip).
         ``wbranch``: optional side stream for the weight-gradient GEMMs (they are leaves: only
         Adam reads them), so that they overlap the dx chain.  ``publish_after_last`` = (flag, counter, add):
         the first launch AFTER the last layer's launches publishes the flag on entry (= both gradients of the
         last layer are final and its weights are no longer read); ``publish_first``: the chain's FIRST launch
-        does (= everything in front of this backward pass is complete)."""
+        does (= everything in front of this backward pass is complete).  ``after_last``: called once the last layer's
+        launches are enqueued (its gradients are final behind them and its weights no longer read).  ``db_last_done``: the
+        last layer's bias gradient has been written by the producer of ``dpre_last`` already (``kernels.nll_rows_raw_cs``)."""
         dpre = dpre_last
         pending_pub = publish_first
-        for li in range(len(self.layers) - 1, -1, -1):
+        n_layers = len(self.layers)
+        for li in range(n_layers - 1, -1, -1):
+            if li == n_layers - 2 and after_last is not None:
+                after_last()
+                after_last = None
             l = self.layers[li]
+            db = None if (db_last_done and li == n_layers - 1) else l.db
             srcs = list(inputs) if li == 0 else [self.out[li - 1]]
             if li == len(self.layers) - 2 and publish_after_last is not None:
                 pending_pub = publish_after_last
 
-            def wgrad(l=l, srcs=srcs, dpre=dpre):
+            def wgrad(l=l, srcs=srcs, dpre=dpre, db=db):
                 dW = l.raw if l.g is not None else l.dW
                 c0 = 0
                 for si, s in enumerate(srcs):
                     w = s.shape[1]
-                    K.linear_bwd_weight(dW[:, c0:c0 + w], dpre, s, dbias=l.db if si == 0 else None, overread=True,
+                    K.linear_bwd_weight(dW[:, c0:c0 + w], dpre, s, dbias=db if si == 0 else None, overread=True,
                                         npad=len(srcs) == 1 and l.g is None)
                     c0 += w
                 if l.g is not None:
@@ -133,13 +141,13 @@ class _Chain:
             if wbranch is None and l.g is None and len(srcs) == 1 and single_dst:
                 if li > 0:
                     prev = self.layers[li - 1]
-                    K.linear_bwd_pair(l.dW, l.db, self.dpre[li - 1], dpre, srcs[0], l.W, yref=self.out[li - 1],
+                    K.linear_bwd_pair(l.dW, db, self.dpre[li - 1], dpre, srcs[0], l.W, yref=self.out[li - 1],
                                       act=prev.act0, shift=prev.shift0, overread=True, publish=pending_pub, npad=True,
                                       npad_x=True)
                     dpre = self.dpre[li - 1]
                 else:
                     dst, alpha, beta = dinputs[0][0]
-                    K.linear_bwd_pair(l.dW, l.db, dst, dpre, srcs[0], l.W, alpha=alpha, beta_x=beta, overread=True,
+                    K.linear_bwd_pair(l.dW, db, dst, dpre, srcs[0], l.W, alpha=alpha, beta_x=beta, overread=True,
                                       publish=pending_pub, npad=True, npad_x=_whole_rows(dst))
                 pending_pub = None
                 continue
@@ -164,5 +172,7 @@ class _Chain:
                         K.linear_bwd_data(dst, dpre, l.W[:, c0:c0 + w], kscale=l.scale, alpha=alpha, beta=beta,
                                           overread=True)
                     c0 += w
+        if after_last is not None:
+            after_last()
         if wbranch is not None:
             wbranch.join()

@@ -577,6 +577,87 @@ __global__ __launch_bounds__(256) void nll_rows_raw_sp_kernel(const float* __res
     }
 }
 
+// The same pass with the bias gradient of the heads folded in (round 5): db = column sums of (dmu | dsd) over the rows
+// used to be a pass of its own over the 1.3 GB of gradients this kernel has just written (wide configuration: 0.23 ms
+// per step).  Here a workgroup owns 256 four-gene groups x a block of kNllCsRows rows: every lane keeps the column sums
+// of its four genes in registers while it walks the rows, and a row's log-likelihood comes out as one partial per
+// column chunk (the loss assembly sums a row's partials: dv_loss_term.row_len).  Per-block column sums go to a small
+// workspace (row_blocks x ldw), summed in a fixed order by dv_colsum over row_blocks rows: deterministic, no atomics.
+constexpr int kNllCsRows = 64;
+struct NllCsArgs {
+    const float* coef; const float* x; int64_t ldx; const int32_t* xidx; const float* mu; const float* sd; int64_t ldp;
+    int M, X; float shift; float* out_part; int chunks; float* dmu; float* dsd; int64_t ldd;
+    const float* bias_mu; const float* bias_sd; float* ws; int64_t ldw; int64_t sd_off;
+};
+
+__global__ __launch_bounds__(256) void nll_rows_raw_cs_kernel(NllCsArgs a) {
+    __shared__ float part[4][kNllCsRows];
+    typedef float nt_f4 __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int X4 = a.X >> 2;
+    const int chunk = blockIdx.x, rb = blockIdx.y;
+    const int q = chunk * 256 + threadIdx.x;
+    const bool on = q < X4;
+    const int qc = on ? q : X4 - 1;
+    const int r0 = rb * kNllCsRows, r1 = r0 + kNllCsRows < a.M ? r0 + kNllCsRows : a.M;
+    const float4 bm = reinterpret_cast<const float4*>(a.bias_mu)[qc], bs = reinterpret_cast<const float4*>(a.bias_sd)[qc];
+    float4 cm = make_float4(0.f, 0.f, 0.f, 0.f), cs = make_float4(0.f, 0.f, 0.f, 0.f);
+    // two rows per trip: six 16-B loads in flight per lane (the loop is a chain of memory round trips otherwise)
+    for (int r = r0; r < r1; r += 2) {
+        const bool two = r + 1 < r1;
+        const int ra = r, rbb = two ? r + 1 : r;
+        const float c0 = a.coef[ra], c1 = a.coef[rbb];
+        const float4 x0 = reinterpret_cast<const float4*>(a.x + (int64_t)(a.xidx ? a.xidx[ra] : ra) * a.ldx)[qc];
+        const float4 x1 = reinterpret_cast<const float4*>(a.x + (int64_t)(a.xidx ? a.xidx[rbb] : rbb) * a.ldx)[qc];
+        const nt_f4 m0 = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(a.mu + (int64_t)ra * a.ldp) + qc);
+        const nt_f4 s0 = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(a.sd + (int64_t)ra * a.ldp) + qc);
+        const nt_f4 m1 = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(a.mu + (int64_t)rbb * a.ldp) + qc);
+        const nt_f4 s1 = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(a.sd + (int64_t)rbb * a.ldp) + qc);
+        float acc0 = 0.f, acc1 = 0.f;
+        nt_f4 gm0, gs0, gm1, gs1;
+        float u, v;
+        nll_raw_sp_elem(c0, a.shift, x0.x, m0[0], s0[0], bm.x, bs.x, acc0, u, v); gm0[0] = u; gs0[0] = v;
+        nll_raw_sp_elem(c0, a.shift, x0.y, m0[1], s0[1], bm.y, bs.y, acc0, u, v); gm0[1] = u; gs0[1] = v;
+        nll_raw_sp_elem(c0, a.shift, x0.z, m0[2], s0[2], bm.z, bs.z, acc0, u, v); gm0[2] = u; gs0[2] = v;
+        nll_raw_sp_elem(c0, a.shift, x0.w, m0[3], s0[3], bm.w, bs.w, acc0, u, v); gm0[3] = u; gs0[3] = v;
+        nll_raw_sp_elem(c1, a.shift, x1.x, m1[0], s1[0], bm.x, bs.x, acc1, u, v); gm1[0] = u; gs1[0] = v;
+        nll_raw_sp_elem(c1, a.shift, x1.y, m1[1], s1[1], bm.y, bs.y, acc1, u, v); gm1[1] = u; gs1[1] = v;
+        nll_raw_sp_elem(c1, a.shift, x1.z, m1[2], s1[2], bm.z, bs.z, acc1, u, v); gm1[2] = u; gs1[2] = v;
+        nll_raw_sp_elem(c1, a.shift, x1.w, m1[3], s1[3], bm.w, bs.w, acc1, u, v); gm1[3] = u; gs1[3] = v;
+        if (on) {
+            __builtin_nontemporal_store(gm0, reinterpret_cast<nt_f4*>(a.dmu + (int64_t)ra * a.ldd) + q);
+            __builtin_nontemporal_store(gs0, reinterpret_cast<nt_f4*>(a.dsd + (int64_t)ra * a.ldd) + q);
+            // (fixed order: row r, then row r + 1 -- the same sums whatever the grid)
+            cm.x += gm0[0]; cm.y += gm0[1]; cm.z += gm0[2]; cm.w += gm0[3];
+            cs.x += gs0[0]; cs.y += gs0[1]; cs.z += gs0[2]; cs.w += gs0[3];
+            if (two) {
+                __builtin_nontemporal_store(gm1, reinterpret_cast<nt_f4*>(a.dmu + (int64_t)rbb * a.ldd) + q);
+                __builtin_nontemporal_store(gs1, reinterpret_cast<nt_f4*>(a.dsd + (int64_t)rbb * a.ldd) + q);
+                cm.x += gm1[0]; cm.y += gm1[1]; cm.z += gm1[2]; cm.w += gm1[3];
+                cs.x += gs1[0]; cs.y += gs1[1]; cs.z += gs1[2]; cs.w += gs1[3];
+            }
+        } else {
+            acc0 = acc1 = 0.f;
+        }
+        acc0 = dv_wave_sum_all(acc0);
+        acc1 = dv_wave_sum_all(acc1);
+        if (lane == 0) {
+            part[wave][ra - r0] = acc0;
+            if (two) part[wave][rbb - r0] = acc1;
+        }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < r1 - r0) {
+        const int t = threadIdx.x;
+        a.out_part[(int64_t)(r0 + t) * a.chunks + chunk] = -0.5f * ((part[0][t] + part[1][t]) + (part[2][t] + part[3][t]));
+    }
+    if (on) {
+        float* w = a.ws + (int64_t)rb * a.ldw;
+        reinterpret_cast<float4*>(w)[q] = cm;
+        reinterpret_cast<float4*>(w + a.sd_off)[q] = cs;
+    }
+}
+
 // Bernoulli / Poisson reconstruction rows (type_rec = 'binary' / 'poisson': the decoders src/DrVAE.py:124-129 names;
 // the reference ships neither class -- labelled extension).  v = the head's POST-activation output
 // (probability = sigmoid(a), or rate = softplus(a) + shift); out[r] = sum_g log p(x|v); with coef != NULL also
@@ -1961,6 +2042,27 @@ extern "C" int dv_gauss_nll_rows_fwdbwd(const float* coef, const float* x, int64
                            M, X, mode, sd_act, sd_shift, out, dmu, dsd, ldd, bias_mu, bias_sd);
     DV_RETURN_LAUNCH();
 }
+
+extern "C" int dv_gauss_nll_rows_raw_cs(const dv_nll_raw_cs_desc* dsc, dv_stream_t stream) {
+    DV_REQUIRE(dsc != nullptr);
+    const dv_nll_raw_cs_desc& d = *dsc;
+    DV_REQUIRE(d.M >= 0 && d.X >= 4 && d.X % 4 == 0);
+    if (d.M == 0) return DV_OK;
+    DV_REQUIRE(d.coef && d.x && d.mu && d.sd && d.out_part && d.dmu && d.dsd && d.bias_mu && d.bias_sd && d.ws);
+    auto a16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    DV_REQUIRE(a16(d.x) && a16(d.mu) && a16(d.sd) && a16(d.dmu) && a16(d.dsd) && a16(d.bias_mu) && a16(d.bias_sd) && a16(d.ws));
+    DV_REQUIRE(d.ldx % 4 == 0 && d.ldp % 4 == 0 && d.ldd % 4 == 0 && d.ldw % 4 == 0 && d.sd_off % 4 == 0);
+    DV_REQUIRE(d.sd_off >= d.X && d.sd_off + d.X <= d.ldw);
+    const int chunks = dv_nll_raw_cs_chunks(d.X), row_blocks = dv_nll_raw_cs_row_blocks(d.M);
+    DV_REQUIRE(d.chunks == chunks && d.row_blocks == row_blocks && row_blocks <= 65535);
+    NllCsArgs a{d.coef, d.x, d.ldx, d.xidx, d.mu, d.sd, d.ldp, d.M, d.X, d.shift, d.out_part, chunks, d.dmu, d.dsd, d.ldd,
+                d.bias_mu, d.bias_sd, d.ws, d.ldw, d.sd_off};
+    hipLaunchKernelGGL(nll_rows_raw_cs_kernel, dim3(chunks, row_blocks), dim3(256), 0, ST(stream), a);
+    DV_RETURN_LAUNCH();
+}
+
+extern "C" int dv_nll_raw_cs_chunks(int32_t X) { return X < 4 ? 0 : ((X >> 2) + 255) / 256; }
+extern "C" int dv_nll_raw_cs_row_blocks(int32_t M) { return M <= 0 ? 0 : (M + kNllCsRows - 1) / kNllCsRows; }
 
 extern "C" int dv_rec_nll_rows(int32_t kind, float shift, const float* coef, const float* x, int64_t ldx,
                                const int32_t* xidx, const float* v, int64_t ldv, int32_t M, int32_t X, float* out,

@@ -7,6 +7,7 @@ import numpy as np
 import torch
 
 from . import kernels as K
+from . import tuning as T
 from .arena import N_LOSS
 from .chain import _Chain, _pad4
 
@@ -172,6 +173,12 @@ class _Plan:
         # per-tile partial sums of the reconstruction rows when they come out of the decoder-heads launch itself
         # (dv_gemm_heads, DV_HEADS_NLL): row r's log-likelihood = NLLP[r].sum()
         self.NLLP = zf(Md, K.heads_tiles(X))
+        # chip-filling heads (wide configuration): the NLL row pass behind the plain product also emits the heads' bias
+        # gradient -- per-chunk row partials and per-row-block column sums (``kernels.nll_rows_raw_cs``)
+        self.NLLC = self.NLLWS = None
+        if cfg.type_rec == 'diag_gaussian' and X % 4 == 0 and Md > 0 and (T.get('nll_cs') == 2 or not eng._heads_small(self.DPX)):
+            chunks, rbs = K.nll_raw_cs_shape(Md, X)
+            self.NLLC, self.NLLWS = zf(Md, chunks), zf(rbs, 2 * X)
         if cfg.has_pert:
             self.c_z2F = _Chain(eng.L_z2F, L * B, dev, resid_cols=Z1)
             self.Z2F, self.D, self.DZ2F = mat(L * B, Z1), mat(L * B, Z1), mat(L * B, Z1)

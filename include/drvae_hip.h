@@ -405,6 +405,43 @@ int dv_rec_nll_rows(int32_t kind, float shift, const float* coef, const float* x
                     const float* v, int64_t ldv, int32_t M, int32_t X, float* out, float* dpre, int64_t ldd,
                     dv_stream_t stream);
 
+/* The raw-heads forward + backward pass below (dv_gauss_nll_rows_fwdbwd with bias_mu / bias_sd, sigma head = softplus +
+ * shift) with the heads' BIAS GRADIENT folded in (wide configuration: saves the separate 1.3-GB column-sum pass over the
+ * gradients this kernel writes).  A workgroup owns 1024 genes x 64 rows:
+ *   out_part[r, c] = partial log-likelihood of row r over gene chunk c  (M x chunks; out[r] = sum_c out_part[r, c] --
+ *                    the loss assembly sums them: dv_loss_term.row_len = chunks)
+ *   dmu / dsd      = as dv_gauss_nll_rows_fwdbwd
+ *   ws[b, g]          = sum over the rows of row block b of dmu[r, g]        } (row_blocks x ldw; the caller sums the
+ *   ws[b, sd_off + g] = the same of dsd[r, g]                                } blocks: dv_colsum(ws, ldw, row_blocks, ..))
+ * chunks = dv_nll_raw_cs_chunks(X), row_blocks = dv_nll_raw_cs_row_blocks(M).  X % 4 == 0, 16-B aligned rows.
+ * Deterministic (fixed summation order, no atomics). */
+typedef struct dv_nll_raw_cs_desc {
+    const float* coef;
+    const float* x;
+    int64_t ldx;
+    const int32_t* xidx;
+    const float* mu;
+    const float* sd;
+    int64_t ldp;
+    int32_t M;
+    int32_t X;
+    float shift;
+    float* out_part;
+    int32_t chunks;
+    float* dmu;
+    float* dsd;
+    int64_t ldd;
+    const float* bias_mu;
+    const float* bias_sd;
+    float* ws;
+    int64_t ldw;
+    int64_t sd_off;
+    int32_t row_blocks;
+} dv_nll_raw_cs_desc;
+int dv_gauss_nll_rows_raw_cs(const dv_nll_raw_cs_desc* d, dv_stream_t stream);
+int dv_nll_raw_cs_chunks(int32_t X);
+int dv_nll_raw_cs_row_blocks(int32_t M);
+
 /* forward + backward in one row pass (the loss is linear in the row terms with coefficients
  * known up front): out[r] as _fwd, dmu/dsd[r,:] = coef[r] * d out[r]/d(mu, pre-activation of sd).
  * bias_mu / bias_sd (both or neither; X floats each): mu / sd then hold the heads' RAW products (x W^T without bias and

@@ -65,7 +65,7 @@ def test_gemm_desc_layout_matches_header():
                                           ('dv_publish', 'Publish'), ('dv_heads_epi', 'HeadsEpi'),
                                           ('dv_fprop_kl', 'FpropKl'), ('dv_ymarg', 'Ymarg'), ('dv_seg_add', 'SegAdd'),
                                           ('dv_batch_masks_desc', 'BatchMasks'), ('dv_batch_feed_desc', 'BatchFeed'),
-                                          ('dv_kl_rows_desc', 'KlRows')])
+                                          ('dv_kl_rows_desc', 'KlRows'), ('dv_nll_raw_cs_desc', 'NllRawCs')])
 def test_small_struct_layouts_match_header(cname, pyname):
     from drvae_amd import _lib
     src = open(os.path.join(ROOT, 'include', 'drvae_hip.h')).read()

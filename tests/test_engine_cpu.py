@@ -341,3 +341,46 @@ def test_bernoulli_poisson_decoders_match_oracle(kind, type_rec, monkeypatch):
             close(v, float(want[k].detach()), 2e-5, 2e-6)
     for k, prm in tr.params.items():
         close(arena.p(k), prm.detach().numpy(), 1e-4, 2e-5)
+
+
+@pytest.mark.parametrize('kind', ['drvae', 'vfae'])
+def test_wide_step_path_bias_gradient_in_the_nll_pass_and_early_optimiser_slice(kind, monkeypatch):
+    """round 5, the chip-filling step's path at a size the CPU mirror handles (tuning switches force it): the decoder heads
+    as a plain product; the NLL row pass finishes them AND emits their bias gradient (per-chunk row partials, per-row-block
+    column sums summed by a small colsum: ``nll_rows_raw_cs``; no column-sum pass inside the weight-gradient launch); the
+    decoder heads' slice of the optimiser sweep is issued right behind the heads' backward products (step counter + 1),
+    the rest at the end of the step -- same losses and parameters as the oracle"""
+    from drvae_amd import tuning as T
+    monkeypatch.setenv('DRVAE_TUNE', 'fuse_heads=0,raw_heads=2,nll_cs=2,early_adam=2')
+    T.reload()
+    try:
+        kernel_ref.install(monkeypatch)
+        import drvae_amd.kernels as K
+        seen = dict(cs=0, adam=[], colsum_rows=[])
+        real_cs, real_adam, real_colsum, real_pair = kernel_ref.nll_rows_raw_cs, kernel_ref.adam_l2, kernel_ref.colsum, kernel_ref.linear_bwd_pair
+        monkeypatch.setattr(K, 'nll_rows_raw_cs', lambda *a, **k: (seen.__setitem__('cs', seen['cs'] + 1), real_cs(*a, **k))[1])
+        monkeypatch.setattr(K, 'adam_l2', lambda p, *a, **k: (seen['adam'].append(p.numel()), real_adam(p, *a, **k))[1])
+        monkeypatch.setattr(K, 'colsum', lambda out, X_, **k: (seen['colsum_rows'].append(X_.shape[0]), real_colsum(out, X_, **k))[1])
+        no_db = []
+        monkeypatch.setattr(K, 'linear_bwd_pair', lambda dW, db, *a, **k: (no_db.append(db is None), real_pair(dW, db, *a, **k))[1])
+        spec = C.tiny_spec(kind, dim_x=2056, h_de_x=[8], dim_z1=6)       # 3 gene chunks (the last one ragged)
+        n = 70                                                           # 2 row blocks of the pass (64 + ragged)
+        batch, params = M.make_batch(spec, n, seed=3), M.init_params(spec, 4, as_numpy=True)
+        eng, arena = make_engine(spec, params)
+        set_batch(eng, batch)
+        tr = M.RefTrainer(spec, M.init_params(spec, 4))
+        for step in range(3):
+            noise = M.make_noise(spec, n, seed=30 + step)
+            eng.train_step(noise)
+            ref, _ = tr.step(batch, noise)
+            for k, v in eng.losses().items():
+                r = float(ref[k].detach()) if torch.is_tensor(ref[k]) else float(ref[k])
+                assert abs(v - r) <= 1e-4 * max(1.0, abs(r)), (step, k, v, r)
+        for k, prm in tr.params.items():
+            close(arena.p(k), prm.detach().numpy(), 2e-4, 5e-5)
+        assert seen['cs'] == 3 and len(seen['adam']) == 6 and all(a + b == arena.n_live for a, b in zip(seen['adam'][0::2], seen['adam'][1::2]))
+        assert seen['adam'][0] == 2 * 2056 * 8 + 2 * 2056            # the heads' slice goes first
+        assert all(r <= 8 for r in seen['colsum_rows']) and no_db.count(True) == 3
+    finally:
+        monkeypatch.delenv('DRVAE_TUNE')
+        T.reload()

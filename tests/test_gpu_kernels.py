@@ -1229,3 +1229,45 @@ def test_batch_masks_global_counts(K, dev):
     assert nz.numel() and torch.allclose(nz, torch.full_like(nz, 1.0 / (L * n_p)))
     assert torch.allclose(got[0]['w_yl'], torch.full_like(got[0]['w_yl'], 1.0 / (L * n_l)))
     assert torch.allclose(got[0]['w_recl'][:L * B], torch.full((L * B,), 1.0 / (L * 3 * B), device=dev))
+
+
+@pytest.mark.parametrize('M,X,pad', [(130, 2052, 0), (64, 1024, 4), (7, 4, 0), (257, 4100, 8)])
+def test_nll_rows_raw_pass_with_the_bias_gradient_folded_in(K, dev, M, X, pad):
+    """dv_gauss_nll_rows_raw_cs (round 5): the raw-heads NLL forward + backward pass whose workgroups also keep the column
+    sums of the gradients they write -- row partials per gene chunk, column sums per row block -- against the host
+    reference and against the unfused pass (same gradients bit for bit; same row sums / bias gradient to rounding)"""
+    g = torch.Generator().manual_seed(M + X)
+    n_src = max(M // 3, 1)
+    x = strided(dev, n_src, X, pad, seed=1)
+    xidx = torch.randint(0, n_src, (M,), generator=g).to(torch.int32).to(dev)
+    raw = rnd(dev, M, 2 * X + pad, seed=2)
+    mu, sd = raw[:, :X], raw[:, X:2 * X]
+    bias = rnd(dev, 2 * X, seed=3)
+    coef = rnd(dev, M, seed=4)
+    chunks, rbs = K.nll_raw_cs_shape(M, X)
+    assert (chunks, rbs) == R.nll_raw_cs_shape(M, X)
+    outs = []
+    for Lb in (K, R):
+        dpre = torch.full((M, 2 * X + pad), 7.0, device=dev)
+        part, ws = torch.full((M, chunks), 7.0, device=dev), torch.full((rbs, 2 * X), 7.0, device=dev)
+        Lb.nll_rows_raw_cs(part, dpre[:, :X], dpre[:, X:2 * X], ws, coef, x, mu, sd, (bias[:X], bias[X:]), xidx=xidx, sd_shift=1e-3)
+        outs.append((part, dpre, ws))
+    (pk, dk, wk), (pr, dr, wr) = outs
+    close(dk[:, :2 * X], dr[:, :2 * X], rtol=2e-4, atol=2e-5)
+    close(pk, pr, rtol=2e-4, atol=2e-3)
+    close(wk, wr, rtol=2e-4, atol=2e-4)
+    if pad:
+        assert bool((dk[:, 2 * X:] == 7.0).all())
+    # against the unfused pass of the same library: gradients bitwise, sums to rounding
+    full, d2 = torch.zeros(M, device=dev), torch.zeros(M, 2 * X + pad, device=dev)
+    K.nll_rows_fwdbwd(full, d2[:, :X], d2[:, X:2 * X], coef, x, mu, sd, mode=1, xidx=xidx, sd_act='softplus', sd_shift=1e-3,
+                      bias=(bias[:X], bias[X:]))
+    assert torch.equal(d2[:, :2 * X], dk[:, :2 * X])
+    close(pk.sum(1), full, rtol=2e-5, atol=2e-3)
+    db = torch.zeros(2 * X, device=dev)
+    K.colsum(db, wk)
+    close(db, d2[:, :2 * X].double().sum(0).float(), rtol=2e-4, atol=2e-4)
+    # reproducible bit for bit
+    part2, ws2, d3 = torch.zeros_like(pk), torch.zeros_like(wk), torch.zeros_like(dk)
+    K.nll_rows_raw_cs(part2, d3[:, :X], d3[:, X:2 * X], ws2, coef, x, mu, sd, (bias[:X], bias[X:]), xidx=xidx, sd_shift=1e-3)
+    assert torch.equal(part2, pk) and torch.equal(ws2, wk)
