@@ -100,23 +100,19 @@ class _Chain:
         return self.out[-1]
 
     def backward(self, dpre_last, inputs, dinputs=None, wbranch=None, publish_after_last=None, publish_first=None,
-                 after_last=None, db_last_done=False):
+                 db_last_done=False):
         """dpre_last: gradient w.r.t. the last layer's pre-activation.  ``dinputs``: per input
         source a list of (dst, alpha, beta) destinations for its gradient (or None to skip).
         ``wbranch``: optional side stream for the weight-gradient GEMMs (they are leaves: only
         Adam reads them), so that they overlap the dx chain.  ``publish_after_last`` = (flag, counter, add):
         the first launch AFTER the last layer's launches publishes the flag on entry (= both gradients of the
         last layer are final and its weights are no longer read); ``publish_first``: the chain's FIRST launch
-        does (= everything in front of this backward pass is complete).  ``after_last``: called once the last layer's
-        launches are enqueued (its gradients are final behind them and its weights no longer read).  ``db_last_done``: the
+        does (= everything in front of this backward pass is complete).  ``db_last_done``: the
         last layer's bias gradient has been written by the producer of ``dpre_last`` already (``kernels.nll_rows_raw_cs``)."""
         dpre = dpre_last
         pending_pub = publish_first
         n_layers = len(self.layers)
         for li in range(n_layers - 1, -1, -1):
-            if li == n_layers - 2 and after_last is not None:
-                after_last()
-                after_last = None
             l = self.layers[li]
             db = None if (db_last_done and li == n_layers - 1) else l.db
             srcs = list(inputs) if li == 0 else [self.out[li - 1]]
@@ -172,7 +168,5 @@ class _Chain:
                         K.linear_bwd_data(dst, dpre, l.W[:, c0:c0 + w], kscale=l.scale, alpha=alpha, beta=beta,
                                           overread=True)
                     c0 += w
-        if after_last is not None:
-            after_last()
         if wbranch is not None:
             wbranch.join()

