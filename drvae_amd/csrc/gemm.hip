@@ -1151,11 +1151,46 @@ static int gemm_launch(const dv_gemm_desc& g_in, const LoadCfg& lc, int tiling, 
     return pipe ? launch_kpipe<32, 32, 64, 4, 2, 4>(g, lc, st) : launch_cfg<32, 32, 64, 1, 1, 4>(g, lc, st);
 }
 
+// A chip-filling product on the 128x256 tiling whose N is no multiple of 256: the ragged last column of tiles costs
+// every CU a whole tile time whenever it pushes the tiles per CU over an integer -- 8192 x 40000 x 2048 (decoder heads of
+// the wide configuration, 64 x 157 = 10048 tiles = 39.25 per CU): 9129 us, exactly the 9106 us of N = 40960 (40 per CU),
+// against 8878 us for N = 39936 (39 per CU); time is linear in tiles per CU, rounded UP (measured, round 5).  A plain
+// product then runs as two launches: columns [0, N - N % 256) on the big tiles, the narrow rest (<= 128 columns) on the
+// small-tile family (8192 x 64 x 2048: ~30 us).  Only where it removes a tile per CU.
+static bool ragged_n_split_pays(const dv_gemm_desc& g, int tiling) {
+    if (tiling != 40 || tune_of(g).tiling != 0 || tune_of(g).opt[6] == -1) return false;
+    if (g.epilogue != DV_EPI_PLAIN || g.scale || g.bias || g.resid || g.yref || g.a_colsum || g.A2 || g.a_kscale) return false;
+    const int n_tail = g.N % 256, n_main = g.N - n_tail;
+    if (n_tail == 0 || n_tail > 128 || n_main == 0) return false;
+    const int64_t rows_t = (g.M + 127) / 128, kCUs = 256;
+    const int64_t full = rows_t * ((g.N + 255) / 256), main = rows_t * (n_main / 256);
+    return (full + kCUs - 1) / kCUs > (main + kCUs - 1) / kCUs;
+}
+
 extern "C" int dv_gemm(const dv_gemm_desc* d, dv_stream_t stream) {
     LoadCfg lc;
     int tiling = 0;
     const int rc = gemm_prepare(d, lc, tiling);
     if (rc != DV_OK) return rc;
+    if (ragged_n_split_pays(*d, tiling)) {
+        const int n_tail = d->N % 256, n_main = d->N - n_tail;
+        dv_gemm_desc g1 = *d, g2 = *d;
+        g1.N = n_main;
+        g2.N = n_tail;
+        g2.B = d->B + (d->b_kcontig ? (int64_t)n_main * d->ldb : (int64_t)n_main);
+        g2.C = d->C + n_main;
+        g2.pub_flag = nullptr;                  // (the launch publishes once, on entry of the first)
+        g2.tune = nullptr;
+        LoadCfg l1, l2;
+        int t1 = 0, t2 = 0;
+        int r = gemm_prepare(&g1, l1, t1);
+        if (r != DV_OK) return r;
+        r = gemm_prepare(&g2, l2, t2);
+        if (r != DV_OK) return r;
+        r = gemm_launch(g1, l1, t1, static_cast<hipStream_t>(stream));
+        if (r != DV_OK) return r;
+        return gemm_launch(g2, l2, t2, static_cast<hipStream_t>(stream));
+    }
     return gemm_launch(*d, lc, tiling, static_cast<hipStream_t>(stream));
 }
 

@@ -1271,3 +1271,30 @@ def test_nll_rows_raw_pass_with_the_bias_gradient_folded_in(K, dev, M, X, pad):
     part2, ws2, d3 = torch.zeros_like(pk), torch.zeros_like(wk), torch.zeros_like(dk)
     K.nll_rows_raw_cs(part2, d3[:, :X], d3[:, X:2 * X], ws2, coef, x, mu, sd, (bias[:X], bias[X:]), xidx=xidx, sd_shift=1e-3)
     assert torch.equal(part2, pk) and torch.equal(ws2, wk)
+
+
+@pytest.mark.parametrize('a_kc,b_kc', [(True, True), (True, False), (False, False)])
+def test_gemm_ragged_last_tile_column_runs_as_two_launches(K, dev, a_kc, b_kc):
+    """round 5: a chip-filling plain product whose N leaves a narrow last column of 128x256 tiles that costs every CU one
+    more tile (here 32 x 33 tiles = 4.1 per CU -> 5; 32 x 32 = 4) runs the full tiles and the narrow rest as two launches
+    (dv_gemm; ``dv_gemm_tune.opt[6] = -1``: one launch) -- same product either way, against the host reference"""
+    M, N, Kd = 4096, 32 * 256 + 64, 64
+    A = rnd(dev, *((M, Kd) if a_kc else (Kd, M)), seed=1)
+    B = rnd(dev, *((N, Kd) if b_kc else (Kd, N)), seed=2)
+    ref = ((A if a_kc else A.t()).cpu() @ (B.t() if b_kc else B).cpu())
+    outs = []
+    for opt in (0, -1):
+        K.gemm_set_option(6, opt)
+        try:
+            Cm = torch.full((M, N + 4), 7.0, device=dev)[:, :N]
+            K.gemm(Cm, A, B, a_kc, b_kc, overread=False)
+            close(Cm, ref, **gemm_tol(Kd))
+            outs.append(Cm)
+        finally:
+            K.gemm_set_option(6, 0)
+    assert torch.equal(outs[0][:, :32 * 256], outs[1][:, :32 * 256])       # the full tiles: the same kernel, same tiles
+    # with accumulate / scaling (beta C + alpha A B): the split carries them to both parts
+    C0 = rnd(dev, M, N, seed=3)
+    C1 = C0.clone()
+    K.gemm(C1, A, B, a_kc, b_kc, alpha=0.5, beta=2.0)
+    close(C1, 2.0 * C0.cpu() + 0.5 * ref, **gemm_tol(Kd))
