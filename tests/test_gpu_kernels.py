@@ -1235,7 +1235,7 @@ def test_batch_masks_global_counts(K, dev):
 def test_nll_rows_raw_pass_with_the_bias_gradient_folded_in(K, dev, M, X, pad):
     """dv_gauss_nll_rows_raw_cs (round 5): the raw-heads NLL forward + backward pass whose workgroups also keep the column
     sums of the gradients they write -- row partials per gene chunk, column sums per row block -- against the host
-    reference and against the unfused pass (same gradients bit for bit; same row sums / bias gradient to rounding)"""
+    reference and against the unfused pass (same gradients, row sums and bias gradient to rounding)"""
     g = torch.Generator().manual_seed(M + X)
     n_src = max(M // 3, 1)
     x = strided(dev, n_src, X, pad, seed=1)
@@ -1258,11 +1258,11 @@ def test_nll_rows_raw_pass_with_the_bias_gradient_folded_in(K, dev, M, X, pad):
     close(wk, wr, rtol=3e-4, atol=3e-4)
     if pad:
         assert bool((dk[:, 2 * X:] == 7.0).all())
-    # against the unfused pass of the same library: gradients bitwise, sums to rounding
+    # against the unfused pass of the same library
     full, d2 = torch.zeros(M, device=dev), torch.zeros(M, 2 * X + pad, device=dev)
     K.nll_rows_fwdbwd(full, d2[:, :X], d2[:, X:2 * X], coef, x, mu, sd, mode=1, xidx=xidx, sd_act='softplus', sd_shift=1e-3,
                       bias=(bias[:X], bias[X:]))
-    assert torch.equal(d2[:, :2 * X], dk[:, :2 * X])
+    close(d2[:, :2 * X], dk[:, :2 * X], rtol=2e-6, atol=1e-7)      # (same element function; the compiler contracts it per kernel)
     close(pk.sum(1), full, rtol=2e-5, atol=2e-3)
     db = torch.zeros(2 * X, device=dev)
     K.colsum(db, wk)
