@@ -161,7 +161,9 @@ SIGNATURES = {
     'dv_rows_segment_sum': [_p, _i64, _p, _p, _p, _i32, _i32, _p, _p, _i64, _f, C.POINTER(Wait), _p],
     'dv_weighted_sum': [_p, _p, _p, _i32, _f, _p, _f, _p],
     'dv_recon_row_stats': [_p, _i64, _p, _i64, _i32, _i32, _p, _p],
-    'dv_col_moments': [_p, _i64, _p, _i64, _i32, _i32, _p, _i32, _p],
+    'dv_col_moments': [_p, _i64, _p, _i64, _i32, _i32, _p, _i32, _p, _p],
+    'dv_recon_finalize': [_p, _p, _i32, _i32, _p, _i32, _p, _p, _p],
+    'dv_rank_metrics': [_p, _i64, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _p],
     'dv_loss_assemble': [C.POINTER(LossTerm), _i32, _p, _p, _p, _p, _i32, _p, _p],
     'dv_loss_assemble_after': [C.POINTER(Wait), C.POINTER(LossTerm), _i32, _p, _p, _p, C.POINTER(Bump), _p, _i32, _p, _p],
     'dv_axpby': [_p, _f, _p, _f, _i64, _p],

@@ -1543,7 +1543,8 @@ __global__ __launch_bounds__(256) void recon_row_stats_kernel(const float* __res
 // the ingredients of the variance-weighted R^2 (sklearn r2_score, src/DGMMixin.py:137)
 __global__ __launch_bounds__(256) void col_moments_kernel(const float* __restrict__ x, int64_t ldx,
                                                           const float* __restrict__ r, int64_t ldr, int M, int X,
-                                                          double* __restrict__ out, int rows_per_block) {
+                                                          double* __restrict__ out, int rows_per_block,
+                                                          const int32_t* __restrict__ sel) {
     // workgroup = (64 columns, one row block): 4 row groups of 64 lanes walk the block's rows, coalesced along the
     // columns; partial sums of the block go to out[blockIdx.y] (the caller adds the blocks up in a fixed order)
     __shared__ double part[4][3][64];
@@ -1552,7 +1553,8 @@ __global__ __launch_bounds__(256) void col_moments_kernel(const float* __restric
     const int i0 = blockIdx.y * rows_per_block, i1 = min(M, i0 + rows_per_block);
     double s1 = 0., s2 = 0., se = 0.;
     if (g < X)
-        for (int i = i0 + rg; i < i1; i += 4) {
+        for (int ii = i0 + rg; ii < i1; ii += 4) {
+            const int i = sel ? sel[ii] : ii;       // (sel: the M rows that count, e.g. the rows with a second profile)
             const double a = x[(int64_t)i * ldx + g], b = r[(int64_t)i * ldr + g];
             s1 += a;
             s2 += a * a;
@@ -1565,6 +1567,148 @@ __global__ __launch_bounds__(256) void col_moments_kernel(const float* __restric
     if (rg == 0 && g < X)
         for (int k = 0; k < 3; ++k)
             out[((int64_t)blockIdx.y * 3 + k) * X + g] = (part[0][k][c] + part[1][k][c]) + (part[2][k][c] + part[3][k][c]);
+}
+
+// ------------------------------------------------------------------ evaluation tail (round 5)
+// What follows the big kernels of a whole-set evaluation (src/DGMMixin.py:128-190) used to be ~75 small library launches
+// per evaluation (two sorts, scans, gathers, float64 element-wise chains); as three launches:
+//   recon_finalize : the float64 combination of dv_recon_row_stats / dv_col_moments / the log-likelihood rows
+//   pair_counts    : per labeled row i and class: how many rows (positives) score above / equal -- O(n^2) integer
+//                    counting over the chip instead of a sort (n <= 32768: 8192 rows = 67 M pairs = a few us)
+//   rank_finalize  : accuracy, ROC-AUC and average precision from those counts
+// ROC-AUC = sum over negatives j of (#pos above j + 1/2 #pos tied with j) / (n_pos n_neg)  -- the trapezoids over the
+// distinct thresholds, sklearn's roc_auc_score; integer arithmetic, exact.  AP = 1/n_pos sum over positives i of
+// (#pos >= s_i) / (#all >= s_i) -- sklearn's average_precision_score (one threshold per distinct score).
+
+// out[0..3] = rmse, variance-weighted R^2, mean per-row Pearson r, mean log-likelihood (float64); rows: (M_all, 6) of
+// dv_recon_row_stats; sel (n rows, optional): the rows that count; cols: (row_blocks, 3, X) partials of dv_col_moments
+// over the same rows; ll (per row, optional).  One workgroup, fixed summation order.
+__global__ __launch_bounds__(1024) void recon_finalize_kernel(const float* __restrict__ rows, const int32_t* __restrict__ sel,
+                                                              int n, int X, const double* __restrict__ cols, int row_blocks,
+                                                              const float* __restrict__ ll, double* __restrict__ out) {
+    __shared__ double red[5][16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double sse = 0., pr = 0., sl = 0., num = 0., den = 0.;
+    for (int e = threadIdx.x; e < n; e += 1024) {
+        const int i = sel ? sel[e] : e;
+        const float* o = rows + (int64_t)i * 6;
+        sse += (double)o[0];
+        pr += (double)o[5] / sqrt((double)o[3] * (double)o[4]);
+        if (ll) sl += (double)ll[i];
+    }
+    for (int g = threadIdx.x; g < X; g += 1024) {
+        double c0 = 0., c1 = 0., c2 = 0.;
+        for (int b = 0; b < row_blocks; ++b) {
+            const double* c = cols + (int64_t)b * 3 * X;
+            c0 += c[g];
+            c1 += c[X + g];
+            c2 += c[2 * (int64_t)X + g];
+        }
+        num += c2;
+        den += c1 - c0 * c0 / (double)n;
+    }
+    double v[5] = {sse, pr, sl, num, den};
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        double t = v[k];
+        for (int off = 32; off >= 1; off >>= 1) t += __shfl_xor(t, off);
+        if (lane == 0) red[k][wave] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t[5];
+        for (int k = 0; k < 5; ++k) {
+            t[k] = 0.;
+            for (int w = 0; w < 16; ++w) t[k] += red[k][w];
+        }
+        const double nan = __longlong_as_double(0x7ff8000000000000LL);
+        out[0] = n ? sqrt(t[0] / ((double)n * X)) : nan;
+        out[1] = 1.0 - t[3] / t[4];
+        out[2] = n ? t[1] / n : nan;
+        out[3] = (ll && n) ? t[2] / n : nan;
+    }
+}
+
+// counts[c][e][0..3] += { rows scoring above e, rows tied with e (e itself included), positives above, positives tied }
+// over the j-range of this workgroup; e, j index the selected rows; class c scores proba[row, c0 + c]
+constexpr int kPairJ = 512;
+__global__ __launch_bounds__(256) void pair_counts_kernel(const float* __restrict__ proba, int64_t ldp,
+                                                          const int32_t* __restrict__ y, const int32_t* __restrict__ sel,
+                                                          int n, int c0, int binary, int32_t* __restrict__ counts) {
+    __shared__ float sj[kPairJ];
+    __shared__ int pj[kPairJ];
+    const int cls = c0 + blockIdx.z;
+    const int j0 = blockIdx.y * kPairJ, j1 = min(n, j0 + kPairJ);
+    for (int t = threadIdx.x; t < j1 - j0; t += 256) {
+        const int row = sel ? sel[j0 + t] : j0 + t;
+        sj[t] = proba[(int64_t)row * ldp + cls];
+        pj[t] = binary ? (y[row] > 0) : (y[row] == cls);
+    }
+    __syncthreads();
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    const float si = proba[(int64_t)(sel ? sel[e] : e) * ldp + cls];
+    int ga = 0, ea = 0, gp = 0, ep = 0;
+    for (int t = 0; t < j1 - j0; ++t) {
+        const float v = sj[t];
+        const int p = pj[t];
+        const int g = v > si, q = v == si;
+        ga += g; ea += q; gp += g & p; ep += q & p;
+    }
+    int32_t* o = counts + ((int64_t)blockIdx.z * n + e) * 4;
+    // (integer atomics: order-independent, the result is reproducible)
+    atomicAdd(o + 0, ga); atomicAdd(o + 1, ea); atomicAdd(o + 2, gp); atomicAdd(o + 3, ep);
+}
+
+// per class c (one workgroup each): out[c*2 + 0] = ROC-AUC, out[c*2 + 1] = average precision (nan / 0 for the degenerate
+// cases like metrics.roc_auc / average_precision); class 0's workgroup also writes acc -> out[2*n_cls].  Zeroes the
+// counts it has read: the buffer is ready for the next evaluation.
+__global__ __launch_bounds__(1024) void rank_finalize_kernel(int32_t* __restrict__ counts, const int32_t* __restrict__ y,
+                                                             const int32_t* __restrict__ pred, const int32_t* __restrict__ sel,
+                                                             int n, int c0, int binary, int n_cls, double* __restrict__ out) {
+    __shared__ double red[16];
+    __shared__ long long redi[3][16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x, cls = c0 + c;
+    long long s2 = 0, npos = 0, hit = 0;
+    double ap = 0.;
+    for (int e = threadIdx.x; e < n; e += 1024) {
+        const int row = sel ? sel[e] : e;
+        int32_t* o = counts + ((int64_t)c * n + e) * 4;
+        const int ga = o[0], ea = o[1], gp = o[2], ep = o[3];
+        o[0] = o[1] = o[2] = o[3] = 0;
+        const int p = binary ? (y[row] > 0) : (y[row] == cls);
+        if (p) {
+            npos += 1;
+            ap += (double)(gp + ep) / (double)(ga + ea);
+        } else {
+            s2 += 2LL * gp + ep;
+        }
+        if (pred) hit += pred[row] == y[row];
+    }
+    long long vi[3] = {s2, npos, hit};
+    for (int off = 32; off >= 1; off >>= 1) ap += __shfl_xor(ap, off);
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        for (int off = 32; off >= 1; off >>= 1) vi[k] += __shfl_xor(vi[k], off);
+    if (lane == 0) {
+        red[wave] = ap;
+        for (int k = 0; k < 3; ++k) redi[k][wave] = vi[k];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0.;
+        long long t[3] = {0, 0, 0};
+        for (int w = 0; w < 16; ++w) {
+            a += red[w];
+            for (int k = 0; k < 3; ++k) t[k] += redi[k][w];
+        }
+        const double nan = __longlong_as_double(0x7ff8000000000000LL);
+        const long long np = t[1], nn = (long long)n - np;
+        out[2 * c + 0] = (n == 0 || np == 0 || nn == 0) ? nan : ((double)t[0] * 0.5) / ((double)np * (double)nn);
+        out[2 * c + 1] = (n == 0 || np == 0) ? 0.0 : a / (double)np;
+        if (c == 0) out[2 * n_cls] = n ? (double)((float)t[2] / (float)n) : nan;
+    }
 }
 
 // ---------------------------------------------------------------------- BatchNorm1d / Dropout (blocks.MLP options)
@@ -2392,12 +2536,32 @@ extern "C" int dv_recon_row_stats(const float* x, int64_t ldx, const float* r, i
 }
 
 extern "C" int dv_col_moments(const float* x, int64_t ldx, const float* r, int64_t ldr, int32_t M, int32_t X,
-                              double* out, int32_t row_blocks, dv_stream_t stream) {
+                              double* out, int32_t row_blocks, const int32_t* sel, dv_stream_t stream) {
     DV_REQUIRE(M >= 0 && X >= 1 && row_blocks >= 1 && row_blocks <= 65535);
     DV_REQUIRE(x && r && out);
     const int rpb = (M + row_blocks - 1) / row_blocks;
     hipLaunchKernelGGL(col_moments_kernel, dim3((X + 63) / 64, row_blocks), dim3(256), 0, ST(stream), x, ldx, r, ldr, M, X, out,
-                       rpb > 0 ? rpb : 1);
+                       rpb > 0 ? rpb : 1, sel);
+    DV_RETURN_LAUNCH();
+}
+
+extern "C" int dv_recon_finalize(const float* rows, const int32_t* sel, int32_t n, int32_t X, const double* cols,
+                                 int32_t row_blocks, const float* ll, double* out, dv_stream_t stream) {
+    DV_REQUIRE(n >= 0 && X >= 1 && row_blocks >= 1 && rows && cols && out);
+    hipLaunchKernelGGL(recon_finalize_kernel, dim3(1), dim3(1024), 0, ST(stream), rows, sel, n, X, cols, row_blocks, ll, out);
+    DV_RETURN_LAUNCH();
+}
+
+extern "C" int dv_rank_metrics(const float* proba, int64_t ldp, const int32_t* y, const int32_t* pred, const int32_t* sel,
+                               int32_t n, int32_t c0, int32_t n_cls, int32_t binary, int32_t* counts, double* out,
+                               dv_stream_t stream) {
+    DV_REQUIRE(n >= 0 && c0 >= 0 && n_cls >= 1 && n_cls <= 64 && proba && y && counts && out);
+    if (n > DV_RANK_MAX_ROWS) return DV_ERR_UNSUPPORTED;
+    if (n > 0)
+        hipLaunchKernelGGL(pair_counts_kernel, dim3((n + 255) / 256, (n + kPairJ - 1) / kPairJ, n_cls), dim3(256), 0,
+                           ST(stream), proba, ldp, y, sel, n, c0, binary, counts);
+    hipLaunchKernelGGL(rank_finalize_kernel, dim3(n_cls), dim3(1024), 0, ST(stream), counts, y, pred, sel, n, c0, binary,
+                       n_cls, out);
     DV_RETURN_LAUNCH();
 }
 

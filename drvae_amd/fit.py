@@ -443,6 +443,8 @@ class _EvalGraph:
         # rows of the groups (once per dataset: a host sync each)
         self.x2idx = torch.nonzero(g('has_x2').reshape(-1).to(dev)).reshape(-1) if kind != 'vfae' else None
         self.yidx = torch.nonzero(g('has_y').reshape(-1).to(dev)).reshape(-1) if kind != 'pvae' else None
+        self.x2idx32 = self.x2idx.to(torch.int32) if self.x2idx is not None else None
+        self.yidx32 = self.yidx.to(torch.int32) if self.yidx is not None else None
         # the loss plan of the whole set: built by the ordinary path (host index lists), then reused
         eng = model.engine()
         keep, keep_training, was_training = eng.plan, eng.training, model.training
@@ -472,9 +474,11 @@ class _EvalGraph:
 
     def _sequence(self):
         """the launch sequence (eager for the warm-up, then under capture); -> (names, float64 vector, loss keys)"""
+        from . import kernels as K
         m, ds, kind = self.model, self.ds, self.model.kind
         eng, p = m.engine(), self.plan
         eng.plan = p
+        dev = ds.x1.device
         # --- evaluation-mode losses on the whole set: the fused forward on this plan, inputs from the dataset
         p.feed_active = False
         x1 = ds.x1.to(torch.float32)
@@ -486,23 +490,60 @@ class _EvalGraph:
         eng.draw_noise()
         eng.forward()
         losses = m._loss_tensors(eng)
-        vals = OrderedDict(('loss_' + k, v.double()) for k, v in losses.items())
-        # --- means-only inference + metrics
+        # every scalar of the evaluation lands in ONE float64 vector: [losses | y metrics | x1 metrics | x2 metrics]
+        names = ['loss_' + k for k in sorted(E.LOSS_IDX, key=E.LOSS_IDX.get)]      # (all seven; ``run`` picks the model's)
+        n_loss = len(names)
+        if kind != 'pvae':
+            names += ['y_auroc', 'y_aupr', 'y_acc']
+        names += ['x1_' + k for k in _NAN4]
+        has_x2 = kind != 'vfae' and len(self.x2idx) > 0
+        if has_x2:
+            names += ['x2_' + k for k in _NAN4]
+        if not hasattr(self, 'vec'):
+            self.vec = torch.zeros(len(names), dtype=torch.float64, device=dev)
+        vec = self.vec
+        vec[:n_loss].copy_(eng.arena.loss[:n_loss])
+        o = n_loss
+        # --- means-only inference + metrics (the tail: dv_rank_metrics / dv_recon_finalize, no sort, no host decisions)
         res = self._infer()
         if kind != 'pvae':
-            y = ds.y.to(ds.x1.device)
+            self._y_metrics(res, vec[o:o + 3])
+            o += 3
+        self._recon(ds.x1, res['px1'][0], res['px1'][1], None, vec[o:o + 4], 'x1')
+        o += 4
+        if has_x2:
+            self._recon(ds.x2, res['px2'][0], res['px2'][1], self.x2idx32, vec[o:o + 4], 'x2')
+        return names, vec, list(losses)
+
+    def _y_metrics(self, res, out3):
+        """accuracy / ROC-AUC / average precision of the labeled rows (src/DGMMixin.py:158-190) -> out3 = [auroc, aupr, acc]"""
+        from . import kernels as K
+        m, ds = self.model, self.ds
+        dev = ds.x1.device
+        n_lab, Y = int(self.yidx.numel()), m.dim_y
+        if n_lab > K.RANK_MAX_ROWS or n_lab == 0:      # (beyond the pair-counting kernel's range: the sort + scan formulation)
+            y = ds.y.to(dev)
             ylab = y.reshape(-1).index_select(0, self.yidx)
-            for k, v in MET.eval_y_prediction_dev(res['pred'].index_select(0, self.yidx), res['proba'].index_select(0, self.yidx),
-                                                  ylab, m.dim_y).items():
-                vals['y_' + k] = v
-        for k, v in self._recon(ds.x1, *res['px1']).items():
-            vals['x1_' + k] = v
-        if kind != 'vfae' and len(self.x2idx) > 0:
-            x2p = ds.x2.index_select(0, self.x2idx)
-            for k, v in self._recon(x2p, res['px2'][0].index_select(0, self.x2idx), res['px2'][1].index_select(0, self.x2idx)).items():
-                vals['x2_' + k] = v
-        names = list(vals)
-        return names, torch.stack([v.reshape(()) for v in vals.values()]), list(losses)
+            v = MET.eval_y_prediction_dev(res['pred'].index_select(0, self.yidx), res['proba'].index_select(0, self.yidx), ylab, Y)
+            out3.copy_(torch.stack([v['auroc'].reshape(()), v['aupr'].reshape(()), v['acc'].reshape(())]))
+            return
+        if not hasattr(self, 'y32'):
+            n_cls = 1 if Y == 2 else Y
+            self.y32 = torch.zeros(int(ds.x1.shape[0]), dtype=torch.int32, device=dev)
+            self.pred32 = torch.zeros_like(self.y32)
+            self.rank_counts = torch.zeros(n_cls, n_lab, 4, dtype=torch.int32, device=dev)
+            self.rank_out = torch.zeros(2 * n_cls + 1, dtype=torch.float64, device=dev)
+        self.y32.copy_(ds.y.reshape(-1))
+        self.pred32.copy_(res['pred'].reshape(-1))
+        proba = res['proba']
+        if Y == 2:
+            K.rank_metrics(out3, self.rank_counts, proba, self.y32, pred32=self.pred32, sel=self.yidx32, c0=1, n_cls=1, binary=True)
+        else:       # macro average over the one-vs-rest problems (nan as soon as one class's value is: the mean propagates it)
+            K.rank_metrics(self.rank_out, self.rank_counts, proba, self.y32, pred32=self.pred32, sel=self.yidx32, c0=0,
+                           n_cls=Y, binary=False)
+            out3[0:1].copy_(self.rank_out[0:2 * Y:2].mean().reshape(1))
+            out3[1:2].copy_(self.rank_out[1:2 * Y:2].mean().reshape(1))
+            out3[2:3].copy_(self.rank_out[2 * Y:2 * Y + 1])
 
     def _infer(self):
         """``forward`` (means-only inference, src/DrVAE.py:253-311) with its two heavy blocks on the fused step's layer
@@ -547,24 +588,25 @@ class _EvalGraph:
             res['px2'] = (PX[n:, :X], PX[n:, X:2 * X])
         return res
 
-    def _recon(self, x, x_rec, x_std):
-        """``eval_x_reconstruction`` (src/DGMMixin.py:128-156) with its float64 combination on the device"""
+    def _recon(self, x, x_rec, x_std, sel, out4, tag):
+        """``eval_x_reconstruction`` (src/DGMMixin.py:128-156) over the rows ``sel`` (all when None): row statistics, column
+        moments and log-likelihood rows from the HIP kernels, combined in float64 by ``dv_recon_finalize`` into ``out4`` =
+        [rmse, r2, pearr, ll].  The statistics are taken over ALL rows and selected afterwards (no gathered copies of
+        the x2 rows and their reconstructions)."""
         from . import kernels as K
-        m = self.model
+        from ._lib import GAUSS_SIGMA
         x = x.to(torch.float32)
         M, X = x.shape
-        rows = torch.empty(M, 6, device=x.device)
-        cols = torch.empty(3, X, dtype=torch.float64, device=x.device)
+        n = int(sel.numel()) if sel is not None else M
+        buf = self.__dict__.setdefault('_recon_bufs', {})
+        if tag not in buf:
+            buf[tag] = (torch.empty(M, 6, device=x.device), torch.empty(K.col_moment_blocks(n), 3, X, dtype=torch.float64, device=x.device),
+                        torch.empty(M, device=x.device))
+        rows, part, ll = buf[tag]
         K.recon_row_stats(rows, x, x_rec)
-        K.col_moments(cols, x, x_rec)
-        r = rows.double()
-        out = OrderedDict()
-        out['rmse'] = torch.sqrt(r[:, 0].sum() / (M * X))
-        ss_tot = cols[1] - cols[0] ** 2 / M
-        out['r2'] = 1.0 - cols[2].sum() / ss_tot.sum()
-        out['pearr'] = (r[:, 5] / torch.sqrt(r[:, 3] * r[:, 4])).mean()
-        out['ll'] = m.decoder_x.logp_perx(x, x_rec, x_std).double().mean()
-        return out
+        K.col_moments(None, x, x_rec, sel=sel, part=part)
+        K.nll_rows_fwd(ll, x, x_rec, x_std, mode=GAUSS_SIGMA)
+        K.recon_finalize(out4, rows, part, X, sel=sel, n=n, ll=ll)
 
     def run(self):
         m, kind = self.model, self.model.kind

@@ -670,16 +670,50 @@ def recon_row_stats(out, x, r):
                'dv_recon_row_stats')
 
 
-def col_moments(out, x, r):
-    """out (3,X) float64: per-column sum x, sum x^2, sum (x-r)^2."""
-    M, X = x.shape
-    assert out.dtype == torch.float64 and out.is_cuda and out.is_contiguous() and tuple(out.shape) == (3, X)
-    nb = max(1, min(64, (M + 63) // 64))          # row blocks: partial sums per block, added up here in a fixed order
-    part = out.unsqueeze(0) if nb == 1 else torch.empty(nb, 3, X, dtype=torch.float64, device=out.device)
-    _lib.check(_lib.load().dv_col_moments(_f32(x), _ld(x), _f32(r), _ld(r), M, X, part.data_ptr(), nb, _stream()),
+def col_moments(out, x, r, sel=None, part=None):
+    """out (3,X) float64: per-column sum x, sum x^2, sum (x-r)^2 over the rows (``sel``: int32 list of the rows that
+    count).  ``part`` (row_blocks, 3, X) float64: leave the per-block partials there instead (``recon_finalize`` adds
+    them up); out may then be None."""
+    M = sel.numel() if sel is not None else x.shape[0]
+    X = x.shape[1]
+    if part is not None:
+        nb = part.shape[0]
+        assert part.dtype == torch.float64 and part.is_cuda and part.is_contiguous() and tuple(part.shape[1:]) == (3, X)
+    else:
+        assert out.dtype == torch.float64 and out.is_cuda and out.is_contiguous() and tuple(out.shape) == (3, X)
+        nb = col_moment_blocks(M)      # row blocks: partial sums per block, added up here in a fixed order
+        part = out.unsqueeze(0) if nb == 1 else torch.empty(nb, 3, X, dtype=torch.float64, device=out.device)
+    _lib.check(_lib.load().dv_col_moments(_f32(x), _ld(x), _f32(r), _ld(r), M, X, part.data_ptr(), nb, _i32(sel), _stream()),
                'dv_col_moments')
-    if nb > 1:
+    if out is not None and part.data_ptr() != out.data_ptr():
         torch.sum(part, 0, out=out)
+
+
+def col_moment_blocks(M):
+    return max(1, min(64, (M + 63) // 64))
+
+
+def recon_finalize(out4, rows, part, X, *, sel=None, n=None, ll=None):
+    """out4 (4 float64) = rmse, variance-weighted R^2, mean per-row Pearson r, mean log-likelihood from the partials of
+    ``recon_row_stats`` / ``col_moments(part=...)`` (+ the per-row log-likelihoods): ``dv_recon_finalize``"""
+    n = (sel.numel() if sel is not None else rows.shape[0]) if n is None else n
+    assert out4.dtype == torch.float64 and out4.is_cuda and out4.numel() >= 4 and out4.is_contiguous()
+    assert part.dtype == torch.float64 and part.is_contiguous() and rows.is_contiguous() and rows.shape[1] == 6
+    _lib.check(_lib.load().dv_recon_finalize(_f32(rows), _i32(sel), n, X, part.data_ptr(), part.shape[0], _f32(ll),
+                                             out4.data_ptr(), _stream()), 'dv_recon_finalize')
+
+
+RANK_MAX_ROWS = 32768       # DV_RANK_MAX_ROWS
+
+
+def rank_metrics(out, counts, proba, y32, *, pred32=None, sel=None, c0=1, n_cls=1, binary=True):
+    """ROC-AUC / average precision per class and the accuracy (``dv_rank_metrics``): out (2 n_cls + 1 float64), counts
+    (n_cls, n, 4) int32 zeros (left zeroed)"""
+    n = sel.numel() if sel is not None else proba.shape[0]
+    assert out.dtype == torch.float64 and out.is_cuda and out.numel() >= 2 * n_cls + 1 and out.is_contiguous()
+    assert counts.dtype == torch.int32 and counts.is_contiguous() and counts.numel() >= n_cls * n * 4
+    _lib.check(_lib.load().dv_rank_metrics(_f32(proba), _ld(proba), _i32(y32), _i32(pred32), _i32(sel), n, c0, n_cls,
+                                           int(bool(binary)), counts.data_ptr(), out.data_ptr(), _stream()), 'dv_rank_metrics')
 
 
 def loss_assemble(loss, terms, w_elbo, w_cmpl, after=None, bump=(), halt=None, accum=None):

@@ -674,7 +674,28 @@ int dv_weighted_sum(const float* x, const float* w, const int32_t* idx, int32_t 
 int dv_recon_row_stats(const float* x, int64_t ldx, const float* r, int64_t ldr, int32_t M, int32_t X, float* out,
                        dv_stream_t stream);
 int dv_col_moments(const float* x, int64_t ldx, const float* r, int64_t ldr, int32_t M, int32_t X, double* out,
-                   int32_t row_blocks, dv_stream_t stream);
+                   int32_t row_blocks, const int32_t* sel, dv_stream_t stream);
+/* `sel` (optional, ABI 11): the M rows that count, as indices into x / r (e.g. the rows with a second profile) */
+
+/* The tail of a whole-set evaluation (round 5) in three launches instead of ~75 small library ones:
+ * dv_recon_finalize: out[0..3] = rmse, variance-weighted R^2, mean per-row Pearson r, mean log-likelihood (float64) from
+ *   dv_recon_row_stats' rows (M_all x 6; `sel`: the n rows that count, NULL = rows 0..n-1), dv_col_moments' partials over
+ *   the same rows (row_blocks x 3 x X) and the per-row log-likelihoods `ll` (optional: out[3] = nan without) --
+ *   `eval_x_reconstruction`, src/DGMMixin.py:128-156.  One workgroup, fixed summation order.
+ * dv_rank_metrics: accuracy, ROC-AUC and average precision of `eval_y_prediction` (src/DGMMixin.py:158-190; sklearn's
+ *   roc_auc_score / average_precision_score: one threshold per distinct score) WITHOUT a sort: for the n selected rows
+ *   (`sel`, NULL = all) and each class c in [c0, c0 + n_cls) the launch counts, per row, how many rows / positives
+ *   score above and equal (O(n^2) integer counting spread over the chip; n <= DV_RANK_MAX_ROWS, DV_ERR_UNSUPPORTED
+ *   above), then   AUC = sum_{negatives j} (#pos above j + #pos tied with j / 2) / (n_pos n_neg)   (integer sums: exact)
+ *                  AP  = 1/n_pos sum_{positives i} #pos(score >= s_i) / #rows(score >= s_i)
+ *   positive = binary ? y > 0 : y == c; score = proba[row, c].  out[2c] = AUC (nan: one class only / empty), out[2c + 1]
+ *   = AP (0: no positive), out[2 n_cls] = accuracy mean(pred == y) (pred optional).  `counts` (n_cls x n x 4 int32) must
+ *   be zero on entry and is zero again on return.  Deterministic. */
+#define DV_RANK_MAX_ROWS 32768
+int dv_recon_finalize(const float* rows, const int32_t* sel, int32_t n, int32_t X, const double* cols, int32_t row_blocks,
+                      const float* ll, double* out, dv_stream_t stream);
+int dv_rank_metrics(const float* proba, int64_t ldp, const int32_t* y, const int32_t* pred, const int32_t* sel, int32_t n,
+                    int32_t c0, int32_t n_cls, int32_t binary, int32_t* counts, double* out, dv_stream_t stream);
 
 /* All loss scalars of one step in a single launch (src/DrVAE.py:611-624):
  *   loss[0..4] = 0; for each term: loss[out] += scale * sum_i w[i]*x[i]   (w == NULL: plain sum)

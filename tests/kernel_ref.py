@@ -681,9 +681,44 @@ def recon_row_stats(out, x, r):
                            ((x - mx) * (r - mr)).sum(1)], 1))
 
 
-def col_moments(out, x, r):
+def col_moment_blocks(M):
+    return max(1, min(64, (M + 63) // 64))
+
+
+def col_moments(out, x, r, sel=None, part=None):
+    if sel is not None:
+        x, r = x[sel.long()], r[sel.long()]
     xd, rd = x.double(), r.double()
-    out.copy_(torch.stack([xd.sum(0), (xd * xd).sum(0), ((xd - rd) ** 2).sum(0)], 0))
+    tot = torch.stack([xd.sum(0), (xd * xd).sum(0), ((xd - rd) ** 2).sum(0)], 0)
+    if part is not None:
+        part.zero_()
+        part[0].copy_(tot)
+    if out is not None:
+        out.copy_(tot)
+
+
+def recon_finalize(out4, rows, part, X, *, sel=None, n=None, ll=None):
+    r = (rows[sel.long()] if sel is not None else rows).double()
+    n = r.shape[0] if n is None else n
+    cols = part.sum(0)
+    out4[0] = torch.sqrt(r[:, 0].sum() / (n * X)) if n else float('nan')
+    out4[1] = 1.0 - cols[2].sum() / (cols[1] - cols[0] ** 2 / n).sum()
+    out4[2] = (r[:, 5] / torch.sqrt(r[:, 3] * r[:, 4])).mean() if n else float('nan')
+    out4[3] = (ll[sel.long()] if sel is not None else ll).double().mean() if (ll is not None and n) else float('nan')
+
+
+RANK_MAX_ROWS = 32768
+
+
+def rank_metrics(out, counts, proba, y32, *, pred32=None, sel=None, c0=1, n_cls=1, binary=True):
+    from drvae_amd import metrics as MET
+    idx = sel.long() if sel is not None else torch.arange(proba.shape[0])
+    y, pr = y32[idx], proba[idx]
+    for c in range(n_cls):
+        pos = (y > 0) if binary else (y == c0 + c)
+        out[2 * c] = MET.roc_auc(pos, pr[:, c0 + c])
+        out[2 * c + 1] = MET.average_precision(pos, pr[:, c0 + c])
+    out[2 * n_cls] = float((pred32[idx] == y).float().sum() / max(len(idx), 1)) if (pred32 is not None and len(idx)) else float('nan')
 
 
 def _halted(halt):
@@ -855,7 +890,7 @@ def nll_rows_raw_cs(out_part, dmu, dsd, ws, coef, x, mu, sd, bias, *, xidx=None,
         ws[b, X:2 * X] = dsd[b * 64:(b + 1) * 64].sum(0)
 
 
-FUNCTIONS = ['nll_raw_cs_shape', 'nll_rows_raw_cs', 'rec_nll_rows', 'batch_masks', 'fill_normal_rows', 'linear_heads', 'heads_tiles', 'adamax_l2', 'batch_feed', 'mmd_rff_fwd', 'mmd_rff_bwd', 'counters_add2', 'ycont_fwd', 'ycont_bwd', 'flag_publish', 'flag_wait', 'gemm', 'linear_fwd', 'linear_bwd_data', 'linear_bwd_weight', 'linear_bwd_pair', 'colsum', 'act_bwd_', 'wn_scale', 'wn_bwd',
+FUNCTIONS = ['col_moment_blocks', 'recon_finalize', 'rank_metrics', 'nll_raw_cs_shape', 'nll_rows_raw_cs', 'rec_nll_rows', 'batch_masks', 'fill_normal_rows', 'linear_heads', 'heads_tiles', 'adamax_l2', 'batch_feed', 'mmd_rff_fwd', 'mmd_rff_bwd', 'counters_add2', 'ycont_fwd', 'ycont_bwd', 'flag_publish', 'flag_wait', 'gemm', 'linear_fwd', 'linear_bwd_data', 'linear_bwd_weight', 'linear_bwd_pair', 'colsum', 'act_bwd_', 'wn_scale', 'wn_bwd',
              'reparam_fwd', 'reparam_bwd', 'reparam_bwd_seg', 'z2f_post_bwd', 'kl_rows_fwd', 'kl_rows_bwd', 'nll_rows_fwd', 'nll_rows_bwd', 'nll_rows_fwdbwd',
              'softmax_clamp_fwd', 'softmax_clamp_bwd', 'cat_terms_fwd', 'cat_terms_bwd', 'smalln_fwd', 'smalln_bwd_data',
              'smalln_bwd_weight', 'ymarg_fwd', 'ymarg_bwd', 'ymarg_fwdbwd',

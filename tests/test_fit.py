@@ -344,3 +344,36 @@ def test_captured_evaluation_equals_step_by_step(kind, dev):
     # a dataset whose tensors were replaced is captured again
     va.x1 = va.x1.clone()
     assert F._EvalGraph.get(model, va) is not ev
+
+
+@pytest.mark.gpu
+def test_captured_evaluation_follows_the_engine(dev):
+    """round-4 advisor (medium): the captured evaluation points into the engine's arena / plans; ``.cpu().cuda()`` retires
+    the engine (DGMMixin._apply), so the cached graph must go with it -- evaluate, move the model away and back, train,
+    evaluate: the numbers are those of the step-by-step path on the CURRENT parameters"""
+    from drvae_amd import fit as F
+    model = _tiny_model('drvae', device='cuda', epochs=2)
+    va = _tiny_dataset('drvae', 48, 2, 'cuda')
+    g = lambda k: getattr(va, k, None)
+    first, _ = model.evaluate_performance_on_dataset(va)
+    ev = F._EvalGraph.get(model, va)
+    eng0 = model.engine()
+    model.cpu()
+    model.cuda()
+    assert '_eval_graphs' not in model.__dict__ or not model.__dict__['_eval_graphs']
+    batch = tuple(getattr(va, f) for f in va.FIELDS)
+    for _ in range(5):
+        model.run_on_batch(train_mode=True, **model._batch_kwargs(batch))
+    assert model.engine() is not eng0
+    got, _ = model.evaluate_performance_on_dataset(va)
+    assert F._EvalGraph.get(model, va) is not ev
+    ref, _ = model._evaluate(g('x1'), g('x2'), g('s'), g('y'), g('has_x2'), g('has_y'))
+    assert got['x1_rmse'] != first['x1_rmse']
+    for k in ('x1_rmse', 'x1_pearr', 'x2_rmse', 'y_auroc', 'y_aupr', 'y_acc'):
+        assert abs(got[k] - ref[k]) <= 1e-6 * max(1.0, abs(ref[k])), (k, got[k], ref[k])
+    # a host-resident label array: the captured path declines (no pageable copy under capture), the step-by-step one runs
+    va2 = _tiny_dataset('drvae', 48, 2, 'cuda')
+    va2.y = va2.y.cpu()
+    assert F._EvalGraph.get(model, va2) is None
+    perf, _ = model.evaluate_performance_on_dataset(va2)
+    assert np.isfinite(perf['x1_rmse'])

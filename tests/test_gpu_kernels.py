@@ -1298,3 +1298,77 @@ def test_gemm_ragged_last_tile_column_runs_as_two_launches(K, dev, a_kc, b_kc):
     C1 = C0.clone()
     K.gemm(C1, A, B, a_kc, b_kc, alpha=0.5, beta=2.0)
     close(C1, 2.0 * C0.cpu() + 0.5 * ref, **gemm_tol(Kd))
+
+
+@pytest.mark.parametrize('n,Y,ties', [(3000, 2, True), (517, 2, False), (900, 3, True), (1, 2, False), (40, 2, True)])
+def test_rank_metrics_without_a_sort(K, dev, n, Y, ties):
+    """dv_rank_metrics (round 5): ROC-AUC / average precision / accuracy of the labeled rows from pair counts, against
+    scikit-learn (the reference's own choice, src/DGMMixin.py:163-180) and the sort-based formulation -- tie groups, one
+    class only, no rows"""
+    from sklearn.metrics import average_precision_score, roc_auc_score
+    from drvae_amd import metrics as MET
+    g = torch.Generator().manual_seed(n + Y)
+    N_all = n + 50
+    proba = torch.softmax(torch.randn(N_all, Y, generator=g) * 2.0, 1)
+    if ties:
+        proba = (proba * 20).round() / 20 + 1e-3          # many tied scores
+    y = torch.randint(0, Y, (N_all,), generator=g)
+    pred = proba.argmax(1)
+    sel = torch.randperm(N_all, generator=g)[:n].sort().values
+    pd, yd, prd, sd = proba.to(dev).contiguous(), y.to(torch.int32).to(dev), pred.to(torch.int32).to(dev), sel.to(torch.int32).to(dev)
+    n_cls = 1 if Y == 2 else Y
+    counts = torch.zeros(n_cls, n, 4, dtype=torch.int32, device=dev)
+    out = torch.zeros(2 * n_cls + 1, dtype=torch.float64, device=dev)
+    for rep in range(2):          # (second call: the counts came back zeroed)
+        K.rank_metrics(out, counts, pd, yd, pred32=prd, sel=sd, c0=1 if Y == 2 else 0, n_cls=n_cls, binary=Y == 2)
+        torch.cuda.synchronize()
+        assert int(counts.abs().sum()) == 0
+        o = out.cpu().numpy()
+        ys, ps = y[sel].numpy(), proba[sel].numpy()
+        for c in range(n_cls):
+            cls = 1 if Y == 2 else c
+            pos = (ys > 0) if Y == 2 else (ys == cls)
+            if pos.all() or not pos.any():
+                assert np.isnan(o[2 * c]) and (o[2 * c + 1] == 0.0 if not pos.any() else True)
+                continue
+            assert abs(o[2 * c] - roc_auc_score(pos, ps[:, cls])) < 1e-12
+            assert abs(o[2 * c + 1] - average_precision_score(pos, ps[:, cls])) < 1e-12
+            assert o[2 * c] == MET.roc_auc(torch.from_numpy(pos), torch.from_numpy(ps[:, cls]))      # integer arithmetic: exact
+        assert abs(o[2 * n_cls] - float((pred[sel] == y[sel]).float().mean())) < 1e-7
+    # degenerate: only positives / only negatives / no rows
+    for yy in (torch.ones(N_all, dtype=torch.int32), torch.zeros(N_all, dtype=torch.int32)):
+        K.rank_metrics(out, counts, pd, yy.to(dev), pred32=prd, sel=sd, c0=1, n_cls=1, binary=True)
+        o = out.cpu().numpy()
+        assert np.isnan(o[0]) and (o[1] == 0.0 if int(yy[0]) == 0 else o[1] > 0.99)
+    K.rank_metrics(out, counts, pd, yd, pred32=prd, sel=sd[:0], c0=1, n_cls=1, binary=True)
+    o = out.cpu().numpy()
+    assert np.isnan(o[0]) and o[1] == 0.0 and np.isnan(o[2])
+
+
+@pytest.mark.parametrize('M,X,with_sel', [(300, 978, False), (300, 978, True), (70, 13, True)])
+def test_recon_finalize(K, dev, M, X, with_sel):
+    """dv_recon_finalize + dv_col_moments(sel): the float64 combination of the reconstruction partials over a row
+    subset == the host formulas of eval_x_reconstruction (src/DGMMixin.py:128-156) on the gathered rows"""
+    x, r, sd = rnd(dev, M, X, seed=1), rnd(dev, M, X, seed=2), rnd(dev, M, X, seed=3).abs() + 0.1
+    sel = torch.arange(0, M, 3, dtype=torch.int32, device=dev) if with_sel else None
+    n = sel.numel() if with_sel else M
+    rows, ll = torch.empty(M, 6, device=dev), torch.empty(M, device=dev)
+    part = torch.empty(K.col_moment_blocks(n), 3, X, dtype=torch.float64, device=dev)
+    out = torch.zeros(4, dtype=torch.float64, device=dev)
+    K.recon_row_stats(rows, x, r)
+    K.col_moments(None, x, r, sel=sel, part=part)
+    K.nll_rows_fwd(ll, x, r, sd, mode=1)
+    K.recon_finalize(out, rows, part, X, sel=sel, n=n, ll=ll)
+    xs, rs, ss = (t[sel.long()] if with_sel else t for t in (x, r, sd))
+    xs, rs, ss = xs.double().cpu(), rs.double().cpu(), ss.double().cpu()
+    rmse = float(torch.sqrt(((xs - rs) ** 2).mean()))
+    r2 = float(1.0 - ((xs - rs) ** 2).sum() / ((xs - xs.mean(0)) ** 2).sum())
+    xc, rc = xs - xs.mean(1, keepdim=True), rs - rs.mean(1, keepdim=True)
+    pear = float(((xc * rc).sum(1) / torch.sqrt((xc ** 2).sum(1) * (rc ** 2).sum(1))).mean())
+    llm = float((-0.5 * (np.log(2 * np.pi) + 2 * torch.log(ss) + ((xs - rs) / ss) ** 2)).sum(1).mean())
+    o = out.cpu().numpy()
+    np.testing.assert_allclose(o, [rmse, r2, pear, llm], rtol=2e-6, atol=1e-6)
+    # the partial-free form (out given) still adds the blocks up itself
+    cols = torch.empty(3, X, dtype=torch.float64, device=dev)
+    K.col_moments(cols, x, r, sel=sel)
+    close(cols, part.sum(0), rtol=1e-12, atol=1e-9)
