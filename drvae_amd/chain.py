@@ -61,6 +61,17 @@ class _Chain:
         # gradient w.r.t. the pre-activation of every layer but the last (the caller owns that one)
         self.dpre = [torch.zeros(M, _pad4(l.N), device=device)[:, :l.N] for l in layers[:-1]]
 
+    @staticmethod
+    def _pad_ok(t):
+        """may a product over ``t`` run over its padded width?  Only when the caller's contract is checkable: rows that are
+        not padded at all, or WHOLE rows of a row-padded buffer (``plan.mat`` / this chain's own buffers / the arena's
+        padded weights), whose pad columns are zero by construction.  A column slice of a wider buffer (``Q[:, :Z]`` with
+        ld = 2 Z) has neighbours, not zeros, behind its last column (round-4 advisor)."""
+        if t.dim() != 2 or t.shape[1] % 4 == 0:
+            return True
+        ld = t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
+        return ld == t.shape[1] or _whole_rows(t)
+
     def raw_last_ok(self):
         """may the last layer run as a plain product (no bias, no activation), finished by its consumer?"""
         l = self.layers[-1]
@@ -78,6 +89,7 @@ class _Chain:
             if l.g is not None:
                 K.wn_scale(l.scale, l.norm, l.W, l.g)
             last = li == len(self.layers) - 1
+            kpad = len(x) == 1 and self._pad_ok(x[0])      # (only inputs whose pad columns are zero BY CONSTRUCTION)
             if last and heads is not None:
                 assert l.split * 2 == l.N
                 K.linear_heads(heads.get('out', self.out[li]), x[0], l.W, l.b, split=l.split,
@@ -85,17 +97,17 @@ class _Chain:
                                shift0=l.shift0, shift1=l.shift1, resid=resid,
                                resid_cols=self.resid_cols if resid is not None else 0, overread=True,
                                publish=publish if (li == 0 and l.g is None) else None,
-                               sample=heads.get('sample'), nll=heads.get('nll'), kpad=True)
+                               sample=heads.get('sample'), nll=heads.get('nll'), kpad=kpad)
                 return self.out[-1]
             if last and raw_last:
                 assert self.raw_last_ok() and resid is None
                 K.gemm(self.out[li], x[0], l.W, True, True, A2=x[1] if len(x) > 1 else None, overread=True,
-                       publish=publish if li == 0 else None, kpad=True)
+                       publish=publish if li == 0 else None, kpad=kpad)
                 return self.out[-1]
             K.linear_fwd(self.out[li], x[0], l.W, l.b, x2=x[1] if len(x) > 1 else None, scale=l.scale, split=l.split,
                          act0=l.act0, act1=l.act1, shift0=l.shift0, shift1=l.shift1,
                          resid=resid if last else None, resid_cols=self.resid_cols if (last and resid is not None) else 0,
-                         overread=True, publish=publish if (li == 0 and l.g is None) else None, kpad=True)
+                         overread=True, publish=publish if (li == 0 and l.g is None) else None, kpad=kpad)
             x = [self.out[li]]
         return self.out[-1]
 
@@ -125,7 +137,7 @@ class _Chain:
                 for si, s in enumerate(srcs):
                     w = s.shape[1]
                     K.linear_bwd_weight(dW[:, c0:c0 + w], dpre, s, dbias=db if si == 0 else None, overread=True,
-                                        npad=len(srcs) == 1 and l.g is None)
+                                        npad=len(srcs) == 1 and l.g is None and self._pad_ok(s))
                     c0 += w
                 if l.g is not None:
                     K.wn_bwd(l.dW, l.dg, l.raw, l.W, l.g, l.norm)
@@ -138,13 +150,13 @@ class _Chain:
                 if li > 0:
                     prev = self.layers[li - 1]
                     K.linear_bwd_pair(l.dW, db, self.dpre[li - 1], dpre, srcs[0], l.W, yref=self.out[li - 1],
-                                      act=prev.act0, shift=prev.shift0, overread=True, publish=pending_pub, npad=True,
-                                      npad_x=True)
+                                      act=prev.act0, shift=prev.shift0, overread=True, publish=pending_pub,
+                                      npad=self._pad_ok(srcs[0]), npad_x=True)
                     dpre = self.dpre[li - 1]
                 else:
                     dst, alpha, beta = dinputs[0][0]
                     K.linear_bwd_pair(l.dW, db, dst, dpre, srcs[0], l.W, alpha=alpha, beta_x=beta, overread=True,
-                                      publish=pending_pub, npad=True, npad_x=_whole_rows(dst))
+                                      publish=pending_pub, npad=self._pad_ok(srcs[0]), npad_x=_whole_rows(dst))
                 pending_pub = None
                 continue
             if pending_pub is not None:      # (no paired launch for this layer: a launch of its own)

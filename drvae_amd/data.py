@@ -268,6 +268,8 @@ class DeviceBatcher:
                 if fd.y32 is None:
                     fd.y32 = self.hy32
             p.feed = fd
+        else:
+            self._refresh_feed_rows(fd)
         p.feed_active = True
         if self.mode == 'sampler':
             # WeightedRandomSampler: i.i.d. draws over ALL rows; DataLoader(drop_last): consecutive full batches
@@ -323,10 +325,23 @@ class DeviceBatcher:
         fd.base.copy_(self.engine.step_dev)
         self._k = 0
 
+    def _refresh_feed_rows(self, fd):
+        """the padded copies of ``_feed_rows`` follow a dataset edited IN PLACE between two epochs (normalisation,
+        augmentation): checked by the tensors' version counters at every ``begin_epoch``, refreshed in place -- the captured
+        steps keep reading the same buffer (round-4 advisor: train and evaluation must see the same data)"""
+        for name in ('x1', 'x2'):
+            x, cur = getattr(self.ds, name, None), getattr(fd, name, None)
+            if x is None or cur is None or cur.data_ptr() == x.data_ptr():
+                continue
+            seen = self.__dict__.setdefault('_rows_version', {})
+            if seen.get(name) != (x.data_ptr(), x._version):
+                cur.copy_(x)
+                seen[name] = (x.data_ptr(), x._version)
+
     def _feed_rows(self, x):
         """the dataset as the graph-resident feed reads it: fp32 rows 16-B aligned -- a copy with padded rows when the gene
         count is no multiple of 4 (978): the feed's row gather is then 16-B loads instead of 4-B ones (epoch feed 0.1932 ->
-        0.1916 ms per step).  A snapshot taken when the feed is built: the dataset is read-only input, as in the reference"""
+        0.1916 ms per step).  Kept current by ``_refresh_feed_rows`` when the dataset is edited in place"""
         if x is None or x.device.type != 'cuda':
             return x
         if x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0:

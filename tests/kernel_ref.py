@@ -88,12 +88,40 @@ def _seg(N, split, a0, a1, v0, v1, dev):
     return first
 
 
+def _ldr(t):
+    """leading dimension as ``drvae_amd.kernels._ld`` sees it"""
+    if t is None:
+        return 0
+    if t.dim() == 1:
+        return t.numel()
+    return t.stride(0) if t.size(0) > 1 else max(t.stride(0), t.size(1))
+
+
+def _widen(t, cols):
+    """the (rows, cols) view over the SAME rows of a row-padded buffer (what a kernel sees when it runs over padded K / N)"""
+    return torch.as_strided(t, (t.shape[0], cols), (_ldr(t), 1), t.storage_offset())
+
+
 def gemm(Cm, A, B, a_kc, b_kc, *, A2=None, a_kscale=None, alpha=1.0, beta=0.0, epi=EPI_PLAIN, scale=None,
          bias=None, split=None, act0=0, act1=0, shift0=0.0, shift1=0.0, resid=None, resid_cols=0, yref=None,
          a_colsum=None, colsum_beta=0.0, overread=False, publish=None, kpad=False, npad=False):
+    """mirrors ``kernels._gemm_desc`` INCLUDING its padded forms (round 5, advisor): with ``kpad`` the product runs over
+    K rounded up to 4 and so reads the operands' pad columns; with ``npad`` it runs over N rounded up and WRITES C's pad
+    columns -- a pad that is not zero shows up in the CPU suite exactly as it would on the device"""
     if publish is not None:
         flag_publish(publish[0], publish[1], publish[2])
     M, N = Cm.shape
+    K_ = (A.shape[1] + (A2.shape[1] if A2 is not None else 0)) if a_kc else A.shape[0]
+    Kp, Np = (K_ + 3) & ~3, (N + 3) & ~3
+    if kpad and a_kc and b_kc and A2 is None and (K_ & 3) and min(_ldr(A), _ldr(B)) >= Kp and not ((_ldr(A) | _ldr(B)) & 3):
+        A, B = _widen(A, Kp), _widen(B, Kp)
+    if npad and not b_kc and (N & 3) and min(_ldr(B), _ldr(Cm)) >= Np and not ((_ldr(B) | _ldr(Cm)) & 3) and resid is None \
+            and scale is None and bias is None and (yref is None or _ldr(yref) >= Np):
+        B, Cm = _widen(B, Np), _widen(Cm, Np)
+        if yref is not None:
+            yref = _widen(yref, Np)
+        split = N if split is None else split
+        N = Np
     Aop = (torch.cat([A, A2], 1) if A2 is not None else A) if a_kc else A.t()
     if a_kscale is not None:
         Aop = Aop * a_kscale[None, :]
@@ -120,7 +148,7 @@ def gemm(Cm, A, B, a_kc, b_kc, *, A2=None, a_kscale=None, alpha=1.0, beta=0.0, e
 def linear_fwd(out, x, W, bias=None, *, x2=None, scale=None, split=None, act0=0, act1=0, shift0=0.0, shift1=0.0,
                resid=None, resid_cols=0, overread=False, publish=None, kpad=False):
     gemm(out, x, W, True, True, A2=x2, epi=EPI_FWD, scale=scale, bias=bias, split=split, act0=act0, act1=act1,
-         shift0=shift0, shift1=shift1, resid=resid, resid_cols=resid_cols, publish=publish)
+         shift0=shift0, shift1=shift1, resid=resid, resid_cols=resid_cols, publish=publish, kpad=kpad)
 
 
 def heads_tiles(split):
@@ -133,7 +161,7 @@ def linear_heads(out, x, W, bias=None, *, split, x2=None, scale=None, act0=0, ac
     M, N = out.shape
     heads = torch.zeros(M, N, device=out.device) if nll is not None else out
     linear_fwd(heads, x, W, bias, x2=x2, scale=scale, split=split, act0=act0, act1=act1, shift0=shift0, shift1=shift1,
-               resid=resid, resid_cols=resid_cols, publish=publish)
+               resid=resid, resid_cols=resid_cols, publish=publish, kpad=kpad)
     mu, sd = heads[:, :split], heads[:, split:]
     if sample is not None:
         g = sample.get
@@ -161,22 +189,22 @@ def linear_heads(out, x, W, bias=None, *, split, x2=None, scale=None, act0=0, ac
 def linear_bwd_data(dx, dpre, W, *, kscale=None, alpha=1.0, beta=0.0, yref=None, act=0, shift=0.0, overread=False,
                     npad=False):
     if yref is None:
-        gemm(dx, dpre, W, True, False, a_kscale=kscale, alpha=alpha, beta=beta)
+        gemm(dx, dpre, W, True, False, a_kscale=kscale, alpha=alpha, beta=beta, npad=npad)
     else:
         gemm(dx, dpre, W, True, False, a_kscale=kscale, alpha=alpha, beta=beta, epi=EPI_BWD, yref=yref, act0=act,
-             act1=act, shift0=shift, shift1=shift)
+             act1=act, shift0=shift, shift1=shift, npad=npad)
 
 
 def linear_bwd_weight(dW, dpre, x, *, beta=0.0, dbias=None, overread=False, npad=False):
-    gemm(dW, dpre, x, False, False, beta=beta, a_colsum=dbias, colsum_beta=beta)
+    gemm(dW, dpre, x, False, False, beta=beta, a_colsum=dbias, colsum_beta=beta, npad=npad)
 
 
 def linear_bwd_pair(dW, dbias, dx, dpre, x, W, *, kscale=None, alpha=1.0, beta_x=0.0, yref=None, act=0, shift=0.0,
                     overread=False, publish=None, npad=False, npad_x=False):
     if publish is not None:
         flag_publish(publish[0], publish[1], publish[2])
-    linear_bwd_weight(dW, dpre, x, dbias=dbias)
-    linear_bwd_data(dx, dpre, W, kscale=kscale, alpha=alpha, beta=beta_x, yref=yref, act=act, shift=shift)
+    linear_bwd_weight(dW, dpre, x, dbias=dbias, npad=npad)
+    linear_bwd_data(dx, dpre, W, kscale=kscale, alpha=alpha, beta=beta_x, yref=yref, act=act, shift=shift, npad=npad_x)
 
 
 def colsum(out, X, beta=0.0):

@@ -225,3 +225,26 @@ def test_sampler_mode_label_buckets(monkeypatch):
     bat_p = D.DeviceBatcher(ds, w, 16, seed=2, mode='sampler', pair_bucket=4, label_bucket=2)
     bat_p.bind(eng_p)
     assert bat_p.label_bucket is None and bat_p.pair_bucket == 4
+
+
+@pytest.mark.gpu
+def test_epoch_feed_follows_a_dataset_edited_in_place(dev):
+    """round-4 advisor: the graph-resident feed reads a row-padded COPY of a 978-gene dataset; an in-place edit of the
+    dataset between two epochs (normalisation, augmentation) must reach it at the next ``begin_epoch``"""
+    from oracle import models_ref as M
+    from tests.test_engine_cpu import make_engine
+    spec = C.tiny_spec('drvae', dim_x=13)
+    eng, _ = make_engine(spec, M.init_params(spec, 3, as_numpy=True), dev)
+    big = M.make_batch(spec, 64, seed=4)
+    t = lambda k: torch.from_numpy(big[k].copy()).to(dev)
+    ds = D.DrVAEDataset(t('x1'), t('x2'), t('s'), t('y'), t('has_x2'), t('has_y'))
+    bat = D.DeviceBatcher(ds, torch.ones(64), 16, seed=2)
+    bat.bind(eng)
+    bat.begin_epoch()
+    fd = eng.plan.feed
+    assert fd.x1.data_ptr() != ds.x1.data_ptr() and torch.equal(fd.x1, ds.x1)      # 13 genes: a padded copy
+    ds.x1.mul_(2.0).add_(1.0)
+    assert not torch.equal(fd.x1, ds.x1)
+    bat.begin_epoch()
+    assert eng.plan.feed is fd and torch.equal(fd.x1, ds.x1) and torch.equal(fd.x2, ds.x2)
+    assert not bool(fd.x1._base[:, 13:].any())

@@ -382,3 +382,55 @@ def test_wide_step_path_bias_gradient_in_the_nll_pass(kind, monkeypatch):
     finally:
         monkeypatch.delenv('DRVAE_TUNE')
         T.reload()
+
+
+@pytest.mark.parametrize('optim', ['adam', 'adamax'])
+def test_pad_columns_stay_zero_through_training(optim, monkeypatch):
+    """round-4 advisor: products over padded K / N are only correct while every pad column is exactly 0.  The CPU mirror
+    now runs the padded forms for real (``kernel_ref.gemm``: it reads the operands' pads and writes the outputs' pads), so
+    this trains a model whose every inner dimension is odd (inner dimensions >= 16 are row-padded in the arena) and checks
+    parameters, gradients, both moments and the plan's activation buffers after every step -- and the oracle's losses"""
+    kernel_ref.install(monkeypatch)
+    spec = C.tiny_spec('drvae', dim_x=21, dim_z1=17, dim_z3=18, h_en_z1=[19], h_de_z1=[22], h_en_z3=[23], h_de_x=[25],
+                       optim_alg=optim, weight_decay=0.05)
+    n = 14
+    batch, params = M.make_batch(spec, n, seed=2), M.init_params(spec, 6, as_numpy=True)
+    eng, arena = make_engine(spec, params)
+    assert len(arena.pads(arena.param)) >= 6                      # there ARE padded rows in this model
+    set_batch(eng, batch)
+    tr = M.RefTrainer(spec, M.init_params(spec, 6))
+    for step in range(4):
+        noise = M.make_noise(spec, n, seed=40 + step)
+        eng.train_step(noise)
+        ref, _ = tr.step(batch, noise)
+        for k, v in eng.losses().items():
+            r = float(ref[k].detach()) if torch.is_tensor(ref[k]) else float(ref[k])
+            assert abs(v - r) <= 1e-4 * max(1.0, abs(r)), (step, k, v, r)
+        bufs = [('param', arena.param), ('grad', arena.grad), ('exp_avg', arena.exp_avg)]
+        if optim == 'adam':     # (Adamax: u = max(beta2 u, |g| + eps) makes the pads of its infinity norm eps, as torch's does for
+            bufs.append(('exp_avg_sq', arena.exp_avg_sq))       # a zero gradient; nothing multiplies by them: 0 / eps = 0)
+        for name, buf in bufs:
+            assert not any(bool(p.any()) for p in arena.pads(buf)), (step, name)
+        p = eng.plan
+        for name in ('XIN', 'ZDEC', 'DZDEC', 'Z2F', 'D', 'DZ2F', 'FPIN', 'Z3IN', 'DZ1B'):
+            t = getattr(p, name, None)
+            if t is not None and t._base is not None and t._base.shape[1] != t.shape[1]:
+                assert not bool(t._base[:, t.shape[1]:].any()), (step, name)
+        for ch in (p.c_enc, p.c_decx, p.c_z2F, p.c_top, p.c_dz1):
+            for t in ch.out + ch.dpre:
+                if t._base is not None and t._base.shape[1] != t.shape[1]:
+                    assert not bool(t._base[:, t.shape[1]:].any()), step
+    for k, prm in tr.params.items():
+        close(arena.p(k), prm.detach().numpy(), 2e-4, 5e-5)
+
+
+def test_chain_refuses_padded_products_over_column_slices(monkeypatch):
+    """a column slice of a wider buffer (Q[:, :Z] with Z % 4 != 0) has neighbours behind its last column, not zeros: the
+    chain must not run the padded-K / padded-N forms over it"""
+    from drvae_amd.chain import _Chain
+    wide = torch.zeros(6, 20)
+    assert _Chain._pad_ok(torch.zeros(6, 12)[:, :10])             # whole rows of a row-padded buffer
+    assert _Chain._pad_ok(torch.zeros(6, 10))                     # unpadded rows
+    assert _Chain._pad_ok(wide[:, :8])                            # a multiple of 4: nothing to pad
+    assert not _Chain._pad_ok(wide[:, :10])                       # a slice with live neighbours
+    assert not _Chain._pad_ok(torch.zeros(6, 12)[:, 1:11])
