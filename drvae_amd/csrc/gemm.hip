@@ -64,6 +64,13 @@ __device__ __forceinline__ float4 ld_edge(const Operand& o, int line, int pos) {
     return make_float4(e[0], e[1], e[2], e[3]);
 }
 
+// first of the RPT consecutive rows of a paired-heads tile that the 16- / 32-lane group `grp` of the epilogue owns.  Two
+// neighbouring groups share a 32-lane LDS access; with the reduction buffer's row stride of BN + 1 floats, rows r and
+// r + RPT put them on overlapping banks (0.11-0.22 LDS bank conflicts per access in the round-4 counters) -- half a tile
+// apart (BM / 2 rows = 16 banks) they are disjoint.  A bijection of the groups onto the tile's rows.
+template <int BM, int RPT>
+__device__ __forceinline__ int heads_row0(int grp) { return (grp & 1) * (BM / 2) + (grp >> 1) * RPT; }
+
 // Epilogue of a paired-heads tile: thread -> (column c of the half tile, RPT consecutive rows); both heads of
 // an element are reduced over the KS partial sums by the same thread, pass through the DV_EPI_FWD column
 // epilogue, and feed the row work of the mode (see dv_heads_epi in drvae_hip.h).
@@ -74,7 +81,8 @@ __device__ __forceinline__ void heads_epilogue(const dv_gemm_desc& g, const dv_h
     constexpr bool PRE = (KS == 8 && BN == 32);      // (segment bounds of the thread's one row loaded by the caller)
     static_assert(!PRE || RPT == 1, "prefetched bounds: one row per thread");
     static_assert((HB == 32 || HB == 16) && RPT >= 1, "half tile = 16 or 32 adjacent lanes");
-    const int tid = threadIdx.x, c = tid % HB, r0 = (tid / HB) * RPT;
+    static_assert((NT / HB) % 2 == 0 && (BM / 2) % RPT == 0, "row groups come in pairs");
+    const int tid = threadIdx.x, c = tid % HB, r0 = heads_row0<BM, RPT>(tid / HB);
     const int col0 = tn * HB + c, col1 = g.split + col0;
     const bool ok = col0 < g.split && col1 < g.N;
     const int cc0 = ok ? col0 : g.split - 1, cc1 = ok ? col1 : g.N - 1;
@@ -323,7 +331,7 @@ __device__ __forceinline__ void gemm_body(const dv_gemm_desc& g, const LoadCfg& 
     int pre_s0 = 0, pre_s1 = 0;
     if constexpr (PAIR && KS == 8 && BN == 32) {
         if (he->mode == DV_HEADS_SAMPLE && he->seg_ptr != nullptr) {
-            const int prow = m0 + tid / (BN / 2);
+            const int prow = m0 + heads_row0<BM, 1>(tid / (BN / 2));      // (the row heads_epilogue gives this thread)
             if (prow < he->n_src && prow < g.M) {
                 pre_s0 = he->seg_ptr[prow];
                 pre_s1 = he->seg_ptr[prow + 1];
