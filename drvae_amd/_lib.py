@@ -147,7 +147,7 @@ SIGNATURES = {
                                   C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_f), C.POINTER(_f), C.POINTER(_i32),
                                   C.POINTER(_f), _p, _i64, _p, _p],
     'dv_smalln_linear_bwd_weight': [_p, _i64, _p, _i64, _p, _i64, _i32, _p, _i64, _i32, _i32, _i32, _p, _i64, _p, _f,
-                                    _p, _p],
+                                    _p, _p, _i32, _p],
     'dv_ymarg_fwd': [_p, _i64, _p, _p, _p, _f, _p, _i32, _i32, _p, _p, _p],
     'dv_ymarg_fwdbwd': [_p, _i64, _p, _p, _p, _f, _p, _p, _p, _i32, _i32, _p, _p, _p, _p, _i64, _p],
     'dv_ymarg_bwd': [_p, _i64, _p, _p, _p, _f, _p, _p, _p, _i32, _i32, _p, _p, _i64, _p],

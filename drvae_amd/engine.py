@@ -1031,11 +1031,12 @@ class FusedStep(StepSchedule):
         B, Np, L, Z1 = p.B, p.Np, cfg.L, cfg.dim_z1
 
         def wgrad_clf(*args):
+            ws = getattr(p, 'SNWS', None)       # (row-split workspace: plans with >= 1024 classifier rows)
             if late:
                 # (its entry also tells the main chain that the side chain's data gradients are final: see below)
-                leaf.append(lambda pub=None: K.smalln_bwd_weight(*args, publish=pub))
+                leaf.append(lambda pub=None: K.smalln_bwd_weight(*args, publish=pub, ws=ws))
             else:
-                K.smalln_bwd_weight(*args)
+                K.smalln_bwd_weight(*args, ws=ws)
 
         if self.fuse_bwd and mode == 1:
             self._loss_scalars()         # leaf work, off the critical path

@@ -526,13 +526,24 @@ def smalln_bwd_data(dsts, dprobs, probs, W, seg=None):
                'dv_smalln_linear_bwd_data')
 
 
-def smalln_bwd_weight(dW, db, dprobs, probs, a1, a2=None, beta=0.0, publish=None):
-    """``publish`` = (flag, ctr[, add]): the launch publishes on entry that everything in front of it is complete"""
+SMALLN_WS_SPLITS = 16
+
+
+def smalln_ws_numel(N, K):
+    """floats of the optional row-split workspace of ``smalln_bwd_weight`` for N classes and K = K1 + K2 inputs"""
+    return SMALLN_WS_SPLITS * N * (K + 1)
+
+
+def smalln_bwd_weight(dW, db, dprobs, probs, a1, a2=None, beta=0.0, publish=None, ws=None):
+    """``publish`` = (flag, ctr[, add]): the launch publishes on entry that everything in front of it is complete;
+    ``ws`` (``smalln_ws_numel`` floats): lets many-row products (>= 1024 rows) split the rows over workgroups"""
     M, N = dprobs.shape
     K1, K2 = a1.shape[1], (a2.shape[1] if a2 is not None else 0)
+    assert ws is None or (ws.is_contiguous() and ws.numel() >= smalln_ws_numel(N, K1 + K2))
     _lib.check(_lib.load().dv_smalln_linear_bwd_weight(_f32(dprobs), _ld(dprobs), _f32(probs), _ld(probs), _f32(a1),
                                                        _ld(a1), K1, _f32(a2), _ld(a2), K2, M, N, _f32(dW), _ld(dW),
-                                                       _f32(db), beta, _publish(publish), _stream()),
+                                                       _f32(db), beta, _publish(publish), _f32(ws),
+                                                       SMALLN_WS_SPLITS if ws is not None else 0, _stream()),
                'dv_smalln_linear_bwd_weight')
 
 

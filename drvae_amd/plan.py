@@ -191,6 +191,9 @@ class _Plan:
             R, Mf = L * B, self.Mf
             self.c_clf = _Chain(eng.L_clf, R, dev)
             self.QY, self.DQY, self.DLOG = zf(R, Y), zf(R, Y), zf(R, 1 if cfg.clf_1sig else Y)
+            # many classifier rows (wide configuration: 4096): the single-Linear head's weight gradient splits its rows over
+            # workgroups through this workspace (``kernels.smalln_bwd_weight(ws=...)``)
+            self.SNWS = zf(K.smalln_ws_numel(Y, 2 * Z1)) if (R >= 1024 and Y <= 8) else None
             self.ylab = zf(B, Y)                            # regression targets (type_y='cont')
             # log p(y): the uniform prior as a scalar, a class prior given as data as a device vector
             self.log_prior = math.log(1.0 / Y) if cfg.prior_y is None else \

@@ -498,7 +498,11 @@ int dv_smalln_linear_bwd_data(const float* dprobs, int64_t lddp, const float* pr
 int dv_smalln_linear_bwd_weight(const float* dprobs, int64_t lddp, const float* probs, int64_t ldp,
                                 const float* a1, int64_t lda1, int32_t K1, const float* a2, int64_t lda2,
                                 int32_t K2, int32_t M, int32_t N, float* dW, int64_t ldd, float* db, float beta,
-                                const dv_publish* pub, dv_stream_t stream);
+                                const dv_publish* pub, float* ws, int32_t ws_splits, dv_stream_t stream);
+/* ws / ws_splits (optional, ABI 11): a workspace of ws_splits x N x (K1 + K2 + 1) floats lets the launch split the rows
+ * over up to ws_splits workgroups per block of 16 weight columns (M >= 1024 rows: the wide configuration's 4096) and add
+ * the partial sums up in a fixed order with a second tiny launch -- deterministic; without it one workgroup per column
+ * block walks all M rows */
 
 /* y-marginalisation of src/DrVAE.py:503-534 / src/VFAE.py:331-390 over the stacked
  * "fprop" rows.  For every (l, i) classifier row r (R rows):

@@ -545,7 +545,11 @@ def smalln_bwd_data(dsts, dprobs, probs, W, seg=None):
         _acc(dst, v, beta)
 
 
-def smalln_bwd_weight(dW, db, dprobs, probs, a1, a2=None, beta=0.0, publish=None):
+def smalln_ws_numel(N, K):
+    return 16 * N * (K + 1)
+
+
+def smalln_bwd_weight(dW, db, dprobs, probs, a1, a2=None, beta=0.0, publish=None, ws=None):
     if publish is not None:
         flag_publish(*publish)
     dl = _dlogits(dprobs, probs)
@@ -918,7 +922,7 @@ def nll_rows_raw_cs(out_part, dmu, dsd, ws, coef, x, mu, sd, bias, *, xidx=None,
         ws[b, X:2 * X] = dsd[b * 64:(b + 1) * 64].sum(0)
 
 
-FUNCTIONS = ['col_moment_blocks', 'recon_finalize', 'rank_metrics', 'nll_raw_cs_shape', 'nll_rows_raw_cs', 'rec_nll_rows', 'batch_masks', 'fill_normal_rows', 'linear_heads', 'heads_tiles', 'adamax_l2', 'batch_feed', 'mmd_rff_fwd', 'mmd_rff_bwd', 'counters_add2', 'ycont_fwd', 'ycont_bwd', 'flag_publish', 'flag_wait', 'gemm', 'linear_fwd', 'linear_bwd_data', 'linear_bwd_weight', 'linear_bwd_pair', 'colsum', 'act_bwd_', 'wn_scale', 'wn_bwd',
+FUNCTIONS = ['smalln_ws_numel', 'col_moment_blocks', 'recon_finalize', 'rank_metrics', 'nll_raw_cs_shape', 'nll_rows_raw_cs', 'rec_nll_rows', 'batch_masks', 'fill_normal_rows', 'linear_heads', 'heads_tiles', 'adamax_l2', 'batch_feed', 'mmd_rff_fwd', 'mmd_rff_bwd', 'counters_add2', 'ycont_fwd', 'ycont_bwd', 'flag_publish', 'flag_wait', 'gemm', 'linear_fwd', 'linear_bwd_data', 'linear_bwd_weight', 'linear_bwd_pair', 'colsum', 'act_bwd_', 'wn_scale', 'wn_bwd',
              'reparam_fwd', 'reparam_bwd', 'reparam_bwd_seg', 'z2f_post_bwd', 'kl_rows_fwd', 'kl_rows_bwd', 'nll_rows_fwd', 'nll_rows_bwd', 'nll_rows_fwdbwd',
              'softmax_clamp_fwd', 'softmax_clamp_bwd', 'cat_terms_fwd', 'cat_terms_bwd', 'smalln_fwd', 'smalln_bwd_data',
              'smalln_bwd_weight', 'ymarg_fwd', 'ymarg_bwd', 'ymarg_fwdbwd',

@@ -12,9 +12,21 @@ from tests.test_engine_cpu import make_engine, set_batch
 pytestmark = pytest.mark.gpu
 
 LOSS_RTOL = 1e-4          # BASELINE.json north_star: 1e-4 relative, fp32
-# element-wise gradients: fp32 sums in another order than the reference's (K up to 20000 products per element); the
-# absolute term covers elements that are differences of large terms
+# Gradients and post-Adam parameters are held to the SAME 1e-4, norm-wise per parameter tensor (|| a - ref || / || ref ||):
+# that is the quantity the north_star's tolerance can be asked of.  Element-wise the bound is looser BY CONSTRUCTION and the
+# looser figures below are derived, not chosen: one gradient element is an fp32 sum of K products (K = rows x L, up to 20000
+# per element in the decoder heads) accumulated in another order than the reference's, so it differs by up to
+# ~sqrt(K) 2^-24 sum|terms| -- relative to an element whose terms CANCEL (|sum| << sum|terms|) that exceeds 1e-4 although
+# every term is exact to 6e-8: GRAD_RTOL 5e-4 with an absolute term of 2e-5 max|ref|.  Adam then turns a gradient element
+# that is pure cancellation noise into a move of up to lr = 5e-4 in either direction: 2e-4 / 5e-5 element-wise on the
+# parameters after N steps (|p| ~ 0.03-1).  The norm-wise checks are the tight ones.
+NORM_RTOL = 1e-4
 GRAD_RTOL = 5e-4
+
+
+def rel_norm(a, ref):
+    a, ref = np.asarray(a, np.float64), np.asarray(ref, np.float64)
+    return float(np.linalg.norm(a - ref) / max(np.linalg.norm(ref), 1e-30))
 
 
 def close(a, b, rtol, atol):
@@ -43,8 +55,10 @@ def test_train_steps_match_reference_golden(name, dev):
         if case['full']:
             ref = gold['grad/' + k]
             close(g, ref, GRAD_RTOL, 2e-5 * max(1.0, float(np.abs(ref).max())))
+            if float(np.abs(ref).max()) > 1e-6:
+                assert rel_norm(g, ref) <= NORM_RTOL, (k, rel_norm(g, ref))
         else:
-            close(np.sqrt((g.astype(np.float64) ** 2).sum()), gold['gradnorm/' + k], 2e-4, 1e-7)
+            close(np.sqrt((g.astype(np.float64) ** 2).sum()), gold['gradnorm/' + k], NORM_RTOL, 1e-7)
             ref = gold['gradsample/' + k]
             close(g.reshape(-1)[C.sample_index(g.size)], ref, GRAD_RTOL, 1e-4 * max(1e-3, float(np.abs(ref).max())))
     nsteps = len(case['noises'])
@@ -57,6 +71,7 @@ def test_train_steps_match_reference_golden(name, dev):
                 a = arena.p(k).cpu().numpy()
                 if case['full']:
                     close(a, gold['param%d/%s' % (step, k)], 2e-4, 5e-5)
+                    assert rel_norm(a, gold['param%d/%s' % (step, k)]) <= NORM_RTOL, (step, k)
                 else:
                     close(a.astype(np.float64).sum(), gold['paramsum%d/%s' % (step, k)], 2e-4, 5e-3)
                     close(a.reshape(-1)[C.sample_index(a.size)], gold['paramsample%d/%s' % (step, k)], 2e-4, 5e-5)

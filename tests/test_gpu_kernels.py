@@ -1372,3 +1372,29 @@ def test_recon_finalize(K, dev, M, X, with_sel):
     cols = torch.empty(3, X, dtype=torch.float64, device=dev)
     K.col_moments(cols, x, r, sel=sel)
     close(cols, part.sum(0), rtol=1e-12, atol=1e-9)
+
+
+@pytest.mark.parametrize('M,K1,K2,N', [(4096, 200, 200, 2), (1500, 37, 0, 3), (900, 50, 50, 2)])
+def test_smalln_weight_gradient_row_split(K, dev, M, K1, K2, N):
+    """round 5: with a workspace the single-Linear classifier head's weight gradient splits >= 1024 rows over workgroups
+    (two-stage, fixed order): same result as the one-workgroup-per-column-block form and as the host reference;
+    reproducible bit for bit; below 1024 rows the workspace is ignored"""
+    probs = torch.softmax(rnd(dev, M, N, seed=1), 1)
+    g = rnd(dev, M, N, seed=2, scale=0.1)
+    a1 = strided(dev, M, K1, 4, seed=3)
+    a2 = strided(dev, M, K2, 0, seed=4) if K2 else None
+    KT = K1 + K2
+    ws = torch.full((K.smalln_ws_numel(N, KT),), 7.0, device=dev)
+    outs = []
+    for w in (None, ws, ws):
+        dW, db = torch.full((N, KT), 0.5, device=dev), torch.full((N,), 0.5, device=dev)
+        K.smalln_bwd_weight(dW, db, g, probs, a1, a2, beta=1.0, ws=w)
+        outs.append((dW, db))
+    rW, rb = torch.full((N, KT), 0.5, device=dev), torch.full((N,), 0.5, device=dev)
+    R.smalln_bwd_weight(rW, rb, g, probs, a1, a2, beta=1.0)
+    for dW, db in outs:
+        close(dW, rW, rtol=2e-4, atol=2e-5 * M ** 0.5)
+        close(db, rb, rtol=2e-4, atol=2e-5 * M ** 0.5)
+    assert torch.equal(outs[1][0], outs[2][0]) and torch.equal(outs[1][1], outs[2][1])
+    if M < 1024:
+        assert torch.equal(outs[0][0], outs[1][0]) and bool((ws == 7.0).all())
