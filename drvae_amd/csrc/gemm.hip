@@ -1163,13 +1163,14 @@ static int gemm_launch(const dv_gemm_desc& g_in, const LoadCfg& lc, int tiling, 
 // every CU a whole tile time whenever it pushes the tiles per CU over an integer -- 8192 x 40000 x 2048 (decoder heads of
 // the wide configuration, 64 x 157 = 10048 tiles = 39.25 per CU): 9129 us, exactly the 9106 us of N = 40960 (40 per CU),
 // against 8878 us for N = 39936 (39 per CU); time is linear in tiles per CU, rounded UP (measured, round 5).  A plain
-// product then runs as two launches: columns [0, N - N % 256) on the big tiles, the narrow rest (<= 128 columns) on the
-// small-tile family (8192 x 64 x 2048: ~30 us).  Only where it removes a tile per CU.
+// product then runs as two launches: columns [0, N - N % 256) on the big tiles, the rest (< 256 columns) on the
+// small-tile family (8192 x 64 x 2048: ~30 us) -- fused epilogues included (bias / scale / the two heads' split / residual /
+// activation backward move with their columns; whole-set evaluation: 32768 x 1956 x 600 with the heads' epilogue, 8 -> 7
+// tiles per CU).  Only where it removes a tile per CU.
 static bool ragged_n_split_pays(const dv_gemm_desc& g, int tiling) {
     if (tiling != 40 || tune_of(g).tiling != 0 || tune_of(g).opt[6] == -1) return false;
-    if (g.epilogue != DV_EPI_PLAIN || g.scale || g.bias || g.resid || g.yref || g.a_colsum || g.A2 || g.a_kscale) return false;
     const int n_tail = g.N % 256, n_main = g.N - n_tail;
-    if (n_tail == 0 || n_tail > 128 || n_main == 0) return false;
+    if (n_tail == 0 || n_main == 0) return false;
     const int64_t rows_t = (g.M + 127) / 128, kCUs = 256;
     const int64_t full = rows_t * ((g.N + 255) / 256), main = rows_t * (n_main / 256);
     return (full + kCUs - 1) / kCUs > (main + kCUs - 1) / kCUs;
@@ -1181,12 +1182,24 @@ extern "C" int dv_gemm(const dv_gemm_desc* d, dv_stream_t stream) {
     const int rc = gemm_prepare(d, lc, tiling);
     if (rc != DV_OK) return rc;
     if (ragged_n_split_pays(*d, tiling)) {
+        // columns [0, n_main) | [n_main, N): every per-column operand of the epilogue moves with its columns
         const int n_tail = d->N % 256, n_main = d->N - n_tail;
         dv_gemm_desc g1 = *d, g2 = *d;
         g1.N = n_main;
         g2.N = n_tail;
         g2.B = d->B + (d->b_kcontig ? (int64_t)n_main * d->ldb : (int64_t)n_main);
         g2.C = d->C + n_main;
+        g1.split = d->split < n_main ? d->split : n_main;
+        g2.split = d->split > n_main ? d->split - n_main : 0;
+        if (d->scale) g2.scale = d->scale + n_main;
+        if (d->bias) g2.bias = d->bias + n_main;
+        if (d->yref) g2.yref = d->yref + n_main;
+        if (d->resid) {
+            g1.resid_cols = d->resid_cols < n_main ? d->resid_cols : n_main;
+            g2.resid_cols = d->resid_cols > n_main ? d->resid_cols - n_main : 0;
+            g2.resid = g2.resid_cols > 0 ? d->resid + n_main : nullptr;
+        }
+        g2.a_colsum = nullptr;                  // (column sums of A: once, with the first part)
         g2.pub_flag = nullptr;                  // (the launch publishes once, on entry of the first)
         g2.tune = nullptr;
         LoadCfg l1, l2;

@@ -1398,3 +1398,34 @@ def test_smalln_weight_gradient_row_split(K, dev, M, K1, K2, N):
     assert torch.equal(outs[1][0], outs[2][0]) and torch.equal(outs[1][1], outs[2][1])
     if M < 1024:
         assert torch.equal(outs[0][0], outs[1][0]) and bool((ws == 7.0).all())
+
+
+def test_gemm_ragged_split_carries_the_fused_epilogues(K, dev):
+    """the [full tiles | narrow rest] split of a chip-filling product (dv_gemm) with the per-column operands of the fused
+    epilogues moving with their columns: bias, WeightNorm scale, the two heads' split on either side of the cut, residual
+    columns, accumulate, and the activation backward (yref)"""
+    M, N, Kd = 4096, 32 * 256 + 164, 48
+    x, W, b = rnd(dev, M, Kd, seed=1), rnd(dev, N, Kd, seed=2, scale=Kd ** -0.5), rnd(dev, N, seed=3)
+    sc = rnd(dev, N, seed=4).abs() + 0.5
+    res = rnd(dev, M, N, seed=5)
+    for kw in (dict(bias=b, act0='elu', act1='elu'),
+               dict(bias=b, scale=sc, split=978, act0='identity', act1='softplus', shift1=1e-3),          # split inside the full tiles
+               dict(bias=b, split=32 * 256 + 100, act0='identity', act1='softplus', shift1=1e-3),      # ... inside the narrow rest
+               dict(bias=b, split=N // 2, act0='identity', act1='identity', shift1=-2.0, resid=res, resid_cols=32 * 256 + 7)):
+        out, ref = torch.full((M, N), 7.0, device=dev), torch.zeros(M, N, device=dev)
+        K.linear_fwd(out, x, W, **kw)
+        R.linear_fwd(ref, x, W, **kw)
+        close(out, ref, **gemm_tol(Kd))
+        K.gemm_set_option(6, -1)
+        try:
+            one = torch.zeros(M, N, device=dev)
+            K.linear_fwd(one, x, W, **kw)
+        finally:
+            K.gemm_set_option(6, 0)
+        assert torch.equal(one[:, :32 * 256], out[:, :32 * 256])
+    # dx = (dpre W) * act'(yref), accumulated: the BWD epilogue across the cut
+    dpre, Wt, y = rnd(dev, M, Kd, seed=6), rnd(dev, Kd, N, seed=7), rnd(dev, M, N, seed=8)
+    dx, rx = res.clone(), res.clone()
+    K.linear_bwd_data(dx, dpre, Wt, yref=y, act='elu', beta=1.0)
+    R.linear_bwd_data(rx, dpre, Wt, yref=y, act='elu', beta=1.0)
+    close(dx, rx, **gemm_tol(Kd))
