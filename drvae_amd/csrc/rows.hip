@@ -1028,7 +1028,9 @@ __global__ __launch_bounds__(1024) void smalln_bwd_weight_kernel(const float* __
                                                                  float* __restrict__ dW, int64_t ldd,
                                                                  float* __restrict__ db, float beta, dv_publish pub,
                                                                  float* __restrict__ ws, int rows_per_split) {
-    __shared__ float part[kSnRG][kMaxSmallN][kSnCols];
+    // (one spare class slot: a row-group stride of 144 floats = 16 banks, so the two row groups of a 32-lane access sit on
+    // disjoint banks -- with 128 they shared them: 0.49 LDS bank conflicts per access in the round-5 counters)
+    __shared__ float part[kSnRG][kMaxSmallN + 1][kSnCols];
     publish_block0(pub);
     const int c = threadIdx.x % kSnCols, rg = threadIdx.x / kSnCols;
     const int k = blockIdx.x * kSnCols + c, KT = K1 + K2;   // k == KT is the bias column
