@@ -590,6 +590,7 @@ struct NllCsArgs {
     const float* bias_mu; const float* bias_sd; float* ws; int64_t ldw; int64_t sd_off;
 };
 
+template <bool FWD_ONLY>
 __global__ __launch_bounds__(256) void nll_rows_raw_cs_kernel(NllCsArgs a) {
     __shared__ float part[4][kNllCsRows];
     typedef float nt_f4 __attribute__((ext_vector_type(4)));
@@ -624,7 +625,9 @@ __global__ __launch_bounds__(256) void nll_rows_raw_cs_kernel(NllCsArgs a) {
         nll_raw_sp_elem(c1, a.shift, x1.y, m1[1], s1[1], bm.y, bs.y, acc1, u, v); gm1[1] = u; gs1[1] = v;
         nll_raw_sp_elem(c1, a.shift, x1.z, m1[2], s1[2], bm.z, bs.z, acc1, u, v); gm1[2] = u; gs1[2] = v;
         nll_raw_sp_elem(c1, a.shift, x1.w, m1[3], s1[3], bm.w, bs.w, acc1, u, v); gm1[3] = u; gs1[3] = v;
-        if (on) {
+        if constexpr (FWD_ONLY) {         // (evaluation: the row terms only -- no gradients, no column sums)
+            if (!on) acc0 = acc1 = 0.f;
+        } else if (on) {
             __builtin_nontemporal_store(gm0, reinterpret_cast<nt_f4*>(a.dmu + (int64_t)ra * a.ldd) + q);
             __builtin_nontemporal_store(gs0, reinterpret_cast<nt_f4*>(a.dsd + (int64_t)ra * a.ldd) + q);
             // (fixed order: row r, then row r + 1 -- the same sums whatever the grid)
@@ -651,10 +654,12 @@ __global__ __launch_bounds__(256) void nll_rows_raw_cs_kernel(NllCsArgs a) {
         const int t = threadIdx.x;
         a.out_part[(int64_t)(r0 + t) * a.chunks + chunk] = -0.5f * ((part[0][t] + part[1][t]) + (part[2][t] + part[3][t]));
     }
-    if (on) {
-        float* w = a.ws + (int64_t)rb * a.ldw;
-        reinterpret_cast<float4*>(w)[q] = cm;
-        reinterpret_cast<float4*>(w + a.sd_off)[q] = cs;
+    if constexpr (!FWD_ONLY) {
+        if (on) {
+            float* w = a.ws + (int64_t)rb * a.ldw;
+            reinterpret_cast<float4*>(w)[q] = cm;
+            reinterpret_cast<float4*>(w + a.sd_off)[q] = cs;
+        }
     }
 }
 
@@ -2215,16 +2220,24 @@ extern "C" int dv_gauss_nll_rows_raw_cs(const dv_nll_raw_cs_desc* dsc, dv_stream
     const dv_nll_raw_cs_desc& d = *dsc;
     DV_REQUIRE(d.M >= 0 && d.X >= 4 && d.X % 4 == 0);
     if (d.M == 0) return DV_OK;
-    DV_REQUIRE(d.coef && d.x && d.mu && d.sd && d.out_part && d.dmu && d.dsd && d.bias_mu && d.bias_sd && d.ws);
+    const bool fwd_only = d.dmu == nullptr;        // (evaluation: row terms only)
+    DV_REQUIRE(d.x && d.mu && d.sd && d.out_part && d.bias_mu && d.bias_sd);
+    DV_REQUIRE(fwd_only ? (d.dsd == nullptr && d.ws == nullptr) : (d.coef && d.dsd && d.ws));
     auto a16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-    DV_REQUIRE(a16(d.x) && a16(d.mu) && a16(d.sd) && a16(d.dmu) && a16(d.dsd) && a16(d.bias_mu) && a16(d.bias_sd) && a16(d.ws));
-    DV_REQUIRE(d.ldx % 4 == 0 && d.ldp % 4 == 0 && d.ldd % 4 == 0 && d.ldw % 4 == 0 && d.sd_off % 4 == 0);
-    DV_REQUIRE(d.sd_off >= d.X && d.sd_off + d.X <= d.ldw);
+    DV_REQUIRE(a16(d.x) && a16(d.mu) && a16(d.sd) && a16(d.bias_mu) && a16(d.bias_sd));
+    DV_REQUIRE(d.ldx % 4 == 0 && d.ldp % 4 == 0);
+    if (!fwd_only) {
+        DV_REQUIRE(a16(d.dmu) && a16(d.dsd) && a16(d.ws) && d.ldd % 4 == 0 && d.ldw % 4 == 0 && d.sd_off % 4 == 0);
+        DV_REQUIRE(d.sd_off >= d.X && d.sd_off + d.X <= d.ldw);
+    }
     const int chunks = dv_nll_raw_cs_chunks(d.X), row_blocks = dv_nll_raw_cs_row_blocks(d.M);
     DV_REQUIRE(d.chunks == chunks && d.row_blocks == row_blocks && row_blocks <= 65535);
     NllCsArgs a{d.coef, d.x, d.ldx, d.xidx, d.mu, d.sd, d.ldp, d.M, d.X, d.shift, d.out_part, chunks, d.dmu, d.dsd, d.ldd,
                 d.bias_mu, d.bias_sd, d.ws, d.ldw, d.sd_off};
-    hipLaunchKernelGGL(nll_rows_raw_cs_kernel, dim3(chunks, row_blocks), dim3(256), 0, ST(stream), a);
+    if (fwd_only)
+        hipLaunchKernelGGL(nll_rows_raw_cs_kernel<true>, dim3(chunks, row_blocks), dim3(256), 0, ST(stream), a);
+    else
+        hipLaunchKernelGGL(nll_rows_raw_cs_kernel<false>, dim3(chunks, row_blocks), dim3(256), 0, ST(stream), a);
     DV_RETURN_LAUNCH();
 }
 

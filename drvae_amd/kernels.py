@@ -408,16 +408,23 @@ def nll_raw_cs_shape(M, X):
 def nll_rows_raw_cs(out_part, dmu, dsd, ws, coef, x, mu, sd, bias, *, xidx=None, sd_shift=1e-3):
     """the raw-heads NLL forward + backward pass with the heads' bias gradient folded in (``dv_gauss_nll_rows_raw_cs``):
     ``out_part`` (M, chunks) partial row log-likelihoods, ``ws`` (row_blocks, ld) per-block column sums of (dmu | dsd) --
-    dsd's at the column offset dsd has behind dmu; the caller sums the blocks (``colsum``)"""
+    dsd's at the column offset dsd has behind dmu; the caller sums the blocks (``colsum``).  ``dmu = dsd = ws = coef =
+    None``: forward only (evaluation)."""
     M, X = mu.shape
     chunks, rbs = nll_raw_cs_shape(M, X)
-    assert _ld(mu) == _ld(sd) and _ld(dmu) == _ld(dsd) and dmu.untyped_storage().data_ptr() == dsd.untyped_storage().data_ptr()
-    off = dsd.storage_offset() - dmu.storage_offset()
-    assert tuple(out_part.shape) == (M, chunks) and out_part.is_contiguous() and ws.shape[0] == rbs and ws.dim() == 2
+    fwd_only = dmu is None
+    assert _ld(mu) == _ld(sd) and tuple(out_part.shape) == (M, chunks) and out_part.is_contiguous()
+    off = 0
+    if not fwd_only:
+        assert _ld(dmu) == _ld(dsd) and dmu.untyped_storage().data_ptr() == dsd.untyped_storage().data_ptr()
+        off = dsd.storage_offset() - dmu.storage_offset()
+        assert ws.shape[0] == rbs and ws.dim() == 2
+    else:
+        assert dsd is None and ws is None
     d = _lib.NllRawCs(coef=_f32(coef), x=_f32(x), ldx=_ld(x), xidx=_i32(xidx), mu=_f32(mu), sd=_f32(sd), ldp=_ld(mu), M=M,
                       X=X, shift=sd_shift, out_part=_f32(out_part), chunks=chunks, dmu=_f32(dmu), dsd=_f32(dsd),
-                      ldd=_ld(dmu), bias_mu=_f32(bias[0]), bias_sd=_f32(bias[1]), ws=_f32(ws), ldw=ws.stride(0),
-                      sd_off=off, row_blocks=rbs)
+                      ldd=_ld(dmu), bias_mu=_f32(bias[0]), bias_sd=_f32(bias[1]), ws=_f32(ws),
+                      ldw=ws.stride(0) if ws is not None else 0, sd_off=off, row_blocks=rbs)
     _lib.check(_lib.load().dv_gauss_nll_rows_raw_cs(C.byref(d), _stream()), 'dv_gauss_nll_rows_raw_cs')
 
 

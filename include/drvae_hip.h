@@ -415,7 +415,10 @@ int dv_rec_nll_rows(int32_t kind, float shift, const float* coef, const float* x
  *   ws[b, g]          = sum over the rows of row block b of dmu[r, g]        } (row_blocks x ldw; the caller sums the
  *   ws[b, sd_off + g] = the same of dsd[r, g]                                } blocks: dv_colsum(ws, ldw, row_blocks, ..))
  * chunks = dv_nll_raw_cs_chunks(X), row_blocks = dv_nll_raw_cs_row_blocks(M).  X % 4 == 0, 16-B aligned rows.
- * Deterministic (fixed summation order, no atomics). */
+ * Deterministic (fixed summation order, no atomics).
+ * dmu == dsd == ws == NULL (coef unused): FORWARD ONLY -- the row partials of an evaluation pass behind a plain heads
+ * product (the whole-set evaluation's loss pass: no activation epilogue in the GEMM, no finished heads written and
+ * read back). */
 typedef struct dv_nll_raw_cs_desc {
     const float* coef;
     const float* x;

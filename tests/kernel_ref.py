@@ -906,20 +906,23 @@ def nll_raw_cs_shape(M, X):
 
 
 def nll_rows_raw_cs(out_part, dmu, dsd, ws, coef, x, mu, sd, bias, *, xidx=None, sd_shift=1e-3):
-    """stand-in of dv_gauss_nll_rows_raw_cs: per-chunk row partials (1024 genes per chunk), per-block (64 rows) column sums"""
+    """stand-in of dv_gauss_nll_rows_raw_cs: per-chunk row partials (1024 genes per chunk), per-block (64 rows) column sums;
+    dmu is None: forward only"""
     M, X = mu.shape
     chunks, rbs = nll_raw_cs_shape(M, X)
-    full = torch.zeros(M, dtype=mu.dtype, device=mu.device)
-    nll_rows_fwdbwd(full, dmu, dsd, coef, x, mu, sd, mode=GAUSS_SIGMA, xidx=xidx, sd_act='softplus', sd_shift=sd_shift, bias=bias)
+    if dmu is not None:
+        full = torch.zeros(M, dtype=mu.dtype, device=mu.device)
+        nll_rows_fwdbwd(full, dmu, dsd, coef, x, mu, sd, mode=GAUSS_SIGMA, xidx=xidx, sd_act='softplus', sd_shift=sd_shift, bias=bias)
     xs = x[xidx.long()] if xidx is not None else x
     m = mu + bias[0]
     s_ = F.softplus(sd + bias[1]) + sd_shift
     el = -0.5 * (math.log(2 * math.pi) + 2 * torch.log(s_) + ((xs - m) / s_) ** 2)
     for c in range(chunks):
         out_part[:, c] = el[:, c * 1024:(c + 1) * 1024].sum(1)
-    for b in range(rbs):
-        ws[b, :X] = dmu[b * 64:(b + 1) * 64].sum(0)
-        ws[b, X:2 * X] = dsd[b * 64:(b + 1) * 64].sum(0)
+    if dmu is not None:
+        for b in range(rbs):
+            ws[b, :X] = dmu[b * 64:(b + 1) * 64].sum(0)
+            ws[b, X:2 * X] = dsd[b * 64:(b + 1) * 64].sum(0)
 
 
 FUNCTIONS = ['smalln_ws_numel', 'col_moment_blocks', 'recon_finalize', 'rank_metrics', 'nll_raw_cs_shape', 'nll_rows_raw_cs', 'rec_nll_rows', 'batch_masks', 'fill_normal_rows', 'linear_heads', 'heads_tiles', 'adamax_l2', 'batch_feed', 'mmd_rff_fwd', 'mmd_rff_bwd', 'counters_add2', 'ycont_fwd', 'ycont_bwd', 'flag_publish', 'flag_wait', 'gemm', 'linear_fwd', 'linear_bwd_data', 'linear_bwd_weight', 'linear_bwd_pair', 'colsum', 'act_bwd_', 'wn_scale', 'wn_bwd',

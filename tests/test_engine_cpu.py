@@ -368,6 +368,18 @@ def test_wide_step_path_bias_gradient_in_the_nll_pass(kind, monkeypatch):
         eng, arena = make_engine(spec, params)
         set_batch(eng, batch)
         tr = M.RefTrainer(spec, M.init_params(spec, 4))
+        # an evaluation pass first: plain heads product + the forward-only row pass (no gradients, no column sums)
+        noise0 = M.make_noise(spec, n, seed=29)
+        eng.training = False
+        eng.set_noise(noise0)
+        eng.forward()
+        ref0, _ = tr.loss(batch, noise0, training=False)
+        for k, v in eng.losses().items():
+            r = float(ref0[k].detach()) if torch.is_tensor(ref0[k]) else float(ref0[k])
+            assert abs(v - r) <= 1e-4 * max(1.0, abs(r)), ('eval', k, v, r)
+        assert seen['cs'] == 1 and not seen['adam']
+        seen['cs'] = 0
+        eng.training = True
         for step in range(3):
             noise = M.make_noise(spec, n, seed=30 + step)
             eng.train_step(noise)
