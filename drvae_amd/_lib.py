@@ -129,7 +129,7 @@ SIGNATURES = {
     'dv_kl_rows_fwd': [C.POINTER(KlRows), C.POINTER(Wait), _p],
     'dv_kl_rows_bwd': [_p, _p, _i32, _f, _p, _p, _i64, _p, _p, _p, _i64, _p, _f, _f, _i32, _i32, _i32, _i32,
                        _p, _p, _i64, _p, _p, _i64, _f, _p, _i64, _p, _i64, _p],
-    'dv_gauss_nll_rows_fwd': [_p, _i64, _p, _p, _p, _i64, _i32, _i32, _i32, _p, _p],
+    'dv_gauss_nll_rows_fwd': [_p, _i64, _p, _p, _p, _i64, _i32, _i32, _i32, _p, _p, _p, _f, _p],
     'dv_gauss_nll_rows_fwdbwd': [_p, _p, _i64, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _f, _p, _p, _p, _i64, _p, _p, _p],
     'dv_gauss_nll_rows_raw_cs': [C.POINTER(NllRawCs), _p],
     'dv_nll_raw_cs_chunks': [_i32],

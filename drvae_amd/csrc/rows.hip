@@ -394,30 +394,53 @@ __device__ __forceinline__ float nll_term(int mode, float x, float m, float s) {
     return kLog2Pi + s + d * d / expf(s);
 }
 
-template <bool VEC4>
+// one term of a row's Gaussian log-likelihood from the heads' RAW product (x W^T without bias / activation): mu = m + bm,
+// sd = softplus(s + bs) + shift on the hardware transcendentals (the forward half of nll_raw_sp_elem below)
+__device__ __forceinline__ float nll_raw_term(float shift, float xv, float mraw, float sraw, float bm, float bs) {
+    const float a = sraw + bs;
+    const float e = __expf(-fabsf(a));
+    const float sdv = fmaxf(a, 0.f) + __logf(1.f + e) + shift;
+    const float t = (xv - (mraw + bm)) * __frcp_rn(sdv);
+    return kLog2Pi + 2.f * __logf(sdv) + t * t;
+}
+
+// RAW (evaluation passes behind a plain heads product, round 5): mu / sd are the raw products, finished on the way
+template <bool VEC4, bool RAW>
 __global__ __launch_bounds__(256) void nll_rows_fwd_kernel(const float* __restrict__ x, int64_t ldx,
                                                            const int32_t* __restrict__ xidx,
                                                            const float* __restrict__ mu,
                                                            const float* __restrict__ sd, int64_t ldp, int M, int X,
-                                                           int mode, float* __restrict__ out) {
+                                                           int mode, float* __restrict__ out,
+                                                           const float* __restrict__ bias_mu,
+                                                           const float* __restrict__ bias_sd, float shift) {
     const int lane = threadIdx.x & 63;
     for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < M; r += gridDim.x * 4) {
         const float* xr = x + (int64_t)(xidx ? xidx[r] : r) * ldx;
         const float* mr = mu + (int64_t)r * ldp;
         const float* sr = sd + (int64_t)r * ldp;
         float s = 0.f;
+        auto term = [&](float xv, float m, float sv, int g) -> float {
+            if constexpr (RAW) return nll_raw_term(shift, xv, m, sv, bias_mu[g], bias_sd[g]);
+            else return nll_term(mode, xv, m, sv);
+        };
         if (VEC4) {
             const int X4 = X >> 2;
             for (int c = lane; c < X4; c += 64) {
                 const float4 xv = reinterpret_cast<const float4*>(xr)[c];
                 const float4 mv = reinterpret_cast<const float4*>(mr)[c];
                 const float4 sv = reinterpret_cast<const float4*>(sr)[c];
-                s += nll_term(mode, xv.x, mv.x, sv.x) + nll_term(mode, xv.y, mv.y, sv.y) +
-                     nll_term(mode, xv.z, mv.z, sv.z) + nll_term(mode, xv.w, mv.w, sv.w);
+                s += term(xv.x, mv.x, sv.x, 4 * c) + term(xv.y, mv.y, sv.y, 4 * c + 1) +
+                     term(xv.z, mv.z, sv.z, 4 * c + 2) + term(xv.w, mv.w, sv.w, 4 * c + 3);
             }
-            for (int g = (X4 << 2) + lane; g < X; g += 64) s += nll_term(mode, xr[g], mr[g], sr[g]);
+            for (int g = (X4 << 2) + lane; g < X; g += 64) s += term(xr[g], mr[g], sr[g], g);
         } else {
-            for (int g = lane; g < X; g += 64) s += nll_term(mode, xr[g], mr[g], sr[g]);
+            // (four independent elements per trip: the scalar path serves 978-gene rows, whose sigma half starts 8 B
+            // off a 16-B boundary)
+            int g = lane;
+            for (; g + 192 < X; g += 256)
+                s += (term(xr[g], mr[g], sr[g], g) + term(xr[g + 64], mr[g + 64], sr[g + 64], g + 64)) +
+                     (term(xr[g + 128], mr[g + 128], sr[g + 128], g + 128) + term(xr[g + 192], mr[g + 192], sr[g + 192], g + 192));
+            for (; g < X; g += 64) s += term(xr[g], mr[g], sr[g], g);
         }
         s = dv_wave_sum_all(s);
         if (lane == 0) out[r] = -0.5f * s;
@@ -2173,18 +2196,28 @@ extern "C" int dv_kl_rows_bwd(const float* coef, const float* raw, int32_t free_
 
 extern "C" int dv_gauss_nll_rows_fwd(const float* x, int64_t ldx, const int32_t* xidx, const float* mu,
                                      const float* sd, int64_t ldp, int32_t M, int32_t X, int32_t mode, float* out,
-                                     dv_stream_t stream) {
+                                     const float* bias_mu, const float* bias_sd, float sd_shift, dv_stream_t stream) {
     DV_REQUIRE(M >= 0 && X >= 0);
     if (M == 0) return DV_OK;
-    DV_REQUIRE(x && mu && sd && out);
+    DV_REQUIRE(x && mu && sd && out && ((bias_mu == nullptr) == (bias_sd == nullptr)));
+    DV_REQUIRE(bias_mu == nullptr || mode == DV_GAUSS_SIGMA);      // (raw heads: the sigma head = softplus + shift)
     const bool v4 = aligned16(x) && aligned16(mu) && aligned16(sd) && (ldx % 4 == 0) && (ldp % 4 == 0);
     const dim3 grid(grid_for(M, 4, 8192)), block(256);
+    if (bias_mu) {
+        if (v4)
+            hipLaunchKernelGGL((nll_rows_fwd_kernel<true, true>), grid, block, 0, ST(stream), x, ldx, xidx, mu, sd, ldp, M, X,
+                               mode, out, bias_mu, bias_sd, sd_shift);
+        else
+            hipLaunchKernelGGL((nll_rows_fwd_kernel<false, true>), grid, block, 0, ST(stream), x, ldx, xidx, mu, sd, ldp, M, X,
+                               mode, out, bias_mu, bias_sd, sd_shift);
+        DV_RETURN_LAUNCH();
+    }
     if (v4)
-        hipLaunchKernelGGL(nll_rows_fwd_kernel<true>, grid, block, 0, ST(stream), x, ldx, xidx, mu, sd, ldp, M, X,
-                           mode, out);
+        hipLaunchKernelGGL((nll_rows_fwd_kernel<true, false>), grid, block, 0, ST(stream), x, ldx, xidx, mu, sd, ldp, M, X,
+                           mode, out, bias_mu, bias_sd, sd_shift);
     else
-        hipLaunchKernelGGL(nll_rows_fwd_kernel<false>, grid, block, 0, ST(stream), x, ldx, xidx, mu, sd, ldp, M, X,
-                           mode, out);
+        hipLaunchKernelGGL((nll_rows_fwd_kernel<false, false>), grid, block, 0, ST(stream), x, ldx, xidx, mu, sd, ldp, M, X,
+                           mode, out, bias_mu, bias_sd, sd_shift);
     DV_RETURN_LAUNCH();
 }
 

@@ -648,19 +648,23 @@ class FusedStep(StepSchedule):
             # an EVALUATION pass over many rows (whole-set evaluation, round 5): the heads are needed for the row terms only
             # -- plain product, finished inside the row pass (32768 x 1956 x 600: 737 -> 589 us for the product, and no
             # 256 MB of finished heads written and read back)
-            raw_eval = raw_ok and not self.fuse_bwd and not self.training and p.NLLC is not None and bool(T.get('nll_cs'))
+            raw_eval = raw_ok and not self.fuse_bwd and not self.training and bool(T.get('nll_cs'))
             PX = p.c_decx.forward(p.dec_in, publish=pub, raw_last=raw or raw_eval)
         if self._nll_fused:
             raw_eval = False
         elif not gauss:        # Bernoulli / Poisson rows (+ the gradient w.r.t. the head's pre-activation in a train step)
             K.rec_nll_rows(p.NLL, p.XIN, PX, kind=cfg.type_rec, shift=REC_ACT[cfg.type_rec][1], xidx=p.tgt,
                            coef=p.c_nll if self.fuse_bwd else None, dpre=p.DPX if self.fuse_bwd else None)
-        elif raw_eval:
+        elif raw_eval and p.NLLC is not None:
             # evaluation: the row terms from the raw heads (bias + softplus + shift applied by the pass; no gradients)
             lh = p.c_decx.layers[-1]
             K.nll_rows_raw_cs(p.NLLC, None, None, None, None, p.XIN, PX[:, :X], PX[:, X:], (lh.b[:X], lh.b[X:]), xidx=p.tgt,
                               sd_shift=lh.shift1)
             self._nll_cs = True
+        elif raw_eval:         # (gene counts that are no multiple of 4 -- 978: the wave-per-row pass)
+            lh = p.c_decx.layers[-1]
+            K.nll_rows_fwd(p.NLL, p.XIN, PX[:, :X], PX[:, X:], mode=GAUSS_SIGMA, xidx=p.tgt, bias=(lh.b[:X], lh.b[X:]),
+                           sd_shift=lh.shift1)
         elif self.fuse_bwd and raw and p.NLLC is not None and T.get('nll_cs'):
             # ... and the heads' bias gradient with it (column sums of the gradients this pass writes: no second pass over them)
             lh = p.c_decx.layers[-1]

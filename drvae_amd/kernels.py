@@ -379,11 +379,15 @@ def kl_rows_bwd(dq_mu, dq_sd, dp_mu, dp_sd, coef, raw, mu_q, sd_q, mu_p=None, sd
 
 
 # ------------------------------------------------------------------------- NLL rows
-def nll_rows_fwd(out, x, mu, sd, *, mode=GAUSS_SIGMA, xidx=None):
+def nll_rows_fwd(out, x, mu, sd, *, mode=GAUSS_SIGMA, xidx=None, bias=None, sd_shift=1e-3):
+    """``bias`` = (bias_mu, bias_sd): ``mu`` / ``sd`` are the heads' raw products, finished by the pass (mu + bias_mu,
+    softplus(sd + bias_sd) + sd_shift): evaluation passes behind a plain heads product"""
     M, X = mu.shape
     assert _ld(mu) == _ld(sd)
     _lib.check(_lib.load().dv_gauss_nll_rows_fwd(_f32(x), _ld(x), _i32(xidx), _f32(mu), _f32(sd), _ld(mu), M, X,
-                                                 mode, _f32(out), _stream()), 'dv_gauss_nll_rows_fwd')
+                                                 mode, _f32(out), _f32(bias[0]) if bias is not None else None,
+                                                 _f32(bias[1]) if bias is not None else None, sd_shift, _stream()),
+               'dv_gauss_nll_rows_fwd')
 
 
 def nll_rows_fwdbwd(out, dmu, dsd, coef, x, mu, sd, *, mode=GAUSS_SIGMA, xidx=None, sd_act=0, sd_shift=0.0, bias=None):

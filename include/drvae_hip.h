@@ -389,7 +389,10 @@ int dv_kl_rows_bwd(const float* coef, const float* raw, int32_t free_bits, float
  * through sd = sd_act(pre) + sd_shift when sd_act != IDENTITY, i.e. directly the
  * gradient w.r.t. the head's pre-activation (src/blocks.py:415).  dx optional. */
 int dv_gauss_nll_rows_fwd(const float* x, int64_t ldx, const int32_t* xidx, const float* mu, const float* sd,
-                          int64_t ldp, int32_t M, int32_t X, int32_t mode, float* out, dv_stream_t stream);
+                          int64_t ldp, int32_t M, int32_t X, int32_t mode, float* out, const float* bias_mu,
+                          const float* bias_sd, float sd_shift, dv_stream_t stream);
+/* bias_mu / bias_sd (both or neither, SIGMA mode; ABI 11): mu / sd hold the heads' RAW products and the pass finishes them
+ * on its way (mu + bias_mu, softplus(sd + bias_sd) + sd_shift) -- evaluation passes behind a plain heads product */
 int dv_gauss_nll_rows_bwd(const float* coef, const float* x, int64_t ldx, const int32_t* xidx, const float* mu,
                           const float* sd, int64_t ldp, int32_t M, int32_t X, int32_t mode, int32_t sd_act,
                           float sd_shift, float* dmu, float* dsd, int64_t ldd, float* dx, int64_t lddx, float beta,

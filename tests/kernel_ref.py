@@ -403,7 +403,10 @@ def kl_rows_bwd(dq_mu, dq_sd, dp_mu, dp_sd, coef, raw, mu_q, sd_q, mu_p=None, sd
         _acc(dp_sd, c * gsp, beta)
 
 
-def nll_rows_fwd(out, x, mu, sd, *, mode=GAUSS_SIGMA, xidx=None):
+def nll_rows_fwd(out, x, mu, sd, *, mode=GAUSS_SIGMA, xidx=None, bias=None, sd_shift=1e-3):
+    if bias is not None:          # raw heads: finished here
+        mu = mu + bias[0]
+        sd = F.softplus(sd + bias[1]) + sd_shift
     xr = x[xidx.long()] if xidx is not None else x
     if mode == GAUSS_SIGMA:
         t = LOG_2PI + torch.log(sd ** 2) + (xr - mu) ** 2 / sd ** 2

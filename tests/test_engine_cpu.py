@@ -364,6 +364,22 @@ def test_wide_step_path_bias_gradient_in_the_nll_pass(kind, monkeypatch):
         monkeypatch.setattr(K, 'linear_bwd_pair', lambda dW, db, *a, **k: (no_db.append(db is None), real_pair(dW, db, *a, **k))[1])
         spec = C.tiny_spec(kind, dim_x=2056, h_de_x=[8], dim_z1=6)       # 3 gene chunks (the last one ragged)
         n = 70                                                           # 2 row blocks of the pass (64 + ragged)
+        # (a gene count that is no multiple of 4 -- 978: an evaluation pass takes the wave-per-row raw pass instead)
+        spec_odd = C.tiny_spec(kind, dim_x=978, h_de_x=[8], dim_z1=6)
+        eng_o, _ = make_engine(spec_odd, M.init_params(spec_odd, 4, as_numpy=True))
+        b_o, n_o = M.make_batch(spec_odd, 20, seed=3), M.make_noise(spec_odd, 20, seed=28)
+        set_batch(eng_o, b_o)
+        eng_o.training = False
+        eng_o.set_noise(n_o)
+        raw_calls = []
+        real_fwd = kernel_ref.nll_rows_fwd
+        monkeypatch.setattr(K, 'nll_rows_fwd', lambda *a, **k: (raw_calls.append(k.get('bias') is not None), real_fwd(*a, **k))[1])
+        eng_o.forward()
+        ref_o, _ = M.RefTrainer(spec_odd, M.init_params(spec_odd, 4)).loss(b_o, n_o, training=False)
+        for k, v in eng_o.losses().items():
+            r = float(ref_o[k].detach()) if torch.is_tensor(ref_o[k]) else float(ref_o[k])
+            assert abs(v - r) <= 1e-4 * max(1.0, abs(r)), ('eval 978', k, v, r)
+        assert raw_calls == [True] and seen['cs'] == 0
         batch, params = M.make_batch(spec, n, seed=3), M.init_params(spec, 4, as_numpy=True)
         eng, arena = make_engine(spec, params)
         set_batch(eng, batch)

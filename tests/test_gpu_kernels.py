@@ -440,6 +440,13 @@ def test_nll_rows(K, dev, mode, X, pad):
     close(o2, ro, rtol=2e-5, atol=1e-3)
     close(D2, RD2, rtol=2e-4, atol=2e-4)
     if mode == 1:
+        # raw heads, forward only (evaluation passes): the same numbers as finishing the heads first
+        rawf = rnd(dev, M, 2 * X + pad, seed=7)
+        bf = rnd(dev, 2 * X, seed=8)
+        o5, o6 = torch.empty(M, device=dev), torch.empty(M, device=dev)
+        K.nll_rows_fwd(o5, x, rawf[:, :X], rawf[:, X:2 * X], mode=1, xidx=xidx, bias=(bf[:X], bf[X:]), sd_shift=1e-3)
+        R.nll_rows_fwd(o6, x, rawf[:, :X], rawf[:, X:2 * X], mode=1, xidx=xidx, bias=(bf[:X], bf[X:]), sd_shift=1e-3)
+        close(o5, o6, rtol=3e-5, atol=2e-3)
         # raw heads: mu / sd hold x W^T, the pass adds the bias and applies softplus + shift itself
         raw = rnd(dev, M, 2 * (X + pad), seed=5)
         rmu, rsd = raw[:, :X], raw[:, X + pad:2 * X + pad]
