@@ -728,7 +728,9 @@ class FusedStep(StepSchedule):
                 else:
                     K.rows_gather(p.FPIN, Z1blk, p.fp_src, onehot_cls=p.fp_cls, n_classes=Y,
                                   park=(first_park[0], first_park[1], first_park[2]) if first_park is not None else None)
-                if self.fuse_heads:
+                # (evaluation passes over many fprop rows -- whole-set evaluation: 24576 -- take the plain product + row pass:
+                # the 32 x (16 + 16) paired-heads tiles are the latency-bound sizes' kernel; 3.33 -> 3.27 ms per pair)
+                if self.fuse_heads and (self.fuse_bwd or p.Mf < 8192):
                     # the z3 sample leaves the heads' launch of q(z3|z1,y); its KL term against N(0,I) (with its
                     # own free bits) is evaluated next to the z1 term below: one launch less
                     Q3 = p.c_top.forward([p.FPIN], heads=dict(sample=dict(eps=p.E3, out=p.Z3IN[:, :Z3], n_src=p.Mf)))
