@@ -162,6 +162,11 @@ SIGNATURES = {
     'dv_weighted_sum': [_p, _p, _p, _i32, _f, _p, _f, _p],
     'dv_recon_row_stats': [_p, _i64, _p, _i64, _i32, _i32, _p, _p],
     'dv_col_moments': [_p, _i64, _p, _i64, _i32, _i32, _p, _i32, _p, _p],
+    'dv_mmd_mix_fwd': [_p, _i64, _i32, _i32, _i32, _p, _i32, _p, _i64, _p, _i64, _p, _p],
+    'dv_mmd_mix_bwd': [_p, _i64, _i32, _i32, _i32, _p, _i32, _p, _i64, _p, _i64, _p, _f, _p, _i64, _p, _p],
+    'dv_mmd_mix_combine': [_p, _i32, _f, _p, _i32, _f, _p, _i32, _f, _p, _p],
+    'dv_mmd_identity_fwd': [_p, _i64, _i32, _p, _i64, _i32, _i32, _p, _p, _p],
+    'dv_mmd_identity_bwd': [_p, _p, _f, _i32, _i32, _p, _i64, _p],
     'dv_recon_finalize': [_p, _p, _i32, _i32, _p, _i32, _p, _p, _p],
     'dv_rank_metrics': [_p, _i64, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _p],
     'dv_loss_assemble': [C.POINTER(LossTerm), _i32, _p, _p, _p, _p, _i32, _p, _p],

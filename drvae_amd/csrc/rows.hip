@@ -1620,6 +1620,112 @@ __global__ __launch_bounds__(256) void col_moments_kernel(const float* __restric
             out[((int64_t)blockIdx.y * 3 + k) * X + g] = (part[0][k][c] + part[1][k][c]) + (part[2][k][c] + part[3][k][c]);
 }
 
+// ------------------------------------------------------------------ kernel-mixture MMD (src/blocks.py:29-38,59-76; round 5)
+// mmd_objective(kernel = 'rbf' | 'poly'): mean_ij k(a_i, b_j) with k = 1/nb sum_b f(., gamma_b) over three Gram products
+// (x1 x1^T, x2 x2^T, x1 x2^T: dv_gemm).  The element-wise mixture, its mean and its derivative were library element-wise
+// chains (pow / exp per bandwidth, five times over); here one row pass each way.
+//   poly: f = (gamma G_ij + 1)^2                     (degree 2, bias 1: what mmd_objective calls, src/blocks.py:34-35,70-74)
+//   rbf : f = exp(-gamma (|a_i|^2 + |b_j|^2 - 2 G_ij))   (the Gram form of src/blocks.py:29-32's intent)
+// |a_i|^2 = the diagonal of a a^T: sa[i * sa_stride], no pass of its own.
+struct MixArgs {
+    const float* G; int64_t ldg; int M, N, kind, nb; float gam[8];
+    const float* sa; int64_t sa_stride; const float* sb; int64_t sb_stride;
+};
+
+__device__ __forceinline__ float mix_val(const MixArgs& a, float g, float d2, float& dv) {
+    float v = 0.f;
+    dv = 0.f;
+    for (int b = 0; b < a.nb; ++b) {
+        const float gm = a.gam[b];
+        if (a.kind == 0) {
+            const float t = fmaf(gm, g, 1.f);
+            v += t * t;
+            dv += 2.f * gm * t;             // d/dG
+        } else {
+            const float e = __expf(-gm * d2);
+            v += e;
+            dv -= gm * e;                   // d/d(d2)
+        }
+    }
+    const float inv = 1.f / (float)a.nb;
+    dv *= inv;
+    return v * inv;
+}
+
+// part[i] = sum_j k_ij (fwd) | W[i, j] = c * dk_ij, rs[i] = sum_j W[i, j] (bwd; c = coef * gout[0]); one workgroup per row
+template <bool BWD>
+__global__ __launch_bounds__(256) void mmd_mix_kernel(MixArgs a, float* __restrict__ part, const float* __restrict__ gout,
+                                                      float coef, float* __restrict__ W, int64_t ldw, float* __restrict__ rs) {
+    __shared__ float red[4];
+    const int i = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* g = a.G + (int64_t)i * a.ldg;
+    const float sai = a.kind ? a.sa[(int64_t)i * a.sa_stride] : 0.f;
+    const float c = BWD ? coef * gout[0] : 0.f;
+    float acc = 0.f;
+    for (int j = threadIdx.x; j < a.N; j += 256) {
+        const float gij = g[j];
+        const float d2 = a.kind ? fmaxf(sai + a.sb[(int64_t)j * a.sb_stride] - 2.f * gij, 0.f) : 0.f;
+        float dv;
+        const float v = mix_val(a, gij, d2, dv);
+        if (BWD) {
+            const float w = c * dv;
+            W[(int64_t)i * ldw + j] = w;
+            acc += w;
+        } else {
+            acc += v;
+        }
+    }
+    acc = dv_wave_sum_all(acc);
+    if (lane == 0) red[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) (BWD ? rs : part)[i] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// out[0] = m11 - 2 m12 + m22 (the MMD^2), out[1..3] = the three means; fixed summation order, one thread
+__global__ void mmd_mix_combine_kernel(const float* p11, int n11, float c11, const float* p12, int n12, float c12,
+                                       const float* p22, int n22, float c22, float* out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double s11 = 0., s12 = 0., s22 = 0.;
+    for (int i = 0; i < n11; ++i) s11 += p11[i];
+    for (int i = 0; i < n12; ++i) s12 += p12[i];
+    for (int i = 0; i < n22; ++i) s22 += p22[i];
+    const double m11 = s11 / c11, m12 = s12 / c12, m22 = s22 / c22;
+    out[0] = (float)(m11 - 2. * m12 + m22);
+    out[1] = (float)m11;
+    out[2] = (float)m12;
+    out[3] = (float)m22;
+}
+
+// identity kernel (src/blocks.py:37-38): out[0] = || mean(x1, 0) - mean(x2, 0) ||^2, diff[d] = the difference of the means
+__global__ __launch_bounds__(256) void mmd_identity_fwd_kernel(const float* __restrict__ x1, int64_t ld1, int n1,
+                                                               const float* __restrict__ x2, int64_t ld2, int n2, int Z,
+                                                               float* __restrict__ diff, float* __restrict__ out) {
+    __shared__ float red[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float acc = 0.f;
+    for (int d = threadIdx.x; d < Z; d += 256) {
+        float s1 = 0.f, s2 = 0.f;
+        for (int i = 0; i < n1; ++i) s1 += x1[(int64_t)i * ld1 + d];
+        for (int i = 0; i < n2; ++i) s2 += x2[(int64_t)i * ld2 + d];
+        const float df = s1 / (float)n1 - s2 / (float)n2;
+        diff[d] = df;
+        acc += df * df;
+    }
+    acc = dv_wave_sum_all(acc);
+    if (lane == 0) red[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// dx[i, d] = coef * gout[0] * diff[d]     (d ||diff||^2 / d x1[i, d] = 2 diff[d] / n1: coef = +-2 / n)
+__global__ void mmd_identity_bwd_kernel(const float* __restrict__ diff, const float* __restrict__ gout, float coef, int n,
+                                        int Z, float* __restrict__ dx, int64_t ldd) {
+    const int64_t total = (int64_t)n * Z;
+    const float c = coef * gout[0];
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x)
+        dx[(e / Z) * ldd + (e % Z)] = c * diff[e % Z];
+}
+
 // ------------------------------------------------------------------ evaluation tail (round 5)
 // What follows the big kernels of a whole-set evaluation (src/DGMMixin.py:128-190) used to be ~75 small library launches
 // per evaluation (two sorts, scans, gathers, float64 element-wise chains); as three launches:
@@ -2623,6 +2729,60 @@ extern "C" int dv_col_moments(const float* x, int64_t ldx, const float* r, int64
     const int rpb = (M + row_blocks - 1) / row_blocks;
     hipLaunchKernelGGL(col_moments_kernel, dim3((X + 63) / 64, row_blocks), dim3(256), 0, ST(stream), x, ldx, r, ldr, M, X, out,
                        rpb > 0 ? rpb : 1, sel);
+    DV_RETURN_LAUNCH();
+}
+
+static int mix_args(MixArgs& a, const float* G, int64_t ldg, int32_t M, int32_t N, int32_t kind, const float* gammas,
+                    int32_t nb, const float* sa, int64_t sa_stride, const float* sb, int64_t sb_stride) {
+    DV_REQUIRE(G && M >= 1 && N >= 1 && (kind == 0 || kind == 1) && gammas && nb >= 1 && nb <= 8);
+    DV_REQUIRE(kind == 0 || (sa && sb));
+    a = MixArgs{G, ldg, M, N, kind, nb, {0}, sa, sa_stride, sb, sb_stride};
+    for (int b = 0; b < nb; ++b) a.gam[b] = gammas[b];
+    return DV_OK;
+}
+
+extern "C" int dv_mmd_mix_fwd(const float* G, int64_t ldg, int32_t M, int32_t N, int32_t kind, const float* gammas,
+                              int32_t nb, const float* sa, int64_t sa_stride, const float* sb, int64_t sb_stride,
+                              float* part, dv_stream_t stream) {
+    MixArgs a;
+    const int rc = mix_args(a, G, ldg, M, N, kind, gammas, nb, sa, sa_stride, sb, sb_stride);
+    if (rc != DV_OK) return rc;
+    DV_REQUIRE(part != nullptr);
+    hipLaunchKernelGGL(mmd_mix_kernel<false>, dim3(M), dim3(256), 0, ST(stream), a, part, (const float*)nullptr, 0.f,
+                       (float*)nullptr, (int64_t)0, (float*)nullptr);
+    DV_RETURN_LAUNCH();
+}
+
+extern "C" int dv_mmd_mix_bwd(const float* G, int64_t ldg, int32_t M, int32_t N, int32_t kind, const float* gammas,
+                              int32_t nb, const float* sa, int64_t sa_stride, const float* sb, int64_t sb_stride,
+                              const float* gout, float coef, float* W, int64_t ldw, float* rs, dv_stream_t stream) {
+    MixArgs a;
+    const int rc = mix_args(a, G, ldg, M, N, kind, gammas, nb, sa, sa_stride, sb, sb_stride);
+    if (rc != DV_OK) return rc;
+    DV_REQUIRE(gout && W && rs);
+    hipLaunchKernelGGL(mmd_mix_kernel<true>, dim3(M), dim3(256), 0, ST(stream), a, (float*)nullptr, gout, coef, W, ldw, rs);
+    DV_RETURN_LAUNCH();
+}
+
+extern "C" int dv_mmd_mix_combine(const float* p11, int32_t n11, float c11, const float* p12, int32_t n12, float c12,
+                                  const float* p22, int32_t n22, float c22, float* out, dv_stream_t stream) {
+    DV_REQUIRE(p11 && p12 && p22 && out && n11 >= 1 && n12 >= 1 && n22 >= 1 && c11 > 0.f && c12 > 0.f && c22 > 0.f);
+    hipLaunchKernelGGL(mmd_mix_combine_kernel, dim3(1), dim3(64), 0, ST(stream), p11, n11, c11, p12, n12, c12, p22, n22, c22, out);
+    DV_RETURN_LAUNCH();
+}
+
+extern "C" int dv_mmd_identity_fwd(const float* x1, int64_t ld1, int32_t n1, const float* x2, int64_t ld2, int32_t n2,
+                                   int32_t Z, float* diff, float* out, dv_stream_t stream) {
+    DV_REQUIRE(x1 && x2 && diff && out && n1 >= 1 && n2 >= 1 && Z >= 1);
+    hipLaunchKernelGGL(mmd_identity_fwd_kernel, dim3(1), dim3(256), 0, ST(stream), x1, ld1, n1, x2, ld2, n2, Z, diff, out);
+    DV_RETURN_LAUNCH();
+}
+
+extern "C" int dv_mmd_identity_bwd(const float* diff, const float* gout, float coef, int32_t n, int32_t Z, float* dx,
+                                   int64_t ldd, dv_stream_t stream) {
+    DV_REQUIRE(diff && gout && dx && n >= 1 && Z >= 1);
+    hipLaunchKernelGGL(mmd_identity_bwd_kernel, dim3(grid_for((int64_t)n * Z, 256)), dim3(256), 0, ST(stream), diff, gout,
+                       coef, n, Z, dx, ldd);
     DV_RETURN_LAUNCH();
 }
 

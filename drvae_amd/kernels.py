@@ -614,6 +614,46 @@ def mmd_rff_bwd(G, th, diff, gout, coef):
                                           _stream()), 'dv_mmd_rff_bwd')
 
 
+MMD_KIND = {'poly': 0, 'rbf': 1}
+
+
+def _gammas(gammas):
+    arr = (C.c_float * len(gammas))(*[float(g) for g in gammas])
+    return arr, len(gammas)
+
+
+def mmd_mix_fwd(part, G, kind, gammas, sa=None, sb=None):
+    """part[i] = sum_j of the kernel mixture on the Gram matrix ``G`` (``dv_mmd_mix_fwd``); ``sa`` / ``sb``: the self
+    products whose diagonals are the squared row norms (rbf)"""
+    arr, nb = _gammas(gammas)
+    M, N = G.shape
+    _lib.check(_lib.load().dv_mmd_mix_fwd(_f32(G), _ld(G), M, N, MMD_KIND[kind], arr, nb, _f32(sa), (_ld(sa) + 1) if sa is not None else 0,
+                                          _f32(sb), (_ld(sb) + 1) if sb is not None else 0, _f32(part), _stream()), 'dv_mmd_mix_fwd')
+
+
+def mmd_mix_bwd(W, rs, G, kind, gammas, gout, coef, sa=None, sb=None):
+    arr, nb = _gammas(gammas)
+    M, N = G.shape
+    _lib.check(_lib.load().dv_mmd_mix_bwd(_f32(G), _ld(G), M, N, MMD_KIND[kind], arr, nb, _f32(sa), (_ld(sa) + 1) if sa is not None else 0,
+                                          _f32(sb), (_ld(sb) + 1) if sb is not None else 0, _f32(gout), coef, _f32(W), _ld(W),
+                                          _f32(rs), _stream()), 'dv_mmd_mix_bwd')
+
+
+def mmd_mix_combine(out4, p11, p12, p22, c11, c12, c22):
+    _lib.check(_lib.load().dv_mmd_mix_combine(_f32(p11), p11.numel(), c11, _f32(p12), p12.numel(), c12, _f32(p22), p22.numel(),
+                                              c22, _f32(out4), _stream()), 'dv_mmd_mix_combine')
+
+
+def mmd_identity_fwd(diff, out, x1, x2):
+    _lib.check(_lib.load().dv_mmd_identity_fwd(_f32(x1), _ld(x1), x1.shape[0], _f32(x2), _ld(x2), x2.shape[0], x1.shape[1],
+                                               _f32(diff), _f32(out), _stream()), 'dv_mmd_identity_fwd')
+
+
+def mmd_identity_bwd(dx, diff, gout, coef):
+    _lib.check(_lib.load().dv_mmd_identity_bwd(_f32(diff), _f32(gout), coef, dx.shape[0], dx.shape[1], _f32(dx), _ld(dx),
+                                               _stream()), 'dv_mmd_identity_bwd')
+
+
 def rows_gather(out, src, idx=None, *, noise=None, sigma=0.0, onehot_cls=None, n_classes=0, width=None, park=None):
     n = out.shape[0]
     W = (src.shape[1] if src is not None else 0) if width is None else width

@@ -62,6 +62,94 @@ class MMDRff(torch.autograd.Function):
         return grads[0], grads[1], None, None, None, None
 
 
+class MMDMix(torch.autograd.Function):
+    """MMD^2 of two row sets under a mixture of polynomial or RBF kernels -- ``mmd_objective(kernel='poly' | 'rbf')``
+    before its square root (src/blocks.py:59-76): the three Gram products on the MFMA GEMM, the element-wise mixture, its
+    means and its derivative on row kernels (``dv_mmd_mix_*``), the input gradients as GEMMs again."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, kind, gammas):
+        x1, x2 = x1.contiguous().float(), x2.contiguous().float()
+        dev, n1, n2 = x1.device, x1.shape[0], x2.shape[0]
+        G11, G22, G12 = torch.empty(n1, n1, device=dev), torch.empty(n2, n2, device=dev), torch.empty(n1, n2, device=dev)
+        K.gemm(G11, x1, x1, True, True)
+        K.gemm(G22, x2, x2, True, True)
+        K.gemm(G12, x1, x2, True, True)
+        p11, p12, p22 = torch.empty(n1, device=dev), torch.empty(n1, device=dev), torch.empty(n2, device=dev)
+        K.mmd_mix_fwd(p11, G11, kind, gammas, G11, G11)
+        K.mmd_mix_fwd(p22, G22, kind, gammas, G22, G22)
+        K.mmd_mix_fwd(p12, G12, kind, gammas, G11, G22)
+        out = torch.empty(4, device=dev)
+        K.mmd_mix_combine(out, p11, p12, p22, float(n1) * n1, float(n1) * n2, float(n2) * n2)
+        ctx.save_for_backward(x1, x2, G11, G22, G12)
+        ctx.kind, ctx.gammas = kind, tuple(float(g) for g in gammas)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        x1, x2, G11, G22, G12 = ctx.saved_tensors
+        kind, gammas = ctx.kind, ctx.gammas
+        dev, n1, n2, Z = x1.device, x1.shape[0], x2.shape[0], x1.shape[1]
+        g = g.reshape(1).contiguous().float()
+        W11, W22, W12 = torch.empty_like(G11), torch.empty_like(G22), torch.empty_like(G12)
+        r11, r22, r12 = torch.empty(n1, device=dev), torch.empty(n2, device=dev), torch.empty(n1, device=dev)
+        # d mmd^2 / d(m11, m12, m22) = (1, -2, 1); every mean is a sum over M x N elements.  The factors of the chain rule
+        # below ride on ``coef`` (W and its row sums come out scaled): no element-wise launches in between
+        #   poly: W = dL/dG, G = a b^T -> da = W b, db = W^T a; a self product is symmetric: da = 2 W a
+        #   rbf : W = dL/d(d2), d2_ij = |a_i|^2 + |b_j|^2 - 2 a_i.b_j -> da = 2 (rowsum(W) * a - W b),
+        #         db = 2 (colsum(W) * b - W^T a); a self product counts twice: da = 4 (rowsum(W) * a - W a)
+        f_self, f_cross = (2.0, 1.0) if kind == 'poly' else (4.0, 2.0)
+        K.mmd_mix_bwd(W11, r11, G11, kind, gammas, g, f_self / (n1 * n1), G11, G11)
+        K.mmd_mix_bwd(W22, r22, G22, kind, gammas, g, f_self / (n2 * n2), G22, G22)
+        K.mmd_mix_bwd(W12, r12, G12, kind, gammas, g, f_cross * -2.0 / (n1 * n2), G11, G22)
+        dx1 = torch.empty(n1, Z, device=dev) if ctx.needs_input_grad[0] else None
+        dx2 = torch.empty(n2, Z, device=dev) if ctx.needs_input_grad[1] else None
+        sgn = 1.0 if kind == 'poly' else -1.0
+        if dx1 is not None:
+            K.gemm(dx1, W11, x1, True, False, alpha=sgn)
+            K.gemm(dx1, W12, x2, True, False, alpha=sgn, beta=1.0)
+        if dx2 is not None:
+            K.gemm(dx2, W22, x2, True, False, alpha=sgn)
+            K.gemm(dx2, W12, x1, False, False, alpha=sgn, beta=1.0)
+        if kind == 'rbf':
+            if dx1 is not None:
+                K.rows_segment_sum(dx1, x1, w=r11, n=n1, beta=1.0)
+                K.rows_segment_sum(dx1, x1, w=r12, n=n1, beta=1.0)
+            if dx2 is not None:
+                c12 = torch.empty(n2, device=dev)
+                K.colsum(c12, W12)
+                K.rows_segment_sum(dx2, x2, w=r22, n=n2, beta=1.0)
+                K.rows_segment_sum(dx2, x2, w=c12, n=n2, beta=1.0)
+        return dx1, dx2, None, None
+
+
+class MMDIdentity(torch.autograd.Function):
+    """|| mean(x1, 0) - mean(x2, 0) ||^2 -- the ``identity`` kernel (src/blocks.py:37-38) on one HIP launch each way"""
+
+    @staticmethod
+    def forward(ctx, x1, x2):
+        x1, x2 = x1.contiguous().float(), x2.contiguous().float()
+        diff, out = torch.empty(x1.shape[1], device=x1.device), torch.empty(1, device=x1.device)
+        K.mmd_identity_fwd(diff, out, x1, x2)
+        ctx.save_for_backward(diff)
+        ctx.n = (x1.shape[0], x2.shape[0])
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        diff, = ctx.saved_tensors
+        g = g.reshape(1).contiguous().float()
+        outs = []
+        for n, sign, need in ((ctx.n[0], 1.0, ctx.needs_input_grad[0]), (ctx.n[1], -1.0, ctx.needs_input_grad[1])):
+            if not need:
+                outs.append(None)
+                continue
+            dx = torch.empty(n, diff.numel(), device=diff.device)
+            K.mmd_identity_bwd(dx, diff, g, sign * 2.0 / n)
+            outs.append(dx)
+        return outs[0], outs[1]
+
+
 class _LinearAct(torch.autograd.Function):
     """y = act(scale * ([x1|x2] W^T) + b) + shift, scale = g/||W|| when g is given.
     Replaces F.linear / nn.Linear + activation module (src/blocks.py:139-151,163) and

@@ -687,6 +687,26 @@ int dv_col_moments(const float* x, int64_t ldx, const float* r, int64_t ldr, int
                    int32_t row_blocks, const int32_t* sel, dv_stream_t stream);
 /* `sel` (optional, ABI 11): the M rows that count, as indices into x / r (e.g. the rows with a second profile) */
 
+/* Kernel-mixture MMD of `mmd_objective(kernel='poly' | 'rbf')` and the `identity` kernel (src/blocks.py:29-38,59-76; round
+ * 5).  The three Gram products x1 x1^T, x2 x2^T, x1 x2^T are dv_gemm calls; on a Gram matrix G (M x N):
+ *   dv_mmd_mix_fwd : part[i] = sum_j k_ij, k = 1/nb sum_b f(., gammas[b]) (HOST array, nb <= 8)
+ *                    kind 0 poly: f = (gamma G_ij + 1)^2;  kind 1 rbf: f = exp(-gamma d2_ij), d2_ij = sa[i sa_stride] +
+ *                    sb[j sb_stride] - 2 G_ij (the squared row norms: the diagonals of the self products)
+ *   dv_mmd_mix_bwd : W[i, j] = coef * gout[0] * dk_ij / d(G_ij | d2_ij),  rs[i] = sum_j W[i, j]
+ *   dv_mmd_mix_combine: out[0] = m11 - 2 m12 + m22 (MMD^2; m = sum(p) / c), out[1..3] = the means
+ *   dv_mmd_identity_fwd: diff[d] = mean_i x1[i, d] - mean_i x2[i, d], out[0] = sum_d diff^2;  _bwd: dx[i, d] = coef gout[0] diff[d] */
+int dv_mmd_mix_fwd(const float* G, int64_t ldg, int32_t M, int32_t N, int32_t kind, const float* gammas, int32_t nb,
+                   const float* sa, int64_t sa_stride, const float* sb, int64_t sb_stride, float* part, dv_stream_t stream);
+int dv_mmd_mix_bwd(const float* G, int64_t ldg, int32_t M, int32_t N, int32_t kind, const float* gammas, int32_t nb,
+                   const float* sa, int64_t sa_stride, const float* sb, int64_t sb_stride, const float* gout, float coef,
+                   float* W, int64_t ldw, float* rs, dv_stream_t stream);
+int dv_mmd_mix_combine(const float* p11, int32_t n11, float c11, const float* p12, int32_t n12, float c12, const float* p22,
+                       int32_t n22, float c22, float* out, dv_stream_t stream);
+int dv_mmd_identity_fwd(const float* x1, int64_t ld1, int32_t n1, const float* x2, int64_t ld2, int32_t n2, int32_t Z,
+                        float* diff, float* out, dv_stream_t stream);
+int dv_mmd_identity_bwd(const float* diff, const float* gout, float coef, int32_t n, int32_t Z, float* dx, int64_t ldd,
+                        dv_stream_t stream);
+
 /* The tail of a whole-set evaluation (round 5) in three launches instead of ~75 small library ones:
  * dv_recon_finalize: out[0..3] = rmse, variance-weighted R^2, mean per-row Pearson r, mean log-likelihood (float64) from
  *   dv_recon_row_stats' rows (M_all x 6; `sel`: the n rows that count, NULL = rows 0..n-1), dv_col_moments' partials over

@@ -371,3 +371,46 @@ def test_masked_linear_on_the_hip_gemm(mods, dev, tag):
         close(lay.bias.grad, dy.cpu().sum(0).numpy())
         assert list(lay.state_dict()) == ['weight', 'bias']          # mask / m are attributes, not state (reference)
         m_pre = lay.get_m()
+
+
+def _mmd_objective_host(x1, x2, kernel, bandwidths):
+    """the reference's mixture (src/blocks.py:59-76) on the host in float64, with the Gram form of rbf's evident intent"""
+    import math as _m
+    x1, x2 = x1.double(), x2.double()
+    if kernel == 'identity':
+        return torch.sqrt(((x1.mean(0) - x2.mean(0)) ** 2).sum())
+
+    def k(a, b, gam):
+        if kernel == 'poly':
+            return (gam * a @ b.t() + 1.0) ** 2
+        d2 = ((a[:, None, :] - b[None, :, :]) ** 2).sum(2)
+        return torch.exp(-gam * d2)
+    tot = 0.0
+    for bw in bandwidths:
+        gam = _m.sqrt(x1.shape[1]) * float(bw)
+        tot = tot + (k(x1, x1, gam).mean() - 2 * k(x1, x2, gam).mean() + k(x2, x2, gam).mean()) / len(bandwidths)
+    return torch.sqrt(tot)
+
+
+@pytest.mark.parametrize('kernel', ['poly', 'rbf', 'identity'])
+@pytest.mark.parametrize('n1,n2,Z', [(75, 75, 100), (37, 52, 13), (1, 9, 5)])
+def test_mmd_objective_mixture_kernels_on_hip(mods, dev, kernel, n1, n2, Z):
+    """a5 leftovers (round 5): ``mmd_objective(kernel='poly' | 'rbf' | 'identity')`` -- the bandwidth mixture, its means and
+    its derivative on HIP row kernels around the MFMA Gram products (``ops.MMDMix`` / ``ops.MMDIdentity``): value and both
+    input gradients against the host float64 formulas (``poly`` / ``identity`` are also pinned to the reference's own
+    values by the G7 goldens; ``rbf`` is the Gram form of what src/blocks.py:29-32 evidently intends)"""
+    blk, _ = mods
+    g = torch.Generator().manual_seed(n1 * 100 + n2)
+    x1 = (torch.randn(n1, Z, generator=g) * 0.3)
+    x2 = (torch.randn(n2, Z, generator=g) * 0.3 + 0.2)
+    bws = 1. / (2 * (np.array([1., 2., 5., 8., 10]) ** 2))
+    a, b = x1.clone().requires_grad_(True), x2.clone().requires_grad_(True)
+    ref = _mmd_objective_host(a, b, kernel, bws)
+    ref.backward()
+    c, d = x1.to(dev).requires_grad_(True), x2.to(dev).requires_grad_(True)
+    got = blk.mmd_objective(c, d, kernel=kernel, bandwidths=bws)
+    got.backward()
+    close(got, float(ref), rtol=2e-4, atol=1e-6)
+    sc = float(a.grad.abs().max()) + 1e-12
+    close(c.grad, a.grad.float().numpy(), rtol=2e-3, atol=2e-4 * sc)
+    close(d.grad, b.grad.float().numpy(), rtol=2e-3, atol=2e-4 * float(b.grad.abs().max() + 1e-12))
