@@ -20,7 +20,7 @@ def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, h) for h in ('dv_common.h', 'gemm_common.inc', 'gemm_pipe.inc', 'gemm_skinny.inc')] + [
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, h) for h in ('dv_common.h', 'gemm_common.inc', 'gemm_pipe.inc')] + [
         os.path.join(os.path.dirname(HERE), 'include', 'drvae_hip.h')]
     return any(os.path.getmtime(d) > t for d in deps)
 

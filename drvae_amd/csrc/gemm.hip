@@ -1071,8 +1071,6 @@ static int colsum_setup(dv_gemm_desc& g, int tiling, hipStream_t st) {
     return DV_OK;
 }
 
-#include "gemm_skinny.inc"
-
 static int gemm_launch(const dv_gemm_desc& g_in, const LoadCfg& lc, int tiling, hipStream_t st) {
     if (tiling < 0) return DV_OK;
     dv_gemm_desc g = g_in;
@@ -1080,7 +1078,6 @@ static int gemm_launch(const dv_gemm_desc& g_in, const LoadCfg& lc, int tiling, 
         const int rc = colsum_setup(g, tiling, st);
         if (rc != DV_OK) return rc;
     }
-    if (skinny_ok(g, lc)) return launch_skinny(g, st);      // short K, many rows: rows resident in registers, no K loop
     if (tiling == 3) return launch_cfg<128, 128, 32, 2, 2, 1>(g, lc, st);
     if (tiling >= 40 && tiling < 50 && !pipe_ok(g, lc)) return launch_cfg<128, 128, 32, 2, 2, 1>(g, lc, st);
     if (tiling == 40) return launch_pipe<128, 256, 16, 2, 2, 3, 2>(g, lc, st);

@@ -1436,34 +1436,3 @@ def test_gemm_ragged_split_carries_the_fused_epilogues(K, dev):
     K.linear_bwd_data(dx, dpre, Wt, yref=y, act='elu', beta=1.0)
     R.linear_bwd_data(rx, dpre, Wt, yref=y, act='elu', beta=1.0)
     close(dx, rx, **gemm_tol(Kd))
-
-
-@pytest.mark.parametrize('M,N,Kd', [(4096 + 13, 600, 100), (5000, 200, 102), (8192, 70, 200), (4100, 33, 256), (4096, 2048, 200),
-                                   (6144, 200, 8), (4099, 601, 128)])
-def test_gemm_short_k_many_rows(K, dev, M, N, Kd):
-    """round 5, ``gemm_skinny_kernel``: forward-layout products with K <= 256 and thousands of rows (the hidden layers and
-    heads of a whole-set evaluation) -- a workgroup owns 64 rows for the whole product, the rows' operand fragment lives in
-    registers, no K loop -- with every fused forward epilogue, against the host reference and against the K-split tiling
-    (``dv_gemm_tune.opt[5] = -1``)"""
-    x = strided(dev, M, Kd, (4 - Kd % 4) % 4, seed=1)
-    W = strided(dev, N, Kd, (4 - Kd % 4) % 4, seed=2)
-    if Kd % 4:
-        x._base[:, Kd:] = 0
-        W._base[:, Kd:] = 0
-    W.mul_(Kd ** -0.5)
-    b, sc, res = rnd(dev, N, seed=3), rnd(dev, N, seed=4).abs() + 0.5, rnd(dev, M, N, seed=5)
-    for kw in (dict(), dict(bias=b, act0='elu', act1='elu'),
-               dict(bias=b, scale=sc, split=N // 2, act0='identity', act1='softplus', shift1=1e-3),
-               dict(bias=b, split=N // 2, act0='identity', act1='identity', shift1=-2.0, resid=res, resid_cols=N // 2)):
-        out, ref = torch.full((M, N + 3), 7.0, device=dev)[:, :N], torch.zeros(M, N, device=dev)
-        K.linear_fwd(out, x, W, overread=True, kpad=True, **kw)
-        R.linear_fwd(ref, x, W, **kw)
-        close(out, ref, **gemm_tol(Kd))
-        assert bool((out._base[:, N:] == 7.0).all())
-        K.gemm_set_option(5, -1)
-        try:
-            old = torch.zeros(M, N, device=dev)
-            K.linear_fwd(old, x, W, overread=True, kpad=True, **kw)
-        finally:
-            K.gemm_set_option(5, 0)
-        close(out, old, rtol=1e-4, atol=1e-5 * max(1.0, Kd ** 0.5))

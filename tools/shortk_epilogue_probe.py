@@ -13,7 +13,7 @@ for (M, N, Kd) in [(32768, 600, 100), (32768, 608, 104), (32768, 640, 96), (2457
     bias = torch.randn(N, device='cuda')
     row = '%-20s' % ('%dx%dx%d' % (M, N, Kd))
     for opt in (0, -1):
-        K.gemm_set_option(5, opt)
+        K.gemm_set_option(5, opt)      # (lab: -1 switched the skinny kernel of tools/lab/gemm_skinny.inc off)
         us = time_call(lambda: K.gemm(C, A, B, True, True, overread=True, kpad=True), repeats=10)
         row += ' %s plain %6.1f |' % ('sk' if opt == 0 else 'ks', us)
         us = time_call(lambda: K.linear_fwd(C, A, B, bias, act0='elu', act1='elu', overread=True, kpad=True), repeats=10)
