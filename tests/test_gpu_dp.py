@@ -229,7 +229,9 @@ def _fit_epochs(model, ds, w, bs, buckets, n_epochs=2):
     """``fit``'s training half: ``_epoch_device`` per epoch (bind with the model's dp state, epoch table, captured
     graphs, replays); returns per-epoch mean objectives and the tables this rank ran"""
     from drvae_amd import data as D
-    bat = D.DeviceBatcher(ds, w, bs, seed=11, mode='sampler', **buckets)
+    buckets = dict(buckets)
+    mode = buckets.pop('mode', 'sampler')
+    bat = D.DeviceBatcher(ds, w, bs, seed=11, mode=mode, **buckets)
     model.add_noise = True
     means, tabs = [], []
     for ep in range(n_epochs):
@@ -250,12 +252,32 @@ def _fit_worker(rank, world, port, kind, buckets, backend, q):
         model, ds, w = _fit_case(kind, dev)
         assert model.enable_data_parallel() == (rank, world)
         assert model._allreduce is not None and model._dp == (rank, world)
+        if buckets.get('loader'):
+            # tuple loaders: ``fit`` -> ``_epoch_loader`` -> one batch-independent captured step, the three global counts
+            # of every batch from a host all-reduce (``run_on_batch`` under data parallelism)
+            from tests.test_dp_gloo import _shard_loader
+            from tests.test_fit import _tiny_dataset, _tiny_model
+            model = _tiny_model(kind, device=dev, epochs=2)
+            assert model.enable_data_parallel() == (rank, world)
+            model.w2log = lambda *a: None
+            tr, va = _tiny_dataset(kind, 64, 1, 'cuda'), _tiny_dataset(kind, 24, 2, 'cuda')
+            model.fit(_shard_loader(tr, 16 // world, rank, world), _shard_loader(va, 8, 0, 1), add_noise=True, early_stop=False,
+                      model_filename='/tmp/dp_fit_%d.pth' % os.getpid())
+            eng = model.engine()
+            torch.cuda.synchronize()
+            assert eng.universal and eng._graphs and len(eng._graphs) == 2
+            q.put((rank, dict(param=eng.arena.param.cpu().numpy(), iters=model.finished_training_iters)))
+            dist.barrier()
+            dist.destroy_process_group()
+            return
         means, tabs, bat = _fit_epochs(model, ds, w, 32 // world, buckets)
         eng = model.engine()
         torch.cuda.synchronize()
         eng.check_sync()
         assert len(eng._graphs) == 2                     # split graphs around the exchange
         perf, _ = model.evaluate_performance_on_dataset(ds)
+        if getattr(bat, 'global_table', None) is None:
+            bat.global_table = torch.zeros(1, 1)
         q.put((rank, dict(means=means, tabs=tabs, gtab=bat.global_table.cpu().numpy(), param=eng.arena.param.cpu().numpy(),
                           iters=model.finished_training_iters, x1_pearr=perf['x1_pearr'],
                           elbo=float(perf['losses']['ELBO']))))
@@ -357,5 +379,57 @@ def test_fit_epochs_over_rccl_single_rank(dev):
     (r0,) = _run_fit_ranks(1, kind, {}, backend='nccl')
     np.testing.assert_array_equal(r0['tabs'][1], tabs[1])
     np.testing.assert_allclose(r0['means'], means, rtol=1e-4)
+    err = np.linalg.norm(r0['param'] - single) / np.linalg.norm(single)
+    assert err < 1e-4, err
+
+
+def test_fit_on_tuple_loaders_two_ranks_equal_one_rank(dev):
+    """``fit`` fed by per-rank tuple loaders under ``enable_data_parallel`` on the GPU: every batch goes through ONE
+    batch-independent captured step (split graphs around the exchange); its normalisers are the global batch's -- N_total
+    = the plan's, (N_pairs, N_labeled) handed over per batch (``set_batch(counts=...)`` -> ``dv_batch_masks_desc.gcounts``)
+    -- and the job trains like one process on the concatenated batches"""
+    from tests.test_dp_gloo import _shard_loader
+    from tests.test_fit import _tiny_dataset, _tiny_model
+    kind = 'drvae'
+    model = _tiny_model(kind, device=dev, epochs=2)
+    model.w2log = lambda *a: None
+    tr, va = _tiny_dataset(kind, 64, 1, 'cuda'), _tiny_dataset(kind, 24, 2, 'cuda')
+    model.fit(_shard_loader(tr, 16, 0, 1), _shard_loader(va, 8, 0, 1), add_noise=True, early_stop=False,
+              model_filename='/tmp/dp_fit_single_%d.pth' % os.getpid())
+    torch.cuda.synchronize()
+    single = model.engine().arena.param.cpu().numpy()
+    r0, r1 = _run_fit_ranks(2, kind, dict(loader=True))
+    assert r0['iters'] == r1['iters'] == model.finished_training_iters == 2 * 4
+    np.testing.assert_array_equal(r0['param'], r1['param'])
+    err = np.linalg.norm(r0['param'] - single) / np.linalg.norm(single)
+    assert err < 1e-4, err
+
+
+def test_fit_epochs_stratified_feed_two_ranks(dev):
+    """the stratified device feed under data parallelism: every rank's batch has the same composition, the normalisers are
+    world x the local counts, the ranks draw ``world x c`` rows per group from the shared generator and take their share --
+    replicas bit-identical, and one process given the ranks' batches side by side (explicit 32-row batches, Philox draws
+    keyed by global row) trains the same"""
+    from tests.test_engine_cpu import make_engine
+    kind = 'drvae'
+    r0, r1 = _run_fit_ranks(2, kind, dict(mode='stratified'))
+    np.testing.assert_array_equal(r0['param'], r1['param'])
+    assert np.all(np.isfinite(r0['means'])) and r0['means'] == r1['means']
+    assert not np.array_equal(r0['tabs'][1], r1['tabs'][1])                   # different rows on the two ranks
+    model, ds, w = _fit_case(kind, dev)
+    model.add_noise = True
+    eng = model.engine()
+    eng.add_noise = True
+    t = lambda a: a
+    for ep in range(2):
+        tab = np.concatenate([r0['tabs'][ep], r1['tabs'][ep]], 1)           # (batches, 32): rank 0's rows | rank 1's
+        for b in range(tab.shape[0]):
+            idx = torch.from_numpy(tab[b]).long().to(dev)
+            eng.iters = model.finished_training_iters
+            eng.set_batch(ds.x1[idx], ds.x2[idx], ds.y[idx].cpu().numpy(), ds.has_x2[idx].cpu().numpy(), ds.has_y[idx].cpu().numpy())
+            eng.train_step()
+            model.finished_training_iters = eng.iters
+    torch.cuda.synchronize()
+    single = eng.arena.param.cpu().numpy()
     err = np.linalg.norm(r0['param'] - single) / np.linalg.norm(single)
     assert err < 1e-4, err
