@@ -214,8 +214,14 @@ class DeviceBatcher:
         columns [rank B, (rank + 1) B) of it.  The loss normalisers are the global batch's: N_total = world B, and
         N_pairs / N_labeled of every batch are counted over the global table (``gcounts``, read by the feed launch) --
         no communication.  The Philox draws are keyed by the row's position in the global batch (``engine.row0``)."""
+        dp = None if dp is None else (int(dp[0]), int(dp[1]))
+        sig = (id(engine), dp, counts, self.pair_bucket, self.label_bucket)
+        if getattr(self, '_bound', None) == sig and engine.plan is getattr(self, '_bound_plan', None) and not self.bucketed:
+            if dp is not None:
+                engine.row0 = dp[0] * self.batch_size
+            return engine.plan          # (every epoch of ``fit`` binds: nothing to rebuild)
         self.engine = engine
-        self.dp = None if dp is None else (int(dp[0]), int(dp[1]))
+        self.dp = dp
         assert self.dp is None or 0 <= self.dp[0] < self.dp[1]
         if self.dp is not None:
             assert not engine.cfg.use_MMD, 'use_MMD: the MMD penalty is a cross-row term, it cannot be sharded over ranks'
@@ -231,13 +237,15 @@ class DeviceBatcher:
                 self.pair_bucket = None                      # (no pairs in this model: nothing to bucket)
             if self.label_bucket and not engine.cfg.has_y:
                 self.label_bucket = None
-            return engine.set_structure_universal(self.batch_size, n_tot=self._n_tot())
+            self._bound, self._bound_plan = sig, engine.set_structure_universal(self.batch_size, n_tot=self._n_tot())
+            return self._bound_plan
         if counts is None and self.dp is not None:      # every rank's batch has the same composition
             cfg = engine.cfg
             n_lab = int(self.has_y.sum()) if cfg.has_y else 0
             n_tot = n_lab if (cfg.kind == 'vfae' and not cfg.semi_supervised) else self.batch_size
             counts = tuple(self.world * c for c in (n_tot, int(self.has_x2.sum()) if cfg.has_pert else 0, n_lab))
         engine.set_structure(self.has_x2, self.has_y, counts)
+        self._bound, self._bound_plan = sig, engine.plan
         return engine.plan
 
     def begin_epoch(self, n_batches=None, table=None):
@@ -276,6 +284,8 @@ class DeviceBatcher:
             if table is not None:
                 draws = torch.as_tensor(table).to(fd.table.device)
                 assert tuple(draws.shape) == (n_b, self.global_batch)
+            elif self._take_ahead(n_b) is not None:
+                draws = self._ahead_draws
             elif self.cpu_stream:
                 rows = []
                 while sum(len(r) for r in rows) < n_b:
@@ -307,6 +317,8 @@ class DeviceBatcher:
             return fd.table
         if table is not None:
             tab = torch.as_tensor(table).to(fd.table.device).reshape(n_b, self.world, self.batch_size)[:, self.rank]
+        elif self._take_ahead(n_b) is not None:
+            tab = self._ahead_draws
         else:
             # (data parallelism: world x c draws per group and batch from the shared generator; this rank's c of them)
             R, r = self.world, self.rank
@@ -316,6 +328,31 @@ class DeviceBatcher:
         fd.table.copy_(tab)
         fd.base.copy_(eng.step_dev)         # device to device: batch index = optimiser step - base
         return fd.table
+
+    def draw_ahead(self, n_batches=None):
+        """Draw the NEXT epoch's index table now (``fit`` calls this once the current epoch's replays are enqueued): the
+        dozen small launches of the draw then queue behind the running steps instead of standing between two epochs with
+        the GPU idle (0.21 -> 0.03 ms per epoch at cfg 2).  The batcher's generator is consumed in the same order as
+        without it -- the tables are the same.  Not with ``generator='cpu'``: that stream is torch's DEFAULT generator,
+        whose order against the caller's other draws is the reference's."""
+        if self.cpu_stream or self.engine.cfg.use_s:
+            return
+        n_b = len(self) if n_batches is None else n_batches
+        if self.mode == 'sampler':
+            d = torch.multinomial(self.weights, n_b * self.global_batch, replacement=True, generator=self.gen)
+        else:
+            R, r = self.world, self.rank
+            d = torch.cat([m[torch.multinomial(w, c * R * n_b, replacement=True, generator=self.gen)].reshape(n_b, R, c)[:, r]
+                           for m, w, c in zip(self.members, self.gweights, self.group_counts) if c > 0], 1)
+        self._ahead = (n_b, self.mode, self.dp, d)
+
+    def _take_ahead(self, n_b):
+        """the table drawn ahead for this epoch, if there is one for this number of batches / mode / dp state"""
+        a, self._ahead = getattr(self, '_ahead', None), None
+        self._ahead_draws = None
+        if a is not None and a[:3] == (n_b, self.mode, self.dp):
+            self._ahead_draws = a[3]
+        return self._ahead_draws
 
     def rebase(self):
         """the current epoch table again from its first batch: batch index = optimiser step - base (after replays that

@@ -280,6 +280,8 @@ class FitMixin:
             if verbose and b % every == 0:
                 self._log_losses(epoch, b * batcher.batch_size, len(batcher.dataset), b / n_b, self._loss_tensors(eng))
         self.finished_training_iters = eng.iters
+        if eng.plan.live_feed is not None and epoch < self.epochs:
+            batcher.draw_ahead()           # (the next epoch's table: queued behind the running steps)
         if in_graph:
             if side is not None:
                 torch.cuda.current_stream().wait_stream(side)
