@@ -332,25 +332,42 @@ class DeviceBatcher:
     def draw_ahead(self, n_batches=None):
         """Draw the NEXT epoch's index table now (``fit`` calls this once the current epoch's replays are enqueued): the
         dozen small launches of the draw then queue behind the running steps instead of standing between two epochs with
-        the GPU idle (0.21 -> 0.03 ms per epoch at cfg 2).  The batcher's generator is consumed in the same order as
+        the GPU idle.  The batcher's generator is consumed in the same order as
         without it -- the tables are the same.  Not with ``generator='cpu'``: that stream is torch's DEFAULT generator,
         whose order against the caller's other draws is the reference's."""
         if self.cpu_stream or self.engine.cfg.use_s:
             return
         n_b = len(self) if n_batches is None else n_batches
-        if self.mode == 'sampler':
-            d = torch.multinomial(self.weights, n_b * self.global_batch, replacement=True, generator=self.gen)
+        dev = self.ds.x1.device
+        ev = None
+        if dev.type == 'cuda':
+            # on a stream of its own: the draw's small launches run NEXT TO the epoch's steps, not behind them
+            if getattr(self, '_draw_stream', None) is None:
+                self._draw_stream = torch.cuda.Stream(device=dev)
+            ctx = torch.cuda.stream(self._draw_stream)
         else:
-            R, r = self.world, self.rank
-            d = torch.cat([m[torch.multinomial(w, c * R * n_b, replacement=True, generator=self.gen)].reshape(n_b, R, c)[:, r]
-                           for m, w, c in zip(self.members, self.gweights, self.group_counts) if c > 0], 1)
-        self._ahead = (n_b, self.mode, self.dp, d)
+            import contextlib
+            ctx = contextlib.nullcontext()
+        with ctx:
+            if self.mode == 'sampler':
+                d = torch.multinomial(self.weights, n_b * self.global_batch, replacement=True, generator=self.gen)
+            else:
+                R, r = self.world, self.rank
+                d = torch.cat([m[torch.multinomial(w, c * R * n_b, replacement=True, generator=self.gen)].reshape(n_b, R, c)[:, r]
+                               for m, w, c in zip(self.members, self.gweights, self.group_counts) if c > 0], 1)
+            if dev.type == 'cuda':
+                ev = torch.cuda.Event()
+                ev.record()
+        self._ahead = (n_b, self.mode, self.dp, d, ev)
 
     def _take_ahead(self, n_b):
         """the table drawn ahead for this epoch, if there is one for this number of batches / mode / dp state"""
         a, self._ahead = getattr(self, '_ahead', None), None
         self._ahead_draws = None
         if a is not None and a[:3] == (n_b, self.mode, self.dp):
+            if a[4] is not None:
+                torch.cuda.current_stream().wait_event(a[4])       # (drawn on the batcher's own stream)
+                a[3].record_stream(torch.cuda.current_stream())
             self._ahead_draws = a[3]
         return self._ahead_draws
 
