@@ -339,7 +339,7 @@ def fit_epoch(device, n_train=8192, n_valid=2048, batch=150, epochs=3):
     from tools.eval_bench import dataset, eval_gflop
     model = DrVAE(dim_x=978, dim_s=1, dim_y=2, dim_h_en_z1=[800], dim_h_de_z1=[200], dim_h_en_z3=[200], dim_h_de_x=[600],
                   dim_h_clf=[], dim_z1=100, dim_z3=100, type_rec='diag_gaussian', nonlinearity='elu', learning_rate=5e-4, L=2,
-                  weight_decay=0.05, add_noise_var=0.01, pertloss_rate=0.05, use_MMD=False, random_seed=123, epochs=1,
+                  weight_decay=0.05, add_noise_var=0.01, pertloss_rate=0.05, use_MMD=False, random_seed=123, epochs=epochs + 1,
                   batch_size=batch).to(device)
     model.w2log = lambda *a: None
     model.add_noise = True
@@ -349,7 +349,7 @@ def fit_epoch(device, n_train=8192, n_valid=2048, batch=150, epochs=3):
     for ep in range(epochs):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        model._epoch_device(bat, ep, False)
+        model._epoch_device(bat, ep + 1, False)        # (epoch numbers as ``fit`` passes them: 1 .. epochs)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         ptr, _ = model.evaluate_performance_on_dataset(tr)

@@ -33,7 +33,7 @@ print('epochs %d, %d steps/epoch, total %.2f s -> %.1f ms/epoch' % (model.epochs
 eng = model.engine()
 for rep in range(2):
     torch.cuda.synchronize(); t0 = time.time()
-    model._epoch_device(bat, 99, False); torch.cuda.synchronize(); t1 = time.time()
+    model._epoch_device(bat, 1, False); torch.cuda.synchronize(); t1 = time.time()
     model.evaluate_performance_on_dataset(tr); torch.cuda.synchronize(); t2 = time.time()
     model.evaluate_performance_on_dataset(va); torch.cuda.synchronize(); t3 = time.time()
 print('steady-state epoch: train part %.1f ms (%d steps, %.3f ms/step) | eval train set %.1f ms | eval valid set %.1f ms '
