@@ -108,6 +108,23 @@ def test_argument_validation_without_gpu(lib):
     assert lib.dv_gemm(None, None) == -1
     assert lib.dv_counter_add(None, 3, 1, None) == -1
     assert lib.dv_softmax_clamp_fwd(None, 0, 5, 0, 0, None, 0, None) == -1   # Y < 1
+    # the descriptor entry points of ABI 11: a missing descriptor, and descriptors whose required fields are missing
+    import ctypes as C
+    from drvae_amd import _lib
+    assert lib.dv_batch_feed(None, None, None, None) == -1
+    assert lib.dv_kl_rows_fwd(None, None, None) == -1
+    assert lib.dv_batch_masks(None, None, 0, None, None, 4, 2, None) == -1
+    assert lib.dv_gauss_nll_rows_raw_cs(None, None) == -1
+    d = _lib.BatchFeed(B=4, L=1, n_batches=1, X=8)                # B > 0 but no x1 / table / counters
+    assert lib.dv_batch_feed(C.byref(d), None, None, None) == -1
+    k = _lib.KlRows(n=3, reps=1, Z=5)                              # rows to do, no operands
+    assert lib.dv_kl_rows_fwd(C.byref(k), None, None) == -1
+    m = _lib.BatchMasks(Np=9, n_tot=4.0)                           # more pair slots than rows
+    assert lib.dv_batch_masks(C.byref(m), None, 0, None, None, 4, 2, None) == -1
+    assert lib.dv_loss_assemble_after(None, None, 0, None, None, None, None, None, 0, None, None) == -1
+    assert lib.dv_rank_metrics(None, 0, None, None, None, 5, 0, 1, 1, None, None, None) == -1
+    assert lib.dv_recon_finalize(None, None, 5, 8, None, 1, None, None, None) == -1
+    assert lib.dv_mmd_mix_fwd(None, 0, 3, 3, 0, None, 5, None, 0, None, 0, None, None) == -1
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
