@@ -93,6 +93,18 @@ class KlRows(C.Structure):       # dv_kl_rows_desc
                 ('zout', _p), ('ldz', _i64), ('mu2', _p), ('sd2', _p), ('ld2', _i64), ('Z2', _i32), ('raw2_out', _p)]
 
 
+class KlRowsGrad(C.Structure):   # dv_kl_rows_grad
+    _fields_ = [('coef', _p), ('dq_mu', _p), ('dq_sd', _p), ('lddq', _i64), ('dp_mu', _p), ('dp_sd', _p), ('lddp', _i64),
+                ('beta', _f), ('dz', _p), ('ldz', _i64)]
+
+
+class Z2F(C.Structure):          # dv_z2f_desc
+    _fields_ = [('dz2f', _p), ('ld_dz2f', _i64), ('dzdec_pert', _p), ('ld_pert', _i64), ('pair_slot', _p), ('eps', _p),
+                ('lde', _i64), ('p2', _p), ('ldp2', _i64), ('q2', _p), ('ldq2', _i64), ('coef', _p), ('raw', _p),
+                ('kl_min', _f), ('dz1b', _p), ('ld_dz1b', _i64), ('dp2', _p), ('ld_dp2', _i64), ('dz1', _p),
+                ('ld_dz1', _i64), ('dq2', _p), ('ld_dq2', _i64), ('L', _i32), ('B', _i32), ('Np', _i32), ('Z', _i32)]
+
+
 class NllRawCs(C.Structure):     # dv_nll_raw_cs_desc
     _fields_ = [('coef', _p), ('x', _p), ('ldx', _i64), ('xidx', _p), ('mu', _p), ('sd', _p), ('ldp', _i64), ('M', _i32),
                 ('X', _i32), ('shift', _f), ('out_part', _p), ('chunks', _i32), ('dmu', _p), ('dsd', _p), ('ldd', _i64),
@@ -123,12 +135,10 @@ SIGNATURES = {
                        _p],
     'dv_reparam_bwd_seg': [_p, _i64, _p, _i64, _p, _i64, _p, _p, _i32, _i32, _i32, _p, _i64, _p, _p, _p, _p, _i64, _f,
                            C.POINTER(Bump), C.POINTER(SegAdd), C.POINTER(Wait), _p],
-    'dv_z2f_post_bwd': [_p, _i64, _p, _i64, _p, _p, _i64, _p, _i64, _p, _i64, _p, _p, _f, _p, _i64, _p, _i64, _p, _i64,
-                        _p, _i64, _i32, _i32, _i32, _i32, C.POINTER(Wait), _p],
+    'dv_z2f_post_bwd': [C.POINTER(Z2F), C.POINTER(Wait), _p],
     'dv_reparam_bwd': [_p, _i64, _p, _i64, _p, _i64, _p, _i32, _i32, _i32, _i32, _p, _p, _i64, _f, _p],
     'dv_kl_rows_fwd': [C.POINTER(KlRows), C.POINTER(Wait), _p],
-    'dv_kl_rows_bwd': [_p, _p, _i32, _f, _p, _p, _i64, _p, _p, _p, _i64, _p, _f, _f, _i32, _i32, _i32, _i32,
-                       _p, _p, _i64, _p, _p, _i64, _f, _p, _i64, _p, _i64, _p],
+    'dv_kl_rows_bwd': [C.POINTER(KlRows), C.POINTER(KlRowsGrad), _p],
     'dv_gauss_nll_rows_fwd': [_p, _i64, _p, _p, _p, _i64, _i32, _i32, _i32, _p, _p, _p, _f, _p],
     'dv_gauss_nll_rows_fwdbwd': [_p, _p, _i64, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _f, _p, _p, _p, _i64, _p, _p, _p],
     'dv_gauss_nll_rows_raw_cs': [C.POINTER(NllRawCs), _p],

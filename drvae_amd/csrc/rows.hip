@@ -2238,25 +2238,22 @@ extern "C" int dv_reparam_bwd_seg(const float* dz, int64_t ldz, const float* eps
     DV_RETURN_LAUNCH();
 }
 
-extern "C" int dv_z2f_post_bwd(const float* dz2f, int64_t ld_dz2f, const float* dzdec_pert, int64_t ld_pert,
-                               const int32_t* pair_slot, const float* eps, int64_t lde, const float* p2, int64_t ldp2,
-                               const float* q2, int64_t ldq2, const float* coef, const float* raw, float kl_min,
-                               const float* dz1b, int64_t ld_dz1b, float* dp2, int64_t ld_dp2, float* dz1,
-                               int64_t ld_dz1, float* dq2, int64_t ld_dq2, int32_t L, int32_t B, int32_t Np, int32_t Z,
-                               const dv_wait* park_in, dv_stream_t stream) {
-    DV_REQUIRE(park_ok(park_in));
+extern "C" int dv_z2f_post_bwd(const dv_z2f_desc* dsc, const dv_wait* park_in, dv_stream_t stream) {
+    DV_REQUIRE(dsc != nullptr && park_ok(park_in));
+    const dv_z2f_desc& d = *dsc;
     const ParkArgs park = park_in ? *park_in : ParkArgs{};
-    DV_REQUIRE(L >= 0 && B >= 0 && Np >= 0 && Z >= 0);
-    DV_REQUIRE(park.flag == nullptr || (L > 0 && B > 0 && Z > 0));
+    DV_REQUIRE(d.L >= 0 && d.B >= 0 && d.Np >= 0 && d.Z >= 0);
+    DV_REQUIRE(park.flag == nullptr || (d.L > 0 && d.B > 0 && d.Z > 0));
     // every workgroup of a parked launch polls: keep such grids far below what the chip holds resident
     // (256 CUs x 8 workgroups), or the chain that is to publish may find no slot to run in
-    if (park.flag != nullptr && grid_for((int64_t)B * Z, 256) > DV_MAX_PARKED_GRID) return DV_ERR_UNSUPPORTED;
-    if (L == 0 || B == 0 || Z == 0) return DV_OK;
-    DV_REQUIRE(eps && p2 && dp2 && dz1);       // dz2f == NULL: nothing flows into the z2Fz1 samples from a classifier
-    DV_REQUIRE(Np == 0 || (pair_slot && q2 && coef && raw));
-    Z2FArgs a{dz2f, ld_dz2f, dzdec_pert, ld_pert, Np ? pair_slot : nullptr, eps, lde, p2, ldp2, q2, ldq2, coef, raw,
-              kl_min, dz1b, ld_dz1b, dp2, ld_dp2, dz1, ld_dz1, dq2, ld_dq2, L, B, Np, Z};
-    hipLaunchKernelGGL(z2f_post_bwd_kernel, dim3(grid_for((int64_t)B * Z, 256)), dim3(256), 0, ST(stream), a, park);
+    if (park.flag != nullptr && grid_for((int64_t)d.B * d.Z, 256) > DV_MAX_PARKED_GRID) return DV_ERR_UNSUPPORTED;
+    if (d.L == 0 || d.B == 0 || d.Z == 0) return DV_OK;
+    DV_REQUIRE(d.eps && d.p2 && d.dp2 && d.dz1);   // dz2f == NULL: nothing flows into the z2Fz1 samples from a classifier
+    DV_REQUIRE(d.Np == 0 || (d.pair_slot && d.q2 && d.coef && d.raw));
+    Z2FArgs a{d.dz2f, d.ld_dz2f, d.dzdec_pert, d.ld_pert, d.Np ? d.pair_slot : nullptr, d.eps, d.lde, d.p2, d.ldp2,
+              d.q2, d.ldq2, d.coef, d.raw, d.kl_min, d.dz1b, d.ld_dz1b, d.dp2, d.ld_dp2, d.dz1, d.ld_dz1, d.dq2,
+              d.ld_dq2, d.L, d.B, d.Np, d.Z};
+    hipLaunchKernelGGL(z2f_post_bwd_kernel, dim3(grid_for((int64_t)d.B * d.Z, 256)), dim3(256), 0, ST(stream), a, park);
     DV_RETURN_LAUNCH();
 }
 
@@ -2279,24 +2276,22 @@ extern "C" int dv_kl_rows_fwd(const dv_kl_rows_desc* dsc, const dv_wait* park_in
     DV_RETURN_LAUNCH();
 }
 
-extern "C" int dv_kl_rows_bwd(const float* coef, const float* raw, int32_t free_bits, float kl_min,
-                              const float* mu_q, const float* sd_q, int64_t ldq, const int32_t* qidx,
-                              const float* mu_p, const float* sd_p, int64_t ldp, const int32_t* pidx,
-                              float prior_mu, float prior_sd, int32_t n, int32_t reps, int32_t Z, int32_t mode,
-                              float* dq_mu, float* dq_sd, int64_t lddq, float* dp_mu, float* dp_sd, int64_t lddp,
-                              float beta, const float* dz, int64_t ldz, const float* eps, int64_t lde,
-                              dv_stream_t stream) {
-    DV_REQUIRE(n >= 0 && reps >= 0 && Z >= 0);
-    if (n == 0 || reps == 0 || Z == 0) return DV_OK;
-    DV_REQUIRE(coef && mu_q && sd_q && dq_mu && dq_sd);
-    DV_REQUIRE(!free_bits || raw != nullptr);
-    DV_REQUIRE((mu_p == nullptr) == (sd_p == nullptr));
-    DV_REQUIRE((dp_mu == nullptr) == (dp_sd == nullptr));
-    DV_REQUIRE(dp_mu == nullptr || mu_p != nullptr);
-    DV_REQUIRE(dz == nullptr || eps != nullptr);
-    KlArgs a{mu_q, sd_q, ldq, qidx, mu_p, sd_p, ldp, pidx, prior_mu, prior_sd, n, reps, Z, mode};
-    hipLaunchKernelGGL(kl_rows_bwd_kernel, dim3(grid_for((int64_t)n * reps * Z, 256)), dim3(256), 0, ST(stream), a,
-                       coef, raw, free_bits, kl_min, dq_mu, dq_sd, lddq, dp_mu, dp_sd, lddp, beta, dz, ldz, eps, lde);
+extern "C" int dv_kl_rows_bwd(const dv_kl_rows_desc* dsc, const dv_kl_rows_grad* grad, dv_stream_t stream) {
+    DV_REQUIRE(dsc != nullptr && grad != nullptr);
+    const dv_kl_rows_desc& d = *dsc;
+    const dv_kl_rows_grad& g = *grad;
+    DV_REQUIRE(d.n >= 0 && d.reps >= 0 && d.Z >= 0);
+    if (d.n == 0 || d.reps == 0 || d.Z == 0) return DV_OK;
+    DV_REQUIRE(g.coef && d.mu_q && d.sd_q && g.dq_mu && g.dq_sd);
+    DV_REQUIRE(!d.free_bits || d.raw_out != nullptr);
+    DV_REQUIRE((d.mu_p == nullptr) == (d.sd_p == nullptr));
+    DV_REQUIRE((g.dp_mu == nullptr) == (g.dp_sd == nullptr));
+    DV_REQUIRE(g.dp_mu == nullptr || d.mu_p != nullptr);
+    DV_REQUIRE(g.dz == nullptr || d.eps != nullptr);
+    KlArgs a{d.mu_q, d.sd_q, d.ldq, d.qidx, d.mu_p, d.sd_p, d.ldp, d.pidx, d.prior_mu, d.prior_sd, d.n, d.reps, d.Z, d.mode};
+    hipLaunchKernelGGL(kl_rows_bwd_kernel, dim3(grid_for((int64_t)d.n * d.reps * d.Z, 256)), dim3(256), 0, ST(stream), a,
+                       g.coef, (const float*)d.raw_out, d.free_bits, d.kl_min, g.dq_mu, g.dq_sd, g.lddq, g.dp_mu, g.dp_sd,
+                       g.lddp, g.beta, g.dz, g.ldz, d.eps, d.lde);
     DV_RETURN_LAUNCH();
 }
 

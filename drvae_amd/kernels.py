@@ -338,11 +338,12 @@ def z2f_post_bwd(dp2, dz1, dq2, dz2f, dzdec_pert, pair_slot, eps, p2, q2, coef, 
     """fused backward of the z2Fz1 sample / KL(q(z2|x2)||p(z2|z1)) / residual block, see dv_z2f_post_bwd.
     ``park`` = (flag, ctr, err[, add[, max_spins]]): the launch first parks on another chain's flag."""
     Z = dp2.shape[1] // 2
-    _lib.check(_lib.load().dv_z2f_post_bwd(_f32(dz2f), _ld(dz2f), _f32(dzdec_pert), _ld(dzdec_pert),
-                                           _i32(pair_slot), _f32(eps), _ld(eps), _f32(p2), _ld(p2), _f32(q2),
-                                           _ld(q2), _f32(coef), _f32(raw), kl_min, _f32(dz1b), _ld(dz1b),
-                                           _f32(dp2), _ld(dp2), _f32(dz1), _ld(dz1), _f32(dq2), _ld(dq2), L, B, Np, Z,
-                                           _wait(park), _stream()), 'dv_z2f_post_bwd')
+    d = _lib.Z2F(dz2f=_f32(dz2f), ld_dz2f=_ld(dz2f), dzdec_pert=_f32(dzdec_pert), ld_pert=_ld(dzdec_pert),
+                 pair_slot=_i32(pair_slot), eps=_f32(eps), lde=_ld(eps), p2=_f32(p2), ldp2=_ld(p2), q2=_f32(q2),
+                 ldq2=_ld(q2), coef=_f32(coef), raw=_f32(raw), kl_min=kl_min, dz1b=_f32(dz1b), ld_dz1b=_ld(dz1b),
+                 dp2=_f32(dp2), ld_dp2=_ld(dp2), dz1=_f32(dz1), ld_dz1=_ld(dz1), dq2=_f32(dq2), ld_dq2=_ld(dq2),
+                 L=L, B=B, Np=Np, Z=Z)
+    _lib.check(_lib.load().dv_z2f_post_bwd(C.byref(d), _wait(park), _stream()), 'dv_z2f_post_bwd')
 
 
 # --------------------------------------------------------------------------- KL rows
@@ -371,11 +372,12 @@ def kl_rows_bwd(dq_mu, dq_sd, dp_mu, dp_sd, coef, raw, mu_q, sd_q, mu_p=None, sd
     n = R // reps
     Z = mu_q.shape[1]
     assert _ld(dq_mu) == _ld(dq_sd) and (dp_mu is None or _ld(dp_mu) == _ld(dp_sd))
-    _lib.check(_lib.load().dv_kl_rows_bwd(_f32(coef), _f32(raw), int(free_bits), kl_min, _f32(mu_q), _f32(sd_q),
-                                          _ld(mu_q), _i32(qidx), _f32(mu_p), _f32(sd_p), _ld(mu_p), _i32(pidx),
-                                          prior[0], prior[1], n, reps, Z, mode, _f32(dq_mu), _f32(dq_sd),
-                                          _ld(dq_mu), _f32(dp_mu), _f32(dp_sd), _ld(dp_mu), beta, _f32(dz), _ld(dz),
-                                          _f32(eps), _ld(eps), _stream()), 'dv_kl_rows_bwd')
+    d = _lib.KlRows(mu_q=_f32(mu_q), sd_q=_f32(sd_q), ldq=_ld(mu_q), qidx=_i32(qidx), mu_p=_f32(mu_p), sd_p=_f32(sd_p),
+                    ldp=_ld(mu_p), pidx=_i32(pidx), prior_mu=prior[0], prior_sd=prior[1], n=n, reps=reps, Z=Z, mode=mode,
+                    free_bits=int(free_bits), kl_min=kl_min, raw_out=_f32(raw), eps=_f32(eps), lde=_ld(eps))
+    g = _lib.KlRowsGrad(coef=_f32(coef), dq_mu=_f32(dq_mu), dq_sd=_f32(dq_sd), lddq=_ld(dq_mu), dp_mu=_f32(dp_mu),
+                        dp_sd=_f32(dp_sd), lddp=_ld(dp_mu), beta=beta, dz=_f32(dz), ldz=_ld(dz))
+    _lib.check(_lib.load().dv_kl_rows_bwd(C.byref(d), C.byref(g), _stream()), 'dv_kl_rows_bwd')
 
 
 # ------------------------------------------------------------------------- NLL rows

@@ -319,12 +319,36 @@ int dv_reparam_bwd_seg(const float* dz, int64_t ldz, const float* eps, int64_t l
  *   dp2[r]  = (g | g*eps*0.5*exp(0.5*lv2)) + [jp >= 0] d KL(q2[jp] || p2[r]) / d p2 * coef[l*Np+jp]*mask
  *   dz1[r] += dp2[r].mu (residual mu2 = z1 + ..., src/blocks.py:357) + (dz1b ? dz1b[r] : 0)
  *   dq2[jp] = sum_l d KL / d q2 * coef*mask                      (mask = free-bits gate on raw)      */
-int dv_z2f_post_bwd(const float* dz2f, int64_t ld_dz2f, const float* dzdec_pert, int64_t ld_pert,
-                    const int32_t* pair_slot, const float* eps, int64_t lde, const float* p2, int64_t ldp2,
-                    const float* q2, int64_t ldq2, const float* coef, const float* raw, float kl_min,
-                    const float* dz1b, int64_t ld_dz1b, float* dp2, int64_t ld_dp2, float* dz1, int64_t ld_dz1,
-                    float* dq2, int64_t ld_dq2, int32_t L, int32_t B, int32_t Np, int32_t Z, const dv_wait* park,
-                    dv_stream_t stream);
+/* ABI 11: the operands travel in a descriptor (28 positional arguments before); shapes in the comments */
+typedef struct dv_z2f_desc {
+    const float* dz2f;       /* (L*B, Z) or NULL */
+    int64_t ld_dz2f;
+    const float* dzdec_pert; /* (L*Np, Z) gradient of the decoded z2Fz1 copies, or NULL */
+    int64_t ld_pert;
+    const int32_t* pair_slot; /* (B) jp or -1 */
+    const float* eps;        /* (L*B, Z) */
+    int64_t lde;
+    const float* p2;         /* (L*B, 2Z) mu2 | lv2 */
+    int64_t ldp2;
+    const float* q2;         /* (Np, 2Z) mu | lv of q(z2|x2) */
+    int64_t ldq2;
+    const float* coef;       /* (L*Np) KL coefficients */
+    const float* raw;        /* (L*Np) raw KL (free bits) */
+    float kl_min;
+    const float* dz1b;       /* (L*B, Z) or NULL */
+    int64_t ld_dz1b;
+    float* dp2;              /* (L*B, 2Z) out */
+    int64_t ld_dp2;
+    float* dz1;              /* (L*B, Z) in/out (+=) */
+    int64_t ld_dz1;
+    float* dq2;              /* (Np, 2Z) out, or NULL */
+    int64_t ld_dq2;
+    int32_t L;
+    int32_t B;
+    int32_t Np;
+    int32_t Z;
+} dv_z2f_desc;
+int dv_z2f_post_bwd(const dv_z2f_desc* d, const dv_wait* park, dv_stream_t stream);
 
 /* ------------------------------------------------ diagonal-Gaussian KL per row (K4)
  * row r = l*n + j: q row = qidx ? qidx[j] : j ; p row = pidx ? pidx[r] : r, or the
@@ -374,12 +398,22 @@ typedef struct dv_kl_rows_desc {
     float* raw2_out;
 } dv_kl_rows_desc;
 int dv_kl_rows_fwd(const dv_kl_rows_desc* d, const dv_wait* park, dv_stream_t stream);
-int dv_kl_rows_bwd(const float* coef, const float* raw, int32_t free_bits, float kl_min, const float* mu_q,
-                   const float* sd_q, int64_t ldq, const int32_t* qidx, const float* mu_p, const float* sd_p,
-                   int64_t ldp, const int32_t* pidx, float prior_mu, float prior_sd, int32_t n, int32_t reps,
-                   int32_t Z, int32_t mode, float* dq_mu, float* dq_sd, int64_t lddq, float* dp_mu, float* dp_sd,
-                   int64_t lddp, float beta, const float* dz, int64_t ldz, const float* eps, int64_t lde,
-                   dv_stream_t stream);
+/* the backward reads the forward's descriptor -- operands, n / reps / Z / mode, free_bits, kl_min, eps / lde, and raw_out
+ * as the raw KL the forward stored (required with free_bits); out / add / zout / mu2.. are not looked at -- plus its own
+ * outputs (30 positional arguments before ABI 11) */
+typedef struct dv_kl_rows_grad {
+    const float* coef;       /* (n*reps) dLoss / d out */
+    float* dq_mu;
+    float* dq_sd;
+    int64_t lddq;
+    float* dp_mu;            /* NULL (with dp_sd): no gradient towards p */
+    float* dp_sd;
+    int64_t lddp;
+    float beta;              /* outputs = beta * old + gradient */
+    const float* dz;         /* gradient of the fused sample, or NULL */
+    int64_t ldz;
+} dv_kl_rows_grad;
+int dv_kl_rows_bwd(const dv_kl_rows_desc* d, const dv_kl_rows_grad* g, dv_stream_t stream);
 
 /* ------------------------------------- Gaussian log-likelihood over genes per row (K5)
  * out[r] = -1/2 sum_g [log 2pi + log var + (x-mu)^2/var], x row = xidx ? xidx[r] : r
