@@ -105,6 +105,11 @@ class Z2F(C.Structure):          # dv_z2f_desc
                 ('ld_dz1', _i64), ('dq2', _p), ('ld_dq2', _i64), ('L', _i32), ('B', _i32), ('Np', _i32), ('Z', _i32)]
 
 
+class ReconRows(C.Structure):    # dv_recon_rows_desc
+    _fields_ = [('x', _p), ('ldx', _i64), ('mu', _p), ('sd', _p), ('ldp', _i64), ('bias_mu', _p), ('bias_sd', _p),
+                ('sd_shift', _f), ('M', _i32), ('X', _i32), ('rows', _p), ('ll', _p)]
+
+
 class NllRawCs(C.Structure):     # dv_nll_raw_cs_desc
     _fields_ = [('coef', _p), ('x', _p), ('ldx', _i64), ('xidx', _p), ('mu', _p), ('sd', _p), ('ldp', _i64), ('M', _i32),
                 ('X', _i32), ('shift', _f), ('out_part', _p), ('chunks', _i32), ('dmu', _p), ('dsd', _p), ('ldd', _i64),
@@ -171,7 +176,8 @@ SIGNATURES = {
     'dv_rows_segment_sum': [_p, _i64, _p, _p, _p, _i32, _i32, _p, _p, _i64, _f, C.POINTER(Wait), _p],
     'dv_weighted_sum': [_p, _p, _p, _i32, _f, _p, _f, _p],
     'dv_recon_row_stats': [_p, _i64, _p, _i64, _i32, _i32, _p, _p],
-    'dv_col_moments': [_p, _i64, _p, _i64, _i32, _i32, _p, _i32, _p, _p],
+    'dv_recon_rows': [C.POINTER(ReconRows), _p],
+    'dv_col_moments': [_p, _i64, _p, _i64, _i32, _i32, _p, _i32, _p, _p, _p],
     'dv_mmd_mix_fwd': [_p, _i64, _i32, _i32, _i32, _p, _i32, _p, _i64, _p, _i64, _p, _p],
     'dv_mmd_mix_bwd': [_p, _i64, _i32, _i32, _i32, _p, _i32, _p, _i64, _p, _i64, _p, _f, _p, _i64, _p, _p],
     'dv_mmd_mix_combine': [_p, _i32, _f, _p, _i32, _f, _p, _i32, _f, _p, _p],

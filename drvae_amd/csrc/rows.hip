@@ -1595,7 +1595,8 @@ __global__ __launch_bounds__(256) void recon_row_stats_kernel(const float* __res
 __global__ __launch_bounds__(256) void col_moments_kernel(const float* __restrict__ x, int64_t ldx,
                                                           const float* __restrict__ r, int64_t ldr, int M, int X,
                                                           double* __restrict__ out, int rows_per_block,
-                                                          const int32_t* __restrict__ sel) {
+                                                          const int32_t* __restrict__ sel,
+                                                          const float* __restrict__ r_bias) {
     // workgroup = (64 columns, one row block): 4 row groups of 64 lanes walk the block's rows, coalesced along the
     // columns; partial sums of the block go to out[blockIdx.y] (the caller adds the blocks up in a fixed order)
     __shared__ double part[4][3][64];
@@ -1603,14 +1604,16 @@ __global__ __launch_bounds__(256) void col_moments_kernel(const float* __restric
     const int g = blockIdx.x * 64 + c;
     const int i0 = blockIdx.y * rows_per_block, i1 = min(M, i0 + rows_per_block);
     double s1 = 0., s2 = 0., se = 0.;
-    if (g < X)
+    if (g < X) {
+        const float rb = r_bias ? r_bias[g] : 0.f;      // (r = a raw heads product: its bias is added here)
         for (int ii = i0 + rg; ii < i1; ii += 4) {
             const int i = sel ? sel[ii] : ii;       // (sel: the M rows that count, e.g. the rows with a second profile)
-            const double a = x[(int64_t)i * ldx + g], b = r[(int64_t)i * ldr + g];
+            const double a = x[(int64_t)i * ldx + g], b = r_bias ? r[(int64_t)i * ldr + g] + rb : r[(int64_t)i * ldr + g];
             s1 += a;
             s2 += a * a;
             se += (a - b) * (a - b);
         }
+    }
     part[rg][0][c] = s1;
     part[rg][1][c] = s2;
     part[rg][2][c] = se;
@@ -1618,6 +1621,89 @@ __global__ __launch_bounds__(256) void col_moments_kernel(const float* __restric
     if (rg == 0 && g < X)
         for (int k = 0; k < 3; ++k)
             out[((int64_t)blockIdx.y * 3 + k) * X + g] = (part[0][k][c] + part[1][k][c]) + (part[2][k][c] + part[3][k][c]);
+}
+
+// dv_recon_row_stats + the log-likelihood rows in ONE pass over (x, mu, sd) for rows of up to 1024 columns (whole-set
+// evaluation: 978 genes): a wave holds its row in registers (16 columns per lane), the centred second pass costs no
+// memory traffic.  Same outputs and summation orders as recon_row_stats_kernel / nll_rows_fwd_kernel's scalar path.
+// RAW: mu / sd are the heads' raw products, finished on the way (mu + bias_mu, softplus(sd + bias_sd) + shift) -- the
+// decoder's heads of the inference pass run as a plain product.
+constexpr int kRcG = 16;
+struct RcArgs {
+    const float* x; int64_t ldx; const float* mu; const float* sd; int64_t ldp;
+    const float* bias_mu; const float* bias_sd; float shift;
+    int M, X;
+    float* rows; float* ll;
+};
+
+template <bool RAW>
+__global__ __launch_bounds__(256) void recon_rows_kernel(RcArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int X = a.X;
+    for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < a.M; i += gridDim.x * 4) {
+        const float* xr = a.x + (int64_t)i * a.ldx;
+        const float* mr = a.mu + (int64_t)i * a.ldp;
+        const float* sr = a.sd + (int64_t)i * a.ldp;
+        float av[kRcG], bv[kRcG], tv[kRcG];
+#pragma unroll
+        for (int k = 0; k < kRcG; ++k) {
+            const int g = lane + 64 * k;
+            av[k] = bv[k] = tv[k] = 0.f;
+            if (g < X) {
+                const float xv = xr[g], m = mr[g], sv = sr[g];
+                av[k] = xv;
+                if constexpr (RAW) {
+                    const float bm = a.bias_mu[g];
+                    bv[k] = m + bm;
+                    tv[k] = nll_raw_term(a.shift, xv, m, sv, bm, a.bias_sd[g]);
+                } else {
+                    bv[k] = m;
+                    tv[k] = nll_term(DV_GAUSS_SIGMA, xv, m, sv);
+                }
+            }
+        }
+        float sx = 0.f, sb = 0.f, sse = 0.f, sl = 0.f;
+#pragma unroll
+        for (int k = 0; k < kRcG; ++k)
+            if (lane + 64 * k < X) {
+                sx += av[k];
+                sb += bv[k];
+                sse += (av[k] - bv[k]) * (av[k] - bv[k]);
+            }
+        // (the log-likelihood terms in the order of nll_rows_fwd_kernel's scalar path: four per trip while four fit)
+#pragma unroll
+        for (int k = 0; k < kRcG; k += 4) {
+            if (lane + 64 * (k + 3) < X) {
+                sl += (tv[k] + tv[k + 1]) + (tv[k + 2] + tv[k + 3]);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (lane + 64 * (k + q) < X) sl += tv[k + q];
+            }
+        }
+        sx = dv_wave_sum_all(sx);
+        sb = dv_wave_sum_all(sb);
+        sse = dv_wave_sum_all(sse);
+        sl = dv_wave_sum_all(sl);
+        const float mx = sx / X, mb = sb / X;
+        float cxx = 0.f, cbb = 0.f, cxb = 0.f;
+#pragma unroll
+        for (int k = 0; k < kRcG; ++k)
+            if (lane + 64 * k < X) {
+                const float p = av[k] - mx, q = bv[k] - mb;
+                cxx += p * p;
+                cbb += q * q;
+                cxb += p * q;
+            }
+        cxx = dv_wave_sum_all(cxx);
+        cbb = dv_wave_sum_all(cbb);
+        cxb = dv_wave_sum_all(cxb);
+        if (lane == 0) {
+            float* o = a.rows + (int64_t)i * 6;
+            o[0] = sse; o[1] = mx; o[2] = mb; o[3] = cxx; o[4] = cbb; o[5] = cxb;
+            if (a.ll) a.ll[i] = -0.5f * sl;
+        }
+    }
 }
 
 // ------------------------------------------------------------------ kernel-mixture MMD (src/blocks.py:29-38,59-76; round 5)
@@ -1755,6 +1841,7 @@ __global__ __launch_bounds__(1024) void recon_finalize_kernel(const float* __res
     }
     for (int g = threadIdx.x; g < X; g += 1024) {
         double c0 = 0., c1 = 0., c2 = 0.;
+#pragma unroll 8
         for (int b = 0; b < row_blocks; ++b) {
             const double* c = cols + (int64_t)b * 3 * X;
             c0 += c[g];
@@ -2718,12 +2805,30 @@ extern "C" int dv_recon_row_stats(const float* x, int64_t ldx, const float* r, i
 }
 
 extern "C" int dv_col_moments(const float* x, int64_t ldx, const float* r, int64_t ldr, int32_t M, int32_t X,
-                              double* out, int32_t row_blocks, const int32_t* sel, dv_stream_t stream) {
+                              double* out, int32_t row_blocks, const int32_t* sel, const float* r_bias,
+                              dv_stream_t stream) {
     DV_REQUIRE(M >= 0 && X >= 1 && row_blocks >= 1 && row_blocks <= 65535);
     DV_REQUIRE(x && r && out);
     const int rpb = (M + row_blocks - 1) / row_blocks;
     hipLaunchKernelGGL(col_moments_kernel, dim3((X + 63) / 64, row_blocks), dim3(256), 0, ST(stream), x, ldx, r, ldr, M, X, out,
-                       rpb > 0 ? rpb : 1, sel);
+                       rpb > 0 ? rpb : 1, sel, r_bias);
+    DV_RETURN_LAUNCH();
+}
+
+extern "C" int dv_recon_rows(const dv_recon_rows_desc* dsc, dv_stream_t stream) {
+    DV_REQUIRE(dsc != nullptr);
+    const dv_recon_rows_desc& d = *dsc;
+    DV_REQUIRE(d.M >= 0 && d.X >= 1);
+    if (d.X > DV_RECON_ROWS_MAX_X) return DV_ERR_UNSUPPORTED;
+    if (d.M == 0) return DV_OK;
+    DV_REQUIRE(d.x && d.mu && d.sd && d.rows);
+    DV_REQUIRE((d.bias_mu == nullptr) == (d.bias_sd == nullptr));
+    RcArgs a{d.x, d.ldx, d.mu, d.sd, d.ldp, d.bias_mu, d.bias_sd, d.sd_shift, d.M, d.X, d.rows, d.ll};
+    const dim3 grid(grid_for(d.M, 4, 8192)), block(256);
+    if (d.bias_mu)
+        hipLaunchKernelGGL((recon_rows_kernel<true>), grid, block, 0, ST(stream), a);
+    else
+        hipLaunchKernelGGL((recon_rows_kernel<false>), grid, block, 0, ST(stream), a);
     DV_RETURN_LAUNCH();
 }
 

@@ -511,10 +511,10 @@ class _EvalGraph:
         if kind != 'pvae':
             self._y_metrics(res, vec[o:o + 3])
             o += 3
-        self._recon(ds.x1, res['px1'][0], res['px1'][1], None, vec[o:o + 4], 'x1')
+        self._recon(ds.x1, res['px1'][0], res['px1'][1], None, vec[o:o + 4], 'x1', res['px_bias'])
         o += 4
         if has_x2:
-            self._recon(ds.x2, res['px2'][0], res['px2'][1], self.x2idx32, vec[o:o + 4], 'x2')
+            self._recon(ds.x2, res['px2'][0], res['px2'][1], self.x2idx32, vec[o:o + 4], 'x2', res['px_bias'])
         return names, vec, list(losses)
 
     def _y_metrics(self, res, out3):
@@ -553,6 +553,7 @@ class _EvalGraph:
         with its (mu | std) heads as one product -- 3 launches of 2n rows instead of 6 of n (the block modules compute
         every head with a launch of its own).  The small blocks in between are the model's own modules."""
         from .chain import _Chain
+        from . import kernels as K, tuning as T
         m, ds, kind = self.model, self.ds, self.model.kind
         eng = m.engine()
         n, Z, X = int(ds.x1.shape[0]), eng.cfg.dim_z1, eng.cfg.dim_x
@@ -591,30 +592,42 @@ class _EvalGraph:
         self.zd[:n].copy_(z1)
         if kind != 'vfae':
             self.zd[n:].copy_(z2)
-        PX = self.c_dec.forward([self.zd])
+        # the decoder's heads as a PLAIN product where the one-pass reconstruction statistics finish them on their way
+        # (bias, softplus + shift: ``dv_recon_rows`` / ``dv_col_moments``): 16384 x 1956 x 600 at the raw product's 126 instead of 104 TF/s
+        lh = eng.L_decx[-1]
+        raw = bool(X <= K.RECON_ROWS_MAX_X and self.c_dec.raw_last_ok() and lh.act1 == 'softplus' and T.get('raw_heads'))
+        PX = self.c_dec.forward([self.zd], raw_last=raw)
+        res['px_bias'] = (lh.b[:X], lh.b[X:2 * X], lh.shift1) if raw else None
         res['px1'] = (PX[:n, :X], PX[:n, X:2 * X])
         if kind != 'vfae':
             res['px2'] = (PX[n:, :X], PX[n:, X:2 * X])
         return res
 
-    def _recon(self, x, x_rec, x_std, sel, out4, tag):
+    def _recon(self, x, x_rec, x_std, sel, out4, tag, bias=None):
         """``eval_x_reconstruction`` (src/DGMMixin.py:128-156) over the rows ``sel`` (all when None): row statistics, column
         moments and log-likelihood rows from the HIP kernels, combined in float64 by ``dv_recon_finalize`` into ``out4`` =
         [rmse, r2, pearr, ll].  The statistics are taken over ALL rows and selected afterwards (no gathered copies of
-        the x2 rows and their reconstructions)."""
+        the x2 rows and their reconstructions).  Rows of up to 1024 genes: row statistics and log-likelihood rows in ONE pass
+        (``dv_recon_rows``); ``bias`` = (bias_mu, bias_sd, shift): the heads are raw products, finished by the passes."""
         from . import kernels as K
         from ._lib import GAUSS_SIGMA
         x = x.to(torch.float32)
         M, X = x.shape
         n = int(sel.numel()) if sel is not None else M
+        one_pass = X <= K.RECON_ROWS_MAX_X
+        assert bias is None or one_pass
         buf = self.__dict__.setdefault('_recon_bufs', {})
         if tag not in buf:
             buf[tag] = (torch.empty(M, 6, device=x.device), torch.empty(K.col_moment_blocks(n), 3, X, dtype=torch.float64, device=x.device),
                         torch.empty(M, device=x.device))
         rows, part, ll = buf[tag]
-        K.recon_row_stats(rows, x, x_rec)
-        K.col_moments(None, x, x_rec, sel=sel, part=part)
-        K.nll_rows_fwd(ll, x, x_rec, x_std, mode=GAUSS_SIGMA)
+        if one_pass:
+            K.recon_rows(rows, ll, x, x_rec, x_std, bias=bias[:2] if bias is not None else None,
+                         sd_shift=bias[2] if bias is not None else 0.0)
+        else:
+            K.recon_row_stats(rows, x, x_rec)
+            K.nll_rows_fwd(ll, x, x_rec, x_std, mode=GAUSS_SIGMA)
+        K.col_moments(None, x, x_rec, sel=sel, part=part, r_bias=bias[0] if bias is not None else None)
         K.recon_finalize(out4, rows, part, X, sel=sel, n=n, ll=ll)
 
     def run(self):

@@ -734,10 +734,10 @@ def recon_row_stats(out, x, r):
                'dv_recon_row_stats')
 
 
-def col_moments(out, x, r, sel=None, part=None):
+def col_moments(out, x, r, sel=None, part=None, r_bias=None):
     """out (3,X) float64: per-column sum x, sum x^2, sum (x-r)^2 over the rows (``sel``: int32 list of the rows that
     count).  ``part`` (row_blocks, 3, X) float64: leave the per-block partials there instead (``recon_finalize`` adds
-    them up); out may then be None."""
+    them up); out may then be None.  ``r_bias`` (X): r is a raw heads product, r + r_bias the reconstruction."""
     M = sel.numel() if sel is not None else x.shape[0]
     X = x.shape[1]
     if part is not None:
@@ -747,7 +747,7 @@ def col_moments(out, x, r, sel=None, part=None):
         assert out.dtype == torch.float64 and out.is_cuda and out.is_contiguous() and tuple(out.shape) == (3, X)
         nb = col_moment_blocks(M)      # row blocks: partial sums per block, added up here in a fixed order
         part = out.unsqueeze(0) if nb == 1 else torch.empty(nb, 3, X, dtype=torch.float64, device=out.device)
-    _lib.check(_lib.load().dv_col_moments(_f32(x), _ld(x), _f32(r), _ld(r), M, X, part.data_ptr(), nb, _i32(sel), _stream()),
+    _lib.check(_lib.load().dv_col_moments(_f32(x), _ld(x), _f32(r), _ld(r), M, X, part.data_ptr(), nb, _i32(sel), _f32(r_bias), _stream()),
                'dv_col_moments')
     if out is not None and part.data_ptr() != out.data_ptr():
         torch.sum(part, 0, out=out)
@@ -755,6 +755,23 @@ def col_moments(out, x, r, sel=None, part=None):
 
 def col_moment_blocks(M):
     return max(1, min(64, (M + 63) // 64))
+
+
+RECON_ROWS_MAX_X = 1024
+
+
+def recon_rows(rows, ll, x, mu, sd, *, bias=None, sd_shift=1e-3):
+    """row statistics (M, 6) and log-likelihood rows (M; may be None) of a reconstruction in ONE pass over (x, mu, sd),
+    X <= RECON_ROWS_MAX_X -- ``recon_row_stats`` + ``nll_rows_fwd``.  ``bias`` = (bias_mu, bias_sd): mu / sd are the
+    heads' raw products, finished on the way."""
+    M, X = x.shape
+    assert tuple(mu.shape) == (M, X) and tuple(sd.shape) == (M, X) and _ld(mu) == _ld(sd)
+    assert rows.is_contiguous() and tuple(rows.shape) == (M, 6)
+    d = _lib.ReconRows(x=_f32(x), ldx=_ld(x), mu=_f32(mu), sd=_f32(sd), ldp=_ld(mu),
+                       bias_mu=_f32(bias[0]) if bias is not None else None,
+                       bias_sd=_f32(bias[1]) if bias is not None else None, sd_shift=sd_shift, M=M, X=X,
+                       rows=_f32(rows), ll=_f32(ll))
+    _lib.check(_lib.load().dv_recon_rows(C.byref(d), _stream()), 'dv_recon_rows')
 
 
 def recon_finalize(out4, rows, part, X, *, sel=None, n=None, ll=None):

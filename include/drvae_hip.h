@@ -718,8 +718,31 @@ int dv_weighted_sum(const float* x, const float* w, const int32_t* idx, int32_t 
 int dv_recon_row_stats(const float* x, int64_t ldx, const float* r, int64_t ldr, int32_t M, int32_t X, float* out,
                        dv_stream_t stream);
 int dv_col_moments(const float* x, int64_t ldx, const float* r, int64_t ldr, int32_t M, int32_t X, double* out,
-                   int32_t row_blocks, const int32_t* sel, dv_stream_t stream);
+                   int32_t row_blocks, const int32_t* sel, const float* r_bias, dv_stream_t stream);
 /* `sel` (optional, ABI 11): the M rows that count, as indices into x / r (e.g. the rows with a second profile) */
+/* `r_bias` (X, optional, round 5): r holds a RAW heads product, r + r_bias is the reconstruction.
+ * dv_recon_rows: dv_recon_row_stats AND the Gaussian log-likelihood rows (dv_gauss_nll_rows_fwd, SIGMA mode) in ONE pass
+ * over (x, mu, sd) for rows of up to DV_RECON_ROWS_MAX_X columns -- the whole-set evaluation's 978 genes: a wave holds its
+ * row in registers.  Same outputs (bitwise; the log-likelihood in the order of the scalar row pass): rows (M, 6), ll (M,
+ * optional).  bias_mu / bias_sd (both or neither): mu / sd are the heads' RAW products and are finished on the way
+ * (mu + bias_mu, softplus(sd + bias_sd) + sd_shift).  X beyond the limit: DV_ERR_UNSUPPORTED (callers take the two
+ * separate passes). */
+#define DV_RECON_ROWS_MAX_X 1024
+typedef struct dv_recon_rows_desc {
+    const float* x;
+    int64_t ldx;
+    const float* mu;
+    const float* sd;
+    int64_t ldp;
+    const float* bias_mu;
+    const float* bias_sd;
+    float sd_shift;
+    int32_t M;
+    int32_t X;
+    float* rows;
+    float* ll;
+} dv_recon_rows_desc;
+int dv_recon_rows(const dv_recon_rows_desc* d, dv_stream_t stream);
 
 /* Kernel-mixture MMD of `mmd_objective(kernel='poly' | 'rbf')` and the `identity` kernel (src/blocks.py:29-38,59-76; round
  * 5).  The three Gram products x1 x1^T, x2 x2^T, x1 x2^T are dv_gemm calls; on a Gram matrix G (M x N):

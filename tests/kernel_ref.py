@@ -720,7 +720,9 @@ def col_moment_blocks(M):
     return max(1, min(64, (M + 63) // 64))
 
 
-def col_moments(out, x, r, sel=None, part=None):
+def col_moments(out, x, r, sel=None, part=None, r_bias=None):
+    if r_bias is not None:
+        r = r + r_bias
     if sel is not None:
         x, r = x[sel.long()], r[sel.long()]
     xd, rd = x.double(), r.double()
@@ -730,6 +732,18 @@ def col_moments(out, x, r, sel=None, part=None):
         part[0].copy_(tot)
     if out is not None:
         out.copy_(tot)
+
+
+RECON_ROWS_MAX_X = 1024
+
+
+def recon_rows(rows, ll, x, mu, sd, *, bias=None, sd_shift=1e-3):
+    if bias is not None:          # raw heads: finished here
+        mu = mu + bias[0]
+        sd = F.softplus(sd + bias[1]) + sd_shift
+    recon_row_stats(rows, x, mu)
+    if ll is not None:
+        nll_rows_fwd(ll, x, mu, sd, mode=GAUSS_SIGMA)
 
 
 def recon_finalize(out4, rows, part, X, *, sel=None, n=None, ll=None):
@@ -932,7 +946,7 @@ FUNCTIONS = ['smalln_ws_numel', 'col_moment_blocks', 'recon_finalize', 'rank_met
              'reparam_fwd', 'reparam_bwd', 'reparam_bwd_seg', 'z2f_post_bwd', 'kl_rows_fwd', 'kl_rows_bwd', 'nll_rows_fwd', 'nll_rows_bwd', 'nll_rows_fwdbwd',
              'softmax_clamp_fwd', 'softmax_clamp_bwd', 'cat_terms_fwd', 'cat_terms_bwd', 'smalln_fwd', 'smalln_bwd_data',
              'smalln_bwd_weight', 'ymarg_fwd', 'ymarg_bwd', 'ymarg_fwdbwd',
-             'rows_gather', 'rows_segment_sum', 'weighted_sum', 'recon_row_stats', 'col_moments', 'loss_assemble', 'axpby', 'adam_l2', 'counter_add', 'fill_normal']
+             'rows_gather', 'rows_segment_sum', 'weighted_sum', 'recon_row_stats', 'recon_rows', 'col_moments', 'loss_assemble', 'axpby', 'adam_l2', 'counter_add', 'fill_normal']
 
 
 def install(monkeypatch):

@@ -66,7 +66,8 @@ def test_gemm_desc_layout_matches_header():
                                           ('dv_fprop_kl', 'FpropKl'), ('dv_ymarg', 'Ymarg'), ('dv_seg_add', 'SegAdd'),
                                           ('dv_batch_masks_desc', 'BatchMasks'), ('dv_batch_feed_desc', 'BatchFeed'),
                                           ('dv_kl_rows_desc', 'KlRows'), ('dv_nll_raw_cs_desc', 'NllRawCs'),
-                                          ('dv_kl_rows_grad', 'KlRowsGrad'), ('dv_z2f_desc', 'Z2F')])
+                                          ('dv_kl_rows_grad', 'KlRowsGrad'), ('dv_z2f_desc', 'Z2F'),
+                                          ('dv_recon_rows_desc', 'ReconRows')])
 def test_small_struct_layouts_match_header(cname, pyname):
     from drvae_amd import _lib
     src = open(os.path.join(ROOT, 'include', 'drvae_hip.h')).read()
@@ -123,7 +124,9 @@ def test_argument_validation_without_gpu(lib):
     assert lib.dv_kl_rows_bwd(C.byref(k), None, None) == -1       # no gradient descriptor
     assert lib.dv_kl_rows_bwd(C.byref(k), C.byref(_lib.KlRowsGrad()), None) == -1
     assert lib.dv_z2f_post_bwd(None, None, None) == -1
-    assert lib.dv_z2f_post_bwd(C.byref(_lib.Z2F(L=1, B=4, Np=0, Z=3)), None, None) == -1
+    assert lib.dv_recon_rows(None, None) == -1
+    assert lib.dv_recon_rows(C.byref(_lib.ReconRows(M=4, X=8)), None) == -1          # no operands
+    assert lib.dv_recon_rows(C.byref(_lib.ReconRows(M=4, X=4096)), None) == -3       # beyond the resident width
     m = _lib.BatchMasks(Np=9, n_tot=4.0)                           # more pair slots than rows
     assert lib.dv_batch_masks(C.byref(m), None, 0, None, None, 4, 2, None) == -1
     assert lib.dv_loss_assemble_after(None, None, 0, None, None, None, None, None, 0, None, None) == -1
