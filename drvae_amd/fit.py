@@ -580,9 +580,12 @@ class _EvalGraph:
         z1 = Q[:, :Z]
         res = OrderedDict(z1=z1, qz1=(z1, Q[:, Z:2 * Z]))
         if kind != 'vfae':
-            pz2 = m.decoder_z2Fz1([z1])
-            z2 = pz2[0]
-            res.update(z2=z2, pz2=pz2)
+            # the perturbation function's MEAN only (its log-variance feeds no metric): z2 = z1 + z1 W_mu^T + b
+            # (src/blocks.py:357), one launch, straight into the second half of the decoder's stacked input
+            lz = eng.L_z2F[0]
+            z2 = self.zd[n:]
+            K.linear_fwd(z2, z1, lz.W[:Z], lz.b[:Z], resid=z1, resid_cols=Z, overread=True)
+            res.update(z2=z2)
         if kind != 'pvae':
             if kind == 'drvae':
                 clf_in = [z1, z2 - z1] if m.clf_z1z2 else [z2]
@@ -590,8 +593,6 @@ class _EvalGraph:
                 clf_in = [z1]
             res.update(**m._pred_proba(m.encoder_y(clf_in)))
         self.zd[:n].copy_(z1)
-        if kind != 'vfae':
-            self.zd[n:].copy_(z2)
         # the decoder's heads as a PLAIN product where the one-pass reconstruction statistics finish them on their way
         # (bias, softplus + shift: ``dv_recon_rows`` / ``dv_col_moments``): 16384 x 1956 x 600 at the raw product's 126 instead of 104 TF/s
         lh = eng.L_decx[-1]
