@@ -754,7 +754,9 @@ def col_moments(out, x, r, sel=None, part=None, r_bias=None):
 
 
 def col_moment_blocks(M):
-    return max(1, min(64, (M + 63) // 64))
+    """row blocks of ``col_moments`` (16-wave workgroups): 256 rows up to 16 blocks, then 512 rows, at most 64 --
+    ``recon_finalize``, one workgroup, walks every block's partials"""
+    return max(1, min(64, max(min(16, (M + 255) // 256), (M + 511) // 512)))
 
 
 RECON_ROWS_MAX_X = 1024

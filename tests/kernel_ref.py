@@ -717,7 +717,7 @@ def recon_row_stats(out, x, r):
 
 
 def col_moment_blocks(M):
-    return max(1, min(64, (M + 63) // 64))
+    return max(1, min(64, max(min(16, (M + 255) // 256), (M + 511) // 512)))
 
 
 def col_moments(out, x, r, sel=None, part=None, r_bias=None):
