@@ -462,7 +462,13 @@ class FusedStep(StepSchedule):
         if self._rec == 'main' and self.noise_ahead:
             self._rng_pending = n         # dual-graph step: the side chain of the PREVIOUS step has drawn them
             return
-        K.fill_normal_rows(self.plan.noise, self.plan.noise_desc, self.seed, self.rng_ctr)
+        desc = self.plan.noise_desc
+        if not (self.training and self.add_noise and self.cfg.add_noise_var > 0):
+            # no input noise in this pass (evaluation; ``fit(add_noise=False)``): its rows -- two thirds of the arena at
+            # 978 genes -- are not drawn (whole-set evaluation of 8192 rows: 40 -> 15 us); a draw is keyed by (draw id,
+            # global row), so the latent draws are the same numbers either way
+            desc = desc[self.plan.B + self.plan.Np:]
+        K.fill_normal_rows(self.plan.noise, desc, self.seed, self.rng_ctr)
         self._noise_stale = True          # (an eager draw: a later replay must draw for its own counter first)
         if bump:
             K.counter_add(self.rng_ctr, n)
