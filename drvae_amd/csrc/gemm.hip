@@ -1071,6 +1071,22 @@ static int colsum_setup(dv_gemm_desc& g, int tiling, hipStream_t st) {
     return DV_OK;
 }
 
+// The 128 x 256 pipe kernel runs two workgroups per CU.  OPT-IN (dv_gemm_tune.opt[5] = percent of the estimate below; 0 =
+// off, the default): under a plain epilogue (stores only) the second resident workgroup of the first dispatch round starts
+// half a tile late (gemm_pipe_kernel), so that one workgroup's epilogue and prologue run under the other's K loop.  Half a
+// tile of two co-resident workgroups = one tile's matrix time alone: BM x BN x K x 2 flop at 0.6145 TFLOP/s per CU; in
+// ticks of 10 ns.  Measured (tools/stagger_probe.py, launches back to back): 32768 x 1956 x 600 627 -> 581 us, 2048 x 20000 x
+// 1536 (2.47 rounds of the chip's 512 slots) 1029 -> 872 us, nothing from K = 2048 on, +1.5 % on a product of exactly one
+// round -- and NOTHING inside the whole-set evaluation's graph (the same 32768-row product: 707 -> 716 us in situ,
+// evaluation 2.67-2.73 ms either way): the launches around it de-phase the workgroups already.  Hence not a default.
+static int pipe_stagger_ticks(const dv_gemm_desc& g, int bm, int bn) {
+    const int o5 = tune_of(g).opt[5];
+    const int64_t tiles = (int64_t)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn);
+    if (o5 <= 0 || tiles < 768 || g.K > 2048 || g.epilogue != DV_EPI_PLAIN) return 0;
+    const double us = 2.0 * bm * bn * (double)g.K / 0.6145e6;
+    return (int)(us * o5);
+}
+
 static int gemm_launch(const dv_gemm_desc& g_in, const LoadCfg& lc, int tiling, hipStream_t st) {
     if (tiling < 0) return DV_OK;
     dv_gemm_desc g = g_in;
@@ -1080,7 +1096,11 @@ static int gemm_launch(const dv_gemm_desc& g_in, const LoadCfg& lc, int tiling, 
     }
     if (tiling == 3) return launch_cfg<128, 128, 32, 2, 2, 1>(g, lc, st);
     if (tiling >= 40 && tiling < 50 && !pipe_ok(g, lc)) return launch_cfg<128, 128, 32, 2, 2, 1>(g, lc, st);
-    if (tiling == 40) return launch_pipe<128, 256, 16, 2, 2, 3, 2>(g, lc, st);
+    if (tiling == 40) {
+        LoadCfg l2 = lc;
+        l2.stagger = pipe_stagger_ticks(g, 128, 256);
+        return launch_pipe<128, 256, 16, 2, 2, 3, 2>(g, l2, st);
+    }
     // few output tiles, long K (encoder layer 1 of the wide configuration: 1536 x 2048 x 20000 = 768 tiles of 64 x 64 =
     // three per CU, all resident): the 64x64 tiling's pipelined form
     if (tiling == 46 && pipe_ok(g, lc)) return launch_pipe<64, 64, 32, 2, 2, 3, 3>(g, lc, st);

@@ -151,7 +151,7 @@ typedef struct dv_bump {
  * hooks of ABI <= 8).  tiling: see dv_gemm_has_tiling.  opt[0] = workgroup -> tile map (-1 by tiling, 0 linear, 1 XCD
  * chunk-major, >= 2 bands of that many tile rows); opt[1] extra dynamic LDS of the chip-filling 32x32 launches; opt[2] = 1:
  * no fused form of dv_gemm_pair; opt[3]: tiles of 64x64 from which the 64x64 tiling runs (-1: never the hand-pipelined
- * LDS-DMA kernels); opt[4] heads kernel variant; opt[6] = -1: a chip-filling plain product with a ragged last column of
+ * LDS-DMA kernels); opt[4] heads kernel variant; opt[5] > 0 (opt-in, tuning): the 128x256 tiling's second resident workgroup of a CU starts that many percent of an estimated half tile late under a plain epilogue; opt[6] = -1: a chip-filling plain product with a ragged last column of
  * 128x256 tiles is NOT split into [full tiles | narrow rest] (dv_gemm: two launches where that saves a tile per CU); opt[7] = 1: four-wave K split for the k-contiguous layouts; opt[8]: tiles of
  * 32x32 from which the seven-per-CU tiling runs; opt[9] = 1: chip-filling dW || dX as two launches */
 typedef struct dv_gemm_tune {

@@ -34,6 +34,9 @@ def eval_gflop(ds, L=2, X=978, H1=800, Z=100, HD=600, HF=200, Y=2):
 
 def main():
     reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+    for kv in filter(None, os.environ.get('GEMM_OPTS', '').split(',')):      # tuning A/Bs: dv_gemm_tune.opt keys, e.g. GEMM_OPTS=5=-1
+        import drvae_amd.kernels as K
+        K.gemm_set_option(*[int(v) for v in kv.split('=')])
     model = DrVAE(dim_x=978, dim_s=1, dim_y=2, dim_h_en_z1=[800], dim_h_de_z1=[200], dim_h_en_z3=[200], dim_h_de_x=[600],
                   dim_h_clf=[], dim_z1=100, dim_z3=100, type_rec='diag_gaussian', nonlinearity='elu', learning_rate=5e-4, L=2,
                   weight_decay=0.05, add_noise_var=0.01, pertloss_rate=0.05, use_MMD=False, random_seed=123, epochs=1,
