@@ -37,6 +37,10 @@ class Wait(C.Structure):       # dv_wait: a device-side wait carried by a launch
     _fields_ = [('flag', _p), ('ctr', _p), ('add', _i32), ('max_spins', _i32), ('err', _p)]
 
 
+class AdamHyper(C.Structure):  # dv_adam_hyper
+    _fields_ = [('lr', _f), ('beta1', _f), ('beta2', _f), ('eps', _f), ('weight_decay', _f), ('gscale', _f)]
+
+
 class Publish(C.Structure):    # dv_publish: "this launch has started", published on entry
     _fields_ = [('flag', _p), ('ctr', _p), ('add', _i32)]
 
@@ -188,10 +192,9 @@ SIGNATURES = {
     'dv_loss_assemble': [C.POINTER(LossTerm), _i32, _p, _p, _p, _p, _i32, _p, _p],
     'dv_loss_assemble_after': [C.POINTER(Wait), C.POINTER(LossTerm), _i32, _p, _p, _p, C.POINTER(Bump), _p, _i32, _p, _p],
     'dv_axpby': [_p, _f, _p, _f, _i64, _p],
-    'dv_adam_l2': [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _f, _p, _p, _i32, _p],
-    'dv_adam_l2_gated': [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _f, _p, _p, _p, _i32, _p, _i32, _i64, _i64, _p,
-                         _i32, _p],
-    'dv_adamax_l2': [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _f, _p, _p, _i32, _p],
+    'dv_adam_l2': [_p, _p, _p, _p, _i64, C.POINTER(AdamHyper), _p, _p, _i32, _p],
+    'dv_adam_l2_gated': [_p, _p, _p, _p, _i64, C.POINTER(AdamHyper), _p, C.POINTER(Wait), _i64, _i64, _p, _i32, _p],
+    'dv_adamax_l2': [_p, _p, _p, _p, _i64, C.POINTER(AdamHyper), _p, _p, _i32, _p],
     'dv_flag_publish': [_p, _p, _i32, _p],
     'dv_flag_wait': [_p, _p, _i32, _p, _i32, C.POINTER(Publish), _p],
     'dv_counter_add': [_p, _i32, _i64, _p],

@@ -382,32 +382,31 @@ static int adam_launch(float* p, const float* g, float* m, float* v, int64_t n, 
     DV_RETURN_LAUNCH();
 }
 
-extern "C" int dv_adam_l2(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
-                          float beta2, float eps, float weight_decay, float gscale, const int32_t* step_dev,
-                          const int32_t* halt, int32_t n_halt, dv_stream_t stream) {
-    return adam_launch(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, gscale, step_dev, AdamGate{}, halt, n_halt,
-                       stream);
+extern "C" int dv_adam_l2(float* p, const float* g, float* m, float* v, int64_t n, const dv_adam_hyper* h,
+                          const int32_t* step_dev, const int32_t* halt, int32_t n_halt, dv_stream_t stream) {
+    DV_REQUIRE(h != nullptr);
+    return adam_launch(p, g, m, v, n, h->lr, h->beta1, h->beta2, h->eps, h->weight_decay, h->gscale, step_dev, AdamGate{},
+                       halt, n_halt, stream);
 }
 
-extern "C" int dv_adam_l2_gated(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
-                                float beta2, float eps, float weight_decay, float gscale, const int32_t* step_dev,
-                                int32_t* flag, const int32_t* ctr, int32_t add, int32_t* err, int32_t max_spins,
-                                int64_t lo, int64_t hi, const int32_t* halt, int32_t n_halt, dv_stream_t stream) {
-    DV_REQUIRE(flag && ctr && err && max_spins > 0 && lo >= 0 && hi >= lo && hi <= n);
-    return adam_launch(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, gscale, step_dev,
-                       AdamGate{flag, ctr, add, err, max_spins, lo, hi}, halt, n_halt, stream);
+extern "C" int dv_adam_l2_gated(float* p, const float* g, float* m, float* v, int64_t n, const dv_adam_hyper* h,
+                                const int32_t* step_dev, const dv_wait* gate, int64_t lo, int64_t hi,
+                                const int32_t* halt, int32_t n_halt, dv_stream_t stream) {
+    DV_REQUIRE(h != nullptr && gate != nullptr);
+    DV_REQUIRE(gate->flag && gate->ctr && gate->err && gate->max_spins > 0 && lo >= 0 && hi >= lo && hi <= n);
+    return adam_launch(p, g, m, v, n, h->lr, h->beta1, h->beta2, h->eps, h->weight_decay, h->gscale, step_dev,
+                       AdamGate{gate->flag, gate->ctr, gate->add, gate->err, gate->max_spins, lo, hi}, halt, n_halt, stream);
 }
 
-extern "C" int dv_adamax_l2(float* p, const float* g, float* m, float* u, int64_t n, float lr, float beta1,
-                            float beta2, float eps, float weight_decay, float gscale, const int32_t* step_dev,
-                            const int32_t* halt, int32_t n_halt, dv_stream_t stream) {
-    DV_REQUIRE(n >= 0 && n_halt >= 0 && (halt || n_halt == 0));
+extern "C" int dv_adamax_l2(float* p, const float* g, float* m, float* u, int64_t n, const dv_adam_hyper* h,
+                            const int32_t* step_dev, const int32_t* halt, int32_t n_halt, dv_stream_t stream) {
+    DV_REQUIRE(h != nullptr && n >= 0 && n_halt >= 0 && (halt || n_halt == 0));
     if (n == 0) return DV_OK;
     DV_REQUIRE(p && g && m && u && step_dev);
     int64_t blocks = (n + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(adamax_kernel, dim3((unsigned)blocks), dim3(256), 0, ST(stream), p, g, m, u, n, lr, beta1, beta2,
-                       eps, weight_decay, gscale, step_dev, halt, n_halt);
+    hipLaunchKernelGGL(adamax_kernel, dim3((unsigned)blocks), dim3(256), 0, ST(stream), p, g, m, u, n, h->lr, h->beta1,
+                       h->beta2, h->eps, h->weight_decay, h->gscale, step_dev, halt, n_halt);
     DV_RETURN_LAUNCH();
 }
 

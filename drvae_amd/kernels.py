@@ -835,21 +835,22 @@ def adam_l2(p, g, m, v, step_dev, *, lr, beta1=0.9, beta2=0.999, eps=1e-8, weigh
     ``halt``: the (err, ticks) pairs of the step's waits -- any error set: nothing is updated"""
     assert p.is_contiguous() and g.is_contiguous() and m.is_contiguous() and v.is_contiguous()
     hp, hn = _halt(halt)
+    h = _lib.AdamHyper(lr=lr, beta1=beta1, beta2=beta2, eps=eps, weight_decay=weight_decay, gscale=gscale)
     if gate is None:
-        _lib.check(_lib.load().dv_adam_l2(_f32(p), _f32(g), _f32(m), _f32(v), p.numel(), lr, beta1, beta2, eps,
-                                          weight_decay, gscale, _i32(step_dev), hp, hn, _stream()), 'dv_adam_l2')
+        _lib.check(_lib.load().dv_adam_l2(_f32(p), _f32(g), _f32(m), _f32(v), p.numel(), C.byref(h), _i32(step_dev), hp, hn,
+                                          _stream()), 'dv_adam_l2')
     else:
         flag, ctr, add, err, lo, hi = gate
-        _lib.check(_lib.load().dv_adam_l2_gated(_f32(p), _f32(g), _f32(m), _f32(v), p.numel(), lr, beta1, beta2, eps,
-                                                weight_decay, gscale, _i32(step_dev), _i32(flag), _i32(ctr), add,
-                                                _i32(err), WAIT_SPINS, lo, hi, hp, hn, _stream()), 'dv_adam_l2_gated')
+        _lib.check(_lib.load().dv_adam_l2_gated(_f32(p), _f32(g), _f32(m), _f32(v), p.numel(), C.byref(h), _i32(step_dev),
+                                                _wait((flag, ctr, err, add)), lo, hi, hp, hn, _stream()), 'dv_adam_l2_gated')
 
 
 def adamax_l2(p, g, m, u, step_dev, *, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, gscale=1.0, halt=None):
     assert p.is_contiguous() and g.is_contiguous() and m.is_contiguous() and u.is_contiguous()
     hp, hn = _halt(halt)
-    _lib.check(_lib.load().dv_adamax_l2(_f32(p), _f32(g), _f32(m), _f32(u), p.numel(), lr, beta1, beta2, eps,
-                                        weight_decay, gscale, _i32(step_dev), hp, hn, _stream()), 'dv_adamax_l2')
+    h = _lib.AdamHyper(lr=lr, beta1=beta1, beta2=beta2, eps=eps, weight_decay=weight_decay, gscale=gscale)
+    _lib.check(_lib.load().dv_adamax_l2(_f32(p), _f32(g), _f32(m), _f32(u), p.numel(), C.byref(h), _i32(step_dev), hp, hn,
+                                        _stream()), 'dv_adamax_l2')
 
 
 def flag_publish(flag, ctr, add=1):

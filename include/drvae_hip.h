@@ -835,22 +835,27 @@ int dv_axpby(const float* x, float a, float* y, float b, int64_t n, dv_stream_t 
  * step_dev[0] (int32, device) is the 1-based step used for the bias corrections; it is
  * read, not modified (bump it with dv_counter_add so graph replays advance). gscale
  * multiplies g first (1/world_size style scaling; 1.0 for summed gradients). */
-int dv_adam_l2(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
-               float eps, float weight_decay, float gscale, const int32_t* step_dev, const int32_t* halt,
-               int32_t n_halt, dv_stream_t stream);
-/* same sweep, but the elements [lo, hi) are touched only after another launch chain has published `flag`
+typedef struct dv_adam_hyper {      /* ABI 11: six same-typed scalars travel by name, not by position */
+    float lr;
+    float beta1;
+    float beta2;
+    float eps;
+    float weight_decay;
+    float gscale;
+} dv_adam_hyper;
+int dv_adam_l2(float* p, const float* g, float* m, float* v, int64_t n, const dv_adam_hyper* h,
+               const int32_t* step_dev, const int32_t* halt, int32_t n_halt, dv_stream_t stream);
+/* same sweep, but the elements [lo, hi) are touched only after another launch chain has published `gate->flag`
  * (flag[0] >= ctr[0] + add, see dv_flag_publish): only the workgroups overlapping the range park (bounded
  * like dv_flag_wait: err[0] = 1 on time-out, err[1] += ticks parked), so gradients that are leaves of
  * the backward pass may still be in flight on the other chain when the optimiser launch starts */
-int dv_adam_l2_gated(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
-                     float eps, float weight_decay, float gscale, const int32_t* step_dev, int32_t* flag,
-                     const int32_t* ctr, int32_t add, int32_t* err, int32_t max_spins, int64_t lo, int64_t hi,
-                     const int32_t* halt, int32_t n_halt, dv_stream_t stream);
+int dv_adam_l2_gated(float* p, const float* g, float* m, float* v, int64_t n, const dv_adam_hyper* h,
+                     const int32_t* step_dev, const dv_wait* gate, int64_t lo, int64_t hi, const int32_t* halt,
+                     int32_t n_halt, dv_stream_t stream);
 /* torch.optim.Adamax with coupled L2 (the `optim_alg='adamax'` branch of src/DGMMixin.py:37-38):
  * u is the exponentially weighted infinity norm; same conventions as dv_adam_l2. */
-int dv_adamax_l2(float* p, const float* g, float* m, float* u, int64_t n, float lr, float beta1, float beta2,
-                 float eps, float weight_decay, float gscale, const int32_t* step_dev, const int32_t* halt,
-                 int32_t n_halt, dv_stream_t stream);
+int dv_adamax_l2(float* p, const float* g, float* m, float* u, int64_t n, const dv_adam_hyper* h,
+                 const int32_t* step_dev, const int32_t* halt, int32_t n_halt, dv_stream_t stream);
 int dv_counter_add(int32_t* counter_lo_hi, int32_t n_words, int64_t inc, dv_stream_t stream);
 /* Joins folded into their consumers: dv_z2f_post_bwd, dv_reparam_bwd_seg and dv_rows_segment_sum take an optional `park`
  * (every workgroup of the launch first parks like dv_flag_wait: the first consumer of another chain's
