@@ -347,6 +347,40 @@ def test_captured_evaluation_equals_step_by_step(kind, dev):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('X', [1100, 978])
+def test_captured_evaluation_beyond_the_register_resident_rows(X, dev):
+    """round 5: rows of up to 1024 genes take the one-pass reconstruction statistics behind RAW decoder heads
+    (dv_recon_rows / dv_col_moments(r_bias)); wider rows the separate passes behind finished heads -- both equal the
+    step-by-step evaluation, metric by metric"""
+    from drvae_amd import data as D, fit as F, kernels as K
+    model = _tiny_model('drvae', dim_x=X, device='cuda', epochs=2)
+    rs = np.random.RandomState(3)
+    n = 40
+    y = rs.randint(0, 2, n)
+    x1 = (rs.standard_normal((n, X)) + 0.5 * (2 * y[:, None] - 1) * (np.arange(X) % 3 == 0)).astype(np.float32)
+    hx = (np.arange(n) % 3 == 0).astype(np.int64)
+    x2 = ((x1 * 0.7 + 0.2) * hx[:, None]).astype(np.float32)
+    hy = (np.arange(n) % 4 != 1).astype(np.int64)
+    t = lambda a: torch.from_numpy(a).to('cuda')
+    va = D.DrVAEDataset(t(x1), t(x2), t(np.zeros(n, np.int64)), t(y), t(hx), t(hy))
+    g = lambda k: getattr(va, k, None)
+    ref, _ = model._evaluate(g('x1'), g('x2'), g('s'), g('y'), g('has_x2'), g('has_y'))
+    calls = []
+    real = K.recon_rows
+    K.recon_rows = lambda *a, **kw: (calls.append(kw.get('bias') is not None), real(*a, **kw))[1]
+    try:
+        got, _ = model.evaluate_performance_on_dataset(va)
+    finally:
+        K.recon_rows = real
+    assert F._EvalGraph.get(model, va) is not None
+    assert (len(calls) > 0 and all(calls)) == (X <= K.RECON_ROWS_MAX_X)       # (one pass, raw heads) only up to 1024 genes
+    for k, v in ref.items():
+        if k in ('losses', 'model_class'):
+            continue
+        assert (np.isnan(v) and np.isnan(got[k])) or abs(got[k] - v) <= 2e-6 * max(1.0, abs(v)), (k, got[k], v)
+
+
+@pytest.mark.gpu
 def test_captured_evaluation_follows_the_engine(dev):
     """round-4 advisor (medium): the captured evaluation points into the engine's arena / plans; ``.cpu().cuda()`` retires
     the engine (DGMMixin._apply), so the cached graph must go with it -- evaluate, move the model away and back, train,
