@@ -241,6 +241,7 @@ class FusedStep(StepSchedule):
         # (PVAE: its side chain would be the two KL row launches; as a graph branch next to the decoder they cost more
         # than they hide: cfg 1 0.167 -> 0.175 ms)
         self.branch = _Branch(self.dev, enabled=concurrent and cfg.has_y)
+        self.concurrent = bool(concurrent)
         self.wbranch = _Branch(self.dev, enabled=concurrent and bool(T.get('wbranch')))   # measured slower on MI355X (third graph branch): off
         self._build_layers()
 
@@ -513,6 +514,8 @@ class FusedStep(StepSchedule):
         mode = self._mode()
         if mode == 5:
             two = cfg.has_pert                      # flag 0: z1 samples final; flag 2: z2Fz1 samples final
+            if rec == 'side' and not cfg.has_y:
+                return              # (PVAE: the side chain is the step's tail only, see ``_side_graph_tail``)
             if rec == 'side':
                 w0 = (self.flags[0:1], self.side_ctr, self.sync_err[2:4])
                 w2 = (self.flags[2:3], self.side_ctr, self.sync_err[4:6])
@@ -534,7 +537,9 @@ class FusedStep(StepSchedule):
             pub = None
         self._decoder_forward(pub)
         if mode == 5:
-            if self._klz2_on_main() and cfg.has_pert and Np:
+            if cfg.kind == 'pvae':      # (its KL rows against the prior: the main chain's own, the backward reads their raw values)
+                K.kl_rows_fwd(p.KLP, p.KLPraw, Qmu, Qlv, prior=(0.0, 0.0), free_bits=True, kl_min=cfg.kl_min)
+            if (self._klz2_on_main() or not cfg.has_y) and cfg.has_pert and Np:
                 P2 = p.c_z2F.out[-1]
                 K.kl_rows_fwd(p.KLZ2, p.KLZ2raw, Qmu, Qlv, P2[:, :Z1], P2[:, Z1:], qidx=p.qz2_idx, pidx=p.pidx,
                               reps=L, free_bits=True, kl_min=cfg.kl_min)
@@ -809,13 +814,28 @@ class FusedStep(StepSchedule):
         if getattr(self, '_side_graph', None) is not None and self.dev.type == 'cuda':
             torch.cuda.current_stream().wait_stream(self.flag_side)
 
+    def _dual_capable(self):
+        """may this model's train step run as two flag-ordered graphs?  With a classifier the side chain is the fprop /
+        classifier chain and the step's tail; PVAE (no classifier) has only the tail to give it -- the decoder heads' half of
+        the optimiser sweep, the loss scalars, the next step's noise (cfg 1: 20 serial launches -> 16 + a 4-launch tail)"""
+        cfg = self.cfg
+        if cfg.has_y:
+            return self.branch.on
+        return bool(cfg.kind == 'pvae' and self.concurrent and T.get('pvae_tail') and self.late_leaf and self.side_adam
+                    and cfg.optim_alg == 'adam' and self.fold_join)
+
+    def _late_ok(self):
+        """the side chain carries the step's leaf work (classifier dW, heads' optimiser half, loss scalars) behind the join"""
+        cfg = self.cfg
+        return bool(self.late_leaf and not cfg.cont and cfg.optim_alg == 'adam'
+                    and (self.clf_small if cfg.has_y else self._dual_capable()))
+
     def _tail_gated(self):
         """dual-graph train step (ONE pair of graphs) whose side chain runs its half of the optimiser sweep and the loss
         scalars behind the join: the optimiser launch gates on the classifier's gradient only, and the NEXT step's first
         launch waits for the tail's end"""
         cfg = self.cfg
-        if not (self._mode() == 5 and self.late_leaf and cfg.has_y and not cfg.cont and self.clf_small
-                and cfg.optim_alg == 'adam' and not getattr(self, '_split_kind', False) and T.get('tail_gate')):
+        if not (self._mode() == 5 and self._late_ok() and not getattr(self, '_split_kind', False) and T.get('tail_gate')):
             return False
         if not self._side_adam_layout()[0]:     # (= ``side_adam`` of backward(): the tail then holds the flag-4 wait launch)
             return False
@@ -948,8 +968,7 @@ class FusedStep(StepSchedule):
         # leaf work may still move behind the join (only the optimiser half cannot: it follows the exchange); the
         # overlapped / captured exchanges keep everything in front of the join
         split_kind = getattr(self, '_split_kind', False)
-        late = (mode == 5 and self.late_leaf and cfg.has_y and not cfg.cont and self.clf_small
-                and cfg.optim_alg == 'adam' and split_kind in (False, True))
+        late = mode == 5 and self._late_ok() and split_kind in (False, True)
         leaf = []
         # ... and HALF of the optimiser sweep moves there too: the decoder heads (the tail of the arena, half of
         # all parameters) are final and no longer read once the heads' backward products are through -- the
@@ -1012,9 +1031,12 @@ class FusedStep(StepSchedule):
         elif mode == 3:         # (the step / Philox counters ride on this launch: two launches less in front of the optimiser)
             self._loss_scalars(bump_counters=True)
         if mode == 5 and late and not split_kind:      # (the step counter is advanced before the optimiser launch: counter + 0 by then)
-            lc = self.L_clf[0]
-            lo = min(lc.dW.storage_offset(), lc.db.storage_offset()) - g0
-            hi = max(lc.dW.storage_offset() + span(lc.dW), lc.db.storage_offset() + lc.db.numel()) - g0
+            if cfg.has_y:
+                lc = self.L_clf[0]
+                lo = min(lc.dW.storage_offset(), lc.db.storage_offset()) - g0
+                hi = max(lc.dW.storage_offset() + span(lc.dW), lc.db.storage_offset() + lc.db.numel()) - g0
+            else:       # (no classifier, no leaf gradient in flight: the first workgroup's elements stand in for the slice --
+                lo, hi = 0, 4       # the gate is what orders the NEXT step behind the side chain's tail, see ``_tail_gated``)
             self._adam_gate = (self.flags[6:7] if self._tail_gated() else self.flags[3:4], self.step_dev, 0,
                                self.sync_err[6:8], lo, hi)
             self._adam_n = hs if side_adam else None
@@ -1191,7 +1213,7 @@ class FusedStep(StepSchedule):
             self._rng_pending = 0
         else:
             K.counter_add(self.step_dev, 1)
-        if self._rec == 'both' and self.sched == 5 and cfg.has_y:       # (no classifier: never a dual-graph step)
+        if self._rec == 'both' and self.sched == 5 and self._dual_capable():
             # eager step: the side chain's counters follow, and so does the "side chain's tail is through" flag that the
             # NEXT captured step's first launch waits for (published on entry: counter + 1 = the advanced value)
             K.counters_add2(self.side_ctr, 1, self.side_t, 1, publish=(self.flags[3:4], self.side_ctr, 1))

@@ -161,12 +161,16 @@ class StepSchedule:
         # two flag-ordered graphs only for the latency-bound steps: once the decoder products alone fill the chip many
         # times over (wide configuration) the side chain's small kernels, squeezed in between the resident GEMM
         # workgroups of a second queue, cost more than they hide (36.7 ms dual, 35.9 ms as one graph with a fork/join)
-        dual = self.sched == 5 and self.branch.on and self.cfg.has_y and self._latency_bound() and self._flags_usable()
+        dual = self.sched == 5 and self._dual_capable() and self._latency_bound() and self._flags_usable()
+        if dual and not self.cfg.has_y and split_for_allreduce:
+            # PVAE's side chain is the step's tail only (optimiser half, loss scalars, noise): under a gradient exchange
+            # the optimiser half cannot move there and the rest does not pay for the second graph (one-rank RCCL, cfg 1:
+            # 0.1848 -> 0.1913 split, 0.1695 -> 0.1737 captured)
+            dual = False
         self._split_capture = bool(split_for_allreduce)
         self._split_kind = split_for_allreduce          # False | True (two graphs) | 'overlap' | 'captured'
         cfg = self.cfg
-        self.noise_ahead = bool(dual and split_for_allreduce in (False, True) and self.late_leaf and not cfg.cont and self.clf_small
-                                and cfg.optim_alg == 'adam' and T.get('noise_ahead'))
+        self.noise_ahead = bool(dual and split_for_allreduce in (False, True) and self._late_ok() and T.get('noise_ahead'))
         self._noise_stale = True
         if dual:
             self._rec = 'main'
@@ -217,7 +221,11 @@ class StepSchedule:
         # only for latency-bound steps: once the decoder products alone fill the chip many times over
         # (wide configuration) the main chain needs every CU (measured: 52 ms -> 66 ms/step when masked)
         small = self._latency_bound()
-        return bool(self.branch.on and self.sched == 5 and self.cfg.has_y and small and
+        # (a model without a classifier -- PVAE's tail-only side chain -- only once its step IS captured as two graphs:
+        # under a gradient exchange it is not, and a masked main stream would only cost it CUs)
+        if not self.cfg.has_y and self._side_graph is None:
+            return False
+        return bool(self.sched == 5 and self._dual_capable() and small and
                     int(os.environ.get('DRVAE_SIDE_CUS', '64')) > 0)
 
     def _part_streams(self, n_side):

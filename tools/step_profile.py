@@ -71,6 +71,23 @@ def main():
     print('single-stream graph, main-stream launches only : %.1f us' % timed_graph([f for _, s, f in rec if not s]))
     print('single-stream graph, side-stream launches only : %.1f us' % timed_graph([f for _, s, f in rec if s]))
     print('single-stream graph, all launches in order     : %.1f us' % timed_graph([f for _, _, f in rec]))
+    if os.environ.get('STEP_PROFILE_DROP'):
+        # upper bound of an offload: the main chain WITHOUT the named launches (as if another chain ran them), on the
+        # whole chip and on what a reserve of 32 / 64 CUs would leave it
+        drop = set(os.environ['STEP_PROFILE_DROP'].split(','))
+        kept = [f for (nm, sd, f) in rec if not sd and nm not in drop]
+        gone = [f for (nm, sd, f) in rec if not sd and nm in drop]
+        print('main chain without %s: %.1f us (%d launches); the dropped ones alone: %.1f us' % (
+            sorted(drop), timed_graph(kept), len(kept), timed_graph(gone)))
+        for n in (32, 64):
+            pair = eng._part_streams(n)
+            if pair is None:
+                continue
+            with torch.cuda.stream(pair[0]):
+                a = timed_graph(kept)
+            with torch.cuda.stream(pair[1]):
+                b = timed_graph(gone)
+            print('  ... on %d CUs: %.1f us; the dropped ones on the %d-CU reserve: %.1f us' % (256 - n, a, n, b))
     if os.environ.get('STEP_PROFILE_MASKS'):
         # the side chain's launches under a CU mask (the reserve of partition()): per launch and as one graph
         for n in [int(x) for x in os.environ['STEP_PROFILE_MASKS'].split(',')]:
