@@ -46,3 +46,20 @@ for ep in range(5):
     model._epoch_device(bat, ep, False)
 sync()
 print('whole _epoch_device: %.3f ms' % ((time.perf_counter() - t0) / 5 * 1e3))
+# ... and with the whole-set evaluations of fit between the epochs (epochs numbered as fit numbers them: the index table of the
+# next epoch is drawn ahead behind the running steps)
+va = dataset(2048, 2, dev)
+model.epochs = 100
+for ep in range(3):
+    model._epoch_device(bat, ep + 1, False); model.evaluate_performance_on_dataset(tr); model.evaluate_performance_on_dataset(va)
+sync()
+for label, ev in (('epochs back to back (draw-ahead)', False), ('epochs with the two evaluations in between', True)):
+    tt = []
+    for ep in range(6):
+        sync(); t0 = time.perf_counter()
+        model._epoch_device(bat, ep + 4, False)
+        sync(); t1 = time.perf_counter()
+        if ev:
+            model.evaluate_performance_on_dataset(tr); model.evaluate_performance_on_dataset(va)
+        tt.append((t1 - t0) * 1e3)
+    print('%-46s _epoch_device %.3f ms (min %.3f)' % (label, sorted(tt)[len(tt) // 2], min(tt)))
