@@ -405,7 +405,7 @@ __device__ __forceinline__ float nll_raw_term(float shift, float xv, float mraw,
 }
 
 // RAW (evaluation passes behind a plain heads product, round 5): mu / sd are the raw products, finished on the way
-template <bool VEC4, bool RAW>
+template <int VEC, bool RAW>
 __global__ __launch_bounds__(256) void nll_rows_fwd_kernel(const float* __restrict__ x, int64_t ldx,
                                                            const int32_t* __restrict__ xidx,
                                                            const float* __restrict__ mu,
@@ -423,7 +423,7 @@ __global__ __launch_bounds__(256) void nll_rows_fwd_kernel(const float* __restri
             if constexpr (RAW) return nll_raw_term(shift, xv, m, sv, bias_mu[g], bias_sd[g]);
             else return nll_term(mode, xv, m, sv);
         };
-        if (VEC4) {
+        if constexpr (VEC == 4) {
             const int X4 = X >> 2;
             for (int c = lane; c < X4; c += 64) {
                 const float4 xv = reinterpret_cast<const float4*>(xr)[c];
@@ -433,9 +433,28 @@ __global__ __launch_bounds__(256) void nll_rows_fwd_kernel(const float* __restri
                      term(xv.z, mv.z, sv.z, 4 * c + 2) + term(xv.w, mv.w, sv.w, 4 * c + 3);
             }
             for (int g = (X4 << 2) + lane; g < X; g += 64) s += term(xr[g], mr[g], sr[g], g);
+        } else if constexpr (VEC == 2) {
+            // (978-gene rows: the sigma half starts 8 B off a 16-B boundary -- 8-B loads, two pairs per trip; dword loads
+            // hold a row pass at 3.9 TB/s, round 5)
+            const int X2 = X >> 1;
+            auto pair = [&](int c) -> float {
+                const float2 xv = reinterpret_cast<const float2*>(xr)[c];
+                const float2 mv = reinterpret_cast<const float2*>(mr)[c];
+                const float2 sv = reinterpret_cast<const float2*>(sr)[c];
+                if constexpr (RAW) {
+                    const float2 bm = reinterpret_cast<const float2*>(bias_mu)[c];
+                    const float2 bs = reinterpret_cast<const float2*>(bias_sd)[c];
+                    return nll_raw_term(shift, xv.x, mv.x, sv.x, bm.x, bs.x) + nll_raw_term(shift, xv.y, mv.y, sv.y, bm.y, bs.y);
+                } else {
+                    return nll_term(mode, xv.x, mv.x, sv.x) + nll_term(mode, xv.y, mv.y, sv.y);
+                }
+            };
+            int c = lane;
+            for (; c + 64 < X2; c += 128) s += pair(c) + pair(c + 64);
+            for (; c < X2; c += 64) s += pair(c);
+            if ((X & 1) && lane == 0) s += term(xr[X - 1], mr[X - 1], sr[X - 1], X - 1);
         } else {
-            // (four independent elements per trip: the scalar path serves 978-gene rows, whose sigma half starts 8 B
-            // off a 16-B boundary)
+            // (four independent elements per trip)
             int g = lane;
             for (; g + 192 < X; g += 256)
                 s += (term(xr[g], mr[g], sr[g], g) + term(xr[g + 64], mr[g + 64], sr[g + 64], g + 64)) +
@@ -1631,7 +1650,7 @@ __global__ __launch_bounds__(64 * kCmRG) void col_moments_kernel(const float* __
 
 // dv_recon_row_stats + the log-likelihood rows in ONE pass over (x, mu, sd) for rows of up to 1024 columns (whole-set
 // evaluation: 978 genes): a wave holds its row in registers (16 columns per lane), the centred second pass costs no
-// memory traffic.  Same outputs and summation orders as recon_row_stats_kernel / nll_rows_fwd_kernel's scalar path.
+// memory traffic.  Same outputs (and, on the dword path, summation orders) as recon_row_stats_kernel / nll_rows_fwd_kernel.
 // RAW: mu / sd are the heads' raw products, finished on the way (mu + bias_mu, softplus(sd + bias_sd) + shift) -- the
 // decoder's heads of the inference pass run as a plain product.
 constexpr int kRcG = 16;
@@ -1642,36 +1661,58 @@ struct RcArgs {
     float* rows; float* ll;
 };
 
-template <bool RAW>
+// V2: 8-B loads -- a lane holds the column PAIRS lane + 64 k (even X, 8-B aligned rows); element e of the lane's registers is
+// column 2 (lane + 64 (e / 2)) + e % 2
+template <bool RAW, bool V2>
 __global__ __launch_bounds__(256) void recon_rows_kernel(RcArgs a) {
     const int lane = threadIdx.x & 63;
     const int X = a.X;
+    auto col = [lane](int e) { return V2 ? 2 * (lane + 64 * (e >> 1)) + (e & 1) : lane + 64 * e; };
     for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < a.M; i += gridDim.x * 4) {
         const float* xr = a.x + (int64_t)i * a.ldx;
         const float* mr = a.mu + (int64_t)i * a.ldp;
         const float* sr = a.sd + (int64_t)i * a.ldp;
         float av[kRcG], bv[kRcG], tv[kRcG];
+        auto elem = [&](int k, float xv, float m, float sv, float bm, float bs) {
+            av[k] = xv;
+            if constexpr (RAW) {
+                bv[k] = m + bm;
+                tv[k] = nll_raw_term(a.shift, xv, m, sv, bm, bs);
+            } else {
+                bv[k] = m;
+                tv[k] = nll_term(DV_GAUSS_SIGMA, xv, m, sv);
+            }
+        };
 #pragma unroll
-        for (int k = 0; k < kRcG; ++k) {
-            const int g = lane + 64 * k;
-            av[k] = bv[k] = tv[k] = 0.f;
-            if (g < X) {
-                const float xv = xr[g], m = mr[g], sv = sr[g];
-                av[k] = xv;
-                if constexpr (RAW) {
-                    const float bm = a.bias_mu[g];
-                    bv[k] = m + bm;
-                    tv[k] = nll_raw_term(a.shift, xv, m, sv, bm, a.bias_sd[g]);
-                } else {
-                    bv[k] = m;
-                    tv[k] = nll_term(DV_GAUSS_SIGMA, xv, m, sv);
+        for (int k = 0; k < kRcG; ++k) av[k] = bv[k] = tv[k] = 0.f;
+        if constexpr (V2) {
+#pragma unroll
+            for (int k = 0; k < kRcG / 2; ++k) {
+                const int c = lane + 64 * k;
+                if (2 * c < X) {        // (X even: the pair is whole)
+                    const float2 xv = reinterpret_cast<const float2*>(xr)[c];
+                    const float2 mv = reinterpret_cast<const float2*>(mr)[c];
+                    const float2 sv = reinterpret_cast<const float2*>(sr)[c];
+                    float2 bm = make_float2(0.f, 0.f), bs = make_float2(0.f, 0.f);
+                    if constexpr (RAW) {
+                        bm = reinterpret_cast<const float2*>(a.bias_mu)[c];
+                        bs = reinterpret_cast<const float2*>(a.bias_sd)[c];
+                    }
+                    elem(2 * k, xv.x, mv.x, sv.x, bm.x, bs.x);
+                    elem(2 * k + 1, xv.y, mv.y, sv.y, bm.y, bs.y);
                 }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < kRcG; ++k) {
+                const int g = lane + 64 * k;
+                if (g < X) elem(k, xr[g], mr[g], sr[g], RAW ? a.bias_mu[g] : 0.f, RAW ? a.bias_sd[g] : 0.f);
             }
         }
         float sx = 0.f, sb = 0.f, sse = 0.f, sl = 0.f;
 #pragma unroll
         for (int k = 0; k < kRcG; ++k)
-            if (lane + 64 * k < X) {
+            if (col(k) < X) {
                 sx += av[k];
                 sb += bv[k];
                 sse += (av[k] - bv[k]) * (av[k] - bv[k]);
@@ -1679,12 +1720,12 @@ __global__ __launch_bounds__(256) void recon_rows_kernel(RcArgs a) {
         // (the log-likelihood terms in the order of nll_rows_fwd_kernel's scalar path: four per trip while four fit)
 #pragma unroll
         for (int k = 0; k < kRcG; k += 4) {
-            if (lane + 64 * (k + 3) < X) {
+            if (col(k + 3) < X && col(k) < X) {
                 sl += (tv[k] + tv[k + 1]) + (tv[k + 2] + tv[k + 3]);
             } else {
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    if (lane + 64 * (k + q) < X) sl += tv[k + q];
+                    if (col(k + q) < X) sl += tv[k + q];
             }
         }
         sx = dv_wave_sum_all(sx);
@@ -1695,7 +1736,7 @@ __global__ __launch_bounds__(256) void recon_rows_kernel(RcArgs a) {
         float cxx = 0.f, cbb = 0.f, cxb = 0.f;
 #pragma unroll
         for (int k = 0; k < kRcG; ++k)
-            if (lane + 64 * k < X) {
+            if (col(k) < X) {
                 const float p = av[k] - mx, q = bv[k] - mb;
                 cxx += p * p;
                 cbb += q * q;
@@ -2395,22 +2436,22 @@ extern "C" int dv_gauss_nll_rows_fwd(const float* x, int64_t ldx, const int32_t*
     DV_REQUIRE(x && mu && sd && out && ((bias_mu == nullptr) == (bias_sd == nullptr)));
     DV_REQUIRE(bias_mu == nullptr || mode == DV_GAUSS_SIGMA);      // (raw heads: the sigma head = softplus + shift)
     const bool v4 = aligned16(x) && aligned16(mu) && aligned16(sd) && (ldx % 4 == 0) && (ldp % 4 == 0);
+    auto a8 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7) == 0; };
+    const bool v2 = a8(x) && a8(mu) && a8(sd) && (ldx % 2 == 0) && (ldp % 2 == 0) && (!bias_mu || (a8(bias_mu) && a8(bias_sd)));
     const dim3 grid(grid_for(M, 4, 8192)), block(256);
+#define DV_NLL_FWD(VEC, RAW)                                                                                             \
+    hipLaunchKernelGGL((nll_rows_fwd_kernel<VEC, RAW>), grid, block, 0, ST(stream), x, ldx, xidx, mu, sd, ldp, M, X, mode, \
+                       out, bias_mu, bias_sd, sd_shift)
     if (bias_mu) {
-        if (v4)
-            hipLaunchKernelGGL((nll_rows_fwd_kernel<true, true>), grid, block, 0, ST(stream), x, ldx, xidx, mu, sd, ldp, M, X,
-                               mode, out, bias_mu, bias_sd, sd_shift);
-        else
-            hipLaunchKernelGGL((nll_rows_fwd_kernel<false, true>), grid, block, 0, ST(stream), x, ldx, xidx, mu, sd, ldp, M, X,
-                               mode, out, bias_mu, bias_sd, sd_shift);
-        DV_RETURN_LAUNCH();
+        if (v4) DV_NLL_FWD(4, true);
+        else if (v2) DV_NLL_FWD(2, true);
+        else DV_NLL_FWD(1, true);
+    } else {
+        if (v4) DV_NLL_FWD(4, false);
+        else if (v2) DV_NLL_FWD(2, false);
+        else DV_NLL_FWD(1, false);
     }
-    if (v4)
-        hipLaunchKernelGGL((nll_rows_fwd_kernel<true, false>), grid, block, 0, ST(stream), x, ldx, xidx, mu, sd, ldp, M, X,
-                           mode, out, bias_mu, bias_sd, sd_shift);
-    else
-        hipLaunchKernelGGL((nll_rows_fwd_kernel<false, false>), grid, block, 0, ST(stream), x, ldx, xidx, mu, sd, ldp, M, X,
-                           mode, out, bias_mu, bias_sd, sd_shift);
+#undef DV_NLL_FWD
     DV_RETURN_LAUNCH();
 }
 
@@ -2830,10 +2871,16 @@ extern "C" int dv_recon_rows(const dv_recon_rows_desc* dsc, dv_stream_t stream) 
     DV_REQUIRE((d.bias_mu == nullptr) == (d.bias_sd == nullptr));
     RcArgs a{d.x, d.ldx, d.mu, d.sd, d.ldp, d.bias_mu, d.bias_sd, d.sd_shift, d.M, d.X, d.rows, d.ll};
     const dim3 grid(grid_for(d.M, 4, 8192)), block(256);
-    if (d.bias_mu)
-        hipLaunchKernelGGL((recon_rows_kernel<true>), grid, block, 0, ST(stream), a);
-    else
-        hipLaunchKernelGGL((recon_rows_kernel<false>), grid, block, 0, ST(stream), a);
+    auto a8 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7) == 0; };
+    const bool v2 = d.X % 2 == 0 && d.ldx % 2 == 0 && d.ldp % 2 == 0 && a8(d.x) && a8(d.mu) && a8(d.sd) &&
+                    (!d.bias_mu || (a8(d.bias_mu) && a8(d.bias_sd)));
+    if (d.bias_mu) {
+        if (v2) hipLaunchKernelGGL((recon_rows_kernel<true, true>), grid, block, 0, ST(stream), a);
+        else hipLaunchKernelGGL((recon_rows_kernel<true, false>), grid, block, 0, ST(stream), a);
+    } else {
+        if (v2) hipLaunchKernelGGL((recon_rows_kernel<false, true>), grid, block, 0, ST(stream), a);
+        else hipLaunchKernelGGL((recon_rows_kernel<false, false>), grid, block, 0, ST(stream), a);
+    }
     DV_RETURN_LAUNCH();
 }
 

@@ -723,8 +723,8 @@ int dv_col_moments(const float* x, int64_t ldx, const float* r, int64_t ldr, int
 /* `r_bias` (X, optional, round 5): r holds a RAW heads product, r + r_bias is the reconstruction.
  * dv_recon_rows: dv_recon_row_stats AND the Gaussian log-likelihood rows (dv_gauss_nll_rows_fwd, SIGMA mode) in ONE pass
  * over (x, mu, sd) for rows of up to DV_RECON_ROWS_MAX_X columns -- the whole-set evaluation's 978 genes: a wave holds its
- * row in registers.  Same outputs (bitwise; the log-likelihood in the order of the scalar row pass): rows (M, 6), ll (M,
- * optional).  bias_mu / bias_sd (both or neither): mu / sd are the heads' RAW products and are finished on the way
+ * row in registers.  Same outputs: rows (M, 6), ll (M, optional) -- bitwise those of dv_recon_row_stats on the dword path
+ * (odd X or unaligned rows); rows of even width are read with 8-B loads (a lane owns column pairs: another summation order).  bias_mu / bias_sd (both or neither): mu / sd are the heads' RAW products and are finished on the way
  * (mu + bias_mu, softplus(sd + bias_sd) + sd_shift).  X beyond the limit: DV_ERR_UNSUPPORTED (callers take the two
  * separate passes). */
 #define DV_RECON_ROWS_MAX_X 1024
