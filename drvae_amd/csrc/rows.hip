@@ -1004,6 +1004,143 @@ __global__ __launch_bounds__(256) void smalln_fwd_kernel(const float* __restrict
     }
 }
 
+// The same launch for the train step's common case -- two classes, [z1 | z2F - z1] of <= 256 columns, latent widths <= 128 --
+// with every operand in flight before the first result is formed (round 5).  The generic kernel above walks
+// [fp_ptr -> qidx -> KL rows -> reduce] per fprop row, then the classifier's operands, then re-reads the KL rows for the
+// backward: seven dependent round trips on the side chain's critical path (10.9 us isolated); here three --
+// [classifier operands, fp_ptr] -> [qidx] -> [all KL rows] -- and the backward works from registers.  Same summation orders
+// (the results agree to the rounding of contracted multiply-adds).  cfg 2: 10.9 -> 8.1 us isolated, and -- the side chain in
+// front of the join is the step's critical path -- 0.1906 -> 0.1863 ms per step.
+__global__ __launch_bounds__(256) void smalln_fwd2_kernel(const float* __restrict__ a1, int64_t lda1, int K1,
+                                                          const float* __restrict__ a2, int64_t lda2, int K2,
+                                                          const float* __restrict__ W, int64_t ldw,
+                                                          const float* __restrict__ bias, int M, int N,
+                                                          float* __restrict__ logits, int64_t ldl,
+                                                          float* __restrict__ probs, int64_t ldp, dv_ymarg ym,
+                                                          ParkArgs park, dv_fprop_kl kf) {
+    park_block(park);
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= M) return;
+    const int Kt = K1 + K2, Z1 = kf.Z1, Z3 = kf.Z3;
+    // ---- round trip 1: the classifier's operands and the row's fprop range
+    float xs[4], w0[4], w1[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int k = lane + 64 * c;
+        xs[c] = w0[c] = w1[c] = 0.f;
+        if (k < Kt) {
+            xs[c] = k < K1 ? a1[(int64_t)r * lda1 + k] : a2[(int64_t)r * lda2 + (k - K1)];
+            w0[c] = W[k];
+            if (N > 1) w1[c] = W[ldw + k];
+        }
+    }
+    const int f0 = ym.fp_ptr[r];
+    int nf = ym.fp_ptr[r + 1] - f0;
+    nf = nf < 2 ? nf : 2;                       // (one fprop row for a labeled row, one per class otherwise; N <= 2)
+    // ---- round trip 2: which q row each fprop row reads
+    int qi[2] = {0, 0};
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+        if (u < nf) qi[u] = kf.qidx[f0 + u];
+    // ---- round trip 3: the KL rows
+    float qm[2][2], ql[2][2], pm[2][2], pl[2][2], tm[2][2], tl[2][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int d = lane + 64 * c;
+            qm[u][c] = ql[u][c] = pm[u][c] = pl[u][c] = tm[u][c] = tl[u][c] = 0.f;
+            if (u < nf) {
+                const int t = f0 + u;
+                if (d < Z1) {
+                    const float* q = kf.mu_q + (int64_t)qi[u] * kf.ldq;
+                    const float* pp = kf.mu_p + (int64_t)t * kf.ldp;
+                    qm[u][c] = q[d]; ql[u][c] = q[Z1 + d]; pm[u][c] = pp[d]; pl[u][c] = pp[Z1 + d];
+                }
+                if (d < Z3) {
+                    const float* q3 = kf.mu3 + (int64_t)t * kf.ld3;
+                    tm[u][c] = q3[d]; tl[u][c] = q3[Z3 + d];
+                }
+            }
+        }
+    // ---- the fprop rows' KL terms
+    float raw1[2] = {0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        if (u >= nf) break;
+        float s1 = 0.f, s3 = 0.f;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            if (lane + 64 * c < Z1) s1 += kl_term(DV_GAUSS_LOGVAR, qm[u][c], ql[u][c], pm[u][c], pl[u][c]);
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            if (lane + 64 * c < Z3) s3 += kl_term(DV_GAUSS_LOGVAR, tm[u][c], tl[u][c], 0.f, 0.f);
+        }
+        s1 = dv_wave_sum_all(s1);
+        s3 = dv_wave_sum_all(s3);
+        raw1[u] = -0.5f * s1;
+        if (lane == 0) {
+            const int t = f0 + u;
+            kf.raw1[t] = raw1[u];
+            kf.raw3[t] = -0.5f * s3;
+            kf.klfp[t] = fmaxf(raw1[u], kf.kl_min) + fmaxf(-0.5f * s3, kf.kl_min);
+        }
+    }
+    // ---- the classifier and the y-marginalisation
+    float acc[kMaxSmallN];
+#pragma unroll
+    for (int j = 0; j < kMaxSmallN; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+        if (lane + 64 * c < Kt) {
+            acc[0] += xs[c] * w0[c];
+            if (N > 1) acc[1] += xs[c] * w1[c];
+        }
+    acc[0] = dv_wave_sum_all(acc[0]);
+    acc[1] = dv_wave_sum_all(acc[1]);
+    if (lane == 0) {
+        float mx = -3.4e38f;
+        for (int j = 0; j < N; ++j) {
+            acc[j] += bias ? bias[j] : 0.f;
+            if (logits) logits[(int64_t)r * ldl + j] = acc[j];
+            mx = fmaxf(mx, acc[j]);
+        }
+        float den = 0.f;
+        for (int j = 0; j < N; ++j) den += expf(acc[j] - mx);
+        float q[kMaxSmallN];
+        for (int j = 0; j < N; ++j) {
+            q[j] = fminf(fmaxf(expf(acc[j] - mx) / den, kPMin), kPMax);
+            probs[(int64_t)r * ldp + j] = q[j];
+        }
+        ymarg_row(ym, r, N, q, acc);         // (acc: reused for the fprop rows' coefficients)
+    }
+    // ---- backward of the z1 term with those coefficients (lane 0 holds them), from the registers
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        if (u >= nf) break;
+        const int t = f0 + u;
+        float c = __shfl(acc[u], 0, 64);
+        c *= raw1[u] > kf.kl_min ? 1.f : (raw1[u] == kf.kl_min ? 0.5f : 0.f);
+        float* dq = kf.dq + (int64_t)t * kf.lddq;
+        float* dp = kf.dp + (int64_t)t * kf.lddp;
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+            const int d = lane + 64 * cc;
+            if (d < Z1) {
+                const float mq = qm[u][cc], sq = ql[u][cc], mp = pm[u][cc], sp = pl[u][cc];
+                const float dm = mq - mp, ivp = expf(-sp), vq = expf(sq);
+                const float gmq = dm * ivp, gsq = -0.5f * (1.f - vq * ivp);
+                dq[d] = c * gmq;
+                dq[Z1 + d] = c * gsq;
+                dp[d] = c * -gmq;
+                dp[Z1 + d] = c * (-0.5f * (-1.f + (dm * dm + vq) * ivp));
+            }
+        }
+    }
+}
+
 // d logits of row r from (d probs, probs) through clamp + softmax, see softmax_clamp_bwd_kernel
 __device__ __forceinline__ void smalln_dlogits(const float* g, const float* p, int N, float* dl) {
     float dot = 0.f;
@@ -2604,6 +2741,12 @@ extern "C" int dv_smalln_linear_fwd(const float* a1, int64_t lda1, int32_t K1, c
         kf = *kf_in;
         DV_REQUIRE(ym.fp_ptr != nullptr && kf.klfp == ym.klfp && kf.qidx && kf.mu_p && kf.mu3 && kf.raw1 && kf.raw3 &&
                    kf.dq && kf.dp && kf.Z1 >= 0 && kf.Z3 >= 0);
+    }
+    if (kf.mu_q != nullptr && probs != nullptr && N <= 2 && K1 + K2 <= 256 && kf.Z1 <= 128 && kf.Z3 <= 128) {
+        // (the train step's launch at its common shape: every operand in flight first, see smalln_fwd2_kernel)
+        hipLaunchKernelGGL(smalln_fwd2_kernel, dim3((M + 3) / 4), dim3(256), 0, ST(stream), a1, lda1, K1, a2, lda2, K2, W,
+                           ldw, bias, M, N, logits, ldl, probs, ldp, ym, park, kf);
+        DV_RETURN_LAUNCH();
     }
     hipLaunchKernelGGL(smalln_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, ST(stream), a1, lda1, K1, a2, lda2, K2, W,
                        ldw, bias, M, N, logits, ldl, probs, ldp, ym, park, kf);
