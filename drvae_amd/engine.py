@@ -976,19 +976,6 @@ class FusedStep(StepSchedule):
         g0 = self.arena.grad.storage_offset()
         side_ok, hs = self._side_adam_layout()
         side_adam = late and not split_kind and side_ok
-        pct = T.get('side_adam_pct')
-        if pct < 0:
-            # the two sweeps are balanced against the two chains' TAILS, not against each other: DrVAE's side chain also runs
-            # the classifier's weight gradient, the loss scalars and the next noise behind the join, and the main chain's
-            # optimiser launch waited ~9 us per step for it (cfg 2: 0.1908 -> 0.1891 ms with half of the heads' slice back on
-            # the main chain's sweep; VFAE: no difference; PVAE's tail-only chain: the whole slice is better, 0.1605 / 0.1632)
-            # (with the graph-resident feeds the optimiser launch gates on the leaf gradients only and the NEXT step's feed
-            # launch waits for the tail -- ``_tail_gated`` -- there the whole slice on the side chain is better: epoch feed
-            # 0.1930 / 0.1969, sampler feed 0.2001 / 0.2037)
-            pct = 50 if (cfg.kind == 'drvae' and not self._tail_gated()) else 100
-        if side_adam and pct < 100:
-            n_heads = self.arena.n_live - hs
-            hs += (n_heads * (100 - max(0, pct)) // 100) & ~3
         # the loss scalars (a leaf: only the host / the exchange reads them) are assembled by the side chain behind
         # the join, once the main chain has published that its reconstruction rows are final
         side_loss = side_adam or (late and split_kind is True and len(self.L_decx) > 1 and not self.wbranch.on)
