@@ -147,6 +147,7 @@ SIGNATURES = {
     'dv_z2f_post_bwd': [C.POINTER(Z2F), C.POINTER(Wait), _p],
     'dv_reparam_bwd': [_p, _i64, _p, _i64, _p, _i64, _p, _i32, _i32, _i32, _i32, _p, _p, _i64, _f, _p],
     'dv_kl_rows_fwd': [C.POINTER(KlRows), C.POINTER(Wait), _p],
+    'dv_kl_rows_fwd_pair': [C.POINTER(KlRows), C.POINTER(KlRows), _p],
     'dv_kl_rows_bwd': [C.POINTER(KlRows), C.POINTER(KlRowsGrad), _p],
     'dv_gauss_nll_rows_fwd': [_p, _i64, _p, _p, _p, _i64, _i32, _i32, _i32, _p, _p, _p, _f, _p],
     'dv_gauss_nll_rows_fwdbwd': [_p, _p, _i64, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _f, _p, _p, _p, _i64, _p, _p, _p],

@@ -332,6 +332,45 @@ __global__ __launch_bounds__(256) void kl_rows_fwd_kernel(KlArgs a, int free_bit
     }
 }
 
+// Two independent sets of KL rows in ONE launch (round 5; PVAE's main chain runs KL(q(z1|x) || N(0,I)) and the pairs'
+// KL(q(z2|x2) || p(z2|z1)) back to back: two launches of ~40 workgroups each): workgroups [0, blocks_a) take set a, the rest
+// set b; per row the arithmetic and summation order of kl_rows_fwd_kernel (no fused sample, no second term, no park).
+struct KlFwd {
+    KlArgs k;
+    int free_bits;
+    float kl_min;
+    float* raw_out;
+    float* out;
+    const float* add;
+};
+
+__global__ __launch_bounds__(256) void kl_rows_fwd_pair_kernel(KlFwd sa, KlFwd sb, int blocks_a) {
+    const bool first = (int)blockIdx.x < blocks_a;
+    const KlFwd& s = first ? sa : sb;
+    const KlArgs& a = s.k;
+    const int blk = first ? blockIdx.x : blockIdx.x - blocks_a;
+    const int lane = threadIdx.x & 63;
+    const int rows = a.n * a.reps;
+    const int r = blk * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int j = r % a.n;
+    const int64_t qi = a.qidx ? a.qidx[j] : j;
+    const int64_t pi = a.pidx ? a.pidx[r] : r;
+    float sum = 0.f;
+    for (int d = lane; d < a.Z; d += 64) {
+        const float mq = a.mu_q[qi * a.ldq + d], sq = a.sd_q[qi * a.ldq + d];
+        const float mp = a.mu_p ? a.mu_p[pi * a.ldp + d] : a.prior_mu;
+        const float sp = a.mu_p ? a.sd_p[pi * a.ldp + d] : a.prior_sd;
+        sum += kl_term(a.mode, mq, sq, mp, sp);
+    }
+    sum = dv_wave_sum_all(sum);
+    if (lane == 0) {
+        const float raw = -0.5f * sum;
+        if (s.raw_out) s.raw_out[r] = raw;
+        s.out[r] = (s.free_bits ? fmaxf(raw, s.kl_min) : raw) + (s.add ? s.add[r] : 0.f);
+    }
+}
+
 __global__ void kl_rows_bwd_kernel(KlArgs a, const float* __restrict__ coef, const float* __restrict__ raw,
                                    int free_bits, float kl_min, float* __restrict__ dq_mu,
                                    float* __restrict__ dq_sd, int64_t lddq, float* __restrict__ dp_mu,
@@ -2543,6 +2582,30 @@ extern "C" int dv_kl_rows_fwd(const dv_kl_rows_desc* dsc, const dv_wait* park_in
     hipLaunchKernelGGL(kl_rows_fwd_kernel, dim3(grid_for((int64_t)d.n * d.reps, 4)), dim3(256), 0, ST(stream), a,
                        d.free_bits, d.kl_min, d.raw_out, d.out, d.add, d.eps, d.lde, d.zout, d.ldz, park, d.mu2, d.sd2,
                        d.ld2, d.Z2, d.raw2_out);
+    DV_RETURN_LAUNCH();
+}
+
+static int kl_fwd_of(const dv_kl_rows_desc& d, KlFwd& f) {
+    DV_REQUIRE(d.n >= 0 && d.reps >= 0 && d.Z >= 0 && d.mu_q && d.sd_q && d.out);
+    DV_REQUIRE((d.mu_p == nullptr) == (d.sd_p == nullptr));
+    DV_REQUIRE(d.zout == nullptr && d.eps == nullptr && d.mu2 == nullptr && d.sd2 == nullptr);   // (plain rows only)
+    f = KlFwd{KlArgs{d.mu_q, d.sd_q, d.ldq, d.qidx, d.mu_p, d.sd_p, d.ldp, d.pidx, d.prior_mu, d.prior_sd, d.n, d.reps, d.Z,
+                     d.mode},
+              d.free_bits, d.kl_min, d.raw_out, d.out, d.add};
+    return DV_OK;
+}
+
+extern "C" int dv_kl_rows_fwd_pair(const dv_kl_rows_desc* d1, const dv_kl_rows_desc* d2, dv_stream_t stream) {
+    DV_REQUIRE(d1 != nullptr && d2 != nullptr);
+    KlFwd a, b;
+    int rc = kl_fwd_of(*d1, a);
+    if (rc != DV_OK) return rc;
+    rc = kl_fwd_of(*d2, b);
+    if (rc != DV_OK) return rc;
+    const int64_t ba = ((int64_t)d1->n * d1->reps + 3) / 4, bb = ((int64_t)d2->n * d2->reps + 3) / 4;
+    if (ba + bb == 0) return DV_OK;
+    if (ba + bb > 0x7fffffff) return DV_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(kl_rows_fwd_pair_kernel, dim3((unsigned)(ba + bb)), dim3(256), 0, ST(stream), a, b, (int)ba);
     DV_RETURN_LAUNCH();
 }
 

@@ -537,12 +537,19 @@ class FusedStep(StepSchedule):
             pub = None
         self._decoder_forward(pub)
         if mode == 5:
+            klz2 = (self._klz2_on_main() or not cfg.has_y) and cfg.has_pert and Np
+            P2 = p.c_z2F.out[-1] if klz2 else None
+            z2 = ((p.KLZ2, p.KLZ2raw, Qmu, Qlv, P2[:, :Z1], P2[:, Z1:]),
+                  dict(qidx=p.qz2_idx, pidx=p.pidx, reps=L, free_bits=True, kl_min=cfg.kl_min)) if klz2 else None
             if cfg.kind == 'pvae':      # (its KL rows against the prior: the main chain's own, the backward reads their raw values)
-                K.kl_rows_fwd(p.KLP, p.KLPraw, Qmu, Qlv, prior=(0.0, 0.0), free_bits=True, kl_min=cfg.kl_min)
-            if (self._klz2_on_main() or not cfg.has_y) and cfg.has_pert and Np:
-                P2 = p.c_z2F.out[-1]
-                K.kl_rows_fwd(p.KLZ2, p.KLZ2raw, Qmu, Qlv, P2[:, :Z1], P2[:, Z1:], qidx=p.qz2_idx, pidx=p.pidx,
-                              reps=L, free_bits=True, kl_min=cfg.kl_min)
+                zp = ((p.KLP, p.KLPraw, Qmu, Qlv), dict(prior=(0.0, 0.0), free_bits=True, kl_min=cfg.kl_min))
+                if klz2 and T.get('kl_pair'):                # ... next to the pairs' rows: one launch for both sets
+                    K.kl_rows_fwd_pair(zp, z2)
+                    z2 = None
+                else:
+                    K.kl_rows_fwd(*zp[0], **zp[1])
+            if z2 is not None:
+                K.kl_rows_fwd(*z2[0], **z2[1])
             return             # main-chain graph: the side chain lives in its own graph on the side stream
         with self.branch:
             self._side_forward(Qmu, Qlv, Z1blk)

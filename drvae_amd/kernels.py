@@ -347,6 +347,23 @@ def z2f_post_bwd(dp2, dz1, dq2, dz2f, dzdec_pert, pair_slot, eps, p2, q2, coef, 
 
 
 # --------------------------------------------------------------------------- KL rows
+def _kl_desc(out, raw, mu_q, sd_q, mu_p=None, sd_p=None, *, prior=(0.0, 0.0), mode=GAUSS_LOGVAR, qidx=None, pidx=None,
+             reps=1, free_bits=False, kl_min=0.0, add=None):
+    R = out.numel()
+    assert _ld(mu_q) == _ld(sd_q) and (mu_p is None or _ld(mu_p) == _ld(sd_p))
+    return _lib.KlRows(mu_q=_f32(mu_q), sd_q=_f32(sd_q), ldq=_ld(mu_q), qidx=_i32(qidx), mu_p=_f32(mu_p), sd_p=_f32(sd_p),
+                       ldp=_ld(mu_p), pidx=_i32(pidx), prior_mu=prior[0], prior_sd=prior[1], n=R // reps, reps=reps,
+                       Z=mu_q.shape[1], mode=mode, free_bits=int(free_bits), kl_min=kl_min, raw_out=_f32(raw), out=_f32(out),
+                       add=_f32(add))
+
+
+def kl_rows_fwd_pair(first, second):
+    """two independent sets of plain KL rows in one launch; ``first`` / ``second`` = (args, kwargs) of ``kl_rows_fwd``
+    (no fused sample, no second term, no park)"""
+    d1, d2 = _kl_desc(*first[0], **first[1]), _kl_desc(*second[0], **second[1])
+    _lib.check(_lib.load().dv_kl_rows_fwd_pair(C.byref(d1), C.byref(d2), _stream()), 'dv_kl_rows_fwd_pair')
+
+
 def kl_rows_fwd(out, raw, mu_q, sd_q, mu_p=None, sd_p=None, *, prior=(0.0, 0.0), mode=GAUSS_LOGVAR, qidx=None,
                 pidx=None, reps=1, free_bits=False, kl_min=0.0, add=None, eps=None, zout=None, park=None, second=None):
     """``second`` = (mu2, sd2, raw2): a second, row-aligned term KL(N(mu2, sd2) || N(prior)) with its own free bits is

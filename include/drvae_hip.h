@@ -398,6 +398,9 @@ typedef struct dv_kl_rows_desc {
     float* raw2_out;
 } dv_kl_rows_desc;
 int dv_kl_rows_fwd(const dv_kl_rows_desc* d, const dv_wait* park, dv_stream_t stream);
+/* two independent sets of plain KL rows (no fused sample, no second term) in ONE launch -- PVAE's prior term and the pairs' term
+ * sit back to back on its main chain (round 5) */
+int dv_kl_rows_fwd_pair(const dv_kl_rows_desc* d1, const dv_kl_rows_desc* d2, dv_stream_t stream);
 /* the backward reads the forward's descriptor -- operands, n / reps / Z / mode, free_bits, kl_min, eps / lde, and raw_out
  * as the raw KL the forward stored (required with free_bits); out / add / zout / mu2.. are not looked at -- plus its own
  * outputs (30 positional arguments before ABI 11) */

@@ -373,6 +373,11 @@ def kl_rows_fwd(out, raw, mu_q, sd_q, mu_p=None, sd_p=None, *, prior=(0.0, 0.0),
     out.copy_(v)
 
 
+def kl_rows_fwd_pair(first, second):
+    kl_rows_fwd(*first[0], **first[1])
+    kl_rows_fwd(*second[0], **second[1])
+
+
 def kl_rows_bwd(dq_mu, dq_sd, dp_mu, dp_sd, coef, raw, mu_q, sd_q, mu_p=None, sd_p=None, *, prior=(0.0, 0.0),
                 mode=GAUSS_LOGVAR, qidx=None, pidx=None, reps=1, free_bits=False, kl_min=0.0, beta=0.0, dz=None,
                 eps=None):
@@ -943,7 +948,7 @@ def nll_rows_raw_cs(out_part, dmu, dsd, ws, coef, x, mu, sd, bias, *, xidx=None,
 
 
 FUNCTIONS = ['smalln_ws_numel', 'col_moment_blocks', 'recon_finalize', 'rank_metrics', 'nll_raw_cs_shape', 'nll_rows_raw_cs', 'rec_nll_rows', 'batch_masks', 'fill_normal_rows', 'linear_heads', 'heads_tiles', 'adamax_l2', 'batch_feed', 'mmd_rff_fwd', 'mmd_rff_bwd', 'counters_add2', 'ycont_fwd', 'ycont_bwd', 'flag_publish', 'flag_wait', 'gemm', 'linear_fwd', 'linear_bwd_data', 'linear_bwd_weight', 'linear_bwd_pair', 'colsum', 'act_bwd_', 'wn_scale', 'wn_bwd',
-             'reparam_fwd', 'reparam_bwd', 'reparam_bwd_seg', 'z2f_post_bwd', 'kl_rows_fwd', 'kl_rows_bwd', 'nll_rows_fwd', 'nll_rows_bwd', 'nll_rows_fwdbwd',
+             'reparam_fwd', 'reparam_bwd', 'reparam_bwd_seg', 'z2f_post_bwd', 'kl_rows_fwd', 'kl_rows_fwd_pair', 'kl_rows_bwd', 'nll_rows_fwd', 'nll_rows_bwd', 'nll_rows_fwdbwd',
              'softmax_clamp_fwd', 'softmax_clamp_bwd', 'cat_terms_fwd', 'cat_terms_bwd', 'smalln_fwd', 'smalln_bwd_data',
              'smalln_bwd_weight', 'ymarg_fwd', 'ymarg_bwd', 'ymarg_fwdbwd',
              'rows_gather', 'rows_segment_sum', 'weighted_sum', 'recon_row_stats', 'recon_rows', 'col_moments', 'loss_assemble', 'axpby', 'adam_l2', 'counter_add', 'fill_normal']

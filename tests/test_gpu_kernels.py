@@ -939,6 +939,31 @@ def test_reparam_bwd_seg(K, dev):
         close(dq, rq, rtol=1e-5, atol=1e-5)
 
 
+def test_kl_rows_fwd_pair_is_two_launches(K, dev):
+    """dv_kl_rows_fwd_pair (round 5): two independent sets of KL rows (a prior term over every row, a q || p term over
+    gathered rows with L repetitions) in one launch == the two launches, bitwise"""
+    n, Np, L, Z = 225, 75, 2, 100
+    Q = rnd(dev, n, 2 * Z, seed=1, scale=0.5)
+    P2 = rnd(dev, L * 150, 2 * Z, seed=2, scale=0.5)
+    qidx = (150 + torch.arange(Np)).to(torch.int32).to(dev)
+    pidx = (torch.arange(L)[:, None] * 150 + torch.arange(0, 150, 2)[None, :]).reshape(-1).to(torch.int32).to(dev)
+    a = ((None, None, Q[:, :Z], Q[:, Z:]), dict(prior=(0.0, 0.0), free_bits=True, kl_min=30.0))
+    b = ((None, None, Q[:, :Z], Q[:, Z:], P2[:, :Z], P2[:, Z:]), dict(qidx=qidx, pidx=pidx, reps=L, free_bits=True, kl_min=30.0))
+    outs = []
+    for paired in (False, True):
+        o1, r1 = torch.full((n,), 7.0, device=dev), torch.full((n,), 7.0, device=dev)
+        o2, r2 = torch.full((L * Np,), 7.0, device=dev), torch.full((L * Np,), 7.0, device=dev)
+        fa, fb = ((o1, r1) + a[0][2:], a[1]), ((o2, r2) + b[0][2:], b[1])
+        if paired:
+            K.kl_rows_fwd_pair(fa, fb)
+        else:
+            K.kl_rows_fwd(*fa[0], **fa[1])
+            K.kl_rows_fwd(*fb[0], **fb[1])
+        outs.append((o1, r1, o2, r2))
+    for x, y in zip(*outs):
+        assert torch.equal(x, y)
+
+
 @pytest.mark.parametrize('with_pairs,with_b', [(True, True), (True, False), (False, True)])
 def test_z2f_post_bwd(K, dev, with_pairs, with_b):
     L, B, Z = 2, 19, 100
