@@ -37,6 +37,10 @@ class Wait(C.Structure):       # dv_wait: a device-side wait carried by a launch
     _fields_ = [('flag', _p), ('ctr', _p), ('add', _i32), ('max_spins', _i32), ('err', _p)]
 
 
+class PriorKl(C.Structure):    # dv_prior_kl
+    _fields_ = [('coef', _p), ('raw', _p), ('kl_min', _f), ('mu', _p), ('ld', _i64)]
+
+
 class AdamHyper(C.Structure):  # dv_adam_hyper
     _fields_ = [('lr', _f), ('beta1', _f), ('beta2', _f), ('eps', _f), ('weight_decay', _f), ('gscale', _f)]
 
@@ -106,7 +110,8 @@ class Z2F(C.Structure):          # dv_z2f_desc
     _fields_ = [('dz2f', _p), ('ld_dz2f', _i64), ('dzdec_pert', _p), ('ld_pert', _i64), ('pair_slot', _p), ('eps', _p),
                 ('lde', _i64), ('p2', _p), ('ldp2', _i64), ('q2', _p), ('ldq2', _i64), ('coef', _p), ('raw', _p),
                 ('kl_min', _f), ('dz1b', _p), ('ld_dz1b', _i64), ('dp2', _p), ('ld_dp2', _i64), ('dz1', _p),
-                ('ld_dz1', _i64), ('dq2', _p), ('ld_dq2', _i64), ('L', _i32), ('B', _i32), ('Np', _i32), ('Z', _i32)]
+                ('ld_dz1', _i64), ('dq2', _p), ('ld_dq2', _i64), ('L', _i32), ('B', _i32), ('Np', _i32), ('Z', _i32),
+                ('prior_coef', _p), ('prior_raw', _p)]
 
 
 class ReconRows(C.Structure):    # dv_recon_rows_desc
@@ -143,7 +148,7 @@ SIGNATURES = {
     'dv_reparam_fwd': [_p, _p, _i64, _p, _i32, _i32, _i32, _p, _i64, _i32, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p,
                        _p],
     'dv_reparam_bwd_seg': [_p, _i64, _p, _i64, _p, _i64, _p, _p, _i32, _i32, _i32, _p, _i64, _p, _p, _p, _p, _i64, _f,
-                           C.POINTER(Bump), C.POINTER(SegAdd), C.POINTER(Wait), _p],
+                           C.POINTER(Bump), C.POINTER(SegAdd), C.POINTER(Wait), C.POINTER(PriorKl), _p],
     'dv_z2f_post_bwd': [C.POINTER(Z2F), C.POINTER(Wait), _p],
     'dv_reparam_bwd': [_p, _i64, _p, _i64, _p, _i64, _p, _i32, _i32, _i32, _i32, _p, _p, _i64, _f, _p],
     'dv_kl_rows_fwd': [C.POINTER(KlRows), C.POINTER(Wait), _p],

@@ -180,7 +180,7 @@ __global__ void reparam_bwd_seg_kernel(const float* __restrict__ dz, int64_t ldz
                                        const int32_t* __restrict__ ex_ptr, const int32_t* __restrict__ ex_rows,
                                        float* __restrict__ dmu, float* __restrict__ dsd, int64_t lddq, float beta,
                                        CounterBump bump, const float* __restrict__ dz2, int64_t ldz2, int n2,
-                                       ParkArgs park) {
+                                       ParkArgs park, dv_prior_kl pk) {
     park_block(park);
     // (the counters are not read by this kernel: whoever starts first may advance them)
     if (blockIdx.x == 0 && threadIdx.x == 0) bump_counters(bump);
@@ -205,8 +205,17 @@ __global__ void reparam_bwd_seg_kernel(const float* __restrict__ dz, int64_t ldz
         }
         float* pm = dmu + (int64_t)i * lddq + d;
         float* ps = dsd + (int64_t)i * lddq + d;
-        *pm = (beta != 0.f ? beta * *pm : 0.f) + a;
-        *ps = (beta != 0.f ? beta * *ps : 0.f) + b;
+        float vm = (beta != 0.f ? beta * *pm : 0.f) + a;
+        float vs = (beta != 0.f ? beta * *ps : 0.f) + b;
+        if (pk.coef != nullptr) {       // + d/d(mu, logvar) of coef * max(KL(q_i || N(0,I)), kl_min): what dv_kl_rows_bwd(beta = 1) added
+            const float rv = pk.raw[i];
+            const float c = pk.coef[i] * (rv > pk.kl_min ? 1.f : (rv == pk.kl_min ? 0.5f : 0.f));
+            const float mq = pk.mu[(int64_t)i * pk.ld + d], vq = expf(sd[(int64_t)i * ldq + d]);
+            vm += c * (mq * 1.f);
+            vs += c * (-0.5f * (1.f - vq * 1.f));
+        }
+        *pm = vm;
+        *ps = vs;
     }
 }
 
@@ -229,6 +238,7 @@ struct Z2FArgs {
     float* dz1; int64_t ld_dz1;                // (L*B, Z) in/out (+=)
     float* dq2; int64_t ld_dq2;                // (Np, 2Z) out, or NULL
     int L, B, Np, Z;
+    const float* prior_coef; const float* prior_raw;   // (Np) or NULL: the prior-KL gradient of q2 rides along (dv_prior_kl)
 };
 
 __global__ void z2f_post_bwd_kernel(Z2FArgs a, ParkArgs park) {
@@ -264,6 +274,12 @@ __global__ void z2f_post_bwd_kernel(Z2FArgs a, ParkArgs park) {
             *z1 += dmu + (a.dz1b ? a.dz1b[r * a.ld_dz1b + d] : 0.f);
         }
         if (jp >= 0 && a.dq2) {
+            if (a.prior_coef != nullptr) {      // + the prior term of q(z2|x2) row jp (what dv_kl_rows_bwd(beta = 1) added)
+                const float rv = a.prior_raw[jp];
+                const float c = a.prior_coef[jp] * (rv > a.kl_min ? 1.f : (rv == a.kl_min ? 0.5f : 0.f));
+                gq_mu += c * (mq * 1.f);
+                gq_lv += c * (-0.5f * (1.f - expf(lq) * 1.f));
+            }
             a.dq2[(int64_t)jp * a.ld_dq2 + d] = gq_mu;
             a.dq2[(int64_t)jp * a.ld_dq2 + a.Z + d] = gq_lv;
         }
@@ -2530,8 +2546,10 @@ extern "C" int dv_reparam_bwd_seg(const float* dz, int64_t ldz, const float* eps
                                   int32_t Z, int32_t mode, const float* extra, int64_t ldx, const int32_t* ex_ptr,
                                   const int32_t* ex_rows, float* dmu, float* dsd, int64_t lddq, float beta,
                                   const dv_bump* bump_in, const dv_seg_add* add, const dv_wait* park_in,
-                                  dv_stream_t stream) {
+                                  const dv_prior_kl* prior, dv_stream_t stream) {
     DV_REQUIRE(bump_ok(bump_in) && park_ok(park_in));
+    DV_REQUIRE(prior == nullptr || prior->coef == nullptr || (prior->raw && prior->mu && mode == DV_GAUSS_LOGVAR));
+    const dv_prior_kl pk = prior ? *prior : dv_prior_kl{};
     const CounterBump bump = bump_in ? *bump_in : CounterBump{};
     const ParkArgs park = park_in ? *park_in : ParkArgs{};
     DV_REQUIRE(nq >= 0 && Z >= 0);
@@ -2543,7 +2561,7 @@ extern "C" int dv_reparam_bwd_seg(const float* dz, int64_t ldz, const float* eps
     DV_REQUIRE(extra == nullptr || (ex_ptr && ex_rows));
     hipLaunchKernelGGL(reparam_bwd_seg_kernel, dim3(grid_for((int64_t)nq * Z, 256)), dim3(256), 0, ST(stream), dz,
                        ldz, eps, lde, sd, ldq, seg_ptr, seg_rows, nq, Z, mode, extra, ldx, ex_ptr, ex_rows, dmu, dsd,
-                       lddq, beta, bump, add ? add->dz : nullptr, add ? add->ld : 0, add ? add->n : 0, park);
+                       lddq, beta, bump, add ? add->dz : nullptr, add ? add->ld : 0, add ? add->n : 0, park, pk);
     DV_RETURN_LAUNCH();
 }
 
@@ -2559,9 +2577,10 @@ extern "C" int dv_z2f_post_bwd(const dv_z2f_desc* dsc, const dv_wait* park_in, d
     if (d.L == 0 || d.B == 0 || d.Z == 0) return DV_OK;
     DV_REQUIRE(d.eps && d.p2 && d.dp2 && d.dz1);   // dz2f == NULL: nothing flows into the z2Fz1 samples from a classifier
     DV_REQUIRE(d.Np == 0 || (d.pair_slot && d.q2 && d.coef && d.raw));
+    DV_REQUIRE((d.prior_coef == nullptr) == (d.prior_raw == nullptr));
     Z2FArgs a{d.dz2f, d.ld_dz2f, d.dzdec_pert, d.ld_pert, d.Np ? d.pair_slot : nullptr, d.eps, d.lde, d.p2, d.ldp2,
               d.q2, d.ldq2, d.coef, d.raw, d.kl_min, d.dz1b, d.ld_dz1b, d.dp2, d.ld_dp2, d.dz1, d.ld_dz1, d.dq2,
-              d.ld_dq2, d.L, d.B, d.Np, d.Z};
+              d.ld_dq2, d.L, d.B, d.Np, d.Z, d.Np ? d.prior_coef : nullptr, d.Np ? d.prior_raw : nullptr};
     hipLaunchKernelGGL(z2f_post_bwd_kernel, dim3(grid_for((int64_t)d.B * d.Z, 256)), dim3(256), 0, ST(stream), a, park);
     DV_RETURN_LAUNCH();
 }

@@ -1055,7 +1055,8 @@ class FusedStep(StepSchedule):
             K.z2f_post_bwd(p.DP2, DZ1, DQ[B:] if Np else None, p.DZ2F if cfg.has_y else None,     # (no classifier: no gradient into the z2Fz1 samples but the decoder's)
                            p.DZDEC[p.o3:] if Np else None, p.pair_slot,
                            p.E2F, P2, Q[B:] if Np else None, p.c_klz2, p.KLZ2raw, cfg.kl_min,
-                           p.DZ1B if cfg.has_y else None, L, B, Np, park=park)
+                           p.DZ1B if cfg.has_y else None, L, B, Np, park=park,
+                           prior=(p.c_klp[B:], p.KLPraw[B:]) if (cfg.kind == 'pvae' and Np) else None)
             # perturbation function: mu = z1 + z1 W^T + b, logvar head
             p.c_z2F.backward(p.DP2, [Z1blk], [[(DZ1, 1.0, 1.0)]])
         # (VFAE: the side chain's share of d/dz1 is a second source of the sample backward below, no summing launch of
@@ -1067,10 +1068,11 @@ class FusedStep(StepSchedule):
         fp = cfg.has_y and p.Mf
         K.reparam_bwd_seg(DQ[:B, :Z1], DQ[:B, Z1:], p.DZDEC, p.E12, Qlv, p.zseg_ptr, p.zseg_rows,
                           extra=p.DQFP if fp else None, ex_ptr=p.q_ptr if fp else None,
-                          ex_rows=p.q_rows if fp else None, bump=bump, dz_add=add1)
-        if cfg.kind == 'pvae':
-            K.kl_rows_bwd(DQ[:, :Z1], DQ[:, Z1:], None, None, p.c_klp, p.KLPraw, Qmu, Qlv, prior=(0.0, 0.0),
-                          free_bits=True, kl_min=cfg.kl_min, beta=1.0)
+                          ex_rows=p.q_rows if fp else None, bump=bump, dz_add=add1,
+                          # PVAE's prior term KL(q || N(0,I)) (src/PVAE.py): its gradient rides on the two launches that
+                          # write q's gradient rows (here: rows [0, B); ``z2f_post_bwd``: the pairs' q(z2|x2) rows) instead
+                          # of a dv_kl_rows_bwd launch behind them (cfg 1: one launch less on the critical chain)
+                          prior=(p.c_klp, p.KLPraw, cfg.kl_min, Qmu) if cfg.kind == 'pvae' else None)
         p.c_enc.backward(DQ, p.enc_in, None,
                          publish_first=(self.flags[5:6], self.step_dev, 0) if (late and self.noise_ahead) else None)
 

@@ -317,32 +317,38 @@ def _halt(halt):
 
 
 def reparam_bwd_seg(dmu, dsd, dz, eps, sd, seg_ptr, seg_rows, *, mode=GAUSS_LOGVAR, extra=None, ex_ptr=None,
-                    ex_rows=None, beta=0.0, bump=None, dz_add=None, park=None):
+                    ex_rows=None, beta=0.0, bump=None, dz_add=None, park=None, prior=None):
     """CSR backward of the reparameterisation (+ row-aligned extra (dmu|dsd) rows), see dv_reparam_bwd_seg.
     ``bump``: up to two (counter, inc) the launch advances as well; ``dz_add``: a second gradient source for the first
-    ``dz_add.shape[0]`` sample rows; ``park`` = (flag, ctr, err[, add[, max_spins]]): the launch parks on another chain's flag"""
+    ``dz_add.shape[0]`` sample rows; ``park`` = (flag, ctr, err[, add[, max_spins]]): the launch parks on another chain's flag;
+    ``prior`` = (coef, raw, kl_min, mu): the gradient of coef * max(KL(q_i || N(0,I)), kl_min) is added to row i (dv_prior_kl)"""
     nq, Z = seg_ptr.numel() - 1, dz.shape[1]
     assert _ld(dmu) == _ld(dsd)
     add = None
     if dz_add is not None:
         add = _lib.SegAdd(_f32(dz_add), _ld(dz_add), dz_add.shape[0])
+    pk = None
+    if prior is not None:
+        pk = C.byref(_lib.PriorKl(coef=_f32(prior[0]), raw=_f32(prior[1]), kl_min=prior[2], mu=_f32(prior[3]), ld=_ld(prior[3])))
     _lib.check(_lib.load().dv_reparam_bwd_seg(_f32(dz), _ld(dz), _f32(eps), _ld(eps), _f32(sd), _ld(sd),
                                               _i32(seg_ptr), _i32(seg_rows), nq, Z, mode, _f32(extra), _ld(extra),
                                               _i32(ex_ptr), _i32(ex_rows), _f32(dmu), _f32(dsd), _ld(dmu), beta,
-                                              _bump(bump), C.byref(add) if add is not None else None, _wait(park),
+                                              _bump(bump), C.byref(add) if add is not None else None, _wait(park), pk,
                                               _stream()), 'dv_reparam_bwd_seg')
 
 
 def z2f_post_bwd(dp2, dz1, dq2, dz2f, dzdec_pert, pair_slot, eps, p2, q2, coef, raw, kl_min, dz1b, L, B, Np,
-                 park=None):
+                 park=None, prior=None):
     """fused backward of the z2Fz1 sample / KL(q(z2|x2)||p(z2|z1)) / residual block, see dv_z2f_post_bwd.
-    ``park`` = (flag, ctr, err[, add[, max_spins]]): the launch first parks on another chain's flag."""
+    ``park`` = (flag, ctr, err[, add[, max_spins]]): the launch first parks on another chain's flag.
+    ``prior`` = (coef, raw) of the Np q2 rows: their prior-KL gradient (same kl_min) is added to dq2 (dv_prior_kl)."""
     Z = dp2.shape[1] // 2
     d = _lib.Z2F(dz2f=_f32(dz2f), ld_dz2f=_ld(dz2f), dzdec_pert=_f32(dzdec_pert), ld_pert=_ld(dzdec_pert),
                  pair_slot=_i32(pair_slot), eps=_f32(eps), lde=_ld(eps), p2=_f32(p2), ldp2=_ld(p2), q2=_f32(q2),
                  ldq2=_ld(q2), coef=_f32(coef), raw=_f32(raw), kl_min=kl_min, dz1b=_f32(dz1b), ld_dz1b=_ld(dz1b),
                  dp2=_f32(dp2), ld_dp2=_ld(dp2), dz1=_f32(dz1), ld_dz1=_ld(dz1), dq2=_f32(dq2), ld_dq2=_ld(dq2),
-                 L=L, B=B, Np=Np, Z=Z)
+                 L=L, B=B, Np=Np, Z=Z, prior_coef=_f32(prior[0]) if prior is not None else None,
+                 prior_raw=_f32(prior[1]) if prior is not None else None)
     _lib.check(_lib.load().dv_z2f_post_bwd(C.byref(d), _wait(park), _stream()), 'dv_z2f_post_bwd')
 
 

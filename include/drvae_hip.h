@@ -303,6 +303,16 @@ int dv_reparam_bwd(const float* dz, int64_t ldz, const float* eps, int64_t lde, 
  * `add` (optional, ABI 10): a second gradient source for the first add->n sample rows, g[r] = dz[r] + add->dz[r] for
  * r < add->n (VFAE: the classifier / fprop chain's share of d/dz1, which used to be summed into dz by a launch of its
  * own); `park` (optional): the launch parks on another chain's flag first, like dv_z2f_post_bwd. */
+/* KL(q || N(0, I)) of the launch's OWN q rows with per-row free bits (PVAE's prior term, src/PVAE.py): its gradient w.r.t.
+ * (mu, logvar) -- coef[i] * gate(raw[i]) * (mu, (e^logvar - 1) / 2) -- is added to the row's result on the way out instead
+ * of a dv_kl_rows_bwd launch behind it (round 5).  LOGVAR parameterisation; the log-variances are the launch's own operand. */
+typedef struct dv_prior_kl {
+    const float* coef;       /* (rows) dLoss / d KL */
+    const float* raw;        /* (rows) raw KL of the forward (the free-bits gate) */
+    float kl_min;
+    const float* mu;         /* (rows, ld) the rows' means; NULL where the launch has them already (dv_z2f_post_bwd: q2) */
+    int64_t ld;
+} dv_prior_kl;
 typedef struct dv_seg_add {
     const float* dz;
     int64_t ld;
@@ -312,7 +322,8 @@ int dv_reparam_bwd_seg(const float* dz, int64_t ldz, const float* eps, int64_t l
                        const int32_t* seg_ptr, const int32_t* seg_rows, int32_t nq, int32_t Z, int32_t mode,
                        const float* extra, int64_t ldx, const int32_t* ex_ptr, const int32_t* ex_rows, float* dmu,
                        float* dsd, int64_t lddq, float beta, const dv_bump* bump, const dv_seg_add* add,
-                       const dv_wait* park, dv_stream_t stream);
+                       const dv_wait* park, const dv_prior_kl* prior, dv_stream_t stream);
+/* `prior` (optional, round 5): the prior-KL gradient of q row i is added to (dmu, dsd)[i], see dv_prior_kl */
 /* Backward of everything hanging on the z2Fz1 samples (src/DrVAE.py:431-433, 459-487) in one pass
  * over (row i < B, dim d < Z), looping the L samples r = l*B + i; jp = pair_slot[i] (-1: singleton):
  *   g       = dz2f[r] (0 when dz2f == NULL: a model without a classifier) + (jp >= 0 ? dzdec_pert[l*Np + jp] : 0)
@@ -347,6 +358,8 @@ typedef struct dv_z2f_desc {
     int32_t B;
     int32_t Np;
     int32_t Z;
+    const float* prior_coef; /* (Np) or NULL (with prior_raw): the prior-KL gradient of q2 row jp is added to dq2[jp], */
+    const float* prior_raw;  /* see dv_prior_kl (kl_min as above) */
 } dv_z2f_desc;
 int dv_z2f_post_bwd(const dv_z2f_desc* d, const dv_wait* park, dv_stream_t stream);
 

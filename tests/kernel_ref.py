@@ -268,8 +268,14 @@ def reparam_bwd(dmu, dsd, dz, eps, sd, *, mode=GAUSS_LOGVAR, src_idx=None, reps=
         dsd[q] = b
 
 
+def _prior_kl_grad(coef, raw, kl_min, mu, lv):
+    c = (coef * torch.where(raw > kl_min, torch.ones_like(raw), torch.where(raw == kl_min, 0.5 * torch.ones_like(raw),
+                                                                           torch.zeros_like(raw))))[:, None]
+    return c * mu, c * (-0.5 * (1 - torch.exp(lv)))
+
+
 def reparam_bwd_seg(dmu, dsd, dz, eps, sd, seg_ptr, seg_rows, *, mode=GAUSS_LOGVAR, extra=None, ex_ptr=None,
-                    ex_rows=None, beta=0.0, bump=None, dz_add=None, park=None):
+                    ex_rows=None, beta=0.0, bump=None, dz_add=None, park=None, prior=None):
     if park is not None:
         flag_wait(park[0], park[1], park[2], park[3] if len(park) > 3 else 1)
     for (c, inc) in (bump or ()):
@@ -291,10 +297,14 @@ def reparam_bwd_seg(dmu, dsd, dz, eps, sd, seg_ptr, seg_rows, *, mode=GAUSS_LOGV
             b = b + extra[er][:, Z:2 * Z].sum(0)
         dmu[i] = (beta * dmu[i] if beta != 0.0 else 0) + a
         dsd[i] = (beta * dsd[i] if beta != 0.0 else 0) + b
+    if prior is not None:
+        gm, gs = _prior_kl_grad(prior[0][:nq], prior[1][:nq], prior[2], prior[3][:nq], sd[:nq])
+        dmu[:nq] += gm
+        dsd[:nq] += gs
 
 
 def z2f_post_bwd(dp2, dz1, dq2, dz2f, dzdec_pert, pair_slot, eps, p2, q2, coef, raw, kl_min, dz1b, L, B, Np,
-                 park=None):
+                 park=None, prior=None):
     if park is not None:
         flag_wait(park[0], park[1], park[2], park[3] if len(park) > 3 else 1)                  # single-threaded stand-in: the producer has run already
     Z = dp2.shape[1] // 2
@@ -328,6 +338,10 @@ def z2f_post_bwd(dp2, dz1, dq2, dz2f, dzdec_pert, pair_slot, eps, p2, q2, coef, 
         dp2[rs, :Z] = dmu
         dp2[rs, Z:2 * Z] = dlv
         dz1[rs] = dz1[rs] + dmu + (dz1b[rs] if dz1b is not None else 0)
+    if prior is not None and Np and dq2 is not None:
+        gm, gs = _prior_kl_grad(prior[0][:Np], prior[1][:Np], kl_min, q2[:Np, :Z], q2[:Np, Z:2 * Z])
+        dq2[:Np, :Z] += gm
+        dq2[:Np, Z:2 * Z] += gs
 
 
 def _kl_operands(mu_q, sd_q, mu_p, sd_p, prior, qidx, pidx, R, reps):

@@ -67,7 +67,8 @@ def test_gemm_desc_layout_matches_header():
                                           ('dv_batch_masks_desc', 'BatchMasks'), ('dv_batch_feed_desc', 'BatchFeed'),
                                           ('dv_kl_rows_desc', 'KlRows'), ('dv_nll_raw_cs_desc', 'NllRawCs'),
                                           ('dv_kl_rows_grad', 'KlRowsGrad'), ('dv_z2f_desc', 'Z2F'),
-                                          ('dv_recon_rows_desc', 'ReconRows'), ('dv_adam_hyper', 'AdamHyper')])
+                                          ('dv_recon_rows_desc', 'ReconRows'), ('dv_adam_hyper', 'AdamHyper'),
+                                          ('dv_prior_kl', 'PriorKl')])
 def test_small_struct_layouts_match_header(cname, pyname):
     from drvae_amd import _lib
     src = open(os.path.join(ROOT, 'include', 'drvae_hip.h')).read()
@@ -125,6 +126,8 @@ def test_argument_validation_without_gpu(lib):
     assert lib.dv_kl_rows_bwd(C.byref(k), C.byref(_lib.KlRowsGrad()), None) == -1
     assert lib.dv_z2f_post_bwd(None, None, None) == -1
     assert lib.dv_recon_rows(None, None) == -1
+    assert lib.dv_kl_rows_fwd_pair(None, None, None) == -1
+    assert lib.dv_kl_rows_fwd_pair(C.byref(k), C.byref(k), None) == -1          # rows to do, no operands
     assert lib.dv_adam_l2(None, None, None, None, 8, None, None, None, 0, None) == -1            # no hyper-parameters
     assert lib.dv_adam_l2_gated(None, None, None, None, 8, C.byref(_lib.AdamHyper(lr=1e-3)), None, None, 0, 8, None, 0, None) == -1
     assert lib.dv_adamax_l2(None, None, None, None, 8, None, None, None, 0, None) == -1

@@ -939,6 +939,43 @@ def test_reparam_bwd_seg(K, dev):
         close(dq, rq, rtol=1e-5, atol=1e-5)
 
 
+def test_prior_kl_gradient_rides_on_the_gradient_row_launches(K, dev):
+    """dv_prior_kl (round 5): the gradient of coef * max(KL(q || N(0,I)), kl_min) added by dv_reparam_bwd_seg (rows [0, B)) and
+    dv_z2f_post_bwd (the pairs' q2 rows) == a dv_kl_rows_bwd(beta = 1) launch behind them"""
+    L, B, Z = 2, 150, 100
+    pairs = torch.arange(B)[torch.arange(B) % 2 == 0]
+    Np = len(pairs)
+    Me = B + Np
+    Q = rnd(dev, Me, 2 * Z, seed=1, scale=0.5)
+    coef = rnd(dev, Me, seed=2)
+    raw = torch.empty(Me, device=dev)
+    K.kl_rows_fwd(torch.empty(Me, device=dev), raw, Q[:, :Z], Q[:, Z:], prior=(0.0, 0.0), free_bits=True, kl_min=0.0)
+    kl_min = float(raw.median())
+    # rows [0, B): the CSR sample backward
+    seg_ptr = (torch.arange(B + 1) * L).to(torch.int32).to(dev)
+    seg_rows = (torch.arange(L)[None, :] * B + torch.arange(B)[:, None]).reshape(-1).to(torch.int32).to(dev)
+    dz, eps = rnd(dev, L * B, Z, seed=3), rnd(dev, L * B, Z, seed=4)
+    ref, got = torch.zeros(Me, 2 * Z, device=dev), torch.zeros(Me, 2 * Z, device=dev)
+    K.reparam_bwd_seg(ref[:B, :Z], ref[:B, Z:], dz, eps, Q[:B, Z:], seg_ptr, seg_rows)
+    K.reparam_bwd_seg(got[:B, :Z], got[:B, Z:], dz, eps, Q[:B, Z:], seg_ptr, seg_rows, prior=(coef, raw, kl_min, Q[:B, :Z]))
+    # the pairs' rows: the z2Fz1 backward
+    slot = torch.full((B,), -1, dtype=torch.int32)
+    slot[pairs] = torch.arange(Np, dtype=torch.int32)
+    slot = slot.to(dev)
+    p2, pert = rnd(dev, L * B, 2 * Z, seed=5, scale=0.5), rnd(dev, L * Np, Z, seed=6)
+    c2, r2 = rnd(dev, L * Np, seed=7), rnd(dev, L * Np, seed=8).abs() * 40
+    for out, pr in ((ref, None), (got, (coef[B:], raw[B:]))):
+        K.z2f_post_bwd(torch.zeros(L * B, 2 * Z, device=dev), rnd(dev, L * B, Z, seed=9), out[B:], None, pert, slot,
+                       rnd(dev, L * B, Z, seed=10), p2, Q[B:], c2, r2, kl_min, None, L, B, Np, prior=pr)
+    K.kl_rows_bwd(ref[:, :Z], ref[:, Z:], None, None, coef, raw, Q[:, :Z], Q[:, Z:], prior=(0.0, 0.0), free_bits=True,
+                  kl_min=kl_min, beta=1.0)
+    close(got, ref.cpu(), rtol=1e-6, atol=1e-6)      # (to the rounding of a contracted multiply-add)
+    # the stand-ins of the CPU suite
+    rgot = torch.zeros(Me, 2 * Z, device=dev)
+    R.reparam_bwd_seg(rgot[:B, :Z], rgot[:B, Z:], dz, eps, Q[:B, Z:], seg_ptr, seg_rows, prior=(coef, raw, kl_min, Q[:B, :Z]))
+    close(rgot[:B], ref[:B].cpu(), rtol=2e-5, atol=2e-5)
+
+
 def test_kl_rows_fwd_pair_is_two_launches(K, dev):
     """dv_kl_rows_fwd_pair (round 5): two independent sets of KL rows (a prior term over every row, a q || p term over
     gathered rows with L repetitions) in one launch == the two launches, bitwise"""
