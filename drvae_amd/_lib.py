@@ -14,7 +14,7 @@ ACT = {'identity': 0, 'elu': 1, 'softplus': 2, 'sigmoid': 3, 'tanh': 4, 'relu': 
        'softsign': 8, 'cos': 9}
 GAUSS_LOGVAR, GAUSS_SIGMA = 0, 1
 REC_KIND = {'binary': 0, 'poisson': 1}
-EPI_PLAIN, EPI_FWD, EPI_BWD = 0, 1, 2
+EPI_PLAIN, EPI_FWD, EPI_BWD, EPI_KLQ = 0, 1, 2, 3
 
 _f, _i32, _i64, _u64, _p = C.c_float, C.c_int32, C.c_int64, C.c_uint64, C.c_void_p
 

@@ -112,7 +112,7 @@ class _Chain:
         return self.out[-1]
 
     def backward(self, dpre_last, inputs, dinputs=None, wbranch=None, publish_after_last=None, publish_first=None,
-                 db_last_done=False):
+                 db_last_done=False, klq=None):
         """dpre_last: gradient w.r.t. the last layer's pre-activation.  ``dinputs``: per input
         source a list of (dst, alpha, beta) destinations for its gradient (or None to skip).
         ``wbranch``: optional side stream for the weight-gradient GEMMs (they are leaves: only
@@ -120,9 +120,13 @@ class _Chain:
         the first launch AFTER the last layer's launches publishes the flag on entry (= both gradients of the
         last layer are final and its weights are no longer read); ``publish_first``: the chain's FIRST launch
         does (= everything in front of this backward pass is complete).  ``db_last_done``: the
-        last layer's bias gradient has been written by the producer of ``dpre_last`` already (``kernels.nll_rows_raw_cs``)."""
+        last layer's bias gradient has been written by the producer of ``dpre_last`` already (``kernels.nll_rows_raw_cs``).
+        ``klq`` (see ``kernels.linear_bwd_pair``): the chain's input is a sample of q rows -- the FIRST layer's data-gradient
+        launch writes d/d(mu | logvar) of those rows instead of d/d(input); returns True when the launch took it (a paired
+        first layer), else the caller runs the row pass itself."""
         dpre = dpre_last
         pending_pub = publish_first
+        took_klq = False
         n_layers = len(self.layers)
         for li in range(n_layers - 1, -1, -1):
             l = self.layers[li]
@@ -155,8 +159,13 @@ class _Chain:
                     dpre = self.dpre[li - 1]
                 else:
                     dst, alpha, beta = dinputs[0][0]
-                    K.linear_bwd_pair(l.dW, db, dst, dpre, srcs[0], l.W, alpha=alpha, beta_x=beta, overread=True,
-                                      publish=pending_pub, npad=self._pad_ok(srcs[0]), npad_x=_whole_rows(dst))
+                    if klq is not None and beta == 0.0:
+                        K.linear_bwd_pair(l.dW, db, None, dpre, srcs[0], l.W, alpha=alpha, overread=True, publish=pending_pub,
+                                          npad=self._pad_ok(srcs[0]), klq=klq)
+                        took_klq = True
+                    else:
+                        K.linear_bwd_pair(l.dW, db, dst, dpre, srcs[0], l.W, alpha=alpha, beta_x=beta, overread=True,
+                                          publish=pending_pub, npad=self._pad_ok(srcs[0]), npad_x=_whole_rows(dst))
                 pending_pub = None
                 continue
             if pending_pub is not None:      # (no paired launch for this layer: a launch of its own)
@@ -182,3 +191,4 @@ class _Chain:
                     c0 += w
         if wbranch is not None:
             wbranch.join()
+        return took_klq

@@ -1000,8 +1000,10 @@ static int gemm_prepare(const dv_gemm_desc* d, LoadCfg& lc, int& tiling) {
         return DV_OK;
     }
     DV_REQUIRE(g.A && g.B && g.C);
-    DV_REQUIRE(g.epilogue == DV_EPI_PLAIN || g.epilogue == DV_EPI_FWD || g.epilogue == DV_EPI_BWD);
+    DV_REQUIRE(g.epilogue == DV_EPI_PLAIN || g.epilogue == DV_EPI_FWD || g.epilogue == DV_EPI_BWD || g.epilogue == DV_EPI_KLQ);
     DV_REQUIRE(g.epilogue != DV_EPI_BWD || g.yref != nullptr);
+    DV_REQUIRE(g.epilogue != DV_EPI_KLQ || (g.yref && g.resid && g.bias && g.scale && g.split > 0 && g.split <= g.N &&
+                                            g.ldc >= 2 * (int64_t)g.split && g.beta == 0.f && g.a_colsum == nullptr));
     DV_REQUIRE(g.A2 == nullptr || (g.a_kcontig && g.K1 >= 0 && g.K1 <= g.K));
     DV_REQUIRE(g.a_kscale == nullptr || g.a_kcontig);
     DV_REQUIRE(g.a_colsum == nullptr || !g.a_kcontig);

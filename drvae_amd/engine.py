@@ -1126,10 +1126,14 @@ class FusedStep(StepSchedule):
                     K.kl_rows_bwd(p.DQFP[:, :Z1], p.DQFP[:, Z1:], p.DPZ1[:, :Z1], p.DPZ1[:, Z1:], p.CFP, p.KL1raw,
                                   Qmu, Qlv, PZ1[:, :Z1], PZ1[:, Z1:], qidx=p.fp_q, free_bits=True,
                                   kl_min=cfg.kl_min)
-                p.c_dz1.backward(p.DPZ1, [p.Z3IN], [[(p.DZ3IN, 1.0, 0.0)]])
-                # KL(q(z3|z1,y) || N(0,I)) + the sample path
-                K.kl_rows_bwd(p.DQ3[:, :Z3], p.DQ3[:, Z3:], None, None, p.CFP, p.KL3raw, Q3[:, :Z3], Q3[:, Z3:],
-                              prior=(0.0, 0.0), free_bits=True, kl_min=cfg.kl_min, dz=p.DZ3IN[:, :Z3], eps=p.E3)
+                # KL(q(z3|z1,y) || N(0,I)) + the sample path: in the epilogue of the data-gradient product that produces
+                # d/dz3 (``DV_EPI_KLQ``: the side chain in front of the join is a chain of dependent launches -- one less),
+                # else a row pass behind it
+                klq = dict(out=p.DQ3, q=Q3, eps=p.E3, coef=p.CFP, raw=p.KL3raw, kl_min=cfg.kl_min, Z=Z3) \
+                    if (self.fuse_bwd and T.get('klq_epi')) else None
+                if not p.c_dz1.backward(p.DPZ1, [p.Z3IN], [[(p.DZ3IN, 1.0, 0.0)]], klq=klq):
+                    K.kl_rows_bwd(p.DQ3[:, :Z3], p.DQ3[:, Z3:], None, None, p.CFP, p.KL3raw, Q3[:, :Z3], Q3[:, Z3:],
+                                  prior=(0.0, 0.0), free_bits=True, kl_min=cfg.kl_min, dz=p.DZ3IN[:, :Z3], eps=p.E3)
                 p.c_top.backward(p.DQ3, [p.FPIN], [[(p.DFPIN, 1.0, 0.0)]])
                 # z1 feeds one (labeled) or Y (unlabeled) fprop rows: their d/dz1 is summed per z1 row -- inside
                 # the classifier's data-gradient launch where that launch writes DZ1B anyway, else on its own

@@ -12,7 +12,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import ACT, EPI_BWD, EPI_FWD, EPI_PLAIN, GAUSS_LOGVAR, GAUSS_SIGMA, GemmDesc  # noqa: F401
+from ._lib import ACT, EPI_BWD, EPI_FWD, EPI_KLQ, EPI_PLAIN, GAUSS_LOGVAR, GAUSS_SIGMA, GemmDesc  # noqa: F401
 
 
 def _stream():
@@ -137,11 +137,20 @@ def gemm(Cm, A, B, a_kc, b_kc, **kw):
 
 
 def linear_bwd_pair(dW, dbias, dx, dpre, x, W, *, kscale=None, alpha=1.0, beta_x=0.0, yref=None, act=0, shift=0.0,
-                    overread=False, publish=None, npad=False, npad_x=False):
+                    overread=False, publish=None, npad=False, npad_x=False, klq=None):
     """dW = dpre^T x (+ dbias) and dx = beta_x*dx + alpha*(dpre W) * act'(yref) in ONE launch when both fit
-    the fused form of ``dv_gemm_pair`` (otherwise two launches)."""
+    the fused form of ``dv_gemm_pair`` (otherwise two launches).
+    ``klq`` = dict(out, q, eps, coef, raw, kl_min, Z): the layer's input was [a sample z of the q rows | ...]: instead of
+    dx the launch writes d/d(mu | logvar) of those rows incl. their prior term into ``out`` (M, 2Z) -- the epilogue
+    DV_EPI_KLQ of include/drvae_hip.h; ``dx`` is not written (pass None)"""
     d1 = _gemm_desc(dW, dpre, x, False, False, a_colsum=dbias, overread=overread, publish=publish, npad=npad)
-    if yref is None:
+    if klq is not None:
+        assert yref is None and kscale is None and beta_x == 0.0
+        Z, out = klq['Z'], klq['out']
+        assert out.shape[1] == 2 * Z and W.shape[1] >= Z and W.shape[1] <= 2 * Z
+        d2 = _gemm_desc(out[:, :W.shape[1]], dpre, W, True, False, alpha=alpha, epi=EPI_KLQ, split=Z, yref=klq['q'],
+                        resid=klq['eps'], bias=klq['coef'], scale=klq['raw'], shift0=klq['kl_min'], overread=overread)
+    elif yref is None:
         d2 = _gemm_desc(dx, dpre, W, True, False, a_kscale=kscale, alpha=alpha, beta=beta_x, overread=overread, npad=npad_x)
     else:
         d2 = _gemm_desc(dx, dpre, W, True, False, a_kscale=kscale, alpha=alpha, beta=beta_x, epi=EPI_BWD, yref=yref,

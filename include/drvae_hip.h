@@ -45,7 +45,7 @@ enum {
  * GaussianSigmaMixin (src/blocks.py:204-240) */
 enum { DV_GAUSS_LOGVAR = 0, DV_GAUSS_SIGMA = 1 };
 
-enum { DV_EPI_PLAIN = 0, DV_EPI_FWD = 1, DV_EPI_BWD = 2 };
+enum { DV_EPI_PLAIN = 0, DV_EPI_FWD = 1, DV_EPI_BWD = 2, DV_EPI_KLQ = 3 };
 
 int dv_abi_version(void);
 const char* dv_error_string(int code);
@@ -145,6 +145,13 @@ typedef struct dv_bump {
  *          `std = softplus(sg(h)) + 1e-3` (src/blocks.py:401,415);
  *   v += resid[m*ldr+n] for n < resid_cols  -- `mu = x + F.linear(x,W_mu) + b` (src/blocks.py:357).
  * epilogue DV_EPI_BWD: v *= act'(yref[m*ldy+n] - shift) with the same (split, act, shift)
+ * epilogue DV_EPI_KLQ (round 5): the product is d/dz of a reparameterised sample z = mu + eps * exp(logvar / 2) of q rows that
+ *   also carry a prior term coef[m] * max(KL(q_m || N(0,I)), kl_min): with Z = split, for columns n < Z the launch writes the
+ *   gradient w.r.t. (mu | logvar) instead of v -- C[m, n] = c_m * mu + v, C[m, Z + n] = c_m * (e^logvar - 1) / 2 +
+ *   v * eps[m, n] * e^(logvar / 2) / 2, c_m = coef[m] * gate(raw[m]) (1 above kl_min, 1/2 on a tie, 0 below) -- what
+ *   dv_kl_rows_bwd(dz = v, eps) computes in a launch of its own; columns n >= Z are dropped.  Operands travel in fields this
+ *   epilogue does not otherwise use: yref / ldy = the q rows (mu | logvar), resid / ldr = eps, bias = coef (per ROW),
+ *   scale = raw (per ROW), shift0 = kl_min; ldc >= 2 Z, beta = 0.
  *   selection: the activation backward of the layer BELOW fused into the dx GEMM.
  */
 /* Per-call steering of the GEMM dispatcher (ABI 9; replaces the process-global dv_gemm_force_tiling / dv_gemm_set_option

@@ -200,10 +200,17 @@ def linear_bwd_weight(dW, dpre, x, *, beta=0.0, dbias=None, overread=False, npad
 
 
 def linear_bwd_pair(dW, dbias, dx, dpre, x, W, *, kscale=None, alpha=1.0, beta_x=0.0, yref=None, act=0, shift=0.0,
-                    overread=False, publish=None, npad=False, npad_x=False):
+                    overread=False, publish=None, npad=False, npad_x=False, klq=None):
     if publish is not None:
         flag_publish(publish[0], publish[1], publish[2])
     linear_bwd_weight(dW, dpre, x, dbias=dbias, npad=npad)
+    if klq is not None:        # DV_EPI_KLQ: d/d(mu | logvar) of the sampled q rows instead of dx
+        Z, q, out = klq['Z'], klq['q'], klq['out']
+        v = alpha * (dpre @ W)[:, :Z]
+        gm, gs = _prior_kl_grad(klq['coef'], klq['raw'], klq['kl_min'], q[:, :Z], q[:, Z:2 * Z])
+        out[:, :Z] = gm + v
+        out[:, Z:2 * Z] = gs + v * klq['eps'] * 0.5 * torch.exp(0.5 * q[:, Z:2 * Z])
+        return
     linear_bwd_data(dx, dpre, W, kscale=kscale, alpha=alpha, beta=beta_x, yref=yref, act=act, shift=shift, npad=npad_x)
 
 

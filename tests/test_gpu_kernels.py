@@ -976,6 +976,35 @@ def test_prior_kl_gradient_rides_on_the_gradient_row_launches(K, dev):
     close(rgot[:B], ref[:B].cpu(), rtol=2e-5, atol=2e-5)
 
 
+@pytest.mark.parametrize('M,Z,Y,H', [(450, 100, 2, 200), (596, 37, 3, 64), (33, 128, 0, 200)])
+def test_gemm_epilogue_klq_is_the_kl_row_backward(K, dev, M, Z, Y, H):
+    """DV_EPI_KLQ (round 5): the data gradient of a layer whose input is [a sample of q rows | class columns] leaves the
+    launch as d/d(mu | logvar) of those rows incl. their prior term == the plain data gradient + dv_kl_rows_bwd(dz, eps)
+    behind it; the weight gradient of the paired launch is untouched"""
+    Kin = Z + Y
+    x, W = rnd(dev, M, Kin, seed=1), rnd(dev, H, Kin, seed=2, scale=Kin ** -0.5)
+    dpre = rnd(dev, M, H, seed=3)
+    Q, eps = rnd(dev, M, 2 * Z, seed=4, scale=0.5), rnd(dev, M, Z, seed=5)
+    coef = rnd(dev, M, seed=6)
+    raw = torch.empty(M, device=dev)
+    K.kl_rows_fwd(torch.empty(M, device=dev), raw, Q[:, :Z], Q[:, Z:], prior=(0.0, 0.0), free_bits=True, kl_min=0.0)
+    kl_min = float(raw.median())
+    # reference: two launches + the row pass
+    dW0, db0, dx0 = torch.empty(H, Kin, device=dev), torch.empty(H, device=dev), torch.empty(M, Kin, device=dev)
+    K.linear_bwd_pair(dW0, db0, dx0, dpre, x, W, overread=False)
+    ref = torch.empty(M, 2 * Z, device=dev)
+    K.kl_rows_bwd(ref[:, :Z], ref[:, Z:], None, None, coef, raw, Q[:, :Z], Q[:, Z:], prior=(0.0, 0.0), free_bits=True,
+                  kl_min=kl_min, dz=dx0[:, :Z], eps=eps)
+    dW1, db1, got = torch.empty(H, Kin, device=dev), torch.empty(H, device=dev), torch.full((M, 2 * Z), 7.0, device=dev)
+    klq = dict(out=got, q=Q, eps=eps, coef=coef, raw=raw, kl_min=kl_min, Z=Z)
+    K.linear_bwd_pair(dW1, db1, None, dpre, x, W, klq=klq)
+    close(got, ref.cpu(), rtol=2e-5, atol=2e-5)
+    assert torch.equal(dW1, dW0) and torch.equal(db1, db0)
+    rgot = torch.empty(M, 2 * Z, device=dev)
+    R.linear_bwd_pair(torch.empty(H, Kin, device=dev), torch.empty(H, device=dev), None, dpre, x, W, klq=dict(klq, out=rgot))
+    close(rgot, ref.cpu(), **gemm_tol(H))
+
+
 def test_kl_rows_fwd_pair_is_two_launches(K, dev):
     """dv_kl_rows_fwd_pair (round 5): two independent sets of KL rows (a prior term over every row, a q || p term over
     gathered rows with L repetitions) in one launch == the two launches, bitwise"""
