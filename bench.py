@@ -222,9 +222,11 @@ def gemm_roofline(eng, cfg, rows, frac_pair, frac_lab, repeats=20, workload='cfg
 
     def rec_pair(dW, dbias, dx, dpre, x, W, **kw):      # dW = dpre^T x and dx = dpre W share one launch
         Mb, Nw = dpre.shape
+        n_dx = W.shape[1]       # (dx may be None: the DV_EPI_KLQ form writes d/d(mu | logvar) of the input's q rows instead)
+        out_dx = dx if dx is not None else kw['klq']['out']
         calls.append((lambda: real_pair(dW, dbias, dx, dpre, x, W, **kw), [dx] if kw.get('beta_x', 0.0) != 0.0 else [],
-                      2.0 * Mb * Nw * x.shape[1] + 2.0 * Mb * Nw * dx.shape[1],
-                      ('pair dW+dX', Mb, Nw, x.shape[1], dx.shape[1]), nbytes(dW, dx, dpre, x, W)))
+                      2.0 * Mb * Nw * x.shape[1] + 2.0 * Mb * Nw * n_dx,
+                      ('pair dW+dX', Mb, Nw, x.shape[1], n_dx), nbytes(dW, out_dx, dpre, x, W)))
         real_pair(dW, dbias, dx, dpre, x, W, **kw)
 
     K.gemm, K.linear_bwd_pair, K.linear_heads = rec_gemm, rec_pair, rec_heads
