@@ -32,6 +32,7 @@ DEFAULTS = {
     'nll_cs': 1,         # chip-filling heads: their bias gradient folded into the NLL row pass (no column-sum pass of its own; 2: buffers at any size -- tests, with raw_heads=2)
     'klq_epi': 1,        # the z3 term's backward (KL + sample path of q(z3|z1,y)) in the epilogue of the data-gradient product in front of it
     'kl_pair': 1,        # PVAE's two sets of KL rows (prior term, pairs' term) as one launch on its main chain
+    'main_first': 1,     # replay(): the main chain's graph is launched before the side chain's (the step's first kernels start one graph launch earlier after a host sync; steady state unchanged)
     'pvae_tail': 1,      # PVAE (no classifier): the dual-graph schedule with a side chain that is only the step's tail (heads' optimiser half, loss scalars, next noise)
     'sync_poll': 64,     # replays between two polls of the sticky wait-error words
 }
