@@ -287,7 +287,15 @@ class FitMixin:
                 torch.cuda.current_stream().wait_stream(side)
             sums = OrderedDict((k, eng.loss_sum[E.LOSS_IDX[k]]) for k in self._loss_tensors(eng))
             total = self._train_objective(sums)
-        mean = float(total) / n_b          # the epoch's one host sync
+        # the epoch's ONE host sync: the objective and the sticky words of the device-side waits travel in one copy (a second
+        # wait left the device idle once more per epoch)
+        eng.join_side()
+        if eng.dev.type == 'cuda' and torch.is_tensor(total):
+            both = torch.stack([total.reshape(()).double(), eng.sync_err[0::2].abs().sum().double()]).cpu().tolist()
+            if both[1] != 0:
+                eng.check_sync()           # (raises with the wait sites)
+            return both[0] / n_b
+        mean = float(total) / n_b
         eng.check_sync()
         return mean
 
