@@ -25,6 +25,24 @@ def load(sub):
     return acc, calls, max(steps, 1)
 
 
+def durations():
+    """average kernel duration (us) from the --kernel-trace --stats run of the same command (tools/pmc_collect.sh)"""
+    import os
+    out = {}
+    path = '%s/kernel_stats.csv' % root
+    if not os.path.exists(path):
+        return out
+    with open(path) as fh:
+        for row in csv.DictReader(fh):
+            k = row['Name'].replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0]
+            c, t = int(row['Calls']), float(row['TotalDurationNs'])
+            if k in out:
+                c, t = c + out[k][0], t + out[k][1]
+            out[k] = (c, t)
+    return {k: v[1] / max(v[0], 1) / 1e3 for k, v in out.items()}
+
+
+dur = durations()
 fetch, calls, steps = load('fetch')
 write, _, s2 = load('write')
 sq, _, s3 = load('sq')
@@ -36,17 +54,22 @@ print('# FETCH_SIZE/WRITE_SIZE in KB as reported; gfx950 correction (MI355X_MICR
 print('# 1/2 of the bytes of wide (16 B/lane) coalesced reads.')
 print('# ldsConfl = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE (extra LDS-array cycles per LDS cycle); mfma/wave = SQ_VALU_MFMA_BUSY_CYCLES /')
 print('# (4 x SQ_WAVE_CYCLES): matrix-pipe cycles per cycle of wave lifetime (SQ_WAVE_CYCLES counts quad-cycles)')
-print('%-46s %6s %10s %10s %6s %8s %8s %8s %12s %9s %9s' % ('kernel', 'calls', 'FETCH_KB', 'WRITE_KB', 'L2hit', 'waitAny', 'waitInst',
-                                                   'active', 'mfmaBusyCyc', 'ldsConfl', 'mfma/wave'))
+print('# avg_us = average kernel duration of a --kernel-trace --stats run of the same command (no counters attached); GB/s = (2 x FETCH + WRITE)')
+print('# per call / avg_us: memory-side bytes with the x2 wide-load correction (an upper bound; exact for 16-B-per-lane streams)')
+print('%-46s %6s %10s %10s %6s %8s %8s %8s %12s %9s %9s %9s %8s' % ('kernel', 'calls', 'FETCH_KB', 'WRITE_KB', 'L2hit', 'waitAny', 'waitInst',
+                                                   'active', 'mfmaBusyCyc', 'ldsConfl', 'mfma/wave', 'avg_us', 'GB/s'))
 tot_f = tot_w = gf = gw = gc = 0
 for k in sorted(fetch, key=lambda k: -fetch[k]['FETCH_SIZE']):
     f, w = fetch[k]['FETCH_SIZE'] / steps, write[k]['WRITE_SIZE'] / s2
     h, m = tcc[k]['TCC_HIT_sum'], tcc[k]['TCC_MISS_sum']
     wc = max(sq[k]['SQ_WAVE_CYCLES'], 1)
-    print('%-46s %6.1f %10.0f %10.0f %6.2f %8.2f %8.2f %8.2f %12.0f %9.3f %9.3f' % (
+    cps = max(calls[k] / steps, 1e-9)
+    d_us = dur.get(k, 0.0)
+    gbs = (2 * f + w) / cps * 1e3 / (d_us * 1e-6) / 1e9 if d_us else 0.0
+    print('%-46s %6.1f %10.0f %10.0f %6.2f %8.2f %8.2f %8.2f %12.0f %9.3f %9.3f %9.1f %8.0f' % (
         k[:46], calls[k] / steps, f, w, h / max(h + m, 1), sq[k]['SQ_WAIT_ANY'] / wc, sq[k]['SQ_WAIT_INST_ANY'] / wc,
         sq[k]['SQ_ACTIVE_INST_ANY'] / wc, sq[k]['SQ_VALU_MFMA_BUSY_CYCLES'] / s3,
-        sq[k]['SQ_LDS_BANK_CONFLICT'] / max(sq[k]['SQ_LDS_IDX_ACTIVE'], 1), sq[k]['SQ_VALU_MFMA_BUSY_CYCLES'] / (4 * wc)))
+        sq[k]['SQ_LDS_BANK_CONFLICT'] / max(sq[k]['SQ_LDS_IDX_ACTIVE'], 1), sq[k]['SQ_VALU_MFMA_BUSY_CYCLES'] / (4 * wc), d_us, gbs))
     tot_f += f
     tot_w += w
     if 'gemm' in k:
@@ -59,3 +82,20 @@ print('# GEMM family per step: %.0f launches, FETCH %.1f MB reported -> %.1f MB 
       'HBM-side traffic per launch' % (gc, gf / 1e3, 2 * gf / 1e3, gw / 1e3, (2 * gf + gw) / 1e3 / max(gc, 1)))
 lds = sum(v.get('SQ_LDS_BANK_CONFLICT', 0) for v in sq.values())
 print('# SQ_LDS_BANK_CONFLICT summed over all kernels: %.0f' % lds)
+
+# ---- optional memory-side pass (PMC_EXTRA of tools/pmc_collect.sh): L2 -> fabric read requests, how many of them are addressed to
+# DRAM (as opposed to GMI / IO), and the average time a read request is outstanding (LEVEL / RDREQ, in L2 clocks): an Infinity-Cache
+# hit returns sooner than an HBM access, so a kernel whose operands the Infinity Cache serves shows the latency of the cfg-2 optimiser
+# sweep (65 MB arena, resident), one that streams from HBM that of the wide configuration's sweep (3.5 GB)
+import os
+if os.path.exists('%s/extra0/p_counter_collection.csv.gz' % root):
+    ex, ecalls, es = load('extra0')
+    print()
+    print('# memory-side pass: TCC_EA0_RDREQ (all L2 -> fabric read requests), _32B (of which 32-byte), _DRAM (addressed to the memory')
+    print('# controllers), avg outstanding = TCC_EA0_RDREQ_LEVEL / TCC_EA0_RDREQ in L2 clocks.  Per-STEP averages over %d steps.' % es)
+    print('%-46s %6s %12s %12s %12s %14s' % ('kernel', 'calls', 'RDREQ', 'RDREQ_32B', 'RDREQ_DRAM', 'avg_outst_clk'))
+    for k in sorted(ex, key=lambda k: -ex[k].get('TCC_EA0_RDREQ_sum', 0)):
+        r = ex[k].get('TCC_EA0_RDREQ_sum', 0)
+        print('%-46s %6.1f %12.0f %12.0f %12.0f %14.1f' % (k[:46], ecalls[k] / es, r / es, ex[k].get('TCC_EA0_RDREQ_32B_sum', 0) / es,
+                                                    ex[k].get('TCC_EA0_RDREQ_DRAM_sum', 0) / es,
+                                                    ex[k].get('TCC_EA0_RDREQ_LEVEL_sum', 0) / max(r, 1)))

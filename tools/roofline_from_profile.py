@@ -62,8 +62,12 @@ def pmc_table(path):
             parts = line.rstrip('\n').split()
             if len(parts) < 9:
                 continue
-            # (round 4 added two trailing columns: ldsConfl, mfma/wave)
-            ncol = 10 if len(parts) >= 11 and _isnum(parts[-10]) else 8
+            # (round 4 added two trailing columns: ldsConfl, mfma/wave; round 6 two more: avg_us, GB/s)
+            ncol = 0
+            while ncol < len(parts) - 1 and _isnum(parts[-1 - ncol]):
+                ncol += 1
+            if ncol < 8:
+                continue
             try:
                 nums = [float(v) for v in parts[-ncol:]][:8]
             except ValueError:
