@@ -133,6 +133,7 @@ class LossTerm(C.Structure):
 SIGNATURES = {
     'dv_abi_version': [],
     'dv_error_string': [_i32],
+    'dv_source_hash': [],
     'dv_gemm': [C.POINTER(GemmDesc), _p],
     'dv_gemm_pair': [C.POINTER(GemmDesc), C.POINTER(GemmDesc), _p],
     'dv_gemm_heads': [C.POINTER(GemmDesc), C.POINTER(HeadsEpi), _p],
@@ -210,7 +211,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 11    # DV_ABI_VERSION of include/drvae_hip.h
+ABI_VERSION = 12    # DV_ABI_VERSION of include/drvae_hip.h
 
 
 def load():
@@ -233,7 +234,7 @@ def load():
         except AttributeError as e:
             raise RuntimeError('drvae_amd: symbol %s missing from %s (stale build?)' % (name, LIB_PATH)) from e
         fn.argtypes = argtypes
-        fn.restype = C.c_char_p if name == 'dv_error_string' else C.c_int
+        fn.restype = C.c_char_p if name in ('dv_error_string', 'dv_source_hash') else C.c_int
     if lib.dv_abi_version() != ABI_VERSION:
         raise RuntimeError('drvae_amd: ABI version mismatch in %s' % LIB_PATH)
     _lib = lib

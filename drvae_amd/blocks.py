@@ -110,10 +110,9 @@ def poly(x1, x2, degree=2, gamma=1., bias=1.):
 
 
 def identity(x1, x2):
-    """src/blocks.py:37-38 (device tensors: one HIP launch each way, ``ops.MMDIdentity``)."""
-    if x1.is_cuda:
-        return ops.MMDIdentity.apply(x1, x2)
-    return ((x1.mean(0) - x2.mean(0)) ** 2).sum()
+    """src/blocks.py:37-38: one HIP launch each way (``ops.MMDIdentity``).  No ATen fallback: host tensors are refused
+    by the launcher like everywhere else in the package."""
+    return ops.MMDIdentity.apply(x1, x2)
 
 
 def mmd_fourier(x1, x2, bandwidth=2., dim_r=500):
@@ -136,18 +135,15 @@ def mmd_objective(x1, x2, kernel='rbf', bandwidths=1. / (2 * (np.array([1., 2., 
         return torch.sqrt(fn(x1, x2))
     if kernel == 'rbf_fourier':
         return torch.sqrt(fn(x1, x2, bandwidth=2.))
-    if x1.is_cuda and kernel in ('rbf', 'poly') and len(bandwidths) <= 8 and x1.size(1) == x2.size(1):
-        # the bandwidth mixture, its means and its derivative on HIP row kernels around the three Gram products
-        # (``ops.MMDMix``; round 5) instead of ~15 element-wise launches per Gram matrix
-        gam = [math.sqrt(x1.size(1)) * float(bw) for bw in bandwidths]
-        return torch.sqrt(ops.MMDMix.apply(x1, x2, kernel, gam))
-    k11 = k12 = k22 = 0
-    nb = len(bandwidths)
-    for bw in bandwidths:
-        k11 = k11 + fn(x1, x1, gamma=math.sqrt(x1.size(1)) * bw) / nb
-        k22 = k22 + fn(x2, x2, gamma=math.sqrt(x2.size(1)) * bw) / nb
-        k12 = k12 + fn(x1, x2, gamma=math.sqrt(x1.size(1)) * bw) / nb
-    return torch.sqrt(k11.mean() - 2 * k12.mean() + k22.mean())
+    # the bandwidth mixture, its means and its derivative on HIP row kernels around the three Gram products on the MFMA
+    # GEMM (``ops.MMDMix``).  No ATen fallback (host tensors are refused by the launchers); the row kernels hold at most
+    # 8 bandwidths (the reference's default: 5)
+    if len(bandwidths) > 8:
+        raise NotImplementedError('mmd_objective(kernel=%r): at most 8 bandwidths (got %d)' % (kernel, len(bandwidths)))
+    if x1.size(1) != x2.size(1):
+        raise ValueError('mmd_objective: the two row sets differ in width (%d, %d)' % (x1.size(1), x2.size(1)))
+    gam = [math.sqrt(x1.size(1)) * float(bw) for bw in bandwidths]
+    return torch.sqrt(ops.MMDMix.apply(x1, x2, kernel, gam))
 
 
 def one_hot(y, max_dim):

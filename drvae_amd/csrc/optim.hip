@@ -2,6 +2,7 @@
 // on-device N(0,1) generator (Philox4x32-10 + Box-Muller) of the Dr.VAE train step.
 // All HBM-streaming: 16-B per lane, grid-stride, 7 words of traffic per parameter.
 #include "dv_common.h"
+#include <cstring>
 
 namespace {
 
@@ -349,6 +350,17 @@ __global__ __launch_bounds__(256) void adamax_kernel(float* __restrict__ p, cons
         u[i] = uu;
         p[i] = pp + (-clr) * (mm / uu);
     }
+}
+
+/* sha256 over the library's sources (csrc/ *.hip *.inc *.h + include/drvae_hip.h, see drvae_amd/build.py::source_hash),
+ * baked in at build time: lets a test on the GPU box assert that the shipped binary was built from the tree next to it */
+#ifndef DV_SOURCE_HASH
+#define DV_SOURCE_HASH "unhashed"
+#endif
+static const char dv_src_tag[] = DV_SOURCE_HASH;      /* "dv-src-sha256:<hex>": the tag lets build.py find it in the file */
+extern "C" const char* dv_source_hash(void) {
+    const char* c = strchr(dv_src_tag, ':');
+    return c ? c + 1 : dv_src_tag;
 }
 
 extern "C" const char* dv_error_string(int code) {

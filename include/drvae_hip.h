@@ -30,7 +30,7 @@ extern "C" {
 
 typedef void* dv_stream_t;
 
-#define DV_ABI_VERSION 11
+#define DV_ABI_VERSION 12
 
 enum { DV_OK = 0, DV_ERR_ARG = -1, DV_ERR_LAUNCH = -2, DV_ERR_UNSUPPORTED = -3 };
 
@@ -49,6 +49,10 @@ enum { DV_EPI_PLAIN = 0, DV_EPI_FWD = 1, DV_EPI_BWD = 2, DV_EPI_KLQ = 3 };
 
 int dv_abi_version(void);
 const char* dv_error_string(int code);
+/* hex sha256 over the sources this binary was built from (every file of drvae_amd/csrc/ that is compiled or included,
+ * in name order, + this header; `drvae_amd.build.source_hash()` recomputes it from a tree) -- "unhashed" for a build that
+ * did not go through drvae_amd/build.py.  The reference has no native layer, hence no counterpart. */
+const char* dv_source_hash(void);
 
 /* A device-side wait carried by a launch (see dv_flag_wait): the launch first parks until
  * flag[0] >= ctr[0] + add.  Bounded: after max_spins polls it records err[0] = 1 (sticky: nothing on

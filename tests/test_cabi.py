@@ -39,10 +39,37 @@ def test_library_exports_every_symbol(lib):
     for name in _header_decls():
         assert hasattr(lib, name), name
     from drvae_amd import _lib
-    assert lib.dv_abi_version() == _lib.ABI_VERSION == 11
+    assert lib.dv_abi_version() == _lib.ABI_VERSION == 12
     assert 'dv_arm_park' not in _lib.SIGNATURES and not hasattr(lib, 'dv_arm_park')     # no armed (hidden) state
     assert lib.dv_error_string(0) == b'ok'
     assert lib.dv_error_string(-1) == b'invalid argument'
+
+
+def test_library_identifies_its_sources(lib):
+    """the shipped binary says which sources it was built from: dv_source_hash() == sha256 over csrc/* + the header of THIS
+    tree (``build.source_hash``), and the same string is found in the file without loading it (``build.built_hash``)"""
+    from drvae_amd import build
+    want = build.source_hash()
+    assert len(want) == 64
+    assert lib.dv_source_hash().decode() == want
+    assert build.built_hash() == want
+    assert not build.needs_build()
+
+
+def test_build_is_reproducible(tmp_path):
+    """two compilations of one source file of one tree give byte-identical objects (paths mapped away, nothing
+    time-dependent baked in; the link adds no build id: ``build.build``) -- checked on the smallest source"""
+    import subprocess
+    from drvae_amd import build
+    objs = []
+    for i in range(2):
+        (tmp_path / str(i)).mkdir()
+        o = str(tmp_path / str(i) / 'optim.o')
+        subprocess.check_call([build._hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC',
+                               '-ffile-prefix-map=%s=.' % build.CSRC, '-cuid=dv-optim', '-DDV_SOURCE_HASH="dv-src-sha256:%s"' % ('0' * 64),
+                               '-c', 'optim.hip', '-o', o], cwd=build.CSRC)
+        objs.append(open(o, 'rb').read())
+    assert objs[0] == objs[1]
 
 
 def test_gemm_desc_layout_matches_header():
@@ -154,6 +181,20 @@ def test_kernels_refuse_cpu_tensors():
     import drvae_amd.kernels as K
     with pytest.raises(RuntimeError, match='no CPU'):
         K.colsum(torch.zeros(3), torch.zeros(2, 3))
+
+
+def test_mmd_functions_have_no_aten_fallback():
+    """``blocks.identity`` / ``mmd_objective`` (every kernel) refuse host tensors like the rest of the package"""
+    import torch
+    from drvae_amd import blocks as blk
+    a, b = torch.randn(5, 4), torch.randn(6, 4)
+    for kernel in ('identity', 'poly', 'rbf', 'rbf_fourier'):
+        with pytest.raises(RuntimeError, match='no CPU'):
+            blk.mmd_objective(a, b, kernel)
+    with pytest.raises(RuntimeError, match='no CPU'):
+        blk.identity(a, b)
+    with pytest.raises(NotImplementedError):
+        blk.mmd_objective(a, b, 'poly', bandwidths=[0.1] * 9)
 
 
 def _kernel_metadata(tmp_path):
