@@ -34,6 +34,13 @@ WORKLOADS = {
              'DrVAE wide synthetic: 20000 genes, z1=z3=200, enc 2048, dec 2048 (assumed), batch 1024/GPU, L=4'),
 }
 WORKLOADS['cfg5'] = WORKLOADS['wide']         # BASELINE.json's name for it
+# BASELINE.json configs[3] "exercises y-classifier + MMD loss path": the same VFAE step with the nuisance variable s as a
+# model input and the model-level MMD penalty between the nuisance classes' latent samples (src/DGMMixin.py:42-66,
+# src/blocks.py:40-76; an EXTENSION -- the reference's own glue raises as shipped) inside the captured step
+WORKLOADS['cfg4_mmd'] = ('vfae', 150, 2, {'add_noise_var': 0.0, 'use_s': True, 'dim_s': 2, 'use_MMD': True,
+                                          'kernel_MMD': 'rbf_fourier'},
+                         'VFAE/SSVAE with use_s + use_MMD (rbf_fourier penalty per data group and sample in the captured '
+                         'step): 978 genes, z1=z2=100, enc 800, dec 600, batch 150/GPU, L=2')
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak (dense, exact fp32)
 
 
@@ -77,7 +84,9 @@ def build(workload, device, rank, world, seed=123):
     # weak scaling: every rank has the same group mix, so the global counts are world * local
     counts = (world * rows, world * int(hx.sum()), world * int(hy.sum()))
     t = lambda k: torch.from_numpy(batch[k]).to(device)
-    eng.set_batch(t('x1'), t('x2'), batch['y'], hx, hy, counts=counts)
+    # (use_s workloads: two nuisance classes, alternating by global row)
+    sv = ((rank * rows + np.arange(rows)) // 4 % cfg.dim_s) if cfg.use_s else None
+    eng.set_batch(t('x1'), t('x2'), batch['y'], hx, hy, counts=counts, s=sv)
     return cfg, eng, arena, batch, desc
 
 
@@ -303,6 +312,10 @@ def gemm_roofline(eng, cfg, rows, frac_pair, frac_lab, repeats=20, workload='cfg
                                for t, f, sh in top]
         if prof is not None and 'kernel_us_per_step' in (prof.get('gemm_in_graph') or {}):
             out['in_graph'] = in_graph(prof['gemm_in_graph'])
+        if prof is not None and prof.get('traffic'):     # memory-side bytes per GEMM launch from the committed --pmc passes
+            out['traffic'] = round(1e6 * prof['traffic']['gemm']['per_launch_corrected_upper_mb'])
+            out['traffic_unit'] = 'bytes per GEMM launch (FETCH_SIZE x2 gfx950 wide-load correction + WRITE_SIZE)'
+            out['profile'] = prof_file
         return out
     out.update({'algorithmic_mbytes_per_step': round(alg_bytes / 1e6, 2),
                 'algorithmic_gemm_mbytes_per_step': round(gemm_bytes / 1e6, 2),
@@ -365,6 +378,7 @@ def fit_epoch(device, n_train=8192, n_valid=2048, batch=150, epochs=7):
     ts = sorted(ts[2:], key=sum)
     t = ts[len(ts) // 2]
     gf = eval_gflop(tr) + eval_gflop(va)
+    gfx = eval_gflop(tr, executed=True) + eval_gflop(va, executed=True)
     ev_ms = 1e3 * (t[1] + t[2])
     return {'train_ms': round(1e3 * t[0], 3), 'steps': len(bat), 'ms_per_step': round(1e3 * t[0] / len(bat), 4),
             'eval_train_ms': round(1e3 * t[1], 3), 'eval_valid_ms': round(1e3 * t[2], 3),
@@ -372,8 +386,41 @@ def fit_epoch(device, n_train=8192, n_valid=2048, batch=150, epochs=7):
             'finite': bool(np.isfinite(ptr['x1_rmse']) and np.isfinite(pva['x1_rmse'])),
             'eval_roofline': {'bound': 'mfma', 'achieved': round(gf / ev_ms, 2), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                               'frac': round(gf / ev_ms / FP32_MFMA_PEAK_TFLOPS, 4), 'gflop': round(gf, 1),
+                              'gflop_executed': round(gfx, 1), 'frac_executed': round(gfx / ev_ms / FP32_MFMA_PEAK_TFLOPS, 4),
+                              'executed_note': 'the means-only inference takes q(z1|x1) from the loss pass (same rows, same '
+                                               'kernels, no input noise in evaluation): its encoder FLOPs are algorithmic, not executed',
                               'what': 'forward FLOPs of both whole-set evaluations (loss pass with L = 2 samples + means-only '
                                       'inference) / their wall time incl. the metrics and the one host copy each'}}
+
+
+def mmd_addon(device, n=150, Z=100, reps=50):
+    """The block-level MMD add-on of cfg 4: ``mmd_objective(z[:n/2], z[n/2:], 'rbf_fourier')`` (Z = 100, 500
+    random Fourier features; src/blocks.py:40-76), forward + backward through the HIP-backed block incl. its two RNG draws,
+    replayed from a hipGraph."""
+    from drvae_amd import blocks as blk
+    z = torch.randn(n, Z, device=device, requires_grad=True)
+
+    def step():
+        z.grad = None
+        m = blk.mmd_objective(z[:n // 2], z[n // 2:], 'rbf_fourier')
+        m.backward()
+        return m
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        step()
+    g.replay()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    return {'us_per_call': round(e0.elapsed_time(e1) * 1e3 / reps, 2), 'rows': [n // 2, n - n // 2], 'dim_z': Z, 'dim_r': 500,
+            'finite': bool(torch.isfinite(z.grad).all()),
+            'what': "mmd_objective(z[:75], z[75:], 'rbf_fourier') forward + backward incl. the two RNG draws, hipGraph replay"}
 
 
 class _Watchdog:
@@ -788,9 +835,25 @@ def main():
                 out['roofline'].setdefault('workloads', {})[name] = {
                     'ms_per_step': r3['ms_per_step'], 'steps': k_, 'frac': rf['frac'], 'achieved': rf['achieved'],
                     'algorithmic_gflop_per_step': rf['algorithmic_gflop_per_step'],
-                    'isolated_frac': rf['isolated']['frac'], 'value': r3['value']}
+                    'isolated_frac': rf['isolated']['frac'], 'value': r3['value'], 'traffic': rf.get('traffic')}
             ok = ok and r3['finite']
             del c3
+        # cfg 4 WITH its MMD loss path (BASELINE.json configs[3]): the penalty inside the captured step, and the
+        # block-level add-on by itself
+        gc.collect()
+        torch.cuda.empty_cache()
+        try:
+            r4, c4 = measure(args, 'cfg4_mmd', 'resident', 20, 5, device, rank, world)
+            out['other_workloads']['cfg4_mmd'] = {
+                'ms_per_step': r4['ms_per_step'], 'value': r4['value'], 'steps': 20, 'warmup': 5, 'finite': r4['finite'],
+                'workload': r4['config']['workload'], 'side_chain_cus': r4['config']['side_chain_cus'],
+                'mmd_last_step': r4['losses_last_step'].get('MMD'), 'block_addon': mmd_addon(device)}
+            ok = ok and r4['finite']
+            del c4
+        except Exception as e:       # noqa: BLE001
+            print('bench.py: other_workloads leg cfg4_mmd failed: %r' % (e,), file=sys.stderr)
+            out['other_workloads']['cfg4_mmd'] = {'error': repr(e)}
+            out.setdefault('extras_failed', []).append('cfg4_mmd')
     import torch.distributed as dist
     if world > 1:
         dist.barrier()

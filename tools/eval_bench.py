@@ -17,7 +17,7 @@ def dataset(n, seed, dev='cuda'):
     return D.DrVAEDataset(t('x1'), t('x2'), torch.zeros(n, dtype=torch.int64, device=dev), t('y'), t('has_x2'), t('has_y'))
 
 
-def eval_gflop(ds, L=2, X=978, H1=800, Z=100, HD=600, HF=200, Y=2):
+def eval_gflop(ds, L=2, X=978, H1=800, Z=100, HD=600, HF=200, Y=2, executed=False):
     """forward FLOPs of one evaluation: the eval-mode loss pass (src/DrVAE.py:367-543 on every row, L samples) + the
     means-only inference (src/DrVAE.py:253-311)"""
     B = len(ds)
@@ -28,7 +28,8 @@ def eval_gflop(ds, L=2, X=978, H1=800, Z=100, HD=600, HF=200, Y=2):
     z2f = 2.0 * (Z * 2 * Z)
     fp = 2.0 * 2 * ((Z + Y) * HF + HF * 2 * Z)
     loss = (B + Np) * enc + (L * B + 2 * L * Np) * dec + L * B * z2f + L * (Nl + Y * (B - Nl)) * fp
-    infer = B * (enc + z2f + 2 * dec + 2.0 * 2 * Z * Y)
+    # (``executed``: the inference pass re-uses q(z1|x1) of the loss pass -- its encoder product is not run a second time)
+    infer = B * ((0.0 if executed else enc) + z2f + 2 * dec + 2.0 * 2 * Z * Y)
     return (loss + infer) / 1e9
 
 

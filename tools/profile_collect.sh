@@ -8,7 +8,7 @@
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out/final
-R=${ROUND:-r04}
+R=${ROUND:-r06}
 rm -rf $O && mkdir -p $O
 export DRVAE_SIDE_CUS=64      # fixed split: no tuning replays in the profile
 for wl in cfg2 cfg1 cfg4 wide; do
@@ -20,9 +20,14 @@ for wl in cfg2 cfg1 cfg4 wide; do
   rm -rf $O/k_$wl
 done
 unset DRVAE_SIDE_CUS
-bash tools/pmc_collect.sh > $O/pmc.log 2>&1
-python3 tools/pmc_summary.py gpurun_out/pmc_rr > $O/cfg2_pmc_summary.txt 2>&1
-rm -rf gpurun_out/pmc_rr
+# counters for the latency-bound headline AND for the one MFMA-/HBM-bound configuration (cfg 5), incl. the memory-side request pass
+export PMC_EXTRA="TCC_EA0_RDREQ_sum,TCC_EA0_RDREQ_LEVEL_sum,TCC_EA0_RDREQ_DRAM_sum,TCC_EA0_RDREQ_32B_sum"
+for wl in cfg2 wide; do
+  bash tools/pmc_collect.sh $wl > $O/pmc_$wl.log 2>&1
+  python3 tools/pmc_summary.py gpurun_out/pmc_rr > $O/${wl}_pmc_summary.txt 2>&1
+  rm -rf gpurun_out/pmc_rr
+done
+unset PMC_EXTRA
 for wl in cfg2 cfg1 cfg4 wide; do
   if [ $wl = wide ]; then ST="--steps 6 --warmup 2"; else ST="--steps 300 --warmup 20"; fi
   python3 bench.py --workload $wl $ST --no-extras --no-cpu-baseline > $O/${wl}_bench.json 2> $O/${wl}_bench.err
