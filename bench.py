@@ -432,6 +432,8 @@ class _Watchdog:
         self.t = None
         self.beat = time.time()
 
+    fallback = None      # (line, exit code): what a stall prints / returns instead of failing (the captured-exchange probe)
+
     def start(self, timeout, rank):
         import threading
         self.beat = time.time()
@@ -439,10 +441,15 @@ class _Watchdog:
 
         def run():
             while self.on:
-                time.sleep(1.0)
+                time.sleep(0.5)
                 if time.time() - self.beat > timeout:
                     print('bench.py: rank %d made no progress for %.0f s: giving up' % (rank, timeout), file=sys.stderr,
                           flush=True)
+                    if self.fallback is not None:      # the measured headline is out already: print it, say what stalled
+                        line, code = self.fallback
+                        if rank == 0 and line:
+                            print(line, flush=True)
+                        os._exit(code)
                     os._exit(5)
         self.t = threading.Thread(target=run, daemon=True)
         self.t.start()
@@ -639,6 +646,43 @@ def measure(args, workload, feed, steps, warmup, device, rank, world, steady_s=0
     return out, dict(eng=eng, cfg=cfg, batch=batch, rows=rows, dp=dp)
 
 
+def captured_exchange_probe(args, ctx, device, rank, world, single_ms):
+    """Data-parallel runs: the SAME step with the gradient all-reduce captured INTO its graph (no graph boundary, no host
+    launch between backward and the optimiser sweep; the side chain draws the next step's noise behind the join: DESIGN.md, Multi-GPU), timed
+    like the headline region in the same rank processes, after it.  The headline stays the two-graph form (`single`): a
+    captured collective that misbehaved on N ranks would hang rather than raise -- the caller arms the stall watchdog with the
+    headline line already assembled, so a stalled probe costs nothing but this entry."""
+    from drvae_amd import dist as D
+    import torch.distributed as dist
+    eng = ctx['eng']
+    eng.capture(split_for_allreduce='captured', allreduce=D.allreduce_sum)
+    steps, warm = max(args.steps, 20), 5
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        _WATCHDOG.kick()
+    with eng.partition():
+        for _ in range(warm):
+            eng.replay(None)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            eng.replay(None)
+        barrier()
+        dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    losses = eng.losses()
+    rows, L = ctx['rows'], ctx['cfg'].L
+    return {'ms_per_step': round(1e3 * dt / steps, 4), 'steps': steps, 'value': round(world * rows * L * steps / dt, 1),
+            'finite': bool(all(np.isfinite(v) for v in losses.values())), 'noise_drawn_ahead': bool(eng.noise_ahead),
+            'vs_single': round(1e3 * dt / steps / single_ms, 4)}
+
+
 def _free_port():
     import socket
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
@@ -716,6 +760,7 @@ def main():
     ap.add_argument('--dp-exchange', default='single', choices=['single', 'overlap', 'captured'],
                     help='data-parallel gradient exchange: one all-reduce between two graphs (default), two overlapped '
                          'pieces between three graphs, or the collective captured into the step graph')
+    ap.add_argument('--no-exchange-modes', action='store_true', help='data-parallel runs: skip the captured-exchange probe that follows the headline')
     ap.add_argument('--no-steady', action='store_true', help='skip the second, longer timed region')
     ap.add_argument('--no-extras', action='store_true',
                     help='skip the realistic-feed and other-workload measurements that follow the headline (cfg2 only)')
@@ -772,6 +817,20 @@ def main():
         if not args.no_cpu_baseline and args.workload != 'wide' and world == 1:   # rank 0 at N=1 only
             out['cpu_baseline'] = cpu_baseline(args.workload)
             out['elbo_vs_ref'] = parity_vs_cpu(args.workload, device)
+    if dp and not args.no_graph and args.dp_exchange == 'single' and not args.no_exchange_modes and args.feed == 'resident':
+        # both exchange forms in one record: the headline (`single`: two graphs, the all-reduce between them) and the
+        # captured form, probed AFTER it under the stall watchdog with the headline line as its fallback
+        out['exchange_modes'] = {'single': {'ms_per_step': res['ms_per_step'], 'value': res['value']},
+                                 'captured': {'error': 'the probe stalled (watchdog): the captured collective did not complete'}}
+        _WATCHDOG.fallback = (json.dumps(out) if rank == 0 else '', 0 if ok else 1)
+        _WATCHDOG.start(min(args.stall_timeout, 90.0), rank)
+        try:
+            out['exchange_modes']['captured'] = captured_exchange_probe(args, ctx, device, rank, world, res['ms_per_step'])
+        except Exception as e:       # noqa: BLE001  (e.g. an RCCL build that cannot be stream-captured)
+            print('bench.py: captured-exchange probe failed: %r' % (e,), file=sys.stderr)
+            out['exchange_modes']['captured'] = {'error': repr(e)}
+        _WATCHDOG.stop()
+        _WATCHDOG.fallback = None
     del ctx
     if world == 1 and not args.no_extras and args.workload == 'cfg2' and args.feed == 'resident' and not args.no_graph:
         # next to the headline (inputs resident in HBM, stratified batch): (1) the same step fed the way the

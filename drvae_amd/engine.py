@@ -983,6 +983,14 @@ class FusedStep(StepSchedule):
         g0 = self.arena.grad.storage_offset()
         side_ok, hs = self._side_adam_layout()
         side_adam = late and not split_kind and side_ok
+        # the gradient exchange captured INTO the step's graph (data parallelism, ``split_kind == 'captured'``): every gradient
+        # and the loss scalars are final in front of the collective, so no leaf work moves behind the join -- but the side chain,
+        # idle behind it, draws the NEXT step's noise (the main chain's graph then no longer starts with the draw) and the
+        # sweep's first workgroup orders the next step behind that.  Measured (one-rank RCCL, same box): cfg 2 0.2042 -> 0.2007 ms,
+        # cfg 4 0.1799 -> 0.1769; the heads' half of the sweep behind the collective on the side chain's 64 CUs as well
+        # (a flag published on entry of the main chain's sweep): 0.2124 / 0.1871 -- half the arena through a quarter of the
+        # chip's bandwidth takes longer than the whole sweep on the rest (profiles/r06_experiments.md)
+        cap_fork = self._cap_fork(mode, split_kind, side_ok)
         # the loss scalars (a leaf: only the host / the exchange reads them) are assembled by the side chain behind
         # the join, once the main chain has published that its reconstruction rows are final
         side_loss = side_adam or (late and split_kind is True and len(self.L_decx) > 1 and not self.wbranch.on)
@@ -998,7 +1006,7 @@ class FusedStep(StepSchedule):
                            xidx=p.tgt, sd_act='softplus', sd_shift=1e-3)
         if mode == 5 and self._rec == 'side':
             self._side_backward(Qmu, Qlv, Z1blk, mode, late, leaf)
-            self._side_graph_tail(late, leaf, side_loss, side_adam, hs)
+            self._side_graph_tail(late, leaf, side_loss, side_adam, hs, cap_fork=cap_fork)
             return
         if mode < 2:
             self.branch.fork()
@@ -1047,6 +1055,10 @@ class FusedStep(StepSchedule):
             self._adam_gate = (self.flags[6:7] if self._tail_gated() else self.flags[3:4], self.step_dev, 0,
                                self.sync_err[6:8], lo, hi)
             self._adam_n = hs if side_adam else None
+        if cap_fork:
+            # (the sweep's first workgroup also parks on the side chain's "tail through" flag: what orders the NEXT step --
+            # its first launch reads the noise the side chain has drawn -- behind it)
+            self._adam_gate = (self.flags[3:4], self.step_dev, 0, self.sync_err[6:8], 0, 4)
         if cfg.has_pert:
             P2 = p.c_z2F.out[-1]
             # everything that hangs on the z2Fz1 samples, one launch: scatter-back of the decoded
@@ -1074,7 +1086,7 @@ class FusedStep(StepSchedule):
                           # of a dv_kl_rows_bwd launch behind them (cfg 1: one launch less on the critical chain)
                           prior=(p.c_klp, p.KLPraw, cfg.kl_min, Qmu) if cfg.kind == 'pvae' else None)
         p.c_enc.backward(DQ, p.enc_in, None,
-                         publish_first=(self.flags[5:6], self.step_dev, 0) if (late and self.noise_ahead) else None)
+                         publish_first=(self.flags[5:6], self.step_dev, 0) if ((late or cap_fork) and self.noise_ahead) else None)
 
     def _side_backward(self, Qmu, Qlv, Z1blk, mode, late, leaf):
         """the side chain's share of the backward pass: y-marginalisation, fprop blocks, classifier -> ``DZ1B`` (its share
@@ -1170,11 +1182,24 @@ class FusedStep(StepSchedule):
                 else:
                     p.c_clf.backward(p.DLOG, [Z1blk], [[(p.DZ1B, 1.0, b1)]])
 
-    def _side_graph_tail(self, late, leaf, side_loss, side_adam, hs):
+    def _cap_fork(self, mode, split_kind, side_ok):
+        """data-parallel step with the exchange captured into its graph: does the side chain, idle behind the join, draw the
+        NEXT step's noise (``noise_ahead``, as in the single-GPU step)?"""
+        return bool(mode == 5 and split_kind == 'captured' and side_ok and self._late_ok() and self.cfg.has_y
+                    and T.get('dp_fork'))
+
+    def _side_graph_tail(self, late, leaf, side_loss, side_adam, hs, cap_fork=False):
         """(dual-graph schedule) what the side chain's graph runs behind its backward pass: publish its data gradients, the
         deferred leaf launches, the decoder heads' half of the optimiser sweep, the loss scalars, the NEXT step's noise, its
         own counters"""
         cfg, p = self.cfg, self.plan
+        if cap_fork:
+            K.flag_publish(self.flags[1:2], self.side_ctr)         # DZ1B / DZ2F / every side gradient is final (the join)
+            if self.noise_ahead:      # the next step's draws: this step's readers are through once the encoder backward has started
+                K.flag_wait(self.flags[5:6], self.side_ctr, self.sync_err[10:12])
+                K.fill_normal_rows(p.noise, p.noise_desc, self.seed, self.rng_ctr)
+            K.counters_add2(self.side_ctr, 1, self.side_t, 1, publish=(self.flags[3:4], self.side_ctr, 1))
+            return
         # DZ1B / DZ2F / side gradients are final: published on entry of the first leaf launch behind them (the
         # classifier's weight gradient) where there is one, else by a launch of its own
         tail = (self.fold_tail & 1) and late and len(leaf) > 0

@@ -170,7 +170,10 @@ class StepSchedule:
         self._split_capture = bool(split_for_allreduce)
         self._split_kind = split_for_allreduce          # False | True (two graphs) | 'overlap' | 'captured'
         cfg = self.cfg
-        self.noise_ahead = bool(dual and split_for_allreduce in (False, True) and self._late_ok() and T.get('noise_ahead'))
+        # (under a CAPTURED exchange too: the side chain then draws behind the join and sweeps its half behind the collective)
+        cap_fork = bool(dual and split_for_allreduce == 'captured' and self._cap_fork(5, 'captured', self._side_adam_layout()[0]))
+        self.noise_ahead = bool(dual and (split_for_allreduce in (False, True) or cap_fork) and self._late_ok()
+                                and T.get('noise_ahead'))
         self._noise_stale = True
         if dual:
             self._rec = 'main'

@@ -664,6 +664,43 @@ def mmd_rff_bwd(G, th, diff, gout, coef):
     G.copy_(-coef * gout.reshape(-1)[0] * diff[None, :] * torch.sin(th))
 
 
+def mmd_identity_fwd(diff, out, x1, x2):
+    d = x1.mean(0) - x2.mean(0)
+    diff.copy_(d)
+    out[0] = (d ** 2).sum()
+
+
+def mmd_identity_bwd(dx, diff, gout, coef):
+    dx.copy_((coef * gout.reshape(-1)[0] * diff)[None, :].expand_as(dx))
+
+
+def _mix(G, kind, gammas, sa, sb):
+    """the kernel mixture on a Gram matrix and its derivative w.r.t. G (poly) / the squared distance (rbf): dv_mmd_mix_*"""
+    gam = [float(g) for g in gammas]
+    if kind == 'poly':
+        v = sum((g * G + 1.0) ** 2 for g in gam) / len(gam)
+        dv = sum(2.0 * g * (g * G + 1.0) for g in gam) / len(gam)
+    else:
+        d2 = (sa.diagonal()[:, None] + sb.diagonal()[None, :] - 2.0 * G).clamp_min(0.0)
+        v = sum(torch.exp(-g * d2) for g in gam) / len(gam)
+        dv = sum(-g * torch.exp(-g * d2) for g in gam) / len(gam)
+    return v, dv
+
+
+def mmd_mix_fwd(part, G, kind, gammas, sa=None, sb=None):
+    part.copy_(_mix(G, kind, gammas, sa, sb)[0].sum(1))
+
+
+def mmd_mix_bwd(W, rs, G, kind, gammas, gout, coef, sa=None, sb=None):
+    W.copy_(coef * gout.reshape(-1)[0] * _mix(G, kind, gammas, sa, sb)[1])
+    rs.copy_(W.sum(1))
+
+
+def mmd_mix_combine(out4, p11, p12, p22, c11, c12, c22):
+    m11, m12, m22 = p11.double().sum() / c11, p12.double().sum() / c12, p22.double().sum() / c22
+    out4.copy_(torch.stack([m11 - 2.0 * m12 + m22, m11, m12, m22]).float())
+
+
 def rows_gather(out, src, idx=None, *, noise=None, sigma=0.0, onehot_cls=None, n_classes=0, width=None, park=None):
     if park is not None:
         flag_wait(park[0], park[1], park[2], park[3] if len(park) > 3 else 1)
@@ -968,7 +1005,7 @@ def nll_rows_raw_cs(out_part, dmu, dsd, ws, coef, x, mu, sd, bias, *, xidx=None,
             ws[b, X:2 * X] = dsd[b * 64:(b + 1) * 64].sum(0)
 
 
-FUNCTIONS = ['smalln_ws_numel', 'col_moment_blocks', 'recon_finalize', 'rank_metrics', 'nll_raw_cs_shape', 'nll_rows_raw_cs', 'rec_nll_rows', 'batch_masks', 'fill_normal_rows', 'linear_heads', 'heads_tiles', 'adamax_l2', 'batch_feed', 'mmd_rff_fwd', 'mmd_rff_bwd', 'counters_add2', 'ycont_fwd', 'ycont_bwd', 'flag_publish', 'flag_wait', 'gemm', 'linear_fwd', 'linear_bwd_data', 'linear_bwd_weight', 'linear_bwd_pair', 'colsum', 'act_bwd_', 'wn_scale', 'wn_bwd',
+FUNCTIONS = ['mmd_identity_fwd', 'mmd_identity_bwd', 'mmd_mix_fwd', 'mmd_mix_bwd', 'mmd_mix_combine', 'smalln_ws_numel', 'col_moment_blocks', 'recon_finalize', 'rank_metrics', 'nll_raw_cs_shape', 'nll_rows_raw_cs', 'rec_nll_rows', 'batch_masks', 'fill_normal_rows', 'linear_heads', 'heads_tiles', 'adamax_l2', 'batch_feed', 'mmd_rff_fwd', 'mmd_rff_bwd', 'counters_add2', 'ycont_fwd', 'ycont_bwd', 'flag_publish', 'flag_wait', 'gemm', 'linear_fwd', 'linear_bwd_data', 'linear_bwd_weight', 'linear_bwd_pair', 'colsum', 'act_bwd_', 'wn_scale', 'wn_bwd',
              'reparam_fwd', 'reparam_bwd', 'reparam_bwd_seg', 'z2f_post_bwd', 'kl_rows_fwd', 'kl_rows_fwd_pair', 'kl_rows_bwd', 'nll_rows_fwd', 'nll_rows_bwd', 'nll_rows_fwdbwd',
              'softmax_clamp_fwd', 'softmax_clamp_bwd', 'cat_terms_fwd', 'cat_terms_bwd', 'smalln_fwd', 'smalln_bwd_data',
              'smalln_bwd_weight', 'ymarg_fwd', 'ymarg_bwd', 'ymarg_fwdbwd',

@@ -129,9 +129,17 @@ def test_step_path_over_rccl_single_rank(dev):
     plain = run()
     single = run(DRVAE_FORCE_DP='1', MASTER_PORT='29561')
     pieces = run('--dp-exchange', 'overlap', DRVAE_FORCE_DP='1', MASTER_PORT='29562')
-    assert plain['finite'] and single['finite'] and pieces['finite']
-    assert single['losses_last_step'] == plain['losses_last_step'] == pieces['losses_last_step']
-    assert all(v == 0 for v in single['chain_wait_ticks'][0::2] + pieces['chain_wait_ticks'][0::2])
+    captured = run('--dp-exchange', 'captured', DRVAE_FORCE_DP='1', MASTER_PORT='29563')
+    assert plain['finite'] and single['finite'] and pieces['finite'] and captured['finite']
+    assert single['losses_last_step'] == plain['losses_last_step'] == pieces['losses_last_step'] == captured['losses_last_step']
+    assert all(v == 0 for v in single['chain_wait_ticks'][0::2] + pieces['chain_wait_ticks'][0::2] + captured['chain_wait_ticks'][0::2])
+    # round 6: the headline of a data-parallel run stays the two-graph form, the captured form (RCCL's all-reduce inside the step's
+    # graph, the side chain drawing the next step's noise behind the join) is probed after it in the same process and rides in the same line
+    assert captured['config']['dp_exchange'] == 'captured' and 'exchange_modes' not in captured
+    em = single['exchange_modes']
+    assert em['single']['ms_per_step'] == single['ms_per_step']
+    assert em['captured'].get('finite') is True and em['captured']['noise_drawn_ahead'] is True, em
+    assert em['captured']['ms_per_step'] < 1.5 * single['ms_per_step']
 
 
 def test_bench_self_launch_two_ranks_one_gpu(dev):

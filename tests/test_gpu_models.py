@@ -1,6 +1,8 @@
 """-m gpu: the model classes (drop-in counterparts of the reference's DrVAE / PVAE / VFAE)
 through their reference-style API -- ctor kwargs, state_dict, run_on_batch, forward --
 against the golden vectors, plus hipGraph replay == eager launches."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -149,6 +151,67 @@ def test_partitioned_replay_equals_eager(kind, dev):
     assert graph.iters == eager.iters == 7
     assert torch.equal(a0.param, a1.param) and torch.equal(a0.exp_avg_sq, a1.exp_avg_sq)
     assert eager.losses() == graph.losses()
+
+
+@pytest.mark.parametrize('kind', ['drvae', 'vfae'])
+def test_captured_exchange_forks_behind_the_collective(kind, dev):
+    """data parallelism with the gradient exchange captured INTO the step's graph (round 6): the side chain, idle behind the
+    join, draws the NEXT step's noise as in the single-GPU step (the main chain's graph no longer starts with the draw; the
+    sweep's first workgroup orders the next step behind the side chain's tail).  With a capturable stand-in collective (a
+    device copy of the buffer onto itself through a scratch: the schedule does not depend on what the collective computes) the
+    replays are bitwise the eager steps with the same collective, and bitwise the two-graph split form; no wait times out."""
+    from tests.test_engine_cpu import make_engine, set_batch
+    spec = M.ModelSpec(kind=kind, L=2)
+    params = M.init_params(spec, 3, as_numpy=True)
+    batch = M.make_batch(spec, 150, seed=5)
+    engines = [make_engine(spec, params, dev) for _ in range(3)]
+    scratch = [torch.empty_like(a.xchg) for _, a in engines]
+
+    def make_ar(i):
+        def ar(buf):         # (in place, stream-ordered, capturable: what an all-reduce over one rank is)
+            scratch[i].copy_(buf)
+            buf.copy_(scratch[i])
+        return ar
+    for i, (e, _) in enumerate(engines):
+        set_batch(e, batch, dev)
+        e.train_step(allreduce=make_ar(i))
+    (eager, a0), (cap, a1), (split, a2) = engines
+    cap.capture(split_for_allreduce='captured', allreduce=make_ar(1))
+    assert cap._side_graph is not None and len(cap._graphs) == 1
+    assert cap.noise_ahead, 'the captured exchange step does not draw ahead on the side chain'
+    split.capture(split_for_allreduce=True)
+    for e, ar in ((cap, None), (split, make_ar(2))):
+        with e.partition(64):
+            for _ in range(8):
+                e.replay(ar)
+    for _ in range(8):
+        eager.train_step(allreduce=make_ar(0))
+    torch.cuda.synchronize()
+    cap.check_sync()
+    split.check_sync()
+    assert cap.iters == eager.iters == split.iters == 9
+    for a in (a1, a2):
+        assert torch.equal(a0.param, a.param) and torch.equal(a0.exp_avg, a.exp_avg) and torch.equal(a0.exp_avg_sq, a.exp_avg_sq)
+    assert eager.losses() == cap.losses() == split.losses()
+    # ... and the switch that turns the fork off gives the same numbers (the round-5 form: everything in front of the join)
+    from drvae_amd import tuning
+    os.environ['DRVAE_TUNE'] = 'dp_fork=0'
+    tuning.reload()
+    try:
+        plain, a3 = make_engine(spec, params, dev)
+        set_batch(plain, batch, dev)
+        plain.train_step(allreduce=make_ar(0))
+        plain.capture(split_for_allreduce='captured', allreduce=make_ar(0))
+        assert not plain.noise_ahead
+        with plain.partition(64):
+            for _ in range(8):
+                plain.replay(None)
+        torch.cuda.synchronize()
+        plain.check_sync()
+    finally:
+        os.environ.pop('DRVAE_TUNE')
+        tuning.reload()
+    assert torch.equal(a0.param, a3.param) and eager.losses() == plain.losses()
 
 
 def test_checkpoint_roundtrip_and_errors(dev, tmp_path):
