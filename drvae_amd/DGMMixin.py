@@ -59,9 +59,13 @@ class DeepGenerativeModelMixin:
         * ``fit(DeviceBatcher(..., batch_size=rows per rank), ...)`` binds the batcher with ``dp=(rank, world)``: every
           rank draws the same global index table from the shared seed and runs its columns; the global counts of every
           batch are table data (no collective but the gradient exchange); captured split graphs + the exchange per step;
-        * evaluation (``run_on_batch(train_mode=False)``, ``evaluate_performance_on_dataset``) is NOT sharded: every rank
-          evaluates what it is given with the same draws, so early stopping decides the same on every rank; only rank 0
-          writes snapshots and log lines.
+        * ``evaluate_performance_on_dataset`` of an HBM-resident dataset is sharded BY ROWS (round 6): every rank runs the loss
+          pass and the inference on its n / world rows (global normalisers, Philox draws keyed by the row's position in
+          the whole set), the partials -- loss scalars, per-row statistics, float64 column moments, class probabilities --
+          meet in ONE all-reduce, and the same finalising launches as in a one-rank evaluation leave identical metrics on
+          every rank, so early stopping decides the same everywhere (``model.shard_evaluation = False``: every rank
+          evaluates the whole set); ``run_on_batch(train_mode=False)`` evaluates what it is given; only rank 0 writes
+          snapshots and log lines.
 
         ``broadcast``: parameters, Adam moments and the step / Philox counters of rank 0 go to every rank first.
         Returns (rank, world).  A one-rank world (or none) leaves the model single-process unless DRVAE_FORCE_DP=1."""
@@ -197,7 +201,7 @@ class DeepGenerativeModelMixin:
         has_x2 = has_x2 if has_x2 is not None else zeros
         has_y = has_y if has_y is not None else zeros
         counts = getattr(self, '_global_counts', None)
-        eng.row0 = 0
+        eng.row0 = int(getattr(self, '_row0_override', 0))      # (a row shard of a whole-set evaluation: ``fit._EvalGraph``)
         if dp and self._dp is not None:
             from . import dist as D
             eng.row0 = self._dp[0] * n          # (every rank feeds the same number of rows: ``shard_rows``)

@@ -86,15 +86,15 @@ class OverlappedAllReduce:
             work.wait()
 
 
-def global_counts(has_x2, has_y, kind='drvae', semi_supervised=True):
+def global_counts(has_x2, has_y, kind='drvae', semi_supervised=True, local=False):
     """(N_total, N_pairs, N_labeled) over all ranks (tiny host-side all-reduce; the flags
-    come from the host data pipeline)."""
+    come from the host data pipeline).  ``local``: the flags already are the whole set's (no collective)."""
     hx = np.asarray(has_x2).astype(bool).reshape(-1)
     hy = np.asarray(has_y).astype(bool).reshape(-1)
     n_tot = int(hy.sum()) if (kind == 'vfae' and not semi_supervised) else len(hy)
     c = torch.tensor([n_tot, int(hx.sum()) if kind != 'vfae' else 0, int(hy.sum()) if kind != 'pvae' else 0],
                      dtype=torch.float64)
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if not local and dist.is_initialized() and dist.get_world_size() > 1:
         if dist.get_backend() == 'nccl':
             c = c.cuda()
         dist.all_reduce(c, op=dist.ReduceOp.SUM)

@@ -427,15 +427,19 @@ class _EvalGraph:
         # the engine (DGMMixin._apply) and a graph of the old one would read freed parameters -- the engine's identity is
         # part of the signature (and ``_apply`` drops the cache)
         eng = model.engine()
+        # data parallelism: the ROWS of a whole-set evaluation are sharded over the ranks (every rank holds the dataset; its
+        # heavy passes run on rows [n r / W, n (r + 1) / W) only), the partials meet in ONE all-reduce -- see ``_sequence_partial``
+        dp = model._dp if (getattr(model, '_dp', None) is not None and getattr(model, 'shard_evaluation', True)
+                           and int(x1.shape[0]) >= 2 * model._dp[1]) else None
         sig = tuple(int(t.data_ptr()) if torch.is_tensor(t) else 0
                     for t in (getattr(ds, k, None) for k in ('x1', 'x2', 'y', 'has_x2', 'has_y'))) + \
-            (int(x1.shape[0]), id(eng), int(eng.arena.param.data_ptr()))
+            (int(x1.shape[0]), id(eng), int(eng.arena.param.data_ptr()), dp)
         ev = cache.get(id(ds))
         if ev is None or ev.sig != sig:
             if len(cache) > 8:
                 cache.clear()
             try:
-                ev = cache[id(ds)] = _EvalGraph(model, ds, sig)
+                ev = cache[id(ds)] = _EvalGraph(model, ds, sig, dp=dp)
             except Exception as e:      # the reference evaluates on regardless of a failing loss pass (src/DrVAE.py:647-654):
                 import warnings         # so does the step-by-step path, which this dataset now takes
                 warnings.warn('drvae_amd: the captured whole-set evaluation could not be built (%s: %s); evaluating step '
@@ -444,11 +448,31 @@ class _EvalGraph:
                 ev.sig, ev.graph = sig, None
         return ev if ev.graph is not None else None
 
-    def __init__(self, model, ds, sig):
-        self.model, self.ds, self.sig = model, ds, sig
+    def __init__(self, model, ds, sig, dp=None):
+        self.model, self.sig = model, sig
         self.graph = None
         kind = model.kind
         dev = ds.x1.device
+        self.dp, self.full = dp, None
+        if dp is not None:
+            # this rank's rows as VIEWS of the dataset's tensors; the normalisers of the loss pass are the whole set's counts,
+            # the Philox draws are keyed by the row's position in the whole set (``row0``): the shards' terms add up to the
+            # one-rank evaluation's
+            import types
+            from . import dist as D
+            rank, world = dp
+            n_all = int(ds.x1.shape[0])
+            self.lo, self.hi = n_all * rank // world, n_all * (rank + 1) // world
+            self.full = ds
+            hx = getattr(ds, 'has_x2', None) if kind != 'vfae' else None
+            hy = getattr(ds, 'has_y', None) if kind != 'pvae' else None
+            zer = np.zeros(n_all, np.int64)
+            eng0 = model.engine()
+            self.counts = D.global_counts(hx.cpu().numpy() if hx is not None else zer, hy.cpu().numpy() if hy is not None else zer,
+                                          eng0.cfg.kind, eng0.cfg.semi_supervised, local=True)
+            ds = types.SimpleNamespace(**{k: (getattr(ds, k)[self.lo:self.hi] if torch.is_tensor(getattr(ds, k, None)) else None)
+                                          for k in ('x1', 'x2', 's', 'y', 'has_x2', 'has_y')})
+        self.ds = ds
         g = lambda k: getattr(ds, k, None)
         # rows of the groups (once per dataset: a host sync each)
         self.x2idx = torch.nonzero(g('has_x2').reshape(-1).to(dev)).reshape(-1) if kind != 'vfae' else None
@@ -458,6 +482,7 @@ class _EvalGraph:
         # the loss plan of the whole set: built by the ordinary path (host index lists), then reused
         eng = model.engine()
         keep, keep_training, was_training = eng.plan, eng.training, model.training
+        keep_counts, keep_row0 = model.__dict__.get('_global_counts'), eng.row0
         try:
             model.eval()
             kw = dict(x1=g('x1'), s=g('s'))
@@ -466,21 +491,38 @@ class _EvalGraph:
             if kind != 'pvae':
                 kw.update(y=g('y'), has_y=g('has_y'))
             self.kw = kw
+            if dp is not None:
+                model._global_counts, model._row0_override = self.counts, self.lo
             model.run_on_batch(train_mode=False, **kw)          # (also the warm-up of every kernel of the sequence)
             self.plan = eng.plan
             n_in = int(ds.x1.shape[0])
             rows = np.asarray(self.plan.rows)
             self.sel = None if (len(rows) == n_in and (rows == np.arange(n_in)).all()) else torch.as_tensor(rows, device=dev)
+            if dp is not None:
+                self._shard_layout()
             self._sequence()                                    # warm-up of the rest (allocations, code objects)
             torch.cuda.synchronize()
             gph = torch.cuda.CUDAGraph()
             eng.join_side()
             with torch.cuda.graph(gph):
                 self.names, self.vec, self.loss_keys = self._sequence()
+            if dp is not None:
+                self._finalize_full()                           # (warm-up)
+                torch.cuda.synchronize()
+                self.graph_final = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph_final):
+                    self._finalize_full()
             self.graph = gph
         finally:
             eng.plan, eng.training = keep, keep_training
             model.train(was_training)
+            if dp is not None:
+                model.__dict__.pop('_row0_override', None)
+                if keep_counts is None:
+                    model.__dict__.pop('_global_counts', None)
+                else:
+                    model._global_counts = keep_counts
+                eng.row0 = keep_row0
 
     def _sequence(self):
         """the launch sequence (eager for the warm-up, then under capture); -> (names, float64 vector, loss keys)"""
@@ -506,7 +548,7 @@ class _EvalGraph:
         if kind != 'pvae':
             names += ['y_auroc', 'y_aupr', 'y_acc']
         names += ['x1_' + k for k in _NAN4]
-        has_x2 = kind != 'vfae' and len(self.x2idx) > 0
+        has_x2 = kind != 'vfae' and (len(self.x2idx) > 0 if self.dp is None else self.full_n_x2 > 0)
         if has_x2:
             names += ['x2_' + k for k in _NAN4]
         if not hasattr(self, 'vec'):
@@ -516,6 +558,9 @@ class _EvalGraph:
         o = n_loss
         # --- means-only inference + metrics (the tail: dv_rank_metrics / dv_recon_finalize, no sort, no host decisions)
         res = self._infer()
+        if self.dp is not None:
+            self._sequence_partial(res, vec[:n_loss])
+            return names, vec, list(losses)
         if kind != 'pvae':
             self._y_metrics(res, vec[o:o + 3])
             o += 3
@@ -524,6 +569,137 @@ class _EvalGraph:
         if has_x2:
             self._recon(ds.x2, res['px2'][0], res['px2'][1], self.x2idx32, vec[o:o + 4], 'x2', res['px_bias'])
         return names, vec, list(losses)
+
+    # ------------------------------------------------------------ rows sharded over ranks (data parallelism, round 6)
+    def _shard_layout(self):
+        """ONE flat float64 exchange buffer for the whole evaluation, laid out for the WHOLE set: [loss scalars | proba | pred |
+        x1: row statistics, log-likelihood rows, column-moment blocks of every rank | x2: the same].  Every rank writes its
+        rows' slots (zeros elsewhere), one sum all-reduce leaves the complete arrays on every rank (float32 / int32 values are
+        exact in float64, and x + 0 = x), and the finalising launches -- the same kernels as without sharding -- run on them."""
+        from . import kernels as K
+        m, full, kind = self.model, self.full, self.model.kind
+        dev = full.x1.device
+        rank, world = self.dp
+        n, X, Y = int(full.x1.shape[0]), int(full.x1.shape[1]), (m.dim_y if kind != 'pvae' else 0)
+        self.n_all = n
+        bounds = [(n * r // world, n * (r + 1) // world) for r in range(world)]
+        self.full_x2idx32 = self.full_yidx32 = None
+        self.full_n_x2 = 0
+        blk2 = 1
+        if kind != 'vfae':
+            hx = full.has_x2.reshape(-1).to(dev) != 0
+            self.full_x2idx32 = torch.nonzero(hx).reshape(-1).to(torch.int32)
+            self.full_n_x2 = int(self.full_x2idx32.numel())
+            per = [int(hx[a:b].sum()) for a, b in bounds]
+            blk2 = max(K.col_moment_blocks(max(c, 1)) for c in per)
+        if kind != 'pvae':
+            self.full_yidx32 = torch.nonzero(full.has_y.reshape(-1).to(dev)).reshape(-1).to(torch.int32)
+        blk1 = max(K.col_moment_blocks(b - a) for a, b in bounds)
+        o, self.off = 0, {}
+        for name, size in (('loss', 8), ('proba', n * Y), ('pred', n if Y else 0), ('rows1', n * 6), ('ll1', n),
+                           ('part1', world * blk1 * 3 * X), ('rows2', n * 6 if self.full_n_x2 else 0),
+                           ('ll2', n if self.full_n_x2 else 0), ('part2', world * blk2 * 3 * X if self.full_n_x2 else 0)):
+            self.off[name] = (o, size)
+            o += size
+        self.blk = {'x1': blk1, 'x2': blk2}
+        self.pack = torch.zeros(o, dtype=torch.float64, device=dev)
+        f32 = lambda *shape: torch.zeros(*shape, device=dev)
+        self.g_rows = {'x1': f32(n, 6), 'x2': f32(n, 6)}
+        self.g_ll = {'x1': f32(n), 'x2': f32(n)}
+        if Y:
+            self.g_proba, self.g_pred32 = f32(n, Y), torch.zeros(n, dtype=torch.int32, device=dev)
+            self.g_y32 = full.y.reshape(-1).to(dev, torch.int32).contiguous()
+
+    def _slot(self, name):
+        o, size = self.off[name]
+        return self.pack[o:o + size]
+
+    def _sequence_partial(self, res, loss_vec):
+        """this rank's share of the evaluation's partials into the exchange buffer (captured; no finalising launch)"""
+        from . import kernels as K
+        from ._lib import GAUSS_SIGMA
+        m, ds, kind = self.model, self.ds, self.model.kind
+        rank, world = self.dp
+        lo, hi, X = self.lo, self.hi, int(ds.x1.shape[1])
+        self.pack.zero_()
+        self._slot('loss')[:loss_vec.numel()].copy_(loss_vec)
+        if kind != 'pvae':
+            Y = m.dim_y
+            self._slot('proba').view(self.n_all, Y)[lo:hi].copy_(res['proba'])
+            self._slot('pred')[lo:hi].copy_(res['pred'].reshape(-1))
+        bias = res['px_bias']
+        for tag, x, key, sel in (('x1', ds.x1, 'px1', None), ('x2', getattr(ds, 'x2', None), 'px2', self.x2idx32)):
+            if tag == 'x2' and (kind == 'vfae' or not self.full_n_x2):
+                continue
+            x = x.to(torch.float32)
+            M = int(x.shape[0])
+            n_sel = int(sel.numel()) if sel is not None else M
+            buf = self.__dict__.setdefault('_recon_bufs', {})
+            if tag not in buf:
+                buf[tag] = (torch.empty(M, 6, device=x.device),
+                            torch.zeros(self.blk[tag], 3, X, dtype=torch.float64, device=x.device), torch.empty(M, device=x.device))
+            rows, part, ll = buf[tag]
+            x_rec, x_std = res[key][0], res[key][1]
+            if X <= K.RECON_ROWS_MAX_X:
+                K.recon_rows(rows, ll, x, x_rec, x_std, bias=bias[:2] if bias is not None else None,
+                             sd_shift=bias[2] if bias is not None else 0.0)
+            else:
+                K.recon_row_stats(rows, x, x_rec)
+                K.nll_rows_fwd(ll, x, x_rec, x_std, mode=GAUSS_SIGMA)
+            t = '1' if tag == 'x1' else '2'
+            self._slot('rows' + t).view(self.n_all, 6)[lo:hi].copy_(rows)
+            self._slot('ll' + t)[lo:hi].copy_(ll)
+            if n_sel > 0:
+                nb = K.col_moment_blocks(n_sel)
+                K.col_moments(None, x, x_rec, sel=sel, part=part[:nb], r_bias=bias[0] if bias is not None else None)
+                self._slot('part' + t).view(world, self.blk[tag], 3, X)[rank, :nb].copy_(part[:nb])
+
+    def _finalize_full(self):
+        """behind the all-reduce: the complete arrays out of the exchange buffer, then the SAME finalising launches as the
+        unsharded evaluation (``dv_rank_metrics``, ``dv_recon_finalize``) over the whole set -> ``vec``"""
+        from . import kernels as K
+        m, kind, full = self.model, self.model.kind, self.full
+        vec, n, X = self.vec, self.n_all, int(full.x1.shape[1])
+        n_loss = len(E.LOSS_IDX)
+        vec[:n_loss].copy_(self._slot('loss')[:n_loss])
+        o = n_loss
+        if kind != 'pvae':
+            Y = m.dim_y
+            self.g_proba.copy_(self._slot('proba').view(n, Y))
+            self.g_pred32.copy_(self._slot('pred'))
+            self._rank_metrics(self.g_proba, self.g_y32, self.g_pred32, self.full_yidx32, vec[o:o + 3], n)
+            o += 3
+        for tag, t, sel in (('x1', '1', None), ('x2', '2', self.full_x2idx32)):
+            if tag == 'x2' and (kind == 'vfae' or not self.full_n_x2):
+                continue
+            self.g_rows[tag].copy_(self._slot('rows' + t).view(n, 6))
+            self.g_ll[tag].copy_(self._slot('ll' + t))
+            part = self._slot('part' + t).view(-1, 3, X)
+            K.recon_finalize(vec[o:o + 4], self.g_rows[tag], part, X, sel=sel, n=int(sel.numel()) if sel is not None else n,
+                             ll=self.g_ll[tag])
+            o += 4
+
+    def _rank_metrics(self, proba, y32, pred32, yidx32, out3, n_rows):
+        """[auroc, aupr, acc] of the labeled rows ``yidx32`` from the pair-counting kernel (sort + scan beyond its range)"""
+        from . import kernels as K
+        m = self.model
+        n_lab, Y = int(yidx32.numel()), m.dim_y
+        if n_lab > K.RANK_MAX_ROWS or n_lab == 0:
+            idx = yidx32.long()
+            v = MET.eval_y_prediction_dev(pred32.index_select(0, idx), proba.index_select(0, idx), y32.index_select(0, idx).long(), Y)
+            out3.copy_(torch.stack([v['auroc'].reshape(()), v['aupr'].reshape(()), v['acc'].reshape(())]))
+            return
+        if not hasattr(self, 'rank_counts'):
+            n_cls = 1 if Y == 2 else Y
+            self.rank_counts = torch.zeros(n_cls, n_lab, 4, dtype=torch.int32, device=proba.device)
+            self.rank_out = torch.zeros(2 * n_cls + 1, dtype=torch.float64, device=proba.device)
+        if Y == 2:
+            K.rank_metrics(out3, self.rank_counts, proba, y32, pred32=pred32, sel=yidx32, c0=1, n_cls=1, binary=True)
+        else:
+            K.rank_metrics(self.rank_out, self.rank_counts, proba, y32, pred32=pred32, sel=yidx32, c0=0, n_cls=Y, binary=False)
+            out3[0:1].copy_(self.rank_out[0:2 * Y:2].mean().reshape(1))
+            out3[1:2].copy_(self.rank_out[1:2 * Y:2].mean().reshape(1))
+            out3[2:3].copy_(self.rank_out[2 * Y:2 * Y + 1])
 
     def _y_metrics(self, res, out3):
         """accuracy / ROC-AUC / average precision of the labeled rows (src/DGMMixin.py:158-190) -> out3 = [auroc, aupr, acc]"""
@@ -647,6 +823,10 @@ class _EvalGraph:
         self.plan.set_beta(eng.beta_pert())                 # (the annealing coefficient is data of the plan, not of the graph)
         self.graph.replay()
         eng._noise_stale = True      # (the replay drew from the Philox counter: a train step drawn ahead re-draws, as after any eager draw)
+        if self.dp is not None:      # rows sharded over the ranks: ONE sum all-reduce of the partials, then the finalising launches
+            from . import dist as D
+            D.allreduce_sum(self.pack)
+            self.graph_final.replay()
         v = dict(zip(self.names, self.vec.cpu().tolist()))  # THE host sync of the evaluation
         perf = OrderedDict()
         perf['losses'] = OrderedDict((k, torch.tensor(v['loss_' + k])) for k in self.loss_keys)

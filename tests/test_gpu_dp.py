@@ -278,6 +278,26 @@ def _fit_worker(rank, world, port, kind, buckets, backend, q):
             dist.barrier()
             dist.destroy_process_group()
             return
+        if buckets.get('eval_only'):
+            # the whole-set evaluation with its rows sharded over the ranks against the SAME evaluation (same parameters,
+            # same Philox counter) of the whole set on this rank alone
+            eng = model.engine()
+            ctr = eng.rng_ctr.clone()
+            out = {}
+            for tag, shard in (('sharded', True), ('whole', False), ('again', True)):
+                model.shard_evaluation = shard
+                eng.rng_ctr.copy_(ctr)
+                perf, txt = model.evaluate_performance_on_dataset(ds)
+                out[tag] = {k: (float(v) if not isinstance(v, (dict, str)) else v) for k, v in perf.items() if k != 'losses'}
+                out[tag].update({'loss_' + k: float(v) for k, v in perf['losses'].items()})
+                out[tag]['txt'] = txt
+            from drvae_amd.fit import _EvalGraph
+            ev = model._eval_graphs[id(ds)]
+            out['rows'] = (ev.lo, ev.hi) if ev.dp is not None else None
+            q.put((rank, out))
+            dist.barrier()
+            dist.destroy_process_group()
+            return
         means, tabs, bat = _fit_epochs(model, ds, w, 32 // world, buckets)
         eng = model.engine()
         torch.cuda.synchronize()
@@ -441,3 +461,30 @@ def test_fit_epochs_stratified_feed_two_ranks(dev):
     single = eng.arena.param.cpu().numpy()
     err = np.linalg.norm(r0['param'] - single) / np.linalg.norm(single)
     assert err < 1e-4, err
+
+
+@pytest.mark.parametrize('kind', ['drvae', 'vfae', 'pvae'])
+def test_whole_set_evaluation_is_sharded_by_rows_under_data_parallelism(dev, kind):
+    """round 6 (missing 5): under ``enable_data_parallel`` the whole-set evaluation of an HBM-resident dataset runs
+    every rank on its n / world rows (loss pass with the whole set's normalisers and Philox draws keyed by the row's position
+    in the whole set, inference, per-row statistics, float64 column moments), the partials meet in ONE all-reduce and the
+    same finalising launches give every metric of the one-rank evaluation: losses 1e-5 (fp32 row sums in another order),
+    reconstruction metrics 1e-6, accuracy / ROC-AUC / AP exactly (integer pair counts); identical on every rank"""
+    r0, r1 = _run_fit_ranks(2, kind, {'eval_only': True})
+    assert r0['rows'] == (0, 256) and r1['rows'] == (256, 512)
+    for r in (r0, r1):
+        a, b = r['sharded'], r['whole']
+        assert set(a) == set(b)
+        for k in a:
+            if k in ('model_class', 'txt'):
+                assert a[k] == b[k] or k == 'txt'
+            elif k.startswith('loss_'):
+                assert abs(a[k] - b[k]) <= 2e-5 * max(1.0, abs(b[k])), (k, a[k], b[k])
+            elif k.startswith('y_'):
+                assert a[k] == b[k], (k, a[k], b[k])
+            elif np.isnan(b[k]):
+                assert np.isnan(a[k]), k
+            else:
+                assert abs(a[k] - b[k]) <= 1e-6 * max(1.0, abs(b[k])), (k, a[k], b[k])
+        assert r['again'] == r['sharded']                    # replays of the two graphs + the exchange: reproducible
+    assert r0['sharded'] == r1['sharded']                    # identical on every rank: early stopping decides alike
