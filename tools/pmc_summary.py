@@ -6,6 +6,7 @@ import sys
 from collections import defaultdict
 
 root = sys.argv[1] if len(sys.argv) > 1 else 'gpurun_out/pmc_r1'
+wl = sys.argv[2] if len(sys.argv) > 2 else 'cfg2'      # the workload the passes ran (tools/pmc_collect.sh <workload>)
 
 
 def load(sub):
@@ -48,7 +49,7 @@ write, _, s2 = load('write')
 sq, _, s3 = load('sq')
 tcc, _, s4 = load('tcc')
 print('# rocprofv3 --pmc passes (separate runs: FETCH_SIZE | WRITE_SIZE | 8 SQ counters | TCC_HIT/MISS) over')
-print('#   python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline     (tools/pmc_collect.sh;')
+print('#   python3 bench.py --workload %s %s --no-cpu-baseline --no-roofline --no-steady --no-extras     (tools/pmc_collect.sh %s;' % (wl, '--steps 3 --warmup 1' if wl == 'wide' else '--steps 20 --warmup 5', wl))
 print('#   single-graph schedule: counter collection serializes dispatches).  Per-STEP averages over %d steps.' % steps)
 print('# FETCH_SIZE/WRITE_SIZE in KB as reported; gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE counts')
 print('# 1/2 of the bytes of wide (16 B/lane) coalesced reads.')
@@ -76,8 +77,10 @@ for k in sorted(fetch, key=lambda k: -fetch[k]['FETCH_SIZE']):
         gf += f
         gw += w
         gc += calls[k] / steps
-print('# TOTAL per step: FETCH %.1f MB (reported; <= %.1f MB after the x2 wide-load correction), WRITE %.1f MB; '
-      'algorithmic ~94 MB (SURVEY 8(d))' % (tot_f / 1e3, 2 * tot_f / 1e3, tot_w / 1e3))
+alg = {'cfg2': 'algorithmic ~94 MB (SURVEY 8(d))',
+       'wide': 'algorithmic ~5.1 GB (124.5 M parameters x 10 words: read forward and backward, gradient, Adam\'s 7; + 0.12 GB of inputs)'}.get(wl, '')
+print('# TOTAL per step: FETCH %.1f MB (reported; <= %.1f MB after the x2 wide-load correction), WRITE %.1f MB; %s'
+      % (tot_f / 1e3, 2 * tot_f / 1e3, tot_w / 1e3, alg))
 print('# GEMM family per step: %.0f launches, FETCH %.1f MB reported -> %.1f MB corrected, WRITE %.1f MB => %.2f MB '
       'HBM-side traffic per launch' % (gc, gf / 1e3, 2 * gf / 1e3, gw / 1e3, (2 * gf + gw) / 1e3 / max(gc, 1)))
 lds = sum(v.get('SQ_LDS_BANK_CONFLICT', 0) for v in sq.values())

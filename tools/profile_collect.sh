@@ -24,7 +24,7 @@ unset DRVAE_SIDE_CUS
 export PMC_EXTRA="TCC_EA0_RDREQ_sum,TCC_EA0_RDREQ_LEVEL_sum,TCC_EA0_RDREQ_DRAM_sum,TCC_EA0_RDREQ_32B_sum"
 for wl in cfg2 wide; do
   bash tools/pmc_collect.sh $wl > $O/pmc_$wl.log 2>&1
-  python3 tools/pmc_summary.py gpurun_out/pmc_rr > $O/${wl}_pmc_summary.txt 2>&1
+  python3 tools/pmc_summary.py gpurun_out/pmc_rr $wl > $O/${wl}_pmc_summary.txt 2>&1
   rm -rf gpurun_out/pmc_rr
 done
 unset PMC_EXTRA
