@@ -533,7 +533,8 @@ class FusedStep(StepSchedule):
                 K.flag_publish(pub[0], pub[1], 1)
                 pub = None
         else:
-            self.branch.fork()
+            if not getattr(self, '_late_fork', False):
+                self.branch.fork()
             pub = None
         self._decoder_forward(pub)
         if mode == 5:
@@ -668,6 +669,8 @@ class FusedStep(StepSchedule):
             # 256 MB of finished heads written and read back)
             raw_eval = raw_ok and not self.fuse_bwd and not self.training and bool(T.get('nll_cs'))
             PX = p.c_decx.forward(p.dec_in, publish=pub, raw_last=raw or raw_eval)
+            if getattr(self, '_late_fork', False):       # (chip-filling step: the side chain starts HERE, next to the row pass below)
+                self.branch.fork()
         if self._nll_fused:
             raw_eval = False
         elif not gauss:        # Bernoulli / Poisson rows (+ the gradient w.r.t. the head's pre-activation in a train step)

@@ -188,7 +188,13 @@ class StepSchedule:
         # workgroups of the other queue and cost more than they hide (measured, round 4: 32.0 ms with the fork/join,
         # 31.5 ms in order on one stream)
         branch_on = self.branch.on
-        if branch_on and not dual and not self._latency_bound() and T.get('wide_single'):
+        self._late_fork = False
+        if branch_on and not dual and not self._latency_bound() and T.get('wide_single') == 2:
+            # (round 6) ... or as a branch forked LATE: behind the decoder heads' product, next to the HBM-bound NLL row pass
+            # -- the one stretch of the main chain that leaves the matrix pipes idle -- and joined behind the decoder's
+            # backward products (the side chain's 0.4 ms of small launches are through long before)
+            self._late_fork = True
+        elif branch_on and not dual and not self._latency_bound() and T.get('wide_single'):
             self.branch.on = False
         try:
             self._capture_main(split_for_allreduce)
@@ -208,6 +214,7 @@ class StepSchedule:
         finally:
             self._rec = 'both'
             self.branch.on = branch_on
+            self._late_fork = False
             if gc_was_on:
                 gc.enable()
         self._graph_key = self.plan.key

@@ -28,7 +28,7 @@ DEFAULTS = {
     'tail_gate': 1,      # the side chain's tail is awaited by the NEXT step's first launch (0: by this step's optimiser launch)
     'concurrent': 1,     # side chain at all (0: one stream)
     'part_xcd': 0,       # the side chain's CU reserve as whole XCDs (1) instead of n/32 CUs of every shader engine (0)
-    'wide_single': 1,    # chip-filling steps (wide configuration) are captured on one stream, no fork/join
+    'wide_single': 2,    # chip-filling steps (wide configuration): 1 = captured on one stream, no fork/join; 2 = the side chain as a branch forked LATE, next to the HBM-bound NLL row pass (cfg 5: 31.09-31.15 -> 30.87-30.89 ms); 0 = forked at the start of the step (31.2-31.4)
     'nll_cs': 1,         # chip-filling heads: their bias gradient folded into the NLL row pass (no column-sum pass of its own; 2: buffers at any size -- tests, with raw_heads=2)
     'klq_epi': 1,        # the z3 term's backward (KL + sample path of q(z3|z1,y)) in the epilogue of the data-gradient product in front of it
     'kl_pair': 1,        # PVAE's two sets of KL rows (prior term, pairs' term) as one launch on its main chain
