@@ -822,15 +822,19 @@ def main():
         # captured form, probed AFTER it under the stall watchdog with the headline line as its fallback
         out['exchange_modes'] = {'single': {'ms_per_step': res['ms_per_step'], 'value': res['value']},
                                  'captured': {'error': 'the probe stalled (watchdog): the captured collective did not complete'}}
-        _WATCHDOG.fallback = (json.dumps(out) if rank == 0 else '', 0 if ok else 1)
-        _WATCHDOG.start(min(args.stall_timeout, 90.0), rank)
-        try:
-            out['exchange_modes']['captured'] = captured_exchange_probe(args, ctx, device, rank, world, res['ms_per_step'])
-        except Exception as e:       # noqa: BLE001  (e.g. an RCCL build that cannot be stream-captured)
-            print('bench.py: captured-exchange probe failed: %r' % (e,), file=sys.stderr)
-            out['exchange_modes']['captured'] = {'error': repr(e)}
-        _WATCHDOG.stop()
-        _WATCHDOG.fallback = None
+        if dist.is_initialized() and dist.get_backend() != 'nccl':
+            # (gloo -- the one-GPU functional tests of the multi-rank path -- runs its collectives on the host: nothing to capture)
+            out['exchange_modes']['captured'] = {'skipped': 'backend %s cannot be captured into a hipGraph' % dist.get_backend()}
+        else:
+            _WATCHDOG.fallback = (json.dumps(out) if rank == 0 else '', 0 if ok else 1)
+            _WATCHDOG.start(min(args.stall_timeout, 90.0), rank)
+            try:
+                out['exchange_modes']['captured'] = captured_exchange_probe(args, ctx, device, rank, world, res['ms_per_step'])
+            except Exception as e:       # noqa: BLE001  (e.g. an RCCL build that cannot be stream-captured)
+                print('bench.py: captured-exchange probe failed: %r' % (e,), file=sys.stderr)
+                out['exchange_modes']['captured'] = {'error': repr(e)}
+            _WATCHDOG.stop()
+            _WATCHDOG.fallback = None
     del ctx
     if world == 1 and not args.no_extras and args.workload == 'cfg2' and args.feed == 'resident' and not args.no_graph:
         # next to the headline (inputs resident in HBM, stratified batch): (1) the same step fed the way the
