@@ -909,6 +909,8 @@ class FusedStep(StepSchedule):
         graph-safe device generator; a captured step is valid for the composition of nuisance classes it was
         captured with (``replay`` checks)."""
         cfg, p = self.cfg, self.plan
+        if cfg.kernel_MMD in ('rbf_fourier', 'identity') and getattr(p, 'mmd_items', None) and T.get('mmd_explicit'):
+            return self._mmd_penalty_launches()
         from . import blocks as blk
         with torch.enable_grad():
             z = p.ZDEC[:p.o3].detach().clone().requires_grad_(True)
@@ -919,6 +921,58 @@ class FusedStep(StepSchedule):
         p.MMDval.copy_(total.detach().reshape(1))
         # CMPL = ... - mmd_rate * MMD_sum / N_total  (src/DrVAE.py:616,623-624)
         p.DZMMD.copy_(z.grad * (-cfg.mmd_rate / p.n_tot))
+
+    def _mmd_penalty_launches(self):
+        """the same penalty WITHOUT autograd (round 6): per call and category pair an explicit launch list -- gather both sides'
+        sample rows, [random Fourier features: draw W ~ N(0,1), b ~ U(0,1) in the block's order; ONE projection product over both
+        sides with the scale / bias epilogue; cos / column means / difference (``dv_mmd_rff_fwd``)] or [the difference of the
+        column means (``dv_mmd_identity_fwd``)], value -w sqrt(mmd^2) into ``MMDval``, the gradient of that -- times the
+        penalty's factor in CMPL -- back through the same kernels and added to the rows' slots of ``DZMMD``: 13 launches per
+        term instead of ~38 (cfg 4 with the penalty: 0.543 -> 0.379 ms per step, same box).  Same draws in the same order as
+        the block-level path, same kernels: the two agree to rounding (``tests/test_gpu_models.py``)."""
+        cfg, p = self.cfg, self.plan
+        Z, rff = cfg.dim_z1, cfg.kernel_MMD == 'rbf_fourier'
+        R = 500                                                  # dim_r of blocks.mmd_fourier (src/blocks.py:40)
+        a, c = math.sqrt(2. / 2.) / math.sqrt(Z), math.sqrt(2. / R)     # bandwidth 2 (blocks.mmd_objective)
+        z = p.ZDEC[:p.o3]
+        dev = z.device
+        bufs = p.__dict__.get('_mmd_bufs')
+        if bufs is None:
+            f = lambda *shape: torch.zeros(*shape, device=dev)
+            nmax = max(it['n0'] + it['n1'] for it in p.mmd_items)
+            bufs = p._mmd_bufs = dict(zz=f(nmax, _pad4(Z))[:, :Z], dz=f(nmax, _pad4(Z))[:, :Z], diff=f(R if rff else Z), m2=f(1),
+                                      rs=f(1), g=f(1))
+            if rff:
+                bufs.update(th=f(nmax, R), G=f(nmax, R), W=f(Z, R), b=f(R), bias=f(R), scale=torch.full((R,), a, device=dev))
+        B_ = bufs
+        p.DZMMD.zero_()
+        p.MMDval.zero_()
+        fac = -cfg.mmd_rate / p.n_tot                            # CMPL = ... - mmd_rate * MMD_sum / N_total
+        for it in p.mmd_items:
+            n0, n1 = it['n0'], it['n1']
+            n = n0 + n1
+            zz, dz = B_['zz'][:n], B_['dz'][:n]
+            K.rows_gather(zz, z, it['idx32'])
+            if rff:
+                th, G = B_['th'][:n], B_['G'][:n]
+                B_['W'].normal_()
+                B_['b'].uniform_()
+                torch.mul(B_['b'], 2 * math.pi, out=B_['bias'])
+                K.gemm(th, zz, B_['W'], True, False, epi=K.EPI_FWD, scale=B_['scale'], bias=B_['bias'])
+                K.mmd_rff_fwd(B_['diff'], B_['m2'], th[:n0], th[n0:], c)
+            else:
+                K.mmd_identity_fwd(B_['diff'], B_['m2'], zz[:n0], zz[n0:])
+            torch.rsqrt(B_['m2'], out=B_['rs'])
+            p.MMDval.addcmul_(B_['m2'], B_['rs'], value=-it['w'])         # - w sqrt(mmd^2)
+            torch.mul(B_['rs'], -0.5 * it['w'] * fac, out=B_['g'])         # d(that, times the CMPL factor) / d(mmd^2)
+            if rff:
+                K.mmd_rff_bwd(G[:n0], th[:n0], B_['diff'], B_['g'], 2.0 * c / n0)
+                K.mmd_rff_bwd(G[n0:], th[n0:], B_['diff'], B_['g'], -2.0 * c / n1)
+                K.gemm(dz, G, B_['W'], True, True, alpha=a)
+            else:
+                K.mmd_identity_bwd(dz[:n0], B_['diff'], B_['g'], 2.0 / n0)
+                K.mmd_identity_bwd(dz[n0:], B_['diff'], B_['g'], -2.0 / n1)
+            p.DZMMD.index_add_(0, it['idx'], dz)
 
     def _loss_scalars(self, after=None, terms_elsewhere=False, bump_counters=False):
         """RECL, KLD, PERT, YL, ELBO, CMPL (src/DrVAE.py:611-624) as device scalars.  ``terms_elsewhere``

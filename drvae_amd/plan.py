@@ -286,6 +286,25 @@ class _Plan:
                     if hx[idx[0]]:
                         self.mmd_calls.append((torch.as_tensor(self.o2 + l * Np + slot[idx], device=dev), sind, pairs))
             self.mmd_sig = sv.tobytes()          # a captured step is valid for THIS composition of nuisance classes
+            # the same penalty as explicit launch lists (``FusedStep._mmd_penalty``: no autograd inside the step): per call
+            # and category pair the rows of both sides as ONE index list into the stacked sample rows [side 0 | side 1],
+            # and the term's weight 1 / L (two categories: the first pair only; else the mean over the categories,
+            # src/DGMMixin.py:42-66).  None when a side is empty (the reference then compares with one random row: the
+            # step falls back to the block-level operators)
+            items, ncat = [], cfg.dim_s
+            for rows, _, pairs in self.mmd_calls:
+                for k in range(1 if ncat == 2 else ncat):
+                    i0, i1 = pairs[k]
+                    if i0.numel() == 0 or i1.numel() == 0:
+                        items = None
+                        break
+                    g = torch.cat([rows.index_select(0, i0), rows.index_select(0, i1)])
+                    items.append(dict(idx=g.long(), idx32=g.to(torch.int32), n0=int(i0.numel()), n1=int(i1.numel()),
+                                      w=(1.0 if ncat == 2 else 1.0 / ncat) / L))
+                if items is None:
+                    break
+            self.mmd_items = items
+            self.__dict__.pop('_mmd_bufs', None)
 
     def set_s_device(self, s_dev):
         """nuisance classes of this batch's rows from a DEVICE tensor (``DeviceBatcher.feed``: rows drawn on the device):

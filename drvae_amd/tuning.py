@@ -34,6 +34,7 @@ DEFAULTS = {
     'kl_pair': 1,        # PVAE's two sets of KL rows (prior term, pairs' term) as one launch on its main chain
     'main_first': 1,     # replay(): the main chain's graph is launched before the side chain's (the step's first kernels start one graph launch earlier after a host sync; steady state unchanged)
     'pvae_tail': 1,      # PVAE (no classifier): the dual-graph schedule with a side chain that is only the step's tail (heads' optimiser half, loss scalars, next noise)
+    'mmd_explicit': 1,   # model-level MMD penalty (use_s extension, rbf_fourier / identity kernels) as explicit launch lists, no autograd inside the step
     'dp_fork': 1,        # captured gradient exchange: the side chain draws the next step's noise behind the join (as in the single-GPU step)
     'sync_poll': 64,     # replays between two polls of the sticky wait-error words
 }

@@ -704,6 +704,56 @@ def test_use_s_model_api_with_fourier_mmd(dev):
     assert np.isfinite(float(ev['MMD']))
 
 
+@pytest.mark.parametrize('kernel', ['rbf_fourier', 'identity'])
+@pytest.mark.parametrize('kind', ['drvae', 'vfae'])
+def test_mmd_penalty_as_launch_lists_equals_the_block_level_path(kind, kernel, dev):
+    """round 6: the model-level MMD penalty inside the fused step as explicit launch lists (no autograd) against the
+    block-level operators it replaced (``DRVAE_TUNE=mmd_explicit=0``): the same random Fourier features (torch's generator,
+    same seed, same order of draws), the same kernels -- penalty value, its gradient w.r.t. the samples and three train steps
+    agree to rounding; three nuisance classes (the mean over the categories) and two (the first pair only)"""
+    from drvae_amd import tuning
+    from tests.test_engine_cpu import make_engine
+    for dim_s in (2, 3):
+        spec = C.tiny_spec(kind, use_s=True, dim_s=dim_s, use_MMD=True, mmd_rate=0.7, kernel_MMD=kernel)
+        batch = M.make_batch(spec, 48, seed=3)
+        hx, hy = batch['has_x2'].astype(bool).reshape(-1), batch['has_y'].astype(bool).reshape(-1)
+        sv = np.zeros(48, np.int64)                        # every data group holds every class: round-robin inside each group
+        for grp in ([hy & ~hx, ~hy & ~hx, hy & hx, ~hy & hx] if kind == 'drvae' else [hy, ~hy]):
+            sv[np.nonzero(grp)[0]] = np.arange(int(grp.sum())) % dim_s
+        params = M.init_params(spec, 9, as_numpy=True)
+        t = lambda k: torch.from_numpy(batch[k].copy()).to(dev)
+        out = {}
+        for mode in (1, 0):
+            os.environ['DRVAE_TUNE'] = 'mmd_explicit=%d' % mode
+            tuning.reload()
+            try:
+                eng, arena = make_engine(spec, params, dev)
+                eng.set_batch(t('x1'), t('x2'), batch['y'], batch['has_x2'], batch['has_y'], s=sv)
+                assert (eng.plan.mmd_items is not None) and len(eng.plan.mmd_items) >= 2
+                torch.manual_seed(5)
+                eng.training = True
+                eng.set_noise(M.make_noise(spec, 48, seed=4))
+                eng.forward()
+                eng.backward()
+                res = dict(mmd=eng.plan.MMDval.clone(), dz=eng.plan.DZMMD.clone(), grad=arena.grad.clone(), loss=eng.losses())
+                for step in range(3):
+                    eng.train_step(M.make_noise(spec, 48, seed=10 + step))
+                res.update(param=arena.param.clone(), last=eng.losses())
+                out[mode] = res
+            finally:
+                os.environ.pop('DRVAE_TUNE')
+                tuning.reload()
+        a, b = out[1], out[0]
+        assert abs(float(b['mmd'])) > 1e-4
+        np.testing.assert_allclose(a['mmd'].cpu().numpy(), b['mmd'].cpu().numpy(), rtol=2e-5)
+        assert float((a['dz'] - b['dz']).norm() / b['dz'].norm()) < 2e-5
+        assert float((a['grad'] - b['grad']).norm() / b['grad'].norm()) < 2e-5
+        for k in a['loss']:
+            np.testing.assert_allclose(a['loss'][k], b['loss'][k], rtol=2e-5, atol=1e-6)
+            np.testing.assert_allclose(a['last'][k], b['last'][k], rtol=1e-4, atol=1e-5)
+        assert float((a['param'] - b['param']).norm() / b['param'].norm()) < 1e-4
+
+
 @pytest.mark.parametrize('type_rec', ['binary', 'poisson'])
 @pytest.mark.parametrize('kind', ['drvae', 'vfae'])
 def test_bernoulli_poisson_decoders_gpu(kind, type_rec, dev):
