@@ -608,7 +608,7 @@ class _EvalGraph:
         self.g_ll = {'x1': f32(n), 'x2': f32(n)}
         if Y:
             self.g_proba, self.g_pred32 = f32(n, Y), torch.zeros(n, dtype=torch.int32, device=dev)
-            self.g_y32 = full.y.reshape(-1).to(dev, torch.int32).contiguous()
+            self.g_y32 = torch.zeros(n, dtype=torch.int32, device=dev)
 
     def _slot(self, name):
         o, size = self.off[name]
@@ -667,6 +667,7 @@ class _EvalGraph:
             Y = m.dim_y
             self.g_proba.copy_(self._slot('proba').view(n, Y))
             self.g_pred32.copy_(self._slot('pred'))
+            self.g_y32.copy_(full.y.reshape(-1))      # (read by the replay: a dataset edited in place is evaluated as edited)
             self._rank_metrics(self.g_proba, self.g_y32, self.g_pred32, self.full_yidx32, vec[o:o + 3], n)
             o += 3
         for tag, t, sel in (('x1', '1', None), ('x2', '2', self.full_x2idx32)):
