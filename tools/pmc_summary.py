@@ -57,8 +57,10 @@ print('# ldsConfl = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE (extra LDS-array cy
 print('# (4 x SQ_WAVE_CYCLES): matrix-pipe cycles per cycle of wave lifetime (SQ_WAVE_CYCLES counts quad-cycles)')
 print('# avg_us = average kernel duration of a --kernel-trace --stats run of the same command (no counters attached); GB/s = (2 x FETCH + WRITE)')
 print('# per call / avg_us: memory-side bytes with the x2 wide-load correction (an upper bound; exact for 16-B-per-lane streams)')
-print('%-46s %6s %10s %10s %6s %8s %8s %8s %12s %9s %9s %9s %8s' % ('kernel', 'calls', 'FETCH_KB', 'WRITE_KB', 'L2hit', 'waitAny', 'waitInst',
-                                                   'active', 'mfmaBusyCyc', 'ldsConfl', 'mfma/wave', 'avg_us', 'GB/s'))
+print('# mfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES per call / (avg_us x 2.4 GHz x 1024 SIMDs): the share of the chip\'s matrix-pipe cycles the kernel')
+print('# keeps busy over its duration (nominal 2.4 GHz: under sustained load the clock is lower, so this understates a little)')
+print('%-46s %6s %10s %10s %6s %8s %8s %8s %12s %9s %9s %9s %8s %8s' % ('kernel', 'calls', 'FETCH_KB', 'WRITE_KB', 'L2hit', 'waitAny', 'waitInst',
+                                                   'active', 'mfmaBusyCyc', 'ldsConfl', 'mfma/wave', 'avg_us', 'GB/s', 'mfmaUtil'))
 tot_f = tot_w = gf = gw = gc = 0
 for k in sorted(fetch, key=lambda k: -fetch[k]['FETCH_SIZE']):
     f, w = fetch[k]['FETCH_SIZE'] / steps, write[k]['WRITE_SIZE'] / s2
@@ -67,10 +69,11 @@ for k in sorted(fetch, key=lambda k: -fetch[k]['FETCH_SIZE']):
     cps = max(calls[k] / steps, 1e-9)
     d_us = dur.get(k, 0.0)
     gbs = (2 * f + w) / cps * 1e3 / (d_us * 1e-6) / 1e9 if d_us else 0.0
-    print('%-46s %6.1f %10.0f %10.0f %6.2f %8.2f %8.2f %8.2f %12.0f %9.3f %9.3f %9.1f %8.0f' % (
+    mutil = (sq[k]['SQ_VALU_MFMA_BUSY_CYCLES'] / s3 / cps) / (d_us * 1e-6 * 2.4e9 * 1024) if d_us else 0.0
+    print('%-46s %6.1f %10.0f %10.0f %6.2f %8.2f %8.2f %8.2f %12.0f %9.3f %9.3f %9.1f %8.0f %8.3f' % (
         k[:46], calls[k] / steps, f, w, h / max(h + m, 1), sq[k]['SQ_WAIT_ANY'] / wc, sq[k]['SQ_WAIT_INST_ANY'] / wc,
         sq[k]['SQ_ACTIVE_INST_ANY'] / wc, sq[k]['SQ_VALU_MFMA_BUSY_CYCLES'] / s3,
-        sq[k]['SQ_LDS_BANK_CONFLICT'] / max(sq[k]['SQ_LDS_IDX_ACTIVE'], 1), sq[k]['SQ_VALU_MFMA_BUSY_CYCLES'] / (4 * wc), d_us, gbs))
+        sq[k]['SQ_LDS_BANK_CONFLICT'] / max(sq[k]['SQ_LDS_IDX_ACTIVE'], 1), sq[k]['SQ_VALU_MFMA_BUSY_CYCLES'] / (4 * wc), d_us, gbs, mutil))
     tot_f += f
     tot_w += w
     if 'gemm' in k:
